@@ -1,0 +1,380 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
+//
+// Link shim that lets the reference's OWN translation units
+//     /root/reference/src/mesh_gen.cpp, erosion.cpp, upsurface.cpp   (+ vendored glm 0.9.9.1 headers)
+// be compiled unmodified, in place, into oracle/_ref/liboracle_ref.so (recipe: oracle/Makefile).
+// No reference source is copied: this file only (1) DEFINES the process globals those TUs declare
+// `extern` (they live in 3DWorld.cpp / Textures.cpp / display_world.cpp / Universe.cpp, which cannot be
+// built without OpenGL), (2) STUBS the GL/IO entry points they reference but that the CPU path never
+// calls, and (3) exports a plain C harness ("ref_*") that ctypes can drive.
+//
+// The handful of functions that live in TUs we cannot build are restated here, each with its citation:
+//   set_scene_constants   src/matrix_ops.cpp:59-84
+//   get_bare_ls_tid       src/Textures.cpp:1284-1287
+//   gen_tex_height_tables src/Textures.cpp:1757-1761
+//   rgen_core_t::randd    src/gen_object.cpp:377-381
+//   the voxel fill loop   src/voxels.cpp:312-345       (voxels.o has >100 unrelated externals)
+//   tile_t::create_zvals  src/tiled_mesh.cpp:467-546   (driver only; generator + erosion are the real TUs)
+//   tile_t::get_norm / upload_normal_texture  src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880
+//   heightmap_t::from_floats / write_pixel_16_bits  src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893
+
+#include "3DWorld.h"
+#include "mesh.h"
+#include "textures.h"
+#include "heightmap.h"
+#include "shaders.h"
+#include "upsurface.h"
+#include "sinf.h"
+#include <glm/gtc/noise.hpp>
+#include <omp.h>
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------------------------
+// (1) globals normally defined in 3DWorld.cpp / matrix_ops.cpp / Textures.cpp / display_world.cpp
+// ---------------------------------------------------------------------------------------------
+int MESH_X_SIZE(128), MESH_Y_SIZE(128), MESH_Z_SIZE(0);
+float X_SCENE_SIZE(4.0), Y_SCENE_SIZE(4.0), Z_SCENE_SIZE(4.0);
+int MESH_SIZE[3] = {0}, MAX_XY_SIZE(0), XY_MULT_SIZE(0), XY_SUM_SIZE(0), MAX_RUN_DIST(0), I_TIMESCALE(0);
+float SCENE_SIZE[3] = {0}, MESH_HEIGHT(0), XY_SCENE_SIZE(0), TWO_XSS(0), TWO_YSS(0);
+float DX_VAL(0), DY_VAL(0), HALF_DXY(0), DX_VAL_INV(0), DY_VAL_INV(0), DZ_VAL(0), dxdy(0), CLOUD_CEILING(0), LARGE_ZVAL(0);
+double c_radius(0), c_theta(0), c_phi(0);
+int camera_mode(0), world_mode(WMODE_INF_TERRAIN), do_read_mesh(0), read_heightmap(0), read_landscape(0), invert_mh_image(0);
+int xoff(0), yoff(0), xoff2(0), yoff2(0), rand_gen_index(0), mesh_rgen_index(0), mesh_scale_change(0), mesh_seed(0), scrolling(0), display_mode(0);
+point camera_origin, surface_pos, mesh_origin, camera_pos;
+bool combined_gu(0);
+float custom_glaciate_exp(0.0), disabled_mesh_z(FAR_DISTANCE), erode_amount(1.0), init_temperature(DEF_TEMPERATURE), temperature(DEF_TEMPERATURE), univ_temp(0.0);
+float mesh_file_scale(1.0), mesh_file_tz(0.0), relh_adj_tex(0.0), read_mesh_zmm(0.0), water_h_off(0.0), water_h_off_rel(0.0), water_plane_z(0.0);
+unsigned erosion_iters(0), erosion_iters_tt(0);
+rand_gen_t global_rand_gen;
+unsigned char **mesh_draw = NULL;
+float **mesh_height = NULL;
+char *mesh_file(nullptr), *mh_filename(nullptr), *mh_filename_tt(nullptr);
+float h_dirt[NTEX_DIRT], clip_hd1;
+float ocean_wave_height(0.0); // reference default is DEF_OCEAN_WAVE_HEIGHT; harness sets it explicitly
+
+extern float zmin, zmax, zmax_est, glaciate_exp, mesh_scale, mesh_scale_z, mesh_scale_z_inv, mesh_height_scale;
+extern int start_eval_sin, GLACIATE, mesh_gen_mode, mesh_gen_shape, mesh_freq_filter;
+extern float sinTable[][5];
+extern float MESH_START_MAG, MESH_START_FREQ, MESH_MAG_MULT, MESH_FREQ_MULT;
+extern hmap_params_t hmap_params;
+extern ttex lttex_dirt[];
+
+// ---------------------------------------------------------------------------------------------
+// (2) stubs for GL / IO symbols referenced by the TUs but never reached on the CPU path
+// ---------------------------------------------------------------------------------------------
+static void ref_unreachable(char const *what) {fprintf(stderr, "oracle ref_shim: unexpected call to %s\n", what); abort();}
+void compute_shader_t::begin() {ref_unreachable("compute_shader_t::begin");}
+void compute_shader_t::end_shader() {}
+void compute_shader_t::setup_and_run(unsigned &, bool, bool, bool) {ref_unreachable("setup_and_run");}
+void compute_shader_t::prep_for_read_pixels(bool) {ref_unreachable("prep_for_read_pixels");}
+void compute_shader_t::read_float_vals(vector<float> &, bool, bool) {ref_unreachable("read_float_vals");}
+void shader_t::set_prefix(char const *, unsigned) {}
+void shader_t::enable() {}
+void shader_t::disable() {}
+bool shader_t::add_uniform_float(char const *const, float) const {return 0;}
+void texture_t::load(int, bool, bool, bool) {ref_unreachable("texture_t::load");}
+void texture_t::resize(int, int) {ref_unreachable("texture_t::resize");}
+void texture_t::gl_delete() {}
+void texture_t::free_client_mem() {}
+float heightmap_t::get_heightmap_value(unsigned, unsigned) const {ref_unreachable("get_heightmap_value"); return 0;}
+void free_texture(unsigned &tid) {tid = 0;}
+void checked_fclose(FILE *fp) {if (fp) fclose(fp);}
+bool open_file(FILE *&fp, char const *const fn, string const &, char const *const mode) {fp = fopen(fn, mode); return (fp != nullptr);}
+void gen_scene(int, int, int, int, int) {}
+void regen_lightmap() {}
+void update_cpos() {}
+float int_mesh_zval_pt_off(point const &, int, int, bool) {return 0.0;}
+bool using_hmap_with_detail() {return 0;}
+bool using_tiled_terrain_hmap_tex() {return 0;}
+float get_tiled_terrain_height_tex(float, float, bool) {return 0.0;}
+void register_timing_value(const char *, int, bool) {}
+extern "C" int glutGet(unsigned) {return 0;}
+
+// src/gen_object.cpp:377-381
+double rgen_core_t::randd() {
+	double rand_num;
+	randome_int(rand_num);
+	return rand_num/2147483563.;
+}
+
+// src/Textures.cpp:1757-1761
+void gen_tex_height_tables() {
+	for (unsigned i = 0; i < NTEX_DIRT; ++i) {h_dirt[i] = pow(lttex_dirt[i].zval, glaciate_exp);}
+	clip_hd1 = (0.90*h_dirt[1] + 0.10*h_dirt[0]);
+}
+// src/Textures.cpp:1284-1287
+int get_bare_ls_tid(float zval) {
+	float const relh(relh_adj_tex + (zval - zmin)/(zmax - zmin));
+	return ((relh > clip_hd1) ? (int)ROCK_TEX : (int)DIRT_TEX); // rock or dirt
+}
+
+// src/matrix_ops.cpp:59-84 (only the constants the hot path reads)
+static void ref_set_scene_constants() {
+	MESH_SIZE[0]  = MESH_X_SIZE; MESH_SIZE[1] = MESH_Y_SIZE; MESH_SIZE[2] = MESH_Z_SIZE;
+	SCENE_SIZE[0] = X_SCENE_SIZE; SCENE_SIZE[1] = Y_SCENE_SIZE; SCENE_SIZE[2] = Z_SCENE_SIZE;
+	MAX_XY_SIZE   = max(MESH_X_SIZE, MESH_Y_SIZE);
+	XY_MULT_SIZE  = MESH_X_SIZE*MESH_Y_SIZE;
+	XY_SUM_SIZE   = MESH_X_SIZE + MESH_Y_SIZE;
+	MESH_HEIGHT   = 0.10f*Z_SCENE_SIZE;
+	XY_SCENE_SIZE = 0.5f*(X_SCENE_SIZE + Y_SCENE_SIZE);
+	TWO_XSS       = 2.0f*X_SCENE_SIZE;
+	TWO_YSS       = 2.0f*Y_SCENE_SIZE;
+	DX_VAL        = TWO_XSS/(float)MESH_X_SIZE;
+	DY_VAL        = TWO_YSS/(float)MESH_Y_SIZE;
+	HALF_DXY      = 0.5f*(DX_VAL + DY_VAL);
+	DX_VAL_INV    = 1.0f/DX_VAL;
+	DY_VAL_INV    = 1.0f/DY_VAL;
+	DZ_VAL        = float(2.0f*Z_SCENE_SIZE)/(float)max(MESH_Z_SIZE, 1);
+	dxdy          = DX_VAL*DY_VAL;
+	MAX_RUN_DIST  = min(MESH_X_SIZE, MESH_Y_SIZE)/2;
+	CLOUD_CEILING = CLOUD_CEILING0*Z_SCENE_SIZE;
+	LARGE_ZVAL    = 100.0f*CLOUD_CEILING;
+}
+
+// reference functions (defined in the reference TUs) the harness calls
+void create_sin_table();
+void compute_scale();
+void gen_rand_sine_table_entries(float scaled_height);
+void estimate_zminmax(bool using_eq);
+void set_zmax_est(float zval);
+void gen_mesh(int surface_type, int keep_sin_table, int update_zvals);
+void init_terrain_mesh();
+float get_water_z_height();
+float gen_noise(float xv, float yv, int mode, int shape);
+float get_noise_zval(float xval, float yval, int mode, int shape);
+void gen_rx_ry(float &rx, float &ry);
+float eval_mesh_sin_terms(float xv, float yv);
+void apply_erosion(float *heightmap, int xsize, int ysize, float min_zval, unsigned num_iters);
+
+// ---------------------------------------------------------------------------------------------
+// (3) C harness
+// ---------------------------------------------------------------------------------------------
+struct ref_config_t { // all scalars a config file would set for this path (src/3DWorld.cpp:1763-2110)
+	int mesh_x, mesh_y;                 // mesh_size
+	float scene_x, scene_y, scene_z;    // scene_size
+	float mesh_height, mesh_scale;      // mesh_height (-> mesh_height_scale), mesh_scale
+	int mesh_seed, mesh_freq_filter, mesh_gen_mode, mesh_gen_shape, glaciate;
+	float custom_glaciate_exp;
+	float hmap[14];                     // hmap_params_t in declaration order (src/mesh.h:84-88)
+	float erode_amount, water_h_off, water_h_off_rel, relh_adj_tex, ocean_wave_height;
+	float start_mag, start_freq, mag_mult, freq_mult;
+};
+
+struct ref_state_t { // everything derived, for injection into the system under test
+	float sinTable[90][5];
+	int start_eval_sin;
+	float MESH_HEIGHT, DX_VAL, DY_VAL, DX_VAL_INV, DY_VAL_INV, HALF_DXY, dxdy, XY_SCENE_SIZE;
+	float mesh_scale, mesh_scale_z_inv, mesh_height_scale;
+	float zmax_est, zmin, zmax, water_plane_z, glaciate_exp, clip_hd1, relh_adj_tex;
+	float rx, ry;
+};
+
+static vector<float> mesh_height_store;
+static vector<float*> mesh_height_rows;
+
+REF_API int ref_num_threads() {return omp_get_max_threads();}
+REF_API void ref_set_num_threads(int n) {omp_set_num_threads(n);}
+
+// Mirrors main(): create_sin_table(); set_scene_constants(); load config; init_terrain_mesh(); gen_scene()->gen_mesh()
+// (src/3DWorld.cpp:2393-2460, src/build_world.cpp:628). gen_mesh() generates the 128^2 ground mesh, which is what
+// seeds zmin/zmax before estimate_zminmax() -> zmax_est (src/mesh_gen.cpp:337-343,447-485).
+REF_API void ref_init(ref_config_t const *c) {
+	MESH_X_SIZE = c->mesh_x; MESH_Y_SIZE = c->mesh_y;
+	X_SCENE_SIZE = c->scene_x; Y_SCENE_SIZE = c->scene_y; Z_SCENE_SIZE = c->scene_z;
+	create_sin_table();
+	ref_set_scene_constants();
+	mesh_height_scale = c->mesh_height; mesh_scale = c->mesh_scale;
+	mesh_scale_z = 1.0; mesh_scale_z_inv = 1.0; // a config-file mesh_scale leaves these at 1; only the runtime update_mesh() (src/mesh_gen.cpp:862-874) changes them
+	mesh_seed = c->mesh_seed; mesh_freq_filter = c->mesh_freq_filter; mesh_gen_mode = c->mesh_gen_mode; mesh_gen_shape = c->mesh_gen_shape;
+	GLACIATE = c->glaciate; custom_glaciate_exp = c->custom_glaciate_exp;
+	memcpy(&hmap_params, c->hmap, 14*sizeof(float));
+	erode_amount = c->erode_amount; water_h_off = c->water_h_off; water_h_off_rel = c->water_h_off_rel; relh_adj_tex = c->relh_adj_tex;
+	ocean_wave_height = c->ocean_wave_height;
+	MESH_START_MAG = c->start_mag; MESH_START_FREQ = c->start_freq; MESH_MAG_MULT = c->mag_mult; MESH_FREQ_MULT = c->freq_mult;
+	erosion_iters = 0; // ground-mode erosion off during init; harness calls apply_erosion explicitly
+	mesh_height_store.assign(size_t(MESH_X_SIZE)*MESH_Y_SIZE, 0.0f);
+	mesh_height_rows.resize(MESH_Y_SIZE);
+	for (int i = 0; i < MESH_Y_SIZE; ++i) {mesh_height_rows[i] = mesh_height_store.data() + size_t(i)*MESH_X_SIZE;}
+	mesh_height = mesh_height_rows.data();
+	init_terrain_mesh(); // lttex_dirt zvals (src/mesh_gen.cpp:407-431)
+	gen_mesh(0, 0, 1);   // sine table, ground mesh, zmax_est, water_plane_z, glaciate_exp
+	gen_tex_height_tables(); // after glaciate_exp is known (gen_mesh->gen_terrain_map->glaciate sets it)
+}
+
+REF_API void ref_get_state(ref_state_t *s) {
+	memcpy(s->sinTable, sinTable, sizeof(s->sinTable));
+	s->start_eval_sin = start_eval_sin;
+	s->MESH_HEIGHT = MESH_HEIGHT; s->DX_VAL = DX_VAL; s->DY_VAL = DY_VAL; s->DX_VAL_INV = DX_VAL_INV; s->DY_VAL_INV = DY_VAL_INV;
+	s->HALF_DXY = HALF_DXY; s->dxdy = dxdy; s->XY_SCENE_SIZE = XY_SCENE_SIZE;
+	s->mesh_scale = mesh_scale; s->mesh_scale_z_inv = mesh_scale_z_inv; s->mesh_height_scale = mesh_height_scale;
+	s->zmax_est = zmax_est; s->zmin = zmin; s->zmax = zmax; s->water_plane_z = water_plane_z; s->glaciate_exp = glaciate_exp;
+	s->clip_hd1 = clip_hd1; s->relh_adj_tex = relh_adj_tex;
+	gen_rx_ry(s->rx, s->ry);
+}
+
+REF_API void ref_set_zmax_est(float v) {set_zmax_est(v); zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height();}
+REF_API void ref_set_water_plane_z(float v) {water_plane_z = v;}
+REF_API void ref_set_mode(int mode, int shape) {mesh_gen_mode = mode; mesh_gen_shape = shape;}
+REF_API void ref_set_start_eval_sin(int v) {start_eval_sin = v;}
+REF_API void ref_set_erode_amount(float v) {erode_amount = v;}
+REF_API void ref_get_ground_mesh(float *out) {memcpy(out, mesh_height_store.data(), mesh_height_store.size()*sizeof(float));}
+REF_API float ref_sin_table(int i) {return sin_table[i];}
+
+// mesh_xy_grid_cache_t::build_arrays + enable_glaciate + the caller's eval_index double loop
+// (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:455-464,495-514)
+REF_API void ref_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int min_start_sin, float *out) {
+	mesh_xy_grid_cache_t height_gen;
+	height_gen.build_arrays(x0, y0, dx, dy, nx, ny, (cache_values != 0));
+	if (glaciate) {height_gen.enable_glaciate();}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)ny; ++y) {
+		for (unsigned x = 0; x < nx; ++x) {out[size_t(y)*nx + x] = height_gen.eval_index(x, y, min_start_sin);}
+	}
+}
+
+REF_API void ref_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters) {apply_erosion(hmap, xsize, ysize, min_zval, iters);}
+REF_API float ref_get_noise_zval(float x, float y, int mode, int shape) {return get_noise_zval(x, y, mode, shape);}
+REF_API float ref_gen_noise(float x, float y, int mode, int shape) {return gen_noise(x, y, mode, shape);}
+REF_API float ref_eval_mesh_sin_terms(float x, float y) {return eval_mesh_sin_terms(x, y);}
+REF_API float ref_glm_simplex2(float x, float y) {return glm::simplex(glm::vec2(x, y));}
+REF_API float ref_glm_perlin2 (float x, float y) {return glm::perlin (glm::vec2(x, y));}
+REF_API float ref_glm_simplex3(float x, float y, float z) {return glm::simplex(glm::vec3(x, y, z));}
+REF_API float ref_glm_perlin3 (float x, float y, float z) {return glm::perlin (glm::vec3(x, y, z));}
+REF_API int   ref_get_bare_ls_tid_is_rock(float z) {return (get_bare_ls_tid(z) == ROCK_TEX);}
+REF_API float ref_get_max_sea_level() {return (get_water_z_height() + ocean_wave_height);} // src/tiled_mesh.cpp:141
+
+// RNG streams (src/rand_gen.h:20-35,63-79)
+REF_API void ref_rand_ints(long s1, long s2, int n, int *out) {rand_gen_t r; r.set_state(s1, s2); for (int i = 0; i < n; ++i) {out[i] = r.rand();}}
+REF_API void ref_rand_floats(long s1, long s2, int n, float *out) {rand_gen_t r; r.set_state(s1, s2); for (int i = 0; i < n; ++i) {out[i] = r.rand_float();}}
+REF_API void ref_rand_uniforms(long s1, long s2, float a, float b, int n, float *out) {rand_gen_t r; r.set_state(s1, s2); for (int i = 0; i < n; ++i) {out[i] = r.rand_uniform(a, b);}}
+
+// tile_t::create_zvals driver (src/tiled_mesh.cpp:467-546) for tile (tx,ty), size=128: zvals[130*130], sub_zmin/zmax[4][4], water bbox
+struct ref_tile_stats_t {float sub_zmin[16], sub_zmax[16], mzmin, mzmax, radius; int wx1, wy1, wx2, wy2;};
+
+REF_API void ref_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, ref_tile_stats_t *st) {
+	unsigned const size(128), stride(size+1), zvsize(stride+1);
+	int const x1(tx*size), y1(ty*size), x2(x1 + size), y2(y1 + size);
+	int wx1(x2), wy1(y2), wx2(x1), wy2(y1); // start denormalized (src/tiled_mesh.cpp:308)
+	mesh_xy_grid_cache_t height_gen;
+	height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0, 0); // setup_height_gen_async, xy_scale=1
+	height_gen.enable_glaciate();
+	float mzmin(FAR_DISTANCE), mzmax(-FAR_DISTANCE);
+	unsigned const block_size(zvsize/4);
+	float const wpz_max(ref_get_max_sea_level());
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)zvsize; ++y) {
+		for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = height_gen.eval_index(x, y);}
+	}
+	apply_erosion(zvals, zvsize, zvsize, zmin, iters_tt);
+
+	for (unsigned yy = 0; yy < 4; ++yy) {
+		for (unsigned xx = 0; xx < 4; ++xx) {
+			unsigned const x_end((xx+1)*block_size), y_end((yy+1)*block_size);
+			float &szmin(st->sub_zmin[yy*4+xx]), &szmax(st->sub_zmax[yy*4+xx]);
+			szmin = FAR_DISTANCE; szmax = -FAR_DISTANCE;
+			for (unsigned y = yy*block_size; y <= y_end; ++y) {
+				for (unsigned x = xx*block_size; x <= x_end; ++x) {
+					float const z(zvals[y*zvsize + x]);
+					szmin = min(szmin, z); szmax = max(szmax, z);
+					if (z < wpz_max) {
+						wx1 = min(wx1, x1+int(x)); wy1 = min(wy1, y1+int(y));
+						wx2 = max(wx2, x1+int(x)); wy2 = max(wy2, y1+int(y));
+					}
+				}
+			}
+			mzmin = min(mzmin, szmin);
+			mzmax = max(mzmax, szmax);
+		}
+	}
+	st->mzmin = mzmin; st->mzmax = mzmax;
+	st->radius = 0.5*sqrt((DX_VAL*DX_VAL + DY_VAL*DY_VAL)*size*size + (mzmax - mzmin)*(mzmax - mzmin));
+	st->wx1 = wx1; st->wy1 = wy1; st->wx2 = wx2; st->wy2 = wy2;
+}
+
+// tile_t::upload_normal_texture CPU part (src/tiled_mesh.cpp:865-880, src/tiled_mesh.h:281-284); returns min_normal_z
+REF_API float ref_tile_normals(float const *zvals, unsigned char *rgba /*129*129*4*/) {
+	unsigned const stride(129), zvsize(130);
+	float min_normal_z(1.0);
+	memset(rgba, 0, 4*stride*stride);
+	for (unsigned y = 0; y < stride; ++y) {
+		for (unsigned x = 0; x < stride; ++x) {
+			unsigned const ix(y*stride + x), ix2(y*zvsize + x), ix_off(4*ix);
+			vector3d const norm(vector3d(DY_VAL*(zvals[ix2] - zvals[ix2 + 1]), DX_VAL*(zvals[ix2] - zvals[ix2 + zvsize]), dxdy).get_norm());
+			min_normal_z = min(min_normal_z, norm.z);
+			UNROLL_3X(rgba[ix_off+i_] = (unsigned char)(127.0*(norm[i_] + 1.0));)
+		}
+	}
+	return min_normal_z;
+}
+
+// heightmap_t::proc_gen tail (src/heightmap.cpp:146-150,205-215; src/Textures.cpp:1889-1893; src/mesh_gen.cpp:120-131):
+// z-range -> 16-bit quantise. out = 2 bytes per pixel, [lo, hi].
+REF_API void ref_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out) {
+	float min_z(vals[0]), max_z(vals[0]);
+	for (size_t i = 0; i < n; ++i) {min_z = min(min_z, vals[i]); max_z = max(max_z, vals[i]);}
+	float const dz(max(TOLERANCE, (max_z - min_z)));
+	float const READ_MESH_H_SCALE(0.0008);
+	// set_mesh_height_scales_for_zval_range(min_z, dz/255.0)
+	float const dzs(dz/255.0);
+	float const file_scale(dzs/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv)), file_tz(min_z/mesh_scale_z_inv);
+	float const mult(READ_MESH_H_SCALE*mesh_height_scale*file_scale*mesh_scale_z_inv), add(file_tz*mesh_scale_z_inv); // get_mh_texture_mult/add
+	float const val_div(1.0/mult), val_add(add);
+	for (size_t i = 0; i < n; ++i) {
+		float v((vals[i] - val_add)*val_div);
+		unsigned char const high_bits(v);
+		out[(i<<1)+1] = high_bits;
+		out[i<<1]     = (unsigned char)(256.0f*(v - float(high_bits)));
+	}
+	*min_z_out = min_z; *dz_out = dz;
+}
+
+// voxel_manager::create_procedural fill loop (src/voxels.cpp:278-345) around the real noise_gen_3d (src/upsurface.cpp:16-70).
+// out is z-fastest: ix = z + (x + y*nx)*nz  (src/voxels.h:141-144)
+REF_API void ref_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],
+	float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1)
+{
+	unsigned const xyz_num[3] = {nx, ny, nz};
+	vector<float> xyz_vals[3];
+	noise_gen_3d ngen;
+	float rx(0.0), ry(0.0);
+	point const lo(lo_pos[0], lo_pos[1], lo_pos[2]);
+	vector3d const off(offset[0], offset[1], offset[2]), step(vsz[0], vsz[1], vsz[2]);
+
+	if (gen_mode == MGEN_SINE) {
+		ngen.set_rand_seeds(rseed1, rseed2);
+		ngen.gen_sines(mag, freq);
+		ngen.gen_xyz_vals((lo + off), step, xyz_num, xyz_vals);
+	}
+	else {gen_rx_ry(rx, ry);}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)ny; ++y) {
+		for (unsigned x = 0; x < nx; ++x) {
+			for (unsigned z = 0; z < nz; ++z) {
+				float val(0.0);
+				if (gen_mode == MGEN_SINE) {val = ngen.get_val(x, y, z, xyz_vals);}
+				else {
+					point const pos(point((x*step.x + lo.x), (y*step.y + lo.y), (z*step.z + lo.z)) + off); // get_pt_at (src/voxels.h:126) + offset
+					glm::vec3 const v(pos.x, pos.y, pos.z);
+					float nmag(mag), nfreq(0.25*freq);
+					float const lacunarity(1.92), gain(0.5);
+					for (int n = 0; n < max(1, (5 - mesh_freq_filter)); ++n) { // MAX_FREQ_BINS = 5 (src/upsurface.h)
+						glm::vec3 const nv(nfreq*v + glm::vec3(rx, ry, rx-ry));
+						val   += nmag*((gen_mode == MGEN_PERLIN) ? glm::perlin(nv) : glm::simplex(nv));
+						nmag  *= gain;
+						nfreq *= lacunarity;
+					}
+				}
+				val += z*zscale;
+				if (normalize_to_1) {val = CLIP_TO_pm1(val);}
+				out[z + (x + size_t(y)*nx)*nz] = val;
+			}
+		}
+	}
+}
+REF_API void ref_voxel_rdata(int rseed1, int rseed2, float mag, float freq, float *rdata /*420*/) {
+	noise_gen_3d ngen;
+	ngen.set_rand_seeds(rseed1, rseed2);
+	ngen.gen_sines(mag, freq);
+	memcpy(rdata, ngen.rdata, sizeof(ngen.rdata));
+}
