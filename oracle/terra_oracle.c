@@ -1,0 +1,924 @@
+/* oracle/terra_oracle.c -- TEST INFRASTRUCTURE ONLY (see terra_oracle.h).
+ *
+ * Plain-C restatement of the reference CPU algorithm for the terrain hot path.  Every function cites the
+ * reference lines it follows (relative to /root/reference/).  Written for bit-exact agreement with the
+ * reference built by its own flags (makefile:10: g++ -O3 -fopenmp, x86-64 baseline => SSE2 scalar float, no FMA):
+ * compile with -ffp-contract=off, keep every float/double promotion exactly where the C++ source has it.
+ * Validated against oracle/_ref (the reference TUs themselves) by tests/test_oracle_vs_ref.py.
+ */
+#include "terra_oracle.h"
+#include <math.h>
+#include <float.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <omp.h>
+
+/* ------------------------------------------------------------------ constants (src/3DWorld.h, src/mesh_gen.cpp:14-30) */
+#define PI_F 3.141592654f                                   /* src/3DWorld.h:43 */
+static float TWO_PI_F;                                      /* float const TWO_PI = 2.0*PI; src/3DWorld.h:129 */
+#define NUM_FREQ_COMP 9
+#define N_RAND_SIN2 10
+#define MIN_FREQS 3
+#define F_TABLE_SIZE ORC_F_TABLE_SIZE
+#define EST_RAND_PARAM 128u
+#define TBITS 15
+#define TSIZE (1 << TBITS)                                  /* src/sinf.h:8 */
+static float const W_PLANE_Z = 0.42f, MESH_SCALE_FACTOR = 0.0007f, DEF_GLACIATE_EXP = 3.0f; /* src/mesh_gen.cpp:19,23,26 */
+static float const FAR_DISTANCE = 100.0f, TOLERANCE_F = 1.0E-12f, DEF_TEMPERATURE = 20.0f; /* src/3DWorld.h:116,50,87 */
+static float const CLOUD_CEILING0 = 1.5f;                   /* src/3DWorld.h:74 */
+
+static inline float fmin_std(float a, float b) {return (b < a) ? b : a;} /* std::min */
+static inline float fmax_std(float a, float b) {return (a < b) ? b : a;} /* std::max */
+static inline int   imin(int a, int b) {return (b < a) ? b : a;}
+static inline int   imax(int a, int b) {return (a < b) ? b : a;}
+static inline float clip01(float x) {return fmax_std(0.0f, fmin_std(1.0f, x));}   /* CLIP_TO_01  src/3DWorld.h:148 */
+static inline float clip_pm1(float x) {return fmax_std(-1.0f, fmin_std(1.0f, x));} /* CLIP_TO_pm1 src/3DWorld.h:149 */
+/* x86 cvttss2si semantics for float->int (NaN / out of range -> INT_MIN), as the reference binary behaves */
+static inline int f2i(float f) {return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : INT_MIN;}
+
+/* ------------------------------------------------------------------ globals mirrored from the reference */
+static int MESH_X_SIZE = 128, MESH_Y_SIZE = 128, MESH_Z_SIZE = 0;
+static float X_SCENE_SIZE = 4, Y_SCENE_SIZE = 4, Z_SCENE_SIZE = 4;
+static float MESH_HEIGHT, XY_SCENE_SIZE, DX_VAL, DY_VAL, HALF_DXY, DX_VAL_INV, DY_VAL_INV, dxdy;
+static float MESH_START_MAG = 0.02f, MESH_START_FREQ = 240.0f, MESH_MAG_MULT = 2.0f, MESH_FREQ_MULT = 0.5f;
+static int start_eval_sin = 0, GLACIATE = 1, mesh_gen_mode = 0, mesh_gen_shape = 0, mesh_freq_filter = 2, mesh_seed = 0, mesh_rgen_index = 0;
+static float zmax, zmin, zmax_est, zmax_est2 = 1.0f, zmax_est2_inv = 1.0f, zbottom, ztop;
+static float mesh_scale = 1.0f, mesh_scale_z_inv = 1.0f, mesh_height_scale = 1.0f, glaciate_exp = 1.0f;
+static float custom_glaciate_exp = 0.0f, erode_amount = 1.0f, water_plane_z = 0.0f, water_h_off = 0.0f, water_h_off_rel = 0.0f, relh_adj_tex = 0.0f;
+static float ocean_wave_height = 0.0f, temperature = 20.0f;
+static float sinTable[F_TABLE_SIZE][5];
+static float *sin_table = NULL; /* 2*TSIZE */
+static float sscale;
+static float h_dirt[5], clip_hd1, lttex_dirt_zval[5];
+static float *ground_mesh = NULL;
+typedef struct {float plat_bot, plat_h, plat_s, plat_max, crat_h, crat_s, crack_lo, crack_hi, crack_d, sine_mag, sine_freq, sine_bias, volcano_width, volcano_height;} hmap_params_t; /* src/mesh.h:84-88 */
+static hmap_params_t hp;
+
+/* ------------------------------------------------------------------ a2: RNG (src/rand_gen.h:20-35,63-79; src/gen_object.cpp:377-381) */
+typedef struct {long rseed1, rseed2;} rgen_t;
+static inline void rgen_set_state(rgen_t *r, long s1, long s2) {r->rseed1 = s1; r->rseed2 = s2;}
+static inline void rgen_advance(rgen_t *r) { /* randome_int, src/rand_gen.h:23-27 */
+	if ((r->rseed1 = 40014*(r->rseed1%53668) - 12211*(r->rseed1/53668)) < 0) r->rseed1 += 2147483563;
+	if ((r->rseed2 = 40692*(r->rseed2%52774) - 3791 *(r->rseed2/52774)) < 0) r->rseed2 += 2147483399;
+}
+static inline int rgen_rand(rgen_t *r) { /* T=int: (int)rseed1 - (int)rseed2 */
+	rgen_advance(r);
+	int v = (int)r->rseed1 - (int)r->rseed2;
+	if (v < 1) v += 2147483562;
+	return v;
+}
+static inline double rgen_randd(rgen_t *r) { /* T=double */
+	rgen_advance(r);
+	double v = (double)r->rseed1 - (double)r->rseed2;
+	if (v < 1) v += 2147483562;
+	return v/2147483563.;
+}
+static inline float rgen_rand_float(rgen_t *r) {return (float)(0.000001*(rgen_rand(r)%1000000));}                 /* src/rand_gen.h:87 */
+static inline float rgen_rand_uniform(rgen_t *r, float a, float b) {return a + (b - a)*(float)rgen_randd(r);}     /* src/rand_gen.h:91 */
+
+/* ------------------------------------------------------------------ a1: sin table (src/mesh_gen.cpp:72-81, src/sinf.h:8-21) */
+static void create_sin_table(void) {
+	if (sin_table) return;
+	TWO_PI_F = (float)(2.0*(double)PI_F);
+	sscale   = (float)TSIZE/TWO_PI_F;
+	sin_table = (float *)malloc(2*TSIZE*sizeof(float));
+	for (unsigned i = 0; i < TSIZE; ++i) {
+		sin_table[i]       = sinf((float)i/sscale);
+		sin_table[i+TSIZE] = cosf((float)i/sscale);
+	}
+}
+static inline int ST_SCALE(float v) {return ((int)(sscale*v)) & (TSIZE-1);}
+static inline float SINF(float v) {return (v < 0) ? -sin_table[ST_SCALE(-v)] : sin_table[ST_SCALE(v)];}
+static inline float COSF(float v) {return sin_table[TSIZE + ST_SCALE(fabsf(v))];}
+
+/* ------------------------------------------------------------------ scene constants (src/matrix_ops.cpp:59-84) */
+static void set_scene_constants(void) {
+	MESH_HEIGHT   = 0.10f*Z_SCENE_SIZE;
+	XY_SCENE_SIZE = 0.5f*(X_SCENE_SIZE + Y_SCENE_SIZE);
+	DX_VAL        = (2.0f*X_SCENE_SIZE)/(float)MESH_X_SIZE;
+	DY_VAL        = (2.0f*Y_SCENE_SIZE)/(float)MESH_Y_SIZE;
+	HALF_DXY      = 0.5f*(DX_VAL + DY_VAL);
+	DX_VAL_INV    = 1.0f/DX_VAL;
+	DY_VAL_INV    = 1.0f/DY_VAL;
+	dxdy          = DX_VAL*DY_VAL;
+}
+
+/* ------------------------------------------------------------------ a3: sine table entries (src/mesh_gen.cpp:213-254,544-548) */
+static rgen_t sine_rgen = {1, 1}; /* "static rand_gen_t rgen" in gen_rand_sine_table_entries; rgen_core_t() = set_state(1,1) */
+
+static void apply_mesh_rand_seed(rgen_t *r) { /* src/mesh_gen.cpp:213-216 */
+	if (mesh_seed != 0) {rgen_set_state(r, mesh_seed, 12345);}
+	else if (mesh_gen_mode != ORC_MGEN_SINE) {rgen_set_state(r, mesh_rgen_index+1, 12345);}
+}
+static void gen_rand_sine_table_entries(float scaled_height) { /* src/mesh_gen.cpp:219-254 */
+	float xf_scale = (float)MESH_Y_SIZE/(float)MESH_X_SIZE, yf_scale = (float)(1.0/(double)xf_scale);
+	if (X_SCENE_SIZE > Y_SCENE_SIZE) yf_scale *= (float)Y_SCENE_SIZE/(float)X_SCENE_SIZE;
+	if (Y_SCENE_SIZE > X_SCENE_SIZE) xf_scale *= (float)X_SCENE_SIZE/(float)Y_SCENE_SIZE;
+	float mags[NUM_FREQ_COMP] = {0}, freqs[NUM_FREQ_COMP] = {0};
+	freqs[0] = MESH_START_FREQ;
+	mags [0] = MESH_START_MAG;
+	for (int i = 1; i < NUM_FREQ_COMP; ++i) {
+		freqs[i] = freqs[i-1]*MESH_FREQ_MULT;
+		mags [i] = mags[i-1]*MESH_MAG_MULT;
+	}
+	float const mesh_h = (float)((double)scaled_height/sqrt(0.1*N_RAND_SIN2));
+	apply_mesh_rand_seed(&sine_rgen);
+
+	for (int l = 0; l < NUM_FREQ_COMP; ++l) {
+		int const offset = l*N_RAND_SIN2;
+		float const x_freq = freqs[l]/((float)MESH_X_SIZE), y_freq = freqs[l]/((float)MESH_Y_SIZE);
+		float const mheight = mags[l]*mesh_h;
+		for (int i = 0; i < N_RAND_SIN2; ++i) {
+			int const index = offset + i;
+			sinTable[index][0] = rgen_rand_uniform(&sine_rgen, 0.2f, 1.0f)*mheight;
+			sinTable[index][1] = rgen_rand_float(&sine_rgen)*TWO_PI_F;
+			sinTable[index][2] = rgen_rand_float(&sine_rgen)*TWO_PI_F;
+			sinTable[index][3] = rgen_rand_uniform(&sine_rgen, 0.1f, 1.0f)*x_freq*yf_scale;
+			sinTable[index][4] = rgen_rand_uniform(&sine_rgen, 0.1f, 1.0f)*y_freq*xf_scale;
+		}
+	}
+}
+static void compute_scale(void) { /* src/mesh_gen.cpp:544-548 */
+	int const iscale = (int)log2f(mesh_scale);
+	start_eval_sin = N_RAND_SIN2*imax(0, imin(NUM_FREQ_COMP-MIN_FREQS, (iscale+mesh_freq_filter)));
+}
+static void gen_rx_ry(float *rx, float *ry) { /* src/mesh_gen.cpp:581-586 */
+	rgen_t r = {1, 1};
+	apply_mesh_rand_seed(&r);
+	*rx = (float)((double)rgen_rand_float(&r) + 1.0);
+	*ry = (float)((double)rgen_rand_float(&r) + 1.0);
+}
+
+/* ------------------------------------------------------------------ a7: glm::simplex / glm::perlin (dependencies/glm/glm/gtc/noise.inl, detail/_noise.hpp) */
+static inline float g_mod289(float x) {return x - floorf(x*(1.0f/289.0f))*289.0f;}            /* _noise.hpp:14-18 */
+static inline float g_permute(float x) {return g_mod289(((x*34.0f) + 1.0f)*x);}                /* _noise.hpp:20-24 */
+static inline float g_tis(float r) {return 1.79284291400159f - 0.85373472095314f*r;}           /* _noise.hpp:44-48 */
+static inline float g_fade(float t) {return (t*t*t)*(t*(t*6.0f - 15.0f) + 10.0f);}             /* _noise.hpp:68-84 */
+static inline float g_mod(float a, float b) {return a - b*floorf(a/b);}                        /* func_common.inl:211-218 */
+static inline float g_fract(float x) {return x - floorf(x);}                                   /* func_common.inl:386-398 */
+static inline float g_mix(float x, float y, float a) {return x + a*(y - x);}                   /* func_common.inl:123-131 */
+static inline float g_step(float edge, float x) {return (x < edge) ? 0.0f : 1.0f;}             /* func_common.inl:543-546 */
+static inline float g_max(float a, float b) {return (a < b) ? b : a;}
+static inline float g_min(float a, float b) {return (b < a) ? b : a;}
+
+static float glm_simplex2(float vx, float vy) { /* noise.inl:592-646 */
+	float const Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f, Cw = 0.024390243902439f;
+	float const d1 = vx*Cy + vy*Cy;
+	float ix = floorf(vx + d1), iy = floorf(vy + d1);
+	float const d2 = ix*Cx + iy*Cx;
+	float const x0x = vx - ix + d2, x0y = vy - iy + d2;
+	float const i1x = (x0x > x0y) ? 1.0f : 0.0f, i1y = (x0x > x0y) ? 0.0f : 1.0f;
+	float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
+	x12x = x12x - i1x; x12y = x12y - i1y;
+	ix = g_mod(ix, 289.0f); iy = g_mod(iy, 289.0f);
+	float const p0 = g_permute(g_permute(iy + 0.0f) + ix + 0.0f);
+	float const p1 = g_permute(g_permute(iy + i1y ) + ix + i1x );
+	float const p2 = g_permute(g_permute(iy + 1.0f) + ix + 1.0f);
+	float m0 = g_max(0.5f - (x0x*x0x + x0y*x0y), 0.0f);
+	float m1 = g_max(0.5f - (x12x*x12x + x12y*x12y), 0.0f);
+	float m2 = g_max(0.5f - (x12z*x12z + x12w*x12w), 0.0f);
+	m0 = m0*m0; m1 = m1*m1; m2 = m2*m2;
+	m0 = m0*m0; m1 = m1*m1; m2 = m2*m2;
+	float const xx0 = 2.0f*g_fract(p0*Cw) - 1.0f, xx1 = 2.0f*g_fract(p1*Cw) - 1.0f, xx2 = 2.0f*g_fract(p2*Cw) - 1.0f;
+	float const h0 = fabsf(xx0) - 0.5f, h1 = fabsf(xx1) - 0.5f, h2 = fabsf(xx2) - 0.5f;
+	float const ox0 = floorf(xx0 + 0.5f), ox1 = floorf(xx1 + 0.5f), ox2 = floorf(xx2 + 0.5f);
+	float const a00 = xx0 - ox0, a01 = xx1 - ox1, a02 = xx2 - ox2;
+	m0 *= 1.79284291400159f - 0.85373472095314f*(a00*a00 + h0*h0);
+	m1 *= 1.79284291400159f - 0.85373472095314f*(a01*a01 + h1*h1);
+	m2 *= 1.79284291400159f - 0.85373472095314f*(a02*a02 + h2*h2);
+	float const gx = a00*x0x  + h0*x0y;
+	float const gy = a01*x12x + h1*x12y;
+	float const gz = a02*x12z + h2*x12w;
+	return 130.0f*(m0*gx + m1*gy + m2*gz);
+}
+
+static float glm_perlin2(float Px, float Py) { /* noise.inl:25-62 */
+	float Pix = floorf(Px) + 0.0f, Piy = floorf(Py) + 0.0f, Piz = floorf(Px) + 1.0f, Piw = floorf(Py) + 1.0f;
+	float const Pfx = g_fract(Px) - 0.0f, Pfy = g_fract(Py) - 0.0f, Pfz = g_fract(Px) - 1.0f, Pfw = g_fract(Py) - 1.0f;
+	Pix = g_mod(Pix, 289.0f); Piy = g_mod(Piy, 289.0f); Piz = g_mod(Piz, 289.0f); Piw = g_mod(Piw, 289.0f);
+	float const ix[4] = {Pix, Piz, Pix, Piz}, iy[4] = {Piy, Piy, Piw, Piw}, fx[4] = {Pfx, Pfz, Pfx, Pfz}, fy[4] = {Pfy, Pfy, Pfw, Pfw};
+	float gx[4], gy[4];
+	for (int k = 0; k < 4; ++k) {
+		float const i = g_permute(g_permute(ix[k]) + iy[k]);
+		float g = 2.0f*g_fract(i/41.0f) - 1.0f;
+		gy[k] = fabsf(g) - 0.5f;
+		float const tx = floorf(g + 0.5f);
+		gx[k] = g - tx;
+	}
+	/* g00=(gx.x,gy.x) g10=(gx.y,gy.y) g01=(gx.z,gy.z) g11=(gx.w,gy.w); norm = tis(dot(g00),dot(g01),dot(g10),dot(g11)) */
+	float const n_g00 = g_tis(gx[0]*gx[0] + gy[0]*gy[0]), n_g01 = g_tis(gx[2]*gx[2] + gy[2]*gy[2]);
+	float const n_g10 = g_tis(gx[1]*gx[1] + gy[1]*gy[1]), n_g11 = g_tis(gx[3]*gx[3] + gy[3]*gy[3]);
+	float const g00x = gx[0]*n_g00, g00y = gy[0]*n_g00, g01x = gx[2]*n_g01, g01y = gy[2]*n_g01;
+	float const g10x = gx[1]*n_g10, g10y = gy[1]*n_g10, g11x = gx[3]*n_g11, g11y = gy[3]*n_g11;
+	float const n00 = g00x*fx[0] + g00y*fy[0];
+	float const n10 = g10x*fx[1] + g10y*fy[1];
+	float const n01 = g01x*fx[2] + g01y*fy[2];
+	float const n11 = g11x*fx[3] + g11y*fy[3];
+	float const fade_x = g_fade(Pfx), fade_y = g_fade(Pfy);
+	float const n_x0 = g_mix(n00, n10, fade_x), n_x1 = g_mix(n01, n11, fade_x);
+	float const n_xy = g_mix(n_x0, n_x1, fade_y);
+	return 2.3f*n_xy;
+}
+
+static float glm_perlin3(float Px, float Py, float Pz) { /* noise.inl:66-133 */
+	float const P[3] = {Px, Py, Pz};
+	float Pi0[3], Pi1[3], Pf0[3], Pf1[3];
+	for (int d = 0; d < 3; ++d) {
+		Pi0[d] = floorf(P[d]); Pi1[d] = Pi0[d] + 1.0f;
+		Pi0[d] = g_mod289(Pi0[d]); Pi1[d] = g_mod289(Pi1[d]);
+		Pf0[d] = g_fract(P[d]); Pf1[d] = Pf0[d] - 1.0f;
+	}
+	float const ix[4] = {Pi0[0], Pi1[0], Pi0[0], Pi1[0]}, iy[4] = {Pi0[1], Pi0[1], Pi1[1], Pi1[1]};
+	float gx0[4], gy0[4], gz0[4], gx1[4], gy1[4], gz1[4];
+	for (int k = 0; k < 4; ++k) {
+		float const ixy  = g_permute(g_permute(ix[k]) + iy[k]);
+		float const ixy0 = g_permute(ixy + Pi0[2]), ixy1 = g_permute(ixy + Pi1[2]);
+		for (int s = 0; s < 2; ++s) {
+			float gx = (s ? ixy1 : ixy0)*(float)(1.0/7.0);
+			float gy = g_fract(floorf(gx)*(float)(1.0/7.0)) - 0.5f;
+			gx = g_fract(gx);
+			float const gz = 0.5f - fabsf(gx) - fabsf(gy);
+			float const sz = g_step(gz, 0.0f);
+			gx -= sz*(g_step(0.0f, gx) - 0.5f);
+			gy -= sz*(g_step(0.0f, gy) - 0.5f);
+			if (s) {gx1[k] = gx; gy1[k] = gy; gz1[k] = gz;} else {gx0[k] = gx; gy0[k] = gy; gz0[k] = gz;}
+		}
+	}
+	/* g000=.x g100=.y g010=.z g110=.w ; norm0 = tis(dot(g000), dot(g010), dot(g100), dot(g110)) applied g000*=n.x g010*=n.y g100*=n.z g110*=n.w */
+	float g0[4][3], g1[4][3];
+	for (int k = 0; k < 4; ++k) {
+		float const n0 = g_tis(gx0[k]*gx0[k] + gy0[k]*gy0[k] + gz0[k]*gz0[k]);
+		float const n1 = g_tis(gx1[k]*gx1[k] + gy1[k]*gy1[k] + gz1[k]*gz1[k]);
+		g0[k][0] = gx0[k]*n0; g0[k][1] = gy0[k]*n0; g0[k][2] = gz0[k]*n0;
+		g1[k][0] = gx1[k]*n1; g1[k][1] = gy1[k]*n1; g1[k][2] = gz1[k]*n1;
+	}
+	/* k: 0=(x0,y0) 1=(x1,y0) 2=(x0,y1) 3=(x1,y1) */
+	float n0[4], n1[4];
+	for (int k = 0; k < 4; ++k) {
+		float const fxk = (k & 1) ? Pf1[0] : Pf0[0], fyk = (k & 2) ? Pf1[1] : Pf0[1];
+		n0[k] = g0[k][0]*fxk + g0[k][1]*fyk + g0[k][2]*Pf0[2];
+		n1[k] = g1[k][0]*fxk + g1[k][1]*fyk + g1[k][2]*Pf1[2];
+	}
+	float const fade_x = g_fade(Pf0[0]), fade_y = g_fade(Pf0[1]), fade_z = g_fade(Pf0[2]);
+	/* n_z = mix((n000,n100,n010,n110),(n001,n101,n011,n111), fade.z) */
+	float const nz0 = g_mix(n0[0], n1[0], fade_z), nz1 = g_mix(n0[1], n1[1], fade_z), nz2 = g_mix(n0[2], n1[2], fade_z), nz3 = g_mix(n0[3], n1[3], fade_z);
+	/* n_yz = mix((n_z.x,n_z.y),(n_z.z,n_z.w), fade.y) */
+	float const nyz0 = g_mix(nz0, nz2, fade_y), nyz1 = g_mix(nz1, nz3, fade_y);
+	float const n_xyz = g_mix(nyz0, nyz1, fade_x);
+	return 2.2f*n_xyz;
+}
+
+static float glm_simplex3(float vx, float vy, float vz) { /* noise.inl:649-722 */
+	float const Cx = (float)(1.0/6.0), Cy = (float)(1.0/3.0);
+	float const d1 = vx*Cy + vy*Cy + vz*Cy;
+	float ix = floorf(vx + d1), iy = floorf(vy + d1), iz = floorf(vz + d1);
+	float const d2 = ix*Cx + iy*Cx + iz*Cx;
+	float const x0[3] = {vx - ix + d2, vy - iy + d2, vz - iz + d2};
+	/* g = step(x0.yzx, x0) ; l = 1 - g ; i1 = min(g, l.zxy) ; i2 = max(g, l.zxy) */
+	float const g[3] = {g_step(x0[1], x0[0]), g_step(x0[2], x0[1]), g_step(x0[0], x0[2])};
+	float const l[3] = {1.0f - g[0], 1.0f - g[1], 1.0f - g[2]};
+	float const i1[3] = {g_min(g[0], l[2]), g_min(g[1], l[0]), g_min(g[2], l[1])};
+	float const i2[3] = {g_max(g[0], l[2]), g_max(g[1], l[0]), g_max(g[2], l[1])};
+	float x1[3], x2[3], x3[3];
+	for (int d = 0; d < 3; ++d) {x1[d] = x0[d] - i1[d] + Cx; x2[d] = x0[d] - i2[d] + Cy; x3[d] = x0[d] - 0.5f;}
+	ix = g_mod289(ix); iy = g_mod289(iy); iz = g_mod289(iz);
+	float const ozs[4] = {0.0f, i1[2], i2[2], 1.0f}, oys[4] = {0.0f, i1[1], i2[1], 1.0f}, oxs[4] = {0.0f, i1[0], i2[0], 1.0f};
+	float const n_ = 0.142857142857f;
+	float const nsx = n_*2.0f - 0.0f, nsy = n_*0.5f - 1.0f, nsz = n_*1.0f - 0.0f; /* ns = n_*D.wyz - D.xzx */
+	float xx[4], yy[4], hh[4];
+	for (int k = 0; k < 4; ++k) {
+		float const p = g_permute(g_permute(g_permute(iz + ozs[k]) + iy + oys[k]) + ix + oxs[k]);
+		float const j = p - 49.0f*floorf(p*nsz*nsz);
+		float const x_ = floorf(j*nsz);
+		float const y_ = floorf(j - 7.0f*x_);
+		xx[k] = x_*nsx + nsy;
+		yy[k] = y_*nsx + nsy;
+		hh[k] = 1.0f - fabsf(xx[k]) - fabsf(yy[k]);
+	}
+	float const b0[4] = {xx[0], xx[1], yy[0], yy[1]}, b1[4] = {xx[2], xx[3], yy[2], yy[3]};
+	float s0[4], s1[4], sh[4];
+	for (int k = 0; k < 4; ++k) {s0[k] = floorf(b0[k])*2.0f + 1.0f; s1[k] = floorf(b1[k])*2.0f + 1.0f; sh[k] = -g_step(hh[k], 0.0f);}
+	/* a0 = b0.xzyw + s0.xzyw*sh.xxyy ; a1 = b1.xzyw + s1.xzyw*sh.zzww */
+	float const a0[4] = {b0[0] + s0[0]*sh[0], b0[2] + s0[2]*sh[0], b0[1] + s0[1]*sh[1], b0[3] + s0[3]*sh[1]};
+	float const a1[4] = {b1[0] + s1[0]*sh[2], b1[2] + s1[2]*sh[2], b1[1] + s1[1]*sh[3], b1[3] + s1[3]*sh[3]};
+	float p0[3] = {a0[0], a0[1], hh[0]}, p1[3] = {a0[2], a0[3], hh[1]}, p2[3] = {a1[0], a1[1], hh[2]}, p3[3] = {a1[2], a1[3], hh[3]};
+	float const nm0 = g_tis(p0[0]*p0[0] + p0[1]*p0[1] + p0[2]*p0[2]), nm1 = g_tis(p1[0]*p1[0] + p1[1]*p1[1] + p1[2]*p1[2]);
+	float const nm2 = g_tis(p2[0]*p2[0] + p2[1]*p2[1] + p2[2]*p2[2]), nm3 = g_tis(p3[0]*p3[0] + p3[1]*p3[1] + p3[2]*p3[2]);
+	for (int d = 0; d < 3; ++d) {p0[d] *= nm0; p1[d] *= nm1; p2[d] *= nm2; p3[d] *= nm3;}
+	float m0 = g_max(0.6f - (x0[0]*x0[0] + x0[1]*x0[1] + x0[2]*x0[2]), 0.0f);
+	float m1 = g_max(0.6f - (x1[0]*x1[0] + x1[1]*x1[1] + x1[2]*x1[2]), 0.0f);
+	float m2 = g_max(0.6f - (x2[0]*x2[0] + x2[1]*x2[1] + x2[2]*x2[2]), 0.0f);
+	float m3 = g_max(0.6f - (x3[0]*x3[0] + x3[1]*x3[1] + x3[2]*x3[2]), 0.0f);
+	m0 = m0*m0; m1 = m1*m1; m2 = m2*m2; m3 = m3*m3;
+	float const q0 = p0[0]*x0[0] + p0[1]*x0[1] + p0[2]*x0[2], q1 = p1[0]*x1[0] + p1[1]*x1[1] + p1[2]*x1[2];
+	float const q2 = p2[0]*x2[0] + p2[1]*x2[1] + p2[2]*x2[2], q3 = p3[0]*x3[0] + p3[1]*x3[1] + p3[2]*x3[2];
+	return 42.0f*(((m0*m0)*q0 + (m1*m1)*q1) + ((m2*m2)*q2 + (m3*m3)*q3)); /* dot(vec4,vec4) = (x+y)+(z+w) */
+}
+
+/* ------------------------------------------------------------------ a5/a6: noise shaping, fBm, domain warp (src/mesh_gen.cpp:550-571,706-751) */
+static float get_hmap_scale(int mode) { /* src/mesh_gen.cpp:550-553 */
+	float const scale = (mode == ORC_MGEN_SIMPLEX || mode == ORC_MGEN_SIMPLEX_GPU || mode == ORC_MGEN_DWARP_GPU) ? 16.0f : 32.0f;
+	return scale*MESH_HEIGHT*mesh_height_scale*mesh_scale_z_inv;
+}
+static void postproc_noise_zval(float *zval) { /* src/mesh_gen.cpp:555-562 */
+	float z = *zval;
+	if (z > hp.plat_bot) {z = hp.plat_bot + hp.plat_h*(z - hp.plat_bot) + fmin_std(hp.plat_max, hp.plat_s*(z - hp.plat_bot));}
+	if (z > hp.crat_h  ) {z = hp.crat_h - hp.crat_s*(z - hp.crat_h);}
+	if (z > hp.crack_lo && z < hp.crack_hi) {z -= hp.crack_d*fmin_std(z-hp.crack_lo, hp.crack_hi-z);}
+	*zval = z;
+}
+static void apply_noise_shape_final(float *noise, int shape) { /* src/mesh_gen.cpp:564-571 */
+	switch (shape) {
+	case 0: break;
+	case 1: *noise = (float)((double)fabsf(*noise) - 2.0); break;
+	case 2: *noise = (float)(3.5 - (double)fabsf(*noise)); break;
+	}
+	postproc_noise_zval(noise);
+}
+static float gen_noise(float xv, float yv, int mode, int shape) { /* src/mesh_gen.cpp:706-730 */
+	float zval = 0.0f, mag = 1.0f, freq = 1.0f, rx, ry;
+	unsigned const end_octave = NUM_FREQ_COMP - start_eval_sin/N_RAND_SIN2;
+	float const lacunarity = 1.92f, gain = 0.5f;
+	gen_rx_ry(&rx, &ry);
+	for (unsigned i = 0; i < end_octave; ++i) {
+		float const px = freq*xv + rx, py = freq*yv + ry;
+		float noise = (mode == ORC_MGEN_SIMPLEX || mode == ORC_MGEN_SIMPLEX_GPU || mode == ORC_MGEN_DWARP_GPU) ? glm_simplex2(px, py) : glm_perlin2(px, py);
+		switch (shape) {
+		case 0: break;
+		case 1: noise = (float)((double)fabsf(noise) - 0.40); break;
+		case 2: noise = (float)(0.45 - (double)fabsf(noise)); break;
+		}
+		zval += mag*noise;
+		mag  *= gain;
+		freq *= lacunarity;
+		rx    = (float)((double)rx*1.5);
+		ry    = (float)((double)ry*1.5);
+	}
+	return zval;
+}
+static float get_noise_zval(float xval, float yval, int mode, int shape) { /* src/mesh_gen.cpp:734-751 */
+	float const xy_scale = MESH_SCALE_FACTOR*mesh_scale;
+	float xv = xy_scale*xval, yv = xy_scale*yval;
+	if (mode == ORC_MGEN_DWARP_GPU) {
+		float const scale = 0.2f;
+		float const dx1 = gen_noise((float)((double)xv+0.0), (float)((double)yv+0.0), mode, shape);
+		float const dy1 = gen_noise((float)((double)xv+5.2), (float)((double)yv+1.3), mode, shape);
+		float const dx2 = gen_noise((float)((double)(xv + scale*dx1) + 1.7), (float)((double)(yv + scale*dy1) + 9.2), mode, shape);
+		float const dy2 = gen_noise((float)((double)(xv + scale*dx1) + 8.3), (float)((double)(yv + scale*dy1) + 2.8), mode, shape);
+		xv += scale*dx2; yv += scale*dy2;
+	}
+	float zval = gen_noise(xv, yv, mode, shape);
+	postproc_noise_zval(&zval);
+	return zval*get_hmap_scale(mode);
+}
+
+/* ------------------------------------------------------------------ glaciate / islands / volcano (src/mesh_gen.cpp:162-167,358-385) */
+static void set_zmax_est(float zval) {zmax_est = zval; zmax_est2 = (float)(2.0*(double)zmax_est); zmax_est2_inv = (float)(1.0/(double)zmax_est2);}
+static float do_glaciate_exp(float value) {return (custom_glaciate_exp == 0.0f) ? value*value*value : powf(value, custom_glaciate_exp);}
+static float get_rel_wpz(void) {return clip01(W_PLANE_Z + water_h_off_rel);}
+static float get_volcano_height(float xi, float yi) { /* src/mesh_gen.cpp:364-371 */
+	float const freq = mesh_scale/hp.volcano_width, x = freq*xi, y = freq*yi, dist = sqrtf(x*x + y*y);
+	if ((double)dist > 2.0) return 0.0f;
+	float const val = COSF(x)*COSF(y);
+	double const hole_d = 400.0*((double)val - 0.999);
+	float const hole = (float)((0.0 < hole_d) ? hole_d : 0.0); /* max(0.0, ...) */
+	float const peak = (float)(0.08*(double)val/(double)fmax_std(0.04f, dist));
+	return hp.volcano_height*fmax_std(0.0f, (peak - hole))*mesh_scale_z_inv;
+}
+static void apply_mesh_sine(float *zval, float x, float y) { /* src/mesh_gen.cpp:373-379 */
+	if (hp.sine_mag > 0.0f) {
+		float const freq = mesh_scale*hp.sine_freq;
+		*zval += (hp.sine_mag*COSF(x*freq)*COSF(y*freq) + hp.sine_bias)*mesh_scale_z_inv;
+		if (hp.volcano_width > 0.0f && hp.volcano_height > 0.0f) {*zval += get_volcano_height(x, y);}
+	}
+}
+static void apply_glaciate(float *zval) { /* src/mesh_gen.cpp:380-385 */
+	if (GLACIATE) {
+		float const relh = (*zval + zmax_est)*zmax_est2_inv;
+		*zval = do_glaciate_exp(relh)*zmax_est2 - zmax_est;
+	}
+}
+static float get_water_z_height(void) { /* src/mesh_gen.cpp:507-512 */
+	float wpz = get_rel_wpz();
+	if (GLACIATE) {wpz = do_glaciate_exp(wpz);}
+	return wpz*zmax_est2 - zmax_est + water_h_off;
+}
+
+/* ------------------------------------------------------------------ a4/a5: mesh_xy_grid_cache_t (src/mesh.h:22-45, src/mesh_gen.cpp:588-650,754-792) */
+typedef struct {
+	float *xyterms, *sine_mag_terms, *cached_vals;
+	unsigned cur_nx, cur_ny, yterms_start;
+	float mx0, my0, mdx, mdy, sine_offset;
+	int gen_mode, gen_shape, do_glaciate, has_sine_mag;
+} grid_cache_t;
+
+static float gc_eval_index(grid_cache_t const *g, unsigned x, unsigned y, int min_start_sin, int use_cache);
+
+static void gc_build_arrays(grid_cache_t *g, float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int cache_values, int force_sine_mode) {
+	memset(g, 0, sizeof(*g));
+	g->cur_nx = nx; g->cur_ny = ny; g->mx0 = dx*x0; g->my0 = dy*y0; g->mdx = dx; g->mdy = dy;
+	g->gen_mode  = force_sine_mode ? ORC_MGEN_SINE : mesh_gen_mode;
+	g->gen_shape = force_sine_mode ? 0 : mesh_gen_shape;
+	if (g->gen_mode == ORC_MGEN_SINE) {
+		g->yterms_start = nx*F_TABLE_SIZE;
+		g->xyterms = (float *)calloc((size_t)(nx + ny)*F_TABLE_SIZE, sizeof(float));
+		float const msx = mesh_scale*DX_VAL_INV, msy = mesh_scale*DY_VAL_INV, ms2 = (float)(0.5*(double)mesh_scale);
+		for (int k = start_eval_sin; k < F_TABLE_SIZE; ++k) {
+			float const x_mult = msx*sinTable[k][4], y_mult = msy*sinTable[k][3], y_scale = mesh_scale_z_inv*sinTable[k][0];
+			float const x_const = ms2*sinTable[k][4] + sinTable[k][2] + x_mult*g->mx0, y_const = ms2*sinTable[k][3] + sinTable[k][1] + y_mult*g->my0;
+			float const xmdx = x_mult*dx, ymdy = y_mult*dy;
+			float *x_ptr = g->xyterms + k, *y_ptr = x_ptr + g->yterms_start;
+			for (unsigned i = 0; i < nx; ++i) {x_ptr[(size_t)i*F_TABLE_SIZE] = SINF(xmdx*(float)i + x_const);}
+			for (unsigned i = 0; i < ny; ++i) {y_ptr[(size_t)i*F_TABLE_SIZE] = y_scale*SINF(ymdy*(float)i + y_const);}
+		}
+	}
+	if (cache_values) {
+		float *cv = (float *)malloc((size_t)nx*ny*sizeof(float));
+#pragma omp parallel for schedule(static,1)
+		for (int y = 0; y < (int)ny; ++y) {
+			for (unsigned x = 0; x < nx; ++x) {cv[(size_t)y*nx + x] = gc_eval_index(g, x, y, 0, 0);}
+		}
+		g->cached_vals = cv;
+	}
+}
+static void gc_enable_glaciate(grid_cache_t *g) { /* src/mesh_gen.cpp:640-650 */
+	g->do_glaciate = 1;
+	if (hp.sine_mag == 0.0f) return;
+	g->has_sine_mag = 1;
+	g->sine_mag_terms = (float *)malloc((size_t)(g->cur_nx + g->cur_ny)*sizeof(float)); /* reference over-allocates nx*ny; only nx+ny are used */
+	g->sine_offset = hp.sine_bias*mesh_scale_z_inv;
+	float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq;
+	for (unsigned x = 0; x < g->cur_nx; ++x) {g->sine_mag_terms[x] = sm_scale*COSF(((float)x*g->mdx + g->mx0)*DX_VAL_INV*freq);}
+	for (unsigned y = 0; y < g->cur_ny; ++y) {g->sine_mag_terms[g->cur_nx + y] = COSF(((float)y*g->mdy + g->my0)*DY_VAL_INV*freq);}
+}
+static void gc_free(grid_cache_t *g) {free(g->xyterms); free(g->sine_mag_terms); free(g->cached_vals); memset(g, 0, sizeof(*g));}
+
+static float gc_eval_index(grid_cache_t const *g, unsigned x, unsigned y, int min_start_sin, int use_cache) { /* src/mesh_gen.cpp:754-792 */
+	float zval = 0.0f;
+	if ((use_cache || g->gen_mode >= ORC_MGEN_SIMPLEX_GPU) && g->cached_vals) {
+		zval += g->cached_vals[(size_t)y*g->cur_nx + x];
+	}
+	else if (g->gen_mode != ORC_MGEN_SINE) {
+		float const xval = ((float)x*g->mdx + g->mx0)*DX_VAL_INV, yval = ((float)y*g->mdy + g->my0)*DY_VAL_INV;
+		zval += get_noise_zval(xval, yval, g->gen_mode, g->gen_shape);
+	}
+	else {
+		float const *const xptr = g->xyterms + (size_t)x*F_TABLE_SIZE;
+		float const *const yptr = g->xyterms + g->yterms_start + (size_t)y*F_TABLE_SIZE;
+		int const start_ix = imax(start_eval_sin, min_start_sin);
+		for (int i = start_ix; i < F_TABLE_SIZE; ++i) {zval += xptr[i]*yptr[i];}
+		apply_noise_shape_final(&zval, g->gen_shape);
+	}
+	if (g->do_glaciate) {
+		apply_glaciate(&zval);
+		if (hp.sine_mag > 0.0f) {
+			zval += g->sine_mag_terms[x]*g->sine_mag_terms[g->cur_nx + y] + g->sine_offset;
+			if (hp.volcano_width > 0.0f && hp.volcano_height > 0.0f) {zval += get_volcano_height(((float)x*g->mdx + g->mx0)*DX_VAL_INV, ((float)y*g->mdy + g->my0)*DY_VAL_INV);}
+		}
+	}
+	return zval;
+}
+
+/* a8: point query (src/mesh_gen.cpp:797-805) */
+static float eval_mesh_sin_terms(float xv, float yv) {
+	float zval = 0.0f;
+	for (int k = start_eval_sin; k < F_TABLE_SIZE; ++k) {
+		float const *stk = sinTable[k];
+		zval += stk[0]*SINF(stk[3]*yv + stk[1])*SINF(stk[4]*xv + stk[2]);
+	}
+	return zval;
+}
+
+/* ------------------------------------------------------------------ a9: zmax_est (src/mesh_gen.cpp:447-512), thresholds (:407-431), Textures.cpp:1284-1287,1757-1761 */
+static void set_zvals(void) { /* src/mesh_gen.cpp:494-504 */
+	zbottom = zmin; ztop = zmax;
+	zmin = -zmax_est; zmax = zmax_est;
+	water_plane_z = get_water_z_height();
+}
+static void estimate_zminmax(int using_eq) { /* src/mesh_gen.cpp:447-485 (mesh_scale_change == 0 branch) */
+	set_zmax_est(fmax_std(zmax, -zmin));
+	if (using_eq && zmax == zmin) {set_zmax_est((float)((double)zmax_est + 1.0E-6)); return;}
+	if (using_eq) {
+		float const rm_scale = (float)(1000.0*(double)XY_SCENE_SIZE/(double)mesh_scale);
+		grid_cache_t g;
+		gc_build_arrays(&g, 0.0f, 0.0f, rm_scale, rm_scale, EST_RAND_PARAM, EST_RAND_PARAM, 0, 0);
+		for (unsigned i = 0; i < EST_RAND_PARAM; ++i) {
+			for (unsigned j = 0; j < EST_RAND_PARAM; ++j) {
+				float const height = gc_eval_index(&g, j, i, 0, 1);
+				zmax_est = fmax_std(zmax_est, fabsf(height));
+			}
+		}
+		gc_free(&g);
+		if (mesh_gen_mode != ORC_MGEN_SINE) {zmax_est = (float)((double)zmax_est*1.2);}
+	}
+	set_zmax_est((float)(1.1*(double)zmax_est));
+	set_zvals();
+}
+static void init_terrain_mesh(void) { /* src/mesh_gen.cpp:407-431 */
+	static float const mesh_rh_dirt[5] = {0.40f, 0.44f, 0.60f, 0.75f, 1.0f}; /* src/mesh_gen.cpp:42 */
+	float const rel_wpz = get_rel_wpz();
+	for (unsigned i = 0; i < 5; ++i) {
+		float const def_h = mesh_rh_dirt[i];
+		float h;
+		if (mesh_rh_dirt[i] < W_PLANE_Z) {h = def_h*rel_wpz/W_PLANE_Z;}
+		else {
+			float const rel_h = (def_h - W_PLANE_Z)/(1.0f - W_PLANE_Z);
+			h = (float)((double)rel_wpz + (double)rel_h*(1.0 - (double)rel_wpz));
+			if (i == 4) { /* SNOW_TEX */
+				h = fmin_std(h, def_h);
+				if ((double)temperature > 40.0) h = (float)((double)h + 0.01*((double)temperature - 40.0));
+			}
+		}
+		lttex_dirt_zval[i] = h;
+	}
+}
+static void gen_tex_height_tables(void) { /* src/Textures.cpp:1757-1761 */
+	for (unsigned i = 0; i < 5; ++i) {h_dirt[i] = powf(lttex_dirt_zval[i], glaciate_exp);}
+	clip_hd1 = (float)(0.90*(double)h_dirt[1] + 0.10*(double)h_dirt[0]);
+}
+static int get_bare_ls_tid_is_rock(float zval) { /* src/Textures.cpp:1284-1287 */
+	float const relh = relh_adj_tex + (zval - zmin)/(zmax - zmin);
+	return (relh > clip_hd1);
+}
+
+/* gen_mesh(surface_type=0, keep_sin_table=0, update_zvals=1) as run once at start-up (src/mesh_gen.cpp:257-356) */
+static void gen_mesh_startup(void) {
+	float const scaled_height = MESH_HEIGHT*mesh_height_scale;
+	compute_scale();
+	gen_rand_sine_table_entries(scaled_height);
+	/* gen_mesh_sine_table(mesh_height, xoff2=0, yoff2=0, MX, MY): src/mesh_gen.cpp:201-210 */
+	free(ground_mesh);
+	ground_mesh = (float *)malloc((size_t)MESH_X_SIZE*MESH_Y_SIZE*sizeof(float));
+	grid_cache_t g;
+	gc_build_arrays(&g, (float)(0 - MESH_X_SIZE/2), (float)(0 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, MESH_X_SIZE, MESH_Y_SIZE, 0, 0);
+	for (int i = 0; i < MESH_Y_SIZE; ++i) {
+		for (int j = 0; j < MESH_X_SIZE; ++j) {ground_mesh[(size_t)i*MESH_X_SIZE + j] = gc_eval_index(&g, j, i, 0, 1);}
+	}
+	gc_free(&g);
+	zmin = zmax = ground_mesh[0]; /* calc_zminmax, src/mesh_gen.cpp:84-99 */
+	for (size_t i = 0; i < (size_t)MESH_X_SIZE*MESH_Y_SIZE; ++i) {zmin = fmin_std(zmin, ground_mesh[i]); zmax = fmax_std(zmax, ground_mesh[i]);}
+	estimate_zminmax(1);
+	/* gen_terrain_map -> glaciate(): src/mesh_gen.cpp:388-404,434-444 (ground-mesh values are not part of the hot path outputs, but kept for the C1 plumbing check) */
+	if (GLACIATE) {
+		glaciate_exp = (custom_glaciate_exp == 0.0f) ? DEF_GLACIATE_EXP : custom_glaciate_exp;
+		for (int i = 0; i < MESH_Y_SIZE; ++i) {
+			for (int j = 0; j < MESH_X_SIZE; ++j) {
+				float *z = &ground_mesh[(size_t)i*MESH_X_SIZE + j];
+				apply_glaciate(z);
+				apply_mesh_sine(z, (float)(j + 0 - MESH_X_SIZE/2), (float)(i + 0 - MESH_Y_SIZE/2));
+			}
+		}
+	}
+	else {glaciate_exp = 1.0f;}
+}
+
+/* ------------------------------------------------------------------ a11: apply_erosion (src/erosion.cpp:14-164) */
+typedef struct {
+	float *mh; int NX, NY, xsize, ysize;
+} egrid_t;
+
+static inline int hmap_index(egrid_t const *e, int x, int y) {return e->NX*imax(imin(y, e->NY-1), 0) + imax(imin(x, e->NX-1), 0);}
+
+static void erosion_impl(float *heightmap, int xsize, int ysize, float min_zval, unsigned num_iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet) {
+	if (num_iters == 0 || erode_amount <= 0.0f) return;
+	float const Kq=10, Kw=0.001f, Kr=0.9f, Kd=0.02f, Ki=0.1f, minSlope=0.05f, g=20, Kg=g*2;
+	int const PAD=4, NX=xsize+2*PAD, NY=ysize+2*PAD;
+	unsigned const MAX_PATH_LEN = 4u*NX*NY;
+	float *mh_padded = (float *)malloc((size_t)NX*NY*sizeof(float));
+	egrid_t const e = {mh_padded, NX, NY, xsize, ysize};
+	float const one_minus_Kw = 1-Kw;
+
+	for (int y = 0; y < NY; ++y) { /* src/erosion.cpp:31-37 */
+		size_t const offset = (size_t)imax(imin(y-PAD, ysize-1), 0)*xsize;
+		for (int x = 0; x < NX; ++x) {mh_padded[(size_t)y*NX + x] = heightmap[imax(imin(x-PAD, xsize-1), 0) + offset];}
+	}
+#define HMAP(x, y) mh_padded[hmap_index(&e, (x), (y))]
+#define DEPOSIT_AT(X, Z, W) { \
+	float const delta = ds*erode_amount*(W); \
+	int const ix = hmap_index(&e, (X), (Z)); \
+	if (!((X) < 0 || (Z) < 0 || (X) >= NX || (Z) >= NY)) {mh_padded[ix] += delta;} \
+}
+#define DEPOSIT(H) \
+	DEPOSIT_AT(xi  , zi  , (1-xf)*(1-zf)) \
+	DEPOSIT_AT(xi+1, zi  ,    xf *(1-zf)) \
+	DEPOSIT_AT(xi  , zi+1, (1-xf)*   zf ) \
+	DEPOSIT_AT(xi+1, zi+1,    xf *   zf ) \
+	(H)+=ds;
+
+	/* serial order iter = 0,1,2,...: the only deterministic order of the reference (OMP_NUM_THREADS=1); see SURVEY section 7 */
+	for (int iter = 0; iter < (int)num_iters; ++iter) {
+		rgen_t rgen;
+		rgen_set_state(&rgen, iter+11, 79*iter+121);
+		int xi = PAD + (rgen_rand(&rgen)%xsize);
+		int zi = PAD + (rgen_rand(&rgen)%ysize);
+		float xp=xi, zp=zi, xf=0, zf=0, s=0, v=0, w=1, dx=0, dz=0;
+		float h=HMAP(xi, zi), h00=h, h10=HMAP(xi+1, zi), h01=HMAP(xi, zi+1), h11=HMAP(xi+1, zi+1);
+		unsigned numMoves = 0;
+		int saw_nan = 0;
+
+		for (; numMoves < MAX_PATH_LEN; ++numMoves) {
+			float gx=h00+h01-h10-h11, gz=h00+h10-h01-h11;
+			dx=(dx-gx)*Ki+gx;
+			dz=(dz-gz)*Ki+gz;
+			float dl=sqrtf(dx*dx+dz*dz);
+			if (dl<=FLT_EPSILON) {
+				float a=rgen_rand_float(&rgen)*TWO_PI_F;
+				dx=cosf(a); dz=sinf(a);
+			}
+			else {dx/=dl; dz/=dl;}
+			float nxp=xp+dx, nzp=zp+dz;
+			int nxi=f2i(floorf(nxp)), nzi=f2i(floorf(nzp));
+			float nxf=nxp-nxi, nzf=nzp-nzi;
+			float nh00=HMAP(nxi, nzi), nh10=HMAP(nxi+1, nzi), nh01=HMAP(nxi, nzi+1), nh11=HMAP(nxi+1, nzi+1);
+			float nh=(nh00*(1-nxf)+nh10*nxf)*(1-nzf)+(nh01*(1-nxf)+nh11*nxf)*nzf;
+			if (fmax_std(fmax_std(nh00, nh10), fmax_std(nh01, nh11)) < water_plane_z - HALF_DXY) {if (st) ++st->ocean_stops; break;}
+
+			int const outside = (xi < 0 || zi < 0 || xi >= NX || zi >= NY);
+			if (nh>=h || outside) {
+				float ds=(nh-h)+0.001f;
+				if (ds>=s || outside) {
+					ds=s;
+					DEPOSIT(h)
+					s=0;
+					if (st) ++st->pit_stops;
+					break;
+				}
+				DEPOSIT(h)
+				s-=ds;
+				v=0;
+			}
+			float dh=h-nh;
+			float slope=dh;
+			float q=fmax_std(slope, minSlope)*v*w*Kq;
+			float ds=s-q;
+			if (ds>=0) {
+				ds*=Kd;
+				DEPOSIT(dh)
+				s-=ds;
+				if (st) ++st->deposit_steps;
+			}
+			else {
+				ds*=-Kr;
+				ds=fmin_std(ds, dh*0.99f);
+				ds=(float)((double)ds*(get_bare_ls_tid_is_rock(nh) ? 0.5 : 2.0));
+				for (int z=zi-1; z<=zi+2; ++z) {
+					float zo=z-zp, zo2=zo*zo;
+					for (int x=xi-1; x<=xi+2; ++x) {
+						float xo=x-xp;
+						float wb=1-(xo*xo+zo2)*0.25f;
+						if (wb<=0) continue;
+						wb*=0.1591549430918953f;
+						float const delta=ds*erode_amount*wb;
+						mh_padded[hmap_index(&e, x, z)]-=delta;
+					}
+				}
+				dh-=ds;
+				s+=ds;
+				if (st) ++st->erode_steps;
+			}
+			v=sqrtf(v*v+Kg*dh);
+			if (v != v) saw_nan = 1;
+			w*=one_minus_Kw;
+			xp=nxp; zp=nzp; xi=nxi; zi=nzi; xf=nxf; zf=nzf;
+			h=nh; h00=nh00; h10=nh10; h01=nh01; h11=nh11;
+		}
+		if (st) {st->steps += numMoves; if (numMoves > st->max_steps) st->max_steps = numMoves; st->nan_droplets += saw_nan;}
+		if (steps_per_droplet) steps_per_droplet[iter] = numMoves;
+	}
+	for (int y = 0; y < ysize; ++y) { /* src/erosion.cpp:158-162 */
+		for (int x = 0; x < xsize; ++x) {heightmap[(size_t)y*xsize + x] = fmax_std(min_zval, mh_padded[(size_t)(y+PAD)*NX + x+PAD]);}
+	}
+	free(mh_padded);
+#undef HMAP
+#undef DEPOSIT_AT
+#undef DEPOSIT
+}
+
+/* ------------------------------------------------------------------ a14/a15: noise_gen_3d + voxel fill (src/upsurface.cpp:16-70, src/voxels.cpp:278-345) */
+#define SINES_PER_FREQ 12
+#define MAX_FREQ_BINS 5
+#define TOT_NUM_SINES (SINES_PER_FREQ*MAX_FREQ_BINS)
+#define NUM_SINE_PARAMS 7
+static void ngen_gen_sines(rgen_t *r, float mag, float freq, float *rdata) { /* src/upsurface.cpp:16-38 */
+	for (unsigned i = 0; i < MAX_FREQ_BINS; ++i) {
+		unsigned const offset2 = SINES_PER_FREQ*i;
+		for (unsigned j = 0; j < SINES_PER_FREQ; ++j) {
+			unsigned const offset = NUM_SINE_PARAMS*(offset2 + j);
+			rdata[offset+0] = rgen_rand_uniform(r, 0.2f, 1.0f)*mag;
+			rdata[offset+1] = rgen_rand_uniform(r, 0.1f, 1.0f)*freq;
+			rdata[offset+2] = (float)(rgen_randd(r)*(double)TWO_PI_F);
+			rdata[offset+3] = rgen_rand_uniform(r, 0.1f, 1.0f)*freq;
+			rdata[offset+4] = (float)(rgen_randd(r)*(double)TWO_PI_F);
+			rdata[offset+5] = rgen_rand_uniform(r, 0.1f, 1.0f)*freq;
+			rdata[offset+6] = (float)(rgen_randd(r)*(double)TWO_PI_F);
+		}
+		mag  *= 0.5f; /* M_ATTEN_FACTOR */
+		freq /= 0.4f; /* F_ATTEN_FACTOR */
+	}
+}
+
+/* ------------------------------------------------------------------ exported harness (same shapes as ref_* in oracle/ref_shim.cpp) */
+void orc_init(orc_config_t const *c) {
+	MESH_X_SIZE = c->mesh_x; MESH_Y_SIZE = c->mesh_y; MESH_Z_SIZE = 0;
+	X_SCENE_SIZE = c->scene_x; Y_SCENE_SIZE = c->scene_y; Z_SCENE_SIZE = c->scene_z;
+	create_sin_table();
+	set_scene_constants();
+	mesh_height_scale = c->mesh_height; mesh_scale = c->mesh_scale; mesh_scale_z_inv = 1.0f;
+	mesh_seed = c->mesh_seed; mesh_freq_filter = c->mesh_freq_filter; mesh_gen_mode = c->mesh_gen_mode; mesh_gen_shape = c->mesh_gen_shape;
+	GLACIATE = c->glaciate; custom_glaciate_exp = c->custom_glaciate_exp;
+	memcpy(&hp, c->hmap, sizeof(hp));
+	erode_amount = c->erode_amount; water_h_off = c->water_h_off; water_h_off_rel = c->water_h_off_rel; relh_adj_tex = c->relh_adj_tex;
+	ocean_wave_height = c->ocean_wave_height;
+	MESH_START_MAG = c->start_mag; MESH_START_FREQ = c->start_freq; MESH_MAG_MULT = c->mag_mult; MESH_FREQ_MULT = c->freq_mult;
+	temperature = DEF_TEMPERATURE;
+	init_terrain_mesh();
+	gen_mesh_startup();
+	gen_tex_height_tables();
+}
+void orc_get_state(orc_state_t *s) {
+	memcpy(s->sinTable, sinTable, sizeof(sinTable));
+	s->start_eval_sin = start_eval_sin;
+	s->MESH_HEIGHT = MESH_HEIGHT; s->DX_VAL = DX_VAL; s->DY_VAL = DY_VAL; s->DX_VAL_INV = DX_VAL_INV; s->DY_VAL_INV = DY_VAL_INV;
+	s->HALF_DXY = HALF_DXY; s->dxdy = dxdy; s->XY_SCENE_SIZE = XY_SCENE_SIZE;
+	s->mesh_scale = mesh_scale; s->mesh_scale_z_inv = mesh_scale_z_inv; s->mesh_height_scale = mesh_height_scale;
+	s->zmax_est = zmax_est; s->zmin = zmin; s->zmax = zmax; s->water_plane_z = water_plane_z; s->glaciate_exp = glaciate_exp;
+	s->clip_hd1 = clip_hd1; s->relh_adj_tex = relh_adj_tex;
+	gen_rx_ry(&s->rx, &s->ry);
+}
+void  orc_set_zmax_est(float v) {set_zmax_est(v); zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height();}
+void  orc_set_water_plane_z(float v) {water_plane_z = v;}
+void  orc_set_mode(int mode, int shape) {mesh_gen_mode = mode; mesh_gen_shape = shape;}
+void  orc_set_start_eval_sin(int v) {start_eval_sin = v;}
+void  orc_set_erode_amount(float v) {erode_amount = v;}
+void  orc_get_ground_mesh(float *out) {memcpy(out, ground_mesh, (size_t)MESH_X_SIZE*MESH_Y_SIZE*sizeof(float));}
+float orc_sin_table(int i) {return sin_table[i];}
+int   orc_num_threads(void) {return omp_get_max_threads();}
+void  orc_set_num_threads(int n) {omp_set_num_threads(n);}
+
+void orc_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int min_start_sin, float *out) {
+	grid_cache_t g;
+	gc_build_arrays(&g, x0, y0, dx, dy, nx, ny, cache_values, 0);
+	if (glaciate) {gc_enable_glaciate(&g);}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)ny; ++y) {
+		for (unsigned x = 0; x < nx; ++x) {out[(size_t)y*nx + x] = gc_eval_index(&g, x, y, min_start_sin, 1);}
+	}
+	gc_free(&g);
+}
+void orc_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters) {erosion_impl(hmap, xsize, ysize, min_zval, iters, NULL, NULL);}
+void orc_apply_erosion_stats(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet) {
+	if (st) memset(st, 0, sizeof(*st));
+	erosion_impl(hmap, xsize, ysize, min_zval, iters, st, steps_per_droplet);
+}
+float orc_get_noise_zval(float x, float y, int mode, int shape) {return get_noise_zval(x, y, mode, shape);}
+float orc_gen_noise(float x, float y, int mode, int shape) {return gen_noise(x, y, mode, shape);}
+float orc_eval_mesh_sin_terms(float x, float y) {return eval_mesh_sin_terms(x, y);}
+float orc_glm_simplex2(float x, float y) {return glm_simplex2(x, y);}
+float orc_glm_perlin2(float x, float y) {return glm_perlin2(x, y);}
+float orc_glm_simplex3(float x, float y, float z) {return glm_simplex3(x, y, z);}
+float orc_glm_perlin3(float x, float y, float z) {return glm_perlin3(x, y, z);}
+int   orc_get_bare_ls_tid_is_rock(float z) {return get_bare_ls_tid_is_rock(z);}
+float orc_get_max_sea_level(void) {return get_water_z_height() + ocean_wave_height;} /* src/tiled_mesh.cpp:141 */
+void  orc_rand_ints(long s1, long s2, int n, int *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand(&r);}}
+void  orc_rand_floats(long s1, long s2, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_float(&r);}}
+void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_uniform(&r, a, b);}}
+
+/* a10: tile_t::create_zvals (src/tiled_mesh.cpp:302-314,447-546), size=128 */
+void orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_tile_stats_t *st) {
+	unsigned const size = 128, stride = size+1, zvsize = stride+1;
+	int const x1 = tx*(int)size, y1 = ty*(int)size, x2 = x1 + (int)size, y2 = y1 + (int)size;
+	int wx1 = x2, wy1 = y2, wx2 = x1, wy2 = y1;
+	grid_cache_t g;
+	gc_build_arrays(&g, (float)(x1 - MESH_X_SIZE/2), (float)(y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0);
+	gc_enable_glaciate(&g);
+	float mzmin = FAR_DISTANCE, mzmax = -FAR_DISTANCE;
+	unsigned const block_size = zvsize/4;
+	float const wpz_max = orc_get_max_sea_level();
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)zvsize; ++y) {
+		for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = gc_eval_index(&g, x, y, 0, 1);}
+	}
+	gc_free(&g);
+	orc_apply_erosion(zvals, zvsize, zvsize, zmin, iters_tt);
+	for (unsigned yy = 0; yy < 4; ++yy) {
+		for (unsigned xx = 0; xx < 4; ++xx) {
+			unsigned const x_end = (xx+1)*block_size, y_end = (yy+1)*block_size;
+			float szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE;
+			for (unsigned y = yy*block_size; y <= y_end; ++y) {
+				for (unsigned x = xx*block_size; x <= x_end; ++x) {
+					float const z = zvals[y*zvsize + x];
+					szmin = fmin_std(szmin, z); szmax = fmax_std(szmax, z);
+					if (z < wpz_max) {
+						wx1 = imin(wx1, x1+(int)x); wy1 = imin(wy1, y1+(int)y);
+						wx2 = imax(wx2, x1+(int)x); wy2 = imax(wy2, y1+(int)y);
+					}
+				}
+			}
+			st->sub_zmin[yy*4+xx] = szmin; st->sub_zmax[yy*4+xx] = szmax;
+			mzmin = fmin_std(mzmin, szmin);
+			mzmax = fmax_std(mzmax, szmax);
+		}
+	}
+	st->mzmin = mzmin; st->mzmax = mzmax;
+	st->radius = (float)(0.5*sqrt((double)((DX_VAL*DX_VAL + DY_VAL*DY_VAL)*size*size + (mzmax - mzmin)*(mzmax - mzmin))));
+	st->wx1 = wx1; st->wy1 = wy1; st->wx2 = wx2; st->wy2 = wy2;
+}
+
+/* a13: normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880; vector3d::get_norm src/3DWorld.h) */
+float orc_tile_normals(float const *zvals, unsigned char *rgba) {
+	unsigned const stride = 129, zvsize = 130;
+	float min_normal_z = 1.0f;
+	memset(rgba, 0, 4*stride*stride);
+	for (unsigned y = 0; y < stride; ++y) {
+		for (unsigned x = 0; x < stride; ++x) {
+			unsigned const ix = y*stride + x, ix2 = y*zvsize + x, ix_off = 4*ix;
+			float n[3] = {DY_VAL*(zvals[ix2] - zvals[ix2 + 1]), DX_VAL*(zvals[ix2] - zvals[ix2 + zvsize]), dxdy};
+			/* pointT::get_norm() (src/3DWorld.h:297-300): vmag = sqrt(x*x+y*y+z*z); (vmag < TOLERANCE) ? *this : (x/vmag, y/vmag, z/vmag) */
+			float const mag = sqrtf(n[0]*n[0] + n[1]*n[1] + n[2]*n[2]);
+			if (!(mag < TOLERANCE_F)) {n[0] /= mag; n[1] /= mag; n[2] /= mag;}
+			min_normal_z = fmin_std(min_normal_z, n[2]);
+			for (int i = 0; i < 3; ++i) {rgba[ix_off+i] = (unsigned char)(127.0*((double)n[i] + 1.0));}
+		}
+	}
+	return min_normal_z;
+}
+
+/* K10: 16-bit quantise (src/heightmap.cpp:146-150,205-215; src/Textures.cpp:1889-1893; src/mesh_gen.cpp:120-131) */
+void orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out) {
+	float min_z = vals[0], max_z = vals[0];
+	for (size_t i = 0; i < n; ++i) {min_z = fmin_std(min_z, vals[i]); max_z = fmax_std(max_z, vals[i]);}
+	float const dz = fmax_std(TOLERANCE_F, (max_z - min_z));
+	float const READ_MESH_H_SCALE = 0.0008f;
+	float const dzs = (float)((double)dz/255.0);
+	float const file_scale = dzs/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv), file_tz = min_z/mesh_scale_z_inv;
+	float const mult = READ_MESH_H_SCALE*mesh_height_scale*file_scale*mesh_scale_z_inv, add = file_tz*mesh_scale_z_inv;
+	float const val_div = (float)(1.0/(double)mult), val_add = add;
+	for (size_t i = 0; i < n; ++i) {
+		float const v = (vals[i] - val_add)*val_div;
+		unsigned char const high_bits = (unsigned char)v;
+		out[(i<<1)+1] = high_bits;
+		out[i<<1]     = (unsigned char)(256.0f*(v - (float)high_bits));
+	}
+	*min_z_out = min_z; *dz_out = dz;
+}
+
+void orc_voxel_rdata(int rseed1, int rseed2, float mag, float freq, float *rdata) {
+	rgen_t r; rgen_set_state(&r, rseed1, rseed2);
+	ngen_gen_sines(&r, mag, freq, rdata);
+}
+void orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],
+	float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1)
+{
+	unsigned const xyz_num[3] = {nx, ny, nz};
+	float *xyz_vals[3] = {NULL, NULL, NULL};
+	float rdata[NUM_SINE_PARAMS*TOT_NUM_SINES];
+	unsigned const num_sines = TOT_NUM_SINES;
+	float rx = 0.0f, ry = 0.0f;
+	if (gen_mode == ORC_MGEN_SINE) {
+		orc_voxel_rdata(rseed1, rseed2, mag, freq, rdata);
+		for (unsigned d = 0; d < 3; ++d) { /* gen_xyz_vals, src/upsurface.cpp:41-57 */
+			xyz_vals[d] = (float *)malloc((size_t)num_sines*xyz_num[d]*sizeof(float));
+			float val = lo_pos[d] + offset[d];
+			for (unsigned i = 0; i < xyz_num[d]; ++i) {
+				for (unsigned k = 0; k < num_sines; ++k) {
+					unsigned const index2 = NUM_SINE_PARAMS*k + 2*d;
+					float v = SINF(rdata[index2+1]*val + rdata[index2+2]);
+					if (d == 0) {v *= rdata[index2];}
+					xyz_vals[d][(size_t)i*num_sines + k] = v;
+				}
+				val += vsz[d];
+			}
+		}
+	}
+	else {gen_rx_ry(&rx, &ry);}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)ny; ++y) {
+		for (unsigned x = 0; x < nx; ++x) {
+			for (unsigned z = 0; z < nz; ++z) {
+				float val = 0.0f;
+				if (gen_mode == ORC_MGEN_SINE) { /* get_val, src/upsurface.cpp:60-70 */
+					float const *xv = xyz_vals[0] + (size_t)x*num_sines, *yv = xyz_vals[1] + (size_t)y*num_sines, *zv = xyz_vals[2] + (size_t)z*num_sines;
+					for (unsigned k = 0; k < num_sines; ++k) {val += xv[k]*yv[k]*zv[k];}
+				}
+				else {
+					float const px = ((float)x*vsz[0] + lo_pos[0]) + offset[0], py = ((float)y*vsz[1] + lo_pos[1]) + offset[1], pz = ((float)z*vsz[2] + lo_pos[2]) + offset[2];
+					float nmag = mag, nfreq = (float)(0.25*(double)freq);
+					float const lacunarity = 1.92f, gain = 0.5f;
+					int const nn = imax(1, (MAX_FREQ_BINS - mesh_freq_filter));
+					for (int n = 0; n < nn; ++n) {
+						float const nvx = nfreq*px + rx, nvy = nfreq*py + ry, nvz = nfreq*pz + (rx-ry);
+						val   += nmag*((gen_mode == ORC_MGEN_PERLIN) ? glm_perlin3(nvx, nvy, nvz) : glm_simplex3(nvx, nvy, nvz));
+						nmag  *= gain;
+						nfreq *= lacunarity;
+					}
+				}
+				val += (float)z*zscale;
+				if (normalize_to_1) {val = clip_pm1(val);}
+				out[z + (x + (size_t)y*nx)*nz] = val;
+			}
+		}
+	}
+	for (unsigned d = 0; d < 3; ++d) {free(xyz_vals[d]);}
+}

@@ -1,0 +1,91 @@
+/* oracle/terra_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the 3DWorld procedural-terrain hot path, used as the CPU
+ * checker for the HIP library.  Nothing under oracle/ is linked into, imported by, or called from the product
+ * (3dworld_amd/, libterra_hip.so); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * PARITY PIN: this restatement is checked bit-for-bit against the reference's own translation units compiled
+ * in place (oracle/_ref/liboracle_ref.so, recipe oracle/Makefile) by tests/test_oracle_vs_ref.py whenever
+ * /root/reference is present, and against tests/golden/ fixtures generated from that build
+ * (tests/golden/make_golden.py) everywhere else.
+ *
+ * All citations are relative to /root/reference/.
+ */
+#ifndef TERRA_ORACLE_H
+#define TERRA_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_F_TABLE_SIZE 90 /* NUM_FREQ_COMP(9) * N_RAND_SIN2(10), src/mesh_gen.cpp:14,16,30 */
+
+enum {ORC_MGEN_SINE = 0, ORC_MGEN_SIMPLEX, ORC_MGEN_PERLIN, ORC_MGEN_SIMPLEX_GPU, ORC_MGEN_DWARP_GPU}; /* src/3DWorld.h:1399 */
+
+/* what a config file sets (src/3DWorld.cpp:1763-2110); same layout as ref_config_t in oracle/ref_shim.cpp */
+typedef struct {
+	int mesh_x, mesh_y;
+	float scene_x, scene_y, scene_z;
+	float mesh_height, mesh_scale;
+	int mesh_seed, mesh_freq_filter, mesh_gen_mode, mesh_gen_shape, glaciate;
+	float custom_glaciate_exp;
+	float hmap[14]; /* hmap_params_t, src/mesh.h:84-88: plat_bot plat_h plat_s plat_max crat_h crat_s crack_lo crack_hi crack_d sine_mag sine_freq sine_bias volcano_width volcano_height */
+	float erode_amount, water_h_off, water_h_off_rel, relh_adj_tex, ocean_wave_height;
+	float start_mag, start_freq, mag_mult, freq_mult;
+} orc_config_t;
+
+/* derived state; same layout as ref_state_t in oracle/ref_shim.cpp */
+typedef struct {
+	float sinTable[ORC_F_TABLE_SIZE][5];
+	int start_eval_sin;
+	float MESH_HEIGHT, DX_VAL, DY_VAL, DX_VAL_INV, DY_VAL_INV, HALF_DXY, dxdy, XY_SCENE_SIZE;
+	float mesh_scale, mesh_scale_z_inv, mesh_height_scale;
+	float zmax_est, zmin, zmax, water_plane_z, glaciate_exp, clip_hd1, relh_adj_tex;
+	float rx, ry;
+} orc_state_t;
+
+typedef struct {float sub_zmin[16], sub_zmax[16], mzmin, mzmax, radius; int wx1, wy1, wx2, wy2;} orc_tile_stats_t;
+
+/* per-droplet trace statistics (instrumentation only) */
+typedef struct {uint64_t steps, erode_steps, deposit_steps, ocean_stops, pit_stops, nan_droplets; uint32_t max_steps;} orc_erosion_stats_t;
+
+void  orc_init(orc_config_t const *c);
+void  orc_get_state(orc_state_t *s);
+void  orc_set_zmax_est(float v);
+void  orc_set_water_plane_z(float v);
+void  orc_set_mode(int mode, int shape);
+void  orc_set_start_eval_sin(int v);
+void  orc_set_erode_amount(float v);
+void  orc_get_ground_mesh(float *out);
+float orc_sin_table(int i);
+int   orc_num_threads(void);
+void  orc_set_num_threads(int n);
+
+void  orc_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int min_start_sin, float *out);
+void  orc_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters);
+void  orc_apply_erosion_stats(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet);
+float orc_get_noise_zval(float x, float y, int mode, int shape);
+float orc_gen_noise(float x, float y, int mode, int shape);
+float orc_eval_mesh_sin_terms(float x, float y);
+float orc_glm_simplex2(float x, float y);
+float orc_glm_perlin2(float x, float y);
+float orc_glm_simplex3(float x, float y, float z);
+float orc_glm_perlin3(float x, float y, float z);
+int   orc_get_bare_ls_tid_is_rock(float z);
+float orc_get_max_sea_level(void);
+void  orc_rand_ints(long s1, long s2, int n, int *out);
+void  orc_rand_floats(long s1, long s2, int n, float *out);
+void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out);
+void  orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_tile_stats_t *st);
+float orc_tile_normals(float const *zvals, unsigned char *rgba);
+void  orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out);
+void  orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],
+	float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
+void  orc_voxel_rdata(int rseed1, int rseed2, float mag, float freq, float *rdata);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

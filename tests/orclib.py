@@ -1,0 +1,239 @@
+"""ctypes bindings for the two CPU checkers (TEST INFRASTRUCTURE ONLY).
+
+    oracle/liboracle.so            plain-C restatement (prefix "orc_")
+    oracle/_ref/liboracle_ref.so   the reference's own TUs compiled in place (prefix "ref_"), only where it was built
+
+Both export the same harness, so `Checker("orc")` and `Checker("ref")` are interchangeable.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class Config(C.Structure):
+    _fields_ = [("mesh_x", C.c_int), ("mesh_y", C.c_int), ("scene_x", C.c_float), ("scene_y", C.c_float), ("scene_z", C.c_float),
+                ("mesh_height", C.c_float), ("mesh_scale", C.c_float), ("mesh_seed", C.c_int), ("mesh_freq_filter", C.c_int),
+                ("mesh_gen_mode", C.c_int), ("mesh_gen_shape", C.c_int), ("glaciate", C.c_int), ("custom_glaciate_exp", C.c_float),
+                ("hmap", C.c_float * 14), ("erode_amount", C.c_float), ("water_h_off", C.c_float), ("water_h_off_rel", C.c_float),
+                ("relh_adj_tex", C.c_float), ("ocean_wave_height", C.c_float),
+                ("start_mag", C.c_float), ("start_freq", C.c_float), ("mag_mult", C.c_float), ("freq_mult", C.c_float)]
+
+
+_STATE_FLOATS = ("MESH_HEIGHT DX_VAL DY_VAL DX_VAL_INV DY_VAL_INV HALF_DXY dxdy XY_SCENE_SIZE mesh_scale mesh_scale_z_inv "
+                 "mesh_height_scale zmax_est zmin zmax water_plane_z glaciate_exp clip_hd1 relh_adj_tex rx ry").split()
+
+
+class State(C.Structure):
+    _fields_ = [("sinTable", (C.c_float * 5) * 90), ("start_eval_sin", C.c_int)] + [(n, C.c_float) for n in _STATE_FLOATS]
+
+    def sin_table_np(self):
+        return np.ctypeslib.as_array(self.sinTable).reshape(90, 5).copy()
+
+
+class TileStats(C.Structure):
+    _fields_ = [("sub_zmin", C.c_float * 16), ("sub_zmax", C.c_float * 16), ("mzmin", C.c_float), ("mzmax", C.c_float), ("radius", C.c_float),
+                ("wx1", C.c_int), ("wy1", C.c_int), ("wx2", C.c_int), ("wy2", C.c_int)]
+
+
+class ErosionStats(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("erode_steps", C.c_uint64), ("deposit_steps", C.c_uint64), ("ocean_stops", C.c_uint64),
+                ("pit_stops", C.c_uint64), ("nan_droplets", C.c_uint64), ("max_steps", C.c_uint32)]
+
+
+HMAP_DEFAULT = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 0, 0, 0, 0, 0]          # hmap_params_t defaults, src/mesh.h:84-88
+HMAP_ISLANDS = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 0, 0]  # scene_config/config.txt:76
+
+
+def make_config(mesh_gen_mode=0, mesh_gen_shape=0, mesh_seed=1, mesh_freq_filter=0, hmap=None, glaciate=1, mesh_scale=1.0,
+                mesh_height=0.7, custom_glaciate_exp=0.0, erode_amount=1.0, mesh_xy=128, scene=(4.0, 4.0, 4.0)):
+    """BASELINE.md section 3 synthetic inputs (scene_config/config.txt:56-97)."""
+    c = Config()
+    c.mesh_x = c.mesh_y = mesh_xy
+    c.scene_x, c.scene_y, c.scene_z = scene
+    c.mesh_height = mesh_height
+    c.mesh_scale = mesh_scale
+    c.mesh_seed = mesh_seed
+    c.mesh_freq_filter = mesh_freq_filter
+    c.mesh_gen_mode = mesh_gen_mode
+    c.mesh_gen_shape = mesh_gen_shape
+    c.glaciate = glaciate
+    c.custom_glaciate_exp = custom_glaciate_exp
+    for i, v in enumerate(HMAP_ISLANDS if hmap is None else hmap):
+        c.hmap[i] = v
+    c.erode_amount = erode_amount
+    c.water_h_off = c.water_h_off_rel = c.relh_adj_tex = c.ocean_wave_height = 0.0
+    c.start_mag, c.start_freq, c.mag_mult, c.freq_mult = 0.02, 240.0, 2.0, 0.5
+    return c
+
+
+def build_oracle():
+    """make oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "liboracle_ref.so"))
+
+
+_fp = C.POINTER(C.c_float)
+
+
+class Checker:
+    """Thin wrapper; kind = 'orc' (C restatement) or 'ref' (reference TUs)."""
+
+    def __init__(self, kind="orc"):
+        self.kind = kind
+        path = os.path.join(ORACLE_DIR, "liboracle.so" if kind == "orc" else os.path.join("_ref", "liboracle_ref.so"))
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = C.CDLL(path)
+        self.p = kind + "_"
+        f = self._f
+        f("init", None, [C.POINTER(Config)])
+        f("get_state", None, [C.POINTER(State)])
+        f("set_zmax_est", None, [C.c_float])
+        f("set_water_plane_z", None, [C.c_float])
+        f("set_mode", None, [C.c_int, C.c_int])
+        f("set_start_eval_sin", None, [C.c_int])
+        f("set_erode_amount", None, [C.c_float])
+        f("get_ground_mesh", None, [C.c_void_p])
+        f("sin_table", C.c_float, [C.c_int])
+        f("num_threads", C.c_int, [])
+        f("set_num_threads", None, [C.c_int])
+        f("gen_grid", None, [C.c_float] * 4 + [C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        f("apply_erosion", None, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint])
+        f("get_noise_zval", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
+        f("gen_noise", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
+        f("eval_mesh_sin_terms", C.c_float, [C.c_float, C.c_float])
+        f("glm_simplex2", C.c_float, [C.c_float] * 2)
+        f("glm_perlin2", C.c_float, [C.c_float] * 2)
+        f("glm_simplex3", C.c_float, [C.c_float] * 3)
+        f("glm_perlin3", C.c_float, [C.c_float] * 3)
+        f("get_bare_ls_tid_is_rock", C.c_int, [C.c_float])
+        f("get_max_sea_level", C.c_float, [])
+        f("rand_ints", None, [C.c_long, C.c_long, C.c_int, C.c_void_p])
+        f("rand_floats", None, [C.c_long, C.c_long, C.c_int, C.c_void_p])
+        f("rand_uniforms", None, [C.c_long, C.c_long, C.c_float, C.c_float, C.c_int, C.c_void_p])
+        f("tile_create_zvals", None, [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.POINTER(TileStats)])
+        f("tile_normals", C.c_float, [C.c_void_p, C.c_void_p])
+        f("quantize16", None, [C.c_void_p, C.c_size_t, C.c_void_p, _fp, _fp])
+        f("voxel_fill", None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int])
+        f("voxel_rdata", None, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p])
+        if kind == "orc":
+            f("apply_erosion_stats", None, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint, C.POINTER(ErosionStats), C.c_void_p])
+
+    def _f(self, name, restype, argtypes):
+        fn = getattr(self.lib, self.p + name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+        setattr(self, "_" + name, fn)
+
+    # ---- harness
+    def init(self, cfg):
+        self._init(C.byref(cfg))
+        return self.state()
+
+    def state(self):
+        s = State()
+        self._get_state(C.byref(s))
+        return s
+
+    def set_zmax_est(self, v): self._set_zmax_est(v)
+    def set_water_plane_z(self, v): self._set_water_plane_z(v)
+    def set_mode(self, mode, shape=0): self._set_mode(mode, shape)
+    def set_start_eval_sin(self, v): self._set_start_eval_sin(v)
+    def set_erode_amount(self, v): self._set_erode_amount(v)
+    def set_num_threads(self, n): self._set_num_threads(n)
+    def num_threads(self): return self._num_threads()
+    def get_max_sea_level(self): return self._get_max_sea_level()
+
+    def ground_mesh(self, n=128):
+        out = np.zeros((n, n), np.float32)
+        self._get_ground_mesh(out.ctypes.data)
+        return out
+
+    def sin_table(self):
+        return np.array([self._sin_table(i) for i in range(65536)], np.float32)
+
+    def gen_grid(self, x0, y0, dx, dy, nx, ny, glaciate=1, cache_values=0, min_start_sin=0):
+        out = np.zeros((ny, nx), np.float32)
+        self._gen_grid(x0, y0, dx, dy, nx, ny, glaciate, cache_values, min_start_sin, out.ctypes.data)
+        return out
+
+    def apply_erosion(self, hmap, min_zval, iters):
+        assert hmap.dtype == np.float32 and hmap.flags.c_contiguous
+        ys, xs = hmap.shape
+        self._apply_erosion(hmap.ctypes.data, xs, ys, min_zval, iters)
+        return hmap
+
+    def apply_erosion_stats(self, hmap, min_zval, iters):
+        ys, xs = hmap.shape
+        st = ErosionStats()
+        steps = np.zeros(iters, np.uint32)
+        self._apply_erosion_stats(hmap.ctypes.data, xs, ys, min_zval, iters, C.byref(st), steps.ctypes.data)
+        return st, steps
+
+    def noise_zval(self, x, y, mode, shape=0): return self._get_noise_zval(x, y, mode, shape)
+    def gen_noise(self, x, y, mode, shape=0): return self._gen_noise(x, y, mode, shape)
+    def eval_mesh_sin_terms(self, x, y): return self._eval_mesh_sin_terms(x, y)
+    def simplex2(self, x, y): return self._glm_simplex2(x, y)
+    def perlin2(self, x, y): return self._glm_perlin2(x, y)
+    def simplex3(self, x, y, z): return self._glm_simplex3(x, y, z)
+    def perlin3(self, x, y, z): return self._glm_perlin3(x, y, z)
+    def is_rock(self, z): return self._get_bare_ls_tid_is_rock(z)
+
+    def rand_ints(self, s1, s2, n):
+        out = np.zeros(n, np.int32); self._rand_ints(s1, s2, n, out.ctypes.data); return out
+
+    def rand_floats(self, s1, s2, n):
+        out = np.zeros(n, np.float32); self._rand_floats(s1, s2, n, out.ctypes.data); return out
+
+    def rand_uniforms(self, s1, s2, a, b, n):
+        out = np.zeros(n, np.float32); self._rand_uniforms(s1, s2, a, b, n, out.ctypes.data); return out
+
+    def tile_create_zvals(self, tx, ty, iters_tt=0):
+        z = np.zeros((130, 130), np.float32)
+        st = TileStats()
+        self._tile_create_zvals(tx, ty, iters_tt, z.ctypes.data, C.byref(st))
+        return z, st
+
+    def tile_normals(self, zvals):
+        rgba = np.zeros((129, 129, 4), np.uint8)
+        mnz = self._tile_normals(np.ascontiguousarray(zvals, np.float32).ctypes.data, rgba.ctypes.data)
+        return rgba, mnz
+
+    def quantize16(self, vals):
+        vals = np.ascontiguousarray(vals, np.float32)
+        out = np.zeros(vals.size * 2, np.uint8)
+        mn, dz = C.c_float(), C.c_float()
+        self._quantize16(vals.ctypes.data, vals.size, out.ctypes.data, C.byref(mn), C.byref(dz))
+        return out, mn.value, dz.value
+
+    def voxel_fill(self, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
+        out = np.zeros((ny, nx, nz), np.float32)
+        a = lambda v: (C.c_float * 3)(*v)
+        self._voxel_fill(out.ctypes.data, nx, ny, nz, a(lo_pos), a(vsz), a(offset), mag, freq, rseed1, rseed2, gen_mode, zscale, normalize)
+        return out
+
+    def voxel_rdata(self, rseed1, rseed2, mag, freq):
+        out = np.zeros(420, np.float32)
+        self._voxel_rdata(rseed1, rseed2, mag, freq, out.ctypes.data)
+        return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        idx = np.argwhere(~same)
+        i = tuple(idx[0])
+        raise AssertionError(f"{what}: {len(idx)} of {a.size} values differ; first at {i}: {a[i]!r} vs {b[i]!r}; max abs diff {np.nanmax(np.abs(a - b))}")
