@@ -1,0 +1,259 @@
+// terra_api_impl.hpp -- the extern "C" entry points of include/terra.h, written once over terra_engine<BACKEND>.
+// Included by exactly one translation unit per library after it has defined `terra_backend_t`:
+//   3dworld_amd/csrc/terra_hip.hip  -> libterra_hip.so  (product, HIP/gfx950)
+//   tests/emul/terra_emul.cpp       -> tests/emul/libterra_emul.so (test-only host emulation of the kernel bodies)
+#pragma once
+#include "terra_driver.hpp"
+#include <new>
+
+namespace terra {
+static thread_local std::string g_last_error;
+inline int fail(int code, char const *what) {g_last_error = what ? what : "unknown error"; return code;}
+} // namespace terra
+
+struct terra_ctx {
+	terra::terra_engine<terra_backend_t> eng;
+};
+
+struct terra_gen { // mesh_xy_grid_cache_t (src/mesh.h:22-45)
+	terra_ctx *ctx = nullptr;
+	float x0 = 0, y0 = 0, dx = 0, dy = 0;
+	uint32_t nx = 0, ny = 0, flags = 0;
+	bool built = false, running = false, glaciated = false, collected = false;
+	float *d_vals = nullptr; size_t d_count = 0;
+	std::vector<float> cached_vals;
+};
+
+#define TERRA_TRY   try {
+#define TERRA_CATCH } catch (std::invalid_argument const &e) {return terra::fail(TERRA_ERR_ARG, e.what());} \
+                      catch (std::logic_error const &e) {return terra::fail(TERRA_ERR_STATE, e.what());} \
+                      catch (std::bad_alloc const &) {return terra::fail(TERRA_ERR_LIMIT, "out of memory");} \
+                      catch (std::exception const &e) {return terra::fail(TERRA_ERR_HIP, e.what());} \
+                      return TERRA_OK;
+#define TERRA_CHECK_CTX if (!ctx) return terra::fail(TERRA_ERR_ARG, "null terra_ctx");
+
+extern "C" {
+
+const char *terra_last_error(void) {return terra::g_last_error.c_str();}
+int terra_device_count(void) {return terra_backend_t::device_count();}
+
+int terra_create(terra_ctx **out, int device_index) {
+	if (!out) return terra::fail(TERRA_ERR_ARG, "terra_create: null out pointer");
+	*out = nullptr;
+	int const ndev = terra_backend_t::device_count();
+	if (ndev <= 0) return terra::fail(TERRA_ERR_NODEVICE, "terra_create: no usable HIP device (libterra_hip has no CPU fall-back)");
+	if (device_index < 0 || device_index >= ndev) return terra::fail(TERRA_ERR_ARG, "terra_create: device index out of range");
+	TERRA_TRY
+		terra_ctx *c = new terra_ctx();
+		try {c->eng.be.init(device_index);} catch (...) {delete c; throw;}
+		*out = c;
+	TERRA_CATCH
+}
+void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (...) {} delete ctx;}}
+int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
+int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
+
+int terra_init_scene(terra_ctx *ctx, const terra_config *cfg) {
+	TERRA_CHECK_CTX
+	if (!cfg) return terra::fail(TERRA_ERR_ARG, "terra_init_scene: null config");
+	TERRA_TRY ctx->eng.init_scene(*cfg); TERRA_CATCH
+}
+int terra_get_state(terra_ctx *ctx, terra_state *out) {TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out"); TERRA_TRY ctx->eng.require_scene(); ctx->eng.get_state(*out); TERRA_CATCH}
+int terra_set_state(terra_ctx *ctx, const terra_state *in) {TERRA_CHECK_CTX if (!in) return terra::fail(TERRA_ERR_ARG, "null state"); TERRA_TRY ctx->eng.set_state(*in); TERRA_CATCH}
+int terra_set_mode(terra_ctx *ctx, int mode, int shape) {
+	TERRA_CHECK_CTX
+	if (mode < 0 || mode > TERRA_MGEN_DWARP_GPU || shape < 0 || shape > 2) return terra::fail(TERRA_ERR_ARG, "terra_set_mode: bad mode/shape");
+	ctx->eng.mode = mode; ctx->eng.shape = shape; return TERRA_OK;
+}
+int terra_set_zmax_est(terra_ctx *ctx, float v) {TERRA_CHECK_CTX ctx->eng.set_zmax_est(v); ctx->eng.set_zvals(); return TERRA_OK;}
+int terra_set_water_plane_z(terra_ctx *ctx, float v) {TERRA_CHECK_CTX ctx->eng.water_plane_z = v; return TERRA_OK;}
+int terra_set_start_eval_sin(terra_ctx *ctx, int v) {
+	TERRA_CHECK_CTX
+	if (v < 0 || v > TERRA_F_TABLE_SIZE) return terra::fail(TERRA_ERR_ARG, "start_eval_sin out of range"); // assert(start_eval_sin <= F_TABLE_SIZE), src/mesh_gen.cpp:590
+	ctx->eng.start_eval_sin = v; return TERRA_OK;
+}
+int terra_set_erode_amount(terra_ctx *ctx, float v) {TERRA_CHECK_CTX ctx->eng.erode_amount = v; return TERRA_OK;}
+float terra_get_max_sea_level(terra_ctx *ctx) {return ctx ? ctx->eng.get_max_sea_level() : 0.0f;}
+
+// ---- generator handle
+int terra_gen_create(terra_ctx *ctx, terra_gen **out) {
+	TERRA_CHECK_CTX
+	if (!out) return terra::fail(TERRA_ERR_ARG, "null out");
+	TERRA_TRY *out = new terra_gen(); (*out)->ctx = ctx; TERRA_CATCH
+}
+void terra_gen_destroy(terra_gen *g) {
+	if (!g) return;
+	try {if (g->d_vals) {g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);}} catch (...) {}
+	delete g;
+}
+static void terra_gen_do_collect(terra_gen *g) {
+	if (g->collected) return;
+	g->cached_vals.resize((size_t)g->nx*g->ny);
+	g->ctx->eng.be.d2h(g->cached_vals.data(), g->d_vals, g->cached_vals.size()*sizeof(float)); // blocks on the stream, like read_float_vals (src/shaders.cpp:1196-1235)
+	g->running = false; g->collected = true;
+}
+int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags) {
+	if (!g) return terra::fail(TERRA_ERR_ARG, "null terra_gen");
+	try {
+		bool const no_wait = (flags & TERRA_GEN_NO_WAIT) != 0;
+		uint32_t const key = flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE);
+		bool const same = g->built && g->x0 == x0 && g->y0 == y0 && g->dx == dx && g->dy == dy && g->nx == nx && g->ny == ny && (g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE)) == key;
+		bool const was_running = g->running && same;
+		if (!was_running) { // launch the job (run_gpu_simplex, src/mesh_gen.cpp:652-681)
+			size_t const count = (size_t)nx*ny;
+			if (count == 0) return terra::fail(TERRA_ERR_ARG, "build_arrays: nx, ny must be > 0");
+			if (count > g->d_count) {if (g->d_vals) {g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);} g->d_vals = (float *)g->ctx->eng.be.alloc(count*sizeof(float)); g->d_count = count;}
+			g->x0 = x0; g->y0 = y0; g->dx = dx; g->dy = dy; g->nx = nx; g->ny = ny; g->flags = flags;
+			g->ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, 0, g->d_vals);
+			g->built = true; g->running = true; g->collected = false; g->glaciated = (flags & TERRA_GEN_GLACIATE) != 0;
+			g->cached_vals.clear();
+		}
+		if (no_wait && !was_running) return 0; // just started, results not yet available
+		terra_gen_do_collect(g);
+		return 1;
+	}
+	catch (std::invalid_argument const &e) {return terra::fail(TERRA_ERR_ARG, e.what());}
+	catch (std::logic_error const &e) {return terra::fail(TERRA_ERR_STATE, e.what());}
+	catch (std::exception const &e) {return terra::fail(TERRA_ERR_HIP, e.what());}
+}
+int terra_gen_enable_glaciate(terra_gen *g) {
+	if (!g) return terra::fail(TERRA_ERR_ARG, "null terra_gen");
+	if (!g->built) return terra::fail(TERRA_ERR_STATE, "enable_glaciate: build_arrays() must have been called first"); // assert(cur_nx > 0 && cur_ny > 0), src/mesh_gen.cpp:644
+	if (g->glaciated) return TERRA_OK;
+	TERRA_TRY
+		// not fused at build time: re-evaluate with the glaciate epilogue (pure per-cell function, identical values)
+		g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags | TERRA_GEN_GLACIATE, 0, g->d_vals);
+		g->flags |= TERRA_GEN_GLACIATE; g->glaciated = true; g->running = true; g->collected = false;
+	TERRA_CATCH
+}
+int terra_gen_is_running(terra_gen *g) {return (g && g->running) ? 1 : 0;}
+int terra_gen_collect(terra_gen *g, float *host_out) {
+	if (!g || !host_out) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (!g->built) return terra::fail(TERRA_ERR_STATE, "collect: nothing was built");
+	TERRA_TRY terra_gen_do_collect(g); memcpy(host_out, g->cached_vals.data(), g->cached_vals.size()*sizeof(float)); TERRA_CATCH
+}
+float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y) {
+	if (!g || !g->built || x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;} // assert(x < cur_nx && y < cur_ny), src/mesh_gen.cpp:756
+	try {terra_gen_do_collect(g);} catch (std::exception const &e) {terra::fail(TERRA_ERR_HIP, e.what()); return 0.0f;}
+	return g->cached_vals[(size_t)y*g->nx + x];
+}
+const float *terra_gen_device_values(terra_gen *g) {return (g && g->built) ? g->d_vals : nullptr;}
+
+int terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out) {
+	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out); TERRA_CATCH
+}
+int terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out) {
+	TERRA_CHECK_CTX if (!h_out) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY
+		size_t const bytes = (size_t)nx*ny*sizeof(float);
+		if (bytes == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0");
+		float *d = (float *)ctx->eng.be.alloc(bytes);
+		try {ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d); ctx->eng.be.d2h(h_out, d, bytes);} catch (...) {ctx->eng.be.free(d); throw;}
+		ctx->eng.be.free(d);
+	TERRA_CATCH
+}
+
+// ---- erosion
+int terra_apply_erosion_dev(terra_ctx *ctx, float *d, int xs, int ys, float min_zval, uint32_t iters, uint32_t flags) {
+	TERRA_CHECK_CTX if (!d) return terra::fail(TERRA_ERR_ARG, "null heightmap");
+	TERRA_TRY ctx->eng.apply_erosion_dev(d, xs, ys, min_zval, iters, flags); TERRA_CATCH
+}
+int terra_apply_erosion(terra_ctx *ctx, float *h, int xs, int ys, float min_zval, uint32_t iters) {
+	TERRA_CHECK_CTX if (!h) return terra::fail(TERRA_ERR_ARG, "null heightmap");
+	TERRA_TRY
+		if (iters == 0 || ctx->eng.erode_amount <= 0.0f) return TERRA_OK;
+		if (xs <= 0 || ys <= 0) throw std::invalid_argument("apply_erosion: bad grid size");
+		size_t const bytes = (size_t)xs*ys*sizeof(float);
+		float *d = (float *)ctx->eng.be.alloc(bytes);
+		try {ctx->eng.be.h2d(d, h, bytes); ctx->eng.apply_erosion_dev(d, xs, ys, min_zval, iters, 0); ctx->eng.be.d2h(h, d, bytes);} catch (...) {ctx->eng.be.free(d); throw;}
+		ctx->eng.be.free(d);
+	TERRA_CATCH
+}
+int terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out) {TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out"); *out = ctx->eng.report; return TERRA_OK;}
+
+// ---- whole heightmap (heightmap_t::proc_gen, src/heightmap.cpp:130-151)
+int terra_minmax_dev(terra_ctx *ctx, const float *d, size_t n, float *h_min, float *h_max) {
+	TERRA_CHECK_CTX if (!d || n == 0) return terra::fail(TERRA_ERR_ARG, "empty input");
+	TERRA_TRY float mn, mx; ctx->eng.minmax_dev(d, n, mn, mx); if (h_min) *h_min = mn; if (h_max) *h_max = mx; TERRA_CATCH
+}
+int terra_quantize16_dev(terra_ctx *ctx, const float *d, size_t n, float min_z, float dz, uint8_t *d_pix) {
+	TERRA_CHECK_CTX if (!d || !d_pix) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (!(dz > 0.0f)) return terra::fail(TERRA_ERR_ARG, "quantize16: dz must be > 0"); // assert(dz > 0.0), src/mesh_gen.cpp:126
+	TERRA_TRY ctx->eng.quantize16_dev(d, n, min_z, dz, d_pix); TERRA_CATCH
+}
+int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height, uint32_t erosion_iters, float *d_vals, uint8_t *d_pix, float *h_range) {
+	TERRA_CHECK_CTX if (!d_vals) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY
+		auto &e = ctx->eng;
+		size_t const n = (size_t)width*height;
+		e.gen_grid_dev((float)(-0.5*(double)width), (float)(-0.5*(double)height), e.DX_VAL, e.DY_VAL, width, height, TERRA_GEN_GLACIATE, 0, d_vals); // src/heightmap.cpp:135-143
+		if (erosion_iters > 0) { // run_erosion (src/heightmap.cpp:153-187): min_zval = min(vals)
+			float mn, mx; e.minmax_dev(d_vals, n, mn, mx);
+			e.apply_erosion_dev(d_vals, (int)width, (int)height, mn, erosion_iters, TERRA_ERODE_MINZ_IS_MIN);
+		}
+		if (d_pix || h_range) {
+			float mn, mx; e.minmax_dev(d_vals, n, mn, mx); // get_heightmap_z_range
+			float const dz = terra::max_std(1.0E-12f, (mx - mn)); // max(TOLERANCE, ...), src/heightmap.cpp:148
+			if (h_range) {h_range[0] = mn; h_range[1] = dz;}
+			if (d_pix) {e.quantize16_dev(d_vals, n, mn, dz, d_pix);}
+		}
+	TERRA_CATCH
+}
+
+// ---- tiles
+int terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.tiles_create_zvals_dev(tile_xy, n, iters_tt, d_zvals, d_stats, d_normals, d_min_nz); TERRA_CATCH
+}
+int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t iters_tt, float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_nz) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (n == 0) return TERRA_OK;
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		size_t const zb = (size_t)n*130*130*4, sb = (size_t)n*sizeof(terra_tile_stats), nb = (size_t)n*129*129*4, mb = (size_t)n*4;
+		uint8_t *d = (uint8_t *)be.alloc(zb + sb + nb + mb + 1024);
+		float *dz = (float *)d; terra_tile_stats *ds = (terra_tile_stats *)(d + zb); uint8_t *dn = d + zb + sb; float *dm = (float *)(d + zb + sb + nb);
+		try {
+			ctx->eng.tiles_create_zvals_dev(tile_xy, n, iters_tt, dz, h_stats ? ds : nullptr, h_normals ? dn : nullptr, (h_normals && h_min_nz) ? dm : nullptr);
+			be.d2h(h_zvals, dz, zb);
+			if (h_stats) be.d2h(h_stats, ds, sb);
+			if (h_normals) be.d2h(h_normals, dn, nb);
+			if (h_normals && h_min_nz) be.d2h(h_min_nz, dm, mb);
+		} catch (...) {be.free(d); throw;}
+		be.free(d);
+	TERRA_CATCH
+}
+
+// ---- voxels
+int terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo[3], const float vsz[3], const float off[3],
+	float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize)
+{
+	TERRA_CHECK_CTX if (!d_out || !lo || !vsz || !off) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (gen_mode < 0 || gen_mode > TERRA_MGEN_DWARP_GPU) return terra::fail(TERRA_ERR_ARG, "bad gen_mode");
+	if (!(mag > 0.0f) || !(freq > 0.0f)) return terra::fail(TERRA_ERR_ARG, "voxel_fill: mag and freq must be > 0"); // assert(mag > 0.0 && freq > 0.0), src/upsurface.cpp:19
+	TERRA_TRY ctx->eng.voxel_fill_dev(d_out, nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, gen_mode, zscale, normalize); TERRA_CATCH
+}
+int terra_voxel_fill(terra_ctx *ctx, float *h_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo[3], const float vsz[3], const float off[3],
+	float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize)
+{
+	TERRA_CHECK_CTX if (!h_out) return terra::fail(TERRA_ERR_ARG, "null output");
+	size_t const bytes = (size_t)nx*ny*nz*sizeof(float);
+	if (bytes == 0) return terra::fail(TERRA_ERR_ARG, "voxel_fill: empty grid");
+	float *d = nullptr;
+	try {d = (float *)ctx->eng.be.alloc(bytes);} catch (std::exception const &e) {return terra::fail(TERRA_ERR_LIMIT, e.what());}
+	int const rc = terra_voxel_fill_dev(ctx, d, nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, gen_mode, zscale, normalize);
+	if (rc == TERRA_OK) {try {ctx->eng.be.d2h(h_out, d, bytes);} catch (std::exception const &e) {ctx->eng.be.free(d); return terra::fail(TERRA_ERR_HIP, e.what());}}
+	ctx->eng.be.free(d);
+	return rc;
+}
+
+// ---- plumbing
+int terra_malloc(terra_ctx *ctx, void **p, size_t bytes) {TERRA_CHECK_CTX if (!p) return terra::fail(TERRA_ERR_ARG, "null out"); TERRA_TRY *p = ctx->eng.be.alloc(bytes ? bytes : 1); TERRA_CATCH}
+int terra_free(terra_ctx *ctx, void *p) {TERRA_CHECK_CTX TERRA_TRY if (p) {ctx->eng.be.sync(); ctx->eng.be.free(p);} TERRA_CATCH}
+int terra_memcpy_h2d(terra_ctx *ctx, void *d, const void *h, size_t bytes) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.h2d(d, h, bytes); ctx->eng.be.sync(); TERRA_CATCH}
+int terra_memcpy_d2h(terra_ctx *ctx, void *h, const void *d, size_t bytes) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.d2h(h, d, bytes); TERRA_CATCH}
+int terra_timer_start(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.timer_start(); TERRA_CATCH}
+int terra_timer_stop(terra_ctx *ctx, float *ms) {TERRA_CHECK_CTX TERRA_TRY float const t = ctx->eng.be.timer_stop(); if (ms) *ms = t; TERRA_CATCH}
+
+} // extern "C"

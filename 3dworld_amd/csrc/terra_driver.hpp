@@ -1,0 +1,646 @@
+// terra_driver.hpp -- host-side logic of libterra_hip: scene derivation, kernel sequencing, erosion rounds.
+//
+// Templated on a BACKEND that owns memory and launches "one call per logical thread" bodies:
+//   * hip_backend_t (terra_hip.hip)       -- the product: HIP kernels on gfx950, LDS-tiled fast paths for the hot kernels;
+//   * cpu_backend_t (tests/emul)          -- TEST ONLY: runs the same bodies in host loops so the sequencing logic
+//                                            (scene start-up, speculative erosion rounds, tile batching) is checkable
+//                                            against the oracle on machines without a GPU.  Never part of the product.
+// Citations are relative to the 3DWorld reference tree.
+#pragma once
+#include "terra_common.hpp"
+#include "terra_noise.hpp"
+#include "terra_erosion.hpp"
+#include "../../include/terra.h"
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <stdexcept>
+#include <string.h>
+#include <stdio.h>
+
+namespace terra {
+
+// per-k constants of mesh_xy_grid_cache_t::build_arrays (src/mesh_gen.cpp:604-626), computed on the host in fp32
+struct sine_k_t {float xmdx[F_TABLE_SIZE], xconst[F_TABLE_SIZE], ymdy[F_TABLE_SIZE], yconst[F_TABLE_SIZE], yscale[F_TABLE_SIZE];};
+
+struct grid_job_t { // one build_arrays() + eval loop
+	float mx0, my0, mdx, mdy;
+	uint32_t nx, ny, nxp, nyp; // padded table row lengths
+	int mode, shape, kstart, glaciate, use_sine_mag;
+	float sine_offset;
+};
+
+// noise_gen_3d constants (src/upsurface.h:10-16)
+constexpr unsigned VOX_SINES = 60, VOX_PARAMS = 7;
+
+inline uint32_t round_up(uint32_t v, uint32_t m) {return (v + m - 1)/m*m;}
+
+// float <-> order-preserving uint (for atomic min/max of floats)
+TERRA_HD uint32_t f2ord(float f) {uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u);}
+TERRA_HD float ord2f(uint32_t o) {uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; memcpy(&f, &u, 4); return f;}
+
+// ---- "simple" (one logical thread per cell) bodies shared by the CPU emulator and the GPU cross-check kernels
+struct tile_ref_pod_t {int32_t tx, ty; uint32_t xi, yi;};
+
+TERRA_HD float sine_cell(grid_job_t const &job, float const *xt, float const *yt, unsigned x, unsigned y) {
+	float z = 0.0f;
+	for (int k = job.kstart; k < F_TABLE_SIZE; ++k) {z += xt[(size_t)k*job.nxp + x]*yt[(size_t)k*job.nyp + y];}
+	return z;
+}
+TERRA_HD float finish_cell(float z, grid_job_t const &job, noise_consts_t const &nc, sin_lut_t const &L, float const *smx, float const *smy, unsigned x, unsigned y) {
+	if (job.mode == MGEN_SINE) {z = apply_noise_shape_final(z, job.shape, nc.hp);}
+	if (job.glaciate) {
+		float const xg = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yg = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+		z = glaciate_epilogue(z, job.use_sine_mag ? smx[x] : 0.0f, job.use_sine_mag ? smy[y] : 0.0f, job.sine_offset, xg, yg, nc, L);
+	}
+	return z;
+}
+TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsigned x, unsigned y) {
+	float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+	switch (job.mode) {
+	case MGEN_PERLIN:      return noise_zval<MGEN_PERLIN>(xval, yval, job.shape, nc);
+	case MGEN_DWARP_GPU:   return noise_zval<MGEN_DWARP_GPU>(xval, yval, job.shape, nc);
+	case MGEN_SIMPLEX_GPU: return noise_zval<MGEN_SIMPLEX_GPU>(xval, yval, job.shape, nc);
+	default:               return noise_zval<MGEN_SIMPLEX>(xval, yval, job.shape, nc);
+	}
+}
+
+
+template<class BE> struct terra_engine {
+	BE be;
+	terra_config cfg{};
+	// ---- derived globals (the reference's process globals for this path)
+	float MESH_HEIGHT = 0, XY_SCENE_SIZE = 0, DX_VAL = 0, DY_VAL = 0, HALF_DXY = 0, DX_VAL_INV = 0, DY_VAL_INV = 0, dxdy = 0;
+	float sinTable[F_TABLE_SIZE][5] = {};
+	int   start_eval_sin = 0, mode = 0, shape = 0, glaciate = 1;
+	float mesh_scale = 1, mesh_scale_z_inv = 1, mesh_height_scale = 1;
+	float zmin = 0, zmax = 0, zmax_est = 0, zmax_est2 = 1, zmax_est2_inv = 1, water_plane_z = 0, glaciate_exp = 1, clip_hd1 = 0;
+	float relh_adj_tex = 0, erode_amount = 1, custom_glaciate_exp = 0, water_h_off = 0, water_h_off_rel = 0, ocean_wave_height = 0;
+	float rx = 1, ry = 1, two_pi = 0, sscale = 0;
+	hmap_params_t hp{};
+	rand_gen_t sine_rgen{1, 1}; // the function-static rgen of gen_rand_sine_table_entries (src/mesh_gen.cpp:239)
+	bool scene_ready = false;
+	std::vector<float> h_sin_table;
+	float *d_sin_table = nullptr;
+	terra_erosion_report report{};
+
+	// grow-only device scratch
+	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_tiles, s_vox, s_sk;
+	template<class T> T *scratch(scratch_t &s, size_t count) {
+		size_t const bytes = std::max<size_t>(count*sizeof(T), 256);
+		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
+		return (T *)s.p;
+	}
+	~terra_engine() {
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_tiles, &s_vox, &s_sk}) {if (s->p) be.free(s->p);}
+		if (d_sin_table) be.free(d_sin_table);
+	}
+
+	sin_lut_t lut() const {return sin_lut_t{d_sin_table, sscale};}
+	sin_lut_t host_lut() const {return sin_lut_t{h_sin_table.data(), sscale};}
+	noise_consts_t consts() const {
+		noise_consts_t nc;
+		nc.hp = hp; nc.mesh_scale = mesh_scale; nc.mesh_scale_z_inv = mesh_scale_z_inv; nc.DX_VAL_INV = DX_VAL_INV; nc.DY_VAL_INV = DY_VAL_INV;
+		nc.MESH_HEIGHT = MESH_HEIGHT; nc.mesh_height_scale = mesh_height_scale; nc.zmax_est = zmax_est; nc.zmax_est2 = zmax_est2; nc.zmax_est2_inv = zmax_est2_inv;
+		nc.custom_glaciate_exp = custom_glaciate_exp; nc.rx = rx; nc.ry = ry; nc.start_eval_sin = start_eval_sin; nc.glaciate = glaciate;
+		return nc;
+	}
+
+	// ================================================================ scene start-up (a1, a3, a9)
+	void create_sin_table() { // src/mesh_gen.cpp:72-81 (host libm, exactly like the reference), uploaded once
+		if (!h_sin_table.empty()) return;
+		two_pi = (float)(2.0*(double)PI_F);
+		sscale = (float)TSIZE/two_pi;
+		h_sin_table.resize(2*TSIZE);
+		for (unsigned i = 0; i < (unsigned)TSIZE; ++i) {
+			h_sin_table[i]       = sinf((float)i/sscale);
+			h_sin_table[i+TSIZE] = cosf((float)i/sscale);
+		}
+		d_sin_table = (float *)be.alloc(2*TSIZE*sizeof(float));
+		be.h2d(d_sin_table, h_sin_table.data(), 2*TSIZE*sizeof(float));
+	}
+	void set_scene_constants() { // src/matrix_ops.cpp:59-84
+		MESH_HEIGHT   = 0.10f*cfg.scene_z;
+		XY_SCENE_SIZE = 0.5f*(cfg.scene_x + cfg.scene_y);
+		DX_VAL        = (2.0f*cfg.scene_x)/(float)cfg.mesh_x;
+		DY_VAL        = (2.0f*cfg.scene_y)/(float)cfg.mesh_y;
+		HALF_DXY      = 0.5f*(DX_VAL + DY_VAL);
+		DX_VAL_INV    = 1.0f/DX_VAL;
+		DY_VAL_INV    = 1.0f/DY_VAL;
+		dxdy          = DX_VAL*DY_VAL;
+	}
+	void apply_mesh_rand_seed(rand_gen_t &r) const { // src/mesh_gen.cpp:213-216 (mesh_rgen_index = 0)
+		if (cfg.mesh_seed != 0) {r.set_state(cfg.mesh_seed, 12345);}
+		else if (mode != MGEN_SINE) {r.set_state(0+1, 12345);}
+	}
+	void gen_rand_sine_table_entries(float scaled_height) { // src/mesh_gen.cpp:219-254
+		float xf_scale = (float)cfg.mesh_y/(float)cfg.mesh_x, yf_scale = (float)(1.0/(double)xf_scale);
+		if (cfg.scene_x > cfg.scene_y) yf_scale *= cfg.scene_y/cfg.scene_x;
+		if (cfg.scene_y > cfg.scene_x) xf_scale *= cfg.scene_x/cfg.scene_y;
+		float mags[NUM_FREQ_COMP], freqs[NUM_FREQ_COMP];
+		freqs[0] = cfg.start_freq; mags[0] = cfg.start_mag;
+		for (int i = 1; i < NUM_FREQ_COMP; ++i) {freqs[i] = freqs[i-1]*cfg.freq_mult; mags[i] = mags[i-1]*cfg.mag_mult;}
+		float const mesh_h = (float)((double)scaled_height/sqrt(0.1*N_RAND_SIN2));
+		apply_mesh_rand_seed(sine_rgen);
+		for (int l = 0; l < NUM_FREQ_COMP; ++l) {
+			float const x_freq = freqs[l]/((float)cfg.mesh_x), y_freq = freqs[l]/((float)cfg.mesh_y), mheight = mags[l]*mesh_h;
+			for (int i = 0; i < N_RAND_SIN2; ++i) {
+				float *st = sinTable[l*N_RAND_SIN2 + i];
+				st[0] = sine_rgen.rand_uniform(0.2f, 1.0f)*mheight;  // magnitude
+				st[1] = sine_rgen.rand_float()*two_pi;                // y phase
+				st[2] = sine_rgen.rand_float()*two_pi;                // x phase
+				st[3] = sine_rgen.rand_uniform(0.1f, 1.0f)*x_freq*yf_scale; // y frequency
+				st[4] = sine_rgen.rand_uniform(0.1f, 1.0f)*y_freq*xf_scale; // x frequency
+			}
+		}
+	}
+	void compute_scale() { // src/mesh_gen.cpp:544-548
+		int const iscale = (int)log2f(mesh_scale);
+		start_eval_sin = N_RAND_SIN2*imax(0, imin(NUM_FREQ_COMP-3, iscale + cfg.mesh_freq_filter));
+	}
+	void gen_rx_ry() { // src/mesh_gen.cpp:581-586
+		rand_gen_t r{1, 1};
+		apply_mesh_rand_seed(r);
+		rx = (float)((double)r.rand_float() + 1.0);
+		ry = (float)((double)r.rand_float() + 1.0);
+	}
+	void set_zmax_est(float v) {zmax_est = v; zmax_est2 = (float)(2.0*(double)v); zmax_est2_inv = (float)(1.0/(double)zmax_est2);} // src/mesh_gen.cpp:162-167
+	float get_rel_wpz() const {return clip01(0.42f + water_h_off_rel);}               // W_PLANE_Z, src/mesh_gen.cpp:362
+	float get_water_z_height() const {                                               // src/mesh_gen.cpp:507-512
+		float wpz = get_rel_wpz();
+		if (glaciate) {wpz = glaciate_exp_fn(wpz, custom_glaciate_exp);}
+		return wpz*zmax_est2 - zmax_est + water_h_off;
+	}
+	float get_max_sea_level() const {return get_water_z_height() + ocean_wave_height;} // src/tiled_mesh.cpp:141
+	void set_zvals() {zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height();} // src/mesh_gen.cpp:494-504
+	void gen_tex_height_tables() { // init_terrain_mesh (src/mesh_gen.cpp:407-431) + gen_tex_height_tables (src/Textures.cpp:1757-1761), dirt/sand entries only
+		static float const mesh_rh_dirt[2] = {0.40f, 0.44f};
+		float const rel_wpz = get_rel_wpz(), W_PLANE_Z = 0.42f;
+		float h_dirt[2];
+		for (int i = 0; i < 2; ++i) {
+			float const def_h = mesh_rh_dirt[i];
+			float h;
+			if (def_h < W_PLANE_Z) {h = def_h*rel_wpz/W_PLANE_Z;}
+			else {float const rel_h = (def_h - W_PLANE_Z)/(1.0f - W_PLANE_Z); h = (float)((double)rel_wpz + (double)rel_h*(1.0 - (double)rel_wpz));}
+			h_dirt[i] = powf(h, glaciate_exp);
+		}
+		clip_hd1 = (float)(0.90*(double)h_dirt[1] + 0.10*(double)h_dirt[0]);
+	}
+
+	void init_scene(terra_config const &c) {
+		if (c.mesh_x <= 0 || c.mesh_y <= 0 || !(c.scene_x > 0) || !(c.scene_y > 0) || !(c.mesh_scale > 0)) throw std::invalid_argument("terra_init_scene: bad mesh/scene size");
+		if (c.mesh_gen_mode < 0 || c.mesh_gen_mode > MGEN_DWARP_GPU || c.mesh_gen_shape < 0 || c.mesh_gen_shape > 2) throw std::invalid_argument("terra_init_scene: bad mesh_gen_mode/shape");
+		cfg = c;
+		create_sin_table();
+		set_scene_constants();
+		mesh_height_scale = c.mesh_height; mesh_scale = c.mesh_scale; mesh_scale_z_inv = 1.0f; // config-file mesh_scale leaves mesh_scale_z at 1 (src/mesh_gen.cpp:862-874 only runs on runtime rescale)
+		mode = c.mesh_gen_mode; shape = c.mesh_gen_shape; glaciate = c.glaciate; custom_glaciate_exp = c.custom_glaciate_exp;
+		memcpy(&hp, c.hmap, sizeof(hp));
+		erode_amount = c.erode_amount; water_h_off = c.water_h_off; water_h_off_rel = c.water_h_off_rel; relh_adj_tex = c.relh_adj_tex; ocean_wave_height = c.ocean_wave_height;
+		// gen_mesh(0, 0, 1) at start-up (src/mesh_gen.cpp:257-356)
+		compute_scale();
+		gen_rand_sine_table_entries(MESH_HEIGHT*mesh_height_scale);
+		gen_rx_ry();
+		scene_ready = true;
+		uint32_t const MX = c.mesh_x, MY = c.mesh_y;
+		std::vector<float> h((size_t)std::max<uint32_t>(MX*MY, 128*128));
+		float *d = scratch<float>(s_misc, h.size());
+		gen_grid_dev((float)(0 - (int)MX/2), (float)(0 - (int)MY/2), DX_VAL, DY_VAL, MX, MY, 0, 0, d); // gen_mesh_sine_table (src/mesh_gen.cpp:201-210)
+		be.d2h(h.data(), d, (size_t)MX*MY*sizeof(float));
+		zmin = zmax = h[0]; // calc_zminmax
+		for (size_t i = 0; i < (size_t)MX*MY; ++i) {zmin = min_std(zmin, h[i]); zmax = max_std(zmax, h[i]);}
+		// estimate_zminmax(using_eq=1) (src/mesh_gen.cpp:447-485)
+		set_zmax_est(max_std(zmax, -zmin));
+		if (zmax == zmin) {set_zmax_est((float)((double)zmax_est + 1.0E-6));}
+		else {
+			float const rm_scale = (float)(1000.0*(double)XY_SCENE_SIZE/(double)mesh_scale);
+			gen_grid_dev(0.0f, 0.0f, rm_scale, rm_scale, 128, 128, 0, 0, d);
+			be.d2h(h.data(), d, 128*128*sizeof(float));
+			float ze = zmax_est;
+			for (size_t i = 0; i < 128*128; ++i) {ze = max_std(ze, fabsf(h[i]));}
+			if (mode != MGEN_SINE) {ze = (float)((double)ze*1.2);}
+			set_zmax_est((float)(1.1*(double)ze));
+			set_zvals();
+		}
+		glaciate_exp = glaciate ? ((custom_glaciate_exp == 0.0f) ? 3.0f : custom_glaciate_exp) : 1.0f; // glaciate() / gen_terrain_map (src/mesh_gen.cpp:388-444)
+		gen_tex_height_tables();
+	}
+	void get_state(terra_state &s) const {
+		memcpy(s.sinTable, sinTable, sizeof(sinTable));
+		s.start_eval_sin = start_eval_sin; s.MESH_HEIGHT = MESH_HEIGHT; s.DX_VAL = DX_VAL; s.DY_VAL = DY_VAL; s.DX_VAL_INV = DX_VAL_INV; s.DY_VAL_INV = DY_VAL_INV;
+		s.HALF_DXY = HALF_DXY; s.dxdy = dxdy; s.XY_SCENE_SIZE = XY_SCENE_SIZE; s.mesh_scale = mesh_scale; s.mesh_scale_z_inv = mesh_scale_z_inv; s.mesh_height_scale = mesh_height_scale;
+		s.zmax_est = zmax_est; s.zmin = zmin; s.zmax = zmax; s.water_plane_z = water_plane_z; s.glaciate_exp = glaciate_exp; s.clip_hd1 = clip_hd1; s.relh_adj_tex = relh_adj_tex;
+		s.rx = rx; s.ry = ry;
+	}
+	void set_state(terra_state const &s) {
+		create_sin_table();
+		memcpy(sinTable, s.sinTable, sizeof(sinTable));
+		start_eval_sin = s.start_eval_sin; MESH_HEIGHT = s.MESH_HEIGHT; DX_VAL = s.DX_VAL; DY_VAL = s.DY_VAL; DX_VAL_INV = s.DX_VAL_INV; DY_VAL_INV = s.DY_VAL_INV;
+		HALF_DXY = s.HALF_DXY; dxdy = s.dxdy; XY_SCENE_SIZE = s.XY_SCENE_SIZE; mesh_scale = s.mesh_scale; mesh_scale_z_inv = s.mesh_scale_z_inv; mesh_height_scale = s.mesh_height_scale;
+		set_zmax_est(s.zmax_est); zmin = s.zmin; zmax = s.zmax; water_plane_z = s.water_plane_z; glaciate_exp = s.glaciate_exp; clip_hd1 = s.clip_hd1; relh_adj_tex = s.relh_adj_tex;
+		rx = s.rx; ry = s.ry;
+		if (cfg.mesh_x == 0) {cfg.mesh_x = cfg.mesh_y = 128;}
+		scene_ready = true;
+	}
+	void require_scene() const {if (!scene_ready) throw std::logic_error("terra: scene not initialised (call terra_init_scene or terra_set_state first)");}
+
+	// ================================================================ generator (a4, a5, a6)
+	sine_k_t make_sine_k(float mx0, float my0, float dx, float dy) const { // src/mesh_gen.cpp:607-613
+		sine_k_t sk;
+		float const msx = mesh_scale*DX_VAL_INV, msy = mesh_scale*DY_VAL_INV, ms2 = (float)(0.5*(double)mesh_scale);
+		for (int k = 0; k < F_TABLE_SIZE; ++k) {
+			float const x_mult = msx*sinTable[k][4], y_mult = msy*sinTable[k][3];
+			sk.yscale[k] = mesh_scale_z_inv*sinTable[k][0];
+			sk.xconst[k] = ms2*sinTable[k][4] + sinTable[k][2] + x_mult*mx0;
+			sk.yconst[k] = ms2*sinTable[k][3] + sinTable[k][1] + y_mult*my0;
+			sk.xmdx[k] = x_mult*dx; sk.ymdy[k] = y_mult*dy;
+		}
+		return sk;
+	}
+
+	// build_arrays + [enable_glaciate] + eval_index over the whole grid, device resident, async
+	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out) {
+		require_scene();
+		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
+		grid_job_t job;
+		job.mx0 = dx*x0; job.my0 = dy*y0; job.mdx = dx; job.mdy = dy; job.nx = nx; job.ny = ny;
+		job.nxp = round_up(nx, 128); job.nyp = round_up(ny, 128);
+		bool const force_sine = (flags & TERRA_GEN_FORCE_SINE) != 0;
+		job.mode = force_sine ? (int)MGEN_SINE : mode; job.shape = force_sine ? 0 : shape;
+		job.kstart = imax(start_eval_sin, min_start_sin);
+		job.glaciate = (flags & TERRA_GEN_GLACIATE) ? 1 : 0;
+		job.use_sine_mag = (job.glaciate && hp.sine_mag > 0.0f) ? 1 : 0;
+		job.sine_offset = hp.sine_bias*mesh_scale_z_inv;
+		noise_consts_t const nc = consts();
+		sin_lut_t const L = lut();
+		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
+		if (job.use_sine_mag) { // enable_glaciate (src/mesh_gen.cpp:640-650)
+			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
+			float const mx0 = job.mx0, my0 = job.my0, mdx = dx, mdy = dy;
+			be.launch((size_t)nx + ny, [=] TERRA_LAMBDA (size_t i) {
+				if (i < nx) {smx[i] = sm_scale*L.COSF(((float)(unsigned)i*mdx + mx0)*dxi*freq);}
+				else {unsigned const y = (unsigned)(i - nx); smy[y] = L.COSF(((float)y*mdy + my0)*dyi*freq);}
+			});
+		}
+		if (job.mode == MGEN_SINE) {
+			sine_k_t const h_sk = make_sine_k(job.mx0, job.my0, dx, dy);
+			sine_k_t *d_skp = scratch<sine_k_t>(s_sk, 1); // per-k constants live in device memory: a by-value kernel argument indexed per lane would be spilled to scratch
+			be.h2d(d_skp, &h_sk, sizeof(h_sk));
+			float *xt = scratch<float>(s_xt, (size_t)F_TABLE_SIZE*job.nxp), *yt = scratch<float>(s_yt, (size_t)F_TABLE_SIZE*job.nyp);
+			uint32_t const nxp = job.nxp, nyp = job.nyp;
+			// tables, k-major: xt[k*nxp + x] = SINF(xmdx*x + x_const), yt[k*nyp + y] = y_scale*SINF(ymdy*y + y_const); zero padding
+			be.launch((size_t)F_TABLE_SIZE*(nxp + nyp), [=] TERRA_LAMBDA (size_t i) {
+				if (i < (size_t)F_TABLE_SIZE*nxp) {
+					unsigned const k = (unsigned)(i / nxp), x = (unsigned)(i % nxp);
+					xt[i] = (x < nx) ? L.SINF(d_skp->xmdx[k]*(float)x + d_skp->xconst[k]) : 0.0f;
+				}
+				else {
+					size_t const j = i - (size_t)F_TABLE_SIZE*nxp;
+					unsigned const k = (unsigned)(j / nyp), y = (unsigned)(j % nyp);
+					yt[j] = (y < ny) ? d_skp->yscale[k]*L.SINF(d_skp->ymdy[k]*(float)y + d_skp->yconst[k]) : 0.0f;
+				}
+			});
+			be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out);
+		}
+		else {be.noise_grid(job, nc, L, smx, smy, d_out);}
+	}
+
+	// ================================================================ reductions / quantise (a12, K10)
+	void minmax_dev(float const *d_vals, size_t n, float &mn, float &mx) { // min_eq/max_eq folds (std::min/std::max): NaNs never win a comparison
+		uint32_t *d = scratch<uint32_t>(s_misc, 2);
+		uint32_t const init[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+		be.h2d(d, init, sizeof(init));
+		size_t const chunk = 2048, nchunks = (n + chunk - 1)/chunk;
+		be.launch(nchunks, [=] TERRA_LAMBDA (size_t c) {
+			size_t const b = c*chunk, e = (b + chunk < n) ? b + chunk : n;
+			bool have = false; float lo = 0, hi = 0;
+			for (size_t i = b; i < e; ++i) {
+				float const v = d_vals[i];
+				if (v != v) continue;
+				if (!have) {lo = hi = v; have = true;}
+				lo = min_std(lo, v); hi = max_std(hi, v);
+			}
+			if (have) {TERRA_ATOMIC_MIN(&d[0], f2ord(lo)); TERRA_ATOMIC_MIN(&d[1], ~f2ord(hi));} // max as min of the complement
+		});
+		uint32_t out[2];
+		be.d2h(out, d, sizeof(out));
+		mn = ord2f(out[0]); mx = ord2f(~out[1]);
+	}
+	// heightmap_t::from_floats + write_pixel_16_bits (src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893) with the scale of
+	// set_mesh_height_scales_for_zval_range(min_z, dz/255) (src/mesh_gen.cpp:125-131)
+	void quantize16_dev(float const *d_vals, size_t n, float min_z, float dz, uint8_t *d_pix) {
+		float const READ_MESH_H_SCALE = 0.0008f;
+		float const dzs = (float)((double)dz/255.0);
+		float const file_scale = dzs/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv), file_tz = min_z/mesh_scale_z_inv;
+		float const mult = READ_MESH_H_SCALE*mesh_height_scale*file_scale*mesh_scale_z_inv, add = file_tz*mesh_scale_z_inv;
+		float const val_div = (float)(1.0/(double)mult), val_add = add;
+		be.launch(n, [=] TERRA_LAMBDA (size_t i) {
+			float const v = (d_vals[i] - val_add)*val_div;
+			uint8_t const hi = (uint8_t)v;
+			d_pix[(i<<1)+1] = hi;
+			d_pix[i<<1]     = (uint8_t)(256.0f*(v - (float)hi));
+		});
+	}
+
+	// ================================================================ erosion (a11)
+	erosion_consts_t make_erosion_consts(int xsize, int ysize, float min_zval) const {
+		erosion_consts_t ec;
+		ec.xsize = xsize; ec.ysize = ysize; ec.NX = xsize + 2*EROSION_PAD; ec.NY = ysize + 2*EROSION_PAD;
+		ec.max_path_len = 4u*(unsigned)ec.NX*(unsigned)ec.NY;
+		ec.erode_amount = erode_amount; ec.water_thresh = water_plane_z - HALF_DXY;
+		ec.relh_adj_tex = relh_adj_tex; ec.zmin = zmin; ec.zrange = zmax - zmin; ec.clip_hd1 = clip_hd1; ec.two_pi = two_pi; ec.min_zval = min_zval;
+		return ec;
+	}
+
+	struct spec_cfg_t {uint32_t window = 4096, cap_log2 = 11, maxb = 256, bshift = 3, max_rounds = 100000;} spec_cfg;
+
+	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
+		require_scene();
+		report = terra_erosion_report{};
+		if (num_iters == 0 || erode_amount <= 0.0f) return; // erosion disabled (src/erosion.cpp:16)
+		if (xsize <= 0 || ysize <= 0 || (uint64_t)(xsize + 8)*(uint64_t)(ysize + 8) >= (1ull << 30)) throw std::invalid_argument("apply_erosion: bad grid size");
+		erosion_consts_t const ec = make_erosion_consts(xsize, ysize, min_zval);
+		grid_view_t g;
+		g.interior = d_hmap; g.xsize = xsize; g.ysize = ysize; g.NX = ec.NX; g.NY = ec.NY;
+		size_t const nborder = grid_view_t::border_floats(xsize, ysize);
+		g.border = scratch<float>(s_border, nborder);
+		be.launch(nborder, [=] TERRA_LAMBDA (size_t i) {border_init_body(g, i);});
+		report.droplets = num_iters;
+
+		if (flags & TERRA_ERODE_SERIAL) {
+			be.launch(1, [=] TERRA_LAMBDA (size_t) {
+				direct_mem_t m{g};
+				for (uint32_t it = 0; it < num_iters; ++it) {simulate_droplet((int)it, m, ec);}
+			}, 64);
+			report.windows = 1; report.serial_fallbacks = num_iters;
+		}
+		else {speculative_erosion(g, ec, num_iters);}
+		// remove padding and clamp to min_zval (src/erosion.cpp:158-162): in place, so only the clamp remains
+		size_t const n = (size_t)xsize*ysize;
+		be.launch((n + 3)/4, [=] TERRA_LAMBDA (size_t q) {
+			size_t const b = q*4, e = (b + 4 < n) ? b + 4 : n;
+			for (size_t i = b; i < e; ++i) {d_hmap[i] = max_std(min_zval, d_hmap[i]);}
+		});
+	}
+
+	void speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters) {
+		spec_buffers_t sb{};
+		sb.grid = g; sb.ec = ec;
+		uint32_t const Wmax = std::min<uint32_t>(spec_cfg.window, num_iters);
+		sb.cap_log2 = spec_cfg.cap_log2; sb.maxb = spec_cfg.maxb; sb.bshift = spec_cfg.bshift;
+		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
+		size_t const cap = (size_t)1 << sb.cap_log2, nblocks = (size_t)sb.nbx*sb.nby;
+		// carve one allocation
+		size_t off = 0;
+		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
+		size_t o_keys[2], o_vals[2], o_bl[2], o_bc[2], o_chk[2];
+		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(Wmax*cap*4); o_vals[b] = carve(Wmax*cap*4); o_bl[b] = carve((size_t)Wmax*sb.maxb*4); o_bc[b] = carve(Wmax*4); o_chk[b] = carve(Wmax*8);}
+		size_t const o_cur = carve(Wmax*4), o_need = carve(Wmax*4), o_chg = carve(Wmax*4), o_flags = carve(Wmax*4), o_nsteps = carve(Wmax*4);
+		size_t const o_head = carve(nblocks*4), o_next = carve((size_t)Wmax*sb.maxb*4), o_dirty = carve(nblocks*4), o_cnt = carve(64);
+		uint8_t *base = scratch<uint8_t>(s_spec, off);
+		for (int b = 0; b < 2; ++b) {
+			sb.log_keys[b] = (uint32_t *)(base + o_keys[b]); sb.log_vals[b] = (float *)(base + o_vals[b]);
+			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]); sb.chk[b] = (uint64_t *)(base + o_chk[b]);
+		}
+		sb.cur = (uint32_t *)(base + o_cur); sb.need = (uint32_t *)(base + o_need); sb.changed = (uint32_t *)(base + o_chg);
+		sb.flags = (uint32_t *)(base + o_flags); sb.nsteps = (uint32_t *)(base + o_nsteps);
+		sb.head = (uint32_t *)(base + o_head); sb.next = (uint32_t *)(base + o_next); sb.dirty_min = (uint32_t *)(base + o_dirty); sb.counters = (uint32_t *)(base + o_cnt);
+
+		std::vector<uint32_t> h_nsteps, h_flags;
+		uint32_t done = 0;
+		while (done < num_iters) {
+			uint32_t const W = std::min<uint32_t>(Wmax, num_iters - done);
+			sb.first_iter = done; sb.W = W; sb.cut = W; sb.use_lists = 0;
+			++report.windows;
+			be.fill32(sb.cur, 0, W); be.fill32(sb.need, 1, W); be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
+			be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks); be.fill32(sb.head, SPEC_NIL, nblocks);
+			bool first = true;
+			for (uint32_t round = 0; round < spec_cfg.max_rounds; ++round, first = false) {
+				++report.rounds;
+				uint32_t const hc_init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
+				be.h2d(sb.counters, hc_init, sizeof(hc_init));
+				spec_buffers_t const s = sb;
+				if (first) {be.fill32(sb.log_keys[1], SPEC_EMPTY, (size_t)W*cap);} // all droplets trace into buffer 1 - cur = 1
+				else {be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});}
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_trace_body(s, (uint32_t)i);}, 64);
+				uint32_t hc[4];
+				be.d2h(hc, sb.counters, sizeof(hc));
+				report.traces += hc[2]; report.traced_steps += hc[3];
+				if (hc[1] < sb.cut) { // a droplet overflowed its log / block list: cut the window there
+					sb.cut = hc[1];
+				}
+				spec_buffers_t const s2 = sb; // cut may have changed
+				bool const fr = first;
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s2, (uint32_t)i, fr);});
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s2, (uint32_t)i);});
+				be.fill32(sb.head, SPEC_NIL, nblocks);
+				be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s2, (uint32_t)(i / s2.maxb), (uint32_t)(i % s2.maxb));});
+				uint32_t const zero = 0;
+				be.h2d(sb.counters, &zero, 4);
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s2, (uint32_t)i);});
+				be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks);
+				uint32_t nneed = 0;
+				be.d2h(&nneed, sb.counters, 4);
+				sb.use_lists = 1;
+				if (nneed == 0) break;
+			}
+			// flush committed droplets [0, cut)
+			if (sb.cut > 0) {
+				spec_buffers_t const s = sb;
+				be.launch((size_t)sb.cut*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)), false);});
+				h_nsteps.resize(sb.cut); h_flags.resize(sb.cut);
+				be.d2h(h_nsteps.data(), sb.nsteps, sb.cut*4); be.d2h(h_flags.data(), sb.flags, sb.cut*4);
+				for (uint32_t i = 0; i < sb.cut; ++i) {report.steps += h_nsteps[i]; report.nan_droplets += (h_flags[i] & SPEC_F_NAN) ? 1 : 0;}
+			}
+			done += sb.cut;
+			if (sb.cut < W) { // the overflowed droplet runs alone, directly on the grid (it is now the lowest uncommitted droplet)
+				uint32_t const it = done;
+				grid_view_t const gg = g; erosion_consts_t const ee = ec;
+				be.launch(1, [=] TERRA_LAMBDA (size_t) {direct_mem_t m{gg}; simulate_droplet((int)it, m, ee);}, 64);
+				++report.serial_fallbacks;
+				++done;
+			}
+		}
+	}
+
+	// ================================================================ tiles (a10, a13, K6, K7)
+	void tiles_create_zvals_dev(int32_t const *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
+		require_scene();
+		if (n == 0) return;
+		uint32_t const size = 128, stride = 129, zv = 130;
+		// a tile's X table depends only on its tile x, its Y table only on its tile y: build each distinct one once
+		std::vector<int32_t> ux, uy;
+		for (uint32_t i = 0; i < n; ++i) {ux.push_back(tile_xy[2*i]); uy.push_back(tile_xy[2*i+1]);}
+		std::sort(ux.begin(), ux.end()); ux.erase(std::unique(ux.begin(), ux.end()), ux.end());
+		std::sort(uy.begin(), uy.end()); uy.erase(std::unique(uy.begin(), uy.end()), uy.end());
+		typedef tile_ref_pod_t tile_ref_t;
+		std::vector<tile_ref_t> refs(n);
+		for (uint32_t i = 0; i < n; ++i) {
+			refs[i].tx = tile_xy[2*i]; refs[i].ty = tile_xy[2*i+1];
+			refs[i].xi = (uint32_t)(std::lower_bound(ux.begin(), ux.end(), refs[i].tx) - ux.begin());
+			refs[i].yi = (uint32_t)(std::lower_bound(uy.begin(), uy.end(), refs[i].ty) - uy.begin());
+		}
+		uint32_t const nux = (uint32_t)ux.size(), nuy = (uint32_t)uy.size();
+		size_t const tab_floats = (size_t)(nux + nuy)*F_TABLE_SIZE*zv, sm_floats = (size_t)(nux + nuy)*zv;
+		size_t const bytes = refs.size()*sizeof(tile_ref_t) + (nux + nuy)*sizeof(sine_k_t) + (tab_floats + sm_floats)*4 + 1024;
+		uint8_t *base = scratch<uint8_t>(s_tiles, bytes);
+		tile_ref_t *d_refs = (tile_ref_t *)base;
+		sine_k_t *d_sk = (sine_k_t *)(base + ((refs.size()*sizeof(tile_ref_t) + 255) & ~(size_t)255));
+		float *d_tab = (float *)((uint8_t *)d_sk + (((nux + nuy)*sizeof(sine_k_t) + 255) & ~(size_t)255));
+		float *d_sm = d_tab + tab_floats;
+		be.h2d(d_refs, refs.data(), refs.size()*sizeof(tile_ref_t));
+		// per distinct tx / ty: build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, 130, 130) (src/tiled_mesh.cpp:458-464)
+		std::vector<sine_k_t> sks(nux + nuy);
+		std::vector<float> h_m0(nux + nuy);
+		for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)(ux[i]*(int)size - cfg.mesh_x/2); h_m0[i] = DX_VAL*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, DX_VAL, DY_VAL);}
+		for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)(uy[i]*(int)size - cfg.mesh_y/2); h_m0[nux+i] = DY_VAL*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], DX_VAL, DY_VAL);}
+		be.h2d(d_sk, sks.data(), sks.size()*sizeof(sine_k_t));
+		float *d_m0 = scratch<float>(s_misc, nux + nuy + 16);
+		be.h2d(d_m0, h_m0.data(), h_m0.size()*4);
+		noise_consts_t const nc = consts();
+		sin_lut_t const L = lut();
+		int const md = mode, shp = shape, kstart = start_eval_sin;
+		bool const use_sm = (hp.sine_mag > 0.0f);
+		float const dxv = DX_VAL, dyv = DY_VAL, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
+		if (use_sm) { // enable_glaciate per distinct tx / ty
+			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq;
+			be.launch((size_t)(nux + nuy)*zv, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const u = (unsigned)(i / zv), c = (unsigned)(i % zv);
+				if (u < nux) {d_sm[i] = sm_scale*L.COSF(((float)c*dxv + d_m0[u])*dxi*freq);}
+				else         {d_sm[i] = L.COSF(((float)c*dyv + d_m0[u])*dyi*freq);}
+			});
+		}
+		if (md == MGEN_SINE) { // tables [u][k][c]
+			be.launch(tab_floats, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const c = (unsigned)(i % zv), k = (unsigned)((i / zv) % F_TABLE_SIZE), u = (unsigned)(i / ((size_t)zv*F_TABLE_SIZE));
+				sine_k_t const &sk = d_sk[u];
+				d_tab[i] = (u < nux) ? L.SINF(sk.xmdx[k]*(float)c + sk.xconst[k]) : sk.yscale[k]*L.SINF(sk.ymdy[k]*(float)c + sk.yconst[k]);
+			});
+		}
+		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
+		be.tile_grid(n, d_refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_zvals);
+		// erosion: every tile alone on its clamp-padded 138x138 copy, droplets in order (src/tiled_mesh.cpp:515)
+		if (iters_tt > 0 && erode_amount > 0.0f) {
+			erosion_consts_t const ec = make_erosion_consts((int)zv, (int)zv, zmin);
+			be.tile_erosion(n, d_zvals, ec, iters_tt);
+		}
+		// sub-block z ranges + water bbox (src/tiled_mesh.cpp:517-541)
+		if (d_stats) {
+			float const wpz_max = get_max_sea_level();
+			float const rad_c = (dxv*dxv + dyv*dyv)*size*size;
+			be.launch((size_t)n*16, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i >> 4), sbk = (unsigned)(i & 15), yy = sbk >> 2, xx = sbk & 3, bs = zv/4;
+				float const *z = d_zvals + (size_t)t*zv*zv;
+				float szmin = 100.0f, szmax = -100.0f; // FAR_DISTANCE (src/3DWorld.h:116)
+				for (unsigned y = yy*bs; y <= (yy+1)*bs; ++y) {
+					for (unsigned x = xx*bs; x <= (xx+1)*bs; ++x) {float const v = z[y*zv + x]; szmin = min_std(szmin, v); szmax = max_std(szmax, v);}
+				}
+				d_stats[t].sub_zmin[sbk] = szmin; d_stats[t].sub_zmax[sbk] = szmax;
+			});
+			be.launch(n, [=] TERRA_LAMBDA (size_t t) {
+				tile_ref_t const r = d_refs[t];
+				int const x1 = r.tx*(int)size, y1 = r.ty*(int)size;
+				float const *z = d_zvals + (size_t)t*zv*zv;
+				terra_tile_stats &st = d_stats[t];
+				float mzmin = 100.0f, mzmax = -100.0f;
+				for (int sbk = 0; sbk < 16; ++sbk) {mzmin = min_std(mzmin, st.sub_zmin[sbk]); mzmax = max_std(mzmax, st.sub_zmax[sbk]);}
+				int wx1 = x1 + (int)size, wy1 = y1 + (int)size, wx2 = x1, wy2 = y1;
+				unsigned const lim = 4*(zv/4); // cells 0..128 are visited by the 4x4 blocks; row/column 129 is skipped
+				for (unsigned y = 0; y <= lim; ++y) {
+					for (unsigned x = 0; x <= lim; ++x) {
+						if (z[y*zv + x] < wpz_max) {wx1 = imin(wx1, x1+(int)x); wy1 = imin(wy1, y1+(int)y); wx2 = imax(wx2, x1+(int)x); wy2 = imax(wy2, y1+(int)y);}
+					}
+				}
+				st.mzmin = mzmin; st.mzmax = mzmax;
+				st.radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
+				st.wx1 = wx1; st.wy1 = wy1; st.wx2 = wx2; st.wy2 = wy2;
+			});
+		}
+		// normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880)
+		if (d_normals) {
+			uint32_t *d_mnz = (uint32_t *)d_min_nz;
+			if (d_mnz) {be.fill32(d_mnz, 0x3F800000u /*1.0f*/, n);}
+			float const dxy = dxdy;
+			be.launch((size_t)n*stride*stride, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i / (stride*stride)), p = (unsigned)(i % (stride*stride)), y = p / stride, x = p % stride;
+				float const *z = d_zvals + (size_t)t*zv*zv;
+				unsigned const ix2 = y*zv + x;
+				float nv[3] = {dyv*(z[ix2] - z[ix2 + 1]), dxv*(z[ix2] - z[ix2 + zv]), dxy};
+				float const mag = sqrtf(nv[0]*nv[0] + nv[1]*nv[1] + nv[2]*nv[2]);
+				if (!(mag < 1.0E-12f)) {nv[0] /= mag; nv[1] /= mag; nv[2] /= mag;} // pointT::get_norm (src/3DWorld.h:297-300), TOLERANCE (:50)
+				uint8_t *o = d_normals + i*4;
+				o[0] = (uint8_t)(127.0*((double)nv[0] + 1.0)); o[1] = (uint8_t)(127.0*((double)nv[1] + 1.0)); o[2] = (uint8_t)(127.0*((double)nv[2] + 1.0)); o[3] = 0;
+				if (d_mnz && nv[2] < 1.0f) { // min_normal_z = min(min_normal_z, norm.z), seeded with 1.0; norm.z = dxdy/mag >= 0 so uint order == float order; NaN never wins
+					uint32_t u; memcpy(&u, &nv[2], 4);
+					TERRA_ATOMIC_MIN(&d_mnz[t], u);
+				}
+			});
+		}
+	}
+
+	// ================================================================ voxels (a14, a15, K8, K9)
+	void voxel_fill_dev(float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, float const lo[3], float const vsz[3], float const off[3],
+		float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize)
+	{
+		require_scene();
+		if (nx == 0 || ny == 0 || nz == 0) throw std::invalid_argument("voxel_fill: empty grid");
+		size_t const nvox = (size_t)nx*ny*nz;
+		sin_lut_t const L = lut();
+		if (gen_mode == MGEN_SINE) {
+			// noise_gen_3d::gen_sines (src/upsurface.cpp:16-38) on the host: 420 floats
+			std::vector<float> rdata(VOX_SINES*VOX_PARAMS);
+			rand_gen_t r; r.set_state(rs1, rs2);
+			float m = mag, f = freq;
+			for (unsigned i = 0; i < 5; ++i) {
+				for (unsigned j = 0; j < 12; ++j) {
+					float *p = &rdata[VOX_PARAMS*(12*i + j)];
+					p[0] = r.rand_uniform(0.2f, 1.0f)*m;
+					p[1] = r.rand_uniform(0.1f, 1.0f)*f; p[2] = (float)(r.randd()*(double)two_pi);
+					p[3] = r.rand_uniform(0.1f, 1.0f)*f; p[4] = (float)(r.randd()*(double)two_pi);
+					p[5] = r.rand_uniform(0.1f, 1.0f)*f; p[6] = (float)(r.randd()*(double)two_pi);
+				}
+				m *= 0.5f; f /= 0.4f; // M_ATTEN_FACTOR, F_ATTEN_FACTOR (src/upsurface.cpp:10-11)
+			}
+			// gen_xyz_vals (src/upsurface.cpp:41-57): val accumulates `val += step` sequentially, so positions are prefix sums computed on the host
+			uint32_t const dims[3] = {nx, ny, nz};
+			std::vector<float> pos((size_t)nx + ny + nz);
+			size_t o = 0;
+			for (unsigned d = 0; d < 3; ++d) {float val = lo[d] + off[d]; for (uint32_t i = 0; i < dims[d]; ++i) {pos[o++] = val; val += vsz[d];}}
+			size_t const ntab = ((size_t)nx + ny + nz)*VOX_SINES;
+			float *d_base = scratch<float>(s_vox, ntab + pos.size() + rdata.size() + 64);
+			float *d_tab = d_base, *d_pos = d_base + ntab, *d_rd = d_pos + pos.size();
+			be.h2d(d_pos, pos.data(), pos.size()*4); be.h2d(d_rd, rdata.data(), rdata.size()*4);
+			be.launch(ntab, [=] TERRA_LAMBDA (size_t i) {
+				size_t const e = i / VOX_SINES; unsigned const k = (unsigned)(i % VOX_SINES);
+				unsigned const d = (e < nx) ? 0u : ((e < (size_t)nx + ny) ? 1u : 2u);
+				unsigned const index2 = VOX_PARAMS*k + 2*d;
+				float v = L.SINF(d_rd[index2+1]*d_pos[e] + d_rd[index2+2]);
+				if (d == 0) {v *= d_rd[index2];}
+				d_tab[i] = v;
+			});
+			be.voxel_sines(d_out, nx, ny, nz, d_tab, zscale, normalize);
+		}
+		else {
+			float const l0 = lo[0], l1 = lo[1], l2 = lo[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2], o0 = off[0], o1 = off[1], o2 = off[2];
+			float const frx = rx, fry = ry;
+			int const nn = imax(1, 5 - cfg.mesh_freq_filter); // MAX_FREQ_BINS - mesh_freq_filter (src/voxels.cpp:332)
+			bool const perlin = (gen_mode == MGEN_PERLIN);
+			be.launch(nvox, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const z = (unsigned)(i % nz), x = (unsigned)((i / nz) % nx), y = (unsigned)(i / ((size_t)nz*nx));
+				float const px = ((float)x*v0 + l0) + o0, py = ((float)y*v1 + l1) + o1, pz = ((float)z*v2 + l2) + o2; // get_pt_at (src/voxels.h:146) + offset
+				float val = 0.0f, nmag = mag, nfreq = (float)(0.25*(double)freq);
+				for (int n = 0; n < nn; ++n) {
+					float const ax = nfreq*px + frx, ay = nfreq*py + fry, az = nfreq*pz + (frx - fry);
+					val += nmag*(perlin ? perlin3(ax, ay, az) : simplex3(ax, ay, az));
+					nmag *= 0.5f; nfreq *= 1.92f;
+				}
+				val += (float)z*zscale;
+				if (normalize) {val = clip_pm1(val);}
+				d_out[i] = val;
+			});
+		}
+	}
+};
+
+} // namespace terra

@@ -1,0 +1,151 @@
+// terra_kernels.hpp -- hand-written gfx950 kernels for the hot loops (device only; included by terra_hip.hip).
+//
+//   k_sine_grid     K1+K4: z = sum_k X[x][k]*Y[y][k] as an LDS-tiled rank-90 outer-product contraction + fused
+//                   shape/glaciate/island epilogue (mesh_xy_grid_cache_t::eval_index, src/mesh_gen.cpp:766-790)
+//   k_noise_grid    K2/K3: per-cell simplex/Perlin fBm and domain warp (get_noise_zval, src/mesh_gen.cpp:734-751)
+//   k_tile_erosion  K5 (tile mode): one wave per tile, the clamp-padded 138x138 grid resident in LDS, droplets in serial order
+//   k_voxel_sines   K8: rank-60 3-D sine field, z-fastest output (noise_gen_3d::get_val, src/upsurface.cpp:60-70)
+//
+// No MFMA: the sums must round exactly like the CPU's mul-then-add chain (an MFMA/fma chain rounds once per term).
+// Wave = 64 lanes; block sizes are multiples of 64; LDS tiles are read with 16-byte ds_read_b128 and broadcast.
+#pragma once
+#include "terra_driver.hpp"
+
+namespace terra {
+
+template<class F> __global__ void k_generic(size_t n, F f) {
+	size_t const i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i < n) {f(i);}
+}
+
+// ------------------------------------------------------------------ K1: sine-sum grid
+constexpr int SG_BX = 128, SG_BY = 64, SG_TX = 8, SG_TY = 4, SG_THREADS = 256; // 16 x 16 threads, 8 x 4 cells each
+constexpr int SG_ROWGROUP = 4; // tile rows walked together so an X tile is reused from L2 before moving on
+
+// XCD-aware tile order: the dispatcher places block b on XCD b % 8 (observed, speed only); give every XCD one contiguous
+// band of tile rows so its private L2 keeps that band's Y tiles, and walk the band in groups of SG_ROWGROUP rows.
+__device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsigned nty, unsigned &bx, unsigned &by) {
+	unsigned const nb = ntx*nty, per_xcd = (nb + 7)/8;
+	unsigned const lin = (b & 7)*per_xcd + (b >> 3); // position in the global tile order
+	if (lin >= nb) return false;
+	unsigned const group = lin/(SG_ROWGROUP*ntx), r = lin % (SG_ROWGROUP*ntx);
+	unsigned const rows_here = (nty - group*SG_ROWGROUP < (unsigned)SG_ROWGROUP) ? nty - group*SG_ROWGROUP : SG_ROWGROUP;
+	bx = r/rows_here; by = group*SG_ROWGROUP + r % rows_here;
+	if (bx >= ntx) { // only in a short last group: remaining slots are unused
+		return false;
+	}
+	return true;
+}
+
+__global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
+	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty)
+{
+	extern __shared__ __attribute__((aligned(16))) float sg_lds[];
+	unsigned bxi, byi;
+	if (!sg_tile_of_block(blockIdx.x, ntx, nty, bxi, byi)) return;
+	int const nk = F_TABLE_SIZE - job.kstart;
+	float *sX = sg_lds, *sY = sg_lds + nk*SG_BX;
+	unsigned const tid = threadIdx.x, bx0 = bxi*SG_BX, by0 = byi*SG_BY;
+	// stage the tile's table slices: rows kstart..89 of xt (SG_BX wide) and yt (SG_BY wide); tables are zero-padded to 128
+	for (int idx = tid; idx < nk*(SG_BX/4); idx += SG_THREADS) {
+		int const k = idx/(SG_BX/4), c = idx % (SG_BX/4);
+		*(float4 *)&sX[k*SG_BX + c*4] = *(float4 const *)&xt[(size_t)(job.kstart + k)*job.nxp + bx0 + c*4];
+	}
+	for (int idx = tid; idx < nk*(SG_BY/4); idx += SG_THREADS) {
+		int const k = idx/(SG_BY/4), c = idx % (SG_BY/4);
+		*(float4 *)&sY[k*SG_BY + c*4] = *(float4 const *)&yt[(size_t)(job.kstart + k)*job.nyp + by0 + c*4];
+	}
+	__syncthreads();
+	unsigned const tx = tid & 15, ty = tid >> 4;
+	float acc[SG_TY][SG_TX];
+#pragma unroll
+	for (int i = 0; i < SG_TY; ++i) {
+#pragma unroll
+		for (int j = 0; j < SG_TX; ++j) {acc[i][j] = 0.0f;}
+	}
+	// thread (tx,ty) owns columns {tx*4..tx*4+3} and {64+tx*4..} and rows ty*4..ty*4+3: every LDS read is one aligned ds_read_b128
+	float const *px = sX + tx*4, *py = sY + ty*4;
+#pragma unroll 2
+	for (int k = 0; k < nk; ++k) {
+		float4 const xa = *(float4 const *)(px + k*SG_BX), xb = *(float4 const *)(px + k*SG_BX + 64), ya = *(float4 const *)(py + k*SG_BY);
+		float const xs[SG_TX] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, ys[SG_TY] = {ya.x, ya.y, ya.z, ya.w};
+#pragma unroll
+		for (int i = 0; i < SG_TY; ++i) {
+#pragma unroll
+			for (int j = 0; j < SG_TX; ++j) {acc[i][j] = __fadd_rn(acc[i][j], __fmul_rn(xs[j], ys[i]));} // zval += xptr[k]*yptr[k]: product rounded, then added
+		}
+	}
+	bool const vec_ok = ((job.nx & 3u) == 0);
+#pragma unroll
+	for (int i = 0; i < SG_TY; ++i) {
+		unsigned const y = by0 + ty*4 + i;
+		if (y >= job.ny) continue;
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			unsigned const x = bx0 + half*64 + tx*4;
+			if (x >= job.nx) continue;
+			float v[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {v[j] = (x + j < job.nx) ? finish_cell(acc[i][half*4 + j], job, nc, L, smx, smy, x + j, y) : 0.0f;}
+			float *o = out + (size_t)y*job.nx + x;
+			if (vec_ok) {*(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);}
+			else {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {if (x + j < job.nx) o[j] = v[j];}
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------ K2/K3: fBm / domain-warp grid, one cell per thread, x fastest
+template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out) {
+	unsigned const x = blockIdx.x*64 + (threadIdx.x & 63), y = blockIdx.y*4 + (threadIdx.x >> 6);
+	if (x >= job.nx || y >= job.ny) return;
+	float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+	float const z = noise_zval<MODE>(xval, yval, job.shape, nc);
+	out[(size_t)y*job.nx + x] = finish_cell(z, job, nc, L, smx, smy, x, y);
+}
+
+// ------------------------------------------------------------------ K5 tile mode: LDS-resident padded grid, serial droplets
+__global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters) {
+	extern __shared__ __attribute__((aligned(16))) float te_pad[];
+	int const NX = ec.NX, NY = ec.NY, xs = ec.xsize, ys = ec.ysize;
+	float *z = zvals + (size_t)blockIdx.x*xs*ys;
+	for (int i = threadIdx.x; i < NX*NY; i += 64) { // clamp-padded copy (src/erosion.cpp:31-37), coalesced rows
+		int const X = i % NX, Z = i / NX;
+		te_pad[i] = z[(size_t)imax(imin(Z - EROSION_PAD, ys-1), 0)*xs + imax(imin(X - EROSION_PAD, xs-1), 0)];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { // droplet order is the semantics: one lane walks them; LDS latency (not HBM) bounds every step
+		grid_view_t g; g.interior = te_pad; g.border = nullptr; g.xsize = xs; g.ysize = ys; g.NX = NX; g.NY = NY;
+		direct_mem_t m{g};
+		for (uint32_t it = 0; it < iters; ++it) {simulate_droplet((int)it, m, ec);}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < xs*ys; i += 64) { // unpad + clamp (src/erosion.cpp:158-162)
+		int const x = i % xs, y = i / xs;
+		z[i] = max_std(ec.min_zval, te_pad[(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
+	}
+}
+
+// ------------------------------------------------------------------ K8: voxel sine field. One block per (x,y) column pair group; lanes run along z (the fastest output axis)
+// tab = [nx + ny + nz][60]; P[k] = xv[k]*yv[k] is uniform per (x,y): computed once into LDS, then each lane folds its own z row.
+__global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ tab, float zscale, int normalize) {
+	__shared__ float P[VOX_SINES];
+	uint32_t const x = blockIdx.x, y = blockIdx.y;
+	if (threadIdx.x < VOX_SINES) {P[threadIdx.x] = __fmul_rn(tab[(size_t)x*VOX_SINES + threadIdx.x], tab[((size_t)nx + y)*VOX_SINES + threadIdx.x]);}
+	__syncthreads();
+	float const *zt = tab + ((size_t)nx + ny)*VOX_SINES;
+	float *o = out + ((size_t)x + (size_t)y*nx)*nz;
+	for (uint32_t z = threadIdx.x; z < nz; z += blockDim.x) {
+		float const *zv = zt + (size_t)z*VOX_SINES;
+		float val = 0.0f;
+#pragma unroll 4
+		for (unsigned k = 0; k < VOX_SINES; ++k) {val = __fadd_rn(val, __fmul_rn(P[k], zv[k]));} // (xv*yv)*zv, summed in k order
+		val = __fadd_rn(val, __fmul_rn((float)z, zscale));
+		if (normalize) {val = clip_pm1(val);}
+		o[z] = val;
+	}
+}
+
+} // namespace terra

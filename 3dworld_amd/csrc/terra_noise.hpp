@@ -1,0 +1,259 @@
+// terra_noise.hpp -- per-cell evaluators of the heightmap generator (host+device).
+//
+// Replaces the CPU inner loops of mesh_xy_grid_cache_t::eval_index (src/mesh_gen.cpp:754-792):
+//   * 2-D / 3-D simplex and classic Perlin noise as vendored by the reference
+//     (dependencies/glm/glm/gtc/noise.inl, GLM 0.9.9.1) -- same operation order, fp32, no FMA contraction;
+//   * fBm accumulation and domain warp (src/mesh_gen.cpp:706-751);
+//   * noise shaping / plateau-crater-crack post-process (src/mesh_gen.cpp:555-571);
+//   * glaciate cubic remap, sine-mag islands, volcano (src/mesh_gen.cpp:358-385,782-790).
+// One thread evaluates one cell; there is no cross-lane traffic in these functions.
+#pragma once
+#include "terra_common.hpp"
+
+namespace terra {
+
+// ---- GLM scalar helpers (detail/_noise.hpp:14-84, detail/func_common.inl:123-131,211-218,386-398,543-546)
+TERRA_HD float gl_mod289(float x)  {return x - floorf(x*(1.0f/289.0f))*289.0f;}
+TERRA_HD float gl_permute(float x) {return gl_mod289(((x*34.0f) + 1.0f)*x);}
+TERRA_HD float gl_tinvsqrt(float r) {return 1.79284291400159f - 0.85373472095314f*r;}
+TERRA_HD float gl_fade(float t)    {return (t*t*t)*(t*(t*6.0f - 15.0f) + 10.0f);}
+TERRA_HD float gl_mod(float a, float b) {return a - b*floorf(a/b);}
+TERRA_HD float gl_fract(float x)   {return x - floorf(x);}
+TERRA_HD float gl_mix(float x, float y, float a) {return x + a*(y - x);}
+TERRA_HD float gl_step(float edge, float x) {return (x < edge) ? 0.0f : 1.0f;}
+
+// glm::simplex(vec2)  (gtc/noise.inl:592-646)
+TERRA_HD float simplex2(float vx, float vy) {
+	float const C0 = 0.211324865405187f, C1 = 0.366025403784439f, C2 = -0.577350269189626f, C3 = 0.024390243902439f;
+	float const skew = vx*C1 + vy*C1;                       // dot(v, C.yy)
+	float cx = floorf(vx + skew), cy = floorf(vy + skew);   // first corner (skewed cell)
+	float const unskew = cx*C0 + cy*C0;                     // dot(i, C.xx)
+	float const ax = vx - cx + unskew, ay = vy - cy + unskew; // x0
+	bool  const lower = (ax > ay);
+	float const ox = lower ? 1.0f : 0.0f, oy = lower ? 0.0f : 1.0f; // i1
+	float const bx = (ax + C0) - ox, by = (ay + C0) - oy;   // x12.xy
+	float const ex = ax + C2, ey = ay + C2;                 // x12.zw
+	cx = gl_mod(cx, 289.0f); cy = gl_mod(cy, 289.0f);
+	float const pa = gl_permute(gl_permute(cy + 0.0f) + cx + 0.0f);
+	float const pb = gl_permute(gl_permute(cy + oy  ) + cx + ox  );
+	float const pc = gl_permute(gl_permute(cy + 1.0f) + cx + 1.0f);
+	float ma = max_std(0.5f - (ax*ax + ay*ay), 0.0f);
+	float mb = max_std(0.5f - (bx*bx + by*by), 0.0f);
+	float mc = max_std(0.5f - (ex*ex + ey*ey), 0.0f);
+	ma = ma*ma; mb = mb*mb; mc = mc*mc;
+	ma = ma*ma; mb = mb*mb; mc = mc*mc;
+	// gradients: 41 points on a line mapped onto a diamond
+	float const ga = 2.0f*gl_fract(pa*C3) - 1.0f, gb = 2.0f*gl_fract(pb*C3) - 1.0f, gc = 2.0f*gl_fract(pc*C3) - 1.0f;
+	float const ha = fabsf(ga) - 0.5f, hb = fabsf(gb) - 0.5f, hc = fabsf(gc) - 0.5f;
+	float const a0a = ga - floorf(ga + 0.5f), a0b = gb - floorf(gb + 0.5f), a0c = gc - floorf(gc + 0.5f);
+	ma *= 1.79284291400159f - 0.85373472095314f*(a0a*a0a + ha*ha);
+	mb *= 1.79284291400159f - 0.85373472095314f*(a0b*a0b + hb*hb);
+	mc *= 1.79284291400159f - 0.85373472095314f*(a0c*a0c + hc*hc);
+	float const da = a0a*ax + ha*ay;
+	float const db = a0b*bx + hb*by;
+	float const dc = a0c*ex + hc*ey;
+	return 130.0f*(ma*da + mb*db + mc*dc);
+}
+
+// glm::perlin(vec2)  (gtc/noise.inl:25-62)
+TERRA_HD float perlin2(float px, float py) {
+	float const flx = floorf(px), fly = floorf(py);
+	float const frx = px - flx, fry = py - fly;                    // fract
+	float const cx0 = gl_mod(flx + 0.0f, 289.0f), cy0 = gl_mod(fly + 0.0f, 289.0f);
+	float const cx1 = gl_mod(flx + 1.0f, 289.0f), cy1 = gl_mod(fly + 1.0f, 289.0f);
+	float const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
+	// corner order of the vec4 lanes: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+	float gx[4], gy[4];
+	float const cxs[4] = {cx0, cx1, cx0, cx1}, cys[4] = {cy0, cy0, cy1, cy1};
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		float const h = gl_permute(gl_permute(cxs[c]) + cys[c]);
+		float const g = 2.0f*gl_fract(h/41.0f) - 1.0f;
+		gy[c] = fabsf(g) - 0.5f;
+		gx[c] = g - floorf(g + 0.5f);
+	}
+	// norm = taylorInvSqrt(dot(g00), dot(g01), dot(g10), dot(g11)); lanes: g00=0 g10=1 g01=2 g11=3
+	float const n00 = gl_tinvsqrt(gx[0]*gx[0] + gy[0]*gy[0]), n01 = gl_tinvsqrt(gx[2]*gx[2] + gy[2]*gy[2]);
+	float const n10 = gl_tinvsqrt(gx[1]*gx[1] + gy[1]*gy[1]), n11 = gl_tinvsqrt(gx[3]*gx[3] + gy[3]*gy[3]);
+	float const d00 = (gx[0]*n00)*fx0 + (gy[0]*n00)*fy0;
+	float const d10 = (gx[1]*n10)*fx1 + (gy[1]*n10)*fy0;
+	float const d01 = (gx[2]*n01)*fx0 + (gy[2]*n01)*fy1;
+	float const d11 = (gx[3]*n11)*fx1 + (gy[3]*n11)*fy1;
+	float const ux = gl_fade(fx0), uy = gl_fade(fy0);
+	float const lo = gl_mix(d00, d10, ux), hi = gl_mix(d01, d11, ux);
+	return 2.3f*gl_mix(lo, hi, uy);
+}
+
+// glm::perlin(vec3)  (gtc/noise.inl:66-133)
+TERRA_HD float perlin3(float px, float py, float pz) {
+	float const p[3] = {px, py, pz};
+	float c0[3], c1[3], f0[3], f1[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		float const fl = floorf(p[d]);
+		c0[d] = gl_mod289(fl); c1[d] = gl_mod289(fl + 1.0f);
+		f0[d] = p[d] - fl; f1[d] = f0[d] - 1.0f;
+	}
+	float const seventh = (float)(1.0/7.0);
+	float nlo[4], nhi[4]; // dot products at z0 / z1 for lanes (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		float const hx = (c & 1) ? c1[0] : c0[0], hy = (c & 2) ? c1[1] : c0[1];
+		float const hxy = gl_permute(gl_permute(hx) + hy);
+		float const fxc = (c & 1) ? f1[0] : f0[0], fyc = (c & 2) ? f1[1] : f0[1];
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			float const hz = gl_permute(hxy + (s ? c1[2] : c0[2]));
+			float gx = hz*seventh;
+			float gy = gl_fract(floorf(gx)*seventh) - 0.5f;
+			gx = gl_fract(gx);
+			float const gz = 0.5f - fabsf(gx) - fabsf(gy);
+			float const sz = gl_step(gz, 0.0f);
+			gx -= sz*(gl_step(0.0f, gx) - 0.5f);
+			gy -= sz*(gl_step(0.0f, gy) - 0.5f);
+			float const nrm = gl_tinvsqrt(gx*gx + gy*gy + gz*gz);
+			float const d = (gx*nrm)*fxc + (gy*nrm)*fyc + (gz*nrm)*(s ? f1[2] : f0[2]);
+			if (s) {nhi[c] = d;} else {nlo[c] = d;}
+		}
+	}
+	float const ux = gl_fade(f0[0]), uy = gl_fade(f0[1]), uz = gl_fade(f0[2]);
+	float const z0 = gl_mix(nlo[0], nhi[0], uz), z1 = gl_mix(nlo[1], nhi[1], uz), z2 = gl_mix(nlo[2], nhi[2], uz), z3 = gl_mix(nlo[3], nhi[3], uz);
+	float const y0 = gl_mix(z0, z2, uy), y1 = gl_mix(z1, z3, uy);
+	return 2.2f*gl_mix(y0, y1, ux);
+}
+
+// glm::simplex(vec3)  (gtc/noise.inl:649-722)
+TERRA_HD float simplex3(float vx, float vy, float vz) {
+	float const G = (float)(1.0/6.0), F = (float)(1.0/3.0);
+	float const skew = vx*F + vy*F + vz*F;
+	float ci[3] = {floorf(vx + skew), floorf(vy + skew), floorf(vz + skew)};
+	float const unskew = ci[0]*G + ci[1]*G + ci[2]*G;
+	float const a[3] = {vx - ci[0] + unskew, vy - ci[1] + unskew, vz - ci[2] + unskew}; // x0
+	float const g[3] = {gl_step(a[1], a[0]), gl_step(a[2], a[1]), gl_step(a[0], a[2])};  // step(x0.yzx, x0)
+	float const l[3] = {1.0f - g[0], 1.0f - g[1], 1.0f - g[2]};
+	float const o1[3] = {min_std(g[0], l[2]), min_std(g[1], l[0]), min_std(g[2], l[1])}; // i1 = min(g, l.zxy)
+	float const o2[3] = {max_std(g[0], l[2]), max_std(g[1], l[0]), max_std(g[2], l[1])}; // i2 = max(g, l.zxy)
+	float b[3], c[3], e[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {b[d] = a[d] - o1[d] + G; c[d] = a[d] - o2[d] + F; e[d] = a[d] - 0.5f;}
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {ci[d] = gl_mod289(ci[d]);}
+	float const n_ = 0.142857142857f;
+	float const ns0 = n_*2.0f - 0.0f, ns1 = n_*0.5f - 1.0f, ns2 = n_*1.0f - 0.0f;
+	float const offz[4] = {0.0f, o1[2], o2[2], 1.0f}, offy[4] = {0.0f, o1[1], o2[1], 1.0f}, offx[4] = {0.0f, o1[0], o2[0], 1.0f};
+	float qx[4], qy[4], qh[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		float const pm = gl_permute(gl_permute(gl_permute(ci[2] + offz[k]) + ci[1] + offy[k]) + ci[0] + offx[k]);
+		float const j  = pm - 49.0f*floorf(pm*ns2*ns2);
+		float const x_ = floorf(j*ns2);
+		float const y_ = floorf(j - 7.0f*x_);
+		qx[k] = x_*ns0 + ns1;
+		qy[k] = y_*ns0 + ns1;
+		qh[k] = 1.0f - fabsf(qx[k]) - fabsf(qy[k]);
+	}
+	// b0 = (x.xy, y.xy), b1 = (x.zw, y.zw); s = floor(b)*2+1; sh = -step(h,0); a0 = b0.xzyw + s0.xzyw*sh.xxyy; a1 = b1.xzyw + s1.xzyw*sh.zzww
+	float gx[4], gy[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		float const sh = -gl_step(qh[k], 0.0f);
+		gx[k] = qx[k] + (floorf(qx[k])*2.0f + 1.0f)*sh;
+		gy[k] = qy[k] + (floorf(qy[k])*2.0f + 1.0f)*sh;
+	}
+	float const *xs[4] = {a, b, c, e};
+	float w[4], dp[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		float const nrm = gl_tinvsqrt(gx[k]*gx[k] + gy[k]*gy[k] + qh[k]*qh[k]);
+		float const *xk = xs[k];
+		dp[k] = (gx[k]*nrm)*xk[0] + (gy[k]*nrm)*xk[1] + (qh[k]*nrm)*xk[2];
+		float m = max_std(0.6f - (xk[0]*xk[0] + xk[1]*xk[1] + xk[2]*xk[2]), 0.0f);
+		m = m*m;
+		w[k] = m*m;
+	}
+	return 42.0f*((w[0]*dp[0] + w[1]*dp[1]) + (w[2]*dp[2] + w[3]*dp[3]));
+}
+
+// ---- noise shaping (src/mesh_gen.cpp:555-571)
+TERRA_HD float postproc_noise_zval(float z, hmap_params_t const &h) {
+	if (z > h.plat_bot) {z = h.plat_bot + h.plat_h*(z - h.plat_bot) + min_std(h.plat_max, h.plat_s*(z - h.plat_bot));}
+	if (z > h.crat_h  ) {z = h.crat_h - h.crat_s*(z - h.crat_h);}
+	if (z > h.crack_lo && z < h.crack_hi) {z -= h.crack_d*min_std(z - h.crack_lo, h.crack_hi - z);}
+	return z;
+}
+TERRA_HD float apply_noise_shape_final(float n, int shape, hmap_params_t const &h) {
+	if      (shape == 1) {n = (float)((double)fabsf(n) - 2.0);}
+	else if (shape == 2) {n = (float)(3.5 - (double)fabsf(n));}
+	return postproc_noise_zval(n, h);
+}
+
+// ---- fBm (gen_noise, src/mesh_gen.cpp:706-730). SIMPLEX selects glm::simplex vs glm::perlin.
+template<bool SIMPLEX> TERRA_HD float fbm2(float xv, float yv, int shape, unsigned end_octave, float rx, float ry) {
+	float zval = 0.0f, mag = 1.0f, freq = 1.0f;
+	for (unsigned i = 0; i < end_octave; ++i) {
+		float const qx = freq*xv + rx, qy = freq*yv + ry;
+		float n = SIMPLEX ? simplex2(qx, qy) : perlin2(qx, qy);
+		if      (shape == 1) {n = (float)((double)fabsf(n) - 0.40);}
+		else if (shape == 2) {n = (float)(0.45 - (double)fabsf(n));}
+		zval += mag*n;
+		mag  *= 0.5f;
+		freq *= 1.92f;
+		rx   *= 1.5f; // (float)((double)rx*1.5): one correctly rounded product either way
+		ry   *= 1.5f;
+	}
+	return zval;
+}
+
+// get_hmap_scale (src/mesh_gen.cpp:550-553)
+TERRA_HD float hmap_scale(int mode, noise_consts_t const &nc) {
+	float const scale = (mode == MGEN_SIMPLEX || mode == MGEN_SIMPLEX_GPU || mode == MGEN_DWARP_GPU) ? 16.0f : 32.0f;
+	return scale*nc.MESH_HEIGHT*nc.mesh_height_scale*nc.mesh_scale_z_inv;
+}
+
+// get_noise_zval (src/mesh_gen.cpp:734-751). MODE is MGEN_SIMPLEX / MGEN_PERLIN / MGEN_SIMPLEX_GPU / MGEN_DWARP_GPU.
+template<int MODE> TERRA_HD float noise_zval(float xval, float yval, int shape, noise_consts_t const &nc) {
+	constexpr bool SIMPLEX = (MODE != MGEN_PERLIN);
+	float const xy_scale = 0.0007f*nc.mesh_scale; // MESH_SCALE_FACTOR
+	float xv = xy_scale*xval, yv = xy_scale*yval;
+	unsigned const end_octave = NUM_FREQ_COMP - nc.start_eval_sin/N_RAND_SIN2;
+	if (MODE == MGEN_DWARP_GPU) {
+		float const scale = 0.2f;
+		float const dx1 = fbm2<SIMPLEX>((float)((double)xv + 0.0), (float)((double)yv + 0.0), shape, end_octave, nc.rx, nc.ry);
+		float const dy1 = fbm2<SIMPLEX>((float)((double)xv + 5.2), (float)((double)yv + 1.3), shape, end_octave, nc.rx, nc.ry);
+		float const wx = xv + scale*dx1, wy = yv + scale*dy1;
+		float const dx2 = fbm2<SIMPLEX>((float)((double)wx + 1.7), (float)((double)wy + 9.2), shape, end_octave, nc.rx, nc.ry);
+		float const dy2 = fbm2<SIMPLEX>((float)((double)wx + 8.3), (float)((double)wy + 2.8), shape, end_octave, nc.rx, nc.ry);
+		xv += scale*dx2; yv += scale*dy2;
+	}
+	float z = fbm2<SIMPLEX>(xv, yv, shape, end_octave, nc.rx, nc.ry);
+	z = postproc_noise_zval(z, nc.hp);
+	return z*hmap_scale(MODE, nc);
+}
+
+// ---- glaciate + islands + volcano epilogue of eval_index (src/mesh_gen.cpp:358-385,782-790)
+TERRA_HD float glaciate_exp_fn(float v, float custom_exp) {return (custom_exp == 0.0f) ? v*v*v : powf(v, custom_exp);}
+
+TERRA_HD float volcano_height(float xi, float yi, noise_consts_t const &nc, sin_lut_t const &lut) { // src/mesh_gen.cpp:364-371
+	float const freq = nc.mesh_scale/nc.hp.volcano_width, x = freq*xi, y = freq*yi, dist = sqrtf(x*x + y*y);
+	if ((double)dist > 2.0) return 0.0f;
+	float const val = lut.COSF(x)*lut.COSF(y);
+	double const hole_d = 400.0*((double)val - 0.999);
+	float const hole = (float)((0.0 < hole_d) ? hole_d : 0.0);
+	float const peak = (float)(0.08*(double)val/(double)max_std(0.04f, dist));
+	return nc.hp.volcano_height*max_std(0.0f, (peak - hole))*nc.mesh_scale_z_inv;
+}
+
+// smx = sine_mag_terms[x], smy = sine_mag_terms[nx+y] (enable_glaciate, src/mesh_gen.cpp:640-650); xg/yg = eval_index's (x*mdx+mx0)*DX_VAL_INV
+TERRA_HD float glaciate_epilogue(float z, float smx, float smy, float sine_offset, float xg, float yg, noise_consts_t const &nc, sin_lut_t const &lut) {
+	if (nc.glaciate) {
+		float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv;
+		z = glaciate_exp_fn(relh, nc.custom_glaciate_exp)*nc.zmax_est2 - nc.zmax_est;
+	}
+	if (nc.hp.sine_mag > 0.0f) {
+		z += smx*smy + sine_offset;
+		if (nc.hp.volcano_width > 0.0f && nc.hp.volcano_height > 0.0f) {z += volcano_height(xg, yg, nc, lut);}
+	}
+	return z;
+}
+
+} // namespace terra

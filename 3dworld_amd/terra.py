@@ -1,0 +1,306 @@
+"""ctypes bindings for include/terra.h (libterra_hip.so).  Host glue only -- no arithmetic happens in Python."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES = 1, 2, 4, 8
+ERODE_SERIAL, ERODE_MINZ_IS_MIN = 1, 2
+MGEN_SINE, MGEN_SIMPLEX, MGEN_PERLIN, MGEN_SIMPLEX_GPU, MGEN_DWARP_GPU = range(5)
+
+
+class TerraError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"terra error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):  # terra_config
+    _fields_ = [("mesh_x", C.c_int32), ("mesh_y", C.c_int32), ("scene_x", C.c_float), ("scene_y", C.c_float), ("scene_z", C.c_float),
+                ("mesh_height", C.c_float), ("mesh_scale", C.c_float), ("mesh_seed", C.c_int32), ("mesh_freq_filter", C.c_int32),
+                ("mesh_gen_mode", C.c_int32), ("mesh_gen_shape", C.c_int32), ("glaciate", C.c_int32), ("custom_glaciate_exp", C.c_float),
+                ("hmap", C.c_float * 14), ("erode_amount", C.c_float), ("water_h_off", C.c_float), ("water_h_off_rel", C.c_float),
+                ("relh_adj_tex", C.c_float), ("ocean_wave_height", C.c_float),
+                ("start_mag", C.c_float), ("start_freq", C.c_float), ("mag_mult", C.c_float), ("freq_mult", C.c_float)]
+
+
+_STATE_FLOATS = ("MESH_HEIGHT DX_VAL DY_VAL DX_VAL_INV DY_VAL_INV HALF_DXY dxdy XY_SCENE_SIZE mesh_scale mesh_scale_z_inv "
+                 "mesh_height_scale zmax_est zmin zmax water_plane_z glaciate_exp clip_hd1 relh_adj_tex rx ry").split()
+
+
+class State(C.Structure):  # terra_state
+    _fields_ = [("sinTable", (C.c_float * 5) * 90), ("start_eval_sin", C.c_int32)] + [(n, C.c_float) for n in _STATE_FLOATS]
+
+
+class TileStats(C.Structure):  # terra_tile_stats
+    _fields_ = [("sub_zmin", C.c_float * 16), ("sub_zmax", C.c_float * 16), ("mzmin", C.c_float), ("mzmax", C.c_float), ("radius", C.c_float),
+                ("wx1", C.c_int32), ("wy1", C.c_int32), ("wx2", C.c_int32), ("wy2", C.c_int32)]
+
+
+class ErosionReport(C.Structure):  # terra_erosion_report
+    _fields_ = [("droplets", C.c_uint32), ("windows", C.c_uint32), ("rounds", C.c_uint32), ("traces", C.c_uint32),
+                ("serial_fallbacks", C.c_uint32), ("nan_droplets", C.c_uint32), ("steps", C.c_uint64), ("traced_steps", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+HMAP_ISLANDS = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 0, 0]  # hmap_params_t defaults + scene_config/config.txt:76
+
+
+def make_config(mesh_gen_mode=0, mesh_gen_shape=0, mesh_seed=1, mesh_freq_filter=0, hmap=None, glaciate=1, mesh_scale=1.0,
+                mesh_height=0.7, custom_glaciate_exp=0.0, erode_amount=1.0, mesh_xy=128, scene=(4.0, 4.0, 4.0)):
+    """The synthetic scene of BASELINE.md section 3 (scene_config/config.txt:56-97)."""
+    c = Config()
+    c.mesh_x = c.mesh_y = mesh_xy
+    c.scene_x, c.scene_y, c.scene_z = scene
+    c.mesh_height, c.mesh_scale = mesh_height, mesh_scale
+    c.mesh_seed, c.mesh_freq_filter, c.mesh_gen_mode, c.mesh_gen_shape, c.glaciate = mesh_seed, mesh_freq_filter, mesh_gen_mode, mesh_gen_shape, glaciate
+    c.custom_glaciate_exp = custom_glaciate_exp
+    for i, v in enumerate(HMAP_ISLANDS if hmap is None else hmap):
+        c.hmap[i] = v
+    c.erode_amount = erode_amount
+    c.water_h_off = c.water_h_off_rel = c.relh_adj_tex = c.ocean_wave_height = 0.0
+    c.start_mag, c.start_freq, c.mag_mult, c.freq_mult = 0.02, 240.0, 2.0, 0.5
+    return c
+
+
+def default_lib_path():
+    return os.path.join(HERE, "libterra_hip.so")
+
+
+_vp, _f, _u32, _i32, _sz = C.c_void_p, C.c_float, C.c_uint32, C.c_int, C.c_size_t
+_f3 = C.POINTER(C.c_float)
+
+_PROTOS = {
+    "terra_last_error": (C.c_char_p, []),
+    "terra_device_count": (_i32, []),
+    "terra_create": (_i32, [C.POINTER(_vp), _i32]),
+    "terra_destroy": (None, [_vp]),
+    "terra_set_stream": (_i32, [_vp, _vp]),
+    "terra_synchronize": (_i32, [_vp]),
+    "terra_init_scene": (_i32, [_vp, C.POINTER(Config)]),
+    "terra_get_state": (_i32, [_vp, C.POINTER(State)]),
+    "terra_set_state": (_i32, [_vp, C.POINTER(State)]),
+    "terra_set_mode": (_i32, [_vp, _i32, _i32]),
+    "terra_set_zmax_est": (_i32, [_vp, _f]),
+    "terra_set_water_plane_z": (_i32, [_vp, _f]),
+    "terra_set_start_eval_sin": (_i32, [_vp, _i32]),
+    "terra_set_erode_amount": (_i32, [_vp, _f]),
+    "terra_get_max_sea_level": (_f, [_vp]),
+    "terra_gen_create": (_i32, [_vp, C.POINTER(_vp)]),
+    "terra_gen_destroy": (None, [_vp]),
+    "terra_gen_build_arrays": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32]),
+    "terra_gen_enable_glaciate": (_i32, [_vp]),
+    "terra_gen_is_running": (_i32, [_vp]),
+    "terra_gen_collect": (_i32, [_vp, _vp]),
+    "terra_gen_eval_index": (_f, [_vp, _u32, _u32]),
+    "terra_gen_device_values": (_vp, [_vp]),
+    "terra_gen_grid_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
+    "terra_gen_grid": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
+    "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
+    "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
+    "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
+    "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "terra_minmax_dev": (_i32, [_vp, _vp, _sz, _f3, _f3]),
+    "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
+    "terra_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
+    "terra_voxel_fill": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
+    "terra_malloc": (_i32, [_vp, C.POINTER(_vp), _sz]),
+    "terra_free": (_i32, [_vp, _vp]),
+    "terra_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "terra_memcpy_d2h": (_i32, [_vp, _vp, _vp, _sz]),
+    "terra_timer_start": (_i32, [_vp]),
+    "terra_timer_stop": (_i32, [_vp, _f3]),
+}
+EXPORTED_SYMBOLS = sorted(_PROTOS)
+
+
+def load_library(path=None):
+    path = path or default_lib_path()
+    if not os.path.exists(path):
+        raise TerraError(-4, f"{path} not found: build it with __graft_entry__.build() (hipcc, gfx950). There is no CPU fall-back.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+class DeviceBuffer:
+    """A device allocation owned through the C ABI (for callers that have no torch tensor to hand over)."""
+
+    def __init__(self, terra, nbytes):
+        self.t, self.nbytes = terra, nbytes
+        p = _vp()
+        terra._ck(terra.lib.terra_malloc(terra.ctx, C.byref(p), nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.t._ck(self.t.lib.terra_memcpy_h2d(self.t.ctx, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.t._ck(self.t.lib.terra_memcpy_d2h(self.t.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.t.lib.terra_free(self.t.ctx, self.ptr)
+            self.ptr = None
+
+
+class Terra:
+    """One terra_ctx (one GPU, one stream)."""
+
+    def __init__(self, device=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        ctx = _vp()
+        rc = self.lib.terra_create(C.byref(ctx), device)
+        if rc != 0:
+            raise TerraError(rc, self.lib.terra_last_error().decode())
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.terra_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise TerraError(rc, self.lib.terra_last_error().decode())
+        return rc
+
+    # ---- scene
+    def init_scene(self, cfg):
+        self._ck(self.lib.terra_init_scene(self.ctx, C.byref(cfg)))
+        return self.state()
+
+    def state(self):
+        s = State()
+        self._ck(self.lib.terra_get_state(self.ctx, C.byref(s)))
+        return s
+
+    def set_state(self, s): self._ck(self.lib.terra_set_state(self.ctx, C.byref(s)))
+    def set_mode(self, mode, shape=0): self._ck(self.lib.terra_set_mode(self.ctx, mode, shape))
+    def set_zmax_est(self, v): self._ck(self.lib.terra_set_zmax_est(self.ctx, v))
+    def set_water_plane_z(self, v): self._ck(self.lib.terra_set_water_plane_z(self.ctx, v))
+    def set_start_eval_sin(self, v): self._ck(self.lib.terra_set_start_eval_sin(self.ctx, v))
+    def set_erode_amount(self, v): self._ck(self.lib.terra_set_erode_amount(self.ctx, v))
+    def set_stream(self, stream_ptr): self._ck(self.lib.terra_set_stream(self.ctx, stream_ptr))
+    def synchronize(self): self._ck(self.lib.terra_synchronize(self.ctx))
+    def max_sea_level(self): return self.lib.terra_get_max_sea_level(self.ctx)
+    def alloc(self, nbytes): return DeviceBuffer(self, nbytes)
+    def timer_start(self): self._ck(self.lib.terra_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.lib.terra_timer_stop(self.ctx, C.byref(ms)))
+        return ms.value
+
+    # ---- host-buffer drop-ins
+    def gen_grid(self, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
+        out = np.empty((ny, nx), np.float32)
+        self._ck(self.lib.terra_gen_grid(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, out.ctypes.data))
+        return out
+
+    def apply_erosion(self, hmap, min_zval, iters):
+        assert hmap.dtype == np.float32 and hmap.flags.c_contiguous
+        ys, xs = hmap.shape
+        self._ck(self.lib.terra_apply_erosion(self.ctx, hmap.ctypes.data, xs, ys, min_zval, iters))
+        return hmap
+
+    def erosion_report(self):
+        r = ErosionReport()
+        self._ck(self.lib.terra_get_erosion_report(self.ctx, C.byref(r)))
+        return r
+
+    def tiles_create_zvals(self, tile_xy, iters_tt=0, stats=True, normals=True):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        z = np.empty((n, 130, 130), np.float32)
+        st = (TileStats * n)() if stats else None
+        nm = np.empty((n, 129, 129, 4), np.uint8) if normals else None
+        mnz = np.empty(n, np.float32) if normals else None
+        self._ck(self.lib.terra_tiles_create_zvals(self.ctx, txy.ctypes.data, n, iters_tt, z.ctypes.data,
+                                                    C.addressof(st) if stats else None, nm.ctypes.data if normals else None,
+                                                    mnz.ctypes.data if normals else None))
+        return z, st, nm, mnz
+
+    def voxel_fill(self, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
+        out = np.empty((ny, nx, nz), np.float32)
+        a = lambda v: (C.c_float * 3)(*v)
+        self._ck(self.lib.terra_voxel_fill(self.ctx, out.ctypes.data, nx, ny, nz, a(lo_pos), a(vsz), a(offset), mag, freq, rseed1, rseed2, gen_mode, zscale, normalize))
+        return out
+
+    # ---- device-resident entry points (ptr = raw device pointer, e.g. torch_tensor.data_ptr())
+    def gen_grid_dev(self, ptr, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
+        self._ck(self.lib.terra_gen_grid_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr))
+
+    def apply_erosion_dev(self, ptr, xsize, ysize, min_zval, iters, flags=0):
+        self._ck(self.lib.terra_apply_erosion_dev(self.ctx, ptr, xsize, ysize, min_zval, iters, flags))
+
+    def heightmap_proc_gen_dev(self, ptr, width, height, erosion_iters, pix_ptr=None):
+        rng = (C.c_float * 2)()
+        self._ck(self.lib.terra_heightmap_proc_gen_dev(self.ctx, width, height, erosion_iters, ptr, pix_ptr, C.addressof(rng)))
+        return rng[0], rng[1]
+
+    def minmax_dev(self, ptr, n):
+        mn, mx = C.c_float(), C.c_float()
+        self._ck(self.lib.terra_minmax_dev(self.ctx, ptr, n, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    def quantize16_dev(self, ptr, n, min_z, dz, pix_ptr):
+        self._ck(self.lib.terra_quantize16_dev(self.ctx, ptr, n, min_z, dz, pix_ptr))
+
+    def tiles_create_zvals_dev(self, tile_xy, iters_tt, z_ptr, stats_ptr=None, normals_ptr=None, mnz_ptr=None):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        self._ck(self.lib.terra_tiles_create_zvals_dev(self.ctx, txy.ctypes.data, len(txy), iters_tt, z_ptr, stats_ptr, normals_ptr, mnz_ptr))
+
+    def voxel_fill_dev(self, ptr, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
+        a = lambda v: (C.c_float * 3)(*v)
+        self._ck(self.lib.terra_voxel_fill_dev(self.ctx, ptr, nx, ny, nz, a(lo_pos), a(vsz), a(offset), mag, freq, rseed1, rseed2, gen_mode, zscale, normalize))
+
+    # ---- async generator handle (mesh_xy_grid_cache_t protocol)
+    def generator(self):
+        return Generator(self)
+
+
+class Generator:
+    def __init__(self, terra):
+        self.t = terra
+        g = _vp()
+        terra._ck(terra.lib.terra_gen_create(terra.ctx, C.byref(g)))
+        self.g = g
+        self.shape = None
+
+    def build_arrays(self, x0, y0, dx, dy, nx, ny, flags=0):
+        self.shape = (ny, nx)
+        return self.t._ck(self.t.lib.terra_gen_build_arrays(self.g, x0, y0, dx, dy, nx, ny, flags))
+
+    def enable_glaciate(self): self.t._ck(self.t.lib.terra_gen_enable_glaciate(self.g))
+    def is_running(self): return bool(self.t.lib.terra_gen_is_running(self.g))
+    def eval_index(self, x, y): return self.t.lib.terra_gen_eval_index(self.g, x, y)
+
+    def collect(self):
+        out = np.empty(self.shape, np.float32)
+        self.t._ck(self.t.lib.terra_gen_collect(self.g, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.g:
+            self.t.lib.terra_gen_destroy(self.g)
+            self.g = None

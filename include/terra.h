@@ -1,0 +1,168 @@
+/* terra.h -- C ABI of libterra_hip.so: MI355X (gfx950) procedural-terrain hot path of 3DWorld.
+ *
+ * Drop-in boundary.  3DWorld has no plugin/FFI layer; the seam is the three C++ call surfaces
+ * below plus the voxel fill.  Every entry point names the reference interface it replaces (paths relative to the
+ * 3DWorld tree).  All pointers are plain host or device pointers, all sizes plain integers; nothing here depends on
+ * torch, OpenGL or the engine's headers.  The engine keeps its process globals; they cross the boundary explicitly
+ * as terra_config (what the config file sets) or terra_state (already-derived globals).
+ *
+ *   reference interface                                                     replaced by
+ *   ----------------------------------------------------------------------  -------------------------------------------
+ *   create_sin_table / gen_rand_sine_table_entries / compute_scale /        terra_init_scene
+ *     estimate_zminmax / set_zvals / init_terrain_mesh / gen_tex_height_tables
+ *     (src/mesh_gen.cpp:72-81,213-254,407-431,447-512,544-548; src/Textures.cpp:1757-1761)
+ *   mesh_xy_grid_cache_t::build_arrays / enable_glaciate / eval_index       terra_gen_* handle, terra_gen_grid[_dev]
+ *     (src/mesh.h:22-45, src/mesh_gen.cpp:588-650,754-792)
+ *   apply_erosion(float*,int,int,float,unsigned)                            terra_apply_erosion[_dev]
+ *     (src/function_registry.h:354, src/erosion.cpp:14-164)
+ *   tile_t::create_zvals + get_norm/upload_normal_texture CPU part          terra_tiles_create_zvals[_dev]
+ *     (src/tiled_mesh.h:277,281-284; src/tiled_mesh.cpp:467-546,865-880)
+ *   heightmap_t::proc_gen / run_erosion / from_floats                       terra_heightmap_proc_gen[_dev], terra_quantize16_dev
+ *     (src/heightmap.cpp:130-215, src/Textures.cpp:1889-1893)
+ *   voxel_manager::create_procedural                                        terra_voxel_fill[_dev]
+ *     (src/voxels.cpp:278-346, src/upsurface.cpp:16-70)
+ *
+ * Error behaviour: the reference asserts; this library returns TERRA_OK (0) or a negative terra_status and keeps a
+ * thread-local message (terra_last_error).  There is NO CPU fall-back: without a usable HIP device terra_create fails.
+ *
+ * Threading: one terra_ctx per host thread / GPU (one process per GPU in multi-GPU runs).  All *_dev work is enqueued
+ * on the context's HIP stream (its own, or the caller's via terra_set_stream) and is asynchronous unless noted.
+ */
+#ifndef TERRA_H
+#define TERRA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TERRA_F_TABLE_SIZE 90 /* F_TABLE_SIZE, src/mesh_gen.cpp:30 */
+
+typedef enum {TERRA_OK = 0, TERRA_ERR_ARG = -1, TERRA_ERR_HIP = -2, TERRA_ERR_STATE = -3, TERRA_ERR_NODEVICE = -4, TERRA_ERR_LIMIT = -5} terra_status;
+
+/* mesh_gen_mode values (src/3DWorld.h:1399) */
+enum {TERRA_MGEN_SINE = 0, TERRA_MGEN_SIMPLEX = 1, TERRA_MGEN_PERLIN = 2, TERRA_MGEN_SIMPLEX_GPU = 3, TERRA_MGEN_DWARP_GPU = 4};
+
+/* What the engine's config file sets for this path (keyword -> global binding in src/3DWorld.cpp:1763-2110). */
+typedef struct terra_config {
+	int32_t mesh_x, mesh_y;                  /* mesh_size            -> MESH_X_SIZE, MESH_Y_SIZE */
+	float scene_x, scene_y, scene_z;         /* scene_size           -> X/Y/Z_SCENE_SIZE */
+	float mesh_height, mesh_scale;           /* mesh_height (-> mesh_height_scale), mesh_scale */
+	int32_t mesh_seed, mesh_freq_filter, mesh_gen_mode, mesh_gen_shape, glaciate; /* mesh_seed, mesh_freq_filter, mesh_gen_mode, mesh_gen_shape, GLACIATE */
+	float custom_glaciate_exp;               /* custom_glaciate_exp (0 = cubic) */
+	float hmap[14];                          /* hmap_params_t in declaration order, src/mesh.h:84-88 */
+	float erode_amount, water_h_off, water_h_off_rel, relh_adj_tex, ocean_wave_height;
+	float start_mag, start_freq, mag_mult, freq_mult; /* mesh_start_mag/freq, mesh_mag/freq_mult */
+} terra_config;
+
+/* The derived globals of the reference; terra_get_state exports them, terra_set_state injects an engine's own values. */
+typedef struct terra_state {
+	float sinTable[TERRA_F_TABLE_SIZE][5];   /* {mag, y-phase, x-phase, y-freq, x-freq}, src/mesh_gen.cpp:247-251 */
+	int32_t start_eval_sin;
+	float MESH_HEIGHT, DX_VAL, DY_VAL, DX_VAL_INV, DY_VAL_INV, HALF_DXY, dxdy, XY_SCENE_SIZE;
+	float mesh_scale, mesh_scale_z_inv, mesh_height_scale;
+	float zmax_est, zmin, zmax, water_plane_z, glaciate_exp, clip_hd1, relh_adj_tex;
+	float rx, ry;                            /* gen_rx_ry(), src/mesh_gen.cpp:581-586 */
+} terra_state;
+
+/* tile_t outputs of create_zvals (src/tiled_mesh.cpp:517-541): 4x4 sub-block z range, tile z range, radius, water bbox (ints, bit-exact) */
+typedef struct terra_tile_stats {
+	float sub_zmin[16], sub_zmax[16], mzmin, mzmax, radius;
+	int32_t wx1, wy1, wx2, wy2;
+} terra_tile_stats;
+
+/* counters of the last terra_apply_erosion*_dev call (diagnostics / bench) */
+typedef struct terra_erosion_report {
+	uint32_t droplets, windows, rounds, traces, serial_fallbacks, nan_droplets;
+	uint64_t steps;          /* droplet steps of the final (committed) traces */
+	uint64_t traced_steps;   /* droplet steps actually simulated, re-traces included */
+} terra_erosion_report;
+
+typedef struct terra_ctx terra_ctx;
+typedef struct terra_gen terra_gen;
+
+/* flags of terra_gen_grid* / terra_gen_build_arrays (bool arguments of build_arrays, src/mesh.h:40) */
+#define TERRA_GEN_GLACIATE     1u  /* enable_glaciate() after build_arrays() */
+#define TERRA_GEN_FORCE_SINE   2u  /* force_sine_mode */
+#define TERRA_GEN_NO_WAIT      4u  /* no_wait: return 0 right after launch */
+#define TERRA_GEN_CACHE_VALUES 8u  /* cache_values (accepted, no effect: every cell is always evaluated on the device) */
+/* flags of terra_apply_erosion*_dev */
+#define TERRA_ERODE_SERIAL        1u /* walk droplets one by one on one lane (reference order, no speculation): debugging / tiny grids */
+#define TERRA_ERODE_MINZ_IS_MIN   2u /* caller guarantees min_zval <= every grid value (heightmap_t::run_erosion passes min(vals)): clamp only written cells */
+
+const char *terra_last_error(void);
+int  terra_device_count(void);
+
+/* ---- context */
+int  terra_create(terra_ctx **out, int device_index);
+void terra_destroy(terra_ctx *ctx);
+int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
+int  terra_synchronize(terra_ctx *ctx);
+
+/* ---- scene / globals.  terra_init_scene = main()'s start-up sequence for this path (src/3DWorld.cpp:2393-2460 -> gen_mesh). */
+int  terra_init_scene(terra_ctx *ctx, const terra_config *cfg);
+int  terra_get_state(terra_ctx *ctx, terra_state *out);
+int  terra_set_state(terra_ctx *ctx, const terra_state *in);
+int  terra_set_mode(terra_ctx *ctx, int mesh_gen_mode, int mesh_gen_shape);
+int  terra_set_zmax_est(terra_ctx *ctx, float zmax_est);          /* set_zmax_est + zmin/zmax/water_plane_z, src/mesh_gen.cpp:162-167,494-512 */
+int  terra_set_water_plane_z(terra_ctx *ctx, float water_plane_z);
+int  terra_set_start_eval_sin(terra_ctx *ctx, int start_eval_sin);
+int  terra_set_erode_amount(terra_ctx *ctx, float erode_amount);
+float terra_get_max_sea_level(terra_ctx *ctx);                    /* src/tiled_mesh.cpp:141 */
+
+/* ---- generator: mesh_xy_grid_cache_t (src/mesh.h:22-45).  One handle per in-flight grid, like height_gens[8] (src/tiled_mesh.h:418). */
+int  terra_gen_create(terra_ctx *ctx, terra_gen **out);
+void terra_gen_destroy(terra_gen *g);                              /* ~mesh_xy_grid_cache_t / clear_context */
+/* build_arrays: returns 1 = results available, 0 = launched and not ready (only with TERRA_GEN_NO_WAIT), <0 = error.
+ * Same async protocol as the GL path (src/mesh_gen.cpp:597-603): call again with the same arguments to collect. */
+int  terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags);
+int  terra_gen_enable_glaciate(terra_gen *g);                      /* must follow build_arrays, as in the reference */
+int  terra_gen_is_running(terra_gen *g);                           /* compute_shader_t::get_is_running (src/shaders.h:233) */
+int  terra_gen_collect(terra_gen *g, float *host_out);            /* blocks; copies nx*ny floats (cached_vals) */
+float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y);  /* eval_index on collected values (src/mesh_gen.cpp:759-761) */
+const float *terra_gen_device_values(terra_gen *g);                /* device pointer to the nx*ny grid (valid until the next build) */
+
+/* one-shot: build_arrays + [enable_glaciate] + the caller's eval_index double loop (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:495-514) */
+int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out);
+int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out);
+
+/* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0. */
+int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
+int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
+int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
+
+/* ---- whole heightmap: heightmap_t::proc_gen (src/heightmap.cpp:130-151) minus run_city_gen.
+ * d_vals: width*height floats (final z); d_pixels16: optional 2 bytes per pixel {lo, hi} (from_floats/write_pixel_16_bits);
+ * h_range: optional {min_z, dz} used for the 16-bit scale. */
+int  terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height, uint32_t erosion_iters, float *d_vals, uint8_t *d_pixels16, float *h_range);
+int  terra_minmax_dev(terra_ctx *ctx, const float *d_vals, size_t n, float *h_min, float *h_max); /* synchronous */
+int  terra_quantize16_dev(terra_ctx *ctx, const float *d_vals, size_t n, float min_z, float dz, uint8_t *d_pixels16);
+
+/* ---- tiles: tile_t::create_zvals batch, size = 128 (zvsize 130, stride 129).
+ * tile_xy: n pairs (tile x, tile y) on the HOST.  d_zvals: n*130*130 floats.  d_stats: n terra_tile_stats (optional).
+ * d_normals: n*129*129*4 bytes RGBA8 with A = 0 (optional); d_min_normal_z: n floats (optional). */
+int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
+                                  float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_normal_z);
+int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
+                              float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
+
+/* ---- voxels: voxel_manager::create_procedural fill (src/voxels.cpp:278-346).  out is z-fastest: ix = z + (x + y*nx)*nz (src/voxels.h:141-144). */
+int  terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
+                          float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
+int  terra_voxel_fill(terra_ctx *ctx, float *h_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
+                      float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
+
+/* ---- plumbing for callers without a HIP runtime of their own (tests, ctypes) */
+int  terra_malloc(terra_ctx *ctx, void **d_ptr, size_t bytes);
+int  terra_free(terra_ctx *ctx, void *d_ptr);
+int  terra_memcpy_h2d(terra_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
+int  terra_memcpy_d2h(terra_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+/* timing on the context's stream (HIP events): t0 = terra_timer_start; ... ; ms = terra_timer_stop (synchronises) */
+int  terra_timer_start(terra_ctx *ctx);
+int  terra_timer_stop(terra_ctx *ctx, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERRA_H */

@@ -1,0 +1,41 @@
+// tests/emul/terra_emul.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Builds tests/emul/libterra_emul.so: the SAME host driver (terra_driver.hpp) and the SAME kernel bodies as
+// libterra_hip.so, with a backend that runs every "logical thread" in a host loop.  It exists so that the scene start-up,
+// the speculative erosion round logic, the tile batching and the argument checking of the C ABI can be tested against
+// the oracle on machines without a GPU (`pytest -m "not gpu"`).  It is NOT a fall-back: the 3dworld_amd package never
+// loads it, libterra_hip.so contains no host execution path, and terra_create() there fails without a HIP device.
+// LDS-tiled fast kernels have no emulation; only their one-thread-per-cell equivalents run here.
+#include "../../3dworld_amd/csrc/terra_simple_paths.hpp"
+#include <chrono>
+#include <stdlib.h>
+#include <omp.h>
+
+struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
+	std::chrono::steady_clock::time_point t0;
+	static int device_count() {return 1;}
+	void init(int) {}
+	void set_stream(void *) {}
+	void sync() {}
+	void *alloc(size_t bytes) {void *p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p;}
+	void free(void *p) {::free(p);}
+	void fill32(void *p, uint32_t v, size_t count) {uint32_t *q = (uint32_t *)p; for (size_t i = 0; i < count; ++i) q[i] = v;}
+	void h2d(void *d, void const *h, size_t bytes) {memcpy(d, h, bytes);}
+	void d2h(void *h, void const *d, size_t bytes) {memcpy(h, d, bytes);}
+	void timer_start() {t0 = std::chrono::steady_clock::now();}
+	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
+	// sequential on purpose: bodies use non-atomic stand-ins for atomics (terra_erosion.hpp)
+	template<class F> void launch(size_t n, F f, int = 256) {for (size_t i = 0; i < n; ++i) f(i);}
+
+	void sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out);}
+	void noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out) {noise_grid_simple(job, nc, L, smx, smy, out);}
+	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
+		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
+	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
+		std::vector<float> padded((size_t)n*ec.NX*ec.NY);
+		tile_erosion_simple(n, zvals, ec, iters, padded.data());
+	}
+	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize);}
+};
+typedef cpu_backend_t terra_backend_t;
+#include "../../3dworld_amd/csrc/terra_api_impl.hpp"
