@@ -457,7 +457,11 @@ template<class BE> struct terra_engine {
 			if (sb.cut < W) { // the overflowed droplet runs alone, directly on the grid (it is now the lowest uncommitted droplet)
 				uint32_t const it = done;
 				grid_view_t const gg = g; erosion_consts_t const ee = ec;
-				be.launch(1, [=] TERRA_LAMBDA (size_t) {direct_mem_t m{gg}; simulate_droplet((int)it, m, ee);}, 64);
+				uint32_t *cnt = sb.counters;
+				be.launch(1, [=] TERRA_LAMBDA (size_t) {direct_mem_t m{gg}; droplet_result_t const r = simulate_droplet((int)it, m, ee); cnt[4] = r.steps; cnt[5] = (uint32_t)r.nan_seen;}, 64);
+				uint32_t hr[2];
+				be.d2h(hr, sb.counters + 4, sizeof(hr));
+				report.steps += hr[0]; report.traced_steps += hr[0]; report.nan_droplets += hr[1];
 				++report.serial_fallbacks;
 				++done;
 			}

@@ -20,6 +20,7 @@
 // and x86 float->int conversion are reproduced because the reference does produce NaNs (v = sqrtf(v*v + Kg*dh) with dh < 0).
 #pragma once
 #include "terra_common.hpp"
+#include "terra_sincosf.hpp"
 
 namespace terra {
 
@@ -93,9 +94,9 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 		dx = (dx-gx)*Ki+gx;
 		dz = (dz-gz)*Ki+gz;
 		float const dl = sqrtf(dx*dx+dz*dz);
-		if (dl <= FLT_EPSILON) { // pick random dir (libm cosf/sinf in the reference; correctly rounded here via fp64)
+		if (dl <= FLT_EPSILON) { // pick random dir: libm cosf/sinf in the reference, reproduced bit-for-bit (terra_sincosf.hpp)
 			float const a = rgen.rand_float()*ec.two_pi;
-			dx = (float)cos((double)a); dz = (float)sin((double)a);
+			dx = glibc_cosf(a); dz = glibc_sinf(a);
 		}
 		else {dx /= dl; dz /= dl;}
 		float const nxp = xp+dx, nzp = zp+dz;

@@ -1,0 +1,90 @@
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref = 3DWorld's own mesh_gen.cpp / erosion.cpp /
+upsurface.cpp compiled in place, see oracle/Makefile).  Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The fixtures pin the C restatement (oracle/terra_oracle.c) and, transitively, the HIP path on machines where the reference
+tree does not exist (the GPU box).  All inputs are seeded; erosion runs with OMP_NUM_THREADS=1,
+the only deterministic order of the reference.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import orclib  # noqa: E402
+
+MODES = (0, 1, 2, 4)
+VOX = dict(lo=(-3.9, -3.9, -1.0), vsz=(0.0152, 0.0152, 0.0625), off=(0.1, 0.2, 0.3), mag=1.0, freq=1.0, rs1=123, rs2=456, zscale=0.01)
+
+
+def state_dict(s):
+    d = {"sinTable": s.sin_table_np(), "start_eval_sin": np.int32(s.start_eval_sin)}
+    for n in orclib._STATE_FLOATS:
+        d[n] = np.float32(getattr(s, n))
+    return d
+
+
+def main():
+    orclib.build_oracle()
+    assert orclib.ref_available(), "needs /root/reference (oracle/_ref)"
+    R = orclib.Checker("ref")
+    R.set_num_threads(1)
+    out = {}
+    for mode in MODES:
+        s = R.init(orclib.make_config(mesh_gen_mode=mode))
+        for k, v in state_dict(s).items():
+            out[f"m{mode}_state_{k}"] = v
+        out[f"m{mode}_tile00_raw"] = R.gen_grid(-64, -64, s.DX_VAL, s.DY_VAL, 130, 130, 0)
+        out[f"m{mode}_tile00_glac"] = R.gen_grid(-64, -64, s.DX_VAL, s.DY_VAL, 130, 130, 1)
+        out[f"m{mode}_odd_glac"] = R.gen_grid(1000.0, -777.0, s.DX_VAL, s.DY_VAL, 67, 45, 1)
+        out[f"m{mode}_ground"] = R.ground_mesh()
+    # shapes / post-process / 8 octaves in sine mode
+    s = R.init(orclib.make_config(mesh_gen_mode=0, mesh_gen_shape=1, mesh_freq_filter=1, hmap=[0.2, 0.5, 2.0, 0.2, 0.5, 2.0, 0.0, 0.05, 4.0, 5.0, 0.001, -4.0, 1200.0, 4.0]))
+    out["shape1_sine"] = R.gen_grid(-50, -50, s.DX_VAL, s.DY_VAL, 100, 100, 1)
+    s = R.init(orclib.make_config(mesh_gen_mode=1, mesh_gen_shape=2, mesh_freq_filter=1))
+    out["shape2_simplex"] = R.gen_grid(-50, -50, s.DX_VAL, s.DY_VAL, 64, 64, 1)
+    # erosion + tiles + quantise (sine mode)
+    s = R.init(orclib.make_config(mesh_gen_mode=0))
+    g = R.gen_grid(-80, -80, s.DX_VAL, s.DY_VAL, 160, 160, 1)
+    out["ero_in"] = g.copy()
+    out["ero_min"] = np.float32(g.min())
+    out["ero_out_400"] = R.apply_erosion(g.copy(), float(g.min()), 400)
+    z, st = R.tile_create_zvals(-3, 7, 150)
+    out["tile_m3_7_z"] = z
+    out["tile_m3_7_stats"] = np.frombuffer(bytes(st), np.uint8).copy()
+    nm, mnz = R.tile_normals(z)
+    out["tile_m3_7_normals"] = nm
+    out["tile_m3_7_min_normal_z"] = np.float32(mnz)
+    q, mn, dz = R.quantize16(out["ero_out_400"])
+    out["quant_bytes"] = q
+    out["quant_range"] = np.array([mn, dz], np.float32)
+    out["max_sea_level"] = np.float32(R.get_max_sea_level())
+    # voxels
+    for mode in (0, 1, 2):
+        nx, ny, nz = (40, 24, 32) if mode == 0 else (12, 10, 16)
+        out[f"vox{mode}"] = R.voxel_fill(nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], VOX["mag"], VOX["freq"], VOX["rs1"], VOX["rs2"], mode, VOX["zscale"], 1)
+    out["vox_rdata"] = R.voxel_rdata(123, 456, 1.0, 1.0)
+    # glm noise, point queries, RNG, sin table
+    rng = np.random.default_rng(20260923)
+    pts = rng.uniform(-300, 300, (512, 3)).astype(np.float32)
+    out["pts"] = pts
+    out["simplex2"] = np.array([R.simplex2(x, y) for x, y, _ in pts], np.float32)
+    out["perlin2"] = np.array([R.perlin2(x, y) for x, y, _ in pts], np.float32)
+    out["simplex3"] = np.array([R.simplex3(x, y, z) for x, y, z in pts], np.float32)
+    out["perlin3"] = np.array([R.perlin3(x, y, z) for x, y, z in pts], np.float32)
+    out["sin_terms"] = np.array([R.eval_mesh_sin_terms(x, y) for x, y, _ in pts], np.float32)
+    for mode in (1, 2, 4):
+        out[f"noise_zval_{mode}"] = np.array([R.noise_zval(x, y, mode, 0) for x, y, _ in pts[:128]], np.float32)
+    out["rand_ints_11_121"] = R.rand_ints(11, 121, 256)
+    out["rand_floats_1_12345"] = R.rand_floats(1, 12345, 256)
+    out["rand_uniforms_1_12345"] = R.rand_uniforms(1, 12345, 0.2, 1.0, 256)
+    out["sin_table"] = R.sin_table()
+    np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
+    print("wrote", os.path.join(HERE, "reference_vectors.npz"), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")), "bytes;", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

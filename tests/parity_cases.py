@@ -1,0 +1,260 @@
+"""Parity cases shared by the emulator tests (CPU, host logic) and the GPU tests (the product).
+
+`t` is a 3dworld_amd.Terra bound to either library; `orc` is the C-restatement oracle; `G` the golden vectors produced by
+the reference itself (tests/golden/make_golden.py).  Integer / index / byte outputs and every fp32 value are compared
+BIT-EXACT: the path is built without FMA contraction and with the reference's operation order, so the 1e-5 relative
+tolerance of BASELINE.json is met with zero slack (the only documented exception is custom_glaciate_exp != 0, where powf
+differs between libm and the device: tolerance 2e-6 relative, see test_custom_glaciate_exp).
+"""
+import os
+
+import numpy as np
+
+import orclib
+from orclib import assert_bit_equal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VOX = dict(lo=(-3.9, -3.9, -1.0), vsz=(0.0152, 0.0152, 0.0625), off=(0.1, 0.2, 0.3))
+_G = None
+
+
+def golden():
+    global _G
+    if _G is None:
+        _G = dict(np.load(os.path.join(HERE, "golden", "reference_vectors.npz")))
+    return _G
+
+
+def cfg_pair(pkg, **kw):
+    return pkg.make_config(**kw), orclib.make_config(**kw)
+
+
+def check_state(st, G, mode):
+    assert (np.ctypeslib.as_array(st.sinTable).reshape(90, 5).view(np.uint32) == G[f"m{mode}_state_sinTable"].view(np.uint32)).all()
+    assert st.start_eval_sin == int(G[f"m{mode}_state_start_eval_sin"])
+    for n in orclib._STATE_FLOATS:
+        a, b = np.float32(getattr(st, n)), G[f"m{mode}_state_{n}"]
+        assert a.view(np.uint32) == b.view(np.uint32), (mode, n, a, b)
+
+
+def case_scene_and_grids(pkg, t, mode):
+    """terra_init_scene + gen_grid against the reference's own outputs (golden), raw and glaciated, odd sizes and origins."""
+    G = golden()
+    st = t.init_scene(pkg.make_config(mesh_gen_mode=mode))
+    check_state(st, G, mode)
+    assert_bit_equal(t.gen_grid(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, 0), G[f"m{mode}_tile00_raw"], f"mode {mode} tile(0,0) raw")
+    assert_bit_equal(t.gen_grid(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, pkg.GEN_GLACIATE), G[f"m{mode}_tile00_glac"], f"mode {mode} tile(0,0) glaciated")
+    assert_bit_equal(t.gen_grid(1000.0, -777.0, st.DX_VAL, st.DY_VAL, 67, 45, pkg.GEN_GLACIATE), G[f"m{mode}_odd_glac"], f"mode {mode} 67x45")
+
+
+def case_shapes(pkg, t):
+    G = golden()
+    hm = [0.2, 0.5, 2.0, 0.2, 0.5, 2.0, 0.0, 0.05, 4.0, 5.0, 0.001, -4.0, 1200.0, 4.0]
+    st = t.init_scene(pkg.make_config(mesh_gen_mode=0, mesh_gen_shape=1, mesh_freq_filter=1, hmap=hm))
+    assert st.start_eval_sin == 10
+    assert_bit_equal(t.gen_grid(-50, -50, st.DX_VAL, st.DY_VAL, 100, 100, pkg.GEN_GLACIATE), G["shape1_sine"], "billowy sine + plateau/crater/crack + volcano, 8 octaves")
+    st = t.init_scene(pkg.make_config(mesh_gen_mode=1, mesh_gen_shape=2, mesh_freq_filter=1))
+    assert_bit_equal(t.gen_grid(-50, -50, st.DX_VAL, st.DY_VAL, 64, 64, pkg.GEN_GLACIATE), G["shape2_simplex"], "ridged simplex, 8 octaves")
+
+
+def case_grid_vs_oracle(pkg, t, orc, mode, n, min_start_sin=0, force_sine=False):
+    """larger grids against the oracle (bit-exact), incl. min_start_sin and force_sine_mode."""
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=mode)
+    st = t.init_scene(pc)
+    orc.init(oc)
+    flags = pkg.GEN_GLACIATE | (pkg.GEN_FORCE_SINE if force_sine else 0)
+    if force_sine:
+        orc.set_mode(0, 0)
+    a = orc.gen_grid(-n / 2, -n / 2 + 3, st.DX_VAL, st.DY_VAL, n, n - 17, 1, 0, min_start_sin)
+    b = t.gen_grid(-n / 2, -n / 2 + 3, st.DX_VAL, st.DY_VAL, n, n - 17, flags, min_start_sin)
+    assert_bit_equal(a, b, f"grid mode {mode} n {n} mss {min_start_sin}")
+
+
+def case_erosion_golden(pkg, t):
+    G = golden()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    h = G["ero_in"].copy()
+    t.apply_erosion(h, float(G["ero_min"]), 400)
+    assert_bit_equal(h, G["ero_out_400"], "erosion 160x160, 400 droplets (reference, single thread)")
+    r = t.erosion_report()
+    assert r.droplets == 400
+    return r
+
+
+def case_erosion_vs_oracle(pkg, t, orc, n, iters, mode=0, flags=0, seed=1):
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=mode, mesh_seed=seed)
+    st = t.init_scene(pc)
+    orc.init(oc)
+    a = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+    mn = float(a.min())
+    b = a.copy()
+    stats, steps = orc.apply_erosion_stats(a, mn, iters)
+    if flags:
+        buf = t.alloc(b.nbytes).upload(b)
+        t.apply_erosion_dev(buf.ptr, n, n, mn, iters, flags)
+        b = buf.download(np.float32, (n, n))
+        buf.free()
+    else:
+        t.apply_erosion(b, mn, iters)
+    assert_bit_equal(a, b, f"erosion {n}x{n} {iters} droplets flags {flags}")
+    r = t.erosion_report()
+    if not (flags & pkg.ERODE_SERIAL):
+        assert r.steps == stats.steps, (r.steps, stats.steps)
+        assert r.nan_droplets == stats.nan_droplets
+    return r, stats
+
+
+def case_erosion_edge(pkg, t, orc):
+    """disabled erosion, flat terrain (random-direction branch), water everywhere, 1-cell-wide grids."""
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    st = t.init_scene(pc)
+    orc.init(oc)
+    h = np.full((64, 64), 1.5, np.float32)
+    a, b = h.copy(), h.copy()
+    orc.apply_erosion(a, 0.0, 0); t.apply_erosion(b, 0.0, 0)          # num_iters == 0
+    assert_bit_equal(a, h); assert_bit_equal(b, h)
+    t.set_erode_amount(0.0); t.apply_erosion(b, 0.0, 10); t.set_erode_amount(1.0)  # erode_amount <= 0
+    assert_bit_equal(b, h)
+    # perfectly flat above water: every droplet takes the dl <= FLT_EPSILON branch (rand_float, cosf/sinf)
+    orc.set_water_plane_z(-10.0); t.set_water_plane_z(-10.0)
+    a, b = h.copy(), h.copy()
+    orc.apply_erosion(a, 0.0, 3000); t.apply_erosion(b, 0.0, 3000)  # libm cosf/sinf are not correctly rounded (2.6% of arguments): 3000 draws would expose any other sin/cos
+    assert_bit_equal(a, b, "flat terrain")
+    # everything below water: droplets stop at once, output = clamp only
+    orc.set_water_plane_z(10.0); t.set_water_plane_z(10.0)
+    a, b = h.copy(), h.copy()
+    orc.apply_erosion(a, 2.0, 50); t.apply_erosion(b, 2.0, 50)
+    assert_bit_equal(a, b, "all ocean"); assert (b == 2.0).all()
+    # degenerate shapes
+    orc.set_water_plane_z(-10.0); t.set_water_plane_z(-10.0)
+    rng = np.random.default_rng(3)
+    for shape in ((1, 40), (40, 1), (3, 5), (1, 1)):
+        h2 = rng.uniform(0, 1, shape).astype(np.float32)
+        a, b = h2.copy(), h2.copy()
+        orc.apply_erosion(a, 0.0, 60); t.apply_erosion(b, 0.0, 60)
+        assert_bit_equal(a, b, f"shape {shape}")
+
+
+def case_tiles(pkg, t, orc, mode, iters, tiles=((0, 0), (-3, 7), (20, -31), (5, 5), (5, -2), (-32, -32))):
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=mode)
+    t.init_scene(pc)
+    orc.init(oc)
+    z, st, nm, mnz = t.tiles_create_zvals(tiles, iters)
+    for i, (tx, ty) in enumerate(tiles):
+        zo, so = orc.tile_create_zvals(tx, ty, iters)
+        assert_bit_equal(zo, z[i], f"tile ({tx},{ty}) zvals")
+        assert bytes(so) == bytes(st[i]), f"tile ({tx},{ty}) stats / water bbox"
+        no, mo = orc.tile_normals(zo)
+        assert (no == nm[i]).all(), f"tile ({tx},{ty}) normals"
+        assert np.float32(mo).view(np.uint32) == mnz[i].view(np.uint32)
+
+
+def case_tile_golden(pkg, t):
+    G = golden()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    z, st, nm, mnz = t.tiles_create_zvals([(-3, 7)], 150)
+    assert_bit_equal(z[0], G["tile_m3_7_z"], "tile (-3,7), 150 droplets")
+    assert bytes(st[0]) == G["tile_m3_7_stats"].tobytes()
+    assert (nm[0] == G["tile_m3_7_normals"]).all()
+    assert mnz[0].view(np.uint32) == G["tile_m3_7_min_normal_z"].view(np.uint32)
+    assert np.float32(t.max_sea_level()).view(np.uint32) == G["max_sea_level"].view(np.uint32)
+
+
+def case_voxels_golden(pkg, t):
+    G = golden()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    for mode in (0, 1, 2):
+        nx, ny, nz = (40, 24, 32) if mode == 0 else (12, 10, 16)
+        v = t.voxel_fill(nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], 1.0, 1.0, 123, 456, mode, 0.01, 1)
+        assert_bit_equal(v, G[f"vox{mode}"], f"voxel mode {mode}")
+
+
+def case_voxels_vs_oracle(pkg, t, orc, mode, dims):
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc)
+    orc.init(oc)
+    nx, ny, nz = dims
+    a = orc.voxel_fill(nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], 0.8, 1.3, 7, 9, mode, -0.02, 0)
+    b = t.voxel_fill(nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], 0.8, 1.3, 7, 9, mode, -0.02, 0)
+    assert_bit_equal(a, b, f"voxels {dims} mode {mode}")
+
+
+def case_proc_gen(pkg, t, orc, N, iters):
+    """heightmap_t::proc_gen: generate + glaciate + erosion(min(vals)) + 16-bit quantise."""
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    st = t.init_scene(pc)
+    orc.init(oc)
+    buf, pix = t.alloc(N * N * 4), t.alloc(N * N * 2)
+    mn, dz = t.heightmap_proc_gen_dev(buf.ptr, N, N, iters, pix.ptr)
+    z = buf.download(np.float32, (N, N))
+    p = pix.download(np.uint8, (N * N * 2,))
+    buf.free(); pix.free()
+    a = orc.gen_grid(-0.5 * N, -0.5 * N, st.DX_VAL, st.DY_VAL, N, N, 1)
+    orc.apply_erosion(a, float(a.min()), iters)
+    assert_bit_equal(a, z, "proc_gen z")
+    q, qmn, qdz = orc.quantize16(a)
+    assert (q == p).all(), "16-bit pixels"
+    assert (np.float32(qmn).view(np.uint32), np.float32(qdz).view(np.uint32)) == (np.float32(mn).view(np.uint32), np.float32(dz).view(np.uint32))
+
+
+def case_quantize_golden(pkg, t):
+    G = golden()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    vals = G["ero_out_400"]
+    buf, pix = t.alloc(vals.nbytes).upload(vals), t.alloc(vals.size * 2)
+    mn, mx = t.minmax_dev(buf.ptr, vals.size)
+    assert mn == float(G["quant_range"][0])
+    dz = max(np.float32(1e-12), np.float32(mx) - np.float32(mn))
+    assert np.float32(dz) == G["quant_range"][1]
+    t.quantize16_dev(buf.ptr, vals.size, mn, float(dz), pix.ptr)
+    assert (pix.download(np.uint8, (vals.size * 2,)) == G["quant_bytes"]).all()
+    buf.free(); pix.free()
+
+
+def case_generator_protocol(pkg, t, orc):
+    """mesh_xy_grid_cache_t async protocol: no_wait launch returns 0, the second call collects (src/mesh_gen.cpp:597-603)."""
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=1)
+    st = t.init_scene(pc)
+    orc.init(oc)
+    g = t.generator()
+    assert g.build_arrays(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, pkg.GEN_NO_WAIT) == 0
+    assert g.is_running()
+    assert g.build_arrays(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, 0) == 1
+    assert not g.is_running()
+    raw = g.collect()
+    assert_bit_equal(raw, orc.gen_grid(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, 0), "generator raw")
+    g.enable_glaciate()
+    gl = g.collect()
+    assert_bit_equal(gl, orc.gen_grid(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, 1), "generator glaciated")
+    assert g.eval_index(7, 11) == gl[11, 7]
+    g.close()
+
+
+def case_api_errors(pkg, t):
+    """error behaviour of the boundary: the reference asserts, the C ABI returns negative codes and never crashes."""
+    import pytest
+    lib = t.lib
+    fresh = pkg.Terra(0, t.lib._name)
+    with pytest.raises(pkg.TerraError) as e:  # scene not initialised
+        fresh.gen_grid(0, 0, 1, 1, 4, 4)
+    assert e.value.code == -3
+    fresh.close()
+    st = t.init_scene(pkg.make_config())
+    with pytest.raises(pkg.TerraError) as e:  # assert(nx > 0 && ny > 0)
+        t.gen_grid(0, 0, st.DX_VAL, st.DY_VAL, 0, 4)
+    assert e.value.code == -1
+    with pytest.raises(pkg.TerraError):
+        t.set_mode(9, 0)
+    with pytest.raises(pkg.TerraError):
+        t.set_start_eval_sin(91)
+    bad = pkg.make_config(); bad.mesh_x = 0
+    with pytest.raises(pkg.TerraError):
+        t.init_scene(bad)
+    assert lib.terra_init_scene(None, None) == -1
+    assert lib.terra_apply_erosion(t.ctx, None, 4, 4, 0.0, 1) == -1
+    assert b"null" in lib.terra_last_error()
+    g = t.generator()
+    with pytest.raises(pkg.TerraError):  # enable_glaciate before build_arrays
+        g.enable_glaciate()
+    g.close()
+    t.init_scene(pkg.make_config())

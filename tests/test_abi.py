@@ -1,0 +1,53 @@
+"""The C-ABI shared library loads and exports every symbol include/terra.h declares (no compute: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "terra.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(terra_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def product_lib(pkg):
+    return pkg.build_library()
+
+
+def test_header_and_binding_agree(pkg):
+    from importlib import import_module
+    terra = import_module("3dworld_amd.terra")
+    assert declared_symbols() == terra.EXPORTED_SYMBOLS
+
+
+def test_product_library_exports_every_declared_symbol(product_lib):
+    lib = ctypes.CDLL(product_lib)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"libterra_hip.so does not export {name}"
+
+
+def test_no_cpu_fallback_in_product(pkg, product_lib):
+    """Without a HIP device terra_create must fail with TERRA_ERR_NODEVICE (-4) -- the product never computes on the host."""
+    lib = ctypes.CDLL(product_lib)
+    if lib.terra_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.TerraError) as e:
+        pkg.Terra(0)
+    assert e.value.code == -4 and "no CPU fall-back" in str(e.value)
+
+
+def test_product_does_not_link_the_oracle(product_lib):
+    syms = [l.split()[-1] for l in os.popen(f"nm -D {product_lib}").read().splitlines() if l.strip()]
+    assert not [s for s in syms if s.startswith(("orc_", "ref_"))]
+    needed = os.popen(f"readelf -d {product_lib}").read()
+    assert "liboracle" not in needed
+    for d in ("", "csrc"):
+        for f in os.listdir(os.path.join(ROOT, "3dworld_amd", d)):
+            if f.endswith((".py", ".hpp", ".hip")):
+                txt = open(os.path.join(ROOT, "3dworld_amd", d, f)).read()
+                assert "liboracle" not in txt and "terra_oracle" not in txt and "orclib" not in txt, f

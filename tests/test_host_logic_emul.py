@@ -1,0 +1,67 @@
+"""CPU tests of the HOST LOGIC of libterra_hip (scene start-up, kernel sequencing, speculative erosion rounds, tile batching,
+C-ABI argument checking) through tests/emul/libterra_emul.so -- the same driver and kernel bodies with a host-loop backend.
+This is test infrastructure, not a product path; the product (libterra_hip.so) is exercised by tests/test_gpu_parity.py."""
+import pytest
+
+import parity_cases as pc
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
+def test_scene_and_grids_golden(pkg, emul, mode):
+    pc.case_scene_and_grids(pkg, emul, mode)
+
+
+def test_shapes_golden(pkg, emul):
+    pc.case_shapes(pkg, emul)
+
+
+@pytest.mark.parametrize("mode,n,mss,force", [(0, 260, 0, False), (0, 140, 50, False), (1, 140, 0, True), (3, 96, 0, False)])
+def test_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force):
+    pc.case_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force)
+
+
+def test_erosion_golden(pkg, emul):
+    r = pc.case_erosion_golden(pkg, emul)
+    assert r.rounds >= 2  # dense case: the fixed point needs re-traces
+
+
+@pytest.mark.parametrize("n,iters", [(96, 50), (256, 300), (512, 1000), (1024, 400)])
+def test_speculative_erosion_equals_serial(pkg, emul, orc, n, iters):
+    pc.case_erosion_vs_oracle(pkg, emul, orc, n, iters)
+
+
+def test_erosion_serial_flag_and_overflow_fallback(pkg, emul, orc):
+    pc.case_erosion_vs_oracle(pkg, emul, orc, 128, 120, flags=pkg.ERODE_SERIAL)
+    r, _ = pc.case_erosion_vs_oracle(pkg, emul, orc, 512, 1000)  # droplet 0..999 on 512^2: long paths overflow the block list at least once
+    assert r.serial_fallbacks >= 1 and r.windows >= 2
+
+
+def test_erosion_edge_cases(pkg, emul, orc):
+    pc.case_erosion_edge(pkg, emul, orc)
+
+
+@pytest.mark.parametrize("mode,iters", [(0, 0), (0, 120), (1, 60)])
+def test_tiles(pkg, emul, orc, mode, iters):
+    pc.case_tiles(pkg, emul, orc, mode, iters, tiles=((0, 0), (-3, 7), (5, -2)))
+
+
+def test_tile_golden(pkg, emul):
+    pc.case_tile_golden(pkg, emul)
+
+
+def test_voxels(pkg, emul, orc):
+    pc.case_voxels_golden(pkg, emul)
+    pc.case_voxels_vs_oracle(pkg, emul, orc, 0, (33, 17, 20))
+
+
+def test_proc_gen_and_quantize(pkg, emul, orc):
+    pc.case_proc_gen(pkg, emul, orc, 160, 120)
+    pc.case_quantize_golden(pkg, emul)
+
+
+def test_generator_protocol(pkg, emul, orc):
+    pc.case_generator_protocol(pkg, emul, orc)
+
+
+def test_api_errors(pkg, emul):
+    pc.case_api_errors(pkg, emul)

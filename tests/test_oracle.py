@@ -1,0 +1,118 @@
+"""CPU tests of the oracle (oracle/terra_oracle.c): against the reference's own translation units when they can be built
+here (oracle/_ref), and always against the golden vectors those produced (tests/golden/reference_vectors.npz)."""
+import numpy as np
+import pytest
+
+import orclib
+from orclib import assert_bit_equal
+from parity_cases import golden, VOX
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
+def test_oracle_matches_golden_grids(orc, mode):
+    G = golden()
+    s = orc.init(orclib.make_config(mesh_gen_mode=mode))
+    assert (s.sin_table_np().view(np.uint32) == G[f"m{mode}_state_sinTable"].view(np.uint32)).all()
+    for n in orclib._STATE_FLOATS:
+        assert np.float32(getattr(s, n)).view(np.uint32) == G[f"m{mode}_state_{n}"].view(np.uint32), n
+    assert_bit_equal(orc.gen_grid(-64, -64, s.DX_VAL, s.DY_VAL, 130, 130, 0), G[f"m{mode}_tile00_raw"])
+    assert_bit_equal(orc.gen_grid(-64, -64, s.DX_VAL, s.DY_VAL, 130, 130, 1), G[f"m{mode}_tile00_glac"])
+    assert_bit_equal(orc.gen_grid(1000.0, -777.0, s.DX_VAL, s.DY_VAL, 67, 45, 1), G[f"m{mode}_odd_glac"])
+    assert_bit_equal(orc.ground_mesh(), G[f"m{mode}_ground"])
+
+
+def test_survey_anchor_values(orc):
+    """SURVEY.md section 8c anchors (produced by the survey's own build of the reference)."""
+    s = orc.init(orclib.make_config(mesh_gen_mode=0, hmap=orclib.HMAP_DEFAULT))
+    assert np.float32(s.MESH_HEIGHT) == np.float32(0.400000006) and s.DX_VAL == 0.0625 and s.start_eval_sin == 0
+    st = s.sin_table_np()
+    np.testing.assert_array_equal(st[0], np.array([0.00455211475, 2.10988116, 5.98097086, 0.921557486, 0.217441186], np.float32))
+    np.testing.assert_array_equal(st[89], np.array([1.25131238, 4.9162159, 6.09049273, 0.00157837011, 0.00172762678], np.float32))
+    z = orc.gen_grid(-64, -64, s.DX_VAL, s.DY_VAL, 130, 130, 0)
+    assert z[0, 0] == np.float32(0.514751375) and z[64, 64] == np.float32(0.316928059) and z[129, 129] == np.float32(-0.470116168)
+    assert abs(float(z.astype(np.float64).sum()) - 7214.74102) < 1e-4
+    orc.set_zmax_est(2.0)
+    zg = orc.gen_grid(-64, -64, s.DX_VAL, s.DY_VAL, 130, 130, 1)
+    assert zg[0, 0] == np.float32(-1.00604844) and zg[64, 64] == np.float32(-1.22264802)
+    assert list(orc.rand_ints(11, 121, 3)) == [2142999984, 1939390777, 815763296]
+    assert orc.simplex2(.3, .7) == np.float32(-0.442619652) and orc.perlin2(.3, .7) == np.float32(-0.427569121)
+    assert orc.simplex3(.3, .7, 1.1) == np.float32(-0.0851529166) and orc.perlin3(.3, .7, 1.1) == np.float32(-0.0404006653)
+    for mode, v1, v2 in ((1, -2.5190413, -2.875772), (2, 1.49259567, 0.469020426), (4, -1.32977569, -2.59287405)):
+        assert orc.noise_zval(10, 20, mode) == np.float32(v1) and orc.noise_zval(-37, 5, mode) == np.float32(v2)
+    tab = orc.sin_table()
+    assert tab[1] == np.float32(0.000191747604) and tab[12345] == np.float32(0.69933629) and tab[32768 + 777] == np.float32(0.988921821)
+
+
+def test_oracle_matches_golden_misc(orc):
+    G = golden()
+    hm = [0.2, 0.5, 2.0, 0.2, 0.5, 2.0, 0.0, 0.05, 4.0, 5.0, 0.001, -4.0, 1200.0, 4.0]
+    s = orc.init(orclib.make_config(mesh_gen_mode=0, mesh_gen_shape=1, mesh_freq_filter=1, hmap=hm))
+    assert_bit_equal(orc.gen_grid(-50, -50, s.DX_VAL, s.DY_VAL, 100, 100, 1), G["shape1_sine"])
+    s = orc.init(orclib.make_config(mesh_gen_mode=1, mesh_gen_shape=2, mesh_freq_filter=1))
+    assert_bit_equal(orc.gen_grid(-50, -50, s.DX_VAL, s.DY_VAL, 64, 64, 1), G["shape2_simplex"])
+    s = orc.init(orclib.make_config(mesh_gen_mode=0))
+    assert_bit_equal(orc.apply_erosion(G["ero_in"].copy(), float(G["ero_min"]), 400), G["ero_out_400"])
+    z, st = orc.tile_create_zvals(-3, 7, 150)
+    assert_bit_equal(z, G["tile_m3_7_z"]); assert bytes(st) == G["tile_m3_7_stats"].tobytes()
+    nm, mnz = orc.tile_normals(z)
+    assert (nm == G["tile_m3_7_normals"]).all() and np.float32(mnz) == G["tile_m3_7_min_normal_z"]
+    q, mn, dz = orc.quantize16(G["ero_out_400"])
+    assert (q == G["quant_bytes"]).all() and (mn, dz) == tuple(float(v) for v in G["quant_range"])
+    for mode in (0, 1, 2):
+        nx, ny, nz = (40, 24, 32) if mode == 0 else (12, 10, 16)
+        assert_bit_equal(orc.voxel_fill(nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], 1.0, 1.0, 123, 456, mode, 0.01, 1), G[f"vox{mode}"])
+    assert_bit_equal(orc.voxel_rdata(123, 456, 1.0, 1.0), G["vox_rdata"])
+    pts = G["pts"]
+    for name in ("simplex2", "perlin2"):
+        assert_bit_equal(np.array([getattr(orc, name)(x, y) for x, y, _ in pts], np.float32), G[name], name)
+    for name in ("simplex3", "perlin3"):
+        assert_bit_equal(np.array([getattr(orc, name)(x, y, z) for x, y, z in pts], np.float32), G[name], name)
+    assert_bit_equal(np.array([orc.eval_mesh_sin_terms(x, y) for x, y, _ in pts], np.float32), G["sin_terms"])
+    for mode in (1, 2, 4):
+        assert_bit_equal(np.array([orc.noise_zval(x, y, mode) for x, y, _ in pts[:128]], np.float32), G[f"noise_zval_{mode}"])
+    assert (orc.rand_ints(11, 121, 256) == G["rand_ints_11_121"]).all()
+    assert_bit_equal(orc.rand_floats(1, 12345, 256), G["rand_floats_1_12345"])
+    assert_bit_equal(orc.rand_uniforms(1, 12345, 0.2, 1.0, 256), G["rand_uniforms_1_12345"])
+    assert_bit_equal(orc.sin_table(), G["sin_table"])
+
+
+def test_oracle_vs_reference_tus(orc, ref):
+    """Only where /root/reference exists: the restatement against the reference's own TUs on fresh (non-golden) inputs."""
+    ref.set_num_threads(1)
+    for mode, n in ((0, 300), (1, 150), (2, 150), (4, 96)):
+        cfg = orclib.make_config(mesh_gen_mode=mode, mesh_seed=5, mesh_freq_filter=1)
+        sr, so = ref.init(cfg), orc.init(cfg)
+        assert bytes(sr.sinTable) == bytes(so.sinTable) and sr.zmax_est == so.zmax_est and sr.water_plane_z == so.water_plane_z and sr.clip_hd1 == so.clip_hd1
+        for gl in (0, 1):
+            assert_bit_equal(ref.gen_grid(-n / 2, 11, sr.DX_VAL, sr.DY_VAL, n, n - 9, gl), orc.gen_grid(-n / 2, 11, sr.DX_VAL, sr.DY_VAL, n, n - 9, gl), f"mode {mode}")
+    cfg = orclib.make_config(mesh_gen_mode=0)
+    sr, so = ref.init(cfg), orc.init(cfg)
+    g = ref.gen_grid(-128, -128, sr.DX_VAL, sr.DY_VAL, 256, 256, 1)
+    for iters in (700, 5000):
+        a, b = g.copy(), g.copy()
+        ref.apply_erosion(a, float(g.min()), iters); orc.apply_erosion(b, float(g.min()), iters)
+        assert_bit_equal(a, b, f"erosion {iters}")
+    for tx, ty in ((1, 2), (-9, 4)):
+        za, sa = ref.tile_create_zvals(tx, ty, 100); zb, sb = orc.tile_create_zvals(tx, ty, 100)
+        assert_bit_equal(za, zb); assert bytes(sa) == bytes(sb)
+    rng = np.random.default_rng(99)
+    pts = rng.uniform(-2000, 2000, (3000, 3)).astype(np.float32)
+    for name in ("simplex2", "perlin2"):
+        assert_bit_equal(np.array([getattr(ref, name)(x, y) for x, y, _ in pts], np.float32), np.array([getattr(orc, name)(x, y) for x, y, _ in pts], np.float32), name)
+    for name in ("simplex3", "perlin3"):
+        assert_bit_equal(np.array([getattr(ref, name)(x, y, z) for x, y, z in pts], np.float32), np.array([getattr(orc, name)(x, y, z) for x, y, z in pts], np.float32), name)
+
+
+def test_libm_sincosf_is_not_correctly_rounded_but_reproducible():
+    """The droplet's random-direction branch calls libm cosf/sinf on a = rand_float()*TWO_PI (src/erosion.cpp:80-83).
+    glibc's sinf/cosf are not correctly rounded, which is why 3dworld_amd/csrc/terra_sincosf.hpp restates their algorithm
+    instead of using (float)cos((double)a); this documents the fact on a sample (the exhaustive comparison of the restatement
+    is the flat-terrain erosion case, CPU emulator and GPU)."""
+    import ctypes
+    m = ctypes.CDLL("libm.so.6")
+    m.cosf.restype = m.sinf.restype = ctypes.c_float
+    m.cosf.argtypes = m.sinf.argtypes = [ctypes.c_float]
+    two_pi = np.float32(2.0 * np.float64(np.float32(3.141592654)))
+    a = (0.000001 * np.arange(0, 1000000, 50)).astype(np.float32) * two_pi
+    diff = sum(np.float32(m.cosf(float(v))) != np.float32(np.cos(np.float64(v))) for v in a)
+    assert diff > 0  # ~2.6% on glibc 2.35
