@@ -58,6 +58,11 @@ int terra_init_scene(terra_ctx *ctx, const terra_config *cfg) {
 	if (!cfg) return terra::fail(TERRA_ERR_ARG, "terra_init_scene: null config");
 	TERRA_TRY ctx->eng.init_scene(*cfg); TERRA_CATCH
 }
+int terra_set_config(terra_ctx *ctx, const terra_config *cfg) {
+	TERRA_CHECK_CTX
+	if (!cfg) return terra::fail(TERRA_ERR_ARG, "terra_set_config: null config");
+	TERRA_TRY ctx->eng.set_config(*cfg); TERRA_CATCH
+}
 int terra_get_state(terra_ctx *ctx, terra_state *out) {TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out"); TERRA_TRY ctx->eng.require_scene(); ctx->eng.get_state(*out); TERRA_CATCH}
 int terra_set_state(terra_ctx *ctx, const terra_state *in) {TERRA_CHECK_CTX if (!in) return terra::fail(TERRA_ERR_ARG, "null state"); TERRA_TRY ctx->eng.set_state(*in); TERRA_CATCH}
 int terra_set_mode(terra_ctx *ctx, int mode, int shape) {

@@ -74,7 +74,9 @@ struct rand_gen_t {
 struct sin_lut_t {
 	float const *tab; // [2*TSIZE]: sin then cos
 	float sscale;     // float(TSIZE)/TWO_PI
-	TERRA_HD int st_scale(float v) const {return ((int)(sscale*v)) & (TSIZE-1);}
+	// int(sscale*val) overflows for |val| > ~4e5 (estimate_zminmax samples at a 4000-cell spacing): the reference binary then gets
+	// cvttss2si's 0x80000000 -> table index 0, so the x86 conversion is part of the function's definition
+	TERRA_HD int st_scale(float v) const {return f2i_x86(sscale*v) & (TSIZE-1);}
 	TERRA_HD float SINF(float v) const {return (v < 0) ? -tab[st_scale(-v)] : tab[st_scale(v)];}
 	TERRA_HD float COSF(float v) const {return tab[TSIZE + st_scale(fabsf(v))];}
 };

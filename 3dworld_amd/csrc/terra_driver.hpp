@@ -79,7 +79,7 @@ template<class BE> struct terra_engine {
 	float rx = 1, ry = 1, two_pi = 0, sscale = 0;
 	hmap_params_t hp{};
 	rand_gen_t sine_rgen{1, 1}; // the function-static rgen of gen_rand_sine_table_entries (src/mesh_gen.cpp:239)
-	bool scene_ready = false;
+	bool scene_ready = false, have_config = false;
 	std::vector<float> h_sin_table;
 	float *d_sin_table = nullptr;
 	terra_erosion_report report{};
@@ -188,16 +188,21 @@ template<class BE> struct terra_engine {
 		clip_hd1 = (float)(0.90*(double)h_dirt[1] + 0.10*(double)h_dirt[0]);
 	}
 
-	void init_scene(terra_config const &c) {
-		if (c.mesh_x <= 0 || c.mesh_y <= 0 || !(c.scene_x > 0) || !(c.scene_y > 0) || !(c.mesh_scale > 0)) throw std::invalid_argument("terra_init_scene: bad mesh/scene size");
-		if (c.mesh_gen_mode < 0 || c.mesh_gen_mode > MGEN_DWARP_GPU || c.mesh_gen_shape < 0 || c.mesh_gen_shape > 2) throw std::invalid_argument("terra_init_scene: bad mesh_gen_mode/shape");
+	// the config-file values only (no derivation): what an engine that already owns the derived globals passes before terra_set_state
+	void set_config(terra_config const &c) {
+		if (c.mesh_x <= 0 || c.mesh_y <= 0 || !(c.scene_x > 0) || !(c.scene_y > 0) || !(c.mesh_scale > 0)) throw std::invalid_argument("terra config: bad mesh/scene size");
+		if (c.mesh_gen_mode < 0 || c.mesh_gen_mode > MGEN_DWARP_GPU || c.mesh_gen_shape < 0 || c.mesh_gen_shape > 2) throw std::invalid_argument("terra config: bad mesh_gen_mode/shape");
 		cfg = c;
 		create_sin_table();
-		set_scene_constants();
 		mesh_height_scale = c.mesh_height; mesh_scale = c.mesh_scale; mesh_scale_z_inv = 1.0f; // config-file mesh_scale leaves mesh_scale_z at 1 (src/mesh_gen.cpp:862-874 only runs on runtime rescale)
 		mode = c.mesh_gen_mode; shape = c.mesh_gen_shape; glaciate = c.glaciate; custom_glaciate_exp = c.custom_glaciate_exp;
 		memcpy(&hp, c.hmap, sizeof(hp));
 		erode_amount = c.erode_amount; water_h_off = c.water_h_off; water_h_off_rel = c.water_h_off_rel; relh_adj_tex = c.relh_adj_tex; ocean_wave_height = c.ocean_wave_height;
+		have_config = true;
+	}
+	void init_scene(terra_config const &c) {
+		set_config(c);
+		set_scene_constants();
 		// gen_mesh(0, 0, 1) at start-up (src/mesh_gen.cpp:257-356)
 		compute_scale();
 		gen_rand_sine_table_entries(MESH_HEIGHT*mesh_height_scale);
@@ -234,13 +239,13 @@ template<class BE> struct terra_engine {
 		s.rx = rx; s.ry = ry;
 	}
 	void set_state(terra_state const &s) {
+		if (!have_config) throw std::logic_error("terra_set_state: call terra_set_config (or terra_init_scene) first: hmap_params, modes and erosion scalars are not part of terra_state");
 		create_sin_table();
 		memcpy(sinTable, s.sinTable, sizeof(sinTable));
 		start_eval_sin = s.start_eval_sin; MESH_HEIGHT = s.MESH_HEIGHT; DX_VAL = s.DX_VAL; DY_VAL = s.DY_VAL; DX_VAL_INV = s.DX_VAL_INV; DY_VAL_INV = s.DY_VAL_INV;
 		HALF_DXY = s.HALF_DXY; dxdy = s.dxdy; XY_SCENE_SIZE = s.XY_SCENE_SIZE; mesh_scale = s.mesh_scale; mesh_scale_z_inv = s.mesh_scale_z_inv; mesh_height_scale = s.mesh_height_scale;
 		set_zmax_est(s.zmax_est); zmin = s.zmin; zmax = s.zmax; water_plane_z = s.water_plane_z; glaciate_exp = s.glaciate_exp; clip_hd1 = s.clip_hd1; relh_adj_tex = s.relh_adj_tex;
 		rx = s.rx; ry = s.ry;
-		if (cfg.mesh_x == 0) {cfg.mesh_x = cfg.mesh_y = 128;}
 		scene_ready = true;
 	}
 	void require_scene() const {if (!scene_ready) throw std::logic_error("terra: scene not initialised (call terra_init_scene or terra_set_state first)");}

@@ -81,6 +81,7 @@ _PROTOS = {
     "terra_set_stream": (_i32, [_vp, _vp]),
     "terra_synchronize": (_i32, [_vp]),
     "terra_init_scene": (_i32, [_vp, C.POINTER(Config)]),
+    "terra_set_config": (_i32, [_vp, C.POINTER(Config)]),
     "terra_get_state": (_i32, [_vp, C.POINTER(State)]),
     "terra_set_state": (_i32, [_vp, C.POINTER(State)]),
     "terra_set_mode": (_i32, [_vp, _i32, _i32]),
@@ -195,6 +196,7 @@ class Terra:
         return s
 
     def set_state(self, s): self._ck(self.lib.terra_set_state(self.ctx, C.byref(s)))
+    def set_config(self, cfg): self._ck(self.lib.terra_set_config(self.ctx, C.byref(cfg)))
     def set_mode(self, mode, shape=0): self._ck(self.lib.terra_set_mode(self.ctx, mode, shape))
     def set_zmax_est(self, v): self._ck(self.lib.terra_set_zmax_est(self.ctx, v))
     def set_water_plane_z(self, v): self._ck(self.lib.terra_set_water_plane_z(self.ctx, v))

@@ -102,6 +102,7 @@ int  terra_synchronize(terra_ctx *ctx);
 
 /* ---- scene / globals.  terra_init_scene = main()'s start-up sequence for this path (src/3DWorld.cpp:2393-2460 -> gen_mesh). */
 int  terra_init_scene(terra_ctx *ctx, const terra_config *cfg);
+int  terra_set_config(terra_ctx *ctx, const terra_config *cfg);   /* store the config-file values only (engine integration: follow with terra_set_state) */
 int  terra_get_state(terra_ctx *ctx, terra_state *out);
 int  terra_set_state(terra_ctx *ctx, const terra_state *in);
 int  terra_set_mode(terra_ctx *ctx, int mesh_gen_mode, int mesh_gen_shape);

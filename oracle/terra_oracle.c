@@ -89,7 +89,7 @@ static void create_sin_table(void) {
 		sin_table[i+TSIZE] = cosf((float)i/sscale);
 	}
 }
-static inline int ST_SCALE(float v) {return ((int)(sscale*v)) & (TSIZE-1);}
+static inline int ST_SCALE(float v) {return f2i(sscale*v) & (TSIZE-1);} /* int(sscale*val): overflows to 0x80000000 on x86 for large val (estimate_zminmax), made explicit */
 static inline float SINF(float v) {return (v < 0) ? -sin_table[ST_SCALE(-v)] : sin_table[ST_SCALE(v)];}
 static inline float COSF(float v) {return sin_table[TSIZE + ST_SCALE(fabsf(v))];}
 

@@ -230,6 +230,24 @@ def case_generator_protocol(pkg, t, orc):
     g.close()
 
 
+def case_inject_engine_state(pkg, t, orc):
+    """engine integration path: terra_set_config + terra_set_state (the engine's own derived globals) instead of terra_init_scene."""
+    import ctypes as C
+    import pytest
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=2, mesh_seed=7)
+    so = orc.init(oc)
+    fresh = pkg.Terra(0, t.lib._name)
+    st = pkg.State()
+    C.memmove(C.byref(st), C.byref(so), C.sizeof(st))
+    with pytest.raises(pkg.TerraError):
+        fresh.set_state(st)  # config first
+    fresh.set_config(pc_)
+    fresh.set_state(st)
+    assert_bit_equal(orc.gen_grid(-64, -64, so.DX_VAL, so.DY_VAL, 130, 130, 1), fresh.gen_grid(-64, -64, so.DX_VAL, so.DY_VAL, 130, 130, pkg.GEN_GLACIATE), "injected state")
+    assert bytes(fresh.state()) == bytes(st)
+    fresh.close()
+
+
 def case_api_errors(pkg, t):
     """error behaviour of the boundary: the reference asserts, the C ABI returns negative codes and never crashes."""
     import pytest

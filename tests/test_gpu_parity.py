@@ -72,6 +72,10 @@ def test_generator_protocol(pkg, gpu, orc):
     pc.case_generator_protocol(pkg, gpu, orc)
 
 
+def test_inject_engine_state(pkg, gpu, orc):
+    pc.case_inject_engine_state(pkg, gpu, orc)
+
+
 def test_api_errors(pkg, gpu):
     pc.case_api_errors(pkg, gpu)
 

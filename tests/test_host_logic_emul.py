@@ -63,5 +63,9 @@ def test_generator_protocol(pkg, emul, orc):
     pc.case_generator_protocol(pkg, emul, orc)
 
 
+def test_inject_engine_state(pkg, emul, orc):
+    pc.case_inject_engine_state(pkg, emul, orc)
+
+
 def test_api_errors(pkg, emul):
     pc.case_api_errors(pkg, emul)
