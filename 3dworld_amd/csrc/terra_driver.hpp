@@ -316,18 +316,7 @@ template<class BE> struct terra_engine {
 		uint32_t *d = scratch<uint32_t>(s_misc, 2);
 		uint32_t const init[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 		be.h2d(d, init, sizeof(init));
-		size_t const chunk = 2048, nchunks = (n + chunk - 1)/chunk;
-		be.launch(nchunks, [=] TERRA_LAMBDA (size_t c) {
-			size_t const b = c*chunk, e = (b + chunk < n) ? b + chunk : n;
-			bool have = false; float lo = 0, hi = 0;
-			for (size_t i = b; i < e; ++i) {
-				float const v = d_vals[i];
-				if (v != v) continue;
-				if (!have) {lo = hi = v; have = true;}
-				lo = min_std(lo, v); hi = max_std(hi, v);
-			}
-			if (have) {TERRA_ATOMIC_MIN(&d[0], f2ord(lo)); TERRA_ATOMIC_MIN(&d[1], ~f2ord(hi));} // max as min of the complement
-		});
+		be.minmax(d_vals, n, d); // d[0] = min of f2ord(v), d[1] = min of ~f2ord(v)
 		uint32_t out[2];
 		be.d2h(out, d, sizeof(out));
 		mn = ord2f(out[0]); mx = ord2f(~out[1]);
@@ -358,7 +347,7 @@ template<class BE> struct terra_engine {
 		return ec;
 	}
 
-	struct spec_cfg_t {uint32_t window = 4096, cap_log2 = 11, maxb = 256, bshift = 3, max_rounds = 100000;} spec_cfg;
+	struct spec_cfg_t {uint32_t window = 4096, cap_log2 = 12, maxb = 256, bshift = 3, max_rounds = 100000;} spec_cfg;
 
 	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
 		require_scene();
@@ -380,6 +369,12 @@ template<class BE> struct terra_engine {
 			}, 64);
 			report.windows = 1; report.serial_fallbacks = num_iters;
 		}
+		else if (flags & TERRA_ERODE_SERIAL_WAVE) { // droplets one after another, each by a whole wave through the LDS window, directly on the grid
+			be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {
+				for (uint32_t it = 0; it < num_iters; ++it) {direct_droplet_wave(g, ec, it, nullptr, ws);}
+			});
+			report.windows = 1; report.serial_fallbacks = num_iters;
+		}
 		else {speculative_erosion(g, ec, num_iters);}
 		// remove padding and clamp to min_zval (src/erosion.cpp:158-162): in place, so only the clamp remains
 		size_t const n = (size_t)xsize*ysize;
@@ -393,7 +388,8 @@ template<class BE> struct terra_engine {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec;
 		uint32_t const Wmax = std::min<uint32_t>(spec_cfg.window, num_iters);
-		sb.cap_log2 = spec_cfg.cap_log2; sb.maxb = spec_cfg.maxb; sb.bshift = spec_cfg.bshift;
+		sb.cap_log2 = spec_cfg.cap_log2; sb.maxb = spec_cfg.maxb; sb.bshift = std::max<uint32_t>(spec_cfg.bshift, 3);
+		if (((size_t)1 << sb.cap_log2) < (size_t)4*EW*EW) throw std::logic_error("speculative erosion: log capacity too small for the window");
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
 		size_t const cap = (size_t)1 << sb.cap_log2, nblocks = (size_t)sb.nbx*sb.nby;
 		// carve one allocation
@@ -428,7 +424,7 @@ template<class BE> struct terra_engine {
 				spec_buffers_t const s = sb;
 				if (first) {be.fill32(sb.log_keys[1], SPEC_EMPTY, (size_t)W*cap);} // all droplets trace into buffer 1 - cur = 1
 				else {be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});}
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_trace_body(s, (uint32_t)i);}, 64);
+				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, ws);});
 				uint32_t hc[4];
 				be.d2h(hc, sb.counters, sizeof(hc));
 				report.traces += hc[2]; report.traced_steps += hc[3];
@@ -453,7 +449,7 @@ template<class BE> struct terra_engine {
 			// flush committed droplets [0, cut)
 			if (sb.cut > 0) {
 				spec_buffers_t const s = sb;
-				be.launch((size_t)sb.cut*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)), false);});
+				be.launch((size_t)sb.cut*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
 				h_nsteps.resize(sb.cut); h_flags.resize(sb.cut);
 				be.d2h(h_nsteps.data(), sb.nsteps, sb.cut*4); be.d2h(h_flags.data(), sb.flags, sb.cut*4);
 				for (uint32_t i = 0; i < sb.cut; ++i) {report.steps += h_nsteps[i]; report.nan_droplets += (h_flags[i] & SPEC_F_NAN) ? 1 : 0;}
@@ -463,7 +459,7 @@ template<class BE> struct terra_engine {
 				uint32_t const it = done;
 				grid_view_t const gg = g; erosion_consts_t const ee = ec;
 				uint32_t *cnt = sb.counters;
-				be.launch(1, [=] TERRA_LAMBDA (size_t) {direct_mem_t m{gg}; droplet_result_t const r = simulate_droplet((int)it, m, ee); cnt[4] = r.steps; cnt[5] = (uint32_t)r.nan_seen;}, 64);
+				be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {direct_droplet_wave(gg, ee, it, cnt + 4, ws);});
 				uint32_t hr[2];
 				be.d2h(hr, sb.counters + 4, sizeof(hr));
 				report.steps += hr[0]; report.traced_steps += hr[0]; report.nan_droplets += hr[1];

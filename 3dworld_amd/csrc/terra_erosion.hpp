@@ -56,9 +56,17 @@ struct erosion_consts_t {
 
 struct droplet_result_t {unsigned steps; int nan_seen;};
 
+TERRA_HD int clampi(int v, int hi) {return imax(imin(v, hi), 0);} // HMAP_INDEX clamp (src/erosion.cpp:39)
+TERRA_HD int sati(int v, int n) {return imax(imin(v, n + 8), -8);}   // keeps xi-1 / xi+2 free of signed overflow when a NaN position became INT_MIN; clamping afterwards is unchanged
+
 // ------------------------------------------------------------------ one droplet (src/erosion.cpp:67-155)
-// MEM supplies: float read(int X, int Z) ; void write(int X, int Z, float v) ; bool begin_step(int xi, int zi) (false => abort trace)
-// X/Z passed to read/write are already clamped into the padded grid (HMAP_INDEX).
+// The scalar state machine below is the reference's loop verbatim; everything that touches the grid goes through MEM:
+//   bool begin_step(xi, zi)                 footprint / residency hook for the step's 4x4 brush box; false => abort the trace
+//   void corners(x, z, out[4])              HMAP(x,z), HMAP(x+1,z), HMAP(x,z+1), HMAP(x+1,z+1) (indices clamped, src/erosion.cpp:39-40)
+//   void deposit(xi, zi, xf, zf, dse)       DEPOSIT_AT x4 with dse = ds*erode_amount (src/erosion.cpp:42-54)
+//   void erode(xi, zi, xp, zp, dse)         the 4x4 radial brush (src/erosion.cpp:134-147)
+// MEM is either scalar (one lane does everything) or wave-cooperative (64 lanes run this scalar code redundantly and
+// split the brush / corner accesses between them); both give identical results.
 template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &mem, erosion_consts_t const &ec) {
 	float const Kq = 10, Kw = 0.001f, Kr = 0.9f, Kd = 0.02f, Ki = 0.1f, minSlope = 0.05f, g = 20, Kg = g*2;
 	float const evap = 1 - Kw;
@@ -69,23 +77,10 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 	int xi = EROSION_PAD + (rgen.rand() % ec.xsize);
 	int zi = EROSION_PAD + (rgen.rand() % ec.ysize);
 	float xp = (float)xi, zp = (float)zi, xf = 0, zf = 0, s = 0, v = 0, w = 1, dx = 0, dz = 0;
-
-#define TERRA_CX(x) imax(imin((x), NX-1), 0)
-#define TERRA_CZ(z) imax(imin((z), NY-1), 0)
-#define TERRA_HMAP(x, z) mem.read(TERRA_CX(x), TERRA_CZ(z))
-#define TERRA_DEPOSIT_AT(X, Z, W) { \
-	float const delta = ds*ec.erode_amount*(W); \
-	if (!((X) < 0 || (Z) < 0 || (X) >= NX || (Z) >= NY)) {float const old = mem.read((X), (Z)); mem.write((X), (Z), old + delta);} \
-}
-#define TERRA_DEPOSIT(H) \
-	TERRA_DEPOSIT_AT(xi  , zi  , (1-xf)*(1-zf)) \
-	TERRA_DEPOSIT_AT(xi+1, zi  ,    xf *(1-zf)) \
-	TERRA_DEPOSIT_AT(xi  , zi+1, (1-xf)*   zf ) \
-	TERRA_DEPOSIT_AT(xi+1, zi+1,    xf *   zf ) \
-	(H) += ds;
-
 	if (!mem.begin_step(xi, zi)) {return res;}
-	float h = TERRA_HMAP(xi, zi), h00 = h, h10 = TERRA_HMAP(xi+1, zi), h01 = TERRA_HMAP(xi, zi+1), h11 = TERRA_HMAP(xi+1, zi+1);
+	float c[4];
+	mem.corners(xi, zi, c);
+	float h = c[0], h00 = c[0], h10 = c[1], h01 = c[2], h11 = c[3];
 	unsigned numMoves = 0;
 
 	for (; numMoves < ec.max_path_len; ++numMoves) {
@@ -102,7 +97,8 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 		float const nxp = xp+dx, nzp = zp+dz;
 		int const nxi = f2i_x86(floorf(nxp)), nzi = f2i_x86(floorf(nzp));
 		float const nxf = nxp-(float)nxi, nzf = nzp-(float)nzi;
-		float const nh00 = TERRA_HMAP(nxi, nzi), nh10 = TERRA_HMAP(nxi+1, nzi), nh01 = TERRA_HMAP(nxi, nzi+1), nh11 = TERRA_HMAP(nxi+1, nzi+1);
+		mem.corners(nxi, nzi, c);
+		float const nh00 = c[0], nh10 = c[1], nh01 = c[2], nh11 = c[3];
 		float const nh = (nh00*(1-nxf)+nh10*nxf)*(1-nzf)+(nh01*(1-nxf)+nh11*nxf)*nzf;
 		if (max_std(max_std(nh00, nh10), max_std(nh01, nh11)) < ec.water_thresh) break; // reached ocean water, sediment discarded
 
@@ -111,11 +107,11 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 			float ds = (nh-h)+0.001f;
 			if (ds >= s || outside) {
 				ds = s;
-				TERRA_DEPOSIT(h)
+				mem.deposit(xi, zi, xf, zf, ds*ec.erode_amount); h += ds; // deposit all sediment
 				s = 0;
 				break;
 			}
-			TERRA_DEPOSIT(h)
+			mem.deposit(xi, zi, xf, zf, ds*ec.erode_amount); h += ds;
 			s -= ds;
 			v = 0;
 		}
@@ -124,7 +120,7 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 		float ds = s-q;
 		if (ds >= 0) {
 			ds *= Kd;
-			TERRA_DEPOSIT(dh)
+			mem.deposit(xi, zi, xf, zf, ds*ec.erode_amount); dh += ds;
 			s -= ds;
 		}
 		else {
@@ -132,19 +128,7 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 			ds = min_std(ds, dh*0.99f);
 			float const relh = ec.relh_adj_tex + (nh - ec.zmin)/ec.zrange;
 			ds = (float)((double)ds*((relh > ec.clip_hd1) ? 0.5 : 2.0)); // rock erodes slower than dirt
-			for (int z = zi-1; z <= zi+2; ++z) {
-				float const zo = (float)z-zp, zo2 = zo*zo;
-				for (int x = xi-1; x <= xi+2; ++x) {
-					float const xo = (float)x-xp;
-					float wb = 1-(xo*xo+zo2)*0.25f;
-					if (wb <= 0) continue;
-					wb *= 0.1591549430918953f;
-					float const delta = ds*ec.erode_amount*wb;
-					int const cx = TERRA_CX(x), cz = TERRA_CZ(z);
-					float const old = mem.read(cx, cz);
-					mem.write(cx, cz, old - delta);
-				}
-			}
+			mem.erode(xi, zi, xp, zp, ds*ec.erode_amount);
 			dh -= ds;
 			s  += ds;
 		}
@@ -156,25 +140,193 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 	}
 	res.steps = numMoves;
 	return res;
-#undef TERRA_CX
-#undef TERRA_CZ
-#undef TERRA_HMAP
-#undef TERRA_DEPOSIT_AT
-#undef TERRA_DEPOSIT
 }
 
-// ------------------------------------------------------------------ serial policy: reads/writes hit the grid directly
+// brush weight of cell (x,z) for a droplet at (xp,zp): w = max(0, 1 - (xo^2+zo^2)/4) * 1/(2 pi) (src/erosion.cpp:135-141); <= 0 => untouched
+TERRA_HD float brush_weight(int x, int z, float xp, float zp) {
+	float const zo = (float)z-zp, zo2 = zo*zo, xo = (float)x-xp;
+	float wb = 1-(xo*xo+zo2)*0.25f;
+	if (wb <= 0) return 0.0f;
+	return wb*0.1591549430918953f;
+}
+TERRA_HD float deposit_weight(int q, float xf, float zf) { // (1-xf)*(1-zf), xf*(1-zf), (1-xf)*zf, xf*zf
+	return ((q & 1) ? xf : (1-xf))*((q & 2) ? zf : (1-zf));
+}
+
+// ------------------------------------------------------------------ scalar policy: one lane, reads/writes hit the grid directly.
+// Used by the TERRA_ERODE_SERIAL walk and the one-thread-per-tile cross-check path: an implementation independent of the wave code.
 struct direct_mem_t {
 	grid_view_t g;
-	TERRA_HD bool  begin_step(int, int) {return true;}
-	TERRA_HD float read(int X, int Z) const {return *g.at(X, Z);}
-	TERRA_HD void  write(int X, int Z, float v) {*g.at(X, Z) = v;}
+	TERRA_HD bool begin_step(int, int) {return true;}
+	TERRA_HD void corners(int x, int z, float out[4]) const {
+		int const x0 = clampi(x, g.NX-1), x1 = clampi(x+1, g.NX-1), z0 = clampi(z, g.NY-1), z1 = clampi(z+1, g.NY-1);
+		out[0] = *g.at(x0, z0); out[1] = *g.at(x1, z0); out[2] = *g.at(x0, z1); out[3] = *g.at(x1, z1);
+	}
+	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {
+		for (int q = 0; q < 4; ++q) {
+			int const X = xi + (q & 1), Z = zi + (q >> 1);
+			float const delta = dse*deposit_weight(q, xf, zf);
+			if (!(X < 0 || Z < 0 || X >= g.NX || Z >= g.NY)) {*g.at(X, Z) += delta;}
+		}
+	}
+	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {
+		for (int z = zi-1; z <= zi+2; ++z) {
+			for (int x = xi-1; x <= xi+2; ++x) {
+				float const wb = brush_weight(x, z, xp, zp);
+				if (wb <= 0) continue;
+				*g.at(clampi(x, g.NX-1), clampi(z, g.NY-1)) -= dse*wb;
+			}
+		}
+	}
 };
 
-// ------------------------------------------------------------------ speculative policy
+// ================================================================== wave-cooperative execution
+// One droplet = one 64-lane wave (workgroups of the wave kernels are exactly one wave, so __syncthreads() is the wave's
+// LDS / global visibility point).  All lanes run simulate_droplet's scalar code redundantly (identical registers, no
+// divergence); TERRA_LANES splits the memory-heavy parts across lanes.  On the host (test emulator) a "wave" is one
+// call and TERRA_LANES is a plain loop in lane order, which visits brush cells in the reference's z-major order.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TERRA_LANES(l, n) for (int l = (int)(threadIdx.x & 63); l < (int)(n); l += 64)
+#define TERRA_LANE0 ((threadIdx.x & 63) == 0)
+#define TERRA_WAVE_SYNC() __syncthreads()
+#define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define TERRA_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define TERRA_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define TERRA_ATOMIC_EXCH(p, v) atomicExch((p), (v))
+#define TERRA_ATOMIC_CAS(p, c, v) atomicCAS((p), (c), (v))
+#else
+#define TERRA_LANES(l, n) for (int l = 0; l < (int)(n); ++l)
+#define TERRA_LANE0 true
+#define TERRA_WAVE_SYNC() do {} while (0)
+template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
+template<class T> inline T terra_host_atomic_add(T *p, T v) {T o = *p; *p = o + v; return o;}
+template<class T> inline T terra_host_atomic_or(T *p, T v) {T o = *p; *p = o | v; return o;}
+template<class T> inline T terra_host_atomic_exch(T *p, T v) {T o = *p; *p = v; return o;}
+template<class T> inline T terra_host_atomic_cas(T *p, T c, T v) {T o = *p; if (o == c) *p = v; return o;}
+#define TERRA_ATOMIC_MIN(p, v) terra_host_atomic_min((p), (v))
+#define TERRA_ATOMIC_ADD(p, v) terra_host_atomic_add((p), (v))
+#define TERRA_ATOMIC_OR(p, v) terra_host_atomic_or((p), (v))
+#define TERRA_ATOMIC_EXCH(p, v) terra_host_atomic_exch((p), (v))
+#define TERRA_ATOMIC_CAS(p, c, v) terra_host_atomic_cas((p), (c), (v))
+#endif
+
+// lane-parallel deposit / brush on a cell store addressed through DERIVED::cell(X,Z) (an LDS pointer), + DERIVED::mark(X,Z)
+template<class DERIVED> struct wave_cell_ops {
+	TERRA_HD DERIVED &self() {return *static_cast<DERIVED *>(this);}
+	TERRA_HD void deposit_cells(int xi, int zi, float xf, float zf, float dse, int NX, int NY) {
+		TERRA_LANES(q, 4) { // the four cells are distinct: no write conflicts between lanes
+			int const X = xi + (q & 1), Z = zi + (q >> 1);
+			float const delta = dse*deposit_weight(q, xf, zf);
+			if (!(X < 0 || Z < 0 || X >= NX || Z >= NY)) {*self().cell(X, Z) += delta; self().mark(X, Z);}
+		}
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD void erode_cells(int xi, int zi, float xp, float zp, float dse, int NX, int NY) {
+		if (xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1) { // interior: 16 distinct cells, one lane each
+			TERRA_LANES(l, 16) {
+				int const x = xi-1 + (l & 3), z = zi-1 + (l >> 2);
+				float const wb = brush_weight(x, z, xp, zp);
+				if (wb > 0) {*self().cell(x, z) -= dse*wb; self().mark(x, z);}
+			}
+		}
+		else if (TERRA_LANE0) { // clamping may fold several brush cells onto one grid cell: keep the reference's loop order on one lane
+			for (int z = zi-1; z <= zi+2; ++z) {
+				for (int x = xi-1; x <= xi+2; ++x) {
+					float const wb = brush_weight(x, z, xp, zp);
+					if (wb <= 0) continue;
+					int const cx = clampi(x, NX-1), cz = clampi(z, NY-1);
+					*self().cell(cx, cz) -= dse*wb; self().mark(cx, cz);
+				}
+			}
+		}
+		TERRA_WAVE_SYNC();
+	}
+};
+
+// ---- tile mode: the whole clamp-padded grid is resident in LDS
+struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
+	float *pad; int NX, NY;
+	TERRA_HD float *cell(int X, int Z) const {return pad + Z*NX + X;}
+	TERRA_HD void mark(int, int) {}
+	TERRA_HD bool begin_step(int, int) {return true;}
+	TERRA_HD void corners(int x, int z, float out[4]) const {
+		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
+		out[0] = *cell(x0, z0); out[1] = *cell(x1, z0); out[2] = *cell(x0, z1); out[3] = *cell(x1, z1);
+	}
+	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
+	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {erode_cells(xi, zi, xp, zp, dse, NX, NY);}
+};
+
+// ---- big grids: a WS x WS window of the grid follows the droplet in LDS; BACK is where cells come from / go to.
+constexpr int EW = 32; // window edge (cells): 4 KiB of LDS per droplet; a droplet moves one cell per step, so a centred window lasts >= 13 steps
+struct wave_shared_t { // per-wave LDS scratch
+	uint32_t nlog, flags, pad_;
+	unsigned long long chk;
+	uint8_t blk_shared[64];
+};
+
+template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
+	float *win; uint8_t *dirty; // LDS: EW*EW each
+	int wx0, wz0, NX, NY; bool have;
+	BACK back;
+	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; dirty = d; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
+	TERRA_HD bool in_window(int X, int Z) const {return have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;}
+	TERRA_HD float *cell(int X, int Z) const {return win + (Z - wz0)*EW + (X - wx0);}
+	TERRA_HD void mark(int X, int Z) {dirty[(Z - wz0)*EW + (X - wx0)] = 1;}
+	TERRA_HD void flush() {
+		if (have) {
+			TERRA_LANES(i, EW*EW) {if (dirty[i]) {back.store(wx0 + (i % EW), wz0 + (i / EW), win[i]); dirty[i] = 0;}}
+		}
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD void recenter(int cx, int cz) {
+		flush();
+		wx0 = clampi(cx - EW/2, imax(NX - EW, 0)); wz0 = clampi(cz - EW/2, imax(NY - EW, 0));
+		back.prepare_window(wx0, wz0);
+		TERRA_LANES(i, EW*EW) {
+			int const X = wx0 + (i % EW), Z = wz0 + (i / EW);
+			dirty[i] = 0;
+			if (X < NX && Z < NY) {win[i] = back.load(X, Z);}
+		}
+		have = true;
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD bool begin_step(int xi, int zi) {
+		xi = sati(xi, NX); zi = sati(zi, NY);
+		if (!back.begin_step(xi, zi)) return false;
+		int const bx0 = clampi(xi-1, NX-1), bx1 = clampi(xi+2, NX-1), bz0 = clampi(zi-1, NY-1), bz1 = clampi(zi+2, NY-1);
+		if (!(have && bx0 >= wx0 && bx1 < wx0 + EW && bz0 >= wz0 && bz1 < wz0 + EW)) {recenter((bx0 + bx1)/2, (bz0 + bz1)/2);}
+		return !back.failed();
+	}
+	TERRA_HD float read_any(int X, int Z) { // outside the window only after a NaN position (index INT_MIN clamps to 0): slow path, still part of the footprint
+		if (in_window(X, Z)) return *cell(X, Z);
+		back.note_far_read(X, Z);
+		return back.load(X, Z);
+	}
+	TERRA_HD void corners(int x, int z, float out[4]) {
+		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
+		out[0] = read_any(x0, z0); out[1] = read_any(x1, z0); out[2] = read_any(x0, z1); out[3] = read_any(x1, z1);
+	}
+	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {this->deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
+	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {this->erode_cells(xi, zi, xp, zp, dse, NX, NY);}
+	TERRA_HD void finish() {flush();}
+};
+
+// backing store = the grid itself (serial fall-back droplet: it is the lowest uncommitted droplet, nothing to speculate about)
+struct grid_back_t {
+	grid_view_t g;
+	TERRA_HD bool begin_step(int, int) {return true;}
+	TERRA_HD bool failed() const {return false;}
+	TERRA_HD void prepare_window(int, int) {}
+	TERRA_HD void note_far_read(int, int) {}
+	TERRA_HD float load(int X, int Z) const {return *g.at(X, Z);}
+	TERRA_HD void store(int X, int Z, float v) {*g.at(X, Z) = v;}
+};
+
+// ------------------------------------------------------------------ speculative (multi-version) backing store
 constexpr uint32_t SPEC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SPEC_NIL   = 0xFFFFFFFFu;
-constexpr int      SPEC_BCACHE = 8;
+constexpr int      SPEC_BCACHE = 4;
 enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4};
 
 struct spec_buffers_t {
@@ -185,14 +337,14 @@ struct spec_buffers_t {
 	uint32_t cut;          // slots >= cut are excluded (overflowed droplet and everything after it)
 	uint32_t cap_log2;     // log capacity = 1 << cap_log2
 	uint32_t maxb;         // block-list capacity per droplet
-	uint32_t bshift;       // block edge = 1 << bshift cells
+	uint32_t bshift;       // block edge = 1 << bshift cells (>= 3)
 	uint32_t nbx, nby;     // blocks per row / column of the padded grid
 	uint32_t use_lists;    // 0 in round 1 (no cross-droplet reads yet)
 	uint32_t *log_keys[2]; // [W][cap]
 	float    *log_vals[2]; // [W][cap]
 	uint32_t *blk_list[2]; // [W][maxb]
 	uint32_t *blk_cnt[2];  // [W]
-	uint64_t *chk[2];      // [W] order-dependent checksum of the write sequence
+	uint64_t *chk[2];      // [W] checksum of the write-back sequence
 	uint32_t *cur;         // [W] which buffer holds the droplet's current trace
 	uint32_t *need;        // [W] (re)trace in this round
 	uint32_t *changed;     // [W] this round's trace differs from the previous one
@@ -201,25 +353,17 @@ struct spec_buffers_t {
 	uint32_t *head;        // [nbx*nby] block -> first node
 	uint32_t *next;        // [W*maxb]  node -> next node ; node id = slot*maxb + entry
 	uint32_t *dirty_min;   // [nbx*nby] lowest changed droplet slot touching the block this round
-	uint32_t *counters;    // [0] = any_need, [1] = min overflowed slot, [2] = traced this round, [3] = total steps (low), ...
+	uint32_t *counters;    // [0] = any_need, [1] = min overflowed slot, [2] = traced this round, [3] = steps traced, [4..5] = serial fall-back steps / nan
 };
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
-#define TERRA_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#define TERRA_ATOMIC_EXCH(p, v) atomicExch((p), (v))
-#else
-template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
-template<class T> inline T terra_host_atomic_add(T *p, T v) {T o = *p; *p = o + v; return o;}
-template<class T> inline T terra_host_atomic_exch(T *p, T v) {T o = *p; *p = v; return o;}
-#define TERRA_ATOMIC_MIN(p, v) terra_host_atomic_min((p), (v))
-#define TERRA_ATOMIC_ADD(p, v) terra_host_atomic_add((p), (v))
-#define TERRA_ATOMIC_EXCH(p, v) terra_host_atomic_exch((p), (v))
-#endif
-
+// splitmix64 finaliser.  The per-store terms of the trace checksum must be mixed non-linearly: a lower droplet's change often moves
+// some cells up one ulp and others down one ulp, which a linear (multiplicative) term sum cannot see.
+TERRA_HD uint64_t spec_mix64(uint64_t x) {
+	x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+	return x;
+}
 TERRA_HD uint32_t spec_hash(uint32_t cell, uint32_t cap_log2) {return (cell*2654435761u) >> (32 - cap_log2);}
 
-// probe a droplet's log for `cell`; returns slot index or SPEC_EMPTY-terminated miss (found=false)
 TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t cap_log2, uint32_t cell, float &out) {
 	uint32_t const mask = (1u << cap_log2) - 1;
 	uint32_t h = spec_hash(cell, cap_log2);
@@ -231,116 +375,144 @@ TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t ca
 	return false;
 }
 
-struct spec_mem_t {
+struct spec_back_t {
 	spec_buffers_t const *sb;
-	uint32_t slot;         // this droplet's window slot
+	wave_shared_t *sh;     // LDS
+	uint32_t slot;
 	uint32_t *my_keys; float *my_vals; uint32_t *my_blks; // the "new" buffers (1 - cur)
-	uint32_t nlog, nblk, flags;
-	uint64_t chk;
-	uint32_t bc_id[SPEC_BCACHE]; // recently touched blocks ...
-	uint8_t  bc_shared[SPEC_BCACHE]; // ... and whether a lower-numbered droplet also touched them
-	uint32_t bc_pos;
+	uint32_t nblk;
+	uint32_t bc_id[SPEC_BCACHE]; uint32_t bc_pos;
+	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
 
-	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_) {
-		sb = sb_; slot = slot_;
+	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_, wave_shared_t *sh_) {
+		sb = sb_; slot = slot_; sh = sh_;
 		uint32_t const nb = 1u - sb->cur[slot];
 		size_t const cap = (size_t)1 << sb->cap_log2;
 		my_keys = sb->log_keys[nb] + (size_t)slot*cap;
 		my_vals = sb->log_vals[nb] + (size_t)slot*cap;
 		my_blks = sb->blk_list[nb] + (size_t)slot*sb->maxb;
-		nlog = 0; nblk = 0; flags = 0; chk = 1469598103934665603ull; bc_pos = 0;
-		for (int i = 0; i < SPEC_BCACHE; ++i) {bc_id[i] = SPEC_NIL; bc_shared[i] = 0;}
+		nblk = 0; bc_pos = 0; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
+		for (int i = 0; i < SPEC_BCACHE; ++i) {bc_id[i] = SPEC_NIL;}
+		if (TERRA_LANE0) {sh->nlog = 0; sh->flags = 0; sh->chk = 0;}
+		TERRA_WAVE_SYNC();
 	}
-	// does any lower-numbered droplet of the window have this block in its (previous-round) footprint?
-	TERRA_HD bool block_shared(uint32_t b) const {
-		if (!sb->use_lists) return false;
-		for (uint32_t node = sb->head[b]; node != SPEC_NIL; node = sb->next[node]) {
-			if (node / sb->maxb < slot) return true;
-		}
-		return false;
+	TERRA_HD bool failed() const {return (sh->flags & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) != 0;}
+	TERRA_HD void touch_block(uint32_t b) { // wave-uniform bookkeeping; lane 0 owns the global write
+		for (int i = 0; i < SPEC_BCACHE; ++i) {if (bc_id[i] == b) return;}
+		bc_id[bc_pos++ % SPEC_BCACHE] = b;
+		if (nblk >= sb->maxb) {if (TERRA_LANE0) {sh->flags |= SPEC_F_BLK_OVERFLOW;} return;}
+		if (TERRA_LANE0) {my_blks[nblk] = b;}
+		++nblk;
 	}
-	TERRA_HD int touch_block(uint32_t b) { // returns cache index
-		for (int i = 0; i < SPEC_BCACHE; ++i) {if (bc_id[i] == b) return i;}
-		int const i = (int)(bc_pos++ % SPEC_BCACHE);
-		bc_id[i] = b; bc_shared[i] = block_shared(b) ? 1 : 0;
-		if (nblk >= sb->maxb) {flags |= SPEC_F_BLK_OVERFLOW; return i;}
-		my_blks[nblk++] = b;
-		return i;
-	}
+	TERRA_HD void note_far_read(int X, int Z) {touch_block((uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift)); TERRA_WAVE_SYNC();}
 	TERRA_HD bool begin_step(int xi, int zi) { // footprint of one step = the 4x4 brush box, which also covers every read of that step
-		int const x0 = imax(imin(xi-1, sb->ec.NX-1), 0) >> sb->bshift, x1 = imax(imin(xi+2, sb->ec.NX-1), 0) >> sb->bshift;
-		int const z0 = imax(imin(zi-1, sb->ec.NY-1), 0) >> sb->bshift, z1 = imax(imin(zi+2, sb->ec.NY-1), 0) >> sb->bshift;
+		int const x0 = clampi(xi-1, sb->ec.NX-1) >> sb->bshift, x1 = clampi(xi+2, sb->ec.NX-1) >> sb->bshift;
+		int const z0 = clampi(zi-1, sb->ec.NY-1) >> sb->bshift, z1 = clampi(zi+2, sb->ec.NY-1) >> sb->bshift;
 		touch_block((uint32_t)z0*sb->nbx + x0);
 		if (x1 != x0) {touch_block((uint32_t)z0*sb->nbx + x1);}
 		if (z1 != z0) {
 			touch_block((uint32_t)z1*sb->nbx + x0);
 			if (x1 != x0) {touch_block((uint32_t)z1*sb->nbx + x1);}
 		}
-		return (flags & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) == 0;
+		TERRA_WAVE_SYNC();
+		return !failed();
 	}
-	TERRA_HD float read(int X, int Z) {
+	// which blocks under the new window are also in a LOWER droplet's footprint (only those need the multi-version lookup)
+	TERRA_HD void prepare_window(int wx0, int wz0) {
+		wbx0 = wx0 >> sb->bshift; wbz0 = wz0 >> sb->bshift;
+		TERRA_LANES(i, wnb*wnb) {
+			uint8_t shared = 0;
+			uint32_t const bx = (uint32_t)(wbx0 + i % wnb), bz = (uint32_t)(wbz0 + i / wnb);
+			if (sb->use_lists && bx < sb->nbx && bz < sb->nby) {
+				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {if (node / sb->maxb < slot) {shared = 1; break;}}
+			}
+			sh->blk_shared[i] = shared;
+		}
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD float load(int X, int Z) const {
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
 		float v;
-		if (nlog && spec_log_find(my_keys, my_vals, sb->cap_log2, cell, v)) return v; // own writes first
-		uint32_t const b = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
-		int const ci = touch_block(b);
-		if (bc_shared[ci]) { // value written by the highest-numbered lower droplet, if any
-			uint32_t best = SPEC_NIL;
-			size_t const cap = (size_t)1 << sb->cap_log2;
-			for (uint32_t node = sb->head[b]; node != SPEC_NIL; node = sb->next[node]) {
-				uint32_t const j = node / sb->maxb;
-				if (j >= slot || (best != SPEC_NIL && j <= best)) continue;
-				uint32_t const cb = sb->cur[j];
-				float vj;
-				if (spec_log_find(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
+		if (sh->nlog && spec_log_find(my_keys, my_vals, sb->cap_log2, cell, v)) return v; // own earlier write-backs first
+		if (sb->use_lists) {
+			int const bx = X >> sb->bshift, bz = Z >> sb->bshift;
+			int const wi = (bz - wbz0)*wnb + (bx - wbx0);
+			bool shared = true; // outside the prepared window (NaN positions): look the block up directly
+			if ((unsigned)(bx - wbx0) < (unsigned)wnb && (unsigned)(bz - wbz0) < (unsigned)wnb) {shared = sh->blk_shared[wi] != 0;}
+			if (shared) { // value written by the highest-numbered lower droplet, if any
+				uint32_t best = SPEC_NIL;
+				size_t const cap = (size_t)1 << sb->cap_log2;
+				for (uint32_t node = sb->head[(uint32_t)bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {
+					uint32_t const j = node / sb->maxb;
+					if (j >= slot || (best != SPEC_NIL && j <= best)) continue;
+					uint32_t const cb = sb->cur[j];
+					float vj;
+					if (spec_log_find(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
+				}
+				if (best != SPEC_NIL) return v;
 			}
-			if (best != SPEC_NIL) return v;
 		}
 		return *sb->grid.at(X, Z);
 	}
-	TERRA_HD void write(int X, int Z, float val) {
+	TERRA_HD void store(int X, int Z, float val) { // called from lanes in parallel, each with a distinct cell
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
-		uint32_t const mask = (1u << sb->cap_log2) - 1;
+		uint32_t const mask = (1u << sb->cap_log2) - 1, limit = mask - (uint32_t)(EW*EW) - 64u;
 		uint32_t vb; memcpy(&vb, &val, 4);
-		chk = (chk ^ (((uint64_t)cell << 32) | vb))*1099511628211ull;
+		TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)spec_mix64(((uint64_t)cell << 32) | vb)); // commutative (lanes add in any order) over NON-LINEARLY mixed terms
 		uint32_t h = spec_hash(cell, sb->cap_log2);
 		for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
-			uint32_t const k = my_keys[h];
+			uint32_t k = my_keys[h];
+			if (k == SPEC_EMPTY) {k = TERRA_ATOMIC_CAS(&my_keys[h], SPEC_EMPTY, cell); if (k == SPEC_EMPTY) {my_vals[h] = val; if (TERRA_ATOMIC_ADD(&sh->nlog, 1u) >= limit) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);} return;}}
 			if (k == cell) {my_vals[h] = val; return;}
-			if (k == SPEC_EMPTY) {
-				if (nlog >= mask - (mask >> 2)) {flags |= SPEC_F_LOG_OVERFLOW; return;} // keep load factor <= 0.75
-				my_keys[h] = cell; my_vals[h] = val; ++nlog; return;
-			}
 		}
-		flags |= SPEC_F_LOG_OVERFLOW;
+		TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);
 	}
 };
 
-// ---- kernel bodies (one call per logical thread; the __global__ wrappers and the CPU emulator both call these)
+// ---- wave bodies: one call per droplet-wave (device: one 64-lane workgroup; host: one call)
 
-// clear the "new" buffers of every droplet that will be traced this round: one thread per (slot, log entry)
+// LDS scratch a wave body needs; the kernels / the emulator provide it
+struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;};
+
+TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, wave_scratch_t const &ws) {
+	if (slot >= sb.cut || !sb.need[slot]) return;
+	window_mem_t<spec_back_t> mem;
+	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
+	mem.back.init(&sb, slot, ws.sh);
+	droplet_result_t const r = simulate_droplet((int)(sb.first_iter + slot), mem, sb.ec);
+	mem.finish();
+	if (TERRA_LANE0) {
+		uint32_t const nb = 1u - sb.cur[slot];
+		uint32_t const fl = ws.sh->flags;
+		sb.blk_cnt[nb][slot] = mem.back.nblk;
+		sb.chk[nb][slot]     = (uint64_t)ws.sh->chk ^ ((uint64_t)r.steps << 40);
+		sb.nsteps[slot]      = r.steps;
+		sb.flags[slot]       = fl | (r.nan_seen ? SPEC_F_NAN : 0);
+		if (fl & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) {TERRA_ATOMIC_MIN(&sb.counters[1], slot);}
+		TERRA_ATOMIC_ADD(&sb.counters[2], 1u);
+		TERRA_ATOMIC_ADD(&sb.counters[3], r.steps);
+	}
+}
+
+// the lowest uncommitted droplet, alone, directly on the grid (overflow fall-back)
+TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &ec, uint32_t iter, uint32_t *out_steps_nan, wave_scratch_t const &ws) {
+	window_mem_t<grid_back_t> mem;
+	mem.init(ws.win, ws.dirty, ec.NX, ec.NY);
+	mem.back.g = g;
+	droplet_result_t const r = simulate_droplet((int)iter, mem, ec);
+	mem.finish();
+	if (TERRA_LANE0 && out_steps_nan) {out_steps_nan[0] = r.steps; out_steps_nan[1] = (uint32_t)r.nan_seen;}
+}
+
+// ---- per-logical-thread bodies of the bookkeeping kernels
+
+// clear the "new" log of every droplet that will be traced this round: one thread per (slot, log entry)
 TERRA_HD void spec_clear_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
 	if (slot >= sb.cut || !sb.need[slot]) return;
 	uint32_t const nb = 1u - sb.cur[slot];
 	sb.log_keys[nb][((size_t)slot << sb.cap_log2) + entry] = SPEC_EMPTY;
 }
-
-TERRA_HD void spec_trace_body(spec_buffers_t const &sb, uint32_t slot) {
-	if (slot >= sb.cut || !sb.need[slot]) return;
-	spec_mem_t mem;
-	mem.init(&sb, slot);
-	droplet_result_t const r = simulate_droplet((int)(sb.first_iter + slot), mem, sb.ec);
-	uint32_t const nb = 1u - sb.cur[slot];
-	sb.blk_cnt[nb][slot] = mem.nblk;
-	sb.chk[nb][slot]     = mem.chk ^ ((uint64_t)r.steps << 40);
-	sb.nsteps[slot]      = r.steps;
-	sb.flags[slot]       = mem.flags | (r.nan_seen ? SPEC_F_NAN : 0);
-	if (mem.flags & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) {TERRA_ATOMIC_MIN(&sb.counters[1], slot);}
-	TERRA_ATOMIC_ADD(&sb.counters[2], 1u);
-	TERRA_ATOMIC_ADD(&sb.counters[3], r.steps);
-}
-
-// after all traces of the round: publish dirty blocks of changed droplets, then flip their buffer
+// after all traces of the round: publish dirty blocks of changed droplets
 TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, bool first_round) {
 	if (slot >= sb.cut || !sb.need[slot]) {if (slot < sb.W) sb.changed[slot] = 0; return;}
 	uint32_t const ob = sb.cur[slot], nb = 1u - ob;
@@ -380,8 +552,8 @@ TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot) {
 	sb.need[slot] = need;
 	if (need) {TERRA_ATOMIC_ADD(&sb.counters[0], 1u);}
 }
-// flush: the highest-numbered writer of a cell stores it; one thread per (slot, log entry). clamp_written applies max(min_zval, .)
-TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry, bool clamp_written) {
+// flush: the highest-numbered writer of a cell stores it; one thread per (slot, log entry)
+TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
 	if (slot >= sb.cut) return;
 	uint32_t const cb = sb.cur[slot];
 	size_t const cap = (size_t)1 << sb.cap_log2;
@@ -396,9 +568,7 @@ TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		float vj;
 		if (spec_log_find(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later droplet owns the final value
 	}
-	float v = sb.log_vals[cb][(size_t)slot*cap + entry];
-	if (clamp_written) {v = max_std(sb.ec.min_zval, v);}
-	*sb.grid.at((int)X, (int)Z) = v;
+	*sb.grid.at((int)X, (int)Z) = sb.log_vals[cb][(size_t)slot*cap + entry];
 }
 
 // ring initialisation = the clamp-padded copy of src/erosion.cpp:31-37 restricted to the ring; one thread per ring float

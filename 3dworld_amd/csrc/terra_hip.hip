@@ -55,6 +55,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 
+	template<class F> void launch_waves(size_t n, F f) {
+		if (n == 0) return;
+		use();
+		if (n > 0x7FFFFFFFull) throw std::invalid_argument("launch_waves: grid too large");
+		hipLaunchKernelGGL(terra::k_waves<F>, dim3((unsigned)n), dim3(64), 0, stream, f);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
+
 	void sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out) {
 		if (simple_kernels) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return;}
 		use();
@@ -88,6 +96,13 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			return;
 		}
 		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
+	void minmax(float const *vals, size_t n, uint32_t *d) {
+		if (simple_kernels || ((uintptr_t)vals & 15)) {minmax_simple(vals, n, d); return;}
+		use();
+		unsigned const blocks = (unsigned)std::min<size_t>((n/4 + 255)/256 + 1, 256*8);
+		hipLaunchKernelGGL(terra::k_minmax, dim3(blocks), dim3(256), 0, stream, vals, n, d);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {

@@ -18,6 +18,15 @@ template<class F> __global__ void k_generic(size_t n, F f) {
 	if (i < n) {f(i);}
 }
 
+// one 64-lane workgroup (= one wave) per item, with the per-wave LDS scratch of the droplet window (terra_erosion.hpp)
+template<class F> __global__ __launch_bounds__(64) void k_waves(F f) {
+	__shared__ __attribute__((aligned(16))) float win[EW*EW];
+	__shared__ uint8_t dirty[EW*EW];
+	__shared__ wave_shared_t sh;
+	wave_scratch_t const ws{win, dirty, &sh};
+	f((size_t)blockIdx.x, ws);
+}
+
 // ------------------------------------------------------------------ K1: sine-sum grid
 constexpr int SG_BX = 128, SG_BY = 64, SG_TX = 8, SG_TY = 4, SG_THREADS = 256; // 16 x 16 threads, 8 x 4 cells each
 constexpr int SG_ROWGROUP = 4; // tile rows walked together so an X tile is reused from L2 before moving on
@@ -116,9 +125,8 @@ __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, 
 		te_pad[i] = z[(size_t)imax(imin(Z - EROSION_PAD, ys-1), 0)*xs + imax(imin(X - EROSION_PAD, xs-1), 0)];
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) { // droplet order is the semantics: one lane walks them; LDS latency (not HBM) bounds every step
-		grid_view_t g; g.interior = te_pad; g.border = nullptr; g.xsize = xs; g.ysize = ys; g.NX = NX; g.NY = NY;
-		direct_mem_t m{g};
+	{ // droplet order is the semantics: droplets run one after another; within a droplet the wave's lanes share the brush / corner accesses (LDS latency, not HBM, bounds a step)
+		wave_lds_mem_t m; m.pad = te_pad; m.NX = NX; m.NY = NY;
 		for (uint32_t it = 0; it < iters; ++it) {simulate_droplet((int)it, m, ec);}
 	}
 	__syncthreads();
@@ -126,6 +134,26 @@ __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, 
 		int const x = i % xs, y = i / xs;
 		z[i] = max_std(ec.min_zval, te_pad[(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
 	}
+}
+
+// ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell
+// grid-stride float4 loads, wave shuffle reduction, one pair of atomics per wave.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
+__global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, size_t n, uint32_t *__restrict__ d) {
+	uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+	size_t const n4 = n/4, stride = (size_t)gridDim.x*blockDim.x;
+	for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n4; i += stride) {
+		float4 const v = ((float4 const *)vals)[i];
+		float const e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {if (e[j] == e[j]) {uint32_t const o = f2ord(e[j]); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {float const t = vals[n4*4 + threadIdx.x]; if (t == t) {uint32_t const o = f2ord(t); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		uint32_t const l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
+		lo = (l2 < lo) ? l2 : lo; hi = (h2 < hi) ? h2 : hi;
+	}
+	if ((threadIdx.x & 63) == 0) {atomicMin(&d[0], lo); atomicMin(&d[1], hi);}
 }
 
 // ------------------------------------------------------------------ K8: voxel sine field. One block per (x,y) column pair group; lanes run along z (the fastest output axis)

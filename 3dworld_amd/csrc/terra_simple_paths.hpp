@@ -57,6 +57,21 @@ template<class DERIVED> struct simple_paths {
 			zvals[i] = max_std(ec.min_zval, padded[(size_t)t*NX*NY + (size_t)(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
 		});
 	}
+	// min / max of a float array as order-preserving uints (NaNs skipped): one logical thread per 2048-element chunk
+	void minmax_simple(float const *vals, size_t n, uint32_t *d) {
+		size_t const chunk = 2048, nchunks = (n + chunk - 1)/chunk;
+		self().launch(nchunks, [=] TERRA_LAMBDA (size_t c) {
+			size_t const b = c*chunk, e = (b + chunk < n) ? b + chunk : n;
+			bool have = false; float lo = 0, hi = 0;
+			for (size_t i = b; i < e; ++i) {
+				float const v = vals[i];
+				if (v != v) continue;
+				if (!have) {lo = hi = v; have = true;}
+				lo = min_std(lo, v); hi = max_std(hi, v);
+			}
+			if (have) {TERRA_ATOMIC_MIN(&d[0], f2ord(lo)); TERRA_ATOMIC_MIN(&d[1], ~f2ord(hi));} // max as min of the complement
+		});
+	}
 	// voxel sine field: val = sum_k xv[k]*yv[k]*zv[k] (src/upsurface.cpp:60-70); d_tab = [nx + ny + nz][60]
 	void voxel_sines_simple(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {
 		self().launch((size_t)nx*ny*nz, [=] TERRA_LAMBDA (size_t i) {

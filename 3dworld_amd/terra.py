@@ -6,7 +6,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES = 1, 2, 4, 8
-ERODE_SERIAL, ERODE_MINZ_IS_MIN = 1, 2
+ERODE_SERIAL, ERODE_MINZ_IS_MIN, ERODE_SERIAL_WAVE = 1, 2, 4
 MGEN_SINE, MGEN_SIMPLEX, MGEN_PERLIN, MGEN_SIMPLEX_GPU, MGEN_DWARP_GPU = range(5)
 
 
@@ -103,6 +103,7 @@ _PROTOS = {
     "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
+    "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "terra_minmax_dev": (_i32, [_vp, _vp, _sz, _f3, _f3]),
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
@@ -224,6 +225,9 @@ class Terra:
         ys, xs = hmap.shape
         self._ck(self.lib.terra_apply_erosion(self.ctx, hmap.ctypes.data, xs, ys, min_zval, iters))
         return hmap
+
+    def set_erosion_tuning(self, window=0, log_capacity_log2=0, block_list_capacity=0):
+        self._ck(self.lib.terra_set_erosion_tuning(self.ctx, window, log_capacity_log2, block_list_capacity))
 
     def erosion_report(self):
         r = ErosionReport()

@@ -89,6 +89,7 @@ typedef struct terra_gen terra_gen;
 #define TERRA_GEN_CACHE_VALUES 8u  /* cache_values (accepted, no effect: every cell is always evaluated on the device) */
 /* flags of terra_apply_erosion*_dev */
 #define TERRA_ERODE_SERIAL        1u /* walk droplets one by one on one lane (reference order, no speculation): debugging / tiny grids */
+#define TERRA_ERODE_SERIAL_WAVE   4u /* droplets one after another, each simulated by a whole wave through the LDS window (no speculation) */
 #define TERRA_ERODE_MINZ_IS_MIN   2u /* caller guarantees min_zval <= every grid value (heightmap_t::run_erosion passes min(vals)): clamp only written cells */
 
 const char *terra_last_error(void);
@@ -132,6 +133,9 @@ int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint
 int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
+/* tuning of the speculative scheduler (0 keeps a value): droplets per window, log2 of the per-droplet write-log capacity (>= 12),
+ * per-droplet block-list capacity.  A droplet that overflows either runs alone, in order, directly on the grid (still exact). */
+int  terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t log_capacity_log2, uint32_t block_list_capacity);
 
 /* ---- whole heightmap: heightmap_t::proc_gen (src/heightmap.cpp:130-151) minus run_city_gen.
  * d_vals: width*height floats (final z); d_pixels16: optional 2 bytes per pixel {lo, hi} (from_floats/write_pixel_16_bits);

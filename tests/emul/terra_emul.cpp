@@ -26,15 +26,34 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
 	// sequential on purpose: bodies use non-atomic stand-ins for atomics (terra_erosion.hpp)
 	template<class F> void launch(size_t n, F f, int = 256) {for (size_t i = 0; i < n; ++i) f(i);}
+	// a "wave" is one call; its LDS scratch is a few stack arrays
+	template<class F> void launch_waves(size_t n, F f) {
+		std::vector<float> win(terra::EW*terra::EW); std::vector<uint8_t> dirty(terra::EW*terra::EW); terra::wave_shared_t sh;
+		terra::wave_scratch_t const ws{win.data(), dirty.data(), &sh};
+		for (size_t i = 0; i < n; ++i) f(i, ws);
+	}
 
 	void sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out);}
 	void noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out) {noise_grid_simple(job, nc, L, smx, smy, out);}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
 		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
-		std::vector<float> padded((size_t)n*ec.NX*ec.NY);
-		tile_erosion_simple(n, zvals, ec, iters, padded.data());
+		// even tiles: the wave-cooperative LDS code path of k_tile_erosion (lanes run sequentially here); odd tiles: the scalar cross-check path
+		std::vector<float> padded((size_t)ec.NX*ec.NY);
+		for (uint32_t t = 0; t < n; ++t) {
+			float *z = zvals + (size_t)t*ec.xsize*ec.ysize;
+			if (t & 1) {tile_erosion_simple(1, z, ec, iters, padded.data()); continue;}
+			for (int Z = 0; Z < ec.NY; ++Z) for (int X = 0; X < ec.NX; ++X) {
+				padded[(size_t)Z*ec.NX + X] = z[(size_t)terra::imax(terra::imin(Z - terra::EROSION_PAD, ec.ysize-1), 0)*ec.xsize + terra::imax(terra::imin(X - terra::EROSION_PAD, ec.xsize-1), 0)];
+			}
+			terra::wave_lds_mem_t m; m.pad = padded.data(); m.NX = ec.NX; m.NY = ec.NY;
+			for (uint32_t it = 0; it < iters; ++it) {terra::simulate_droplet((int)it, m, ec);}
+			for (int y = 0; y < ec.ysize; ++y) for (int x = 0; x < ec.xsize; ++x) {
+				z[(size_t)y*ec.xsize + x] = terra::max_std(ec.min_zval, padded[(size_t)(y + terra::EROSION_PAD)*ec.NX + x + terra::EROSION_PAD]);
+			}
+		}
 	}
+	void minmax(float const *vals, size_t n, uint32_t *d) {minmax_simple(vals, n, d);}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize);}
 };
 typedef cpu_backend_t terra_backend_t;

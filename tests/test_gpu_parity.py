@@ -38,8 +38,12 @@ def test_speculative_erosion_equals_oracle(pkg, gpu, orc, n, iters):
     pc.case_erosion_vs_oracle(pkg, gpu, orc, n, iters)
 
 
-def test_erosion_serial_flag(pkg, gpu, orc):
+def test_erosion_serial_flags_and_overflow_fallback(pkg, gpu, orc):
     pc.case_erosion_vs_oracle(pkg, gpu, orc, 128, 120, flags=pkg.ERODE_SERIAL)
+    pc.case_erosion_vs_oracle(pkg, gpu, orc, 256, 500, flags=pkg.ERODE_SERIAL_WAVE)
+    gpu.set_erosion_tuning(window=64, block_list_capacity=16)
+    r, _ = pc.case_erosion_vs_oracle(pkg, gpu, orc, 512, 400)
+    assert r.serial_fallbacks >= 1 and r.windows >= 7
 
 
 def test_erosion_edge_cases(pkg, gpu, orc):

@@ -32,8 +32,10 @@ def test_speculative_erosion_equals_serial(pkg, emul, orc, n, iters):
 
 def test_erosion_serial_flag_and_overflow_fallback(pkg, emul, orc):
     pc.case_erosion_vs_oracle(pkg, emul, orc, 128, 120, flags=pkg.ERODE_SERIAL)
-    r, _ = pc.case_erosion_vs_oracle(pkg, emul, orc, 512, 1000)  # droplet 0..999 on 512^2: long paths overflow the block list at least once
-    assert r.serial_fallbacks >= 1 and r.windows >= 2
+    pc.case_erosion_vs_oracle(pkg, emul, orc, 128, 120, flags=pkg.ERODE_SERIAL_WAVE)
+    emul.set_erosion_tuning(window=64, block_list_capacity=16)  # tiny block lists + small windows: long droplets overflow and run alone, in order
+    r, _ = pc.case_erosion_vs_oracle(pkg, emul, orc, 512, 400)
+    assert r.serial_fallbacks >= 1 and r.windows >= 7
 
 
 def test_erosion_edge_cases(pkg, emul, orc):
