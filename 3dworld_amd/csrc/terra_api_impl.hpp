@@ -148,6 +148,10 @@ int terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, u
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out); TERRA_CATCH
 }
+int terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max) {
+	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY float mm[2]; ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out, mm); if (h_min) *h_min = mm[0]; if (h_max) *h_max = mm[1]; TERRA_CATCH
+}
 int terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out) {
 	TERRA_CHECK_CTX if (!h_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY
@@ -200,11 +204,10 @@ int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height
 	TERRA_TRY
 		auto &e = ctx->eng;
 		size_t const n = (size_t)width*height;
-		e.gen_grid_dev((float)(-0.5*(double)width), (float)(-0.5*(double)height), e.DX_VAL, e.DY_VAL, width, height, TERRA_GEN_GLACIATE, 0, d_vals); // src/heightmap.cpp:135-143
-		if (erosion_iters > 0) { // run_erosion (src/heightmap.cpp:153-187): min_zval = min(vals)
-			float mn, mx; e.minmax_dev(d_vals, n, mn, mx);
-			e.apply_erosion_dev(d_vals, (int)width, (int)height, mn, erosion_iters, TERRA_ERODE_MINZ_IS_MIN);
-		}
+		float mm[2];
+		bool const erode = erosion_iters > 0 && e.erode_amount > 0.0f;
+		e.gen_grid_dev((float)(-0.5*(double)width), (float)(-0.5*(double)height), e.DX_VAL, e.DY_VAL, width, height, TERRA_GEN_GLACIATE, 0, d_vals, erode ? mm : nullptr); // src/heightmap.cpp:135-143
+		if (erode) {e.apply_erosion_dev(d_vals, (int)width, (int)height, mm[0], erosion_iters, TERRA_ERODE_MINZ_IS_MIN);} // run_erosion (src/heightmap.cpp:153-187): min_zval = min(vals)
 		if (d_pix || h_range) {
 			float mn, mx; e.minmax_dev(d_vals, n, mn, mx); // get_heightmap_z_range
 			float const dz = terra::max_std(1.0E-12f, (mx - mn)); // max(TOLERANCE, ...), src/heightmap.cpp:148

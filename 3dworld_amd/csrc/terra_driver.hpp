@@ -86,14 +86,14 @@ template<class BE> struct terra_engine {
 
 	// grow-only device scratch
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
-	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_tiles, s_vox, s_sk;
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_tiles, s_vox, s_sk, s_mm;
 	template<class T> T *scratch(scratch_t &s, size_t count) {
 		size_t const bytes = std::max<size_t>(count*sizeof(T), 256);
 		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
 		return (T *)s.p;
 	}
 	~terra_engine() {
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_tiles, &s_vox, &s_sk}) {if (s->p) be.free(s->p);}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_tiles, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 	}
 
@@ -265,7 +265,8 @@ template<class BE> struct terra_engine {
 	}
 
 	// build_arrays + [enable_glaciate] + eval_index over the whole grid, device resident, async
-	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out) {
+	// h_minmax (optional): receives {min, max} of the generated grid (NaNs skipped); fused into the grid kernel where the backend can, and SYNCHRONOUS
+	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr) {
 		require_scene();
 		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
 		grid_job_t job;
@@ -280,6 +281,9 @@ template<class BE> struct terra_engine {
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
+		uint32_t *d_mm = nullptr;
+		if (h_minmax) {d_mm = scratch<uint32_t>(s_mm, 2); be.fill32(d_mm, 0xFFFFFFFFu, 2);}
+		bool fused;
 		if (job.use_sine_mag) { // enable_glaciate (src/mesh_gen.cpp:640-650)
 			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
 			float const mx0 = job.mx0, my0 = job.my0, mdx = dx, mdy = dy;
@@ -306,9 +310,15 @@ template<class BE> struct terra_engine {
 					yt[j] = (y < ny) ? d_skp->yscale[k]*L.SINF(d_skp->ymdy[k]*(float)y + d_skp->yconst[k]) : 0.0f;
 				}
 			});
-			be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out);
+			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, d_mm);
 		}
-		else {be.noise_grid(job, nc, L, smx, smy, d_out);}
+		else {fused = be.noise_grid(job, nc, L, smx, smy, d_out, d_mm);}
+		if (h_minmax) {
+			if (!fused) {be.minmax(d_out, (size_t)nx*ny, d_mm);}
+			uint32_t out[2];
+			be.d2h(out, d_mm, sizeof(out));
+			h_minmax[0] = ord2f(out[0]); h_minmax[1] = ord2f(~out[1]);
+		}
 	}
 
 	// ================================================================ reductions / quantise (a12, K10)
@@ -375,7 +385,10 @@ template<class BE> struct terra_engine {
 			});
 			report.windows = 1; report.serial_fallbacks = num_iters;
 		}
-		else {speculative_erosion(g, ec, num_iters);}
+		else {
+			bool const sparse = (flags & TERRA_ERODE_MINZ_IS_MIN) != 0;
+			if (speculative_erosion(g, ec, num_iters, sparse)) return; // sparse clamp already applied to every written cell
+		}
 		// remove padding and clamp to min_zval (src/erosion.cpp:158-162): in place, so only the clamp remains
 		size_t const n = (size_t)xsize*ysize;
 		be.launch((n + 3)/4, [=] TERRA_LAMBDA (size_t q) {
@@ -384,7 +397,8 @@ template<class BE> struct terra_engine {
 		});
 	}
 
-	void speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters) {
+	// returns true when the final clamp was applied sparsely (record_touched and the record did not overflow)
+	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched) {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec;
 		uint32_t const Wmax = std::min<uint32_t>(spec_cfg.window, num_iters);
@@ -399,6 +413,8 @@ template<class BE> struct terra_engine {
 		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(Wmax*cap*4); o_vals[b] = carve(Wmax*cap*4); o_bl[b] = carve((size_t)Wmax*sb.maxb*4); o_bc[b] = carve(Wmax*4); o_chk[b] = carve(Wmax*8);}
 		size_t const o_cur = carve(Wmax*4), o_need = carve(Wmax*4), o_chg = carve(Wmax*4), o_flags = carve(Wmax*4), o_nsteps = carve(Wmax*4);
 		size_t const o_head = carve(nblocks*4), o_next = carve((size_t)Wmax*sb.maxb*4), o_dirty = carve(nblocks*4), o_cnt = carve(64);
+		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
+		size_t const o_touched = carve((size_t)touched_cap*4 + 4);
 		uint8_t *base = scratch<uint8_t>(s_spec, off);
 		for (int b = 0; b < 2; ++b) {
 			sb.log_keys[b] = (uint32_t *)(base + o_keys[b]); sb.log_vals[b] = (float *)(base + o_vals[b]);
@@ -406,10 +422,12 @@ template<class BE> struct terra_engine {
 		}
 		sb.cur = (uint32_t *)(base + o_cur); sb.need = (uint32_t *)(base + o_need); sb.changed = (uint32_t *)(base + o_chg);
 		sb.flags = (uint32_t *)(base + o_flags); sb.nsteps = (uint32_t *)(base + o_nsteps);
+		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
 		sb.head = (uint32_t *)(base + o_head); sb.next = (uint32_t *)(base + o_next); sb.dirty_min = (uint32_t *)(base + o_dirty); sb.counters = (uint32_t *)(base + o_cnt);
 
 		std::vector<uint32_t> h_nsteps, h_flags;
 		uint32_t done = 0;
+		be.fill32(sb.counters, 0, 16);
 		while (done < num_iters) {
 			uint32_t const W = std::min<uint32_t>(Wmax, num_iters - done);
 			sb.first_iter = done; sb.W = W; sb.cut = W; sb.use_lists = 0;
@@ -420,7 +438,7 @@ template<class BE> struct terra_engine {
 			for (uint32_t round = 0; round < spec_cfg.max_rounds; ++round, first = false) {
 				++report.rounds;
 				uint32_t const hc_init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
-				be.h2d(sb.counters, hc_init, sizeof(hc_init));
+				be.h2d(sb.counters, hc_init, sizeof(hc_init)); // counters[6] (touched count) is left alone
 				spec_buffers_t const s = sb;
 				if (first) {be.fill32(sb.log_keys[1], SPEC_EMPTY, (size_t)W*cap);} // all droplets trace into buffer 1 - cur = 1
 				else {be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});}
@@ -459,7 +477,8 @@ template<class BE> struct terra_engine {
 				uint32_t const it = done;
 				grid_view_t const gg = g; erosion_consts_t const ee = ec;
 				uint32_t *cnt = sb.counters;
-				be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {direct_droplet_wave(gg, ee, it, cnt + 4, ws);});
+				uint32_t *tch = sb.touched; uint32_t const tcap = sb.touched_cap;
+				be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {direct_droplet_wave(gg, ee, it, cnt + 4, ws, tch, cnt + 6, tcap);});
 				uint32_t hr[2];
 				be.d2h(hr, sb.counters + 4, sizeof(hr));
 				report.steps += hr[0]; report.traced_steps += hr[0]; report.nan_droplets += hr[1];
@@ -467,6 +486,13 @@ template<class BE> struct terra_engine {
 				++done;
 			}
 		}
+		if (!record_touched) return false;
+		uint32_t ntouched = 0;
+		be.d2h(&ntouched, sb.counters + 6, 4);
+		if (ntouched > sb.touched_cap) return false; // record overflowed: the caller clamps the whole grid
+		uint32_t const *tch = sb.touched; float const mz = ec.min_zval; grid_view_t const gg = g;
+		be.launch(ntouched, [=] TERRA_LAMBDA (size_t i) {touched_clamp_body(gg, tch, (uint32_t)i, mz);});
+		return true;
 	}
 
 	// ================================================================ tiles (a10, a13, K6, K7)

@@ -187,6 +187,7 @@ struct direct_mem_t {
 // call and TERRA_LANES is a plain loop in lane order, which visits brush cells in the reference's z-major order.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TERRA_LANES(l, n) for (int l = (int)(threadIdx.x & 63); l < (int)(n); l += 64)
+#define TERRA_EACH_LANE(l) for (int l = (int)(threadIdx.x & 63), l##_once = 1; l##_once; l##_once = 0)
 #define TERRA_LANE0 ((threadIdx.x & 63) == 0)
 #define TERRA_WAVE_SYNC() __syncthreads()
 #define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
@@ -196,6 +197,7 @@ struct direct_mem_t {
 #define TERRA_ATOMIC_CAS(p, c, v) atomicCAS((p), (c), (v))
 #else
 #define TERRA_LANES(l, n) for (int l = 0; l < (int)(n); ++l)
+#define TERRA_EACH_LANE(l) for (int l = 0; l < 64; ++l)
 #define TERRA_LANE0 true
 #define TERRA_WAVE_SYNC() do {} while (0)
 template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
@@ -266,29 +268,57 @@ struct wave_shared_t { // per-wave LDS scratch
 };
 
 template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
-	float *win; uint8_t *dirty; // LDS: EW*EW each
+	float *win, *win_alt; uint8_t *dirty, *dirty_alt; // LDS: EW*EW each, double-buffered so a window shift copies the overlap LDS -> LDS
 	int wx0, wz0, NX, NY; bool have;
 	BACK back;
-	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; dirty = d; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
+	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; win_alt = w + EW*EW; dirty = d; dirty_alt = d + EW*EW; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
 	TERRA_HD bool in_window(int X, int Z) const {return have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;}
 	TERRA_HD float *cell(int X, int Z) const {return win + (Z - wz0)*EW + (X - wx0);}
 	TERRA_HD void mark(int X, int Z) {dirty[(Z - wz0)*EW + (X - wx0)] = 1;}
-	TERRA_HD void flush() {
+	TERRA_HD void flush() { // final write-back of every dirty cell
 		if (have) {
 			TERRA_LANES(i, EW*EW) {if (dirty[i]) {back.store(wx0 + (i % EW), wz0 + (i / EW), win[i]); dirty[i] = 0;}}
 		}
 		TERRA_WAVE_SYNC();
 	}
+	// Move the window so that (cx,cz) is near its centre.  Cells that stay inside are copied LDS -> LDS together with their dirty bit
+	// (no global traffic, no log look-up); dirty cells that leave are written back; cells that enter are fetched with all plain grid
+	// loads of a lane issued back to back (one HBM latency per shift), then patched where a multi-version look-up is needed.
 	TERRA_HD void recenter(int cx, int cz) {
-		flush();
-		wx0 = clampi(cx - EW/2, imax(NX - EW, 0)); wz0 = clampi(cz - EW/2, imax(NY - EW, 0));
-		back.prepare_window(wx0, wz0);
-		TERRA_LANES(i, EW*EW) {
-			int const X = wx0 + (i % EW), Z = wz0 + (i / EW);
-			dirty[i] = 0;
-			if (X < NX && Z < NY) {win[i] = back.load(X, Z);}
+		int const nx0 = clampi(cx - EW/2, imax(NX - EW, 0)), nz0 = clampi(cz - EW/2, imax(NY - EW, 0));
+		if (have) {
+			TERRA_LANES(i, EW*EW) {
+				if (dirty[i]) {
+					int const X = wx0 + (i % EW), Z = wz0 + (i / EW);
+					if (!((unsigned)(X - nx0) < (unsigned)EW && (unsigned)(Z - nz0) < (unsigned)EW)) {back.store(X, Z, win[i]);}
+				}
+			}
+			back.note_written_rect(wx0, wz0);
+			TERRA_WAVE_SYNC();
 		}
-		have = true;
+		back.prepare_window(nx0, nz0);
+		constexpr int PER_LANE = EW*EW/64;
+		TERRA_EACH_LANE(lane) {
+			float gv[PER_LANE]; uint8_t src[PER_LANE]; // src: 0 = outside grid, 1 = copied from the old window, 2 = fetched
+#pragma unroll
+			for (int k = 0; k < PER_LANE; ++k) { // independent loads first
+				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW), ox = X - wx0, oz = Z - wz0;
+				gv[k] = 0.0f; src[k] = 0;
+				if (have && (unsigned)ox < (unsigned)EW && (unsigned)oz < (unsigned)EW) {src[k] = 1;}
+				else if (X < NX && Z < NY) {gv[k] = back.base(X, Z); src[k] = 2;}
+			}
+#pragma unroll
+			for (int k = 0; k < PER_LANE; ++k) {
+				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
+				uint8_t d = 0;
+				if (src[k] == 1) {int const o = (Z - wz0)*EW + (X - wx0); gv[k] = win[o]; d = dirty[o];}
+				else if (src[k] == 2 && back.needs_lookup(X, Z)) {gv[k] = back.lookup(X, Z, gv[k]);}
+				win_alt[i] = gv[k]; dirty_alt[i] = d;
+			}
+		}
+		float *tw = win; win = win_alt; win_alt = tw;
+		uint8_t *td = dirty; dirty = dirty_alt; dirty_alt = td;
+		wx0 = nx0; wz0 = nz0; have = true;
 		TERRA_WAVE_SYNC();
 	}
 	TERRA_HD bool begin_step(int xi, int zi) {
@@ -301,7 +331,8 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD float read_any(int X, int Z) { // outside the window only after a NaN position (index INT_MIN clamps to 0): slow path, still part of the footprint
 		if (in_window(X, Z)) return *cell(X, Z);
 		back.note_far_read(X, Z);
-		return back.load(X, Z);
+		float const b = back.base(X, Z);
+		return back.lookup(X, Z, b);
 	}
 	TERRA_HD void corners(int x, int z, float out[4]) {
 		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
@@ -315,12 +346,19 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 // backing store = the grid itself (serial fall-back droplet: it is the lowest uncommitted droplet, nothing to speculate about)
 struct grid_back_t {
 	grid_view_t g;
+	uint32_t *touched; uint32_t *touched_count; uint32_t touched_cap; // optional record of written cells
 	TERRA_HD bool begin_step(int, int) {return true;}
 	TERRA_HD bool failed() const {return false;}
 	TERRA_HD void prepare_window(int, int) {}
 	TERRA_HD void note_far_read(int, int) {}
-	TERRA_HD float load(int X, int Z) const {return *g.at(X, Z);}
-	TERRA_HD void store(int X, int Z, float v) {*g.at(X, Z) = v;}
+	TERRA_HD void note_written_rect(int, int) {}
+	TERRA_HD float base(int X, int Z) const {return *g.at(X, Z);}
+	TERRA_HD bool needs_lookup(int, int) const {return false;}
+	TERRA_HD float lookup(int, int, float b) const {return b;}
+	TERRA_HD void store(int X, int Z, float v) {
+		*g.at(X, Z) = v;
+		if (touched) {uint32_t const k = TERRA_ATOMIC_ADD(touched_count, 1u); if (k < touched_cap) {touched[k] = (uint32_t)Z*(uint32_t)g.NX + (uint32_t)X;}}
+	}
 };
 
 // ------------------------------------------------------------------ speculative (multi-version) backing store
@@ -353,6 +391,8 @@ struct spec_buffers_t {
 	uint32_t *head;        // [nbx*nby] block -> first node
 	uint32_t *next;        // [W*maxb]  node -> next node ; node id = slot*maxb + entry
 	uint32_t *dirty_min;   // [nbx*nby] lowest changed droplet slot touching the block this round
+	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp); counters[6] = count (may exceed the capacity)
+	uint32_t touched_cap;
 	uint32_t *counters;    // [0] = any_need, [1] = min overflowed slot, [2] = traced this round, [3] = steps traced, [4..5] = serial fall-back steps / nan
 };
 
@@ -383,6 +423,7 @@ struct spec_back_t {
 	uint32_t nblk;
 	uint32_t bc_id[SPEC_BCACHE]; uint32_t bc_pos;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
+	int own_x0, own_z0, own_x1, own_z1; // bounding box of the cells this droplet may already have written back
 
 	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_, wave_shared_t *sh_) {
 		sb = sb_; slot = slot_; sh = sh_;
@@ -392,6 +433,7 @@ struct spec_back_t {
 		my_vals = sb->log_vals[nb] + (size_t)slot*cap;
 		my_blks = sb->blk_list[nb] + (size_t)slot*sb->maxb;
 		nblk = 0; bc_pos = 0; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
+		own_x0 = own_z0 = INT_MAX; own_x1 = own_z1 = INT_MIN;
 		for (int i = 0; i < SPEC_BCACHE; ++i) {bc_id[i] = SPEC_NIL;}
 		if (TERRA_LANE0) {sh->nlog = 0; sh->flags = 0; sh->chk = 0;}
 		TERRA_WAVE_SYNC();
@@ -430,29 +472,39 @@ struct spec_back_t {
 		}
 		TERRA_WAVE_SYNC();
 	}
-	TERRA_HD float load(int X, int Z) const {
+	TERRA_HD void note_written_rect(int wx0, int wz0) { // the droplet's own write-backs all lie inside the union of its past windows
+		own_x0 = imin(own_x0, wx0); own_z0 = imin(own_z0, wz0); own_x1 = imax(own_x1, wx0 + EW - 1); own_z1 = imax(own_z1, wz0 + EW - 1);
+	}
+	TERRA_HD float base(int X, int Z) const {return *sb->grid.at(X, Z);}
+	TERRA_HD bool block_flag(int X, int Z) const { // is the cell's block also in a LOWER droplet's footprint?
+		if (!sb->use_lists) return false;
+		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
+		if ((unsigned)bx < (unsigned)wnb && (unsigned)bz < (unsigned)wnb) return sh->blk_shared[bz*wnb + bx] != 0;
+		return true; // outside the prepared window (far read): look the block up directly
+	}
+	TERRA_HD bool needs_lookup(int X, int Z) const {
+		bool const own = sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1;
+		return own || block_flag(X, Z);
+	}
+	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`
+	TERRA_HD float lookup(int X, int Z, float b) const {
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
 		float v;
-		if (sh->nlog && spec_log_find(my_keys, my_vals, sb->cap_log2, cell, v)) return v; // own earlier write-backs first
-		if (sb->use_lists) {
-			int const bx = X >> sb->bshift, bz = Z >> sb->bshift;
-			int const wi = (bz - wbz0)*wnb + (bx - wbx0);
-			bool shared = true; // outside the prepared window (NaN positions): look the block up directly
-			if ((unsigned)(bx - wbx0) < (unsigned)wnb && (unsigned)(bz - wbz0) < (unsigned)wnb) {shared = sh->blk_shared[wi] != 0;}
-			if (shared) { // value written by the highest-numbered lower droplet, if any
-				uint32_t best = SPEC_NIL;
-				size_t const cap = (size_t)1 << sb->cap_log2;
-				for (uint32_t node = sb->head[(uint32_t)bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {
-					uint32_t const j = node / sb->maxb;
-					if (j >= slot || (best != SPEC_NIL && j <= best)) continue;
-					uint32_t const cb = sb->cur[j];
-					float vj;
-					if (spec_log_find(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
-				}
-				if (best != SPEC_NIL) return v;
+		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1 && spec_log_find(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
+		if (block_flag(X, Z)) {
+			uint32_t best = SPEC_NIL;
+			size_t const cap = (size_t)1 << sb->cap_log2;
+			uint32_t const blk = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
+			for (uint32_t node = sb->head[blk]; node != SPEC_NIL; node = sb->next[node]) {
+				uint32_t const j = node / sb->maxb;
+				if (j >= slot || (best != SPEC_NIL && j <= best)) continue;
+				uint32_t const cb = sb->cur[j];
+				float vj;
+				if (spec_log_find(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
 			}
+			if (best != SPEC_NIL) return v;
 		}
-		return *sb->grid.at(X, Z);
+		return b;
 	}
 	TERRA_HD void store(int X, int Z, float val) { // called from lanes in parallel, each with a distinct cell
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
@@ -472,7 +524,7 @@ struct spec_back_t {
 // ---- wave bodies: one call per droplet-wave (device: one 64-lane workgroup; host: one call)
 
 // LDS scratch a wave body needs; the kernels / the emulator provide it
-struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;};
+struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;}; // win / dirty hold 2*EW*EW entries (double-buffered window)
 
 TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, wave_scratch_t const &ws) {
 	if (slot >= sb.cut || !sb.need[slot]) return;
@@ -495,10 +547,12 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, wave_scra
 }
 
 // the lowest uncommitted droplet, alone, directly on the grid (overflow fall-back)
-TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &ec, uint32_t iter, uint32_t *out_steps_nan, wave_scratch_t const &ws) {
+TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &ec, uint32_t iter, uint32_t *out_steps_nan, wave_scratch_t const &ws,
+	uint32_t *touched = nullptr, uint32_t *touched_count = nullptr, uint32_t touched_cap = 0)
+{
 	window_mem_t<grid_back_t> mem;
 	mem.init(ws.win, ws.dirty, ec.NX, ec.NY);
-	mem.back.g = g;
+	mem.back.g = g; mem.back.touched = touched; mem.back.touched_count = touched_count; mem.back.touched_cap = touched_cap;
 	droplet_result_t const r = simulate_droplet((int)iter, mem, ec);
 	mem.finish();
 	if (TERRA_LANE0 && out_steps_nan) {out_steps_nan[0] = r.steps; out_steps_nan[1] = (uint32_t)r.nan_seen;}
@@ -569,6 +623,14 @@ TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		if (spec_log_find(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later droplet owns the final value
 	}
 	*sb.grid.at((int)X, (int)Z) = sb.log_vals[cb][(size_t)slot*cap + entry];
+	if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.counters[6], 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
+}
+// sparse version of "clamp to min_zval" (src/erosion.cpp:158-162) when min_zval <= every untouched cell: one thread per recorded write
+TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, uint32_t i, float min_zval) {
+	uint32_t const cell = touched[i];
+	int const X = (int)(cell % (uint32_t)g.NX), Z = (int)(cell / (uint32_t)g.NX);
+	int const x = X - EROSION_PAD, z = Z - EROSION_PAD;
+	if ((unsigned)x < (unsigned)g.xsize && (unsigned)z < (unsigned)g.ysize) {float *p = g.interior + (size_t)z*g.xsize + x; *p = max_std(min_zval, *p);} // idempotent: duplicates are harmless
 }
 
 // ring initialisation = the clamp-padded copy of src/erosion.cpp:31-37 restricted to the ring; one thread per ring float

@@ -63,26 +63,29 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 
-	void sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out) {
-		if (simple_kernels) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return;}
+	// mm (optional): device uint32[2] pre-set to 0xFFFFFFFF receiving min f2ord(z) / min ~f2ord(z); returns false when the caller must run minmax() itself
+	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *mm) {
+		if (simple_kernels) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
 		size_t const lds = (size_t)(terra::F_TABLE_SIZE - job.kstart)*(terra::SG_BX + terra::SG_BY)*sizeof(float);
-		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), lds, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty);
+		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), lds, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm);
 		TERRA_HIP_CHECK(hipGetLastError());
+		return true;
 	}
-	void noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out) {
-		if (simple_kernels) {noise_grid_simple(job, nc, L, smx, smy, out); return;}
+	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *mm) {
+		if (simple_kernels) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 		use();
 		dim3 const grid((job.nx + 63)/64, (job.ny + 3)/4), block(256);
 		switch (job.mode) {
-		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out); break;
-		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out); break;
-		case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, job, nc, L, smx, smy, out); break;
-		default:                      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, job, nc, L, smx, smy, out); break;
+		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
+		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
+		case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
+		default:                      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
 		}
 		TERRA_HIP_CHECK(hipGetLastError());
+		return true;
 	}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
 		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}

@@ -20,12 +20,23 @@ template<class F> __global__ void k_generic(size_t n, F f) {
 
 // one 64-lane workgroup (= one wave) per item, with the per-wave LDS scratch of the droplet window (terra_erosion.hpp)
 template<class F> __global__ __launch_bounds__(64) void k_waves(F f) {
-	__shared__ __attribute__((aligned(16))) float win[EW*EW];
-	__shared__ uint8_t dirty[EW*EW];
+	__shared__ __attribute__((aligned(16))) float win[2*EW*EW];
+	__shared__ uint8_t dirty[2*EW*EW];
 	__shared__ wave_shared_t sh;
 	wave_scratch_t const ws{win, dirty, &sh};
 	f((size_t)blockIdx.x, ws);
 }
+
+// fold a thread's (min,max) of order-preserving uints over its wave and publish with two atomics per wave
+__device__ __forceinline__ void wave_minmax_publish(uint32_t lo, uint32_t hi, uint32_t *mm) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		uint32_t const l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
+		lo = (l2 < lo) ? l2 : lo; hi = (h2 < hi) ? h2 : hi;
+	}
+	if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) {atomicMin(&mm[0], lo); atomicMin(&mm[1], hi);}
+}
+__device__ __forceinline__ void minmax_acc(float v, uint32_t &lo, uint32_t &hi) {if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
 
 // ------------------------------------------------------------------ K1: sine-sum grid
 constexpr int SG_BX = 128, SG_BY = 64, SG_TX = 8, SG_TY = 4, SG_THREADS = 256; // 16 x 16 threads, 8 x 4 cells each
@@ -47,11 +58,12 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 }
 
 __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
-	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty)
+	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm)
 {
 	extern __shared__ __attribute__((aligned(16))) float sg_lds[];
 	unsigned bxi, byi;
 	if (!sg_tile_of_block(blockIdx.x, ntx, nty, bxi, byi)) return;
+	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu; // fused min(vals)/max(vals) (heightmap_t::run_erosion, get_heightmap_z_range): saves a 4 B/cell read pass
 	int const nk = F_TABLE_SIZE - job.kstart;
 	float *sX = sg_lds, *sY = sg_lds + nk*SG_BX;
 	unsigned const tid = threadIdx.x, bx0 = bxi*SG_BX, by0 = byi*SG_BY;
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 			if (x >= job.nx) continue;
 			float v[4];
 #pragma unroll
-			for (int j = 0; j < 4; ++j) {v[j] = (x + j < job.nx) ? finish_cell(acc[i][half*4 + j], job, nc, L, smx, smy, x + j, y) : 0.0f;}
+			for (int j = 0; j < 4; ++j) {v[j] = (x + j < job.nx) ? finish_cell(acc[i][half*4 + j], job, nc, L, smx, smy, x + j, y) : 0.0f; if (mm && x + j < job.nx) {minmax_acc(v[j], mm_lo, mm_hi);}}
 			float *o = out + (size_t)y*job.nx + x;
 			if (vec_ok) {*(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);}
 			else {
@@ -104,15 +116,20 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 			}
 		}
 	}
+	if (mm) {wave_minmax_publish(mm_lo, mm_hi, mm);}
 }
 
 // ------------------------------------------------------------------ K2/K3: fBm / domain-warp grid, one cell per thread, x fastest
-template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out) {
+template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, uint32_t *__restrict__ mm) {
 	unsigned const x = blockIdx.x*64 + (threadIdx.x & 63), y = blockIdx.y*4 + (threadIdx.x >> 6);
-	if (x >= job.nx || y >= job.ny) return;
-	float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
-	float const z = noise_zval<MODE>(xval, yval, job.shape, nc);
-	out[(size_t)y*job.nx + x] = finish_cell(z, job, nc, L, smx, smy, x, y);
+	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu;
+	if (x < job.nx && y < job.ny) {
+		float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+		float const z = finish_cell(noise_zval<MODE>(xval, yval, job.shape, nc), job, nc, L, smx, smy, x, y);
+		out[(size_t)y*job.nx + x] = z;
+		minmax_acc(z, mm_lo, mm_hi);
+	}
+	if (mm) {wave_minmax_publish(mm_lo, mm_hi, mm);}
 }
 
 // ------------------------------------------------------------------ K5 tile mode: LDS-resident padded grid, serial droplets

@@ -100,6 +100,7 @@ _PROTOS = {
     "terra_gen_device_values": (_vp, [_vp]),
     "terra_gen_grid_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
     "terra_gen_grid": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
+    "terra_gen_grid_minmax_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _f3, _f3]),
     "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
@@ -255,6 +256,11 @@ class Terra:
     # ---- device-resident entry points (ptr = raw device pointer, e.g. torch_tensor.data_ptr())
     def gen_grid_dev(self, ptr, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
         self._ck(self.lib.terra_gen_grid_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr))
+
+    def gen_grid_minmax_dev(self, ptr, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
+        mn, mx = C.c_float(), C.c_float()
+        self._ck(self.lib.terra_gen_grid_minmax_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
 
     def apply_erosion_dev(self, ptr, xsize, ysize, min_zval, iters, flags=0):
         self._ck(self.lib.terra_apply_erosion_dev(self.ctx, ptr, xsize, ysize, min_zval, iters, flags))

@@ -99,9 +99,8 @@ def main():
 
     def step():
         # heightmap_t::proc_gen on the device: noise + glaciate -> min -> erosion (in place)
-        t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-        mn, _ = t.minmax_dev(z.data_ptr(), cells)
-        t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, 0)
+        mn, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
+        t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                     # run_erosion passes min(vals): only written cells can need the clamp
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -130,7 +129,7 @@ def main():
             reps = max(3, args.steps)
             t.timer_start()
             for _ in range(reps):
-                t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+                t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
             ms_gen = t.timer_stop() / reps
             mn, _ = t.minmax_dev(z.data_ptr(), cells)
             t.timer_start()
@@ -143,7 +142,7 @@ def main():
                 z.copy_(zc)
                 torch.cuda.synchronize(dev)
                 t.timer_start()
-                t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, 0)
+                t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)
                 ms_ero += t.timer_stop() / reps
             detail = {"ms_noise_kernels": round(ms_gen, 4), "ms_minmax": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)}
 

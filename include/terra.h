@@ -127,6 +127,8 @@ const float *terra_gen_device_values(terra_gen *g);                /* device poi
 
 /* one-shot: build_arrays + [enable_glaciate] + the caller's eval_index double loop (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:495-514) */
 int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out);
+/* same, plus min(vals)/max(vals) folded into the grid kernel (what heightmap_t::run_erosion / get_heightmap_z_range compute next); synchronous */
+int  terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max);
 int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out);
 
 /* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0. */

@@ -28,13 +28,13 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	template<class F> void launch(size_t n, F f, int = 256) {for (size_t i = 0; i < n; ++i) f(i);}
 	// a "wave" is one call; its LDS scratch is a few stack arrays
 	template<class F> void launch_waves(size_t n, F f) {
-		std::vector<float> win(terra::EW*terra::EW); std::vector<uint8_t> dirty(terra::EW*terra::EW); terra::wave_shared_t sh;
+		std::vector<float> win(2*terra::EW*terra::EW); std::vector<uint8_t> dirty(2*terra::EW*terra::EW); terra::wave_shared_t sh;
 		terra::wave_scratch_t const ws{win.data(), dirty.data(), &sh};
 		for (size_t i = 0; i < n; ++i) f(i, ws);
 	}
 
-	void sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out);}
-	void noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out) {noise_grid_simple(job, nc, L, smx, smy, out);}
+	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
+	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
 		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {

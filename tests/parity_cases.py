@@ -211,6 +211,18 @@ def case_quantize_golden(pkg, t):
     buf.free(); pix.free()
 
 
+def case_gen_grid_minmax(pkg, t, orc, mode, n):
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode)
+    st = t.init_scene(pc_)
+    orc.init(oc)
+    buf = t.alloc(n * (n - 5) * 4)
+    mn, mx = t.gen_grid_minmax_dev(buf.ptr, -n / 2, 9, st.DX_VAL, st.DY_VAL, n, n - 5, pkg.GEN_GLACIATE)
+    z = buf.download(np.float32, (n - 5, n)); buf.free()
+    a = orc.gen_grid(-n / 2, 9, st.DX_VAL, st.DY_VAL, n, n - 5, 1)
+    assert_bit_equal(a, z, "gen_grid_minmax grid")
+    assert np.float32(mn) == a.min() and np.float32(mx) == a.max(), (mn, mx, a.min(), a.max())
+
+
 def case_generator_protocol(pkg, t, orc):
     """mesh_xy_grid_cache_t async protocol: no_wait launch returns 0, the second call collects (src/mesh_gen.cpp:597-603)."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=1)

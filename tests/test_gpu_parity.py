@@ -72,6 +72,11 @@ def test_proc_gen_and_quantize(pkg, gpu, orc):
     pc.case_quantize_golden(pkg, gpu)
 
 
+@pytest.mark.parametrize("mode,n", [(0, 1500), (0, 131), (1, 700), (4, 300)])
+def test_gen_grid_minmax(pkg, gpu, orc, mode, n):
+    pc.case_gen_grid_minmax(pkg, gpu, orc, mode, n)
+
+
 def test_generator_protocol(pkg, gpu, orc):
     pc.case_generator_protocol(pkg, gpu, orc)
 

@@ -61,6 +61,11 @@ def test_proc_gen_and_quantize(pkg, emul, orc):
     pc.case_quantize_golden(pkg, emul)
 
 
+@pytest.mark.parametrize("mode,n", [(0, 150), (1, 90)])
+def test_gen_grid_minmax(pkg, emul, orc, mode, n):
+    pc.case_gen_grid_minmax(pkg, emul, orc, mode, n)
+
+
 def test_generator_protocol(pkg, emul, orc):
     pc.case_generator_protocol(pkg, emul, orc)
 
