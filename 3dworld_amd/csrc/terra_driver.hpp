@@ -425,7 +425,6 @@ template<class BE> struct terra_engine {
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
 		sb.head = (uint32_t *)(base + o_head); sb.next = (uint32_t *)(base + o_next); sb.dirty_min = (uint32_t *)(base + o_dirty); sb.counters = (uint32_t *)(base + o_cnt);
 
-		std::vector<uint32_t> h_nsteps, h_flags;
 		uint32_t done = 0;
 		be.fill32(sb.counters, 0, 16);
 		while (done < num_iters) {
@@ -434,57 +433,49 @@ template<class BE> struct terra_engine {
 			++report.windows;
 			be.fill32(sb.cur, 0, W); be.fill32(sb.need, 1, W); be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
 			be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks); be.fill32(sb.head, SPEC_NIL, nblocks);
+			be.fill32(sb.counters + 1, 0xFFFFFFFFu, 1);            // lowest overflowed slot of this window
+			be.fill32(sb.counters + 2, 0, 2); be.fill32(sb.counters + 7, 0, 2);
 			bool first = true;
+			// one host round trip per round: everything a round needs (cut, counters) lives in device memory
 			for (uint32_t round = 0; round < spec_cfg.max_rounds; ++round, first = false) {
 				++report.rounds;
-				uint32_t const hc_init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
-				be.h2d(sb.counters, hc_init, sizeof(hc_init)); // counters[6] (touched count) is left alone
+				be.fill32(sb.counters, 0, 1);
 				spec_buffers_t const s = sb;
 				if (first) {be.fill32(sb.log_keys[1], SPEC_EMPTY, (size_t)W*cap);} // all droplets trace into buffer 1 - cur = 1
 				else {be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});}
 				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, ws);});
-				uint32_t hc[4];
-				be.d2h(hc, sb.counters, sizeof(hc));
-				report.traces += hc[2]; report.traced_steps += hc[3];
-				if (hc[1] < sb.cut) { // a droplet overflowed its log / block list: cut the window there
-					sb.cut = hc[1];
-				}
-				spec_buffers_t const s2 = sb; // cut may have changed
 				bool const fr = first;
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s2, (uint32_t)i, fr);});
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s2, (uint32_t)i);});
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)i, fr);});
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s, (uint32_t)i);});
 				be.fill32(sb.head, SPEC_NIL, nblocks);
-				be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s2, (uint32_t)(i / s2.maxb), (uint32_t)(i % s2.maxb));});
-				uint32_t const zero = 0;
-				be.h2d(sb.counters, &zero, 4);
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s2, (uint32_t)i);});
+				be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s, (uint32_t)i);});
 				be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks);
-				uint32_t nneed = 0;
-				be.d2h(&nneed, sb.counters, 4);
+				uint32_t hc[2];
+				be.d2h(hc, sb.counters, sizeof(hc)); // {droplets to re-trace, lowest overflowed slot}
+				if (hc[1] < sb.cut) {sb.cut = hc[1];}
 				sb.use_lists = 1;
-				if (nneed == 0) break;
+				if (hc[0] == 0) break;
 			}
-			// flush committed droplets [0, cut)
+			// flush committed droplets [0, cut), gather the window's totals
+			spec_buffers_t const s = sb;
 			if (sb.cut > 0) {
-				spec_buffers_t const s = sb;
 				be.launch((size_t)sb.cut*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
-				h_nsteps.resize(sb.cut); h_flags.resize(sb.cut);
-				be.d2h(h_nsteps.data(), sb.nsteps, sb.cut*4); be.d2h(h_flags.data(), sb.flags, sb.cut*4);
-				for (uint32_t i = 0; i < sb.cut; ++i) {report.steps += h_nsteps[i]; report.nan_droplets += (h_flags[i] & SPEC_F_NAN) ? 1 : 0;}
+				be.launch(sb.cut, [=] TERRA_LAMBDA (size_t i) {spec_totals_body(s, (uint32_t)i);});
 			}
-			done += sb.cut;
-			if (sb.cut < W) { // the overflowed droplet runs alone, directly on the grid (it is now the lowest uncommitted droplet)
-				uint32_t const it = done;
+			uint32_t const committed = sb.cut;
+			if (committed < W) { // the overflowed droplet runs alone, directly on the grid (it is now the lowest uncommitted droplet)
+				uint32_t const it = done + committed;
 				grid_view_t const gg = g; erosion_consts_t const ee = ec;
 				uint32_t *cnt = sb.counters;
 				uint32_t *tch = sb.touched; uint32_t const tcap = sb.touched_cap;
 				be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {direct_droplet_wave(gg, ee, it, cnt + 4, ws, tch, cnt + 6, tcap);});
-				uint32_t hr[2];
-				be.d2h(hr, sb.counters + 4, sizeof(hr));
-				report.steps += hr[0]; report.traced_steps += hr[0]; report.nan_droplets += hr[1];
-				++report.serial_fallbacks;
-				++done;
 			}
+			uint32_t hw[9];
+			be.d2h(hw, sb.counters, sizeof(hw));
+			report.traces += hw[2]; report.traced_steps += hw[3]; report.steps += hw[7]; report.nan_droplets += hw[8];
+			done += committed;
+			if (committed < W) {report.steps += hw[4]; report.traced_steps += hw[4]; report.nan_droplets += hw[5]; ++report.serial_fallbacks; ++done;}
 		}
 		if (!record_touched) return false;
 		uint32_t ntouched = 0;

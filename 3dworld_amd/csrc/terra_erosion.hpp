@@ -299,21 +299,21 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		back.prepare_window(nx0, nz0);
 		constexpr int PER_LANE = EW*EW/64;
 		TERRA_EACH_LANE(lane) {
-			float gv[PER_LANE]; uint8_t src[PER_LANE]; // src: 0 = outside grid, 1 = copied from the old window, 2 = fetched
+			float gv[PER_LANE];
 #pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) { // independent loads first
-				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW), ox = X - wx0, oz = Z - wz0;
-				gv[k] = 0.0f; src[k] = 0;
-				if (have && (unsigned)ox < (unsigned)EW && (unsigned)oz < (unsigned)EW) {src[k] = 1;}
-				else if (X < NX && Z < NY) {gv[k] = back.base(X, Z); src[k] = 2;}
+			for (int k = 0; k < PER_LANE; ++k) { // all plain grid loads of the lane first: they are independent and overlap in flight
+				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
+				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
+				gv[k] = (!in_old && X < NX && Z < NY) ? back.base(X, Z) : 0.0f;
 			}
 #pragma unroll
 			for (int k = 0; k < PER_LANE; ++k) {
 				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-				uint8_t d = 0;
-				if (src[k] == 1) {int const o = (Z - wz0)*EW + (X - wx0); gv[k] = win[o]; d = dirty[o];}
-				else if (src[k] == 2 && back.needs_lookup(X, Z)) {gv[k] = back.lookup(X, Z, gv[k]);}
-				win_alt[i] = gv[k]; dirty_alt[i] = d;
+				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
+				float val = gv[k]; uint8_t d = 0;
+				if (in_old) {int const o = (Z - wz0)*EW + (X - wx0); val = win[o]; d = dirty[o];}
+				else if (X < NX && Z < NY && back.needs_lookup(X, Z)) {val = back.lookup(X, Z, val);}
+				win_alt[i] = val; dirty_alt[i] = d;
 			}
 		}
 		float *tw = win; win = win_alt; win_alt = tw;
@@ -364,7 +364,6 @@ struct grid_back_t {
 // ------------------------------------------------------------------ speculative (multi-version) backing store
 constexpr uint32_t SPEC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SPEC_NIL   = 0xFFFFFFFFu;
-constexpr int      SPEC_BCACHE = 4;
 enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4};
 
 struct spec_buffers_t {
@@ -393,8 +392,11 @@ struct spec_buffers_t {
 	uint32_t *dirty_min;   // [nbx*nby] lowest changed droplet slot touching the block this round
 	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp); counters[6] = count (may exceed the capacity)
 	uint32_t touched_cap;
-	uint32_t *counters;    // [0] = any_need, [1] = min overflowed slot, [2] = traced this round, [3] = steps traced, [4..5] = serial fall-back steps / nan
+	uint32_t *counters;    // [0] droplets to re-trace, [1] lowest overflowed slot of this window, [2] traces, [3] steps traced, [4..5] fall-back droplet steps / nan, [6] touched cells, [7..8] committed steps / nan droplets
 };
+
+// slots >= cut are out of the window: `cut` is what the host knew at launch, counters[1] the lowest slot that overflowed since (device side)
+TERRA_HD uint32_t spec_cut(spec_buffers_t const &sb) {uint32_t const c = sb.counters[1]; return (c < sb.cut) ? c : sb.cut;}
 
 // splitmix64 finaliser.  The per-store terms of the trace checksum must be mixed non-linearly: a lower droplet's change often moves
 // some cells up one ulp and others down one ulp, which a linear (multiplicative) term sum cannot see.
@@ -404,12 +406,20 @@ TERRA_HD uint64_t spec_mix64(uint64_t x) {
 }
 TERRA_HD uint32_t spec_hash(uint32_t cell, uint32_t cap_log2) {return (cell*2654435761u) >> (32 - cap_log2);}
 
-TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t cap_log2, uint32_t cell, float &out) {
+// L2LOAD: read through to L2.  A droplet's OWN log is written by the other lanes of its wave (CAS + plain stores) in the same
+// kernel; the CU's vector L1 may still hold the line from an earlier probe that saw SPEC_EMPTY, so those probes must not hit L1.
+// Other droplets' logs were written by earlier kernels (the boundary makes them visible) and use plain cached loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TERRA_L2_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define TERRA_L2_LOAD(p) (*(p))
+#endif
+template<bool L2LOAD> TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t cap_log2, uint32_t cell, float &out) {
 	uint32_t const mask = (1u << cap_log2) - 1;
 	uint32_t h = spec_hash(cell, cap_log2);
 	for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
-		uint32_t const k = keys[h];
-		if (k == cell) {out = vals[h]; return true;}
+		uint32_t const k = L2LOAD ? TERRA_L2_LOAD(&keys[h]) : keys[h];
+		if (k == cell) {out = L2LOAD ? TERRA_L2_LOAD(&vals[h]) : vals[h]; return true;}
 		if (k == SPEC_EMPTY) return false;
 	}
 	return false;
@@ -421,7 +431,8 @@ struct spec_back_t {
 	uint32_t slot;
 	uint32_t *my_keys; float *my_vals; uint32_t *my_blks; // the "new" buffers (1 - cur)
 	uint32_t nblk;
-	uint32_t bc_id[SPEC_BCACHE]; uint32_t bc_pos;
+	uint32_t bc0, bc1, bc2, bc3; // the four most recently recorded blocks (plain registers: an indexed array would live in scratch memory)
+	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
 	int own_x0, own_z0, own_x1, own_z1; // bounding box of the cells this droplet may already have written back
 
@@ -432,21 +443,21 @@ struct spec_back_t {
 		my_keys = sb->log_keys[nb] + (size_t)slot*cap;
 		my_vals = sb->log_vals[nb] + (size_t)slot*cap;
 		my_blks = sb->blk_list[nb] + (size_t)slot*sb->maxb;
-		nblk = 0; bc_pos = 0; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
+		nblk = 0; bc0 = bc1 = bc2 = bc3 = SPEC_NIL; blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
 		own_x0 = own_z0 = INT_MAX; own_x1 = own_z1 = INT_MIN;
-		for (int i = 0; i < SPEC_BCACHE; ++i) {bc_id[i] = SPEC_NIL;}
 		if (TERRA_LANE0) {sh->nlog = 0; sh->flags = 0; sh->chk = 0;}
 		TERRA_WAVE_SYNC();
 	}
-	TERRA_HD bool failed() const {return (sh->flags & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) != 0;}
+	// sh->flags only changes inside window write-backs, which end with a wave sync; blk_overflow is a wave-uniform register
+	TERRA_HD bool failed() const {return blk_overflow || (sh->flags & SPEC_F_LOG_OVERFLOW) != 0;}
 	TERRA_HD void touch_block(uint32_t b) { // wave-uniform bookkeeping; lane 0 owns the global write
-		for (int i = 0; i < SPEC_BCACHE; ++i) {if (bc_id[i] == b) return;}
-		bc_id[bc_pos++ % SPEC_BCACHE] = b;
-		if (nblk >= sb->maxb) {if (TERRA_LANE0) {sh->flags |= SPEC_F_BLK_OVERFLOW;} return;}
+		if (b == bc0 || b == bc1 || b == bc2 || b == bc3) return;
+		bc3 = bc2; bc2 = bc1; bc1 = bc0; bc0 = b;
+		if (nblk >= sb->maxb) {blk_overflow = true; return;}
 		if (TERRA_LANE0) {my_blks[nblk] = b;}
 		++nblk;
 	}
-	TERRA_HD void note_far_read(int X, int Z) {touch_block((uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift)); TERRA_WAVE_SYNC();}
+	TERRA_HD void note_far_read(int X, int Z) {touch_block((uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift));}
 	TERRA_HD bool begin_step(int xi, int zi) { // footprint of one step = the 4x4 brush box, which also covers every read of that step
 		int const x0 = clampi(xi-1, sb->ec.NX-1) >> sb->bshift, x1 = clampi(xi+2, sb->ec.NX-1) >> sb->bshift;
 		int const z0 = clampi(zi-1, sb->ec.NY-1) >> sb->bshift, z1 = clampi(zi+2, sb->ec.NY-1) >> sb->bshift;
@@ -456,7 +467,6 @@ struct spec_back_t {
 			touch_block((uint32_t)z1*sb->nbx + x0);
 			if (x1 != x0) {touch_block((uint32_t)z1*sb->nbx + x1);}
 		}
-		TERRA_WAVE_SYNC();
 		return !failed();
 	}
 	// which blocks under the new window are also in a LOWER droplet's footprint (only those need the multi-version lookup)
@@ -490,7 +500,7 @@ struct spec_back_t {
 	TERRA_HD float lookup(int X, int Z, float b) const {
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
 		float v;
-		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1 && spec_log_find(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
+		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1 && spec_log_find<true>(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
 		if (block_flag(X, Z)) {
 			uint32_t best = SPEC_NIL;
 			size_t const cap = (size_t)1 << sb->cap_log2;
@@ -500,7 +510,7 @@ struct spec_back_t {
 				if (j >= slot || (best != SPEC_NIL && j <= best)) continue;
 				uint32_t const cb = sb->cur[j];
 				float vj;
-				if (spec_log_find(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
+				if (spec_log_find<false>(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
 			}
 			if (best != SPEC_NIL) return v;
 		}
@@ -527,7 +537,7 @@ struct spec_back_t {
 struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;}; // win / dirty hold 2*EW*EW entries (double-buffered window)
 
 TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, wave_scratch_t const &ws) {
-	if (slot >= sb.cut || !sb.need[slot]) return;
+	if (slot >= spec_cut(sb) || !sb.need[slot]) return;
 	window_mem_t<spec_back_t> mem;
 	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
 	mem.back.init(&sb, slot, ws.sh);
@@ -535,7 +545,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, wave_scra
 	mem.finish();
 	if (TERRA_LANE0) {
 		uint32_t const nb = 1u - sb.cur[slot];
-		uint32_t const fl = ws.sh->flags;
+		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
 		sb.blk_cnt[nb][slot] = mem.back.nblk;
 		sb.chk[nb][slot]     = (uint64_t)ws.sh->chk ^ ((uint64_t)r.steps << 40);
 		sb.nsteps[slot]      = r.steps;
@@ -562,13 +572,13 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 
 // clear the "new" log of every droplet that will be traced this round: one thread per (slot, log entry)
 TERRA_HD void spec_clear_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	if (slot >= sb.cut || !sb.need[slot]) return;
+	if (slot >= spec_cut(sb) || !sb.need[slot]) return;
 	uint32_t const nb = 1u - sb.cur[slot];
 	sb.log_keys[nb][((size_t)slot << sb.cap_log2) + entry] = SPEC_EMPTY;
 }
 // after all traces of the round: publish dirty blocks of changed droplets
 TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, bool first_round) {
-	if (slot >= sb.cut || !sb.need[slot]) {if (slot < sb.W) sb.changed[slot] = 0; return;}
+	if (slot >= spec_cut(sb) || !sb.need[slot]) {if (slot < sb.W) sb.changed[slot] = 0; return;}
 	uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 	bool const changed = first_round || (sb.chk[ob][slot] != sb.chk[nb][slot]) || (sb.blk_cnt[ob][slot] != sb.blk_cnt[nb][slot]);
 	sb.changed[slot] = changed ? 1u : 0u;
@@ -582,12 +592,12 @@ TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, bool first
 	}
 }
 TERRA_HD void spec_flip_body(spec_buffers_t const &sb, uint32_t slot) {
-	if (slot >= sb.cut || !sb.need[slot]) return;
+	if (slot >= spec_cut(sb) || !sb.need[slot]) return;
 	sb.cur[slot] = 1u - sb.cur[slot];
 }
 // rebuild block -> droplet lists from the current footprints (head[] was reset to SPEC_NIL before): one thread per (slot, entry)
 TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	if (slot >= sb.cut) return;
+	if (slot >= spec_cut(sb)) return;
 	uint32_t const cb = sb.cur[slot];
 	if (entry >= sb.blk_cnt[cb][slot]) return;
 	uint32_t const b = sb.blk_list[cb][(size_t)slot*sb.maxb + entry];
@@ -598,7 +608,7 @@ TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t e
 TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot) {
 	if (slot >= sb.W) return;
 	uint32_t need = 0;
-	if (slot < sb.cut) {
+	if (slot < spec_cut(sb)) {
 		uint32_t const cb = sb.cur[slot];
 		uint32_t const *bl = sb.blk_list[cb] + (size_t)slot*sb.maxb;
 		for (uint32_t e = 0; e < sb.blk_cnt[cb][slot]; ++e) {if (sb.dirty_min[bl[e]] < slot) {need = 1; break;}}
@@ -608,7 +618,8 @@ TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot) {
 }
 // flush: the highest-numbered writer of a cell stores it; one thread per (slot, log entry)
 TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	if (slot >= sb.cut) return;
+	uint32_t const cut = spec_cut(sb);
+	if (slot >= cut) return;
 	uint32_t const cb = sb.cur[slot];
 	size_t const cap = (size_t)1 << sb.cap_log2;
 	uint32_t const cell = sb.log_keys[cb][(size_t)slot*cap + entry];
@@ -617,10 +628,10 @@ TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	uint32_t const b = (Z >> sb.bshift)*sb.nbx + (X >> sb.bshift);
 	for (uint32_t node = sb.head[b]; node != SPEC_NIL; node = sb.next[node]) {
 		uint32_t const j = node / sb.maxb;
-		if (j <= slot || j >= sb.cut) continue;
+		if (j <= slot || j >= cut) continue;
 		uint32_t const jb = sb.cur[j];
 		float vj;
-		if (spec_log_find(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later droplet owns the final value
+		if (spec_log_find<false>(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later droplet owns the final value
 	}
 	*sb.grid.at((int)X, (int)Z) = sb.log_vals[cb][(size_t)slot*cap + entry];
 	if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.counters[6], 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
@@ -631,6 +642,13 @@ TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, 
 	int const X = (int)(cell % (uint32_t)g.NX), Z = (int)(cell / (uint32_t)g.NX);
 	int const x = X - EROSION_PAD, z = Z - EROSION_PAD;
 	if ((unsigned)x < (unsigned)g.xsize && (unsigned)z < (unsigned)g.ysize) {float *p = g.interior + (size_t)z*g.xsize + x; *p = max_std(min_zval, *p);} // idempotent: duplicates are harmless
+}
+
+// per-window totals of the committed droplets: one thread per slot -> counters[7] (steps), counters[8] (droplets that went NaN)
+TERRA_HD void spec_totals_body(spec_buffers_t const &sb, uint32_t slot) {
+	if (slot >= spec_cut(sb)) return;
+	TERRA_ATOMIC_ADD(&sb.counters[7], sb.nsteps[slot]);
+	if (sb.flags[slot] & SPEC_F_NAN) {TERRA_ATOMIC_ADD(&sb.counters[8], 1u);}
 }
 
 // ring initialisation = the clamp-padded copy of src/erosion.cpp:31-37 restricted to the ring; one thread per ring float

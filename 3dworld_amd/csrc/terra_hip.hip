@@ -59,7 +59,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (n == 0) return;
 		use();
 		if (n > 0x7FFFFFFFull) throw std::invalid_argument("launch_waves: grid too large");
-		hipLaunchKernelGGL(terra::k_waves<F>, dim3((unsigned)n), dim3(64), 0, stream, f);
+		hipLaunchKernelGGL(terra::k_waves<F>, dim3((unsigned)n), dim3(64), 0, stream, f, 0u);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 

@@ -19,12 +19,12 @@ template<class F> __global__ void k_generic(size_t n, F f) {
 }
 
 // one 64-lane workgroup (= one wave) per item, with the per-wave LDS scratch of the droplet window (terra_erosion.hpp)
-template<class F> __global__ __launch_bounds__(64) void k_waves(F f) {
+template<class F> __global__ __launch_bounds__(64) void k_waves(F f, unsigned first) {
 	__shared__ __attribute__((aligned(16))) float win[2*EW*EW];
 	__shared__ uint8_t dirty[2*EW*EW];
 	__shared__ wave_shared_t sh;
 	wave_scratch_t const ws{win, dirty, &sh};
-	f((size_t)blockIdx.x, ws);
+	f((size_t)blockIdx.x + first, ws);
 }
 
 // fold a thread's (min,max) of order-preserving uints over its wave and publish with two atomics per wave
@@ -34,7 +34,11 @@ __device__ __forceinline__ void wave_minmax_publish(uint32_t lo, uint32_t hi, ui
 		uint32_t const l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
 		lo = (l2 < lo) ? l2 : lo; hi = (h2 < hi) ? h2 : hi;
 	}
-	if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) {atomicMin(&mm[0], lo); atomicMin(&mm[1], hi);}
+	// thousands of waves fold into the same two words: look first (a stale value only costs a redundant atomic), so the atomics die out once the extrema have been seen
+	if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) {
+		if (lo < __hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {atomicMin(&mm[0], lo);}
+		if (hi < __hip_atomic_load(&mm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {atomicMin(&mm[1], hi);}
+	}
 }
 __device__ __forceinline__ void minmax_acc(float v, uint32_t &lo, uint32_t &hi) {if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
 
