@@ -25,7 +25,6 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		char const *s = getenv("TERRA_SIMPLE_KERNELS");
 		simple_kernels = (s && s[0] == '1');
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
-		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_sine_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 	}
 	~hip_backend_t() {
@@ -69,8 +68,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		size_t const lds = (size_t)(terra::F_TABLE_SIZE - job.kstart)*(terra::SG_BX + terra::SG_BY)*sizeof(float);
-		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), lds, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm);
+		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm);
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}

@@ -43,7 +43,12 @@ __device__ __forceinline__ void wave_minmax_publish(uint32_t lo, uint32_t hi, ui
 __device__ __forceinline__ void minmax_acc(float v, uint32_t &lo, uint32_t &hi) {if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
 
 // ------------------------------------------------------------------ K1: sine-sum grid
-constexpr int SG_BX = 128, SG_BY = 64, SG_TX = 8, SG_TY = 4, SG_THREADS = 256; // 16 x 16 threads, 8 x 4 cells each
+// z[y][x] = sum_k X[k][x]*Y[k][y] is a rank-(90-kstart) outer-product contraction.  It is fp32-VALU bound: every term costs one
+// v_mul and one v_add (no FMA: the CPU reference rounds the product before adding), i.e. 2*terms VALU ops for 4 B written.
+// Tiling: 128 x 128 cells per 256-thread block, 8 x 8 cells per thread (64 independent accumulator chains), the K range staged
+// through LDS in two chunks (<= 45 k each, 46 KB -> 3 blocks = 12 waves per CU), operands of step k+1 prefetched from LDS while
+// step k is multiplied.  Per k a thread issues four ds_read_b128 (conflict-free / broadcast) for 64 mul + 64 add.
+constexpr int SG_BX = 128, SG_BY = 128, SG_TX = 8, SG_TY = 8, SG_THREADS = 256, SG_KC = 45; // 16 x 16 threads
 constexpr int SG_ROWGROUP = 4; // tile rows walked together so an X tile is reused from L2 before moving on
 
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (observed, speed only); give every XCD one contiguous
@@ -55,55 +60,83 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 	unsigned const group = lin/(SG_ROWGROUP*ntx), r = lin % (SG_ROWGROUP*ntx);
 	unsigned const rows_here = (nty - group*SG_ROWGROUP < (unsigned)SG_ROWGROUP) ? nty - group*SG_ROWGROUP : SG_ROWGROUP;
 	bx = r/rows_here; by = group*SG_ROWGROUP + r % rows_here;
-	if (bx >= ntx) { // only in a short last group: remaining slots are unused
-		return false;
+	return bx < ntx;
+}
+
+struct sg_operands_t {float4 xa, xb, ya, yb;};
+__device__ __forceinline__ sg_operands_t sg_load(float const *px, float const *py, int k) {
+	sg_operands_t o;
+	o.xa = *(float4 const *)(px + k*SG_BX); o.xb = *(float4 const *)(px + k*SG_BX + 64);
+	o.ya = *(float4 const *)(py + k*SG_BY); o.yb = *(float4 const *)(py + k*SG_BY + 64);
+	return o;
+}
+__device__ __forceinline__ void sg_accumulate(float (&acc)[SG_TY][SG_TX], sg_operands_t const &o) {
+	float const xs[SG_TX] = {o.xa.x, o.xa.y, o.xa.z, o.xa.w, o.xb.x, o.xb.y, o.xb.z, o.xb.w};
+	float const ys[SG_TY] = {o.ya.x, o.ya.y, o.ya.z, o.ya.w, o.yb.x, o.yb.y, o.yb.z, o.yb.w};
+#pragma unroll
+	for (int i = 0; i < SG_TY; ++i) {
+#pragma unroll
+		for (int j = 0; j < SG_TX; ++j) {acc[i][j] = __fadd_rn(acc[i][j], __fmul_rn(xs[j], ys[i]));} // zval += xptr[k]*yptr[k]: product rounded, then added
 	}
-	return true;
 }
 
 __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
 	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm)
 {
-	extern __shared__ __attribute__((aligned(16))) float sg_lds[];
+	__shared__ __attribute__((aligned(16))) float sX[SG_KC*SG_BX];
+	__shared__ __attribute__((aligned(16))) float sY[SG_KC*SG_BY];
 	unsigned bxi, byi;
 	if (!sg_tile_of_block(blockIdx.x, ntx, nty, bxi, byi)) return;
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu; // fused min(vals)/max(vals) (heightmap_t::run_erosion, get_heightmap_z_range): saves a 4 B/cell read pass
-	int const nk = F_TABLE_SIZE - job.kstart;
-	float *sX = sg_lds, *sY = sg_lds + nk*SG_BX;
 	unsigned const tid = threadIdx.x, bx0 = bxi*SG_BX, by0 = byi*SG_BY;
-	// stage the tile's table slices: rows kstart..89 of xt (SG_BX wide) and yt (SG_BY wide); tables are zero-padded to 128
-	for (int idx = tid; idx < nk*(SG_BX/4); idx += SG_THREADS) {
-		int const k = idx/(SG_BX/4), c = idx % (SG_BX/4);
-		*(float4 *)&sX[k*SG_BX + c*4] = *(float4 const *)&xt[(size_t)(job.kstart + k)*job.nxp + bx0 + c*4];
-	}
-	for (int idx = tid; idx < nk*(SG_BY/4); idx += SG_THREADS) {
-		int const k = idx/(SG_BY/4), c = idx % (SG_BY/4);
-		*(float4 *)&sY[k*SG_BY + c*4] = *(float4 const *)&yt[(size_t)(job.kstart + k)*job.nyp + by0 + c*4];
-	}
-	__syncthreads();
 	unsigned const tx = tid & 15, ty = tid >> 4;
+	// thread (tx,ty) owns columns {tx*4..+3} u {64+tx*4..+3} and rows {ty*4..+3} u {64+ty*4..+3}: every LDS read is one aligned ds_read_b128,
+	// 16 distinct 16-byte slots per 16-lane group for X (conflict-free) and a broadcast for Y
+	float const *px = sX + tx*4, *py = sY + ty*4;
 	float acc[SG_TY][SG_TX];
 #pragma unroll
 	for (int i = 0; i < SG_TY; ++i) {
 #pragma unroll
 		for (int j = 0; j < SG_TX; ++j) {acc[i][j] = 0.0f;}
 	}
-	// thread (tx,ty) owns columns {tx*4..tx*4+3} and {64+tx*4..} and rows ty*4..ty*4+3: every LDS read is one aligned ds_read_b128
-	float const *px = sX + tx*4, *py = sY + ty*4;
-#pragma unroll 2
-	for (int k = 0; k < nk; ++k) {
-		float4 const xa = *(float4 const *)(px + k*SG_BX), xb = *(float4 const *)(px + k*SG_BX + 64), ya = *(float4 const *)(py + k*SG_BY);
-		float const xs[SG_TX] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, ys[SG_TY] = {ya.x, ya.y, ya.z, ya.w};
-#pragma unroll
-		for (int i = 0; i < SG_TY; ++i) {
-#pragma unroll
-			for (int j = 0; j < SG_TX; ++j) {acc[i][j] = __fadd_rn(acc[i][j], __fmul_rn(xs[j], ys[i]));} // zval += xptr[k]*yptr[k]: product rounded, then added
+	int const nk = F_TABLE_SIZE - job.kstart, nchunks = (nk + SG_KC - 1)/SG_KC, per_chunk = (nk + nchunks - 1)/nchunks;
+	for (int c = 0; c < nchunks; ++c) { // terms are summed in k order across chunks, exactly like the CPU loop
+		int const k0 = job.kstart + c*per_chunk, kn = ((k0 + per_chunk > F_TABLE_SIZE) ? F_TABLE_SIZE - k0 : per_chunk);
+		if (c > 0) {__syncthreads();} // everyone is done reading the previous chunk
+		for (int idx = tid; idx < kn*(SG_BX/4); idx += SG_THREADS) { // tables are zero-padded to a multiple of 128 columns / rows
+			int const k = idx/(SG_BX/4), q = idx % (SG_BX/4);
+			*(float4 *)&sX[k*SG_BX + q*4] = *(float4 const *)&xt[(size_t)(k0 + k)*job.nxp + bx0 + q*4];
+			*(float4 *)&sY[k*SG_BY + q*4] = *(float4 const *)&yt[(size_t)(k0 + k)*job.nyp + by0 + q*4];
 		}
+		__syncthreads();
+		// two operand sets in ping-pong: the loads of step k+1 are in flight while step k is accumulated, without register copies
+		sg_operands_t A = sg_load(px, py, 0), B;
+		int k = 0;
+		for (; k + 2 < kn; k += 2) {
+			B = sg_load(px, py, k + 1);
+			sg_accumulate(acc, A);
+			A = sg_load(px, py, k + 2);
+			sg_accumulate(acc, B);
+		}
+		if (k + 1 < kn) {B = sg_load(px, py, k + 1); sg_accumulate(acc, A); sg_accumulate(acc, B);}
+		else {sg_accumulate(acc, A);}
 	}
+	// ---- epilogue (eval_index's tail, src/mesh_gen.cpp:781-790): shape / post-process, glaciate, sine-mag islands, volcano.
+	// The common configuration (linear shape, no plateau/crater/crack, no volcano) takes a short path with the island terms of the
+	// thread's 8 columns / 8 rows loaded once; anything else goes through the general finish_cell().  Same arithmetic either way.
 	bool const vec_ok = ((job.nx & 3u) == 0);
+	hmap_params_t const &hp = nc.hp;
+	bool const plain = (job.shape == 0) && !(hp.crack_lo < hp.crack_hi) && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f);
+	float const pp_limit = min_std(hp.plat_bot, hp.crat_h); // below this the post-process is the identity
+	float smxv[SG_TX], smyv[SG_TY];
+#pragma unroll
+	for (int j = 0; j < SG_TX; ++j) {unsigned const x = bx0 + (j >> 2)*64 + tx*4 + (j & 3); smxv[j] = (job.use_sine_mag && x < job.nx) ? smx[x] : 0.0f;}
+#pragma unroll
+	for (int i = 0; i < SG_TY; ++i) {unsigned const y = by0 + (i >> 2)*64 + ty*4 + (i & 3); smyv[i] = (job.use_sine_mag && y < job.ny) ? smy[y] : 0.0f;}
+	float fmn = INFINITY, fmx = -INFINITY;
 #pragma unroll
 	for (int i = 0; i < SG_TY; ++i) {
-		unsigned const y = by0 + ty*4 + i;
+		unsigned const y = by0 + (i >> 2)*64 + ty*4 + (i & 3);
 		if (y >= job.ny) continue;
 #pragma unroll
 		for (int half = 0; half < 2; ++half) {
@@ -111,7 +144,18 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 			if (x >= job.nx) continue;
 			float v[4];
 #pragma unroll
-			for (int j = 0; j < 4; ++j) {v[j] = (x + j < job.nx) ? finish_cell(acc[i][half*4 + j], job, nc, L, smx, smy, x + j, y) : 0.0f; if (mm && x + j < job.nx) {minmax_acc(v[j], mm_lo, mm_hi);}}
+			for (int j = 0; j < 4; ++j) {
+				float z = acc[i][half*4 + j];
+				if (plain && !(z > pp_limit)) {
+					if (job.glaciate) {
+						if (nc.glaciate) {float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv; z = glaciate_exp_fn(relh, nc.custom_glaciate_exp)*nc.zmax_est2 - nc.zmax_est;}
+						if (job.use_sine_mag) {z += smxv[half*4 + j]*smyv[i] + job.sine_offset;}
+					}
+				}
+				else {z = (x + j < job.nx) ? finish_cell(z, job, nc, L, smx, smy, x + j, y) : 0.0f;}
+				v[j] = z;
+				if (x + j < job.nx) {fmn = fminf(fmn, z); fmx = fmaxf(fmx, z);} // fminf/fmaxf skip NaNs, like min_eq/max_eq never let a NaN win
+			}
 			float *o = out + (size_t)y*job.nx + x;
 			if (vec_ok) {*(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);}
 			else {
@@ -120,7 +164,10 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 			}
 		}
 	}
-	if (mm) {wave_minmax_publish(mm_lo, mm_hi, mm);}
+	if (mm) {
+		if (fmn <= fmx) {mm_lo = f2ord(fmn); mm_hi = ~f2ord(fmx);}
+		wave_minmax_publish(mm_lo, mm_hi, mm);
+	}
 }
 
 // ------------------------------------------------------------------ K2/K3: fBm / domain-warp grid, one cell per thread, x fastest
