@@ -35,12 +35,13 @@ VALU_PEAK_TOPS = 78.6      # fp32 VALU without FMA: 256 CU x 4 SIMD x 32 lanes x
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=16)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--size", type=int, default=16384)
     p.add_argument("--mode", default="sine", choices=sorted(MODES))
     p.add_argument("--droplets", type=int, default=1000)
     p.add_argument("--octaves", type=int, default=8)
+    p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-size", type=int, default=0, help="grid edge of the CPU sample (default: min(size, 8192))")
     return p.parse_args()
@@ -86,34 +87,54 @@ def main():
     pkg = importlib.import_module("3dworld_amd")
     if not os.path.exists(pkg.default_lib_path()):
         raise SystemExit("libterra_hip.so missing: run __graft_entry__.build() (no CPU fall-back)")
-    t = pkg.Terra(local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    t.set_stream(stream.cuda_stream)          # library work and torch events share one HIP stream
+    import threading
     mode = MODES[args.mode]
-    st = t.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
     N = args.size
     cells = N * N
-    z = torch.empty(cells, dtype=torch.float32, device=dev)
+    P = max(1, min(args.pipelines, args.steps))
+    # P independent heightmaps in flight per GPU, each with its own context (HIP stream, scratch) and its own z grid in HBM.
+    # A heightmap's erosion is a latency-bound chain of dependent droplet steps on ~1000 waves; the next heightmap's noise kernel
+    # (VALU-bound, whole chip) runs beside it.  The reference keeps 8 generator objects in flight for the same reason (src/tiled_mesh.h:418).
+    ctxs = [pkg.Terra(local_rank) for _ in range(P)]
+    sts = [c.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves)) for c in ctxs]
+    st = sts[0]
+    t = ctxs[0]
+    zs = [torch.empty(cells, dtype=torch.float32, device=dev) for _ in range(P)]
+    z = zs[0]
     x0 = -N / 2 + rank * N  # each rank owns its own N x N region of the world
     y0 = -N / 2
 
-    def step():
-        # heightmap_t::proc_gen on the device: noise + glaciate -> min -> erosion (in place)
-        mn, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
-        t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                     # run_erosion passes min(vals): only written cells can need the clamp
+    def step(p=0):
+        # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
+        c, zz = ctxs[p], zs[p]
+        mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
+        c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                   # run_erosion passes min(vals): only written cells can need the clamp
+
+    def run_steps(k):
+        """k steps in total, dealt round-robin to the P pipelines (one host thread each: the library calls release the GIL)."""
+        if P == 1:
+            for _ in range(k):
+                step(0)
+            return
+        def worker(p):
+            for _ in range(p, k, P):
+                step(p)
+        th = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
+    if True:
+        run_steps(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run_steps(args.steps)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         barrier()
@@ -162,7 +183,7 @@ def main():
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident",
-                          "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "parallelism": f"{world} independent regions (one per GPU), no collective"},
+                          "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P, "parallelism": f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU"},
                "roofline": roof, "detail": dict(detail, erosion=rep)}
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -170,7 +191,8 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
-    t.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
