@@ -1,0 +1,87 @@
+// terra_cxx.hpp -- engine-side C++ mirror of the reference's call surface over the C ABI (include/terra.h).
+//
+// Same names, argument meaning and blocking behaviour as the 3DWorld interfaces they stand in for, so the callers
+// (tile_t::create_zvals, heightmap_t::proc_gen, gen_mesh, voxel_manager) stay untouched:
+//   mesh_xy_grid_cache_t  src/mesh.h:22-45        (build_arrays / enable_glaciate / eval_index / clear_context / free_cshader)
+//   apply_erosion         src/function_registry.h:354, src/erosion.cpp:14
+//   create_procedural     src/voxels.cpp:278      (fill part)
+// Header only; link with -lterra_hip.  The reference asserts on misuse; so does this header (terra_status < 0 -> assert + message).
+#pragma once
+#include "terra.h"
+#include <vector>
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+
+namespace terra_cxx {
+
+inline void check(int rc, char const *what) {
+	if (rc < 0) {std::fprintf(stderr, "terra: %s failed (%d): %s\n", what, rc, terra_last_error()); assert(!"terra call failed"); std::abort();}
+}
+
+// process-wide context, like the engine's process-wide globals; created on first use on GPU 0 (TERRA_DEVICE overrides)
+inline terra_ctx *default_ctx() {
+	static terra_ctx *ctx = [] {
+		terra_ctx *c = nullptr;
+		char const *dev = std::getenv("TERRA_DEVICE");
+		check(terra_create(&c, dev ? std::atoi(dev) : 0), "terra_create");
+		return c;
+	}();
+	return ctx;
+}
+
+// Call once after the engine has loaded its config and derived its globals (after gen_scene()/estimate_zminmax()):
+// copies the config-file values and the derived globals across the boundary.  Alternatively terra_init_scene() derives them itself.
+inline void set_engine_state(terra_config const &cfg, terra_state const &st) {
+	check(terra_set_config(default_ctx(), &cfg), "terra_set_config");
+	check(terra_set_state(default_ctx(), &st), "terra_set_state");
+}
+
+class mesh_xy_grid_cache_t { // src/mesh.h:22-45
+	terra_gen *gen = nullptr;
+	unsigned cur_nx = 0, cur_ny = 0;
+	terra_gen *handle() {if (!gen) {check(terra_gen_create(default_ctx(), &gen), "terra_gen_create");} return gen;}
+public:
+	mesh_xy_grid_cache_t() = default;
+	mesh_xy_grid_cache_t(mesh_xy_grid_cache_t const &) = delete;
+	mesh_xy_grid_cache_t &operator=(mesh_xy_grid_cache_t const &) = delete;
+	~mesh_xy_grid_cache_t() {clear_context();}
+	// returns 1 when values are available, 0 when no_wait and the job was only launched (call again with the same arguments)
+	bool build_arrays(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, bool cache_values=0, bool force_sine_mode=0, bool no_wait=0) {
+		assert(nx > 0 && ny > 0);
+		unsigned const flags = (cache_values ? TERRA_GEN_CACHE_VALUES : 0u) | (force_sine_mode ? TERRA_GEN_FORCE_SINE : 0u) | (no_wait ? TERRA_GEN_NO_WAIT : 0u);
+		int const rc = terra_gen_build_arrays(handle(), x0, y0, dx, dy, nx, ny, flags);
+		check(rc, "build_arrays");
+		cur_nx = nx; cur_ny = ny;
+		return rc != 0;
+	}
+	void enable_glaciate() {check(terra_gen_enable_glaciate(handle()), "enable_glaciate");}
+	// min_start_sin / use_cache are accepted for source compatibility; the device always evaluates from start_eval_sin and caches every cell
+	float eval_index(unsigned x, unsigned y, int /*min_start_sin*/=0, bool /*use_cache*/=1) const {
+		assert(x < cur_nx && y < cur_ny);
+		return terra_gen_eval_index(gen, x, y);
+	}
+	float const *device_values() const {return terra_gen_device_values(gen);} // extension: the grid stays in HBM for erosion / normals
+	void clear_context() {if (gen) {terra_gen_destroy(gen); gen = nullptr;}}
+	void free_cshader() {} // nothing GL-side to release
+};
+
+// src/erosion.cpp:14 -- in place on a host buffer, blocking, silent no-op when disabled
+inline void apply_erosion(float *heightmap, int xsize, int ysize, float min_zval, unsigned num_iters) {
+	check(terra_apply_erosion(default_ctx(), heightmap, xsize, ysize, min_zval, num_iters), "apply_erosion");
+}
+
+// tile_t::create_zvals for a batch of tiles (src/tiled_mesh.cpp:467-546): zvals n*130*130, stats n, normals n*129*129*4 (optional)
+inline void tiles_create_zvals(int const *tile_xy, unsigned n, unsigned erosion_iters_tt, float *zvals, terra_tile_stats *stats, unsigned char *normals=nullptr, float *min_normal_z=nullptr) {
+	check(terra_tiles_create_zvals(default_ctx(), tile_xy, n, erosion_iters_tt, zvals, stats, normals, min_normal_z), "tiles_create_zvals");
+}
+
+// voxel_manager::create_procedural fill (src/voxels.cpp:278-346): `vals` is the voxel_grid<float> storage, z fastest
+inline void voxel_create_procedural(std::vector<float> &vals, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],
+	float mag, float freq, bool normalize_to_1, int rseed1, int rseed2, int gen_mode, float zscale)
+{
+	vals.resize((size_t)nx*ny*nz);
+	check(terra_voxel_fill(default_ctx(), vals.data(), nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize_to_1 ? 1 : 0), "voxel_create_procedural");
+}
+
+} // namespace terra_cxx

@@ -51,3 +51,9 @@ def test_product_does_not_link_the_oracle(product_lib):
             if f.endswith((".py", ".hpp", ".hip")):
                 txt = open(os.path.join(ROOT, "3dworld_amd", d, f)).read()
                 assert "liboracle" not in txt and "terra_oracle" not in txt and "orclib" not in txt, f
+
+
+def test_cxx_mirror_header_keeps_reference_signatures():
+    """include/terra_cxx.hpp: mesh_xy_grid_cache_t::build_arrays/enable_glaciate/eval_index and apply_erosion with the reference's signatures."""
+    import subprocess
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "cxx_mirror_check.cpp")], check=True)
