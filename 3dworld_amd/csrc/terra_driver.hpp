@@ -66,6 +66,14 @@ TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsig
 }
 
 
+// tile_t::get_norm (src/tiled_mesh.h:281-284): n = normalize(DY*(z - z[+1]), DX*(z - z[+zvsize]), dxdy), pointT::get_norm (src/3DWorld.h:297-300, TOLERANCE :50)
+TERRA_HD void tile_normal(float const *z, unsigned x, unsigned y, float dxv, float dyv, float dxy, float nv[3]) {
+	unsigned const zv = 130, ix2 = y*zv + x;
+	nv[0] = dyv*(z[ix2] - z[ix2 + 1]); nv[1] = dxv*(z[ix2] - z[ix2 + zv]); nv[2] = dxy;
+	float const mag = sqrtf(nv[0]*nv[0] + nv[1]*nv[1] + nv[2]*nv[2]);
+	if (!(mag < 1.0E-12f)) {nv[0] /= mag; nv[1] /= mag; nv[2] /= mag;}
+}
+
 template<class BE> struct terra_engine {
 	BE be;
 	terra_config cfg{};
@@ -504,7 +512,10 @@ template<class BE> struct terra_engine {
 			refs[i].yi = (uint32_t)(std::lower_bound(uy.begin(), uy.end(), refs[i].ty) - uy.begin());
 		}
 		uint32_t const nux = (uint32_t)ux.size(), nuy = (uint32_t)uy.size();
-		size_t const tab_floats = (size_t)(nux + nuy)*F_TABLE_SIZE*zv, sm_floats = (size_t)(nux + nuy)*zv;
+		// tables of all distinct tile columns / rows side by side, k-major like the big-grid tables: xt[k][u*130 + c], yt[k][u*130 + c].
+		// The batch is then ONE "virtual" (nux*130) x (nuy*130) sine grid whose cells are exactly the requested tiles' cells.
+		uint32_t const nxpv = round_up(nux*zv, 128), nypv = round_up(nuy*zv, 128);
+		size_t const tab_floats = (size_t)F_TABLE_SIZE*(nxpv + nypv), sm_floats = (size_t)(nux + nuy)*zv;
 		size_t const bytes = refs.size()*sizeof(tile_ref_t) + (nux + nuy)*sizeof(sine_k_t) + (tab_floats + sm_floats)*4 + 1024;
 		uint8_t *base = scratch<uint8_t>(s_tiles, bytes);
 		tile_ref_t *d_refs = (tile_ref_t *)base;
@@ -533,71 +544,32 @@ template<class BE> struct terra_engine {
 				else         {d_sm[i] = L.COSF(((float)c*dyv + d_m0[u])*dyi*freq);}
 			});
 		}
-		if (md == MGEN_SINE) { // tables [u][k][c]
+		float *d_taby = d_tab + (size_t)F_TABLE_SIZE*nxpv;
+		if (md == MGEN_SINE) {
 			be.launch(tab_floats, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const c = (unsigned)(i % zv), k = (unsigned)((i / zv) % F_TABLE_SIZE), u = (unsigned)(i / ((size_t)zv*F_TABLE_SIZE));
-				sine_k_t const &sk = d_sk[u];
-				d_tab[i] = (u < nux) ? L.SINF(sk.xmdx[k]*(float)c + sk.xconst[k]) : sk.yscale[k]*L.SINF(sk.ymdy[k]*(float)c + sk.yconst[k]);
+				bool const isx = i < (size_t)F_TABLE_SIZE*nxpv;
+				size_t const j = isx ? i : i - (size_t)F_TABLE_SIZE*nxpv;
+				unsigned const rowlen = isx ? nxpv : nypv, k = (unsigned)(j / rowlen), v = (unsigned)(j % rowlen), u = v / zv, c = v % zv;
+				float val = 0.0f; // zero padding up to a multiple of 128
+				if (u < (isx ? nux : nuy)) {
+					sine_k_t const &sk = d_sk[isx ? u : nux + u];
+					val = isx ? L.SINF(sk.xmdx[k]*(float)c + sk.xconst[k]) : sk.yscale[k]*L.SINF(sk.ymdy[k]*(float)c + sk.yconst[k]);
+				}
+				d_tab[i] = val;
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_zvals);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_zvals);
 		// erosion: every tile alone on its clamp-padded 138x138 copy, droplets in order (src/tiled_mesh.cpp:515)
 		if (iters_tt > 0 && erode_amount > 0.0f) {
 			erosion_consts_t const ec = make_erosion_consts((int)zv, (int)zv, zmin);
 			be.tile_erosion(n, d_zvals, ec, iters_tt);
 		}
-		// sub-block z ranges + water bbox (src/tiled_mesh.cpp:517-541)
-		if (d_stats) {
+		// sub-block z ranges + water bbox (src/tiled_mesh.cpp:517-541) and normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880)
+		if (d_stats || d_normals) {
 			float const wpz_max = get_max_sea_level();
 			float const rad_c = (dxv*dxv + dyv*dyv)*size*size;
-			be.launch((size_t)n*16, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const t = (unsigned)(i >> 4), sbk = (unsigned)(i & 15), yy = sbk >> 2, xx = sbk & 3, bs = zv/4;
-				float const *z = d_zvals + (size_t)t*zv*zv;
-				float szmin = 100.0f, szmax = -100.0f; // FAR_DISTANCE (src/3DWorld.h:116)
-				for (unsigned y = yy*bs; y <= (yy+1)*bs; ++y) {
-					for (unsigned x = xx*bs; x <= (xx+1)*bs; ++x) {float const v = z[y*zv + x]; szmin = min_std(szmin, v); szmax = max_std(szmax, v);}
-				}
-				d_stats[t].sub_zmin[sbk] = szmin; d_stats[t].sub_zmax[sbk] = szmax;
-			});
-			be.launch(n, [=] TERRA_LAMBDA (size_t t) {
-				tile_ref_t const r = d_refs[t];
-				int const x1 = r.tx*(int)size, y1 = r.ty*(int)size;
-				float const *z = d_zvals + (size_t)t*zv*zv;
-				terra_tile_stats &st = d_stats[t];
-				float mzmin = 100.0f, mzmax = -100.0f;
-				for (int sbk = 0; sbk < 16; ++sbk) {mzmin = min_std(mzmin, st.sub_zmin[sbk]); mzmax = max_std(mzmax, st.sub_zmax[sbk]);}
-				int wx1 = x1 + (int)size, wy1 = y1 + (int)size, wx2 = x1, wy2 = y1;
-				unsigned const lim = 4*(zv/4); // cells 0..128 are visited by the 4x4 blocks; row/column 129 is skipped
-				for (unsigned y = 0; y <= lim; ++y) {
-					for (unsigned x = 0; x <= lim; ++x) {
-						if (z[y*zv + x] < wpz_max) {wx1 = imin(wx1, x1+(int)x); wy1 = imin(wy1, y1+(int)y); wx2 = imax(wx2, x1+(int)x); wy2 = imax(wy2, y1+(int)y);}
-					}
-				}
-				st.mzmin = mzmin; st.mzmax = mzmax;
-				st.radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
-				st.wx1 = wx1; st.wy1 = wy1; st.wx2 = wx2; st.wy2 = wy2;
-			});
-		}
-		// normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880)
-		if (d_normals) {
-			uint32_t *d_mnz = (uint32_t *)d_min_nz;
-			if (d_mnz) {be.fill32(d_mnz, 0x3F800000u /*1.0f*/, n);}
-			float const dxy = dxdy;
-			be.launch((size_t)n*stride*stride, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const t = (unsigned)(i / (stride*stride)), p = (unsigned)(i % (stride*stride)), y = p / stride, x = p % stride;
-				float const *z = d_zvals + (size_t)t*zv*zv;
-				unsigned const ix2 = y*zv + x;
-				float nv[3] = {dyv*(z[ix2] - z[ix2 + 1]), dxv*(z[ix2] - z[ix2 + zv]), dxy};
-				float const mag = sqrtf(nv[0]*nv[0] + nv[1]*nv[1] + nv[2]*nv[2]);
-				if (!(mag < 1.0E-12f)) {nv[0] /= mag; nv[1] /= mag; nv[2] /= mag;} // pointT::get_norm (src/3DWorld.h:297-300), TOLERANCE (:50)
-				uint8_t *o = d_normals + i*4;
-				o[0] = (uint8_t)(127.0*((double)nv[0] + 1.0)); o[1] = (uint8_t)(127.0*((double)nv[1] + 1.0)); o[2] = (uint8_t)(127.0*((double)nv[2] + 1.0)); o[3] = 0;
-				if (d_mnz && nv[2] < 1.0f) { // min_normal_z = min(min_normal_z, norm.z), seeded with 1.0; norm.z = dxdy/mag >= 0 so uint order == float order; NaN never wins
-					uint32_t u; memcpy(&u, &nv[2], 4);
-					TERRA_ATOMIC_MIN(&d_mnz[t], u);
-				}
-			});
+			be.tile_post(n, d_refs, d_zvals, d_stats, d_normals, d_min_nz, wpz_max, rad_c, dxv, dyv, dxdy);
 		}
 	}
 

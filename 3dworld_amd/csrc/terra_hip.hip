@@ -29,6 +29,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	~hip_backend_t() {
 		if (tile_pad) (void)hipFree(tile_pad);
+		if (tile_map) (void)hipFree(tile_map);
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
 		if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -68,7 +69,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm);
+		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, terra::sg_tiles_t{nullptr, nullptr, 0});
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
@@ -85,15 +86,45 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
-	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
-		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
+	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
+	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals)
+	{
+		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
+		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
+		if (simple_kernels || md != terra::MGEN_SINE || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals); return;}
+		use();
+		size_t const cnt = (size_t)nux*nuy;
+		if (cnt > tile_map_count) {if (tile_map) {sync(); (void)hipFree(tile_map);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_map, cnt*sizeof(int32_t))); tile_map_count = cnt;}
+		fill32(tile_map, 0xFFFFFFFFu, cnt);
+		int32_t *tm = tile_map;
+		launch(n, [=] TERRA_LAMBDA (size_t i) {terra::tile_ref_pod_t const r = refs[i]; tm[(size_t)r.yi*nux + r.xi] = (int32_t)i;});
+		terra::grid_job_t job;
+		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*130; job.ny = nuy*130; job.nxp = nxpv; job.nyp = nypv;
+		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
+		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
+		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, terra::sg_tiles_t{tm, d_m0, nux});
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
+	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
+		if (simple_kernels) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;}
+		use();
+		hipLaunchKernelGGL(terra::k_tile_post, dim3(n), dim3(256), 0, stream, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
 		use();
 		size_t const lds = (size_t)ec.NX*ec.NY*sizeof(float);
-		if (simple_kernels || lds > 96*1024) { // cross-check path: padded scratch in HBM
+		// default: the whole clamp-padded tile resident in LDS (76 KB, 2 tiles per CU; measured 126 ms for 4096 tiles x 1000 droplets);
+		// TERRA_TILE_EROSION=window: a 32x32 LDS window over an HBM/L2-resident copy (10 KB, ~15 tiles per CU; 141 ms: the batch is bound by its
+		// heaviest land tiles, ~50k dependent droplet steps each, not by occupancy).  Grids too large for LDS always use the window.
+		char const *sel = getenv("TERRA_TILE_EROSION");
+		bool const use_lds = !(sel && sel[0] == 'w') && lds <= 96*1024;
+		if (!use_lds) {
 			size_t const bytes = (size_t)n*lds;
 			if (bytes > tile_pad_bytes) {if (tile_pad) {sync(); (void)hipFree(tile_pad);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_pad, bytes)); tile_pad_bytes = bytes;}
-			tile_erosion_simple(n, zvals, ec, iters, tile_pad);
+			if (simple_kernels) {tile_erosion_simple(n, zvals, ec, iters, tile_pad);} // cross-check path: one scalar lane per tile
+			else {tile_erosion_windowed(n, zvals, ec, iters, tile_pad);}
 			return;
 		}
 		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters);

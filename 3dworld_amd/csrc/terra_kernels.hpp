@@ -63,6 +63,10 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 	return bx < ntx;
 }
 
+// tile batches run as one "virtual" grid whose columns / rows are the distinct tile columns / rows side by side (130 cells each);
+// the epilogue scatters every cell to its tile's [130][130] block (tile_map[uy*nux + ux] = tile slot or -1 when that pair was not requested)
+struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux;};
+
 struct sg_operands_t {float4 xa, xb, ya, yb;};
 __device__ __forceinline__ sg_operands_t sg_load(float const *px, float const *py, int k) {
 	sg_operands_t o;
@@ -81,7 +85,7 @@ __device__ __forceinline__ void sg_accumulate(float (&acc)[SG_TY][SG_TX], sg_ope
 }
 
 __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
-	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm)
+	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm, sg_tiles_t tiles)
 {
 	__shared__ __attribute__((aligned(16))) float sX[SG_KC*SG_BX];
 	__shared__ __attribute__((aligned(16))) float sY[SG_KC*SG_BY];
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 	// ---- epilogue (eval_index's tail, src/mesh_gen.cpp:781-790): shape / post-process, glaciate, sine-mag islands, volcano.
 	// The common configuration (linear shape, no plateau/crater/crack, no volcano) takes a short path with the island terms of the
 	// thread's 8 columns / 8 rows loaded once; anything else goes through the general finish_cell().  Same arithmetic either way.
-	bool const vec_ok = ((job.nx & 3u) == 0);
+	bool const vec_ok = ((job.nx & 3u) == 0) && !tiles.tile_map;
 	hmap_params_t const &hp = nc.hp;
 	bool const plain = (job.shape == 0) && !(hp.crack_lo < hp.crack_hi) && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f);
 	float const pp_limit = min_std(hp.plat_bot, hp.crat_h); // below this the post-process is the identity
@@ -152,9 +156,28 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 						if (job.use_sine_mag) {z += smxv[half*4 + j]*smyv[i] + job.sine_offset;}
 					}
 				}
-				else {z = (x + j < job.nx) ? finish_cell(z, job, nc, L, smx, smy, x + j, y) : 0.0f;}
+				else if (x + j < job.nx) {
+					if (tiles.tile_map) { // general epilogue in tile-local coordinates (volcano term needs the tile's own origin)
+						unsigned const ux = (x + j)/130u, uy = y/130u;
+						grid_job_t jt = job; jt.mx0 = tiles.m0[ux]; jt.my0 = tiles.m0[tiles.nux + uy];
+						z = finish_cell(z, jt, nc, L, smx + ux*130u, smy + uy*130u, (x + j) - ux*130u, y - uy*130u);
+					}
+					else {z = finish_cell(z, job, nc, L, smx, smy, x + j, y);}
+				}
+				else {z = 0.0f;}
 				v[j] = z;
 				if (x + j < job.nx) {fmn = fminf(fmn, z); fmx = fmaxf(fmx, z);} // fminf/fmaxf skip NaNs, like min_eq/max_eq never let a NaN win
+			}
+			if (tiles.tile_map) {
+				unsigned const uy = y/130u, cy = y - uy*130u;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					if (x + j >= job.nx) continue;
+					unsigned const ux = (x + j)/130u, cx = (x + j) - ux*130u;
+					int const t = tiles.tile_map[uy*tiles.nux + ux];
+					if (t >= 0) {out[(size_t)t*16900u + cy*130u + cx] = v[j];}
+				}
+				continue;
 			}
 			float *o = out + (size_t)y*job.nx + x;
 			if (vec_ok) {*(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);}
@@ -202,6 +225,55 @@ __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, 
 		int const x = i % xs, y = i / xs;
 		z[i] = max_std(ec.min_zval, te_pad[(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
 	}
+}
+
+// ------------------------------------------------------------------ K6+K7: tile post-pass, one 256-thread block per tile
+// sub-block z ranges, water bbox (ints), mzmin/mzmax/radius (src/tiled_mesh.cpp:517-541) and RGBA8 normals + min_normal_z (src/tiled_mesh.cpp:865-880).
+// HBM-bound: 4 B read + 4 B written per cell; reductions go through LDS atomics on order-preserving uints.
+__global__ __launch_bounds__(256) void k_tile_post(tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, terra_tile_stats *__restrict__ stats,
+	uint8_t *__restrict__ normals, float *__restrict__ min_nz, float wpz_max, float rad_c, float dxv, float dyv, float dxy)
+{
+	__shared__ uint32_t s_lo[16], s_hi[16], s_mnz;
+	__shared__ int s_bb[4];
+	unsigned const t = blockIdx.x, tid = threadIdx.x, zv = 130, stride = 129, bs = 32;
+	tile_ref_pod_t const r = refs[t];
+	int const x1 = r.tx*128, y1 = r.ty*128;
+	if (tid < 16) {s_lo[tid] = f2ord(100.0f); s_hi[tid] = ~f2ord(-100.0f);} // szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
+	if (tid == 0) {s_mnz = 0x3F800000u; s_bb[0] = x1 + 128; s_bb[1] = y1 + 128; s_bb[2] = x1; s_bb[3] = y1;} // water bbox starts denormalized
+	__syncthreads();
+	float const *z = zvals + (size_t)t*zv*zv;
+	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) : nullptr;
+	for (unsigned p = tid; p < stride*stride; p += 256) { // cells 0..128 x 0..128: exactly the cells the 4x4 sub-blocks visit and the texels of the normal map
+		unsigned const y = p/stride, x = p - y*stride;
+		float const v = z[y*zv + x];
+		if (stats) {
+			if (v == v) { // std::min / std::max never let a NaN win
+				uint32_t const o = f2ord(v);
+				unsigned const xa = (x == 0) ? 0 : (x - 1)/bs, xb = (x/bs > 3) ? 3 : x/bs, ya = (y == 0) ? 0 : (y - 1)/bs, yb = (y/bs > 3) ? 3 : y/bs; // sub-blocks overlap on their shared edges
+				for (unsigned yy = ya; yy <= yb; ++yy) {for (unsigned xx = xa; xx <= xb; ++xx) {atomicMin(&s_lo[yy*4 + xx], o); atomicMin(&s_hi[yy*4 + xx], ~o);}}
+			}
+			if (v < wpz_max) {atomicMin(&s_bb[0], x1 + (int)x); atomicMin(&s_bb[1], y1 + (int)y); atomicMax(&s_bb[2], x1 + (int)x); atomicMax(&s_bb[3], y1 + (int)y);}
+		}
+		if (nout) {
+			float nv[3];
+			tile_normal(z, x, y, dxv, dyv, dxy, nv);
+			uint32_t const b0 = (uint8_t)(127.0*((double)nv[0] + 1.0)), b1 = (uint8_t)(127.0*((double)nv[1] + 1.0)), b2 = (uint8_t)(127.0*((double)nv[2] + 1.0));
+			nout[p] = b0 | (b1 << 8) | (b2 << 16); // A = 0
+			if (nv[2] < 1.0f) {uint32_t u; memcpy(&u, &nv[2], 4); atomicMin(&s_mnz, u);}
+		}
+	}
+	__syncthreads();
+	if (stats) {
+		if (tid < 16) {stats[t].sub_zmin[tid] = ord2f(s_lo[tid]); stats[t].sub_zmax[tid] = ord2f(~s_hi[tid]);}
+		if (tid == 0) {
+			float mzmin = 100.0f, mzmax = -100.0f;
+			for (int k = 0; k < 16; ++k) {mzmin = min_std(mzmin, ord2f(s_lo[k])); mzmax = max_std(mzmax, ord2f(~s_hi[k]));}
+			stats[t].mzmin = mzmin; stats[t].mzmax = mzmax;
+			stats[t].radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
+			stats[t].wx1 = s_bb[0]; stats[t].wy1 = s_bb[1]; stats[t].wx2 = s_bb[2]; stats[t].wy2 = s_bb[3];
+		}
+	}
+	if (min_nz && nout && tid == 0) {float f; uint32_t const u = s_mnz; memcpy(&f, &u, 4); min_nz[t] = f;}
 }
 
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell

@@ -21,21 +21,95 @@ template<class DERIVED> struct simple_paths {
 			out[i] = finish_cell(noise_cell(job, nc, x, y), job, nc, L, smx, smy, x, y);
 		});
 	}
-	// tiles: d_tab = [nux + nuy][90][130] tables, d_sm = [nux + nuy][130] sine-mag terms, d_m0 = per distinct tx / ty grid origin (mx0 / my0)
-	void tile_grid_simple(uint32_t n, tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals)
+	// tiles: xt / yt = k-major tables of all distinct tile columns / rows side by side (row lengths nxpv / nypv), d_sm = [nux + nuy][130] sine-mag terms,
+	// d_m0 = per distinct tx / ty grid origin (mx0 / my0)
+	void tile_grid_simple(uint32_t n, tile_ref_pod_t const *refs, uint32_t nux, uint32_t /*nuy*/, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv,
+		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals)
 	{
 		unsigned const zv = 130;
 		self().launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
 			tile_ref_pod_t const r = refs[t];
 			grid_job_t job;
-			job.mx0 = d_m0[r.xi]; job.my0 = d_m0[nux + r.yi]; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = zv; job.nxp = job.nyp = zv;
+			job.mx0 = d_m0[r.xi]; job.my0 = d_m0[nux + r.yi]; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = zv; job.nxp = nxpv; job.nyp = nypv;
 			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = sine_offset;
 			float z;
-			if (md == MGEN_SINE) {z = sine_cell(job, d_tab + (size_t)r.xi*F_TABLE_SIZE*zv, d_tab + (size_t)(nux + r.yi)*F_TABLE_SIZE*zv, x, y);}
+			if (md == MGEN_SINE) {z = sine_cell(job, xt, yt, r.xi*zv + x, r.yi*zv + y);}
 			else {z = noise_cell(job, nc, x, y);}
 			zvals[i] = finish_cell(z, job, nc, L, d_sm + (size_t)r.xi*zv, d_sm + (size_t)(nux + r.yi)*zv, x, y);
+		});
+	}
+	// tile post-pass, simple form: sub-block ranges + water bbox (one logical thread per (tile, sub-block) then per tile), normals (one per texel)
+	void tile_post_simple(uint32_t n, tile_ref_pod_t const *d_refs, float const *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz,
+		float wpz_max, float rad_c, float dxv, float dyv, float dxy)
+	{
+		unsigned const size = 128, stride = 129, zv = 130;
+		if (d_stats) {
+			self().launch((size_t)n*16, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i >> 4), sbk = (unsigned)(i & 15), yy = sbk >> 2, xx = sbk & 3, bs = zv/4;
+				float const *z = d_zvals + (size_t)t*zv*zv;
+				float szmin = 100.0f, szmax = -100.0f; // FAR_DISTANCE (src/3DWorld.h:116)
+				for (unsigned y = yy*bs; y <= (yy+1)*bs; ++y) {
+					for (unsigned x = xx*bs; x <= (xx+1)*bs; ++x) {float const v = z[y*zv + x]; szmin = min_std(szmin, v); szmax = max_std(szmax, v);}
+				}
+				d_stats[t].sub_zmin[sbk] = szmin; d_stats[t].sub_zmax[sbk] = szmax;
+			});
+			self().launch(n, [=] TERRA_LAMBDA (size_t t) {
+				tile_ref_pod_t const r = d_refs[t];
+				int const x1 = r.tx*(int)size, y1 = r.ty*(int)size;
+				float const *z = d_zvals + (size_t)t*zv*zv;
+				terra_tile_stats &st = d_stats[t];
+				float mzmin = 100.0f, mzmax = -100.0f;
+				for (int sbk = 0; sbk < 16; ++sbk) {mzmin = min_std(mzmin, st.sub_zmin[sbk]); mzmax = max_std(mzmax, st.sub_zmax[sbk]);}
+				int wx1 = x1 + (int)size, wy1 = y1 + (int)size, wx2 = x1, wy2 = y1; // start denormalized (src/tiled_mesh.cpp:308)
+				unsigned const lim = 4*(zv/4); // cells 0..128 are visited by the 4x4 blocks; row/column 129 is skipped
+				for (unsigned y = 0; y <= lim; ++y) {
+					for (unsigned x = 0; x <= lim; ++x) {
+						if (z[y*zv + x] < wpz_max) {wx1 = imin(wx1, x1+(int)x); wy1 = imin(wy1, y1+(int)y); wx2 = imax(wx2, x1+(int)x); wy2 = imax(wy2, y1+(int)y);}
+					}
+				}
+				st.mzmin = mzmin; st.mzmax = mzmax;
+				st.radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
+				st.wx1 = wx1; st.wy1 = wy1; st.wx2 = wx2; st.wy2 = wy2;
+			});
+		}
+		if (d_normals) {
+			uint32_t *d_mnz = (uint32_t *)d_min_nz;
+			if (d_mnz) {self().fill32(d_mnz, 0x3F800000u /*1.0f*/, n);}
+			self().launch((size_t)n*stride*stride, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i / (stride*stride)), p = (unsigned)(i % (stride*stride)), y = p / stride, x = p % stride;
+				float nv[3];
+				tile_normal(d_zvals + (size_t)t*zv*zv, x, y, dxv, dyv, dxy, nv);
+				uint8_t *o = d_normals + i*4;
+				o[0] = (uint8_t)(127.0*((double)nv[0] + 1.0)); o[1] = (uint8_t)(127.0*((double)nv[1] + 1.0)); o[2] = (uint8_t)(127.0*((double)nv[2] + 1.0)); o[3] = 0;
+				if (d_mnz && nv[2] < 1.0f) { // min_normal_z = min(min_normal_z, norm.z), seeded with 1.0; norm.z = dxdy/mag >= 0 so uint order == float order; NaN never wins
+					uint32_t u; memcpy(&u, &nv[2], 4);
+					TERRA_ATOMIC_MIN(&d_mnz[t], u);
+				}
+			});
+		}
+	}
+	// tile erosion, wave form: the clamp-padded copies live in HBM/L2, ONE WAVE per tile walks the droplets in order through a 32x32 LDS window
+	// (10 KB of LDS per tile instead of 76 KB: ~15 tiles per CU in flight instead of 2)
+	void tile_erosion_windowed(uint32_t n, float *zvals, erosion_consts_t const &ec, uint32_t iters, float *padded /* n*NX*NY */) {
+		int const NX = ec.NX, NY = ec.NY, xs = ec.xsize, ys = ec.ysize;
+		self().launch((size_t)n*NX*NY, [=] TERRA_LAMBDA (size_t i) { // clamp-padded copy (src/erosion.cpp:31-37)
+			unsigned const t = (unsigned)(i / ((size_t)NX*NY)), p = (unsigned)(i % ((size_t)NX*NY));
+			int const X = (int)(p % NX), Z = (int)(p / NX);
+			padded[i] = zvals[(size_t)t*xs*ys + (size_t)imax(imin(Z - EROSION_PAD, ys-1), 0)*xs + imax(imin(X - EROSION_PAD, xs-1), 0)];
+		});
+		self().launch_waves(n, [=] TERRA_LAMBDA (size_t t, wave_scratch_t const &ws) {
+			window_mem_t<grid_back_t> mem;
+			mem.init(ws.win, ws.dirty, NX, NY);
+			mem.back.g.interior = padded + t*(size_t)NX*NY; mem.back.g.border = nullptr; mem.back.g.xsize = xs; mem.back.g.ysize = ys; mem.back.g.NX = NX; mem.back.g.NY = NY;
+			mem.back.touched = nullptr; mem.back.touched_count = nullptr; mem.back.touched_cap = 0;
+			for (uint32_t it = 0; it < iters; ++it) {simulate_droplet((int)it, mem, ec);} // the window carries over from droplet to droplet
+			mem.finish();
+		});
+		self().launch((size_t)n*xs*ys, [=] TERRA_LAMBDA (size_t i) { // unpad + clamp (src/erosion.cpp:158-162)
+			unsigned const t = (unsigned)(i / ((size_t)xs*ys)), p = (unsigned)(i % ((size_t)xs*ys));
+			int const x = (int)(p % xs), y = (int)(p / xs);
+			zvals[i] = max_std(ec.min_zval, padded[(size_t)t*NX*NY + (size_t)(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
 		});
 	}
 	// tile erosion on a global-memory padded scratch: one logical thread per tile, droplets in order

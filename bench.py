@@ -77,9 +77,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a HIP device (no CPU fall-back)")
+    backend = os.environ.get("TERRA_BENCH_BACKEND", "nccl")  # "gloo" only to smoke-test the multi-rank orchestration on a box with fewer GPUs than ranks
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPUs: one rank per GPU")
+    local_rank %= ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, "launch one rank per GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -139,7 +149,7 @@ def main():
         dt = time.perf_counter() - t0
         barrier()
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         rep = t.erosion_report().as_dict()

@@ -35,14 +35,16 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 
 	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
-	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, float const *d_tab, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
-		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, d_tab, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
+	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
+		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
+	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
-		// even tiles: the wave-cooperative LDS code path of k_tile_erosion (lanes run sequentially here); odd tiles: the scalar cross-check path
+		// tiles cycle through the three implementations: wave-cooperative whole-tile-in-LDS (k_tile_erosion's body; lanes run sequentially here), scalar, wave + window
 		std::vector<float> padded((size_t)ec.NX*ec.NY);
 		for (uint32_t t = 0; t < n; ++t) {
 			float *z = zvals + (size_t)t*ec.xsize*ec.ysize;
-			if (t & 1) {tile_erosion_simple(1, z, ec, iters, padded.data()); continue;}
+			if ((t % 3) == 1) {tile_erosion_simple(1, z, ec, iters, padded.data()); continue;}   // scalar cross-check path
+			if ((t % 3) == 2) {tile_erosion_windowed(1, z, ec, iters, padded.data()); continue;} // wave + LDS window over the padded copy
 			for (int Z = 0; Z < ec.NY; ++Z) for (int X = 0; X < ec.NX; ++X) {
 				padded[(size_t)Z*ec.NX + X] = z[(size_t)terra::imax(terra::imin(Z - terra::EROSION_PAD, ec.ysize-1), 0)*ec.xsize + terra::imax(terra::imin(X - terra::EROSION_PAD, ec.xsize-1), 0)];
 			}

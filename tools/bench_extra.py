@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Secondary workloads of BASELINE.json (configs 2-5) on one GPU: device-resident throughput with HIP-event timing.
+Not the headline metric (bench.py); used to find the next kernel to work on.  Prints one JSON object."""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+pkg = importlib.import_module("3dworld_amd")
+t = pkg.Terra(0)
+out = {}
+
+def timed(fn, reps=3, warm=1):
+    for _ in range(warm): fn()
+    t.synchronize(); t.timer_start()
+    for _ in range(reps): fn()
+    return t.timer_stop() / reps
+
+# C2: 4096^2 single heightmap, every mode, 9 octaves (reference default) and 8
+N = 4096
+z = t.alloc(N * N * 4)
+for name, mode in (("sine", 0), ("simplex", 1), ("perlin", 2), ("dwarp", 4)):
+    for octv in (9, 8):
+        st = t.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - octv))
+        ms = timed(lambda: t.gen_grid_dev(z.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE))
+        out[f"C2_{name}_{octv}oct_4096_gcells_s"] = round(N * N / ms / 1e6, 2)
+# C3: 4096^2 + erosion, 1e3 / 1e5 / 1e6 droplets
+st = t.init_scene(pkg.make_config(mesh_gen_mode=0))
+for D in (1000, 100000, 1000000):
+    mn, mx = t.gen_grid_minmax_dev(z.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+    t.synchronize(); t0 = time.perf_counter()
+    t.apply_erosion_dev(z.ptr, N, N, mn, D, pkg.ERODE_MINZ_IS_MIN); t.synchronize()
+    dt = time.perf_counter() - t0
+    r = t.erosion_report().as_dict()
+    out[f"C3_erosion_4096_{D}_droplets"] = {"ms": round(dt * 1e3, 2), "droplets_per_s": round(D / dt), "steps_per_s": round(r["steps"] / dt), "rounds": r["rounds"], "windows": r["windows"], "traces": r["traces"], "fallbacks": r["serial_fallbacks"]}
+z.free()
+# C4: 64x64 tiles of 128^2
+tiles = np.array([(tx, ty) for ty in range(-32, 32) for tx in range(-32, 32)], np.int32)
+n = len(tiles)
+zt = t.alloc(n * 130 * 130 * 4); stt = t.alloc(n * 160); nm = t.alloc(n * 129 * 129 * 4); mz = t.alloc(n * 4)
+for name, mode in (("sine", 0), ("simplex", 1)):
+    t.init_scene(pkg.make_config(mesh_gen_mode=mode))
+    for it in (0, 1000):
+        if mode == 1 and it: continue
+        ms = timed(lambda: t.tiles_create_zvals_dev(tiles, it, zt.ptr, stt.ptr, nm.ptr, mz.ptr), reps=2)
+        out[f"C4_tiles64x64_{name}_{it}iters"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3), "gcells_s": round(n * 130 * 130 / ms / 1e6, 3)}
+for b in (zt, stt, nm, mz): b.free()
+# C5: voxels
+t.init_scene(pkg.make_config(mesh_gen_mode=0))
+lo, vsz, off = (-15.9, -15.9, -1.0), (0.0622, 0.0622, 0.0625), (0.0, 0.0, 0.0)
+for dims in ((512, 512, 64), (512, 512, 512)):
+    v = t.alloc(dims[0] * dims[1] * dims[2] * 4)
+    for name, mode in (("sines", 0), ("simplex", 1)):
+        if mode == 1 and dims[2] == 512: continue
+        ms = timed(lambda: t.voxel_fill_dev(v.ptr, dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, mode, 0.01, 1), reps=2)
+        out[f"C5_voxels_{dims[0]}x{dims[1]}x{dims[2]}_{name}_gvoxels_s"] = round(dims[0] * dims[1] * dims[2] / ms / 1e6, 2)
+    v.free()
+print(json.dumps(out))
