@@ -14,6 +14,8 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool simple_kernels = false; // TERRA_SIMPLE_KERNELS=1: run the one-thread-per-cell cross-check kernels instead of the LDS-tiled ones
 	float *tile_pad = nullptr; size_t tile_pad_bytes = 0;
+	float *vox_p = nullptr; size_t vox_p_bytes = 0;
+	unsigned sg_rowgroup = 4; // TERRA_SG_ROWGROUP: tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
 	static int device_count() {int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n;}
 	void init(int dev) {
@@ -24,12 +26,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipEventCreate(&ev0)); TERRA_HIP_CHECK(hipEventCreate(&ev1));
 		char const *s = getenv("TERRA_SIMPLE_KERNELS");
 		simple_kernels = (s && s[0] == '1');
+		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 	}
 	~hip_backend_t() {
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_map) (void)hipFree(tile_map);
+		if (vox_p) (void)hipFree(vox_p);
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
 		if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -69,7 +73,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, terra::sg_tiles_t{nullptr, nullptr, 0});
+		hipLaunchKernelGGL(terra::k_sine_grid<false>, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, terra::sg_tiles_t{nullptr, nullptr, 0, sg_rowgroup});
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
@@ -103,7 +107,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*130; job.ny = nuy*130; job.nxp = nxpv; job.nyp = nypv;
 		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		hipLaunchKernelGGL(terra::k_sine_grid, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, terra::sg_tiles_t{tm, d_m0, nux});
+		hipLaunchKernelGGL(terra::k_sine_grid<true>, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, terra::sg_tiles_t{tm, d_m0, nux, sg_rowgroup});
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
@@ -140,8 +144,12 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize); return;}
 		use();
+		size_t const np = (size_t)nx*ny*terra::VOX_SINES;
+		if (np*4 > vox_p_bytes) {if (vox_p) {sync(); (void)hipFree(vox_p);} TERRA_HIP_CHECK(hipMalloc((void **)&vox_p, np*4)); vox_p_bytes = np*4;}
+		hipLaunchKernelGGL(terra::k_voxel_P, dim3((unsigned)((np + 255)/256)), dim3(256), 0, stream, vox_p, nx, ny, d_tab);
 		unsigned const block = (nz >= 256) ? 256 : ((nz + 63)/64)*64;
-		hipLaunchKernelGGL(terra::k_voxel_sines, dim3(nx, ny), dim3(block), 0, stream, out, nx, ny, nz, d_tab, zscale, normalize);
+		size_t const ncol = (size_t)nx*ny;
+		hipLaunchKernelGGL(terra::k_voxel_sines, dim3((unsigned)((ncol + terra::VX_PER_BLOCK - 1)/terra::VX_PER_BLOCK), (nz + block - 1)/block), dim3(block), 0, stream, out, nx, ny, nz, d_tab, vox_p, zscale, normalize);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 };

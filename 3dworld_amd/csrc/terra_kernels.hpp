@@ -49,23 +49,20 @@ __device__ __forceinline__ void minmax_acc(float v, uint32_t &lo, uint32_t &hi) 
 // through LDS in two chunks (<= 45 k each, 46 KB -> 3 blocks = 12 waves per CU), operands of step k+1 prefetched from LDS while
 // step k is multiplied.  Per k a thread issues four ds_read_b128 (conflict-free / broadcast) for 64 mul + 64 add.
 constexpr int SG_BX = 128, SG_BY = 128, SG_TX = 8, SG_TY = 8, SG_THREADS = 256, SG_KC = 45; // 16 x 16 threads
-constexpr int SG_ROWGROUP = 4; // tile rows walked together so an X tile is reused from L2 before moving on
-
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (observed, speed only); give every XCD one contiguous
-// band of tile rows so its private L2 keeps that band's Y tiles, and walk the band in groups of SG_ROWGROUP rows.
-__device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsigned nty, unsigned &bx, unsigned &by) {
+// band of tile rows so its private L2 keeps that band's Y tiles, and walk the band in groups of `rowgroup` tile rows
+// (an X slice is reused by `rowgroup` consecutive blocks before the walk moves to the next tile column).
+__device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsigned nty, unsigned rowgroup, unsigned &bx, unsigned &by) {
 	unsigned const nb = ntx*nty, per_xcd = (nb + 7)/8;
 	unsigned const lin = (b & 7)*per_xcd + (b >> 3); // position in the global tile order
 	if (lin >= nb) return false;
-	unsigned const group = lin/(SG_ROWGROUP*ntx), r = lin % (SG_ROWGROUP*ntx);
-	unsigned const rows_here = (nty - group*SG_ROWGROUP < (unsigned)SG_ROWGROUP) ? nty - group*SG_ROWGROUP : SG_ROWGROUP;
-	bx = r/rows_here; by = group*SG_ROWGROUP + r % rows_here;
+	unsigned const group = lin/(rowgroup*ntx), r = lin % (rowgroup*ntx);
+	unsigned const rows_here = (nty - group*rowgroup < rowgroup) ? nty - group*rowgroup : rowgroup;
+	bx = r/rows_here; by = group*rowgroup + r % rows_here;
 	return bx < ntx;
 }
 
-// tile batches run as one "virtual" grid whose columns / rows are the distinct tile columns / rows side by side (130 cells each);
-// the epilogue scatters every cell to its tile's [130][130] block (tile_map[uy*nux + ux] = tile slot or -1 when that pair was not requested)
-struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux;};
+struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup;};
 
 struct sg_operands_t {float4 xa, xb, ya, yb;};
 __device__ __forceinline__ sg_operands_t sg_load(float const *px, float const *py, int k) {
@@ -84,13 +81,13 @@ __device__ __forceinline__ void sg_accumulate(float (&acc)[SG_TY][SG_TX], sg_ope
 	}
 }
 
-__global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
+template<bool TILES> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
 	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm, sg_tiles_t tiles)
 {
 	__shared__ __attribute__((aligned(16))) float sX[SG_KC*SG_BX];
 	__shared__ __attribute__((aligned(16))) float sY[SG_KC*SG_BY];
 	unsigned bxi, byi;
-	if (!sg_tile_of_block(blockIdx.x, ntx, nty, bxi, byi)) return;
+	if (!sg_tile_of_block(blockIdx.x, ntx, nty, tiles.rowgroup, bxi, byi)) return;
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu; // fused min(vals)/max(vals) (heightmap_t::run_erosion, get_heightmap_z_range): saves a 4 B/cell read pass
 	unsigned const tid = threadIdx.x, bx0 = bxi*SG_BX, by0 = byi*SG_BY;
 	unsigned const tx = tid & 15, ty = tid >> 4;
@@ -128,7 +125,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 	// ---- epilogue (eval_index's tail, src/mesh_gen.cpp:781-790): shape / post-process, glaciate, sine-mag islands, volcano.
 	// The common configuration (linear shape, no plateau/crater/crack, no volcano) takes a short path with the island terms of the
 	// thread's 8 columns / 8 rows loaded once; anything else goes through the general finish_cell().  Same arithmetic either way.
-	bool const vec_ok = ((job.nx & 3u) == 0) && !tiles.tile_map;
+	bool const vec_ok = ((job.nx & 3u) == 0) && !TILES;
 	hmap_params_t const &hp = nc.hp;
 	bool const plain = (job.shape == 0) && !(hp.crack_lo < hp.crack_hi) && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f);
 	float const pp_limit = min_std(hp.plat_bot, hp.crat_h); // below this the post-process is the identity
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 					}
 				}
 				else if (x + j < job.nx) {
-					if (tiles.tile_map) { // general epilogue in tile-local coordinates (volcano term needs the tile's own origin)
+					if (TILES) { // general epilogue in tile-local coordinates (volcano term needs the tile's own origin)
 						unsigned const ux = (x + j)/130u, uy = y/130u;
 						grid_job_t jt = job; jt.mx0 = tiles.m0[ux]; jt.my0 = tiles.m0[tiles.nux + uy];
 						z = finish_cell(z, jt, nc, L, smx + ux*130u, smy + uy*130u, (x + j) - ux*130u, y - uy*130u);
@@ -168,7 +165,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_
 				v[j] = z;
 				if (x + j < job.nx) {fmn = fminf(fmn, z); fmx = fmaxf(fmx, z);} // fminf/fmaxf skip NaNs, like min_eq/max_eq never let a NaN win
 			}
-			if (tiles.tile_map) {
+			if (TILES) {
 				unsigned const uy = y/130u, cy = y - uy*130u;
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
@@ -296,23 +293,36 @@ __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, 
 	if ((threadIdx.x & 63) == 0) {atomicMin(&d[0], lo); atomicMin(&d[1], hi);}
 }
 
-// ------------------------------------------------------------------ K8: voxel sine field. One block per (x,y) column pair group; lanes run along z (the fastest output axis)
-// tab = [nx + ny + nz][60]; P[k] = xv[k]*yv[k] is uniform per (x,y): computed once into LDS, then each lane folds its own z row.
-__global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ tab, float zscale, int normalize) {
-	__shared__ float P[VOX_SINES];
-	uint32_t const x = blockIdx.x, y = blockIdx.y;
-	if (threadIdx.x < VOX_SINES) {P[threadIdx.x] = __fmul_rn(tab[(size_t)x*VOX_SINES + threadIdx.x], tab[((size_t)nx + y)*VOX_SINES + threadIdx.x]);}
-	__syncthreads();
-	float const *zt = tab + ((size_t)nx + ny)*VOX_SINES;
-	float *o = out + ((size_t)x + (size_t)y*nx)*nz;
-	for (uint32_t z = threadIdx.x; z < nz; z += blockDim.x) {
-		float const *zv = zt + (size_t)z*VOX_SINES;
+// ------------------------------------------------------------------ K8: voxel sine field (noise_gen_3d::get_val, src/upsurface.cpp:60-70)
+// val[y][x][z] = sum_k (xv[x][k]*yv[y][k])*zv[z][k], z fastest.  fp32-VALU bound (60 mul + 60 add per voxel for 4 B written).
+// One lane = one z: its 60 zv values stay in registers; the block walks VX_PER_BLOCK (x,y) columns, whose 60 products
+// P[k] = xv*yv are wave-uniform (scalar loads feeding v_mul directly).  Output rows are contiguous along z: coalesced stores.
+constexpr int VX_PER_BLOCK = 32;
+__global__ __launch_bounds__(256) void k_voxel_P(float *__restrict__ P, uint32_t nx, uint32_t ny, float const *__restrict__ tab) { // P[(y*nx + x)*60 + k]
+	size_t const i = (size_t)blockIdx.x*256 + threadIdx.x;
+	if (i >= (size_t)nx*ny*VOX_SINES) return;
+	uint32_t const k = (uint32_t)(i % VOX_SINES); size_t const c = i / VOX_SINES; uint32_t const x = (uint32_t)(c % nx), y = (uint32_t)(c / nx);
+	P[i] = __fmul_rn(tab[(size_t)x*VOX_SINES + k], tab[((size_t)nx + y)*VOX_SINES + k]);
+}
+__global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ tab, float const *__restrict__ P, float zscale, int normalize) {
+	uint32_t const z = blockIdx.y*blockDim.x + threadIdx.x;
+	bool const active = z < nz;
+	float zv[VOX_SINES];
+	float const *zrow = tab + ((size_t)nx + ny + (active ? z : 0))*VOX_SINES;
+#pragma unroll
+	for (unsigned k = 0; k < VOX_SINES; ++k) {zv[k] = zrow[k];}
+	float const zterm = __fmul_rn((float)z, zscale);
+	size_t const c0 = (size_t)blockIdx.x*VX_PER_BLOCK, ncol = (size_t)nx*ny;
+	for (int c = 0; c < VX_PER_BLOCK; ++c) {
+		size_t const col = c0 + c; // = x + y*nx, wave-uniform
+		if (col >= ncol) break;
+		float const *p = P + col*VOX_SINES;
 		float val = 0.0f;
-#pragma unroll 4
-		for (unsigned k = 0; k < VOX_SINES; ++k) {val = __fadd_rn(val, __fmul_rn(P[k], zv[k]));} // (xv*yv)*zv, summed in k order
-		val = __fadd_rn(val, __fmul_rn((float)z, zscale));
+#pragma unroll
+		for (unsigned k = 0; k < VOX_SINES; ++k) {val = __fadd_rn(val, __fmul_rn(p[k], zv[k]));} // (xv*yv)*zv, summed in k order
+		val = __fadd_rn(val, zterm);
 		if (normalize) {val = clip_pm1(val);}
-		o[z] = val;
+		if (active) {out[col*nz + z] = val;}
 	}
 }
 
