@@ -162,6 +162,10 @@ def main():
             for _ in range(reps):
                 t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
             ms_gen = t.timer_stop() / reps
+            t.timer_start()
+            for _ in range(reps):  # the grid kernel with its two small table kernels, no min/max read-back: what rocprofv3 reports as k_sine_grid / k_noise_grid (+ ~20 us)
+                t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+            ms_grid = t.timer_stop() / reps
             mn, _ = t.minmax_dev(z.data_ptr(), cells)
             t.timer_start()
             for _ in range(reps):
@@ -175,17 +179,24 @@ def main():
                 t.timer_start()
                 t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)
                 ms_ero += t.timer_stop() / reps
-            detail = {"ms_noise_kernels": round(ms_gen, 4), "ms_minmax": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)}
+            detail = {"ms_noise_kernels": round(ms_gen, 4), "ms_grid_kernel": round(ms_grid, 4), "ms_minmax_unfused": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * cells * args.steps / dt / 1e9
         terms = 10 * args.octaves if mode == 0 else None
         # dominant kernel by time: the noise grid kernel (k_sine_grid / k_noise_grid). Algorithmic bytes: 4 B written per cell.
-        ms_k = detail["ms_noise_kernels"]
+        ms_k = detail["ms_grid_kernel"]
         achieved = 4.0 * cells / (ms_k * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE), only for the configuration they were taken on
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_sine_grid<false>"]
+            if mode == 0 and N == 16384 and args.octaves == 8:
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": "k_sine_grid (+table kernels)" if mode == 0 else f"k_noise_grid<{args.mode}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": 4 * cells,
                 "note": "kernel is fp32-VALU bound, not HBM bound: see valu_frac (mul and add issue separately because the CPU reference has no FMA)"}
         if terms:
             ops = 2.0 * terms * cells / (ms_k * 1e-3) / 1e12

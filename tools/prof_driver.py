@@ -13,5 +13,9 @@ z = t.alloc(N * N * 4)
 for _ in range(reps):
     mn, mx = t.gen_grid_minmax_dev(z.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
     t.apply_erosion_dev(z.ptr, N, N, mn, 1000, pkg.ERODE_MINZ_IS_MIN)
+# calibration points for the TCC counters in the same trace: a pure float4 read of the grid (k_minmax) and a 4 B/lane read + 2x1 B/lane write (quantise)
+pix = t.alloc(N * N * 2)
+mn2, mx2 = t.minmax_dev(z.ptr, N * N)
+t.quantize16_dev(z.ptr, N * N, mn2, max(mx2 - mn2, 1e-12), pix.ptr)
 t.synchronize()
 print("done", mn, mx, t.erosion_report().as_dict())
