@@ -163,6 +163,15 @@ int terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint3
 	TERRA_CATCH
 }
 
+int terra_eval_mesh_sin_terms(terra_ctx *ctx, float xv, float yv, float *out) {
+	TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out");
+	TERRA_TRY *out = ctx->eng.eval_mesh_sin_terms(xv, yv); TERRA_CATCH
+}
+int terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop) {
+	TERRA_CHECK_CTX if (!d_mesh) return terra::fail(TERRA_ERR_ARG, "null mesh");
+	TERRA_TRY ctx->eng.glaciate_mesh_dev(d_mesh, nx, ny, xoff2, yoff2, h_zbottom_ztop); TERRA_CATCH
+}
+
 // ---- erosion
 int terra_apply_erosion_dev(terra_ctx *ctx, float *d, int xs, int ys, float min_zval, uint32_t iters, uint32_t flags) {
 	TERRA_CHECK_CTX if (!d) return terra::fail(TERRA_ERR_ARG, "null heightmap");

@@ -329,6 +329,39 @@ template<class BE> struct terra_engine {
 		}
 	}
 
+	// ================================================================ point query + ground-mode glaciate (a8, a16)
+	// eval_mesh_sin_terms (src/mesh_gen.cpp:797-805): scattered point queries (biome parameters, collision height) stay on the host
+	float eval_mesh_sin_terms(float xv, float yv) const {
+		require_scene();
+		sin_lut_t const HL = host_lut();
+		float zval = 0.0f;
+		for (int k = start_eval_sin; k < F_TABLE_SIZE; ++k) {
+			float const *stk = sinTable[k];
+			zval += stk[0]*HL.SINF(stk[3]*yv + stk[1])*HL.SINF(stk[4]*xv + stk[2]);
+		}
+		return zval;
+	}
+	// glaciate() (src/mesh_gen.cpp:388-404): in-place apply_glaciate + apply_mesh_sine over a MESH_X x MESH_Y ground mesh; zbottom/ztop = min/max after
+	void glaciate_mesh_dev(float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop) {
+		require_scene();
+		if (nx == 0 || ny == 0) throw std::invalid_argument("glaciate: empty mesh");
+		noise_consts_t const nc = consts();
+		sin_lut_t const L = lut();
+		int const hx = (int)nx/2, hy = (int)ny/2;
+		be.launch((size_t)nx*ny, [=] TERRA_LAMBDA (size_t i) {
+			unsigned const x = (unsigned)(i % nx), y = (unsigned)(i / nx);
+			float z = d_mesh[i];
+			if (nc.glaciate) {float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv; z = glaciate_exp_fn(relh, nc.custom_glaciate_exp)*nc.zmax_est2 - nc.zmax_est;}
+			if (nc.hp.sine_mag > 0.0f) { // apply_mesh_sine (src/mesh_gen.cpp:373-379), point form
+				float const fx = (float)((int)x + xoff2 - hx), fy = (float)((int)y + yoff2 - hy), freq = nc.mesh_scale*nc.hp.sine_freq;
+				z += (nc.hp.sine_mag*L.COSF(fx*freq)*L.COSF(fy*freq) + nc.hp.sine_bias)*nc.mesh_scale_z_inv;
+				if (nc.hp.volcano_width > 0.0f && nc.hp.volcano_height > 0.0f) {z += volcano_height(fx, fy, nc, L);}
+			}
+			d_mesh[i] = z;
+		});
+		if (h_zbottom_ztop) {minmax_dev(d_mesh, (size_t)nx*ny, h_zbottom_ztop[0], h_zbottom_ztop[1]);}
+	}
+
 	// ================================================================ reductions / quantise (a12, K10)
 	void minmax_dev(float const *d_vals, size_t n, float &mn, float &mx) { // min_eq/max_eq folds (std::min/std::max): NaNs never win a comparison
 		uint32_t *d = scratch<uint32_t>(s_misc, 2);

@@ -101,6 +101,8 @@ _PROTOS = {
     "terra_gen_grid_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
     "terra_gen_grid": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
     "terra_gen_grid_minmax_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _f3, _f3]),
+    "terra_eval_mesh_sin_terms": (_i32, [_vp, _f, _f, _f3]),
+    "terra_glaciate_mesh_dev": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp]),
     "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
@@ -261,6 +263,16 @@ class Terra:
         mn, mx = C.c_float(), C.c_float()
         self._ck(self.lib.terra_gen_grid_minmax_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr, C.byref(mn), C.byref(mx)))
         return mn.value, mx.value
+
+    def eval_mesh_sin_terms(self, xv, yv):
+        out = C.c_float()
+        self._ck(self.lib.terra_eval_mesh_sin_terms(self.ctx, xv, yv, C.byref(out)))
+        return out.value
+
+    def glaciate_mesh_dev(self, ptr, nx, ny, xoff2=0, yoff2=0):
+        r = (C.c_float * 2)()
+        self._ck(self.lib.terra_glaciate_mesh_dev(self.ctx, ptr, nx, ny, xoff2, yoff2, C.addressof(r)))
+        return r[0], r[1]
 
     def apply_erosion_dev(self, ptr, xsize, ysize, min_zval, iters, flags=0):
         self._ck(self.lib.terra_apply_erosion_dev(self.ctx, ptr, xsize, ysize, min_zval, iters, flags))

@@ -131,6 +131,13 @@ int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, 
 int  terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max);
 int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out);
 
+/* ---- point query and ground-mode post-pass
+ * eval_mesh_sin_terms (src/mesh_gen.cpp:797-805): non-separable point query used for biome parameters / collision height; evaluated on the host.
+ * glaciate() (src/mesh_gen.cpp:388-404): in-place apply_glaciate + apply_mesh_sine over the MESH_X x MESH_Y ground mesh (xoff2/yoff2 = scroll offsets);
+ * h_zbottom_ztop (optional) receives {zbottom, ztop}. */
+int  terra_eval_mesh_sin_terms(terra_ctx *ctx, float xv, float yv, float *out);
+int  terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop);
+
 /* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0. */
 int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);

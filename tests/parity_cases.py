@@ -211,6 +211,24 @@ def case_quantize_golden(pkg, t):
     buf.free(); pix.free()
 
 
+def case_ground_mesh_and_point_queries(pkg, t, orc):
+    """config 1 plumbing: the 128^2 ground mesh of gen_mesh() (gen_mesh_sine_table + glaciate(), src/mesh_gen.cpp:201-210,388-404) against the
+    reference's own mesh (golden), and eval_mesh_sin_terms point queries (src/mesh_gen.cpp:797-805)."""
+    G = golden()
+    for mode in (0, 1):
+        st = t.init_scene(pkg.make_config(mesh_gen_mode=mode))
+        buf = t.alloc(128 * 128 * 4)
+        t.gen_grid_dev(buf.ptr, -64, -64, st.DX_VAL, st.DY_VAL, 128, 128, 0)
+        zb, zt = t.glaciate_mesh_dev(buf.ptr, 128, 128)
+        m = buf.download(np.float32, (128, 128)); buf.free()
+        assert_bit_equal(m, G[f"m{mode}_ground"], f"ground mesh mode {mode}")
+        assert np.float32(zb) == m.min() and np.float32(zt) == m.max()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    pts = G["pts"]
+    got = np.array([t.eval_mesh_sin_terms(float(x), float(y)) for x, y, _ in pts], np.float32)
+    assert_bit_equal(got, G["sin_terms"], "eval_mesh_sin_terms")
+
+
 def case_gen_grid_minmax(pkg, t, orc, mode, n):
     pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode)
     st = t.init_scene(pc_)

@@ -77,6 +77,10 @@ def test_gen_grid_minmax(pkg, gpu, orc, mode, n):
     pc.case_gen_grid_minmax(pkg, gpu, orc, mode, n)
 
 
+def test_ground_mesh_and_point_queries(pkg, gpu, orc):
+    pc.case_ground_mesh_and_point_queries(pkg, gpu, orc)
+
+
 def test_generator_protocol(pkg, gpu, orc):
     pc.case_generator_protocol(pkg, gpu, orc)
 

@@ -66,6 +66,10 @@ def test_gen_grid_minmax(pkg, emul, orc, mode, n):
     pc.case_gen_grid_minmax(pkg, emul, orc, mode, n)
 
 
+def test_ground_mesh_and_point_queries(pkg, emul, orc):
+    pc.case_ground_mesh_and_point_queries(pkg, emul, orc)
+
+
 def test_generator_protocol(pkg, emul, orc):
     pc.case_generator_protocol(pkg, emul, orc)
 
