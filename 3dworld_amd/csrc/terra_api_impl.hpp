@@ -196,6 +196,12 @@ int terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t cap_log2,
 	if (maxb) ctx->eng.spec_cfg.maxb = maxb;
 	return TERRA_OK;
 }
+int terra_set_erosion_slice_steps(terra_ctx *ctx, uint32_t steps) {
+	TERRA_CHECK_CTX
+	if (steps == 0) return terra::fail(TERRA_ERR_ARG, "terra_set_erosion_slice_steps: steps must be > 0");
+	ctx->eng.spec_cfg.slice_steps = steps;
+	return TERRA_OK;
+}
 int terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out) {TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out"); *out = ctx->eng.report; return TERRA_OK;}
 
 // ---- whole heightmap (heightmap_t::proc_gen, src/heightmap.cpp:130-151)

@@ -398,7 +398,7 @@ template<class BE> struct terra_engine {
 		return ec;
 	}
 
-	struct spec_cfg_t {uint32_t window = 4096, cap_log2 = 12, maxb = 256, bshift = 3, max_rounds = 100000;} spec_cfg;
+	struct spec_cfg_t {uint32_t window = 4096, cap_log2 = 12, maxb = 256, bshift = 3, slice_steps = 64, max_rounds = 4000000;} spec_cfg;
 
 	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
 		require_scene();
@@ -438,12 +438,16 @@ template<class BE> struct terra_engine {
 		});
 	}
 
+	// Sliding ring of W in-flight droplets (terra_erosion.hpp).  One round = every unfinished droplet advances by at most `slice` steps,
+	// finished versions are published, dependants of changed versions start over, the valid finished prefix is flushed to the grid and its
+	// slots are handed to the next droplets.  While droplets are waiting for a slot the traces are sliced, so that one long path (they run
+	// to thousands of steps at ~1 us each) does not hold up a whole window; once everything is admitted the remaining traces run to the end.
 	// returns true when the final clamp was applied sparsely (record_touched and the record did not overflow)
 	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched) {
 		spec_buffers_t sb{};
-		sb.grid = g; sb.ec = ec;
-		uint32_t const Wmax = std::min<uint32_t>(spec_cfg.window, num_iters);
-		sb.cap_log2 = spec_cfg.cap_log2; sb.maxb = spec_cfg.maxb; sb.bshift = std::max<uint32_t>(spec_cfg.bshift, 3);
+		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
+		uint32_t const W = std::min<uint32_t>(spec_cfg.window, num_iters);
+		sb.W = W; sb.cap_log2 = spec_cfg.cap_log2; sb.maxb = spec_cfg.maxb; sb.bshift = std::max<uint32_t>(spec_cfg.bshift, 3);
 		if (((size_t)1 << sb.cap_log2) < (size_t)4*EW*EW) throw std::logic_error("speculative erosion: log capacity too small for the window");
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
 		size_t const cap = (size_t)1 << sb.cap_log2, nblocks = (size_t)sb.nbx*sb.nby;
@@ -451,9 +455,10 @@ template<class BE> struct terra_engine {
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_keys[2], o_vals[2], o_bl[2], o_bc[2], o_chk[2];
-		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(Wmax*cap*4); o_vals[b] = carve(Wmax*cap*4); o_bl[b] = carve((size_t)Wmax*sb.maxb*4); o_bc[b] = carve(Wmax*4); o_chk[b] = carve(Wmax*8);}
-		size_t const o_cur = carve(Wmax*4), o_need = carve(Wmax*4), o_chg = carve(Wmax*4), o_flags = carve(Wmax*4), o_nsteps = carve(Wmax*4);
-		size_t const o_head = carve(nblocks*4), o_next = carve((size_t)Wmax*sb.maxb*4), o_dirty = carve(nblocks*4), o_cnt = carve(64);
+		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(W*cap*4); o_vals[b] = carve(W*cap*4); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
+		size_t const o_slot = carve((size_t)W*4*9); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps
+		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
+		size_t const o_head = carve(nblocks*4), o_next = carve((size_t)W*sb.maxb*4), o_dirty = carve(nblocks*4), o_ctl = carve(sizeof(spec_ctl_t));
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
 		size_t const o_touched = carve((size_t)touched_cap*4 + 4);
 		uint8_t *base = scratch<uint8_t>(s_spec, off);
@@ -461,66 +466,58 @@ template<class BE> struct terra_engine {
 			sb.log_keys[b] = (uint32_t *)(base + o_keys[b]); sb.log_vals[b] = (float *)(base + o_vals[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]); sb.chk[b] = (uint64_t *)(base + o_chk[b]);
 		}
-		sb.cur = (uint32_t *)(base + o_cur); sb.need = (uint32_t *)(base + o_need); sb.changed = (uint32_t *)(base + o_chg);
-		sb.flags = (uint32_t *)(base + o_flags); sb.nsteps = (uint32_t *)(base + o_nsteps);
+		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
+		sb.it = slot_arrays; sb.phase = slot_arrays + W; sb.has_ver = slot_arrays + 2*(size_t)W; sb.cur = slot_arrays + 3*(size_t)W; sb.changed = slot_arrays + 4*(size_t)W;
+		sb.restart = slot_arrays + 5*(size_t)W; sb.run_nblk = slot_arrays + 6*(size_t)W; sb.flags = slot_arrays + 7*(size_t)W; sb.nsteps = slot_arrays + 8*(size_t)W;
+		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
-		sb.head = (uint32_t *)(base + o_head); sb.next = (uint32_t *)(base + o_next); sb.dirty_min = (uint32_t *)(base + o_dirty); sb.counters = (uint32_t *)(base + o_cnt);
+		sb.head = (uint32_t *)(base + o_head); sb.next = (uint32_t *)(base + o_next); sb.dirty_min = (uint32_t *)(base + o_dirty); sb.ctl = (spec_ctl_t *)(base + o_ctl);
 
-		uint32_t done = 0;
-		be.fill32(sb.counters, 0, 16);
-		while (done < num_iters) {
-			uint32_t const W = std::min<uint32_t>(Wmax, num_iters - done);
-			sb.first_iter = done; sb.W = W; sb.cut = W; sb.use_lists = 0;
-			++report.windows;
-			be.fill32(sb.cur, 0, W); be.fill32(sb.need, 1, W); be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
-			be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks); be.fill32(sb.head, SPEC_NIL, nblocks);
-			be.fill32(sb.counters + 1, 0xFFFFFFFFu, 1);            // lowest overflowed slot of this window
-			be.fill32(sb.counters + 2, 0, 2); be.fill32(sb.counters + 7, 0, 2);
-			bool first = true;
-			// one host round trip per round: everything a round needs (cut, counters) lives in device memory
-			for (uint32_t round = 0; round < spec_cfg.max_rounds; ++round, first = false) {
-				++report.rounds;
-				be.fill32(sb.counters, 0, 1);
-				spec_buffers_t const s = sb;
-				if (first) {be.fill32(sb.log_keys[1], SPEC_EMPTY, (size_t)W*cap);} // all droplets trace into buffer 1 - cur = 1
-				else {be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});}
-				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, ws);});
-				bool const fr = first;
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)i, fr);});
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s, (uint32_t)i);});
-				be.fill32(sb.head, SPEC_NIL, nblocks);
-				be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s, (uint32_t)i);});
-				be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks);
-				uint32_t hc[2];
-				be.d2h(hc, sb.counters, sizeof(hc)); // {droplets to re-trace, lowest overflowed slot}
-				if (hc[1] < sb.cut) {sb.cut = hc[1];}
-				sb.use_lists = 1;
-				if (hc[0] == 0) break;
-			}
-			// flush committed droplets [0, cut), gather the window's totals
-			spec_buffers_t const s = sb;
-			if (sb.cut > 0) {
-				be.launch((size_t)sb.cut*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
-				be.launch(sb.cut, [=] TERRA_LAMBDA (size_t i) {spec_totals_body(s, (uint32_t)i);});
-			}
-			uint32_t const committed = sb.cut;
-			if (committed < W) { // the overflowed droplet runs alone, directly on the grid (it is now the lowest uncommitted droplet)
-				uint32_t const it = done + committed;
+		spec_buffers_t const s = sb;
+		be.fill32(slot_arrays, 0, (size_t)W*9);
+		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
+		be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks); be.fill32(sb.head, SPEC_NIL, nblocks);
+		be.launch(W, [=] TERRA_LAMBDA (size_t i) { // the first W droplets take the slots (num_iters >= W)
+			s.it[i] = (uint32_t)i; s.phase[i] = SPEC_FRESH;
+			if (i == 0) {spec_ctl_t c{}; c.base = 0; c.new_base = s.W; c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; *s.ctl = c;}
+		});
+		report.windows = (num_iters + W - 1)/W;
+		uint32_t const slice = std::max<uint32_t>(spec_cfg.slice_steps, 1);
+		uint32_t host_base = 0;
+		spec_ctl_t hc{};
+		for (uint32_t round = 0; host_base < num_iters; ++round) {
+			if (round >= spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
+			++report.rounds;
+			uint32_t const budget = ((uint64_t)host_base + W >= num_iters) ? DROPLET_NO_BUDGET : slice; // nobody is waiting for a slot: run to the end
+			be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
+			be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, budget, ws);});
+			be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+			be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s, (uint32_t)i);});
+			be.fill32(sb.head, SPEC_NIL, nblocks);
+			be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+			be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+			be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks);
+			be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_scan_body(s, (uint32_t)i);});
+			be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
+			be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
+			be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
+			be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of the round
+			host_base = hc.base;
+			if (host_base < num_iters && hc.stop_at == host_base) { // the lowest uncommitted droplet overflowed its log / block list: it runs alone, directly on the grid
+				uint32_t const it = host_base;
 				grid_view_t const gg = g; erosion_consts_t const ee = ec;
-				uint32_t *cnt = sb.counters;
+				uint32_t *fb = &sb.ctl->fb_steps, *tcount = &sb.ctl->touched;
 				uint32_t *tch = sb.touched; uint32_t const tcap = sb.touched_cap;
-				be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {direct_droplet_wave(gg, ee, it, cnt + 4, ws, tch, cnt + 6, tcap);});
+				be.launch_waves(1, [=] TERRA_LAMBDA (size_t, wave_scratch_t const &ws) {direct_droplet_wave(gg, ee, it, fb, ws, tch, tcount, tcap);});
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_fallback_reset_body(s, (uint32_t)i);});
+				be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_fallback_advance_body(s);});
+				++report.serial_fallbacks; ++host_base;
 			}
-			uint32_t hw[9];
-			be.d2h(hw, sb.counters, sizeof(hw));
-			report.traces += hw[2]; report.traced_steps += hw[3]; report.steps += hw[7]; report.nan_droplets += hw[8];
-			done += committed;
-			if (committed < W) {report.steps += hw[4]; report.traced_steps += hw[4]; report.nan_droplets += hw[5]; ++report.serial_fallbacks; ++done;}
 		}
+		be.d2h(&hc, sb.ctl, sizeof(hc));
+		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		if (!record_touched) return false;
-		uint32_t ntouched = 0;
-		be.d2h(&ntouched, sb.counters + 6, 4);
+		uint32_t const ntouched = hc.touched;
 		if (ntouched > sb.touched_cap) return false; // record overflowed: the caller clamps the whole grid
 		uint32_t const *tch = sb.touched; float const mz = ec.min_zval; grid_view_t const gg = g;
 		be.launch(ntouched, [=] TERRA_LAMBDA (size_t i) {touched_clamp_body(gg, tch, (uint32_t)i, mz);});

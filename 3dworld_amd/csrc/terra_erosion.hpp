@@ -23,6 +23,12 @@
 #include "terra_sincosf.hpp"
 
 namespace terra {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(TERRA_INSTR)
+static unsigned long long g_cnt[16];
+#define TERRA_CNT(i, n) (g_cnt[i] += (n))
+#else
+#define TERRA_CNT(i, n) do {} while (0)
+#endif
 
 // ------------------------------------------------------------------ grid addressing
 // Padded coordinates X in [0,NX), Z in [0,NY), NX = xsize + 2*PAD.  The interior lives in the caller's buffer (in place);
@@ -67,23 +73,47 @@ TERRA_HD int sati(int v, int n) {return imax(imin(v, n + 8), -8);}   // keeps xi
 //   void erode(xi, zi, xp, zp, dse)         the 4x4 radial brush (src/erosion.cpp:134-147)
 // MEM is either scalar (one lane does everything) or wave-cooperative (64 lanes run this scalar code redundantly and
 // split the brush / corner accesses between them); both give identical results.
-template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &mem, erosion_consts_t const &ec) {
+// Loop-carried state of one droplet at the top of a step: a trace can stop there and be resumed later, bit for bit
+struct droplet_state_t {
+	int xi, zi;
+	float xp, zp, xf, zf, s, v, w, dx, dz, h, h00, h10, h01, h11;
+	unsigned numMoves;
+	int nan_seen;
+	rand_gen_t rgen;
+};
+constexpr unsigned DROPLET_NO_BUDGET = 0xFFFFFFFFu;
+
+// spawn (src/erosion.cpp:67-84); false => the memory policy aborted the trace before the first step
+template<class MEM> TERRA_HD bool droplet_start(int iter, MEM &mem, erosion_consts_t const &ec, droplet_state_t &d) {
+	d.rgen.set_state(iter + 11, 79*(int64_t)iter + 121);
+	d.xi = EROSION_PAD + (d.rgen.rand() % ec.xsize);
+	d.zi = EROSION_PAD + (d.rgen.rand() % ec.ysize);
+	d.xp = (float)d.xi; d.zp = (float)d.zi; d.xf = 0; d.zf = 0; d.s = 0; d.v = 0; d.w = 1; d.dx = 0; d.dz = 0;
+	d.numMoves = 0; d.nan_seen = 0;
+	d.h = d.h00 = d.h10 = d.h01 = d.h11 = 0;
+	if (!mem.begin_step(d.xi, d.zi)) return false;
+	float c[4];
+	mem.corners(d.xi, d.zi, c);
+	d.h = c[0]; d.h00 = c[0]; d.h10 = c[1]; d.h01 = c[2]; d.h11 = c[3];
+	return true;
+}
+
+// the step loop (src/erosion.cpp:86-154), at most `budget` steps of it; true => the droplet is finished (d.numMoves = its step count)
+template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, erosion_consts_t const &ec, unsigned budget) {
 	float const Kq = 10, Kw = 0.001f, Kr = 0.9f, Kd = 0.02f, Ki = 0.1f, minSlope = 0.05f, g = 20, Kg = g*2;
 	float const evap = 1 - Kw;
 	int const NX = ec.NX, NY = ec.NY;
-	droplet_result_t res = {0, 0};
-	rand_gen_t rgen;
-	rgen.set_state(iter + 11, 79*(int64_t)iter + 121);
-	int xi = EROSION_PAD + (rgen.rand() % ec.xsize);
-	int zi = EROSION_PAD + (rgen.rand() % ec.ysize);
-	float xp = (float)xi, zp = (float)zi, xf = 0, zf = 0, s = 0, v = 0, w = 1, dx = 0, dz = 0;
-	if (!mem.begin_step(xi, zi)) {return res;}
+	int xi = d.xi, zi = d.zi;
+	float xp = d.xp, zp = d.zp, xf = d.xf, zf = d.zf, s = d.s, v = d.v, w = d.w, dx = d.dx, dz = d.dz;
+	float h = d.h, h00 = d.h00, h10 = d.h10, h01 = d.h01, h11 = d.h11;
+	rand_gen_t rgen = d.rgen;
+	unsigned numMoves = d.numMoves, used = 0;
+	int nan_seen = d.nan_seen;
+	bool finished = true;
 	float c[4];
-	mem.corners(xi, zi, c);
-	float h = c[0], h00 = c[0], h10 = c[1], h01 = c[2], h11 = c[3];
-	unsigned numMoves = 0;
 
-	for (; numMoves < ec.max_path_len; ++numMoves) {
+	for (; numMoves < ec.max_path_len; ++numMoves, ++used) {
+		if (used == budget) {finished = false; break;}
 		if (numMoves > 0 && !mem.begin_step(xi, zi)) {break;}
 		float const gx = h00+h01-h10-h11, gz = h00+h10-h01-h11;
 		dx = (dx-gx)*Ki+gx;
@@ -133,12 +163,23 @@ template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &me
 			s  += ds;
 		}
 		v = sqrtf(v*v+Kg*dh);
-		if (v != v) {res.nan_seen = 1;}
+		if (v != v) {nan_seen = 1;}
 		w *= evap;
 		xp = nxp; zp = nzp; xi = nxi; zi = nzi; xf = nxf; zf = nzf;
 		h = nh; h00 = nh00; h10 = nh10; h01 = nh01; h11 = nh11;
 	}
-	res.steps = numMoves;
+	d.xi = xi; d.zi = zi; d.xp = xp; d.zp = zp; d.xf = xf; d.zf = zf; d.s = s; d.v = v; d.w = w; d.dx = dx; d.dz = dz;
+	d.h = h; d.h00 = h00; d.h10 = h10; d.h01 = h01; d.h11 = h11;
+	d.rgen = rgen; d.numMoves = numMoves; d.nan_seen = nan_seen;
+	return finished;
+}
+
+template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &mem, erosion_consts_t const &ec) {
+	droplet_state_t d;
+	droplet_result_t res = {0, 0};
+	if (!droplet_start(iter, mem, ec, d)) {return res;}
+	droplet_run(d, mem, ec, DROPLET_NO_BUDGET);
+	res.steps = d.numMoves; res.nan_seen = d.nan_seen;
 	return res;
 }
 
@@ -278,6 +319,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD void flush() { // final write-back of every dirty cell
 		if (have) {
 			TERRA_LANES(i, EW*EW) {if (dirty[i]) {back.store(wx0 + (i % EW), wz0 + (i / EW), win[i]); dirty[i] = 0;}}
+			back.note_written_rect(wx0, wz0);
 		}
 		TERRA_WAVE_SYNC();
 	}
@@ -285,6 +327,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	// (no global traffic, no log look-up); dirty cells that leave are written back; cells that enter are fetched with all plain grid
 	// loads of a lane issued back to back (one HBM latency per shift), then patched where a multi-version look-up is needed.
 	TERRA_HD void recenter(int cx, int cz) {
+		TERRA_CNT(6, 1);
 		int const nx0 = clampi(cx - EW/2, imax(NX - EW, 0)), nz0 = clampi(cz - EW/2, imax(NY - EW, 0));
 		if (have) {
 			TERRA_LANES(i, EW*EW) {
@@ -338,8 +381,8 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
 		out[0] = read_any(x0, z0); out[1] = read_any(x1, z0); out[2] = read_any(x0, z1); out[3] = read_any(x1, z1);
 	}
-	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {this->deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
-	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {this->erode_cells(xi, zi, xp, zp, dse, NX, NY);}
+	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
+	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {back.note_write(); this->erode_cells(xi, zi, xp, zp, dse, NX, NY);}
 	TERRA_HD void finish() {flush();}
 };
 
@@ -351,6 +394,7 @@ struct grid_back_t {
 	TERRA_HD bool failed() const {return false;}
 	TERRA_HD void prepare_window(int, int) {}
 	TERRA_HD void note_far_read(int, int) {}
+	TERRA_HD void note_write() {}
 	TERRA_HD void note_written_rect(int, int) {}
 	TERRA_HD float base(int X, int Z) const {return *g.at(X, Z);}
 	TERRA_HD bool needs_lookup(int, int) const {return false;}
@@ -365,45 +409,67 @@ struct grid_back_t {
 constexpr uint32_t SPEC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SPEC_NIL   = 0xFFFFFFFFu;
 enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4};
+constexpr uint32_t SPEC_BLK_WRITTEN = 0x80000000u; // block-list entry flag: the droplet may have WRITTEN cells of the block (else it only read them)
+// life of a ring slot: FRESH (trace from the spawn) -> RUNNING (trace suspended at a step boundary, state saved) -> DONE_NEW (finished in
+// this round, not published yet) -> IDLE (its finished version is published and believed valid); FAILED = the trace overflowed its log or
+// block list and waits to become the lowest uncommitted droplet, which then runs alone directly on the grid.
+enum {SPEC_IDLE = 0, SPEC_FRESH = 1, SPEC_RUNNING = 2, SPEC_DONE_NEW = 3, SPEC_FAILED = 4};
+
+struct spec_ctl_t { // device-resident control block: a round needs no host decision
+	uint32_t base;         // lowest uncommitted droplet
+	uint32_t new_base;     // commit scan: lowest droplet that is not committable
+	uint32_t stop_at;      // lowest FAILED droplet (SPEC_NIL: none); droplets above it are paused
+	uint32_t new_stop;
+	uint32_t unfinished;   // slots that are not IDLE after the round
+	uint32_t traces;       // traces started (first traces + restarts)
+	uint32_t nan_droplets; // committed droplets that went NaN
+	uint32_t touched;      // cells recorded for the sparse clamp (may exceed the capacity)
+	uint32_t fb_steps, fb_nan; // fall-back droplet
+	uint32_t pad_[2];
+	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
+};
+struct spec_resume_t {uint32_t nblk, nlog, flags, bc[4], be[4], bwmask, far_last; int own_x0, own_z0, own_x1, own_z1; unsigned long long chk;}; // spec_back_t state of a suspended trace
 
 struct spec_buffers_t {
 	grid_view_t grid;
 	erosion_consts_t ec;
-	uint32_t first_iter;   // droplet number of window slot 0
-	uint32_t W;            // slots in the window
-	uint32_t cut;          // slots >= cut are excluded (overflowed droplet and everything after it)
+	uint32_t num_iters;    // droplets of the whole run
+	uint32_t W;            // ring slots; droplet `it` lives in slot it % W, in-flight droplets are [base, base + W)
 	uint32_t cap_log2;     // log capacity = 1 << cap_log2
 	uint32_t maxb;         // block-list capacity per droplet
 	uint32_t bshift;       // block edge = 1 << bshift cells (>= 3)
 	uint32_t nbx, nby;     // blocks per row / column of the padded grid
-	uint32_t use_lists;    // 0 in round 1 (no cross-droplet reads yet)
 	uint32_t *log_keys[2]; // [W][cap]
 	float    *log_vals[2]; // [W][cap]
 	uint32_t *blk_list[2]; // [W][maxb]
 	uint32_t *blk_cnt[2];  // [W]
-	uint64_t *chk[2];      // [W] checksum of the write-back sequence
-	uint32_t *cur;         // [W] which buffer holds the droplet's current trace
-	uint32_t *need;        // [W] (re)trace in this round
-	uint32_t *changed;     // [W] this round's trace differs from the previous one
+	uint64_t *chk[2];      // [W] checksum of the version's final log content (+ step count)
+	uint32_t *it;          // [W] droplet number held by the slot (SPEC_NIL: none)
+	uint32_t *phase;       // [W]
+	uint32_t *has_ver;     // [W] buffer cur[] holds a published finished version (visible to higher droplets)
+	uint32_t *cur;         // [W] which buffer holds the published version; a (re)trace builds the other one
+	uint32_t *changed;     // [W] the version finished this round differs from the published one
+	uint32_t *restart;     // [W] set by the mark pass
+	uint32_t *run_nblk;    // [W] blocks recorded so far by the suspended / failed trace
 	uint32_t *flags;       // [W]
 	uint32_t *nsteps;      // [W]
+	droplet_state_t *state;// [W] suspended traces
+	spec_resume_t *resume; // [W]
 	uint32_t *head;        // [nbx*nby] block -> first node
 	uint32_t *next;        // [W*maxb]  node -> next node ; node id = slot*maxb + entry
-	uint32_t *dirty_min;   // [nbx*nby] lowest changed droplet slot touching the block this round
-	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp); counters[6] = count (may exceed the capacity)
+	uint32_t *dirty_min;   // [nbx*nby] lowest droplet whose published version changed in a way that touches the block, this round
+	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp)
 	uint32_t touched_cap;
-	uint32_t *counters;    // [0] droplets to re-trace, [1] lowest overflowed slot of this window, [2] traces, [3] steps traced, [4..5] fall-back droplet steps / nan, [6] touched cells, [7..8] committed steps / nan droplets
+	spec_ctl_t *ctl;
 };
 
-// slots >= cut are out of the window: `cut` is what the host knew at launch, counters[1] the lowest slot that overflowed since (device side)
-TERRA_HD uint32_t spec_cut(spec_buffers_t const &sb) {uint32_t const c = sb.counters[1]; return (c < sb.cut) ? c : sb.cut;}
-
-// splitmix64 finaliser.  The per-store terms of the trace checksum must be mixed non-linearly: a lower droplet's change often moves
+// splitmix64 finaliser.  The per-cell terms of the log checksum must be mixed non-linearly: a lower droplet's change often moves
 // some cells up one ulp and others down one ulp, which a linear (multiplicative) term sum cannot see.
 TERRA_HD uint64_t spec_mix64(uint64_t x) {
 	x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
 	return x;
 }
+TERRA_HD uint64_t spec_term(uint32_t cell, float val) {uint32_t vb; memcpy(&vb, &val, 4); return spec_mix64(((uint64_t)cell << 32) | vb);}
 TERRA_HD uint32_t spec_hash(uint32_t cell, uint32_t cap_log2) {return (cell*2654435761u) >> (32 - cap_log2);}
 
 // L2LOAD: read through to L2.  A droplet's OWN log is written by the other lanes of its wave (CAS + plain stores) in the same
@@ -417,7 +483,9 @@ TERRA_HD uint32_t spec_hash(uint32_t cell, uint32_t cap_log2) {return (cell*2654
 template<bool L2LOAD> TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t cap_log2, uint32_t cell, float &out) {
 	uint32_t const mask = (1u << cap_log2) - 1;
 	uint32_t h = spec_hash(cell, cap_log2);
+	TERRA_CNT(L2LOAD ? 0 : 1, 1);
 	for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
+		TERRA_CNT(L2LOAD ? 2 : 3, 1);
 		uint32_t const k = L2LOAD ? TERRA_L2_LOAD(&keys[h]) : keys[h];
 		if (k == cell) {out = L2LOAD ? TERRA_L2_LOAD(&vals[h]) : vals[h]; return true;}
 		if (k == SPEC_EMPTY) return false;
@@ -428,36 +496,70 @@ template<bool L2LOAD> TERRA_HD bool spec_log_find(uint32_t const *keys, float co
 struct spec_back_t {
 	spec_buffers_t const *sb;
 	wave_shared_t *sh;     // LDS
-	uint32_t slot;
-	uint32_t *my_keys; float *my_vals; uint32_t *my_blks; // the "new" buffers (1 - cur)
+	uint32_t slot, iter;
+	uint32_t *my_keys; float *my_vals; uint32_t *my_blks; // the version being built (buffer 1 - cur)
 	uint32_t nblk;
-	uint32_t bc0, bc1, bc2, bc3; // the four most recently recorded blocks (plain registers: an indexed array would live in scratch memory)
+	// the four most recently recorded brush-box blocks with their list entries (plain registers: an indexed array would live in scratch memory);
+	// bit k of bwmask: cache position k was written to since it entered the cache
+	uint32_t bc0, bc1, bc2, bc3, be0, be1, be2, be3, bwmask, far_last;
 	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
 	int own_x0, own_z0, own_x1, own_z1; // bounding box of the cells this droplet may already have written back
 
-	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_, wave_shared_t *sh_) {
-		sb = sb_; slot = slot_; sh = sh_;
+	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_, uint32_t iter_, wave_shared_t *sh_, spec_resume_t const *rs) {
+		sb = sb_; slot = slot_; iter = iter_; sh = sh_;
 		uint32_t const nb = 1u - sb->cur[slot];
 		size_t const cap = (size_t)1 << sb->cap_log2;
 		my_keys = sb->log_keys[nb] + (size_t)slot*cap;
 		my_vals = sb->log_vals[nb] + (size_t)slot*cap;
 		my_blks = sb->blk_list[nb] + (size_t)slot*sb->maxb;
-		nblk = 0; bc0 = bc1 = bc2 = bc3 = SPEC_NIL; blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
+		nblk = 0; bc0 = bc1 = bc2 = bc3 = SPEC_NIL; be0 = be1 = be2 = be3 = 0; bwmask = 0; far_last = SPEC_NIL;
+		blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
 		own_x0 = own_z0 = INT_MAX; own_x1 = own_z1 = INT_MIN;
-		if (TERRA_LANE0) {sh->nlog = 0; sh->flags = 0; sh->chk = 0;}
+		if (rs) { // resume a suspended trace
+			nblk = rs->nblk; own_x0 = rs->own_x0; own_z0 = rs->own_z0; own_x1 = rs->own_x1; own_z1 = rs->own_z1;
+			bc0 = rs->bc[0]; bc1 = rs->bc[1]; bc2 = rs->bc[2]; bc3 = rs->bc[3]; be0 = rs->be[0]; be1 = rs->be[1]; be2 = rs->be[2]; be3 = rs->be[3];
+			bwmask = rs->bwmask; far_last = rs->far_last;
+		}
+		if (TERRA_LANE0) {sh->nlog = rs ? rs->nlog : 0; sh->flags = rs ? rs->flags : 0; sh->chk = rs ? rs->chk : 0;}
 		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD void save(spec_resume_t &rs) const {
+		rs.nblk = nblk; rs.nlog = sh->nlog; rs.flags = sh->flags; rs.chk = sh->chk;
+		rs.bc[0] = bc0; rs.bc[1] = bc1; rs.bc[2] = bc2; rs.bc[3] = bc3; rs.be[0] = be0; rs.be[1] = be1; rs.be[2] = be2; rs.be[3] = be3;
+		rs.bwmask = bwmask; rs.far_last = far_last;
+		rs.own_x0 = own_x0; rs.own_z0 = own_z0; rs.own_x1 = own_x1; rs.own_z1 = own_z1;
 	}
 	// sh->flags only changes inside window write-backs, which end with a wave sync; blk_overflow is a wave-uniform register
 	TERRA_HD bool failed() const {return blk_overflow || (sh->flags & SPEC_F_LOG_OVERFLOW) != 0;}
-	TERRA_HD void touch_block(uint32_t b) { // wave-uniform bookkeeping; lane 0 owns the global write
+	// Footprint bookkeeping (wave-uniform; lane 0 owns the global writes).  Every write of a step lands in the step's brush box, whose
+	// (at most four) blocks are all in the cache after begin_step(): a deposit / brush therefore flags the whole cache as written
+	// (a superset is fine).  The flag reaches the list entry when the block leaves the cache or the trace stops.
+	TERRA_HD void touch_block(uint32_t b) {
 		if (b == bc0 || b == bc1 || b == bc2 || b == bc3) return;
-		bc3 = bc2; bc2 = bc1; bc1 = bc0; bc0 = b;
 		if (nblk >= sb->maxb) {blk_overflow = true; return;}
+		if ((bwmask & 8u) && bc3 != SPEC_NIL && TERRA_LANE0) {my_blks[be3] = bc3 | SPEC_BLK_WRITTEN;}
+		bc3 = bc2; bc2 = bc1; bc1 = bc0; bc0 = b; be3 = be2; be2 = be1; be1 = be0; be0 = nblk; bwmask = (bwmask << 1) & 0xFu;
 		if (TERRA_LANE0) {my_blks[nblk] = b;}
 		++nblk;
 	}
-	TERRA_HD void note_far_read(int X, int Z) {touch_block((uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift));}
+	TERRA_HD void note_write() {bwmask = 0xFu;}
+	TERRA_HD void flush_block_flags() const { // the trace stops (finished or suspended)
+		if (!TERRA_LANE0) return;
+		if ((bwmask & 1u) && bc0 != SPEC_NIL) {my_blks[be0] = bc0 | SPEC_BLK_WRITTEN;}
+		if ((bwmask & 2u) && bc1 != SPEC_NIL) {my_blks[be1] = bc1 | SPEC_BLK_WRITTEN;}
+		if ((bwmask & 4u) && bc2 != SPEC_NIL) {my_blks[be2] = bc2 | SPEC_BLK_WRITTEN;}
+		if ((bwmask & 8u) && bc3 != SPEC_NIL) {my_blks[be3] = bc3 | SPEC_BLK_WRITTEN;}
+	}
+	// reads outside the window (only after a NaN position): read-only entries that stay out of the brush-box cache
+	TERRA_HD void note_far_read(int X, int Z) {
+		uint32_t const b = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
+		if (b == far_last || b == bc0 || b == bc1 || b == bc2 || b == bc3) return;
+		if (nblk >= sb->maxb) {blk_overflow = true; return;}
+		far_last = b;
+		if (TERRA_LANE0) {my_blks[nblk] = b;}
+		++nblk;
+	}
 	TERRA_HD bool begin_step(int xi, int zi) { // footprint of one step = the 4x4 brush box, which also covers every read of that step
 		int const x0 = clampi(xi-1, sb->ec.NX-1) >> sb->bshift, x1 = clampi(xi+2, sb->ec.NX-1) >> sb->bshift;
 		int const z0 = clampi(zi-1, sb->ec.NY-1) >> sb->bshift, z1 = clampi(zi+2, sb->ec.NY-1) >> sb->bshift;
@@ -469,14 +571,17 @@ struct spec_back_t {
 		}
 		return !failed();
 	}
+	// a list node counts when its slot holds a published version of a LOWER droplet (nodes of slots that were re-assigned since the lists
+	// were built have no published version yet)
+	TERRA_HD bool lower_version(uint32_t j) const {return sb->has_ver[j] && sb->it[j] < iter;}
 	// which blocks under the new window are also in a LOWER droplet's footprint (only those need the multi-version lookup)
 	TERRA_HD void prepare_window(int wx0, int wz0) {
 		wbx0 = wx0 >> sb->bshift; wbz0 = wz0 >> sb->bshift;
 		TERRA_LANES(i, wnb*wnb) {
 			uint8_t shared = 0;
 			uint32_t const bx = (uint32_t)(wbx0 + i % wnb), bz = (uint32_t)(wbz0 + i / wnb);
-			if (sb->use_lists && bx < sb->nbx && bz < sb->nby) {
-				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {if (node / sb->maxb < slot) {shared = 1; break;}}
+			if (bx < sb->nbx && bz < sb->nby) {
+				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {TERRA_CNT(4, 1); if (lower_version(node / sb->maxb)) {shared = 1; break;}}
 			}
 			sh->blk_shared[i] = shared;
 		}
@@ -487,7 +592,6 @@ struct spec_back_t {
 	}
 	TERRA_HD float base(int X, int Z) const {return *sb->grid.at(X, Z);}
 	TERRA_HD bool block_flag(int X, int Z) const { // is the cell's block also in a LOWER droplet's footprint?
-		if (!sb->use_lists) return false;
 		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
 		if ((unsigned)bx < (unsigned)wnb && (unsigned)bz < (unsigned)wnb) return sh->blk_shared[bz*wnb + bx] != 0;
 		return true; // outside the prepared window (far read): look the block up directly
@@ -502,30 +606,47 @@ struct spec_back_t {
 		float v;
 		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1 && spec_log_find<true>(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
 		if (block_flag(X, Z)) {
-			uint32_t best = SPEC_NIL;
+			uint32_t best = SPEC_NIL; // droplet number of the best writer so far
 			size_t const cap = (size_t)1 << sb->cap_log2;
 			uint32_t const blk = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
 			for (uint32_t node = sb->head[blk]; node != SPEC_NIL; node = sb->next[node]) {
+				TERRA_CNT(5, 1);
 				uint32_t const j = node / sb->maxb;
-				if (j >= slot || (best != SPEC_NIL && j <= best)) continue;
+				if (!lower_version(j)) continue;
+				uint32_t const ij = sb->it[j];
+				if (best != SPEC_NIL && ij <= best) continue;
 				uint32_t const cb = sb->cur[j];
 				float vj;
-				if (spec_log_find<false>(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = j; v = vj;}
+				if (spec_log_find<false>(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = ij; v = vj;}
 			}
 			if (best != SPEC_NIL) return v;
 		}
 		return b;
 	}
-	TERRA_HD void store(int X, int Z, float val) { // called from lanes in parallel, each with a distinct cell
+	// called from lanes in parallel, each with a distinct cell.  sh->chk = sum over the log's cells of a non-linear term of (cell, latest value):
+	// a function of the log CONTENT only, so two traces of a droplet compare equal however their write-backs were scheduled
+	TERRA_HD void store(int X, int Z, float val) {
+		TERRA_CNT(7, 1);
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
 		uint32_t const mask = (1u << sb->cap_log2) - 1, limit = mask - (uint32_t)(EW*EW) - 64u;
-		uint32_t vb; memcpy(&vb, &val, 4);
-		TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)spec_mix64(((uint64_t)cell << 32) | vb)); // commutative (lanes add in any order) over NON-LINEARLY mixed terms
 		uint32_t h = spec_hash(cell, sb->cap_log2);
 		for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
 			uint32_t k = my_keys[h];
-			if (k == SPEC_EMPTY) {k = TERRA_ATOMIC_CAS(&my_keys[h], SPEC_EMPTY, cell); if (k == SPEC_EMPTY) {my_vals[h] = val; if (TERRA_ATOMIC_ADD(&sh->nlog, 1u) >= limit) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);} return;}}
-			if (k == cell) {my_vals[h] = val; return;}
+			if (k == SPEC_EMPTY) {
+				k = TERRA_ATOMIC_CAS(&my_keys[h], SPEC_EMPTY, cell);
+				if (k == SPEC_EMPTY) {
+					my_vals[h] = val;
+					TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)spec_term(cell, val));
+					if (TERRA_ATOMIC_ADD(&sh->nlog, 1u) >= limit) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);}
+					return;
+				}
+			}
+			if (k == cell) {
+				float const old = TERRA_L2_LOAD(&my_vals[h]);
+				my_vals[h] = val;
+				TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)(spec_term(cell, val) - spec_term(cell, old)));
+				return;
+			}
 		}
 		TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);
 	}
@@ -536,23 +657,55 @@ struct spec_back_t {
 // LDS scratch a wave body needs; the kernels / the emulator provide it
 struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;}; // win / dirty hold 2*EW*EW entries (double-buffered window)
 
-TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, wave_scratch_t const &ws) {
-	if (slot >= spec_cut(sb) || !sb.need[slot]) return;
+TERRA_HD bool spec_slot_active(spec_buffers_t const &sb, uint32_t slot, uint32_t &iter) { // holds a droplet that is not paused
+	iter = sb.it[slot];
+	return iter != SPEC_NIL && iter <= sb.ctl->stop_at;
+}
+
+// trace (or continue tracing) the slot's droplet for at most `budget` steps
+TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t budget, wave_scratch_t const &ws) {
+	uint32_t iter;
+	if (!spec_slot_active(sb, slot, iter)) return;
+	uint32_t const ph = sb.phase[slot];
+	if (ph != SPEC_FRESH && ph != SPEC_RUNNING) return;
+	TERRA_CNT(ph == SPEC_FRESH ? 8 : 9, 1);
 	window_mem_t<spec_back_t> mem;
 	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
-	mem.back.init(&sb, slot, ws.sh);
-	droplet_result_t const r = simulate_droplet((int)(sb.first_iter + slot), mem, sb.ec);
-	mem.finish();
+	droplet_state_t d;
+	bool finished = false;
+	if (ph == SPEC_FRESH) {
+		mem.back.init(&sb, slot, iter, ws.sh, nullptr);
+		finished = !droplet_start((int)iter, mem, sb.ec, d);
+	}
+	else {
+		d = sb.state[slot];
+		mem.back.init(&sb, slot, iter, ws.sh, &sb.resume[slot]);
+	}
+	if (!finished) {finished = droplet_run(d, mem, sb.ec, budget);}
+	unsigned const steps_before = (ph == SPEC_FRESH) ? 0u : sb.state[slot].numMoves;
+	mem.finish(); // the window's dirty cells go to the log: a suspended trace keeps nothing in LDS
+	mem.back.flush_block_flags();
 	if (TERRA_LANE0) {
-		uint32_t const nb = 1u - sb.cur[slot];
+		uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
-		sb.blk_cnt[nb][slot] = mem.back.nblk;
-		sb.chk[nb][slot]     = (uint64_t)ws.sh->chk ^ ((uint64_t)r.steps << 40);
-		sb.nsteps[slot]      = r.steps;
-		sb.flags[slot]       = fl | (r.nan_seen ? SPEC_F_NAN : 0);
-		if (fl & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) {TERRA_ATOMIC_MIN(&sb.counters[1], slot);}
-		TERRA_ATOMIC_ADD(&sb.counters[2], 1u);
-		TERRA_ATOMIC_ADD(&sb.counters[3], r.steps);
+		bool const failed = (fl & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) != 0;
+		sb.run_nblk[slot] = mem.back.nblk;
+		if (finished || failed) {
+			uint64_t const chk = (uint64_t)ws.sh->chk ^ ((uint64_t)d.numMoves << 40);
+			sb.blk_cnt[nb][slot] = mem.back.nblk;
+			sb.chk[nb][slot]     = chk;
+			sb.nsteps[slot]      = d.numMoves;
+			sb.flags[slot]       = fl | (d.nan_seen ? SPEC_F_NAN : 0);
+			sb.changed[slot]     = (!sb.has_ver[slot] || sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk) ? 1u : 0u;
+			sb.phase[slot]       = failed ? (uint32_t)SPEC_FAILED : (uint32_t)SPEC_DONE_NEW;
+		}
+		else {
+			sb.state[slot] = d;
+			mem.back.save(sb.resume[slot]);
+			sb.phase[slot] = SPEC_RUNNING;
+		}
+		if (ph == SPEC_FRESH) {TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u);}
+		TERRA_ATOMIC_ADD(&sb.ctl->traced_steps, (unsigned long long)(d.numMoves - steps_before));
 	}
 }
 
@@ -568,58 +721,69 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 	if (TERRA_LANE0 && out_steps_nan) {out_steps_nan[0] = r.steps; out_steps_nan[1] = (uint32_t)r.nan_seen;}
 }
 
-// ---- per-logical-thread bodies of the bookkeeping kernels
+// ---- per-logical-thread bodies of the bookkeeping kernels (one round = clear, trace, post, flip, link, mark, scan, flush, admit, advance)
 
-// clear the "new" log of every droplet that will be traced this round: one thread per (slot, log entry)
+// empty the version buffer of every droplet that starts a trace this round: one thread per (slot, log entry)
 TERRA_HD void spec_clear_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	if (slot >= spec_cut(sb) || !sb.need[slot]) return;
+	uint32_t iter;
+	if (!spec_slot_active(sb, slot, iter) || sb.phase[slot] != SPEC_FRESH) return;
 	uint32_t const nb = 1u - sb.cur[slot];
 	sb.log_keys[nb][((size_t)slot << sb.cap_log2) + entry] = SPEC_EMPTY;
 }
-// after all traces of the round: publish dirty blocks of changed droplets
-TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, bool first_round) {
-	if (slot >= spec_cut(sb) || !sb.need[slot]) {if (slot < sb.W) sb.changed[slot] = 0; return;}
+// a version finished this round and differs from the published one: its old and new footprints are dirty for every higher droplet.
+// One thread per (slot, block-list entry).
+TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
+	uint32_t const iter = sb.it[slot];
+	if (iter == SPEC_NIL || sb.phase[slot] != SPEC_DONE_NEW || !sb.changed[slot]) return;
 	uint32_t const ob = sb.cur[slot], nb = 1u - ob;
-	bool const changed = first_round || (sb.chk[ob][slot] != sb.chk[nb][slot]) || (sb.blk_cnt[ob][slot] != sb.blk_cnt[nb][slot]);
-	sb.changed[slot] = changed ? 1u : 0u;
-	if (changed) {
-		if (!first_round) {
-			uint32_t const *ol = sb.blk_list[ob] + (size_t)slot*sb.maxb;
-			for (uint32_t e = 0; e < sb.blk_cnt[ob][slot]; ++e) {TERRA_ATOMIC_MIN(&sb.dirty_min[ol[e]], slot);}
-		}
-		uint32_t const *nl = sb.blk_list[nb] + (size_t)slot*sb.maxb;
-		for (uint32_t e = 0; e < sb.blk_cnt[nb][slot]; ++e) {TERRA_ATOMIC_MIN(&sb.dirty_min[nl[e]], slot);}
+	if (sb.has_ver[slot] && entry < sb.blk_cnt[ob][slot]) {
+		uint32_t const e = sb.blk_list[ob][(size_t)slot*sb.maxb + entry];
+		if (e & SPEC_BLK_WRITTEN) {TERRA_ATOMIC_MIN(&sb.dirty_min[e & ~SPEC_BLK_WRITTEN], iter);} // only written blocks can invalidate a reader
+	}
+	if (entry < sb.blk_cnt[nb][slot]) {
+		uint32_t const e = sb.blk_list[nb][(size_t)slot*sb.maxb + entry];
+		if (e & SPEC_BLK_WRITTEN) {TERRA_ATOMIC_MIN(&sb.dirty_min[e & ~SPEC_BLK_WRITTEN], iter);}
 	}
 }
+// publish the versions finished this round
 TERRA_HD void spec_flip_body(spec_buffers_t const &sb, uint32_t slot) {
-	if (slot >= spec_cut(sb) || !sb.need[slot]) return;
-	sb.cur[slot] = 1u - sb.cur[slot];
+	if (sb.it[slot] == SPEC_NIL || sb.phase[slot] != SPEC_DONE_NEW) return;
+	sb.cur[slot] = 1u - sb.cur[slot]; sb.has_ver[slot] = 1; sb.phase[slot] = SPEC_IDLE;
 }
-// rebuild block -> droplet lists from the current footprints (head[] was reset to SPEC_NIL before): one thread per (slot, entry)
+// rebuild block -> writer lists from the published footprints (head[] was reset to SPEC_NIL before): one thread per (slot, entry)
 TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	if (slot >= spec_cut(sb)) return;
+	if (sb.it[slot] == SPEC_NIL || !sb.has_ver[slot]) return;
 	uint32_t const cb = sb.cur[slot];
 	if (entry >= sb.blk_cnt[cb][slot]) return;
-	uint32_t const b = sb.blk_list[cb][(size_t)slot*sb.maxb + entry];
+	uint32_t const e = sb.blk_list[cb][(size_t)slot*sb.maxb + entry];
+	if (!(e & SPEC_BLK_WRITTEN)) return; // the lists answer "who wrote here": read-only entries stay out
 	uint32_t const node = slot*sb.maxb + entry;
-	sb.next[node] = TERRA_ATOMIC_EXCH(&sb.head[b], node);
+	sb.next[node] = TERRA_ATOMIC_EXCH(&sb.head[e & ~SPEC_BLK_WRITTEN], node);
 }
-// who must be re-traced next round: any droplet sharing a block with a lower-numbered droplet that changed this round
-TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot) {
-	if (slot >= sb.W) return;
-	uint32_t need = 0;
-	if (slot < spec_cut(sb)) {
-		uint32_t const cb = sb.cur[slot];
-		uint32_t const *bl = sb.blk_list[cb] + (size_t)slot*sb.maxb;
-		for (uint32_t e = 0; e < sb.blk_cnt[cb][slot]; ++e) {if (sb.dirty_min[bl[e]] < slot) {need = 1; break;}}
-	}
-	sb.need[slot] = need;
-	if (need) {TERRA_ATOMIC_ADD(&sb.counters[0], 1u);}
+// who must start over: any droplet whose footprint (so far) contains a block dirtied by a lower droplet.  One thread per (slot, entry).
+TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
+	uint32_t const iter = sb.it[slot];
+	if (iter == SPEC_NIL) return;
+	uint32_t const ph = sb.phase[slot], cb = sb.cur[slot];
+	uint32_t const *bl; uint32_t cnt;
+	if (ph == SPEC_RUNNING || ph == SPEC_FAILED) {bl = sb.blk_list[1u - cb] + (size_t)slot*sb.maxb; cnt = sb.run_nblk[slot];}
+	else if (ph == SPEC_IDLE && sb.has_ver[slot]) {bl = sb.blk_list[cb] + (size_t)slot*sb.maxb; cnt = sb.blk_cnt[cb][slot];}
+	else return;
+	if (entry < cnt && sb.dirty_min[bl[entry] & ~SPEC_BLK_WRITTEN] < iter) {sb.restart[slot] = 1;}
 }
-// flush: the highest-numbered writer of a cell stores it; one thread per (slot, log entry)
+// apply the restarts, find the commit point and the lowest failed droplet: one thread per slot
+TERRA_HD void spec_scan_body(spec_buffers_t const &sb, uint32_t slot) {
+	uint32_t const iter = sb.it[slot];
+	if (iter == SPEC_NIL) return;
+	if (sb.restart[slot]) {sb.restart[slot] = 0; sb.phase[slot] = SPEC_FRESH;}
+	uint32_t const ph = sb.phase[slot];
+	if (ph == SPEC_FAILED) {TERRA_ATOMIC_MIN(&sb.ctl->new_stop, iter);}
+	if (!(ph == SPEC_IDLE && sb.has_ver[slot])) {TERRA_ATOMIC_MIN(&sb.ctl->new_base, iter); TERRA_ATOMIC_ADD(&sb.ctl->unfinished, 1u);}
+}
+// flush the committed droplets [base, new_base): the highest-numbered committed writer of a cell stores it; one thread per (slot, log entry)
 TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	uint32_t const cut = spec_cut(sb);
-	if (slot >= cut) return;
+	uint32_t const iter = sb.it[slot], nbase = sb.ctl->new_base;
+	if (iter == SPEC_NIL || iter >= nbase) return;
 	uint32_t const cb = sb.cur[slot];
 	size_t const cap = (size_t)1 << sb.cap_log2;
 	uint32_t const cell = sb.log_keys[cb][(size_t)slot*cap + entry];
@@ -627,14 +791,52 @@ TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	uint32_t const X = cell % (uint32_t)sb.ec.NX, Z = cell / (uint32_t)sb.ec.NX;
 	uint32_t const b = (Z >> sb.bshift)*sb.nbx + (X >> sb.bshift);
 	for (uint32_t node = sb.head[b]; node != SPEC_NIL; node = sb.next[node]) {
-		uint32_t const j = node / sb.maxb;
-		if (j <= slot || j >= cut) continue;
+		uint32_t const j = node / sb.maxb, ij = sb.it[j];
+		if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
 		uint32_t const jb = sb.cur[j];
 		float vj;
-		if (spec_log_find<false>(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later droplet owns the final value
+		if (spec_log_find<false>(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later committed droplet owns the final value
 	}
 	*sb.grid.at((int)X, (int)Z) = sb.log_vals[cb][(size_t)slot*cap + entry];
-	if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.counters[6], 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
+	if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.ctl->touched, 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
+}
+// hand a slot to the next droplet of the ring
+TERRA_HD void spec_reassign(spec_buffers_t const &sb, uint32_t slot, uint32_t iter) {
+	uint64_t const nit = (uint64_t)iter + sb.W;
+	sb.it[slot] = (nit < sb.num_iters) ? (uint32_t)nit : SPEC_NIL;
+	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
+}
+// committed droplets leave, their slots are handed to the next droplets: one thread per slot
+TERRA_HD void spec_admit_body(spec_buffers_t const &sb, uint32_t slot) {
+	uint32_t const iter = sb.it[slot];
+	if (iter == SPEC_NIL || iter >= sb.ctl->new_base) return;
+	TERRA_ATOMIC_ADD(&sb.ctl->steps, (unsigned long long)sb.nsteps[slot]);
+	if (sb.flags[slot] & SPEC_F_NAN) {TERRA_ATOMIC_ADD(&sb.ctl->nan_droplets, 1u);}
+	spec_reassign(sb, slot, iter);
+}
+// end of round (one thread)
+TERRA_HD void spec_advance_body(spec_buffers_t const &sb) {
+	spec_ctl_t &c = *sb.ctl;
+	c.base = c.new_base;
+	uint64_t const nb = (uint64_t)c.base + sb.W;
+	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;
+	c.stop_at = c.new_stop; c.new_stop = SPEC_NIL; c.unfinished = 0;
+}
+// after the fall-back droplet `base` ran directly on the grid: it is committed and every other in-flight trace starts over (the grid
+// changed under them without a version to compare against).  One thread per slot, then spec_fallback_advance_body.
+TERRA_HD void spec_fallback_reset_body(spec_buffers_t const &sb, uint32_t slot) {
+	uint32_t const iter = sb.it[slot];
+	if (iter == SPEC_NIL) return;
+	if (iter == sb.ctl->base) {spec_reassign(sb, slot, iter); return;}
+	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
+}
+TERRA_HD void spec_fallback_advance_body(spec_buffers_t const &sb) {
+	spec_ctl_t &c = *sb.ctl;
+	c.base += 1;
+	uint64_t const nb = (uint64_t)c.base + sb.W;
+	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;
+	c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; c.unfinished = 0;
+	c.steps += c.fb_steps; c.traced_steps += c.fb_steps; c.nan_droplets += c.fb_nan;
 }
 // sparse version of "clamp to min_zval" (src/erosion.cpp:158-162) when min_zval <= every untouched cell: one thread per recorded write
 TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, uint32_t i, float min_zval) {
@@ -642,13 +844,6 @@ TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, 
 	int const X = (int)(cell % (uint32_t)g.NX), Z = (int)(cell / (uint32_t)g.NX);
 	int const x = X - EROSION_PAD, z = Z - EROSION_PAD;
 	if ((unsigned)x < (unsigned)g.xsize && (unsigned)z < (unsigned)g.ysize) {float *p = g.interior + (size_t)z*g.xsize + x; *p = max_std(min_zval, *p);} // idempotent: duplicates are harmless
-}
-
-// per-window totals of the committed droplets: one thread per slot -> counters[7] (steps), counters[8] (droplets that went NaN)
-TERRA_HD void spec_totals_body(spec_buffers_t const &sb, uint32_t slot) {
-	if (slot >= spec_cut(sb)) return;
-	TERRA_ATOMIC_ADD(&sb.counters[7], sb.nsteps[slot]);
-	if (sb.flags[slot] & SPEC_F_NAN) {TERRA_ATOMIC_ADD(&sb.counters[8], 1u);}
 }
 
 // ring initialisation = the clamp-padded copy of src/erosion.cpp:31-37 restricted to the ring; one thread per ring float

@@ -107,6 +107,7 @@ _PROTOS = {
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
+    "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
     "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "terra_minmax_dev": (_i32, [_vp, _vp, _sz, _f3, _f3]),
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
@@ -231,6 +232,9 @@ class Terra:
 
     def set_erosion_tuning(self, window=0, log_capacity_log2=0, block_list_capacity=0):
         self._ck(self.lib.terra_set_erosion_tuning(self.ctx, window, log_capacity_log2, block_list_capacity))
+
+    def set_erosion_slice_steps(self, steps):
+        self._ck(self.lib.terra_set_erosion_slice_steps(self.ctx, steps))
 
     def erosion_report(self):
         r = ErosionReport()

@@ -74,7 +74,7 @@ typedef struct terra_tile_stats {
 
 /* counters of the last terra_apply_erosion*_dev call (diagnostics / bench) */
 typedef struct terra_erosion_report {
-	uint32_t droplets, windows, rounds, traces, serial_fallbacks, nan_droplets;
+	uint32_t droplets, windows /* ring generations = ceil(droplets / slots) */, rounds, traces, serial_fallbacks, nan_droplets;
 	uint64_t steps;          /* droplet steps of the final (committed) traces */
 	uint64_t traced_steps;   /* droplet steps actually simulated, re-traces included */
 } terra_erosion_report;
@@ -142,9 +142,11 @@ int  terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_
 int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
-/* tuning of the speculative scheduler (0 keeps a value): droplets per window, log2 of the per-droplet write-log capacity (>= 12),
- * per-droplet block-list capacity.  A droplet that overflows either runs alone, in order, directly on the grid (still exact). */
+/* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots), log2 of the per-droplet write-log capacity (>= 12),
+ * per-droplet block-list capacity.  A droplet that overflows either runs alone, in order, directly on the grid (still exact).
+ * slice_steps: while droplets wait for a slot a trace advances at most this many steps per round (default 64).  Results never depend on any of these. */
 int  terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t log_capacity_log2, uint32_t block_list_capacity);
+int  terra_set_erosion_slice_steps(terra_ctx *ctx, uint32_t slice_steps);
 
 /* ---- whole heightmap: heightmap_t::proc_gen (src/heightmap.cpp:130-151) minus run_city_gen.
  * d_vals: width*height floats (final z); d_pixels16: optional 2 bytes per pixel {lo, hi} (from_floats/write_pixel_16_bits);

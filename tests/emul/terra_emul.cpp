@@ -60,3 +60,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 };
 typedef cpu_backend_t terra_backend_t;
 #include "../../3dworld_amd/csrc/terra_api_impl.hpp"
+
+#ifdef TERRA_INSTR
+extern "C" unsigned long long *terra_emul_counters() {return terra::g_cnt;}
+#endif

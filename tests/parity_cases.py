@@ -104,6 +104,20 @@ def case_erosion_vs_oracle(pkg, t, orc, n, iters, mode=0, flags=0, seed=1):
     return r, stats
 
 
+def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_cap=0, seed=1):
+    """many more droplets than ring slots, traces suspended every `slice_steps` steps: commits, slot hand-over, resumed traces,
+    restarts of suspended traces and (blk_cap) overflow fall-backs in the middle of the ring -- still the serial result, bit for bit."""
+    t.set_erosion_tuning(window=window, block_list_capacity=blk_cap)
+    t.set_erosion_slice_steps(slice_steps)
+    try:
+        r, stats = case_erosion_vs_oracle(pkg, t, orc, n, iters, seed=seed)
+    finally:
+        t.set_erosion_tuning(window=4096, block_list_capacity=256)
+        t.set_erosion_slice_steps(64)
+    assert r.windows == -(-iters // window)
+    return r, stats
+
+
 def case_erosion_edge(pkg, t, orc):
     """disabled erosion, flat terrain (random-direction branch), water everywhere, 1-cell-wide grids."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=0)

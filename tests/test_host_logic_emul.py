@@ -38,6 +38,14 @@ def test_erosion_serial_flag_and_overflow_fallback(pkg, emul, orc):
     assert r.serial_fallbacks >= 1 and r.windows >= 7
 
 
+@pytest.mark.parametrize("n,iters,window,slice_steps,blk_cap", [(128, 2000, 32, 4, 0), (256, 3000, 64, 16, 0), (96, 1500, 16, 1, 0), (256, 1200, 48, 8, 12), (192, 900, 7, 3, 0)])
+def test_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk_cap):
+    r, _ = pc.case_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk_cap)
+    assert r.rounds > r.windows
+    if blk_cap:
+        assert r.serial_fallbacks >= 1
+
+
 def test_erosion_edge_cases(pkg, emul, orc):
     pc.case_erosion_edge(pkg, emul, orc)
 
