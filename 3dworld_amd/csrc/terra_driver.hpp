@@ -398,7 +398,7 @@ template<class BE> struct terra_engine {
 		return ec;
 	}
 
-	struct spec_cfg_t {uint32_t window = 4096, cap_log2 = 12, maxb = 256, bshift = 3, slice_steps = 64, max_rounds = 4000000;} spec_cfg;
+	struct spec_cfg_t {uint32_t window = 0 /* auto */, cap_log2 = 12, maxb = 256, bshift = 3, slice_steps = 1024, max_rounds = 4000000;} spec_cfg;
 
 	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
 		require_scene();
@@ -446,7 +446,10 @@ template<class BE> struct terra_engine {
 	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched) {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
-		uint32_t const W = std::min<uint32_t>(spec_cfg.window, num_iters);
+		// ring slots: more droplets in flight = more parallel work but also more speculation on stale cells; measured best (MI355X, 10^5..10^6 droplets
+		// on 4096^2..16384^2) near one slot per 16K cells.  64 KiB of log per slot and buffer: 16384 slots = 2 GiB of the 288.
+		uint32_t const auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)ec.NX*ec.NY) >> 14, 2048), 16384);
+		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.W = W; sb.cap_log2 = spec_cfg.cap_log2; sb.maxb = spec_cfg.maxb; sb.bshift = std::max<uint32_t>(spec_cfg.bshift, 3);
 		if (((size_t)1 << sb.cap_log2) < (size_t)4*EW*EW) throw std::logic_error("speculative erosion: log capacity too small for the window");
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;

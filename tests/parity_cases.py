@@ -112,8 +112,8 @@ def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_ca
     try:
         r, stats = case_erosion_vs_oracle(pkg, t, orc, n, iters, seed=seed)
     finally:
-        t.set_erosion_tuning(window=4096, block_list_capacity=256)
-        t.set_erosion_slice_steps(64)
+        t.set_erosion_tuning(window=0xFFFFFFFF, block_list_capacity=256)
+        t.set_erosion_slice_steps(1024)
     assert r.windows == -(-iters // window)
     return r, stats
 
