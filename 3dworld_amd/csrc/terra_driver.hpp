@@ -28,6 +28,7 @@ struct grid_job_t { // one build_arrays() + eval loop
 	uint32_t nx, ny, nxp, nyp; // padded table row lengths
 	int mode, shape, kstart, glaciate, use_sine_mag;
 	float sine_offset;
+	int plain_only; // sine mode: no cell can leave the short epilogue (see terra_engine::sine_plain_only): the kernel variant without finish_cell() is exact
 };
 
 // noise_gen_3d constants (src/upsurface.h:10-16)
@@ -274,6 +275,15 @@ template<class BE> struct terra_engine {
 
 	// build_arrays + [enable_glaciate] + eval_index over the whole grid, device resident, async
 	// h_minmax (optional): receives {min, max} of the generated grid (NaNs skipped); fused into the grid kernel where the backend can, and SYNCHRONOUS
+	// The sine kernel's short epilogue (glaciate + island term) is the whole of eval_index's tail when the shape is linear, there is no
+	// crack / volcano and no sum can exceed min(plat_bot, crat_h): |sum| <= sum_k |amplitude_k| because |SINF| <= 1 (+ rounding slack).
+	bool sine_plain_only(int shp, int kstart) const {
+		if (shp != 0 || hp.crack_lo < hp.crack_hi || (hp.volcano_width > 0.0f && hp.volcano_height > 0.0f) || consts().custom_glaciate_exp != 0.0f) return false;
+		double bound = 0.0;
+		for (int k = kstart; k < F_TABLE_SIZE; ++k) {bound += std::fabs((double)(mesh_scale_z_inv*sinTable[k][0]));}
+		return (double)min_std(hp.plat_bot, hp.crat_h) > bound*1.001 + 1e-3;
+	}
+
 	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr) {
 		require_scene();
 		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
@@ -286,6 +296,7 @@ template<class BE> struct terra_engine {
 		job.glaciate = (flags & TERRA_GEN_GLACIATE) ? 1 : 0;
 		job.use_sine_mag = (job.glaciate && hp.sine_mag > 0.0f) ? 1 : 0;
 		job.sine_offset = hp.sine_bias*mesh_scale_z_inv;
+		job.plain_only = (job.mode == MGEN_SINE && sine_plain_only(job.shape, job.kstart)) ? 1 : 0;
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
@@ -592,7 +603,7 @@ template<class BE> struct terra_engine {
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_zvals);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_zvals, md == MGEN_SINE && sine_plain_only(shp, kstart));
 		// erosion: every tile alone on its clamp-padded 138x138 copy, droplets in order (src/tiled_mesh.cpp:515)
 		if (iters_tt > 0 && erode_amount > 0.0f) {
 			erosion_consts_t const ec = make_erosion_consts((int)zv, (int)zv, zmin);

@@ -73,7 +73,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		hipLaunchKernelGGL(terra::k_sine_grid<false>, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, terra::sg_tiles_t{nullptr, nullptr, 0, sg_rowgroup});
+		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup};
+		if (job.plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<false, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);}
+		else                {hipLaunchKernelGGL((terra::k_sine_grid<false, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
@@ -92,7 +94,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only)
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
@@ -107,7 +109,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*130; job.ny = nuy*130; job.nxp = nxpv; job.nyp = nypv;
 		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		hipLaunchKernelGGL(terra::k_sine_grid<true>, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, terra::sg_tiles_t{tm, d_m0, nux, sg_rowgroup});
+		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup};
+		job.plain_only = plain_only ? 1 : 0;
+		if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
+		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {

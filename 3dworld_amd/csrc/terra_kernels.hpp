@@ -81,7 +81,9 @@ __device__ __forceinline__ void sg_accumulate(float (&acc)[SG_TY][SG_TX], sg_ope
 	}
 }
 
-template<bool TILES> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
+// GENERAL = false: the host proved that every cell takes the short epilogue (terra_engine::sine_plain_only), so finish_cell() -- 64 inlined
+// copies of the plateau / crater / crack / volcano / powf code, ~340 KB of instructions the hot path would otherwise be threaded through -- is left out
+template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
 	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm, sg_tiles_t tiles)
 {
 	__shared__ __attribute__((aligned(16))) float sX[SG_KC*SG_BX];
@@ -127,7 +129,7 @@ template<bool TILES> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(g
 	// thread's 8 columns / 8 rows loaded once; anything else goes through the general finish_cell().  Same arithmetic either way.
 	bool const vec_ok = ((job.nx & 3u) == 0) && !TILES;
 	hmap_params_t const &hp = nc.hp;
-	bool const plain = (job.shape == 0) && !(hp.crack_lo < hp.crack_hi) && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f);
+	bool const plain = !GENERAL || ((job.shape == 0) && !(hp.crack_lo < hp.crack_hi) && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f));
 	float const pp_limit = min_std(hp.plat_bot, hp.crat_h); // below this the post-process is the identity
 	float smxv[SG_TX], smyv[SG_TY];
 #pragma unroll
@@ -147,13 +149,13 @@ template<bool TILES> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(g
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				float z = acc[i][half*4 + j];
-				if (plain && !(z > pp_limit)) {
+				if (!GENERAL || (plain && !(z > pp_limit))) {
 					if (job.glaciate) {
-						if (nc.glaciate) {float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv; z = glaciate_exp_fn(relh, nc.custom_glaciate_exp)*nc.zmax_est2 - nc.zmax_est;}
+						if (nc.glaciate) {float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv; z = (GENERAL ? glaciate_exp_fn(relh, nc.custom_glaciate_exp) : relh*relh*relh)*nc.zmax_est2 - nc.zmax_est;} // !GENERAL: custom_glaciate_exp == 0
 						if (job.use_sine_mag) {z += smxv[half*4 + j]*smyv[i] + job.sine_offset;}
 					}
 				}
-				else if (x + j < job.nx) {
+				else if (GENERAL && x + j < job.nx) {
 					if (TILES) { // general epilogue in tile-local coordinates (volcano term needs the tile's own origin)
 						unsigned const ux = (x + j)/130u, uy = y/130u;
 						grid_job_t jt = job; jt.mx0 = tiles.m0[ux]; jt.my0 = tiles.m0[tiles.nux + uy];
