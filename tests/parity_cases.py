@@ -57,6 +57,29 @@ def case_shapes(pkg, t):
     assert_bit_equal(t.gen_grid(-50, -50, st.DX_VAL, st.DY_VAL, 64, 64, pkg.GEN_GLACIATE), G["shape2_simplex"], "ridged simplex, 8 octaves")
 
 
+def case_sine_epilogue_variants(pkg, t, orc):
+    """the sine kernel has a host-proven short-epilogue variant and a general one: configurations on both sides of that decision
+    (plateau below / barely above / far above the largest possible sum, crater, crack, volcano, custom glaciate exponent, no glaciate)."""
+    base = list(pkg.HMAP_ISLANDS) if hasattr(pkg, "HMAP_ISLANDS") else [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 0, 0]
+    def hm(**kw):
+        names = ["plat_bot", "plat_h", "plat_s", "plat_max", "crat_h", "crat_s", "crack_lo", "crack_hi", "crack_d", "sine_mag", "sine_freq", "sine_bias", "volcano_width", "volcano_height"]
+        v = list(base)
+        for k, x in kw.items():
+            v[names.index(k)] = x
+        return v
+    cases = [dict(hmap=hm()), dict(hmap=hm(plat_bot=0.1, plat_h=0.5, plat_s=2.0, plat_max=0.2)), dict(hmap=hm(crat_h=0.3, crat_s=2.0)),
+             dict(hmap=hm(plat_bot=1.2)), dict(hmap=hm(plat_bot=3.0)), dict(hmap=hm(crack_lo=0.0, crack_hi=0.05, crack_d=4.0)),
+             dict(hmap=hm(volcano_width=1200.0, volcano_height=4.0)), dict(hmap=hm(), custom_glaciate_exp=2.5), dict(hmap=hm(), glaciate=0),
+             dict(hmap=hm(sine_mag=0.0)), dict(hmap=hm(plat_bot=0.1, plat_h=0.5), mesh_freq_filter=3)]
+    for kw in cases:
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, **kw)
+        st = t.init_scene(pc_)
+        orc.init(oc)
+        a = orc.gen_grid(-131, 40, st.DX_VAL, st.DY_VAL, 260, 150, 1)
+        b = t.gen_grid(-131, 40, st.DX_VAL, st.DY_VAL, 260, 150, pkg.GEN_GLACIATE)
+        assert_bit_equal(a, b, f"sine epilogue {kw}")
+
+
 def case_grid_vs_oracle(pkg, t, orc, mode, n, min_start_sin=0, force_sine=False):
     """larger grids against the oracle (bit-exact), incl. min_start_sin and force_sine_mode."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=mode)

@@ -29,6 +29,10 @@ def test_grid_vs_oracle(pkg, gpu, orc, mode, n, mss, force):
     pc.case_grid_vs_oracle(pkg, gpu, orc, mode, n, mss, force)
 
 
+def test_sine_epilogue_variants(pkg, gpu, orc):
+    pc.case_sine_epilogue_variants(pkg, gpu, orc)
+
+
 def test_erosion_golden(pkg, gpu):
     pc.case_erosion_golden(pkg, gpu)
 

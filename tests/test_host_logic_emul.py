@@ -20,6 +20,10 @@ def test_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force):
     pc.case_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force)
 
 
+def test_sine_epilogue_variants(pkg, emul, orc):
+    pc.case_sine_epilogue_variants(pkg, emul, orc)
+
+
 def test_erosion_golden(pkg, emul):
     r = pc.case_erosion_golden(pkg, emul)
     assert r.rounds >= 2  # dense case: the fixed point needs re-traces

@@ -103,6 +103,21 @@ def test_oracle_vs_reference_tus(orc, ref):
         assert_bit_equal(np.array([getattr(ref, name)(x, y, z) for x, y, z in pts], np.float32), np.array([getattr(orc, name)(x, y, z) for x, y, z in pts], np.float32), name)
 
 
+def test_oracle_vs_reference_epilogue_configs(orc, ref):
+    """plateau / crater / crack / volcano / custom glaciate exponent in sine mode: the configurations of case_sine_epilogue_variants."""
+    ref.set_num_threads(1)
+    base = list(orclib.HMAP_ISLANDS)
+    variants = [{}, {0: 0.1, 1: 0.5, 2: 2.0, 3: 0.2}, {4: 0.3, 5: 2.0}, {0: 1.2}, {0: 3.0}, {6: 0.0, 7: 0.05, 8: 4.0}, {12: 1200.0, 13: 4.0}, {9: 0.0}]
+    for v in variants:
+        hm = list(base)
+        for i, x in v.items():
+            hm[i] = x
+        for extra in ({}, {"custom_glaciate_exp": 2.5}, {"glaciate": 0}):
+            cfg = orclib.make_config(mesh_gen_mode=0, hmap=hm, **extra)
+            sr, so = ref.init(cfg), orc.init(cfg)
+            assert_bit_equal(ref.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), orc.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), f"{v} {extra}")
+
+
 def test_libm_sincosf_is_not_correctly_rounded_but_reproducible():
     """The droplet's random-direction branch calls libm cosf/sinf on a = rand_float()*TWO_PI (src/erosion.cpp:80-83).
     glibc's sinf/cosf are not correctly rounded, which is why 3dworld_amd/csrc/terra_sincosf.hpp restates their algorithm
