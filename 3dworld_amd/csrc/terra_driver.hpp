@@ -306,9 +306,10 @@ template<class BE> struct terra_engine {
 		if (job.use_sine_mag) { // enable_glaciate (src/mesh_gen.cpp:640-650)
 			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
 			float const mx0 = job.mx0, my0 = job.my0, mdx = dx, mdy = dy;
-			be.launch((size_t)nx + ny, [=] TERRA_LAMBDA (size_t i) {
-				if (i < nx) {smx[i] = sm_scale*L.COSF(((float)(unsigned)i*mdx + mx0)*dxi*freq);}
-				else {unsigned const y = (unsigned)(i - nx); smy[y] = L.COSF(((float)y*mdy + my0)*dyi*freq);}
+			uint32_t const nxp = job.nxp, nyp = job.nyp; // zero padding up to the tile grid: the sine kernel reads whole float4 groups
+			be.launch((size_t)nxp + nyp, [=] TERRA_LAMBDA (size_t i) {
+				if (i < nxp) {smx[i] = (i < nx) ? sm_scale*L.COSF(((float)(unsigned)i*mdx + mx0)*dxi*freq) : 0.0f;}
+				else {unsigned const y = (unsigned)(i - nxp); smy[y] = (y < ny) ? L.COSF(((float)y*mdy + my0)*dyi*freq) : 0.0f;}
 			});
 		}
 		if (job.mode == MGEN_SINE) {

@@ -64,6 +64,7 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 
 struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup;};
 
+typedef float sg_v2f __attribute__((ext_vector_type(2)));
 struct sg_operands_t {float4 xa, xb, ya, yb;};
 __device__ __forceinline__ sg_operands_t sg_load(float const *px, float const *py, int k) {
 	sg_operands_t o;
@@ -71,14 +72,28 @@ __device__ __forceinline__ sg_operands_t sg_load(float const *px, float const *p
 	o.ya = *(float4 const *)(py + k*SG_BY); o.yb = *(float4 const *)(py + k*SG_BY + 64);
 	return o;
 }
-__device__ __forceinline__ void sg_accumulate(float (&acc)[SG_TY][SG_TX], sg_operands_t const &o) {
-	float const xs[SG_TX] = {o.xa.x, o.xa.y, o.xa.z, o.xa.w, o.xb.x, o.xb.y, o.xb.z, o.xb.w};
-	float const ys[SG_TY] = {o.ya.x, o.ya.y, o.ya.z, o.ya.w, o.yb.x, o.yb.y, o.yb.z, o.yb.w};
+// Two rows x eight columns per call: r0[jp] += {x0*y0, x1*y0}, r1[jp] += {x0*y1, x1*y1} with (y0,y1) = one register pair straight from ds_read_b128.
+// v_pk_mul_f32 broadcasts the row's y from either half of the pair through op_sel, so no operand is ever copied (the compiler's own selection
+// moves half of the broadcast operands into fresh registers every step), and the mul/mul/add/add order keeps one independent instruction
+// between each product and the add that consumes it (no hazard nops).  Product rounded by v_pk_mul, then added by v_pk_add: never fused.
+__device__ __forceinline__ void sg_mul_add_2x8(sg_v2f (&r0)[SG_TX/2], sg_v2f (&r1)[SG_TX/2], sg_v2f const (&xp)[4], sg_v2f yp) {
+	sg_v2f t0, t1;
+#define TERRA_SG_2X2(A0, A1, X) \
+	"v_pk_mul_f32 %8, " X ", %13 op_sel:[0,0] op_sel_hi:[1,0]\n\t" \
+	"v_pk_mul_f32 %9, " X ", %13 op_sel:[0,1] op_sel_hi:[1,1]\n\t" \
+	"v_pk_add_f32 " A0 ", " A0 ", %8\n\t" \
+	"v_pk_add_f32 " A1 ", " A1 ", %9\n\t"
+	asm(TERRA_SG_2X2("%0", "%4", "%10") TERRA_SG_2X2("%1", "%5", "%11") TERRA_SG_2X2("%2", "%6", "%12") TERRA_SG_2X2("%3", "%7", "%14")
+	    : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]), "=&v"(t0), "=&v"(t1)
+	    : "v"(xp[0]), "v"(xp[1]), "v"(xp[2]), "v"(yp), "v"(xp[3]));
+#undef TERRA_SG_2X2
+}
+// acc[i][jp] holds cells (row i, columns 2*jp, 2*jp+1) of the thread's 8 x 8 patch
+__device__ __forceinline__ void sg_accumulate(sg_v2f (&acc)[SG_TY][SG_TX/2], sg_operands_t const &o) {
+	sg_v2f const xp[4] = {{o.xa.x, o.xa.y}, {o.xa.z, o.xa.w}, {o.xb.x, o.xb.y}, {o.xb.z, o.xb.w}};
+	sg_v2f const yp[4] = {{o.ya.x, o.ya.y}, {o.ya.z, o.ya.w}, {o.yb.x, o.yb.y}, {o.yb.z, o.yb.w}};
 #pragma unroll
-	for (int i = 0; i < SG_TY; ++i) {
-#pragma unroll
-		for (int j = 0; j < SG_TX; ++j) {acc[i][j] = __fadd_rn(acc[i][j], __fmul_rn(xs[j], ys[i]));} // zval += xptr[k]*yptr[k]: product rounded, then added
-	}
+	for (int ip = 0; ip < 4; ++ip) {sg_mul_add_2x8(acc[2*ip], acc[2*ip + 1], xp, yp[ip]);}
 }
 
 // GENERAL = false: the host proved that every cell takes the short epilogue (terra_engine::sine_plain_only), so finish_cell() -- 64 inlined
@@ -86,8 +101,8 @@ __device__ __forceinline__ void sg_accumulate(float (&acc)[SG_TY][SG_TX], sg_ope
 template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
 	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm, sg_tiles_t tiles)
 {
-	__shared__ __attribute__((aligned(16))) float sX[SG_KC*SG_BX];
-	__shared__ __attribute__((aligned(16))) float sY[SG_KC*SG_BY];
+	__shared__ __attribute__((aligned(16))) float sX[(SG_KC + 2)*SG_BX];
+	__shared__ __attribute__((aligned(16))) float sY[(SG_KC + 2)*SG_BY];
 	unsigned bxi, byi;
 	if (!sg_tile_of_block(blockIdx.x, ntx, nty, tiles.rowgroup, bxi, byi)) return;
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu; // fused min(vals)/max(vals) (heightmap_t::run_erosion, get_heightmap_z_range): saves a 4 B/cell read pass
@@ -96,11 +111,11 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 	// thread (tx,ty) owns columns {tx*4..+3} u {64+tx*4..+3} and rows {ty*4..+3} u {64+ty*4..+3}: every LDS read is one aligned ds_read_b128,
 	// 16 distinct 16-byte slots per 16-lane group for X (conflict-free) and a broadcast for Y
 	float const *px = sX + tx*4, *py = sY + ty*4;
-	float acc[SG_TY][SG_TX];
+	sg_v2f acc[SG_TY][SG_TX/2];
 #pragma unroll
 	for (int i = 0; i < SG_TY; ++i) {
 #pragma unroll
-		for (int j = 0; j < SG_TX; ++j) {acc[i][j] = 0.0f;}
+		for (int jp = 0; jp < SG_TX/2; ++jp) {acc[i][jp] = sg_v2f{0.0f, 0.0f};}
 	}
 	int const nk = F_TABLE_SIZE - job.kstart, nchunks = (nk + SG_KC - 1)/SG_KC, per_chunk = (nk + nchunks - 1)/nchunks;
 	for (int c = 0; c < nchunks; ++c) { // terms are summed in k order across chunks, exactly like the CPU loop
@@ -112,22 +127,64 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 			*(float4 *)&sY[k*SG_BY + q*4] = *(float4 const *)&yt[(size_t)(k0 + k)*job.nyp + by0 + q*4];
 		}
 		__syncthreads();
-		// two operand sets in ping-pong: the loads of step k+1 are in flight while step k is accumulated, without register copies
-		sg_operands_t A = sg_load(px, py, 0), B;
+		// two operand sets in ping-pong.  A set is reloaded right AFTER its accumulate (the scheduling barrier keeps the compiler from hoisting
+		// the loads above it), so the new values can land in the same registers -- no copies at the loop back-edge -- and have the other
+		// set's 128 packed instructions (~512 cycles) to arrive from LDS.
+		sg_operands_t A = sg_load(px, py, 0), B = sg_load(px, py, 1); // rows kn, kn+1 may be read but are never used (SG_KC + 2 rows are allocated)
 		int k = 0;
-		for (; k + 2 < kn; k += 2) {
-			B = sg_load(px, py, k + 1);
-			sg_accumulate(acc, A);
-			A = sg_load(px, py, k + 2);
-			sg_accumulate(acc, B);
+		for (; k + 1 < kn; k += 2) {
+			sg_accumulate(acc, A); __builtin_amdgcn_sched_barrier(0); A = sg_load(px, py, k + 2);
+			sg_accumulate(acc, B); __builtin_amdgcn_sched_barrier(0); B = sg_load(px, py, k + 3);
 		}
-		if (k + 1 < kn) {B = sg_load(px, py, k + 1); sg_accumulate(acc, A); sg_accumulate(acc, B);}
-		else {sg_accumulate(acc, A);}
+		if (k < kn) {sg_accumulate(acc, A);}
 	}
 	// ---- epilogue (eval_index's tail, src/mesh_gen.cpp:781-790): shape / post-process, glaciate, sine-mag islands, volcano.
 	// The common configuration (linear shape, no plateau/crater/crack, no volcano) takes a short path with the island terms of the
 	// thread's 8 columns / 8 rows loaded once; anything else goes through the general finish_cell().  Same arithmetic either way.
 	bool const vec_ok = ((job.nx & 3u) == 0) && !TILES;
+	if (!GENERAL && !TILES && vec_ok) {
+		// the common case, two cells per instruction (v_pk_mul_f32 / v_pk_add_f32): the island tables are zero-padded to the tile grid, rows of 4 cells
+		// are either wholly inside the grid or wholly outside
+		typedef sg_v2f v2f;
+		bool const gl = job.glaciate && nc.glaciate, sm = job.glaciate && job.use_sine_mag;
+		float4 sx[2], sy[2];
+		sx[0] = sx[1] = sy[0] = sy[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (sm) {
+			sx[0] = *(float4 const *)(smx + bx0 + tx*4); sx[1] = *(float4 const *)(smx + bx0 + 64 + tx*4);
+			sy[0] = *(float4 const *)(smy + by0 + ty*4); sy[1] = *(float4 const *)(smy + by0 + 64 + ty*4);
+		}
+		v2f const zme = {nc.zmax_est, nc.zmax_est}, inv = {nc.zmax_est2_inv, nc.zmax_est2_inv}, z2 = {nc.zmax_est2, nc.zmax_est2}, off = {job.sine_offset, job.sine_offset};
+		float fmn = INFINITY, fmx = -INFINITY;
+#pragma unroll
+		for (int i = 0; i < SG_TY; ++i) {
+			unsigned const y = by0 + (i >> 2)*64 + ty*4 + (i & 3);
+			if (y >= job.ny) continue;
+			float const syq[4] = {sy[i >> 2].x, sy[i >> 2].y, sy[i >> 2].z, sy[i >> 2].w};
+			v2f const syi = {syq[i & 3], syq[i & 3]};
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {
+				unsigned const x = bx0 + half*64 + tx*4;
+				if (x >= job.nx) continue;
+				v2f z01 = acc[i][half*2], z23 = acc[i][half*2 + 1];
+				if (gl) {
+					v2f const r01 = (z01 + zme)*inv, r23 = (z23 + zme)*inv;
+					z01 = ((r01*r01)*r01)*z2 - zme; z23 = ((r23*r23)*r23)*z2 - zme;
+				}
+				if (sm) {
+					v2f const s01 = {sx[half].x, sx[half].y}, s23 = {sx[half].z, sx[half].w};
+					z01 = z01 + (s01*syi + off); z23 = z23 + (s23*syi + off);
+				}
+				fmn = fminf(fminf(fmn, z01.x), fminf(z01.y, fminf(z23.x, z23.y)));
+				fmx = fmaxf(fmaxf(fmx, z01.x), fmaxf(z01.y, fmaxf(z23.x, z23.y)));
+				*(float4 *)(out + (size_t)y*job.nx + x) = make_float4(z01.x, z01.y, z23.x, z23.y);
+			}
+		}
+		if (mm) {
+			if (fmn <= fmx) {mm_lo = f2ord(fmn); mm_hi = ~f2ord(fmx);}
+			wave_minmax_publish(mm_lo, mm_hi, mm);
+		}
+		return;
+	}
 	hmap_params_t const &hp = nc.hp;
 	bool const plain = !GENERAL || ((job.shape == 0) && !(hp.crack_lo < hp.crack_hi) && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f));
 	float const pp_limit = min_std(hp.plat_bot, hp.crat_h); // below this the post-process is the identity
@@ -148,7 +205,7 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 			float v[4];
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
-				float z = acc[i][half*4 + j];
+				float z = acc[i][half*2 + (j >> 1)][j & 1];
 				if (!GENERAL || (plain && !(z > pp_limit))) {
 					if (job.glaciate) {
 						if (nc.glaciate) {float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv; z = (GENERAL ? glaciate_exp_fn(relh, nc.custom_glaciate_exp) : relh*relh*relh)*nc.zmax_est2 - nc.zmax_est;} // !GENERAL: custom_glaciate_exp == 0

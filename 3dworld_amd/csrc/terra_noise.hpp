@@ -9,6 +9,7 @@
 // One thread evaluates one cell; there is no cross-lane traffic in these functions.
 #pragma once
 #include "terra_common.hpp"
+#include "terra_powf.hpp"
 
 namespace terra {
 
@@ -231,7 +232,8 @@ template<int MODE> TERRA_HD float noise_zval(float xval, float yval, int shape, 
 }
 
 // ---- glaciate + islands + volcano epilogue of eval_index (src/mesh_gen.cpp:358-385,782-790)
-TERRA_HD float glaciate_exp_fn(float v, float custom_exp) {return (custom_exp == 0.0f) ? v*v*v : powf(v, custom_exp);}
+// pow(val, custom_glaciate_exp) is libm's powf in the reference (float arguments): reproduced bit for bit by terra_powf.hpp
+TERRA_HD float glaciate_exp_fn(float v, float custom_exp) {return (custom_exp == 0.0f) ? v*v*v : glibc_powf(v, custom_exp);}
 
 TERRA_HD float volcano_height(float xi, float yi, noise_consts_t const &nc, sin_lut_t const &lut) { // src/mesh_gen.cpp:364-371
 	float const freq = nc.mesh_scale/nc.hp.volcano_width, x = freq*xi, y = freq*yi, dist = sqrtf(x*x + y*y);

@@ -64,3 +64,18 @@ typedef cpu_backend_t terra_backend_t;
 #ifdef TERRA_INSTR
 extern "C" unsigned long long *terra_emul_counters() {return terra::g_cnt;}
 #endif
+
+// glibc_powf (terra_powf.hpp) against the build host's libm over n pseudo-random arguments: [0,2) ^ {typical exponents}, then raw bit patterns
+extern "C" unsigned long long terra_emul_powf_mismatches(unsigned long long n, uint32_t seed) {
+	unsigned long long bad = 0;
+	auto rnd = [&]() {seed = seed*1664525u + 1013904223u; return seed;};
+	float const exps[] = {2.5f, 0.5f, 1.7f, 3.3f, 0.01f, 7.9f, -1.5f, 2.0f, 3.0f, 1.0f};
+	for (unsigned long long i = 0; i < n; ++i) {
+		float x, y;
+		if (i & 1) {x = (float)(rnd() >> 8)*(1.0f/16777216.0f)*2.0f; y = exps[(i >> 1) % 10];}
+		else {uint32_t const ux = rnd(), uy = rnd(); memcpy(&x, &ux, 4); memcpy(&y, &uy, 4); if (i & 2) {y = (float)((int)(rnd() % 41) - 20)*0.5f;}}
+		float const a = powf(x, y), b = terra::glibc_powf(x, y);
+		if (memcmp(&a, &b, 4) != 0 && !(a != a && b != b)) {++bad;}
+	}
+	return bad;
+}

@@ -69,7 +69,7 @@ def case_sine_epilogue_variants(pkg, t, orc):
         return v
     cases = [dict(hmap=hm()), dict(hmap=hm(plat_bot=0.1, plat_h=0.5, plat_s=2.0, plat_max=0.2)), dict(hmap=hm(crat_h=0.3, crat_s=2.0)),
              dict(hmap=hm(plat_bot=1.2)), dict(hmap=hm(plat_bot=3.0)), dict(hmap=hm(crack_lo=0.0, crack_hi=0.05, crack_d=4.0)),
-             dict(hmap=hm(volcano_width=1200.0, volcano_height=4.0)), dict(hmap=hm(), custom_glaciate_exp=2.5), dict(hmap=hm(), glaciate=0),
+             dict(hmap=hm(volcano_width=1200.0, volcano_height=4.0)), dict(hmap=hm(), custom_glaciate_exp=2.5), dict(hmap=hm(), custom_glaciate_exp=0.7), dict(hmap=hm(plat_bot=0.1, plat_h=0.5), custom_glaciate_exp=3.3), dict(hmap=hm(), glaciate=0),
              dict(hmap=hm(sine_mag=0.0)), dict(hmap=hm(plat_bot=0.1, plat_h=0.5), mesh_freq_filter=3)]
     for kw in cases:
         pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, **kw)

@@ -20,6 +20,16 @@ def test_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force):
     pc.case_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force)
 
 
+def test_powf_restatement_matches_libm(emul_lib):
+    """glaciate's pow(relh, custom_glaciate_exp) is libm powf in the reference; 3dworld_amd/csrc/terra_powf.hpp restates glibc's algorithm so the
+    device gets the same bits (ocml powf does not).  4*10^6 arguments here, 5*10^7 when the header was written."""
+    import ctypes
+    lib = ctypes.CDLL(emul_lib)
+    lib.terra_emul_powf_mismatches.restype = ctypes.c_ulonglong
+    lib.terra_emul_powf_mismatches.argtypes = [ctypes.c_ulonglong, ctypes.c_uint32]
+    assert lib.terra_emul_powf_mismatches(4000000, 2024) == 0
+
+
 def test_sine_epilogue_variants(pkg, emul, orc):
     pc.case_sine_epilogue_variants(pkg, emul, orc)
 
