@@ -95,14 +95,16 @@ template<class BE> struct terra_engine {
 
 	// grow-only device scratch
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
-	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_tiles, s_vox, s_sk, s_mm;
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_vox, s_sk, s_mm;
+	uint32_t *spec_blocks_clean = nullptr; size_t spec_blocks_n = 0; // s_spec_blocks is known to be all-NIL for this pointer / block count
+	uint8_t *spec_logs_base = nullptr; uint32_t spec_logs_w = 0, spec_logs_cap = 0; // the log tables in s_spec satisfy their invariant for this layout
 	template<class T> T *scratch(scratch_t &s, size_t count) {
 		size_t const bytes = std::max<size_t>(count*sizeof(T), 256);
 		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
 		return (T *)s.p;
 	}
 	~terra_engine() {
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_tiles, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 	}
 
@@ -469,16 +471,19 @@ template<class BE> struct terra_engine {
 		// carve one allocation
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
-		size_t o_keys[2], o_vals[2], o_bl[2], o_bc[2], o_chk[2];
-		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(W*cap*4); o_vals[b] = carve(W*cap*4); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
+		size_t o_keys[2], o_vals[2], o_used[2], o_lc[2], o_bl[2], o_bc[2], o_chk[2];
+		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(W*cap*4); o_lc[b] = carve(W*4);} // keys + counts first: they carry state from run to run
+		size_t const persistent_bytes = off;
+		for (int b = 0; b < 2; ++b) {o_vals[b] = carve(W*cap*4); o_used[b] = carve(W*cap*4); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
 		size_t const o_slot = carve((size_t)W*4*9); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps
 		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
-		size_t const o_head = carve(nblocks*4), o_next = carve((size_t)W*sb.maxb*4), o_dirty = carve(nblocks*4), o_ctl = carve(sizeof(spec_ctl_t));
+		size_t const o_next = carve((size_t)W*sb.maxb*4), o_nodeblk = carve((size_t)W*sb.maxb*4), o_dlist = carve((size_t)W*sb.maxb*8), o_ctl = carve(sizeof(spec_ctl_t));
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
 		size_t const o_touched = carve((size_t)touched_cap*4 + 4);
 		uint8_t *base = scratch<uint8_t>(s_spec, off);
 		for (int b = 0; b < 2; ++b) {
 			sb.log_keys[b] = (uint32_t *)(base + o_keys[b]); sb.log_vals[b] = (float *)(base + o_vals[b]);
+			sb.log_used[b] = (uint32_t *)(base + o_used[b]); sb.log_cnt[b] = (uint32_t *)(base + o_lc[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]); sb.chk[b] = (uint64_t *)(base + o_chk[b]);
 		}
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
@@ -486,12 +491,25 @@ template<class BE> struct terra_engine {
 		sb.restart = slot_arrays + 5*(size_t)W; sb.run_nblk = slot_arrays + 6*(size_t)W; sb.flags = slot_arrays + 7*(size_t)W; sb.nsteps = slot_arrays + 8*(size_t)W;
 		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
-		sb.head = (uint32_t *)(base + o_head); sb.next = (uint32_t *)(base + o_next); sb.dirty_min = (uint32_t *)(base + o_dirty); sb.ctl = (spec_ctl_t *)(base + o_ctl);
+		sb.next = (uint32_t *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.ctl = (spec_ctl_t *)(base + o_ctl);
+		// block -> list head and block -> dirty mark: one entry per 8x8 block of the padded grid.  Every run resets exactly the entries it set
+		// (spec_unlink_body / spec_undirty_body), so the O(grid) fill is paid only when the arrays are (re)allocated or the grid shape changes.
+		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks);
+		sb.head = blk_arrays; sb.dirty_min = blk_arrays + nblocks;
+		if (spec_blocks_clean != blk_arrays || spec_blocks_n != nblocks) {be.fill32(blk_arrays, SPEC_NIL, 2*nblocks);}
+		spec_blocks_clean = nullptr; // not clean again until this run has taken its lists apart
+		// log tables: empty except at the positions listed in log_used[0 .. log_cnt) -- an invariant every kernel keeps, so only a fresh (or
+		// re-shaped) allocation pays the O(slots x capacity) initialisation
+		if (spec_logs_base != base || spec_logs_w != W || spec_logs_cap != sb.cap_log2) {
+			for (int b = 0; b < 2; ++b) {be.fill32(sb.log_keys[b], SPEC_EMPTY, (size_t)W*cap); be.fill32(sb.log_cnt[b], 0, W);}
+		}
+		(void)persistent_bytes;
+		spec_logs_base = nullptr;
 
 		spec_buffers_t const s = sb;
 		be.fill32(slot_arrays, 0, (size_t)W*9);
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
-		be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks); be.fill32(sb.head, SPEC_NIL, nblocks);
+		be.fill32(sb.node_blk, SPEC_NIL, (size_t)W*sb.maxb);
 		be.launch(W, [=] TERRA_LAMBDA (size_t i) { // the first W droplets take the slots (num_iters >= W)
 			s.it[i] = (uint32_t)i; s.phase[i] = SPEC_FRESH;
 			if (i == 0) {spec_ctl_t c{}; c.base = 0; c.new_base = s.W; c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; *s.ctl = c;}
@@ -504,18 +522,26 @@ template<class BE> struct terra_engine {
 			if (round >= spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
 			++report.rounds;
 			uint32_t const budget = ((uint64_t)host_base + W >= num_iters) ? DROPLET_NO_BUDGET : slice; // nobody is waiting for a slot: run to the end
-			be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_clear_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
-			be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, budget, ws);});
-			be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-			be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s, (uint32_t)i);});
-			be.fill32(sb.head, SPEC_NIL, nblocks);
-			be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-			be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-			be.fill32(sb.dirty_min, 0xFFFFFFFFu, nblocks);
-			be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_scan_body(s, (uint32_t)i);});
-			be.launch((size_t)W*cap, [=] TERRA_LAMBDA (size_t i) {spec_flush_body(s, (uint32_t)(i >> s.cap_log2), (uint32_t)(i & ((1u << s.cap_log2) - 1)));});
-			be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
-			be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
+			// the round is a fixed sequence of 11 small dependent launches: captured into a hipGraph once per (buffers, budget) and replayed
+			struct {spec_buffers_t s; uint32_t budget; uint32_t tag;} gkey;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.budget = budget; gkey.tag = 0x524e4431u;
+			if (!be.graph_replay(&gkey, sizeof(gkey))) {
+				bool const cap = be.graph_begin();
+				try {
+					be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, budget, ws);});
+					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s, (uint32_t)i);});
+					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);});
+					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+					be.launch((size_t)W*sb.maxb*2, [=] TERRA_LAMBDA (size_t i) {spec_undirty_body(s, (uint32_t)i);});
+					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_scan_body(s, (uint32_t)i);});
+					be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_flush_wave(s, (uint32_t)i);});
+					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
+					be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
+				} catch (...) {be.graph_abort(); throw;}
+				if (cap) {be.graph_end(&gkey, sizeof(gkey));}
+			}
 			be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of the round
 			host_base = hc.base;
 			if (host_base < num_iters && hc.stop_at == host_base) { // the lowest uncommitted droplet overflowed its log / block list: it runs alone, directly on the grid
@@ -529,6 +555,9 @@ template<class BE> struct terra_engine {
 				++report.serial_fallbacks; ++host_base;
 			}
 		}
+		be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);}); // leave head[] all-NIL (dirty_min[] already is)
+		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
+		spec_logs_base = base; spec_logs_w = W; spec_logs_cap = sb.cap_log2;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		if (!record_touched) return false;

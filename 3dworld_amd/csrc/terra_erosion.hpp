@@ -415,6 +415,8 @@ constexpr uint32_t SPEC_BLK_WRITTEN = 0x80000000u; // block-list entry flag: the
 // block list and waits to become the lowest uncommitted droplet, which then runs alone directly on the grid.
 enum {SPEC_IDLE = 0, SPEC_FRESH = 1, SPEC_RUNNING = 2, SPEC_DONE_NEW = 3, SPEC_FAILED = 4};
 
+struct alignas(16) spec_u32x4 {uint32_t x, y, z, w;};
+
 struct spec_ctl_t { // device-resident control block: a round needs no host decision
 	uint32_t base;         // lowest uncommitted droplet
 	uint32_t new_base;     // commit scan: lowest droplet that is not committable
@@ -425,7 +427,8 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t nan_droplets; // committed droplets that went NaN
 	uint32_t touched;      // cells recorded for the sparse clamp (may exceed the capacity)
 	uint32_t fb_steps, fb_nan; // fall-back droplet
-	uint32_t pad_[2];
+	uint32_t ndirty;       // entries of dirty_list
+	uint32_t pad_;
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
 };
 struct spec_resume_t {uint32_t nblk, nlog, flags, bc[4], be[4], bwmask, far_last; int own_x0, own_z0, own_x1, own_z1; unsigned long long chk;}; // spec_back_t state of a suspended trace
@@ -441,6 +444,8 @@ struct spec_buffers_t {
 	uint32_t nbx, nby;     // blocks per row / column of the padded grid
 	uint32_t *log_keys[2]; // [W][cap]
 	float    *log_vals[2]; // [W][cap]
+	uint32_t *log_used[2]; // [W][cap] hash positions in insertion order: clearing and flushing a log cost O(entries), not O(capacity)
+	uint32_t *log_cnt[2];  // [W] entries of log_used; invariant between kernels: a buffer's keys are SPEC_EMPTY except at its listed positions
 	uint32_t *blk_list[2]; // [W][maxb]
 	uint32_t *blk_cnt[2];  // [W]
 	uint64_t *chk[2];      // [W] checksum of the version's final log content (+ step count)
@@ -458,6 +463,8 @@ struct spec_buffers_t {
 	uint32_t *head;        // [nbx*nby] block -> first node
 	uint32_t *next;        // [W*maxb]  node -> next node ; node id = slot*maxb + entry
 	uint32_t *dirty_min;   // [nbx*nby] lowest droplet whose published version changed in a way that touches the block, this round
+	uint32_t *node_blk;    // [W*maxb]  block a node is currently linked under (SPEC_NIL: not linked): head[] is reset through it, not by an O(grid) fill
+	uint32_t *dirty_list;  // [2*W*maxb] blocks whose dirty_min was lowered this round (duplicates allowed), ctl->ndirty entries
 	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp)
 	uint32_t touched_cap;
 	spec_ctl_t *ctl;
@@ -497,7 +504,7 @@ struct spec_back_t {
 	spec_buffers_t const *sb;
 	wave_shared_t *sh;     // LDS
 	uint32_t slot, iter;
-	uint32_t *my_keys; float *my_vals; uint32_t *my_blks; // the version being built (buffer 1 - cur)
+	uint32_t *my_keys; float *my_vals; uint32_t *my_blks, *my_used; // the version being built (buffer 1 - cur)
 	uint32_t nblk;
 	// the four most recently recorded brush-box blocks with their list entries (plain registers: an indexed array would live in scratch memory);
 	// bit k of bwmask: cache position k was written to since it entered the cache
@@ -513,6 +520,7 @@ struct spec_back_t {
 		my_keys = sb->log_keys[nb] + (size_t)slot*cap;
 		my_vals = sb->log_vals[nb] + (size_t)slot*cap;
 		my_blks = sb->blk_list[nb] + (size_t)slot*sb->maxb;
+		my_used = sb->log_used[nb] + (size_t)slot*cap;
 		nblk = 0; bc0 = bc1 = bc2 = bc3 = SPEC_NIL; be0 = be1 = be2 = be3 = 0; bwmask = 0; far_last = SPEC_NIL;
 		blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
 		own_x0 = own_z0 = INT_MAX; own_x1 = own_z1 = INT_MIN;
@@ -637,7 +645,9 @@ struct spec_back_t {
 				if (k == SPEC_EMPTY) {
 					my_vals[h] = val;
 					TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)spec_term(cell, val));
-					if (TERRA_ATOMIC_ADD(&sh->nlog, 1u) >= limit) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);}
+					uint32_t const idx = TERRA_ATOMIC_ADD(&sh->nlog, 1u);
+					my_used[idx] = h; // idx < capacity: one entry per occupied slot of the table
+					if (idx >= limit) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);}
 					return;
 				}
 			}
@@ -674,6 +684,13 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	droplet_state_t d;
 	bool finished = false;
 	if (ph == SPEC_FRESH) {
+		{ // a trace starts with an empty version buffer: remove what the buffer's previous trace (abandoned, superseded or committed) left
+			uint32_t const nbuf = 1u - sb.cur[slot], cnt = sb.log_cnt[nbuf][slot];
+			uint32_t *keys = sb.log_keys[nbuf] + ((size_t)slot << sb.cap_log2);
+			uint32_t const *used = sb.log_used[nbuf] + ((size_t)slot << sb.cap_log2);
+			TERRA_LANES(e, cnt) {keys[used[e]] = SPEC_EMPTY;}
+			TERRA_WAVE_SYNC();
+		}
 		mem.back.init(&sb, slot, iter, ws.sh, nullptr);
 		finished = !droplet_start((int)iter, mem, sb.ec, d);
 	}
@@ -690,6 +707,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
 		bool const failed = (fl & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) != 0;
 		sb.run_nblk[slot] = mem.back.nblk;
+		sb.log_cnt[nb][slot] = ws.sh->nlog;
 		if (finished || failed) {
 			uint64_t const chk = (uint64_t)ws.sh->chk ^ ((uint64_t)d.numMoves << 40);
 			sb.blk_cnt[nb][slot] = mem.back.nblk;
@@ -723,12 +741,12 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 
 // ---- per-logical-thread bodies of the bookkeeping kernels (one round = clear, trace, post, flip, link, mark, scan, flush, admit, advance)
 
-// empty the version buffer of every droplet that starts a trace this round: one thread per (slot, log entry)
-TERRA_HD void spec_clear_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	uint32_t iter;
-	if (!spec_slot_active(sb, slot, iter) || sb.phase[slot] != SPEC_FRESH) return;
-	uint32_t const nb = 1u - sb.cur[slot];
-	sb.log_keys[nb][((size_t)slot << sb.cap_log2) + entry] = SPEC_EMPTY;
+TERRA_HD void spec_dirty(spec_buffers_t const &sb, uint32_t blk, uint32_t iter) { // remember the block so that spec_undirty_body can reset it (no O(grid) fill)
+	TERRA_ATOMIC_MIN(&sb.dirty_min[blk], iter);
+	sb.dirty_list[TERRA_ATOMIC_ADD(&sb.ctl->ndirty, 1u)] = blk;
+}
+TERRA_HD void spec_undirty_body(spec_buffers_t const &sb, uint32_t i) {
+	if (i < sb.ctl->ndirty) {sb.dirty_min[sb.dirty_list[i]] = SPEC_NIL;}
 }
 // a version finished this round and differs from the published one: its old and new footprints are dirty for every higher droplet.
 // One thread per (slot, block-list entry).
@@ -738,11 +756,11 @@ TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, uint32_t e
 	uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 	if (sb.has_ver[slot] && entry < sb.blk_cnt[ob][slot]) {
 		uint32_t const e = sb.blk_list[ob][(size_t)slot*sb.maxb + entry];
-		if (e & SPEC_BLK_WRITTEN) {TERRA_ATOMIC_MIN(&sb.dirty_min[e & ~SPEC_BLK_WRITTEN], iter);} // only written blocks can invalidate a reader
+		if (e & SPEC_BLK_WRITTEN) {spec_dirty(sb, e & ~SPEC_BLK_WRITTEN, iter);} // only written blocks can invalidate a reader
 	}
 	if (entry < sb.blk_cnt[nb][slot]) {
 		uint32_t const e = sb.blk_list[nb][(size_t)slot*sb.maxb + entry];
-		if (e & SPEC_BLK_WRITTEN) {TERRA_ATOMIC_MIN(&sb.dirty_min[e & ~SPEC_BLK_WRITTEN], iter);}
+		if (e & SPEC_BLK_WRITTEN) {spec_dirty(sb, e & ~SPEC_BLK_WRITTEN, iter);}
 	}
 }
 // publish the versions finished this round
@@ -757,8 +775,14 @@ TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t e
 	if (entry >= sb.blk_cnt[cb][slot]) return;
 	uint32_t const e = sb.blk_list[cb][(size_t)slot*sb.maxb + entry];
 	if (!(e & SPEC_BLK_WRITTEN)) return; // the lists answer "who wrote here": read-only entries stay out
-	uint32_t const node = slot*sb.maxb + entry;
-	sb.next[node] = TERRA_ATOMIC_EXCH(&sb.head[e & ~SPEC_BLK_WRITTEN], node);
+	uint32_t const node = slot*sb.maxb + entry, b = e & ~SPEC_BLK_WRITTEN;
+	sb.node_blk[node] = b;
+	sb.next[node] = TERRA_ATOMIC_EXCH(&sb.head[b], node);
+}
+// take the lists apart again (before they are rebuilt, and at the end of the run: head[] is left all-NIL for the next run)
+TERRA_HD void spec_unlink_body(spec_buffers_t const &sb, uint32_t node) {
+	uint32_t const b = sb.node_blk[node];
+	if (b != SPEC_NIL) {sb.head[b] = SPEC_NIL; sb.node_blk[node] = SPEC_NIL;}
 }
 // who must start over: any droplet whose footprint (so far) contains a block dirtied by a lower droplet.  One thread per (slot, entry).
 TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
@@ -780,25 +804,32 @@ TERRA_HD void spec_scan_body(spec_buffers_t const &sb, uint32_t slot) {
 	if (ph == SPEC_FAILED) {TERRA_ATOMIC_MIN(&sb.ctl->new_stop, iter);}
 	if (!(ph == SPEC_IDLE && sb.has_ver[slot])) {TERRA_ATOMIC_MIN(&sb.ctl->new_base, iter); TERRA_ATOMIC_ADD(&sb.ctl->unfinished, 1u);}
 }
-// flush the committed droplets [base, new_base): the highest-numbered committed writer of a cell stores it; one thread per (slot, log entry)
-TERRA_HD void spec_flush_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
+// flush the committed droplets [base, new_base): the highest-numbered committed writer of a cell stores it.  One wave per slot; the
+// flushed buffer is left empty for the slot's next droplet.
+TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 	uint32_t const iter = sb.it[slot], nbase = sb.ctl->new_base;
 	if (iter == SPEC_NIL || iter >= nbase) return;
 	uint32_t const cb = sb.cur[slot];
 	size_t const cap = (size_t)1 << sb.cap_log2;
-	uint32_t const cell = sb.log_keys[cb][(size_t)slot*cap + entry];
-	if (cell == SPEC_EMPTY) return;
-	uint32_t const X = cell % (uint32_t)sb.ec.NX, Z = cell / (uint32_t)sb.ec.NX;
-	uint32_t const b = (Z >> sb.bshift)*sb.nbx + (X >> sb.bshift);
-	for (uint32_t node = sb.head[b]; node != SPEC_NIL; node = sb.next[node]) {
-		uint32_t const j = node / sb.maxb, ij = sb.it[j];
-		if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
-		uint32_t const jb = sb.cur[j];
-		float vj;
-		if (spec_log_find<false>(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) return; // a later committed droplet owns the final value
+	uint32_t const *keys = sb.log_keys[cb] + (size_t)slot*cap, *used = sb.log_used[cb] + (size_t)slot*cap;
+	float const *vals = sb.log_vals[cb] + (size_t)slot*cap;
+	TERRA_LANES(u, sb.log_cnt[cb][slot]) {
+		uint32_t const entry = used[u], cell = keys[entry];
+		uint32_t const X = cell % (uint32_t)sb.ec.NX, Z = cell / (uint32_t)sb.ec.NX;
+		uint32_t const b = (Z >> sb.bshift)*sb.nbx + (X >> sb.bshift);
+		bool owner = true;
+		for (uint32_t node = sb.head[b]; node != SPEC_NIL; node = sb.next[node]) {
+			uint32_t const j = node / sb.maxb, ij = sb.it[j];
+			if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
+			uint32_t const jb = sb.cur[j];
+			// a later committed droplet owns the final value
+			float vj;
+			if (spec_log_find<false>(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) {owner = false; break;}
+		}
+		if (!owner) continue;
+		*sb.grid.at((int)X, (int)Z) = vals[entry];
+		if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.ctl->touched, 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
 	}
-	*sb.grid.at((int)X, (int)Z) = sb.log_vals[cb][(size_t)slot*cap + entry];
-	if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.ctl->touched, 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
 }
 // hand a slot to the next droplet of the ring
 TERRA_HD void spec_reassign(spec_buffers_t const &sb, uint32_t slot, uint32_t iter) {
@@ -820,7 +851,7 @@ TERRA_HD void spec_advance_body(spec_buffers_t const &sb) {
 	c.base = c.new_base;
 	uint64_t const nb = (uint64_t)c.base + sb.W;
 	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;
-	c.stop_at = c.new_stop; c.new_stop = SPEC_NIL; c.unfinished = 0;
+	c.stop_at = c.new_stop; c.new_stop = SPEC_NIL; c.unfinished = 0; c.ndirty = 0;
 }
 // after the fall-back droplet `base` ran directly on the grid: it is committed and every other in-flight trace starts over (the grid
 // changed under them without a version to compare against).  One thread per slot, then spec_fallback_advance_body.

@@ -26,6 +26,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipEventCreate(&ev0)); TERRA_HIP_CHECK(hipEventCreate(&ev1));
 		char const *s = getenv("TERRA_SIMPLE_KERNELS");
 		simple_kernels = (s && s[0] == '1');
+		if (char const *gr = getenv("TERRA_GRAPHS")) {graphs_enabled = (gr[0] != '0');}
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
@@ -36,10 +37,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (vox_p) (void)hipFree(vox_p);
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
+		for (graph_slot_t &g : graphs) {graph_drop(g);}
 		if (own_stream) (void)hipStreamDestroy(own_stream);
 	}
 	void use() {TERRA_HIP_CHECK(hipSetDevice(device));}
-	void set_stream(void *s) {sync(); stream = s ? (hipStream_t)s : own_stream;}
+	void set_stream(void *s) {sync(); stream = s ? (hipStream_t)s : own_stream;} // cached graphs are stream-agnostic (the stream is given at launch)
 	void sync() {use(); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	void *alloc(size_t bytes) {use(); void *p = nullptr; TERRA_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1)); return p;}
 	void free(void *p) {use(); (void)hipFree(p);}
@@ -49,6 +51,40 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void d2h(void *h, void const *d, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	void timer_start() {use(); TERRA_HIP_CHECK(hipEventRecord(ev0, stream));}
 	float timer_stop() {use(); TERRA_HIP_CHECK(hipEventRecord(ev1, stream)); TERRA_HIP_CHECK(hipEventSynchronize(ev1)); float ms = 0; TERRA_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); return ms;}
+
+	// ---- hipGraph cache: a fixed sequence of small dependent launches (one speculative-erosion round) is captured once and replayed with a
+	// single hipGraphLaunch.  `key` = every byte the captured closures depend on; the caller re-captures when it changes.
+	struct graph_slot_t {std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0;};
+	std::vector<graph_slot_t> graphs; uint64_t graph_clock = 0; bool capturing = false; bool graphs_enabled = true;
+	void graph_drop(graph_slot_t &g) {if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr; g.key.clear();}
+	bool graph_replay(void const *key, size_t n) {
+		if (!graphs_enabled) return false;
+		for (graph_slot_t &g : graphs) {
+			if (g.exec && g.key.size() == n && memcmp(g.key.data(), key, n) == 0) {use(); g.last_use = ++graph_clock; TERRA_HIP_CHECK(hipGraphLaunch(g.exec, stream)); return true;}
+		}
+		return false;
+	}
+	bool graph_begin() { // false: graphs are off, the caller's launches simply run
+		if (!graphs_enabled) return false;
+		use();
+		TERRA_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+		capturing = true;
+		return true;
+	}
+	void graph_abort() {if (capturing) {hipGraph_t g = nullptr; (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); capturing = false;}}
+	void graph_end(void const *key, size_t n) { // instantiate, remember (8 slots, least recently used goes), launch
+		hipGraph_t g = nullptr;
+		capturing = false;
+		TERRA_HIP_CHECK(hipStreamEndCapture(stream, &g));
+		hipGraphExec_t ex = nullptr;
+		hipError_t const e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+		if (e != hipSuccess) {(void)hipGraphDestroy(g); throw std::runtime_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));}
+		graph_slot_t *slot = nullptr;
+		if (graphs.size() < 8) {graphs.emplace_back(); slot = &graphs.back();}
+		else {slot = &graphs[0]; for (graph_slot_t &c : graphs) {if (c.last_use < slot->last_use) slot = &c;} graph_drop(*slot);}
+		slot->key.assign((uint8_t const *)key, (uint8_t const *)key + n); slot->graph = g; slot->exec = ex; slot->last_use = ++graph_clock;
+		TERRA_HIP_CHECK(hipGraphLaunch(ex, stream));
+	}
 
 	template<class F> void launch(size_t n, F f, int block = 256) {
 		if (n == 0) return;
@@ -64,6 +100,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		if (n > 0x7FFFFFFFull) throw std::invalid_argument("launch_waves: grid too large");
 		hipLaunchKernelGGL(terra::k_waves<F>, dim3((unsigned)n), dim3(64), 0, stream, f, 0u);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
+
+	template<class F> void launch_waves_nolds(size_t n, F f) { // one 64-lane workgroup per item, no LDS scratch (does not compete with LDS-heavy kernels for a CU)
+		if (n == 0) return;
+		use();
+		if (n > 0x7FFFFFFFull) throw std::invalid_argument("launch_waves: grid too large");
+		hipLaunchKernelGGL(terra::k_waves_nolds<F>, dim3((unsigned)n), dim3(64), 0, stream, f);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 

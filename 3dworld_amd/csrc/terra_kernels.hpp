@@ -27,6 +27,8 @@ template<class F> __global__ __launch_bounds__(64) void k_waves(F f, unsigned fi
 	f((size_t)blockIdx.x + first, ws);
 }
 
+template<class F> __global__ __launch_bounds__(64) void k_waves_nolds(F f) {f((size_t)blockIdx.x);}
+
 // fold a thread's (min,max) of order-preserving uints over its wave and publish with two atomics per wave
 __device__ __forceinline__ void wave_minmax_publish(uint32_t lo, uint32_t hi, uint32_t *mm) {
 #pragma unroll

@@ -24,6 +24,11 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void d2h(void *h, void const *d, size_t bytes) {memcpy(h, d, bytes);}
 	void timer_start() {t0 = std::chrono::steady_clock::now();}
 	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
+	template<class F> void launch_waves_nolds(size_t n, F f) {for (size_t i = 0; i < n; ++i) f(i);}
+	bool graph_replay(void const *, size_t) {return false;} // no graphs here: every launch runs at once
+	bool graph_begin() {return false;}
+	void graph_end(void const *, size_t) {}
+	void graph_abort() {}
 	// sequential on purpose: bodies use non-atomic stand-ins for atomics (terra_erosion.hpp)
 	template<class F> void launch(size_t n, F f, int = 256) {for (size_t i = 0; i < n; ++i) f(i);}
 	// a "wave" is one call; its LDS scratch is a few stack arrays
