@@ -22,6 +22,11 @@
 #define TERRA_LAMBDA
 #endif
 
+// branch-probability hints: they only steer basic-block placement, so that the step loop of a droplet trace stays one compact run of
+// instructions (the rarely taken window shifts, multi-version look-ups and libm restatements are laid out behind it)
+#define TERRA_LIKELY(x)   __builtin_expect(!!(x), 1)
+#define TERRA_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 namespace terra {
 
 constexpr int   F_TABLE_SIZE   = 90;     // NUM_FREQ_COMP(9)*N_RAND_SIN2(10), src/mesh_gen.cpp:14,16,30

@@ -113,13 +113,13 @@ template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, eros
 	float c[4];
 
 	for (; numMoves < ec.max_path_len; ++numMoves, ++used) {
-		if (used == budget) {finished = false; break;}
-		if (numMoves > 0 && !mem.begin_step(xi, zi)) {break;}
+		if (TERRA_UNLIKELY(used == budget)) {finished = false; break;}
+		if (numMoves > 0 && TERRA_UNLIKELY(!mem.begin_step(xi, zi))) {break;}
 		float const gx = h00+h01-h10-h11, gz = h00+h10-h01-h11;
 		dx = (dx-gx)*Ki+gx;
 		dz = (dz-gz)*Ki+gz;
 		float const dl = sqrtf(dx*dx+dz*dz);
-		if (dl <= FLT_EPSILON) { // pick random dir: libm cosf/sinf in the reference, reproduced bit-for-bit (terra_sincosf.hpp)
+		if (TERRA_UNLIKELY(dl <= FLT_EPSILON)) { // pick random dir: libm cosf/sinf in the reference, reproduced bit-for-bit (terra_sincosf.hpp)
 			float const a = rgen.rand_float()*ec.two_pi;
 			dx = glibc_cosf(a); dz = glibc_sinf(a);
 		}
@@ -174,11 +174,100 @@ template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, eros
 	return finished;
 }
 
+// ---- the common case as its own loop.  A step is "hot" when its 4x4 brush box is interior to the grid and resident (MEM::hot_ready), the
+// direction comes from the gradient and the new corners are resident too: then nothing is clamped and nothing has to be fetched, and the
+// step is the same arithmetic as in droplet_run().  Everything else (window shifts with their multi-version look-ups, the libm random
+// direction, brushes at the border, reads after a NaN position, the footprint overflowing) makes this loop stop BEFORE the step has had any
+// effect, and droplet_run() executes that one step.  The point is code layout: the loop below is a few hundred instructions in one piece,
+// while the general step drags ~100 KB of rarely executed code through the instruction cache of a wave that runs thousands of steps.
+enum {DROPLET_EV_DONE = 0, DROPLET_EV_BUDGET = 1, DROPLET_EV_GENERAL = 2};
+template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem, erosion_consts_t const &ec, unsigned budget, unsigned &used) {
+	float const Kq = 10, Kw = 0.001f, Kr = 0.9f, Kd = 0.02f, Ki = 0.1f, minSlope = 0.05f, g = 20, Kg = g*2;
+	float const evap = 1 - Kw;
+	int xi = d.xi, zi = d.zi;
+	float xp = d.xp, zp = d.zp, xf = d.xf, zf = d.zf, s = d.s, v = d.v, w = d.w, dx = d.dx, dz = d.dz;
+	float h = d.h, h00 = d.h00, h10 = d.h10, h01 = d.h01, h11 = d.h11;
+	unsigned numMoves = d.numMoves;
+	int nan_seen = d.nan_seen;
+	int ev = DROPLET_EV_GENERAL;
+	float c[4];
+	for (;;) {
+		if (numMoves >= ec.max_path_len) {ev = DROPLET_EV_DONE; break;}
+		if (used == budget) {ev = DROPLET_EV_BUDGET; break;}
+		if (!mem.hot_ready(xi, zi)) break;
+		float const gx = h00+h01-h10-h11, gz = h00+h10-h01-h11;
+		float tdx = (dx-gx)*Ki+gx, tdz = (dz-gz)*Ki+gz;
+		float const dl = sqrtf(tdx*tdx+tdz*tdz);
+		if (dl <= FLT_EPSILON) break; // random direction: general step
+		tdx /= dl; tdz /= dl;
+		float const nxp = xp+tdx, nzp = zp+tdz;
+		int const nxi = f2i_x86(floorf(nxp)), nzi = f2i_x86(floorf(nzp));
+		float const nxf = nxp-(float)nxi, nzf = nzp-(float)nzi;
+		if (!mem.corners_hot(nxi, nzi, c)) break; // not resident (only after a NaN position): general step
+		// ---- from here on the step is executed
+		float const nh00 = c[0], nh10 = c[1], nh01 = c[2], nh11 = c[3];
+		float const nh = (nh00*(1-nxf)+nh10*nxf)*(1-nzf)+(nh01*(1-nxf)+nh11*nxf)*nzf;
+		if (max_std(max_std(nh00, nh10), max_std(nh01, nh11)) < ec.water_thresh) {ev = DROPLET_EV_DONE; break;}
+		if (nh >= h) { // `outside` is false: the box is interior
+			float ds = (nh-h)+0.001f;
+			if (ds >= s) {
+				ds = s;
+				mem.deposit_hot(xi, zi, xf, zf, ds*ec.erode_amount); h += ds;
+				s = 0;
+				ev = DROPLET_EV_DONE; break;
+			}
+			mem.deposit_hot(xi, zi, xf, zf, ds*ec.erode_amount); h += ds;
+			s -= ds;
+			v = 0;
+		}
+		float dh = h-nh;
+		float const q = max_std(dh, minSlope)*v*w*Kq;
+		float ds = s-q;
+		if (ds >= 0) {
+			ds *= Kd;
+			mem.deposit_hot(xi, zi, xf, zf, ds*ec.erode_amount); dh += ds;
+			s -= ds;
+		}
+		else {
+			ds *= -Kr;
+			ds = min_std(ds, dh*0.99f);
+			float const relh = ec.relh_adj_tex + (nh - ec.zmin)/ec.zrange;
+			ds = (float)((double)ds*((relh > ec.clip_hd1) ? 0.5 : 2.0));
+			mem.erode_hot(xi, zi, xp, zp, ds*ec.erode_amount);
+			dh -= ds;
+			s  += ds;
+		}
+		v = sqrtf(v*v+Kg*dh);
+		if (v != v) {nan_seen = 1;}
+		w *= evap;
+		dx = tdx; dz = tdz;
+		xp = nxp; zp = nzp; xi = nxi; zi = nzi; xf = nxf; zf = nzf;
+		h = nh; h00 = nh00; h10 = nh10; h01 = nh01; h11 = nh11;
+		++numMoves; ++used;
+	}
+	d.xi = xi; d.zi = zi; d.xp = xp; d.zp = zp; d.xf = xf; d.zf = zf; d.s = s; d.v = v; d.w = w; d.dx = dx; d.dz = dz;
+	d.h = h; d.h00 = h00; d.h10 = h10; d.h01 = h01; d.h11 = h11;
+	d.numMoves = numMoves; d.nan_seen = nan_seen;
+	return ev;
+}
+
+// at most `budget` steps: hot steps in their own loop, single general steps in between; true => the droplet is finished
+template<class MEM> TERRA_HD bool droplet_run_fast(droplet_state_t &d, MEM &mem, erosion_consts_t const &ec, unsigned budget) {
+	unsigned used = 0;
+	for (;;) {
+		int const ev = droplet_hot_steps(d, mem, ec, budget, used);
+		if (ev == DROPLET_EV_DONE) return true;
+		if (ev == DROPLET_EV_BUDGET) return false;
+		if (droplet_run(d, mem, ec, 1u)) return true;
+		++used;
+	}
+}
+
 template<class MEM> TERRA_HD droplet_result_t simulate_droplet(int iter, MEM &mem, erosion_consts_t const &ec) {
 	droplet_state_t d;
 	droplet_result_t res = {0, 0};
 	if (!droplet_start(iter, mem, ec, d)) {return res;}
-	droplet_run(d, mem, ec, DROPLET_NO_BUDGET);
+	droplet_run_fast(d, mem, ec, DROPLET_NO_BUDGET);
 	res.steps = d.numMoves; res.nan_seen = d.nan_seen;
 	return res;
 }
@@ -203,6 +292,14 @@ struct direct_mem_t {
 		int const x0 = clampi(x, g.NX-1), x1 = clampi(x+1, g.NX-1), z0 = clampi(z, g.NY-1), z1 = clampi(z+1, g.NY-1);
 		out[0] = *g.at(x0, z0); out[1] = *g.at(x1, z0); out[2] = *g.at(x0, z1); out[3] = *g.at(x1, z1);
 	}
+	TERRA_HD bool hot_ready(int xi, int zi) const {return xi-1 >= 0 && zi-1 >= 0 && xi+2 <= g.NX-1 && zi+2 <= g.NY-1;}
+	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
+		if (!(x >= 0 && z >= 0 && x+1 <= g.NX-1 && z+1 <= g.NY-1)) return false;
+		out[0] = *g.at(x, z); out[1] = *g.at(x+1, z); out[2] = *g.at(x, z+1); out[3] = *g.at(x+1, z+1);
+		return true;
+	}
+	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {deposit(xi, zi, xf, zf, dse);}
+	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {erode(xi, zi, xp, zp, dse);}
 	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {
 		for (int q = 0; q < 4; ++q) {
 			int const X = xi + (q & 1), Z = zi + (q >> 1);
@@ -264,8 +361,24 @@ template<class DERIVED> struct wave_cell_ops {
 		}
 		TERRA_WAVE_SYNC();
 	}
+	// the brush box is interior: no clamping, 4 / 16 distinct cells, one lane each
+	TERRA_HD void deposit_cells_hot(int xi, int zi, float xf, float zf, float dse) {
+		TERRA_LANES(q, 4) {
+			int const X = xi + (q & 1), Z = zi + (q >> 1);
+			*self().cell(X, Z) += dse*deposit_weight(q, xf, zf); self().mark(X, Z);
+		}
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD void erode_cells_hot(int xi, int zi, float xp, float zp, float dse) {
+		TERRA_LANES(l, 16) {
+			int const x = xi-1 + (l & 3), z = zi-1 + (l >> 2);
+			float const wb = brush_weight(x, z, xp, zp);
+			if (wb > 0) {*self().cell(x, z) -= dse*wb; self().mark(x, z);}
+		}
+		TERRA_WAVE_SYNC();
+	}
 	TERRA_HD void erode_cells(int xi, int zi, float xp, float zp, float dse, int NX, int NY) {
-		if (xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1) { // interior: 16 distinct cells, one lane each
+		if (TERRA_LIKELY(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) { // interior: 16 distinct cells, one lane each
 			TERRA_LANES(l, 16) {
 				int const x = xi-1 + (l & 3), z = zi-1 + (l >> 2);
 				float const wb = brush_weight(x, z, xp, zp);
@@ -298,6 +411,15 @@ struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
 	}
 	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
 	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {erode_cells(xi, zi, xp, zp, dse, NX, NY);}
+	TERRA_HD bool hot_ready(int xi, int zi) const {return xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1;}
+	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
+		if (!(x >= 0 && z >= 0 && x+1 <= NX-1 && z+1 <= NY-1)) return false;
+		float const *p = cell(x, z);
+		out[0] = p[0]; out[1] = p[1]; out[2] = p[NX]; out[3] = p[NX+1];
+		return true;
+	}
+	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {deposit_cells_hot(xi, zi, xf, zf, dse);}
+	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {erode_cells_hot(xi, zi, xp, zp, dse);}
 };
 
 // ---- big grids: a WS x WS window of the grid follows the droplet in LDS; BACK is where cells come from / go to.
@@ -368,11 +490,11 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		xi = sati(xi, NX); zi = sati(zi, NY);
 		if (!back.begin_step(xi, zi)) return false;
 		int const bx0 = clampi(xi-1, NX-1), bx1 = clampi(xi+2, NX-1), bz0 = clampi(zi-1, NY-1), bz1 = clampi(zi+2, NY-1);
-		if (!(have && bx0 >= wx0 && bx1 < wx0 + EW && bz0 >= wz0 && bz1 < wz0 + EW)) {recenter((bx0 + bx1)/2, (bz0 + bz1)/2);}
+		if (TERRA_UNLIKELY(!(have && bx0 >= wx0 && bx1 < wx0 + EW && bz0 >= wz0 && bz1 < wz0 + EW))) {recenter((bx0 + bx1)/2, (bz0 + bz1)/2);}
 		return !back.failed();
 	}
 	TERRA_HD float read_any(int X, int Z) { // outside the window only after a NaN position (index INT_MIN clamps to 0): slow path, still part of the footprint
-		if (in_window(X, Z)) return *cell(X, Z);
+		if (TERRA_LIKELY(in_window(X, Z))) return *cell(X, Z);
 		back.note_far_read(X, Z);
 		float const b = back.base(X, Z);
 		return back.lookup(X, Z, b);
@@ -383,6 +505,20 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	}
 	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
 	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {back.note_write(); this->erode_cells(xi, zi, xp, zp, dse, NX, NY);}
+	// hot step: interior brush box, footprint recorded, box inside the resident window
+	TERRA_HD bool hot_ready(int xi, int zi) {
+		if (!(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) return false;
+		if (!back.begin_step(xi, zi)) return false; // idempotent: the general step may record the same blocks again
+		return have && xi-1 >= wx0 && xi+2 < wx0 + EW && zi-1 >= wz0 && zi+2 < wz0 + EW;
+	}
+	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
+		if (!(x >= 0 && z >= 0 && x+1 <= NX-1 && z+1 <= NY-1 && x >= wx0 && x+1 < wx0 + EW && z >= wz0 && z+1 < wz0 + EW)) return false;
+		float const *p = cell(x, z);
+		out[0] = p[0]; out[1] = p[1]; out[2] = p[EW]; out[3] = p[EW+1];
+		return true;
+	}
+	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells_hot(xi, zi, xf, zf, dse);}
+	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {back.note_write(); this->erode_cells_hot(xi, zi, xp, zp, dse);}
 	TERRA_HD void finish() {flush();}
 };
 
@@ -545,7 +681,7 @@ struct spec_back_t {
 	// (a superset is fine).  The flag reaches the list entry when the block leaves the cache or the trace stops.
 	TERRA_HD void touch_block(uint32_t b) {
 		if (b == bc0 || b == bc1 || b == bc2 || b == bc3) return;
-		if (nblk >= sb->maxb) {blk_overflow = true; return;}
+		if (TERRA_UNLIKELY(nblk >= sb->maxb)) {blk_overflow = true; return;}
 		if ((bwmask & 8u) && bc3 != SPEC_NIL && TERRA_LANE0) {my_blks[be3] = bc3 | SPEC_BLK_WRITTEN;}
 		bc3 = bc2; bc2 = bc1; bc1 = bc0; bc0 = b; be3 = be2; be2 = be1; be1 = be0; be0 = nblk; bwmask = (bwmask << 1) & 0xFu;
 		if (TERRA_LANE0) {my_blks[nblk] = b;}
@@ -698,7 +834,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		d = sb.state[slot];
 		mem.back.init(&sb, slot, iter, ws.sh, &sb.resume[slot]);
 	}
-	if (!finished) {finished = droplet_run(d, mem, sb.ec, budget);}
+	if (!finished) {finished = droplet_run_fast(d, mem, sb.ec, budget);}
 	unsigned const steps_before = (ph == SPEC_FRESH) ? 0u : sb.state[slot].numMoves;
 	mem.finish(); // the window's dirty cells go to the log: a suspended trace keeps nothing in LDS
 	mem.back.flush_block_flags();
