@@ -65,6 +65,18 @@ struct droplet_result_t {unsigned steps; int nan_seen;};
 TERRA_HD int clampi(int v, int hi) {return imax(imin(v, hi), 0);} // HMAP_INDEX clamp (src/erosion.cpp:39)
 TERRA_HD int sati(int v, int n) {return imax(imin(v, n + 8), -8);}   // keeps xi-1 / xi+2 free of signed overflow when a NaN position became INT_MIN; clamping afterwards is unchanged
 
+// Every lane of a droplet's wave holds the same droplet state; telling the compiler so (v_readfirstlane) lets the integer / address / control
+// part of a step run on the scalar unit with plain scalar branches instead of vector compares and exec-mask bookkeeping.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int wave_uniform(int v) {return __builtin_amdgcn_readfirstlane(v);}
+__device__ __forceinline__ unsigned wave_uniform(unsigned v) {return (unsigned)__builtin_amdgcn_readfirstlane((int)v);}
+__device__ __forceinline__ float wave_uniform(float v) {return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));}
+#else
+inline int wave_uniform(int v) {return v;}
+inline unsigned wave_uniform(unsigned v) {return v;}
+inline float wave_uniform(float v) {return v;}
+#endif
+
 // ------------------------------------------------------------------ one droplet (src/erosion.cpp:67-155)
 // The scalar state machine below is the reference's loop verbatim; everything that touches the grid goes through MEM:
 //   bool begin_step(xi, zi)                 footprint / residency hook for the step's 4x4 brush box; false => abort the trace
@@ -192,6 +204,7 @@ template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem,
 	int ev = DROPLET_EV_GENERAL;
 	float c[4];
 	for (;;) {
+		xi = wave_uniform(xi); zi = wave_uniform(zi); numMoves = wave_uniform(numMoves); used = wave_uniform(used);
 		if (numMoves >= ec.max_path_len) {ev = DROPLET_EV_DONE; break;}
 		if (used == budget) {ev = DROPLET_EV_BUDGET; break;}
 		if (!mem.hot_ready(xi, zi)) break;
@@ -509,12 +522,13 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD bool hot_ready(int xi, int zi) {
 		if (!(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) return false;
 		if (!back.begin_step(xi, zi)) return false; // idempotent: the general step may record the same blocks again
+		wx0 = wave_uniform(wx0); wz0 = wave_uniform(wz0);
 		return have && xi-1 >= wx0 && xi+2 < wx0 + EW && zi-1 >= wz0 && zi+2 < wz0 + EW;
 	}
 	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
 		if (!(x >= 0 && z >= 0 && x+1 <= NX-1 && z+1 <= NY-1 && x >= wx0 && x+1 < wx0 + EW && z >= wz0 && z+1 < wz0 + EW)) return false;
 		float const *p = cell(x, z);
-		out[0] = p[0]; out[1] = p[1]; out[2] = p[EW]; out[3] = p[EW+1];
+		out[0] = wave_uniform(p[0]); out[1] = wave_uniform(p[1]); out[2] = wave_uniform(p[EW]); out[3] = wave_uniform(p[EW+1]);
 		return true;
 	}
 	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells_hot(xi, zi, xf, zf, dse);}
@@ -705,6 +719,8 @@ struct spec_back_t {
 		++nblk;
 	}
 	TERRA_HD bool begin_step(int xi, int zi) { // footprint of one step = the 4x4 brush box, which also covers every read of that step
+		nblk = wave_uniform(nblk); bwmask = wave_uniform(bwmask); bc0 = wave_uniform(bc0); bc1 = wave_uniform(bc1); bc2 = wave_uniform(bc2); bc3 = wave_uniform(bc3);
+		be0 = wave_uniform(be0); be1 = wave_uniform(be1); be2 = wave_uniform(be2); be3 = wave_uniform(be3);
 		int const x0 = clampi(xi-1, sb->ec.NX-1) >> sb->bshift, x1 = clampi(xi+2, sb->ec.NX-1) >> sb->bshift;
 		int const z0 = clampi(zi-1, sb->ec.NY-1) >> sb->bshift, z1 = clampi(zi+2, sb->ec.NY-1) >> sb->bshift;
 		touch_block((uint32_t)z0*sb->nbx + x0);
