@@ -35,8 +35,8 @@ VALU_PEAK_TOPS = 78.6      # fp32 VALU without FMA: 256 CU x 4 SIMD x 32 lanes x
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=16)
-    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--steps", type=int, default=64)
+    p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--size", type=int, default=16384)
     p.add_argument("--mode", default="sine", choices=sorted(MODES))
     p.add_argument("--droplets", type=int, default=1000)
@@ -190,7 +190,7 @@ def main():
         achieved = 4.0 * cells / (ms_k * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE), only for the configuration they were taken on
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_sine_grid<false>"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_sine_grid"]
             if mode == 0 and N == 16384 and args.octaves == 8:
                 traffic = pm["hbm_bytes_per_launch"]
         except Exception:

@@ -11,7 +11,13 @@ for f in files:
             continue
         k = r["Dispatch_Id"]
         disp.setdefault(k, {"name": r["Kernel_Name"][:60], "grid": r.get("Grid_Size")})[r["Counter_Name"]] = float(r["Counter_Value"])
+dur = {}
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 for k, v in list(disp.items())[-3:]:
+    if k in dur:
+        v["duration_us"] = dur[k]
     w = v.get("SQ_WAVES", 0) or 1
     wc = v.get("SQ_WAVE_CYCLES", 0) or 1
     print(k, v["name"], "grid", v["grid"])
