@@ -472,9 +472,8 @@ template<class BE> struct terra_engine {
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_keys[2], o_vals[2], o_used[2], o_lc[2], o_bl[2], o_bc[2], o_chk[2];
-		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(W*cap*4); o_lc[b] = carve(W*4);} // keys + counts first: they carry state from run to run
-		size_t const persistent_bytes = off;
-		for (int b = 0; b < 2; ++b) {o_vals[b] = carve(W*cap*4); o_used[b] = carve(W*cap*4); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
+		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(W*cap*4); o_used[b] = carve(W*cap*4); o_lc[b] = carve(W*4);} // first, at offsets that depend on (W, cap) only: they carry state from run to run
+		for (int b = 0; b < 2; ++b) {o_vals[b] = carve(W*cap*4); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
 		size_t const o_slot = carve((size_t)W*4*9); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps
 		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
 		size_t const o_next = carve((size_t)W*sb.maxb*4), o_nodeblk = carve((size_t)W*sb.maxb*4), o_dlist = carve((size_t)W*sb.maxb*8), o_ctl = carve(sizeof(spec_ctl_t));
@@ -503,7 +502,6 @@ template<class BE> struct terra_engine {
 		if (spec_logs_base != base || spec_logs_w != W || spec_logs_cap != sb.cap_log2) {
 			for (int b = 0; b < 2; ++b) {be.fill32(sb.log_keys[b], SPEC_EMPTY, (size_t)W*cap); be.fill32(sb.log_cnt[b], 0, W);}
 		}
-		(void)persistent_bytes;
 		spec_logs_base = nullptr;
 
 		spec_buffers_t const s = sb;

@@ -23,12 +23,6 @@
 #include "terra_sincosf.hpp"
 
 namespace terra {
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(TERRA_INSTR)
-static unsigned long long g_cnt[16];
-#define TERRA_CNT(i, n) (g_cnt[i] += (n))
-#else
-#define TERRA_CNT(i, n) do {} while (0)
-#endif
 
 // ------------------------------------------------------------------ grid addressing
 // Padded coordinates X in [0,NX), Z in [0,NY), NX = xsize + 2*PAD.  The interior lives in the caller's buffer (in place);
@@ -462,7 +456,6 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	// (no global traffic, no log look-up); dirty cells that leave are written back; cells that enter are fetched with all plain grid
 	// loads of a lane issued back to back (one HBM latency per shift), then patched where a multi-version look-up is needed.
 	TERRA_HD void recenter(int cx, int cz) {
-		TERRA_CNT(6, 1);
 		int const nx0 = clampi(cx - EW/2, imax(NX - EW, 0)), nz0 = clampi(cz - EW/2, imax(NY - EW, 0));
 		if (have) {
 			TERRA_LANES(i, EW*EW) {
@@ -640,9 +633,7 @@ TERRA_HD uint32_t spec_hash(uint32_t cell, uint32_t cap_log2) {return (cell*2654
 template<bool L2LOAD> TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t cap_log2, uint32_t cell, float &out) {
 	uint32_t const mask = (1u << cap_log2) - 1;
 	uint32_t h = spec_hash(cell, cap_log2);
-	TERRA_CNT(L2LOAD ? 0 : 1, 1);
 	for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
-		TERRA_CNT(L2LOAD ? 2 : 3, 1);
 		uint32_t const k = L2LOAD ? TERRA_L2_LOAD(&keys[h]) : keys[h];
 		if (k == cell) {out = L2LOAD ? TERRA_L2_LOAD(&vals[h]) : vals[h]; return true;}
 		if (k == SPEC_EMPTY) return false;
@@ -741,7 +732,7 @@ struct spec_back_t {
 			uint8_t shared = 0;
 			uint32_t const bx = (uint32_t)(wbx0 + i % wnb), bz = (uint32_t)(wbz0 + i / wnb);
 			if (bx < sb->nbx && bz < sb->nby) {
-				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {TERRA_CNT(4, 1); if (lower_version(node / sb->maxb)) {shared = 1; break;}}
+				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {if (lower_version(node / sb->maxb)) {shared = 1; break;}}
 			}
 			sh->blk_shared[i] = shared;
 		}
@@ -770,7 +761,6 @@ struct spec_back_t {
 			size_t const cap = (size_t)1 << sb->cap_log2;
 			uint32_t const blk = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
 			for (uint32_t node = sb->head[blk]; node != SPEC_NIL; node = sb->next[node]) {
-				TERRA_CNT(5, 1);
 				uint32_t const j = node / sb->maxb;
 				if (!lower_version(j)) continue;
 				uint32_t const ij = sb->it[j];
@@ -786,7 +776,6 @@ struct spec_back_t {
 	// called from lanes in parallel, each with a distinct cell.  sh->chk = sum over the log's cells of a non-linear term of (cell, latest value):
 	// a function of the log CONTENT only, so two traces of a droplet compare equal however their write-backs were scheduled
 	TERRA_HD void store(int X, int Z, float val) {
-		TERRA_CNT(7, 1);
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
 		uint32_t const mask = (1u << sb->cap_log2) - 1, limit = mask - (uint32_t)(EW*EW) - 64u;
 		uint32_t h = spec_hash(cell, sb->cap_log2);
@@ -830,7 +819,6 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	if (!spec_slot_active(sb, slot, iter)) return;
 	uint32_t const ph = sb.phase[slot];
 	if (ph != SPEC_FRESH && ph != SPEC_RUNNING) return;
-	TERRA_CNT(ph == SPEC_FRESH ? 8 : 9, 1);
 	window_mem_t<spec_back_t> mem;
 	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
 	droplet_state_t d;

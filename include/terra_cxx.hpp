@@ -72,6 +72,19 @@ inline void apply_erosion(float *heightmap, int xsize, int ysize, float min_zval
 }
 
 // tile_t::create_zvals for a batch of tiles (src/tiled_mesh.cpp:467-546): zvals n*130*130, stats n, normals n*129*129*4 (optional)
+// ---- eval_mesh_sin_terms (src/mesh_gen.cpp:797-805): point query, evaluated on the host
+inline float eval_mesh_sin_terms(float xv, float yv) {
+	float z = 0.0f;
+	check(terra_eval_mesh_sin_terms(default_ctx(), xv, yv, &z), "eval_mesh_sin_terms");
+	return z;
+}
+// ---- glaciate() over the ground mesh (src/mesh_gen.cpp:388-404): in place on a device buffer, returns zbottom / ztop
+inline void glaciate_mesh_dev(float *d_mesh, unsigned nx, unsigned ny, int xoff2, int yoff2, float &zbottom, float &ztop) {
+	float zz[2] = {0.0f, 0.0f};
+	check(terra_glaciate_mesh_dev(default_ctx(), d_mesh, nx, ny, xoff2, yoff2, zz), "glaciate");
+	zbottom = zz[0]; ztop = zz[1];
+}
+
 inline void tiles_create_zvals(int const *tile_xy, unsigned n, unsigned erosion_iters_tt, float *zvals, terra_tile_stats *stats, unsigned char *normals=nullptr, float *min_normal_z=nullptr) {
 	check(terra_tiles_create_zvals(default_ctx(), tile_xy, n, erosion_iters_tt, zvals, stats, normals, min_normal_z), "tiles_create_zvals");
 }

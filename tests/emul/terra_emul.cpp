@@ -66,9 +66,6 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 typedef cpu_backend_t terra_backend_t;
 #include "../../3dworld_amd/csrc/terra_api_impl.hpp"
 
-#ifdef TERRA_INSTR
-extern "C" unsigned long long *terra_emul_counters() {return terra::g_cnt;}
-#endif
 
 // glibc_powf (terra_powf.hpp) against the build host's libm over n pseudo-random arguments: [0,2) ^ {typical exponents}, then raw bit patterns
 extern "C" unsigned long long terra_emul_powf_mismatches(unsigned long long n, uint32_t seed) {

@@ -141,6 +141,20 @@ def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_ca
     return r, stats
 
 
+def case_erosion_context_reuse(pkg, t, orc):
+    """one context, many runs: the scheduler keeps its block tables and log tables between runs (only the entries a run set are reset), so a
+    sequence that changes grid size, ring size, block-list capacity, log capacity and droplet count exercises every re-use / re-init decision."""
+    seq = [(256, 500, {}), (256, 700, {}), (256, 300, dict(block_list_capacity=16)), (256, 300, dict(block_list_capacity=256)),
+           (320, 400, dict(window=128)), (256, 500, dict(window=0xFFFFFFFF)), (192, 600, dict(log_capacity_log2=13)), (256, 500, dict(log_capacity_log2=12)), (96, 2000, dict(window=64))]
+    try:
+        for n, iters, tune in seq:
+            if tune:
+                t.set_erosion_tuning(**tune)
+            case_erosion_vs_oracle(pkg, t, orc, n, iters)
+    finally:
+        t.set_erosion_tuning(window=0xFFFFFFFF, log_capacity_log2=12, block_list_capacity=256)
+
+
 def case_erosion_edge(pkg, t, orc):
     """disabled erosion, flat terrain (random-direction branch), water everywhere, 1-cell-wide grids."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=0)

@@ -58,6 +58,10 @@ def test_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_
         assert r.serial_fallbacks >= 1
 
 
+def test_erosion_context_reuse(pkg, gpu, orc):
+    pc.case_erosion_context_reuse(pkg, gpu, orc)
+
+
 def test_erosion_edge_cases(pkg, gpu, orc):
     pc.case_erosion_edge(pkg, gpu, orc)
 
