@@ -57,4 +57,38 @@ for dims in ((512, 512, 64), (512, 512, 512)):
         ms = timed(lambda: t.voxel_fill_dev(v.ptr, dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, mode, 0.01, 1), reps=2)
         out[f"C5_voxels_{dims[0]}x{dims[1]}x{dims[2]}_{name}_gvoxels_s"] = round(dims[0] * dims[1] * dims[2] / ms / 1e6, 2)
     v.free()
+# ---- the reference's CPU path beside each number: bounded samples (seconds each) on this host's cores.  kind = "reference" when oracle/_ref
+# (the reference's own TUs) travelled with the repo, else "port" (oracle/terra_oracle.c).  Erosion: 1 thread is the only deterministic order.
+if "--no-cpu" not in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    orclib.build_oracle()
+    kind = "reference" if orclib.ref_available() else "port"
+    ck = orclib.Checker("ref" if kind == "reference" else "orc")
+    cores = ck.num_threads()
+    cpu = {"kind": kind, "cores": cores}
+    def wall(fn):
+        t0 = time.perf_counter(); r = fn(); return time.perf_counter() - t0, r
+    for name, mode, n in (("sine", 0, 4096), ("simplex", 1, 2048), ("perlin", 2, 2048), ("dwarp", 4, 1024)):
+        s_ = ck.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+        dt, _ = wall(lambda: ck.gen_grid(-n / 2, -n / 2, s_.DX_VAL, s_.DY_VAL, n, n, 1))
+        cpu[f"C2_{name}_8oct_{n}_gcells_s"] = round(n * n / dt / 1e9, 5)
+    s_ = ck.init(orclib.make_config(mesh_gen_mode=0))
+    n = 4096
+    g0 = ck.gen_grid(-n / 2, -n / 2, s_.DX_VAL, s_.DY_VAL, n, n, 1)
+    for D, thr in ((1000, cores), (100000, cores), (100000, 1), (1000000, 1)):
+        ck.set_num_threads(thr)
+        g = g0.copy()
+        dt, _ = wall(lambda: ck.apply_erosion(g, float(g0.min()), D))
+        cpu[f"C3_erosion_4096_{D}_droplets_{thr}thr"] = {"ms": round(dt * 1e3, 1), "droplets_per_s": round(D / dt), "deterministic": thr == 1}
+    ck.set_num_threads(cores)
+    nt = 64
+    dt, _ = wall(lambda: [ck.tile_create_zvals(tx, ty, 0) for ty in range(-4, 4) for tx in range(-4, 4)])
+    cpu["C4_tiles_sine_0iters_tiles_per_s_serial_calls"] = round(nt / dt)
+    dt, _ = wall(lambda: [ck.tile_create_zvals(tx, ty, 1000) for ty in range(-2, 2) for tx in range(-2, 2)])
+    cpu["C4_tiles_sine_1000iters_tiles_per_s_serial_calls"] = round(16 / dt, 1)
+    dims = (256, 256, 64)
+    dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, 0, 0.01, 1))
+    cpu["C5_voxels_256x256x64_sines_gvoxels_s"] = round(dims[0] * dims[1] * dims[2] / dt / 1e9, 4)
+    out["cpu"] = cpu
 print(json.dumps(out))
