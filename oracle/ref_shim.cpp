@@ -256,19 +256,34 @@ REF_API void ref_rand_uniforms(long s1, long s2, float a, float b, int n, float 
 // tile_t::create_zvals driver (src/tiled_mesh.cpp:467-546) for tile (tx,ty), size=128: zvals[130*130], sub_zmin/zmax[4][4], water bbox
 struct ref_tile_stats_t {float sub_zmin[16], sub_zmax[16], mzmin, mzmax, radius; int wx1, wy1, wx2, wy2;};
 
+// enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778; scene_config/config.txt:81 turns it on): a config-file flag read by the tile code
+static bool shim_enable_tiled_mesh_ao(0);
+REF_API void ref_set_tiled_mesh_ao(int v) {shim_enable_tiled_mesh_ao = (v != 0);}
+unsigned const SHIM_NUM_AO_DIRS = 8, SHIM_NUM_AO_STEPS = 8, SHIM_AO_RAY_LEN = SHIM_NUM_AO_STEPS*(SHIM_NUM_AO_STEPS+1)/2; // src/tiled_mesh.cpp:41-43
+
 REF_API void ref_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, ref_tile_stats_t *st) {
 	unsigned const size(128), stride(size+1), zvsize(stride+1);
 	int const x1(tx*size), y1(ty*size), x2(x1 + size), y2(y1 + size);
 	int wx1(x2), wy1(y2), wx2(x1), wy2(y1); // start denormalized (src/tiled_mesh.cpp:308)
 	mesh_xy_grid_cache_t height_gen;
-	height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0, 0); // setup_height_gen_async, xy_scale=1
-	height_gen.enable_glaciate();
 	float mzmin(FAR_DISTANCE), mzmax(-FAR_DISTANCE);
-	unsigned const block_size(zvsize/4);
+	unsigned const block_size(zvsize/4), context_sz(stride + 2*SHIM_AO_RAY_LEN);
 	float const wpz_max(ref_get_max_sea_level());
+	if (shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU) { // AO + GPU noise: the zvals are clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505)
+		height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0, 0);
+		height_gen.enable_glaciate();
 #pragma omp parallel for schedule(static,1)
-	for (int y = 0; y < (int)zvsize; ++y) {
-		for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = height_gen.eval_index(x, y);}
+		for (int y = 0; y < (int)zvsize; ++y) {
+			for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = height_gen.eval_index(x + SHIM_AO_RAY_LEN, y + SHIM_AO_RAY_LEN);}
+		}
+	}
+	else {
+		height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0, 0); // setup_height_gen_async, xy_scale=1
+		height_gen.enable_glaciate();
+#pragma omp parallel for schedule(static,1)
+		for (int y = 0; y < (int)zvsize; ++y) {
+			for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = height_gen.eval_index(x, y);}
+		}
 	}
 	apply_erosion(zvals, zvsize, zvsize, zmin, iters_tt);
 
@@ -294,6 +309,53 @@ REF_API void ref_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zva
 	st->mzmin = mzmin; st->mzmax = mzmax;
 	st->radius = 0.5*sqrt((DX_VAL*DX_VAL + DY_VAL*DY_VAL)*size*size + (mzmax - mzmin)*(mzmax - mzmin));
 	st->wx1 = wx1; st->wy1 = wy1; st->wx2 = wx2; st->wy2 = wy2;
+}
+
+// tile_t::calc_mesh_ao_lighting driver (src/tiled_mesh.cpp:586-661) for tile (tx,ty): zvals[130*130] (as create_zvals left them) -> ao[129*129]
+REF_API void ref_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao) {
+	unsigned const size(128), stride(size+1), zvsize(stride+1), context_sz(stride + 2*SHIM_AO_RAY_LEN);
+	int const x1(tx*size), y1(ty*size);
+	int ao_dirs[SHIM_NUM_AO_DIRS][2];
+	unsigned ix(0);
+	for (int y = -1; y <= 1; ++y) {
+		for (int x = -1; x <= 1; ++x) {
+			if (x != 0 || y != 0) {ao_dirs[ix][0] = x; ao_dirs[ix][1] = y; ++ix;}
+		}
+	}
+	bool const use_ao_zvals(shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU); // ao_zvals kept by create_zvals: the whole context, interior included
+	vector<float> czv(context_sz*context_sz);
+	mesh_xy_grid_cache_t height_gen;
+	height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0, 0);
+	height_gen.enable_glaciate();
+	float const dz(0.5*HALF_DXY);
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)context_sz; ++y) {
+		for (int x = 0; x < (int)context_sz; ++x) {
+			int const xv(x - (int)SHIM_AO_RAY_LEN), yv(y - (int)SHIM_AO_RAY_LEN);
+			float &zv(czv[y*context_sz + x]);
+			if (!use_ao_zvals && xv >= 0 && yv >= 0 && xv < (int)zvsize && yv < (int)zvsize) {zv = zvals[yv*zvsize + xv];}
+			else {zv = height_gen.eval_index(x, y);}
+		}
+	}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)stride; ++y) {
+		for (int x = 0; x < (int)stride; ++x) {
+			unsigned atten(0);
+			for (unsigned d = 0; d < SHIM_NUM_AO_DIRS; ++d) {
+				float z0(zvals[y*zvsize + x]);
+				int stepx(ao_dirs[d][0]), stepy(ao_dirs[d][1]), vx(x), vy(y);
+				for (unsigned s = 0; s < SHIM_NUM_AO_STEPS; ++s) {
+					vx += stepx; vy += stepy;
+					z0 += dz;
+					stepx += ao_dirs[d][0]; stepy += ao_dirs[d][1]; // linear increase
+					int const xv(vx + (int)SHIM_AO_RAY_LEN), yv(vy + (int)SHIM_AO_RAY_LEN);
+					if (czv[yv*context_sz + xv] > z0) {atten += (SHIM_NUM_AO_STEPS - s); break;}
+				}
+			}
+			float const ao_scale(1.0 - float(atten)/float(SHIM_NUM_AO_DIRS*SHIM_NUM_AO_STEPS));
+			ao[y*stride + x] = (unsigned char)(255.0*ao_scale);
+		}
+	}
 }
 
 // tile_t::upload_normal_texture CPU part (src/tiled_mesh.cpp:865-880, src/tiled_mesh.h:281-284); returns min_normal_z

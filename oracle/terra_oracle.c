@@ -785,20 +785,37 @@ void  orc_rand_ints(long s1, long s2, int n, int *out) {rgen_t r; rgen_set_state
 void  orc_rand_floats(long s1, long s2, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_float(&r);}}
 void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_uniform(&r, a, b);}}
 
+/* enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778): config flag read by the tile code */
+static int enable_tiled_mesh_ao = 0;
+void orc_set_tiled_mesh_ao(int v) {enable_tiled_mesh_ao = (v != 0);}
+#define NUM_AO_DIRS 8
+#define NUM_AO_STEPS 8
+#define AO_RAY_LEN (NUM_AO_STEPS*(NUM_AO_STEPS+1)/2) /* 36, src/tiled_mesh.cpp:41-43 */
+
 /* a10: tile_t::create_zvals (src/tiled_mesh.cpp:302-314,447-546), size=128 */
 void orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_tile_stats_t *st) {
 	unsigned const size = 128, stride = size+1, zvsize = stride+1;
 	int const x1 = tx*(int)size, y1 = ty*(int)size, x2 = x1 + (int)size, y2 = y1 + (int)size;
 	int wx1 = x2, wy1 = y2, wx2 = x1, wy2 = y1;
 	grid_cache_t g;
-	gc_build_arrays(&g, (float)(x1 - MESH_X_SIZE/2), (float)(y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0);
-	gc_enable_glaciate(&g);
 	float mzmin = FAR_DISTANCE, mzmax = -FAR_DISTANCE;
-	unsigned const block_size = zvsize/4;
+	unsigned const block_size = zvsize/4, context_sz = stride + 2*AO_RAY_LEN;
 	float const wpz_max = orc_get_max_sea_level();
+	if (enable_tiled_mesh_ao && mesh_gen_mode >= ORC_MGEN_SIMPLEX_GPU) { /* zvals clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505) */
+		gc_build_arrays(&g, (float)((x1 - AO_RAY_LEN) - MESH_X_SIZE/2), (float)((y1 - AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0);
+		gc_enable_glaciate(&g);
 #pragma omp parallel for schedule(static,1)
-	for (int y = 0; y < (int)zvsize; ++y) {
-		for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = gc_eval_index(&g, x, y, 0, 1);}
+		for (int y = 0; y < (int)zvsize; ++y) {
+			for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = gc_eval_index(&g, x + AO_RAY_LEN, y + AO_RAY_LEN, 0, 1);}
+		}
+	}
+	else {
+		gc_build_arrays(&g, (float)(x1 - MESH_X_SIZE/2), (float)(y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0);
+		gc_enable_glaciate(&g);
+#pragma omp parallel for schedule(static,1)
+		for (int y = 0; y < (int)zvsize; ++y) {
+			for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = gc_eval_index(&g, x, y, 0, 1);}
+		}
 	}
 	gc_free(&g);
 	orc_apply_erosion(zvals, zvsize, zvsize, zmin, iters_tt);
@@ -824,6 +841,53 @@ void orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_
 	st->mzmin = mzmin; st->mzmax = mzmax;
 	st->radius = (float)(0.5*sqrt((double)((DX_VAL*DX_VAL + DY_VAL*DY_VAL)*size*size + (mzmax - mzmin)*(mzmax - mzmin))));
 	st->wx1 = wx1; st->wy1 = wy1; st->wx2 = wx2; st->wy2 = wy2;
+}
+
+/* f1: tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661): zvals[130*130] as create_zvals left them -> ao[129*129] */
+void orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao) {
+	unsigned const size = 128, stride = size+1, zvsize = stride+1, context_sz = stride + 2*AO_RAY_LEN;
+	int const x1 = tx*(int)size, y1 = ty*(int)size;
+	int ao_dirs[NUM_AO_DIRS][2];
+	unsigned ix = 0;
+	for (int y = -1; y <= 1; ++y) {
+		for (int x = -1; x <= 1; ++x) {
+			if (x != 0 || y != 0) {ao_dirs[ix][0] = x; ao_dirs[ix][1] = y; ++ix;}
+		}
+	}
+	int const use_ao_zvals = (enable_tiled_mesh_ao && mesh_gen_mode >= ORC_MGEN_SIMPLEX_GPU); /* ao_zvals of create_zvals: the whole context, interior included (:606) */
+	float *czv = (float *)malloc((size_t)context_sz*context_sz*sizeof(float));
+	grid_cache_t g;
+	gc_build_arrays(&g, (float)((x1 - AO_RAY_LEN) - MESH_X_SIZE/2), (float)((y1 - AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0); /* setup_height_gen_async (:609) */
+	gc_enable_glaciate(&g);
+	float const dz = (float)(0.5*(double)HALF_DXY); /* float const dz(0.5*HALF_DXY) (:611) */
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)context_sz; ++y) {
+		for (int x = 0; x < (int)context_sz; ++x) {
+			int const xv = x - AO_RAY_LEN, yv = y - AO_RAY_LEN;
+			if (!use_ao_zvals && xv >= 0 && yv >= 0 && xv < (int)zvsize && yv < (int)zvsize) {czv[y*context_sz + x] = zvals[yv*zvsize + xv];}
+			else {czv[y*context_sz + x] = gc_eval_index(&g, x, y, 0, 1);}
+		}
+	}
+	gc_free(&g);
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)stride; ++y) {
+		for (int x = 0; x < (int)stride; ++x) {
+			unsigned atten = 0;
+			for (unsigned d = 0; d < NUM_AO_DIRS; ++d) {
+				float z0 = zvals[y*zvsize + x];
+				int stepx = ao_dirs[d][0], stepy = ao_dirs[d][1], vx = x, vy = y;
+				for (unsigned s = 0; s < NUM_AO_STEPS; ++s) {
+					vx += stepx; vy += stepy;
+					z0 += dz;
+					stepx += ao_dirs[d][0]; stepy += ao_dirs[d][1]; /* linear increase: offsets 1,3,6,...,36 */
+					if (czv[(vy + AO_RAY_LEN)*context_sz + (vx + AO_RAY_LEN)] > z0) {atten += (NUM_AO_STEPS - s); break;} /* hit a higher point */
+				}
+			}
+			float const ao_scale = (float)(1.0 - (double)((float)atten/(float)(NUM_AO_DIRS*NUM_AO_STEPS))); /* float const ao_scale(1.0 - float(atten)/float(...)) */
+			ao[y*stride + x] = (unsigned char)(255.0*(double)ao_scale);
+		}
+	}
+	free(czv);
 }
 
 /* a13: normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880; vector3d::get_norm src/3DWorld.h) */

@@ -79,6 +79,8 @@ void  orc_rand_ints(long s1, long s2, int n, int *out);
 void  orc_rand_floats(long s1, long s2, int n, float *out);
 void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out);
 void  orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_tile_stats_t *st);
+void  orc_set_tiled_mesh_ao(int v);
+void  orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao);
 float orc_tile_normals(float const *zvals, unsigned char *rgba);
 void  orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out);
 void  orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],

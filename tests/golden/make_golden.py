@@ -62,6 +62,18 @@ def main():
     out["quant_bytes"] = q
     out["quant_range"] = np.array([mn, dz], np.float32)
     out["max_sea_level"] = np.float32(R.get_max_sea_level())
+    # row f1: tile AO lighting (tile_t::calc_mesh_ao_lighting) and the AO-context create_zvals of the GL modes (enable_tiled_mesh_ao)
+    out["tile_m3_7_ao"] = R.tile_ao_lighting(-3, 7, z)
+    z0, _ = R.tile_create_zvals(0, 0, 0)
+    out["tile_0_0_ao"] = R.tile_ao_lighting(0, 0, z0)
+    R.init(orclib.make_config(mesh_gen_mode=4))
+    R.set_tiled_mesh_ao(1)
+    z4, st4 = R.tile_create_zvals(2, -1, 40)
+    out["tile_m4ao_2_m1_z"] = z4
+    out["tile_m4ao_2_m1_stats"] = np.frombuffer(bytes(st4), np.uint8).copy()
+    out["tile_m4ao_2_m1_ao"] = R.tile_ao_lighting(2, -1, z4)
+    R.set_tiled_mesh_ao(0)
+    s = R.init(orclib.make_config(mesh_gen_mode=0))
     # voxels
     for mode in (0, 1, 2):
         nx, ny, nz = (40, 24, 32) if mode == 0 else (12, 10, 16)

@@ -120,6 +120,8 @@ class Checker:
         f("rand_uniforms", None, [C.c_long, C.c_long, C.c_float, C.c_float, C.c_int, C.c_void_p])
         f("tile_create_zvals", None, [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.POINTER(TileStats)])
         f("tile_normals", C.c_float, [C.c_void_p, C.c_void_p])
+        f("set_tiled_mesh_ao", None, [C.c_int])
+        f("tile_ao_lighting", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
         f("quantize16", None, [C.c_void_p, C.c_size_t, C.c_void_p, _fp, _fp])
         f("voxel_fill", None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int])
         f("voxel_rdata", None, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p])
@@ -200,6 +202,14 @@ class Checker:
         st = TileStats()
         self._tile_create_zvals(tx, ty, iters_tt, z.ctypes.data, C.byref(st))
         return z, st
+
+    def set_tiled_mesh_ao(self, v): self._set_tiled_mesh_ao(int(v))
+
+    def tile_ao_lighting(self, tx, ty, zvals):
+        assert zvals.dtype == np.float32 and zvals.shape == (130, 130) and zvals.flags.c_contiguous
+        ao = np.zeros((129, 129), np.uint8)
+        self._tile_ao_lighting(tx, ty, zvals.ctypes.data, ao.ctypes.data)
+        return ao
 
     def tile_normals(self, zvals):
         rgba = np.zeros((129, 129, 4), np.uint8)

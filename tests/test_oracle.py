@@ -1,3 +1,4 @@
+import os
 """CPU tests of the oracle (oracle/terra_oracle.c): against the reference's own translation units when they can be built
 here (oracle/_ref), and always against the golden vectors those produced (tests/golden/reference_vectors.npz)."""
 import numpy as np
@@ -76,6 +77,24 @@ def test_oracle_matches_golden_misc(orc):
     assert_bit_equal(orc.sin_table(), G["sin_table"])
 
 
+def test_oracle_matches_golden_tile_ao(orc):
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    orc.init(orclib.make_config(mesh_gen_mode=0))
+    z, _ = orc.tile_create_zvals(-3, 7, 150)
+    assert (orc.tile_ao_lighting(-3, 7, z) == G["tile_m3_7_ao"]).all()
+    z0, _ = orc.tile_create_zvals(0, 0, 0)
+    assert (orc.tile_ao_lighting(0, 0, z0) == G["tile_0_0_ao"]).all()
+    orc.init(orclib.make_config(mesh_gen_mode=4))
+    orc.set_tiled_mesh_ao(1)
+    try:
+        z4, st4 = orc.tile_create_zvals(2, -1, 40)
+        assert_bit_equal(z4, G["tile_m4ao_2_m1_z"], "AO-context zvals, mode 4")
+        assert bytes(st4) == G["tile_m4ao_2_m1_stats"].tobytes()
+        assert (orc.tile_ao_lighting(2, -1, z4) == G["tile_m4ao_2_m1_ao"]).all()
+    finally:
+        orc.set_tiled_mesh_ao(0)
+
+
 def test_oracle_vs_reference_tus(orc, ref):
     """Only where /root/reference exists: the restatement against the reference's own TUs on fresh (non-golden) inputs."""
     ref.set_num_threads(1)
@@ -116,6 +135,25 @@ def test_oracle_vs_reference_epilogue_configs(orc, ref):
             cfg = orclib.make_config(mesh_gen_mode=0, hmap=hm, **extra)
             sr, so = ref.init(cfg), orc.init(cfg)
             assert_bit_equal(ref.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), orc.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), f"{v} {extra}")
+
+
+def test_oracle_vs_reference_tile_ao(orc, ref):
+    """row f1 (tile_t::calc_mesh_ao_lighting) and the AO-context variant of create_zvals (enable_tiled_mesh_ao with the GL modes)."""
+    ref.set_num_threads(1)
+    try:
+        for mode, ao_flag, tiles in ((0, 0, [(0, 0), (-3, 2), (5, -7)]), (1, 1, [(1, 1)]), (4, 1, [(0, 0), (2, -1)]), (3, 1, [(-1, 0)]), (4, 0, [(0, 0)])):
+            cfg = orclib.make_config(mesh_gen_mode=mode)
+            ref.init(cfg); orc.init(cfg)
+            ref.set_tiled_mesh_ao(ao_flag); orc.set_tiled_mesh_ao(ao_flag)
+            for tx, ty in tiles:
+                for iters in (0, 60):
+                    za, sa = ref.tile_create_zvals(tx, ty, iters); zb, sb = orc.tile_create_zvals(tx, ty, iters)
+                    assert_bit_equal(za, zb, f"zvals mode {mode} ao {ao_flag} tile {tx},{ty} iters {iters}")
+                    a, b = ref.tile_ao_lighting(tx, ty, za), orc.tile_ao_lighting(tx, ty, zb)
+                    assert (a == b).all(), f"ao mode {mode} tile {tx},{ty}: {(a != b).sum()} texels differ"
+                    assert a.min() < 255 or za.max() - za.min() < 1e-3  # something is occluded on any non-flat tile
+    finally:
+        ref.set_tiled_mesh_ao(0); orc.set_tiled_mesh_ao(0)
 
 
 def test_libm_sincosf_is_not_correctly_rounded_but_reproducible():
