@@ -233,6 +233,26 @@ int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height
 }
 
 // ---- tiles
+int terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable) {TERRA_CHECK_CTX ctx->eng.tiled_mesh_ao = (enable != 0); return TERRA_OK;}
+int terra_tiles_ao_lighting_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_ao) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_ao)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.tiles_ao_lighting_dev(tile_xy, n, d_zvals, d_ao); TERRA_CATCH
+}
+int terra_tiles_ao_lighting(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, uint8_t *h_ao) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals || !h_ao)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (n == 0) return TERRA_OK;
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		size_t const zb = (size_t)n*130*130*4, ab = (size_t)n*129*129;
+		uint8_t *d = (uint8_t *)be.alloc(zb + ab);
+		try {
+			be.h2d(d, h_zvals, zb);
+			ctx->eng.tiles_ao_lighting_dev(tile_xy, n, (float const *)d, d + zb);
+			be.d2h(h_ao, d + zb, ab);
+		} catch (...) {be.free(d); throw;}
+		be.free(d);
+	TERRA_CATCH
+}
 int terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.tiles_create_zvals_dev(tile_xy, n, iters_tt, d_zvals, d_stats, d_normals, d_min_nz); TERRA_CATCH

@@ -67,6 +67,27 @@ TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsig
 }
 
 
+// one texel of tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:634-659): 8 directions x 8 steps at offsets 1,3,6,...,36 cells, the ray rises by
+// dz per step; the first context cell above the ray attenuates by (8 - step).  ctx(cx, cy): context value at context coordinates.
+template<class CTX> TERRA_HD uint8_t tile_ao_texel(float z_start, int x, int y, float dz, CTX ctx) {
+	unsigned atten = 0;
+	for (int dy = -1; dy <= 1; ++dy) {
+		for (int dx = -1; dx <= 1; ++dx) { // ao_dirs order (src/tiled_mesh.cpp:593-597); the sum does not depend on it
+			if (dx == 0 && dy == 0) continue;
+			float z0 = z_start;
+			int stepx = dx, stepy = dy, vx = x, vy = y;
+			for (unsigned s = 0; s < 8; ++s) {
+				vx += stepx; vy += stepy;
+				z0 += dz;
+				stepx += dx; stepy += dy;
+				if (ctx(vx + 36, vy + 36) > z0) {atten += (8 - s); break;}
+			}
+		}
+	}
+	float const ao_scale = (float)(1.0 - (double)((float)atten/(float)64));
+	return (uint8_t)(255.0*(double)ao_scale);
+}
+
 // tile_t::get_norm (src/tiled_mesh.h:281-284): n = normalize(DY*(z - z[+1]), DX*(z - z[+zvsize]), dxdy), pointT::get_norm (src/3DWorld.h:297-300, TOLERANCE :50)
 TERRA_HD void tile_normal(float const *z, unsigned x, unsigned y, float dxv, float dyv, float dxy, float nv[3]) {
 	unsigned const zv = 130, ix2 = y*zv + x;
@@ -95,7 +116,8 @@ template<class BE> struct terra_engine {
 
 	// grow-only device scratch
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
-	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_vox, s_sk, s_mm;
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_vox, s_sk, s_mm;
+	bool tiled_mesh_ao = false; // enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778)
 	uint32_t *spec_blocks_clean = nullptr; size_t spec_blocks_n = 0; // s_spec_blocks is known to be all-NIL for this pointer / block count
 	uint8_t *spec_logs_base = nullptr; uint32_t spec_logs_w = 0, spec_logs_cap = 0; // the log tables in s_spec satisfy their invariant for this layout
 	template<class T> T *scratch(scratch_t &s, size_t count) {
@@ -104,7 +126,7 @@ template<class BE> struct terra_engine {
 		return (T *)s.p;
 	}
 	~terra_engine() {
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 	}
 
@@ -567,10 +589,11 @@ template<class BE> struct terra_engine {
 	}
 
 	// ================================================================ tiles (a10, a13, K6, K7)
-	void tiles_create_zvals_dev(int32_t const *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
-		require_scene();
-		if (n == 0) return;
-		uint32_t const size = 128, stride = 129, zv = 130;
+	// One height field of tw x tw cells per tile, origin (tile*128 - shift) cells: setup_height_gen_async(height_gen, x1 - shift, y1 - shift, tw, tw)
+	// + the eval_index loop (src/tiled_mesh.cpp:458-464,480-488,494-505).  tw = 130, shift = 0: the tile's zvals; tw = 201, shift = 36: its AO context.
+	// Returns the device copy of the tile references (valid until the next tile call of this context).
+	tile_ref_pod_t const *tile_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out) {
+		uint32_t const size = 128, zv = tw;
 		// a tile's X table depends only on its tile x, its Y table only on its tile y: build each distinct one once
 		std::vector<int32_t> ux, uy;
 		for (uint32_t i = 0; i < n; ++i) {ux.push_back(tile_xy[2*i]); uy.push_back(tile_xy[2*i+1]);}
@@ -584,8 +607,8 @@ template<class BE> struct terra_engine {
 			refs[i].yi = (uint32_t)(std::lower_bound(uy.begin(), uy.end(), refs[i].ty) - uy.begin());
 		}
 		uint32_t const nux = (uint32_t)ux.size(), nuy = (uint32_t)uy.size();
-		// tables of all distinct tile columns / rows side by side, k-major like the big-grid tables: xt[k][u*130 + c], yt[k][u*130 + c].
-		// The batch is then ONE "virtual" (nux*130) x (nuy*130) sine grid whose cells are exactly the requested tiles' cells.
+		// tables of all distinct tile columns / rows side by side, k-major like the big-grid tables: xt[k][u*tw + c], yt[k][u*tw + c].
+		// The batch is then ONE "virtual" (nux*tw) x (nuy*tw) sine grid whose cells are exactly the requested tiles' cells.
 		uint32_t const nxpv = round_up(nux*zv, 128), nypv = round_up(nuy*zv, 128);
 		size_t const tab_floats = (size_t)F_TABLE_SIZE*(nxpv + nypv), sm_floats = (size_t)(nux + nuy)*zv;
 		size_t const bytes = refs.size()*sizeof(tile_ref_t) + (nux + nuy)*sizeof(sine_k_t) + (tab_floats + sm_floats)*4 + 1024;
@@ -595,11 +618,11 @@ template<class BE> struct terra_engine {
 		float *d_tab = (float *)((uint8_t *)d_sk + (((nux + nuy)*sizeof(sine_k_t) + 255) & ~(size_t)255));
 		float *d_sm = d_tab + tab_floats;
 		be.h2d(d_refs, refs.data(), refs.size()*sizeof(tile_ref_t));
-		// per distinct tx / ty: build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, 130, 130) (src/tiled_mesh.cpp:458-464)
+		// per distinct tx / ty: build_arrays((x0 - MESH_X_SIZE/2), (y0 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, tw, tw) with x0 = x1 - shift (src/tiled_mesh.cpp:458-464)
 		std::vector<sine_k_t> sks(nux + nuy);
 		std::vector<float> h_m0(nux + nuy);
-		for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)(ux[i]*(int)size - cfg.mesh_x/2); h_m0[i] = DX_VAL*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, DX_VAL, DY_VAL);}
-		for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)(uy[i]*(int)size - cfg.mesh_y/2); h_m0[nux+i] = DY_VAL*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], DX_VAL, DY_VAL);}
+		for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)((ux[i]*(int)size - shift) - cfg.mesh_x/2); h_m0[i] = DX_VAL*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, DX_VAL, DY_VAL);}
+		for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)((uy[i]*(int)size - shift) - cfg.mesh_y/2); h_m0[nux+i] = DY_VAL*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], DX_VAL, DY_VAL);}
 		be.h2d(d_sk, sks.data(), sks.size()*sizeof(sine_k_t));
 		float *d_m0 = scratch<float>(s_misc, nux + nuy + 16);
 		be.h2d(d_m0, h_m0.data(), h_m0.size()*4);
@@ -631,7 +654,30 @@ template<class BE> struct terra_engine {
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_zvals, md == MGEN_SINE && sine_plain_only(shp, kstart));
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw);
+		return d_refs;
+	}
+
+	static constexpr uint32_t AO_DIRS = 8, AO_STEPS = 8, AO_RAY_LEN = AO_STEPS*(AO_STEPS + 1)/2, AO_CTX = 129 + 2*AO_RAY_LEN; // src/tiled_mesh.cpp:41-43: 36, 201
+	// enable_tiled_mesh_ao with the GL noise modes: create_zvals clips the zvals from the AO context grid (src/tiled_mesh.cpp:478-488,505)
+	bool ao_context_zvals() const {return tiled_mesh_ao && mode >= MGEN_SIMPLEX_GPU;}
+
+	void tiles_create_zvals_dev(int32_t const *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
+		require_scene();
+		if (n == 0) return;
+		uint32_t const size = 128, zv = 130;
+		tile_ref_pod_t const *d_refs;
+		if (ao_context_zvals()) {
+			float *d_ctx = scratch<float>(s_ao, (size_t)n*AO_CTX*AO_CTX);
+			d_refs = tile_fields_dev(tile_xy, n, AO_CTX, (int)AO_RAY_LEN, d_ctx);
+			uint32_t const cs = AO_CTX, rl = AO_RAY_LEN;
+			be.launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
+				d_zvals[i] = d_ctx[(size_t)t*cs*cs + (size_t)(y + rl)*cs + (x + rl)];
+			});
+		}
+		else {d_refs = tile_fields_dev(tile_xy, n, zv, 0, d_zvals);}
+		float const dxv = DX_VAL, dyv = DY_VAL;
 		// erosion: every tile alone on its clamp-padded 138x138 copy, droplets in order (src/tiled_mesh.cpp:515)
 		if (iters_tt > 0 && erode_amount > 0.0f) {
 			erosion_consts_t const ec = make_erosion_consts((int)zv, (int)zv, zmin);
@@ -643,6 +689,25 @@ template<class BE> struct terra_engine {
 			float const rad_c = (dxv*dxv + dyv*dyv)*size*size;
 			be.tile_post(n, d_refs, d_zvals, d_stats, d_normals, d_min_nz, wpz_max, rad_c, dxv, dyv, dxdy);
 		}
+	}
+
+	// tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661): zvals as create_zvals left them -> 129 x 129 ambient-occlusion bytes per tile.
+	// The 201 x 201 context is the tile's own zvals inside the tile (possibly eroded) and eval_index() of the context grid around it; with
+	// enable_tiled_mesh_ao and a GL noise mode it is the context grid everywhere (ao_zvals kept by create_zvals).
+	void tiles_ao_lighting_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, uint8_t *d_ao) {
+		require_scene();
+		if (n == 0) return;
+		uint32_t const zv = 130, cs = AO_CTX, rl = AO_RAY_LEN;
+		float *d_ctx = scratch<float>(s_ao, (size_t)n*cs*cs);
+		tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);
+		if (!ao_context_zvals()) {
+			be.launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
+				d_ctx[(size_t)t*cs*cs + (size_t)(y + rl)*cs + (x + rl)] = d_zvals[i];
+			});
+		}
+		float const dz = (float)(0.5*(double)HALF_DXY);
+		be.tile_ao(n, d_zvals, d_ctx, d_ao, dz);
 	}
 
 	// ================================================================ voxels (a14, a15, K8, K9)

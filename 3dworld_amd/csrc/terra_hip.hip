@@ -117,7 +117,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup};
+		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup, 0};
 		if (job.plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<false, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);}
 		else                {hipLaunchKernelGGL((terra::k_sine_grid<false, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
@@ -138,11 +138,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw)
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
-		if (simple_kernels || md != terra::MGEN_SINE || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals); return;}
+		if (simple_kernels || md != terra::MGEN_SINE || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw); return;}
 		use();
 		size_t const cnt = (size_t)nux*nuy;
 		if (cnt > tile_map_count) {if (tile_map) {sync(); (void)hipFree(tile_map);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_map, cnt*sizeof(int32_t))); tile_map_count = cnt;}
@@ -150,15 +150,16 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		int32_t *tm = tile_map;
 		launch(n, [=] TERRA_LAMBDA (size_t i) {terra::tile_ref_pod_t const r = refs[i]; tm[(size_t)r.yi*nux + r.xi] = (int32_t)i;});
 		terra::grid_job_t job;
-		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*130; job.ny = nuy*130; job.nxp = nxpv; job.nyp = nypv;
+		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*tw; job.ny = nuy*tw; job.nxp = nxpv; job.nyp = nypv;
 		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup};
+		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup, tw};
 		job.plain_only = plain_only ? 1 : 0;
-		if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
-		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*130, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
+		if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
+		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
+	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {tile_ao_simple(n, z, ctx, ao, dz);}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
 		if (simple_kernels) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;}
 		use();

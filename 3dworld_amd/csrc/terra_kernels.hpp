@@ -64,7 +64,7 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 	return bx < ntx;
 }
 
-struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup;};
+struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup; uint32_t tw;}; // tw: cells per tile edge of the virtual grid (130 zvals, 201 AO context)
 
 typedef float sg_v2f __attribute__((ext_vector_type(2)));
 struct sg_operands_t {float4 xa, xb, ya, yb;};
@@ -216,9 +216,9 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 				}
 				else if (GENERAL && x + j < job.nx) {
 					if (TILES) { // general epilogue in tile-local coordinates (volcano term needs the tile's own origin)
-						unsigned const ux = (x + j)/130u, uy = y/130u;
+						unsigned const tw = tiles.tw, ux = (x + j)/tw, uy = y/tw;
 						grid_job_t jt = job; jt.mx0 = tiles.m0[ux]; jt.my0 = tiles.m0[tiles.nux + uy];
-						z = finish_cell(z, jt, nc, L, smx + ux*130u, smy + uy*130u, (x + j) - ux*130u, y - uy*130u);
+						z = finish_cell(z, jt, nc, L, smx + ux*tw, smy + uy*tw, (x + j) - ux*tw, y - uy*tw);
 					}
 					else {z = finish_cell(z, job, nc, L, smx, smy, x + j, y);}
 				}
@@ -227,13 +227,13 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 				if (x + j < job.nx) {fmn = fminf(fmn, z); fmx = fmaxf(fmx, z);} // fminf/fmaxf skip NaNs, like min_eq/max_eq never let a NaN win
 			}
 			if (TILES) {
-				unsigned const uy = y/130u, cy = y - uy*130u;
+				unsigned const tw = tiles.tw, uy = y/tw, cy = y - uy*tw;
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					if (x + j >= job.nx) continue;
-					unsigned const ux = (x + j)/130u, cx = (x + j) - ux*130u;
+					unsigned const ux = (x + j)/tw, cx = (x + j) - ux*tw;
 					int const t = tiles.tile_map[uy*tiles.nux + ux];
-					if (t >= 0) {out[(size_t)t*16900u + cy*130u + cx] = v[j];}
+					if (t >= 0) {out[(size_t)t*tw*tw + cy*tw + cx] = v[j];}
 				}
 				continue;
 			}

@@ -21,12 +21,11 @@ template<class DERIVED> struct simple_paths {
 			out[i] = finish_cell(noise_cell(job, nc, x, y), job, nc, L, smx, smy, x, y);
 		});
 	}
-	// tiles: xt / yt = k-major tables of all distinct tile columns / rows side by side (row lengths nxpv / nypv), d_sm = [nux + nuy][130] sine-mag terms,
+	// tiles: xt / yt = k-major tables of all distinct tile columns / rows side by side (row lengths nxpv / nypv), d_sm = [nux + nuy][zv] sine-mag terms,
 	// d_m0 = per distinct tx / ty grid origin (mx0 / my0)
 	void tile_grid_simple(uint32_t n, tile_ref_pod_t const *refs, uint32_t nux, uint32_t /*nuy*/, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv,
-		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals)
+		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals, uint32_t zv)
 	{
-		unsigned const zv = 130;
 		self().launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
 			tile_ref_pod_t const r = refs[t];
@@ -37,6 +36,15 @@ template<class DERIVED> struct simple_paths {
 			if (md == MGEN_SINE) {z = sine_cell(job, xt, yt, r.xi*zv + x, r.yi*zv + y);}
 			else {z = noise_cell(job, nc, x, y);}
 			zvals[i] = finish_cell(z, job, nc, L, d_sm + (size_t)r.xi*zv, d_sm + (size_t)(nux + r.yi)*zv, x, y);
+		});
+	}
+	// AO lighting, simple form: one logical thread per texel, context read from global memory
+	void tile_ao_simple(uint32_t n, float const *d_zvals, float const *d_ctx, uint8_t *d_ao, float dz) {
+		unsigned const stride = 129, zv = 130, cs = 201;
+		self().launch((size_t)n*stride*stride, [=] TERRA_LAMBDA (size_t i) {
+			unsigned const t = (unsigned)(i / (stride*stride)), p = (unsigned)(i % (stride*stride)), y = p / stride, x = p % stride;
+			float const *c = d_ctx + (size_t)t*cs*cs;
+			d_ao[i] = tile_ao_texel(d_zvals[(size_t)t*zv*zv + y*zv + x], (int)x, (int)y, dz, [=] TERRA_LAMBDA (int cx, int cy) {return c[cy*(int)cs + cx];});
 		});
 	}
 	// tile post-pass, simple form: sub-block ranges + water bbox (one logical thread per (tile, sub-block) then per tile), normals (one per texel)

@@ -108,6 +108,9 @@ _PROTOS = {
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
+    "terra_set_tiled_mesh_ao": (_i32, [_vp, _i32]),
+    "terra_tiles_ao_lighting_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "terra_tiles_ao_lighting": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "terra_minmax_dev": (_i32, [_vp, _vp, _sz, _f3, _f3]),
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
@@ -253,6 +256,17 @@ class Terra:
                                                     mnz.ctypes.data if normals else None))
         return z, st, nm, mnz
 
+    def set_tiled_mesh_ao(self, enable):
+        self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))
+
+    def tiles_ao_lighting(self, tile_xy, zvals):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        z = np.ascontiguousarray(zvals, np.float32).reshape(n, 130, 130)
+        ao = np.empty((n, 129, 129), np.uint8)
+        self._ck(self.lib.terra_tiles_ao_lighting(self.ctx, txy.ctypes.data, n, z.ctypes.data, ao.ctypes.data))
+        return ao
+
     def voxel_fill(self, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
         out = np.empty((ny, nx, nz), np.float32)
         a = lambda v: (C.c_float * 3)(*v)
@@ -297,6 +311,10 @@ class Terra:
     def tiles_create_zvals_dev(self, tile_xy, iters_tt, z_ptr, stats_ptr=None, normals_ptr=None, mnz_ptr=None):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
         self._ck(self.lib.terra_tiles_create_zvals_dev(self.ctx, txy.ctypes.data, len(txy), iters_tt, z_ptr, stats_ptr, normals_ptr, mnz_ptr))
+
+    def tiles_ao_lighting_dev(self, tile_xy, z_ptr, ao_ptr):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        self._ck(self.lib.terra_tiles_ao_lighting_dev(self.ctx, txy.ctypes.data, len(txy), z_ptr, ao_ptr))
 
     def voxel_fill_dev(self, ptr, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
         a = lambda v: (C.c_float * 3)(*v)

@@ -164,6 +164,16 @@ int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32
 int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
                               float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
 
+/* ---- tile ambient-occlusion lighting: tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661).  zvals: [n][130][130] exactly as
+ * terra_tiles_create_zvals left them (eroded or not); ao: [n][129][129] bytes = (unsigned char)(255*(1 - atten/64)).  The 201 x 201 context
+ * around each tile is generated internally (setup_height_gen_async(x1 - 36, y1 - 36, 201, 201)).
+ * terra_set_tiled_mesh_ao = the config key enable_tiled_mesh_ao (src/3DWorld.cpp:1778; scene_config/config.txt turns it on): with mesh_gen_mode >= 3 the
+ * reference clips a tile's zvals out of that context grid instead of a 130 x 130 grid of its own (src/tiled_mesh.cpp:478-488,505), which changes
+ * their low bits; terra_tiles_create_zvals follows the flag. */
+int  terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable);
+int  terra_tiles_ao_lighting_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_ao);
+int  terra_tiles_ao_lighting(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, uint8_t *h_ao);
+
 /* ---- voxels: voxel_manager::create_procedural fill (src/voxels.cpp:278-346).  out is z-fastest: ix = z + (x + y*nx)*nz (src/voxels.h:141-144). */
 int  terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
                           float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);

@@ -25,6 +25,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void timer_start() {t0 = std::chrono::steady_clock::now();}
 	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
 	template<class F> void launch_waves_nolds(size_t n, F f) {for (size_t i = 0; i < n; ++i) f(i);}
+	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {tile_ao_simple(n, z, ctx, ao, dz);}
 	bool graph_replay(void const *, size_t) {return false;} // no graphs here: every launch runs at once
 	bool graph_begin() {return false;}
 	void graph_end(void const *, size_t) {}
@@ -41,7 +42,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
-		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool /*plain_only*/) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals);}
+		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool /*plain_only*/, uint32_t tw) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw);}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
 		// tiles cycle through the three implementations: wave-cooperative whole-tile-in-LDS (k_tile_erosion's body; lanes run sequentially here), scalar, wave + window

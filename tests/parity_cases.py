@@ -211,6 +211,42 @@ def case_tile_golden(pkg, t):
     assert np.float32(t.max_sea_level()).view(np.uint32) == G["max_sea_level"].view(np.uint32)
 
 
+def case_tile_ao(pkg, t, orc):
+    """row f1: tile AO lighting against the reference's vectors (golden) and the oracle, for a batch of tiles (eroded and not), every noise
+    mode, and the AO-context variant of create_zvals that enable_tiled_mesh_ao switches on for the GL noise modes."""
+    G = golden()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    z, _, _, _ = t.tiles_create_zvals([(-3, 7)], 150)
+    assert (t.tiles_ao_lighting([(-3, 7)], z)[0] == G["tile_m3_7_ao"]).all()
+    z, _, _, _ = t.tiles_create_zvals([(0, 0)], 0)
+    assert (t.tiles_ao_lighting([(0, 0)], z)[0] == G["tile_0_0_ao"]).all()
+    t.init_scene(pkg.make_config(mesh_gen_mode=4))
+    t.set_tiled_mesh_ao(1)
+    try:
+        z, st, _, _ = t.tiles_create_zvals([(2, -1)], 40)
+        assert_bit_equal(z[0], G["tile_m4ao_2_m1_z"], "AO-context zvals, mode 4")
+        assert bytes(st[0]) == G["tile_m4ao_2_m1_stats"].tobytes()
+        assert (t.tiles_ao_lighting([(2, -1)], z)[0] == G["tile_m4ao_2_m1_ao"]).all()
+    finally:
+        t.set_tiled_mesh_ao(0)
+    # batches against the oracle
+    for mode, ao_flag, iters, tiles in ((0, 0, 0, [(tx, ty) for ty in range(-2, 2) for tx in range(-3, 3)]), (0, 0, 80, [(1, 1), (-4, 2), (0, -1)]),
+                                        (1, 1, 0, [(0, 0), (1, 0)]), (2, 0, 0, [(3, -2)]), (3, 1, 30, [(0, 1), (5, 5)]), (4, 1, 0, [(0, 0), (0, 1), (-1, 1)])):
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode)
+        t.init_scene(pc_); orc.init(oc)
+        t.set_tiled_mesh_ao(ao_flag); orc.set_tiled_mesh_ao(ao_flag)
+        try:
+            z, _, _, _ = t.tiles_create_zvals(tiles, iters)
+            ao = t.tiles_ao_lighting(tiles, z)
+            for i, (tx, ty) in enumerate(tiles):
+                zo, _ = orc.tile_create_zvals(tx, ty, iters)
+                assert_bit_equal(z[i], zo, f"zvals mode {mode} ao {ao_flag} tile {tx},{ty}")
+                want = orc.tile_ao_lighting(tx, ty, zo)
+                assert (ao[i] == want).all(), f"ao mode {mode} tile {tx},{ty}: {(ao[i] != want).sum()} texels differ"
+        finally:
+            t.set_tiled_mesh_ao(0); orc.set_tiled_mesh_ao(0)
+
+
 def case_voxels_golden(pkg, t):
     G = golden()
     t.init_scene(pkg.make_config(mesh_gen_mode=0))

@@ -46,6 +46,13 @@ for name, mode in (("sine", 0), ("simplex", 1)):
         if mode == 1 and it: continue
         ms = timed(lambda: t.tiles_create_zvals_dev(tiles, it, zt.ptr, stt.ptr, nm.ptr, mz.ptr), reps=2)
         out[f"C4_tiles64x64_{name}_{it}iters"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3), "gcells_s": round(n * 130 * 130 / ms / 1e6, 3)}
+# row f1: AO lighting for the same 64x64 tiles (201^2 context per tile + 8 x 8 ray march per texel)
+t.init_scene(pkg.make_config(mesh_gen_mode=0))
+t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
+ao = t.alloc(n * 129 * 129)
+ms = timed(lambda: t.tiles_ao_lighting_dev(tiles, zt.ptr, ao.ptr), reps=2)
+out["F1_tile_ao_64x64_sine"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+ao.free()
 for b in (zt, stt, nm, mz): b.free()
 # C5: voxels
 t.init_scene(pkg.make_config(mesh_gen_mode=0))
@@ -87,6 +94,11 @@ if "--no-cpu" not in sys.argv:
     cpu["C4_tiles_sine_0iters_tiles_per_s_serial_calls"] = round(nt / dt)
     dt, _ = wall(lambda: [ck.tile_create_zvals(tx, ty, 1000) for ty in range(-2, 2) for tx in range(-2, 2)])
     cpu["C4_tiles_sine_1000iters_tiles_per_s_serial_calls"] = round(16 / dt, 1)
+    ck.set_num_threads(4)  # calc_mesh_ao_lighting: "#pragma omp parallel num_threads(4)" (src/tiled_mesh.cpp:614-616)
+    zs_ = [ck.tile_create_zvals(tx, ty, 0)[0] for ty in range(-2, 2) for tx in range(-2, 2)]
+    dt, _ = wall(lambda: [ck.tile_ao_lighting(tx, ty, zs_[(ty + 2) * 4 + (tx + 2)]) for ty in range(-2, 2) for tx in range(-2, 2)])
+    cpu["F1_tile_ao_tiles_per_s_4thr"] = round(16 / dt, 1)
+    ck.set_num_threads(cores)
     dims = (256, 256, 64)
     dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, 0, 0.01, 1))
     cpu["C5_voxels_256x256x64_sines_gvoxels_s"] = round(dims[0] * dims[1] * dims[2] / dt / 1e9, 4)
