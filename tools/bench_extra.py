@@ -88,12 +88,12 @@ if "--no-cpu" not in sys.argv:
         g = g0.copy()
         dt, _ = wall(lambda: ck.apply_erosion(g, float(g0.min()), D))
         cpu[f"C3_erosion_4096_{D}_droplets_{thr}thr"] = {"ms": round(dt * 1e3, 1), "droplets_per_s": round(D / dt), "deterministic": thr == 1}
-    ck.set_num_threads(cores)
+    ck.set_num_threads(8)  # 130 rows per tile: more threads only add fork/join cost (256 threads: 8 tiles/s)
     nt = 64
     dt, _ = wall(lambda: [ck.tile_create_zvals(tx, ty, 0) for ty in range(-4, 4) for tx in range(-4, 4)])
-    cpu["C4_tiles_sine_0iters_tiles_per_s_serial_calls"] = round(nt / dt)
+    cpu["C4_tiles_sine_0iters_tiles_per_s_8thr"] = round(nt / dt)
     dt, _ = wall(lambda: [ck.tile_create_zvals(tx, ty, 1000) for ty in range(-2, 2) for tx in range(-2, 2)])
-    cpu["C4_tiles_sine_1000iters_tiles_per_s_serial_calls"] = round(16 / dt, 1)
+    cpu["C4_tiles_sine_1000iters_tiles_per_s_8thr"] = round(16 / dt, 1)
     ck.set_num_threads(4)  # calc_mesh_ao_lighting: "#pragma omp parallel num_threads(4)" (src/tiled_mesh.cpp:614-616)
     zs_ = [ck.tile_create_zvals(tx, ty, 0)[0] for ty in range(-2, 2) for tx in range(-2, 2)]
     dt, _ = wall(lambda: [ck.tile_ao_lighting(tx, ty, zs_[(ty + 2) * 4 + (tx + 2)]) for ty in range(-2, 2) for tx in range(-2, 2)])
