@@ -89,6 +89,10 @@ inline void tiles_create_zvals(int const *tile_xy, unsigned n, unsigned erosion_
 	check(terra_tiles_create_zvals(default_ctx(), tile_xy, n, erosion_iters_tt, zvals, stats, normals, min_normal_z), "tiles_create_zvals");
 }
 
+// ---- tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661) for a batch: zvals [n][130][130] -> ao_lighting [n][129][129]
+inline void tiles_ao_lighting(int const *tile_xy, unsigned n, float const *zvals, unsigned char *ao) {
+	check(terra_tiles_ao_lighting(default_ctx(), tile_xy, n, zvals, ao), "calc_mesh_ao_lighting");
+}
 // voxel_manager::create_procedural fill (src/voxels.cpp:278-346): `vals` is the voxel_grid<float> storage, z fastest
 inline void voxel_create_procedural(std::vector<float> &vals, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],
 	float mag, float freq, bool normalize_to_1, int rseed1, int rseed2, int gen_mode, float zscale)
