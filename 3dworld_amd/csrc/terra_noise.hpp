@@ -19,6 +19,23 @@ TERRA_HD float gl_permute(float x) {return gl_mod289(((x*34.0f) + 1.0f)*x);}
 TERRA_HD float gl_tinvsqrt(float r) {return 1.79284291400159f - 0.85373472095314f*r;}
 TERRA_HD float gl_fade(float t)    {return (t*t*t)*(t*(t*6.0f - 15.0f) + 10.0f);}
 TERRA_HD float gl_mod(float a, float b) {return a - b*floorf(a/b);}
+// glm::mod(a, 289.0f) for the integer-valued arguments the lattice code passes (floor() results): for |a| < 2^23 every step below is exact,
+// so the IEEE division of a - b*floor(a/b) can be replaced by a reciprocal estimate of the quotient and one range correction; anything
+// else (huge, inf, NaN) takes the division.  Checked against the division on 2.6e6 integers incl. negatives and on the GPU by the parity tests.
+TERRA_HD float gl_mod289_int(float a) {
+	if (!(fabsf(a) < 8388608.0f)) return gl_mod(a, 289.0f);
+	float const q = floorf(a*(1.0f/289.0f));
+	float r = a - q*289.0f;
+	r = (r < 0.0f) ? r + 289.0f : r;
+	r = (r >= 289.0f) ? r - 289.0f : r;
+	return r;
+}
+// h/41.0f for h = permute(...) in {0, ..., 288}: the correctly rounded quotient by one FMA correction of h*RN(1/41) (all 289 values checked:
+// bit-identical to the IEEE division; a plain multiplication differs on 132 of them)
+TERRA_HD float gl_div41(float h) {
+	float const r = 1.0f/41.0f, q0 = h*r;
+	return fmaf(fmaf(-q0, 41.0f, h), r, q0);
+}
 TERRA_HD float gl_fract(float x)   {return x - floorf(x);}
 TERRA_HD float gl_mix(float x, float y, float a) {return x + a*(y - x);}
 TERRA_HD float gl_step(float edge, float x) {return (x < edge) ? 0.0f : 1.0f;}
@@ -34,7 +51,7 @@ TERRA_HD float simplex2(float vx, float vy) {
 	float const ox = lower ? 1.0f : 0.0f, oy = lower ? 0.0f : 1.0f; // i1
 	float const bx = (ax + C0) - ox, by = (ay + C0) - oy;   // x12.xy
 	float const ex = ax + C2, ey = ay + C2;                 // x12.zw
-	cx = gl_mod(cx, 289.0f); cy = gl_mod(cy, 289.0f);
+	cx = gl_mod289_int(cx); cy = gl_mod289_int(cy);
 	float const pa = gl_permute(gl_permute(cy + 0.0f) + cx + 0.0f);
 	float const pb = gl_permute(gl_permute(cy + oy  ) + cx + ox  );
 	float const pc = gl_permute(gl_permute(cy + 1.0f) + cx + 1.0f);
@@ -60,8 +77,8 @@ TERRA_HD float simplex2(float vx, float vy) {
 TERRA_HD float perlin2(float px, float py) {
 	float const flx = floorf(px), fly = floorf(py);
 	float const frx = px - flx, fry = py - fly;                    // fract
-	float const cx0 = gl_mod(flx + 0.0f, 289.0f), cy0 = gl_mod(fly + 0.0f, 289.0f);
-	float const cx1 = gl_mod(flx + 1.0f, 289.0f), cy1 = gl_mod(fly + 1.0f, 289.0f);
+	float const cx0 = gl_mod289_int(flx + 0.0f), cy0 = gl_mod289_int(fly + 0.0f);
+	float const cx1 = gl_mod289_int(flx + 1.0f), cy1 = gl_mod289_int(fly + 1.0f);
 	float const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
 	// corner order of the vec4 lanes: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
 	float gx[4], gy[4];
@@ -69,7 +86,7 @@ TERRA_HD float perlin2(float px, float py) {
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
 		float const h = gl_permute(gl_permute(cxs[c]) + cys[c]);
-		float const g = 2.0f*gl_fract(h/41.0f) - 1.0f;
+		float const g = 2.0f*gl_fract(gl_div41(h)) - 1.0f; // h/41.0f
 		gy[c] = fabsf(g) - 0.5f;
 		gx[c] = g - floorf(g + 0.5f);
 	}

@@ -82,3 +82,20 @@ extern "C" unsigned long long terra_emul_powf_mismatches(unsigned long long n, u
 	}
 	return bad;
 }
+
+// the division-free lattice helpers of terra_noise.hpp against the divisions they replace
+extern "C" unsigned long long terra_emul_noise_helper_mismatches() {
+	unsigned long long bad = 0;
+	uint32_t seed = 99;
+	auto rnd = [&]() {seed = seed*1664525u + 1013904223u; return seed;};
+	for (int i = -400; i <= 700; ++i) {float const h = (float)i, a = h/41.0f, b = terra::gl_div41(h); if (memcmp(&a, &b, 4) != 0) ++bad;}
+	for (int i = -600000; i <= 600000; ++i) {float const v = (float)i, a = terra::gl_mod(v, 289.0f), b = terra::gl_mod289_int(v); if (memcmp(&a, &b, 4) != 0) ++bad;}
+	for (int i = 0; i < 4000000; ++i) {
+		float const v = (float)((int)(rnd() >> 7) - (1 << 24)); // integers in [-2^24, 2^24): both sides of the 2^23 switch to the division
+		float const a = terra::gl_mod(v, 289.0f), b = terra::gl_mod289_int(v);
+		if (memcmp(&a, &b, 4) != 0) ++bad;
+	}
+	float const special[] = {INFINITY, -INFINITY, NAN, 1e30f, -1e30f, 8388608.0f, -8388608.0f, 8388607.0f};
+	for (float v : special) {float const a = terra::gl_mod(v, 289.0f), b = terra::gl_mod289_int(v); if (memcmp(&a, &b, 4) != 0 && !(a != a && b != b)) ++bad;}
+	return bad;
+}

@@ -20,6 +20,15 @@ def test_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force):
     pc.case_grid_vs_oracle(pkg, emul, orc, mode, n, mss, force)
 
 
+def test_division_free_lattice_helpers(emul_lib):
+    """glm::mod(x, 289) on lattice coordinates and h/41 in glm::perlin are IEEE divisions in the reference; terra_noise.hpp computes the same
+    bits without dividing (exactness argument in the header): 5.2e6 arguments incl. both sides of the fall-back threshold, inf and NaN."""
+    import ctypes
+    lib = ctypes.CDLL(emul_lib)
+    lib.terra_emul_noise_helper_mismatches.restype = ctypes.c_ulonglong
+    assert lib.terra_emul_noise_helper_mismatches() == 0
+
+
 def test_powf_restatement_matches_libm(emul_lib):
     """glaciate's pow(relh, custom_glaciate_exp) is libm powf in the reference; 3dworld_amd/csrc/terra_powf.hpp restates glibc's algorithm so the
     device gets the same bits (ocml powf does not).  4*10^6 arguments here, 5*10^7 when the header was written."""
