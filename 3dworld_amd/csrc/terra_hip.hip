@@ -126,7 +126,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *mm) {
 		if (simple_kernels) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 		use();
-		dim3 const grid((job.nx + 63)/64, (job.ny + 3)/4), block(256);
+		dim3 const grid((job.nx + 127)/128, (job.ny + 3)/4), block(256); // 64 lanes x 2 cells per row segment, 4 rows per block
 		switch (job.mode) {
 		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
 		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;

@@ -253,13 +253,20 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 
 // ------------------------------------------------------------------ K2/K3: fBm / domain-warp grid, one cell per thread, x fastest
 template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, uint32_t *__restrict__ mm) {
-	unsigned const x = blockIdx.x*64 + (threadIdx.x & 63), y = blockIdx.y*4 + (threadIdx.x >> 6);
+	// two neighbouring cells of a row per lane: the lattice noise runs on register pairs (v_pk_mul_f32 / v_pk_add_f32), see terra_noise.hpp
+	unsigned const x = (blockIdx.x*64 + (threadIdx.x & 63))*2, y = blockIdx.y*4 + (threadIdx.x >> 6);
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu;
 	if (x < job.nx && y < job.ny) {
-		float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
-		float const z = finish_cell(noise_zval<MODE>(xval, yval, job.shape, nc), job, nc, L, smx, smy, x, y);
-		out[(size_t)y*job.nx + x] = z;
-		minmax_acc(z, mm_lo, mm_hi);
+		float const xv0 = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, xv1 = ((float)(x + 1)*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+		nv2 const zz = noise_zval_t<MODE, nv2>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc);
+		float const z0 = finish_cell(zz[0], job, nc, L, smx, smy, x, y);
+		out[(size_t)y*job.nx + x] = z0;
+		minmax_acc(z0, mm_lo, mm_hi);
+		if (x + 1 < job.nx) {
+			float const z1 = finish_cell(zz[1], job, nc, L, smx, smy, x + 1, y);
+			out[(size_t)y*job.nx + x + 1] = z1;
+			minmax_acc(z1, mm_lo, mm_hi);
+		}
 	}
 	if (mm) {wave_minmax_publish(mm_lo, mm_hi, mm);}
 }

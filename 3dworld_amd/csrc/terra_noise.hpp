@@ -13,94 +13,123 @@
 
 namespace terra {
 
+// ---- two cells per lane.  The 2-D lattice noise below is written once, as templates over the arithmetic type T: float (one cell; what the
+// host emulator, the 3-D noise and the point queries use) or nv2 = two floats in a 64-bit register pair (two neighbouring cells of a row).
+// With nv2 every multiply / add / subtract becomes one v_pk_mul_f32 / v_pk_add_f32 for both cells -- the same IEEE operations in the same
+// order, so the results are bit-identical to the one-cell instantiation (tests/emul: terra_emul_noise_x2_mismatches; GPU parity tests).
+typedef float nv2 __attribute__((vector_size(8)));
+typedef int   ni2 __attribute__((vector_size(8)));
+template<class T> struct nt_traits;
+template<> struct nt_traits<float> {typedef bool mask_t;};
+template<> struct nt_traits<nv2>   {typedef ni2  mask_t;};
+TERRA_HD float nt_floor(float a) {return floorf(a);}
+TERRA_HD nv2   nt_floor(nv2 a)   {return nv2{floorf(a[0]), floorf(a[1])};}
+TERRA_HD float nt_abs(float a) {return fabsf(a);}
+TERRA_HD nv2   nt_abs(nv2 a)   {return nv2{fabsf(a[0]), fabsf(a[1])};}
+TERRA_HD float nt_sel(bool m, float a, float b) {return m ? a : b;}
+TERRA_HD nv2   nt_sel(ni2 m, nv2 a, nv2 b) {return nv2{m[0] ? a[0] : b[0], m[1] ? a[1] : b[1]};}
+TERRA_HD float nt_max_std(float a, float b) {return (a < b) ? b : a;} // std::max
+TERRA_HD nv2   nt_max_std(nv2 a, nv2 b) {return nt_sel(a < b, b, a);}
+TERRA_HD float nt_fma(float a, float b, float c) {return fmaf(a, b, c);}
+TERRA_HD nv2   nt_fma(nv2 a, nv2 b, nv2 c) {return nv2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};}
+template<class T> TERRA_HD T nt_bc(float v);
+template<> TERRA_HD float nt_bc<float>(float v) {return v;}
+template<> TERRA_HD nv2   nt_bc<nv2>(float v)   {return nv2{v, v};}
+TERRA_HD bool nt_all_below(float a, float lim) {return fabsf(a) < lim;}
+TERRA_HD bool nt_all_below(nv2 a, float lim) {return fabsf(a[0]) < lim && fabsf(a[1]) < lim;}
+
 // ---- GLM scalar helpers (detail/_noise.hpp:14-84, detail/func_common.inl:123-131,211-218,386-398,543-546)
-TERRA_HD float gl_mod289(float x)  {return x - floorf(x*(1.0f/289.0f))*289.0f;}
-TERRA_HD float gl_permute(float x) {return gl_mod289(((x*34.0f) + 1.0f)*x);}
+template<class T> TERRA_HD T gl_mod289(T x)  {return x - nt_floor(x*(1.0f/289.0f))*289.0f;}
+template<class T> TERRA_HD T gl_permute(T x) {return gl_mod289(((x*34.0f) + 1.0f)*x);}
 TERRA_HD float gl_tinvsqrt(float r) {return 1.79284291400159f - 0.85373472095314f*r;}
-TERRA_HD float gl_fade(float t)    {return (t*t*t)*(t*(t*6.0f - 15.0f) + 10.0f);}
+template<class T> TERRA_HD T gl_fade(T t)    {return (t*t*t)*(t*(t*6.0f - 15.0f) + 10.0f);}
 TERRA_HD float gl_mod(float a, float b) {return a - b*floorf(a/b);}
 // glm::mod(a, 289.0f) for the integer-valued arguments the lattice code passes (floor() results): for |a| < 2^23 every step below is exact,
 // so the IEEE division of a - b*floor(a/b) can be replaced by a reciprocal estimate of the quotient and one range correction; anything
-// else (huge, inf, NaN) takes the division.  Checked against the division on 2.6e6 integers incl. negatives and on the GPU by the parity tests.
-TERRA_HD float gl_mod289_int(float a) {
-	if (!(fabsf(a) < 8388608.0f)) return gl_mod(a, 289.0f);
-	float const q = floorf(a*(1.0f/289.0f));
-	float r = a - q*289.0f;
-	r = (r < 0.0f) ? r + 289.0f : r;
-	r = (r >= 289.0f) ? r - 289.0f : r;
+// else (huge, inf, NaN) takes the division.  Checked against the division on 5.2e6 integers incl. negatives and on the GPU by the parity tests.
+template<class T> TERRA_HD T gl_mod289_int_fast(T a) {
+	T const q = nt_floor(a*(1.0f/289.0f));
+	T r = a - q*289.0f;
+	r = nt_sel(r < 0.0f, r + 289.0f, r);
+	r = nt_sel(r >= 289.0f, r - 289.0f, r);
 	return r;
 }
-// h/41.0f for h = permute(...) in {0, ..., 288}: the correctly rounded quotient by one FMA correction of h*RN(1/41) (all 289 values checked:
-// bit-identical to the IEEE division; a plain multiplication differs on 132 of them)
-TERRA_HD float gl_div41(float h) {
-	float const r = 1.0f/41.0f, q0 = h*r;
-	return fmaf(fmaf(-q0, 41.0f, h), r, q0);
+TERRA_HD float gl_mod289_int(float a) {return nt_all_below(a, 8388608.0f) ? gl_mod289_int_fast(a) : gl_mod(a, 289.0f);}
+TERRA_HD nv2   gl_mod289_int(nv2 a)   {return nt_all_below(a, 8388608.0f) ? gl_mod289_int_fast(a) : nv2{gl_mod289_int(a[0]), gl_mod289_int(a[1])};}
+// h/41.0f for h = permute(...) in {0, ..., 288}: the correctly rounded quotient by one FMA correction of h*RN(1/41) (every integer in
+// [-400, 700] checked: bit-identical to the IEEE division; a plain multiplication differs on 132 of the 289 values)
+template<class T> TERRA_HD T gl_div41(T h) {
+	T const r = nt_bc<T>(1.0f/41.0f), q0 = h*r;
+	return nt_fma(nt_fma(-q0, nt_bc<T>(41.0f), h), r, q0);
 }
-TERRA_HD float gl_fract(float x)   {return x - floorf(x);}
-TERRA_HD float gl_mix(float x, float y, float a) {return x + a*(y - x);}
+template<class T> TERRA_HD T gl_fract(T x)   {return x - nt_floor(x);}
+template<class T> TERRA_HD T gl_mix(T x, T y, T a) {return x + a*(y - x);}
 TERRA_HD float gl_step(float edge, float x) {return (x < edge) ? 0.0f : 1.0f;}
 
 // glm::simplex(vec2)  (gtc/noise.inl:592-646)
-TERRA_HD float simplex2(float vx, float vy) {
+template<class T> TERRA_HD T simplex2_t(T vx, T vy) {
 	float const C0 = 0.211324865405187f, C1 = 0.366025403784439f, C2 = -0.577350269189626f, C3 = 0.024390243902439f;
-	float const skew = vx*C1 + vy*C1;                       // dot(v, C.yy)
-	float cx = floorf(vx + skew), cy = floorf(vy + skew);   // first corner (skewed cell)
-	float const unskew = cx*C0 + cy*C0;                     // dot(i, C.xx)
-	float const ax = vx - cx + unskew, ay = vy - cy + unskew; // x0
-	bool  const lower = (ax > ay);
-	float const ox = lower ? 1.0f : 0.0f, oy = lower ? 0.0f : 1.0f; // i1
-	float const bx = (ax + C0) - ox, by = (ay + C0) - oy;   // x12.xy
-	float const ex = ax + C2, ey = ay + C2;                 // x12.zw
+	T const one = nt_bc<T>(1.0f), zero = nt_bc<T>(0.0f);
+	T const skew = vx*C1 + vy*C1;                           // dot(v, C.yy)
+	T cx = nt_floor(vx + skew), cy = nt_floor(vy + skew);   // first corner (skewed cell)
+	T const unskew = cx*C0 + cy*C0;                         // dot(i, C.xx)
+	T const ax = vx - cx + unskew, ay = vy - cy + unskew;   // x0
+	typename nt_traits<T>::mask_t const lower = (ax > ay);
+	T const ox = nt_sel(lower, one, zero), oy = nt_sel(lower, zero, one); // i1
+	T const bx = (ax + C0) - ox, by = (ay + C0) - oy;       // x12.xy
+	T const ex = ax + C2, ey = ay + C2;                     // x12.zw
 	cx = gl_mod289_int(cx); cy = gl_mod289_int(cy);
-	float const pa = gl_permute(gl_permute(cy + 0.0f) + cx + 0.0f);
-	float const pb = gl_permute(gl_permute(cy + oy  ) + cx + ox  );
-	float const pc = gl_permute(gl_permute(cy + 1.0f) + cx + 1.0f);
-	float ma = max_std(0.5f - (ax*ax + ay*ay), 0.0f);
-	float mb = max_std(0.5f - (bx*bx + by*by), 0.0f);
-	float mc = max_std(0.5f - (ex*ex + ey*ey), 0.0f);
+	T const pa = gl_permute(gl_permute(cy + 0.0f) + cx + 0.0f);
+	T const pb = gl_permute(gl_permute(cy + oy  ) + cx + ox  );
+	T const pc = gl_permute(gl_permute(cy + 1.0f) + cx + 1.0f);
+	T ma = nt_max_std(0.5f - (ax*ax + ay*ay), zero);
+	T mb = nt_max_std(0.5f - (bx*bx + by*by), zero);
+	T mc = nt_max_std(0.5f - (ex*ex + ey*ey), zero);
 	ma = ma*ma; mb = mb*mb; mc = mc*mc;
 	ma = ma*ma; mb = mb*mb; mc = mc*mc;
 	// gradients: 41 points on a line mapped onto a diamond
-	float const ga = 2.0f*gl_fract(pa*C3) - 1.0f, gb = 2.0f*gl_fract(pb*C3) - 1.0f, gc = 2.0f*gl_fract(pc*C3) - 1.0f;
-	float const ha = fabsf(ga) - 0.5f, hb = fabsf(gb) - 0.5f, hc = fabsf(gc) - 0.5f;
-	float const a0a = ga - floorf(ga + 0.5f), a0b = gb - floorf(gb + 0.5f), a0c = gc - floorf(gc + 0.5f);
+	T const ga = 2.0f*gl_fract(pa*C3) - 1.0f, gb = 2.0f*gl_fract(pb*C3) - 1.0f, gc = 2.0f*gl_fract(pc*C3) - 1.0f;
+	T const ha = nt_abs(ga) - 0.5f, hb = nt_abs(gb) - 0.5f, hc = nt_abs(gc) - 0.5f;
+	T const a0a = ga - nt_floor(ga + 0.5f), a0b = gb - nt_floor(gb + 0.5f), a0c = gc - nt_floor(gc + 0.5f);
 	ma *= 1.79284291400159f - 0.85373472095314f*(a0a*a0a + ha*ha);
 	mb *= 1.79284291400159f - 0.85373472095314f*(a0b*a0b + hb*hb);
 	mc *= 1.79284291400159f - 0.85373472095314f*(a0c*a0c + hc*hc);
-	float const da = a0a*ax + ha*ay;
-	float const db = a0b*bx + hb*by;
-	float const dc = a0c*ex + hc*ey;
+	T const da = a0a*ax + ha*ay;
+	T const db = a0b*bx + hb*by;
+	T const dc = a0c*ex + hc*ey;
 	return 130.0f*(ma*da + mb*db + mc*dc);
 }
+TERRA_HD float simplex2(float vx, float vy) {return simplex2_t<float>(vx, vy);}
 
 // glm::perlin(vec2)  (gtc/noise.inl:25-62)
-TERRA_HD float perlin2(float px, float py) {
-	float const flx = floorf(px), fly = floorf(py);
-	float const frx = px - flx, fry = py - fly;                    // fract
-	float const cx0 = gl_mod289_int(flx + 0.0f), cy0 = gl_mod289_int(fly + 0.0f);
-	float const cx1 = gl_mod289_int(flx + 1.0f), cy1 = gl_mod289_int(fly + 1.0f);
-	float const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
+template<class T> TERRA_HD T perlin2_t(T px, T py) {
+	T const flx = nt_floor(px), fly = nt_floor(py);
+	T const frx = px - flx, fry = py - fly;                    // fract
+	T const cx0 = gl_mod289_int(flx + 0.0f), cy0 = gl_mod289_int(fly + 0.0f);
+	T const cx1 = gl_mod289_int(flx + 1.0f), cy1 = gl_mod289_int(fly + 1.0f);
+	T const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
 	// corner order of the vec4 lanes: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
-	float gx[4], gy[4];
-	float const cxs[4] = {cx0, cx1, cx0, cx1}, cys[4] = {cy0, cy0, cy1, cy1};
+	T gx[4], gy[4];
+	T const cxs[4] = {cx0, cx1, cx0, cx1}, cys[4] = {cy0, cy0, cy1, cy1};
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
-		float const h = gl_permute(gl_permute(cxs[c]) + cys[c]);
-		float const g = 2.0f*gl_fract(gl_div41(h)) - 1.0f; // h/41.0f
-		gy[c] = fabsf(g) - 0.5f;
-		gx[c] = g - floorf(g + 0.5f);
+		T const h = gl_permute(gl_permute(cxs[c]) + cys[c]);
+		T const g = 2.0f*gl_fract(gl_div41(h)) - 1.0f; // h/41.0f
+		gy[c] = nt_abs(g) - 0.5f;
+		gx[c] = g - nt_floor(g + 0.5f);
 	}
 	// norm = taylorInvSqrt(dot(g00), dot(g01), dot(g10), dot(g11)); lanes: g00=0 g10=1 g01=2 g11=3
-	float const n00 = gl_tinvsqrt(gx[0]*gx[0] + gy[0]*gy[0]), n01 = gl_tinvsqrt(gx[2]*gx[2] + gy[2]*gy[2]);
-	float const n10 = gl_tinvsqrt(gx[1]*gx[1] + gy[1]*gy[1]), n11 = gl_tinvsqrt(gx[3]*gx[3] + gy[3]*gy[3]);
-	float const d00 = (gx[0]*n00)*fx0 + (gy[0]*n00)*fy0;
-	float const d10 = (gx[1]*n10)*fx1 + (gy[1]*n10)*fy0;
-	float const d01 = (gx[2]*n01)*fx0 + (gy[2]*n01)*fy1;
-	float const d11 = (gx[3]*n11)*fx1 + (gy[3]*n11)*fy1;
-	float const ux = gl_fade(fx0), uy = gl_fade(fy0);
-	float const lo = gl_mix(d00, d10, ux), hi = gl_mix(d01, d11, ux);
+	T const n00 = 1.79284291400159f - 0.85373472095314f*(gx[0]*gx[0] + gy[0]*gy[0]), n01 = 1.79284291400159f - 0.85373472095314f*(gx[2]*gx[2] + gy[2]*gy[2]);
+	T const n10 = 1.79284291400159f - 0.85373472095314f*(gx[1]*gx[1] + gy[1]*gy[1]), n11 = 1.79284291400159f - 0.85373472095314f*(gx[3]*gx[3] + gy[3]*gy[3]);
+	T const d00 = (gx[0]*n00)*fx0 + (gy[0]*n00)*fy0;
+	T const d10 = (gx[1]*n10)*fx1 + (gy[1]*n10)*fy0;
+	T const d01 = (gx[2]*n01)*fx0 + (gy[2]*n01)*fy1;
+	T const d11 = (gx[3]*n11)*fx1 + (gy[3]*n11)*fy1;
+	T const ux = gl_fade(fx0), uy = gl_fade(fy0);
+	T const lo = gl_mix(d00, d10, ux), hi = gl_mix(d01, d11, ux);
 	return 2.3f*gl_mix(lo, hi, uy);
 }
+TERRA_HD float perlin2(float px, float py) {return perlin2_t<float>(px, py);}
 
 // glm::perlin(vec3)  (gtc/noise.inl:66-133)
 TERRA_HD float perlin3(float px, float py, float pz) {
@@ -206,13 +235,19 @@ TERRA_HD float apply_noise_shape_final(float n, int shape, hmap_params_t const &
 }
 
 // ---- fBm (gen_noise, src/mesh_gen.cpp:706-730). SIMPLEX selects glm::simplex vs glm::perlin.
-template<bool SIMPLEX> TERRA_HD float fbm2(float xv, float yv, int shape, unsigned end_octave, float rx, float ry) {
-	float zval = 0.0f, mag = 1.0f, freq = 1.0f;
+TERRA_HD float nt_octave_shape(float n, int shape) { // billowy / ridged octave: the constant is a double in the reference
+	if      (shape == 1) {n = (float)((double)fabsf(n) - 0.40);}
+	else if (shape == 2) {n = (float)(0.45 - (double)fabsf(n));}
+	return n;
+}
+TERRA_HD nv2 nt_octave_shape(nv2 n, int shape) {return nv2{nt_octave_shape(n[0], shape), nt_octave_shape(n[1], shape)};}
+template<bool SIMPLEX, class T> TERRA_HD T fbm2_t(T xv, T yv, int shape, unsigned end_octave, float rx, float ry) {
+	T zval = nt_bc<T>(0.0f);
+	float mag = 1.0f, freq = 1.0f;
 	for (unsigned i = 0; i < end_octave; ++i) {
-		float const qx = freq*xv + rx, qy = freq*yv + ry;
-		float n = SIMPLEX ? simplex2(qx, qy) : perlin2(qx, qy);
-		if      (shape == 1) {n = (float)((double)fabsf(n) - 0.40);}
-		else if (shape == 2) {n = (float)(0.45 - (double)fabsf(n));}
+		T const qx = freq*xv + rx, qy = freq*yv + ry;
+		T n = SIMPLEX ? simplex2_t<T>(qx, qy) : perlin2_t<T>(qx, qy);
+		if (shape != 0) {n = nt_octave_shape(n, shape);}
 		zval += mag*n;
 		mag  *= 0.5f;
 		freq *= 1.92f;
@@ -221,6 +256,7 @@ template<bool SIMPLEX> TERRA_HD float fbm2(float xv, float yv, int shape, unsign
 	}
 	return zval;
 }
+template<bool SIMPLEX> TERRA_HD float fbm2(float xv, float yv, int shape, unsigned end_octave, float rx, float ry) {return fbm2_t<SIMPLEX, float>(xv, yv, shape, end_octave, rx, ry);}
 
 // get_hmap_scale (src/mesh_gen.cpp:550-553)
 TERRA_HD float hmap_scale(int mode, noise_consts_t const &nc) {
@@ -228,25 +264,31 @@ TERRA_HD float hmap_scale(int mode, noise_consts_t const &nc) {
 	return scale*nc.MESH_HEIGHT*nc.mesh_height_scale*nc.mesh_scale_z_inv;
 }
 
+TERRA_HD float nt_add_d(float v, double c) {return (float)((double)v + c);} // vec2(xv, yv) + vec2(5.2, 1.3): double literals in the reference
+TERRA_HD nv2   nt_add_d(nv2 v, double c)   {return nv2{nt_add_d(v[0], c), nt_add_d(v[1], c)};}
+TERRA_HD float nt_postproc(float z, hmap_params_t const &h) {return postproc_noise_zval(z, h);}
+TERRA_HD nv2   nt_postproc(nv2 z, hmap_params_t const &h) {return nv2{postproc_noise_zval(z[0], h), postproc_noise_zval(z[1], h)};}
+
 // get_noise_zval (src/mesh_gen.cpp:734-751). MODE is MGEN_SIMPLEX / MGEN_PERLIN / MGEN_SIMPLEX_GPU / MGEN_DWARP_GPU.
-template<int MODE> TERRA_HD float noise_zval(float xval, float yval, int shape, noise_consts_t const &nc) {
+template<int MODE, class T> TERRA_HD T noise_zval_t(T xval, T yval, int shape, noise_consts_t const &nc) {
 	constexpr bool SIMPLEX = (MODE != MGEN_PERLIN);
 	float const xy_scale = 0.0007f*nc.mesh_scale; // MESH_SCALE_FACTOR
-	float xv = xy_scale*xval, yv = xy_scale*yval;
+	T xv = xy_scale*xval, yv = xy_scale*yval;
 	unsigned const end_octave = NUM_FREQ_COMP - nc.start_eval_sin/N_RAND_SIN2;
 	if (MODE == MGEN_DWARP_GPU) {
 		float const scale = 0.2f;
-		float const dx1 = fbm2<SIMPLEX>((float)((double)xv + 0.0), (float)((double)yv + 0.0), shape, end_octave, nc.rx, nc.ry);
-		float const dy1 = fbm2<SIMPLEX>((float)((double)xv + 5.2), (float)((double)yv + 1.3), shape, end_octave, nc.rx, nc.ry);
-		float const wx = xv + scale*dx1, wy = yv + scale*dy1;
-		float const dx2 = fbm2<SIMPLEX>((float)((double)wx + 1.7), (float)((double)wy + 9.2), shape, end_octave, nc.rx, nc.ry);
-		float const dy2 = fbm2<SIMPLEX>((float)((double)wx + 8.3), (float)((double)wy + 2.8), shape, end_octave, nc.rx, nc.ry);
+		T const dx1 = fbm2_t<SIMPLEX, T>(nt_add_d(xv, 0.0), nt_add_d(yv, 0.0), shape, end_octave, nc.rx, nc.ry);
+		T const dy1 = fbm2_t<SIMPLEX, T>(nt_add_d(xv, 5.2), nt_add_d(yv, 1.3), shape, end_octave, nc.rx, nc.ry);
+		T const wx = xv + scale*dx1, wy = yv + scale*dy1;
+		T const dx2 = fbm2_t<SIMPLEX, T>(nt_add_d(wx, 1.7), nt_add_d(wy, 9.2), shape, end_octave, nc.rx, nc.ry);
+		T const dy2 = fbm2_t<SIMPLEX, T>(nt_add_d(wx, 8.3), nt_add_d(wy, 2.8), shape, end_octave, nc.rx, nc.ry);
 		xv += scale*dx2; yv += scale*dy2;
 	}
-	float z = fbm2<SIMPLEX>(xv, yv, shape, end_octave, nc.rx, nc.ry);
-	z = postproc_noise_zval(z, nc.hp);
+	T z = fbm2_t<SIMPLEX, T>(xv, yv, shape, end_octave, nc.rx, nc.ry);
+	z = nt_postproc(z, nc.hp);
 	return z*hmap_scale(MODE, nc);
 }
+template<int MODE> TERRA_HD float noise_zval(float xval, float yval, int shape, noise_consts_t const &nc) {return noise_zval_t<MODE, float>(xval, yval, shape, nc);}
 
 // ---- glaciate + islands + volcano epilogue of eval_index (src/mesh_gen.cpp:358-385,782-790)
 // pow(val, custom_glaciate_exp) is libm's powf in the reference (float arguments): reproduced bit for bit by terra_powf.hpp

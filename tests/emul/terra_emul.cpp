@@ -99,3 +99,29 @@ extern "C" unsigned long long terra_emul_noise_helper_mismatches() {
 	for (float v : special) {float const a = terra::gl_mod(v, 289.0f), b = terra::gl_mod289_int(v); if (memcmp(&a, &b, 4) != 0 && !(a != a && b != b)) ++bad;}
 	return bad;
 }
+
+// the two-cells-per-lane instantiation of the 2-D lattice noise against the one-cell instantiation (must be bit-identical)
+extern "C" unsigned long long terra_emul_noise_x2_mismatches(unsigned n, uint32_t seed) {
+	unsigned long long bad = 0;
+	auto rnd = [&]() {seed = seed*1664525u + 1013904223u; return seed;};
+	auto rf = [&](float lo, float hi) {return lo + (hi - lo)*(float)(rnd() >> 8)*(1.0f/16777216.0f);};
+	auto same = [&](float a, float b) {return memcmp(&a, &b, 4) == 0 || (a != a && b != b);};
+	terra::noise_consts_t nc{};
+	nc.mesh_scale = 1.0f; nc.start_eval_sin = 10; nc.rx = 1.3f; nc.ry = 1.7f; nc.MESH_HEIGHT = 0.1f; nc.mesh_height_scale = 0.7f; nc.mesh_scale_z_inv = 1.0f;
+	nc.hp.plat_bot = 1000.0f; nc.hp.crat_h = 1000.0f;
+	for (unsigned i = 0; i < n; ++i) {
+		float const scale = (i & 3) == 0 ? 1e7f : ((i & 3) == 1 ? 3e4f : 300.0f); // incl. coordinates beyond the 2^23 switch of mod 289
+		float const x0 = rf(-scale, scale), x1 = rf(-scale, scale), y0 = rf(-scale, scale), y1 = rf(-scale, scale);
+		terra::nv2 const xs = {x0, x1}, ys = {y0, y1};
+		terra::nv2 const s2 = terra::simplex2_t<terra::nv2>(xs, ys), p2 = terra::perlin2_t<terra::nv2>(xs, ys);
+		if (!same(s2[0], terra::simplex2(x0, y0)) || !same(s2[1], terra::simplex2(x1, y1))) ++bad;
+		if (!same(p2[0], terra::perlin2(x0, y0)) || !same(p2[1], terra::perlin2(x1, y1))) ++bad;
+		if ((i & 15) == 0) {
+			int const shape = (int)(i >> 4) % 3;
+			terra::nv2 const a = terra::noise_zval_t<terra::MGEN_DWARP_GPU, terra::nv2>(xs, ys, shape, nc), b = terra::noise_zval_t<terra::MGEN_PERLIN, terra::nv2>(xs, ys, shape, nc);
+			if (!same(a[0], terra::noise_zval<terra::MGEN_DWARP_GPU>(x0, y0, shape, nc)) || !same(a[1], terra::noise_zval<terra::MGEN_DWARP_GPU>(x1, y1, shape, nc))) ++bad;
+			if (!same(b[0], terra::noise_zval<terra::MGEN_PERLIN>(x0, y0, shape, nc)) || !same(b[1], terra::noise_zval<terra::MGEN_PERLIN>(x1, y1, shape, nc))) ++bad;
+		}
+	}
+	return bad;
+}

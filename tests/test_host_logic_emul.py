@@ -29,6 +29,15 @@ def test_division_free_lattice_helpers(emul_lib):
     assert lib.terra_emul_noise_helper_mismatches() == 0
 
 
+def test_two_cells_per_lane_noise_equals_one_cell(emul_lib):
+    """k_noise_grid evaluates two cells per lane on register pairs (terra_noise.hpp templates over the arithmetic type): same bits as one cell."""
+    import ctypes
+    lib = ctypes.CDLL(emul_lib)
+    lib.terra_emul_noise_x2_mismatches.restype = ctypes.c_ulonglong
+    lib.terra_emul_noise_x2_mismatches.argtypes = [ctypes.c_uint, ctypes.c_uint32]
+    assert lib.terra_emul_noise_x2_mismatches(300000, 7) == 0
+
+
 def test_powf_restatement_matches_libm(emul_lib):
     """glaciate's pow(relh, custom_glaciate_exp) is libm powf in the reference; 3dworld_amd/csrc/terra_powf.hpp restates glibc's algorithm so the
     device gets the same bits (ocml powf does not).  4*10^6 arguments here, 5*10^7 when the header was written."""
