@@ -142,6 +142,22 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
+		if (!simple_kernels && md != terra::MGEN_SINE) { // fBm modes: per-cell work, two cells per lane
+			use();
+			terra::grid_job_t job;
+			job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = tw; job.nxp = nxpv; job.nyp = nypv;
+			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so; job.plain_only = 0;
+			size_t const threads = (size_t)n*tw*((tw + 1)/2);
+			dim3 const grid((unsigned)((threads + 255)/256)), block(256);
+			switch (md) {
+			case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_PERLIN>,      grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
+			case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
+			case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
+			default:                      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
+			}
+			TERRA_HIP_CHECK(hipGetLastError());
+			return;
+		}
 		if (simple_kernels || md != terra::MGEN_SINE || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw); return;}
 		use();
 		size_t const cnt = (size_t)nux*nuy;

@@ -271,6 +271,24 @@ template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_
 	if (mm) {wave_minmax_publish(mm_lo, mm_hi, mm);}
 }
 
+// fBm tiles: the same two-cells-per-lane evaluation for a batch of tw x tw tile fields (origins per distinct tile column / row in m0)
+template<int MODE> __global__ __launch_bounds__(256) void k_noise_tiles(tile_ref_pod_t const *__restrict__ refs, uint32_t n, uint32_t nux, float const *__restrict__ d_sm, float const *__restrict__ m0,
+	grid_job_t job, noise_consts_t nc, sin_lut_t L, float *__restrict__ out, uint32_t tw)
+{
+	uint32_t const pairs = (tw + 1)/2, per_tile = tw*pairs;
+	size_t const i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= (size_t)n*per_tile) return;
+	uint32_t const t = (uint32_t)(i / per_tile), p = (uint32_t)(i % per_tile), y = p / pairs, x = (p % pairs)*2;
+	tile_ref_pod_t const r = refs[t];
+	job.mx0 = m0[r.xi]; job.my0 = m0[nux + r.yi];
+	float const xv0 = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, xv1 = ((float)(x + 1)*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+	nv2 const zz = noise_zval_t<MODE, nv2>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc);
+	float const *smx = d_sm + (size_t)r.xi*tw, *smy = d_sm + (size_t)(nux + r.yi)*tw;
+	float *o = out + (size_t)t*tw*tw + (size_t)y*tw + x;
+	o[0] = finish_cell(zz[0], job, nc, L, smx, smy, x, y);
+	if (x + 1 < tw) {o[1] = finish_cell(zz[1], job, nc, L, smx, smy, x + 1, y);}
+}
+
 // ------------------------------------------------------------------ K5 tile mode: LDS-resident padded grid, serial droplets
 __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters) {
 	extern __shared__ __attribute__((aligned(16))) float te_pad[];
@@ -295,9 +313,21 @@ __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, 
 // ------------------------------------------------------------------ K6+K7: tile post-pass, one 256-thread block per tile
 // sub-block z ranges, water bbox (ints), mzmin/mzmax/radius (src/tiled_mesh.cpp:517-541) and RGBA8 normals + min_normal_z (src/tiled_mesh.cpp:865-880).
 // HBM-bound: 4 B read + 4 B written per cell; reductions go through LDS atomics on order-preserving uints.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {uint32_t const o = __shfl_down(v, off, 64); v = (o < v) ? o : v;}
+	return v; // valid in lane 0
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {int const o = __shfl_down(v, off, 64); v = (o < v) ? o : v;}
+	return v;
+}
 __global__ __launch_bounds__(256) void k_tile_post(tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, terra_tile_stats *__restrict__ stats,
 	uint8_t *__restrict__ normals, float *__restrict__ min_nz, float wpz_max, float rad_c, float dxv, float dyv, float dxy)
 {
+	// every reduction is folded per lane, then per wave (shuffles), and only then touches LDS: 4 atomics per wave and quantity instead of
+	// several per cell (on an ocean tile every cell is below the water plane and hammered the same four bbox words)
 	__shared__ uint32_t s_lo[16], s_hi[16], s_mnz;
 	__shared__ int s_bb[4];
 	unsigned const t = blockIdx.x, tid = threadIdx.x, zv = 130, stride = 129, bs = 32;
@@ -308,25 +338,43 @@ __global__ __launch_bounds__(256) void k_tile_post(tile_ref_pod_t const *__restr
 	__syncthreads();
 	float const *z = zvals + (size_t)t*zv*zv;
 	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) : nullptr;
+	if (stats) { // sub-block z ranges: sub-block (xx,yy) covers cells [32*xx, 32*xx + 32] x [32*yy, 32*yy + 32] (shared edges belong to both)
+		for (unsigned sbk = 0; sbk < 16; ++sbk) {
+			unsigned const xx = sbk & 3, yy = sbk >> 2;
+			uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+			for (unsigned q = tid; q < (bs + 1)*(bs + 1); q += 256) {
+				unsigned const y = yy*bs + q/(bs + 1), x = xx*bs + q % (bs + 1);
+				float const v = z[y*zv + x];
+				if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;} // std::min / std::max never let a NaN win
+			}
+			lo = wave_min_u32(lo); hi = wave_min_u32(hi);
+			if ((tid & 63) == 0) {atomicMin(&s_lo[sbk], lo); atomicMin(&s_hi[sbk], hi);}
+		}
+	}
+	int bx0 = x1 + 128, by0 = y1 + 128, bx1n = -x1, by1n = -y1; // water bbox as four minima (max = -min(-v))
+	uint32_t mnz = 0x3F800000u;
 	for (unsigned p = tid; p < stride*stride; p += 256) { // cells 0..128 x 0..128: exactly the cells the 4x4 sub-blocks visit and the texels of the normal map
 		unsigned const y = p/stride, x = p - y*stride;
-		float const v = z[y*zv + x];
 		if (stats) {
-			if (v == v) { // std::min / std::max never let a NaN win
-				uint32_t const o = f2ord(v);
-				unsigned const xa = (x == 0) ? 0 : (x - 1)/bs, xb = (x/bs > 3) ? 3 : x/bs, ya = (y == 0) ? 0 : (y - 1)/bs, yb = (y/bs > 3) ? 3 : y/bs; // sub-blocks overlap on their shared edges
-				for (unsigned yy = ya; yy <= yb; ++yy) {for (unsigned xx = xa; xx <= xb; ++xx) {atomicMin(&s_lo[yy*4 + xx], o); atomicMin(&s_hi[yy*4 + xx], ~o);}}
+			float const v = z[y*zv + x];
+			if (v < wpz_max) {
+				int const wx = x1 + (int)x, wy = y1 + (int)y;
+				bx0 = (wx < bx0) ? wx : bx0; by0 = (wy < by0) ? wy : by0; bx1n = (-wx < bx1n) ? -wx : bx1n; by1n = (-wy < by1n) ? -wy : by1n;
 			}
-			if (v < wpz_max) {atomicMin(&s_bb[0], x1 + (int)x); atomicMin(&s_bb[1], y1 + (int)y); atomicMax(&s_bb[2], x1 + (int)x); atomicMax(&s_bb[3], y1 + (int)y);}
 		}
 		if (nout) {
 			float nv[3];
 			tile_normal(z, x, y, dxv, dyv, dxy, nv);
 			uint32_t const b0 = (uint8_t)(127.0*((double)nv[0] + 1.0)), b1 = (uint8_t)(127.0*((double)nv[1] + 1.0)), b2 = (uint8_t)(127.0*((double)nv[2] + 1.0));
 			nout[p] = b0 | (b1 << 8) | (b2 << 16); // A = 0
-			if (nv[2] < 1.0f) {uint32_t u; memcpy(&u, &nv[2], 4); atomicMin(&s_mnz, u);}
+			if (nv[2] < 1.0f) {uint32_t u; memcpy(&u, &nv[2], 4); mnz = (u < mnz) ? u : mnz;} // positive floats order like their bit patterns
 		}
 	}
+	if (stats) {
+		bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1n = wave_min_i32(bx1n); by1n = wave_min_i32(by1n);
+		if ((tid & 63) == 0) {atomicMin(&s_bb[0], bx0); atomicMin(&s_bb[1], by0); atomicMax(&s_bb[2], -bx1n); atomicMax(&s_bb[3], -by1n);}
+	}
+	if (nout) {mnz = wave_min_u32(mnz); if ((tid & 63) == 0) {atomicMin(&s_mnz, mnz);}}
 	__syncthreads();
 	if (stats) {
 		if (tid < 16) {stats[t].sub_zmin[tid] = ord2f(s_lo[tid]); stats[t].sub_zmax[tid] = ord2f(~s_hi[tid]);}
