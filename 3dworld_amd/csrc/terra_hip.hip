@@ -30,6 +30,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 	}
 	~hip_backend_t() {
 		if (tile_pad) (void)hipFree(tile_pad);
@@ -175,7 +176,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {tile_ao_simple(n, z, ctx, ao, dz);}
+	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {
+		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz); return;}
+		use();
+		unsigned const nbands = (terra::AO_TEX + terra::AO_BAND - 1)/terra::AO_BAND;
+		size_t const lds = (size_t)(terra::AO_BAND + terra::AO_RL)*terra::AO_CS*sizeof(float);
+		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(256), lds, stream, z, ctx, ao, dz);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
 		if (simple_kernels) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;}
 		use();

@@ -389,6 +389,64 @@ __global__ __launch_bounds__(256) void k_tile_post(tile_ref_pod_t const *__restr
 	if (min_nz && nout && tid == 0) {float f; uint32_t const u = s_mnz; memcpy(&f, &u, 4); min_nz[t] = f;}
 }
 
+// ------------------------------------------------------------------ row f1: tile AO lighting (tile_t::calc_mesh_ao_lighting, src/tiled_mesh.cpp:634-659)
+// One block = one band of AO_BAND texel rows of one tile.  The context rows the rays of the band can reach are staged in LDS in two passes:
+// rays going up or sideways need context rows [y0, y0 + band + 35], rays going down rows [y0 + 36, y0 + band + 71] (context coordinates =
+// texel + 36) -- 68 rows x 201 floats = 54.7 KB each time, so two blocks share a CU.  A thread owns up to 17 texels and keeps their
+// attenuation sums in registers across the passes.  Same integer sums as the one-thread-per-texel version (tile_ao_simple).
+constexpr unsigned AO_BAND = 32, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_PER_THREAD = (AO_BAND*AO_TEX + 255)/256;
+// one ray, branch-free: the eight samples sit at fixed offsets 1,3,6,...,36 steps from the texel (immediate ds_read offsets after unrolling),
+// are all requested before the first compare, and the first hit is selected backwards (hit at step s attenuates by 8 - s)
+template<int DX, int DY> __device__ __forceinline__ unsigned ao_march(float const *s_base, float const (&zr)[8]) {
+	float smp[8];
+#pragma unroll
+	for (int s = 0; s < 8; ++s) {int const off = (s + 1)*(s + 2)/2; smp[s] = s_base[off*(DY*(int)AO_CS + DX)];}
+	unsigned att = 0;
+#pragma unroll
+	for (int s = 7; s >= 0; --s) {att = (smp[s] > zr[s]) ? (unsigned)(8 - s) : att;}
+	return att;
+}
+__global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
+	extern __shared__ __attribute__((aligned(16))) float s_ao_ctx[];
+	unsigned const nbands = (AO_TEX + AO_BAND - 1)/AO_BAND, t = blockIdx.x/nbands, band = blockIdx.x % nbands, tid = threadIdx.x;
+	unsigned const y0 = band*AO_BAND, rows = (AO_TEX - y0 < AO_BAND) ? AO_TEX - y0 : AO_BAND, ntex = rows*AO_TEX;
+	float const *c = ctx + (size_t)t*AO_CS*AO_CS, *z = zvals + (size_t)t*130*130;
+	unsigned atten[AO_PER_THREAD];
+	float zs[AO_PER_THREAD];
+#pragma unroll
+	for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
+		unsigned const p = tid + k*256;
+		atten[k] = 0;
+		zs[k] = (p < ntex) ? z[(y0 + p/AO_TEX)*130 + p % AO_TEX] : 0.0f;
+	}
+	for (int pass = 0; pass < 2; ++pass) {
+		unsigned const row0 = pass ? y0 + AO_RL : y0, nfl = (rows + AO_RL)*AO_CS;
+		__syncthreads();
+		float const *src = c + (size_t)row0*AO_CS;
+		for (unsigned i = tid; i < nfl; i += 256) {s_ao_ctx[i] = src[i];}
+		__syncthreads();
+#pragma unroll
+		for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
+			unsigned const p = tid + k*256;
+			if (p >= ntex) continue;
+			unsigned const y = y0 + p/AO_TEX, x = p % AO_TEX;
+			float const *sb = s_ao_ctx + ((y + AO_RL) - row0)*AO_CS + (x + AO_RL); // the texel itself in the staged context
+			float zr[8], z0 = zs[k];
+#pragma unroll
+			for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;} // every ray rises by dz per step: sequential float adds, as in the reference
+			if (pass == 0) {atten[k] += ao_march<-1, -1>(sb, zr) + ao_march<0, -1>(sb, zr) + ao_march<1, -1>(sb, zr) + ao_march<-1, 0>(sb, zr) + ao_march<1, 0>(sb, zr);}
+			else           {atten[k] += ao_march<-1, 1>(sb, zr) + ao_march<0, 1>(sb, zr) + ao_march<1, 1>(sb, zr);}
+		}
+	}
+#pragma unroll
+	for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
+		unsigned const p = tid + k*256;
+		if (p >= ntex) continue;
+		float const ao_scale = (float)(1.0 - (double)((float)atten[k]/(float)64));
+		ao[(size_t)t*AO_TEX*AO_TEX + (size_t)y0*AO_TEX + p] = (uint8_t)(255.0*(double)ao_scale);
+	}
+}
+
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell
 // grid-stride float4 loads, wave shuffle reduction, one pair of atomics per wave.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
 __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, size_t n, uint32_t *__restrict__ d) {
