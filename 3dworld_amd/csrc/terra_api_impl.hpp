@@ -233,6 +233,16 @@ int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height
 }
 
 // ---- tiles
+int terra_hmap_set_dev(terra_ctx *ctx, const uint8_t *d_pixels, int width, int height, int ncolors) {
+	TERRA_CHECK_CTX
+	if (d_pixels && (width <= 0 || height <= 0 || (ncolors != 1 && ncolors != 2) || (int64_t)width*height >= (1ll << 31))) return terra::fail(TERRA_ERR_ARG, "terra_hmap_set_dev: bad image shape");
+	ctx->eng.hmap_pix = d_pixels; ctx->eng.hmap_w = d_pixels ? width : 0; ctx->eng.hmap_h = d_pixels ? height : 0; ctx->eng.hmap_nc = d_pixels ? ncolors : 0;
+	return TERRA_OK;
+}
+int terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, float dz) {
+	TERRA_CHECK_CTX
+	TERRA_TRY ctx->eng.set_mesh_height_scales_for_zval_range(min_z, dz); TERRA_CATCH
+}
 int terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable) {TERRA_CHECK_CTX ctx->eng.tiled_mesh_ao = (enable != 0); return TERRA_OK;}
 int terra_tiles_ao_lighting_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_ao) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_ao)) return terra::fail(TERRA_ERR_ARG, "null argument");

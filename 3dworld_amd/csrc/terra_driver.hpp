@@ -67,6 +67,43 @@ TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsig
 }
 
 
+// terrain_hmap_manager_t's sampling of a heightmap texture (src/heightmap.cpp:60-84,310-407; value scaling src/mesh_gen.cpp:120): the image stays where the
+// caller put it in HBM (1 byte per pixel, or 2 = {fraction, integer} as written by terra_quantize16_dev / write_pixel_16_bits)
+struct hmap_view_t {
+	uint8_t const *pix; int width, height, ncolors;
+	float mesh_scale, mesh_height_scale, mesh_file_scale, mesh_file_tz, mesh_scale_z_inv;
+	TERRA_HD float scale_val(float val) const {float const READ_MESH_H_SCALE = 0.0008f; return (READ_MESH_H_SCALE*mesh_height_scale*mesh_file_scale*val + mesh_file_tz)*mesh_scale_z_inv;}
+	TERRA_HD float value(unsigned x, unsigned y) const { // heightmap_t::get_heightmap_value with hmap_filter_width = 0: 0 .. 256
+		unsigned const ix = (unsigned)width*y + x;
+		if (ncolors == 2) {return (float)((double)pix[ix<<1]/256.0 + (double)pix[(ix<<1)+1]);}
+		return (float)pix[ix];
+	}
+	TERRA_HD void clamp_no_scale(int &x, int &y) const { // TEX_EDGE_MODE = 2 (mirror), allow_wrap: always on the texture afterwards
+		x += width/2; y += height/2;
+		if (x >= 0 && y >= 0 && x < width && y < height) return;
+		int const ax = (x < 0) ? -x : x, ay = (y < 0) ? -y : y; // abs()
+		int const xmod = ax % width, ymod = ay % height, xdiv = x/width, ydiv = y/height;
+		x = (xdiv & 1) ? (width  - xmod - 1) : xmod;
+		y = (ydiv & 1) ? (height - ymod - 1) : ymod;
+	}
+	TERRA_HD float raw_height(int x, int y) const {return scale_val(value((unsigned)x, (unsigned)y));}
+	TERRA_HD float clamped_height(int x, int y) const { // get_clamped_height (src/heightmap.cpp:385-392)
+		if (mesh_scale < 1.0f) { // interpolate_height (:394-402)
+			float const sx = mesh_scale*(float)x, sy = mesh_scale*(float)y;
+			int xlo = (int)floor((double)sx), ylo = (int)floor((double)sy), xhi = (int)ceil((double)sx), yhi = (int)ceil((double)sy);
+			float const xv = sx - (float)xlo, yv = sy - (float)ylo;
+			clamp_no_scale(xlo, ylo); clamp_no_scale(xhi, yhi);
+			return    yv *(xv*raw_height(xhi, yhi) + (1.0f-xv)*raw_height(xlo, yhi)) +
+				(1.0f-yv)*(xv*raw_height(xhi, ylo) + (1.0f-xv)*raw_height(xlo, ylo));
+		}
+		float const fx = mesh_scale*((float)x + 0.0f), fy = mesh_scale*((float)y + 0.0f); // clamp_xy (:310-314), round_fp (src/inlines.h:63)
+		x = (fx > 0.0f) ? f2i_x86(fx + 0.5f) : f2i_x86(fx - 0.5f);
+		y = (fy > 0.0f) ? f2i_x86(fy + 0.5f) : f2i_x86(fy - 0.5f);
+		clamp_no_scale(x, y);
+		return raw_height(x, y);
+	}
+};
+
 // one texel of tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:634-659): 8 directions x 8 steps at offsets 1,3,6,...,36 cells, the ray rises by
 // dz per step; the first context cell above the ray attenuates by (8 - step).  ctx(cx, cy): context value at context coordinates.
 template<class CTX> TERRA_HD uint8_t tile_ao_texel(float z_start, int x, int y, float dz, CTX ctx) {
@@ -118,6 +155,8 @@ template<class BE> struct terra_engine {
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
 	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_vox, s_sk, s_mm;
 	bool tiled_mesh_ao = false; // enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778)
+	uint8_t const *hmap_pix = nullptr; int hmap_w = 0, hmap_h = 0, hmap_nc = 0; // terrain_hmap_manager's image (device memory, owned by the caller)
+	float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;                          // src/mesh_gen.cpp:41, set by set_mesh_height_scales_for_zval_range
 	uint32_t *spec_blocks_clean = nullptr; size_t spec_blocks_n = 0; // s_spec_blocks is known to be all-NIL for this pointer / block count
 	uint8_t *spec_logs_base = nullptr; uint32_t spec_logs_w = 0, spec_logs_cap = 0; // the log tables in s_spec satisfy their invariant for this layout
 	template<class T> T *scratch(scratch_t &s, size_t count) {
@@ -592,8 +631,9 @@ template<class BE> struct terra_engine {
 	// One height field of tw x tw cells per tile, origin (tile*128 - shift) cells: setup_height_gen_async(height_gen, x1 - shift, y1 - shift, tw, tw)
 	// + the eval_index loop (src/tiled_mesh.cpp:458-464,480-488,494-505).  tw = 130, shift = 0: the tile's zvals; tw = 201, shift = 36: its AO context.
 	// Returns the device copy of the tile references (valid until the next tile call of this context).
-	tile_ref_pod_t const *tile_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out) {
+	tile_ref_pod_t const *tile_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out, float xy_scale = 1.0f) { // xy_scale 0: only the tile references
 		uint32_t const size = 128, zv = tw;
+		float const fdx = xy_scale*DX_VAL, fdy = xy_scale*DY_VAL; // setup_height_gen_async: build_arrays(..., xy_scale*DX_VAL, xy_scale*DY_VAL, ...)
 		// a tile's X table depends only on its tile x, its Y table only on its tile y: build each distinct one once
 		std::vector<int32_t> ux, uy;
 		for (uint32_t i = 0; i < n; ++i) {ux.push_back(tile_xy[2*i]); uy.push_back(tile_xy[2*i+1]);}
@@ -618,11 +658,12 @@ template<class BE> struct terra_engine {
 		float *d_tab = (float *)((uint8_t *)d_sk + (((nux + nuy)*sizeof(sine_k_t) + 255) & ~(size_t)255));
 		float *d_sm = d_tab + tab_floats;
 		be.h2d(d_refs, refs.data(), refs.size()*sizeof(tile_ref_t));
+		if (xy_scale == 0.0f) return d_refs;
 		// per distinct tx / ty: build_arrays((x0 - MESH_X_SIZE/2), (y0 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, tw, tw) with x0 = x1 - shift (src/tiled_mesh.cpp:458-464)
 		std::vector<sine_k_t> sks(nux + nuy);
 		std::vector<float> h_m0(nux + nuy);
-		for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)((ux[i]*(int)size - shift) - cfg.mesh_x/2); h_m0[i] = DX_VAL*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, DX_VAL, DY_VAL);}
-		for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)((uy[i]*(int)size - shift) - cfg.mesh_y/2); h_m0[nux+i] = DY_VAL*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], DX_VAL, DY_VAL);}
+		for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)((ux[i]*(int)size - shift) - cfg.mesh_x/2); h_m0[i] = fdx*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, fdx, fdy);}
+		for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)((uy[i]*(int)size - shift) - cfg.mesh_y/2); h_m0[nux+i] = fdy*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], fdx, fdy);}
 		be.h2d(d_sk, sks.data(), sks.size()*sizeof(sine_k_t));
 		float *d_m0 = scratch<float>(s_misc, nux + nuy + 16);
 		be.h2d(d_m0, h_m0.data(), h_m0.size()*4);
@@ -630,7 +671,7 @@ template<class BE> struct terra_engine {
 		sin_lut_t const L = lut();
 		int const md = mode, shp = shape, kstart = start_eval_sin;
 		bool const use_sm = (hp.sine_mag > 0.0f);
-		float const dxv = DX_VAL, dyv = DY_VAL, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
+		float const dxv = fdx, dyv = fdy, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
 		if (use_sm) { // enable_glaciate per distinct tx / ty
 			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq;
 			be.launch((size_t)(nux + nuy)*zv, [=] TERRA_LAMBDA (size_t i) {
@@ -662,12 +703,38 @@ template<class BE> struct terra_engine {
 	// enable_tiled_mesh_ao with the GL noise modes: create_zvals clips the zvals from the AO context grid (src/tiled_mesh.cpp:478-488,505)
 	bool ao_context_zvals() const {return tiled_mesh_ao && mode >= MGEN_SIMPLEX_GPU;}
 
+	// tiles from a heightmap texture (using_tiled_terrain_hmap_tex / using_hmap_with_detail, src/tiled_mesh.cpp:273-274,447-451)
+	bool using_hmap() const {return hmap_pix != nullptr;}
+	bool using_hmap_with_detail() const {return using_hmap() && mesh_scale < 0.75f;}
+	hmap_view_t hmap_view() const {return hmap_view_t{hmap_pix, hmap_w, hmap_h, hmap_nc, mesh_scale, mesh_height_scale, mesh_file_scale, mesh_file_tz, mesh_scale_z_inv};}
+	void set_mesh_height_scales_for_zval_range(float min_z, float dz) { // src/mesh_gen.cpp:125-131
+		if (!(dz > 0.0f)) throw std::invalid_argument("set_mesh_height_scales_for_zval_range: dz must be > 0");
+		float const READ_MESH_H_SCALE = 0.0008f;
+		mesh_file_scale = dz/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv);
+		mesh_file_tz    = min_z/mesh_scale_z_inv;
+	}
+	// tw x tw field per tile sampled from the heightmap texture (+ HMAP_DETAIL_MAG * the detail noise grid when mesh_scale < 0.75): src/tiled_mesh.cpp:499-503,623-627
+	tile_ref_pod_t const *tile_hmap_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out) {
+		bool const add_detail = using_hmap_with_detail();
+		tile_ref_pod_t const *d_refs = tile_fields_dev(tile_xy, n, tw, shift, d_out, add_detail ? 16.0f : 0.0f); // HMAP_DETAIL_SCALE (src/heightmap.h:8)
+		hmap_view_t const hv = hmap_view();
+		be.launch((size_t)n*tw*tw, [=] TERRA_LAMBDA (size_t i) {
+			unsigned const t = (unsigned)(i / ((size_t)tw*tw)), p = (unsigned)(i % ((size_t)tw*tw)), y = p / tw, x = p % tw;
+			tile_ref_pod_t const r = d_refs[t];
+			float zval = hv.clamped_height(r.tx*128 - shift + (int)x, r.ty*128 - shift + (int)y);
+			if (add_detail) {zval += 0.01f*d_out[i];} // HMAP_DETAIL_MAG (src/heightmap.h:9)
+			d_out[i] = zval;
+		});
+		return d_refs;
+	}
+
 	void tiles_create_zvals_dev(int32_t const *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
 		require_scene();
 		if (n == 0) return;
 		uint32_t const size = 128, zv = 130;
 		tile_ref_pod_t const *d_refs;
-		if (ao_context_zvals()) {
+		if (using_hmap()) {d_refs = tile_hmap_fields_dev(tile_xy, n, zv, 0, d_zvals); iters_tt = 0;} // "heightmap is eroded during load" (src/tiled_mesh.cpp:515)
+		else if (ao_context_zvals()) {
 			float *d_ctx = scratch<float>(s_ao, (size_t)n*AO_CTX*AO_CTX);
 			d_refs = tile_fields_dev(tile_xy, n, AO_CTX, (int)AO_RAY_LEN, d_ctx);
 			uint32_t const cs = AO_CTX, rl = AO_RAY_LEN;
@@ -699,8 +766,8 @@ template<class BE> struct terra_engine {
 		if (n == 0) return;
 		uint32_t const zv = 130, cs = AO_CTX, rl = AO_RAY_LEN;
 		float *d_ctx = scratch<float>(s_ao, (size_t)n*cs*cs);
-		tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);
-		if (!ao_context_zvals()) {
+		if (using_hmap()) {tile_hmap_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);} else {tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);}
+		if (using_hmap() || !ao_context_zvals()) {
 			be.launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
 				unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
 				d_ctx[(size_t)t*cs*cs + (size_t)(y + rl)*cs + (x + rl)] = d_zvals[i];

@@ -109,6 +109,8 @@ _PROTOS = {
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
     "terra_set_tiled_mesh_ao": (_i32, [_vp, _i32]),
+    "terra_hmap_set_dev": (_i32, [_vp, _vp, _i32, _i32, _i32]),
+    "terra_set_mesh_height_scales_for_zval_range": (_i32, [_vp, _f, _f]),
     "terra_tiles_ao_lighting_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "terra_tiles_ao_lighting": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
@@ -255,6 +257,12 @@ class Terra:
                                                     C.addressof(st) if stats else None, nm.ctypes.data if normals else None,
                                                     mnz.ctypes.data if normals else None))
         return z, st, nm, mnz
+
+    def hmap_set_dev(self, ptr, width=0, height=0, ncolors=2, min_z=None, dz=None):
+        """heightmap texture for the tile path (device pointer kept, not copied; None / 0 switches it off)"""
+        self._ck(self.lib.terra_hmap_set_dev(self.ctx, ptr, width, height, ncolors))
+        if ptr and min_z is not None:
+            self._ck(self.lib.terra_set_mesh_height_scales_for_zval_range(self.ctx, min_z, dz))
 
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))

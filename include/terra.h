@@ -164,6 +164,15 @@ int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32
 int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
                               float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
 
+/* ---- tiles from a heightmap texture instead of the procedural generator: terrain_hmap_manager_t (src/heightmap.h:110-142).
+ * d_pixels: width*height pixels in DEVICE memory, 1 byte each or 2 = {fraction, integer} as written by terra_quantize16_dev / write_pixel_16_bits;
+ * the library keeps the pointer (no copy), NULL switches back to procedural tiles.  While set, terra_tiles_create_zvals samples
+ * get_clamped_height(x1 + x, y1 + y) (nearest for mesh_scale >= 1, bilinear below, mirror-wrapped outside the image; src/heightmap.cpp:310-402), adds
+ * HMAP_DETAIL_MAG * the detail noise grid when mesh_scale < 0.75, skips erosion (src/tiled_mesh.cpp:499-503,515) and the AO context does the same (:623-627).
+ * terra_set_mesh_height_scales_for_zval_range = src/mesh_gen.cpp:125-131 (pixel value -> height, e.g. range[0], range[1]/255 of terra_heightmap_proc_gen_dev). */
+int  terra_hmap_set_dev(terra_ctx *ctx, const uint8_t *d_pixels, int width, int height, int ncolors);
+int  terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, float dz);
+
 /* ---- tile ambient-occlusion lighting: tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661).  zvals: [n][130][130] exactly as
  * terra_tiles_create_zvals left them (eroded or not); ao: [n][129][129] bytes = (unsigned char)(255*(1 - atten/64)).  The 201 x 201 context
  * around each tile is generated internally (setup_height_gen_async(x1 - 36, y1 - 36, 201, 201)).

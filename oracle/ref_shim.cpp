@@ -256,6 +256,55 @@ REF_API void ref_rand_uniforms(long s1, long s2, float a, float b, int n, float 
 // tile_t::create_zvals driver (src/tiled_mesh.cpp:467-546) for tile (tx,ty), size=128: zvals[130*130], sub_zmin/zmax[4][4], water bbox
 struct ref_tile_stats_t {float sub_zmin[16], sub_zmax[16], mzmin, mzmax, radius; int wx1, wy1, wx2, wy2;};
 
+// ---- tiles from a heightmap texture: terrain_hmap_manager_t's sampling (src/heightmap.cpp:60-84,310-407) restated over a raw 1- or 2-byte image
+// (heightmap.cpp itself needs the texture / image-IO stack); the value scaling is the reference's own scale_mh_texture_val /
+// set_mesh_height_scales_for_zval_range from mesh_gen.cpp (src/mesh_gen.cpp:120-131)
+float scale_mh_texture_val(float val);
+void set_mesh_height_scales_for_zval_range(float min_z, float dz);
+static unsigned char const *shim_hm_data(nullptr);
+static int shim_hm_width(0), shim_hm_height(0), shim_hm_ncolors(0);
+float const SHIM_HMAP_DETAIL_SCALE = 16.0, SHIM_HMAP_DETAIL_MAG = 0.01; // src/heightmap.h:8-9
+REF_API void ref_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {shim_hm_data = pixels; shim_hm_width = width; shim_hm_height = height; shim_hm_ncolors = ncolors;}
+REF_API void ref_set_mesh_height_scales_for_zval_range(float min_z, float dz) {set_mesh_height_scales_for_zval_range(min_z, dz);}
+static float shim_get_heightmap_value(unsigned x, unsigned y) { // src/heightmap.cpp:75-80, hmap_filter_width = 0
+	unsigned const ix(shim_hm_width*y + x);
+	if (shim_hm_ncolors == 2) {return (shim_hm_data[ix<<1]/256.0 + shim_hm_data[(ix<<1)+1]);}
+	return shim_hm_data[ix];
+}
+static bool shim_clamp_no_scale(int &x, int &y) { // src/heightmap.cpp:316-343 with TEX_EDGE_MODE = 2, allow_wrap = 1
+	x += shim_hm_width /2;
+	y += shim_hm_height/2;
+	if (x >= 0 && y >= 0 && x < shim_hm_width && y < shim_hm_height) return 1;
+	int const xmod(abs(x)%shim_hm_width), ymod(abs(y)%shim_hm_height), xdiv(x/shim_hm_width), ydiv(y/shim_hm_height);
+	x = ((xdiv & 1) ? (shim_hm_width  - xmod - 1) : xmod);
+	y = ((ydiv & 1) ? (shim_hm_height - ymod - 1) : ymod);
+	return 1;
+}
+static float shim_get_raw_height(int x, int y) {return scale_mh_texture_val(shim_get_heightmap_value(x, y));}
+static float shim_interpolate_height(float x, float y) { // src/heightmap.cpp:394-402
+	float const sx(mesh_scale*x), sy(mesh_scale*y);
+	int xlo(floor(sx)), ylo(floor(sy)), xhi(ceil(sx)), yhi(ceil(sy));
+	float const xv(sx - xlo), yv(sy - ylo);
+	if (!shim_clamp_no_scale(xlo, ylo) || !shim_clamp_no_scale(xhi, yhi)) {return scale_mh_texture_val(0.0);}
+	return    yv *(xv*shim_get_raw_height(xhi, yhi) + (1.0f-xv)*shim_get_raw_height(xlo, yhi)) +
+		(1.0f-yv)*(xv*shim_get_raw_height(xhi, ylo) + (1.0f-xv)*shim_get_raw_height(xlo, ylo));
+}
+static int shim_round_fp(float val) {return ((val > 0.0f) ? int(val + 0.5f) : int(val - 0.5f));} // src/inlines.h:63
+REF_API float ref_get_clamped_height(int x, int y) { // src/heightmap.cpp:385-392, clamp_xy :310-314
+	if (mesh_scale < 1.0) {return shim_interpolate_height(float(x), float(y));}
+	x = shim_round_fp(mesh_scale*(x + 0.0f));
+	y = shim_round_fp(mesh_scale*(y + 0.0f));
+	if (!shim_clamp_no_scale(x, y)) {return scale_mh_texture_val(0.0);}
+	return shim_get_raw_height(x, y);
+}
+static bool shim_using_hmap() {return (shim_hm_data != nullptr);}                             // using_tiled_terrain_hmap_tex (src/tiled_mesh.cpp:273)
+static bool shim_using_hmap_with_detail() {return (shim_using_hmap() && mesh_scale < 0.75);} // src/tiled_mesh.cpp:274
+static float shim_get_xy_scale() { // src/tiled_mesh.cpp:447-451
+	bool const add_detail(shim_using_hmap_with_detail());
+	if (!add_detail && shim_using_hmap()) return 0.0;
+	return (add_detail ? SHIM_HMAP_DETAIL_SCALE : 1.0);
+}
+
 // enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778; scene_config/config.txt:81 turns it on): a config-file flag read by the tile code
 static bool shim_enable_tiled_mesh_ao(0);
 REF_API void ref_set_tiled_mesh_ao(int v) {shim_enable_tiled_mesh_ao = (v != 0);}
@@ -269,7 +318,21 @@ REF_API void ref_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zva
 	float mzmin(FAR_DISTANCE), mzmax(-FAR_DISTANCE);
 	unsigned const block_size(zvsize/4), context_sz(stride + 2*SHIM_AO_RAY_LEN);
 	float const wpz_max(ref_get_max_sea_level());
-	if (shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU) { // AO + GPU noise: the zvals are clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505)
+	if (shim_using_hmap()) { // src/tiled_mesh.cpp:499-503
+		bool const add_detail(shim_using_hmap_with_detail());
+		float const xy_scale(shim_get_xy_scale());
+		if (xy_scale != 0.0) {height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), xy_scale*DX_VAL, xy_scale*DY_VAL, zvsize, zvsize, 0, 0, 0); height_gen.enable_glaciate();}
+#pragma omp parallel for schedule(static,1)
+		for (int y = 0; y < (int)zvsize; ++y) {
+			for (unsigned x = 0; x < zvsize; ++x) {
+				float &zval(zvals[y*zvsize + x]);
+				zval = ref_get_clamped_height((x1 + x), (y1 + y));
+				if (add_detail) {zval += SHIM_HMAP_DETAIL_MAG*height_gen.eval_index(x, y);}
+			}
+		}
+		iters_tt = 0; // heightmap is eroded during load (:515)
+	}
+	else if (shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU) { // AO + GPU noise: the zvals are clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505)
 		height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0, 0);
 		height_gen.enable_glaciate();
 #pragma omp parallel for schedule(static,1)
@@ -322,11 +385,15 @@ REF_API void ref_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned c
 			if (x != 0 || y != 0) {ao_dirs[ix][0] = x; ao_dirs[ix][1] = y; ++ix;}
 		}
 	}
-	bool const use_ao_zvals(shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU); // ao_zvals kept by create_zvals: the whole context, interior included
+	bool const using_hmap(shim_using_hmap()), add_detail(shim_using_hmap_with_detail());
+	bool const use_ao_zvals(!using_hmap && shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU); // ao_zvals kept by create_zvals: the whole context, interior included
 	vector<float> czv(context_sz*context_sz);
 	mesh_xy_grid_cache_t height_gen;
-	height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0, 0);
-	height_gen.enable_glaciate();
+	float const xy_scale(shim_get_xy_scale());
+	if (xy_scale != 0.0) {
+		height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), xy_scale*DX_VAL, xy_scale*DY_VAL, context_sz, context_sz, 0, 0, 0);
+		height_gen.enable_glaciate();
+	}
 	float const dz(0.5*HALF_DXY);
 #pragma omp parallel for schedule(static,1)
 	for (int y = 0; y < (int)context_sz; ++y) {
@@ -334,6 +401,10 @@ REF_API void ref_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned c
 			int const xv(x - (int)SHIM_AO_RAY_LEN), yv(y - (int)SHIM_AO_RAY_LEN);
 			float &zv(czv[y*context_sz + x]);
 			if (!use_ao_zvals && xv >= 0 && yv >= 0 && xv < (int)zvsize && yv < (int)zvsize) {zv = zvals[yv*zvsize + xv];}
+			else if (using_hmap) {
+				zv = ref_get_clamped_height((x1 + xv), (y1 + yv));
+				if (add_detail) {zv += SHIM_HMAP_DETAIL_MAG*height_gen.eval_index(x, y);}
+			}
 			else {zv = height_gen.eval_index(x, y);}
 		}
 	}

@@ -785,6 +785,53 @@ void  orc_rand_ints(long s1, long s2, int n, int *out) {rgen_t r; rgen_set_state
 void  orc_rand_floats(long s1, long s2, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_float(&r);}}
 void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_uniform(&r, a, b);}}
 
+/* ---- tiles from a heightmap texture: terrain_hmap_manager_t (src/heightmap.h:110-142, src/heightmap.cpp:60-84,310-407) over a 1- or 2-byte
+ * grayscale image, scaled by scale_mh_texture_val (src/mesh_gen.cpp:120-131).  The image is kept by pointer (the caller owns it). */
+static unsigned char const *hm_data = NULL;
+static int hm_width = 0, hm_height = 0, hm_ncolors = 0;
+static float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;
+#define HMAP_DETAIL_SCALE 16.0f /* src/heightmap.h:8-9 */
+#define HMAP_DETAIL_MAG   0.01f
+void orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {hm_data = pixels; hm_width = width; hm_height = height; hm_ncolors = ncolors;}
+void orc_set_mesh_height_scales_for_zval_range(float min_z, float dz) { /* src/mesh_gen.cpp:125-131 */
+	float const READ_MESH_H_SCALE = 0.0008f;
+	mesh_file_scale = dz/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv);
+	mesh_file_tz    = min_z/mesh_scale_z_inv;
+}
+static float scale_mh_texture_val(float val) {float const READ_MESH_H_SCALE = 0.0008f; return (READ_MESH_H_SCALE*mesh_height_scale*mesh_file_scale*val + mesh_file_tz)*mesh_scale_z_inv;}
+static float hm_get_heightmap_value(unsigned x, unsigned y) { /* returns values from 0 to 256, src/heightmap.cpp:75-80 (hmap_filter_width = 0) */
+	unsigned const ix = (unsigned)hm_width*y + x;
+	if (hm_ncolors == 2) {return (float)((double)hm_data[ix<<1]/256.0 + (double)hm_data[(ix<<1)+1]);}
+	return (float)hm_data[ix];
+}
+static int hm_clamp_no_scale(int *x, int *y) { /* src/heightmap.cpp:316-343, TEX_EDGE_MODE = 2 (mirror), allow_wrap = 1 */
+	*x += hm_width/2; *y += hm_height/2;
+	if (*x >= 0 && *y >= 0 && *x < hm_width && *y < hm_height) return 1;
+	int const xmod = abs(*x) % hm_width, ymod = abs(*y) % hm_height, xdiv = *x/hm_width, ydiv = *y/hm_height;
+	*x = (xdiv & 1) ? (hm_width  - xmod - 1) : xmod;
+	*y = (ydiv & 1) ? (hm_height - ymod - 1) : ymod;
+	return 1;
+}
+static int round_fp_f(float val) {return (val > 0.0f) ? (int)(val + 0.5f) : (int)(val - 0.5f);} /* src/inlines.h:63 */
+static float hm_get_raw_height(int x, int y) {return scale_mh_texture_val(hm_get_heightmap_value((unsigned)x, (unsigned)y));}
+static float hm_interpolate_height(float x, float y) { /* src/heightmap.cpp:394-402 */
+	float const sx = mesh_scale*x, sy = mesh_scale*y;
+	int xlo = (int)floor((double)sx), ylo = (int)floor((double)sy), xhi = (int)ceil((double)sx), yhi = (int)ceil((double)sy);
+	float const xv = sx - (float)xlo, yv = sy - (float)ylo;
+	if (!hm_clamp_no_scale(&xlo, &ylo) || !hm_clamp_no_scale(&xhi, &yhi)) {return scale_mh_texture_val(0.0f);}
+	return    yv *(xv*hm_get_raw_height(xhi, yhi) + (1.0f-xv)*hm_get_raw_height(xlo, yhi)) +
+		(1.0f-yv)*(xv*hm_get_raw_height(xhi, ylo) + (1.0f-xv)*hm_get_raw_height(xlo, ylo));
+}
+float orc_get_clamped_height(int x, int y) { /* src/heightmap.cpp:385-392 */
+	if (mesh_scale < 1.0f) {return hm_interpolate_height((float)x, (float)y);}
+	x = round_fp_f(mesh_scale*((float)x + 0.0f)); y = round_fp_f(mesh_scale*((float)y + 0.0f)); /* clamp_xy, src/heightmap.cpp:310-314 */
+	if (!hm_clamp_no_scale(&x, &y)) {return scale_mh_texture_val(0.0f);}
+	return hm_get_raw_height(x, y);
+}
+static int using_hmap(void) {return hm_data != NULL;}                                   /* using_tiled_terrain_hmap_tex, src/tiled_mesh.cpp:273 */
+static int using_hmap_with_detail(void) {return using_hmap() && mesh_scale < 0.75f;}   /* src/tiled_mesh.cpp:274 */
+static float get_xy_scale(void) {int const add_detail = using_hmap_with_detail(); if (!add_detail && using_hmap()) return 0.0f; return add_detail ? HMAP_DETAIL_SCALE : 1.0f;} /* src/tiled_mesh.cpp:447-451 */
+
 /* enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778): config flag read by the tile code */
 static int enable_tiled_mesh_ao = 0;
 void orc_set_tiled_mesh_ao(int v) {enable_tiled_mesh_ao = (v != 0);}
@@ -801,7 +848,22 @@ void orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_
 	float mzmin = FAR_DISTANCE, mzmax = -FAR_DISTANCE;
 	unsigned const block_size = zvsize/4, context_sz = stride + 2*AO_RAY_LEN;
 	float const wpz_max = orc_get_max_sea_level();
-	if (enable_tiled_mesh_ao && mesh_gen_mode >= ORC_MGEN_SIMPLEX_GPU) { /* zvals clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505) */
+	if (using_hmap()) { /* src/tiled_mesh.cpp:499-503: heightmap texture (+ procedural detail when mesh_scale < 0.75) */
+		int const add_detail = using_hmap_with_detail();
+		float const xy_scale = get_xy_scale();
+		memset(&g, 0, sizeof(g));
+		if (xy_scale != 0.0f) {gc_build_arrays(&g, (float)(x1 - MESH_X_SIZE/2), (float)(y1 - MESH_Y_SIZE/2), xy_scale*DX_VAL, xy_scale*DY_VAL, zvsize, zvsize, 0, 0); gc_enable_glaciate(&g);}
+#pragma omp parallel for schedule(static,1)
+		for (int y = 0; y < (int)zvsize; ++y) {
+			for (unsigned x = 0; x < zvsize; ++x) {
+				float zval = orc_get_clamped_height(x1 + (int)x, y1 + y);
+				if (add_detail) {zval += HMAP_DETAIL_MAG*gc_eval_index(&g, x, y, 0, 1);}
+				zvals[y*zvsize + x] = zval;
+			}
+		}
+		iters_tt = 0; /* "heightmap is eroded during load" (:515) */
+	}
+	else if (enable_tiled_mesh_ao && mesh_gen_mode >= ORC_MGEN_SIMPLEX_GPU) { /* zvals clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505) */
 		gc_build_arrays(&g, (float)((x1 - AO_RAY_LEN) - MESH_X_SIZE/2), (float)((y1 - AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0);
 		gc_enable_glaciate(&g);
 #pragma omp parallel for schedule(static,1)
@@ -854,17 +916,27 @@ void orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao)
 			if (x != 0 || y != 0) {ao_dirs[ix][0] = x; ao_dirs[ix][1] = y; ++ix;}
 		}
 	}
-	int const use_ao_zvals = (enable_tiled_mesh_ao && mesh_gen_mode >= ORC_MGEN_SIMPLEX_GPU); /* ao_zvals of create_zvals: the whole context, interior included (:606) */
+	int const hmap_on = using_hmap(), add_detail = using_hmap_with_detail();
+	int const use_ao_zvals = (!hmap_on && enable_tiled_mesh_ao && mesh_gen_mode >= ORC_MGEN_SIMPLEX_GPU); /* ao_zvals of create_zvals: the whole context, interior included (:606) */
 	float *czv = (float *)malloc((size_t)context_sz*context_sz*sizeof(float));
 	grid_cache_t g;
-	gc_build_arrays(&g, (float)((x1 - AO_RAY_LEN) - MESH_X_SIZE/2), (float)((y1 - AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0); /* setup_height_gen_async (:609) */
-	gc_enable_glaciate(&g);
+	float const xy_scale = get_xy_scale();
+	memset(&g, 0, sizeof(g));
+	if (xy_scale != 0.0f) { /* setup_height_gen_async (:609) */
+		gc_build_arrays(&g, (float)((x1 - AO_RAY_LEN) - MESH_X_SIZE/2), (float)((y1 - AO_RAY_LEN) - MESH_Y_SIZE/2), xy_scale*DX_VAL, xy_scale*DY_VAL, context_sz, context_sz, 0, 0);
+		gc_enable_glaciate(&g);
+	}
 	float const dz = (float)(0.5*(double)HALF_DXY); /* float const dz(0.5*HALF_DXY) (:611) */
 #pragma omp parallel for schedule(static,1)
 	for (int y = 0; y < (int)context_sz; ++y) {
 		for (int x = 0; x < (int)context_sz; ++x) {
 			int const xv = x - AO_RAY_LEN, yv = y - AO_RAY_LEN;
 			if (!use_ao_zvals && xv >= 0 && yv >= 0 && xv < (int)zvsize && yv < (int)zvsize) {czv[y*context_sz + x] = zvals[yv*zvsize + xv];}
+			else if (hmap_on) { /* :623-627 */
+				float zv = orc_get_clamped_height(x1 + xv, y1 + yv);
+				if (add_detail) {zv += HMAP_DETAIL_MAG*gc_eval_index(&g, x, y, 0, 1);}
+				czv[y*context_sz + x] = zv;
+			}
 			else {czv[y*context_sz + x] = gc_eval_index(&g, x, y, 0, 1);}
 		}
 	}

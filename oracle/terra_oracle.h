@@ -80,6 +80,9 @@ void  orc_rand_floats(long s1, long s2, int n, float *out);
 void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out);
 void  orc_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, orc_tile_stats_t *st);
 void  orc_set_tiled_mesh_ao(int v);
+void  orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolors); /* NULL: back to procedural tiles */
+void  orc_set_mesh_height_scales_for_zval_range(float min_z, float dz);
+float orc_get_clamped_height(int x, int y);
 void  orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao);
 float orc_tile_normals(float const *zvals, unsigned char *rgba);
 void  orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out);

@@ -121,6 +121,9 @@ class Checker:
         f("tile_create_zvals", None, [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.POINTER(TileStats)])
         f("tile_normals", C.c_float, [C.c_void_p, C.c_void_p])
         f("set_tiled_mesh_ao", None, [C.c_int])
+        f("hmap_set", None, [C.c_void_p, C.c_int, C.c_int, C.c_int])
+        f("set_mesh_height_scales_for_zval_range", None, [C.c_float, C.c_float])
+        f("get_clamped_height", C.c_float, [C.c_int, C.c_int])
         f("tile_ao_lighting", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
         f("quantize16", None, [C.c_void_p, C.c_size_t, C.c_void_p, _fp, _fp])
         f("voxel_fill", None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int])
@@ -204,6 +207,19 @@ class Checker:
         return z, st
 
     def set_tiled_mesh_ao(self, v): self._set_tiled_mesh_ao(int(v))
+
+    def hmap_set(self, pixels, min_z=None, dz=None):
+        """pixels: (h, w, 2) or (h, w) uint8 array kept alive by the caller (None: back to procedural tiles); min_z/dz: set_mesh_height_scales_for_zval_range"""
+        if pixels is None:
+            self._hmap_set(None, 0, 0, 0); self._hm_keep = None
+            return
+        assert pixels.dtype == np.uint8 and pixels.flags.c_contiguous
+        self._hm_keep = pixels
+        self._hmap_set(pixels.ctypes.data, pixels.shape[1], pixels.shape[0], 2 if pixels.ndim == 3 else 1)
+        if min_z is not None:
+            self._set_mesh_height_scales_for_zval_range(min_z, dz)
+
+    def get_clamped_height(self, x, y): return self._get_clamped_height(x, y)
 
     def tile_ao_lighting(self, tx, ty, zvals):
         assert zvals.dtype == np.float32 and zvals.shape == (130, 130) and zvals.flags.c_contiguous

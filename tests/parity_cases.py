@@ -247,6 +247,40 @@ def case_tile_ao(pkg, t, orc):
             t.set_tiled_mesh_ao(0); orc.set_tiled_mesh_ao(0)
 
 
+def case_tiles_from_heightmap(pkg, t, orc):
+    """tiles (zvals, stats, normals, AO) sampled from a 16-bit / 8-bit heightmap texture in device memory: nearest, bilinear, mirror wrap far outside
+    the image, procedural detail below mesh_scale 0.75, no erosion -- terrain_hmap_manager_t + the using_hmap branches of the tile code."""
+    s0 = orc.init(orclib.make_config(mesh_gen_mode=0))
+    n = 192
+    g = orc.gen_grid(-n / 2, -n / 2, s0.DX_VAL, s0.DY_VAL, n, n, 1)
+    q, mn, dz = orc.quantize16(g)
+    pix16 = np.ascontiguousarray(q.reshape(n, n, 2))
+    pix8 = np.ascontiguousarray(pix16[:, :, 1])
+    dzs = float(np.float32(np.float64(dz) / 255.0))
+    tiles = [(0, 0), (-1, 0), (1, -2), (7, 5), (-40, 33)]
+    bufs = []
+    try:
+        for mesh_scale, img in ((1.0, pix16), (2.0, pix16), (0.8, pix16), (0.5, pix16), (1.0, pix8), (0.6, pix8)):
+            pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, mesh_scale=mesh_scale)
+            t.init_scene(pc_); orc.init(oc)
+            buf = t.alloc(img.nbytes).upload(img); bufs.append(buf)
+            t.hmap_set_dev(buf.ptr, img.shape[1], img.shape[0], 2 if img.ndim == 3 else 1, float(mn), dzs)
+            orc.hmap_set(img, float(mn), dzs)
+            z, st, nm, mnz = t.tiles_create_zvals(tiles, 50)
+            ao = t.tiles_ao_lighting(tiles, z)
+            for i, (tx, ty) in enumerate(tiles):
+                zo, so = orc.tile_create_zvals(tx, ty, 50)
+                assert_bit_equal(z[i], zo, f"hmap zvals scale {mesh_scale} tile {tx},{ty}")
+                assert bytes(st[i]) == bytes(so)
+                no, mo = orc.tile_normals(zo)
+                assert (nm[i] == no).all() and np.float32(mnz[i]).view(np.uint32) == np.float32(mo).view(np.uint32)
+                assert (ao[i] == orc.tile_ao_lighting(tx, ty, zo)).all(), f"hmap ao scale {mesh_scale} tile {tx},{ty}"
+    finally:
+        t.hmap_set_dev(None); orc.hmap_set(None)
+        for b in bufs:
+            b.free()
+
+
 def case_voxels_golden(pkg, t):
     G = golden()
     t.init_scene(pkg.make_config(mesh_gen_mode=0))

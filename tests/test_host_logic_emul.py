@@ -82,6 +82,10 @@ def test_tile_ao_lighting(pkg, emul, orc):
     pc.case_tile_ao(pkg, emul, orc)
 
 
+def test_tiles_from_heightmap_texture(pkg, emul, orc):
+    pc.case_tiles_from_heightmap(pkg, emul, orc)
+
+
 def test_erosion_context_reuse(pkg, emul, orc):
     pc.case_erosion_context_reuse(pkg, emul, orc)
 

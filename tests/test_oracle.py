@@ -156,6 +156,36 @@ def test_oracle_vs_reference_tile_ao(orc, ref):
         ref.set_tiled_mesh_ao(0); orc.set_tiled_mesh_ao(0)
 
 
+def _hmap_pixels(ck, n=192, mode=0):
+    """a small eroded heightmap quantised like heightmap_t::from_floats: (n, n, 2) bytes + (min_z, dz/255)"""
+    s = ck.init(orclib.make_config(mesh_gen_mode=mode))
+    g = ck.gen_grid(-n / 2, -n / 2, s.DX_VAL, s.DY_VAL, n, n, 1)
+    q, mn, dz = ck.quantize16(g)
+    return np.ascontiguousarray(q.reshape(n, n, 2)), float(mn), float(np.float32(np.float64(dz) / 255.0))
+
+
+def test_oracle_vs_reference_hmap_tiles(orc, ref):
+    """tiles sampled from a heightmap texture (terrain_hmap_manager_t): nearest / bilinear / mirror-wrapped reads, procedural detail, AO context"""
+    ref.set_num_threads(1)
+    pix, mn, dzs = _hmap_pixels(ref)
+    pix8 = np.ascontiguousarray(pix[:, :, 1])
+    try:
+        for mesh_scale, img in ((1.0, pix), (2.0, pix), (0.8, pix), (0.5, pix), (1.0, pix8), (0.6, pix8)):
+            cfg = orclib.make_config(mesh_gen_mode=0, mesh_scale=mesh_scale)
+            ref.init(cfg); orc.init(cfg)
+            ref.hmap_set(img, mn, dzs); orc.hmap_set(img, mn, dzs)
+            for x, y in ((0, 0), (-96, 95), (500, -777), (-100000, 123456), (97, 96)):
+                assert np.float32(ref.get_clamped_height(x, y)).view(np.uint32) == np.float32(orc.get_clamped_height(x, y)).view(np.uint32), (mesh_scale, x, y)
+            for tx, ty in ((0, 0), (-1, 0), (1, -2), (7, 5)):
+                za, sa = ref.tile_create_zvals(tx, ty, 50); zb, sb = orc.tile_create_zvals(tx, ty, 50)
+                assert_bit_equal(za, zb, f"hmap zvals scale {mesh_scale} tile {tx},{ty}")
+                assert bytes(sa) == bytes(sb)
+                a, b = ref.tile_ao_lighting(tx, ty, za), orc.tile_ao_lighting(tx, ty, zb)
+                assert (a == b).all(), f"hmap ao scale {mesh_scale} tile {tx},{ty}"
+    finally:
+        ref.hmap_set(None); orc.hmap_set(None)
+
+
 def test_libm_sincosf_is_not_correctly_rounded_but_reproducible():
     """The droplet's random-direction branch calls libm cosf/sinf on a = rand_float()*TWO_PI (src/erosion.cpp:80-83).
     glibc's sinf/cosf are not correctly rounded, which is why 3dworld_amd/csrc/terra_sincosf.hpp restates their algorithm

@@ -52,6 +52,16 @@ t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
 ao = t.alloc(n * 129 * 129)
 ms = timed(lambda: t.tiles_ao_lighting_dev(tiles, zt.ptr, ao.ptr), reps=2)
 out["F1_tile_ao_64x64_sine"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+# tiles served from a heightmap texture: proc_gen a 4096^2 map (noise + 1000-droplet erosion + 16-bit quantise) on the device, then sample the tile batch from it
+H = 4096
+hv = t.alloc(H * H * 4); hp = t.alloc(H * H * 2)
+rng = t.heightmap_proc_gen_dev(hv.ptr, H, H, 1000, hp.ptr)
+if rng is not None:
+    t.hmap_set_dev(hp.ptr, H, H, 2, float(rng[0]), float(np.float32(np.float64(rng[1]) / 255.0)))
+    ms = timed(lambda: t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr), reps=2)
+    out["C4h_tiles64x64_from_heightmap_texture"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+    t.hmap_set_dev(None)
+hv.free(); hp.free()
 ao.free()
 for b in (zt, stt, nm, mz): b.free()
 # C5: voxels
