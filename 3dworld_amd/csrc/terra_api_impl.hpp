@@ -263,6 +263,25 @@ int terra_tiles_ao_lighting(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, 
 		be.free(d);
 	TERRA_CATCH
 }
+int terra_tiles_mesh_shadows_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.tiles_mesh_shadows_dev(tile_xy, n, d_zvals, light_pos, d_smask); TERRA_CATCH
+}
+int terra_tiles_mesh_shadows(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals || !h_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (n == 0) return TERRA_OK;
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		size_t const zb = (size_t)n*130*130*4, sb = (size_t)n*130*130;
+		uint8_t *d = (uint8_t *)be.alloc(zb + sb);
+		try {
+			be.h2d(d, h_zvals, zb);
+			ctx->eng.tiles_mesh_shadows_dev(tile_xy, n, (float const *)d, light_pos, d + zb);
+			be.d2h(h_smask, d + zb, sb);
+		} catch (...) {be.free(d); throw;}
+		be.free(d);
+	TERRA_CATCH
+}
 int terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t iters_tt, float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.tiles_create_zvals_dev(tile_xy, n, iters_tt, d_zvals, d_stats, d_normals, d_min_nz); TERRA_CATCH

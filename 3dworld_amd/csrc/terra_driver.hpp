@@ -12,6 +12,7 @@
 #include "terra_erosion.hpp"
 #include "../../include/terra.h"
 #include <vector>
+#include <map>
 #include <string>
 #include <algorithm>
 #include <stdexcept>
@@ -66,6 +67,88 @@ TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsig
 	}
 }
 
+
+// ---- row f2: mesh shadows (mesh_shadow_gen::trace_shadow_path, src/visibility.cpp:422-487; do_line_clip src/Math3d.cpp:1029-1086; get_region src/inlines.h:522-528)
+struct shadow_consts_t {
+	float X_SCENE_SIZE, Y_SCENE_SIZE, DX_VAL, DY_VAL, DX_VAL_INV, DY_VAL_INV, zmin, zmax, dist, dirx, diry, dirz;
+	int xsize, ysize;
+	TERRA_HD int xpos(float xval) const {return (int)((double)((xval + X_SCENE_SIZE)*DX_VAL_INV) + 0.5);} // get_xpos (src/mesh.h:129)
+	TERRA_HD int ypos(float yval) const {return (int)((double)((yval + Y_SCENE_SIZE)*DY_VAL_INV) + 0.5);}
+	TERRA_HD float xval(int xp) const {return -X_SCENE_SIZE + DX_VAL*(float)xp;}                           // get_xval (src/mesh.h:122)
+	TERRA_HD float yval(int yp) const {return -Y_SCENE_SIZE + DY_VAL*(float)yp;}
+};
+struct shadow_pt_t {float x, y, z;};
+TERRA_HD int shadow_region(shadow_pt_t v, float const d[3][2]) {
+	int region = 0;
+	if (v.x < d[0][0]) {region |= 0x01;} else if (v.x >= d[0][1]) {region |= 0x02;}
+	if (v.y < d[1][0]) {region |= 0x04;} else if (v.y >= d[1][1]) {region |= 0x08;}
+	if (v.z < d[2][0]) {region |= 0x10;} else if (v.z >= d[2][1]) {region |= 0x20;}
+	return region;
+}
+TERRA_HD bool shadow_line_clip(shadow_pt_t &v1, shadow_pt_t &v2, float const d[3][2]) {
+	int const region1 = shadow_region(v1, d), region2 = shadow_region(v2, d);
+	if (region1 & region2) return false;
+	int const region3 = region1 | region2;
+	if (region3 == 0) return true;
+	float tmin = 0.0f, tmax = 1.0f;
+	shadow_pt_t const dv = {v2.x - v1.x, v2.y - v1.y, v2.z - v1.z};
+#define TERRA_SH_CLIP(reg, va, vb, vd, vc) if (region3 & (reg)) {float const t = ((va) - (vb))/(vd); if ((vc) > 0.0f) {if (t > tmin) tmin = t;} else {if (t < tmax) tmax = t;} if (tmin >= tmax) return false;}
+	TERRA_SH_CLIP(0x01, d[0][0], v1.x, dv.x,  dv.x)
+	TERRA_SH_CLIP(0x02, d[0][1], v1.x, dv.x, -dv.x)
+	TERRA_SH_CLIP(0x04, d[1][0], v1.y, dv.y,  dv.y)
+	TERRA_SH_CLIP(0x08, d[1][1], v1.y, dv.y, -dv.y)
+	TERRA_SH_CLIP(0x10, d[2][0], v1.z, dv.z,  dv.z)
+	TERRA_SH_CLIP(0x20, d[2][1], v1.z, dv.z, -dv.z)
+#undef TERRA_SH_CLIP
+	if ((double)tmax > 1.0E-12) {v2.x = v1.x + dv.x*tmax; v2.y = v1.y + dv.y*tmax; v2.z = v1.z + dv.z*tmax;}
+	if ((double)tmin < (1.0 - 1.0E-12)) {v1.x += dv.x*tmin; v1.y += dv.y*tmin; v1.z += dv.z*tmin;}
+	return true;
+}
+// Sweep number p in the reference's single-threaded order: p < 2*ysize are run_x's sweeps (y = p), the rest run_y's (x = p - 2*ysize).
+// OUT::shadow(x, y) sets the MESH_SHADOW bit; OUT::out_x / out_y(index, order, value) record an outgoing edge height -- `order` grows with the
+// sequential execution order (sweep, then step), the writer with the highest order must win.
+template<class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t const &c, float const *mh, float const *sh_in_x, float const *sh_in_y, unsigned p, OUT &out) {
+	shadow_pt_t v1;
+	if (p < 2u*(unsigned)c.ysize) {v1.x = c.xval((c.dirx > 0) ? 0 : c.xsize); v1.y = (float)((double)-c.Y_SCENE_SIZE + 0.5*(double)c.DY_VAL*(double)(int)p); v1.z = 0.0f;}
+	else {int const xx = (int)(p - 2u*(unsigned)c.ysize); v1.x = (float)((double)-c.X_SCENE_SIZE + 0.5*(double)c.DX_VAL*(double)xx); v1.y = c.yval((c.diry > 0) ? 0 : c.ysize); v1.z = 0.0f;}
+	shadow_pt_t v2 = {v1.x + c.dirx*c.dist, v1.y + c.diry*c.dist, v1.z + 0.0f};
+	float const d[3][2] = {{-c.X_SCENE_SIZE, c.xval(c.xsize)}, {-c.Y_SCENE_SIZE, c.yval(c.ysize)}, {c.zmin, c.zmax}};
+	if (!shadow_line_clip(v1, v2, d)) return;
+	int const xa = c.xpos(v1.x), ya = c.ypos(v1.y), xb = c.xpos(v2.x), yb = c.ypos(v2.y), dx = xb - xa, dy = yb - ya;
+	bool const dim = (fabsf(c.dirx) < fabsf(c.diry));
+	double const dir_ratio = (double)(c.dirz/(dim ? c.diry : c.dirx));
+	bool inited = false;
+	shadow_pt_t cur = {0.0f, 0.0f, 0.0f};
+	int x = xa, y = ya, dx1 = 0, dy1 = 0, dx2 = 0, dy2 = 0;
+	if (dx < 0) {dx1 = -1; dx2 = -1;} else if (dx > 0) {dx1 = 1; dx2 = 1;}
+	if (dy < 0) {dy1 = -1;} else if (dy > 0) {dy1 = 1;}
+	int longest = (dx < 0) ? -dx : dx, shortest = (dy < 0) ? -dy : dy;
+	if (longest <= shortest) {
+		int const tmp = longest; longest = shortest; shortest = tmp;
+		if (dy < 0) {dy2 = -1;} else if (dy > 0) {dy2 = 1;}
+		dx2 = 0;
+	}
+	int numerator = longest >> 1;
+	for (int i = 0; i <= longest; i++) {
+		if (x >= 0 && y >= 0 && x < c.xsize && y < c.ysize) {
+			shadow_pt_t const pt = {-c.X_SCENE_SIZE + c.DX_VAL*(float)x, -c.Y_SCENE_SIZE + c.DY_VAL*(float)y, mh[y*c.xsize + x]};
+			if (sh_in_y != nullptr && x == xa && sh_in_y[y] > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = sh_in_y[y]; inited = true;} // MESH_MIN_Z (src/mesh.h:9)
+			else if (sh_in_x != nullptr && y == ya && sh_in_x[x] > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = sh_in_x[x]; inited = true;}
+			float const shadow_z = (float)((double)((dim ? pt.y : pt.x) - (dim ? cur.y : cur.x))*dir_ratio + (double)cur.z);
+			if (inited && shadow_z > pt.z) {
+				out.shadow(x, y);
+				uint32_t const order = p*1024u + (uint32_t)i + 1u; // sweeps are at most ~2*130 steps long
+				if (x == xb) {out.out_y(y, order, shadow_z);}
+				if (y == yb) {out.out_x(x, order, shadow_z);}
+			}
+			else {cur = pt;}
+			inited = true;
+		}
+		numerator += shortest;
+		if (numerator >= longest) {numerator -= longest; x += dx1; y += dy1;}
+		else {x += dx2; y += dy2;}
+	}
+}
 
 // terrain_hmap_manager_t's sampling of a heightmap texture (src/heightmap.cpp:60-84,310-407; value scaling src/mesh_gen.cpp:120): the image stays where the
 // caller put it in HBM (1 byte per pixel, or 2 = {fraction, integer} as written by terra_quantize16_dev / write_pixel_16_bits)
@@ -153,7 +236,7 @@ template<class BE> struct terra_engine {
 
 	// grow-only device scratch
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
-	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_vox, s_sk, s_mm;
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_shadow, s_vox, s_sk, s_mm;
 	bool tiled_mesh_ao = false; // enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778)
 	uint8_t const *hmap_pix = nullptr; int hmap_w = 0, hmap_h = 0, hmap_nc = 0; // terrain_hmap_manager's image (device memory, owned by the caller)
 	float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;                          // src/mesh_gen.cpp:41, set by set_mesh_height_scales_for_zval_range
@@ -165,7 +248,7 @@ template<class BE> struct terra_engine {
 		return (T *)s.p;
 	}
 	~terra_engine() {
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 	}
 
@@ -755,6 +838,76 @@ template<class BE> struct terra_engine {
 			float const wpz_max = get_max_sea_level();
 			float const rad_c = (dxv*dxv + dyv*dyv)*size*size;
 			be.tile_post(n, d_refs, d_zvals, d_stats, d_normals, d_min_nz, wpz_max, rad_c, dxv, dyv, dxdy);
+		}
+	}
+
+	// tile_t::calc_shadows_for_light + calc_mesh_shadows (src/tiled_mesh.cpp:664-692, src/visibility.cpp:510-520) for a batch and one directional light:
+	// smask[n][130][130] gets the MESH_SHADOW bit.  A tile's sweeps start from the edge heights its two neighbours toward the light left behind
+	// (sh_out -> sh_in), so the batch is processed in dependency levels (anti-diagonals); tiles of one level run in parallel, every sweep of a tile too.
+	void tiles_mesh_shadows_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, float const lpos[3], uint8_t *d_smask) {
+		require_scene();
+		if (n == 0) return;
+		uint32_t const zv = 130;
+		float const lx = lpos[0], ly = lpos[1], lz = lpos[2];
+		bool const all_shadowed = (lz < zmin);
+		be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); // MESH_SHADOW (src/3DWorld.h:1403)
+		if ((double)lx == 0.0 && (double)ly == 0.0) return; // straight down = no mesh shadows
+		shadow_consts_t c;
+		c.X_SCENE_SIZE = cfg.scene_x; c.Y_SCENE_SIZE = cfg.scene_y; c.DX_VAL = DX_VAL; c.DY_VAL = DY_VAL; c.DX_VAL_INV = DX_VAL_INV; c.DY_VAL_INV = DY_VAL_INV;
+		c.zmin = zmin; c.zmax = zmax; c.xsize = (int)zv; c.ysize = (int)zv;
+		float const lmag = sqrtf(lx*lx + ly*ly + lz*lz); // dir = -lpos.get_norm()
+		if ((double)lmag < 1.0E-12) {c.dirx = -lx; c.diry = -ly; c.dirz = -lz;} else {c.dirx = -(lx/lmag); c.diry = -(ly/lmag); c.dirz = -(lz/lmag);}
+		c.dist = (float)(2.0*(double)(cfg.mesh_x + cfg.mesh_y)/(double)sqrtf(c.dirx*c.dirx + c.diry*c.diry)); // 2.0*XY_SUM_SIZE/sqrt(...)
+		// dependency levels
+		int const sx = (lx < 0.0f) ? -1 : 1, sy = (ly < 0.0f) ? -1 : 1;
+		std::map<std::pair<int32_t, int32_t>, uint32_t> index;
+		for (uint32_t i = 0; i < n; ++i) {index[std::make_pair(tile_xy[2*i], tile_xy[2*i+1])] = i;}
+		std::vector<int32_t> adj(2*(size_t)n, -1); // [i][0]: neighbour in x toward the light (its sh_out_y is our sh_in_y), [i][1]: neighbour in y
+		std::vector<uint32_t> level(n, 0), order(n);
+		for (uint32_t i = 0; i < n; ++i) {
+			auto ax = index.find(std::make_pair(tile_xy[2*i] + sx, tile_xy[2*i+1])), ay = index.find(std::make_pair(tile_xy[2*i], tile_xy[2*i+1] + sy));
+			if (ax != index.end()) adj[2*i] = (int32_t)ax->second;
+			if (ay != index.end()) adj[2*i+1] = (int32_t)ay->second;
+		}
+		{ // levels by relaxation over tiles sorted toward the light (a tile's dependencies lie strictly further toward the light in x or y)
+			for (uint32_t i = 0; i < n; ++i) order[i] = i;
+			std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+				int64_t const ka = (int64_t)sx*tile_xy[2*a] + (int64_t)sy*tile_xy[2*a+1], kb = (int64_t)sx*tile_xy[2*b] + (int64_t)sy*tile_xy[2*b+1];
+				return ka > kb;
+			});
+			for (uint32_t i : order) {
+				uint32_t lv = 0;
+				if (adj[2*i] >= 0) lv = std::max(lv, level[adj[2*i]] + 1);
+				if (adj[2*i+1] >= 0) lv = std::max(lv, level[adj[2*i+1]] + 1);
+				level[i] = lv;
+			}
+			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {return level[a] < level[b];});
+		}
+		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*n*zv*8 + (size_t)2*n*zv*4 + 256*3;
+		uint8_t *base = scratch<uint8_t>(s_shadow, bytes);
+		uint32_t *d_order = (uint32_t *)base;
+		int32_t *d_adj = (int32_t *)(base + (((size_t)n*4 + 255) & ~(size_t)255));
+		unsigned long long *d_out = (unsigned long long *)((uint8_t *)d_adj + ((adj.size()*4 + 255) & ~(size_t)255)); // [2][n][zv]: (order << 32) | float bits, 0 = never written
+		float *d_sh = (float *)(d_out + (size_t)2*n*zv); // [2][n][zv]: the finished sh_out arrays (MESH_MIN_Z where nothing was written), read as sh_in by the next level
+		be.h2d(d_order, order.data(), (size_t)n*4);
+		be.h2d(d_adj, adj.data(), adj.size()*4);
+		be.fill32(d_out, 0, (size_t)2*n*zv*2);
+		uint32_t const npaths = 4*zv;
+		for (uint32_t first = 0; first < n;) {
+			uint32_t last = first;
+			while (last < n && level[order[last]] == level[order[first]]) ++last;
+			uint32_t const cnt = last - first;
+			uint32_t const *ord = d_order + first;
+			be.tile_shadows(c, cnt, ord, d_adj, n, d_zvals, d_sh, d_out, d_smask, npaths);
+			be.launch((size_t)cnt*2*zv, [=] TERRA_LAMBDA (size_t i) { // publish the level's outgoing edge heights
+				uint32_t const k = (uint32_t)(i / (2*zv)), r = (uint32_t)(i % (2*zv)), which = r / zv, e = r % zv, t = ord[k];
+				unsigned long long const v = d_out[((size_t)which*n + t)*zv + e];
+				uint32_t const bits = (uint32_t)(v & 0xFFFFFFFFull);
+				float f = -1.0E6f; // MESH_MIN_Z: sh_out[l][d].resize(zvsize, MESH_MIN_Z) (src/tiled_mesh.cpp:677)
+				if (v != 0) {memcpy(&f, &bits, 4);}
+				d_sh[((size_t)which*n + t)*zv + e] = f;
+			});
+			first = last;
 		}
 	}
 

@@ -336,6 +336,7 @@ struct direct_mem_t {
 #define TERRA_LANE0 ((threadIdx.x & 63) == 0)
 #define TERRA_WAVE_SYNC() __syncthreads()
 #define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define TERRA_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define TERRA_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define TERRA_ATOMIC_OR(p, v) atomicOr((p), (v))
 #define TERRA_ATOMIC_EXCH(p, v) atomicExch((p), (v))
@@ -346,11 +347,13 @@ struct direct_mem_t {
 #define TERRA_LANE0 true
 #define TERRA_WAVE_SYNC() do {} while (0)
 template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
+template<class T> inline T terra_host_atomic_max(T *p, T v) {T o = *p; if (v > o) *p = v; return o;}
 template<class T> inline T terra_host_atomic_add(T *p, T v) {T o = *p; *p = o + v; return o;}
 template<class T> inline T terra_host_atomic_or(T *p, T v) {T o = *p; *p = o | v; return o;}
 template<class T> inline T terra_host_atomic_exch(T *p, T v) {T o = *p; *p = v; return o;}
 template<class T> inline T terra_host_atomic_cas(T *p, T c, T v) {T o = *p; if (o == c) *p = v; return o;}
 #define TERRA_ATOMIC_MIN(p, v) terra_host_atomic_min((p), (v))
+#define TERRA_ATOMIC_MAX(p, v) terra_host_atomic_max((p), (v))
 #define TERRA_ATOMIC_ADD(p, v) terra_host_atomic_add((p), (v))
 #define TERRA_ATOMIC_OR(p, v) terra_host_atomic_or((p), (v))
 #define TERRA_ATOMIC_EXCH(p, v) terra_host_atomic_exch((p), (v))

@@ -46,6 +46,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void sync() {use(); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	void *alloc(size_t bytes) {use(); void *p = nullptr; TERRA_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1)); return p;}
 	void free(void *p) {use(); (void)hipFree(p);}
+	void fill8(void *p, uint8_t v, size_t count) {use(); if (count) TERRA_HIP_CHECK(hipMemsetAsync(p, v, count, stream));}
 	void fill32(void *p, uint32_t v, size_t count) {use(); if (count) TERRA_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)p, (int)v, count, stream));}
 	// host buffers are ordinary pageable memory (often stack variables): copies are stream-ordered and then waited for
 	void h2d(void *d, void const *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
@@ -176,6 +177,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
+	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, float const *sh, unsigned long long *out, uint8_t *sm, uint32_t np) {tile_shadows_simple(c, cnt, ord, adj, n, z, sh, out, sm, np);}
 	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {
 		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz); return;}
 		use();

@@ -38,6 +38,35 @@ template<class DERIVED> struct simple_paths {
 			zvals[i] = finish_cell(z, job, nc, L, d_sm + (size_t)r.xi*zv, d_sm + (size_t)(nux + r.yi)*zv, x, y);
 		});
 	}
+	// mesh shadows of one dependency level: one logical thread per (tile, sweep); smask bits by atomic OR on the containing word, outgoing edge
+	// heights by atomic max of (sequential order << 32 | value bits) so that the writer the single-threaded reference would see last wins
+	struct shadow_out_t {
+		uint8_t *sm; unsigned long long *ox, *oy; int xsize;
+		TERRA_HD void shadow(int x, int y) {
+			size_t const o = (size_t)y*xsize + x;
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicOr((unsigned int *)(sm + (o & ~(size_t)3)), 0x02u << (8u*(unsigned)(o & 3))); // tile bases are multiples of 16900 bytes: word-aligned
+#else
+			sm[o] |= 0x02;
+#endif
+		}
+		TERRA_HD static unsigned long long pack(uint32_t order, float v) {uint32_t b; memcpy(&b, &v, 4); return ((unsigned long long)order << 32) | b;}
+		TERRA_HD void out_x(int ix, uint32_t order, float v) {TERRA_ATOMIC_MAX(&ox[ix], pack(order, v));}
+		TERRA_HD void out_y(int iy, uint32_t order, float v) {TERRA_ATOMIC_MAX(&oy[iy], pack(order, v));}
+	};
+	void tile_shadows_simple(shadow_consts_t const &c, uint32_t cnt, uint32_t const *d_order, int32_t const *d_adj, uint32_t n, float const *d_zvals, float const *d_sh,
+		unsigned long long *d_out, uint8_t *d_smask, uint32_t npaths)
+	{
+		unsigned const zv = 130;
+		self().launch((size_t)cnt*npaths, [=] TERRA_LAMBDA (size_t i) {
+			uint32_t const k = (uint32_t)(i / npaths), p = (uint32_t)(i % npaths), t = d_order[k];
+			int32_t const ax = d_adj[2*t], ay = d_adj[2*t + 1];
+			float const *sh_in_y = (ax >= 0) ? d_sh + ((size_t)1*n + ax)*zv : nullptr; // the x-neighbour's sh_out_y (src/tiled_mesh.cpp:676-687)
+			float const *sh_in_x = (ay >= 0) ? d_sh + ((size_t)0*n + ay)*zv : nullptr;
+			shadow_out_t out{d_smask + (size_t)t*zv*zv, d_out + ((size_t)0*n + t)*zv, d_out + ((size_t)1*n + t)*zv, (int)zv};
+			shadow_trace_path(c, d_zvals + (size_t)t*zv*zv, sh_in_x, sh_in_y, p, out);
+		});
+	}
 	// AO lighting, simple form: one logical thread per texel, context read from global memory
 	void tile_ao_simple(uint32_t n, float const *d_zvals, float const *d_ctx, uint8_t *d_ao, float dz) {
 		unsigned const stride = 129, zv = 130, cs = 201;

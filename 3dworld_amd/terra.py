@@ -109,6 +109,8 @@ _PROTOS = {
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
     "terra_set_tiled_mesh_ao": (_i32, [_vp, _i32]),
+    "terra_tiles_mesh_shadows_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
+    "terra_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_hmap_set_dev": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "terra_set_mesh_height_scales_for_zval_range": (_i32, [_vp, _f, _f]),
     "terra_tiles_ao_lighting_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
@@ -263,6 +265,20 @@ class Terra:
         self._ck(self.lib.terra_hmap_set_dev(self.ctx, ptr, width, height, ncolors))
         if ptr and min_z is not None:
             self._ck(self.lib.terra_set_mesh_height_scales_for_zval_range(self.ctx, min_z, dz))
+
+    def tiles_mesh_shadows(self, tile_xy, zvals, light_pos):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        z = np.ascontiguousarray(zvals, np.float32).reshape(n, 130, 130)
+        sm = np.empty((n, 130, 130), np.uint8)
+        lp = (C.c_float * 3)(*light_pos)
+        self._ck(self.lib.terra_tiles_mesh_shadows(self.ctx, txy.ctypes.data, n, z.ctypes.data, lp, sm.ctypes.data))
+        return sm
+
+    def tiles_mesh_shadows_dev(self, tile_xy, z_ptr, light_pos, smask_ptr):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        lp = (C.c_float * 3)(*light_pos)
+        self._ck(self.lib.terra_tiles_mesh_shadows_dev(self.ctx, txy.ctypes.data, len(txy), z_ptr, lp, smask_ptr))
 
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))

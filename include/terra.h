@@ -183,6 +183,14 @@ int  terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable);
 int  terra_tiles_ao_lighting_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_ao);
 int  terra_tiles_ao_lighting(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, uint8_t *h_ao);
 
+/* ---- tile mesh shadows of one directional light: tile_t::calc_shadows_for_light + calc_mesh_shadows / mesh_shadow_gen (src/tiled_mesh.cpp:664-692,
+ * src/visibility.cpp:411-520).  zvals: [n][130][130]; light_pos: the light's position vector (get_light_pos(l)); smask: [n][130][130] bytes, 0 or
+ * MESH_SHADOW (0x02).  Shadows cross tile borders: a tile starts its sweeps from the edge heights left by its neighbours toward the light when those are
+ * part of the batch (sh_out -> sh_in), otherwise from nothing, exactly like a tile whose neighbour does not exist.  Order of evaluation = the
+ * reference's single-threaded order (its two OpenMP sections race). */
+int  terra_tiles_mesh_shadows_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask);
+int  terra_tiles_mesh_shadows(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask);
+
 /* ---- voxels: voxel_manager::create_procedural fill (src/voxels.cpp:278-346).  out is z-fastest: ix = z + (x + y*nx)*nz (src/voxels.h:141-144). */
 int  terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
                           float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);

@@ -19,6 +19,8 @@
 //   heightmap_t::from_floats / write_pixel_16_bits  src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893
 
 #include "3DWorld.h"
+#include <map>
+#include <functional>
 #include "mesh.h"
 #include "textures.h"
 #include "heightmap.h"
@@ -426,6 +428,53 @@ REF_API void ref_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned c
 			float const ao_scale(1.0 - float(atten)/float(SHIM_NUM_AO_DIRS*SHIM_NUM_AO_STEPS));
 			ao[y*stride + x] = (unsigned char)(255.0*ao_scale);
 		}
+	}
+}
+
+// ---- row f2: mesh shadows.  calc_mesh_shadows / mesh_shadow_gen are the reference's own code (src/visibility.cpp:411-517, do_line_clip from src/Math3d.cpp:1070);
+// the chaining of sh_in / sh_out between adjacent tiles restates tile_t::calc_shadows_for_light (src/tiled_mesh.cpp:664-692).
+void calc_mesh_shadows(unsigned l, point const &lpos, float const *const mh, unsigned char *smask, int xsize, int ysize,
+	float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y);
+REF_API void ref_calc_mesh_shadows(float lx, float ly, float lz, float const *mh, unsigned char *smask, int xsize, int ysize,
+	float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y)
+{
+	// mesh_shadow_gen::run() asks for two threads explicitly ("#pragma omp parallel sections num_threads(2)": the X and the Y sweeps), which race on
+	// smask / sh_out.  Called from one thread of an ACTIVE (two-thread) parallel region with max-active-levels = 1, the nested region is
+	// serialised and its sections run in order: the single-threaded semantics.  (A one-thread outer region would not count as active.)
+	omp_set_max_active_levels(1);
+#pragma omp parallel num_threads(2)
+	{
+		if (omp_get_thread_num() == 0) {calc_mesh_shadows(LIGHT_SUN, point(lx, ly, lz), mh, smask, xsize, ysize, sh_in_x, sh_in_y, sh_out_x, sh_out_y);}
+	}
+}
+// a batch of tiles: every tile pulls its inputs from the neighbours toward the light that are part of the batch (computed first, like the recursion in :683)
+REF_API void ref_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float lx, float ly, float lz, unsigned char *smask) {
+	unsigned const zvsize(130);
+	point const lpos(lx, ly, lz);
+	int const sx((lpos.x < 0.0) ? -1 : 1), sy((lpos.y < 0.0) ? -1 : 1); // toward the light source
+	std::map<std::pair<int,int>, unsigned> ix;
+	for (unsigned i = 0; i < n; ++i) {ix[std::make_pair(tile_xy[2*i], tile_xy[2*i+1])] = i;}
+	vector<vector<float>> sh_out[2];
+	sh_out[0].resize(n); sh_out[1].resize(n);
+	vector<char> done(n, 0);
+	std::function<void(unsigned)> run = [&](unsigned i) {
+		if (done[i]) return;
+		done[i] = 1;
+		float const *sh_in[2] = {0, 0};
+		int const adj[2][2] = {{tile_xy[2*i] + sx, tile_xy[2*i+1]}, {tile_xy[2*i], tile_xy[2*i+1] + sy}};
+		for (unsigned d = 0; d < 2; ++d) {
+			sh_out[!d][i].assign(zvsize, MESH_MIN_Z);
+			auto it(ix.find(std::make_pair(adj[d][0], adj[d][1])));
+			if (it == ix.end()) continue; // no adjacent tile
+			run(it->second); // recursive call on adjacent tile
+			sh_in[!d] = sh_out[!d][it->second].data();
+		}
+		calc_mesh_shadows(LIGHT_SUN, lpos, zvals + (size_t)i*zvsize*zvsize, smask + (size_t)i*zvsize*zvsize, zvsize, zvsize, sh_in[0], sh_in[1], sh_out[0][i].data(), sh_out[1][i].data());
+	};
+	omp_set_max_active_levels(1); // see ref_calc_mesh_shadows
+#pragma omp parallel num_threads(2)
+	{
+		if (omp_get_thread_num() == 0) {for (unsigned i = 0; i < n; ++i) {run(i);}}
 	}
 }
 

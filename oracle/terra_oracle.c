@@ -962,6 +962,139 @@ void orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao)
 	free(czv);
 }
 
+/* ---- row f2: mesh shadows.  calc_mesh_shadows + mesh_shadow_gen (src/visibility.cpp:411-508), do_line_clip / get_region (src/Math3d.cpp:1029-1086,
+ * src/inlines.h:522-528), get_xpos / get_xval (src/mesh.h:122-130).  The reference runs the X and the Y sweeps in two OpenMP sections that race on
+ * smask / sh_out; the defined order is the single-threaded one: all X sweeps, then all Y sweeps. */
+#define MESH_MIN_Z_F (-1.0E6f) /* src/mesh.h:9 */
+#define MESH_SHADOW_BIT 0x02   /* src/3DWorld.h:1403 */
+typedef struct {float x, y, z;} pt3;
+static int sh_get_region(pt3 v, float const d[3][2]) {
+	int region = 0;
+	if (v.x < d[0][0]) {region |= 0x01;} else if (v.x >= d[0][1]) {region |= 0x02;}
+	if (v.y < d[1][0]) {region |= 0x04;} else if (v.y >= d[1][1]) {region |= 0x08;}
+	if (v.z < d[2][0]) {region |= 0x10;} else if (v.z >= d[2][1]) {region |= 0x20;}
+	return region;
+}
+#define SH_TEST_CLIP_T(reg, va, vb, vd, vc) \
+	if (region3 & (reg)) { \
+		float const t = ((va) - (vb))/(vd); \
+		if ((double)(vc) > 0.0) {if (t > tmin) tmin = t;} else {if (t < tmax) tmax = t;} \
+		if (tmin >= tmax) return 0; \
+	}
+static int sh_do_line_clip(pt3 *v1, pt3 *v2, float const d[3][2]) { /* src/Math3d.cpp:1070-1086 */
+	int const region1 = sh_get_region(*v1, d), region2 = sh_get_region(*v2, d);
+	if (region1 & region2) return 0;
+	int const region3 = region1 | region2;
+	if (region3 == 0) return 1;
+	float tmin = 0.0f, tmax = 1.0f;
+	pt3 const dv = {v2->x - v1->x, v2->y - v1->y, v2->z - v1->z}; /* vector3d(v2, v1) = v2 - v1 */
+	SH_TEST_CLIP_T(0x01, d[0][0], v1->x, dv.x,  dv.x);
+	SH_TEST_CLIP_T(0x02, d[0][1], v1->x, dv.x, -dv.x);
+	SH_TEST_CLIP_T(0x04, d[1][0], v1->y, dv.y,  dv.y);
+	SH_TEST_CLIP_T(0x08, d[1][1], v1->y, dv.y, -dv.y);
+	SH_TEST_CLIP_T(0x10, d[2][0], v1->z, dv.z,  dv.z);
+	SH_TEST_CLIP_T(0x20, d[2][1], v1->z, dv.z, -dv.z);
+	if ((double)tmax > 1.0E-12) {v2->x = v1->x + dv.x*tmax; v2->y = v1->y + dv.y*tmax; v2->z = v1->z + dv.z*tmax;}       /* TOLERANCE (src/3DWorld.h:50) */
+	if ((double)tmin < (1.0 - 1.0E-12)) {v1->x += dv.x*tmin; v1->y += dv.y*tmin; v1->z += dv.z*tmin;}
+	return 1;
+}
+static int sh_xpos(float xval) {return (int)((double)((xval + X_SCENE_SIZE)*DX_VAL_INV) + 0.5);} /* int((xval + X_SCENE_SIZE)*DX_VAL_INV + 0.5) */
+static int sh_ypos(float yval) {return (int)((double)((yval + Y_SCENE_SIZE)*DY_VAL_INV) + 0.5);}
+static float sh_xval(int xpos) {return -X_SCENE_SIZE + DX_VAL*(float)xpos;}
+static float sh_yval(int ypos) {return -Y_SCENE_SIZE + DY_VAL*(float)ypos;}
+
+typedef struct {
+	unsigned char *smask; float const *mh, *sh_in_x, *sh_in_y; float *sh_out_x, *sh_out_y;
+	float dist; int xsize, ysize; pt3 dir;
+} shadow_gen_t;
+
+static void sh_trace_shadow_path(shadow_gen_t const *g, pt3 v1) { /* src/visibility.cpp:422-487 */
+	pt3 v2 = {v1.x + g->dir.x*g->dist, v1.y + g->dir.y*g->dist, v1.z + 0.0f};
+	float const d[3][2] = {{-X_SCENE_SIZE, sh_xval(g->xsize)}, {-Y_SCENE_SIZE, sh_yval(g->ysize)}, {zmin, zmax}};
+	if (!sh_do_line_clip(&v1, &v2, d)) return;
+	int const xa = sh_xpos(v1.x), ya = sh_ypos(v1.y), xb = sh_xpos(v2.x), yb = sh_ypos(v2.y), dx = xb - xa, dy = yb - ya;
+	int const dim = (fabsf(g->dir.x) < fabsf(g->dir.y));
+	double const dir_ratio = (double)(g->dir.z/(dim ? g->dir.y : g->dir.x));
+	int inited = 0;
+	pt3 cur = {0.0f, 0.0f, 0.0f}; /* uninitialised in the reference; never used before `inited` */
+	int x = xa, y = ya;
+	int dx1 = 0, dy1 = 0, dx2 = 0, dy2 = 0;
+	if (dx < 0) {dx1 = -1; dx2 = -1;} else if (dx > 0) {dx1 = 1; dx2 = 1;}
+	if (dy < 0) {dy1 = -1;} else if (dy > 0) {dy1 = 1;}
+	int longest = abs(dx), shortest = abs(dy);
+	if (longest <= shortest) {
+		int const tmp = longest; longest = shortest; shortest = tmp;
+		if (dy < 0) {dy2 = -1;} else if (dy > 0) {dy2 = 1;}
+		dx2 = 0;
+	}
+	int numerator = longest >> 1;
+	for (int i = 0; i <= longest; i++) {
+		if (x >= 0 && y >= 0 && x < g->xsize && y < g->ysize) {
+			pt3 const pt = {-X_SCENE_SIZE + DX_VAL*(float)x, -Y_SCENE_SIZE + DY_VAL*(float)y, g->mh[y*g->xsize + x]};
+			if (g->sh_in_y != NULL && x == xa && g->sh_in_y[y] > MESH_MIN_Z_F) {cur.x = pt.x; cur.y = pt.y; cur.z = g->sh_in_y[y]; inited = 1;}
+			else if (g->sh_in_x != NULL && y == ya && g->sh_in_x[x] > MESH_MIN_Z_F) {cur.x = pt.x; cur.y = pt.y; cur.z = g->sh_in_x[x]; inited = 1;}
+			float const shadow_z = (float)((double)((dim ? pt.y : pt.x) - (dim ? cur.y : cur.x))*dir_ratio + (double)cur.z);
+			if (inited && shadow_z > pt.z) {
+				g->smask[y*g->xsize + x] |= MESH_SHADOW_BIT;
+				if (g->sh_out_y != NULL && x == xb) {g->sh_out_y[y] = shadow_z;}
+				if (g->sh_out_x != NULL && y == yb) {g->sh_out_x[x] = shadow_z;}
+			}
+			else {cur = pt;}
+			inited = 1;
+		}
+		numerator += shortest;
+		if (numerator >= longest) {numerator -= longest; x += dx1; y += dy1;}
+		else {x += dx2; y += dy2;}
+	}
+}
+void orc_calc_mesh_shadows(float lx, float ly, float lz, float const *mh, unsigned char *smask, int xsize, int ysize,
+	float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y)
+{ /* calc_mesh_shadows (src/visibility.cpp:510-520) for l = LIGHT_SUN (no_shadow only concerns the moon) + mesh_shadow_gen::run (:496-507) */
+	int const all_shadowed = (lz < zmin);
+	for (int i = 0; i < xsize*ysize; ++i) {smask[i] = all_shadowed ? MESH_SHADOW_BIT : 0;}
+	if ((double)lx == 0.0 && (double)ly == 0.0) return; /* straight down = no mesh shadows */
+	shadow_gen_t g;
+	g.smask = smask; g.mh = mh; g.sh_in_x = sh_in_x; g.sh_in_y = sh_in_y; g.sh_out_x = sh_out_x; g.sh_out_y = sh_out_y; g.xsize = xsize; g.ysize = ysize;
+	float const lmag = sqrtf(lx*lx + ly*ly + lz*lz); /* dir = -lpos.get_norm() (src/3DWorld.h:297-300) */
+	if ((double)lmag < 1.0E-12) {g.dir.x = -lx; g.dir.y = -ly; g.dir.z = -lz;} else {g.dir.x = -(lx/lmag); g.dir.y = -(ly/lmag); g.dir.z = -(lz/lmag);}
+	g.dist = (float)(2.0*(double)(MESH_X_SIZE + MESH_Y_SIZE)/(double)sqrtf(g.dir.x*g.dir.x + g.dir.y*g.dir.y)); /* 2.0*XY_SUM_SIZE/sqrt(...) */
+	{ /* run_x */
+		float const xval = sh_xval((g.dir.x > 0) ? 0 : xsize);
+		for (int y = 0; y < 2*ysize; ++y) {pt3 const v = {xval, (float)((double)-Y_SCENE_SIZE + 0.5*(double)DY_VAL*(double)y), 0.0f}; sh_trace_shadow_path(&g, v);}
+	}
+	{ /* run_y */
+		float const yval = sh_yval((g.dir.y > 0) ? 0 : ysize);
+		for (int x = 0; x < 2*xsize; ++x) {pt3 const v = {(float)((double)-X_SCENE_SIZE + 0.5*(double)DX_VAL*(double)x), yval, 0.0f}; sh_trace_shadow_path(&g, v);}
+	}
+}
+/* a batch of tiles chained like tile_t::calc_shadows_for_light (src/tiled_mesh.cpp:664-692): inputs from the batch neighbours toward the light */
+static void orc_tile_shadow_rec(int const *tile_xy, unsigned n, float const *zvals, float lx, float ly, float lz, unsigned char *smask, float *sh_out, char *done, unsigned i) {
+	unsigned const zv = 130;
+	if (done[i]) return;
+	done[i] = 1;
+	int const sx = (lx < 0.0f) ? -1 : 1, sy = (ly < 0.0f) ? -1 : 1;
+	float const *sh_in[2] = {NULL, NULL};
+	int const adj[2][2] = {{tile_xy[2*i] + sx, tile_xy[2*i+1]}, {tile_xy[2*i], tile_xy[2*i+1] + sy}};
+	for (unsigned d = 0; d < 2; ++d) {
+		float *so = sh_out + ((size_t)(!d)*n + i)*zv;
+		for (unsigned k = 0; k < zv; ++k) {so[k] = MESH_MIN_Z_F;}
+		for (unsigned j = 0; j < n; ++j) {
+			if (tile_xy[2*j] == adj[d][0] && tile_xy[2*j+1] == adj[d][1]) {
+				orc_tile_shadow_rec(tile_xy, n, zvals, lx, ly, lz, smask, sh_out, done, j);
+				sh_in[!d] = sh_out + ((size_t)(!d)*n + j)*zv;
+				break;
+			}
+		}
+	}
+	orc_calc_mesh_shadows(lx, ly, lz, zvals + (size_t)i*zv*zv, smask + (size_t)i*zv*zv, (int)zv, (int)zv, sh_in[0], sh_in[1], sh_out + ((size_t)0*n + i)*zv, sh_out + ((size_t)1*n + i)*zv);
+}
+void orc_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float lx, float ly, float lz, unsigned char *smask) {
+	float *sh_out = (float *)malloc((size_t)2*n*130*sizeof(float));
+	char *done = (char *)calloc(n, 1);
+	for (unsigned i = 0; i < n; ++i) {orc_tile_shadow_rec(tile_xy, n, zvals, lx, ly, lz, smask, sh_out, done, i);}
+	free(sh_out); free(done);
+}
+
 /* a13: normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880; vector3d::get_norm src/3DWorld.h) */
 float orc_tile_normals(float const *zvals, unsigned char *rgba) {
 	unsigned const stride = 129, zvsize = 130;

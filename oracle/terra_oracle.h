@@ -84,6 +84,8 @@ void  orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolo
 void  orc_set_mesh_height_scales_for_zval_range(float min_z, float dz);
 float orc_get_clamped_height(int x, int y);
 void  orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao);
+void  orc_calc_mesh_shadows(float lx, float ly, float lz, float const *mh, unsigned char *smask, int xsize, int ysize, float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y);
+void  orc_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float lx, float ly, float lz, unsigned char *smask);
 float orc_tile_normals(float const *zvals, unsigned char *rgba);
 void  orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out);
 void  orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],

@@ -121,6 +121,8 @@ class Checker:
         f("tile_create_zvals", None, [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.POINTER(TileStats)])
         f("tile_normals", C.c_float, [C.c_void_p, C.c_void_p])
         f("set_tiled_mesh_ao", None, [C.c_int])
+        f("calc_mesh_shadows", None, [C.c_float] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4)
+        f("tiles_mesh_shadows", None, [C.c_void_p, C.c_uint, C.c_void_p] + [C.c_float] * 3 + [C.c_void_p])
         f("hmap_set", None, [C.c_void_p, C.c_int, C.c_int, C.c_int])
         f("set_mesh_height_scales_for_zval_range", None, [C.c_float, C.c_float])
         f("get_clamped_height", C.c_float, [C.c_int, C.c_int])
@@ -207,6 +209,25 @@ class Checker:
         return z, st
 
     def set_tiled_mesh_ao(self, v): self._set_tiled_mesh_ao(int(v))
+
+    def calc_mesh_shadows(self, lpos, mh, sh_in_x=None, sh_in_y=None):
+        """calc_mesh_shadows(LIGHT_SUN, lpos, mh, ...) -> (smask, sh_out_x, sh_out_y); sh_out arrays start at MESH_MIN_Z like tile_t does"""
+        mh = np.ascontiguousarray(mh, np.float32)
+        ys, xs = mh.shape
+        smask = np.zeros((ys, xs), np.uint8)
+        so_x = np.full(xs, -1.0e6, np.float32); so_y = np.full(ys, -1.0e6, np.float32)
+        p = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).ctypes.data
+        keep = [np.ascontiguousarray(a, np.float32) for a in (sh_in_x, sh_in_y) if a is not None]
+        self._calc_mesh_shadows(lpos[0], lpos[1], lpos[2], mh.ctypes.data, smask.ctypes.data, xs, ys,
+                                None if sh_in_x is None else keep[0].ctypes.data, None if sh_in_y is None else keep[-1].ctypes.data, so_x.ctypes.data, so_y.ctypes.data)
+        return smask, so_x, so_y
+
+    def tiles_mesh_shadows(self, tile_xy, zvals, lpos):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        z = np.ascontiguousarray(zvals, np.float32).reshape(len(txy), 130, 130)
+        smask = np.zeros((len(txy), 130, 130), np.uint8)
+        self._tiles_mesh_shadows(txy.ctypes.data, len(txy), z.ctypes.data, lpos[0], lpos[1], lpos[2], smask.ctypes.data)
+        return smask
 
     def hmap_set(self, pixels, min_z=None, dz=None):
         """pixels: (h, w, 2) or (h, w) uint8 array kept alive by the caller (None: back to procedural tiles); min_z/dz: set_mesh_height_scales_for_zval_range"""

@@ -247,6 +247,30 @@ def case_tile_ao(pkg, t, orc):
             t.set_tiled_mesh_ao(0); orc.set_tiled_mesh_ao(0)
 
 
+SHADOW_LIGHTS = [(0.6, 0.5, 0.4), (-0.8, 0.3, 0.25), (0.2, -0.9, 0.15), (-0.5, -0.5, 0.8), (1.0, 0.0, 0.3), (0.0, -1.0, 0.2), (0.3, 0.4, -5.0), (0.0, 0.0, 1.0), (0.05, 0.9, 0.02)]
+
+
+def case_tile_mesh_shadows(pkg, t, orc, lights=SHADOW_LIGHTS):
+    """row f2: tile mesh shadows with the edge exchange between neighbouring tiles, against the oracle (itself pinned on the reference's own
+    visibility.cpp / Math3d.cpp): full 3x3 blocks, holes, isolated tiles, lights from every quadrant, axis-aligned, below the terrain, straight down."""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc_); orc.init(oc)
+    tiles = [(tx, ty) for ty in range(-1, 2) for tx in range(0, 3)] + [(7, 7), (4, 0), (5, 1), (4, 2)]
+    z, _, _, _ = t.tiles_create_zvals(tiles, 0, stats=False, normals=False)
+    z = (z * np.float32(4.0)).astype(np.float32)  # steeper terrain: longer shadows that do cross tile borders
+    any_shadow = False
+    for lp in lights:
+        got = t.tiles_mesh_shadows(tiles, z, lp)
+        want = orc.tiles_mesh_shadows(tiles, z, lp)
+        assert (got == want).all(), f"light {lp}: {(got != want).sum()} cells differ"
+        any_shadow |= bool(want.any())
+    assert any_shadow
+    # edge exchange is real: the same tile alone gets a different mask than inside its block (for a low light)
+    alone = t.tiles_mesh_shadows([tiles[4]], z[4:5], lights[1])
+    assert (alone[0] == orc.tiles_mesh_shadows([tiles[4]], z[4:5], lights[1])[0]).all()
+    assert (alone[0] != t.tiles_mesh_shadows(tiles, z, lights[1])[4]).any()
+
+
 def case_tiles_from_heightmap(pkg, t, orc):
     """tiles (zvals, stats, normals, AO) sampled from a 16-bit / 8-bit heightmap texture in device memory: nearest, bilinear, mirror wrap far outside
     the image, procedural detail below mesh_scale 0.75, no erosion -- terrain_hmap_manager_t + the using_hmap branches of the tile code."""

@@ -62,6 +62,10 @@ def test_tile_ao_lighting(pkg, gpu, orc):
     pc.case_tile_ao(pkg, gpu, orc)
 
 
+def test_tile_mesh_shadows(pkg, gpu, orc):
+    pc.case_tile_mesh_shadows(pkg, gpu, orc)
+
+
 def test_tiles_from_heightmap_texture(pkg, gpu, orc):
     pc.case_tiles_from_heightmap(pkg, gpu, orc)
 

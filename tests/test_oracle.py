@@ -186,6 +186,34 @@ def test_oracle_vs_reference_hmap_tiles(orc, ref):
         ref.hmap_set(None); orc.hmap_set(None)
 
 
+LIGHTS = [(0.6, 0.5, 0.4), (-0.8, 0.3, 0.25), (0.2, -0.9, 0.15), (-0.5, -0.5, 0.8), (1.0, 0.0, 0.3), (0.0, -1.0, 0.2), (0.3, 0.4, -5.0), (0.0, 0.0, 1.0), (0.05, 0.9, 0.02)]
+
+
+def test_oracle_vs_reference_mesh_shadows(orc, ref):
+    """row f2: the reference's own calc_mesh_shadows / mesh_shadow_gen / do_line_clip (visibility.cpp, Math3d.cpp compiled in place) against the
+    restatement: single meshes of several shapes with and without incoming edge shadows, then chained tile batches."""
+    ref.set_num_threads(1)  # the two OpenMP sections race on smask / sh_out: one thread is the defined order
+    cfg = orclib.make_config(mesh_gen_mode=0)
+    sr = ref.init(cfg); orc.init(cfg)
+    rng = np.random.default_rng(5)
+    for shape in ((130, 130), (64, 96), (33, 17)):
+        g = ref.gen_grid(-40, 25, sr.DX_VAL, sr.DY_VAL, shape[1], shape[0], 1)
+        g = (g * np.float32(3.0)).astype(np.float32)  # steeper: more shadow
+        for lp in LIGHTS:
+            for with_in in (False, True):
+                six = (g.max() + rng.uniform(-0.3, 0.3, shape[1])).astype(np.float32) if with_in else None
+                siy = np.where(rng.uniform(size=shape[0]) < 0.5, np.float32(-1.0e6), g.mean() + rng.uniform(-0.2, 0.4, shape[0])).astype(np.float32) if with_in else None
+                a = ref.calc_mesh_shadows(lp, g, six, siy); b = orc.calc_mesh_shadows(lp, g, six, siy)
+                assert (a[0] == b[0]).all(), f"smask {shape} light {lp} in {with_in}: {(a[0] != b[0]).sum()} cells"
+                assert_bit_equal(a[1], b[1], "sh_out_x"); assert_bit_equal(a[2], b[2], "sh_out_y")
+    tiles = [(tx, ty) for ty in range(-1, 2) for tx in range(0, 3)] + [(7, 7)]
+    z = np.stack([ref.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tiles]) * np.float32(4.0)
+    for lp in LIGHTS:
+        a = ref.tiles_mesh_shadows(tiles, z, lp); b = orc.tiles_mesh_shadows(tiles, z, lp)
+        assert (a == b).all(), f"tile batch light {lp}: {(a != b).sum()} cells"
+    assert any(ref.tiles_mesh_shadows(tiles, z, lp).any() for lp in LIGHTS)
+
+
 def test_libm_sincosf_is_not_correctly_rounded_but_reproducible():
     """The droplet's random-direction branch calls libm cosf/sinf on a = rand_float()*TWO_PI (src/erosion.cpp:80-83).
     glibc's sinf/cosf are not correctly rounded, which is why 3dworld_amd/csrc/terra_sincosf.hpp restates their algorithm
