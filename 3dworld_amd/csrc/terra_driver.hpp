@@ -107,7 +107,8 @@ TERRA_HD bool shadow_line_clip(shadow_pt_t &v1, shadow_pt_t &v2, float const d[3
 // Sweep number p in the reference's single-threaded order: p < 2*ysize are run_x's sweeps (y = p), the rest run_y's (x = p - 2*ysize).
 // OUT::shadow(x, y) sets the MESH_SHADOW bit; OUT::out_x / out_y(index, order, value) record an outgoing edge height -- `order` grows with the
 // sequential execution order (sweep, then step), the writer with the highest order must win.
-template<class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t const &c, float const *mh, float const *sh_in_x, float const *sh_in_y, unsigned p, OUT &out) {
+// IN::x(ix) / IN::y(iy): incoming edge heights (MESH_MIN_Z = none)
+template<class IN, class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t const &c, float const *mh, IN const &in, unsigned p, OUT &out) {
 	shadow_pt_t v1;
 	if (p < 2u*(unsigned)c.ysize) {v1.x = c.xval((c.dirx > 0) ? 0 : c.xsize); v1.y = (float)((double)-c.Y_SCENE_SIZE + 0.5*(double)c.DY_VAL*(double)(int)p); v1.z = 0.0f;}
 	else {int const xx = (int)(p - 2u*(unsigned)c.ysize); v1.x = (float)((double)-c.X_SCENE_SIZE + 0.5*(double)c.DX_VAL*(double)xx); v1.y = c.yval((c.diry > 0) ? 0 : c.ysize); v1.z = 0.0f;}
@@ -132,8 +133,9 @@ template<class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t const &c, fl
 	for (int i = 0; i <= longest; i++) {
 		if (x >= 0 && y >= 0 && x < c.xsize && y < c.ysize) {
 			shadow_pt_t const pt = {-c.X_SCENE_SIZE + c.DX_VAL*(float)x, -c.Y_SCENE_SIZE + c.DY_VAL*(float)y, mh[y*c.xsize + x]};
-			if (sh_in_y != nullptr && x == xa && sh_in_y[y] > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = sh_in_y[y]; inited = true;} // MESH_MIN_Z (src/mesh.h:9)
-			else if (sh_in_x != nullptr && y == ya && sh_in_x[x] > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = sh_in_x[x]; inited = true;}
+			float siv;
+			if (x == xa && (siv = in.y(y)) > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = siv; inited = true;} // sh_in_y != NULL && x == xa && sh_in_y[y] > MESH_MIN_Z (src/mesh.h:9)
+			else if (y == ya && (siv = in.x(x)) > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = siv; inited = true;}
 			float const shadow_z = (float)((double)((dim ? pt.y : pt.x) - (dim ? cur.y : cur.x))*dir_ratio + (double)cur.z);
 			if (inited && shadow_z > pt.z) {
 				out.shadow(x, y);
@@ -883,30 +885,22 @@ template<class BE> struct terra_engine {
 			}
 			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {return level[a] < level[b];});
 		}
-		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*n*zv*8 + (size_t)2*n*zv*4 + 256*3;
+		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*n*zv*8 + ((size_t)n + 1)*4 + 256*4;
 		uint8_t *base = scratch<uint8_t>(s_shadow, bytes);
 		uint32_t *d_order = (uint32_t *)base;
 		int32_t *d_adj = (int32_t *)(base + (((size_t)n*4 + 255) & ~(size_t)255));
 		unsigned long long *d_out = (unsigned long long *)((uint8_t *)d_adj + ((adj.size()*4 + 255) & ~(size_t)255)); // [2][n][zv]: (order << 32) | float bits, 0 = never written
-		float *d_sh = (float *)(d_out + (size_t)2*n*zv); // [2][n][zv]: the finished sh_out arrays (MESH_MIN_Z where nothing was written), read as sh_in by the next level
 		be.h2d(d_order, order.data(), (size_t)n*4);
 		be.h2d(d_adj, adj.data(), adj.size()*4);
 		be.fill32(d_out, 0, (size_t)2*n*zv*2);
 		uint32_t const npaths = 4*zv;
+		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*n*zv);
+		if (level[order[n - 1]] >= 2 && be.tile_shadows_chain(c, n, d_order, d_adj, d_zvals, d_out, d_smask, d_flags, npaths)) return; // one launch for the whole chain
+		if (level[order[n - 1]] >= 2) {be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); be.fill32(d_out, 0, (size_t)2*n*zv*2);} // chained kernel not used / gave up: start over
 		for (uint32_t first = 0; first < n;) {
 			uint32_t last = first;
 			while (last < n && level[order[last]] == level[order[first]]) ++last;
-			uint32_t const cnt = last - first;
-			uint32_t const *ord = d_order + first;
-			be.tile_shadows(c, cnt, ord, d_adj, n, d_zvals, d_sh, d_out, d_smask, npaths);
-			be.launch((size_t)cnt*2*zv, [=] TERRA_LAMBDA (size_t i) { // publish the level's outgoing edge heights
-				uint32_t const k = (uint32_t)(i / (2*zv)), r = (uint32_t)(i % (2*zv)), which = r / zv, e = r % zv, t = ord[k];
-				unsigned long long const v = d_out[((size_t)which*n + t)*zv + e];
-				uint32_t const bits = (uint32_t)(v & 0xFFFFFFFFull);
-				float f = -1.0E6f; // MESH_MIN_Z: sh_out[l][d].resize(zvsize, MESH_MIN_Z) (src/tiled_mesh.cpp:677)
-				if (v != 0) {memcpy(&f, &bits, 4);}
-				d_sh[((size_t)which*n + t)*zv + e] = f;
-			});
+			be.tile_shadows(c, last - first, d_order + first, d_adj, n, d_zvals, d_out, d_smask, npaths);
 			first = last;
 		}
 	}

@@ -447,6 +447,55 @@ __global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals
 	}
 }
 
+// ------------------------------------------------------------------ row f2: mesh shadows of a whole tile batch in ONE launch
+// Block b works on tile order[b] (tiles sorted by dependency level, so every tile's two neighbours toward the light have smaller block
+// numbers and -- workgroups being dispatched in index order -- are already resident or finished when it starts).  The block stages its 130 x 130
+// heights in LDS, lane 0 waits for the neighbours' done flags (acquire), the 520 sweeps run at once (576 threads) reading the neighbours' outgoing edge
+// heights from L2, and the block publishes its own flag (release).  The chain of 2*64-1 levels costs one kernel instead of 127 launches.
+// A bounded spin (~seconds) sets *err instead of hanging the device should the dispatch-order assumption ever fail; the host then redoes the
+// batch level by level.
+struct shadow_chain_in_t {
+	unsigned long long const *ix, *iy;
+	__device__ static float decode(unsigned long long v) {if (v == 0) return -1.0E6f; uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); float f; memcpy(&f, &b, 4); return f;}
+	__device__ float x(int i) const {return ix ? decode(__hip_atomic_load(&ix[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1.0E6f;}
+	__device__ float y(int i) const {return iy ? decode(__hip_atomic_load(&iy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1.0E6f;}
+};
+struct shadow_chain_out_t {
+	uint8_t *sm; unsigned long long *ox, *oy; int xsize;
+	__device__ void shadow(int x, int y) {size_t const o = (size_t)y*xsize + x; atomicOr((unsigned int *)(sm + (o & ~(size_t)3)), 0x02u << (8u*(unsigned)(o & 3)));}
+	__device__ static unsigned long long pack(uint32_t order, float v) {uint32_t b; memcpy(&b, &v, 4); return ((unsigned long long)order << 32) | b;}
+	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], pack(order, v));}
+	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], pack(order, v));}
+};
+constexpr unsigned SH_CHAIN_THREADS = 576; // 9 waves: all 520 sweeps of a tile in one round
+__global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_chain(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj, float const *__restrict__ zvals,
+	unsigned long long *out, uint8_t *smask, uint32_t *done, uint32_t *err, uint32_t npaths)
+{
+	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
+	unsigned const zv = 130, tid = threadIdx.x;
+	uint32_t const t = order[blockIdx.x];
+	int32_t const ax = adj[2*t], ay = adj[2*t + 1];
+	float const *z = zvals + (size_t)t*zv*zv;
+	for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}
+	if (tid == 0) {
+		int32_t const deps[2] = {ax, ay};
+		for (int k = 0; k < 2; ++k) {
+			if (deps[k] < 0) continue;
+			uint32_t spins = 0;
+			while (__hip_atomic_load(&done[deps[k]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+				if (++spins > (1u << 24)) {atomicExch(err, 1u); break;}
+				__builtin_amdgcn_s_sleep(32);
+			}
+		}
+	}
+	__syncthreads();
+	shadow_chain_in_t const in{(ay >= 0) ? out + ((size_t)0*n + ay)*zv : nullptr, (ax >= 0) ? out + ((size_t)1*n + ax)*zv : nullptr};
+	shadow_chain_out_t o{smask + (size_t)t*zv*zv, out + ((size_t)0*n + t)*zv, out + ((size_t)1*n + t)*zv, (int)zv};
+	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+	__syncthreads();
+	if (tid == 0) {__hip_atomic_store(&done[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);}
+}
+
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell
 // grid-stride float4 loads, wave shuffle reduction, one pair of atomics per wave.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
 __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, size_t n, uint32_t *__restrict__ d) {

@@ -54,17 +54,23 @@ template<class DERIVED> struct simple_paths {
 		TERRA_HD void out_x(int ix, uint32_t order, float v) {TERRA_ATOMIC_MAX(&ox[ix], pack(order, v));}
 		TERRA_HD void out_y(int iy, uint32_t order, float v) {TERRA_ATOMIC_MAX(&oy[iy], pack(order, v));}
 	};
-	void tile_shadows_simple(shadow_consts_t const &c, uint32_t cnt, uint32_t const *d_order, int32_t const *d_adj, uint32_t n, float const *d_zvals, float const *d_sh,
+	// incoming edge heights = what the neighbours toward the light left in their ordered out-arrays (0 = never written = MESH_MIN_Z)
+	struct shadow_in_t {
+		unsigned long long const *ix, *iy; // the y-neighbour's out_x / the x-neighbour's out_y, or nullptr (src/tiled_mesh.cpp:676-687)
+		TERRA_HD static float decode(unsigned long long v) {if (v == 0) return -1.0E6f; uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); float f; memcpy(&f, &b, 4); return f;}
+		TERRA_HD float x(int i) const {return ix ? decode(ix[i]) : -1.0E6f;}
+		TERRA_HD float y(int i) const {return iy ? decode(iy[i]) : -1.0E6f;}
+	};
+	void tile_shadows_simple(shadow_consts_t const &c, uint32_t cnt, uint32_t const *d_order, int32_t const *d_adj, uint32_t n, float const *d_zvals,
 		unsigned long long *d_out, uint8_t *d_smask, uint32_t npaths)
 	{
 		unsigned const zv = 130;
 		self().launch((size_t)cnt*npaths, [=] TERRA_LAMBDA (size_t i) {
 			uint32_t const k = (uint32_t)(i / npaths), p = (uint32_t)(i % npaths), t = d_order[k];
 			int32_t const ax = d_adj[2*t], ay = d_adj[2*t + 1];
-			float const *sh_in_y = (ax >= 0) ? d_sh + ((size_t)1*n + ax)*zv : nullptr; // the x-neighbour's sh_out_y (src/tiled_mesh.cpp:676-687)
-			float const *sh_in_x = (ay >= 0) ? d_sh + ((size_t)0*n + ay)*zv : nullptr;
+			shadow_in_t const in{(ay >= 0) ? d_out + ((size_t)0*n + ay)*zv : nullptr, (ax >= 0) ? d_out + ((size_t)1*n + ax)*zv : nullptr};
 			shadow_out_t out{d_smask + (size_t)t*zv*zv, d_out + ((size_t)0*n + t)*zv, d_out + ((size_t)1*n + t)*zv, (int)zv};
-			shadow_trace_path(c, d_zvals + (size_t)t*zv*zv, sh_in_x, sh_in_y, p, out);
+			shadow_trace_path(c, d_zvals + (size_t)t*zv*zv, in, p, out);
 		});
 	}
 	// AO lighting, simple form: one logical thread per texel, context read from global memory

@@ -66,6 +66,16 @@ def test_tile_mesh_shadows(pkg, gpu, orc):
     pc.case_tile_mesh_shadows(pkg, gpu, orc)
 
 
+def test_tile_mesh_shadows_chained_kernel(pkg, orc, monkeypatch):
+    """the opt-in single-launch variant (blocks wait on their neighbours' done flags) gives the same masks"""
+    monkeypatch.setenv("TERRA_SHADOW_CHAIN", "1")
+    t = pkg.Terra(0)
+    try:
+        pc.case_tile_mesh_shadows(pkg, t, orc, lights=pc.SHADOW_LIGHTS[:4])
+    finally:
+        t.close()
+
+
 def test_tiles_from_heightmap_texture(pkg, gpu, orc):
     pc.case_tiles_from_heightmap(pkg, gpu, orc)
 

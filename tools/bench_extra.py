@@ -52,6 +52,13 @@ t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
 ao = t.alloc(n * 129 * 129)
 ms = timed(lambda: t.tiles_ao_lighting_dev(tiles, zt.ptr, ao.ptr), reps=2)
 out["F1_tile_ao_64x64_sine"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+# row f2: mesh shadows of the 64x64 batch for a low sun (127 dependency levels along the anti-diagonals)
+t.init_scene(pkg.make_config(mesh_gen_mode=0))
+t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
+sm = t.alloc(n * 130 * 130)
+ms = timed(lambda: t.tiles_mesh_shadows_dev(tiles, zt.ptr, (0.6, 0.5, 0.4), sm.ptr), reps=2)
+out["F2_tile_mesh_shadows_64x64"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+sm.free()
 # tiles served from a heightmap texture: proc_gen a 4096^2 map (noise + 1000-droplet erosion + 16-bit quantise) on the device, then sample the tile batch from it
 H = 4096
 hv = t.alloc(H * H * 4); hp = t.alloc(H * H * 2)
@@ -108,6 +115,9 @@ if "--no-cpu" not in sys.argv:
     zs_ = [ck.tile_create_zvals(tx, ty, 0)[0] for ty in range(-2, 2) for tx in range(-2, 2)]
     dt, _ = wall(lambda: [ck.tile_ao_lighting(tx, ty, zs_[(ty + 2) * 4 + (tx + 2)]) for ty in range(-2, 2) for tx in range(-2, 2)])
     cpu["F1_tile_ao_tiles_per_s_4thr"] = round(16 / dt, 1)
+    tl_ = [(tx, ty) for ty in range(-4, 4) for tx in range(-4, 4)]
+    dt, _ = wall(lambda: ck.tiles_mesh_shadows(tl_, np.stack([ck.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tl_]), (0.6, 0.5, 0.4)))
+    cpu["F2_tile_mesh_shadows_tiles_per_s_incl_zvals"] = round(len(tl_) / dt, 1)
     ck.set_num_threads(cores)
     dims = (256, 256, 64)
     dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, 0, 0.01, 1))
