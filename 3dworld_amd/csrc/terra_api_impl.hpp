@@ -267,6 +267,13 @@ int terra_tiles_mesh_shadows_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.tiles_mesh_shadows_dev(tile_xy, n, d_zvals, light_pos, d_smask); TERRA_CATCH
 }
+int terra_tiles_mesh_shadows_halo_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask,
+	const float *h_edge_in, const uint8_t *h_edge_in_present, float *h_edge_out)
+{
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if ((h_edge_in == nullptr) != (h_edge_in_present == nullptr)) return terra::fail(TERRA_ERR_ARG, "edge_in and edge_in_present go together");
+	TERRA_TRY ctx->eng.tiles_mesh_shadows_dev(tile_xy, n, d_zvals, light_pos, d_smask, h_edge_in, h_edge_in_present, h_edge_out); TERRA_CATCH
+}
 int terra_tiles_mesh_shadows(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals || !h_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	if (n == 0) return TERRA_OK;

@@ -846,10 +846,16 @@ template<class BE> struct terra_engine {
 	// tile_t::calc_shadows_for_light + calc_mesh_shadows (src/tiled_mesh.cpp:664-692, src/visibility.cpp:510-520) for a batch and one directional light:
 	// smask[n][130][130] gets the MESH_SHADOW bit.  A tile's sweeps start from the edge heights its two neighbours toward the light left behind
 	// (sh_out -> sh_in), so the batch is processed in dependency levels (anti-diagonals); tiles of one level run in parallel, every sweep of a tile too.
-	void tiles_mesh_shadows_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, float const lpos[3], uint8_t *d_smask) {
+	// edge_in / edge_in_present / edge_out (host, optional): the halo of a batch that is only part of the terrain (another GPU owns the rest).
+	// edge_in[i][0] = sh_in_x, edge_in[i][1] = sh_in_y of tile i, used where present[i][d] != 0 and the neighbour toward the light is not in the batch;
+	// edge_out[i][0..1] = the tile's sh_out_x / sh_out_y (MESH_MIN_Z where nothing was written), for the owner of the next tile away from the light.
+	void tiles_mesh_shadows_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, float const lpos[3], uint8_t *d_smask,
+		float const *edge_in = nullptr, uint8_t const *edge_in_present = nullptr, float *edge_out = nullptr)
+	{
 		require_scene();
 		if (n == 0) return;
 		uint32_t const zv = 130;
+		if (edge_out) {for (size_t i = 0; i < (size_t)n*2*zv; ++i) edge_out[i] = -1.0E6f;} // sh_out[l][d].resize(zvsize, MESH_MIN_Z)
 		float const lx = lpos[0], ly = lpos[1], lz = lpos[2];
 		bool const all_shadowed = (lz < zmin);
 		be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); // MESH_SHADOW (src/3DWorld.h:1403)
@@ -871,6 +877,22 @@ template<class BE> struct terra_engine {
 			if (ax != index.end()) adj[2*i] = (int32_t)ax->second;
 			if (ay != index.end()) adj[2*i+1] = (int32_t)ay->second;
 		}
+		// halo: a present incoming edge becomes a virtual neighbour slot n + k whose out-array holds the received heights
+		std::vector<unsigned long long> virt; // [nvirt][zv]
+		std::vector<std::pair<uint32_t, uint32_t>> virt_slot; // (which array: 0 = out_x, 1 = out_y ; slot)
+		if (edge_in && edge_in_present) {
+			for (uint32_t i = 0; i < n; ++i) {
+				for (uint32_t d = 0; d < 2; ++d) { // d = 0: sh_in_x (from the y-neighbour, adj[2i+1]); d = 1: sh_in_y (from the x-neighbour, adj[2i])
+					int32_t &a = adj[2*i + (1 - d)];
+					if (a >= 0 || !edge_in_present[2*i + d]) continue;
+					a = (int32_t)(n + (uint32_t)virt_slot.size());
+					virt_slot.push_back(std::make_pair(d, (uint32_t)a));
+					float const *src = edge_in + ((size_t)i*2 + d)*zv;
+					for (uint32_t e = 0; e < zv; ++e) {uint32_t b; memcpy(&b, &src[e], 4); virt.push_back((src[e] > -1.0E6f) ? ((1ull << 32) | b) : 0ull);}
+				}
+			}
+		}
+		uint32_t const nslots = n + (uint32_t)virt_slot.size();
 		{ // levels by relaxation over tiles sorted toward the light (a tile's dependencies lie strictly further toward the light in x or y)
 			for (uint32_t i = 0; i < n; ++i) order[i] = i;
 			std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -879,29 +901,45 @@ template<class BE> struct terra_engine {
 			});
 			for (uint32_t i : order) {
 				uint32_t lv = 0;
-				if (adj[2*i] >= 0) lv = std::max(lv, level[adj[2*i]] + 1);
-				if (adj[2*i+1] >= 0) lv = std::max(lv, level[adj[2*i+1]] + 1);
+				if (adj[2*i] >= 0 && (uint32_t)adj[2*i] < n) lv = std::max(lv, level[adj[2*i]] + 1);
+				if (adj[2*i+1] >= 0 && (uint32_t)adj[2*i+1] < n) lv = std::max(lv, level[adj[2*i+1]] + 1);
 				level[i] = lv;
 			}
 			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {return level[a] < level[b];});
 		}
-		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*n*zv*8 + ((size_t)n + 1)*4 + 256*4;
+		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*nslots*zv*8 + ((size_t)n + 1)*4 + 256*4;
 		uint8_t *base = scratch<uint8_t>(s_shadow, bytes);
 		uint32_t *d_order = (uint32_t *)base;
 		int32_t *d_adj = (int32_t *)(base + (((size_t)n*4 + 255) & ~(size_t)255));
 		unsigned long long *d_out = (unsigned long long *)((uint8_t *)d_adj + ((adj.size()*4 + 255) & ~(size_t)255)); // [2][n][zv]: (order << 32) | float bits, 0 = never written
 		be.h2d(d_order, order.data(), (size_t)n*4);
 		be.h2d(d_adj, adj.data(), adj.size()*4);
-		be.fill32(d_out, 0, (size_t)2*n*zv*2);
+		be.fill32(d_out, 0, (size_t)2*nslots*zv*2);
+		for (size_t k = 0; k < virt_slot.size(); ++k) {be.h2d(d_out + ((size_t)virt_slot[k].first*nslots + virt_slot[k].second)*zv, virt.data() + k*zv, (size_t)zv*8);}
 		uint32_t const npaths = 4*zv;
-		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*n*zv);
-		if (level[order[n - 1]] >= 2 && be.tile_shadows_chain(c, n, d_order, d_adj, d_zvals, d_out, d_smask, d_flags, npaths)) return; // one launch for the whole chain
-		if (level[order[n - 1]] >= 2) {be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); be.fill32(d_out, 0, (size_t)2*n*zv*2);} // chained kernel not used / gave up: start over
-		for (uint32_t first = 0; first < n;) {
+		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*nslots*zv);
+		bool chained = false;
+		if (level[order[n - 1]] >= 2 && virt_slot.empty()) {
+			chained = be.tile_shadows_chain(c, n, d_order, d_adj, d_zvals, d_out, d_smask, d_flags, npaths); // one launch for the whole chain (opt-in)
+			if (!chained) {be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); be.fill32(d_out, 0, (size_t)2*nslots*zv*2);} // not used / gave up: start over
+		}
+		for (uint32_t first = 0; first < n && !chained;) {
 			uint32_t last = first;
 			while (last < n && level[order[last]] == level[order[first]]) ++last;
-			be.tile_shadows(c, last - first, d_order + first, d_adj, n, d_zvals, d_out, d_smask, npaths);
+			be.tile_shadows(c, last - first, d_order + first, d_adj, nslots, d_zvals, d_out, d_smask, npaths);
 			first = last;
+		}
+		if (edge_out) { // the tiles' own outgoing edges, decoded
+			std::vector<unsigned long long> h((size_t)2*nslots*zv);
+			be.d2h(h.data(), d_out, h.size()*8);
+			for (uint32_t i = 0; i < n; ++i) {
+				for (uint32_t d = 0; d < 2; ++d) {
+					for (uint32_t e = 0; e < zv; ++e) {
+						unsigned long long const v = h[((size_t)d*nslots + i)*zv + e];
+						if (v != 0) {uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); memcpy(&edge_out[((size_t)i*2 + d)*zv + e], &b, 4);}
+					}
+				}
+			}
 		}
 	}
 

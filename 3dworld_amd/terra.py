@@ -111,6 +111,7 @@ _PROTOS = {
     "terra_set_tiled_mesh_ao": (_i32, [_vp, _i32]),
     "terra_tiles_mesh_shadows_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
+    "terra_tiles_mesh_shadows_halo_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
     "terra_hmap_set_dev": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "terra_set_mesh_height_scales_for_zval_range": (_i32, [_vp, _f, _f]),
     "terra_tiles_ao_lighting_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
@@ -279,6 +280,19 @@ class Terra:
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
         lp = (C.c_float * 3)(*light_pos)
         self._ck(self.lib.terra_tiles_mesh_shadows_dev(self.ctx, txy.ctypes.data, len(txy), z_ptr, lp, smask_ptr))
+
+    def tiles_mesh_shadows_halo_dev(self, tile_xy, z_ptr, light_pos, smask_ptr, edge_in=None, edge_in_present=None, want_edge_out=True):
+        """part of a terrain: edge_in (n,2,130) float32 + edge_in_present (n,2) uint8 on the host, returns edge_out (n,2,130) or None"""
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        lp = (C.c_float * 3)(*light_pos)
+        ei = np.ascontiguousarray(edge_in, np.float32).reshape(n, 2, 130) if edge_in is not None else None
+        ep = np.ascontiguousarray(edge_in_present, np.uint8).reshape(n, 2) if edge_in is not None else None
+        eo = np.empty((n, 2, 130), np.float32) if want_edge_out else None
+        self._ck(self.lib.terra_tiles_mesh_shadows_halo_dev(self.ctx, txy.ctypes.data, n, z_ptr, lp, smask_ptr,
+                                                             ei.ctypes.data if ei is not None else None, ep.ctypes.data if ep is not None else None,
+                                                             eo.ctypes.data if eo is not None else None))
+        return eo
 
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))

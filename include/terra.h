@@ -190,6 +190,12 @@ int  terra_tiles_ao_lighting(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n,
  * reference's single-threaded order (its two OpenMP sections race). */
 int  terra_tiles_mesh_shadows_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask);
 int  terra_tiles_mesh_shadows(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask);
+/* The same for a batch that is only PART of the terrain (the rest lives on another GPU / rank): h_edge_in[i][0] = sh_in_x, h_edge_in[i][1] = sh_in_y of
+ * tile i (130 floats each, host memory), used where h_edge_in_present[i][d] != 0 and the neighbour toward the light is not in the batch; h_edge_out[i][0..1]
+ * receives every tile's sh_out_x / sh_out_y (MESH_MIN_Z = -1e6 where nothing was written) -- what the owner of the next tile away from the light needs.
+ * All three are optional (NULL).  3dworld_amd/dist.py: tile strips over torch.distributed ranks, the border edges travel by send/recv. */
+int  terra_tiles_mesh_shadows_halo_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask,
+                                       const float *h_edge_in, const uint8_t *h_edge_in_present, float *h_edge_out);
 
 /* ---- voxels: voxel_manager::create_procedural fill (src/voxels.cpp:278-346).  out is z-fastest: ix = z + (x + y*nx)*nz (src/voxels.h:141-144). */
 int  terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],

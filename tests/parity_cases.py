@@ -271,6 +271,40 @@ def case_tile_mesh_shadows(pkg, t, orc, lights=SHADOW_LIGHTS):
     assert (alone[0] != t.tiles_mesh_shadows(tiles, z, lights[1])[4]).any()
 
 
+def case_tile_mesh_shadows_halo(pkg, t, orc):
+    """the halo interface: a tile block computed in two halves (the half away from the light receives the other half's outgoing edges) equals the block
+    computed at once -- the property the multi-GPU strips rely on."""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc_); orc.init(oc)
+    tiles = [(tx, ty) for ty in range(0, 3) for tx in range(0, 4)]
+    z, _, _, _ = t.tiles_create_zvals(tiles, 0, stats=False, normals=False)
+    z = (z * np.float32(4.0)).astype(np.float32)
+    for lp in ((0.7, 0.4, 0.3), (-0.8, 0.3, 0.25), (0.3, -0.6, 0.2)):
+        want = orc.tiles_mesh_shadows(tiles, z, lp)
+        sx = -1 if lp[0] < 0 else 1
+        first = [i for i, tl in enumerate(tiles) if (tl[0] >= 2) == (sx > 0)]   # the half toward the light in x
+        second = [i for i in range(len(tiles)) if i not in first]
+        def run(ids, edge_in=None, present=None):
+            sub = [tiles[i] for i in ids]
+            zb = t.alloc(len(ids) * 130 * 130 * 4).upload(np.ascontiguousarray(z[ids]))
+            sm = t.alloc(len(ids) * 130 * 130)
+            eo = t.tiles_mesh_shadows_halo_dev(sub, zb.ptr, lp, sm.ptr, edge_in, present, True)
+            out = sm.download(np.uint8, (len(ids), 130, 130))
+            zb.free(); sm.free()
+            return out, eo
+        m1, eo1 = run(first)
+        pos = {tiles[i]: k for k, i in enumerate(first)}
+        ein = np.full((len(second), 2, 130), -1.0e6, np.float32); pres = np.zeros((len(second), 2), np.uint8)
+        for k, i in enumerate(second):
+            nb = (tiles[i][0] + sx, tiles[i][1])
+            if nb in pos:
+                ein[k, 1] = eo1[pos[nb], 1]; pres[k, 1] = 1
+        m2, _ = run(second, ein, pres)
+        got = np.empty_like(want)
+        got[first] = m1; got[second] = m2
+        assert (got == want).all(), f"light {lp}: {(got != want).sum()} cells differ"
+
+
 def case_tiles_from_heightmap(pkg, t, orc):
     """tiles (zvals, stats, normals, AO) sampled from a 16-bit / 8-bit heightmap texture in device memory: nearest, bilinear, mirror wrap far outside
     the image, procedural detail below mesh_scale 0.75, no erosion -- terrain_hmap_manager_t + the using_hmap branches of the tile code."""

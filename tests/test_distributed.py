@@ -58,3 +58,51 @@ def test_two_ranks_tile_sharding_matches_oracle(emul_lib, orc, tmp_path):
     for i in (0, 7, 10, 19):
         zo, _ = orc.tile_create_zvals(*tiles[i], 40)
         orclib.assert_bit_equal(zo, z[i], f"tile {tiles[i]}")
+
+
+def _shadow_worker(rank, world, port, emul_lib, out_dir, light):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("3dworld_amd")
+    dmod = importlib.import_module("3dworld_amd.dist")
+    t = pkg.Terra(0, emul_lib)
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    tiles = [(tx, ty) for ty in range(-1, 2) for tx in range(-3, 3)]  # 6 columns x 3 rows: strips of 3 columns
+    keep = {}
+    def make_zvals(mine):
+        z, _, _, _ = t.tiles_create_zvals(mine, 0, stats=False, normals=False)
+        z = (z * np.float32(4.0)).astype(np.float32)
+        keep["z"] = t.alloc(z.nbytes).upload(z)
+        return keep["z"].ptr
+    def alloc_smask(n):
+        keep["sm"] = t.alloc(max(n, 1) * 130 * 130)
+        return keep["sm"].ptr
+    mine, sm_ptr = dmod.sharded_tile_mesh_shadows(t, dist, tiles, light, make_zvals, alloc_smask)
+    np.save(os.path.join(out_dir, f"sm_{rank}.npy"), keep["sm"].download(np.uint8, (len(mine), 130, 130)))
+    np.save(os.path.join(out_dir, f"tiles_{rank}.npy"), np.array(mine, np.int32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("light", [(0.7, 0.4, 0.3), (-0.8, 0.3, 0.25)])
+def test_two_ranks_mesh_shadows_with_edge_exchange(emul_lib, orc, tmp_path, light):
+    """the one real exchange step of the tile path: strips of tile columns on two ranks, the border sh_out_y arrays travel by send/recv (gloo here, RCCL on
+    the MI355X node); the union equals the single-process result for lights from both x directions (pipeline runs either way)."""
+    import torch.multiprocessing as mp
+    import orclib
+    port = 31500 + (os.getpid() + int(light[0] * 10)) % 2000
+    mp.spawn(_shadow_worker, args=(2, port, emul_lib, str(tmp_path), light), nprocs=2, join=True)
+    tiles = [(tx, ty) for ty in range(-1, 2) for tx in range(-3, 3)]
+    orc.init(orclib.make_config(mesh_gen_mode=0))
+    z = np.stack([orc.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tiles]) * np.float32(4.0)
+    want = orc.tiles_mesh_shadows(tiles, z, light)
+    seen = 0
+    for r in range(2):
+        sm = np.load(tmp_path / f"sm_{r}.npy"); mine = [tuple(v) for v in np.load(tmp_path / f"tiles_{r}.npy")]
+        assert len(mine) == 9
+        for k, tl in enumerate(mine):
+            assert (sm[k] == want[tiles.index(tl)]).all(), f"rank {r} tile {tl}"
+            seen += 1
+    assert seen == len(tiles) and want.any()

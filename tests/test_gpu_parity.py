@@ -76,6 +76,10 @@ def test_tile_mesh_shadows_chained_kernel(pkg, orc, monkeypatch):
         t.close()
 
 
+def test_tile_mesh_shadows_halo_interface(pkg, gpu, orc):
+    pc.case_tile_mesh_shadows_halo(pkg, gpu, orc)
+
+
 def test_tiles_from_heightmap_texture(pkg, gpu, orc):
     pc.case_tiles_from_heightmap(pkg, gpu, orc)
 

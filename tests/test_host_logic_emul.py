@@ -86,6 +86,10 @@ def test_tile_mesh_shadows(pkg, emul, orc):
     pc.case_tile_mesh_shadows(pkg, emul, orc)
 
 
+def test_tile_mesh_shadows_halo_interface(pkg, emul, orc):
+    pc.case_tile_mesh_shadows_halo(pkg, emul, orc)
+
+
 def test_tiles_from_heightmap_texture(pkg, emul, orc):
     pc.case_tiles_from_heightmap(pkg, emul, orc)
 
