@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libterra_hip.so")
 SOURCES = ["terra_hip.hip"]
-HEADERS = ["terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
+HEADERS = ["terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_png.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
 # -ffp-contract=off: the reference CPU path has no FMA; parity is bit-exact only without contraction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-result"]
@@ -32,7 +32,7 @@ def build_library(force=False, verbose=False):
     """Compile 3dworld_amd/csrc/*.hip -> 3dworld_amd/libterra_hip.so (in tree, so it travels with the repo snapshot)."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc_path()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-lz"]  # zlib: the PNG heightmap files (terra_png.hpp)
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -4,6 +4,7 @@
 //   tests/emul/terra_emul.cpp       -> tests/emul/libterra_emul.so (test-only host emulation of the kernel bodies)
 #pragma once
 #include "terra_driver.hpp"
+#include "terra_png.hpp"
 #include <new>
 
 namespace terra {
@@ -228,6 +229,22 @@ int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height
 			float const dz = terra::max_std(1.0E-12f, (mx - mn)); // max(TOLERANCE, ...), src/heightmap.cpp:148
 			if (h_range) {h_range[0] = mn; h_range[1] = dz;}
 			if (d_pix) {e.quantize16_dev(d_vals, n, mn, dz, d_pix);}
+		}
+	TERRA_CATCH
+}
+
+// ---- heightmap files (host): 8- / 16-bit grayscale PNG with the reference's row order and byte order (terra_png.hpp)
+int terra_heightmap_write_png(const char *path, const uint8_t *h_pixels, uint32_t width, uint32_t height, int ncolors) {
+	if (!path || !h_pixels) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY terra::png_write_gray(path, h_pixels, width, height, ncolors); TERRA_CATCH
+}
+int terra_heightmap_read_png(const char *path, int allow_two_byte_grayscale, uint32_t *width, uint32_t *height, int *ncolors, uint8_t *h_pixels, size_t capacity) {
+	if (!path || !width || !height || !ncolors) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY
+		std::vector<uint8_t> const px = terra::png_read_gray(path, *width, *height, *ncolors, allow_two_byte_grayscale != 0);
+		if (h_pixels) {
+			if (capacity < px.size()) return terra::fail(TERRA_ERR_ARG, "terra_heightmap_read_png: buffer too small");
+			memcpy(h_pixels, px.data(), px.size());
 		}
 	TERRA_CATCH
 }

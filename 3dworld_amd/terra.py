@@ -109,6 +109,8 @@ _PROTOS = {
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
     "terra_set_tiled_mesh_ao": (_i32, [_vp, _i32]),
+    "terra_heightmap_write_png": (_i32, [C.c_char_p, _vp, _u32, _u32, _i32]),
+    "terra_heightmap_read_png": (_i32, [C.c_char_p, _i32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_i32), _vp, C.c_size_t]),
     "terra_tiles_mesh_shadows_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_tiles_mesh_shadows_halo_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
@@ -293,6 +295,18 @@ class Terra:
                                                              ei.ctypes.data if ei is not None else None, ep.ctypes.data if ep is not None else None,
                                                              eo.ctypes.data if eo is not None else None))
         return eo
+
+    def heightmap_write_png(self, path, pixels):
+        """pixels: (h, w) uint8 or (h, w, 2) uint8 {lo, hi}"""
+        px = np.ascontiguousarray(pixels, np.uint8)
+        self._ck(self.lib.terra_heightmap_write_png(str(path).encode(), px.ctypes.data, px.shape[1], px.shape[0], 2 if px.ndim == 3 else 1))
+
+    def heightmap_read_png(self, path, allow_two_byte_grayscale=True):
+        w, h, nc = _u32(), _u32(), _i32()
+        self._ck(self.lib.terra_heightmap_read_png(str(path).encode(), int(allow_two_byte_grayscale), C.byref(w), C.byref(h), C.byref(nc), None, 0))
+        out = np.empty((h.value, w.value, 2) if nc.value == 2 else (h.value, w.value), np.uint8)
+        self._ck(self.lib.terra_heightmap_read_png(str(path).encode(), int(allow_two_byte_grayscale), C.byref(w), C.byref(h), C.byref(nc), out.ctypes.data, out.nbytes))
+        return out
 
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))

@@ -164,6 +164,13 @@ int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32
 int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
                               float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
 
+/* ---- heightmap files, host side: 8- / 16-bit grayscale PNG exactly as the reference reads / writes them through libpng (src/image_io.cpp:493-605):
+ * write: rows in memory order, 16-bit pixels {fraction, integer} -> big-endian samples (heightmap_t::write_png, src/heightmap.cpp:375-378);
+ * read: file row i -> memory row height-1-i (texture_t::load_png flips), allow_two_byte_grayscale keeps 16 bits as 2 bytes per pixel, otherwise the
+ * high byte only.  h_pixels may be NULL to query the size (width*height*ncolors bytes).  Non-grayscale / interlaced files are refused. */
+int  terra_heightmap_write_png(const char *path, const uint8_t *h_pixels, uint32_t width, uint32_t height, int ncolors);
+int  terra_heightmap_read_png(const char *path, int allow_two_byte_grayscale, uint32_t *width, uint32_t *height, int *ncolors, uint8_t *h_pixels, size_t capacity);
+
 /* ---- tiles from a heightmap texture instead of the procedural generator: terrain_hmap_manager_t (src/heightmap.h:110-142).
  * d_pixels: width*height pixels in DEVICE memory, 1 byte each or 2 = {fraction, integer} as written by terra_quantize16_dev / write_pixel_16_bits;
  * the library keeps the pointer (no copy), NULL switches back to procedural tiles.  While set, terra_tiles_create_zvals samples

@@ -64,7 +64,7 @@ def emul_lib():
     csrc = os.path.join(ROOT, "3dworld_amd", "csrc")
     deps = [src, os.path.join(ROOT, "include", "terra.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src, "-lz"], check=True)
     return out
 
 
