@@ -89,6 +89,20 @@ inline void tiles_create_zvals(int const *tile_xy, unsigned n, unsigned erosion_
 	check(terra_tiles_create_zvals(default_ctx(), tile_xy, n, erosion_iters_tt, zvals, stats, normals, min_normal_z), "tiles_create_zvals");
 }
 
+// ---- tile_t::calc_shadows_for_light (src/tiled_mesh.cpp:664-692) for a batch and one light: smask [n][130][130] gets the MESH_SHADOW bits
+inline void tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float const lpos[3], unsigned char *smask) {
+	check(terra_tiles_mesh_shadows(default_ctx(), tile_xy, n, zvals, lpos, smask), "calc_mesh_shadows");
+}
+// ---- terrain_hmap_manager: serve tiles from a heightmap texture that is already on the device (src/heightmap.cpp:385-407, src/mesh_gen.cpp:125-131)
+inline void use_heightmap_texture(unsigned char const *d_pixels, int width, int height, int ncolors, float min_z, float dz) {
+	check(terra_hmap_set_dev(default_ctx(), d_pixels, width, height, ncolors), "terrain_hmap_manager");
+	if (d_pixels) {check(terra_set_mesh_height_scales_for_zval_range(default_ctx(), min_z, dz), "set_mesh_height_scales_for_zval_range");}
+}
+// ---- heightmap_t::write_png / texture_t::load_png for grayscale heightmaps (src/image_io.cpp:493-605)
+inline void write_heightmap_png(char const *fn, unsigned char const *pixels, unsigned width, unsigned height, int ncolors) {
+	check(terra_heightmap_write_png(fn, pixels, width, height, ncolors), "write_png");
+}
+
 // ---- tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661) for a batch: zvals [n][130][130] -> ao_lighting [n][129][129]
 inline void tiles_ao_lighting(int const *tile_xy, unsigned n, float const *zvals, unsigned char *ao) {
 	check(terra_tiles_ao_lighting(default_ctx(), tile_xy, n, zvals, ao), "calc_mesh_ao_lighting");
