@@ -732,6 +732,8 @@ template<class BE> struct terra_engine {
 			refs[i].yi = (uint32_t)(std::lower_bound(uy.begin(), uy.end(), refs[i].ty) - uy.begin());
 		}
 		uint32_t const nux = (uint32_t)ux.size(), nuy = (uint32_t)uy.size();
+		bool unique_tiles = true; // a batch may name a tile twice: the scatter of the virtual grid could serve only one of the copies
+		{std::vector<std::pair<int32_t, int32_t>> tt; for (uint32_t i = 0; i < n; ++i) {tt.push_back(std::make_pair(tile_xy[2*i], tile_xy[2*i+1]));} std::sort(tt.begin(), tt.end()); unique_tiles = (std::adjacent_find(tt.begin(), tt.end()) == tt.end());}
 		// tables of all distinct tile columns / rows side by side, k-major like the big-grid tables: xt[k][u*tw + c], yt[k][u*tw + c].
 		// The batch is then ONE "virtual" (nux*tw) x (nuy*tw) sine grid whose cells are exactly the requested tiles' cells.
 		uint32_t const nxpv = round_up(nux*zv, 128), nypv = round_up(nuy*zv, 128);
@@ -780,7 +782,7 @@ template<class BE> struct terra_engine {
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw, unique_tiles);
 		return d_refs;
 	}
 

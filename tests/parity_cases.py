@@ -211,6 +211,18 @@ def case_tile_golden(pkg, t):
     assert np.float32(t.max_sea_level()).view(np.uint32) == G["max_sea_level"].view(np.uint32)
 
 
+def case_tile_batch_shapes(pkg, t, orc):
+    """odd batches: a tile named twice, a single tile, a sparse scatter, a dense block -- every copy gets its own complete output"""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc_); orc.init(oc)
+    for tiles in ([(0, 0), (1, 0), (0, 0), (1, 1), (1, 0)], [(5, -3)], [(-9, 4), (12, -7), (3, 3)], [(tx, ty) for ty in range(2) for tx in range(3)] + [(1, 1)]):
+        z, st, nm, mnz = t.tiles_create_zvals(tiles, 0)
+        for i, (tx, ty) in enumerate(tiles):
+            zo, so = orc.tile_create_zvals(tx, ty, 0)
+            assert_bit_equal(z[i], zo, f"batch {tiles} entry {i}")
+            assert bytes(st[i]) == bytes(so)
+
+
 def case_tile_ao(pkg, t, orc):
     """row f1: tile AO lighting against the reference's vectors (golden) and the oracle, for a batch of tiles (eroded and not), every noise
     mode, and the AO-context variant of create_zvals that enable_tiled_mesh_ao switches on for the GL noise modes."""

@@ -58,6 +58,10 @@ def test_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_
         assert r.serial_fallbacks >= 1
 
 
+def test_tile_batch_shapes(pkg, gpu, orc):
+    pc.case_tile_batch_shapes(pkg, gpu, orc)
+
+
 def test_tile_ao_lighting(pkg, gpu, orc):
     pc.case_tile_ao(pkg, gpu, orc)
 
