@@ -211,6 +211,17 @@ def case_tile_golden(pkg, t):
     assert np.float32(t.max_sea_level()).view(np.uint32) == G["max_sea_level"].view(np.uint32)
 
 
+def case_grid_degenerate_shapes(pkg, t, orc):
+    """1 x 1, single rows / columns, sizes around the 128-cell tile and the 4-cell vector width, for the sine kernel (both variants) and an fBm mode"""
+    for mode, kw in ((0, {}), (0, dict(hmap=[0.1, 0.5, 2.0, 0.2, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 0, 0])), (1, {})):
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode, **kw)
+        st = t.init_scene(pc_); orc.init(oc)
+        for nx, ny in ((1, 1), (1, 300), (300, 1), (3, 2), (127, 129), (128, 128), (129, 127), (4, 513), (260, 5)):
+            a = orc.gen_grid(-7, 11, st.DX_VAL, st.DY_VAL, nx, ny, 1)
+            b = t.gen_grid(-7, 11, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)
+            assert_bit_equal(a, b, f"mode {mode} {kw} grid {nx}x{ny}")
+
+
 def case_tile_batch_shapes(pkg, t, orc):
     """odd batches: a tile named twice, a single tile, a sparse scatter, a dense block -- every copy gets its own complete output"""
     pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)

@@ -58,6 +58,10 @@ def test_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_
         assert r.serial_fallbacks >= 1
 
 
+def test_grid_degenerate_shapes(pkg, gpu, orc):
+    pc.case_grid_degenerate_shapes(pkg, gpu, orc)
+
+
 def test_tile_batch_shapes(pkg, gpu, orc):
     pc.case_tile_batch_shapes(pkg, gpu, orc)
 

@@ -78,6 +78,10 @@ def test_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk
         assert r.serial_fallbacks >= 1
 
 
+def test_grid_degenerate_shapes(pkg, emul, orc):
+    pc.case_grid_degenerate_shapes(pkg, emul, orc)
+
+
 def test_tile_batch_shapes(pkg, emul, orc):
     pc.case_tile_batch_shapes(pkg, emul, orc)
 
