@@ -201,6 +201,8 @@ def main():
         if terms:
             ops = 2.0 * terms * cells / (ms_k * 1e-3) / 1e12
             roof["valu_tops"] = round(ops, 2); roof["valu_peak_tops"] = VALU_PEAK_TOPS; roof["valu_frac"] = round(ops / VALU_PEAK_TOPS, 4)
+            # the HBM fraction this kernel could reach at 100 % of the (nominal) non-FMA VALU peak: 4 B per 2*terms ops
+            roof["hbm_frac_ceiling_when_valu_bound"] = round(4.0 / (2.0 * terms) * VALU_PEAK_TOPS * 1e12 / (HBM_PEAK_GBS * 1e9), 4)
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident",
