@@ -234,12 +234,12 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize); return;}
 		use();
-		size_t const np = (size_t)nx*ny*terra::VOX_SINES;
+		size_t const ncol2 = ((size_t)nx*ny + 1) & ~(size_t)1, np = (ncol2/2)*terra::VX_PSTRIDE + (size_t)nz*terra::VOX_SINES, nprod = (ncol2 + nz)*terra::VOX_SINES; // column pairs + transposed z table
 		if (np*4 > vox_p_bytes) {if (vox_p) {sync(); (void)hipFree(vox_p);} TERRA_HIP_CHECK(hipMalloc((void **)&vox_p, np*4)); vox_p_bytes = np*4;}
-		hipLaunchKernelGGL(terra::k_voxel_P, dim3((unsigned)((np + 255)/256)), dim3(256), 0, stream, vox_p, nx, ny, d_tab);
+		hipLaunchKernelGGL(terra::k_voxel_P, dim3((unsigned)((nprod + 255)/256)), dim3(256), 0, stream, vox_p, vox_p + (ncol2/2)*terra::VX_PSTRIDE, nx, ny, nz, d_tab);
 		unsigned const block = (nz >= 256) ? 256 : ((nz + 63)/64)*64;
 		size_t const ncol = (size_t)nx*ny;
-		hipLaunchKernelGGL(terra::k_voxel_sines, dim3((unsigned)((ncol + terra::VX_PER_BLOCK - 1)/terra::VX_PER_BLOCK), (nz + block - 1)/block), dim3(block), 0, stream, out, nx, ny, nz, d_tab, vox_p, zscale, normalize);
+		hipLaunchKernelGGL(terra::k_voxel_sines, dim3((unsigned)((ncol + terra::VX_PER_BLOCK - 1)/terra::VX_PER_BLOCK), (nz + block - 1)/block), dim3(block), 0, stream, out, nx, ny, nz, vox_p + (ncol2/2)*terra::VX_PSTRIDE, vox_p, zscale, normalize);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 };

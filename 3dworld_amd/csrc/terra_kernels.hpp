@@ -518,34 +518,61 @@ __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, 
 
 // ------------------------------------------------------------------ K8: voxel sine field (noise_gen_3d::get_val, src/upsurface.cpp:60-70)
 // val[y][x][z] = sum_k (xv[x][k]*yv[y][k])*zv[z][k], z fastest.  fp32-VALU bound (60 mul + 60 add per voxel for 4 B written).
-// One lane = one z: its 60 zv values stay in registers; the block walks VX_PER_BLOCK (x,y) columns, whose 60 products
-// P[k] = xv*yv are wave-uniform (scalar loads feeding v_mul directly).  Output rows are contiguous along z: coalesced stores.
+// One lane = one z: its 60 zv values stay in registers (30 register pairs); the block walks VX_PER_BLOCK (x,y) columns TWO AT A TIME: the products
+// P[k] = xv*yv of a column pair are stored interleaved, so one scalar load delivers {P_a[k], P_b[k]} as an SGPR pair and one v_pk_mul_f32 / v_pk_add_f32
+// (zv broadcast from either half of its pair by op_sel) advances both columns -- same multiplies and adds, half the instructions.
+// (Measured with tools/pk_rate.hip: gfx950 issues a plain fp32 VALU op in ~1.0 ns per SIMD and a packed one in ~1.8 ns, so packing buys ~10%, not 2x.)
+// Output rows are contiguous along z: coalesced stores.
 constexpr int VX_PER_BLOCK = 32;
-__global__ __launch_bounds__(256) void k_voxel_P(float *__restrict__ P, uint32_t nx, uint32_t ny, float const *__restrict__ tab) { // P[(y*nx + x)*60 + k]
-	size_t const i = (size_t)blockIdx.x*256 + threadIdx.x;
-	if (i >= (size_t)nx*ny*VOX_SINES) return;
-	uint32_t const k = (uint32_t)(i % VOX_SINES); size_t const c = i / VOX_SINES; uint32_t const x = (uint32_t)(c % nx), y = (uint32_t)(c / nx);
-	P[i] = __fmul_rn(tab[(size_t)x*VOX_SINES + k], tab[((size_t)nx + y)*VOX_SINES + k]);
+constexpr int VX_PSTRIDE = 128; // floats per column pair in P: 60 interleaved pairs, padded to whole 16-float scalar loads
+typedef float vx_v16f __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_voxel_P(float *__restrict__ P, float *__restrict__ ZT, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ tab) {
+	// P[(col/2)*128 + k*2 + (col & 1)], columns padded to an even count with zeros; ZT[k][z] = the z table transposed, so that lane z of the main kernel reads it coalesced
+	size_t i = (size_t)blockIdx.x*256 + threadIdx.x; size_t const ncol = (size_t)nx*ny, ncol2 = (ncol + 1) & ~(size_t)1;
+	if (i < ncol2*VOX_SINES) {
+		uint32_t const k = (uint32_t)(i % VOX_SINES); size_t const c = i / VOX_SINES;
+		float v = 0.0f;
+		if (c < ncol) {uint32_t const x = (uint32_t)(c % nx), y = (uint32_t)(c / nx); v = __fmul_rn(tab[(size_t)x*VOX_SINES + k], tab[((size_t)nx + y)*VOX_SINES + k]);}
+		P[(c >> 1)*VX_PSTRIDE + k*2 + (c & 1)] = v;
+		return;
+	}
+	i -= ncol2*VOX_SINES;
+	if (i >= (size_t)nz*VOX_SINES) return;
+	uint32_t const z = (uint32_t)(i % nz), k = (uint32_t)(i / nz);
+	ZT[i] = tab[((size_t)nx + ny + z)*VOX_SINES + k];
 }
-__global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ tab, float const *__restrict__ P, float zscale, int normalize) {
+template<int E> __device__ __forceinline__ void vx_mul_add(sg_v2f &val, sg_v2f p2, sg_v2f zpair) { // val += {P_a*z, P_b*z}: product rounded, then added
+	sg_v2f t;
+	if (E == 0) {asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(val), "=&v"(t) : "s"(p2), "v"(zpair));}
+	else        {asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(val), "=&v"(t) : "s"(p2), "v"(zpair));}
+}
+__global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ ZT, float const *__restrict__ P, float zscale, int normalize) {
 	uint32_t const z = blockIdx.y*blockDim.x + threadIdx.x;
 	bool const active = z < nz;
-	float zv[VOX_SINES];
-	float const *zrow = tab + ((size_t)nx + ny + (active ? z : 0))*VOX_SINES;
+	sg_v2f zv[VOX_SINES/2];
+	float const *zcol = ZT + (active ? z : 0);
 #pragma unroll
-	for (unsigned k = 0; k < VOX_SINES; ++k) {zv[k] = zrow[k];}
+	for (unsigned k = 0; k < VOX_SINES/2; ++k) {zv[k] = sg_v2f{zcol[(size_t)(2*k)*nz], zcol[(size_t)(2*k + 1)*nz]};}
 	float const zterm = __fmul_rn((float)z, zscale);
 	size_t const c0 = (size_t)blockIdx.x*VX_PER_BLOCK, ncol = (size_t)nx*ny;
-	for (int c = 0; c < VX_PER_BLOCK; ++c) {
-		size_t const col = c0 + c; // = x + y*nx, wave-uniform
+	for (int c = 0; c < VX_PER_BLOCK; c += 2) {
+		size_t const col = c0 + c; // = x + y*nx of the pair's first column (even), wave-uniform
 		if (col >= ncol) break;
-		float const *p = P + col*VOX_SINES;
-		float val = 0.0f;
+		vx_v16f const *p = (vx_v16f const *)(P + (col >> 1)*VX_PSTRIDE);
+		sg_v2f val = {0.0f, 0.0f};
 #pragma unroll
-		for (unsigned k = 0; k < VOX_SINES; ++k) {val = __fadd_rn(val, __fmul_rn(p[k], zv[k]));} // (xv*yv)*zv, summed in k order
-		val = __fadd_rn(val, zterm);
-		if (normalize) {val = clip_pm1(val);}
-		if (active) {out[col*nz + z] = val;}
+		for (unsigned q = 0; q < 8; ++q) { // (xv*yv)*zv, summed in k order; 8 pairs per 64-byte scalar load
+			vx_v16f const pc = p[q];
+#define VX_STEP(J, LO, HI) if (q*8 + J < VOX_SINES) {vx_mul_add<(J & 1)>(val, sg_v2f{pc.LO, pc.HI}, zv[(q*8 + J) >> 1]);}
+			VX_STEP(0, s0, s1) VX_STEP(1, s2, s3) VX_STEP(2, s4, s5) VX_STEP(3, s6, s7) VX_STEP(4, s8, s9) VX_STEP(5, sa, sb) VX_STEP(6, sc, sd) VX_STEP(7, se, sf)
+#undef VX_STEP
+		}
+		float va = __fadd_rn(val.x, zterm), vb = __fadd_rn(val.y, zterm);
+		if (normalize) {va = clip_pm1(va); vb = clip_pm1(vb);}
+		if (active) {
+			out[col*nz + z] = va;
+			if (col + 1 < ncol) {out[(col + 1)*nz + z] = vb;}
+		}
 	}
 }
 
