@@ -261,6 +261,40 @@ int terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, flo
 	TERRA_TRY ctx->eng.set_mesh_height_scales_for_zval_range(min_z, dz); TERRA_CATCH
 }
 int terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable) {TERRA_CHECK_CTX ctx->eng.tiled_mesh_ao = (enable != 0); return TERRA_OK;}
+int terra_set_landscape(terra_ctx *ctx, const terra_landscape *params) {
+	TERRA_CHECK_CTX if (!params) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.set_landscape(*params); TERRA_CATCH
+}
+int terra_get_landscape(terra_ctx *ctx, terra_landscape *out) {
+	TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null argument");
+	*out = ctx->eng.ls; return TERRA_OK;
+}
+int terra_tiles_terrain_params(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, float *h_params) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !h_params)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.tiles_terrain_params(tile_xy, n, h_params); TERRA_CATCH
+}
+int terra_tiles_create_weights_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_weights, terra_grass_block *d_grass_blocks, uint8_t *d_has_any_grass) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_weights)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	static_assert(sizeof(terra_grass_block) == sizeof(terra::grass_block_pod_t), "grass block layout");
+	TERRA_TRY ctx->eng.tiles_create_weights_dev(tile_xy, n, d_zvals, d_weights, (terra::grass_block_pod_t *)d_grass_blocks, d_has_any_grass); TERRA_CATCH
+}
+int terra_tiles_create_weights(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, uint8_t *h_weights, terra_grass_block *h_grass_blocks, uint8_t *h_has_any_grass) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals || !h_weights)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (n == 0) return TERRA_OK;
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		size_t const zb = (size_t)n*130*130*4, wb = (size_t)n*129*129*4, gb = (size_t)n*32*32*sizeof(terra_grass_block), hb = ((size_t)n + 3) & ~(size_t)3;
+		uint8_t *d = (uint8_t *)be.alloc(zb + wb + gb + hb);
+		try {
+			be.h2d(d, h_zvals, zb);
+			ctx->eng.tiles_create_weights_dev(tile_xy, n, (float const *)d, d + zb, h_grass_blocks ? (terra::grass_block_pod_t *)(d + zb + wb) : nullptr, h_has_any_grass ? d + zb + wb + gb : nullptr);
+			be.d2h(h_weights, d + zb, wb);
+			if (h_grass_blocks) {be.d2h(h_grass_blocks, d + zb + wb, gb);}
+			if (h_has_any_grass) {be.d2h(h_has_any_grass, d + zb + wb + gb, n);}
+		} catch (...) {be.free(d); throw;}
+		be.free(d);
+	TERRA_CATCH
+}
 int terra_tiles_ao_lighting_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_ao) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_ao)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.tiles_ao_lighting_dev(tile_xy, n, d_zvals, d_ao); TERRA_CATCH

@@ -10,6 +10,7 @@
 #include "terra_common.hpp"
 #include "terra_noise.hpp"
 #include "terra_erosion.hpp"
+#include "terra_landscape.hpp"
 #include "../../include/terra.h"
 #include <vector>
 #include <map>
@@ -331,18 +332,34 @@ template<class BE> struct terra_engine {
 	}
 	float get_max_sea_level() const {return get_water_z_height() + ocean_wave_height;} // src/tiled_mesh.cpp:141
 	void set_zvals() {zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height();} // src/mesh_gen.cpp:494-504
-	void gen_tex_height_tables() { // init_terrain_mesh (src/mesh_gen.cpp:407-431) + gen_tex_height_tables (src/Textures.cpp:1757-1761), dirt/sand entries only
-		static float const mesh_rh_dirt[2] = {0.40f, 0.44f};
+	// init_terrain_mesh (src/mesh_gen.cpp:407-431) + gen_tex_height_tables (src/Textures.cpp:1757-1761): the landscape texture heights {sand, dirt, grass, rock, snow}
+	void tex_heights(float h_dirt[5]) const {
+		static float const mesh_rh_dirt[5] = {0.40f, 0.44f, 0.60f, 0.75f, 1.0f}; // src/mesh_gen.cpp:43
 		float const rel_wpz = get_rel_wpz(), W_PLANE_Z = 0.42f;
-		float h_dirt[2];
-		for (int i = 0; i < 2; ++i) {
+		for (int i = 0; i < 5; ++i) {
 			float const def_h = mesh_rh_dirt[i];
 			float h;
 			if (def_h < W_PLANE_Z) {h = def_h*rel_wpz/W_PLANE_Z;}
-			else {float const rel_h = (def_h - W_PLANE_Z)/(1.0f - W_PLANE_Z); h = (float)((double)rel_wpz + (double)rel_h*(1.0 - (double)rel_wpz));}
+			else {
+				float const rel_h = (def_h - W_PLANE_Z)/(1.0f - W_PLANE_Z); h = (float)((double)rel_wpz + (double)rel_h*(1.0 - (double)rel_wpz));
+				if (i == LT_SNOW) { // snow can't get lower when water lowers; less snow with increasing temperature
+					h = min_std(h, def_h);
+					if ((double)ls.temperature > 40.0) {h = (float)((double)h + 0.01*((double)ls.temperature - 40.0));}
+				}
+			}
 			h_dirt[i] = powf(h, glaciate_exp);
 		}
+	}
+	void gen_tex_height_tables() {
+		float h_dirt[5];
+		tex_heights(h_dirt);
 		clip_hd1 = (float)(0.90*(double)h_dirt[1] + 0.10*(double)h_dirt[0]);
+	}
+	terra_landscape ls = {1.0f, 20.0f, 0.0f, 1.0f, 0, 0, 1, 0u, 16u}; // the reference's defaults (src/3DWorld.cpp:109, src/3DWorld.h:87, src/grass.cpp:14, src/tiled_mesh.h:21)
+	void set_landscape(terra_landscape const &p) {
+		if (p.num_rnd_grass_blocks == 0) throw std::invalid_argument("terra_set_landscape: num_rnd_grass_blocks must be > 0");
+		if (!(p.mesh_scale_z > 0.0f)) throw std::invalid_argument("terra_set_landscape: mesh_scale_z must be > 0");
+		ls = p;
 	}
 
 	// the config-file values only (no derivation): what an engine that already owns the derived globals passes before terra_set_state
@@ -716,7 +733,9 @@ template<class BE> struct terra_engine {
 	// One height field of tw x tw cells per tile, origin (tile*128 - shift) cells: setup_height_gen_async(height_gen, x1 - shift, y1 - shift, tw, tw)
 	// + the eval_index loop (src/tiled_mesh.cpp:458-464,480-488,494-505).  tw = 130, shift = 0: the tile's zvals; tw = 201, shift = 36: its AO context.
 	// Returns the device copy of the tile references (valid until the next tile call of this context).
-	tile_ref_pod_t const *tile_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out, float xy_scale = 1.0f) { // xy_scale 0: only the tile references
+	tile_ref_pod_t const *tile_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out, float xy_scale = 1.0f, // xy_scale 0: only the tile references
+		bool glac = true, bool force_sine = false, int min_start_sin = 0) // enable_glaciate() after build_arrays; build_arrays' force_sine_mode; eval_index's min_start_sin
+	{
 		uint32_t const size = 128, zv = tw;
 		float const fdx = xy_scale*DX_VAL, fdy = xy_scale*DY_VAL; // setup_height_gen_async: build_arrays(..., xy_scale*DX_VAL, xy_scale*DY_VAL, ...)
 		// a tile's X table depends only on its tile x, its Y table only on its tile y: build each distinct one once
@@ -756,8 +775,8 @@ template<class BE> struct terra_engine {
 		be.h2d(d_m0, h_m0.data(), h_m0.size()*4);
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
-		int const md = mode, shp = shape, kstart = start_eval_sin;
-		bool const use_sm = (hp.sine_mag > 0.0f);
+		int const md = force_sine ? (int)MGEN_SINE : mode, shp = force_sine ? 0 : shape, kstart = imax(start_eval_sin, min_start_sin);
+		bool const use_sm = glac && (hp.sine_mag > 0.0f);
 		float const dxv = fdx, dyv = fdy, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
 		if (use_sm) { // enable_glaciate per distinct tx / ty
 			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq;
@@ -782,7 +801,7 @@ template<class BE> struct terra_engine {
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw, unique_tiles);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw, unique_tiles, glac);
 		return d_refs;
 	}
 
@@ -962,6 +981,95 @@ template<class BE> struct terra_engine {
 		}
 		float const dz = (float)(0.5*(double)HALF_DXY);
 		be.tile_ao(n, d_zvals, d_ctx, d_ao, dz);
+	}
+
+	// ================================================================ landscape weights texture (f3)
+	// tile_t::update_terrain_params (src/tiled_mesh.cpp:321-343): out[tile][yp][xp] = {veg, grass, dirt}
+	void tiles_terrain_params_dev(tile_ref_pod_t const *d_refs, uint32_t n, float *d_params) {
+		if (!ls.enable_terrain_env) { // terrain_params_t defaults (src/tiled_mesh.h:193)
+			be.launch((size_t)n*12, [=] TERRA_LAMBDA (size_t i) {d_params[i] = ((i % 3) == 2) ? 0.0f : 1.0f;});
+			return;
+		}
+		float *d_st = scratch<float>(s_misc, F_TABLE_SIZE*5 + 16);
+		be.h2d(d_st, &sinTable[0][0], sizeof(sinTable));
+		sin_lut_t const L = lut();
+		int const k0 = start_eval_sin;
+		float const msc = mesh_scale, bxo = ls.biome_x_offset, dxv = DX_VAL, dyv = DY_VAL, xss = cfg.scene_x, yss = cfg.scene_y;
+		be.launch((size_t)n*8, [=] TERRA_LAMBDA (size_t i) { // (tile, corner, {veg, dirt})
+			unsigned const t = (unsigned)(i >> 3), yp = (unsigned)(i >> 2) & 1u, xp = (unsigned)(i >> 1) & 1u, which = (unsigned)i & 1u;
+			tile_ref_pod_t const r = d_refs[t];
+			int const x1 = r.tx*128, y1 = r.ty*128;
+			float const xv1 = -xss + dxv*(float)x1, xv2 = xv1 + (float)128*dxv, yv1 = -yss + dyv*(float)y1, yv2 = yv1 + (float)128*dyv; // get_xval(x1), xv1 + (x2-x1)*DX_VAL
+			float const xv = msc*(xp ? xv2 : xv1) + bxo, yv = msc*(yp ? yv2 : yv1);
+			float const mult = which ? 1.0f : 5.0f; // dirt_mult, veg_mult
+			float const ax = mult*xv, ay = mult*yv;
+			float zval = 0.0f; // eval_mesh_sin_terms (src/mesh_gen.cpp:797-805)
+			for (int k = k0; k < F_TABLE_SIZE; ++k) {
+				float const *stk = d_st + 5*k;
+				zval += stk[0]*L.SINF(stk[3]*ay + stk[1])*L.SINF(stk[4]*ax + stk[2]);
+			}
+			float *o = d_params + (size_t)t*12 + 3*(2*yp + xp);
+			if (which) {o[2] = clip01(5.0f*(zval + 1.0f));}
+			else {o[0] = clip01(5.000f*(zval + 1.5f)); o[1] = clip01(100.0f*(zval + 3.0f));}
+		});
+	}
+	void tiles_terrain_params(int32_t const *tile_xy, uint32_t n, float *h_params) {
+		require_scene();
+		if (n == 0) return;
+		tile_ref_pod_t const *d_refs = tile_fields_dev(tile_xy, n, WT_TEX, 0, nullptr, 0.0f);
+		float *d_params = scratch<float>(s_ao, (size_t)n*12);
+		tiles_terrain_params_dev(d_refs, n, d_params);
+		be.d2h(h_params, d_params, (size_t)n*12*sizeof(float));
+	}
+	landscape_consts_t landscape_consts() const {
+		landscape_consts_t c;
+		tex_heights(c.h_dirt);
+		c.zmin = zmin; c.dz_inv = 1.0f/(zmax - zmin); c.relh_adj_tex = relh_adj_tex; c.water_level = get_water_z_height();
+		float const MESH_NOISE_SCALE = 0.003f;
+		c.noise_scale = (float)(((shape == 2) ? 2.0 : 1.0)*(double)MESH_NOISE_SCALE*(double)ls.mesh_scale_z); // more noise for ridged
+		c.vnz_scale = (mode == MGEN_DWARP_GPU) ? (float)sqrt(2.0) : 1.0f; // steeper slopes are allowed under domain warping
+		c.DX_VAL = DX_VAL; c.DY_VAL = DY_VAL; c.dxdy = dxdy;
+		c.steep_mult_grass = 1.0f/(sthresh_v(0, 1) - sthresh_v(0, 0));
+		c.steep_mult_snow  = 1.0f/(sthresh_v(1, 1) - sthresh_v(1, 0));
+		c.steep_mult_rock  = 1.0f/(0.8f*sthresh_v(0, 0) - 0.5f*sthresh_v(0, 0));
+		c.vegetation = ls.vegetation; c.snow_to_rock = (ls.water_is_lava || ls.disable_water == 2) ? 1 : 0;
+		c.gen_grass_map = (ls.grass_density > 0 && ls.vegetation > 0.0f) ? 1 : 0; // GRASS_THRESH = 1.6 > 0 (src/tiled_mesh.cpp:29,126)
+		c.num_rnd_grass_blocks = ls.num_rnd_grass_blocks;
+		return c;
+	}
+	// tile_t::create_texture (src/tiled_mesh.cpp:1071-1240), terrain-only branch, for a batch of tiles whose zvals are on the device:
+	// d_weights n x 129x129 RGBA8, d_blocks n x 32x32 grass blocks (or null), d_has_grass n bytes (or null)
+	void tiles_create_weights_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, uint8_t *d_weights, grass_block_pod_t *d_blocks, uint8_t *d_has_grass) {
+		require_scene();
+		if (n == 0) return;
+		uint32_t const ts = WT_TEX, zv = WT_ZV;
+		size_t const ntex = (size_t)n*ts*ts;
+		uint8_t *base = scratch<uint8_t>(s_ao, ntex*5 + (size_t)n*(12*4 + 1) + 1024);
+		float *d_rand = (float *)base, *d_params = d_rand + ntex;
+		uint8_t *d_flags = (uint8_t *)(d_params + (size_t)n*12), *d_any = d_flags + ntex;
+		// second noise field: build_arrays(x1 - MESH_X_SIZE/2, y1 - MESH_Y_SIZE/2, 80*DX_VAL, 80*DY_VAL, tsize, tsize, 0, force_sine_mode=1) + eval_index(x, y, 50)
+		tile_ref_pod_t const *d_refs = tile_fields_dev(tile_xy, n, ts, 0, d_rand, 80.0f, false, true, 50);
+		tiles_terrain_params_dev(d_refs, n, d_params);
+		landscape_consts_t const c = landscape_consts();
+		be.fill8(d_any, 0, n);
+		uint32_t *d_w32 = (uint32_t *)d_weights; // n*129*129*4 bytes from a device allocation: 4-byte aligned
+		if (((uintptr_t)d_weights & 3u) != 0) throw std::invalid_argument("tiles_create_weights: d_weights must be 4-byte aligned");
+		be.launch(ntex, [=] TERRA_LAMBDA (size_t i) {
+			unsigned const t = (unsigned)(i / (ts*ts)), p = (unsigned)(i % (ts*ts)), y = p / ts, x = p % ts;
+			unsigned flags;
+			d_w32[i] = weights_texel(c, d_zvals + (size_t)t*zv*zv, d_params + (size_t)t*12, d_rand[i], x, y, flags);
+			d_flags[i] = (uint8_t)flags;
+			if (flags & 1u) {d_any[t] = 1;} // has_any_grass: every writer stores the same value
+		});
+		if (d_blocks) {
+			uint32_t const bd = GRASS_BLOCK_DIM;
+			be.launch((size_t)n*bd*bd, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const t = (unsigned)(i / (bd*bd)), b = (unsigned)(i % (bd*bd));
+				tile_ref_pod_t const r = d_refs[t];
+				d_blocks[i] = grass_block(c, d_zvals + (size_t)t*zv*zv, d_flags + (size_t)t*ts*ts, r.tx*128, r.ty*128, b % bd, b / bd);
+			});
+		}
+		if (d_has_grass) {be.launch(n, [=] TERRA_LAMBDA (size_t i) {d_has_grass[i] = d_any[i];});}
 	}
 
 	// ================================================================ voxels (a14, a15, K8, K9)

@@ -143,7 +143,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true)
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
@@ -151,7 +151,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			use();
 			terra::grid_job_t job;
 			job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = tw; job.nxp = nxpv; job.nyp = nypv;
-			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so; job.plain_only = 0;
+			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = glaciate ? 1 : 0; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so; job.plain_only = 0;
 			size_t const threads = (size_t)n*tw*((tw + 1)/2);
 			dim3 const grid((unsigned)((threads + 255)/256)), block(256);
 			switch (md) {
@@ -163,7 +163,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
 		}
-		if (simple_kernels || md != terra::MGEN_SINE || !unique_tiles || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw); return;}
+		if (simple_kernels || md != terra::MGEN_SINE || !unique_tiles || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate); return;}
 		use();
 		size_t const cnt = (size_t)nux*nuy;
 		if (cnt > tile_map_count) {if (tile_map) {sync(); (void)hipFree(tile_map);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_map, cnt*sizeof(int32_t))); tile_map_count = cnt;}
@@ -172,7 +172,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		launch(n, [=] TERRA_LAMBDA (size_t i) {terra::tile_ref_pod_t const r = refs[i]; tm[(size_t)r.yi*nux + r.xi] = (int32_t)i;});
 		terra::grid_job_t job;
 		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*tw; job.ny = nuy*tw; job.nxp = nxpv; job.nyp = nypv;
-		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = 1; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
+		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = glaciate ? 1 : 0; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
 		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup, tw};
 		job.plain_only = plain_only ? 1 : 0;

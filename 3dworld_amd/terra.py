@@ -38,6 +38,21 @@ class TileStats(C.Structure):  # terra_tile_stats
                 ("wx1", C.c_int32), ("wy1", C.c_int32), ("wx2", C.c_int32), ("wy2", C.c_int32)]
 
 
+class Landscape(C.Structure):  # terra_landscape
+    _fields_ = [("vegetation", C.c_float), ("temperature", C.c_float), ("biome_x_offset", C.c_float), ("mesh_scale_z", C.c_float),
+                ("water_is_lava", C.c_int32), ("disable_water", C.c_int32), ("enable_terrain_env", C.c_int32),
+                ("grass_density", C.c_uint32), ("num_rnd_grass_blocks", C.c_uint32)]
+
+
+def make_landscape(vegetation=1.0, temperature=20.0, biome_x_offset=0.0, mesh_scale_z=1.0, water_is_lava=0, disable_water=0,
+                   enable_terrain_env=1, grass_density=0, num_rnd_grass_blocks=16):
+    """terra_landscape with the reference's defaults."""
+    return Landscape(vegetation, temperature, biome_x_offset, mesh_scale_z, water_is_lava, disable_water, enable_terrain_env, grass_density, num_rnd_grass_blocks)
+
+
+GRASS_BLOCK_DTYPE = np.dtype([("ix", np.uint32), ("zmin", np.float32), ("zmax", np.float32)])  # terra_grass_block
+
+
 class ErosionReport(C.Structure):  # terra_erosion_report
     _fields_ = [("droplets", C.c_uint32), ("windows", C.c_uint32), ("rounds", C.c_uint32), ("traces", C.c_uint32),
                 ("serial_fallbacks", C.c_uint32), ("nan_droplets", C.c_uint32), ("steps", C.c_uint64), ("traced_steps", C.c_uint64)]
@@ -116,6 +131,11 @@ _PROTOS = {
     "terra_tiles_mesh_shadows_halo_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
     "terra_hmap_set_dev": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "terra_set_mesh_height_scales_for_zval_range": (_i32, [_vp, _f, _f]),
+    "terra_set_landscape": (_i32, [_vp, _vp]),
+    "terra_get_landscape": (_i32, [_vp, _vp]),
+    "terra_tiles_terrain_params": (_i32, [_vp, _vp, _u32, _vp]),
+    "terra_tiles_create_weights_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "terra_tiles_create_weights": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_ao_lighting_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "terra_tiles_ao_lighting": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
@@ -311,6 +331,29 @@ class Terra:
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))
 
+    def set_landscape(self, ls):
+        self._ck(self.lib.terra_set_landscape(self.ctx, C.byref(ls)))
+
+    def get_landscape(self):
+        ls = Landscape()
+        self._ck(self.lib.terra_get_landscape(self.ctx, C.byref(ls)))
+        return ls
+
+    def tiles_terrain_params(self, tile_xy):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        out = np.empty((len(txy), 2, 2, 3), np.float32)
+        self._ck(self.lib.terra_tiles_terrain_params(self.ctx, txy.ctypes.data, len(txy), out.ctypes.data))
+        return out
+
+    def tiles_create_weights(self, tile_xy, zvals):
+        """-> (weights u8 [n,129,129,4], grass blocks [n,32,32] of GRASS_BLOCK_DTYPE, has_any_grass bool [n])"""
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        z = np.ascontiguousarray(zvals, np.float32).reshape(n, 130, 130)
+        w = np.empty((n, 129, 129, 4), np.uint8); gb = np.empty((n, 32, 32), GRASS_BLOCK_DTYPE); hg = np.empty(n, np.uint8)
+        self._ck(self.lib.terra_tiles_create_weights(self.ctx, txy.ctypes.data, n, z.ctypes.data, w.ctypes.data, gb.ctypes.data, hg.ctypes.data))
+        return w, gb, hg.astype(bool)
+
     def tiles_ao_lighting(self, tile_xy, zvals):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
         n = len(txy)
@@ -363,6 +406,10 @@ class Terra:
     def tiles_create_zvals_dev(self, tile_xy, iters_tt, z_ptr, stats_ptr=None, normals_ptr=None, mnz_ptr=None):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
         self._ck(self.lib.terra_tiles_create_zvals_dev(self.ctx, txy.ctypes.data, len(txy), iters_tt, z_ptr, stats_ptr, normals_ptr, mnz_ptr))
+
+    def tiles_create_weights_dev(self, tile_xy, z_ptr, weights_ptr, blocks_ptr=None, has_grass_ptr=None):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        self._ck(self.lib.terra_tiles_create_weights_dev(self.ctx, txy.ctypes.data, len(txy), z_ptr, weights_ptr, blocks_ptr, has_grass_ptr))
 
     def tiles_ao_lighting_dev(self, tile_xy, z_ptr, ao_ptr):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)

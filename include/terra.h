@@ -79,6 +79,21 @@ typedef struct terra_erosion_report {
 	uint64_t traced_steps;   /* droplet steps actually simulated, re-traces included */
 } terra_erosion_report;
 
+/* The globals tile_t::create_texture and tile_t::update_terrain_params read beyond terra_config; the defaults are the reference's. */
+typedef struct terra_landscape {
+	float vegetation;            /* config "vegetation" (src/3DWorld.cpp:109): 0 turns ground/grass into rock and disables the sand conversions */
+	float temperature;           /* DEF_TEMPERATURE = 20 (src/3DWorld.h:87): above 40 the snow line rises (src/mesh_gen.cpp:423-426) */
+	float biome_x_offset;        /* config "biome_x_offset" */
+	float mesh_scale_z;          /* src/mesh_gen.cpp:37,873: 1 until the terrain zoom changes it */
+	int32_t water_is_lava;       /* config "water_is_lava": snow -> rock */
+	int32_t disable_water;       /* DISABLE_WATER: 2 also turns snow into rock (src/Textures.cpp:1290) */
+	int32_t enable_terrain_env;  /* ENABLE_TERRAIN_ENV = 1 (src/tiled_mesh.h:21): biome parameters from eval_mesh_sin_terms at the tile corners; 0 = {veg 1, grass 1, dirt 0} */
+	uint32_t grass_density;      /* config "grass_density": 0 = gen_grass_map() false, no grass blocks (src/tiled_mesh.cpp:126) */
+	uint32_t num_rnd_grass_blocks; /* 16 (src/grass.cpp:14) */
+} terra_landscape;
+/* tile_t::grass_block_t (src/tiled_mesh.h:186): ix 0 = no grass in this 4x4-texel block, else 1 + index of the random grass block; z range of its texels */
+typedef struct terra_grass_block {uint32_t ix; float zmin, zmax;} terra_grass_block;
+
 typedef struct terra_ctx terra_ctx;
 typedef struct terra_gen terra_gen;
 
@@ -189,6 +204,18 @@ int  terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, fl
 int  terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable);
 int  terra_tiles_ao_lighting_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_ao);
 int  terra_tiles_ao_lighting(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, uint8_t *h_ao);
+
+/* ---- landscape weights texture of a tile: tile_t::create_texture (src/tiled_mesh.cpp:1071-1240) with update_terrain_params (:321-343), get_tids /
+ * update_lttex_ix (src/Textures.cpp:1289-1316) and add_grass_block_at (src/tiled_mesh.cpp:1354-1371).  Terrain-only branch: the city, tunnel and building
+ * queries and the tree map come from subsystems outside this library (their texels are the caller's to overwrite afterwards, as the reference does).
+ * zvals: [n][130][130]; weights: [n][129][129][4] bytes RGBA = {sand, dirt, grass, rock}, snow = remainder; grass_blocks: [n][32][32] or NULL;
+ * has_any_grass: [n] bytes or NULL.  The second noise field (build_arrays(..., 80*DX_VAL, 80*DY_VAL, 129, 129, 0, force_sine_mode=1) + eval_index(x, y, 50))
+ * and the biome parameters are generated internally.  terra_tiles_terrain_params returns those parameters: [n][2][2][3] = [yp][xp]{veg, grass, dirt}. */
+int  terra_set_landscape(terra_ctx *ctx, const terra_landscape *params);
+int  terra_get_landscape(terra_ctx *ctx, terra_landscape *out);
+int  terra_tiles_terrain_params(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, float *h_params);
+int  terra_tiles_create_weights_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, uint8_t *d_weights, terra_grass_block *d_grass_blocks, uint8_t *d_has_any_grass);
+int  terra_tiles_create_weights(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, uint8_t *h_weights, terra_grass_block *h_grass_blocks, uint8_t *h_has_any_grass);
 
 /* ---- tile mesh shadows of one directional light: tile_t::calc_shadows_for_light + calc_mesh_shadows / mesh_shadow_gen (src/tiled_mesh.cpp:664-692,
  * src/visibility.cpp:411-520).  zvals: [n][130][130]; light_pos: the light's position vector (get_light_pos(l)); smask: [n][130][130] bytes, 0 or

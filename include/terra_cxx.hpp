@@ -107,6 +107,14 @@ inline void write_heightmap_png(char const *fn, unsigned char const *pixels, uns
 inline void tiles_ao_lighting(int const *tile_xy, unsigned n, float const *zvals, unsigned char *ao) {
 	check(terra_tiles_ao_lighting(default_ctx(), tile_xy, n, zvals, ao), "calc_mesh_ao_lighting");
 }
+// ---- tile_t::create_texture's weights (src/tiled_mesh.cpp:1071-1240, terrain-only branch) for a batch: zvals [n][130][130] -> mesh_weight_data
+// [n][129][129][4], grass_blocks [n][32][32] (may be null), has_any_grass [n] (may be null); set_landscape = the globals it reads (vegetation, ...)
+inline void set_landscape(terra_landscape const &params) {check(terra_set_landscape(default_ctx(), &params), "set_landscape");}
+inline void tiles_create_weights(int const *tile_xy, unsigned n, float const *zvals, unsigned char *mesh_weight_data, terra_grass_block *grass_blocks, unsigned char *has_any_grass) {
+	check(terra_tiles_create_weights(default_ctx(), tile_xy, n, zvals, mesh_weight_data, grass_blocks, has_any_grass), "create_texture");
+}
+// tile_t::update_terrain_params (src/tiled_mesh.cpp:321-343): params [n][2][2]{veg, grass, dirt}
+inline void tiles_terrain_params(int const *tile_xy, unsigned n, float *params) {check(terra_tiles_terrain_params(default_ctx(), tile_xy, n, params), "update_terrain_params");}
 // voxel_manager::create_procedural fill (src/voxels.cpp:278-346): `vals` is the voxel_grid<float> storage, z fastest
 inline void voxel_create_procedural(std::vector<float> &vals, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],
 	float mag, float freq, bool normalize_to_1, int rseed1, int rseed2, int gen_mode, float zscale)

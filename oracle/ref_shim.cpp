@@ -479,6 +479,172 @@ REF_API void ref_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const 
 }
 
 // tile_t::upload_normal_texture CPU part (src/tiled_mesh.cpp:865-880, src/tiled_mesh.h:281-284); returns min_normal_z
+// ---- f3: landscape weights texture.  tile_t::create_texture / update_terrain_params live in tiled_mesh.cpp and get_tids / update_lttex_ix in Textures.cpp
+// (GL-bound translation units that cannot be built here), so this is a driver in the reference's own types and macros (vector3d, CLIP_TO_01, ttex ids)
+// around the reference functions that ARE compiled: build_arrays / eval_index (the noise field), eval_mesh_sin_terms (the biome parameters),
+// get_water_z_height, init_terrain_mesh (lttex_dirt), sthresh.  It pins those inputs; the blend logic itself is a second restatement.
+struct ref_landscape_t {float vegetation, temperature, biome_x_offset, mesh_scale_z; int water_is_lava, disable_water, enable_terrain_env; unsigned grass_density, num_rnd_grass_blocks;};
+struct ref_grass_block_t {unsigned ix; float zmin, zmax;}; // tile_t::grass_block_t (src/tiled_mesh.h:186)
+static ref_landscape_t shim_ls = {1.0, DEF_TEMPERATURE, 0.0, 1.0, 0, 0, 1, 0, 16};
+extern float sthresh[2][2];
+REF_API void ref_set_landscape(ref_landscape_t const *p) {
+	shim_ls = *p; temperature = p->temperature; mesh_scale_z = p->mesh_scale_z;
+	init_terrain_mesh(); // calls gen_tex_height_tables()
+}
+static void shim_update_lttex_ix(int &ix) { // src/Textures.cpp:1289-1292
+	if ((shim_ls.water_is_lava || shim_ls.disable_water == 2) && lttex_dirt[ix].id == SNOW_TEX) {--ix;}
+	if (shim_ls.vegetation == 0.0 && lttex_dirt[ix].id == GROUND_TEX) {++ix;}
+}
+static void shim_get_tids(float relh, int &k1, int &k2, float *t=nullptr) { // src/Textures.cpp:1294-1316
+	float const TEXTURE_SMOOTH = 0.01;
+	for (k1 = 0; k1 < NTEX_DIRT-1; ++k1) {if (relh < h_dirt[k1]) break;}
+	if (k1 < NTEX_DIRT-1 && (h_dirt[k1] - relh) < TEXTURE_SMOOTH) {
+		if (t) {*t = 1.0 - (h_dirt[k1] - relh)/TEXTURE_SMOOTH;}
+		k2 = k1+1;
+		shim_update_lttex_ix(k1);
+		shim_update_lttex_ix(k2);
+	}
+	else {
+		shim_update_lttex_ix(k1);
+		k2 = k1;
+	}
+}
+struct shim_terrain_params_t {float veg=1.0, grass=1.0, dirt=0.0;};
+static void shim_update_terrain_params(int x1, int y1, int x2, int y2, shim_terrain_params_t params[2][2]) { // src/tiled_mesh.cpp:321-343
+	float const dirt_mult(1.0), veg_mult(5.0);
+	float const xv1(get_xval(x1)), xv2(xv1 + (x2-x1)*DX_VAL), yv1(get_yval(y1)), yv2(yv1 + (y2-y1)*DY_VAL);
+	for (unsigned yp = 0; yp < 2; ++yp) {
+		for (unsigned xp = 0; xp < 2; ++xp) {
+			shim_terrain_params_t &param(params[yp][xp]);
+			float const xv(mesh_scale*(xp ? xv2 : xv1) + shim_ls.biome_x_offset), yv(mesh_scale*(yp ? yv2 : yv1));
+			float const veg_val(eval_mesh_sin_terms(veg_mult*xv, veg_mult*yv));
+			param.veg   = CLIP_TO_01(5.000f*(veg_val + 1.5f));
+			param.grass = CLIP_TO_01(100.0f*(veg_val + 3.0f));
+			param.dirt  = CLIP_TO_01(5.0f*(eval_mesh_sin_terms(dirt_mult*xv, dirt_mult*yv) + 1.0f));
+		}
+	}
+}
+REF_API void ref_tile_terrain_params(int tx, int ty, float *out) {
+	shim_terrain_params_t params[2][2];
+	if (shim_ls.enable_terrain_env) {shim_update_terrain_params(tx*128, ty*128, tx*128 + 128, ty*128 + 128, params);}
+	for (unsigned i = 0; i < 4; ++i) {shim_terrain_params_t const &p(params[i >> 1][i & 1]); out[3*i] = p.veg; out[3*i+1] = p.grass; out[3*i+2] = p.dirt;}
+}
+#define SHIM_BILINEAR_INTERP(arr, var, x, y) (y*(x*arr[1][1].var + (1.0f-x)*arr[1][0].var) + (1.0f-y)*(x*arr[0][1].var + (1.0f-x)*arr[0][0].var)) // src/tiled_mesh.cpp:189
+REF_API void ref_tile_create_weights(int tx, int ty, float const *zvals, unsigned char *mesh_weight_data, ref_grass_block_t *grass_blocks, int *has_any_grass_out) {
+	unsigned const size(128), stride(size+1), zvsize(stride+1), tsize(stride), grass_block_sz(4), grass_block_dim(1+(size-1)/grass_block_sz);
+	int const x1(tx*size), y1(ty*size);
+	int sand_tex_ix(-1), dirt_tex_ix(-1), grass_tex_ix(-1), rock_tex_ix(-1), snow_tex_ix(-1);
+	for (unsigned i = 0; i < NTEX_DIRT; ++i) { // get_texture_ixs (src/tiled_mesh.cpp:1049-1062)
+		switch (lttex_dirt[i].id) {
+		case SAND_TEX:   sand_tex_ix  = i; break;
+		case DIRT_TEX:   dirt_tex_ix  = i; break;
+		case GROUND_TEX: grass_tex_ix = i; break;
+		case ROCK_TEX:   rock_tex_ix  = i; break;
+		case SNOW_TEX:   snow_tex_ix  = i; break;
+		}
+	}
+	shim_terrain_params_t params[2][2];
+	if (shim_ls.enable_terrain_env) {shim_update_terrain_params(x1, y1, x1 + size, y1 + size, params);}
+	bool has_any_grass(0);
+	bool const gen_grass_map(shim_ls.grass_density > 0 && shim_ls.vegetation > 0.0);
+	if (grass_blocks) {for (unsigned i = 0; i < grass_block_dim*grass_block_dim; ++i) {grass_blocks[i] = ref_grass_block_t{0, 0.0, 0.0};}}
+	float const vegetation(shim_ls.vegetation);
+	float const xy_mult(1.0/float(size)), water_level(get_water_z_height());
+	float const MESH_NOISE_SCALE = 0.003;
+	float const MESH_NOISE_FREQ  = 80.0;
+	float const dz_inv(1.0f/(zmax - zmin));
+	float const noise_scale(((mesh_gen_shape == 2) ? 2.0 : 1.0)*MESH_NOISE_SCALE*mesh_scale_z);
+	float const steep_mult_grass(1.0f/(sthresh[0][1] - sthresh[0][0]));
+	float const steep_mult_snow (1.0f/(sthresh[1][1] - sthresh[1][0]));
+	float const steep_mult_rock (1.0f/(0.8f*sthresh[0][0] - 0.5f*sthresh[0][0]));
+	float const vnz_scale((mesh_gen_mode == MGEN_DWARP_GPU) ? SQRT2 : 1.0);
+	int k1, k2, k3, k4;
+	mesh_xy_grid_cache_t height_gen;
+	height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), MESH_NOISE_FREQ*DX_VAL, MESH_NOISE_FREQ*DY_VAL, tsize, tsize, 0, 1); // force_sine_mode=1
+	vector<float> rand_vals(tsize*tsize);
+	for (unsigned y = 0; y < tsize; ++y) {
+		for (unsigned x = 0; x < tsize; ++x) {rand_vals[y*tsize + x] = noise_scale*height_gen.eval_index(x, y, 50);}
+	}
+	for (unsigned y = 0; y < tsize; ++y) {
+		float const yv(float(y)*xy_mult);
+		for (unsigned x = 0; x < tsize; ++x) {
+			unsigned const ix_val(y*tsize + x), off(4*ix_val), ix(y*zvsize + x);
+			float weights[NTEX_DIRT] = {};
+			float const mh00(zvals[ix]), mh01(zvals[ix+1]), mh10(zvals[ix+zvsize]), mh11(zvals[ix+zvsize+1]);
+			float const mhmin(min(min(mh00, mh01), min(mh10, mh11))), mhmax(max(max(mh00, mh01), max(mh10, mh11)));
+			float const rand_offset(rand_vals[y*tsize + x]);
+			float const relh1(relh_adj_tex + (mhmin - zmin)*dz_inv + rand_offset), relh2(relh_adj_tex + (mhmax - zmin)*dz_inv + rand_offset);
+			shim_get_tids(relh1, k1, k2);
+			shim_get_tids(relh2, k3, k4);
+			bool const same_tid(k1 == k4);
+			float t(0.0);
+			k2 = k4;
+			if (!same_tid) {
+				float const relh(relh_adj_tex + (mh00 - zmin)*dz_inv);
+				shim_get_tids(relh, k1, k2, &t);
+			}
+			float weight_scale(1.0);
+			bool const grass(lttex_dirt[k1].id == GROUND_TEX || lttex_dirt[k2].id == GROUND_TEX), snow(lttex_dirt[k2].id == SNOW_TEX);
+			has_any_grass |= grass;
+			if (grass || snow) {
+				float const *const sti(sthresh[snow]);
+				vector3d const normal(DY_VAL*(zvals[ix] - zvals[ix + 1]), DX_VAL*(zvals[ix] - zvals[ix + zvsize]), dxdy); // get_norm_not_normalized (src/tiled_mesh.h:281)
+				float vnz(vnz_scale*normal.z/normal.mag());
+				if (grass && vnz > sti[1]) {vnz = CLIP_TO_01(1.0f + 20.0f*rand_offset);}
+				if (vnz < sti[1]) {
+					if (grass) {
+						float rock_weight((lttex_dirt[k1].id == GROUND_TEX || lttex_dirt[k2].id == ROCK_TEX) ? t : 0.0);
+						float const steepness(1.0 - CLIP_TO_01((vnz - 0.5f*sti[0])*steep_mult_rock));
+						rock_weight  = rock_weight*(1.0 - steepness) + steepness;
+						weight_scale = CLIP_TO_01((vnz - sti[0])*steep_mult_grass);
+						weights[rock_tex_ix] += (1.0 - weight_scale)*rock_weight;
+						weights[dirt_tex_ix] += (1.0 - weight_scale)*(1.0 - rock_weight);
+					}
+					else {
+						weight_scale = CLIP_TO_01(2.0f*(vnz - sti[0])*steep_mult_snow);
+						weights[rock_tex_ix] += 1.0 - weight_scale;
+					}
+				}
+			}
+			weights[k2] += weight_scale*t;
+			weights[k1] += weight_scale*(1.0 - t);
+			float const xv(float(x)*xy_mult);
+			if (vegetation > 0.0) {
+				float const dirt_scale(SHIM_BILINEAR_INTERP(params, dirt, xv, yv));
+				if (dirt_scale < 1.0) {
+					weights[sand_tex_ix] += (1.0 - dirt_scale)*weights[dirt_tex_ix];
+					weights[dirt_tex_ix] *= dirt_scale;
+				}
+			}
+			if (grass) {
+				float grass_scale((mhmin < water_level) ? 0.0f : SHIM_BILINEAR_INTERP(params, grass, xv, yv));
+				if (grass_scale < 1.0) {
+					float const gscale(CLIP_TO_01(2.5f*(grass_scale - 0.5f) + 0.5f));
+					weights[sand_tex_ix ] += (1.0 - gscale)*weights[grass_tex_ix];
+					weights[grass_tex_ix] *= gscale;
+				}
+				if (grass_scale > 0.0 && grass_blocks && gen_grass_map && x < size && y < size) { // add_grass_block_at (src/tiled_mesh.cpp:1354-1371)
+					ref_grass_block_t &gb(grass_blocks[(y/grass_block_sz)*grass_block_dim + x/grass_block_sz]);
+					if (gb.ix == 0) {
+						gb.ix   = (((x1 + x) + 1567*(y1 + y)) % shim_ls.num_rnd_grass_blocks) + 1;
+						gb.zmin = mhmin;
+						gb.zmax = mhmax;
+					}
+					else {
+						min_eq(gb.zmin, mhmin);
+						max_eq(gb.zmax, mhmax);
+					}
+				}
+			}
+			for (unsigned i = 0; i < NTEX_DIRT-1; ++i) {
+				mesh_weight_data[off+i] = ((weights[i] <= 0.01) ? 0 : ((weights[i] >= 0.99) ? 255 : (unsigned char)(255.0*weights[i])));
+			}
+		}
+	}
+	(void)snow_tex_ix;
+	if (has_any_grass_out) {*has_any_grass_out = has_any_grass;}
+}
+
 REF_API float ref_tile_normals(float const *zvals, unsigned char *rgba /*129*129*4*/) {
 	unsigned const stride(129), zvsize(130);
 	float min_normal_z(1.0);

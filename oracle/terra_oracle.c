@@ -1096,6 +1096,162 @@ void orc_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, 
 }
 
 /* a13: normals (src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880; vector3d::get_norm src/3DWorld.h) */
+/* ------------------------------------------------------------------ f3: landscape weights texture, tile_t::create_texture (src/tiled_mesh.cpp:1071-1240)
+ * Terrain-only branch: no city / tunnel / building queries (check_mesh_mask, check_city, exclude_cubes, check_buildings all false -- those objects belong
+ * to subsystems outside the path) and no tree map.  RGBA = {sand, dirt, grass, rock} weights, snow is the remainder. */
+static orc_landscape_t ls = {1.0f, 20.0f, 0.0f, 1.0f, 0, 0, 1, 0, 16};
+void orc_set_landscape(orc_landscape_t const *p) { /* the globals this row reads; temperature moves the snow line (src/mesh_gen.cpp:423-426) */
+	ls = *p; temperature = p->temperature;
+	init_terrain_mesh();
+	gen_tex_height_tables();
+}
+enum {LT_SAND = 0, LT_DIRT = 1, LT_GROUND = 2, LT_ROCK = 3, LT_SNOW = 4}; /* mesh_tids_dirt order, src/mesh_gen.cpp:42: the index is the texture */
+#define TEXTURE_SMOOTH 0.01f /* src/Textures.cpp:12 */
+static float const sthresh[2][2] = {{0.68f, 0.86f}, {0.48f, 0.72f}}; /* {grass, snow} x {lo, hi}, src/mesh_gen.cpp:44 */
+static void update_lttex_ix(int *ix) { /* src/Textures.cpp:1289-1292 */
+	if ((ls.water_is_lava || ls.disable_water == 2) && *ix == LT_SNOW) {--*ix;}
+	if (ls.vegetation == 0.0f && *ix == LT_GROUND) {++*ix;}
+}
+static void get_tids(float relh, int *k1, int *k2, float *t) { /* src/Textures.cpp:1294-1316 */
+	if      (relh < h_dirt[0]) {*k1 = 0;}
+	else if (relh < h_dirt[1]) {*k1 = 1;}
+	else if (relh < h_dirt[2]) {*k1 = 2;}
+	else if (relh < h_dirt[3]) {*k1 = 3;}
+	else                       {*k1 = 4;}
+	if (*k1 < 4 && (h_dirt[*k1] - relh) < TEXTURE_SMOOTH) {
+		if (t) {*t = (float)(1.0 - (double)((h_dirt[*k1] - relh)/TEXTURE_SMOOTH));}
+		*k2 = *k1 + 1;
+		update_lttex_ix(k1);
+		update_lttex_ix(k2);
+	}
+	else {
+		update_lttex_ix(k1);
+		*k2 = *k1;
+	}
+}
+/* tile_t::update_terrain_params (src/tiled_mesh.cpp:321-343): biome parameters at the 4 tile corners, out[yp][xp] = {veg, grass, dirt} */
+void orc_tile_terrain_params(int tx, int ty, float *out) {
+	int const size = 128, x1 = tx*size, y1 = ty*size, x2 = x1 + size, y2 = y1 + size;
+	float const dirt_mult = 1.0f, veg_mult = 5.0f;
+	float const xv1 = sh_xval(x1), xv2 = xv1 + (float)(x2 - x1)*DX_VAL, yv1 = sh_yval(y1), yv2 = yv1 + (float)(y2 - y1)*DY_VAL;
+	for (unsigned yp = 0; yp < 2; ++yp) {
+		for (unsigned xp = 0; xp < 2; ++xp) {
+			float *o = out + 3*(2*yp + xp);
+			if (!ls.enable_terrain_env) {o[0] = 1.0f; o[1] = 1.0f; o[2] = 0.0f; continue;} /* terrain_params_t defaults, src/tiled_mesh.h:193 */
+			float const xv = mesh_scale*(xp ? xv2 : xv1) + ls.biome_x_offset, yv = mesh_scale*(yp ? yv2 : yv1);
+			float const veg_val = eval_mesh_sin_terms(veg_mult*xv, veg_mult*yv);
+			o[0] = clip01(5.000f*(veg_val + 1.5f));
+			o[1] = clip01(100.0f*(veg_val + 3.0f));
+			o[2] = clip01(5.0f*(eval_mesh_sin_terms(dirt_mult*xv, dirt_mult*yv) + 1.0f));
+		}
+	}
+}
+static float bilinear(float const *prm, int var, float x, float y) { /* BILINEAR_INTERP, src/tiled_mesh.cpp:189 */
+	float const a00 = prm[var], a01 = prm[3 + var], a10 = prm[6 + var], a11 = prm[9 + var]; /* arr[y][x] */
+	return y*(x*a11 + (1.0f - x)*a10) + (1.0f - y)*(x*a01 + (1.0f - x)*a00);
+}
+void orc_tile_create_weights(int tx, int ty, float const *zvals, unsigned char *weights_rgba, orc_grass_block_t *blocks, int *has_any_grass_out) {
+	unsigned const size = 128, stride = size+1, zvsize = stride+1, tsize = stride;
+	unsigned const GRASS_BLOCK_SZ = 4, grass_block_dim = 1 + (size - 1)/GRASS_BLOCK_SZ; /* src/grass.h:10, src/tiled_mesh.h:315 */
+	int const x1 = tx*(int)size, y1 = ty*(int)size;
+	int const sand_tex_ix = LT_SAND, dirt_tex_ix = LT_DIRT, grass_tex_ix = LT_GROUND, rock_tex_ix = LT_ROCK;
+	int has_any_grass = 0;
+	int const gen_grass_map = (ls.grass_density > 0 && ls.vegetation > 0.0f); /* GRASS_THRESH = 1.6 > 0, src/tiled_mesh.cpp:29,126 */
+	float params[12];
+	orc_tile_terrain_params(tx, ty, params);
+	if (blocks) {memset(blocks, 0, (size_t)grass_block_dim*grass_block_dim*sizeof(*blocks));}
+	float const xy_mult = (float)(1.0/(double)(float)size), water_level = get_water_z_height();
+	float const MESH_NOISE_SCALE = 0.003f, MESH_NOISE_FREQ = 80.0f;
+	float const dz_inv = 1.0f/(zmax - zmin);
+	float const noise_scale = (float)(((mesh_gen_shape == 2) ? 2.0 : 1.0)*(double)MESH_NOISE_SCALE*(double)ls.mesh_scale_z);
+	float const steep_mult_grass = 1.0f/(sthresh[0][1] - sthresh[0][0]);
+	float const steep_mult_snow  = 1.0f/(sthresh[1][1] - sthresh[1][0]);
+	float const steep_mult_rock  = 1.0f/(0.8f*sthresh[0][0] - 0.5f*sthresh[0][0]);
+	float const vnz_scale = (mesh_gen_mode == ORC_MGEN_DWARP_GPU) ? (float)sqrt(2.0) : 1.0f;
+	grid_cache_t g;
+	gc_build_arrays(&g, (float)(x1 - MESH_X_SIZE/2), (float)(y1 - MESH_Y_SIZE/2), MESH_NOISE_FREQ*DX_VAL, MESH_NOISE_FREQ*DY_VAL, tsize, tsize, 0, 1); /* force_sine_mode=1 */
+	float *rand_vals = (float *)malloc((size_t)tsize*tsize*sizeof(float));
+	for (unsigned y = 0; y < tsize; ++y) {
+		for (unsigned x = 0; x < tsize; ++x) {rand_vals[y*tsize + x] = noise_scale*gc_eval_index(&g, x, y, 50, 0);}
+	}
+	for (unsigned y = 0; y < tsize; ++y) {
+		float const yv = (float)y*xy_mult;
+		for (unsigned x = 0; x < tsize; ++x) {
+			unsigned const ix_val = y*tsize + x, off = 4*ix_val, ix = y*zvsize + x;
+			float weights[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+			float const mh00 = zvals[ix], mh01 = zvals[ix+1], mh10 = zvals[ix+zvsize], mh11 = zvals[ix+zvsize+1];
+			float const mhmin = fmin_std(fmin_std(mh00, mh01), fmin_std(mh10, mh11)), mhmax = fmax_std(fmax_std(mh00, mh01), fmax_std(mh10, mh11));
+			float const rand_offset = rand_vals[ix_val];
+			float const relh1 = relh_adj_tex + (mhmin - zmin)*dz_inv + rand_offset, relh2 = relh_adj_tex + (mhmax - zmin)*dz_inv + rand_offset;
+			int k1, k2, k3, k4;
+			get_tids(relh1, &k1, &k2, NULL);
+			get_tids(relh2, &k3, &k4, NULL);
+			int const same_tid = (k1 == k4);
+			float t = 0.0f;
+			k2 = k4;
+			if (!same_tid) {
+				float const relh = relh_adj_tex + (mh00 - zmin)*dz_inv;
+				get_tids(relh, &k1, &k2, &t);
+			}
+			float weight_scale = 1.0f;
+			int const grass = (k1 == LT_GROUND || k2 == LT_GROUND), snow = (k2 == LT_SNOW);
+			has_any_grass |= grass;
+			if (grass || snow) {
+				float const *sti = sthresh[snow];
+				float const nx = DY_VAL*(zvals[ix] - zvals[ix + 1]), ny = DX_VAL*(zvals[ix] - zvals[ix + zvsize]), nz = dxdy; /* get_norm_not_normalized, src/tiled_mesh.h:281 */
+				float vnz = vnz_scale*nz/sqrtf(nx*nx + ny*ny + nz*nz);
+				if (grass && vnz > sti[1]) {vnz = clip01(1.0f + 20.0f*rand_offset);}
+				if (vnz < sti[1]) {
+					if (grass) {
+						float rock_weight = (k1 == LT_GROUND || k2 == LT_ROCK) ? t : 0.0f;
+						float const steepness = (float)(1.0 - (double)clip01((vnz - 0.5f*sti[0])*steep_mult_rock));
+						rock_weight  = (float)((double)rock_weight*(1.0 - (double)steepness) + (double)steepness);
+						weight_scale = clip01((vnz - sti[0])*steep_mult_grass);
+						weights[rock_tex_ix] = (float)((double)weights[rock_tex_ix] + (1.0 - (double)weight_scale)*(double)rock_weight);
+						weights[dirt_tex_ix] = (float)((double)weights[dirt_tex_ix] + (1.0 - (double)weight_scale)*(1.0 - (double)rock_weight));
+					}
+					else {
+						weight_scale = clip01(2.0f*(vnz - sti[0])*steep_mult_snow);
+						weights[rock_tex_ix] = (float)((double)weights[rock_tex_ix] + (1.0 - (double)weight_scale));
+					}
+				}
+			}
+			weights[k2] += weight_scale*t;
+			weights[k1] = (float)((double)weights[k1] + (double)weight_scale*(1.0 - (double)t));
+			float const xv = (float)x*xy_mult;
+			if (ls.vegetation > 0.0f) {
+				float const dirt_scale = bilinear(params, 2, xv, yv);
+				if (dirt_scale < 1.0f) {
+					weights[sand_tex_ix] = (float)((double)weights[sand_tex_ix] + (1.0 - (double)dirt_scale)*(double)weights[dirt_tex_ix]);
+					weights[dirt_tex_ix] *= dirt_scale;
+				}
+			}
+			if (grass) {
+				float grass_scale = (mhmin < water_level) ? 0.0f : bilinear(params, 1, xv, yv);
+				if (grass_scale < 1.0f) {
+					float const gscale = clip01(2.5f*(grass_scale - 0.5f) + 0.5f);
+					weights[sand_tex_ix] = (float)((double)weights[sand_tex_ix] + (1.0 - (double)gscale)*(double)weights[grass_tex_ix]);
+					weights[grass_tex_ix] *= gscale;
+				}
+				if (grass_scale > 0.0f && blocks && gen_grass_map && x < size && y < size) { /* add_grass_block_at, src/tiled_mesh.cpp:1354-1371 */
+					orc_grass_block_t *gb = &blocks[(y/GRASS_BLOCK_SZ)*grass_block_dim + x/GRASS_BLOCK_SZ];
+					if (gb->ix == 0) {
+						gb->ix = ((((unsigned)x1 + x) + 1567u*((unsigned)y1 + y)) % ls.num_rnd_grass_blocks) + 1; /* int + unsigned: unsigned arithmetic */
+						gb->zmin = mhmin; gb->zmax = mhmax;
+					}
+					else {gb->zmin = fmin_std(gb->zmin, mhmin); gb->zmax = fmax_std(gb->zmax, mhmax);}
+				}
+			}
+			for (unsigned i = 0; i < 4; ++i) {
+				weights_rgba[off+i] = ((double)weights[i] <= 0.01) ? 0 : (((double)weights[i] >= 0.99) ? 255 : (unsigned char)(255.0*(double)weights[i]));
+			}
+		}
+	}
+	free(rand_vals);
+	gc_free(&g);
+	if (has_any_grass_out) {*has_any_grass_out = has_any_grass;}
+}
+
 float orc_tile_normals(float const *zvals, unsigned char *rgba) {
 	unsigned const stride = 129, zvsize = 130;
 	float min_normal_z = 1.0f;

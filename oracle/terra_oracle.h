@@ -86,6 +86,16 @@ float orc_get_clamped_height(int x, int y);
 void  orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao);
 void  orc_calc_mesh_shadows(float lx, float ly, float lz, float const *mh, unsigned char *smask, int xsize, int ysize, float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y);
 void  orc_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float lx, float ly, float lz, unsigned char *smask);
+/* f3: the globals tile_t::create_texture / update_terrain_params read beyond orc_config_t (defaults = the reference's) */
+typedef struct orc_landscape_t {
+	float vegetation, temperature, biome_x_offset, mesh_scale_z; /* 1, DEF_TEMPERATURE = 20, 0, 1 */
+	int32_t water_is_lava, disable_water /* DISABLE_WATER */, enable_terrain_env /* 1 */;
+	uint32_t grass_density /* 0: no grass blocks */, num_rnd_grass_blocks /* 16 */;
+} orc_landscape_t;
+typedef struct orc_grass_block_t {uint32_t ix; float zmin, zmax;} orc_grass_block_t; /* tile_t::grass_block_t, src/tiled_mesh.h:186 */
+void  orc_set_landscape(orc_landscape_t const *p);
+void  orc_tile_terrain_params(int tx, int ty, float *out12);
+void  orc_tile_create_weights(int tx, int ty, float const *zvals, unsigned char *weights_rgba, orc_grass_block_t *blocks, int *has_any_grass);
 float orc_tile_normals(float const *zvals, unsigned char *rgba);
 void  orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out);
 void  orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float const lo_pos[3], float const vsz[3], float const offset[3],

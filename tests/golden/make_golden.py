@@ -74,6 +74,15 @@ def main():
     out["tile_m4ao_2_m1_ao"] = R.tile_ao_lighting(2, -1, z4)
     R.set_tiled_mesh_ao(0)
     s = R.init(orclib.make_config(mesh_gen_mode=0))
+    # row f3: landscape weights texture (create_texture driver over the reference's build_arrays / eval_index / eval_mesh_sin_terms / lttex tables)
+    R.set_landscape(orclib.make_landscape(grass_density=100))
+    zt, _ = R.tile_create_zvals(-3, 2, 0)
+    w, gb, hg = R.tile_create_weights(-3, 2, zt)
+    out["tile_m3_2_weights"] = w
+    out["tile_m3_2_grass_blocks"] = np.frombuffer(gb.tobytes(), np.uint8).copy()
+    out["tile_m3_2_has_grass"] = np.uint8(hg)
+    out["tile_terrain_params"] = np.stack([R.tile_terrain_params(-3, 2), R.tile_terrain_params(40, 41)])
+    R.set_landscape(orclib.make_landscape())
     # voxels
     for mode in (0, 1, 2):
         nx, ny, nz = (40, 24, 32) if mode == 0 else (12, 10, 16)

@@ -48,6 +48,21 @@ HMAP_DEFAULT = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 0, 0, 0, 0, 0]          # h
 HMAP_ISLANDS = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 0, 0]  # scene_config/config.txt:76
 
 
+class Landscape(C.Structure):
+    """orc_landscape_t / ref_landscape_t / terra_landscape: the globals create_texture and update_terrain_params read beyond Config."""
+    _fields_ = [("vegetation", C.c_float), ("temperature", C.c_float), ("biome_x_offset", C.c_float), ("mesh_scale_z", C.c_float),
+                ("water_is_lava", C.c_int32), ("disable_water", C.c_int32), ("enable_terrain_env", C.c_int32),
+                ("grass_density", C.c_uint32), ("num_rnd_grass_blocks", C.c_uint32)]
+
+
+def make_landscape(vegetation=1.0, temperature=20.0, biome_x_offset=0.0, mesh_scale_z=1.0, water_is_lava=0, disable_water=0,
+                   enable_terrain_env=1, grass_density=0, num_rnd_grass_blocks=16):
+    return Landscape(vegetation, temperature, biome_x_offset, mesh_scale_z, water_is_lava, disable_water, enable_terrain_env, grass_density, num_rnd_grass_blocks)
+
+
+GRASS_BLOCK_DTYPE = np.dtype([("ix", np.uint32), ("zmin", np.float32), ("zmax", np.float32)])
+
+
 def make_config(mesh_gen_mode=0, mesh_gen_shape=0, mesh_seed=1, mesh_freq_filter=0, hmap=None, glaciate=1, mesh_scale=1.0,
                 mesh_height=0.7, custom_glaciate_exp=0.0, erode_amount=1.0, mesh_xy=128, scene=(4.0, 4.0, 4.0)):
     """BASELINE.md section 3 synthetic inputs (scene_config/config.txt:56-97)."""
@@ -127,6 +142,9 @@ class Checker:
         f("set_mesh_height_scales_for_zval_range", None, [C.c_float, C.c_float])
         f("get_clamped_height", C.c_float, [C.c_int, C.c_int])
         f("tile_ao_lighting", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        f("set_landscape", None, [C.POINTER(Landscape)])
+        f("tile_terrain_params", None, [C.c_int, C.c_int, C.c_void_p])
+        f("tile_create_weights", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)])
         f("quantize16", None, [C.c_void_p, C.c_size_t, C.c_void_p, _fp, _fp])
         f("voxel_fill", None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int])
         f("voxel_rdata", None, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p])
@@ -247,6 +265,20 @@ class Checker:
         ao = np.zeros((129, 129), np.uint8)
         self._tile_ao_lighting(tx, ty, zvals.ctypes.data, ao.ctypes.data)
         return ao
+
+    def set_landscape(self, ls): self._set_landscape(C.byref(ls))
+
+    def tile_terrain_params(self, tx, ty):
+        out = np.zeros((2, 2, 3), np.float32)
+        self._tile_terrain_params(tx, ty, out.ctypes.data)
+        return out
+
+    def tile_create_weights(self, tx, ty, zvals):
+        """-> (weights u8[129,129,4], grass blocks [32,32] of GRASS_BLOCK_DTYPE, has_any_grass)"""
+        zvals = np.ascontiguousarray(zvals, np.float32)
+        w = np.zeros((129, 129, 4), np.uint8); gb = np.zeros((32, 32), GRASS_BLOCK_DTYPE); hg = C.c_int(0)
+        self._tile_create_weights(tx, ty, zvals.ctypes.data, w.ctypes.data, gb.ctypes.data, C.byref(hg))
+        return w, gb, bool(hg.value)
 
     def tile_normals(self, zvals):
         rgba = np.zeros((129, 129, 4), np.uint8)

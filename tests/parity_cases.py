@@ -273,6 +273,57 @@ def case_tile_ao(pkg, t, orc):
 SHADOW_LIGHTS = [(0.6, 0.5, 0.4), (-0.8, 0.3, 0.25), (0.2, -0.9, 0.15), (-0.5, -0.5, 0.8), (1.0, 0.0, 0.3), (0.0, -1.0, 0.2), (0.3, 0.4, -5.0), (0.0, 0.0, 1.0), (0.05, 0.9, 0.02)]
 
 
+LANDSCAPE_CASES = (  # (mode, shape, config tweaks, terra_landscape fields, erosion iterations, tiles)
+    (0, 0, {}, dict(grass_density=100), 0, [(tx, ty) for ty in range(-2, 2) for tx in range(-3, 3)]),
+    (0, 0, {}, dict(grass_density=100), 60, [(0, 0), (-3, 2), (7, -5), (40, 41)]),
+    (1, 2, {}, dict(grass_density=100, temperature=55.0), 0, [(0, 0), (-3, 2), (40, 41)]),
+    (4, 0, {}, dict(vegetation=0.0), 0, [(0, 0), (-3, 2), (40, 41)]),
+    (0, 1, dict(water_h_off_rel=0.1, relh_adj_tex=0.03), dict(water_is_lava=1, grass_density=7, num_rnd_grass_blocks=5, biome_x_offset=3.5), 0, [(0, 0), (-3, 2), (7, -5)]),
+    (0, 0, dict(mesh_scale=0.3), dict(grass_density=3, disable_water=2), 0, [(0, 0), (-3, 2), (7, -5), (40, 41)]),
+    (2, 0, {}, dict(enable_terrain_env=0, grass_density=1, mesh_scale_z=1.7), 0, [(0, 0), (-3, 2)]),
+    (3, 0, {}, dict(grass_density=1), 0, [(1, 1)]),
+)
+
+
+def landscape_cfg(pkg, mode, shape, tweaks):
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_scale=tweaks.get("mesh_scale", 1.0))
+    for c in (pc_, oc):
+        c.water_h_off_rel = tweaks.get("water_h_off_rel", 0.0); c.relh_adj_tex = tweaks.get("relh_adj_tex", 0.0)
+    return pc_, oc
+
+
+def case_tile_weights(pkg, t, orc):
+    """row f3: the landscape weights texture of a tile batch (tile_t::create_texture, terrain-only branch): RGBA weights, grass blocks,
+    has_any_grass and the biome parameters, against the oracle (bit-exact) and the vectors generated with the reference build."""
+    G = golden()
+    try:
+        t.init_scene(pkg.make_config(mesh_gen_mode=0))
+        t.set_landscape(pkg.make_landscape(grass_density=100))
+        z, _, _, _ = t.tiles_create_zvals([(-3, 2)], 0)
+        w, gb, hg = t.tiles_create_weights([(-3, 2)], z)
+        assert (w[0] == G["tile_m3_2_weights"]).all() and gb[0].tobytes() == G["tile_m3_2_grass_blocks"].tobytes() and bool(hg[0]) == bool(G["tile_m3_2_has_grass"])
+        assert_bit_equal(t.tiles_terrain_params([(-3, 2), (40, 41)]), G["tile_terrain_params"], "terrain params")
+        for mode, shape, tweaks, lkw, iters, tiles in LANDSCAPE_CASES:
+            pc_, oc = landscape_cfg(pkg, mode, shape, tweaks)
+            t.init_scene(pc_); orc.init(oc)
+            t.set_landscape(pkg.make_landscape(**lkw)); orc.set_landscape(orclib.make_landscape(**lkw))
+            z, _, _, _ = t.tiles_create_zvals(tiles, iters)
+            w, gb, hg = t.tiles_create_weights(tiles, z)
+            prm = t.tiles_terrain_params(tiles)
+            for i, (tx, ty) in enumerate(tiles):
+                zo, _ = orc.tile_create_zvals(tx, ty, iters)
+                assert_bit_equal(z[i], zo, f"zvals mode {mode} tile {tx},{ty}")
+                wo, gbo, hgo = orc.tile_create_weights(tx, ty, zo)
+                assert_bit_equal(prm[i], orc.tile_terrain_params(tx, ty), f"terrain params mode {mode} tile {tx},{ty}")
+                bad = np.argwhere(w[i] != wo)
+                assert len(bad) == 0, (mode, shape, lkw, tx, ty, bad[:4], w[i][tuple(bad[0][:2])], wo[tuple(bad[0][:2])])
+                assert gb[i].tobytes() == gbo.tobytes(), (mode, tx, ty, "grass blocks")
+                assert bool(hg[i]) == hgo
+    finally:
+        t.set_landscape(pkg.make_landscape())
+        orc.set_landscape(orclib.make_landscape())
+
+
 def case_tile_mesh_shadows(pkg, t, orc, lights=SHADOW_LIGHTS):
     """row f2: tile mesh shadows with the edge exchange between neighbouring tiles, against the oracle (itself pinned on the reference's own
     visibility.cpp / Math3d.cpp): full 3x3 blocks, holes, isolated tiles, lights from every quadrant, axis-aligned, below the terrain, straight down."""

@@ -66,6 +66,10 @@ def test_tile_batch_shapes(pkg, gpu, orc):
     pc.case_tile_batch_shapes(pkg, gpu, orc)
 
 
+def test_tile_weights_texture(pkg, gpu, orc):
+    pc.case_tile_weights(pkg, gpu, orc)
+
+
 def test_tile_ao_lighting(pkg, gpu, orc):
     pc.case_tile_ao(pkg, gpu, orc)
 

@@ -86,6 +86,10 @@ def test_tile_batch_shapes(pkg, emul, orc):
     pc.case_tile_batch_shapes(pkg, emul, orc)
 
 
+def test_tile_weights_texture(pkg, emul, orc):
+    pc.case_tile_weights(pkg, emul, orc)
+
+
 def test_tile_ao_lighting(pkg, emul, orc):
     pc.case_tile_ao(pkg, emul, orc)
 

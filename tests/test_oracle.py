@@ -6,6 +6,7 @@ import pytest
 
 import orclib
 from orclib import assert_bit_equal
+import parity_cases as pc
 from parity_cases import golden, VOX
 
 
@@ -135,6 +136,42 @@ def test_oracle_vs_reference_epilogue_configs(orc, ref):
             cfg = orclib.make_config(mesh_gen_mode=0, hmap=hm, **extra)
             sr, so = ref.init(cfg), orc.init(cfg)
             assert_bit_equal(ref.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), orc.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), f"{v} {extra}")
+
+
+def test_oracle_matches_golden_tile_weights(orc):
+    G = pc.golden()
+    orc.init(orclib.make_config(mesh_gen_mode=0))
+    orc.set_landscape(orclib.make_landscape(grass_density=100))
+    try:
+        z, _ = orc.tile_create_zvals(-3, 2, 0)
+        w, gb, hg = orc.tile_create_weights(-3, 2, z)
+        assert (w == G["tile_m3_2_weights"]).all() and gb.tobytes() == G["tile_m3_2_grass_blocks"].tobytes() and hg == bool(G["tile_m3_2_has_grass"])
+        prm = np.stack([orc.tile_terrain_params(-3, 2), orc.tile_terrain_params(40, 41)])
+        assert (prm.view(np.uint32) == G["tile_terrain_params"].view(np.uint32)).all()
+    finally:
+        orc.set_landscape(orclib.make_landscape())
+
+
+def test_oracle_vs_reference_tile_weights(orc, ref):
+    """row f3 against oracle/_ref: the noise field, the biome parameters, the texture height tables and the water level come from the reference's own
+    functions there; the blend itself is the shim's statement-by-statement driver of tile_t::create_texture (tiled_mesh.cpp cannot be built here)."""
+    ref.set_num_threads(1)  # the reference's erosion loop races under OpenMP
+    try:
+        for mode, shape, tweaks, lkw, iters, tiles in pc.LANDSCAPE_CASES:
+            for c in (orc, ref):
+                cfg = orclib.make_config(mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_scale=tweaks.get("mesh_scale", 1.0))
+                cfg.water_h_off_rel = tweaks.get("water_h_off_rel", 0.0); cfg.relh_adj_tex = tweaks.get("relh_adj_tex", 0.0)
+                c.init(cfg); c.set_landscape(orclib.make_landscape(**lkw))
+            for tx, ty in tiles[:6]:
+                za, _ = ref.tile_create_zvals(tx, ty, iters)
+                zb, _ = orc.tile_create_zvals(tx, ty, iters)
+                assert_bit_equal(za, zb, "zvals")
+                a, b = ref.tile_create_weights(tx, ty, za), orc.tile_create_weights(tx, ty, zb)
+                assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes() and a[2] == b[2], (mode, shape, lkw, tx, ty)
+                assert_bit_equal(ref.tile_terrain_params(tx, ty), orc.tile_terrain_params(tx, ty), "terrain params")
+    finally:
+        for c in (orc, ref):
+            c.set_landscape(orclib.make_landscape())
 
 
 def test_oracle_vs_reference_tile_ao(orc, ref):

@@ -52,6 +52,12 @@ t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
 ao = t.alloc(n * 129 * 129)
 ms = timed(lambda: t.tiles_ao_lighting_dev(tiles, zt.ptr, ao.ptr), reps=2)
 out["F1_tile_ao_64x64_sine"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+# row f3: landscape weights texture of the same batch (second noise field + biome parameters + per-texel blend + grass blocks)
+t.set_landscape(pkg.make_landscape(grass_density=100))
+wt = t.alloc(n * 129 * 129 * 4); gbk = t.alloc(n * 32 * 32 * 12); hgr = t.alloc(n)
+ms = timed(lambda: t.tiles_create_weights_dev(tiles, zt.ptr, wt.ptr, gbk.ptr, hgr.ptr), reps=2)
+out["F3_tile_weights_64x64_sine"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3)}
+t.set_landscape(pkg.make_landscape())
 # row f2: mesh shadows of the 64x64 batch for a low sun (127 dependency levels along the anti-diagonals)
 t.init_scene(pkg.make_config(mesh_gen_mode=0))
 t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
@@ -115,6 +121,10 @@ if "--no-cpu" not in sys.argv:
     zs_ = [ck.tile_create_zvals(tx, ty, 0)[0] for ty in range(-2, 2) for tx in range(-2, 2)]
     dt, _ = wall(lambda: [ck.tile_ao_lighting(tx, ty, zs_[(ty + 2) * 4 + (tx + 2)]) for ty in range(-2, 2) for tx in range(-2, 2)])
     cpu["F1_tile_ao_tiles_per_s_4thr"] = round(16 / dt, 1)
+    ck.set_landscape(orclib.make_landscape(grass_density=100))  # create_texture: 2 threads for the noise field, the blend is serial (src/tiled_mesh.cpp:1111,1117)
+    dt, _ = wall(lambda: [ck.tile_create_weights(tx, ty, zs_[(ty + 2) * 4 + (tx + 2)]) for ty in range(-2, 2) for tx in range(-2, 2)])
+    cpu["F3_tile_weights_tiles_per_s_1thr"] = round(16 / dt, 1)
+    ck.set_landscape(orclib.make_landscape())
     tl_ = [(tx, ty) for ty in range(-4, 4) for tx in range(-4, 4)]
     dt, _ = wall(lambda: ck.tiles_mesh_shadows(tl_, np.stack([ck.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tl_]), (0.6, 0.5, 0.4)))
     cpu["F2_tile_mesh_shadows_tiles_per_s_incl_zvals"] = round(len(tl_) / dt, 1)
