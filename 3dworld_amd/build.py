@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libterra_hip.so")
 SOURCES = ["terra_hip.hip"]
-HEADERS = ["terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_png.hpp", "terra_landscape.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
+HEADERS = ["terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_png.hpp", "terra_landscape.hpp", "terra_modmap.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
 # -ffp-contract=off: the reference CPU path has no FMA; parity is bit-exact only without contraction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-result"]

@@ -261,6 +261,54 @@ int terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, flo
 	TERRA_TRY ctx->eng.set_mesh_height_scales_for_zval_range(min_z, dz); TERRA_CATCH
 }
 int terra_set_tiled_mesh_ao(terra_ctx *ctx, int enable) {TERRA_CHECK_CTX ctx->eng.tiled_mesh_ao = (enable != 0); return TERRA_OK;}
+// ---- height edits, the .mod file and the map exporter (rest of row f4)
+static_assert(sizeof(terra_hmap_brush) == sizeof(terra::hmap_brush_pod_t) && sizeof(terra_hmap_mod) == sizeof(terra::hmap_mod_pod_t), "mod record layouts");
+int terra_hmap_apply_brushes_dev(terra_ctx *ctx, const terra_hmap_brush *brushes, uint32_t n, int step_sz, uint32_t num_steps) {
+	TERRA_CHECK_CTX if (n && !brushes) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.hmap_apply_brushes_dev((terra::hmap_brush_pod_t const *)brushes, n, step_sz, num_steps); ctx->eng.be.sync(); TERRA_CATCH
+}
+int terra_hmap_apply_mods_dev(terra_ctx *ctx, const terra_hmap_mod *mods, uint32_t n) {
+	TERRA_CHECK_CTX if (n && !mods) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.hmap_apply_mods_dev((terra::hmap_mod_pod_t const *)mods, n); TERRA_CATCH
+}
+int terra_hmap_read_and_apply_mod_dev(terra_ctx *ctx, const char *path) {
+	TERRA_CHECK_CTX if (!path) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.hmap_read_and_apply_mod_dev(path); ctx->eng.be.sync(); TERRA_CATCH
+}
+int terra_hmap_write_mod(const char *path, const terra_hmap_mod *mods, uint32_t n, const terra_hmap_brush *brushes, uint32_t n_brushes) {
+	if (!path || (n && !mods) || (n_brushes && !brushes)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY terra::write_mod_file(path, (terra::hmap_mod_pod_t const *)mods, n, (terra::hmap_brush_pod_t const *)brushes, n_brushes); TERRA_CATCH
+}
+int terra_hmap_read_mod(const char *path, terra_hmap_mod *mods, uint32_t mods_capacity, uint32_t *n_mods, terra_hmap_brush *brushes, uint32_t brushes_capacity, uint32_t *n_brushes) {
+	if (!path || !n_mods || !n_brushes) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY
+		std::vector<terra::hmap_mod_pod_t> m; std::vector<terra::hmap_brush_pod_t> b;
+		terra::read_mod_file(path, m, b);
+		*n_mods = (uint32_t)m.size(); *n_brushes = (uint32_t)b.size();
+		if (mods) {if (mods_capacity < m.size()) return terra::fail(TERRA_ERR_ARG, "terra_hmap_read_mod: mods buffer too small"); if (!m.empty()) memcpy(mods, m.data(), m.size()*sizeof(terra_hmap_mod));}
+		if (brushes) {if (brushes_capacity < b.size()) return terra::fail(TERRA_ERR_ARG, "terra_hmap_read_mod: brushes buffer too small"); if (!b.empty()) memcpy(brushes, b.data(), b.size()*sizeof(terra_hmap_brush));}
+	TERRA_CATCH
+}
+int terra_export_heightmap_dev(terra_ctx *ctx, float xstart, float ystart, uint32_t width, uint32_t height, float *d_vals, uint8_t *d_pixels16, float *h_min_z_dz) {
+	TERRA_CHECK_CTX if (!d_vals) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY ctx->eng.export_heightmap_dev(xstart, ystart, width, height, d_vals, d_pixels16, h_min_z_dz); ctx->eng.be.sync(); TERRA_CATCH
+}
+int terra_write_map_mode_heightmap_image(terra_ctx *ctx, const char *path, float xstart, float ystart, uint32_t width, uint32_t height) {
+	TERRA_CHECK_CTX if (!path) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		size_t const n = (size_t)width*height;
+		if (n == 0) return terra::fail(TERRA_ERR_ARG, "empty image");
+		uint8_t *d = (uint8_t *)be.alloc(n*6);
+		try {
+			ctx->eng.export_heightmap_dev(xstart, ystart, width, height, (float *)d, d + n*4, nullptr);
+			std::vector<uint8_t> px(n*2);
+			be.d2h(px.data(), d + n*4, n*2);
+			terra::png_write_gray(path, px.data(), width, height, 2);
+		} catch (...) {be.free(d); throw;}
+		be.free(d);
+	TERRA_CATCH
+}
 int terra_set_landscape(terra_ctx *ctx, const terra_landscape *params) {
 	TERRA_CHECK_CTX if (!params) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.set_landscape(*params); TERRA_CATCH

@@ -11,6 +11,7 @@
 #include "terra_noise.hpp"
 #include "terra_erosion.hpp"
 #include "terra_landscape.hpp"
+#include "terra_modmap.hpp"
 #include "../../include/terra.h"
 #include <vector>
 #include <map>
@@ -173,19 +174,23 @@ struct hmap_view_t {
 		y = (ydiv & 1) ? (height - ymod - 1) : ymod;
 	}
 	TERRA_HD float raw_height(int x, int y) const {return scale_val(value((unsigned)x, (unsigned)y));}
-	TERRA_HD float clamped_height(int x, int y) const { // get_clamped_height (src/heightmap.cpp:385-392)
-		if (mesh_scale < 1.0f) { // interpolate_height (:394-402)
-			float const sx = mesh_scale*(float)x, sy = mesh_scale*(float)y;
-			int xlo = (int)floor((double)sx), ylo = (int)floor((double)sy), xhi = (int)ceil((double)sx), yhi = (int)ceil((double)sy);
-			float const xv = sx - (float)xlo, yv = sy - (float)ylo;
-			clamp_no_scale(xlo, ylo); clamp_no_scale(xhi, yhi);
-			return    yv *(xv*raw_height(xhi, yhi) + (1.0f-xv)*raw_height(xlo, yhi)) +
-				(1.0f-yv)*(xv*raw_height(xhi, ylo) + (1.0f-xv)*raw_height(xlo, ylo));
-		}
-		float const fx = mesh_scale*((float)x + 0.0f), fy = mesh_scale*((float)y + 0.0f); // clamp_xy (:310-314), round_fp (src/inlines.h:63)
-		x = (fx > 0.0f) ? f2i_x86(fx + 0.5f) : f2i_x86(fx - 0.5f);
-		y = (fy > 0.0f) ? f2i_x86(fy + 0.5f) : f2i_x86(fy - 0.5f);
+	TERRA_HD float interpolate_height(float x, float y) const { // terrain_hmap_manager_t::interpolate_height (src/heightmap.cpp:394-402), bilinear
+		float const sx = mesh_scale*x, sy = mesh_scale*y;
+		int xlo = (int)floor((double)sx), ylo = (int)floor((double)sy), xhi = (int)ceil((double)sx), yhi = (int)ceil((double)sy);
+		float const xv = sx - (float)xlo, yv = sy - (float)ylo;
+		clamp_no_scale(xlo, ylo); clamp_no_scale(xhi, yhi);
+		return    yv *(xv*raw_height(xhi, yhi) + (1.0f-xv)*raw_height(xlo, yhi)) +
+			(1.0f-yv)*(xv*raw_height(xhi, ylo) + (1.0f-xv)*raw_height(xlo, ylo));
+	}
+	TERRA_HD static int round_fp(float v) {return (v > 0.0f) ? f2i_x86(v + 0.5f) : f2i_x86(v - 0.5f);} // src/inlines.h:63
+	TERRA_HD void clamp_xy(int &x, int &y, float fract_x, float fract_y) const { // src/heightmap.cpp:310-314
+		x = round_fp(mesh_scale*((float)x + fract_x));
+		y = round_fp(mesh_scale*((float)y + fract_y));
 		clamp_no_scale(x, y);
+	}
+	TERRA_HD float clamped_height(int x, int y) const { // get_clamped_height (src/heightmap.cpp:385-392)
+		if (mesh_scale < 1.0f) {return interpolate_height((float)x, (float)y);}
+		clamp_xy(x, y, 0.0f, 0.0f);
 		return raw_height(x, y);
 	}
 };
@@ -981,6 +986,103 @@ template<class BE> struct terra_engine {
 		}
 		float const dz = (float)(0.5*(double)HALF_DXY);
 		be.tile_ao(n, d_zvals, d_ctx, d_ao, dz);
+	}
+
+	// ================================================================ height edits of the heightmap texture and the map exporter (rest of f4)
+	// hmap_brush_t::apply for a list of brushes in order (src/heightmap.cpp:36-58, apply_cur_brushes :438-440) on the image set by terra_hmap_set_dev.
+	// One launch per brush, one thread per brush point (yp, xp, sy, sx); see modify_pixel for why the threads may arrive in any order.
+	void hmap_apply_brushes_dev(hmap_brush_pod_t const *brushes, uint32_t n, int step_sz, uint32_t num_steps) {
+		require_scene();
+		if (!using_hmap()) throw std::logic_error("terra_hmap_apply_brushes_dev: no heightmap texture (terra_hmap_set_dev)");
+		if (step_sz <= 0 || num_steps == 0) throw std::invalid_argument("hmap brush: step_sz and num_steps must be > 0");
+		if (std::max(hmap_w, hmap_h) > 65536) throw std::invalid_argument("hmap brush: image larger than max_tex_ix() = 65536 (src/heightmap.h:42)");
+		hmap_view_t const hv = hmap_view();
+		uint8_t *pix = const_cast<uint8_t *>(hmap_pix);
+		sin_lut_t const L = lut();
+		for (uint32_t bi = 0; bi < n; ++bi) {
+			hmap_brush_pod_t const b = brushes[bi];
+			if (b.shape < 0 || b.shape >= NUM_BSHAPES) throw std::invalid_argument("hmap brush: bad shape");
+			if (b.radius > (1u << 20)) throw std::invalid_argument("hmap brush: radius too large");
+			int const r = (int)b.radius, shape = b.shape, bx = b.x, by = b.y, delta = b.delta, step = step_sz;
+			uint32_t const side = (uint32_t)(2*r)/(uint32_t)step_sz + 1, ns = num_steps;
+			float const step_delta = (float)(1.0/(double)num_steps), r_inv = (float)(1.0/(double)std::max(1u, b.radius));
+			bool const is_delta = !(shape == BSHAPE_FLAT_SQ || shape == BSHAPE_FLAT_CIR);
+			be.launch((size_t)side*side*ns*ns, [=] TERRA_LAMBDA (size_t i) {
+				unsigned const sx = (unsigned)(i % ns), sy = (unsigned)((i / ns) % ns);
+				size_t const c = i / ((size_t)ns*ns);
+				int const xp = bx - r + (int)(c % side)*step, yp = by - r + (int)(c / side)*step;
+				float const dx = (float)sx*step_delta, dy = (float)sy*step_delta;
+				float const ey = ((float)yp + dy) - (float)by, ex = ((float)xp + dx) - (float)bx;
+				float const dist = sqrtf(ey*ey + ex*ex), dval = dist*r_inv;
+				if (shape != BSHAPE_CONST_SQ && shape != BSHAPE_FLAT_SQ && (double)dval > 1.0) return; // round (instead of square)
+				float mod_delta = (float)delta; // adjust_brush_weight (src/heightmap.cpp:27-33)
+				float const PI_F = 3.141592654f;
+				if      (shape == BSHAPE_LINEAR   ) {mod_delta *= 1.0f - dval;}
+				else if (shape == BSHAPE_QUADRATIC) {mod_delta *= 1.0f - dval*dval;}
+				else if (shape == BSHAPE_COSINE   ) {mod_delta *= L.COSF(0.5f*PI_F*dval);}
+				else if (shape == BSHAPE_SINE     ) {mod_delta *= 0.5f*(1.0f + L.SINF(PI_F*dval + 0.5f*PI_F));}
+				int x = xp, y = yp; // modify_height_value (src/tiled_mesh.cpp:259-266)
+				hv.clamp_xy(x, y, dx, dy);
+				modify_pixel(pix, hv.ncolors, (size_t)hv.width*(unsigned)y + (unsigned)x, hmap_view_t::round_fp(mod_delta), is_delta);
+			});
+		}
+	}
+	// add_mod for every element + apply_cur_mod_map (src/heightmap.cpp:216-222,431-436)
+	void hmap_apply_mods_dev(hmap_mod_pod_t const *mods, uint32_t n) {
+		require_scene();
+		if (!using_hmap()) throw std::logic_error("terra_hmap_apply_mods_dev: no heightmap texture (terra_hmap_set_dev)");
+		std::vector<hmap_mod_pod_t> const m = combine_mods(mods, n);
+		for (hmap_mod_pod_t const &e : m) {if ((int)e.x >= hmap_w || (int)e.y >= hmap_h) throw std::invalid_argument("hmap mod outside the texture");}
+		if (m.empty()) return;
+		hmap_mod_pod_t *d_m = scratch<hmap_mod_pod_t>(s_misc, m.size());
+		be.h2d(d_m, m.data(), m.size()*sizeof(hmap_mod_pod_t));
+		uint8_t *pix = const_cast<uint8_t *>(hmap_pix);
+		int const nc = hmap_nc, w = hmap_w;
+		be.launch(m.size(), [=] TERRA_LAMBDA (size_t i) {modify_pixel(pix, nc, (size_t)w*d_m[i].y + d_m[i].x, d_m[i].delta, true);});
+		be.sync();
+	}
+	void hmap_read_and_apply_mod_dev(char const *fn) { // terrain_hmap_manager_t::read_and_apply_mod (src/heightmap.cpp:424-429)
+		std::vector<hmap_mod_pod_t> mods; std::vector<hmap_brush_pod_t> brushes;
+		read_mod_file(fn, mods, brushes);
+		hmap_apply_mods_dev(mods.data(), (uint32_t)mods.size());
+		hmap_apply_brushes_dev(brushes.data(), (uint32_t)brushes.size(), 1, 1);
+	}
+	float get_xy_scale() const {bool const add_detail = using_hmap_with_detail(); if (!add_detail && using_hmap()) return 0.0f; return add_detail ? 16.0f : 1.0f;} // src/tiled_mesh.cpp:447-451
+	// write_map_mode_heightmap_image (src/map_view.cpp:409-442) from the image origin on: heights (rows inverted, as the reference's `heights`) into d_vals,
+	// 16-bit pixels = (h - min_z)*(255/dz) into d_pix; h_range = {min_z, dz}
+	void export_heightmap_dev(float xstart, float ystart, uint32_t width, uint32_t height, float *d_vals, uint8_t *d_pix, float *h_range) {
+		require_scene();
+		if (width == 0 || height == 0) throw std::invalid_argument("export_heightmap: empty image");
+		if (width > 16384 || height > 16384) throw std::invalid_argument("export_heightmap: heightmap image is too large, max size is 16384 pixels"); // src/map_view.cpp:417
+		size_t const n = (size_t)width*height;
+		float const xy_scale = get_xy_scale();
+		if (xy_scale != 0.0f) {gen_grid_dev(xstart/DX_VAL, ystart/DY_VAL, xy_scale*DX_VAL, xy_scale*DY_VAL, width, height, TERRA_GEN_GLACIATE | TERRA_GEN_CACHE_VALUES, 0, d_vals);} // setup_height_gen_cached
+		if (using_hmap()) { // get_mesh_height (src/map_view.cpp:97-105), nearest_texel = 0
+			hmap_view_t const hv = hmap_view();
+			bool const detail = using_hmap_with_detail();
+			float const xs = xstart + cfg.scene_x, ys = ystart + cfg.scene_y, dxv = DX_VAL, dyv = DY_VAL, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
+			be.launch(n, [=] TERRA_LAMBDA (size_t k) {
+				unsigned const i = (unsigned)(k / width), j = (unsigned)(k % width);
+				float zval = hv.interpolate_height((xs + (float)j*dxv)*dxi, (ys + (float)i*dyv)*dyi);
+				if (detail) {zval += 0.01f*d_vals[k];} // HMAP_DETAIL_MAG
+				d_vals[k] = zval;
+			});
+		}
+		be.launch((size_t)(height/2)*width, [=] TERRA_LAMBDA (size_t k) { // invert yval
+			size_t const i = k / width, j = k % width, a = i*width + j, b = (size_t)(height - 1 - i)*width + j;
+			float const t = d_vals[a]; d_vals[a] = d_vals[b]; d_vals[b] = t;
+		});
+		float mn, mx; minmax_dev(d_vals, n, mn, mx); // get_heightmap_z_range
+		float const dz = max_std(1.0E-12f, (mx - mn)), height_scale = (float)(255.0/(double)dz);
+		if (h_range) {h_range[0] = mn; h_range[1] = dz;}
+		if (d_pix) {
+			be.launch(n, [=] TERRA_LAMBDA (size_t i) { // write_pixel_16_bits (src/Textures.cpp:1889-1893)
+				float const v = (d_vals[i] - mn)*height_scale;
+				uint8_t const hi = (uint8_t)v;
+				d_pix[(i<<1)+1] = hi;
+				d_pix[i<<1]     = (uint8_t)(256.0f*(v - (float)hi));
+			});
+		}
 	}
 
 	// ================================================================ landscape weights texture (f3)

@@ -50,6 +50,8 @@ def make_landscape(vegetation=1.0, temperature=20.0, biome_x_offset=0.0, mesh_sc
     return Landscape(vegetation, temperature, biome_x_offset, mesh_scale_z, water_is_lava, disable_water, enable_terrain_env, grass_density, num_rnd_grass_blocks)
 
 
+BRUSH_DTYPE = np.dtype({"names": ["x", "y", "radius", "delta", "shape"], "formats": [np.int32, np.int32, np.uint32, np.int32, np.int16], "itemsize": 20})  # terra_hmap_brush
+MOD_DTYPE = np.dtype([("x", np.uint16), ("y", np.uint16), ("delta", np.int32)])  # terra_hmap_mod
 GRASS_BLOCK_DTYPE = np.dtype([("ix", np.uint32), ("zmin", np.float32), ("zmax", np.float32)])  # terra_grass_block
 
 
@@ -131,6 +133,13 @@ _PROTOS = {
     "terra_tiles_mesh_shadows_halo_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
     "terra_hmap_set_dev": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "terra_set_mesh_height_scales_for_zval_range": (_i32, [_vp, _f, _f]),
+    "terra_hmap_apply_brushes_dev": (_i32, [_vp, _vp, _u32, _i32, _u32]),
+    "terra_hmap_apply_mods_dev": (_i32, [_vp, _vp, _u32]),
+    "terra_hmap_read_and_apply_mod_dev": (_i32, [_vp, C.c_char_p]),
+    "terra_hmap_write_mod": (_i32, [C.c_char_p, _vp, _u32, _vp, _u32]),
+    "terra_hmap_read_mod": (_i32, [C.c_char_p, _vp, _u32, _vp, _vp, _u32, _vp]),
+    "terra_export_heightmap_dev": (_i32, [_vp, _f, _f, _u32, _u32, _vp, _vp, _vp]),
+    "terra_write_map_mode_heightmap_image": (_i32, [_vp, C.c_char_p, _f, _f, _u32, _u32]),
     "terra_set_landscape": (_i32, [_vp, _vp]),
     "terra_get_landscape": (_i32, [_vp, _vp]),
     "terra_tiles_terrain_params": (_i32, [_vp, _vp, _u32, _vp]),
@@ -330,6 +339,36 @@ class Terra:
 
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))
+
+    def hmap_apply_brushes_dev(self, brushes, step_sz=1, num_steps=1):
+        b = np.ascontiguousarray(brushes, BRUSH_DTYPE).reshape(-1)
+        self._ck(self.lib.terra_hmap_apply_brushes_dev(self.ctx, b.ctypes.data, len(b), step_sz, num_steps))
+
+    def hmap_apply_mods_dev(self, mods):
+        m = np.ascontiguousarray(mods, MOD_DTYPE).reshape(-1)
+        self._ck(self.lib.terra_hmap_apply_mods_dev(self.ctx, m.ctypes.data, len(m)))
+
+    def hmap_read_and_apply_mod_dev(self, path):
+        self._ck(self.lib.terra_hmap_read_and_apply_mod_dev(self.ctx, str(path).encode()))
+
+    def hmap_write_mod(self, path, mods, brushes):
+        m = np.ascontiguousarray(mods, MOD_DTYPE).reshape(-1); b = np.ascontiguousarray(brushes, BRUSH_DTYPE).reshape(-1)
+        self._ck(self.lib.terra_hmap_write_mod(str(path).encode(), m.ctypes.data, len(m), b.ctypes.data, len(b)))
+
+    def hmap_read_mod(self, path):
+        n, nb = _u32(), _u32()
+        self._ck(self.lib.terra_hmap_read_mod(str(path).encode(), None, 0, C.byref(n), None, 0, C.byref(nb)))
+        m = np.zeros(n.value, MOD_DTYPE); b = np.zeros(nb.value, BRUSH_DTYPE)
+        self._ck(self.lib.terra_hmap_read_mod(str(path).encode(), m.ctypes.data, len(m), C.byref(n), b.ctypes.data, len(b), C.byref(nb)))
+        return m, b
+
+    def export_heightmap_dev(self, xstart, ystart, width, height, vals_ptr, pix_ptr=None):
+        r = (C.c_float * 2)()
+        self._ck(self.lib.terra_export_heightmap_dev(self.ctx, xstart, ystart, width, height, vals_ptr, pix_ptr, r))
+        return r[0], r[1]
+
+    def write_map_mode_heightmap_image(self, path, xstart, ystart, width, height):
+        self._ck(self.lib.terra_write_map_mode_heightmap_image(self.ctx, str(path).encode(), xstart, ystart, width, height))
 
     def set_landscape(self, ls):
         self._ck(self.lib.terra_set_landscape(self.ctx, C.byref(ls)))

@@ -195,6 +195,28 @@ int  terra_heightmap_read_png(const char *path, int allow_two_byte_grayscale, ui
 int  terra_hmap_set_dev(terra_ctx *ctx, const uint8_t *d_pixels, int width, int height, int ncolors);
 int  terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, float dz);
 
+/* ---- height edits of the heightmap texture (tex_mod_map_manager_t / terrain_hmap_manager_t, src/heightmap.h:38-142, src/heightmap.cpp:27-58,99-115,216-308,
+ * 414-440): brushes, the per-texel mod map and the .mod file that stores both.  The records have the reference's in-memory = on-disk layouts.
+ * The *_dev calls edit the image registered with terra_hmap_set_dev in place (it must be writable device memory, at most 65536 texels per side); a brush
+ * point (xp, yp, sub-step) lands on texel clamp_xy(xp + dx, yp + dy) (mesh_scale, mirror wrap) and adds round_fp(delta * weight(shape, dist / radius)) with
+ * clamping to the pixel range, flatten brushes store delta.  Brushes are applied in list order (apply_cur_brushes); within one brush the reference's
+ * OpenMP loop order is immaterial (same-signed saturating adds commute) and so is the thread order here. */
+enum {TERRA_BSHAPE_CONST_SQ = 0, TERRA_BSHAPE_CNST_CIR, TERRA_BSHAPE_LINEAR, TERRA_BSHAPE_QUADRATIC, TERRA_BSHAPE_COSINE, TERRA_BSHAPE_SINE, TERRA_BSHAPE_FLAT_SQ, TERRA_BSHAPE_FLAT_CIR, TERRA_NUM_BSHAPES};
+typedef struct terra_hmap_brush {int32_t x, y; uint32_t radius; int32_t delta; int16_t shape;} terra_hmap_brush; /* hmap_brush_t, src/heightmap.h:71-76 (20 bytes) */
+typedef struct terra_hmap_mod {uint16_t x, y; int32_t delta;} terra_hmap_mod;                                    /* mod_elem_t, src/heightmap.h:59-64 (8 bytes) */
+int  terra_hmap_apply_brushes_dev(terra_ctx *ctx, const terra_hmap_brush *brushes, uint32_t n, int step_sz, uint32_t num_steps); /* apply_brush(brush, step_sz, num_steps) for each */
+int  terra_hmap_apply_mods_dev(terra_ctx *ctx, const terra_hmap_mod *mods, uint32_t n);      /* add_mod for each (deltas of one texel are summed) + apply_cur_mod_map */
+int  terra_hmap_read_and_apply_mod_dev(terra_ctx *ctx, const char *path);                   /* read_and_apply_mod: mods, then brushes with step_sz = num_steps = 1 */
+int  terra_hmap_write_mod(const char *path, const terra_hmap_mod *mods, uint32_t n, const terra_hmap_brush *brushes, uint32_t n_brushes); /* write_mod */
+/* read_mod: counts always; records when the buffers are non-NULL and large enough (capacities in records).  Mods come back combined, in map order. */
+int  terra_hmap_read_mod(const char *path, terra_hmap_mod *mods, uint32_t mods_capacity, uint32_t *n_mods, terra_hmap_brush *brushes, uint32_t brushes_capacity, uint32_t *n_brushes);
+/* ---- the map-view heightmap exporter write_map_mode_heightmap_image (src/map_view.cpp:409-442) from the image origin on: width x height cells starting at
+ * scene position (xstart, ystart) with the mesh spacing, rows inverted, 16-bit pixels = (h - min_z) * (255 / dz).  d_vals: width*height floats (the
+ * reference's `heights`), d_pixels16: 2 bytes per pixel or NULL, h_min_z_dz: {min_z, dz} or NULL.  With a heightmap texture set the heights are sampled
+ * from it (get_mesh_height, src/map_view.cpp:97-105).  terra_write_map_mode_heightmap_image = the same + the PNG file. */
+int  terra_export_heightmap_dev(terra_ctx *ctx, float xstart, float ystart, uint32_t width, uint32_t height, float *d_vals, uint8_t *d_pixels16, float *h_min_z_dz);
+int  terra_write_map_mode_heightmap_image(terra_ctx *ctx, const char *path, float xstart, float ystart, uint32_t width, uint32_t height);
+
 /* ---- tile ambient-occlusion lighting: tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661).  zvals: [n][130][130] exactly as
  * terra_tiles_create_zvals left them (eroded or not); ao: [n][129][129] bytes = (unsigned char)(255*(1 - atten/64)).  The 201 x 201 context
  * around each tile is generated internally (setup_height_gen_async(x1 - 36, y1 - 36, 201, 201)).

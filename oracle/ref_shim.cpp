@@ -29,6 +29,7 @@
 #include "sinf.h"
 #include <glm/gtc/noise.hpp>
 #include <omp.h>
+#include <cfloat>
 
 #define REF_API extern "C" __attribute__((visibility("default")))
 
@@ -82,8 +83,30 @@ bool shader_t::add_uniform_float(char const *const, float) const {return 0;}
 void texture_t::load(int, bool, bool, bool) {ref_unreachable("texture_t::load");}
 void texture_t::resize(int, int) {ref_unreachable("texture_t::resize");}
 void texture_t::gl_delete() {}
-void texture_t::free_client_mem() {}
-float heightmap_t::get_heightmap_value(unsigned, unsigned) const {ref_unreachable("get_heightmap_value"); return 0;}
+// texture_t client-memory management and 16-bit pixel writer, needed by the reference's heightmap.cpp (src/Textures.cpp:486-490,512-517,1889-1893; src/image_io.cpp:493-496)
+void texture_t::alloc() {free_data(); data = new unsigned char[num_bytes()];}
+void texture_t::free_client_mem() {
+	if (orig_data    != data) {delete [] orig_data;}
+	if (colored_data != data) {delete [] colored_data;}
+	delete [] data;
+	data = orig_data = colored_data = NULL;
+}
+void texture_t::set_16_bit_grayscale() {ncolors = 2; is_16_bit_gray = 1;}
+void texture_t::write_pixel_16_bits(unsigned ix, float val) {
+	unsigned char const high_bits(val); // high bits - truncate
+	data[(ix<<1)+1] = high_bits;
+	data[ix<<1]     = (unsigned char)(256.0f*(val - float(high_bits))); // low bits - remainder
+}
+int texture_t::write_to_png(string const &) const {ref_unreachable("texture_t::write_to_png"); return 0;}
+// city generation and the heightmap output file name are outside the path
+bool have_cities() {return 0;}
+void gen_cities(float *, unsigned, unsigned) {}
+string hmap_out_fn;
+unsigned hmap_filter_width(0);
+void get_heightmap_z_range(vector<float> const &heights, float &min_z, float &max_z) { // src/map_view.cpp:399-407 (GL-bound file)
+	min_z = FLT_MAX; max_z = -FLT_MAX;
+	for (unsigned i = 0; i < heights.size(); ++i) {min_eq(min_z, heights[i]); max_eq(max_z, heights[i]);}
+}
 void free_texture(unsigned &tid) {tid = 0;}
 void checked_fclose(FILE *fp) {if (fp) fclose(fp);}
 bool open_file(FILE *&fp, char const *const fn, string const &, char const *const mode) {fp = fopen(fn, mode); return (fp != nullptr);}
@@ -258,48 +281,94 @@ REF_API void ref_rand_uniforms(long s1, long s2, float a, float b, int n, float 
 // tile_t::create_zvals driver (src/tiled_mesh.cpp:467-546) for tile (tx,ty), size=128: zvals[130*130], sub_zmin/zmax[4][4], water bbox
 struct ref_tile_stats_t {float sub_zmin[16], sub_zmax[16], mzmin, mzmax, radius; int wx1, wy1, wx2, wy2;};
 
-// ---- tiles from a heightmap texture: terrain_hmap_manager_t's sampling (src/heightmap.cpp:60-84,310-407) restated over a raw 1- or 2-byte image
-// (heightmap.cpp itself needs the texture / image-IO stack); the value scaling is the reference's own scale_mh_texture_val /
-// set_mesh_height_scales_for_zval_range from mesh_gen.cpp (src/mesh_gen.cpp:120-131)
+// ---- tiles from a heightmap texture: the reference's own terrain_hmap_manager_t / heightmap_t (src/heightmap.cpp, compiled in place) over an image the
+// harness copies in; modify_height_value is the override of tiled_terrain_hmap_manager_t (src/tiled_mesh.cpp:259-266, a GL-bound file) minus its tile bookkeeping
 float scale_mh_texture_val(float val);
 void set_mesh_height_scales_for_zval_range(float min_z, float dz);
-static unsigned char const *shim_hm_data(nullptr);
-static int shim_hm_width(0), shim_hm_height(0), shim_hm_ncolors(0);
-float const SHIM_HMAP_DETAIL_SCALE = 16.0, SHIM_HMAP_DETAIL_MAG = 0.01; // src/heightmap.h:8-9
-REF_API void ref_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {shim_hm_data = pixels; shim_hm_width = width; shim_hm_height = height; shim_hm_ncolors = ncolors;}
+float const SHIM_HMAP_DETAIL_SCALE = HMAP_DETAIL_SCALE, SHIM_HMAP_DETAIL_MAG = HMAP_DETAIL_MAG; // src/heightmap.h:8-9
+struct shim_hmap_manager_t : public terrain_hmap_manager_t {
+	void set_image(unsigned char const *pixels, int width, int height, int ncolors) {
+		hmap.free_data();
+		if (pixels == nullptr) return;
+		hmap = heightmap_t(0, ((ncolors == 2) ? 8 : 7), width, height, "@harness", 0);
+		hmap.ncolors = 1;
+		if (ncolors == 2) {hmap.set_16_bit_grayscale();}
+		hmap.alloc();
+		memcpy(hmap.get_data(), pixels, hmap.num_bytes());
+	}
+	void get_image(unsigned char *out) const {memcpy(out, hmap.get_data(), hmap.num_bytes());}
+	heightmap_t &image() {return hmap;}
+	virtual bool modify_height_value(int x, int y, hmap_val_t val, bool is_delta, float fract_x, float fract_y, bool allow_wrap=1) {
+		int clamped_x(x), clamped_y(y);
+		if (!clamp_xy(clamped_x, clamped_y, fract_x, fract_y, allow_wrap)) return 0;
+		assert(clamped_x >= 0 && clamped_y >= 0);
+		modify_height(tex_mod_map_manager_t::mod_elem_t(clamped_x, clamped_y, val), is_delta);
+		return 1;
+	}
+	void clear_mods() {mod_map.clear(); brush_vect.clear();}
+	unsigned num_mods() const {return mod_map.size();}
+	unsigned num_brushes() const {return brush_vect.size();}
+	void get_mods(mod_elem_t *mods, hmap_brush_t *brushes) const {
+		unsigned n(0);
+		for (tex_mod_map_t::const_iterator i = mod_map.begin(); i != mod_map.end(); ++i) {mods[n++] = mod_elem_t(*i);}
+		for (unsigned i = 0; i < brush_vect.size(); ++i) {brushes[i] = brush_vect[i];}
+	}
+};
+static shim_hmap_manager_t shim_hmap;
+REF_API void ref_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {shim_hmap.set_image(pixels, width, height, ncolors);}
+REF_API void ref_hmap_get(unsigned char *out) {shim_hmap.get_image(out);}
 REF_API void ref_set_mesh_height_scales_for_zval_range(float min_z, float dz) {set_mesh_height_scales_for_zval_range(min_z, dz);}
-static float shim_get_heightmap_value(unsigned x, unsigned y) { // src/heightmap.cpp:75-80, hmap_filter_width = 0
-	unsigned const ix(shim_hm_width*y + x);
-	if (shim_hm_ncolors == 2) {return (shim_hm_data[ix<<1]/256.0 + shim_hm_data[(ix<<1)+1]);}
-	return shim_hm_data[ix];
+REF_API float ref_get_clamped_height(int x, int y) {return shim_hmap.get_clamped_height(x, y);}
+REF_API float ref_hmap_interpolate_height(float x, float y) {return shim_hmap.interpolate_height(x, y);}
+REF_API float ref_hmap_get_nearest_height(float x, float y) {return shim_hmap.get_nearest_height(x, y);}
+// rest of row f4: brushes, the mod map and its file (src/heightmap.cpp:36-58,216-308,414-440).  hmap_brush_t::apply's "omp parallel for" races on texels several
+// brush points map to; the order-free result (same-sign saturating adds commute) is what one thread produces
+struct ref_hmap_brush_t {int x, y; unsigned radius; int delta; short shape;};
+struct ref_hmap_mod_t {unsigned short x, y; int delta;};
+REF_API void ref_hmap_apply_brush(ref_hmap_brush_t const *b, int step_sz, unsigned num_steps) {
+	int const nt(omp_get_max_threads());
+	omp_set_num_threads(1);
+	shim_hmap.apply_brush(tex_mod_map_manager_t::hmap_brush_t(b->x, b->y, b->delta, b->radius, b->shape), step_sz, num_steps);
+	omp_set_num_threads(nt);
 }
-static bool shim_clamp_no_scale(int &x, int &y) { // src/heightmap.cpp:316-343 with TEX_EDGE_MODE = 2, allow_wrap = 1
-	x += shim_hm_width /2;
-	y += shim_hm_height/2;
-	if (x >= 0 && y >= 0 && x < shim_hm_width && y < shim_hm_height) return 1;
-	int const xmod(abs(x)%shim_hm_width), ymod(abs(y)%shim_hm_height), xdiv(x/shim_hm_width), ydiv(y/shim_hm_height);
-	x = ((xdiv & 1) ? (shim_hm_width  - xmod - 1) : xmod);
-	y = ((ydiv & 1) ? (shim_hm_height - ymod - 1) : ymod);
+REF_API void ref_hmap_apply_mods(ref_hmap_mod_t const *mods, unsigned n) { // add_mod (combine per texel) + apply_cur_mod_map
+	shim_hmap.clear_mods();
+	for (unsigned i = 0; i < n; ++i) {shim_hmap.add_mod(tex_mod_map_manager_t::mod_elem_t(mods[i].x, mods[i].y, mods[i].delta));}
+	shim_hmap.apply_cur_mod_map();
+}
+REF_API int ref_hmap_write_mod(char const *fn, ref_hmap_mod_t const *mods, unsigned n, ref_hmap_brush_t const *brushes, unsigned nb) {
+	static_assert(sizeof(ref_hmap_brush_t) == sizeof(tex_mod_map_manager_t::hmap_brush_t) && sizeof(ref_hmap_mod_t) == sizeof(tex_mod_map_manager_t::mod_elem_t), "layout");
+	shim_hmap.clear_mods();
+	for (unsigned i = 0; i < n; ++i) {shim_hmap.add_mod(tex_mod_map_manager_t::mod_elem_t(mods[i].x, mods[i].y, mods[i].delta));}
+	for (unsigned i = 0; i < nb; ++i) {shim_hmap.add_brush(tex_mod_map_manager_t::hmap_brush_t(brushes[i].x, brushes[i].y, brushes[i].delta, brushes[i].radius, brushes[i].shape));}
+	return shim_hmap.write_mod(fn);
+}
+REF_API int ref_hmap_read_mod(char const *fn, ref_hmap_mod_t *mods, unsigned *n, ref_hmap_brush_t *brushes, unsigned *nb) { // mods / brushes null: counts only
+	if (!shim_hmap.read_mod(fn)) return 0;
+	*n = shim_hmap.num_mods(); *nb = shim_hmap.num_brushes();
+	if (mods && brushes) {shim_hmap.get_mods((tex_mod_map_manager_t::mod_elem_t *)mods, (tex_mod_map_manager_t::hmap_brush_t *)brushes);}
 	return 1;
 }
-static float shim_get_raw_height(int x, int y) {return scale_mh_texture_val(shim_get_heightmap_value(x, y));}
-static float shim_interpolate_height(float x, float y) { // src/heightmap.cpp:394-402
-	float const sx(mesh_scale*x), sy(mesh_scale*y);
-	int xlo(floor(sx)), ylo(floor(sy)), xhi(ceil(sx)), yhi(ceil(sy));
-	float const xv(sx - xlo), yv(sy - ylo);
-	if (!shim_clamp_no_scale(xlo, ylo) || !shim_clamp_no_scale(xhi, yhi)) {return scale_mh_texture_val(0.0);}
-	return    yv *(xv*shim_get_raw_height(xhi, yhi) + (1.0f-xv)*shim_get_raw_height(xlo, yhi)) +
-		(1.0f-yv)*(xv*shim_get_raw_height(xhi, ylo) + (1.0f-xv)*shim_get_raw_height(xlo, ylo));
+REF_API int ref_hmap_read_and_apply_mod(char const *fn) {
+	int const nt(omp_get_max_threads());
+	omp_set_num_threads(1);
+	int const ret(shim_hmap.read_and_apply_mod(fn));
+	omp_set_num_threads(nt);
+	return ret;
 }
-static int shim_round_fp(float val) {return ((val > 0.0f) ? int(val + 0.5f) : int(val - 0.5f));} // src/inlines.h:63
-REF_API float ref_get_clamped_height(int x, int y) { // src/heightmap.cpp:385-392, clamp_xy :310-314
-	if (mesh_scale < 1.0) {return shim_interpolate_height(float(x), float(y));}
-	x = shim_round_fp(mesh_scale*(x + 0.0f));
-	y = shim_round_fp(mesh_scale*(y + 0.0f));
-	if (!shim_clamp_no_scale(x, y)) {return scale_mh_texture_val(0.0);}
-	return shim_get_raw_height(x, y);
+// heightmap_t::proc_gen itself (src/heightmap.cpp:130-151): width x height 16-bit map with erosion_iters_tt droplets; returns the pixels and mesh_file_scale / tz
+extern float mesh_file_scale, mesh_file_tz;
+REF_API void ref_heightmap_proc_gen(int width, int height, unsigned iters, unsigned char *pixels, float *file_scale_tz) {
+	unsigned const prev(erosion_iters_tt);
+	erosion_iters_tt = iters;
+	heightmap_t hm(0, 8, width, height, "@tt_heightmap", 0);
+	hm.proc_gen();
+	memcpy(pixels, hm.get_data(), hm.num_bytes());
+	hm.free_data();
+	file_scale_tz[0] = mesh_file_scale; file_scale_tz[1] = mesh_file_tz;
+	erosion_iters_tt = prev;
 }
-static bool shim_using_hmap() {return (shim_hm_data != nullptr);}                             // using_tiled_terrain_hmap_tex (src/tiled_mesh.cpp:273)
+static bool shim_using_hmap() {return shim_hmap.enabled();}                             // using_tiled_terrain_hmap_tex (src/tiled_mesh.cpp:273)
 static bool shim_using_hmap_with_detail() {return (shim_using_hmap() && mesh_scale < 0.75);} // src/tiled_mesh.cpp:274
 static float shim_get_xy_scale() { // src/tiled_mesh.cpp:447-451
 	bool const add_detail(shim_using_hmap_with_detail());
@@ -679,6 +748,43 @@ REF_API void ref_quantize16(float const *vals, size_t n, unsigned char *out, flo
 		out[i<<1]     = (unsigned char)(256.0f*(v - float(high_bits)));
 	}
 	*min_z_out = min_z; *dz_out = dz;
+}
+
+// write_map_mode_heightmap_image (src/map_view.cpp:409-442, a GL-bound file) from the image origin on: driver over the reference's build_arrays /
+// eval_index / terrain_hmap_manager_t::interpolate_height / get_heightmap_z_range / write_pixel_16_bits; setup_height_gen_cached = src/tiled_mesh.cpp:452-457,
+// get_mesh_height = src/map_view.cpp:97-105.  pixels: 2 bytes per pixel; min_z_dz = {min_z, dz}
+REF_API void ref_export_heightmap(float xstart, float ystart, int width, int height, unsigned char *pixels, float *min_z_dz) {
+	texture_t texture(0, 6, width, height, 0, 2, 0, "heightmap.png"); // two bytes per pixel grayscale
+	texture.set_16_bit_grayscale();
+	texture.alloc();
+	vector<float> heights(texture.num_pixels());
+	mesh_xy_grid_cache_t height_gen;
+	float const xy_scale(shim_get_xy_scale());
+	if (xy_scale != 0.0) {
+		height_gen.build_arrays(xstart/DX_VAL, ystart/DY_VAL, xy_scale*DX_VAL, xy_scale*DY_VAL, width, height, 1); // cache_values=1
+		height_gen.enable_glaciate();
+	}
+	float const xscale(DX_VAL), yscale(DY_VAL);
+#pragma omp parallel for schedule(static,1)
+	for (int i = 0; i < height; ++i) {
+		int const off(width*(height - i - 1)); // invert yval
+		for (int j = 0; j < width; ++j) {
+			float zval;
+			if (shim_using_hmap()) {
+				zval = shim_hmap.interpolate_height((xstart + X_SCENE_SIZE + j*xscale)*DX_VAL_INV, (ystart + Y_SCENE_SIZE + i*yscale)*DY_VAL_INV);
+				if (shim_using_hmap_with_detail()) {zval += HMAP_DETAIL_MAG*height_gen.eval_index(j, i);}
+			}
+			else {zval = height_gen.eval_index(j, i);}
+			heights[off + j] = zval;
+		}
+	}
+	float min_z(0), max_z(0);
+	get_heightmap_z_range(heights, min_z, max_z);
+	float const dz(max(TOLERANCE, (max_z - min_z))), height_scale(255.0/dz); // prevent divide-by-zero
+	for (unsigned i = 0; i < heights.size(); ++i) {texture.write_pixel_16_bits(i, (heights[i] - min_z)*height_scale);}
+	memcpy(pixels, texture.get_data(), texture.num_bytes());
+	texture.free_data();
+	min_z_dz[0] = min_z; min_z_dz[1] = dz;
 }
 
 // voxel_manager::create_procedural fill loop (src/voxels.cpp:278-345) around the real noise_gen_3d (src/upsurface.cpp:16-70).

@@ -786,13 +786,17 @@ void  orc_rand_floats(long s1, long s2, int n, float *out) {rgen_t r; rgen_set_s
 void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out) {rgen_t r; rgen_set_state(&r, s1, s2); for (int i = 0; i < n; ++i) {out[i] = rgen_rand_uniform(&r, a, b);}}
 
 /* ---- tiles from a heightmap texture: terrain_hmap_manager_t (src/heightmap.h:110-142, src/heightmap.cpp:60-84,310-407) over a 1- or 2-byte
- * grayscale image, scaled by scale_mh_texture_val (src/mesh_gen.cpp:120-131).  The image is kept by pointer (the caller owns it). */
-static unsigned char const *hm_data = NULL;
+ * grayscale image, scaled by scale_mh_texture_val (src/mesh_gen.cpp:120-131).  The oracle keeps its own copy (brushes and mods edit it). */
+static unsigned char *hm_data = NULL;
 static int hm_width = 0, hm_height = 0, hm_ncolors = 0;
 static float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;
 #define HMAP_DETAIL_SCALE 16.0f /* src/heightmap.h:8-9 */
 #define HMAP_DETAIL_MAG   0.01f
-void orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {hm_data = pixels; hm_width = width; hm_height = height; hm_ncolors = ncolors;}
+void orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {
+	free(hm_data); hm_data = NULL; hm_width = width; hm_height = height; hm_ncolors = ncolors;
+	if (pixels) {size_t const nb = (size_t)width*height*ncolors; hm_data = (unsigned char *)malloc(nb); memcpy(hm_data, pixels, nb);}
+}
+void orc_hmap_get(unsigned char *out) {memcpy(out, hm_data, (size_t)hm_width*hm_height*hm_ncolors);}
 void orc_set_mesh_height_scales_for_zval_range(float min_z, float dz) { /* src/mesh_gen.cpp:125-131 */
 	float const READ_MESH_H_SCALE = 0.0008f;
 	mesh_file_scale = dz/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv);
@@ -827,6 +831,124 @@ float orc_get_clamped_height(int x, int y) { /* src/heightmap.cpp:385-392 */
 	x = round_fp_f(mesh_scale*((float)x + 0.0f)); y = round_fp_f(mesh_scale*((float)y + 0.0f)); /* clamp_xy, src/heightmap.cpp:310-314 */
 	if (!hm_clamp_no_scale(&x, &y)) {return scale_mh_texture_val(0.0f);}
 	return hm_get_raw_height(x, y);
+}
+float orc_hmap_interpolate_height(float x, float y) {return hm_interpolate_height(x, y);}
+float orc_hmap_get_nearest_height(float x, float y) { /* src/heightmap.cpp:404-407 */
+	int xv = round_fp_f(mesh_scale*x), yv = round_fp_f(mesh_scale*y);
+	return hm_clamp_no_scale(&xv, &yv) ? hm_get_raw_height(xv, yv) : scale_mh_texture_val(0.0f);
+}
+/* ---- rest of row f4: height brushes, the mod map and its file (src/heightmap.cpp:27-58,99-115,216-308,414-440; src/tiled_mesh.cpp:259-266) */
+enum {BSHAPE_CONST_SQ = 0, BSHAPE_CNST_CIR, BSHAPE_LINEAR, BSHAPE_QUADRATIC, BSHAPE_COSINE, BSHAPE_SINE, BSHAPE_FLAT_SQ, BSHAPE_FLAT_CIR, NUM_BSHAPES}; /* src/heightmap.h:11 */
+#define PI_F 3.141592654f /* src/3DWorld.h:43 */
+static void modify_heightmap_value(unsigned x, unsigned y, int val, int val_is_delta) { /* src/heightmap.cpp:99-115 */
+	unsigned const ix = (unsigned)hm_width*y + x;
+	if (hm_ncolors == 1) {
+		if (val_is_delta) {val += hm_data[ix];}
+		hm_data[ix] = (unsigned char)imax(0, imin(255, val));
+	}
+	else {
+		unsigned short *ptr = (unsigned short *)(hm_data + ((size_t)ix<<1));
+		if (val_is_delta) {val += *ptr;}
+		*ptr = (unsigned short)imax(0, imin(65535, val));
+	}
+}
+static int modify_height_value(int x, int y, int val, int is_delta, float fract_x, float fract_y) { /* src/tiled_mesh.cpp:259-266, clamp_xy src/heightmap.cpp:310-314 */
+	x = round_fp_f(mesh_scale*((float)x + fract_x));
+	y = round_fp_f(mesh_scale*((float)y + fract_y));
+	if (!hm_clamp_no_scale(&x, &y)) return 0;
+	modify_heightmap_value((unsigned short)x, (unsigned short)y, val, is_delta); /* mod_elem_t holds 16-bit coordinates */
+	return 1;
+}
+static void adjust_brush_weight(float *delta, float dval, int shape) { /* src/heightmap.cpp:27-33 */
+	if      (shape == BSHAPE_LINEAR   ) {*delta *= 1.0f - dval;}
+	else if (shape == BSHAPE_QUADRATIC) {*delta *= 1.0f - dval*dval;}
+	else if (shape == BSHAPE_COSINE   ) {*delta *= COSF(0.5f*PI_F*dval);}
+	else if (shape == BSHAPE_SINE     ) {*delta *= 0.5f*(1.0f + SINF(PI_F*dval + 0.5f*PI_F));}
+}
+void orc_hmap_apply_brush(orc_hmap_brush_t const *b, int step_sz, unsigned num_steps) { /* hmap_brush_t::apply, src/heightmap.cpp:36-58, one thread */
+	float const step_delta = (float)(1.0/(double)num_steps), r_inv = (float)(1.0/(double)(b->radius > 1u ? b->radius : 1u));
+	int const is_delta = !(b->shape == BSHAPE_FLAT_SQ || b->shape == BSHAPE_FLAT_CIR);
+	int const x = b->x, y = b->y, radius = (int)b->radius, shape = b->shape;
+	for (int yp = y - radius; yp <= y + radius; yp += step_sz) {
+		for (int xp = x - radius; xp <= x + radius; xp += step_sz) {
+			for (unsigned sy = 0; sy < num_steps; ++sy) {
+				for (unsigned sx = 0; sx < num_steps; ++sx) {
+					float const dx = (float)sx*step_delta, dy = (float)sy*step_delta;
+					float const ey = ((float)yp + dy) - (float)y, ex = ((float)xp + dx) - (float)x;
+					float const dist = sqrtf(ey*ey + ex*ex), dval = dist*r_inv;
+					if (shape != BSHAPE_CONST_SQ && shape != BSHAPE_FLAT_SQ && (double)dval > 1.0) continue; /* round (instead of square) */
+					float mod_delta = (float)b->delta;
+					adjust_brush_weight(&mod_delta, dval, shape);
+					modify_height_value(xp, yp, round_fp_f(mod_delta), is_delta, dx, dy);
+				}
+			}
+		}
+	}
+}
+static int mod_cmp(void const *a, void const *b) { /* tex_xy_t::operator<: x first, then y (src/heightmap.h:49) */
+	orc_hmap_mod_t const *p = (orc_hmap_mod_t const *)a, *q = (orc_hmap_mod_t const *)b;
+	if (p->x != q->x) return (p->x < q->x) ? -1 : 1;
+	return (p->y < q->y) ? -1 : (p->y > q->y);
+}
+static unsigned combine_mods(orc_hmap_mod_t *m, unsigned n) { /* tex_mod_map_t::add: one entry per texel, deltas summed (src/heightmap.h:66-69) */
+	qsort(m, n, sizeof(*m), mod_cmp);
+	unsigned k = 0;
+	for (unsigned i = 0; i < n; ++i) {
+		if (k > 0 && m[k-1].x == m[i].x && m[k-1].y == m[i].y) {m[k-1].delta += m[i].delta;} else {m[k++] = m[i];}
+	}
+	return k;
+}
+void orc_hmap_apply_mods(orc_hmap_mod_t const *mods, unsigned n) { /* add_mod + apply_cur_mod_map (src/heightmap.cpp:431-436) */
+	orc_hmap_mod_t *m = (orc_hmap_mod_t *)malloc((size_t)(n ? n : 1)*sizeof(*m));
+	memcpy(m, mods, (size_t)n*sizeof(*m));
+	unsigned const k = combine_mods(m, n);
+	for (unsigned i = 0; i < k; ++i) {modify_heightmap_value(m[i].x, m[i].y, m[i].delta, 1);}
+	free(m);
+}
+#define MOD_HEADER_SIG  0xdeadbeefu /* src/heightmap.cpp:240-241 */
+#define MOD_TRAILER_SIG 0xbeefdeadu
+int orc_hmap_write_mod(char const *fn, orc_hmap_mod_t const *mods, unsigned n, orc_hmap_brush_t const *brushes, unsigned nb) { /* src/heightmap.cpp:283-308 */
+	FILE *fp = fopen(fn, "wb");
+	if (fp == NULL) return 0;
+	orc_hmap_mod_t *m = (orc_hmap_mod_t *)malloc((size_t)(n ? n : 1)*sizeof(*m));
+	memcpy(m, mods, (size_t)n*sizeof(*m));
+	unsigned const k = combine_mods(m, n), hs = MOD_HEADER_SIG, ts = MOD_TRAILER_SIG;
+	fwrite(&hs, 4, 1, fp); fwrite(&k, 4, 1, fp);
+	fwrite(m, sizeof(*m), k, fp);
+	fwrite(&nb, 4, 1, fp);
+	if (nb) {fwrite(brushes, sizeof(*brushes), nb, fp);}
+	fwrite(&ts, 4, 1, fp);
+	fclose(fp); free(m);
+	return 1;
+}
+int orc_hmap_read_mod(char const *fn, orc_hmap_mod_t *mods, unsigned *n, orc_hmap_brush_t *brushes, unsigned *nb) { /* src/heightmap.cpp:243-281; null outputs: counts only */
+	FILE *fp = fopen(fn, "rb");
+	unsigned v = 0, sz = 0, bsz = 0;
+	if (fp == NULL) return 0;
+	if (fread(&v, 4, 1, fp) != 1 || v != MOD_HEADER_SIG || fread(&sz, 4, 1, fp) != 1) {fclose(fp); return 0;}
+	orc_hmap_mod_t *m = (orc_hmap_mod_t *)malloc((size_t)(sz ? sz : 1)*sizeof(*m));
+	if (fread(m, sizeof(*m), sz, fp) != sz) {free(m); fclose(fp); return 0;}
+	unsigned const k = combine_mods(m, sz);
+	if (fread(&bsz, 4, 1, fp) != 1) {free(m); fclose(fp); return 0;}
+	orc_hmap_brush_t *bv = (orc_hmap_brush_t *)malloc((size_t)(bsz ? bsz : 1)*sizeof(*bv));
+	int ok = (fread(bv, sizeof(*bv), bsz, fp) == bsz) && fread(&v, 4, 1, fp) == 1 && v == MOD_TRAILER_SIG;
+	if (ok) {
+		*n = k; *nb = bsz;
+		if (mods && brushes) {memcpy(mods, m, (size_t)k*sizeof(*m)); memcpy(brushes, bv, (size_t)bsz*sizeof(*bv));}
+	}
+	free(m); free(bv); fclose(fp);
+	return ok;
+}
+int orc_hmap_read_and_apply_mod(char const *fn) { /* src/heightmap.cpp:424-440 */
+	unsigned n = 0, nb = 0;
+	if (!orc_hmap_read_mod(fn, NULL, &n, NULL, &nb)) return 0;
+	orc_hmap_mod_t *m = (orc_hmap_mod_t *)malloc((size_t)(n ? n : 1)*sizeof(*m));
+	orc_hmap_brush_t *bv = (orc_hmap_brush_t *)malloc((size_t)(nb ? nb : 1)*sizeof(*bv));
+	orc_hmap_read_mod(fn, m, &n, bv, &nb);
+	for (unsigned i = 0; i < n; ++i) {modify_heightmap_value(m[i].x, m[i].y, m[i].delta, 1);}
+	for (unsigned i = 0; i < nb; ++i) {orc_hmap_apply_brush(&bv[i], 1, 1);}
+	free(m); free(bv);
+	return 1;
 }
 static int using_hmap(void) {return hm_data != NULL;}                                   /* using_tiled_terrain_hmap_tex, src/tiled_mesh.cpp:273 */
 static int using_hmap_with_detail(void) {return using_hmap() && mesh_scale < 0.75f;}   /* src/tiled_mesh.cpp:274 */
@@ -1287,6 +1409,59 @@ void orc_quantize16(float const *vals, size_t n, unsigned char *out, float *min_
 		out[i<<1]     = (unsigned char)(256.0f*(v - (float)high_bits));
 	}
 	*min_z_out = min_z; *dz_out = dz;
+}
+
+/* heightmap_t::proc_gen (src/heightmap.cpp:130-151) with run_erosion (:153-185, APPLY_2X_EROSION_DOWNSAMPLE = 0) and from_floats (:205-215) */
+void orc_heightmap_proc_gen(int width, int height, unsigned iters, unsigned char *pixels, float *file_scale_tz) {
+	size_t const n = (size_t)width*height;
+	float *vals = (float *)malloc(n*sizeof(float));
+	orc_gen_grid((float)(-0.5*(double)width), (float)(-0.5*(double)height), DX_VAL, DY_VAL, (unsigned)width, (unsigned)height, 1, 1, 0, vals);
+	if (iters > 0) {
+		float min_zval = vals[0];
+		for (size_t i = 0; i < n; ++i) {min_zval = fmin_std(min_zval, vals[i]);}
+		erosion_impl(vals, width, height, min_zval, iters, NULL, NULL);
+	}
+	float min_z, dz;
+	orc_quantize16(vals, n, pixels, &min_z, &dz);
+	orc_set_mesh_height_scales_for_zval_range(min_z, (float)((double)dz/255.0));
+	file_scale_tz[0] = mesh_file_scale; file_scale_tz[1] = mesh_file_tz;
+	free(vals);
+}
+/* write_map_mode_heightmap_image (src/map_view.cpp:409-442) from the image origin on: setup_height_gen_cached (src/tiled_mesh.cpp:452-457),
+ * get_mesh_height (src/map_view.cpp:97-105), rows inverted, 16-bit pixels = (h - min_z)*(255/dz).  min_z_dz = {min_z, dz}. */
+void orc_export_heightmap(float xstart, float ystart, int width, int height, unsigned char *pixels, float *min_z_dz) {
+	size_t const n = (size_t)width*height;
+	float *heights = (float *)malloc(n*sizeof(float));
+	float const xy_scale = get_xy_scale();
+	grid_cache_t g; memset(&g, 0, sizeof(g));
+	if (xy_scale != 0.0f) {
+		gc_build_arrays(&g, xstart/DX_VAL, ystart/DY_VAL, xy_scale*DX_VAL, xy_scale*DY_VAL, (unsigned)width, (unsigned)height, 1, 0);
+		gc_enable_glaciate(&g);
+	}
+	for (int i = 0; i < height; ++i) {
+		int const off = width*(height - i - 1); /* invert yval */
+		for (int j = 0; j < width; ++j) {
+			float zval;
+			if (using_hmap()) {
+				zval = hm_interpolate_height((xstart + X_SCENE_SIZE + (float)j*DX_VAL)*DX_VAL_INV, (ystart + Y_SCENE_SIZE + (float)i*DY_VAL)*DY_VAL_INV);
+				if (using_hmap_with_detail()) {zval += HMAP_DETAIL_MAG*gc_eval_index(&g, (unsigned)j, (unsigned)i, 0, 1);}
+			}
+			else {zval = gc_eval_index(&g, (unsigned)j, (unsigned)i, 0, 1);}
+			heights[off + j] = zval;
+		}
+	}
+	float min_z = FLT_MAX, max_z = -FLT_MAX; /* get_heightmap_z_range, src/map_view.cpp:399-407 */
+	for (size_t i = 0; i < n; ++i) {min_z = fmin_std(min_z, heights[i]); max_z = fmax_std(max_z, heights[i]);}
+	float const dz = fmax_std(TOLERANCE_F, (max_z - min_z)), height_scale = (float)(255.0/(double)dz);
+	for (size_t i = 0; i < n; ++i) {
+		float const v = (heights[i] - min_z)*height_scale;
+		unsigned char const high_bits = (unsigned char)v;
+		pixels[(i<<1)+1] = high_bits;
+		pixels[i<<1]     = (unsigned char)(256.0f*(v - (float)high_bits));
+	}
+	min_z_dz[0] = min_z; min_z_dz[1] = dz;
+	if (xy_scale != 0.0f) {gc_free(&g);}
+	free(heights);
 }
 
 void orc_voxel_rdata(int rseed1, int rseed2, float mag, float freq, float *rdata) {

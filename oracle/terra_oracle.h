@@ -83,6 +83,19 @@ void  orc_set_tiled_mesh_ao(int v);
 void  orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolors); /* NULL: back to procedural tiles */
 void  orc_set_mesh_height_scales_for_zval_range(float min_z, float dz);
 float orc_get_clamped_height(int x, int y);
+void  orc_hmap_get(unsigned char *out); /* the current image (after brushes / mods) */
+float orc_hmap_interpolate_height(float x, float y);
+float orc_hmap_get_nearest_height(float x, float y);
+/* rest of row f4: tex_mod_map_manager_t::hmap_brush_t / mod_elem_t with the reference's layouts (src/heightmap.h:59-81), the .mod file and the exporter */
+typedef struct orc_hmap_brush_t {int x, y; unsigned radius; int delta; short shape;} orc_hmap_brush_t;
+typedef struct orc_hmap_mod_t {unsigned short x, y; int delta;} orc_hmap_mod_t;
+void  orc_hmap_apply_brush(orc_hmap_brush_t const *b, int step_sz, unsigned num_steps);
+void  orc_hmap_apply_mods(orc_hmap_mod_t const *mods, unsigned n);
+int   orc_hmap_write_mod(char const *fn, orc_hmap_mod_t const *mods, unsigned n, orc_hmap_brush_t const *brushes, unsigned nb);
+int   orc_hmap_read_mod(char const *fn, orc_hmap_mod_t *mods, unsigned *n, orc_hmap_brush_t *brushes, unsigned *nb);
+int   orc_hmap_read_and_apply_mod(char const *fn);
+void  orc_heightmap_proc_gen(int width, int height, unsigned iters, unsigned char *pixels, float *file_scale_tz);
+void  orc_export_heightmap(float xstart, float ystart, int width, int height, unsigned char *pixels, float *min_z_dz);
 void  orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao);
 void  orc_calc_mesh_shadows(float lx, float ly, float lz, float const *mh, unsigned char *smask, int xsize, int ysize, float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y);
 void  orc_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float lx, float ly, float lz, unsigned char *smask);

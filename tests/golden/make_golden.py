@@ -74,6 +74,24 @@ def main():
     out["tile_m4ao_2_m1_ao"] = R.tile_ao_lighting(2, -1, z4)
     R.set_tiled_mesh_ao(0)
     s = R.init(orclib.make_config(mesh_gen_mode=0))
+    # rest of row f4, produced by the reference's own heightmap.cpp: brushes + mods on a random 16-bit image, the exporter over it, heightmap_t::proc_gen
+    import parity_cases as pc_
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (96, 80, 2), dtype=np.uint8)
+    out["hmap_edit_in"] = img
+    R.set_num_threads(1)
+    R.hmap_set(img.copy(), -1.5, 0.01)
+    for i, row in enumerate(pc_.HMAP_BRUSHES):
+        R.hmap_apply_brush(orclib.make_brushes([row])[0], 1 + (i % 2), 1 + (i % 3) // 2)
+    R.hmap_apply_mods(orclib.make_mods(pc_.HMAP_MODS))
+    out["hmap_edit_out"] = R.hmap_pixels()
+    p, mn, dz = R.export_heightmap(-1.3, 0.7, 40, 30)
+    out["hmap_export_pix"] = p
+    out["hmap_export_range"] = np.array([mn, dz], np.float32)
+    R.hmap_set(None)
+    p, sc, tz = R.heightmap_proc_gen(64, 48, 200)
+    out["proc_gen_pix"] = p
+    out["proc_gen_scale_tz"] = np.array([sc, tz], np.float32)
     # row f3: landscape weights texture (create_texture driver over the reference's build_arrays / eval_index / eval_mesh_sin_terms / lttex tables)
     R.set_landscape(orclib.make_landscape(grass_density=100))
     zt, _ = R.tile_create_zvals(-3, 2, 0)

@@ -60,6 +60,26 @@ def make_landscape(vegetation=1.0, temperature=20.0, biome_x_offset=0.0, mesh_sc
     return Landscape(vegetation, temperature, biome_x_offset, mesh_scale_z, water_is_lava, disable_water, enable_terrain_env, grass_density, num_rnd_grass_blocks)
 
 
+BRUSH_DTYPE = np.dtype({"names": ["x", "y", "radius", "delta", "shape"], "formats": [np.int32, np.int32, np.uint32, np.int32, np.int16], "itemsize": 20})  # hmap_brush_t
+MOD_DTYPE = np.dtype([("x", np.uint16), ("y", np.uint16), ("delta", np.int32)])  # mod_elem_t
+BSHAPE_CONST_SQ, BSHAPE_CNST_CIR, BSHAPE_LINEAR, BSHAPE_QUADRATIC, BSHAPE_COSINE, BSHAPE_SINE, BSHAPE_FLAT_SQ, BSHAPE_FLAT_CIR = range(8)
+
+
+def make_brushes(rows):
+    """[(x, y, radius, delta, shape), ...] -> BRUSH_DTYPE array (padding bytes zero)"""
+    b = np.zeros(len(rows), BRUSH_DTYPE)
+    for i, r in enumerate(rows):
+        b[i] = tuple(r)
+    return b
+
+
+def make_mods(rows):
+    m = np.zeros(len(rows), MOD_DTYPE)
+    for i, r in enumerate(rows):
+        m[i] = tuple(r)
+    return m
+
+
 GRASS_BLOCK_DTYPE = np.dtype([("ix", np.uint32), ("zmin", np.float32), ("zmax", np.float32)])
 
 
@@ -142,6 +162,16 @@ class Checker:
         f("set_mesh_height_scales_for_zval_range", None, [C.c_float, C.c_float])
         f("get_clamped_height", C.c_float, [C.c_int, C.c_int])
         f("tile_ao_lighting", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        f("hmap_get", None, [C.c_void_p])
+        f("hmap_interpolate_height", C.c_float, [C.c_float, C.c_float])
+        f("hmap_get_nearest_height", C.c_float, [C.c_float, C.c_float])
+        f("hmap_apply_brush", None, [C.c_void_p, C.c_int, C.c_uint])
+        f("hmap_apply_mods", None, [C.c_void_p, C.c_uint])
+        f("hmap_write_mod", C.c_int, [C.c_char_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint])
+        f("hmap_read_mod", C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint), C.c_void_p, C.POINTER(C.c_uint)])
+        f("hmap_read_and_apply_mod", C.c_int, [C.c_char_p])
+        f("heightmap_proc_gen", None, [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p])
+        f("export_heightmap", None, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
         f("set_landscape", None, [C.POINTER(Landscape)])
         f("tile_terrain_params", None, [C.c_int, C.c_int, C.c_void_p])
         f("tile_create_weights", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)])
@@ -259,6 +289,49 @@ class Checker:
             self._set_mesh_height_scales_for_zval_range(min_z, dz)
 
     def get_clamped_height(self, x, y): return self._get_clamped_height(x, y)
+
+    def hmap_pixels(self):
+        """the checker's current image (it keeps its own copy, edited by brushes and mods)"""
+        out = np.empty_like(self._hm_keep)
+        self._hmap_get(out.ctypes.data)
+        return out
+
+    def hmap_interpolate_height(self, x, y): return self._hmap_interpolate_height(x, y)
+    def hmap_get_nearest_height(self, x, y): return self._hmap_get_nearest_height(x, y)
+
+    def hmap_apply_brush(self, brush, step_sz=1, num_steps=1):
+        b = np.ascontiguousarray(brush, BRUSH_DTYPE).reshape(1)
+        self._hmap_apply_brush(b.ctypes.data, step_sz, num_steps)
+
+    def hmap_apply_mods(self, mods):
+        m = np.ascontiguousarray(mods, MOD_DTYPE)
+        self._hmap_apply_mods(m.ctypes.data, len(m))
+
+    def hmap_write_mod(self, fn, mods, brushes):
+        m = np.ascontiguousarray(mods, MOD_DTYPE); b = np.ascontiguousarray(brushes, BRUSH_DTYPE)
+        return bool(self._hmap_write_mod(str(fn).encode(), m.ctypes.data, len(m), b.ctypes.data, len(b)))
+
+    def hmap_read_mod(self, fn):
+        n, nb = C.c_uint(0), C.c_uint(0)
+        if not self._hmap_read_mod(str(fn).encode(), None, C.byref(n), None, C.byref(nb)):
+            return None
+        m = np.zeros(n.value, MOD_DTYPE); b = np.zeros(nb.value, BRUSH_DTYPE)
+        assert self._hmap_read_mod(str(fn).encode(), m.ctypes.data, C.byref(n), b.ctypes.data, C.byref(nb))
+        return m, b
+
+    def hmap_read_and_apply_mod(self, fn): return bool(self._hmap_read_and_apply_mod(str(fn).encode()))
+
+    def heightmap_proc_gen(self, width, height, iters):
+        """-> (pixels u8 [h,w,2], mesh_file_scale, mesh_file_tz)"""
+        pix = np.zeros((height, width, 2), np.uint8); st = np.zeros(2, np.float32)
+        self._heightmap_proc_gen(width, height, iters, pix.ctypes.data, st.ctypes.data)
+        return pix, st[0], st[1]
+
+    def export_heightmap(self, xstart, ystart, width, height):
+        """-> (pixels u8 [h,w,2], min_z, dz)"""
+        pix = np.zeros((height, width, 2), np.uint8); r = np.zeros(2, np.float32)
+        self._export_heightmap(xstart, ystart, width, height, pix.ctypes.data, r.ctypes.data)
+        return pix, r[0], r[1]
 
     def tile_ao_lighting(self, tx, ty, zvals):
         assert zvals.dtype == np.float32 and zvals.shape == (130, 130) and zvals.flags.c_contiguous

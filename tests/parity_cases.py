@@ -12,6 +12,7 @@ import numpy as np
 
 import orclib
 from orclib import assert_bit_equal
+from pytest import raises as pytest_raises
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 VOX = dict(lo=(-3.9, -3.9, -1.0), vsz=(0.0152, 0.0152, 0.0625), off=(0.1, 0.2, 0.3))
@@ -407,6 +408,77 @@ def case_tiles_from_heightmap(pkg, t, orc):
                 no, mo = orc.tile_normals(zo)
                 assert (nm[i] == no).all() and np.float32(mnz[i]).view(np.uint32) == np.float32(mo).view(np.uint32)
                 assert (ao[i] == orc.tile_ao_lighting(tx, ty, zo)).all(), f"hmap ao scale {mesh_scale} tile {tx},{ty}"
+    finally:
+        t.hmap_set_dev(None); orc.hmap_set(None)
+        for b in bufs:
+            b.free()
+
+
+HMAP_BRUSHES = [(0, 0, 9, 300, 4), (-30, 20, 12, -20000, 2), (39, 47, 7, 70000, 0), (5, -40, 6, 900, 5), (10, 10, 8, 1234, 3), (-3, 3, 5, -4000, 1),
+                (0, 5, 4, 30000, 6), (60, 60, 10, 12, 7), (2, 2, 0, 500, 4), (-200, 300, 16, -70000, 1)]  # (x, y, radius, delta, shape)
+HMAP_MODS = [(3, 4, 100), (3, 4, -30), (79, 95, 70000), (0, 0, -5), (10, 2, 77), (3, 4, 1), (78, 95, -3), (1, 0, 9)]
+
+
+def case_hmap_edits_and_export(pkg, t, orc, tmp_path):
+    """rest of row f4: height brushes (every shape, sub-steps, strides, saturation at both ends, mirror wrap, mesh_scale != 1), the mod map, the .mod
+    file both ways, read_and_apply_mod and the map-view exporter -- the device image after each edit equals the oracle's (bit-exact), files interoperate."""
+    rng = np.random.default_rng(5)
+    bufs = []
+    try:
+        for mesh_scale in (1.0, 0.5, 2.0):
+            for nc in (2, 1):
+                pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, mesh_scale=mesh_scale)
+                t.init_scene(pc_); orc.init(oc)
+                img = rng.integers(0, 256, (96, 80, 2) if nc == 2 else (96, 80), dtype=np.uint8)
+                buf = t.alloc(img.nbytes).upload(img); bufs.append(buf)
+                t.hmap_set_dev(buf.ptr, 80, 96, nc, -1.5, 0.01)
+                orc.hmap_set(img.copy(), -1.5, 0.01)
+                for i, row in enumerate(HMAP_BRUSHES):
+                    br = orclib.make_brushes([row])
+                    step, ns = ((1, 1), (2, 1), (1, 2), (3, 2))[i % 4]
+                    t.hmap_apply_brushes_dev(br, step, ns); orc.hmap_apply_brush(br[0], step, ns)
+                    got = buf.download(np.uint8, img.shape)
+                    assert (got == orc.hmap_pixels()).all(), (mesh_scale, nc, "brush", row, np.argwhere(got != orc.hmap_pixels())[:4])
+                brs = orclib.make_brushes(HMAP_BRUSHES[:4])  # a list in one call = one after the other
+                t.hmap_apply_brushes_dev(brs, 1, 1)
+                for b in brs:
+                    orc.hmap_apply_brush(b, 1, 1)
+                mods = orclib.make_mods(HMAP_MODS)
+                t.hmap_apply_mods_dev(mods); orc.hmap_apply_mods(mods)
+                assert (buf.download(np.uint8, img.shape) == orc.hmap_pixels()).all(), (mesh_scale, nc, "mods")
+                # the .mod file: written by either side, read by the other; then read_and_apply_mod
+                f_t, f_o = str(tmp_path / f"t_{mesh_scale}_{nc}.mod"), str(tmp_path / f"o_{mesh_scale}_{nc}.mod")
+                t.hmap_write_mod(f_t, mods, brs); assert orc.hmap_write_mod(f_o, mods, brs)
+                assert open(f_t, "rb").read() == open(f_o, "rb").read()  # both sides write zero padding
+                m1, b1 = t.hmap_read_mod(f_o); m2, b2 = orc.hmap_read_mod(f_t)
+                assert m1.tobytes() == m2.tobytes() and len(m1) == 6 and all((b1[k] == b2[k]).all() and (b1[k] == brs[k]).all() for k in brs.dtype.names)
+                t.hmap_read_and_apply_mod_dev(f_o); assert orc.hmap_read_and_apply_mod(f_t)
+                assert (buf.download(np.uint8, img.shape) == orc.hmap_pixels()).all(), (mesh_scale, nc, "read_and_apply_mod")
+                # exporter sampling the (edited) texture, incl. the procedural detail below mesh_scale 0.75
+                w, h = 70, 50
+                v, px = t.alloc(w * h * 4), t.alloc(w * h * 2); bufs += [v, px]
+                mn, dz = t.export_heightmap_dev(-1.3, 0.7, w, h, v.ptr, px.ptr)
+                po, mno, dzo = orc.export_heightmap(-1.3, 0.7, w, h)
+                assert (px.download(np.uint8, (h, w, 2)) == po).all() and np.float32(mn) == mno and np.float32(dz) == dzo, (mesh_scale, nc, "export")
+                t.hmap_set_dev(None); orc.hmap_set(None)
+        # procedural exporter, every mode, odd sizes; and the PNG file
+        for mode, (w, h) in ((0, (90, 33)), (1, (64, 64)), (4, (37, 41)), (0, (1, 1))):
+            pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode)
+            t.init_scene(pc_); orc.init(oc)
+            v, px = t.alloc(w * h * 4), t.alloc(w * h * 2); bufs += [v, px]
+            mn, dz = t.export_heightmap_dev(-2.0, 1.1, w, h, v.ptr, px.ptr)
+            po, mno, dzo = orc.export_heightmap(-2.0, 1.1, w, h)
+            assert (px.download(np.uint8, (h, w, 2)) == po).all() and np.float32(mn) == mno and np.float32(dz) == dzo, (mode, "export")
+            fn = str(tmp_path / f"hm_{mode}_{w}.png")
+            t.write_map_mode_heightmap_image(fn, -2.0, 1.1, w, h)
+            assert (t.heightmap_read_png(fn, 1) == po[::-1]).all()  # texture_t::load_png flips the rows (src/image_io.cpp:540)
+        # error behaviour
+        t.init_scene(pkg.make_config(mesh_gen_mode=0))
+        with pytest_raises(pkg.TerraError):
+            t.hmap_apply_brushes_dev(orclib.make_brushes([(0, 0, 3, 5, 4)]))  # no texture set
+        bad = tmp_path / "bad.mod"; bad.write_bytes(b"\x00" * 16)
+        with pytest_raises(pkg.TerraError):
+            t.hmap_read_mod(bad)
     finally:
         t.hmap_set_dev(None); orc.hmap_set(None)
         for b in bufs:

@@ -66,6 +66,10 @@ def test_tile_batch_shapes(pkg, gpu, orc):
     pc.case_tile_batch_shapes(pkg, gpu, orc)
 
 
+def test_hmap_edits_and_export(pkg, gpu, orc, tmp_path):
+    pc.case_hmap_edits_and_export(pkg, gpu, orc, tmp_path)
+
+
 def test_tile_weights_texture(pkg, gpu, orc):
     pc.case_tile_weights(pkg, gpu, orc)
 

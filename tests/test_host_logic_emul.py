@@ -86,6 +86,10 @@ def test_tile_batch_shapes(pkg, emul, orc):
     pc.case_tile_batch_shapes(pkg, emul, orc)
 
 
+def test_hmap_edits_and_export(pkg, emul, orc, tmp_path):
+    pc.case_hmap_edits_and_export(pkg, emul, orc, tmp_path)
+
+
 def test_tile_weights_texture(pkg, emul, orc):
     pc.case_tile_weights(pkg, emul, orc)
 

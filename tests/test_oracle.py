@@ -138,6 +138,78 @@ def test_oracle_vs_reference_epilogue_configs(orc, ref):
             assert_bit_equal(ref.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), orc.gen_grid(-131, 40, sr.DX_VAL, sr.DY_VAL, 260, 150, 1), f"{v} {extra}")
 
 
+def test_oracle_vs_reference_hmap_edits_files_export(orc, ref, tmp_path):
+    """rest of row f4 against the reference's own heightmap.cpp (compiled in place): brushes, mod map, the .mod file both ways, read_and_apply_mod,
+    interpolate / nearest sampling, heightmap_t::proc_gen, and the exporter driver (map_view.cpp is GL-bound; its pieces are the reference's)."""
+    ref.set_num_threads(1)
+    both = lambda f: (f(orc), f(ref))
+    rng = np.random.default_rng(5)
+    try:
+        for ms in (1.0, 0.5, 2.0):
+            for nc in (2, 1):
+                cfg = orclib.make_config(mesh_gen_mode=0, mesh_scale=ms)
+                pix = rng.integers(0, 256, (96, 80, 2) if nc == 2 else (96, 80), dtype=np.uint8)
+                for c in (orc, ref):
+                    c.init(cfg); c.hmap_set(pix.copy(), -1.5, 0.01)
+                for i, row in enumerate(pc.HMAP_BRUSHES):
+                    br = orclib.make_brushes([row])[0]
+                    step, ns = ((1, 1), (2, 1), (1, 2), (3, 2))[i % 4]
+                    for c in (orc, ref):
+                        c.hmap_apply_brush(br, step, ns)
+                    a, b = both(lambda c: c.hmap_pixels())
+                    assert (a == b).all(), (ms, nc, row, np.argwhere(a != b)[:4])
+                mods = orclib.make_mods(pc.HMAP_MODS)
+                for c in (orc, ref):
+                    c.hmap_apply_mods(mods)
+                a, b = both(lambda c: c.hmap_pixels())
+                assert (a == b).all() and (a != pix).any()
+                brs = orclib.make_brushes(pc.HMAP_BRUSHES[:3])
+                fo, fr = str(tmp_path / "o.mod"), str(tmp_path / "r.mod")
+                assert orc.hmap_write_mod(fo, mods, brs) and ref.hmap_write_mod(fr, mods, brs)
+                assert os.path.getsize(fo) == os.path.getsize(fr) == 4 + 4 + 6 * 8 + 4 + 3 * 20 + 4
+                mo, bo = orc.hmap_read_mod(fr); mr, br_ = ref.hmap_read_mod(fo)  # (the reference leaves the brush padding bytes uninitialised: compare fields)
+                assert mo.tobytes() == mr.tobytes() and all((bo[k] == br_[k]).all() for k in bo.dtype.names)
+                assert orc.hmap_read_and_apply_mod(fr) and ref.hmap_read_and_apply_mod(fo)
+                a, b = both(lambda c: c.hmap_pixels())
+                assert (a == b).all()
+                for x, y in ((0.3, 7.9), (-100.5, 33.25), (1e3, -2e3), (39.5, 47.5)):
+                    a, b = both(lambda c: c.hmap_interpolate_height(x, y)); assert a == b
+                    a, b = both(lambda c: c.hmap_get_nearest_height(x, y)); assert a == b
+                a, b = both(lambda c: c.export_heightmap(-1.3, 0.7, 70, 50))
+                assert (a[0] == b[0]).all() and a[1] == b[1] and a[2] == b[2]
+                for c in (orc, ref):
+                    c.hmap_set(None)
+        for mode in (0, 1, 4):
+            cfg = orclib.make_config(mesh_gen_mode=mode)
+            for c in (orc, ref):
+                c.init(cfg)
+            for iters in (0, 300):
+                a, b = both(lambda c: c.heightmap_proc_gen(96, 64, iters))
+                assert (a[0] == b[0]).all() and a[1] == b[1] and a[2] == b[2], (mode, iters)
+            a, b = both(lambda c: c.export_heightmap(-2.0, 1.1, 90, 33))
+            assert (a[0] == b[0]).all() and a[1] == b[1] and a[2] == b[2]
+    finally:
+        for c in (orc, ref):
+            c.hmap_set(None)
+
+
+def test_oracle_matches_golden_hmap_edits(orc):
+    G = pc.golden()
+    orc.init(orclib.make_config(mesh_gen_mode=0))
+    try:
+        orc.hmap_set(G["hmap_edit_in"].copy(), -1.5, 0.01)
+        for i, row in enumerate(pc.HMAP_BRUSHES):
+            orc.hmap_apply_brush(orclib.make_brushes([row])[0], 1 + (i % 2), 1 + (i % 3) // 2)
+        orc.hmap_apply_mods(orclib.make_mods(pc.HMAP_MODS))
+        assert (orc.hmap_pixels() == G["hmap_edit_out"]).all()
+        p, mn, dz = orc.export_heightmap(-1.3, 0.7, 40, 30)
+        assert (p == G["hmap_export_pix"]).all() and (np.array([mn, dz], np.float32).view(np.uint32) == G["hmap_export_range"].view(np.uint32)).all()
+    finally:
+        orc.hmap_set(None)
+    p, sc, tz = orc.heightmap_proc_gen(64, 48, 200)
+    assert (p == G["proc_gen_pix"]).all() and (np.array([sc, tz], np.float32).view(np.uint32) == G["proc_gen_scale_tz"].view(np.uint32)).all()
+
+
 def test_oracle_matches_golden_tile_weights(orc):
     G = pc.golden()
     orc.init(orclib.make_config(mesh_gen_mode=0))
