@@ -1,7 +1,7 @@
 // oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
 //
 // Link shim that lets the reference's OWN translation units
-//     /root/reference/src/mesh_gen.cpp, erosion.cpp, upsurface.cpp   (+ vendored glm 0.9.9.1 headers)
+//     /root/reference/src/mesh_gen.cpp, erosion.cpp, upsurface.cpp, visibility.cpp, Math3d.cpp, heightmap.cpp   (+ vendored glm 0.9.9.1 headers)
 // be compiled unmodified, in place, into oracle/_ref/liboracle_ref.so (recipe: oracle/Makefile).
 // No reference source is copied: this file only (1) DEFINES the process globals those TUs declare
 // `extern` (they live in 3DWorld.cpp / Textures.cpp / display_world.cpp / Universe.cpp, which cannot be
@@ -16,7 +16,8 @@
 //   the voxel fill loop   src/voxels.cpp:312-345       (voxels.o has >100 unrelated externals)
 //   tile_t::create_zvals  src/tiled_mesh.cpp:467-546   (driver only; generator + erosion are the real TUs)
 //   tile_t::get_norm / upload_normal_texture  src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880
-//   heightmap_t::from_floats / write_pixel_16_bits  src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893
+//   texture_t::alloc / free_client_mem / set_16_bit_grayscale / write_pixel_16_bits  src/Textures.cpp:486-517,1889-1893, src/image_io.cpp:493-496 (for heightmap.cpp)
+//   tile_t::calc_mesh_ao_lighting, create_texture, update_terrain_params; get_tids; write_map_mode_heightmap_image  (drivers, see each)
 
 #include "3DWorld.h"
 #include <map>
