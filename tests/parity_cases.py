@@ -485,6 +485,83 @@ def case_hmap_edits_and_export(pkg, t, orc, tmp_path):
             b.free()
 
 
+def case_random_configs(pkg, t, orc, seeds, big=False):
+    """fixed-seed random sweep over the configuration space (mode, shape, seed, frequency filter, post-processing / island / volcano parameters, scales,
+    water level, landscape globals) and over the call arguments (grid origin / spacing / size, tile coordinates, droplet counts): grids, tile batches with
+    stats + normals + AO + weights + shadows and a whole-map erosion, each bit-exact against the oracle."""
+    for seed in seeds:
+        rng = np.random.default_rng(1000 + seed)
+        mode = int(rng.choice([0, 0, 1, 2, 3, 4])); shape = int(rng.choice([0, 0, 1, 2]))
+        hm = list(orclib.HMAP_DEFAULT)
+        if rng.random() < 0.5: hm[0:4] = [float(rng.uniform(-1, 1.5)), float(rng.uniform(0, 1)), float(rng.uniform(0, 2)), float(rng.uniform(0, 1))]  # plateau
+        if rng.random() < 0.4: hm[4:6] = [float(rng.uniform(0, 2)), float(rng.uniform(0, 3))]                                                       # craters
+        if rng.random() < 0.4: lo = float(rng.uniform(-1, 1)); hm[6:9] = [lo, lo + float(rng.uniform(0.05, 1)), float(rng.uniform(0, 2))]           # cracks
+        if rng.random() < 0.6: hm[9:12] = [float(rng.uniform(0.5, 6)), float(rng.uniform(0.0005, 0.01)), float(rng.uniform(-5, 1))]                # islands
+        if rng.random() < 0.3 and hm[9] > 0: hm[12:14] = [float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.5, 3))]                               # volcano
+        kw = dict(mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_seed=int(rng.integers(0, 50)), mesh_freq_filter=int(rng.integers(0, 4)), hmap=hm,
+                  glaciate=int(rng.random() < 0.85), mesh_scale=float(rng.choice([1.0, 1.0, 0.5, 2.0, 1.37])), mesh_height=float(rng.uniform(0.3, 1.5)),
+                  erode_amount=float(rng.choice([1.0, 1.0, 0.4, 2.5])))
+        pc_, oc = cfg_pair(pkg, **kw)
+        wrel, radj, woff = float(rng.choice([0.0, 0.0, 0.1, -0.15])), float(rng.choice([0.0, 0.0, 0.05, -0.04])), float(rng.choice([0.0, 0.0, 0.2]))
+        for c in (pc_, oc):
+            c.water_h_off_rel = wrel; c.relh_adj_tex = radj; c.water_h_off = woff
+        st = t.init_scene(pc_); so = orc.init(oc)
+        for n_ in orclib._STATE_FLOATS:
+            assert np.float32(getattr(st, n_)).view(np.uint32) == np.float32(getattr(so, n_)).view(np.uint32), (seed, kw, n_)
+        lkw = dict(vegetation=float(rng.choice([1.0, 1.0, 0.0, 0.5])), temperature=float(rng.choice([20.0, 20.0, 48.0])), biome_x_offset=float(rng.uniform(-5, 5)),
+                   water_is_lava=int(rng.random() < 0.2), disable_water=int(rng.choice([0, 0, 2])), enable_terrain_env=int(rng.random() < 0.8),
+                   grass_density=int(rng.choice([0, 50])), num_rnd_grass_blocks=int(rng.integers(1, 33)))
+        t.set_landscape(pkg.make_landscape(**lkw)); orc.set_landscape(orclib.make_landscape(**lkw))
+        ctx_ = (seed, kw, lkw)
+        try:
+            # a grid with arbitrary origin / spacing / size
+            nx, ny = int(rng.integers(1, 700 if big else 200)), int(rng.integers(1, 500 if big else 150))
+            x0, y0 = float(rng.uniform(-5000, 5000)), float(rng.uniform(-5000, 5000))
+            dx, dy = st.DX_VAL * float(rng.choice([1.0, 1.0, 16.0, 0.37])), st.DY_VAL * float(rng.choice([1.0, 1.0, 80.0, 2.5]))
+            gl, mss, fs = int(rng.random() < 0.7), int(rng.choice([0, 0, 50, 23])), bool(rng.random() < 0.2)
+            a = t.gen_grid(x0, y0, dx, dy, nx, ny, (pkg.GEN_GLACIATE if gl else 0) | (pkg.GEN_FORCE_SINE if fs else 0), mss)
+            if fs:
+                orc.set_mode(0, 0)
+            b = orc.gen_grid(x0, y0, dx, dy, nx, ny, gl, 0, mss)
+            orc.set_mode(mode, shape)
+            assert_bit_equal(a, b, f"grid {ctx_} {nx}x{ny} @ {x0},{y0}")
+            # a tile batch through every tile product
+            k = int(rng.integers(1, 7 if big else 4))
+            tiles = [(int(rng.integers(-60, 60)), int(rng.integers(-60, 60))) for _ in range(k)]
+            tiles += [(tiles[0][0] + 1, tiles[0][1]), (tiles[0][0], tiles[0][1] + 1)]  # neighbours: shadow edges cross
+            tiles = list(dict.fromkeys(tiles))
+            iters = int(rng.choice([0, 0, 40, 150]))
+            ao_flag = int(rng.random() < 0.5)
+            t.set_tiled_mesh_ao(ao_flag); orc.set_tiled_mesh_ao(ao_flag)
+            z, stt, nm, mnz = t.tiles_create_zvals(tiles, iters)
+            ao = t.tiles_ao_lighting(tiles, z)
+            w, gb, hg = t.tiles_create_weights(tiles, z)
+            light = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(0.05, 1)))
+            sm = t.tiles_mesh_shadows(tiles, z, light)
+            zo_all = []
+            for i, (tx, ty) in enumerate(tiles):
+                zo, sto = orc.tile_create_zvals(tx, ty, iters)
+                zo_all.append(zo)
+                assert_bit_equal(z[i], zo, f"tile zvals {ctx_} {tx},{ty} iters {iters}")
+                assert bytes(stt[i]) == bytes(sto), (ctx_, tx, ty, "stats")
+                no, mo = orc.tile_normals(zo)
+                assert (nm[i] == no).all() and np.float32(mnz[i]).view(np.uint32) == np.float32(mo).view(np.uint32), (ctx_, tx, ty, "normals")
+                assert (ao[i] == orc.tile_ao_lighting(tx, ty, zo)).all(), (ctx_, tx, ty, "ao")
+                wo, gbo, hgo = orc.tile_create_weights(tx, ty, zo)
+                assert (w[i] == wo).all() and gb[i].tobytes() == gbo.tobytes() and bool(hg[i]) == hgo, (ctx_, tx, ty, "weights")
+            assert (sm == orc.tiles_mesh_shadows(tiles, np.stack(zo_all), light)).all(), (ctx_, "shadows", light)
+            # whole-map erosion
+            n = int(rng.integers(40, 400 if big else 120)); d = int(rng.integers(1, 3000 if big else 300))
+            g = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+            mz = float(g.min()) if rng.random() < 0.7 else float(g.min()) + 0.1
+            e = t.apply_erosion(g.copy(), mz, d)
+            orc.apply_erosion(g, mz, d)
+            assert_bit_equal(e, g, f"erosion {ctx_} n {n} droplets {d}")
+        finally:
+            t.set_tiled_mesh_ao(0); orc.set_tiled_mesh_ao(0)
+            t.set_landscape(pkg.make_landscape()); orc.set_landscape(orclib.make_landscape())
+
+
 def case_voxels_golden(pkg, t):
     G = golden()
     t.init_scene(pkg.make_config(mesh_gen_mode=0))

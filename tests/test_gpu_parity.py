@@ -234,3 +234,8 @@ def test_tiles_batch_64x64_properties(pkg, gpu, orc):
     mz = np.array([s.mzmin for s in stats]), np.array([s.mzmax for s in stats])
     assert (mz[0] == sub.min(1)).all() and (mz[1] == sub.max(1)).all()
     assert (nm[..., 3] == 0).all() and (mnz > 0).all() and (mnz <= 1).all()
+
+
+@pytest.mark.parametrize("block", [0, 1])
+def test_random_configs(pkg, gpu, orc, block):
+    pc.case_random_configs(pkg, gpu, orc, range(block * 7, block * 7 + 7), big=True)

@@ -156,3 +156,7 @@ def test_inject_engine_state(pkg, emul, orc):
 
 def test_api_errors(pkg, emul):
     pc.case_api_errors(pkg, emul)
+
+
+def test_random_configs(pkg, emul, orc):
+    pc.case_random_configs(pkg, emul, orc, range(6))
