@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 		float va = __fadd_rn(val.x, zterm), vb = __fadd_rn(val.y, zterm);
 		if (normalize) {va = clip_pm1(va); vb = clip_pm1(vb);}
 		if (active) {
-			out[col*nz + z] = va;
-			if (col + 1 < ncol) {out[(col + 1)*nz + z] = vb;}
+			__builtin_nontemporal_store(va, &out[col*nz + z]); // written once, never read back by this kernel: keep it out of the L2's way
+			if (col + 1 < ncol) {__builtin_nontemporal_store(vb, &out[(col + 1)*nz + z]);}
 		}
 	}
 }
