@@ -999,10 +999,15 @@ template<class BE> struct terra_engine {
 		hmap_view_t const hv = hmap_view();
 		uint8_t *pix = const_cast<uint8_t *>(hmap_pix);
 		sin_lut_t const L = lut();
-		for (uint32_t bi = 0; bi < n; ++bi) {
-			hmap_brush_pod_t const b = brushes[bi];
+		for (uint32_t bi = 0; bi < n; ++bi) { // validate the whole list before the first edit
+			hmap_brush_pod_t const &b = brushes[bi];
 			if (b.shape < 0 || b.shape >= NUM_BSHAPES) throw std::invalid_argument("hmap brush: bad shape");
 			if (b.radius > (1u << 20)) throw std::invalid_argument("hmap brush: radius too large");
+			uint64_t const side = (uint64_t)(2*b.radius)/(uint64_t)step_sz + 1;
+			if (side*side*num_steps*num_steps > (1ull << 32)) throw std::invalid_argument("hmap brush: more than 2^32 brush points");
+		}
+		for (uint32_t bi = 0; bi < n; ++bi) {
+			hmap_brush_pod_t const b = brushes[bi];
 			int const r = (int)b.radius, shape = b.shape, bx = b.x, by = b.y, delta = b.delta, step = step_sz;
 			uint32_t const side = (uint32_t)(2*r)/(uint32_t)step_sz + 1, ns = num_steps;
 			float const step_delta = (float)(1.0/(double)num_steps), r_inv = (float)(1.0/(double)std::max(1u, b.radius));

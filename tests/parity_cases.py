@@ -707,4 +707,27 @@ def case_api_errors(pkg, t):
     with pytest.raises(pkg.TerraError):  # enable_glaciate before build_arrays
         g.enable_glaciate()
     g.close()
+    # the rows added after the first hot path
+    with pytest.raises(pkg.TerraError):
+        t.set_landscape(pkg.make_landscape(num_rnd_grass_blocks=0))  # would divide by zero in add_grass_block_at
+    assert lib.terra_tiles_create_weights(t.ctx, None, 1, None, None, None, None) == -1
+    assert lib.terra_tiles_create_weights(t.ctx, None, 0, None, None, None, None) == 0  # empty batch
+    assert lib.terra_hmap_write_mod(None, None, 0, None, 0) == -1
+    with pytest.raises(pkg.TerraError):
+        t.hmap_read_mod("/nonexistent/dir/x.mod")
+    with pytest.raises(pkg.TerraError):
+        t.hmap_apply_mods_dev(orclib.make_mods([(1, 1, 5)]))  # no texture registered
+    img = t.alloc(64 * 64 * 2).upload(np.zeros((64, 64, 2), np.uint8))
+    try:
+        t.hmap_set_dev(img.ptr, 64, 64, 2, 0.0, 0.01)
+        for bad_brush, step, ns in (((0, 0, 3, 5, 9), 1, 1), ((0, 0, 3, 5, -1), 1, 1), ((0, 0, 3, 5, 4), 0, 1), ((0, 0, 3, 5, 4), 1, 0), ((0, 0, 1 << 19, 5, 4), 1, 4)):
+            with pytest.raises(pkg.TerraError):
+                t.hmap_apply_brushes_dev(orclib.make_brushes([bad_brush]), step, ns)
+        with pytest.raises(pkg.TerraError):
+            t.hmap_apply_mods_dev(orclib.make_mods([(64, 0, 5)]))  # outside the texture (the reference asserts)
+        assert (img.download(np.uint8, (64, 64, 2)) == 0).all()  # rejected calls left the image alone
+    finally:
+        t.hmap_set_dev(None); img.free()
+    with pytest.raises(pkg.TerraError):
+        t.export_heightmap_dev(0.0, 0.0, 0, 4, 1)
     t.init_scene(pkg.make_config())
