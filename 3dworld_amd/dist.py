@@ -20,9 +20,12 @@ def strip_of(tile_x, x_min, x_max, world):
 def sharded_tile_mesh_shadows(terra, dist, tiles, light_pos, make_zvals, alloc_smask):
     """terra: a Terra context on this rank's device.  tiles: the FULL tile list (same on every rank).  make_zvals(my_tiles) -> device pointer of
     their zvals; alloc_smask(n) -> device pointer for n*130*130 bytes.  Returns (my_tiles, smask_ptr).  Communication: torch.distributed send/recv
-    of CPU tensors (the edge arrays are tiny: 520 B per tile border)."""
+    (the edge arrays are tiny: 520 B per tile border); under the "nccl" (= RCCL) backend the message buffers are staged on this rank's GPU, because
+    RCCL moves device memory only, under gloo they stay on the host."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
+    on_gpu = str(dist.get_backend()).lower() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     tiles = [tuple(int(v) for v in t) for t in tiles]
     xs = [t[0] for t in tiles]
     x_min, x_max = min(xs), max(xs)
@@ -36,10 +39,11 @@ def sharded_tile_mesh_shadows(terra, dist, tiles, light_pos, make_zvals, alloc_s
     src_ranks = sorted({owner[nb] for _, nb in need})
     for src in src_ranks:  # one message per neighbouring strip: the sh_out_y rows of its border tiles, in the order of `need`
         rows = [(i, nb) for i, nb in need if owner[nb] == src]
-        buf = torch.empty((len(rows), 130), dtype=torch.float32)
+        buf = torch.empty((len(rows), 130), dtype=torch.float32, device=dev)
         dist.recv(buf, src=src)
+        host = buf.cpu().numpy()
         for k, (i, _) in enumerate(rows):
-            edge_in[i, 1] = buf[k].numpy()
+            edge_in[i, 1] = host[k]
             present[i, 1] = 1
     z_ptr = make_zvals(mine)
     sm_ptr = alloc_smask(len(mine))
@@ -52,5 +56,5 @@ def sharded_tile_mesh_shadows(terra, dist, tiles, light_pos, make_zvals, alloc_s
         dst_tiles = [t for t in tiles if owner[t] == dst]
         rows = [index[(t[0] + sx, t[1])] for t in dst_tiles if (t[0] + sx, t[1]) in index]  # same order as the receiver's `need`
         if rows:
-            dist.send(torch.from_numpy(np.ascontiguousarray(edge_out[rows, 1])), dst=dst)
+            dist.send(torch.from_numpy(np.ascontiguousarray(edge_out[rows, 1])).to(dev), dst=dst)
     return mine, sm_ptr
