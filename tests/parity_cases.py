@@ -488,7 +488,9 @@ def case_hmap_edits_and_export(pkg, t, orc, tmp_path):
 def case_random_configs(pkg, t, orc, seeds, big=False):
     """fixed-seed random sweep over the configuration space (mode, shape, seed, frequency filter, post-processing / island / volcano parameters, scales,
     water level, landscape globals) and over the call arguments (grid origin / spacing / size, tile coordinates, droplet counts): grids, tile batches with
-    stats + normals + AO + weights + shadows and a whole-map erosion, each bit-exact against the oracle."""
+    stats + normals + AO + weights + shadows and a whole-map erosion, each bit-exact against the oracle.  (mesh_seed stays >= 1: seed 0 continues the
+    function-static generator of gen_rand_sine_table_entries, whose state depends on every earlier init of the process -- the context and the oracle
+    have different histories inside a test session.)"""
     for seed in seeds:
         rng = np.random.default_rng(1000 + seed)
         mode = int(rng.choice([0, 0, 1, 2, 3, 4])); shape = int(rng.choice([0, 0, 1, 2]))
@@ -498,7 +500,7 @@ def case_random_configs(pkg, t, orc, seeds, big=False):
         if rng.random() < 0.4: lo = float(rng.uniform(-1, 1)); hm[6:9] = [lo, lo + float(rng.uniform(0.05, 1)), float(rng.uniform(0, 2))]           # cracks
         if rng.random() < 0.6: hm[9:12] = [float(rng.uniform(0.5, 6)), float(rng.uniform(0.0005, 0.01)), float(rng.uniform(-5, 1))]                # islands
         if rng.random() < 0.3 and hm[9] > 0: hm[12:14] = [float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.5, 3))]                               # volcano
-        kw = dict(mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_seed=int(rng.integers(0, 50)), mesh_freq_filter=int(rng.integers(0, 4)), hmap=hm,
+        kw = dict(mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_seed=int(rng.integers(1, 50)), mesh_freq_filter=int(rng.integers(0, 4)), hmap=hm,
                   glaciate=int(rng.random() < 0.85), mesh_scale=float(rng.choice([1.0, 1.0, 0.5, 2.0, 1.37])), mesh_height=float(rng.uniform(0.3, 1.5)),
                   erode_amount=float(rng.choice([1.0, 1.0, 0.4, 2.5])))
         pc_, oc = cfg_pair(pkg, **kw)
