@@ -32,6 +32,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_post, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
 	}
@@ -201,9 +202,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
-		if (simple_kernels) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;}
+		if (simple_kernels || ((uintptr_t)z & 15)) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;} // the LDS staging reads 16 bytes at a time
 		use();
-		hipLaunchKernelGGL(terra::k_tile_post, dim3(n), dim3(256), 0, stream, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);
+		hipLaunchKernelGGL(terra::k_tile_post, dim3(n), dim3(terra::TP_THREADS), 130*130*sizeof(float), stream, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {

@@ -323,37 +323,45 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 	for (int off = 32; off > 0; off >>= 1) {int const o = __shfl_down(v, off, 64); v = (o < v) ? o : v;}
 	return v;
 }
-__global__ __launch_bounds__(256) void k_tile_post(tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, terra_tile_stats *__restrict__ stats,
+constexpr unsigned TP_THREADS = 512;
+__global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, terra_tile_stats *__restrict__ stats,
 	uint8_t *__restrict__ normals, float *__restrict__ min_nz, float wpz_max, float rad_c, float dxv, float dyv, float dxy)
 {
-	// every reduction is folded per lane, then per wave (shuffles), and only then touches LDS: 4 atomics per wave and quantity instead of
-	// several per cell (on an ocean tile every cell is below the water plane and hammered the same four bbox words)
+	// The tile (130 x 130 floats, 67.6 KB) is staged in LDS with one round of 16-byte loads: every later read (16 sub-block scans, three cells per
+	// normal) is then an LDS read instead of a dependent global load.  Every reduction is folded per lane, then per wave (shuffles), and only then
+	// touches LDS: 4 atomics per wave and quantity instead of several per cell (on an ocean tile every cell is below the water plane and hammered the
+	// same four bbox words).
+	extern __shared__ __attribute__((aligned(16))) float tp_z[];
 	__shared__ uint32_t s_lo[16], s_hi[16], s_mnz;
 	__shared__ int s_bb[4];
 	unsigned const t = blockIdx.x, tid = threadIdx.x, zv = 130, stride = 129, bs = 32;
 	tile_ref_pod_t const r = refs[t];
 	int const x1 = r.tx*128, y1 = r.ty*128;
-	if (tid < 16) {s_lo[tid] = f2ord(100.0f); s_hi[tid] = ~f2ord(-100.0f);} // szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
+	{
+		float4 const *src = (float4 const *)(zvals + (size_t)t*zv*zv); // 67600 bytes per tile: 16-byte aligned
+		for (unsigned i = tid; i < zv*zv/4; i += TP_THREADS) {((float4 *)tp_z)[i] = src[i];}
+	}
 	if (tid == 0) {s_mnz = 0x3F800000u; s_bb[0] = x1 + 128; s_bb[1] = y1 + 128; s_bb[2] = x1; s_bb[3] = y1;} // water bbox starts denormalized
 	__syncthreads();
-	float const *z = zvals + (size_t)t*zv*zv;
+	float const *z = tp_z;
 	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) : nullptr;
 	if (stats) { // sub-block z ranges: sub-block (xx,yy) covers cells [32*xx, 32*xx + 32] x [32*yy, 32*yy + 32] (shared edges belong to both)
-		for (unsigned sbk = 0; sbk < 16; ++sbk) {
+		// each of the 8 waves scans two whole sub-blocks on its own: one shuffle reduction per sub-block and wave instead of one per sub-block for every wave
+		for (unsigned sbk = tid >> 6; sbk < 16; sbk += TP_THREADS/64) {
 			unsigned const xx = sbk & 3, yy = sbk >> 2;
 			uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
-			for (unsigned q = tid; q < (bs + 1)*(bs + 1); q += 256) {
+			for (unsigned q = tid & 63; q < (bs + 1)*(bs + 1); q += 64) {
 				unsigned const y = yy*bs + q/(bs + 1), x = xx*bs + q % (bs + 1);
 				float const v = z[y*zv + x];
 				if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;} // std::min / std::max never let a NaN win
 			}
 			lo = wave_min_u32(lo); hi = wave_min_u32(hi);
-			if ((tid & 63) == 0) {atomicMin(&s_lo[sbk], lo); atomicMin(&s_hi[sbk], hi);}
+			if ((tid & 63) == 0) {uint32_t const l0 = f2ord(100.0f), h0 = ~f2ord(-100.0f); s_lo[sbk] = (lo < l0) ? lo : l0; s_hi[sbk] = (hi < h0) ? hi : h0;} // folds start at szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
 		}
 	}
 	int bx0 = x1 + 128, by0 = y1 + 128, bx1n = -x1, by1n = -y1; // water bbox as four minima (max = -min(-v))
 	uint32_t mnz = 0x3F800000u;
-	for (unsigned p = tid; p < stride*stride; p += 256) { // cells 0..128 x 0..128: exactly the cells the 4x4 sub-blocks visit and the texels of the normal map
+	for (unsigned p = tid; p < stride*stride; p += TP_THREADS) { // cells 0..128 x 0..128: exactly the cells the 4x4 sub-blocks visit and the texels of the normal map
 		unsigned const y = p/stride, x = p - y*stride;
 		if (stats) {
 			float const v = z[y*zv + x];
