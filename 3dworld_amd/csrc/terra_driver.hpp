@@ -121,7 +121,10 @@ template<class IN, class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t co
 	bool const dim = (fabsf(c.dirx) < fabsf(c.diry));
 	double const dir_ratio = (double)(c.dirz/(dim ? c.diry : c.dirx));
 	bool inited = false;
-	shadow_pt_t cur = {0.0f, 0.0f, 0.0f};
+	// a sweep is a chain of ~2*130 dependent steps: the step is kept short.  Of the current point and of the last unshadowed point `cur` only the coordinate
+	// along the dominant light axis and the height enter shadow_z, so only those are carried (same values, same arithmetic as the reference's points)
+	float cur_d = 0.0f, cur_z = 0.0f;
+	float const org_d = dim ? -c.Y_SCENE_SIZE : -c.X_SCENE_SIZE, step_d = dim ? c.DY_VAL : c.DX_VAL; // get_yval / get_xval
 	int x = xa, y = ya, dx1 = 0, dy1 = 0, dx2 = 0, dy2 = 0;
 	if (dx < 0) {dx1 = -1; dx2 = -1;} else if (dx > 0) {dx1 = 1; dx2 = 1;}
 	if (dy < 0) {dy1 = -1;} else if (dy > 0) {dy1 = 1;}
@@ -133,19 +136,19 @@ template<class IN, class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t co
 	}
 	int numerator = longest >> 1;
 	for (int i = 0; i <= longest; i++) {
-		if (x >= 0 && y >= 0 && x < c.xsize && y < c.ysize) {
-			shadow_pt_t const pt = {-c.X_SCENE_SIZE + c.DX_VAL*(float)x, -c.Y_SCENE_SIZE + c.DY_VAL*(float)y, mh[y*c.xsize + x]};
+		if ((unsigned)x < (unsigned)c.xsize && (unsigned)y < (unsigned)c.ysize) { // x >= 0 && y >= 0 && x < xsize && y < ysize
+			float const pt_d = org_d + step_d*(float)(dim ? y : x), pt_z = mh[y*c.xsize + x];
 			float siv;
-			if (x == xa && (siv = in.y(y)) > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = siv; inited = true;} // sh_in_y != NULL && x == xa && sh_in_y[y] > MESH_MIN_Z (src/mesh.h:9)
-			else if (y == ya && (siv = in.x(x)) > -1.0E6f) {cur.x = pt.x; cur.y = pt.y; cur.z = siv; inited = true;}
-			float const shadow_z = (float)((double)((dim ? pt.y : pt.x) - (dim ? cur.y : cur.x))*dir_ratio + (double)cur.z);
-			if (inited && shadow_z > pt.z) {
+			if (x == xa && (siv = in.y(y)) > -1.0E6f) {cur_d = pt_d; cur_z = siv; inited = true;} // sh_in_y != NULL && x == xa && sh_in_y[y] > MESH_MIN_Z (src/mesh.h:9)
+			else if (y == ya && (siv = in.x(x)) > -1.0E6f) {cur_d = pt_d; cur_z = siv; inited = true;}
+			float const shadow_z = (float)((double)(pt_d - cur_d)*dir_ratio + (double)cur_z);
+			if (inited && shadow_z > pt_z) {
 				out.shadow(x, y);
 				uint32_t const order = p*1024u + (uint32_t)i + 1u; // sweeps are at most ~2*130 steps long
 				if (x == xb) {out.out_y(y, order, shadow_z);}
 				if (y == yb) {out.out_x(x, order, shadow_z);}
 			}
-			else {cur = pt;}
+			else {cur_d = pt_d; cur_z = pt_z;}
 			inited = true;
 		}
 		numerator += shortest;

@@ -33,6 +33,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_post, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
 	}
@@ -192,7 +193,12 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		d2h(&err, flags + n, 4);
 		return err == 0;
 	}
-	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np);}
+	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {
+		if (simple_kernels || ((uintptr_t)sm & 3)) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np); return;} // the block ORs its mask out a word at a time
+		use();
+		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_CHAIN_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
 	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {
 		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz); return;}
 		use();

@@ -504,6 +504,54 @@ __global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_chain(shadow_
 	if (tid == 0) {__hip_atomic_store(&done[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);}
 }
 
+// One dependency level of the tile mesh shadows: one block per tile of the level, one thread per sweep.  A sweep is a chain of ~260 dependent steps, so
+// what a step costs is latency: everything it reads AND writes lives in LDS -- the tile's heights, the two incoming edge arrays (decoded), the tile's
+// shadow bytes and its two outgoing edge arrays (ordered 64-bit max, as in the other variants).  The walk touches no global memory at all; with the
+// per-step shadow atomics going to L2 a step took ~270 ns (a wave's atomics drain one after another), with global reads in the loop it also stalled on
+// `s_waitcnt vmcnt(0)` every step.  The block copies its results out at the end: it is the only writer of its tile's mask and edges.
+struct shadow_lds_in_t {
+	float const *ix, *iy; // LDS: decoded incoming edge heights (MESH_MIN_Z where there is none)
+	__device__ float x(int i) const {return ix[i];}
+	__device__ float y(int i) const {return iy[i];}
+};
+struct shadow_lds_out_t {
+	uint8_t *sm; unsigned long long *ox, *oy; int xsize; // all LDS
+	__device__ void shadow(int x, int y) {sm[y*xsize + x] = 0x02;} // MESH_SHADOW: every writer stores the same byte
+	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], shadow_chain_out_t::pack(order, v));}
+	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], shadow_chain_out_t::pack(order, v));}
+};
+constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130; // heights, in edges, out edges, shadow bytes = 87 660 bytes
+__global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
+	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths)
+{
+	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
+	unsigned const zv = 130, tid = threadIdx.x;
+	uint32_t const t = order[blockIdx.x];
+	int32_t const ax = adj[2*t], ay = adj[2*t + 1];
+	float const *z = zvals + (size_t)t*zv*zv;
+	float *s_in = s_sh_mh + zv*zv;
+	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv); // byte offset 68 640: 8-byte aligned
+	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
+	for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}
+	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {s_mask[i] = 0u;}
+	if (tid < 2*zv) { // in.x(i) = the y-neighbour's out_x, in.y(i) = the x-neighbour's out_y (src/tiled_mesh.cpp:676-687); earlier levels have finished
+		bool const isx = tid < zv; unsigned const i = isx ? tid : tid - zv; int32_t const a = isx ? ay : ax;
+		s_in[tid] = (a >= 0) ? shadow_chain_in_t::decode(out[((size_t)(isx ? 0 : 1)*n + a)*zv + i]) : -1.0E6f;
+		s_out[tid] = 0ull; // 0 = never written
+	}
+	__syncthreads();
+	shadow_lds_in_t const in{s_in, s_in + zv};
+	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
+	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+	__syncthreads();
+	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
+	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {uint32_t const w = s_mask[i]; if (w) {gm[i] |= w;}}
+	if (tid < 2*zv) {
+		unsigned long long const v = s_out[tid];
+		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
+	}
+}
+
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell
 // grid-stride float4 loads, wave shuffle reduction, one pair of atomics per wave.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
 __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, size_t n, uint32_t *__restrict__ d) {
