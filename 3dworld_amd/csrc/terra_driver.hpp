@@ -74,6 +74,7 @@ TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsig
 struct shadow_consts_t {
 	float X_SCENE_SIZE, Y_SCENE_SIZE, DX_VAL, DY_VAL, DX_VAL_INV, DY_VAL_INV, zmin, zmax, dist, dirx, diry, dirz;
 	int xsize, ysize;
+	uint32_t mask_fill; // what the caller pre-filled the shadow mask with, 4 bytes at a time (0, or MESH_SHADOW everywhere when the light is below the mesh)
 	TERRA_HD int xpos(float xval) const {return (int)((double)((xval + X_SCENE_SIZE)*DX_VAL_INV) + 0.5);} // get_xpos (src/mesh.h:129)
 	TERRA_HD int ypos(float yval) const {return (int)((double)((yval + Y_SCENE_SIZE)*DY_VAL_INV) + 0.5);}
 	TERRA_HD float xval(int xp) const {return -X_SCENE_SIZE + DX_VAL*(float)xp;}                           // get_xval (src/mesh.h:122)
@@ -891,7 +892,7 @@ template<class BE> struct terra_engine {
 		if ((double)lx == 0.0 && (double)ly == 0.0) return; // straight down = no mesh shadows
 		shadow_consts_t c;
 		c.X_SCENE_SIZE = cfg.scene_x; c.Y_SCENE_SIZE = cfg.scene_y; c.DX_VAL = DX_VAL; c.DY_VAL = DY_VAL; c.DX_VAL_INV = DX_VAL_INV; c.DY_VAL_INV = DY_VAL_INV;
-		c.zmin = zmin; c.zmax = zmax; c.xsize = (int)zv; c.ysize = (int)zv;
+		c.zmin = zmin; c.zmax = zmax; c.xsize = (int)zv; c.ysize = (int)zv; c.mask_fill = all_shadowed ? 0x02020202u : 0u;
 		float const lmag = sqrtf(lx*lx + ly*ly + lz*lz); // dir = -lpos.get_norm()
 		if ((double)lmag < 1.0E-12) {c.dirx = -lx; c.diry = -ly; c.dirz = -lz;} else {c.dirx = -(lx/lmag); c.diry = -(ly/lmag); c.dirz = -(lz/lmag);}
 		c.dist = (float)(2.0*(double)(cfg.mesh_x + cfg.mesh_y)/(double)sqrtf(c.dirx*c.dirx + c.diry*c.diry)); // 2.0*XY_SUM_SIZE/sqrt(...)

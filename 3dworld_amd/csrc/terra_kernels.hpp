@@ -545,7 +545,7 @@ __global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_
 	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
-	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {uint32_t const w = s_mask[i]; if (w) {gm[i] |= w;}}
+	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {gm[i] = s_mask[i] | c.mask_fill;} // plain stores: nobody else writes this tile's mask
 	if (tid < 2*zv) {
 		unsigned long long const v = s_out[tid];
 		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
