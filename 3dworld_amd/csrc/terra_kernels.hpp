@@ -196,6 +196,13 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 #pragma unroll
 	for (int i = 0; i < SG_TY; ++i) {unsigned const y = by0 + (i >> 2)*64 + ty*4 + (i & 3); smyv[i] = (job.use_sine_mag && y < job.ny) ? smy[y] : 0.0f;}
 	float fmn = INFINITY, fmx = -INFINITY;
+	unsigned t_ux[2] = {0, 0}, t_cx[2] = {0, 0}, t_uy[4] = {0, 0, 0, 0}, t_cy[4] = {0, 0, 0, 0}; // TILES: tile column / row and offset of the thread's two 4-cell groups and four 4-row groups
+	if (TILES) {
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {unsigned const x = bx0 + half*64 + tx*4; t_ux[half] = x/tiles.tw; t_cx[half] = x - t_ux[half]*tiles.tw;}
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {unsigned const y = by0 + g*64 + ty*4; t_uy[g] = y/tiles.tw; t_cy[g] = y - t_uy[g]*tiles.tw;}
+	}
 #pragma unroll
 	for (int i = 0; i < SG_TY; ++i) {
 		unsigned const y = by0 + (i >> 2)*64 + ty*4 + (i & 3);
@@ -226,12 +233,15 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 				v[j] = z;
 				if (x + j < job.nx) {fmn = fminf(fmn, z); fmx = fmaxf(fmx, z);} // fminf/fmaxf skip NaNs, like min_eq/max_eq never let a NaN win
 			}
-			if (TILES) {
-				unsigned const tw = tiles.tw, uy = y/tw, cy = y - uy*tw;
+			if (TILES) { // scatter into the per-tile layout: tile column / row and the offsets inside come from the thread's precomputed bases (no division per cell)
+				unsigned const tw = tiles.tw;
+				unsigned uy = t_uy[i >> 2], cy = t_cy[i >> 2] + (unsigned)(i & 3);
+				if (cy >= tw) {cy -= tw; ++uy;}
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					if (x + j >= job.nx) continue;
-					unsigned const ux = (x + j)/tw, cx = (x + j) - ux*tw;
+					unsigned ux = t_ux[half], cx = t_cx[half] + (unsigned)j;
+					if (cx >= tw) {cx -= tw; ++ux;}
 					int const t = tiles.tile_map[uy*tiles.nux + ux];
 					if (t >= 0) {out[(size_t)t*tw*tw + cy*tw + cx] = v[j];}
 				}
