@@ -1192,13 +1192,13 @@ template<class BE> struct terra_engine {
 		size_t const nvox = (size_t)nx*ny*nz;
 		sin_lut_t const L = lut();
 		if (gen_mode == MGEN_SINE) {
-			// noise_gen_3d::gen_sines (src/upsurface.cpp:16-38) on the host: 420 floats
-			std::vector<float> rdata(VOX_SINES*VOX_PARAMS);
+			// noise_gen_3d::gen_sines (src/upsurface.cpp:16-38) on the host: 420 floats, handed to the table kernel by value (kernel argument, no upload)
+			struct vox_rdata_t {float v[VOX_SINES*VOX_PARAMS];} rd;
 			rand_gen_t r; r.set_state(rs1, rs2);
 			float m = mag, f = freq;
 			for (unsigned i = 0; i < 5; ++i) {
 				for (unsigned j = 0; j < 12; ++j) {
-					float *p = &rdata[VOX_PARAMS*(12*i + j)];
+					float *p = &rd.v[VOX_PARAMS*(12*i + j)];
 					p[0] = r.rand_uniform(0.2f, 1.0f)*m;
 					p[1] = r.rand_uniform(0.1f, 1.0f)*f; p[2] = (float)(r.randd()*(double)two_pi);
 					p[3] = r.rand_uniform(0.1f, 1.0f)*f; p[4] = (float)(r.randd()*(double)two_pi);
@@ -1206,21 +1206,24 @@ template<class BE> struct terra_engine {
 				}
 				m *= 0.5f; f /= 0.4f; // M_ATTEN_FACTOR, F_ATTEN_FACTOR (src/upsurface.cpp:10-11)
 			}
-			// gen_xyz_vals (src/upsurface.cpp:41-57): val accumulates `val += step` sequentially, so positions are prefix sums computed on the host
-			uint32_t const dims[3] = {nx, ny, nz};
-			std::vector<float> pos((size_t)nx + ny + nz);
-			size_t o = 0;
-			for (unsigned d = 0; d < 3; ++d) {float val = lo[d] + off[d]; for (uint32_t i = 0; i < dims[d]; ++i) {pos[o++] = val; val += vsz[d];}}
-			size_t const ntab = ((size_t)nx + ny + nz)*VOX_SINES;
-			float *d_base = scratch<float>(s_vox, ntab + pos.size() + rdata.size() + 64);
-			float *d_tab = d_base, *d_pos = d_base + ntab, *d_rd = d_pos + pos.size();
-			be.h2d(d_pos, pos.data(), pos.size()*4); be.h2d(d_rd, rdata.data(), rdata.size()*4);
+			size_t const ntab = ((size_t)nx + ny + nz)*VOX_SINES, npos = (size_t)nx + ny + nz;
+			float *d_base = scratch<float>(s_vox, ntab + npos + 64);
+			float *d_tab = d_base, *d_pos = d_base + ntab;
+			// gen_xyz_vals (src/upsurface.cpp:41-57): val accumulates `val += step` sequentially, so the positions of an axis are a serial prefix sum: one thread per axis
+			float const s0 = lo[0] + off[0], s1 = lo[1] + off[1], s2 = lo[2] + off[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2];
+			be.launch(3, [=] TERRA_LAMBDA (size_t d) {
+				float val = (d == 0) ? s0 : ((d == 1) ? s1 : s2);
+				float const step = (d == 0) ? v0 : ((d == 1) ? v1 : v2);
+				uint32_t const cnt = (d == 0) ? nx : ((d == 1) ? ny : nz);
+				float *o = d_pos + ((d == 0) ? (size_t)0 : ((d == 1) ? (size_t)nx : (size_t)nx + ny));
+				for (uint32_t i = 0; i < cnt; ++i) {o[i] = val; val += step;}
+			});
 			be.launch(ntab, [=] TERRA_LAMBDA (size_t i) {
 				size_t const e = i / VOX_SINES; unsigned const k = (unsigned)(i % VOX_SINES);
 				unsigned const d = (e < nx) ? 0u : ((e < (size_t)nx + ny) ? 1u : 2u);
 				unsigned const index2 = VOX_PARAMS*k + 2*d;
-				float v = L.SINF(d_rd[index2+1]*d_pos[e] + d_rd[index2+2]);
-				if (d == 0) {v *= d_rd[index2];}
+				float v = L.SINF(rd.v[index2+1]*d_pos[e] + rd.v[index2+2]);
+				if (d == 0) {v *= rd.v[index2];}
 				d_tab[i] = v;
 			});
 			be.voxel_sines(d_out, nx, ny, nz, d_tab, zscale, normalize);
