@@ -14,8 +14,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool simple_kernels = false; // TERRA_SIMPLE_KERNELS=1: run the one-thread-per-cell cross-check kernels instead of the LDS-tiled ones
 	float *tile_pad = nullptr; size_t tile_pad_bytes = 0;
+	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
-	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as one chained launch (k_tile_shadows_chain) instead of one launch per dependency level; measured slightly slower (11.0 vs 10.0 ms for 64x64 tiles: a sweep is ~40-50 us of dependent steps either way), kept as an option
+	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as one chained launch (k_tile_shadows_chain) instead of one launch per dependency level; measured slightly slower (11.0 vs 10.0 ms with the first per-level kernel for 64x64 tiles: a sweep is ~40-50 us of dependent steps either way), kept as an option
 	unsigned sg_rowgroup = 4; // TERRA_SG_ROWGROUP: tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
 	static int device_count() {int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n;}
@@ -39,6 +40,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	~hip_backend_t() {
 		if (tile_pad) (void)hipFree(tile_pad);
+		if (tile_order) (void)hipFree(tile_order);
 		if (tile_map) (void)hipFree(tile_map);
 		if (vox_p) (void)hipFree(vox_p);
 		if (ev0) (void)hipEventDestroy(ev0);
@@ -228,7 +230,22 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			else {tile_erosion_windowed(n, zvals, ec, iters, tile_pad);}
 			return;
 		}
-		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters);
+		uint32_t const *d_order = nullptr;
+		if (n > 512 && (uint64_t)n*iters >= (1u << 16)) { // more tiles than the chip holds at once (2 per CU): longest predicted chains first
+			size_t const bytes = (size_t)n*2*sizeof(uint32_t);
+			if (bytes > tile_order_bytes) {if (tile_order) {sync(); (void)hipFree(tile_order);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_order, bytes)); tile_order_bytes = bytes;}
+			uint32_t *d_land = tile_order, *d_ord = tile_order + n;
+			fill32(d_land, 0, n);
+			hipLaunchKernelGGL(terra::k_tile_land_cells, dim3(n), dim3(256), 0, stream, zvals, (uint32_t)(ec.xsize*ec.ysize), ec.water_thresh, d_land);
+			TERRA_HIP_CHECK(hipGetLastError());
+			std::vector<uint32_t> land(n), ord(n);
+			d2h(land.data(), d_land, (size_t)n*4);
+			for (uint32_t i = 0; i < n; ++i) {ord[i] = i;}
+			std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {return land[a] > land[b];});
+			h2d(d_ord, ord.data(), (size_t)n*4);
+			d_order = d_ord;
+		}
+		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters, d_order);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void minmax(float const *vals, size_t n, uint32_t *d) {

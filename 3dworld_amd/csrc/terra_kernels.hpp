@@ -300,10 +300,21 @@ template<int MODE> __global__ __launch_bounds__(256) void k_noise_tiles(tile_ref
 }
 
 // ------------------------------------------------------------------ K5 tile mode: LDS-resident padded grid, serial droplets
-__global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters) {
+// how much of a tile is land: droplets that start under water stop at once, the others walk ~50 steps, so this predicts a tile's serial chain length
+__global__ __launch_bounds__(256) void k_tile_land_cells(float const *__restrict__ zvals, uint32_t cells, float water_thresh, uint32_t *__restrict__ land) {
+	float const *z = zvals + (size_t)blockIdx.x*cells;
+	uint32_t cnt = 0;
+	for (uint32_t i = threadIdx.x; i < cells; i += 256) {cnt += (z[i] >= water_thresh) ? 1u : 0u;}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {cnt += __shfl_down(cnt, off, 64);}
+	if ((threadIdx.x & 63) == 0 && cnt) {atomicAdd(&land[blockIdx.x], cnt);}
+}
+// `order` (or null): the tile each block takes.  Blocks are dispatched in index order and only two tiles fit a CU, so the batch is a list-scheduling
+// problem: handing out the longest chains first keeps the heavy land tiles from forming the tail of the launch.
+__global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters, uint32_t const *__restrict__ order) {
 	extern __shared__ __attribute__((aligned(16))) float te_pad[];
 	int const NX = ec.NX, NY = ec.NY, xs = ec.xsize, ys = ec.ysize;
-	float *z = zvals + (size_t)blockIdx.x*xs*ys;
+	float *z = zvals + (size_t)(order ? order[blockIdx.x] : blockIdx.x)*xs*ys;
 	for (int i = threadIdx.x; i < NX*NY; i += 64) { // clamp-padded copy (src/erosion.cpp:31-37), coalesced rows
 		int const X = i % NX, Z = i / NX;
 		te_pad[i] = z[(size_t)imax(imin(Z - EROSION_PAD, ys-1), 0)*xs + imax(imin(X - EROSION_PAD, xs-1), 0)];

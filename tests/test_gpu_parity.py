@@ -239,3 +239,18 @@ def test_tiles_batch_64x64_properties(pkg, gpu, orc):
 @pytest.mark.parametrize("block", [0, 1])
 def test_random_configs(pkg, gpu, orc, block):
     pc.case_random_configs(pkg, gpu, orc, range(block * 7, block * 7 + 7), big=True)
+
+
+def test_tile_erosion_large_batch_launch_order(pkg, gpu, orc):
+    """more tiles than fit the chip at once: the erosion kernel hands tiles out longest-predicted-chain first (a permutation of the launch, not of
+    the results) -- every tile still equals the oracle's, land and ocean tiles alike"""
+    pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
+    gpu.init_scene(pc_); orc.init(oc)
+    tiles = [(tx, ty) for ty in range(-13, 13) for tx in range(-12, 12)]  # 624 tiles
+    iters = 110
+    z, st, _, _ = gpu.tiles_create_zvals(tiles, iters)
+    rng = np.random.default_rng(3)
+    for i in rng.choice(len(tiles), 60, replace=False):
+        zo, so = orc.tile_create_zvals(tiles[i][0], tiles[i][1], iters)
+        assert_bit_equal(z[i], zo, f"tile {tiles[i]}")
+        assert bytes(st[i]) == bytes(so)
