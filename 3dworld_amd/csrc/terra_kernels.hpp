@@ -419,11 +419,11 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 }
 
 // ------------------------------------------------------------------ row f1: tile AO lighting (tile_t::calc_mesh_ao_lighting, src/tiled_mesh.cpp:634-659)
-// One block = one band of AO_BAND texel rows of one tile.  The context rows the rays of the band can reach are staged in LDS in two passes:
+// One block = one band of AO_BAND texel rows of one tile (33: four bands cover the 129 rows; with 32 a fifth block staged 74 context rows for one texel row).  The context rows the rays of the band can reach are staged in LDS in two passes:
 // rays going up or sideways need context rows [y0, y0 + band + 35], rays going down rows [y0 + 36, y0 + band + 71] (context coordinates =
 // texel + 36) -- 68 rows x 201 floats = 54.7 KB each time, so two blocks share a CU.  A thread owns up to 17 texels and keeps their
 // attenuation sums in registers across the passes.  Same integer sums as the one-thread-per-texel version (tile_ao_simple).
-constexpr unsigned AO_BAND = 32, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_PER_THREAD = (AO_BAND*AO_TEX + 255)/256;
+constexpr unsigned AO_BAND = 33, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_PER_THREAD = (AO_BAND*AO_TEX + 255)/256;
 // one ray, branch-free: the eight samples sit at fixed offsets 1,3,6,...,36 steps from the texel (immediate ds_read offsets after unrolling),
 // are all requested before the first compare, and the first hit is selected backwards (hit at step s attenuates by 8 - s)
 template<int DX, int DY> __device__ __forceinline__ unsigned ao_march(float const *s_base, float const (&zr)[8]) {
