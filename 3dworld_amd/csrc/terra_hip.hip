@@ -167,7 +167,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
 		}
-		if (simple_kernels || md != terra::MGEN_SINE || !unique_tiles || (uint64_t)n*2 < (uint64_t)nux*nuy) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate); return;}
+		if (simple_kernels || md != terra::MGEN_SINE || !unique_tiles || (uint64_t)n*2 < (uint64_t)nux*nuy || ((uintptr_t)zvals & 7)) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate); return;}
 		use();
 		size_t const cnt = (size_t)nux*nuy;
 		if (cnt > tile_map_count) {if (tile_map) {sync(); (void)hipFree(tile_map);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_map, cnt*sizeof(int32_t))); tile_map_count = cnt;}

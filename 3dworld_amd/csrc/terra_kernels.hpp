@@ -237,6 +237,17 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 				unsigned const tw = tiles.tw;
 				unsigned uy = t_uy[i >> 2], cy = t_cy[i >> 2] + (unsigned)(i & 3);
 				if (cy >= tw) {cy -= tw; ++uy;}
+				if ((tw & 1u) == 0) { // even tile width (130): x is a multiple of 4, so cell pairs (j, j+1) share a tile row and are 8-byte aligned there
+#pragma unroll
+					for (int j = 0; j < 4; j += 2) {
+						if (x + j >= job.nx) continue; // nx = nux*tw is even as well: the pair is inside or outside together
+						unsigned ux = t_ux[half], cx = t_cx[half] + (unsigned)j;
+						if (cx >= tw) {cx -= tw; ++ux;}
+						int const t = tiles.tile_map[uy*tiles.nux + ux];
+						if (t >= 0) {*(float2 *)(out + (size_t)t*tw*tw + cy*tw + cx) = make_float2(v[j], v[j + 1]);}
+					}
+					continue;
+				}
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					if (x + j >= job.nx) continue;
