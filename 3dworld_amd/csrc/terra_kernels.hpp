@@ -564,7 +564,8 @@ __global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_
 	float *s_in = s_sh_mh + zv*zv;
 	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv); // byte offset 68 640: 8-byte aligned
 	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
-	for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}
+	if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}} // 67 600 bytes per tile
+	else {for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}}
 	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {s_mask[i] = 0u;}
 	if (tid < 2*zv) { // in.x(i) = the y-neighbour's out_x, in.y(i) = the x-neighbour's out_y (src/tiled_mesh.cpp:676-687); earlier levels have finished
 		bool const isx = tid < zv; unsigned const i = isx ? tid : tid - zv; int32_t const a = isx ? ay : ax;
