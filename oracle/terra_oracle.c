@@ -27,7 +27,6 @@ static float TWO_PI_F;                                      /* float const TWO_P
 #define TSIZE (1 << TBITS)                                  /* src/sinf.h:8 */
 static float const W_PLANE_Z = 0.42f, MESH_SCALE_FACTOR = 0.0007f, DEF_GLACIATE_EXP = 3.0f; /* src/mesh_gen.cpp:19,23,26 */
 static float const FAR_DISTANCE = 100.0f, TOLERANCE_F = 1.0E-12f, DEF_TEMPERATURE = 20.0f; /* src/3DWorld.h:116,50,87 */
-static float const CLOUD_CEILING0 = 1.5f;                   /* src/3DWorld.h:74 */
 
 static inline float fmin_std(float a, float b) {return (b < a) ? b : a;} /* std::min */
 static inline float fmax_std(float a, float b) {return (a < b) ? b : a;} /* std::max */
