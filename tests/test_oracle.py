@@ -336,3 +336,63 @@ def test_libm_sincosf_is_not_correctly_rounded_but_reproducible():
     a = (0.000001 * np.arange(0, 1000000, 50)).astype(np.float32) * two_pi
     diff = sum(np.float32(m.cosf(float(v))) != np.float32(np.cos(np.float64(v))) for v in a)
     assert diff > 0  # ~2.6% on glibc 2.35
+
+
+@pytest.mark.parametrize("block", [0, 1])
+def test_oracle_vs_reference_random_configs(orc, ref, block):
+    """the fixed-seed random sweep of parity_cases.case_random_configs, oracle against the reference build: grids (arbitrary origin / spacing / size,
+    min_start_sin), tile zvals + stats + normals + AO + weights + shadows, whole-map erosion, over random modes / shapes / post-processing / island /
+    volcano parameters, scales, water levels and landscape globals"""
+    ref.set_num_threads(1)
+    try:
+        for seed in range(block * 10, block * 10 + 10):
+            rng = np.random.default_rng(7000 + seed)
+            mode = int(rng.choice([0, 0, 1, 2, 3, 4])); shape = int(rng.choice([0, 0, 1, 2]))
+            hm = list(orclib.HMAP_DEFAULT)
+            if rng.random() < 0.5: hm[0:4] = [float(rng.uniform(-1, 1.5)), float(rng.uniform(0, 1)), float(rng.uniform(0, 2)), float(rng.uniform(0, 1))]
+            if rng.random() < 0.4: hm[4:6] = [float(rng.uniform(0, 2)), float(rng.uniform(0, 3))]
+            if rng.random() < 0.4: lo = float(rng.uniform(-1, 1)); hm[6:9] = [lo, lo + float(rng.uniform(0.05, 1)), float(rng.uniform(0, 2))]
+            if rng.random() < 0.6: hm[9:12] = [float(rng.uniform(0.5, 6)), float(rng.uniform(0.0005, 0.01)), float(rng.uniform(-5, 1))]
+            if rng.random() < 0.3 and hm[9] > 0: hm[12:14] = [float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.5, 3))]
+            cfg = orclib.make_config(mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_seed=int(rng.integers(1, 50)), mesh_freq_filter=int(rng.integers(0, 4)), hmap=hm,
+                                     glaciate=int(rng.random() < 0.85), mesh_scale=float(rng.choice([1.0, 1.0, 0.5, 2.0, 1.37])), mesh_height=float(rng.uniform(0.3, 1.5)),
+                                     erode_amount=float(rng.choice([1.0, 1.0, 0.4, 2.5])))
+            cfg.water_h_off_rel = float(rng.choice([0.0, 0.0, 0.1, -0.15])); cfg.relh_adj_tex = float(rng.choice([0.0, 0.0, 0.05, -0.04])); cfg.water_h_off = float(rng.choice([0.0, 0.0, 0.2]))
+            lkw = dict(vegetation=float(rng.choice([1.0, 1.0, 0.0, 0.5])), temperature=float(rng.choice([20.0, 20.0, 48.0])), biome_x_offset=float(rng.uniform(-5, 5)),
+                       water_is_lava=int(rng.random() < 0.2), disable_water=int(rng.choice([0, 0, 2])), enable_terrain_env=int(rng.random() < 0.8),
+                       grass_density=int(rng.choice([0, 50])), num_rnd_grass_blocks=int(rng.integers(1, 33)))
+            sa, sb = ref.init(cfg), orc.init(cfg)
+            for n_ in orclib._STATE_FLOATS:
+                assert np.float32(getattr(sa, n_)).view(np.uint32) == np.float32(getattr(sb, n_)).view(np.uint32), (seed, n_)
+            for c in (ref, orc):
+                c.set_landscape(orclib.make_landscape(**lkw))
+            nx, ny = int(rng.integers(1, 160)), int(rng.integers(1, 120))
+            x0, y0 = float(rng.uniform(-5000, 5000)), float(rng.uniform(-5000, 5000))
+            dx, dy = sa.DX_VAL * float(rng.choice([1.0, 1.0, 16.0, 0.37])), sa.DY_VAL * float(rng.choice([1.0, 1.0, 80.0, 2.5]))
+            gl, mss = int(rng.random() < 0.7), int(rng.choice([0, 0, 50, 23]))
+            assert_bit_equal(ref.gen_grid(x0, y0, dx, dy, nx, ny, gl, 0, mss), orc.gen_grid(x0, y0, dx, dy, nx, ny, gl, 0, mss), f"grid seed {seed}")
+            tiles = [(int(rng.integers(-60, 60)), int(rng.integers(-60, 60)))]
+            tiles += [(tiles[0][0] + 1, tiles[0][1]), (tiles[0][0], tiles[0][1] + 1)]
+            iters = int(rng.choice([0, 0, 40, 150])); ao_flag = int(rng.random() < 0.5)
+            for c in (ref, orc):
+                c.set_tiled_mesh_ao(ao_flag)
+            za = []
+            for tx, ty in tiles:
+                a, sta = ref.tile_create_zvals(tx, ty, iters); b, stb = orc.tile_create_zvals(tx, ty, iters)
+                assert_bit_equal(a, b, f"tile zvals seed {seed} {tx},{ty}"); assert bytes(sta) == bytes(stb)
+                na, ma = ref.tile_normals(a); nb, mb = orc.tile_normals(b)
+                assert (na == nb).all() and np.float32(ma).view(np.uint32) == np.float32(mb).view(np.uint32)
+                assert (ref.tile_ao_lighting(tx, ty, a) == orc.tile_ao_lighting(tx, ty, b)).all(), (seed, "ao")
+                wa, wb = ref.tile_create_weights(tx, ty, a), orc.tile_create_weights(tx, ty, b)
+                assert (wa[0] == wb[0]).all() and wa[1].tobytes() == wb[1].tobytes() and wa[2] == wb[2], (seed, "weights")
+                za.append(a)
+            light = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(0.05, 1)))
+            assert (ref.tiles_mesh_shadows(tiles, np.stack(za), light) == orc.tiles_mesh_shadows(tiles, np.stack(za), light)).all(), (seed, "shadows")
+            n = int(rng.integers(40, 120)); d = int(rng.integers(1, 300))
+            g = orc.gen_grid(-n / 2, -n / 2, sa.DX_VAL, sa.DY_VAL, n, n, 1)
+            mz = float(g.min()) if rng.random() < 0.7 else float(g.min()) + 0.1
+            ga = ref.apply_erosion(g.copy(), mz, d); gb = orc.apply_erosion(g.copy(), mz, d)
+            assert_bit_equal(ga, gb, f"erosion seed {seed}")
+    finally:
+        for c in (ref, orc):
+            c.set_tiled_mesh_ao(0); c.set_landscape(orclib.make_landscape())
