@@ -396,3 +396,24 @@ def test_oracle_vs_reference_random_configs(orc, ref, block):
     finally:
         for c in (ref, orc):
             c.set_tiled_mesh_ao(0); c.set_landscape(orclib.make_landscape())
+
+
+def test_oracle_vs_reference_random_voxels(orc, ref):
+    """noise_gen_3d (the reference's own upsurface.cpp) and the 3-D fBm fill loop over random dimensions, origins, steps, seeds, frequency filters"""
+    rng = np.random.default_rng(2024)
+    for k in range(12):
+        ff = int(rng.integers(0, 4))
+        cfg = orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=ff, mesh_seed=int(rng.integers(1, 30)))
+        ref.init(cfg); orc.init(cfg)
+        mode = int(rng.choice([0, 0, 1, 2]))
+        nx, ny, nz = (int(rng.integers(1, 40)) for _ in range(3))
+        if mode:
+            nx, ny, nz = min(nx, 14), min(ny, 12), min(nz, 16)
+        lo = tuple(float(v) for v in rng.uniform(-5, 5, 3)); vsz = tuple(float(v) for v in rng.uniform(0.005, 0.3, 3)); off = tuple(float(v) for v in rng.uniform(-1, 1, 3))
+        mag, freq = float(rng.uniform(0.2, 2.0)), float(rng.uniform(0.3, 3.0))
+        rs1, rs2 = int(rng.integers(1, 10000)), int(rng.integers(1, 10000))
+        zscale, norm = float(rng.choice([0.0, 0.01, -0.05])), int(rng.random() < 0.7)
+        a = ref.voxel_fill(nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, mode, zscale, norm)
+        b = orc.voxel_fill(nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, mode, zscale, norm)
+        assert_bit_equal(a, b, f"voxels case {k} mode {mode} {nx}x{ny}x{nz}")
+        assert_bit_equal(ref.voxel_rdata(rs1, rs2, mag, freq), orc.voxel_rdata(rs1, rs2, mag, freq), "rdata")
