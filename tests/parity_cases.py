@@ -564,6 +564,45 @@ def case_random_configs(pkg, t, orc, seeds, big=False):
             t.set_landscape(pkg.make_landscape()); orc.set_landscape(orclib.make_landscape())
 
 
+def case_random_heightmap_textures(pkg, t, orc, cases=6):
+    """fixed-seed random heightmap textures (odd sizes, 8- / 16-bit, mesh scales either side of 1 and of the 0.75 detail threshold): tiles with stats,
+    normals and AO sampled from the texture, and the exporter, against the oracle"""
+    rng = np.random.default_rng(78)
+    bufs = []
+    try:
+        for k in range(cases):
+            ms = float(rng.choice([0.3, 0.6, 0.74, 0.75, 0.9, 1.0, 1.5, 3.0]))
+            pc_, oc = cfg_pair(pkg, mesh_gen_mode=int(rng.choice([0, 0, 1])), mesh_scale=ms)
+            t.init_scene(pc_); orc.init(oc)
+            w, h = int(rng.integers(3, 150)), int(rng.integers(3, 150))
+            nc = int(rng.choice([1, 2]))
+            pix = rng.integers(0, 256, (h, w, 2) if nc == 2 else (h, w), dtype=np.uint8)
+            mn, dzs = float(rng.uniform(-3, 0)), float(rng.uniform(0.001, 0.03))
+            buf = t.alloc(pix.nbytes).upload(pix); bufs.append(buf)
+            t.hmap_set_dev(buf.ptr, w, h, nc, mn, dzs); orc.hmap_set(pix.copy(), mn, dzs)
+            tiles = [(0, 0), (int(rng.integers(-50, 50)), int(rng.integers(-50, 50))), (int(rng.integers(-3, 3)), int(rng.integers(-3, 3)))]
+            tiles = list(dict.fromkeys(tiles))
+            z, st, nm, mnz = t.tiles_create_zvals(tiles, 25)
+            ao = t.tiles_ao_lighting(tiles, z)
+            for i, (tx, ty) in enumerate(tiles):
+                zo, so = orc.tile_create_zvals(tx, ty, 25)
+                assert_bit_equal(z[i], zo, f"hmap tile case {k} {tx},{ty} scale {ms} {w}x{h}x{nc}")
+                assert bytes(st[i]) == bytes(so)
+                no, mo = orc.tile_normals(zo)
+                assert (nm[i] == no).all() and np.float32(mnz[i]).view(np.uint32) == np.float32(mo).view(np.uint32)
+                assert (ao[i] == orc.tile_ao_lighting(tx, ty, zo)).all(), (k, tx, ty, "ao")
+            xs, ys = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
+            v, px = t.alloc(45 * 31 * 4), t.alloc(45 * 31 * 2); bufs += [v, px]
+            mn_, dz_ = t.export_heightmap_dev(xs, ys, 45, 31, v.ptr, px.ptr)
+            po, mno, dzo = orc.export_heightmap(xs, ys, 45, 31)
+            assert (px.download(np.uint8, (31, 45, 2)) == po).all() and np.float32(mn_) == mno and np.float32(dz_) == dzo, (k, "export")
+            t.hmap_set_dev(None); orc.hmap_set(None)
+    finally:
+        t.hmap_set_dev(None); orc.hmap_set(None)
+        for b in bufs:
+            b.free()
+
+
 def case_voxels_golden(pkg, t):
     G = golden()
     t.init_scene(pkg.make_config(mesh_gen_mode=0))

@@ -254,3 +254,7 @@ def test_tile_erosion_large_batch_launch_order(pkg, gpu, orc):
         zo, so = orc.tile_create_zvals(tiles[i][0], tiles[i][1], iters)
         assert_bit_equal(z[i], zo, f"tile {tiles[i]}")
         assert bytes(st[i]) == bytes(so)
+
+
+def test_random_heightmap_textures(pkg, gpu, orc):
+    pc.case_random_heightmap_textures(pkg, gpu, orc)

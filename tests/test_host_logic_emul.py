@@ -160,3 +160,7 @@ def test_api_errors(pkg, emul):
 
 def test_random_configs(pkg, emul, orc):
     pc.case_random_configs(pkg, emul, orc, range(6))
+
+
+def test_random_heightmap_textures(pkg, emul, orc):
+    pc.case_random_heightmap_textures(pkg, emul, orc)

@@ -417,3 +417,36 @@ def test_oracle_vs_reference_random_voxels(orc, ref):
         b = orc.voxel_fill(nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, mode, zscale, norm)
         assert_bit_equal(a, b, f"voxels case {k} mode {mode} {nx}x{ny}x{nz}")
         assert_bit_equal(ref.voxel_rdata(rs1, rs2, mag, freq), orc.voxel_rdata(rs1, rs2, mag, freq), "rdata")
+
+
+def test_oracle_vs_reference_random_heightmap_textures(orc, ref):
+    """terrain_hmap_manager_t (the reference's heightmap.cpp) over random image sizes (odd ones too), 8- and 16-bit pixels, mesh scales on both sides of 1
+    and of the 0.75 detail threshold: point samples far outside the image (mirror wrap), tiles with stats and AO, the exporter"""
+    rng = np.random.default_rng(77)
+    ref.set_num_threads(1)
+    try:
+        for k in range(8):
+            ms = float(rng.choice([0.3, 0.6, 0.74, 0.75, 0.9, 1.0, 1.5, 3.0]))
+            cfg = orclib.make_config(mesh_gen_mode=int(rng.choice([0, 0, 1])), mesh_scale=ms)
+            w, h = int(rng.integers(3, 150)), int(rng.integers(3, 150))
+            nc = int(rng.choice([1, 2]))
+            pix = rng.integers(0, 256, (h, w, 2) if nc == 2 else (h, w), dtype=np.uint8)
+            mn, dzs = float(rng.uniform(-3, 0)), float(rng.uniform(0.001, 0.03))
+            for c in (ref, orc):
+                c.init(cfg); c.hmap_set(pix.copy(), mn, dzs)
+            for _ in range(300):
+                x, y = int(rng.integers(-100000, 100000)), int(rng.integers(-100000, 100000))
+                assert ref.get_clamped_height(x, y) == orc.get_clamped_height(x, y), (k, x, y)
+                fx, fy = float(rng.uniform(-1e4, 1e4)), float(rng.uniform(-1e4, 1e4))
+                assert ref.hmap_interpolate_height(fx, fy) == orc.hmap_interpolate_height(fx, fy)
+                assert ref.hmap_get_nearest_height(fx, fy) == orc.hmap_get_nearest_height(fx, fy)
+            for tx, ty in ((0, 0), (int(rng.integers(-50, 50)), int(rng.integers(-50, 50)))):
+                a, sa = ref.tile_create_zvals(tx, ty, 25); b, sb = orc.tile_create_zvals(tx, ty, 25)
+                assert_bit_equal(a, b, f"hmap tile case {k} {tx},{ty} scale {ms}"); assert bytes(sa) == bytes(sb)
+                assert (ref.tile_ao_lighting(tx, ty, a) == orc.tile_ao_lighting(tx, ty, b)).all()
+            xs, ys = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
+            ea, eb = ref.export_heightmap(xs, ys, 45, 31), orc.export_heightmap(xs, ys, 45, 31)
+            assert (ea[0] == eb[0]).all() and ea[1] == eb[1] and ea[2] == eb[2], (k, "export")
+    finally:
+        for c in (ref, orc):
+            c.hmap_set(None)
