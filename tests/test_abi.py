@@ -57,3 +57,17 @@ def test_cxx_mirror_header_keeps_reference_signatures():
     """include/terra_cxx.hpp: mesh_xy_grid_cache_t::build_arrays/enable_glaciate/eval_index and apply_erosion with the reference's signatures."""
     import subprocess
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "cxx_mirror_check.cpp")], check=True)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: include/terra.h compiles as strict C99 and the structs that cross it have the documented sizes"""
+    import subprocess
+    src = tmp_path / "c_abi_check.c"
+    src.write_text('#include "terra.h"\n'
+                   'typedef char a1[(sizeof(terra_landscape) == 36) ? 1 : -1];\n'
+                   'typedef char a2[(sizeof(terra_hmap_brush) == 20) ? 1 : -1];\n'
+                   'typedef char a3[(sizeof(terra_hmap_mod) == 8) ? 1 : -1];\n'
+                   'typedef char a4[(sizeof(terra_grass_block) == 12) ? 1 : -1];\n'
+                   'typedef char a5[(sizeof(terra_tile_stats) == 160) ? 1 : -1];\n'
+                   'int main(void) {terra_ctx *c = 0; (void)c; return 0;}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], check=True)
