@@ -68,6 +68,6 @@ def test_header_is_plain_c99(tmp_path):
                    'typedef char a2[(sizeof(terra_hmap_brush) == 20) ? 1 : -1];\n'
                    'typedef char a3[(sizeof(terra_hmap_mod) == 8) ? 1 : -1];\n'
                    'typedef char a4[(sizeof(terra_grass_block) == 12) ? 1 : -1];\n'
-                   'typedef char a5[(sizeof(terra_tile_stats) == 160) ? 1 : -1];\n'
+                   'typedef char a5[(sizeof(terra_tile_stats) == 156) ? 1 : -1];\n'
                    'int main(void) {terra_ctx *c = 0; (void)c; return 0;}\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], check=True)
