@@ -111,3 +111,39 @@ def test_round_trip_and_errors(emul_t, tmp_path):
         t.heightmap_read_png(tmp_path / "crc.png")
     with pytest.raises(pkg.TerraError):
         t.heightmap_read_png(tmp_path / "missing.png")
+
+
+def test_file_parsers_survive_mutations(emul_t, tmp_path):
+    """PNG and .mod files with flipped bytes, truncations and inflated counts: the parsers either return an image / a record list or fail with a
+    TerraError -- they never crash, hang or allocate by an untrusted count (run in-process: a crash would take the test session down)"""
+    import orclib
+    pkg, t = emul_t
+    rng = np.random.default_rng(11)
+    pix = rng.integers(0, 256, (21, 19, 2), dtype=np.uint8)
+    t.heightmap_write_png(tmp_path / "ok.png", pix)
+    good_png = (tmp_path / "ok.png").read_bytes()
+    mods = orclib.make_mods([(3, 4, 100), (7, 1, -30), (0, 0, 5)]); brs = orclib.make_brushes([(1, 2, 3, 400, 4), (-7, 8, 5, -600, 2)])
+    t.hmap_write_mod(tmp_path / "ok.mod", mods, brs)
+    good_mod = (tmp_path / "ok.mod").read_bytes()
+    outcomes = {"png_ok": 0, "png_err": 0, "mod_ok": 0, "mod_err": 0}
+    for k in range(400):
+        for kind, good, reader in (("png", good_png, lambda f: t.heightmap_read_png(f, True)), ("mod", good_mod, lambda f: t.hmap_read_mod(f))):
+            data = bytearray(good)
+            op = k % 4
+            if op == 0:    # flip a few bytes
+                for _ in range(int(rng.integers(1, 4))):
+                    data[int(rng.integers(0, len(data)))] ^= int(rng.integers(1, 256))
+            elif op == 1:  # truncate
+                data = data[:int(rng.integers(0, len(data)))]
+            elif op == 2:  # overwrite a 4-byte field with a huge value (chunk length / record count)
+                o = int(rng.integers(0, max(1, len(data) - 4))); data[o:o + 4] = (0xFFFFFFF0 + int(rng.integers(0, 15))).to_bytes(4, "big" if kind == "png" else "little")
+            else:          # append garbage
+                data += bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+            f = tmp_path / f"m.{kind}"
+            f.write_bytes(bytes(data))
+            try:
+                reader(f)
+                outcomes[kind + "_ok"] += 1
+            except pkg.TerraError:
+                outcomes[kind + "_err"] += 1
+    assert outcomes["png_err"] > 100 and outcomes["mod_err"] > 50, outcomes  # most mutations are detected (CRC / signature / length checks)
