@@ -23,6 +23,10 @@ struct terra_gen { // mesh_xy_grid_cache_t (src/mesh.h:22-45)
 	bool built = false, running = false, glaciated = false, collected = false;
 	float *d_vals = nullptr; size_t d_count = 0;
 	std::vector<float> cached_vals;
+	// eval_index(x, y, min_start_sin): the sine sum starts at max(start_eval_sin, min_start_sin) (src/mesh_gen.cpp:770); the device grid was evaluated with
+	// kstart; a caller that asks for another first term gets a grid evaluated with that one (one more launch, kept per first term)
+	int kstart = 0, sev = 0, gen_mode = 0;
+	std::map<int, std::vector<float>> alt_vals;
 };
 
 #define TERRA_TRY   try {
@@ -98,21 +102,23 @@ static void terra_gen_do_collect(terra_gen *g) {
 	g->ctx->eng.be.d2h(g->cached_vals.data(), g->d_vals, g->cached_vals.size()*sizeof(float)); // blocks on the stream, like read_float_vals (src/shaders.cpp:1196-1235)
 	g->running = false; g->collected = true;
 }
-int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags) {
+int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin) {
 	if (!g) return terra::fail(TERRA_ERR_ARG, "null terra_gen");
 	try {
 		bool const no_wait = (flags & TERRA_GEN_NO_WAIT) != 0;
 		uint32_t const key = flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE);
-		bool const same = g->built && g->x0 == x0 && g->y0 == y0 && g->dx == dx && g->dy == dy && g->nx == nx && g->ny == ny && (g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE)) == key;
+		int const sev = g->ctx->eng.start_eval_sin, kstart = terra::imax(sev, min_start_sin);
+		bool const same = g->built && g->x0 == x0 && g->y0 == y0 && g->dx == dx && g->dy == dy && g->nx == nx && g->ny == ny && (g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE)) == key && g->kstart == kstart;
 		bool const was_running = g->running && same;
 		if (!was_running) { // launch the job (run_gpu_simplex, src/mesh_gen.cpp:652-681)
 			size_t const count = (size_t)nx*ny;
 			if (count == 0) return terra::fail(TERRA_ERR_ARG, "build_arrays: nx, ny must be > 0");
 			if (count > g->d_count) {if (g->d_vals) {g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);} g->d_vals = (float *)g->ctx->eng.be.alloc(count*sizeof(float)); g->d_count = count;}
 			g->x0 = x0; g->y0 = y0; g->dx = dx; g->dy = dy; g->nx = nx; g->ny = ny; g->flags = flags;
-			g->ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, 0, g->d_vals);
+			g->ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, g->d_vals);
 			g->built = true; g->running = true; g->collected = false; g->glaciated = (flags & TERRA_GEN_GLACIATE) != 0;
-			g->cached_vals.clear();
+			g->kstart = kstart; g->sev = sev; g->gen_mode = (flags & TERRA_GEN_FORCE_SINE) ? (int)terra::MGEN_SINE : g->ctx->eng.mode;
+			g->cached_vals.clear(); g->alt_vals.clear();
 		}
 		if (no_wait && !was_running) return 0; // just started, results not yet available
 		terra_gen_do_collect(g);
@@ -128,8 +134,8 @@ int terra_gen_enable_glaciate(terra_gen *g) {
 	if (g->glaciated) return TERRA_OK;
 	TERRA_TRY
 		// not fused at build time: re-evaluate with the glaciate epilogue (pure per-cell function, identical values)
-		g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags | TERRA_GEN_GLACIATE, 0, g->d_vals);
-		g->flags |= TERRA_GEN_GLACIATE; g->glaciated = true; g->running = true; g->collected = false;
+		g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags | TERRA_GEN_GLACIATE, g->kstart, g->d_vals);
+		g->flags |= TERRA_GEN_GLACIATE; g->glaciated = true; g->running = true; g->collected = false; g->alt_vals.clear();
 	TERRA_CATCH
 }
 int terra_gen_is_running(terra_gen *g) {return (g && g->running) ? 1 : 0;}
@@ -138,10 +144,33 @@ int terra_gen_collect(terra_gen *g, float *host_out) {
 	if (!g->built) return terra::fail(TERRA_ERR_STATE, "collect: nothing was built");
 	TERRA_TRY terra_gen_do_collect(g); memcpy(host_out, g->cached_vals.data(), g->cached_vals.size()*sizeof(float)); TERRA_CATCH
 }
-float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y) {
+float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_sin, int use_cache) {
 	if (!g || !g->built || x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;} // assert(x < cur_nx && y < cur_ny), src/mesh_gen.cpp:756
-	try {terra_gen_do_collect(g);} catch (std::exception const &e) {terra::fail(TERRA_ERR_HIP, e.what()); return 0.0f;}
-	return g->cached_vals[(size_t)y*g->nx + x];
+	try {
+		// which first sine term the reference would use (src/mesh_gen.cpp:759-770): cached values (cache_values at build time, filled with min_start_sin = 0)
+		// win when use_cache is set; the fBm modes have no sine terms
+		int want = g->kstart;
+		if (g->gen_mode == (int)terra::MGEN_SINE) {want = (use_cache && (g->flags & TERRA_GEN_CACHE_VALUES)) ? g->sev : terra::imax(g->sev, min_start_sin);}
+		if (want == g->kstart) {terra_gen_do_collect(g); return g->cached_vals[(size_t)y*g->nx + x];}
+		std::vector<float> &alt = g->alt_vals[want];
+		if (alt.empty()) { // same grid from another first term: one more launch, kept for the following calls
+			terra_backend_t &be = g->ctx->eng.be;
+			size_t const count = (size_t)g->nx*g->ny;
+			float *d = (float *)be.alloc(count*sizeof(float));
+			std::vector<float> tmp(count);
+			try {
+				// start_eval_sin may have moved since build_arrays(): evaluate with the value the tables were built for
+				int const sev_now = g->ctx->eng.start_eval_sin; g->ctx->eng.start_eval_sin = g->sev;
+				try {g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE), want, d);} catch (...) {g->ctx->eng.start_eval_sin = sev_now; throw;}
+				g->ctx->eng.start_eval_sin = sev_now;
+				be.d2h(tmp.data(), d, count*sizeof(float));
+			} catch (...) {be.free(d); g->alt_vals.erase(want); throw;}
+			be.free(d);
+			alt.swap(tmp);
+		}
+		return alt[(size_t)y*g->nx + x];
+	}
+	catch (std::exception const &e) {terra::fail(TERRA_ERR_HIP, e.what()); return 0.0f;}
 }
 const float *terra_gen_device_values(terra_gen *g) {return (g && g->built) ? g->d_vals : nullptr;}
 
@@ -253,6 +282,7 @@ int terra_heightmap_read_png(const char *path, int allow_two_byte_grayscale, uin
 int terra_hmap_set_dev(terra_ctx *ctx, const uint8_t *d_pixels, int width, int height, int ncolors) {
 	TERRA_CHECK_CTX
 	if (d_pixels && (width <= 0 || height <= 0 || (ncolors != 1 && ncolors != 2) || (int64_t)width*height >= (1ll << 31))) return terra::fail(TERRA_ERR_ARG, "terra_hmap_set_dev: bad image shape");
+	if (d_pixels && ncolors == 2 && ((uintptr_t)d_pixels & 1u)) return terra::fail(TERRA_ERR_ARG, "terra_hmap_set_dev: a 16-bit image must be 2-byte aligned"); // the edit kernels update a texel inside its aligned 32-bit word
 	ctx->eng.hmap_pix = d_pixels; ctx->eng.hmap_w = d_pixels ? width : 0; ctx->eng.hmap_h = d_pixels ? height : 0; ctx->eng.hmap_nc = d_pixels ? ncolors : 0;
 	return TERRA_OK;
 }

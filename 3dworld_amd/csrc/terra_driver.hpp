@@ -584,6 +584,11 @@ template<class BE> struct terra_engine {
 		return ec;
 	}
 
+	// the reference seeds droplet `iter` with (iter + 11, 79*iter + 121) in `int` (src/erosion.cpp:67-69): from iter = 27 182 813 on that is signed overflow
+	// (undefined behaviour in the reference binary), so there is nothing to be identical to -- refused instead of silently diverging
+	static constexpr uint32_t MAX_EROSION_ITERS = 27182812u;
+	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27182812 droplets (the reference's int seed 79*iter+121 overflows)");}
+
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, cap_log2 = 12, maxb = 256, bshift = 3, slice_steps = 1024, max_rounds = 4000000;} spec_cfg;
 
 	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
@@ -591,6 +596,7 @@ template<class BE> struct terra_engine {
 		report = terra_erosion_report{};
 		if (num_iters == 0 || erode_amount <= 0.0f) return; // erosion disabled (src/erosion.cpp:16)
 		if (xsize <= 0 || ysize <= 0 || (uint64_t)(xsize + 8)*(uint64_t)(ysize + 8) >= (1ull << 30)) throw std::invalid_argument("apply_erosion: bad grid size");
+		check_erosion_iters(num_iters);
 		erosion_consts_t const ec = make_erosion_consts(xsize, ysize, min_zval);
 		grid_view_t g;
 		g.interior = d_hmap; g.xsize = xsize; g.ysize = ysize; g.NX = ec.NX; g.NY = ec.NY;
@@ -862,6 +868,7 @@ template<class BE> struct terra_engine {
 		float const dxv = DX_VAL, dyv = DY_VAL;
 		// erosion: every tile alone on its clamp-padded 138x138 copy, droplets in order (src/tiled_mesh.cpp:515)
 		if (iters_tt > 0 && erode_amount > 0.0f) {
+			check_erosion_iters(iters_tt);
 			erosion_consts_t const ec = make_erosion_consts((int)zv, (int)zv, zmin);
 			be.tile_erosion(n, d_zvals, ec, iters_tt);
 		}

@@ -852,6 +852,34 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	unsigned const steps_before = (ph == SPEC_FRESH) ? 0u : sb.state[slot].numMoves;
 	mem.finish(); // the window's dirty cells go to the log: a suspended trace keeps nothing in LDS
 	mem.back.flush_block_flags();
+	// "unchanged" is decided by the content checksum; before a version is declared equal to the published one (which spares every higher droplet a
+	// re-trace) the two logs are compared entry by entry, so a checksum collision can cost time but never a wrong result.  Only the unchanged path pays.
+	{
+		uint32_t const ob = sb.cur[slot], nb = 1u - ob;
+		uint32_t const fl0 = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
+		uint64_t const chk0 = (uint64_t)ws.sh->chk ^ ((uint64_t)d.numMoves << 40);
+		bool const verify = finished && !(fl0 & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) && sb.has_ver[slot] && sb.chk[ob][slot] == chk0 && sb.blk_cnt[ob][slot] == mem.back.nblk;
+		if (TERRA_LANE0) {ws.sh->pad_ = 0;}
+		TERRA_WAVE_SYNC();
+		if (verify) {
+			uint32_t const nlog = ws.sh->nlog;
+			size_t const cap = (size_t)1 << sb.cap_log2;
+			uint32_t const *okeys = sb.log_keys[ob] + (size_t)slot*cap; float const *ovals = sb.log_vals[ob] + (size_t)slot*cap;
+			uint32_t const *nkeys = sb.log_keys[nb] + (size_t)slot*cap, *nused = sb.log_used[nb] + (size_t)slot*cap; float const *nvals = sb.log_vals[nb] + (size_t)slot*cap;
+			if (sb.log_cnt[ob][slot] != nlog) {if (TERRA_LANE0) {ws.sh->pad_ = 1;}}
+			else {
+				TERRA_LANES(e, nlog) { // this trace's log was written by the wave's own lanes in this kernel: read it through to L2
+					uint32_t const h = TERRA_L2_LOAD(&nused[e]), cell = TERRA_L2_LOAD(&nkeys[h]);
+					float const val = TERRA_L2_LOAD(&nvals[h]);
+					float vo; uint32_t a, b;
+					bool const found = spec_log_find<false>(okeys, ovals, sb.cap_log2, cell, vo);
+					memcpy(&a, &val, 4); memcpy(&b, &vo, 4);
+					if (!found || a != b) {TERRA_ATOMIC_OR(&ws.sh->pad_, 1u);}
+				}
+			}
+			TERRA_WAVE_SYNC();
+		}
+	}
 	if (TERRA_LANE0) {
 		uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
@@ -864,7 +892,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 			sb.chk[nb][slot]     = chk;
 			sb.nsteps[slot]      = d.numMoves;
 			sb.flags[slot]       = fl | (d.nan_seen ? SPEC_F_NAN : 0);
-			sb.changed[slot]     = (!sb.has_ver[slot] || sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk) ? 1u : 0u;
+			sb.changed[slot]     = (!sb.has_ver[slot] || sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk || ws.sh->pad_ != 0) ? 1u : 0u;
 			sb.phase[slot]       = failed ? (uint32_t)SPEC_FAILED : (uint32_t)SPEC_DONE_NEW;
 		}
 		else {

@@ -18,12 +18,16 @@ static_assert(sizeof(hmap_brush_pod_t) == 20 && sizeof(hmap_mod_pod_t) == 8, "mo
 // heightmap_t::modify_heightmap_value on an image other threads edit too: a compare-and-swap on the containing 32-bit word.  Within one brush every
 // delta has the sign of the brush's delta (the weights are >= 0) and saturating adds of same-signed values commute, flatten brushes store one value,
 // and the mod map has one entry per texel -- so the result does not depend on the order the threads arrive in.
+// The word is the naturally aligned one around the texel's ABSOLUTE address (a caller may hand in any 2-byte aligned sub-buffer), so the
+// compare-and-swap is always aligned; the bytes of the word that belong to other texels (or, for the first / last word of an image that does
+// not start / end on a 4-byte boundary, to whatever the caller keeps next to it) are written back unchanged.
 TERRA_HD void modify_pixel(uint8_t *pix, int ncolors, size_t ix, int val, bool is_delta) {
 	size_t const byte = (ncolors == 2) ? (ix << 1) : ix;
-	unsigned const shift = (unsigned)(byte & 3u)*8u, mask = (ncolors == 2) ? 0xFFFFu : 0xFFu;
 	int const vmax = (ncolors == 2) ? 65535 : 255;
-	uint32_t *w = (uint32_t *)(pix + (byte & ~(size_t)3));
 #if defined(__HIP_DEVICE_COMPILE__)
+	uintptr_t const a = (uintptr_t)(pix + byte);
+	unsigned const shift = (unsigned)(a & 3u)*8u, mask = (ncolors == 2) ? 0xFFFFu : 0xFFu;
+	uint32_t *w = (uint32_t *)(a & ~(uintptr_t)3);
 	uint32_t old = *w;
 	for (;;) {
 		int v = val;
@@ -35,10 +39,12 @@ TERRA_HD void modify_pixel(uint8_t *pix, int ncolors, size_t ix, int val, bool i
 		old = seen;
 	}
 #else
+	// host emulation (tests): one thread, the texel's own bytes only
 	int v = val;
-	if (is_delta) {v += (int)((*w >> shift) & mask);}
+	if (is_delta) {v += (ncolors == 2) ? ((int)pix[byte] | ((int)pix[byte + 1] << 8)) : (int)pix[byte];}
 	uint32_t const nv = (uint32_t)imax(0, imin(vmax, v));
-	*w = (*w & ~(mask << shift)) | (nv << shift);
+	pix[byte] = (uint8_t)(nv & 0xFFu);
+	if (ncolors == 2) {pix[byte + 1] = (uint8_t)(nv >> 8);}
 #endif
 }
 

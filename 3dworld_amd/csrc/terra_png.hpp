@@ -82,6 +82,9 @@ inline std::vector<uint8_t> png_read_gray(std::string const &path, uint32_t &wid
 			if (data[9] != 0 || (bit_depth != 8 && bit_depth != 16) || data[10] != 0 || data[11] != 0 || data[12] != 0 || width == 0 || height == 0) {
 				throw std::runtime_error("png_read_gray: only non-interlaced 8- or 16-bit grayscale PNGs are supported (" + path + ")");
 			}
+			// libpng refuses dimensions above its user limits (PNG_USER_WIDTH_MAX / HEIGHT_MAX = 1 000 000) and anything above 2^31 - 1; a heightmap is at most
+			// 65536 texels per side (max_tex_ix(), src/heightmap.h:42).  With that bound (row + 1)*height and width*height*2 stay far below 2^63.
+			if (width > 65536u || height > 65536u) throw std::runtime_error("png_read_gray: image dimensions above 65536 (" + path + ")");
 			have_ihdr = true;
 		}
 		else if (memcmp(type, "IDAT", 4) == 0) {idat.insert(idat.end(), data, data + len);}

@@ -109,11 +109,11 @@ _PROTOS = {
     "terra_get_max_sea_level": (_f, [_vp]),
     "terra_gen_create": (_i32, [_vp, C.POINTER(_vp)]),
     "terra_gen_destroy": (None, [_vp]),
-    "terra_gen_build_arrays": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32]),
+    "terra_gen_build_arrays": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32]),
     "terra_gen_enable_glaciate": (_i32, [_vp]),
     "terra_gen_is_running": (_i32, [_vp]),
     "terra_gen_collect": (_i32, [_vp, _vp]),
-    "terra_gen_eval_index": (_f, [_vp, _u32, _u32]),
+    "terra_gen_eval_index": (_f, [_vp, _u32, _u32, _i32, _i32]),
     "terra_gen_device_values": (_vp, [_vp]),
     "terra_gen_grid_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
     "terra_gen_grid": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
@@ -471,13 +471,13 @@ class Generator:
         self.g = g
         self.shape = None
 
-    def build_arrays(self, x0, y0, dx, dy, nx, ny, flags=0):
+    def build_arrays(self, x0, y0, dx, dy, nx, ny, flags=0, min_start_sin=0):
         self.shape = (ny, nx)
-        return self.t._ck(self.t.lib.terra_gen_build_arrays(self.g, x0, y0, dx, dy, nx, ny, flags))
+        return self.t._ck(self.t.lib.terra_gen_build_arrays(self.g, x0, y0, dx, dy, nx, ny, flags, min_start_sin))
 
     def enable_glaciate(self): self.t._ck(self.t.lib.terra_gen_enable_glaciate(self.g))
     def is_running(self): return bool(self.t.lib.terra_gen_is_running(self.g))
-    def eval_index(self, x, y): return self.t.lib.terra_gen_eval_index(self.g, x, y)
+    def eval_index(self, x, y, min_start_sin=0, use_cache=True): return self.t.lib.terra_gen_eval_index(self.g, x, y, min_start_sin, 1 if use_cache else 0)
 
     def collect(self):
         out = np.empty(self.shape, np.float32)

@@ -101,7 +101,7 @@ typedef struct terra_gen terra_gen;
 #define TERRA_GEN_GLACIATE     1u  /* enable_glaciate() after build_arrays() */
 #define TERRA_GEN_FORCE_SINE   2u  /* force_sine_mode */
 #define TERRA_GEN_NO_WAIT      4u  /* no_wait: return 0 right after launch */
-#define TERRA_GEN_CACHE_VALUES 8u  /* cache_values (accepted, no effect: every cell is always evaluated on the device) */
+#define TERRA_GEN_CACHE_VALUES 8u  /* cache_values: every cell is always evaluated on the device; the flag only decides what eval_index(.., use_cache=1) returns */
 /* flags of terra_apply_erosion*_dev */
 #define TERRA_ERODE_SERIAL        1u /* walk droplets one by one on one lane (reference order, no speculation): debugging / tiny grids */
 #define TERRA_ERODE_SERIAL_WAVE   4u /* droplets one after another, each simulated by a whole wave through the LDS window (no speculation) */
@@ -132,12 +132,17 @@ float terra_get_max_sea_level(terra_ctx *ctx);                    /* src/tiled_m
 int  terra_gen_create(terra_ctx *ctx, terra_gen **out);
 void terra_gen_destroy(terra_gen *g);                              /* ~mesh_xy_grid_cache_t / clear_context */
 /* build_arrays: returns 1 = results available, 0 = launched and not ready (only with TERRA_GEN_NO_WAIT), <0 = error.
- * Same async protocol as the GL path (src/mesh_gen.cpp:597-603): call again with the same arguments to collect. */
-int  terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags);
+ * Same async protocol as the GL path (src/mesh_gen.cpp:597-603): call again with the same arguments to collect.
+ * min_start_sin: the first sine term the caller's eval_index() calls will ask for (0 when unknown): the device grid is evaluated from
+ * max(start_eval_sin, min_start_sin), e.g. 50 for tile_t::create_texture's noise field (src/tiled_mesh.cpp:1099,1114). */
+int  terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin);
 int  terra_gen_enable_glaciate(terra_gen *g);                      /* must follow build_arrays, as in the reference */
 int  terra_gen_is_running(terra_gen *g);                           /* compute_shader_t::get_is_running (src/shaders.h:233) */
 int  terra_gen_collect(terra_gen *g, float *host_out);            /* blocks; copies nx*ny floats (cached_vals) */
-float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y);  /* eval_index on collected values (src/mesh_gen.cpp:759-761) */
+/* eval_index(x, y, min_start_sin, use_cache) (src/mesh.h:42, src/mesh_gen.cpp:754-792) on collected values.  Sine mode: the sum starts at
+ * max(start_eval_sin, min_start_sin) unless use_cache && TERRA_GEN_CACHE_VALUES was given (cached values are built with min_start_sin = 0); when that is not
+ * the first term the device grid was evaluated with, the grid is evaluated once more for it (kept until the next build).  fBm modes ignore both arguments. */
+float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_sin, int use_cache);
 const float *terra_gen_device_values(terra_gen *g);                /* device pointer to the nx*ny grid (valid until the next build) */
 
 /* one-shot: build_arrays + [enable_glaciate] + the caller's eval_index double loop (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:495-514) */
@@ -153,7 +158,8 @@ int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint
 int  terra_eval_mesh_sin_terms(terra_ctx *ctx, float xv, float yv, float *out);
 int  terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop);
 
-/* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0. */
+/* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0.
+ * num_iters (and erosion_iters_tt of the tile calls) above 27 182 812 is TERRA_ERR_ARG: the reference's `int` seed 79*iter+121 overflows there (undefined). */
 int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
@@ -197,7 +203,9 @@ int  terra_set_mesh_height_scales_for_zval_range(terra_ctx *ctx, float min_z, fl
 
 /* ---- height edits of the heightmap texture (tex_mod_map_manager_t / terrain_hmap_manager_t, src/heightmap.h:38-142, src/heightmap.cpp:27-58,99-115,216-308,
  * 414-440): brushes, the per-texel mod map and the .mod file that stores both.  The records have the reference's in-memory = on-disk layouts.
- * The *_dev calls edit the image registered with terra_hmap_set_dev in place (it must be writable device memory, at most 65536 texels per side); a brush
+ * The *_dev calls edit the image registered with terra_hmap_set_dev in place (it must be writable device memory, at most 65536 texels per side, 16-bit
+ * images 2-byte aligned; a texel is updated by a compare-and-swap on the aligned 32-bit word around it, so when the image does not start / end on a
+ * 4-byte boundary the up to 3 neighbouring bytes are re-written with their own values: nothing else may modify them during an edit call); a brush
  * point (xp, yp, sub-step) lands on texel clamp_xy(xp + dx, yp + dy) (mesh_scale, mirror wrap) and adds round_fp(delta * weight(shape, dist / radius)) with
  * clamping to the pixel range, flatten brushes store delta.  Brushes are applied in list order (apply_cur_brushes); within one brush the reference's
  * OpenMP loop order is immaterial (same-signed saturating adds commute) and so is the thread order here. */

@@ -50,16 +50,17 @@ public:
 	bool build_arrays(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, bool cache_values=0, bool force_sine_mode=0, bool no_wait=0) {
 		assert(nx > 0 && ny > 0);
 		unsigned const flags = (cache_values ? TERRA_GEN_CACHE_VALUES : 0u) | (force_sine_mode ? TERRA_GEN_FORCE_SINE : 0u) | (no_wait ? TERRA_GEN_NO_WAIT : 0u);
-		int const rc = terra_gen_build_arrays(handle(), x0, y0, dx, dy, nx, ny, flags);
+		int const rc = terra_gen_build_arrays(handle(), x0, y0, dx, dy, nx, ny, flags, 0);
 		check(rc, "build_arrays");
 		cur_nx = nx; cur_ny = ny;
 		return rc != 0;
 	}
 	void enable_glaciate() {check(terra_gen_enable_glaciate(handle()), "enable_glaciate");}
-	// min_start_sin / use_cache are accepted for source compatibility; the device always evaluates from start_eval_sin and caches every cell
-	float eval_index(unsigned x, unsigned y, int /*min_start_sin*/=0, bool /*use_cache*/=1) const {
+	// min_start_sin > start_eval_sin (tile_t::create_texture passes 50, src/tiled_mesh.cpp:1114; grass.cpp:819-820): the library evaluates the grid once more from
+	// that term on the first such call and serves the following ones from it
+	float eval_index(unsigned x, unsigned y, int min_start_sin=0, bool use_cache=1) const {
 		assert(x < cur_nx && y < cur_ny);
-		return terra_gen_eval_index(gen, x, y);
+		return terra_gen_eval_index(gen, x, y, min_start_sin, use_cache ? 1 : 0);
 	}
 	float const *device_values() const {return terra_gen_device_values(gen);} // extension: the grid stays in HBM for erosion / normals
 	void clear_context() {if (gen) {terra_gen_destroy(gen); gen = nullptr;}}

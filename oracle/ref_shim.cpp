@@ -263,6 +263,16 @@ REF_API void ref_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, u
 	}
 }
 
+REF_API void ref_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int force_sine_mode, int min_start_sin, int use_cache, float *out) {
+	mesh_xy_grid_cache_t height_gen;
+	height_gen.build_arrays(x0, y0, dx, dy, nx, ny, (cache_values != 0), (force_sine_mode != 0));
+	if (glaciate) {height_gen.enable_glaciate();}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)ny; ++y) {
+		for (unsigned x = 0; x < nx; ++x) {out[size_t(y)*nx + x] = height_gen.eval_index(x, y, min_start_sin, (use_cache != 0));}
+	}
+}
+
 REF_API void ref_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters) {apply_erosion(hmap, xsize, ysize, min_zval, iters);}
 REF_API float ref_get_noise_zval(float x, float y, int mode, int shape) {return get_noise_zval(x, y, mode, shape);}
 REF_API float ref_gen_noise(float x, float y, int mode, int shape) {return gen_noise(x, y, mode, shape);}

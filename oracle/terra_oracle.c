@@ -766,6 +766,18 @@ void orc_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, unsigned 
 	}
 	gc_free(&g);
 }
+/* the general form of the call pattern: build_arrays(..., cache_values, force_sine_mode) + eval_index(x, y, min_start_sin, use_cache)
+ * (src/mesh.h:40-42; tile_t::create_texture uses force_sine_mode = 1, min_start_sin = 50, src/tiled_mesh.cpp:1099,1114) */
+void orc_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int force_sine_mode, int min_start_sin, int use_cache, float *out) {
+	grid_cache_t g;
+	gc_build_arrays(&g, x0, y0, dx, dy, nx, ny, cache_values, force_sine_mode);
+	if (glaciate) {gc_enable_glaciate(&g);}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)ny; ++y) {
+		for (unsigned x = 0; x < nx; ++x) {out[(size_t)y*nx + x] = gc_eval_index(&g, x, y, min_start_sin, use_cache);}
+	}
+	gc_free(&g);
+}
 void orc_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters) {erosion_impl(hmap, xsize, ysize, min_zval, iters, NULL, NULL);}
 void orc_apply_erosion_stats(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet) {
 	if (st) memset(st, 0, sizeof(*st));

@@ -140,6 +140,7 @@ class Checker:
         f("num_threads", C.c_int, [])
         f("set_num_threads", None, [C.c_int])
         f("gen_grid", None, [C.c_float] * 4 + [C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        f("gen_grid_ex", None, [C.c_float] * 4 + [C.c_uint, C.c_uint] + [C.c_int] * 5 + [C.c_void_p])
         f("apply_erosion", None, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint])
         f("get_noise_zval", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
         f("gen_noise", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
@@ -214,9 +215,12 @@ class Checker:
     def sin_table(self):
         return np.array([self._sin_table(i) for i in range(65536)], np.float32)
 
-    def gen_grid(self, x0, y0, dx, dy, nx, ny, glaciate=1, cache_values=0, min_start_sin=0):
+    def gen_grid(self, x0, y0, dx, dy, nx, ny, glaciate=1, cache_values=0, min_start_sin=0, force_sine=False, use_cache=True):
         out = np.zeros((ny, nx), np.float32)
-        self._gen_grid(x0, y0, dx, dy, nx, ny, glaciate, cache_values, min_start_sin, out.ctypes.data)
+        if force_sine or not use_cache:
+            self._gen_grid_ex(x0, y0, dx, dy, nx, ny, glaciate, cache_values, int(force_sine), min_start_sin, int(use_cache), out.ctypes.data)
+        else:
+            self._gen_grid(x0, y0, dx, dy, nx, ny, glaciate, cache_values, min_start_sin, out.ctypes.data)
         return out
 
     def apply_erosion(self, hmap, min_zval, iters):

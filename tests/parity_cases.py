@@ -700,7 +700,32 @@ def case_generator_protocol(pkg, t, orc):
     gl = g.collect()
     assert_bit_equal(gl, orc.gen_grid(-64, -64, st.DX_VAL, st.DY_VAL, 130, 130, 1), "generator glaciated")
     assert g.eval_index(7, 11) == gl[11, 7]
+    assert g.eval_index(7, 11, 50) == gl[11, 7]  # fBm modes have no sine terms: min_start_sin is ignored (src/mesh_gen.cpp:762-765)
     g.close()
+    # tile_t::create_texture's noise field (src/tiled_mesh.cpp:1099,1114): build_arrays(..., 80*DX, 80*DY, 129, 129, 0, force_sine_mode=1), eval_index(x, y, 50);
+    # grass.cpp:819-820 asks the same object for two different first terms
+    for mode in (0, 1):
+        pc, oc = cfg_pair(pkg, mesh_gen_mode=mode)
+        st = t.init_scene(pc)
+        orc.init(oc)
+        g = t.generator()
+        assert g.build_arrays(-64, 64, 80 * st.DX_VAL, 80 * st.DY_VAL, 129, 129, pkg.GEN_FORCE_SINE) == 1
+        oc_full = orc.gen_grid(-64, 64, 80 * st.DX_VAL, 80 * st.DY_VAL, 129, 129, 0, 0, 0, force_sine=True)
+        oc_50 = orc.gen_grid(-64, 64, 80 * st.DX_VAL, 80 * st.DY_VAL, 129, 129, 0, 0, 50, force_sine=True)
+        oc_70 = orc.gen_grid(-64, 64, 80 * st.DX_VAL, 80 * st.DY_VAL, 129, 129, 0, 0, 70, force_sine=True)
+        assert not (oc_full == oc_50).all()
+        for (x, y) in ((0, 0), (128, 128), (17, 93), (64, 1)):
+            assert np.float32(g.eval_index(x, y, 50)) == oc_50[y, x]
+            assert np.float32(g.eval_index(x, y)) == oc_full[y, x]
+            assert np.float32(g.eval_index(x, y, 70, False)) == oc_70[y, x]
+        # the hint at build time makes the first launch the one the caller needs; other first terms still work
+        assert g.build_arrays(-64, 64, 80 * st.DX_VAL, 80 * st.DY_VAL, 129, 129, pkg.GEN_FORCE_SINE, 50) == 1
+        assert_bit_equal(g.collect(), oc_50, "generator min_start_sin 50")
+        assert np.float32(g.eval_index(5, 6, 50)) == oc_50[6, 5] and np.float32(g.eval_index(5, 6, 0)) == oc_full[6, 5]
+        # cache_values + use_cache: the cached values were built with min_start_sin = 0 and win (src/mesh_gen.cpp:759-761)
+        assert g.build_arrays(-64, 64, 80 * st.DX_VAL, 80 * st.DY_VAL, 129, 129, pkg.GEN_FORCE_SINE | pkg.GEN_CACHE_VALUES) == 1
+        assert np.float32(g.eval_index(5, 6, 50, True)) == oc_full[6, 5] and np.float32(g.eval_index(5, 6, 50, False)) == oc_50[6, 5]
+        g.close()
 
 
 def case_inject_engine_state(pkg, t, orc):
@@ -748,6 +773,9 @@ def case_api_errors(pkg, t):
     with pytest.raises(pkg.TerraError):  # enable_glaciate before build_arrays
         g.enable_glaciate()
     g.close()
+    with pytest.raises(pkg.TerraError) as e:  # 79*iter+121 overflows the reference's int from iter 27 182 813 on: undefined there, refused here
+        t.apply_erosion(np.zeros((16, 16), np.float32), 0.0, 27182813)
+    assert e.value.code == -1
     # the rows added after the first hot path
     with pytest.raises(pkg.TerraError):
         t.set_landscape(pkg.make_landscape(num_rnd_grass_blocks=0))  # would divide by zero in add_grass_block_at

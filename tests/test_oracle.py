@@ -105,6 +105,11 @@ def test_oracle_vs_reference_tus(orc, ref):
         assert bytes(sr.sinTable) == bytes(so.sinTable) and sr.zmax_est == so.zmax_est and sr.water_plane_z == so.water_plane_z and sr.clip_hd1 == so.clip_hd1
         for gl in (0, 1):
             assert_bit_equal(ref.gen_grid(-n / 2, 11, sr.DX_VAL, sr.DY_VAL, n, n - 9, gl), orc.gen_grid(-n / 2, 11, sr.DX_VAL, sr.DY_VAL, n, n - 9, gl), f"mode {mode}")
+        # mesh_xy_grid_cache_t with every argument of build_arrays / eval_index in play (force_sine_mode, cache_values, min_start_sin, use_cache)
+        for fs, cv, mss, uc in ((True, 0, 50, True), (True, 1, 50, True), (True, 1, 50, False), (False, 1, 30, False), (True, 0, 70, False)):
+            a = ref.gen_grid(-64, 64, 80 * sr.DX_VAL, 80 * sr.DY_VAL, 129, 129, 0, cv, mss, force_sine=fs, use_cache=uc)
+            b = orc.gen_grid(-64, 64, 80 * sr.DX_VAL, 80 * sr.DY_VAL, 129, 129, 0, cv, mss, force_sine=fs, use_cache=uc)
+            assert_bit_equal(a, b, f"gen_grid_ex mode {mode} {fs} {cv} {mss} {uc}")
     cfg = orclib.make_config(mesh_gen_mode=0)
     sr, so = ref.init(cfg), orc.init(cfg)
     g = ref.gen_grid(-128, -128, sr.DX_VAL, sr.DY_VAL, 256, 256, 1)

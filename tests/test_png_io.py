@@ -111,6 +111,15 @@ def test_round_trip_and_errors(emul_t, tmp_path):
         t.heightmap_read_png(tmp_path / "crc.png")
     with pytest.raises(pkg.TerraError):
         t.heightmap_read_png(tmp_path / "missing.png")
+    # a well-formed file (valid CRCs) whose IHDR declares dimensions that would wrap the size computations: must be refused before any allocation
+    import struct, zlib
+    def chunk(tp, body):
+        return struct.pack(">I", len(body)) + tp + body + struct.pack(">I", zlib.crc32(tp + body) & 0xFFFFFFFF)
+    for w, h in ((0xFFFFFFFF, 0x80000001), (65537, 1), (1, 0x7FFFFFFF), (0x10000000, 0x10000000)):
+        ihdr = struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)
+        (tmp_path / "huge.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+        with pytest.raises(pkg.TerraError):
+            t.heightmap_read_png(tmp_path / "huge.png")
 
 
 def test_file_parsers_survive_mutations(emul_t, tmp_path):
