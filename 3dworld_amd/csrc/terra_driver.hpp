@@ -566,12 +566,7 @@ template<class BE> struct terra_engine {
 		float const file_scale = dzs/(READ_MESH_H_SCALE*mesh_height_scale*mesh_scale_z_inv), file_tz = min_z/mesh_scale_z_inv;
 		float const mult = READ_MESH_H_SCALE*mesh_height_scale*file_scale*mesh_scale_z_inv, add = file_tz*mesh_scale_z_inv;
 		float const val_div = (float)(1.0/(double)mult), val_add = add;
-		be.launch(n, [=] TERRA_LAMBDA (size_t i) {
-			float const v = (d_vals[i] - val_add)*val_div;
-			uint8_t const hi = (uint8_t)v;
-			d_pix[(i<<1)+1] = hi;
-			d_pix[i<<1]     = (uint8_t)(256.0f*(v - (float)hi));
-		});
+		be.quantize16(d_vals, n, val_add, val_div, d_pix);
 	}
 
 	// ================================================================ erosion (a11)

@@ -255,6 +255,16 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipLaunchKernelGGL(terra::k_minmax, dim3(blocks), dim3(256), 0, stream, vals, n, d);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
+	void quantize16(float const *vals, size_t n, float val_add, float val_div, uint8_t *pix) {
+		size_t const n8 = ((simple_kernels || ((uintptr_t)vals & 15) || ((uintptr_t)pix & 15)) ? 0 : n/8);
+		if (n8) {
+			use();
+			if ((n8 + 255)/256 > 0x7FFFFFFFull) throw std::invalid_argument("quantize16: grid too large");
+			hipLaunchKernelGGL(terra::k_quantize16, dim3((unsigned)((n8 + 255)/256)), dim3(256), 0, stream, vals, n8, val_add, val_div, (terra::st_u4 *)pix);
+			TERRA_HIP_CHECK(hipGetLastError());
+		}
+		quantize16_simple(vals + n8*8, n - n8*8, val_add, val_div, pix + n8*16); // the tail (or everything, unaligned / cross-check)
+	}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize); return;}
 		use();

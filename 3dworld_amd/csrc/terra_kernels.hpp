@@ -586,23 +586,55 @@ __global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_
 }
 
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell
-// grid-stride float4 loads, wave shuffle reduction, one pair of atomics per wave.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
+// Every thread keeps MM_UNROLL independent 16-byte loads in flight per trip (the loop-carried state is only the running min / max), the grid is sized
+// to the chip (256 CUs x 8 blocks of 256 threads) so a 16384^2 grid is ~8 trips of 64 bytes per thread; wave shuffle reduction, then look-before-atomic
+// like the fused variant.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
+constexpr int MM_UNROLL = 4;
+typedef float    st_f4 __attribute__((ext_vector_type(4))); // native vector types: what the nontemporal load / store builtins take
+typedef uint32_t st_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void minmax_acc4(st_f4 const v, float &lo, float &hi) {
+	// fminf / fmaxf drop NaNs (v_min_f32 / v_max_f32 with IEEE mode return the non-NaN operand): the same set of values as the `v == v` filter
+	lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+	hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+}
 __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, size_t n, uint32_t *__restrict__ d) {
-	uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+	float lo = INFINITY, hi = -INFINITY;
+	bool any = false; // +-inf are legitimate values: remember whether anything but NaNs was seen
 	size_t const n4 = n/4, stride = (size_t)gridDim.x*blockDim.x;
-	for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n4; i += stride) {
-		float4 const v = ((float4 const *)vals)[i];
-		float const e[4] = {v.x, v.y, v.z, v.w};
+	st_f4 const *v4 = (st_f4 const *)vals;
+	size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	for (; i + (MM_UNROLL - 1)*stride < n4; i += MM_UNROLL*stride) {
+		st_f4 r[MM_UNROLL];
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {if (e[j] == e[j]) {uint32_t const o = f2ord(e[j]); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
-	}
-	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {float const t = vals[n4*4 + threadIdx.x]; if (t == t) {uint32_t const o = f2ord(t); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;}}
+		for (int u = 0; u < MM_UNROLL; ++u) {r[u] = __builtin_nontemporal_load(&v4[i + u*stride]);}
 #pragma unroll
-	for (int off = 32; off > 0; off >>= 1) {
-		uint32_t const l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
-		lo = (l2 < lo) ? l2 : lo; hi = (h2 < hi) ? h2 : hi;
+		for (int u = 0; u < MM_UNROLL; ++u) {minmax_acc4(r[u], lo, hi);}
 	}
-	if ((threadIdx.x & 63) == 0) {atomicMin(&d[0], lo); atomicMin(&d[1], hi);}
+	for (; i < n4; i += stride) {minmax_acc4(v4[i], lo, hi);}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {float const t = vals[n4*4 + threadIdx.x]; lo = fminf(lo, t); hi = fmaxf(hi, t);}
+	any = (lo <= hi); // false only when every value this thread saw was a NaN (or it saw none)
+	uint32_t mlo = any ? f2ord(lo) : 0xFFFFFFFFu, mhi = any ? ~f2ord(hi) : 0xFFFFFFFFu;
+	wave_minmax_publish(mlo, mhi, d);
+}
+
+// ------------------------------------------------------------------ K10: 16-bit quantise (heightmap_t::from_floats + write_pixel_16_bits, src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893)
+// HBM-bound, 4 B read + 2 B written per cell: eight cells per thread = two 16-byte loads and one 16-byte store of {fraction, integer} byte pairs
+__device__ __forceinline__ uint32_t q16_pair(float z, float val_add, float val_div) {
+	float const v = (z - val_add)*val_div;
+	uint8_t const hi = (uint8_t)v;
+	uint8_t const lo = (uint8_t)(256.0f*(v - (float)hi));
+	return (uint32_t)lo | ((uint32_t)hi << 8);
+}
+__global__ __launch_bounds__(256) void k_quantize16(float const *__restrict__ vals, size_t n8, float val_add, float val_div, st_u4 *__restrict__ pix) {
+	size_t const i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= n8) return;
+	st_f4 const a = __builtin_nontemporal_load((st_f4 const *)vals + 2*i), b = __builtin_nontemporal_load((st_f4 const *)vals + 2*i + 1);
+	st_u4 o;
+	o.x = q16_pair(a.x, val_add, val_div) | (q16_pair(a.y, val_add, val_div) << 16);
+	o.y = q16_pair(a.z, val_add, val_div) | (q16_pair(a.w, val_add, val_div) << 16);
+	o.z = q16_pair(b.x, val_add, val_div) | (q16_pair(b.y, val_add, val_div) << 16);
+	o.w = q16_pair(b.z, val_add, val_div) | (q16_pair(b.w, val_add, val_div) << 16);
+	__builtin_nontemporal_store(o, &pix[i]);
 }
 
 // ------------------------------------------------------------------ K8: voxel sine field (noise_gen_3d::get_val, src/upsurface.cpp:60-70)

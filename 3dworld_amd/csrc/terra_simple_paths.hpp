@@ -174,6 +174,15 @@ template<class DERIVED> struct simple_paths {
 			zvals[i] = max_std(ec.min_zval, padded[(size_t)t*NX*NY + (size_t)(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
 		});
 	}
+	// heightmap_t::from_floats + write_pixel_16_bits (src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893): one logical thread per cell
+	void quantize16_simple(float const *vals, size_t n, float val_add, float val_div, uint8_t *pix) {
+		self().launch(n, [=] TERRA_LAMBDA (size_t i) {
+			float const v = (vals[i] - val_add)*val_div;
+			uint8_t const hi = (uint8_t)v;
+			pix[(i<<1)+1] = hi;
+			pix[i<<1]     = (uint8_t)(256.0f*(v - (float)hi));
+		});
+	}
 	// min / max of a float array as order-preserving uints (NaNs skipped): one logical thread per 2048-element chunk
 	void minmax_simple(float const *vals, size_t n, uint32_t *d) {
 		size_t const chunk = 2048, nchunks = (n + chunk - 1)/chunk;
