@@ -244,6 +244,7 @@ template<class BE> struct terra_engine {
 	bool scene_ready = false, have_config = false;
 	std::vector<float> h_sin_table;
 	float *d_sin_table = nullptr;
+	uint32_t *d_noise_lut = nullptr; // lattice tables of the fBm kernels (terra_noise.hpp: noise_lut_fill), built once per context on the device
 	terra_erosion_report report{};
 
 	// grow-only device scratch
@@ -262,6 +263,7 @@ template<class BE> struct terra_engine {
 	~terra_engine() {
 		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
+		if (d_noise_lut) be.free(d_noise_lut);
 	}
 
 	sin_lut_t lut() const {return sin_lut_t{d_sin_table, sscale};}
@@ -286,6 +288,8 @@ template<class BE> struct terra_engine {
 		}
 		d_sin_table = (float *)be.alloc(2*TSIZE*sizeof(float));
 		be.h2d(d_sin_table, h_sin_table.data(), 2*TSIZE*sizeof(float));
+		uint32_t *nl = d_noise_lut = (uint32_t *)be.alloc(NOISE_LUT_DWORDS*sizeof(uint32_t));
+		be.launch(NOISE_LUT_DWORDS, [=] TERRA_LAMBDA (size_t i) {nl[i] = noise_lut_fill((unsigned)i);}); // the per-cell code itself fills the table: same bits by construction
 	}
 	void set_scene_constants() { // src/matrix_ops.cpp:59-84
 		MESH_HEIGHT   = 0.10f*cfg.scene_z;
@@ -506,7 +510,7 @@ template<class BE> struct terra_engine {
 			});
 			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, d_mm);
 		}
-		else {fused = be.noise_grid(job, nc, L, smx, smy, d_out, d_mm);}
+		else {fused = be.noise_grid(job, nc, L, smx, smy, d_out, d_mm, d_noise_lut);}
 		if (h_minmax) {
 			if (!fused) {be.minmax(d_out, (size_t)nx*ny, d_mm);}
 			uint32_t out[2];
@@ -811,7 +815,7 @@ template<class BE> struct terra_engine {
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw, unique_tiles, glac);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw, unique_tiles, glac, d_noise_lut);
 		return d_refs;
 	}
 

@@ -132,22 +132,22 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
-	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *mm) {
+	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *mm, uint32_t const *nlut) {
 		if (simple_kernels) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 		use();
 		dim3 const grid((job.nx + 127)/128, (job.ny + 3)/4), block(256); // 64 lanes x 2 cells per row segment, 4 rows per block
 		switch (job.mode) {
-		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
-		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
-		case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
-		default:                      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, job, nc, L, smx, smy, out, mm); break;
+		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
+		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
+		case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
+		default:                      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
 		}
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr)
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
@@ -159,10 +159,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			size_t const threads = (size_t)n*tw*((tw + 1)/2);
 			dim3 const grid((unsigned)((threads + 255)/256)), block(256);
 			switch (md) {
-			case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_PERLIN>,      grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
-			case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
-			case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
-			default:                      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw); break;
+			case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_PERLIN>,      grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
+			case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
+			case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
+			default:                      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
 			}
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;

@@ -221,6 +221,123 @@ TERRA_HD float simplex3(float vx, float vy, float vz) {
 	return 42.0f*((w[0]*dp[0] + w[1]*dp[1]) + (w[2]*dp[2] + w[3]*dp[3]));
 }
 
+// ---- lattice tables.  Everything glm's 2-D noises compute from the hashed lattice point alone is a function of one small integer:
+//   simplex: p = permute(permute(cy + oy) + cx + ox) with cx, cy in {0..288} after mod 289 and ox, oy in {0, 1}: the inner permute has 290 possible
+//            arguments, the outer one 579 (0 .. 289 + 288 + 1), and the gradient terms {a0, h, 1.79 - 0.85*(a0^2 + h^2)} depend on p only;
+//   Perlin:  h = permute(permute(cx) + cy), cx / cy in {0..288}: 289 inner arguments, 578 outer ones, {gx*norm, gy*norm} depend on h only.
+// The tables hold exactly what the per-cell code computes for each argument (filled by that code, noise_lut_fill), so a look-up returns the same
+// bits -- including the cases where permute() leaves 289 instead of 0, which is why simplex's inner table is NOT wrapped (cy + 1 = 289 is a
+// different argument from 0) while Perlin's is indexed by mod289(flx + 1).  Per lattice point ~25 instructions become one cvt + add + LDS read.
+// The look-up index is the residue r = a - floor(a*(1/289))*289 WITHOUT range fix-up where the table can absorb it: for an integer |a| < 2^22 the
+// quotient estimate is exact unless a is a multiple of 289, where it may come out one too small (RN(1/289) > 1/289 makes that the negative multiples), so
+// r is the true residue or 289 standing for 0, never negative (every integer of the range is checked by tests/emul).  Entries [289] repeat entries [0].
+// Layout in dwords: simplex part [S_I: 290 pairs {permute(r' + 0) << 4, permute(r' + 1) << 4}, r' = r mod 289][S_G: 579 x {a0, h, norm, 0}],
+// Perlin part [P_I: 292 ints = permute(v mod 289) << 3][P_G: 580 x {gx*n, gy*n}].  A kernel stages the part it needs in LDS.
+constexpr unsigned NOISE_LUT_S_I = 0, NOISE_LUT_S_G = 580, NOISE_LUT_S_DWORDS = 580 + 579*4, NOISE_LUT_P_I = 0, NOISE_LUT_P_G = 292, NOISE_LUT_P_DWORDS = 292 + 580*2;
+constexpr unsigned NOISE_LUT_DWORDS = NOISE_LUT_S_DWORDS + NOISE_LUT_P_DWORDS; // simplex part first, then the Perlin part
+static_assert((NOISE_LUT_S_DWORDS % 4) == 0 && (NOISE_LUT_P_DWORDS % 4) == 0 && (NOISE_LUT_S_G % 4) == 0 && (NOISE_LUT_P_G % 2) == 0, "16-byte rows");
+TERRA_HD uint32_t nt_bits(float f) {uint32_t u; memcpy(&u, &f, 4); return u;}
+TERRA_HD uint32_t noise_lut_fill(unsigned i) { // dword i of the table
+	if (i < NOISE_LUT_S_DWORDS) {
+		if (i < NOISE_LUT_S_G) {return (uint32_t)((int)gl_permute<float>((float)((i >> 1) % 289u) + (float)(i & 1u)) << 4);} // cy + 0.0f, cy + 1.0f for cy = r mod 289
+		unsigned const v = (i - NOISE_LUT_S_G) >> 2, c = (i - NOISE_LUT_S_G) & 3u;
+		float const C3 = 0.024390243902439f;
+		float const p = gl_permute<float>((float)v);
+		float const g = 2.0f*gl_fract(p*C3) - 1.0f, h = nt_abs(g) - 0.5f, a0 = g - nt_floor(g + 0.5f);
+		float const n = 1.79284291400159f - 0.85373472095314f*(a0*a0 + h*h);
+		return (c == 0) ? nt_bits(a0) : ((c == 1) ? nt_bits(h) : ((c == 2) ? nt_bits(n) : 0u));
+	}
+	i -= NOISE_LUT_S_DWORDS;
+	if (i < NOISE_LUT_P_G) {return (uint32_t)((int)gl_permute<float>((float)(i % 289u)) << 3);} // [r] = permute(mod289(fl)), [r + 1] = permute(mod289(fl + 1)), r in 0..289
+	unsigned const v = (i - NOISE_LUT_P_G) >> 1, c = (i - NOISE_LUT_P_G) & 1u;
+	float const h = gl_permute<float>((float)v);
+	float const g = 2.0f*gl_fract(gl_div41(h)) - 1.0f, gy = nt_abs(g) - 0.5f, gx = g - nt_floor(g + 0.5f);
+	float const n = 1.79284291400159f - 0.85373472095314f*(gx*gx + gy*gy);
+	return nt_bits(c ? gy*n : gx*n);
+}
+// residue of an integer |a| < 2^22 in {0, ..., 288} or 289 (= 0) -- see the note above; fixed: the same folded into 0 .. 288
+template<class T> TERRA_HD T gl_mod289_raw(T a) {return a - nt_floor(a*(1.0f/289.0f))*289.0f;}
+template<class T> TERRA_HD T gl_mod289_small(T a) {T const r = gl_mod289_raw(a); return nt_sel(r >= 289.0f, r - 289.0f, r);}
+TERRA_HD float nt_max0(float a) {return fmaxf(a, 0.0f);}                 // std::max(a, 0.0f) for a that is not a NaN: one v_max_f32 instead of compare + select
+TERRA_HD nv2   nt_max0(nv2 a)   {return nv2{fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f)};}
+struct nt_f4 {float x, y, z, w;};
+struct nt_f2 {float x, y;};
+struct nt_i2 {int x, y;};
+// glm::simplex(vec2) for two cells, lattice part from the table (`tab` = start of the simplex part, 16-byte aligned); falls back to simplex2_t when a
+// lattice coordinate is not an exactly representable small integer (|c| >= 2^22, inf, NaN)
+TERRA_HD nv2 simplex2_lut(nv2 vx, nv2 vy, char const *tab) {
+	float const C0 = 0.211324865405187f, C1 = 0.366025403784439f, C2 = -0.577350269189626f;
+	nv2 const one = nt_bc<nv2>(1.0f), zero = nt_bc<nv2>(0.0f);
+	nv2 const skew = vx*C1 + vy*C1;
+	nv2 const cx = nt_floor(vx + skew), cy = nt_floor(vy + skew);
+	if (TERRA_UNLIKELY(!(nt_all_below(cx, 4194304.0f) && nt_all_below(cy, 4194304.0f)))) {return simplex2_t<nv2>(vx, vy);}
+	// from here on everything is finite (cx, cy small => vx, vy small), so std::max(m, 0) is fmaxf(m, 0)
+	nv2 const unskew = cx*C0 + cy*C0;
+	nv2 const ax = vx - cx + unskew, ay = vy - cy + unskew;
+	ni2 const lower = (ax > ay);
+	nv2 const ox = nt_sel(lower, one, zero), oy = one - ox; // (1, 0) or (0, 1)
+	nv2 const bx = (ax + C0) - ox, by = (ay + C0) - oy;
+	nv2 const ex = ax + C2, ey = ay + C2;
+	nv2 const mx = gl_mod289_small(cx), ry = gl_mod289_raw(cy);
+	nv2 ma = nt_max0(0.5f - (ax*ax + ay*ay));
+	nv2 mb = nt_max0(0.5f - (bx*bx + by*by));
+	nv2 mc = nt_max0(0.5f - (ex*ex + ey*ey));
+	ma = ma*ma; mb = mb*mb; mc = mc*mc;
+	ma = ma*ma; mb = mb*mb; mc = mc*mc;
+	nt_f4 ga[2], gb[2], gc[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int const ix16 = (int)mx[e] << 4;
+		nt_i2 const si = *(nt_i2 const *)(tab + ((int)ry[e] << 3)); // {permute(cy + 0) << 4, permute(cy + 1) << 4}
+		char const *g = tab + NOISE_LUT_S_G*4 + ix16;
+		ga[e] = *(nt_f4 const *)(g + si.x);                                  // permute(cy + 0) + cx + 0
+		gb[e] = *(nt_f4 const *)(g + (lower[e] ? si.x + 16 : si.y));          // (ox, oy) = (1, 0) or (0, 1)
+		gc[e] = *(nt_f4 const *)(g + si.y + 16);                              // permute(cy + 1) + cx + 1
+	}
+	nv2 const a0a = {ga[0].x, ga[1].x}, ha = {ga[0].y, ga[1].y}, na = {ga[0].z, ga[1].z};
+	nv2 const a0b = {gb[0].x, gb[1].x}, hb = {gb[0].y, gb[1].y}, nb = {gb[0].z, gb[1].z};
+	nv2 const a0c = {gc[0].x, gc[1].x}, hc = {gc[0].y, gc[1].y}, ncc = {gc[0].z, gc[1].z};
+	ma *= na; mb *= nb; mc *= ncc;
+	nv2 const da = a0a*ax + ha*ay;
+	nv2 const db = a0b*bx + hb*by;
+	nv2 const dc = a0c*ex + hc*ey;
+	return 130.0f*(ma*da + mb*db + mc*dc);
+}
+// glm::perlin(vec2) for two cells (`tab` = start of the Perlin part)
+TERRA_HD nv2 perlin2_lut(nv2 px, nv2 py, char const *tab) {
+	nv2 const flx = nt_floor(px), fly = nt_floor(py);
+	if (TERRA_UNLIKELY(!(nt_all_below(flx, 4194304.0f) && nt_all_below(fly, 4194304.0f)))) {return perlin2_t<nv2>(px, py);}
+	nv2 const frx = px - flx, fry = py - fly;
+	nv2 const mx = gl_mod289_raw(flx), my = gl_mod289_small(fly); // = mod289(fl + 0) (x: 289 stands for 0, the table is indexed that way); mod289(fl + 1) is the next residue
+	nv2 const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
+	nt_f2 g00[2], g10[2], g01[2], g11[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int const *pi = (int const *)(tab + ((int)mx[e] << 2));
+		int const ix0 = pi[0], ix1 = pi[1]; // permute(cx0) << 3, permute(cx1) << 3 (the table wraps 289 -> 0)
+		int const iy0 = (int)my[e];
+		int iy1 = iy0 + 1; iy1 = (iy1 == 289) ? 0 : iy1;
+		char const *g0 = tab + NOISE_LUT_P_G*4 + (iy0 << 3), *g1 = tab + NOISE_LUT_P_G*4 + (iy1 << 3);
+		g00[e] = *(nt_f2 const *)(g0 + ix0); g10[e] = *(nt_f2 const *)(g0 + ix1);
+		g01[e] = *(nt_f2 const *)(g1 + ix0); g11[e] = *(nt_f2 const *)(g1 + ix1);
+	}
+	nv2 const gx00 = {g00[0].x, g00[1].x}, gy00 = {g00[0].y, g00[1].y}, gx10 = {g10[0].x, g10[1].x}, gy10 = {g10[0].y, g10[1].y};
+	nv2 const gx01 = {g01[0].x, g01[1].x}, gy01 = {g01[0].y, g01[1].y}, gx11 = {g11[0].x, g11[1].x}, gy11 = {g11[0].y, g11[1].y};
+	nv2 const d00 = gx00*fx0 + gy00*fy0;
+	nv2 const d10 = gx10*fx1 + gy10*fy0;
+	nv2 const d01 = gx01*fx0 + gy01*fy1;
+	nv2 const d11 = gx11*fx1 + gy11*fy1;
+	nv2 const ux = gl_fade(fx0), uy = gl_fade(fy0);
+	nv2 const lo = gl_mix(d00, d10, ux), hi = gl_mix(d01, d11, ux);
+	return 2.3f*gl_mix(lo, hi, uy);
+}
+// evaluator for fbm2_t / noise_zval_t: stab / ptab = the simplex / Perlin part of the table (only the one the mode uses needs to be valid)
+struct noise_tab_t {
+	char const *stab, *ptab;
+	TERRA_HD nv2 simplex(nv2 x, nv2 y) const {return simplex2_lut(x, y, stab);}
+	TERRA_HD nv2 perlin(nv2 x, nv2 y) const {return perlin2_lut(x, y, ptab);}
+};
+
 // ---- noise shaping (src/mesh_gen.cpp:555-571)
 TERRA_HD float postproc_noise_zval(float z, hmap_params_t const &h) {
 	if (z > h.plat_bot) {z = h.plat_bot + h.plat_h*(z - h.plat_bot) + min_std(h.plat_max, h.plat_s*(z - h.plat_bot));}
@@ -241,12 +358,18 @@ TERRA_HD float nt_octave_shape(float n, int shape) { // billowy / ridged octave:
 	return n;
 }
 TERRA_HD nv2 nt_octave_shape(nv2 n, int shape) {return nv2{nt_octave_shape(n[0], shape), nt_octave_shape(n[1], shape)};}
-template<bool SIMPLEX, class T> TERRA_HD T fbm2_t(T xv, T yv, int shape, unsigned end_octave, float rx, float ry) {
+// NS = how one lattice-noise sample is evaluated: noise_direct_t computes every hash and gradient (below); the grid kernels pass an evaluator that
+// looks the lattice-point part up in LDS tables (terra_kernels.hpp: noise_lds_t) -- same values, fewer instructions
+struct noise_direct_t {
+	template<class T> TERRA_HD T simplex(T x, T y) const {return simplex2_t<T>(x, y);}
+	template<class T> TERRA_HD T perlin(T x, T y) const {return perlin2_t<T>(x, y);}
+};
+template<bool SIMPLEX, class T, class NS = noise_direct_t> TERRA_HD T fbm2_t(T xv, T yv, int shape, unsigned end_octave, float rx, float ry, NS const &ns = NS()) {
 	T zval = nt_bc<T>(0.0f);
 	float mag = 1.0f, freq = 1.0f;
 	for (unsigned i = 0; i < end_octave; ++i) {
 		T const qx = freq*xv + rx, qy = freq*yv + ry;
-		T n = SIMPLEX ? simplex2_t<T>(qx, qy) : perlin2_t<T>(qx, qy);
+		T n = SIMPLEX ? ns.simplex(qx, qy) : ns.perlin(qx, qy);
 		if (shape != 0) {n = nt_octave_shape(n, shape);}
 		zval += mag*n;
 		mag  *= 0.5f;
@@ -270,21 +393,21 @@ TERRA_HD float nt_postproc(float z, hmap_params_t const &h) {return postproc_noi
 TERRA_HD nv2   nt_postproc(nv2 z, hmap_params_t const &h) {return nv2{postproc_noise_zval(z[0], h), postproc_noise_zval(z[1], h)};}
 
 // get_noise_zval (src/mesh_gen.cpp:734-751). MODE is MGEN_SIMPLEX / MGEN_PERLIN / MGEN_SIMPLEX_GPU / MGEN_DWARP_GPU.
-template<int MODE, class T> TERRA_HD T noise_zval_t(T xval, T yval, int shape, noise_consts_t const &nc) {
+template<int MODE, class T, class NS = noise_direct_t> TERRA_HD T noise_zval_t(T xval, T yval, int shape, noise_consts_t const &nc, NS const &ns = NS()) {
 	constexpr bool SIMPLEX = (MODE != MGEN_PERLIN);
 	float const xy_scale = 0.0007f*nc.mesh_scale; // MESH_SCALE_FACTOR
 	T xv = xy_scale*xval, yv = xy_scale*yval;
 	unsigned const end_octave = NUM_FREQ_COMP - nc.start_eval_sin/N_RAND_SIN2;
 	if (MODE == MGEN_DWARP_GPU) {
 		float const scale = 0.2f;
-		T const dx1 = fbm2_t<SIMPLEX, T>(nt_add_d(xv, 0.0), nt_add_d(yv, 0.0), shape, end_octave, nc.rx, nc.ry);
-		T const dy1 = fbm2_t<SIMPLEX, T>(nt_add_d(xv, 5.2), nt_add_d(yv, 1.3), shape, end_octave, nc.rx, nc.ry);
+		T const dx1 = fbm2_t<SIMPLEX, T, NS>(nt_add_d(xv, 0.0), nt_add_d(yv, 0.0), shape, end_octave, nc.rx, nc.ry, ns);
+		T const dy1 = fbm2_t<SIMPLEX, T, NS>(nt_add_d(xv, 5.2), nt_add_d(yv, 1.3), shape, end_octave, nc.rx, nc.ry, ns);
 		T const wx = xv + scale*dx1, wy = yv + scale*dy1;
-		T const dx2 = fbm2_t<SIMPLEX, T>(nt_add_d(wx, 1.7), nt_add_d(wy, 9.2), shape, end_octave, nc.rx, nc.ry);
-		T const dy2 = fbm2_t<SIMPLEX, T>(nt_add_d(wx, 8.3), nt_add_d(wy, 2.8), shape, end_octave, nc.rx, nc.ry);
+		T const dx2 = fbm2_t<SIMPLEX, T, NS>(nt_add_d(wx, 1.7), nt_add_d(wy, 9.2), shape, end_octave, nc.rx, nc.ry, ns);
+		T const dy2 = fbm2_t<SIMPLEX, T, NS>(nt_add_d(wx, 8.3), nt_add_d(wy, 2.8), shape, end_octave, nc.rx, nc.ry, ns);
 		xv += scale*dx2; yv += scale*dy2;
 	}
-	T z = fbm2_t<SIMPLEX, T>(xv, yv, shape, end_octave, nc.rx, nc.ry);
+	T z = fbm2_t<SIMPLEX, T, NS>(xv, yv, shape, end_octave, nc.rx, nc.ry, ns);
 	z = nt_postproc(z, nc.hp);
 	return z*hmap_scale(MODE, nc);
 }

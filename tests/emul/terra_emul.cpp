@@ -43,9 +43,9 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	}
 
 	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
-	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
+	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *, uint32_t const *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
-		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool /*plain_only*/, uint32_t tw, bool /*unique_tiles*/, bool glaciate = true) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate);}
+		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool /*plain_only*/, uint32_t tw, bool /*unique_tiles*/, bool glaciate = true, uint32_t const * = nullptr) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate);}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
 		// tiles cycle through the three implementations: wave-cooperative whole-tile-in-LDS (k_tile_erosion's body; lanes run sequentially here), scalar, wave + window
@@ -99,8 +99,65 @@ extern "C" unsigned long long terra_emul_noise_helper_mismatches() {
 		float const a = terra::gl_mod(v, 289.0f), b = terra::gl_mod289_int(v);
 		if (memcmp(&a, &b, 4) != 0) ++bad;
 	}
+	// the table look-ups' residue (terra_noise.hpp: gl_mod289_raw / gl_mod289_small): every integer below 2^22 in magnitude
+	for (int i = -4194304; i <= 4194304; ++i) {
+		float const v = (float)i, a = terra::gl_mod(v, 289.0f), r = terra::gl_mod289_raw(v), sm = terra::gl_mod289_small(v);
+		if (memcmp(&a, &sm, 4) != 0) ++bad;
+		if (!(r == a || (r == 289.0f && a == 0.0f))) ++bad;
+	}
 	float const special[] = {INFINITY, -INFINITY, NAN, 1e30f, -1e30f, 8388608.0f, -8388608.0f, 8388607.0f};
 	for (float v : special) {float const a = terra::gl_mod(v, 289.0f), b = terra::gl_mod289_int(v); if (memcmp(&a, &b, 4) != 0 && !(a != a && b != b)) ++bad;}
+	return bad;
+}
+
+// the table-driven lattice noise of the grid kernels (simplex2_lut / perlin2_lut over noise_lut_fill) against the direct evaluation: bit-identical
+// on random positions at every octave scale, on positions that straddle the lattice columns / rows where mod 289 wraps (cx = 288 -> 289 vs 0),
+// beyond the 2^22 switch to the direct code, and through the whole fBm / domain-warp evaluation
+extern "C" unsigned long long terra_emul_noise_lut_mismatches(unsigned n, uint32_t seed) {
+	unsigned long long bad = 0;
+	std::vector<uint32_t> tab(terra::NOISE_LUT_DWORDS + 4);
+	uint32_t *t = (uint32_t *)(((uintptr_t)tab.data() + 15) & ~(uintptr_t)15);
+	for (unsigned i = 0; i < terra::NOISE_LUT_DWORDS; ++i) {t[i] = terra::noise_lut_fill(i);}
+	terra::noise_tab_t const ns{(char const *)t, (char const *)(t + terra::NOISE_LUT_S_DWORDS)};
+	auto rnd = [&]() {seed = seed*1664525u + 1013904223u; return seed;};
+	auto rf = [&](float lo, float hi) {return lo + (hi - lo)*(float)(rnd() >> 8)*(1.0f/16777216.0f);};
+	auto same = [&](float a, float b) {return memcmp(&a, &b, 4) == 0 || (a != a && b != b);};
+	terra::noise_consts_t nc{};
+	nc.mesh_scale = 1.0f; nc.start_eval_sin = 10; nc.rx = 1.3f; nc.ry = 1.7f; nc.MESH_HEIGHT = 0.1f; nc.mesh_height_scale = 0.7f; nc.mesh_scale_z_inv = 1.0f;
+	nc.hp.plat_bot = 1000.0f; nc.hp.crat_h = 1000.0f;
+	for (unsigned i = 0; i < n; ++i) {
+		float x0, y0, x1, y1;
+		unsigned const kind = i % 6;
+		if (kind == 0) {float const s = 3e6f; x0 = rf(-s, s); x1 = rf(-s, s); y0 = rf(-s, s); y1 = rf(-s, s);}            // around the 2^22 switch
+		else if (kind == 1) {float const s = 1e8f; x0 = rf(-s, s); x1 = rf(-s, s); y0 = rf(-s, s); y1 = rf(-s, s);}       // far beyond it
+		else if (kind == 2) {                                                                                             // next to the wrap columns / rows: lattice coordinate 289*k - 1 .. 289*k + 1
+			float const kx = (float)((int)(rnd() % 41) - 20)*289.0f, ky = (float)((int)(rnd() % 41) - 20)*289.0f;
+			x0 = kx + rf(-1.5f, 1.5f); x1 = kx + rf(-1.5f, 1.5f); y0 = ky + rf(-1.5f, 1.5f); y1 = ky + rf(-1.5f, 1.5f);
+			if (i & 8) {y0 = rf(-400.0f, 400.0f);} if (i & 16) {x1 = rf(-400.0f, 400.0f);}
+		}
+		else {float const s = (kind == 3) ? 300.0f : ((kind == 4) ? 3.0f : 30000.0f); x0 = rf(-s, s); x1 = rf(-s, s); y0 = rf(-s, s); y1 = rf(-s, s);}
+		terra::nv2 const xs = {x0, x1}, ys = {y0, y1};
+		terra::nv2 const s2 = ns.simplex(xs, ys), p2 = ns.perlin(xs, ys);
+		if (!same(s2[0], terra::simplex2(x0, y0)) || !same(s2[1], terra::simplex2(x1, y1))) ++bad;
+		if (!same(p2[0], terra::perlin2(x0, y0)) || !same(p2[1], terra::perlin2(x1, y1))) ++bad;
+		if ((i & 31) == 0) {
+			int const shape = (int)(i >> 5) % 3;
+			float const sc = 1.0f/0.0007f; // grid coordinates whose noise-space image is x0, y0
+			terra::nv2 const gx = {x0*sc, x1*sc}, gy = {y0*sc, y1*sc};
+			terra::nv2 const a = terra::noise_zval_t<terra::MGEN_DWARP_GPU, terra::nv2, terra::noise_tab_t>(gx, gy, shape, nc, ns), b = terra::noise_zval_t<terra::MGEN_PERLIN, terra::nv2, terra::noise_tab_t>(gx, gy, shape, nc, ns);
+			if (!same(a[0], terra::noise_zval<terra::MGEN_DWARP_GPU>(gx[0], gy[0], shape, nc)) || !same(a[1], terra::noise_zval<terra::MGEN_DWARP_GPU>(gx[1], gy[1], shape, nc))) ++bad;
+			if (!same(b[0], terra::noise_zval<terra::MGEN_PERLIN>(gx[0], gy[0], shape, nc)) || !same(b[1], terra::noise_zval<terra::MGEN_PERLIN>(gx[1], gy[1], shape, nc))) ++bad;
+		}
+	}
+	// every hashed lattice point once, simplex and Perlin, incl. the 288 | 289 column: positions at the cell centres of a 300 x 300 lattice patch
+	for (int cy = -5; cy < 295; ++cy) {
+		for (int cx = -5; cx < 295; cx += 2) {
+			terra::nv2 const xs = {(float)cx + 0.37f, (float)(cx + 1) + 0.81f}, ys = {(float)cy + 0.29f, (float)cy + 0.63f};
+			terra::nv2 const p2 = ns.perlin(xs, ys), s2 = ns.simplex(xs, ys);
+			if (!same(p2[0], terra::perlin2(xs[0], ys[0])) || !same(p2[1], terra::perlin2(xs[1], ys[1]))) ++bad;
+			if (!same(s2[0], terra::simplex2(xs[0], ys[0])) || !same(s2[1], terra::simplex2(xs[1], ys[1]))) ++bad;
+		}
+	}
 	return bad;
 }
 

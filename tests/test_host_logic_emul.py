@@ -38,6 +38,16 @@ def test_two_cells_per_lane_noise_equals_one_cell(emul_lib):
     assert lib.terra_emul_noise_x2_mismatches(300000, 7) == 0
 
 
+def test_lattice_table_noise_equals_direct_evaluation(emul_lib):
+    """the grid kernels read the hashed-lattice-point part of glm's simplex / Perlin from a table (terra_noise.hpp: noise_lut_fill, simplex2_lut,
+    perlin2_lut): same bits as the direct evaluation on random positions, next to the mod-289 wrap columns, beyond the 2^22 switch, through fBm / domain warp"""
+    import ctypes
+    lib = ctypes.CDLL(emul_lib)
+    lib.terra_emul_noise_lut_mismatches.restype = ctypes.c_ulonglong
+    lib.terra_emul_noise_lut_mismatches.argtypes = [ctypes.c_uint, ctypes.c_uint32]
+    assert lib.terra_emul_noise_lut_mismatches(400000, 11) == 0
+
+
 def test_powf_restatement_matches_libm(emul_lib):
     """glaciate's pow(relh, custom_glaciate_exp) is libm powf in the reference; 3dworld_amd/csrc/terra_powf.hpp restates glibc's algorithm so the
     device gets the same bits (ocml powf does not).  4*10^6 arguments here, 5*10^7 when the header was written."""
