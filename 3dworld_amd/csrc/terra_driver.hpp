@@ -32,6 +32,7 @@ struct grid_job_t { // one build_arrays() + eval loop
 	int mode, shape, kstart, glaciate, use_sine_mag;
 	float sine_offset;
 	int plain_only; // sine mode: no cell can leave the short epilogue (see terra_engine::sine_plain_only): the kernel variant without finish_cell() is exact
+	uint32_t row0 = 0; // the job covers rows [row0, row0 + ny) of a taller grid (row strips of one heightmap on several GPUs): cell row y is eval_index's y + row0
 };
 
 // noise_gen_3d constants (src/upsurface.h:10-16)
@@ -54,13 +55,13 @@ TERRA_HD float sine_cell(grid_job_t const &job, float const *xt, float const *yt
 TERRA_HD float finish_cell(float z, grid_job_t const &job, noise_consts_t const &nc, sin_lut_t const &L, float const *smx, float const *smy, unsigned x, unsigned y) {
 	if (job.mode == MGEN_SINE) {z = apply_noise_shape_final(z, job.shape, nc.hp);}
 	if (job.glaciate) {
-		float const xg = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yg = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+		float const xg = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yg = ((float)(y + job.row0)*job.mdy + job.my0)*nc.DY_VAL_INV;
 		z = glaciate_epilogue(z, job.use_sine_mag ? smx[x] : 0.0f, job.use_sine_mag ? smy[y] : 0.0f, job.sine_offset, xg, yg, nc, L);
 	}
 	return z;
 }
 TERRA_HD float noise_cell(grid_job_t const &job, noise_consts_t const &nc, unsigned x, unsigned y) {
-	float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
+	float const xval = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)(y + job.row0)*job.mdy + job.my0)*nc.DY_VAL_INV;
 	switch (job.mode) {
 	case MGEN_PERLIN:      return noise_zval<MGEN_PERLIN>(xval, yval, job.shape, nc);
 	case MGEN_DWARP_GPU:   return noise_zval<MGEN_DWARP_GPU>(xval, yval, job.shape, nc);
@@ -462,11 +463,16 @@ template<class BE> struct terra_engine {
 		return (double)min_std(hp.plat_bot, hp.crat_h) > bound*1.001 + 1e-3;
 	}
 
-	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr) {
+	// row0 / nrows (optional): only rows [row0, row0 + nrows) of the nx x ny grid, written to d_out as an nrows x nx array -- every value is the one the
+	// full-grid call produces (the tables and cell coordinates use the row's index in the whole grid), so row strips evaluated on different GPUs tile the
+	// heightmap exactly (heightmap_t::proc_gen's loop is row-independent, src/heightmap.cpp:139-143)
+	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu) {
 		require_scene();
 		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
+		if (nrows == 0xFFFFFFFFu) {if (row0 != 0) throw std::invalid_argument("gen_grid rows: row0 without a row count"); nrows = ny;}
+		if (nrows == 0 || row0 >= ny || nrows > ny - row0) throw std::invalid_argument("gen_grid rows: [row0, row0 + nrows) must be a non-empty range inside the grid");
 		grid_job_t job;
-		job.mx0 = dx*x0; job.my0 = dy*y0; job.mdx = dx; job.mdy = dy; job.nx = nx; job.ny = ny;
+		job.mx0 = dx*x0; job.my0 = dy*y0; job.mdx = dx; job.mdy = dy; job.nx = nx; job.ny = nrows; job.row0 = row0; ny = nrows;
 		job.nxp = round_up(nx, 128); job.nyp = round_up(ny, 128);
 		bool const force_sine = (flags & TERRA_GEN_FORCE_SINE) != 0;
 		job.mode = force_sine ? (int)MGEN_SINE : mode; job.shape = force_sine ? 0 : shape;
@@ -487,7 +493,7 @@ template<class BE> struct terra_engine {
 			uint32_t const nxp = job.nxp, nyp = job.nyp; // zero padding up to the tile grid: the sine kernel reads whole float4 groups
 			be.launch((size_t)nxp + nyp, [=] TERRA_LAMBDA (size_t i) {
 				if (i < nxp) {smx[i] = (i < nx) ? sm_scale*L.COSF(((float)(unsigned)i*mdx + mx0)*dxi*freq) : 0.0f;}
-				else {unsigned const y = (unsigned)(i - nxp); smy[y] = (y < ny) ? L.COSF(((float)y*mdy + my0)*dyi*freq) : 0.0f;}
+				else {unsigned const y = (unsigned)(i - nxp); smy[y] = (y < ny) ? L.COSF(((float)(y + row0)*mdy + my0)*dyi*freq) : 0.0f;}
 			});
 		}
 		if (job.mode == MGEN_SINE) {
@@ -505,7 +511,7 @@ template<class BE> struct terra_engine {
 				else {
 					size_t const j = i - (size_t)F_TABLE_SIZE*nxp;
 					unsigned const k = (unsigned)(j / nyp), y = (unsigned)(j % nyp);
-					yt[j] = (y < ny) ? d_skp->yscale[k]*L.SINF(d_skp->ymdy[k]*(float)y + d_skp->yconst[k]) : 0.0f;
+					yt[j] = (y < ny) ? d_skp->yscale[k]*L.SINF(d_skp->ymdy[k]*(float)(y + row0) + d_skp->yconst[k]) : 0.0f;
 				}
 			});
 			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, d_mm);

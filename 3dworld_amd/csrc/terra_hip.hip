@@ -135,12 +135,13 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *mm, uint32_t const *nlut) {
 		if (simple_kernels) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 		use();
-		dim3 const grid((job.nx + 127)/128, (job.ny + 3)/4), block(256); // 64 lanes x 2 cells per row segment, 4 rows per block
+		dim3 const grid((job.nx + 127)/128, (job.ny + terra::NG_ROWS - 1)/terra::NG_ROWS), block(256); // 64 lanes x 2 cells per row segment, 4 rows at a time, NG_ROWS rows per block
+		terra::noise_oct_t const oc = terra::make_noise_oct(nc);
 		switch (job.mode) {
-		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
-		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
-		case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
-		default:                      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut); break;
+		case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_PERLIN>,      grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut, oc); break;
+		case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut, oc); break;
+		case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut, oc); break;
+		default:                      hipLaunchKernelGGL(terra::k_noise_grid<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, job, nc, L, smx, smy, out, mm, nlut, oc); break;
 		}
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
@@ -156,13 +157,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			terra::grid_job_t job;
 			job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = tw; job.nxp = nxpv; job.nyp = nypv;
 			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = glaciate ? 1 : 0; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so; job.plain_only = 0;
+			terra::noise_oct_t const oc = terra::make_noise_oct(nc);
 			size_t const threads = (size_t)n*tw*((tw + 1)/2);
 			dim3 const grid((unsigned)((threads + 255)/256)), block(256);
 			switch (md) {
-			case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_PERLIN>,      grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
-			case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
-			case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
-			default:                      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut); break;
+			case terra::MGEN_PERLIN:      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_PERLIN>,      grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut, oc); break;
+			case terra::MGEN_DWARP_GPU:   hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_DWARP_GPU>,   grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut, oc); break;
+			case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut, oc); break;
+			default:                      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut, oc); break;
 			}
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;

@@ -285,25 +285,30 @@ template<int MODE> __device__ __forceinline__ noise_tab_t noise_stage_lut(uint32
 	return noise_tab_t{(char const *)s_lut, (char const *)s_lut};
 }
 template<int MODE> constexpr unsigned noise_lut_dwords() {return (MODE != MGEN_PERLIN) ? NOISE_LUT_S_DWORDS : NOISE_LUT_P_DWORDS;}
+constexpr unsigned NG_ROWS = 16; // rows per block of k_noise_grid
 
 template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, uint32_t *__restrict__ mm,
-	uint32_t const *__restrict__ lut)
+	uint32_t const *__restrict__ lut, noise_oct_t oc)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lut[noise_lut_dwords<MODE>()];
 	noise_tab_t const ns = noise_stage_lut<MODE>(lut, s_lut);
-	// two neighbouring cells of a row per lane: the lattice noise runs on register pairs (v_pk_mul_f32 / v_pk_add_f32), see terra_noise.hpp
-	unsigned const x = (blockIdx.x*64 + (threadIdx.x & 63))*2, y = blockIdx.y*4 + (threadIdx.x >> 6);
+	// two neighbouring cells of a row per lane: the lattice noise runs on register pairs (v_pk_mul_f32 / v_pk_add_f32), see terra_noise.hpp.
+	// A block walks NG_ROWS rows, 4 at a time (one per wave), so the table staging is paid once per NG_ROWS x 128 cells.
+	unsigned const x = (blockIdx.x*64 + (threadIdx.x & 63))*2;
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu;
-	if (x < job.nx && y < job.ny) {
-		float const xv0 = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, xv1 = ((float)(x + 1)*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
-		nv2 const zz = noise_zval_t<MODE, nv2, noise_tab_t>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, ns);
-		float const z0 = finish_cell(zz[0], job, nc, L, smx, smy, x, y);
-		out[(size_t)y*job.nx + x] = z0;
-		minmax_acc(z0, mm_lo, mm_hi);
-		if (x + 1 < job.nx) {
-			float const z1 = finish_cell(zz[1], job, nc, L, smx, smy, x + 1, y);
-			out[(size_t)y*job.nx + x + 1] = z1;
-			minmax_acc(z1, mm_lo, mm_hi);
+	for (unsigned ry = 0; ry < NG_ROWS; ry += 4) {
+		unsigned const y = blockIdx.y*NG_ROWS + ry + (threadIdx.x >> 6);
+		if (x < job.nx && y < job.ny) {
+			float const xv0 = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, xv1 = ((float)(x + 1)*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)(y + job.row0)*job.mdy + job.my0)*nc.DY_VAL_INV;
+			nv2 const zz = noise_zval_tab<MODE>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, oc, ns);
+			float const z0 = finish_cell(zz[0], job, nc, L, smx, smy, x, y);
+			out[(size_t)y*job.nx + x] = z0;
+			minmax_acc(z0, mm_lo, mm_hi);
+			if (x + 1 < job.nx) {
+				float const z1 = finish_cell(zz[1], job, nc, L, smx, smy, x + 1, y);
+				out[(size_t)y*job.nx + x + 1] = z1;
+				minmax_acc(z1, mm_lo, mm_hi);
+			}
 		}
 	}
 	if (mm) {wave_minmax_publish(mm_lo, mm_hi, mm);}
@@ -311,7 +316,7 @@ template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_
 
 // fBm tiles: the same two-cells-per-lane evaluation for a batch of tw x tw tile fields (origins per distinct tile column / row in m0)
 template<int MODE> __global__ __launch_bounds__(256) void k_noise_tiles(tile_ref_pod_t const *__restrict__ refs, uint32_t n, uint32_t nux, float const *__restrict__ d_sm, float const *__restrict__ m0,
-	grid_job_t job, noise_consts_t nc, sin_lut_t L, float *__restrict__ out, uint32_t tw, uint32_t const *__restrict__ lut)
+	grid_job_t job, noise_consts_t nc, sin_lut_t L, float *__restrict__ out, uint32_t tw, uint32_t const *__restrict__ lut, noise_oct_t oc)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t s_lut[noise_lut_dwords<MODE>()];
 	noise_tab_t const ns = noise_stage_lut<MODE>(lut, s_lut);
@@ -322,7 +327,7 @@ template<int MODE> __global__ __launch_bounds__(256) void k_noise_tiles(tile_ref
 	tile_ref_pod_t const r = refs[t];
 	job.mx0 = m0[r.xi]; job.my0 = m0[nux + r.yi];
 	float const xv0 = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, xv1 = ((float)(x + 1)*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)y*job.mdy + job.my0)*nc.DY_VAL_INV;
-	nv2 const zz = noise_zval_t<MODE, nv2, noise_tab_t>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, ns);
+	nv2 const zz = noise_zval_tab<MODE>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, oc, ns);
 	float const *smx = d_sm + (size_t)r.xi*tw, *smy = d_sm + (size_t)(nux + r.yi)*tw;
 	float *o = out + (size_t)t*tw*tw + (size_t)y*tw + x;
 	o[0] = finish_cell(zz[0], job, nc, L, smx, smy, x, y);

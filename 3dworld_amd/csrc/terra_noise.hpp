@@ -227,50 +227,61 @@ TERRA_HD float simplex3(float vx, float vy, float vz) {
 //   Perlin:  h = permute(permute(cx) + cy), cx / cy in {0..288}: 289 inner arguments, 578 outer ones, {gx*norm, gy*norm} depend on h only.
 // The tables hold exactly what the per-cell code computes for each argument (filled by that code, noise_lut_fill), so a look-up returns the same
 // bits -- including the cases where permute() leaves 289 instead of 0, which is why simplex's inner table is NOT wrapped (cy + 1 = 289 is a
-// different argument from 0) while Perlin's is indexed by mod289(flx + 1).  Per lattice point ~25 instructions become one cvt + add + LDS read.
+// different argument from 0) while Perlin's is indexed by mod289(flx + 1).  Per lattice point ~25 instructions become a few integer adds + LDS reads.
 // The look-up index is the residue r = a - floor(a*(1/289))*289 WITHOUT range fix-up where the table can absorb it: for an integer |a| < 2^22 the
 // quotient estimate is exact unless a is a multiple of 289, where it may come out one too small (RN(1/289) > 1/289 makes that the negative multiples), so
 // r is the true residue or 289 standing for 0, never negative (every integer of the range is checked by tests/emul).  Entries [289] repeat entries [0].
-// Layout in dwords: simplex part [S_I: 290 pairs {permute(r' + 0) << 4, permute(r' + 1) << 4}, r' = r mod 289][S_G: 579 x {a0, h, norm, 0}],
-// Perlin part [P_I: 292 ints = permute(v mod 289) << 3][P_G: 580 x {gx*n, gy*n}].  A kernel stages the part it needs in LDS.
-constexpr unsigned NOISE_LUT_S_I = 0, NOISE_LUT_S_G = 580, NOISE_LUT_S_DWORDS = 580 + 579*4, NOISE_LUT_P_I = 0, NOISE_LUT_P_G = 292, NOISE_LUT_P_DWORDS = 292 + 580*2;
+// Layout (dwords; all stored offsets are BYTE offsets from the start of the part, so a look-up is base + offset + (residue << 2)):
+//   simplex part  S_I: 290 x {A, A + 4, C, 0},  A = &a0[permute(r' + 0)], C = &a0[permute(r' + 1)], r' = r mod 289
+//                 S_G: three arrays a0[579], h[579], norm[579] -- structure of arrays on purpose: the two cells of a lane fetch the same field with one
+//                      4-byte read each, into a register PAIR that the packed arithmetic uses as is (an array of {a0, h, norm} records is read with wide
+//                      loads per cell and then needs a register move per value to build the pairs); the array stride (2316 bytes) is neither below
+//                      1 KiB nor a multiple of 256, so the compiler cannot fuse reads of one cell into ds_read2
+//   Perlin part   P_I: 292 x (&gxn[permute(v mod 289)]),  P_G: gxn[580], gyn[580]
+// A kernel stages the part it needs in LDS.
+constexpr unsigned NOISE_LUT_S_G = 290*4, NOISE_LUT_S_N = 579, NOISE_LUT_S_DWORDS = ((NOISE_LUT_S_G + 3*NOISE_LUT_S_N + 3)/4)*4;
+constexpr unsigned NOISE_LUT_P_G = 292, NOISE_LUT_P_N = 580, NOISE_LUT_P_DWORDS = ((NOISE_LUT_P_G + 2*NOISE_LUT_P_N + 3)/4)*4;
 constexpr unsigned NOISE_LUT_DWORDS = NOISE_LUT_S_DWORDS + NOISE_LUT_P_DWORDS; // simplex part first, then the Perlin part
-static_assert((NOISE_LUT_S_DWORDS % 4) == 0 && (NOISE_LUT_P_DWORDS % 4) == 0 && (NOISE_LUT_S_G % 4) == 0 && (NOISE_LUT_P_G % 2) == 0, "16-byte rows");
 TERRA_HD uint32_t nt_bits(float f) {uint32_t u; memcpy(&u, &f, 4); return u;}
 TERRA_HD uint32_t noise_lut_fill(unsigned i) { // dword i of the table
 	if (i < NOISE_LUT_S_DWORDS) {
-		if (i < NOISE_LUT_S_G) {return (uint32_t)((int)gl_permute<float>((float)((i >> 1) % 289u) + (float)(i & 1u)) << 4);} // cy + 0.0f, cy + 1.0f for cy = r mod 289
-		unsigned const v = (i - NOISE_LUT_S_G) >> 2, c = (i - NOISE_LUT_S_G) & 3u;
+		if (i < NOISE_LUT_S_G) {
+			unsigned const r = (i >> 2) % 289u, c = i & 3u;
+			uint32_t const A = NOISE_LUT_S_G*4 + ((uint32_t)(int)gl_permute<float>((float)r + 0.0f) << 2), C = NOISE_LUT_S_G*4 + ((uint32_t)(int)gl_permute<float>((float)r + 1.0f) << 2);
+			return (c == 0) ? A : ((c == 1) ? A + 4 : ((c == 2) ? C : 0u));
+		}
+		unsigned const k = i - NOISE_LUT_S_G, c = k / NOISE_LUT_S_N, v = k % NOISE_LUT_S_N;
+		if (c >= 3) return 0u;
 		float const C3 = 0.024390243902439f;
 		float const p = gl_permute<float>((float)v);
 		float const g = 2.0f*gl_fract(p*C3) - 1.0f, h = nt_abs(g) - 0.5f, a0 = g - nt_floor(g + 0.5f);
 		float const n = 1.79284291400159f - 0.85373472095314f*(a0*a0 + h*h);
-		return (c == 0) ? nt_bits(a0) : ((c == 1) ? nt_bits(h) : ((c == 2) ? nt_bits(n) : 0u));
+		return (c == 0) ? nt_bits(a0) : ((c == 1) ? nt_bits(h) : nt_bits(n));
 	}
 	i -= NOISE_LUT_S_DWORDS;
-	if (i < NOISE_LUT_P_G) {return (uint32_t)((int)gl_permute<float>((float)(i % 289u)) << 3);} // [r] = permute(mod289(fl)), [r + 1] = permute(mod289(fl + 1)), r in 0..289
-	unsigned const v = (i - NOISE_LUT_P_G) >> 1, c = (i - NOISE_LUT_P_G) & 1u;
+	if (i < NOISE_LUT_P_G) {return NOISE_LUT_P_G*4 + ((uint32_t)(int)gl_permute<float>((float)(i % 289u)) << 2);} // [r] -> permute(mod289(fl)), [r + 1] -> permute(mod289(fl + 1)), r in 0..289
+	unsigned const k = i - NOISE_LUT_P_G, c = k / NOISE_LUT_P_N, v = k % NOISE_LUT_P_N;
+	if (c >= 2) return 0u;
 	float const h = gl_permute<float>((float)v);
 	float const g = 2.0f*gl_fract(gl_div41(h)) - 1.0f, gy = nt_abs(g) - 0.5f, gx = g - nt_floor(g + 0.5f);
 	float const n = 1.79284291400159f - 0.85373472095314f*(gx*gx + gy*gy);
 	return nt_bits(c ? gy*n : gx*n);
 }
-// residue of an integer |a| < 2^22 in {0, ..., 288} or 289 (= 0) -- see the note above; fixed: the same folded into 0 .. 288
+// residue of an integer |a| < 2^22 in {0, ..., 288} or 289 (= 0) -- see the note above; _small: the same folded into 0 .. 288
 template<class T> TERRA_HD T gl_mod289_raw(T a) {return a - nt_floor(a*(1.0f/289.0f))*289.0f;}
 template<class T> TERRA_HD T gl_mod289_small(T a) {T const r = gl_mod289_raw(a); return nt_sel(r >= 289.0f, r - 289.0f, r);}
 TERRA_HD float nt_max0(float a) {return fmaxf(a, 0.0f);}                 // std::max(a, 0.0f) for a that is not a NaN: one v_max_f32 instead of compare + select
 TERRA_HD nv2   nt_max0(nv2 a)   {return nv2{fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f)};}
-struct nt_f4 {float x, y, z, w;};
-struct nt_f2 {float x, y;};
-struct nt_i2 {int x, y;};
-// glm::simplex(vec2) for two cells, lattice part from the table (`tab` = start of the simplex part, 16-byte aligned); falls back to simplex2_t when a
-// lattice coordinate is not an exactly representable small integer (|c| >= 2^22, inf, NaN)
-TERRA_HD nv2 simplex2_lut(nv2 vx, nv2 vy, char const *tab) {
+struct alignas(16) nt_i4 {int x, y, z, w;};
+TERRA_HD float nt_ldf(char const *p) {return *(float const *)p;}
+// glm::simplex(vec2) for two cells, lattice part from the table (`tab` = start of the simplex part, 16-byte aligned).  CHECK: fall back to simplex2_t
+// when a lattice coordinate is not an exactly representable small integer (|c| >= 2^22, inf, NaN); without it the caller guarantees that it is.
+template<bool CHECK> TERRA_HD nv2 simplex2_lut(nv2 vx, nv2 vy, char const *tab) {
 	float const C0 = 0.211324865405187f, C1 = 0.366025403784439f, C2 = -0.577350269189626f;
 	nv2 const one = nt_bc<nv2>(1.0f), zero = nt_bc<nv2>(0.0f);
 	nv2 const skew = vx*C1 + vy*C1;
 	nv2 const cx = nt_floor(vx + skew), cy = nt_floor(vy + skew);
-	if (TERRA_UNLIKELY(!(nt_all_below(cx, 4194304.0f) && nt_all_below(cy, 4194304.0f)))) {return simplex2_t<nv2>(vx, vy);}
+	if (CHECK && TERRA_UNLIKELY(!(nt_all_below(cx, 4194304.0f) && nt_all_below(cy, 4194304.0f)))) {return simplex2_t<nv2>(vx, vy);}
 	// from here on everything is finite (cx, cy small => vx, vy small), so std::max(m, 0) is fmaxf(m, 0)
 	nv2 const unskew = cx*C0 + cy*C0;
 	nv2 const ax = vx - cx + unskew, ay = vy - cy + unskew;
@@ -278,25 +289,25 @@ TERRA_HD nv2 simplex2_lut(nv2 vx, nv2 vy, char const *tab) {
 	nv2 const ox = nt_sel(lower, one, zero), oy = one - ox; // (1, 0) or (0, 1)
 	nv2 const bx = (ax + C0) - ox, by = (ay + C0) - oy;
 	nv2 const ex = ax + C2, ey = ay + C2;
-	nv2 const mx = gl_mod289_small(cx), ry = gl_mod289_raw(cy);
+	nv2 const mx4 = gl_mod289_small(cx)*4.0f, ry16 = gl_mod289_raw(cy)*16.0f; // byte offsets of the residues: exact small integers
 	nv2 ma = nt_max0(0.5f - (ax*ax + ay*ay));
 	nv2 mb = nt_max0(0.5f - (bx*bx + by*by));
 	nv2 mc = nt_max0(0.5f - (ex*ex + ey*ey));
 	ma = ma*ma; mb = mb*mb; mc = mc*mc;
 	ma = ma*ma; mb = mb*mb; mc = mc*mc;
-	nt_f4 ga[2], gb[2], gc[2];
+	char const *pa[2], *pb[2], *pc[2];
 #pragma unroll
 	for (int e = 0; e < 2; ++e) {
-		int const ix16 = (int)mx[e] << 4;
-		nt_i2 const si = *(nt_i2 const *)(tab + ((int)ry[e] << 3)); // {permute(cy + 0) << 4, permute(cy + 1) << 4}
-		char const *g = tab + NOISE_LUT_S_G*4 + ix16;
-		ga[e] = *(nt_f4 const *)(g + si.x);                                  // permute(cy + 0) + cx + 0
-		gb[e] = *(nt_f4 const *)(g + (lower[e] ? si.x + 16 : si.y));          // (ox, oy) = (1, 0) or (0, 1)
-		gc[e] = *(nt_f4 const *)(g + si.y + 16);                              // permute(cy + 1) + cx + 1
+		nt_i4 const si = *(nt_i4 const *)(tab + (int)ry16[e]);   // {&a0[permute(cy + 0)], the same + 4, &a0[permute(cy + 1)]}
+		char const *g = tab + (int)mx4[e];
+		pa[e] = g + si.x;                                        // permute(cy + 0) + cx + 0
+		pb[e] = g + (lower[e] ? si.y : si.z);                    // (ox, oy) = (1, 0): permute(cy) + cx + 1, or (0, 1): permute(cy + 1) + cx
+		pc[e] = g + si.z + 4;                                    // permute(cy + 1) + cx + 1
 	}
-	nv2 const a0a = {ga[0].x, ga[1].x}, ha = {ga[0].y, ga[1].y}, na = {ga[0].z, ga[1].z};
-	nv2 const a0b = {gb[0].x, gb[1].x}, hb = {gb[0].y, gb[1].y}, nb = {gb[0].z, gb[1].z};
-	nv2 const a0c = {gc[0].x, gc[1].x}, hc = {gc[0].y, gc[1].y}, ncc = {gc[0].z, gc[1].z};
+	constexpr int SH = NOISE_LUT_S_N*4, SN = 2*NOISE_LUT_S_N*4;
+	nv2 const a0a = {nt_ldf(pa[0]), nt_ldf(pa[1])}, ha = {nt_ldf(pa[0] + SH), nt_ldf(pa[1] + SH)}, na = {nt_ldf(pa[0] + SN), nt_ldf(pa[1] + SN)};
+	nv2 const a0b = {nt_ldf(pb[0]), nt_ldf(pb[1])}, hb = {nt_ldf(pb[0] + SH), nt_ldf(pb[1] + SH)}, nb = {nt_ldf(pb[0] + SN), nt_ldf(pb[1] + SN)};
+	nv2 const a0c = {nt_ldf(pc[0]), nt_ldf(pc[1])}, hc = {nt_ldf(pc[0] + SH), nt_ldf(pc[1] + SH)}, ncc = {nt_ldf(pc[0] + SN), nt_ldf(pc[1] + SN)};
 	ma *= na; mb *= nb; mc *= ncc;
 	nv2 const da = a0a*ax + ha*ay;
 	nv2 const db = a0b*bx + hb*by;
@@ -304,25 +315,25 @@ TERRA_HD nv2 simplex2_lut(nv2 vx, nv2 vy, char const *tab) {
 	return 130.0f*(ma*da + mb*db + mc*dc);
 }
 // glm::perlin(vec2) for two cells (`tab` = start of the Perlin part)
-TERRA_HD nv2 perlin2_lut(nv2 px, nv2 py, char const *tab) {
+template<bool CHECK> TERRA_HD nv2 perlin2_lut(nv2 px, nv2 py, char const *tab) {
 	nv2 const flx = nt_floor(px), fly = nt_floor(py);
-	if (TERRA_UNLIKELY(!(nt_all_below(flx, 4194304.0f) && nt_all_below(fly, 4194304.0f)))) {return perlin2_t<nv2>(px, py);}
+	if (CHECK && TERRA_UNLIKELY(!(nt_all_below(flx, 4194304.0f) && nt_all_below(fly, 4194304.0f)))) {return perlin2_t<nv2>(px, py);}
 	nv2 const frx = px - flx, fry = py - fly;
-	nv2 const mx = gl_mod289_raw(flx), my = gl_mod289_small(fly); // = mod289(fl + 0) (x: 289 stands for 0, the table is indexed that way); mod289(fl + 1) is the next residue
+	nv2 const rx4 = gl_mod289_raw(flx)*4.0f, my = gl_mod289_small(fly); // = mod289(fl + 0) (x: 289 stands for 0, the table is indexed that way); mod289(fl + 1) is the next residue
 	nv2 const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
-	nt_f2 g00[2], g10[2], g01[2], g11[2];
+	char const *p00[2], *p10[2], *p01[2], *p11[2];
 #pragma unroll
 	for (int e = 0; e < 2; ++e) {
-		int const *pi = (int const *)(tab + ((int)mx[e] << 2));
-		int const ix0 = pi[0], ix1 = pi[1]; // permute(cx0) << 3, permute(cx1) << 3 (the table wraps 289 -> 0)
+		int const *pip = (int const *)(tab + (int)rx4[e]);
+		struct {int x, y;} const pi = {pip[0], pip[1]};          // &gxn[permute(cx0)], &gxn[permute(cx1)] (the table wraps 289 -> 0)
 		int const iy0 = (int)my[e];
 		int iy1 = iy0 + 1; iy1 = (iy1 == 289) ? 0 : iy1;
-		char const *g0 = tab + NOISE_LUT_P_G*4 + (iy0 << 3), *g1 = tab + NOISE_LUT_P_G*4 + (iy1 << 3);
-		g00[e] = *(nt_f2 const *)(g0 + ix0); g10[e] = *(nt_f2 const *)(g0 + ix1);
-		g01[e] = *(nt_f2 const *)(g1 + ix0); g11[e] = *(nt_f2 const *)(g1 + ix1);
+		char const *g0 = tab + (iy0 << 2), *g1 = tab + (iy1 << 2);
+		p00[e] = g0 + pi.x; p10[e] = g0 + pi.y; p01[e] = g1 + pi.x; p11[e] = g1 + pi.y;
 	}
-	nv2 const gx00 = {g00[0].x, g00[1].x}, gy00 = {g00[0].y, g00[1].y}, gx10 = {g10[0].x, g10[1].x}, gy10 = {g10[0].y, g10[1].y};
-	nv2 const gx01 = {g01[0].x, g01[1].x}, gy01 = {g01[0].y, g01[1].y}, gx11 = {g11[0].x, g11[1].x}, gy11 = {g11[0].y, g11[1].y};
+	constexpr int SY = NOISE_LUT_P_N*4;
+	nv2 const gx00 = {nt_ldf(p00[0]), nt_ldf(p00[1])}, gy00 = {nt_ldf(p00[0] + SY), nt_ldf(p00[1] + SY)}, gx10 = {nt_ldf(p10[0]), nt_ldf(p10[1])}, gy10 = {nt_ldf(p10[0] + SY), nt_ldf(p10[1] + SY)};
+	nv2 const gx01 = {nt_ldf(p01[0]), nt_ldf(p01[1])}, gy01 = {nt_ldf(p01[0] + SY), nt_ldf(p01[1] + SY)}, gx11 = {nt_ldf(p11[0]), nt_ldf(p11[1])}, gy11 = {nt_ldf(p11[0] + SY), nt_ldf(p11[1] + SY)};
 	nv2 const d00 = gx00*fx0 + gy00*fy0;
 	nv2 const d10 = gx10*fx1 + gy10*fy0;
 	nv2 const d01 = gx01*fx0 + gy01*fy1;
@@ -334,8 +345,13 @@ TERRA_HD nv2 perlin2_lut(nv2 px, nv2 py, char const *tab) {
 // evaluator for fbm2_t / noise_zval_t: stab / ptab = the simplex / Perlin part of the table (only the one the mode uses needs to be valid)
 struct noise_tab_t {
 	char const *stab, *ptab;
-	TERRA_HD nv2 simplex(nv2 x, nv2 y) const {return simplex2_lut(x, y, stab);}
-	TERRA_HD nv2 perlin(nv2 x, nv2 y) const {return perlin2_lut(x, y, ptab);}
+	TERRA_HD nv2 simplex(nv2 x, nv2 y) const {return simplex2_lut<true>(x, y, stab);}
+	TERRA_HD nv2 perlin(nv2 x, nv2 y) const {return perlin2_lut<true>(x, y, ptab);}
+};
+struct noise_tab_nocheck_t { // for sample positions the caller has bounded (fbm2_tab)
+	char const *stab, *ptab;
+	TERRA_HD nv2 simplex(nv2 x, nv2 y) const {return simplex2_lut<false>(x, y, stab);}
+	TERRA_HD nv2 perlin(nv2 x, nv2 y) const {return perlin2_lut<false>(x, y, ptab);}
 };
 
 // ---- noise shaping (src/mesh_gen.cpp:555-571)
@@ -412,6 +428,63 @@ template<int MODE, class T, class NS = noise_direct_t> TERRA_HD T noise_zval_t(T
 	return z*hmap_scale(MODE, nc);
 }
 template<int MODE> TERRA_HD float noise_zval(float xval, float yval, int shape, noise_consts_t const &nc) {return noise_zval_t<MODE, float>(xval, yval, shape, nc);}
+
+// ---- the grid kernels' form of gen_noise / get_noise_zval: the per-octave scalars (freq *= 1.92, mag *= 0.5, rx *= 1.5, ry *= 1.5: the same float products
+// in the same order, made once on the host) arrive as kernel arguments = scalar registers, and the "is every lattice coordinate a small integer" test of
+// the table look-ups is made once per fBm sum from a bound on the sample positions instead of once per octave.
+struct noise_oct_t {float freq[NUM_FREQ_COMP], mag[NUM_FREQ_COMP], rx[NUM_FREQ_COMP], ry[NUM_FREQ_COMP]; float freq_max, r_max; unsigned end_octave;};
+TERRA_HD noise_oct_t make_noise_oct(noise_consts_t const &nc) {
+	noise_oct_t o;
+	o.end_octave = NUM_FREQ_COMP - nc.start_eval_sin/N_RAND_SIN2;
+	float mag = 1.0f, freq = 1.0f, rx = nc.rx, ry = nc.ry;
+	o.freq_max = 0.0f; o.r_max = 0.0f;
+	for (unsigned i = 0; i < (unsigned)NUM_FREQ_COMP; ++i) {
+		o.freq[i] = freq; o.mag[i] = mag; o.rx[i] = rx; o.ry[i] = ry;
+		if (i < o.end_octave) {o.freq_max = max_std(o.freq_max, fabsf(freq)); o.r_max = max_std(o.r_max, max_std(fabsf(rx), fabsf(ry)));}
+		mag *= 0.5f; freq *= 1.92f; rx *= 1.5f; ry *= 1.5f;
+	}
+	return o;
+}
+template<bool SIMPLEX> TERRA_HD nv2 fbm2_tab(nv2 xv, nv2 yv, int shape, noise_oct_t const &oc, noise_tab_t const &ns) {
+	nv2 zval = nt_bc<nv2>(0.0f);
+	// |q| <= freq_max*|v| + r_max for every octave; simplex's skewed coordinate is below 1.74*max|q|: under 2^20 here, every lattice coordinate is an
+	// integer far below 2^22 (a NaN fails the comparison and takes the checked loop)
+	float const vmax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(yv[0]), fabsf(yv[1])));
+	if (TERRA_LIKELY(vmax*oc.freq_max + oc.r_max < 1048576.0f)) {
+		noise_tab_nocheck_t const nn{ns.stab, ns.ptab};
+		for (unsigned i = 0; i < oc.end_octave; ++i) {
+			nv2 const qx = oc.freq[i]*xv + oc.rx[i], qy = oc.freq[i]*yv + oc.ry[i];
+			nv2 n = SIMPLEX ? nn.simplex(qx, qy) : nn.perlin(qx, qy);
+			if (shape != 0) {n = nt_octave_shape(n, shape);}
+			zval += oc.mag[i]*n;
+		}
+		return zval;
+	}
+	for (unsigned i = 0; i < oc.end_octave; ++i) {
+		nv2 const qx = oc.freq[i]*xv + oc.rx[i], qy = oc.freq[i]*yv + oc.ry[i];
+		nv2 n = SIMPLEX ? ns.simplex(qx, qy) : ns.perlin(qx, qy);
+		if (shape != 0) {n = nt_octave_shape(n, shape);}
+		zval += oc.mag[i]*n;
+	}
+	return zval;
+}
+template<int MODE> TERRA_HD nv2 noise_zval_tab(nv2 xval, nv2 yval, int shape, noise_consts_t const &nc, noise_oct_t const &oc, noise_tab_t const &ns) {
+	constexpr bool SIMPLEX = (MODE != MGEN_PERLIN);
+	float const xy_scale = 0.0007f*nc.mesh_scale; // MESH_SCALE_FACTOR
+	nv2 xv = xy_scale*xval, yv = xy_scale*yval;
+	if (MODE == MGEN_DWARP_GPU) {
+		float const scale = 0.2f;
+		nv2 const dx1 = fbm2_tab<SIMPLEX>(nt_add_d(xv, 0.0), nt_add_d(yv, 0.0), shape, oc, ns);
+		nv2 const dy1 = fbm2_tab<SIMPLEX>(nt_add_d(xv, 5.2), nt_add_d(yv, 1.3), shape, oc, ns);
+		nv2 const wx = xv + scale*dx1, wy = yv + scale*dy1;
+		nv2 const dx2 = fbm2_tab<SIMPLEX>(nt_add_d(wx, 1.7), nt_add_d(wy, 9.2), shape, oc, ns);
+		nv2 const dy2 = fbm2_tab<SIMPLEX>(nt_add_d(wx, 8.3), nt_add_d(wy, 2.8), shape, oc, ns);
+		xv += scale*dx2; yv += scale*dy2;
+	}
+	nv2 z = fbm2_tab<SIMPLEX>(xv, yv, shape, oc, ns);
+	z = nt_postproc(z, nc.hp);
+	return z*hmap_scale(MODE, nc);
+}
 
 // ---- glaciate + islands + volcano epilogue of eval_index (src/mesh_gen.cpp:358-385,782-790)
 // pow(val, custom_glaciate_exp) is libm's powf in the reference (float arguments): reproduced bit for bit by terra_powf.hpp

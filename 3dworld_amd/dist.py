@@ -10,6 +10,41 @@ border column of its neighbour)."""
 import numpy as np
 
 
+def partition_tiles(tiles, rank, world):
+    """BASELINE config 4 on several GPUs: contiguous block partition of the tile list (tiles are independent units: tile_t::create_zvals needs nothing
+    from a neighbour, the reference erodes each tile alone on its clamp-padded copy, src/tiled_mesh.cpp:515) -- no collective, rank r computes tiles[lo:hi]"""
+    n = len(tiles)
+    per = (n + world - 1) // world
+    return list(tiles[min(rank * per, n):min((rank + 1) * per, n)])
+
+
+def strip_rows(ny, rank, world):
+    """rows [r0, r1) of an ny-row heightmap owned by `rank` when the grid is cut into `world` contiguous row strips (heightmap_t::proc_gen's loop is
+    independent per row, src/heightmap.cpp:139-143)"""
+    per = (ny + world - 1) // world
+    return min(rank * per, ny), min((rank + 1) * per, ny)
+
+
+def sharded_heightmap_strips(terra, dist, d_out_ptr, x0, y0, dx, dy, nx, ny, flags, min_start_sin=0):
+    """ONE nx x ny heightmap on all ranks of `dist`: this rank evaluates its row strip into d_out_ptr (strip-local layout, (r1 - r0) x nx floats) with
+    terra_gen_grid_rows_minmax_dev -- bit-identical to the same rows of a single-GPU grid -- and min / max of the WHOLE map (what heightmap_t::run_erosion
+    and from_floats need next) come from one all_reduce each of a single float (backend "nccl" = RCCL over xGMI on the MI355X node, gloo in the CPU test).
+    Returns (r0, r1, min, max).  Erosion is not part of this: one shared grid in serial droplet order does not shard (replicas only)."""
+    import torch
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
+    r0, r1 = strip_rows(ny, rank, world)
+    mn, mx = float("inf"), float("-inf")
+    if r1 > r0:
+        mn, mx = terra.gen_grid_rows_minmax_dev(d_out_ptr, x0, y0, dx, dy, nx, ny, r0, r1 - r0, flags, min_start_sin)
+    if world > 1:
+        on_gpu = str(dist.get_backend()).lower() == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        a = torch.tensor([mn], dtype=torch.float32, device=dev); b = torch.tensor([mx], dtype=torch.float32, device=dev)
+        dist.all_reduce(a, op=dist.ReduceOp.MIN); dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        mn, mx = float(a.item()), float(b.item())
+    return r0, r1, mn, mx
+
+
 def strip_of(tile_x, x_min, x_max, world):
     """rank owning tile column tile_x when columns [x_min, x_max] are dealt out in `world` contiguous strips"""
     width = x_max - x_min + 1

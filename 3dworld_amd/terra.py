@@ -114,6 +114,7 @@ _PROTOS = {
     "terra_gen_is_running": (_i32, [_vp]),
     "terra_gen_collect": (_i32, [_vp, _vp]),
     "terra_gen_eval_index": (_f, [_vp, _u32, _u32, _i32, _i32]),
+    "terra_gen_grid_rows_minmax_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _u32, _u32, _vp, _vp, _vp]),
     "terra_gen_device_values": (_vp, [_vp]),
     "terra_gen_grid_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
     "terra_gen_grid": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp]),
@@ -415,6 +416,12 @@ class Terra:
         mn, mx = C.c_float(), C.c_float()
         self._ck(self.lib.terra_gen_grid_minmax_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr, C.byref(mn), C.byref(mx)))
         return mn.value, mx.value
+
+    def gen_grid_rows_minmax_dev(self, ptr, x0, y0, dx, dy, nx, ny, row0, nrows, flags=GEN_GLACIATE, min_start_sin=0, want_minmax=True):
+        mn, mx = C.c_float(), C.c_float()
+        self._ck(self.lib.terra_gen_grid_rows_minmax_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, row0, nrows, ptr,
+                                                         C.byref(mn) if want_minmax else None, C.byref(mx) if want_minmax else None))
+        return (mn.value, mx.value) if want_minmax else None
 
     def eval_mesh_sin_terms(self, xv, yv):
         out = C.c_float()

@@ -9,9 +9,19 @@ The z grid never leaves HBM inside the timed region (there is no input grid; par
   python bench.py [--gpus N --steps K --warmup W --size 16384 --mode sine --droplets 1000]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU)
 
-Multi-GPU: every rank owns one independent N x N region of the world (origin shifted by rank*N cells in x), generated and
+`value` (the headline): every rank owns one independent N x N region of the world (origin shifted by rank*N cells in x), generated and
 eroded exactly like the reference erodes each tile alone on its clamp-padded copy (src/tiled_mesh.cpp:515): no data-path
-collective, weak scaling; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+collective, weak scaling, `pipelines` heightmaps in flight per GPU.
+
+The same run also measures, under `detail` (all ranks take part, rank 0 reports; switch off with --no-extras):
+  single   one heightmap in flight (no overlap of a map's erosion with the next map's noise): the latency of one map
+  strips   STRONG scaling of ONE 16384^2 grid: rank r evaluates rows [r*N/W, (r+1)*N/W) (terra_gen_grid_rows_minmax_dev, bit-identical to the
+           full grid), min(vals) = one float through all_reduce(min) over RCCL; erosion does not shard in the reference's semantics
+           (one shared grid, serial droplet order: replicas only) and is excluded from that line
+  tiles    STRONG scaling of BASELINE config 4: the 64 x 64 tiles of 128^2 block-partitioned over the ranks
+           (tile_t::create_zvals + stats + normals; with 0 and with 1000 droplets per tile), no collective
+  modes    the same 16384^2 step with simplex / Perlin / domain-warp noise (rank 0)
+`--workload strips|tiles` makes one of those the headline `value` instead (for a scaling sweep of that mode alone).
 
 Prints ONE JSON line on rank 0.  `roofline` = dominant kernel, measured with HIP events on the library's stream;
 `cpu_baseline` = the reference's own CPU code (oracle/_ref) or the C restatement (oracle/) timed on this host, rank 0, N=1.
@@ -21,6 +31,7 @@ import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +40,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MODES = {"sine": 0, "simplex": 1, "perlin": 2, "dwarp": 4}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-VALU_PEAK_TOPS = 78.6      # fp32 VALU without FMA: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (mul and add are separate instructions here)
+FP32_PEAK_TFLOPS = 157.3   # fp32 vector peak (packed FMA): 256 CU x 4 SIMD x 16 lanes x 2 (packed) x 2 (FMA) x 2.4 GHz
+VALU_NOFMA_TOPS = 78.6     # the same without fusing: the CPU reference rounds the product before adding, so mul and add are separate instructions here
 
 
 def parse():
@@ -42,32 +54,57 @@ def parse():
     p.add_argument("--droplets", type=int, default=1000)
     p.add_argument("--octaves", type=int, default=8)
     p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
+    p.add_argument("--workload", default="heightmap", choices=["heightmap", "strips", "tiles"], help="which measurement is the headline `value`")
+    p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
+    p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-size", type=int, default=0, help="grid edge of the CPU sample (default: min(size, 8192))")
+    p.add_argument("--cpu-size", type=int, default=0, help="grid edge of the CPU sample (default: the benchmark's own size)")
     return p.parse_args()
 
 
+def flops_per_cell(mode, octaves):
+    """sine 2 flop per term (10 terms per octave); fBm 70 flop per octave and evaluation, domain warp = 5 evaluations."""
+    return 20.0 * octaves if mode == 0 else 70.0 * octaves * (5 if mode == 4 else 1)
+
+
 def cpu_baseline(args, mode):
-    """The reference CPU path on this host's cores: same noise + erosion on a bounded sample (one grid)."""
+    """The reference CPU path on this host's cores: the SAME grid (size, octaves, droplets), all OpenMP threads; then one thread (the only
+    deterministic erosion order) on a bounded sample: the noise on the first 1/16 of the rows, the erosion on the whole grid."""
     import numpy as np
     import orclib
     orclib.build_oracle()
     kind = "reference" if orclib.ref_available() else "port"
     ck = orclib.Checker("ref" if kind == "reference" else "orc")
     cores = ck.num_threads()
-    n = args.cpu_size or min(args.size, 8192)
+    n = args.cpu_size or args.size
     s = ck.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
     t0 = time.perf_counter()
     g = ck.gen_grid(-n / 2, -n / 2, s.DX_VAL, s.DY_VAL, n, n, 1)   # build_arrays + enable_glaciate + eval_index loop, OpenMP over all cores
     t1 = time.perf_counter()
     mn = float(g.min())
+    g1 = g.copy()
     t2 = time.perf_counter()
     ck.apply_erosion(g, mn, args.droplets)                          # reference apply_erosion incl. its pad / unpad copies
     t3 = time.perf_counter()
     total = (t1 - t0) + (t3 - t2)
-    return {"value": round(n * n / total / 1e9, 6), "unit": "Gcells/s", "cores": cores, "kind": kind,
-            "sample": f"one {n}x{n} grid, same seed/params: noise {t1 - t0:.3f}s + apply_erosion({args.droplets}) {t3 - t2:.3f}s, OMP threads={cores}",
-            "noise_gcells_s": round(n * n / (t1 - t0) / 1e9, 6)}
+    out = {"value": round(n * n / total / 1e9, 6), "unit": "Gcells/s", "cores": cores, "kind": kind,
+           "sample": f"one {n}x{n} grid, same seed/params: noise {t1 - t0:.3f}s + apply_erosion({args.droplets}) {t3 - t2:.3f}s, OMP threads={cores}",
+           "noise_gcells_s": round(n * n / (t1 - t0) / 1e9, 6)}
+    try:
+        ck.set_num_threads(1)
+        rows = max(1, n // 16)
+        t4 = time.perf_counter()
+        ck.gen_grid(-n / 2, -n / 2, s.DX_VAL, s.DY_VAL, n, rows, 1)
+        t5 = time.perf_counter()
+        ck.apply_erosion(g1, mn, args.droplets)
+        t6 = time.perf_counter()
+        noise_1 = (t5 - t4) * (n / rows)
+        out["threads_1"] = {"value": round(n * n / (noise_1 + (t6 - t5)) / 1e9, 6), "unit": "Gcells/s", "cores": 1,
+                            "sample": f"noise on the first {rows} of {n} rows ({t5 - t4:.3f}s, scaled x{n // rows}) + apply_erosion({args.droplets}) on the whole {n}x{n} grid {t6 - t5:.3f}s, OMP threads=1",
+                            "noise_gcells_s": round(n * n / noise_1 / 1e9, 6)}
+    finally:
+        ck.set_num_threads(cores)
+    return out
 
 
 def main():
@@ -93,11 +130,12 @@ def main():
     assert world == args.gpus or world == 1, "launch one rank per GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     pkg = importlib.import_module("3dworld_amd")
     if not os.path.exists(pkg.default_lib_path()):
         raise SystemExit("libterra_hip.so missing: run __graft_entry__.build() (no CPU fall-back)")
-    import threading
+    dmod = importlib.import_module("3dworld_amd.dist")
     mode = MODES[args.mode]
     N = args.size
     cells = N * N
@@ -120,16 +158,16 @@ def main():
         mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
         c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                   # run_erosion passes min(vals): only written cells can need the clamp
 
-    def run_steps(k):
-        """k steps in total, dealt round-robin to the P pipelines (one host thread each: the library calls release the GIL)."""
-        if P == 1:
+    def run_steps(k, npipe):
+        """k steps in total, dealt round-robin to npipe pipelines (one host thread each: the library calls release the GIL)."""
+        if npipe == 1:
             for _ in range(k):
                 step(0)
             return
         def worker(p):
-            for _ in range(p, k, P):
+            for _ in range(p, k, npipe):
                 step(p)
-        th = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
+        th = [threading.Thread(target=worker, args=(p,)) for p in range(npipe)]
         for x in th:
             x.start()
         for x in th:
@@ -137,76 +175,180 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
+        for c in ctxs:
+            c.synchronize()
         if world > 1:
             dist.barrier()
 
-    if True:
-        run_steps(args.warmup)
+    def timed(fn, k, warm):
+        """warm untimed calls, then EXACTLY k timed ones between barrier + synchronize on both sides; max over ranks (seconds)."""
+        fn(warm)
         barrier()
         t0 = time.perf_counter()
-        run_steps(args.steps)
+        fn(k)
         torch.cuda.synchronize(dev)
+        for c in ctxs:
+            c.synchronize()
         dt = time.perf_counter() - t0
         barrier()
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        rep = t.erosion_report().as_dict()
+        return dt
 
-        # ---- per-kernel times, live, HIP events on the same stream (rank 0 only)
-        detail = {}
-        if rank == 0:
-            reps = max(3, args.steps)
+    # ---- strong scaling of ONE grid: row strips + all_reduce(min) of one float (SURVEY 8e row 2)
+    r0, r1 = dmod.strip_rows(N, rank, world)
+    red = torch.zeros(1, dtype=torch.float32, device=coll_dev)
+
+    def strips_steps(k):
+        for _ in range(k):
+            mn, _ = t.gen_grid_rows_minmax_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, r0, r1 - r0, pkg.GEN_GLACIATE)
+            if world > 1:
+                red[0] = mn
+                dist.all_reduce(red, op=dist.ReduceOp.MIN)  # min(vals) of the whole map: what run_erosion / from_floats need next
+                mn = float(red.item())
+        return None
+
+    # ---- strong scaling of the tile batch of BASELINE config 4 (SURVEY 8e row 1): 64 x 64 tiles block-partitioned, no collective
+    all_tiles = [(tx, ty) for ty in range(-32, 32) for tx in range(-32, 32)]
+    my_tiles = dmod.partition_tiles(all_tiles, rank, world)
+    nt = len(my_tiles)
+    tile_bufs = {}
+
+    def tiles_steps_fn(droplets):
+        def fn(k):
+            if nt == 0:
+                return
+            if not tile_bufs:
+                tile_bufs["z"] = torch.empty(nt * 130 * 130, dtype=torch.float32, device=dev)
+                tile_bufs["st"] = torch.empty(nt * 39 * 4, dtype=torch.uint8, device=dev)
+                tile_bufs["nm"] = torch.empty(nt * 129 * 129 * 4, dtype=torch.uint8, device=dev)
+                tile_bufs["mnz"] = torch.empty(nt, dtype=torch.float32, device=dev)
+            for _ in range(k):
+                t.tiles_create_zvals_dev(my_tiles, droplets, tile_bufs["z"].data_ptr(), tile_bufs["st"].data_ptr(), tile_bufs["nm"].data_ptr(), tile_bufs["mnz"].data_ptr())
+            t.synchronize()
+        return fn
+
+    K, W = args.steps, args.warmup
+    detail = {}
+    # ---- the headline
+    if args.workload == "heightmap":
+        dt = timed(lambda k: run_steps(k, P), K, max(W, 2 * P))  # at least two untimed steps per pipeline: first-use allocations, graph captures and clocks settle
+        value = world * cells * K / dt / 1e9
+        scaling = "weak"
+        workload = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
+        par = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU"
+    elif args.workload == "strips":
+        dt = timed(strips_steps, K, max(W, 2))
+        value = cells * K / dt / 1e9
+        scaling = "strong"
+        workload = f"ONE {N}x{N} heightmap as {world} row strips, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals) by all_reduce(min); erosion excluded (does not shard: replicas only)"
+        par = f"{world} row strips of {N // world} rows, one 4-byte all_reduce(min) per step over RCCL"
+    else:
+        dt = timed(tiles_steps_fn(args.tile_droplets), K, max(W, 2))
+        value = len(all_tiles) * 130 * 130 * K / dt / 1e9
+        scaling = "strong"
+        workload = f"64x64 tiles of 128^2 (tile_t::create_zvals + sub-block stats + normals, {args.tile_droplets} droplets per tile), block-partitioned over {world} GPUs"
+        par = f"{nt} tiles on rank 0 of {len(all_tiles)}, no collective"
+    rep = t.erosion_report().as_dict()
+
+    # ---- the other measurements of the same run
+    if not args.no_extras:
+        ke = max(4, min(K, 16))
+        if args.workload != "heightmap" or P > 1:
+            d1 = timed(lambda k: run_steps(k, 1), ke, 2)
+            detail["single"] = {"pipelines": 1, "steps": ke, "latency_ms_single": round(d1 / ke * 1e3, 4), "gcells_s": round(world * cells * ke / d1 / 1e9, 3), "scaling": "weak",
+                                "note": "one heightmap in flight per GPU: noise and erosion of a map do not overlap with another map's"}
+        if args.workload != "strips":
+            ds = timed(strips_steps, ke, 2)
+            detail["strips"] = {"steps": ke, "ms_per_step": round(ds / ke * 1e3, 4), "gcells_s": round(cells * ke / ds / 1e9, 3), "scaling": "strong", "rows_per_rank": r1 - r0,
+                                "collective": "all_reduce(min) of one float per step" if world > 1 else "none (1 rank)", "erosion": "excluded: one shared grid in serial droplet order does not shard (replicas only)"}
+        if args.workload != "tiles":
+            dt0 = timed(tiles_steps_fn(0), ke, 2)
+            kt = max(2, min(K, 3))
+            dt1 = timed(tiles_steps_fn(1000), kt, 1)
+            tc = len(all_tiles) * 130 * 130
+            detail["tiles"] = {"tiles": len(all_tiles), "tiles_per_rank": nt, "scaling": "strong", "collective": "none",
+                               "erosion_0": {"steps": ke, "ms_per_batch": round(dt0 / ke * 1e3, 4), "gcells_s": round(tc * ke / dt0 / 1e9, 3), "mtiles_s": round(len(all_tiles) * ke / dt0 / 1e6, 3)},
+                               "erosion_1000": {"steps": kt, "ms_per_batch": round(dt1 / kt * 1e3, 3), "gcells_s": round(tc * kt / dt1 / 1e9, 4), "ktiles_s": round(len(all_tiles) * kt / dt1 / 1e3, 2)}}
+
+    # ---- per-kernel times, live, HIP events on the library's stream (rank 0 only; the other ranks wait at the barrier below)
+    if rank == 0:
+        reps = max(3, min(K, 16))
+        t.timer_start()
+        for _ in range(reps):
+            t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        ms_gen = t.timer_stop() / reps
+        t.timer_start()
+        for _ in range(reps):  # the grid kernel with its two small table kernels, no min/max read-back: what rocprofv3 reports as k_sine_grid / k_noise_grid (+ ~20 us)
+            t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        ms_grid = t.timer_stop() / reps
+        mn, _ = t.minmax_dev(z.data_ptr(), cells)
+        t.timer_start()
+        for _ in range(reps):
+            t.minmax_dev(z.data_ptr(), cells)
+        ms_minmax = t.timer_stop() / reps
+        zc = z.clone()
+        ms_ero = 0.0
+        for _ in range(reps):
+            z.copy_(zc)
+            torch.cuda.synchronize(dev)
             t.timer_start()
-            for _ in range(reps):
-                t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-            ms_gen = t.timer_stop() / reps
-            t.timer_start()
-            for _ in range(reps):  # the grid kernel with its two small table kernels, no min/max read-back: what rocprofv3 reports as k_sine_grid / k_noise_grid (+ ~20 us)
-                t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-            ms_grid = t.timer_stop() / reps
-            mn, _ = t.minmax_dev(z.data_ptr(), cells)
-            t.timer_start()
-            for _ in range(reps):
-                t.minmax_dev(z.data_ptr(), cells)
-            ms_minmax = t.timer_stop() / reps
-            zc = z.clone()
-            ms_ero = 0.0
-            for _ in range(reps):
-                z.copy_(zc)
-                torch.cuda.synchronize(dev)
+            t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)
+            ms_ero += t.timer_stop() / reps
+        del zc
+        detail.update({"ms_noise_kernels": round(ms_gen, 4), "ms_grid_kernel": round(ms_grid, 4), "ms_minmax_unfused": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)})
+        if not args.no_extras:  # the same step in the other noise modes (BASELINE config 2 names Perlin + domain warp): one heightmap, HIP events
+            md = {}
+            for name, m in MODES.items():
+                if m == mode:
+                    md[name] = {"ms_noise": round(ms_gen, 4), "ms_erosion": round(ms_ero, 4), "gcells_s": round(cells / (ms_gen + ms_ero) / 1e6, 3), "gcells_s_noise_only": round(cells / ms_gen / 1e6, 3)}
+                    continue
+                t.init_scene(pkg.make_config(mesh_gen_mode=m, mesh_freq_filter=9 - args.octaves))
+                mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+                rr = 2
                 t.timer_start()
-                t.apply_erosion_dev(z.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)
-                ms_ero += t.timer_stop() / reps
-            detail = {"ms_noise_kernels": round(ms_gen, 4), "ms_grid_kernel": round(ms_grid, 4), "ms_minmax_unfused": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)}
+                for _ in range(rr):
+                    mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+                msn = t.timer_stop() / rr
+                t.timer_start()
+                t.apply_erosion_dev(z.data_ptr(), N, N, mnm, args.droplets, pkg.ERODE_MINZ_IS_MIN)
+                mse = t.timer_stop()
+                fl = flops_per_cell(m, args.octaves)
+                md[name] = {"ms_noise": round(msn, 4), "ms_erosion": round(mse, 4), "gcells_s": round(cells / (msn + mse) / 1e6, 3), "gcells_s_noise_only": round(cells / msn / 1e6, 3),
+                            "tflops_8d": round(fl * cells / (msn * 1e-3) / 1e12, 2), "frac_fp32_peak": round(fl * cells / (msn * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+            t.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
+            detail["modes"] = md
+    barrier()
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = world * cells * args.steps / dt / 1e9
-        terms = 10 * args.octaves if mode == 0 else None
-        # dominant kernel by time: the noise grid kernel (k_sine_grid / k_noise_grid). Algorithmic bytes: 4 B written per cell.
+        ms_step = dt / K * 1e3
+        # dominant kernel by time: the noise grid kernel (k_sine_grid / k_noise_grid).  It is fp32-VALU bound (SURVEY 8d: 45 flop per byte written), so the
+        # roofline is the flop one: achieved = SURVEY 8(d)'s flops per cell x cells / kernel time, peak = the chip's fp32 vector peak.  The HBM side
+        # (4 B written per cell) is reported beside it.
         ms_k = detail["ms_grid_kernel"]
-        achieved = 4.0 * cells / (ms_k * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the PMC passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE), only for the configuration they were taken on
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_sine_grid"]
-            if mode == 0 and N == 16384 and args.octaves == 8:
-                traffic = pm["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        roof = {"bound": "hbm", "kernel": "k_sine_grid (+table kernels)" if mode == 0 else f"k_noise_grid<{args.mode}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": 4 * cells,
-                "note": "kernel is fp32-VALU bound, not HBM bound: see valu_frac (mul and add issue separately because the CPU reference has no FMA)"}
-        if terms:
-            ops = 2.0 * terms * cells / (ms_k * 1e-3) / 1e12
-            roof["valu_tops"] = round(ops, 2); roof["valu_peak_tops"] = VALU_PEAK_TOPS; roof["valu_frac"] = round(ops / VALU_PEAK_TOPS, 4)
-            # the HBM fraction this kernel could reach at 100 % of the (nominal) non-FMA VALU peak: 4 B per 2*terms ops
-            roof["hbm_frac_ceiling_when_valu_bound"] = round(4.0 / (2.0 * terms) * VALU_PEAK_TOPS * 1e12 / (HBM_PEAK_GBS * 1e9), 4)
-        out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident",
-                          "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P, "parallelism": f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU"},
+        fl = flops_per_cell(mode, args.octaves)
+        tflops = fl * cells / (ms_k * 1e-3) / 1e12
+        hbm = 4.0 * cells / (ms_k * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, profiles/*_pmc_traffic.json), only for the configuration they were taken on
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]["k_sine_grid"]
+                if mode == 0 and N == 16384 and args.octaves == 8:
+                    traffic = pm["hbm_bytes_per_launch"]
+                    break
+            except Exception:
+                pass
+        roof = {"bound": "valu", "kernel": "k_sine_grid (+table kernels)" if mode == 0 else f"k_noise_grid<{args.mode}>", "achieved": round(tflops, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "algorithmic_flops": fl * cells, "algorithmic_bytes": 4 * cells,
+                "hbm_achieved_gbs": round(hbm, 2), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm / HBM_PEAK_GBS, 4),
+                "nofma_peak_tops": VALU_NOFMA_TOPS, "nofma_frac": round(tflops / VALU_NOFMA_TOPS, 4),
+                "note": "fp32 VALU bound; the peak counts fused multiply-adds, which bit-parity with the FMA-free CPU reference forbids (mul and add issue separately): nofma_frac is the fraction of the reachable rate"}
+        out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
+               "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if args.workload == "heightmap" else 1, "parallelism": par},
+               "latency_ms_single": detail.get("single", {}).get("latency_ms_single", round(ms_step, 4) if P == 1 else None),
                "roofline": roof, "detail": dict(detail, erosion=rep)}
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -150,6 +150,11 @@ int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, 
 /* same, plus min(vals)/max(vals) folded into the grid kernel (what heightmap_t::run_erosion / get_heightmap_z_range compute next); synchronous */
 int  terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max);
 int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out);
+/* rows [row0, row0 + nrows) of the nx x ny grid only, d_out = nrows*nx floats; bit-identical to the same rows of the full-grid call (heightmap_t::proc_gen's
+ * row loop is independent per row, src/heightmap.cpp:139-143): one heightmap as row strips on several GPUs.  h_min / h_max (optional, synchronous when given):
+ * min / max of the strip -- min(vals) of the whole map is the minimum over the strips (one float through ncclAllReduce(min), see bench.py --workload strips). */
+int  terra_gen_grid_rows_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin,
+                                    uint32_t row0, uint32_t nrows, float *d_out, float *h_min, float *h_max);
 
 /* ---- point query and ground-mode post-pass
  * eval_mesh_sin_terms (src/mesh_gen.cpp:797-805): non-separable point query used for biome parameters / collision height; evaluated on the host.

@@ -144,7 +144,8 @@ extern "C" unsigned long long terra_emul_noise_lut_mismatches(unsigned n, uint32
 			int const shape = (int)(i >> 5) % 3;
 			float const sc = 1.0f/0.0007f; // grid coordinates whose noise-space image is x0, y0
 			terra::nv2 const gx = {x0*sc, x1*sc}, gy = {y0*sc, y1*sc};
-			terra::nv2 const a = terra::noise_zval_t<terra::MGEN_DWARP_GPU, terra::nv2, terra::noise_tab_t>(gx, gy, shape, nc, ns), b = terra::noise_zval_t<terra::MGEN_PERLIN, terra::nv2, terra::noise_tab_t>(gx, gy, shape, nc, ns);
+			terra::noise_oct_t const oc = terra::make_noise_oct(nc);
+			terra::nv2 const a = terra::noise_zval_tab<terra::MGEN_DWARP_GPU>(gx, gy, shape, nc, oc, ns), b = terra::noise_zval_tab<terra::MGEN_PERLIN>(gx, gy, shape, nc, oc, ns);
 			if (!same(a[0], terra::noise_zval<terra::MGEN_DWARP_GPU>(gx[0], gy[0], shape, nc)) || !same(a[1], terra::noise_zval<terra::MGEN_DWARP_GPU>(gx[1], gy[1], shape, nc))) ++bad;
 			if (!same(b[0], terra::noise_zval<terra::MGEN_PERLIN>(gx[0], gy[0], shape, nc)) || !same(b[1], terra::noise_zval<terra::MGEN_PERLIN>(gx[1], gy[1], shape, nc))) ++bad;
 		}

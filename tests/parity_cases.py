@@ -684,6 +684,28 @@ def case_gen_grid_minmax(pkg, t, orc, mode, n):
     assert np.float32(mn) == a.min() and np.float32(mx) == a.max(), (mn, mx, a.min(), a.max())
 
 
+def case_grid_row_strips(pkg, t, orc, mode, nx, ny, nstrips):
+    """one heightmap as row strips (terra_gen_grid_rows_minmax_dev): the strips tile the full grid bit for bit, min / max fold to the grid's."""
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=mode, mesh_freq_filter=1)
+    st = t.init_scene(pc)
+    orc.init(oc)
+    ref = orc.gen_grid(-nx / 2, 7 - ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, 1)
+    bounds = [round(i * ny / nstrips) for i in range(nstrips + 1)]
+    buf = t.alloc(nx * ny * 4)
+    mns, mxs = [], []
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        if r1 == r0:
+            continue
+        mn, mx = t.gen_grid_rows_minmax_dev(buf.ptr + r0 * nx * 4, -nx / 2, 7 - ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, r0, r1 - r0, pkg.GEN_GLACIATE)
+        mns.append(mn); mxs.append(mx)
+    z = buf.download(np.float32, (ny, nx)); buf.free()
+    assert_bit_equal(ref, z, f"row strips mode {mode}")
+    assert np.float32(min(mns)) == ref.min() and np.float32(max(mxs)) == ref.max()
+    import pytest
+    with pytest.raises(pkg.TerraError):
+        t.gen_grid_rows_minmax_dev(0x1000, 0, 0, st.DX_VAL, st.DY_VAL, nx, ny, ny - 1, 2)
+
+
 def case_generator_protocol(pkg, t, orc):
     """mesh_xy_grid_cache_t async protocol: no_wait launch returns 0, the second call collects (src/mesh_gen.cpp:597-603)."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=1)

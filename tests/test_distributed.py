@@ -14,9 +14,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def partition(n_units, world, rank):
-    """contiguous block partition used by bench.py --workload tiles"""
-    per = (n_units + world - 1) // world
-    return range(min(rank * per, n_units), min((rank + 1) * per, n_units))
+    """contiguous block partition used by bench.py's tiles workload (3dworld_amd/dist.py: partition_tiles)"""
+    dmod = importlib.import_module("3dworld_amd.dist")
+    return dmod.partition_tiles(list(range(n_units)), rank, world)
 
 
 def _worker(rank, world, port, emul_lib, out_dir):
@@ -29,7 +29,7 @@ def _worker(rank, world, port, emul_lib, out_dir):
     t = pkg.Terra(0, emul_lib)
     t.init_scene(pkg.make_config(mesh_gen_mode=0))
     tiles = [(tx, ty) for ty in range(-2, 2) for tx in range(-3, 2)]  # 20 tiles
-    mine = [tiles[i] for i in partition(len(tiles), world, rank)]
+    mine = importlib.import_module("3dworld_amd.dist").partition_tiles(tiles, rank, world)
     z, st, nm, mnz = t.tiles_create_zvals(mine, 40)
     np.save(os.path.join(out_dir, f"z_{rank}.npy"), z)
     dist.barrier()
@@ -58,6 +58,50 @@ def test_two_ranks_tile_sharding_matches_oracle(emul_lib, orc, tmp_path):
     for i in (0, 7, 10, 19):
         zo, _ = orc.tile_create_zvals(*tiles[i], 40)
         orclib.assert_bit_equal(zo, z[i], f"tile {tiles[i]}")
+
+
+def _strips_worker(rank, world, port, emul_lib, out_dir, mode, nx, ny):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("3dworld_amd")
+    dmod = importlib.import_module("3dworld_amd.dist")
+    t = pkg.Terra(0, emul_lib)
+    st = t.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+    r0, r1 = dmod.strip_rows(ny, rank, world)
+    buf = t.alloc(max(1, (r1 - r0) * nx * 4))
+    q0, q1, mn, mx = dmod.sharded_heightmap_strips(t, dist, buf.ptr, -nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)
+    assert (q0, q1) == (r0, r1)
+    np.save(os.path.join(out_dir, f"strip_{rank}.npy"), buf.download(np.float32, (r1 - r0, nx)))
+    np.save(os.path.join(out_dir, f"mm_{rank}.npy"), np.array([mn, mx], np.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,nx,ny", [(0, 260, 131), (1, 70, 51)])
+def test_two_ranks_one_heightmap_as_row_strips(emul_lib, orc, tmp_path, mode, nx, ny):
+    """bench.py's strips workload: ONE heightmap, two ranks, each its row strip, min / max of the whole map by all_reduce of one float
+    (gloo here, RCCL on the MI355X node).  The union equals the oracle's full grid bit for bit and every rank holds the global min / max."""
+    import torch.multiprocessing as mp
+    import orclib
+    port = 33500 + (os.getpid() + mode) % 2000
+    mp.spawn(_strips_worker, args=(2, port, emul_lib, str(tmp_path), mode, nx, ny), nprocs=2, join=True)
+    z = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(2)])
+    s = orc.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+    ref = orc.gen_grid(-nx / 2, -ny / 2, s.DX_VAL, s.DY_VAL, nx, ny, 1)
+    orclib.assert_bit_equal(ref, z, "union of the row strips")
+    for r in range(2):
+        mm = np.load(tmp_path / f"mm_{r}.npy")
+        assert mm[0] == ref.min() and mm[1] == ref.max()
+
+
+def test_strip_rows_cover_the_grid_once():
+    dmod = importlib.import_module("3dworld_amd.dist")
+    for ny in (1, 5, 130, 16384):
+        for world in (1, 2, 3, 8):
+            rows = [y for r in range(world) for y in range(*dmod.strip_rows(ny, r, world))]
+            assert rows == list(range(ny))
 
 
 def _shadow_worker(rank, world, port, emul_lib, out_dir, light):

@@ -135,6 +135,11 @@ def test_gen_grid_minmax(pkg, gpu, orc, mode, n):
     pc.case_gen_grid_minmax(pkg, gpu, orc, mode, n)
 
 
+@pytest.mark.parametrize("mode,nx,ny,nstrips", [(0, 1030, 777, 8), (0, 256, 300, 3), (1, 300, 200, 4), (4, 140, 90, 2), (2, 64, 5, 8)])
+def test_grid_row_strips(pkg, gpu, orc, mode, nx, ny, nstrips):
+    pc.case_grid_row_strips(pkg, gpu, orc, mode, nx, ny, nstrips)
+
+
 def test_ground_mesh_and_point_queries(pkg, gpu, orc):
     pc.case_ground_mesh_and_point_queries(pkg, gpu, orc)
 
@@ -182,6 +187,43 @@ def test_full_size_sine_grid_tiled_equals_per_cell_kernel_and_oracle_rows(pkg, g
     cols = orc.gen_grid(-N / 2, -N / 2, st.DX_VAL, st.DY_VAL, 6, N, 1)
     assert_bit_equal(cols, za[:, :6], "oracle columns")
     assert np.isfinite(za).all()
+
+
+def test_bench_step_full_size_equals_oracle(pkg, gpu, orc):
+    """BASELINE's headline configuration, the exact calls bench.py times (gen_grid_minmax_dev with the fused min + apply_erosion_dev with
+    TERRA_ERODE_MINZ_IS_MIN's sparse clamp): 16384^2, 8 octaves = 80 sine terms, 1000 droplets -- the WHOLE grid and the returned min against the
+    oracle's heightmap_t::proc_gen sequence (src/heightmap.cpp:130-187) on the host's cores, bit for bit."""
+    N, droplets = 16384, 1000
+    st = gpu.init_scene(pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    a = gpu.alloc(N * N * 4)
+    mn, mx = gpu.gen_grid_minmax_dev(a.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+    gpu.apply_erosion_dev(a.ptr, N, N, mn, droplets, pkg.ERODE_MINZ_IS_MIN)
+    rep = gpu.erosion_report().as_dict()
+    z = a.download(np.float32, (N, N)); a.free()
+    ref = orc.gen_grid(-N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 1)   # build_arrays + enable_glaciate + eval_index loop, OpenMP over rows
+    rmn, rmx = ref.min(), ref.max()
+    assert np.float32(mn) == rmn and np.float32(mx) == rmx, (mn, mx, rmn, rmx)
+    orc.apply_erosion(ref, float(rmn), droplets)                          # serial droplet order
+    diff = z.view(np.uint32) != ref.view(np.uint32)
+    assert not diff.any(), f"{int(diff.sum())} cells differ, first at {np.argwhere(diff)[:4].tolist()}"
+    assert rep["droplets"] == droplets
+    print("erosion report", rep)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 4])
+def test_full_size_noise_modes_whole_grid_equals_oracle(pkg, gpu, orc, mode):
+    """BASELINE config 2 (4096^2, 8 octaves) in the fBm modes: every cell against the oracle, plus the fused min / max."""
+    N = 4096
+    st = gpu.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+    orc.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+    a = gpu.alloc(N * N * 4)
+    mn, mx = gpu.gen_grid_minmax_dev(a.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+    z = a.download(np.float32, (N, N)); a.free()
+    ref = orc.gen_grid(-N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 1)
+    diff = z.view(np.uint32) != ref.view(np.uint32)
+    assert not diff.any(), f"mode {mode}: {int(diff.sum())} cells differ, first at {np.argwhere(diff)[:4].tolist()}"
+    assert np.float32(mn) == ref.min() and np.float32(mx) == ref.max()
 
 
 def test_full_size_erosion_speculative_equals_serial_walk(pkg, gpu):

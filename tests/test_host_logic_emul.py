@@ -156,6 +156,11 @@ def test_ground_mesh_and_point_queries(pkg, emul, orc):
     pc.case_ground_mesh_and_point_queries(pkg, emul, orc)
 
 
+@pytest.mark.parametrize("mode,nx,ny,nstrips", [(0, 300, 200, 3), (1, 90, 70, 4), (4, 40, 33, 2)])
+def test_grid_row_strips(pkg, emul, orc, mode, nx, ny, nstrips):
+    pc.case_grid_row_strips(pkg, emul, orc, mode, nx, ny, nstrips)
+
+
 def test_generator_protocol(pkg, emul, orc):
     pc.case_generator_protocol(pkg, emul, orc)
 
