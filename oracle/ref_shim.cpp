@@ -1,33 +1,60 @@
 // oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
 //
 // Link shim that lets the reference's OWN translation units
-//     /root/reference/src/mesh_gen.cpp, erosion.cpp, upsurface.cpp, visibility.cpp, Math3d.cpp, heightmap.cpp   (+ vendored glm 0.9.9.1 headers)
+//     /root/reference/src/mesh_gen.cpp, erosion.cpp, upsurface.cpp, visibility.cpp, Math3d.cpp, heightmap.cpp, tiled_mesh.cpp, Textures.cpp   (+ vendored glm 0.9.9.1 headers)
 // be compiled unmodified, in place, into oracle/_ref/liboracle_ref.so (recipe: oracle/Makefile).
 // No reference source is copied: this file only (1) DEFINES the process globals those TUs declare
-// `extern` (they live in 3DWorld.cpp / Textures.cpp / display_world.cpp / Universe.cpp, which cannot be
+// `extern` (they live in 3DWorld.cpp / display_world.cpp / Universe.cpp / grass.cpp, which cannot be
 // built without OpenGL), (2) STUBS the GL/IO entry points they reference but that the CPU path never
-// calls, and (3) exports a plain C harness ("ref_*") that ctypes can drive.
+// calls (tiled_mesh.cpp and Textures.cpp are mostly renderer: -ffunction-sections + --gc-sections drop everything the exported
+// harness does not reach, the link then needs a dozen libGL no-ops instead of hundreds of stubs), and (3) exports a plain C harness ("ref_*") that ctypes can drive.
+// The tile rows are the reference's own members: tile_t::create_zvals, calc_mesh_ao_lighting, create_texture (+ add_grass_block_at, update_terrain_params),
+// upload_normal_texture / get_norm, and get_tids / update_lttex_ix / gen_tex_height_tables / get_bare_ls_tid from Textures.cpp.
 //
 // The handful of functions that live in TUs we cannot build are restated here, each with its citation:
 //   set_scene_constants   src/matrix_ops.cpp:59-84
-//   get_bare_ls_tid       src/Textures.cpp:1284-1287
-//   gen_tex_height_tables src/Textures.cpp:1757-1761
 //   rgen_core_t::randd    src/gen_object.cpp:377-381
 //   the voxel fill loop   src/voxels.cpp:312-345       (voxels.o has >100 unrelated externals)
-//   tile_t::create_zvals  src/tiled_mesh.cpp:467-546   (driver only; generator + erosion are the real TUs)
-//   tile_t::get_norm / upload_normal_texture  src/tiled_mesh.h:281-284, src/tiled_mesh.cpp:865-880
-//   texture_t::alloc / free_client_mem / set_16_bit_grayscale / write_pixel_16_bits  src/Textures.cpp:486-517,1889-1893, src/image_io.cpp:493-496 (for heightmap.cpp)
-//   tile_t::calc_mesh_ao_lighting, create_texture, update_terrain_params; get_tids; write_map_mode_heightmap_image  (drivers, see each)
+//   texture_t::set_16_bit_grayscale  src/image_io.cpp:493-496 (for heightmap.cpp)
+//   write_map_mode_heightmap_image / get_heightmap_z_range  src/map_view.cpp:399-442 (driver over the reference's own setup_height_gen_cached / eval_index / interpolate_height)
 
-#include "3DWorld.h"
+// The tile functions under test are private members of tile_t (src/tiled_mesh.h:156-331): this harness -- and only it -- sees the reference's class
+// definitions with every member public.  Access specifiers do not change g++'s object layout, so the objects are the ones tiled_mesh.o works on.
+#define timer_t stdlib_timer_t // as src/3DWorld.h:7-8 does before its own system includes
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <assert.h>
+#include <vector>
+#include <memory>
+#include <deque>
+#include <algorithm>
+#include <set>
 #include <map>
+#include <iostream>
+#include <fstream>
+#include <string>
+#include <sstream>
+#include <iterator>
 #include <functional>
+#include <unordered_map>
+#include <unordered_set>
+#include <list>
+#include <array>
+#include <cfloat>
+#include <omp.h>
+#define private public
+#define protected public
+#include "3DWorld.h"
 #include "mesh.h"
 #include "textures.h"
 #include "heightmap.h"
 #include "shaders.h"
 #include "upsurface.h"
 #include "sinf.h"
+#include "tiled_mesh.h"
+#undef private
+#undef protected
 #include <glm/gtc/noise.hpp>
 #include <omp.h>
 #include <cfloat>
@@ -54,7 +81,6 @@ rand_gen_t global_rand_gen;
 unsigned char **mesh_draw = NULL;
 float **mesh_height = NULL;
 char *mesh_file(nullptr), *mh_filename(nullptr), *mh_filename_tt(nullptr);
-float h_dirt[NTEX_DIRT], clip_hd1;
 float ocean_wave_height(0.0); // reference default is DEF_OCEAN_WAVE_HEIGHT; harness sets it explicitly
 
 extern float zmin, zmax, zmax_est, glaciate_exp, mesh_scale, mesh_scale_z, mesh_scale_z_inv, mesh_height_scale;
@@ -63,6 +89,9 @@ extern float sinTable[][5];
 extern float MESH_START_MAG, MESH_START_FREQ, MESH_MAG_MULT, MESH_FREQ_MULT;
 extern hmap_params_t hmap_params;
 extern ttex lttex_dirt[];
+extern float h_dirt[NTEX_DIRT], clip_hd1; // src/Textures.cpp (compiled in place)
+void gen_tex_height_tables();             // src/Textures.cpp:1757-1761
+int get_bare_ls_tid(float zval);          // src/Textures.cpp:1284-1287
 
 // ---------------------------------------------------------------------------------------------
 // (2) stubs for GL / IO symbols referenced by the TUs but never reached on the CPU path
@@ -82,22 +111,7 @@ void shader_t::enable() {}
 void shader_t::disable() {}
 bool shader_t::add_uniform_float(char const *const, float) const {return 0;}
 void texture_t::load(int, bool, bool, bool) {ref_unreachable("texture_t::load");}
-void texture_t::resize(int, int) {ref_unreachable("texture_t::resize");}
-void texture_t::gl_delete() {}
-// texture_t client-memory management and 16-bit pixel writer, needed by the reference's heightmap.cpp (src/Textures.cpp:486-490,512-517,1889-1893; src/image_io.cpp:493-496)
-void texture_t::alloc() {free_data(); data = new unsigned char[num_bytes()];}
-void texture_t::free_client_mem() {
-	if (orig_data    != data) {delete [] orig_data;}
-	if (colored_data != data) {delete [] colored_data;}
-	delete [] data;
-	data = orig_data = colored_data = NULL;
-}
-void texture_t::set_16_bit_grayscale() {ncolors = 2; is_16_bit_gray = 1;}
-void texture_t::write_pixel_16_bits(unsigned ix, float val) {
-	unsigned char const high_bits(val); // high bits - truncate
-	data[(ix<<1)+1] = high_bits;
-	data[ix<<1]     = (unsigned char)(256.0f*(val - float(high_bits))); // low bits - remainder
-}
+void texture_t::set_16_bit_grayscale() {ncolors = 2; is_16_bit_gray = 1;} // src/image_io.cpp:493-496
 int texture_t::write_to_png(string const &) const {ref_unreachable("texture_t::write_to_png"); return 0;}
 // city generation and the heightmap output file name are outside the path
 bool have_cities() {return 0;}
@@ -108,16 +122,12 @@ void get_heightmap_z_range(vector<float> const &heights, float &min_z, float &ma
 	min_z = FLT_MAX; max_z = -FLT_MAX;
 	for (unsigned i = 0; i < heights.size(); ++i) {min_eq(min_z, heights[i]); max_eq(max_z, heights[i]);}
 }
-void free_texture(unsigned &tid) {tid = 0;}
 void checked_fclose(FILE *fp) {if (fp) fclose(fp);}
 bool open_file(FILE *&fp, char const *const fn, string const &, char const *const mode) {fp = fopen(fn, mode); return (fp != nullptr);}
 void gen_scene(int, int, int, int, int) {}
 void regen_lightmap() {}
 void update_cpos() {}
 float int_mesh_zval_pt_off(point const &, int, int, bool) {return 0.0;}
-bool using_hmap_with_detail() {return 0;}
-bool using_tiled_terrain_hmap_tex() {return 0;}
-float get_tiled_terrain_height_tex(float, float, bool) {return 0.0;}
 void register_timing_value(const char *, int, bool) {}
 extern "C" int glutGet(unsigned) {return 0;}
 
@@ -128,16 +138,6 @@ double rgen_core_t::randd() {
 	return rand_num/2147483563.;
 }
 
-// src/Textures.cpp:1757-1761
-void gen_tex_height_tables() {
-	for (unsigned i = 0; i < NTEX_DIRT; ++i) {h_dirt[i] = pow(lttex_dirt[i].zval, glaciate_exp);}
-	clip_hd1 = (0.90*h_dirt[1] + 0.10*h_dirt[0]);
-}
-// src/Textures.cpp:1284-1287
-int get_bare_ls_tid(float zval) {
-	float const relh(relh_adj_tex + (zval - zmin)/(zmax - zmin));
-	return ((relh > clip_hd1) ? (int)ROCK_TEX : (int)DIRT_TEX); // rock or dirt
-}
 
 // src/matrix_ops.cpp:59-84 (only the constants the hot path reads)
 static void ref_set_scene_constants() {
@@ -309,13 +309,6 @@ struct shim_hmap_manager_t : public terrain_hmap_manager_t {
 	}
 	void get_image(unsigned char *out) const {memcpy(out, hmap.get_data(), hmap.num_bytes());}
 	heightmap_t &image() {return hmap;}
-	virtual bool modify_height_value(int x, int y, hmap_val_t val, bool is_delta, float fract_x, float fract_y, bool allow_wrap=1) {
-		int clamped_x(x), clamped_y(y);
-		if (!clamp_xy(clamped_x, clamped_y, fract_x, fract_y, allow_wrap)) return 0;
-		assert(clamped_x >= 0 && clamped_y >= 0);
-		modify_height(tex_mod_map_manager_t::mod_elem_t(clamped_x, clamped_y, val), is_delta);
-		return 1;
-	}
 	void clear_mods() {mod_map.clear(); brush_vect.clear();}
 	unsigned num_mods() const {return mod_map.size();}
 	unsigned num_brushes() const {return brush_vect.size();}
@@ -325,7 +318,11 @@ struct shim_hmap_manager_t : public terrain_hmap_manager_t {
 		for (unsigned i = 0; i < brush_vect.size(); ++i) {brushes[i] = brush_vect[i];}
 	}
 };
-static shim_hmap_manager_t shim_hmap;
+// The image lives in the reference's OWN manager object, `terrain_hmap_manager` (src/tiled_mesh.cpp:271; its class tiled_terrain_hmap_manager_t is local to that
+// file and derives from terrain_hmap_manager_t without adding state the harness touches), so that tile_t::create_zvals / calc_mesh_ao_lighting sample it
+// themselves.  The helper subclass above only adds accessors (no data members, the virtual call goes to the reference's override).
+extern terrain_hmap_manager_t terrain_hmap_manager;
+#define shim_hmap (*reinterpret_cast<shim_hmap_manager_t *>(&terrain_hmap_manager))
 REF_API void ref_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {shim_hmap.set_image(pixels, width, height, ncolors);}
 REF_API void ref_hmap_get(unsigned char *out) {shim_hmap.get_image(out);}
 REF_API void ref_set_mesh_height_scales_for_zval_range(float min_z, float dz) {set_mesh_height_scales_for_zval_range(min_z, dz);}
@@ -379,136 +376,161 @@ REF_API void ref_heightmap_proc_gen(int width, int height, unsigned iters, unsig
 	file_scale_tz[0] = mesh_file_scale; file_scale_tz[1] = mesh_file_tz;
 	erosion_iters_tt = prev;
 }
-static bool shim_using_hmap() {return shim_hmap.enabled();}                             // using_tiled_terrain_hmap_tex (src/tiled_mesh.cpp:273)
-static bool shim_using_hmap_with_detail() {return (shim_using_hmap() && mesh_scale < 0.75);} // src/tiled_mesh.cpp:274
-static float shim_get_xy_scale() { // src/tiled_mesh.cpp:447-451
-	bool const add_detail(shim_using_hmap_with_detail());
-	if (!add_detail && shim_using_hmap()) return 0.0;
-	return (add_detail ? SHIM_HMAP_DETAIL_SCALE : 1.0);
+
+// ---------------------------------------------------------------------------------------------
+// (4) the tile functions: the reference's OWN tile_t members (src/tiled_mesh.cpp compiled in place; get_tids / update_lttex_ix / gen_tex_height_tables
+//     from src/Textures.cpp compiled in place).  The harness builds a tile_t, calls the member, copies the member data out.  GL entry points the members
+//     end with (texture uploads) are no-ops below; glTexImage2D hands the uploaded bytes to the harness (that is how the normal map, which
+//     upload_normal_texture builds in a local vector, comes back).  Globals of other subsystems the members read are defined with the reference's defaults.
+// ---------------------------------------------------------------------------------------------
+bool enable_tiled_mesh_ao(0);       // src/3DWorld.cpp:73,1778
+bool add_city_grass(0), water_is_lava(0); // src/3DWorld.cpp
+int DISABLE_WATER(0);
+float vegetation(1.0), biome_x_offset(0.0);
+unsigned grass_density(0), num_rnd_grass_blocks(16); // src/grass.cpp:14
+extern unsigned erosion_iters_tt;
+extern bool enable_terrain_env;     // src/tiled_mesh.cpp:82
+REF_API void ref_set_tiled_mesh_ao(int v) {enable_tiled_mesh_ao = (v != 0);}
+
+// cities / tunnels / buildings / the disabled-mesh mask: other subsystems' inputs of create_zvals / create_texture, absent here (terrain-only branch)
+int  check_city_contains_overlaps(cube_t const &) {return 0;}
+bool check_mesh_disable(point const &, float) {return 0;}
+bool check_inside_city(point const &, float) {return 0;}
+bool city_has_grass_at(point const &, float, cube_t &) {return 0;}
+bool tile_contains_tunnel(cube_t const &) {return 0;}
+bool no_grass_under_buildings() {return 0;}
+bool check_buildings_no_grass(point const &) {return 0;}
+cube_t get_city_grass_bcube_at(cube_t const &) {return cube_t();}
+void get_city_grass_coll_cubes(cube_t const &, vect_cube_t &, vect_cube_t &) {}
+void get_building_grass_coll_cubes(cube_t const &, vect_cube_t &) {}
+// GL: uploads are no-ops; the last 2-D upload's pixels are kept for the harness
+static void const *ref_last_upload = nullptr; static int ref_last_upload_w = 0, ref_last_upload_h = 0;
+extern "C" {
+}
+static vector<unsigned char> ref_upload_copy; // RGBA8 uploads only (what the members under test upload)
+static void ref_keep_upload(GLsizei w, GLsizei h, void const *pixels) {ref_last_upload = pixels; ref_last_upload_w = w; ref_last_upload_h = h; if (pixels) {ref_upload_copy.assign((unsigned char const *)pixels, (unsigned char const *)pixels + (size_t)4*w*h);}}
+extern "C" {
+void glTexImage2D(GLenum, GLint, GLint, GLsizei w, GLsizei h, GLint, GLenum, GLenum, const void *pixels) {ref_keep_upload(w, h, pixels);}
+void glTexSubImage2D(GLenum, GLint, GLint, GLint, GLsizei w, GLsizei h, GLenum, GLenum, const void *pixels) {ref_keep_upload(w, h, pixels);}
+}
+// setup_texture / bind_2d_texture are the reference's own (src/Textures.cpp); what they call in libGL does nothing here
+extern "C" {
+void glGenTextures(GLsizei n, GLuint *t) {for (GLsizei i = 0; i < n; ++i) {t[i] = 1;}}
+void glBindTexture(GLenum, GLuint) {}
+void glDeleteTextures(GLsizei, const GLuint *) {}
+GLboolean glIsTexture(GLuint) {return 1;}
+void glPixelStorei(GLenum, GLint) {}
+void glTexParameterf(GLenum, GLenum, GLfloat) {}
+void glTexParameteri(GLenum, GLenum, GLint) {}
+int gluScaleImage(unsigned, int, int, unsigned, const void *, int, int, unsigned, void *) {ref_unreachable("gluScaleImage"); return 0;}
+const unsigned char *gluErrorString(unsigned) {return (const unsigned char *)"";}
+}
+int omp_get_thread_num_3dw() {return omp_get_thread_num();} // src/3DWorld.cpp
+bool check_gl_error(unsigned) {return 0;}                   // src/gl_ext_arb.cpp: there is no GL context to ask
+
+struct ref_landscape_t {float vegetation, temperature, biome_x_offset, mesh_scale_z; int water_is_lava, disable_water, enable_terrain_env; unsigned grass_density, num_rnd_grass_blocks;};
+struct ref_grass_block_t {unsigned ix; float zmin, zmax;}; // tile_t::grass_block_t (src/tiled_mesh.h:186)
+REF_API void ref_set_landscape(ref_landscape_t const *p) {
+	vegetation = p->vegetation; temperature = p->temperature; biome_x_offset = p->biome_x_offset; mesh_scale_z = p->mesh_scale_z;
+	water_is_lava = (p->water_is_lava != 0); DISABLE_WATER = p->disable_water; enable_terrain_env = (p->enable_terrain_env != 0);
+	grass_density = p->grass_density; num_rnd_grass_blocks = p->num_rnd_grass_blocks;
+	init_terrain_mesh(); // calls gen_tex_height_tables()
 }
 
-// enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778; scene_config/config.txt:81 turns it on): a config-file flag read by the tile code
-static bool shim_enable_tiled_mesh_ao(0);
-REF_API void ref_set_tiled_mesh_ao(int v) {shim_enable_tiled_mesh_ao = (v != 0);}
-unsigned const SHIM_NUM_AO_DIRS = 8, SHIM_NUM_AO_STEPS = 8, SHIM_AO_RAY_LEN = SHIM_NUM_AO_STEPS*(SHIM_NUM_AO_STEPS+1)/2; // src/tiled_mesh.cpp:41-43
+// a tile_t whose heavy members (trees, scenery, clouds: other subsystems, constructors in translation units that are not built) are never constructed:
+// zero-filled storage -- what a value-initialised tile_t of empty containers is -- with the scalar members set as tile_t::tile_t(size, x, y) sets them
+// (src/tiled_mesh.cpp:302-314) and the default member initialisers of the members the functions under test read
+struct ref_tile_box_t {
+	tile_t *t;
+	ref_tile_box_t(int tx, int ty) {
+		t = (tile_t *)calloc(1, sizeof(tile_t));
+		unsigned const size(128);
+		t->size = size; t->stride = size + 1; t->zvsize = size + 2;
+		t->x1 = tx*(int)size; t->y1 = ty*(int)size; t->x2 = t->x1 + size; t->y2 = t->y1 + size;
+		t->wx1 = t->x2; t->wy1 = t->y2; t->wx2 = t->x1; t->wy2 = t->y1; // start denormalized
+		t->mesh_off.set_from_xyoff2(); // tile_offset_t(xoff-xoff2, yoff-yoff2) with all four 0
+		t->xstart = get_xval(t->x1 + t->mesh_off.dxoff); t->ystart = get_yval(t->y1 + t->mesh_off.dyoff);
+		t->radius = t->calc_radius();
+		t->mzmin = t->mzmax = t->ptzmax = t->dtzmax = 0.0; // get_camera_pos().z: overwritten by create_zvals
+		t->base_tsize = 512; // NORM_TEXELS (src/tiled_mesh.cpp)
+		t->sun_shadows_invalid = t->moon_shadows_invalid = t->recalc_tree_grass_weights = 1;
+		for (unsigned i = 0; i < 4; ++i) {tile_t::terrain_params_t &p(t->params[i>>1][i&1]); p.hoff = 0.0; p.hscale = 1.0; p.veg = 1.0; p.grass = 1.0; p.dirt = 0.0;}
+	}
+	~ref_tile_box_t() { // only the containers the harness / the functions under test filled
+		typedef vector<float> vf; typedef vector<unsigned char> vu;
+		t->zvals.~vf(); t->ao_zvals.~vf(); t->mesh_weight_data.~vu(); t->weight_data.~vu(); t->ao_lighting.~vu();
+		t->grass_blocks.~vector<tile_t::grass_block_t>();
+		free(t);
+	}
+	void set_zvals(float const *z) {t->zvals.assign(z, z + t->zvsize*t->zvsize);}
+};
 
 REF_API void ref_tile_create_zvals(int tx, int ty, unsigned iters_tt, float *zvals, ref_tile_stats_t *st) {
-	unsigned const size(128), stride(size+1), zvsize(stride+1);
-	int const x1(tx*size), y1(ty*size), x2(x1 + size), y2(y1 + size);
-	int wx1(x2), wy1(y2), wx2(x1), wy2(y1); // start denormalized (src/tiled_mesh.cpp:308)
+	unsigned const prev(erosion_iters_tt);
+	erosion_iters_tt = iters_tt;
+	ref_tile_box_t b(tx, ty);
 	mesh_xy_grid_cache_t height_gen;
-	float mzmin(FAR_DISTANCE), mzmax(-FAR_DISTANCE);
-	unsigned const block_size(zvsize/4), context_sz(stride + 2*SHIM_AO_RAY_LEN);
-	float const wpz_max(ref_get_max_sea_level());
-	if (shim_using_hmap()) { // src/tiled_mesh.cpp:499-503
-		bool const add_detail(shim_using_hmap_with_detail());
-		float const xy_scale(shim_get_xy_scale());
-		if (xy_scale != 0.0) {height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), xy_scale*DX_VAL, xy_scale*DY_VAL, zvsize, zvsize, 0, 0, 0); height_gen.enable_glaciate();}
-#pragma omp parallel for schedule(static,1)
-		for (int y = 0; y < (int)zvsize; ++y) {
-			for (unsigned x = 0; x < zvsize; ++x) {
-				float &zval(zvals[y*zvsize + x]);
-				zval = ref_get_clamped_height((x1 + x), (y1 + y));
-				if (add_detail) {zval += SHIM_HMAP_DETAIL_MAG*height_gen.eval_index(x, y);}
-			}
-		}
-		iters_tt = 0; // heightmap is eroded during load (:515)
+	bool const ok(b.t->create_zvals(height_gen, 0)); // tile_t::create_zvals itself (src/tiled_mesh.cpp:467-546)
+	erosion_iters_tt = prev;
+	if (!ok) {ref_unreachable("tile_t::create_zvals returned 0 without no_wait");}
+	memcpy(zvals, b.t->zvals.data(), b.t->zvals.size()*sizeof(float));
+	if (st) {
+		for (unsigned i = 0; i < 16; ++i) {st->sub_zmin[i] = b.t->sub_zmin[i>>2][i&3]; st->sub_zmax[i] = b.t->sub_zmax[i>>2][i&3];}
+		st->mzmin = b.t->mzmin; st->mzmax = b.t->mzmax; st->radius = b.t->radius;
+		st->wx1 = b.t->wx1; st->wy1 = b.t->wy1; st->wx2 = b.t->wx2; st->wy2 = b.t->wy2;
 	}
-	else if (shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU) { // AO + GPU noise: the zvals are clipped from the 201^2 AO context (src/tiled_mesh.cpp:478-488,505)
-		height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), DX_VAL, DY_VAL, context_sz, context_sz, 0, 0, 0);
-		height_gen.enable_glaciate();
-#pragma omp parallel for schedule(static,1)
-		for (int y = 0; y < (int)zvsize; ++y) {
-			for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = height_gen.eval_index(x + SHIM_AO_RAY_LEN, y + SHIM_AO_RAY_LEN);}
-		}
-	}
-	else {
-		height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, zvsize, zvsize, 0, 0, 0); // setup_height_gen_async, xy_scale=1
-		height_gen.enable_glaciate();
-#pragma omp parallel for schedule(static,1)
-		for (int y = 0; y < (int)zvsize; ++y) {
-			for (unsigned x = 0; x < zvsize; ++x) {zvals[y*zvsize + x] = height_gen.eval_index(x, y);}
-		}
-	}
-	apply_erosion(zvals, zvsize, zvsize, zmin, iters_tt);
-
-	for (unsigned yy = 0; yy < 4; ++yy) {
-		for (unsigned xx = 0; xx < 4; ++xx) {
-			unsigned const x_end((xx+1)*block_size), y_end((yy+1)*block_size);
-			float &szmin(st->sub_zmin[yy*4+xx]), &szmax(st->sub_zmax[yy*4+xx]);
-			szmin = FAR_DISTANCE; szmax = -FAR_DISTANCE;
-			for (unsigned y = yy*block_size; y <= y_end; ++y) {
-				for (unsigned x = xx*block_size; x <= x_end; ++x) {
-					float const z(zvals[y*zvsize + x]);
-					szmin = min(szmin, z); szmax = max(szmax, z);
-					if (z < wpz_max) {
-						wx1 = min(wx1, x1+int(x)); wy1 = min(wy1, y1+int(y));
-						wx2 = max(wx2, x1+int(x)); wy2 = max(wy2, y1+int(y));
-					}
-				}
-			}
-			mzmin = min(mzmin, szmin);
-			mzmax = max(mzmax, szmax);
-		}
-	}
-	st->mzmin = mzmin; st->mzmax = mzmax;
-	st->radius = 0.5*sqrt((DX_VAL*DX_VAL + DY_VAL*DY_VAL)*size*size + (mzmax - mzmin)*(mzmax - mzmin));
-	st->wx1 = wx1; st->wy1 = wy1; st->wx2 = wx2; st->wy2 = wy2;
 }
-
-// tile_t::calc_mesh_ao_lighting driver (src/tiled_mesh.cpp:586-661) for tile (tx,ty): zvals[130*130] (as create_zvals left them) -> ao[129*129]
+// tile_t::calc_mesh_ao_lighting itself (src/tiled_mesh.cpp:586-661) on a tile whose zvals are the caller's (eroded or not).  With enable_tiled_mesh_ao and a GL
+// noise mode the engine's create_zvals has left the 201^2 context in ao_zvals: reproduced by running create_zvals first, exactly as the engine does.
 REF_API void ref_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao) {
-	unsigned const size(128), stride(size+1), zvsize(stride+1), context_sz(stride + 2*SHIM_AO_RAY_LEN);
-	int const x1(tx*size), y1(ty*size);
-	int ao_dirs[SHIM_NUM_AO_DIRS][2];
-	unsigned ix(0);
-	for (int y = -1; y <= 1; ++y) {
-		for (int x = -1; x <= 1; ++x) {
-			if (x != 0 || y != 0) {ao_dirs[ix][0] = x; ao_dirs[ix][1] = y; ++ix;}
-		}
+	ref_tile_box_t b(tx, ty);
+	if (enable_tiled_mesh_ao && !using_tiled_terrain_hmap_tex() && mesh_gen_mode >= MGEN_SIMPLEX_GPU) {
+		unsigned const prev(erosion_iters_tt);
+		erosion_iters_tt = 0;
+		mesh_xy_grid_cache_t height_gen;
+		b.t->create_zvals(height_gen, 0);
+		erosion_iters_tt = prev;
 	}
-	bool const using_hmap(shim_using_hmap()), add_detail(shim_using_hmap_with_detail());
-	bool const use_ao_zvals(!using_hmap && shim_enable_tiled_mesh_ao && mesh_gen_mode >= MGEN_SIMPLEX_GPU); // ao_zvals kept by create_zvals: the whole context, interior included
-	vector<float> czv(context_sz*context_sz);
+	b.set_zvals(zvals);
+	b.t->calc_mesh_ao_lighting();
+	memcpy(ao, b.t->ao_lighting.data(), b.t->ao_lighting.size());
+}
+// tile_t::update_terrain_params itself (src/tiled_mesh.cpp:321-343): out[yp][xp] = {veg, grass, dirt}
+REF_API void ref_tile_terrain_params(int tx, int ty, float *out) {
+	ref_tile_box_t b(tx, ty);
+	if (enable_terrain_env) {b.t->update_terrain_params();}
+	for (unsigned i = 0; i < 4; ++i) {tile_t::terrain_params_t const &p(b.t->params[i>>1][i&1]); out[3*i] = p.veg; out[3*i+1] = p.grass; out[3*i+2] = p.dirt;}
+}
+// tile_t::create_texture itself (src/tiled_mesh.cpp:1071-1240, with get_tids / update_lttex_ix from src/Textures.cpp:1289-1316 and add_grass_block_at :1354-1371)
+extern vector<texture_t> textures; // src/Textures.cpp:177: the renderer's texture table, filled by load_textures() in the engine
+REF_API void ref_tile_create_weights(int tx, int ty, float const *zvals, unsigned char *mesh_weight_data, ref_grass_block_t *grass_blocks, int *has_any_grass_out) {
+	// create_or_update_weight_tex (the tail of create_texture) averages the landscape textures' colours into avg_mesh_tex_color, a render-only value nobody compares:
+	// give it default entries to read instead of the image files the engine loads
+	if (textures.size() < 256) {textures.resize(256);} // the ids of the built-in texture enum (src/3DWorld.h:1380-1394) are far below 256
+	ref_tile_box_t b(tx, ty);
+	b.set_zvals(zvals);
+	if (enable_terrain_env) {b.t->update_terrain_params();} // what create_zvals does before (src/tiled_mesh.cpp:471)
+	int const nt(omp_get_max_threads());
 	mesh_xy_grid_cache_t height_gen;
-	float const xy_scale(shim_get_xy_scale());
-	if (xy_scale != 0.0) {
-		height_gen.build_arrays(((x1 - (int)SHIM_AO_RAY_LEN) - MESH_X_SIZE/2), ((y1 - (int)SHIM_AO_RAY_LEN) - MESH_Y_SIZE/2), xy_scale*DX_VAL, xy_scale*DY_VAL, context_sz, context_sz, 0, 0, 0);
-		height_gen.enable_glaciate();
+	b.t->create_texture(height_gen);
+	omp_set_num_threads(nt);
+	memcpy(mesh_weight_data, b.t->mesh_weight_data.data(), b.t->mesh_weight_data.size());
+	if (grass_blocks) {
+		unsigned const n(32*32);
+		memset(grass_blocks, 0, n*sizeof(ref_grass_block_t));
+		for (unsigned i = 0; i < b.t->grass_blocks.size() && i < n; ++i) {grass_blocks[i].ix = b.t->grass_blocks[i].ix; grass_blocks[i].zmin = b.t->grass_blocks[i].zmin; grass_blocks[i].zmax = b.t->grass_blocks[i].zmax;}
 	}
-	float const dz(0.5*HALF_DXY);
-#pragma omp parallel for schedule(static,1)
-	for (int y = 0; y < (int)context_sz; ++y) {
-		for (int x = 0; x < (int)context_sz; ++x) {
-			int const xv(x - (int)SHIM_AO_RAY_LEN), yv(y - (int)SHIM_AO_RAY_LEN);
-			float &zv(czv[y*context_sz + x]);
-			if (!use_ao_zvals && xv >= 0 && yv >= 0 && xv < (int)zvsize && yv < (int)zvsize) {zv = zvals[yv*zvsize + xv];}
-			else if (using_hmap) {
-				zv = ref_get_clamped_height((x1 + xv), (y1 + yv));
-				if (add_detail) {zv += SHIM_HMAP_DETAIL_MAG*height_gen.eval_index(x, y);}
-			}
-			else {zv = height_gen.eval_index(x, y);}
-		}
-	}
-#pragma omp parallel for schedule(static,1)
-	for (int y = 0; y < (int)stride; ++y) {
-		for (int x = 0; x < (int)stride; ++x) {
-			unsigned atten(0);
-			for (unsigned d = 0; d < SHIM_NUM_AO_DIRS; ++d) {
-				float z0(zvals[y*zvsize + x]);
-				int stepx(ao_dirs[d][0]), stepy(ao_dirs[d][1]), vx(x), vy(y);
-				for (unsigned s = 0; s < SHIM_NUM_AO_STEPS; ++s) {
-					vx += stepx; vy += stepy;
-					z0 += dz;
-					stepx += ao_dirs[d][0]; stepy += ao_dirs[d][1]; // linear increase
-					int const xv(vx + (int)SHIM_AO_RAY_LEN), yv(vy + (int)SHIM_AO_RAY_LEN);
-					if (czv[yv*context_sz + xv] > z0) {atten += (SHIM_NUM_AO_STEPS - s); break;}
-				}
-			}
-			float const ao_scale(1.0 - float(atten)/float(SHIM_NUM_AO_DIRS*SHIM_NUM_AO_STEPS));
-			ao[y*stride + x] = (unsigned char)(255.0*ao_scale);
-		}
-	}
+	if (has_any_grass_out) {*has_any_grass_out = b.t->has_any_grass;}
+}
+// tile_t::upload_normal_texture itself (src/tiled_mesh.cpp:865-880, get_norm src/tiled_mesh.h:281-284): the RGBA bytes it hands to GL + min_normal_z
+REF_API float ref_tile_normals(float const *zvals, unsigned char *rgba /*129*129*4*/) {
+	ref_tile_box_t b(0, 0);
+	b.set_zvals(zvals);
+	ref_last_upload = nullptr;
+	b.t->upload_normal_texture(0);
+	// upload_normal_texture's vector is gone by now; glTexImage2D was called while it was alive -- copy there instead
+	memcpy(rgba, ref_upload_copy.data(), 4*129*129);
+	return b.t->min_normal_z;
 }
 
 // ---- row f2: mesh shadows.  calc_mesh_shadows / mesh_shadow_gen are the reference's own code (src/visibility.cpp:411-517, do_line_clip from src/Math3d.cpp:1070);
@@ -559,187 +581,6 @@ REF_API void ref_tiles_mesh_shadows(int const *tile_xy, unsigned n, float const 
 }
 
 // tile_t::upload_normal_texture CPU part (src/tiled_mesh.cpp:865-880, src/tiled_mesh.h:281-284); returns min_normal_z
-// ---- f3: landscape weights texture.  tile_t::create_texture / update_terrain_params live in tiled_mesh.cpp and get_tids / update_lttex_ix in Textures.cpp
-// (GL-bound translation units that cannot be built here), so this is a driver in the reference's own types and macros (vector3d, CLIP_TO_01, ttex ids)
-// around the reference functions that ARE compiled: build_arrays / eval_index (the noise field), eval_mesh_sin_terms (the biome parameters),
-// get_water_z_height, init_terrain_mesh (lttex_dirt), sthresh.  It pins those inputs; the blend logic itself is a second restatement.
-struct ref_landscape_t {float vegetation, temperature, biome_x_offset, mesh_scale_z; int water_is_lava, disable_water, enable_terrain_env; unsigned grass_density, num_rnd_grass_blocks;};
-struct ref_grass_block_t {unsigned ix; float zmin, zmax;}; // tile_t::grass_block_t (src/tiled_mesh.h:186)
-static ref_landscape_t shim_ls = {1.0, DEF_TEMPERATURE, 0.0, 1.0, 0, 0, 1, 0, 16};
-extern float sthresh[2][2];
-REF_API void ref_set_landscape(ref_landscape_t const *p) {
-	shim_ls = *p; temperature = p->temperature; mesh_scale_z = p->mesh_scale_z;
-	init_terrain_mesh(); // calls gen_tex_height_tables()
-}
-static void shim_update_lttex_ix(int &ix) { // src/Textures.cpp:1289-1292
-	if ((shim_ls.water_is_lava || shim_ls.disable_water == 2) && lttex_dirt[ix].id == SNOW_TEX) {--ix;}
-	if (shim_ls.vegetation == 0.0 && lttex_dirt[ix].id == GROUND_TEX) {++ix;}
-}
-static void shim_get_tids(float relh, int &k1, int &k2, float *t=nullptr) { // src/Textures.cpp:1294-1316
-	float const TEXTURE_SMOOTH = 0.01;
-	for (k1 = 0; k1 < NTEX_DIRT-1; ++k1) {if (relh < h_dirt[k1]) break;}
-	if (k1 < NTEX_DIRT-1 && (h_dirt[k1] - relh) < TEXTURE_SMOOTH) {
-		if (t) {*t = 1.0 - (h_dirt[k1] - relh)/TEXTURE_SMOOTH;}
-		k2 = k1+1;
-		shim_update_lttex_ix(k1);
-		shim_update_lttex_ix(k2);
-	}
-	else {
-		shim_update_lttex_ix(k1);
-		k2 = k1;
-	}
-}
-struct shim_terrain_params_t {float veg=1.0, grass=1.0, dirt=0.0;};
-static void shim_update_terrain_params(int x1, int y1, int x2, int y2, shim_terrain_params_t params[2][2]) { // src/tiled_mesh.cpp:321-343
-	float const dirt_mult(1.0), veg_mult(5.0);
-	float const xv1(get_xval(x1)), xv2(xv1 + (x2-x1)*DX_VAL), yv1(get_yval(y1)), yv2(yv1 + (y2-y1)*DY_VAL);
-	for (unsigned yp = 0; yp < 2; ++yp) {
-		for (unsigned xp = 0; xp < 2; ++xp) {
-			shim_terrain_params_t &param(params[yp][xp]);
-			float const xv(mesh_scale*(xp ? xv2 : xv1) + shim_ls.biome_x_offset), yv(mesh_scale*(yp ? yv2 : yv1));
-			float const veg_val(eval_mesh_sin_terms(veg_mult*xv, veg_mult*yv));
-			param.veg   = CLIP_TO_01(5.000f*(veg_val + 1.5f));
-			param.grass = CLIP_TO_01(100.0f*(veg_val + 3.0f));
-			param.dirt  = CLIP_TO_01(5.0f*(eval_mesh_sin_terms(dirt_mult*xv, dirt_mult*yv) + 1.0f));
-		}
-	}
-}
-REF_API void ref_tile_terrain_params(int tx, int ty, float *out) {
-	shim_terrain_params_t params[2][2];
-	if (shim_ls.enable_terrain_env) {shim_update_terrain_params(tx*128, ty*128, tx*128 + 128, ty*128 + 128, params);}
-	for (unsigned i = 0; i < 4; ++i) {shim_terrain_params_t const &p(params[i >> 1][i & 1]); out[3*i] = p.veg; out[3*i+1] = p.grass; out[3*i+2] = p.dirt;}
-}
-#define SHIM_BILINEAR_INTERP(arr, var, x, y) (y*(x*arr[1][1].var + (1.0f-x)*arr[1][0].var) + (1.0f-y)*(x*arr[0][1].var + (1.0f-x)*arr[0][0].var)) // src/tiled_mesh.cpp:189
-REF_API void ref_tile_create_weights(int tx, int ty, float const *zvals, unsigned char *mesh_weight_data, ref_grass_block_t *grass_blocks, int *has_any_grass_out) {
-	unsigned const size(128), stride(size+1), zvsize(stride+1), tsize(stride), grass_block_sz(4), grass_block_dim(1+(size-1)/grass_block_sz);
-	int const x1(tx*size), y1(ty*size);
-	int sand_tex_ix(-1), dirt_tex_ix(-1), grass_tex_ix(-1), rock_tex_ix(-1), snow_tex_ix(-1);
-	for (unsigned i = 0; i < NTEX_DIRT; ++i) { // get_texture_ixs (src/tiled_mesh.cpp:1049-1062)
-		switch (lttex_dirt[i].id) {
-		case SAND_TEX:   sand_tex_ix  = i; break;
-		case DIRT_TEX:   dirt_tex_ix  = i; break;
-		case GROUND_TEX: grass_tex_ix = i; break;
-		case ROCK_TEX:   rock_tex_ix  = i; break;
-		case SNOW_TEX:   snow_tex_ix  = i; break;
-		}
-	}
-	shim_terrain_params_t params[2][2];
-	if (shim_ls.enable_terrain_env) {shim_update_terrain_params(x1, y1, x1 + size, y1 + size, params);}
-	bool has_any_grass(0);
-	bool const gen_grass_map(shim_ls.grass_density > 0 && shim_ls.vegetation > 0.0);
-	if (grass_blocks) {for (unsigned i = 0; i < grass_block_dim*grass_block_dim; ++i) {grass_blocks[i] = ref_grass_block_t{0, 0.0, 0.0};}}
-	float const vegetation(shim_ls.vegetation);
-	float const xy_mult(1.0/float(size)), water_level(get_water_z_height());
-	float const MESH_NOISE_SCALE = 0.003;
-	float const MESH_NOISE_FREQ  = 80.0;
-	float const dz_inv(1.0f/(zmax - zmin));
-	float const noise_scale(((mesh_gen_shape == 2) ? 2.0 : 1.0)*MESH_NOISE_SCALE*mesh_scale_z);
-	float const steep_mult_grass(1.0f/(sthresh[0][1] - sthresh[0][0]));
-	float const steep_mult_snow (1.0f/(sthresh[1][1] - sthresh[1][0]));
-	float const steep_mult_rock (1.0f/(0.8f*sthresh[0][0] - 0.5f*sthresh[0][0]));
-	float const vnz_scale((mesh_gen_mode == MGEN_DWARP_GPU) ? SQRT2 : 1.0);
-	int k1, k2, k3, k4;
-	mesh_xy_grid_cache_t height_gen;
-	height_gen.build_arrays((x1 - MESH_X_SIZE/2), (y1 - MESH_Y_SIZE/2), MESH_NOISE_FREQ*DX_VAL, MESH_NOISE_FREQ*DY_VAL, tsize, tsize, 0, 1); // force_sine_mode=1
-	vector<float> rand_vals(tsize*tsize);
-	for (unsigned y = 0; y < tsize; ++y) {
-		for (unsigned x = 0; x < tsize; ++x) {rand_vals[y*tsize + x] = noise_scale*height_gen.eval_index(x, y, 50);}
-	}
-	for (unsigned y = 0; y < tsize; ++y) {
-		float const yv(float(y)*xy_mult);
-		for (unsigned x = 0; x < tsize; ++x) {
-			unsigned const ix_val(y*tsize + x), off(4*ix_val), ix(y*zvsize + x);
-			float weights[NTEX_DIRT] = {};
-			float const mh00(zvals[ix]), mh01(zvals[ix+1]), mh10(zvals[ix+zvsize]), mh11(zvals[ix+zvsize+1]);
-			float const mhmin(min(min(mh00, mh01), min(mh10, mh11))), mhmax(max(max(mh00, mh01), max(mh10, mh11)));
-			float const rand_offset(rand_vals[y*tsize + x]);
-			float const relh1(relh_adj_tex + (mhmin - zmin)*dz_inv + rand_offset), relh2(relh_adj_tex + (mhmax - zmin)*dz_inv + rand_offset);
-			shim_get_tids(relh1, k1, k2);
-			shim_get_tids(relh2, k3, k4);
-			bool const same_tid(k1 == k4);
-			float t(0.0);
-			k2 = k4;
-			if (!same_tid) {
-				float const relh(relh_adj_tex + (mh00 - zmin)*dz_inv);
-				shim_get_tids(relh, k1, k2, &t);
-			}
-			float weight_scale(1.0);
-			bool const grass(lttex_dirt[k1].id == GROUND_TEX || lttex_dirt[k2].id == GROUND_TEX), snow(lttex_dirt[k2].id == SNOW_TEX);
-			has_any_grass |= grass;
-			if (grass || snow) {
-				float const *const sti(sthresh[snow]);
-				vector3d const normal(DY_VAL*(zvals[ix] - zvals[ix + 1]), DX_VAL*(zvals[ix] - zvals[ix + zvsize]), dxdy); // get_norm_not_normalized (src/tiled_mesh.h:281)
-				float vnz(vnz_scale*normal.z/normal.mag());
-				if (grass && vnz > sti[1]) {vnz = CLIP_TO_01(1.0f + 20.0f*rand_offset);}
-				if (vnz < sti[1]) {
-					if (grass) {
-						float rock_weight((lttex_dirt[k1].id == GROUND_TEX || lttex_dirt[k2].id == ROCK_TEX) ? t : 0.0);
-						float const steepness(1.0 - CLIP_TO_01((vnz - 0.5f*sti[0])*steep_mult_rock));
-						rock_weight  = rock_weight*(1.0 - steepness) + steepness;
-						weight_scale = CLIP_TO_01((vnz - sti[0])*steep_mult_grass);
-						weights[rock_tex_ix] += (1.0 - weight_scale)*rock_weight;
-						weights[dirt_tex_ix] += (1.0 - weight_scale)*(1.0 - rock_weight);
-					}
-					else {
-						weight_scale = CLIP_TO_01(2.0f*(vnz - sti[0])*steep_mult_snow);
-						weights[rock_tex_ix] += 1.0 - weight_scale;
-					}
-				}
-			}
-			weights[k2] += weight_scale*t;
-			weights[k1] += weight_scale*(1.0 - t);
-			float const xv(float(x)*xy_mult);
-			if (vegetation > 0.0) {
-				float const dirt_scale(SHIM_BILINEAR_INTERP(params, dirt, xv, yv));
-				if (dirt_scale < 1.0) {
-					weights[sand_tex_ix] += (1.0 - dirt_scale)*weights[dirt_tex_ix];
-					weights[dirt_tex_ix] *= dirt_scale;
-				}
-			}
-			if (grass) {
-				float grass_scale((mhmin < water_level) ? 0.0f : SHIM_BILINEAR_INTERP(params, grass, xv, yv));
-				if (grass_scale < 1.0) {
-					float const gscale(CLIP_TO_01(2.5f*(grass_scale - 0.5f) + 0.5f));
-					weights[sand_tex_ix ] += (1.0 - gscale)*weights[grass_tex_ix];
-					weights[grass_tex_ix] *= gscale;
-				}
-				if (grass_scale > 0.0 && grass_blocks && gen_grass_map && x < size && y < size) { // add_grass_block_at (src/tiled_mesh.cpp:1354-1371)
-					ref_grass_block_t &gb(grass_blocks[(y/grass_block_sz)*grass_block_dim + x/grass_block_sz]);
-					if (gb.ix == 0) {
-						gb.ix   = (((x1 + x) + 1567*(y1 + y)) % shim_ls.num_rnd_grass_blocks) + 1;
-						gb.zmin = mhmin;
-						gb.zmax = mhmax;
-					}
-					else {
-						min_eq(gb.zmin, mhmin);
-						max_eq(gb.zmax, mhmax);
-					}
-				}
-			}
-			for (unsigned i = 0; i < NTEX_DIRT-1; ++i) {
-				mesh_weight_data[off+i] = ((weights[i] <= 0.01) ? 0 : ((weights[i] >= 0.99) ? 255 : (unsigned char)(255.0*weights[i])));
-			}
-		}
-	}
-	(void)snow_tex_ix;
-	if (has_any_grass_out) {*has_any_grass_out = has_any_grass;}
-}
-
-REF_API float ref_tile_normals(float const *zvals, unsigned char *rgba /*129*129*4*/) {
-	unsigned const stride(129), zvsize(130);
-	float min_normal_z(1.0);
-	memset(rgba, 0, 4*stride*stride);
-	for (unsigned y = 0; y < stride; ++y) {
-		for (unsigned x = 0; x < stride; ++x) {
-			unsigned const ix(y*stride + x), ix2(y*zvsize + x), ix_off(4*ix);
-			vector3d const norm(vector3d(DY_VAL*(zvals[ix2] - zvals[ix2 + 1]), DX_VAL*(zvals[ix2] - zvals[ix2 + zvsize]), dxdy).get_norm());
-			min_normal_z = min(min_normal_z, norm.z);
-			UNROLL_3X(rgba[ix_off+i_] = (unsigned char)(127.0*(norm[i_] + 1.0));)
-		}
-	}
-	return min_normal_z;
-}
-
 // heightmap_t::proc_gen tail (src/heightmap.cpp:146-150,205-215; src/Textures.cpp:1889-1893; src/mesh_gen.cpp:120-131):
 // z-range -> 16-bit quantise. out = 2 bytes per pixel, [lo, hi].
 REF_API void ref_quantize16(float const *vals, size_t n, unsigned char *out, float *min_z_out, float *dz_out) {
@@ -764,26 +605,25 @@ REF_API void ref_quantize16(float const *vals, size_t n, unsigned char *out, flo
 // write_map_mode_heightmap_image (src/map_view.cpp:409-442, a GL-bound file) from the image origin on: driver over the reference's build_arrays /
 // eval_index / terrain_hmap_manager_t::interpolate_height / get_heightmap_z_range / write_pixel_16_bits; setup_height_gen_cached = src/tiled_mesh.cpp:452-457,
 // get_mesh_height = src/map_view.cpp:97-105.  pixels: 2 bytes per pixel; min_z_dz = {min_z, dz}
+void setup_height_gen_cached(mesh_xy_grid_cache_t &height_gen, float x0, float y0, float dx, float dy, unsigned nx, unsigned ny);
+bool using_tiled_terrain_hmap_tex();
+bool using_hmap_with_detail();
 REF_API void ref_export_heightmap(float xstart, float ystart, int width, int height, unsigned char *pixels, float *min_z_dz) {
 	texture_t texture(0, 6, width, height, 0, 2, 0, "heightmap.png"); // two bytes per pixel grayscale
 	texture.set_16_bit_grayscale();
 	texture.alloc();
 	vector<float> heights(texture.num_pixels());
 	mesh_xy_grid_cache_t height_gen;
-	float const xy_scale(shim_get_xy_scale());
-	if (xy_scale != 0.0) {
-		height_gen.build_arrays(xstart/DX_VAL, ystart/DY_VAL, xy_scale*DX_VAL, xy_scale*DY_VAL, width, height, 1); // cache_values=1
-		height_gen.enable_glaciate();
-	}
+	setup_height_gen_cached(height_gen, xstart, ystart, DX_VAL, DY_VAL, width, height); // the reference's own (src/tiled_mesh.cpp:452-457)
 	float const xscale(DX_VAL), yscale(DY_VAL);
 #pragma omp parallel for schedule(static,1)
 	for (int i = 0; i < height; ++i) {
 		int const off(width*(height - i - 1)); // invert yval
 		for (int j = 0; j < width; ++j) {
 			float zval;
-			if (shim_using_hmap()) {
+			if (using_tiled_terrain_hmap_tex()) {
 				zval = shim_hmap.interpolate_height((xstart + X_SCENE_SIZE + j*xscale)*DX_VAL_INV, (ystart + Y_SCENE_SIZE + i*yscale)*DY_VAL_INV);
-				if (shim_using_hmap_with_detail()) {zval += HMAP_DETAIL_MAG*height_gen.eval_index(j, i);}
+				if (using_hmap_with_detail()) {zval += HMAP_DETAIL_MAG*height_gen.eval_index(j, i);}
 			}
 			else {zval = height_gen.eval_index(j, i);}
 			heights[off + j] = zval;
