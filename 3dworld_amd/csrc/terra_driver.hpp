@@ -245,6 +245,7 @@ template<class BE> struct terra_engine {
 	bool scene_ready = false, have_config = false;
 	std::vector<float> h_sin_table;
 	float *d_sin_table = nullptr;
+	float *d_sinTable = nullptr; bool sinTable_dev_valid = false; // device copy of sinTable[90][5]: the per-grid constants of build_arrays are derived on the device (no upload per call)
 	uint32_t *d_noise_lut = nullptr; // lattice tables of the fBm kernels (terra_noise.hpp: noise_lut_fill), built once per context on the device
 	terra_erosion_report report{};
 
@@ -265,6 +266,7 @@ template<class BE> struct terra_engine {
 		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 		if (d_noise_lut) be.free(d_noise_lut);
+		if (d_sinTable) be.free(d_sinTable);
 	}
 
 	sin_lut_t lut() const {return sin_lut_t{d_sin_table, sscale};}
@@ -306,7 +308,13 @@ template<class BE> struct terra_engine {
 		if (cfg.mesh_seed != 0) {r.set_state(cfg.mesh_seed, 12345);}
 		else if (mode != MGEN_SINE) {r.set_state(0+1, 12345);}
 	}
+	float const *sinTable_dev() { // uploaded when it changed (scene start-up / terra_set_state), not per grid
+		if (!d_sinTable) {d_sinTable = (float *)be.alloc(sizeof(sinTable));}
+		if (!sinTable_dev_valid) {be.h2d(d_sinTable, &sinTable[0][0], sizeof(sinTable)); sinTable_dev_valid = true;}
+		return d_sinTable;
+	}
 	void gen_rand_sine_table_entries(float scaled_height) { // src/mesh_gen.cpp:219-254
+		sinTable_dev_valid = false;
 		float xf_scale = (float)cfg.mesh_y/(float)cfg.mesh_x, yf_scale = (float)(1.0/(double)xf_scale);
 		if (cfg.scene_x > cfg.scene_y) yf_scale *= cfg.scene_y/cfg.scene_x;
 		if (cfg.scene_y > cfg.scene_x) xf_scale *= cfg.scene_x/cfg.scene_y;
@@ -429,7 +437,7 @@ template<class BE> struct terra_engine {
 	void set_state(terra_state const &s) {
 		if (!have_config) throw std::logic_error("terra_set_state: call terra_set_config (or terra_init_scene) first: hmap_params, modes and erosion scalars are not part of terra_state");
 		create_sin_table();
-		memcpy(sinTable, s.sinTable, sizeof(sinTable));
+		memcpy(sinTable, s.sinTable, sizeof(sinTable)); sinTable_dev_valid = false;
 		start_eval_sin = s.start_eval_sin; MESH_HEIGHT = s.MESH_HEIGHT; DX_VAL = s.DX_VAL; DY_VAL = s.DY_VAL; DX_VAL_INV = s.DX_VAL_INV; DY_VAL_INV = s.DY_VAL_INV;
 		HALF_DXY = s.HALF_DXY; dxdy = s.dxdy; XY_SCENE_SIZE = s.XY_SCENE_SIZE; mesh_scale = s.mesh_scale; mesh_scale_z_inv = s.mesh_scale_z_inv; mesh_height_scale = s.mesh_height_scale;
 		set_zmax_est(s.zmax_est); zmin = s.zmin; zmax = s.zmax; water_plane_z = s.water_plane_z; glaciate_exp = s.glaciate_exp; clip_hd1 = s.clip_hd1; relh_adj_tex = s.relh_adj_tex;
@@ -497,9 +505,19 @@ template<class BE> struct terra_engine {
 			});
 		}
 		if (job.mode == MGEN_SINE) {
-			sine_k_t const h_sk = make_sine_k(job.mx0, job.my0, dx, dy);
 			sine_k_t *d_skp = scratch<sine_k_t>(s_sk, 1); // per-k constants live in device memory: a by-value kernel argument indexed per lane would be spilled to scratch
-			be.h2d(d_skp, &h_sk, sizeof(h_sk));
+			{ // make_sine_k on the device: the same fp32 expressions in the same order (no contraction on either side), so the same bits without a blocking upload per call
+				float const *st = sinTable_dev();
+				float const msx = mesh_scale*DX_VAL_INV, msy = mesh_scale*DY_VAL_INV, ms2 = (float)(0.5*(double)mesh_scale), mszi = mesh_scale_z_inv, jmx0 = job.mx0, jmy0 = job.my0;
+				be.launch((size_t)F_TABLE_SIZE, [=] TERRA_LAMBDA (size_t k) {
+					float const *stk = st + 5*k;
+					float const x_mult = msx*stk[4], y_mult = msy*stk[3];
+					d_skp->yscale[k] = mszi*stk[0];
+					d_skp->xconst[k] = ms2*stk[4] + stk[2] + x_mult*jmx0;
+					d_skp->yconst[k] = ms2*stk[3] + stk[1] + y_mult*jmy0;
+					d_skp->xmdx[k] = x_mult*dx; d_skp->ymdy[k] = y_mult*dy;
+				}, 128);
+			}
 			float *xt = scratch<float>(s_xt, (size_t)F_TABLE_SIZE*job.nxp), *yt = scratch<float>(s_yt, (size_t)F_TABLE_SIZE*job.nyp);
 			uint32_t const nxp = job.nxp, nyp = job.nyp;
 			// tables, k-major: xt[k*nxp + x] = SINF(xmdx*x + x_const), yt[k*nyp + y] = y_scale*SINF(ymdy*y + y_const); zero padding

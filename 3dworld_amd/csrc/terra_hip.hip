@@ -33,7 +33,6 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
-		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_post, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
@@ -41,6 +40,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	~hip_backend_t() {
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_order) (void)hipFree(tile_order);
+		if (tile_acc) (void)hipFree(tile_acc);
 		if (tile_map) (void)hipFree(tile_map);
 		if (vox_p) (void)hipFree(vox_p);
 		if (ev0) (void)hipEventDestroy(ev0);
@@ -211,10 +211,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(256), lds, stream, z, ctx, ao, dz);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
+	uint32_t *tile_acc = nullptr; size_t tile_acc_bytes = 0; // k_tile_post's per-tile accumulators
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
-		if (simple_kernels || ((uintptr_t)z & 15)) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;} // the LDS staging reads 16 bytes at a time
+		if (simple_kernels || ((uintptr_t)z & 15) || ((uintptr_t)nm & 3)) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;} // the LDS staging reads 16 bytes at a time, texels are stored as words
 		use();
-		hipLaunchKernelGGL(terra::k_tile_post, dim3(n), dim3(terra::TP_THREADS), 130*130*sizeof(float), stream, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);
+		size_t const bytes = (size_t)n*terra::TP_ACC*sizeof(uint32_t);
+		if (bytes > tile_acc_bytes) {if (tile_acc) {sync(); (void)hipFree(tile_acc);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_acc, bytes)); tile_acc_bytes = bytes;}
+		hipLaunchKernelGGL(terra::k_tile_post_init, dim3((n*terra::TP_ACC + 255)/256), dim3(256), 0, stream, tile_acc, n);
+		hipLaunchKernelGGL(terra::k_tile_post, dim3(n*4), dim3(terra::TP_THREADS), 0, stream, refs, z, st, nm, mnz, tile_acc, wpz, rad_c, dxv, dyv, dxy);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {

@@ -379,54 +379,58 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 	for (int off = 32; off > 0; off >>= 1) {int const o = __shfl_down(v, off, 64); v = (o < v) ? o : v;}
 	return v;
 }
-constexpr unsigned TP_THREADS = 512;
+// One block per (tile, band of 32 texel rows): 4 x more blocks than tiles and 17.7 KB of LDS each (the whole-tile version staged 67.6 KB: two blocks per CU,
+// every block's load, compute and store phases in sequence).  Band yy owns sub-block row yy completely (rows 32*yy .. 32*yy + 32), so the 4 x 4 sub-block
+// ranges are written by exactly one block each; what spans the tile (mzmin / mzmax / radius, the water bbox, min_normal_z) is folded through 8 words of
+// global scratch per tile with atomics, and the band that arrives last (a ticket counter) writes the tile's totals.
+constexpr unsigned TP_THREADS = 256, TP_BAND_ROWS = 34, TP_ACC = 8; // acc: {-, -, bbox x1, y1, x2, y2, min normal z bits, ticket}
+__global__ __launch_bounds__(256) void k_tile_post_init(uint32_t *__restrict__ acc, uint32_t n) {
+	uint32_t const i = blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= n*TP_ACC) return;
+	uint32_t const f = i % TP_ACC;
+	acc[i] = (f < 2) ? 0xFFFFFFFFu : ((f < 4) ? 0x7FFFFFFFu : ((f < 6) ? 0x80000000u : ((f == 6) ? 0x3F800000u : 0u)));
+}
 __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, terra_tile_stats *__restrict__ stats,
-	uint8_t *__restrict__ normals, float *__restrict__ min_nz, float wpz_max, float rad_c, float dxv, float dyv, float dxy)
+	uint8_t *__restrict__ normals, float *__restrict__ min_nz, uint32_t *__restrict__ acc, float wpz_max, float rad_c, float dxv, float dyv, float dxy)
 {
-	// The tile (130 x 130 floats, 67.6 KB) is staged in LDS with one round of 16-byte loads: every later read (16 sub-block scans, three cells per
-	// normal) is then an LDS read instead of a dependent global load.  Every reduction is folded per lane, then per wave (shuffles), and only then
-	// touches LDS: 4 atomics per wave and quantity instead of several per cell (on an ocean tile every cell is below the water plane and hammered the
-	// same four bbox words).
-	extern __shared__ __attribute__((aligned(16))) float tp_z[];
-	__shared__ uint32_t s_lo[16], s_hi[16], s_mnz;
+	__shared__ __attribute__((aligned(16))) float tp_z[TP_BAND_ROWS*130];
+	__shared__ uint32_t s_lo[4], s_hi[4], s_mnz;
 	__shared__ int s_bb[4];
-	unsigned const t = blockIdx.x, tid = threadIdx.x, zv = 130, stride = 129, bs = 32;
+	unsigned const t = blockIdx.x >> 2, yy = blockIdx.x & 3u, tid = threadIdx.x, zv = 130, stride = 129, bs = 32, row0 = yy*bs;
 	tile_ref_pod_t const r = refs[t];
 	int const x1 = r.tx*128, y1 = r.ty*128;
 	{
-		float4 const *src = (float4 const *)(zvals + (size_t)t*zv*zv); // 67600 bytes per tile: 16-byte aligned
-		for (unsigned i = tid; i < zv*zv/4; i += TP_THREADS) {((float4 *)tp_z)[i] = src[i];}
+		float4 const *src = (float4 const *)(zvals + (size_t)t*zv*zv + (size_t)row0*zv); // 67600 bytes per tile, 16640 per band: 16-byte aligned
+		for (unsigned i = tid; i < TP_BAND_ROWS*zv/4; i += TP_THREADS) {((float4 *)tp_z)[i] = src[i];}
 	}
 	if (tid == 0) {s_mnz = 0x3F800000u; s_bb[0] = x1 + 128; s_bb[1] = y1 + 128; s_bb[2] = x1; s_bb[3] = y1;} // water bbox starts denormalized
 	__syncthreads();
 	float const *z = tp_z;
-	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) : nullptr;
-	if (stats) { // sub-block z ranges: sub-block (xx,yy) covers cells [32*xx, 32*xx + 32] x [32*yy, 32*yy + 32] (shared edges belong to both)
-		// each of the 8 waves scans two whole sub-blocks on its own: one shuffle reduction per sub-block and wave instead of one per sub-block for every wave
-		for (unsigned sbk = tid >> 6; sbk < 16; sbk += TP_THREADS/64) {
-			unsigned const xx = sbk & 3, yy = sbk >> 2;
-			uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
-			for (unsigned q = tid & 63; q < (bs + 1)*(bs + 1); q += 64) {
-				unsigned const y = yy*bs + q/(bs + 1), x = xx*bs + q % (bs + 1);
-				float const v = z[y*zv + x];
-				if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;} // std::min / std::max never let a NaN win
-			}
-			lo = wave_min_u32(lo); hi = wave_min_u32(hi);
-			if ((tid & 63) == 0) {uint32_t const l0 = f2ord(100.0f), h0 = ~f2ord(-100.0f); s_lo[sbk] = (lo < l0) ? lo : l0; s_hi[sbk] = (hi < h0) ? hi : h0;} // folds start at szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
+	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) + (size_t)row0*stride : nullptr;
+	if (stats) { // sub-block (xx, yy) covers cells [32*xx, 32*xx + 32] x [32*yy, 32*yy + 32] (shared edges belong to both): one wave per sub-block
+		unsigned const xx = tid >> 6;
+		uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+		for (unsigned q = tid & 63; q < (bs + 1)*(bs + 1); q += 64) {
+			unsigned const y = q/(bs + 1), x = xx*bs + q % (bs + 1);
+			float const v = z[y*zv + x];
+			if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;} // std::min / std::max never let a NaN win
 		}
+		lo = wave_min_u32(lo); hi = wave_min_u32(hi);
+		if ((tid & 63) == 0) {uint32_t const l0 = f2ord(100.0f), h0 = ~f2ord(-100.0f); s_lo[xx] = (lo < l0) ? lo : l0; s_hi[xx] = (hi < h0) ? hi : h0;} // folds start at szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
 	}
 	int bx0 = x1 + 128, by0 = y1 + 128, bx1n = -x1, by1n = -y1; // water bbox as four minima (max = -min(-v))
 	uint32_t mnz = 0x3F800000u;
-	for (unsigned p = tid; p < stride*stride; p += TP_THREADS) { // cells 0..128 x 0..128: exactly the cells the 4x4 sub-blocks visit and the texels of the normal map
+	unsigned const nrows = (yy == 3) ? bs + 1 : bs; // texel rows of this band: 32, the last band also row 128
+	for (unsigned p = tid; p < (bs + 1)*stride; p += TP_THREADS) { // cells 0..128 of rows row0 .. row0 + 32: what sub-block row yy visits; texels of rows row0 .. row0 + nrows - 1
 		unsigned const y = p/stride, x = p - y*stride;
 		if (stats) {
 			float const v = z[y*zv + x];
 			if (v < wpz_max) {
-				int const wx = x1 + (int)x, wy = y1 + (int)y;
+				int const wx = x1 + (int)x, wy = y1 + (int)(row0 + y);
 				bx0 = (wx < bx0) ? wx : bx0; by0 = (wy < by0) ? wy : by0; bx1n = (-wx < bx1n) ? -wx : bx1n; by1n = (-wy < by1n) ? -wy : by1n;
 			}
 		}
-		if (nout) {
+		if (nout && y < nrows) {
 			float nv[3];
 			tile_normal(z, x, y, dxv, dyv, dxy, nv);
 			uint32_t const b0 = (uint8_t)(127.0*((double)nv[0] + 1.0)), b1 = (uint8_t)(127.0*((double)nv[1] + 1.0)), b2 = (uint8_t)(127.0*((double)nv[2] + 1.0));
@@ -440,17 +444,35 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 	}
 	if (nout) {mnz = wave_min_u32(mnz); if ((tid & 63) == 0) {atomicMin(&s_mnz, mnz);}}
 	__syncthreads();
-	if (stats) {
-		if (tid < 16) {stats[t].sub_zmin[tid] = ord2f(s_lo[tid]); stats[t].sub_zmax[tid] = ord2f(~s_hi[tid]);}
-		if (tid == 0) {
-			float mzmin = 100.0f, mzmax = -100.0f;
-			for (int k = 0; k < 16; ++k) {mzmin = min_std(mzmin, ord2f(s_lo[k])); mzmax = max_std(mzmax, ord2f(~s_hi[k]));}
-			stats[t].mzmin = mzmin; stats[t].mzmax = mzmax;
-			stats[t].radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
-			stats[t].wx1 = s_bb[0]; stats[t].wy1 = s_bb[1]; stats[t].wx2 = s_bb[2]; stats[t].wy2 = s_bb[3];
+	if (tid == 0) { // one thread publishes the band's results, fences, then takes the ticket: the finalising band sees all of them
+		uint32_t *a = acc + (size_t)t*TP_ACC;
+		if (stats) {
+			for (int k = 0; k < 4; ++k) {stats[t].sub_zmin[yy*4 + k] = ord2f(s_lo[k]); stats[t].sub_zmax[yy*4 + k] = ord2f(~s_hi[k]);}
+			atomicMin((int *)&a[2], s_bb[0]); atomicMin((int *)&a[3], s_bb[1]); atomicMax((int *)&a[4], s_bb[2]); atomicMax((int *)&a[5], s_bb[3]);
+		}
+		if (nout) {atomicMin(&a[6], s_mnz);}
+		__threadfence();
+		if (atomicAdd(&a[7], 1u) == 3u) { // the last band of the tile: every other band's contribution is in the accumulators
+			__threadfence();
+			if (stats) {
+				// mzmin / mzmax fold the 16 sub-block ranges in the reference's order with its std::min / std::max (src/tiled_mesh.cpp:536-538); the other bands'
+				// values are read through to L2 (they were plain stores of other blocks)
+				float mzmin = 100.0f, mzmax = -100.0f;
+				uint32_t const *smin = (uint32_t const *)stats[t].sub_zmin, *smax = (uint32_t const *)stats[t].sub_zmax;
+				for (int k = 0; k < 16; ++k) {
+					uint32_t const ul = __hip_atomic_load(&smin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), uh = __hip_atomic_load(&smax[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					float fl, fh; memcpy(&fl, &ul, 4); memcpy(&fh, &uh, 4);
+					mzmin = min_std(mzmin, fl); mzmax = max_std(mzmax, fh);
+				}
+				stats[t].mzmin = mzmin; stats[t].mzmax = mzmax;
+				stats[t].radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
+				int const b0 = (int)__hip_atomic_load(&a[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = (int)__hip_atomic_load(&a[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				int const b2 = (int)__hip_atomic_load(&a[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b3 = (int)__hip_atomic_load(&a[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				stats[t].wx1 = imin(b0, x1 + 128); stats[t].wy1 = imin(b1, y1 + 128); stats[t].wx2 = imax(b2, x1); stats[t].wy2 = imax(b3, y1);
+			}
+			if (min_nz && nout) {float f; uint32_t const u = __hip_atomic_load(&a[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); memcpy(&f, &u, 4); min_nz[t] = f;}
 		}
 	}
-	if (min_nz && nout && tid == 0) {float f; uint32_t const u = s_mnz; memcpy(&f, &u, 4); min_nz[t] = f;}
 }
 
 // ------------------------------------------------------------------ row f1: tile AO lighting (tile_t::calc_mesh_ao_lighting, src/tiled_mesh.cpp:634-659)

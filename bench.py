@@ -152,10 +152,12 @@ def main():
     x0 = -N / 2 + rank * N  # each rank owns its own N x N region of the world
     y0 = -N / 2
 
-    def step(p=0):
+    def step(p=0, noise_done=None):
         # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
         c, zz = ctxs[p], zs[p]
         mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
+        if noise_done is not None:
+            noise_done.set()
         c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                   # run_erosion passes min(vals): only written cells can need the clamp
 
     def run_steps(k, npipe):
@@ -164,9 +166,16 @@ def main():
             for _ in range(k):
                 step(0)
             return
+        # the pipelines start one noise phase apart (worker p issues its first step when worker p-1's first noise call has returned): started together
+        # they run in lockstep -- four noise kernels sharing the chip, then four erosions leaving it idle -- and only drift into an overlapping
+        # pattern after dozens of steps
+        first_noise_done = [threading.Event() for _ in range(npipe)]
         def worker(p):
-            for _ in range(p, k, npipe):
-                step(p)
+            for i, _ in enumerate(range(p, k, npipe)):
+                if i == 0 and p > 0:
+                    first_noise_done[p - 1].wait()
+                step(p, first_noise_done[p] if i == 0 else None)
+            first_noise_done[p].set()  # also when this worker had no step at all
         th = [threading.Thread(target=worker, args=(p,)) for p in range(npipe)]
         for x in th:
             x.start()
