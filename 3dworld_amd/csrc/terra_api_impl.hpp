@@ -459,6 +459,14 @@ int terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny,
 	if (!(mag > 0.0f) || !(freq > 0.0f)) return terra::fail(TERRA_ERR_ARG, "voxel_fill: mag and freq must be > 0"); // assert(mag > 0.0 && freq > 0.0), src/upsurface.cpp:19
 	TERRA_TRY ctx->eng.voxel_fill_dev(d_out, nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, gen_mode, zscale, normalize); TERRA_CATCH
 }
+int terra_voxel_fill_slab_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo[3], const float vsz[3], const float off[3],
+	float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize, uint32_t y0, uint32_t nys)
+{
+	TERRA_CHECK_CTX if (!d_out || !lo || !vsz || !off) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (gen_mode < 0 || gen_mode > TERRA_MGEN_DWARP_GPU) return terra::fail(TERRA_ERR_ARG, "bad gen_mode");
+	if (!(mag > 0.0f) || !(freq > 0.0f)) return terra::fail(TERRA_ERR_ARG, "voxel_fill: mag and freq must be > 0");
+	TERRA_TRY ctx->eng.voxel_fill_dev(d_out, nx, ny, nz, lo, vsz, off, mag, freq, rs1, rs2, gen_mode, zscale, normalize, y0, nys); TERRA_CATCH
+}
 int terra_voxel_fill(terra_ctx *ctx, float *h_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo[3], const float vsz[3], const float off[3],
 	float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize)
 {

@@ -1214,12 +1214,16 @@ template<class BE> struct terra_engine {
 	}
 
 	// ================================================================ voxels (a14, a15, K8, K9)
+	// y0 / nys (optional): only the y slab [y0, y0 + nys) of the nx x ny x nz grid, written to d_out as an nys x nx x nz array with the values the full-grid
+	// call produces (the axis positions are the full grid's running sums): voxels are independent, a field is split over GPUs in y slabs
 	void voxel_fill_dev(float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, float const lo[3], float const vsz[3], float const off[3],
-		float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize)
+		float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize, uint32_t y0 = 0, uint32_t nys = 0xFFFFFFFFu)
 	{
 		require_scene();
 		if (nx == 0 || ny == 0 || nz == 0) throw std::invalid_argument("voxel_fill: empty grid");
-		size_t const nvox = (size_t)nx*ny*nz;
+		if (nys == 0xFFFFFFFFu) {if (y0 != 0) throw std::invalid_argument("voxel_fill slab: y0 without a slab height"); nys = ny;}
+		if (nys == 0 || y0 >= ny || nys > ny - y0) throw std::invalid_argument("voxel_fill slab: [y0, y0 + nys) must be a non-empty range inside the grid");
+		size_t const nvox = (size_t)nx*nys*nz;
 		sin_lut_t const L = lut();
 		if (gen_mode == MGEN_SINE) {
 			// noise_gen_3d::gen_sines (src/upsurface.cpp:16-38) on the host: 420 floats, handed to the table kernel by value (kernel argument, no upload)
@@ -1236,7 +1240,7 @@ template<class BE> struct terra_engine {
 				}
 				m *= 0.5f; f /= 0.4f; // M_ATTEN_FACTOR, F_ATTEN_FACTOR (src/upsurface.cpp:10-11)
 			}
-			size_t const ntab = ((size_t)nx + ny + nz)*VOX_SINES, npos = (size_t)nx + ny + nz;
+			size_t const ntab = ((size_t)nx + nys + nz)*VOX_SINES, npos = (size_t)nx + ny + nz; // tables of the slab's rows only, positions of the whole axes
 			float *d_base = scratch<float>(s_vox, ntab + npos + 64);
 			float *d_tab = d_base, *d_pos = d_base + ntab;
 			// gen_xyz_vals (src/upsurface.cpp:41-57): val accumulates `val += step` sequentially, so the positions of an axis are a serial prefix sum: one thread per axis
@@ -1250,13 +1254,14 @@ template<class BE> struct terra_engine {
 			});
 			be.launch(ntab, [=] TERRA_LAMBDA (size_t i) {
 				size_t const e = i / VOX_SINES; unsigned const k = (unsigned)(i % VOX_SINES);
-				unsigned const d = (e < nx) ? 0u : ((e < (size_t)nx + ny) ? 1u : 2u);
+				unsigned const d = (e < nx) ? 0u : ((e < (size_t)nx + nys) ? 1u : 2u);
+				size_t const pe = (d == 0) ? e : ((d == 1) ? e + y0 : e + (ny - nys)); // index into the whole-axis positions: x as is, y shifted by the slab start, z after all of y
 				unsigned const index2 = VOX_PARAMS*k + 2*d;
-				float v = L.SINF(rd.v[index2+1]*d_pos[e] + rd.v[index2+2]);
+				float v = L.SINF(rd.v[index2+1]*d_pos[pe] + rd.v[index2+2]);
 				if (d == 0) {v *= rd.v[index2];}
 				d_tab[i] = v;
 			});
-			be.voxel_sines(d_out, nx, ny, nz, d_tab, zscale, normalize);
+			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize);
 		}
 		else {
 			float const l0 = lo[0], l1 = lo[1], l2 = lo[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2], o0 = off[0], o1 = off[1], o2 = off[2];
@@ -1264,7 +1269,7 @@ template<class BE> struct terra_engine {
 			int const nn = imax(1, 5 - cfg.mesh_freq_filter); // MAX_FREQ_BINS - mesh_freq_filter (src/voxels.cpp:332)
 			bool const perlin = (gen_mode == MGEN_PERLIN);
 			be.launch(nvox, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const z = (unsigned)(i % nz), x = (unsigned)((i / nz) % nx), y = (unsigned)(i / ((size_t)nz*nx));
+				unsigned const z = (unsigned)(i % nz), x = (unsigned)((i / nz) % nx), y = (unsigned)(i / ((size_t)nz*nx)) + y0;
 				float const px = ((float)x*v0 + l0) + o0, py = ((float)y*v1 + l1) + o1, pz = ((float)z*v2 + l2) + o2; // get_pt_at (src/voxels.h:146) + offset
 				float val = 0.0f, nmag = mag, nfreq = (float)(0.25*(double)freq);
 				for (int n = 0; n < nn; ++n) {

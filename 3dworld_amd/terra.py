@@ -154,6 +154,7 @@ _PROTOS = {
     "terra_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
+    "terra_voxel_fill_slab_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32, _u32, _u32]),
     "terra_voxel_fill": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_malloc": (_i32, [_vp, C.POINTER(_vp), _sz]),
     "terra_free": (_i32, [_vp, _vp]),
@@ -464,6 +465,10 @@ class Terra:
     def voxel_fill_dev(self, ptr, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
         a = lambda v: (C.c_float * 3)(*v)
         self._ck(self.lib.terra_voxel_fill_dev(self.ctx, ptr, nx, ny, nz, a(lo_pos), a(vsz), a(offset), mag, freq, rseed1, rseed2, gen_mode, zscale, normalize))
+
+    def voxel_fill_slab_dev(self, ptr, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize, y0, nys):
+        a = lambda v: (C.c_float * 3)(*v)
+        self._ck(self.lib.terra_voxel_fill_slab_dev(self.ctx, ptr, nx, ny, nz, a(lo_pos), a(vsz), a(offset), mag, freq, rseed1, rseed2, gen_mode, zscale, normalize, y0, nys))
 
     # ---- async generator handle (mesh_xy_grid_cache_t protocol)
     def generator(self):

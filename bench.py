@@ -20,6 +20,7 @@ The same run also measures, under `detail` (all ranks take part, rank 0 reports;
            (one shared grid, serial droplet order: replicas only) and is excluded from that line
   tiles    STRONG scaling of BASELINE config 4: the 64 x 64 tiles of 128^2 block-partitioned over the ranks
            (tile_t::create_zvals + stats + normals; with 0 and with 1000 droplets per tile), no collective
+  voxels   STRONG scaling of BASELINE config 5: one 512^3 voxel noise field as y slabs (terra_voxel_fill_slab_dev), no collective
   modes    the same 16384^2 step with simplex / Perlin / domain-warp noise (rank 0)
 `--workload strips|tiles` makes one of those the headline `value` instead (for a scaling sweep of that mode alone).
 
@@ -239,6 +240,20 @@ def main():
             t.synchronize()
         return fn
 
+    # ---- strong scaling of BASELINE config 5: ONE 512^3 voxel field (voxel_manager::create_procedural, sine mode) as y slabs, no collective
+    VN = 512
+    v0, v1 = dmod.strip_rows(VN, rank, world)
+    vox_buf = {}
+
+    def voxel_steps(k):
+        if v1 <= v0:
+            return
+        if not vox_buf:
+            vox_buf["v"] = torch.empty((v1 - v0) * VN * VN, dtype=torch.float32, device=dev)
+        for _ in range(k):
+            t.voxel_fill_slab_dev(vox_buf["v"].data_ptr(), VN, VN, VN, (-1.0, -1.0, -0.25), (2.0 / VN, 2.0 / VN, 0.5 / VN), (0.0, 0.0, 0.0), 1.0, 1.0, 123, 456, 0, 0.0, 1, v0, v1 - v0)
+        t.synchronize()
+
     K, W = args.steps, args.warmup
     detail = {}
     # ---- the headline
@@ -281,6 +296,12 @@ def main():
             detail["tiles"] = {"tiles": len(all_tiles), "tiles_per_rank": nt, "scaling": "strong", "collective": "none",
                                "erosion_0": {"steps": ke, "ms_per_batch": round(dt0 / ke * 1e3, 4), "gcells_s": round(tc * ke / dt0 / 1e9, 3), "mtiles_s": round(len(all_tiles) * ke / dt0 / 1e6, 3)},
                                "erosion_1000": {"steps": kt, "ms_per_batch": round(dt1 / kt * 1e3, 3), "gcells_s": round(tc * kt / dt1 / 1e9, 4), "ktiles_s": round(len(all_tiles) * kt / dt1 / 1e3, 2)}}
+
+    if not args.no_extras:
+        kv = max(4, min(K, 16))
+        dv = timed(voxel_steps, kv, 2)
+        detail["voxels"] = {"grid": f"{VN}^3", "steps": kv, "ms_per_field": round(dv / kv * 1e3, 4), "gvoxels_s": round(VN ** 3 * kv / dv / 1e9, 2), "scaling": "strong", "y_rows_per_rank": v1 - v0, "collective": "none"}
+        vox_buf.clear()
 
     # ---- per-kernel times, live, HIP events on the library's stream (rank 0 only; the other ranks wait at the barrier below)
     if rank == 0:

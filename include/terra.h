@@ -269,6 +269,10 @@ int  terra_tiles_mesh_shadows_halo_dev(terra_ctx *ctx, const int32_t *tile_xy, u
 /* ---- voxels: voxel_manager::create_procedural fill (src/voxels.cpp:278-346).  out is z-fastest: ix = z + (x + y*nx)*nz (src/voxels.h:141-144). */
 int  terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
                           float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
+/* the y slab [y0, y0 + nys) of the same field: d_out = nys*nx*nz floats, bit-identical to those rows of the full-grid call (voxels are independent; the axis
+ * positions are the full grid's running sums, src/upsurface.cpp:41-57): one field as y slabs on several GPUs, no collective (3dworld_amd/dist.py, bench.py) */
+int  terra_voxel_fill_slab_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
+                               float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1, uint32_t y0, uint32_t nys);
 int  terra_voxel_fill(terra_ctx *ctx, float *h_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
                       float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
 

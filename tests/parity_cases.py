@@ -684,6 +684,23 @@ def case_gen_grid_minmax(pkg, t, orc, mode, n):
     assert np.float32(mn) == a.min() and np.float32(mx) == a.max(), (mn, mx, a.min(), a.max())
 
 
+def case_voxel_slabs(pkg, t, orc, gen_mode, shape, nslabs):
+    """one voxel field as y slabs (terra_voxel_fill_slab_dev): the slabs tile the full field bit for bit"""
+    nx, ny, nz = shape
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc); orc.init(oc)
+    lo, vsz, off = (-1.0, -0.8, -0.3), (2.0 / nx, 1.6 / ny, 0.6 / nz), (0.1, -0.2, 0.05)
+    args = (1.0, 1.0, 123, 456, gen_mode, 0.004, 1)
+    ref = orc.voxel_fill(nx, ny, nz, lo, vsz, off, *args)
+    buf = t.alloc(nx * ny * nz * 4)
+    bounds = [round(i * ny / nslabs) for i in range(nslabs + 1)]
+    for y0, y1 in zip(bounds[:-1], bounds[1:]):
+        if y1 > y0:
+            t.voxel_fill_slab_dev(buf.ptr + y0 * nx * nz * 4, nx, ny, nz, lo, vsz, off, *args, y0, y1 - y0)
+    z = buf.download(np.float32, (ny, nx, nz)); buf.free()
+    assert_bit_equal(ref, z, f"voxel slabs mode {gen_mode}")
+
+
 def case_grid_row_strips(pkg, t, orc, mode, nx, ny, nstrips):
     """one heightmap as row strips (terra_gen_grid_rows_minmax_dev): the strips tile the full grid bit for bit, min / max fold to the grid's."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=mode, mesh_freq_filter=1)

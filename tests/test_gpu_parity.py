@@ -140,6 +140,11 @@ def test_grid_row_strips(pkg, gpu, orc, mode, nx, ny, nstrips):
     pc.case_grid_row_strips(pkg, gpu, orc, mode, nx, ny, nstrips)
 
 
+@pytest.mark.parametrize("gen_mode,shape,nslabs", [(0, (96, 64, 64), 8), (0, (17, 9, 300), 2), (1, (24, 20, 33), 3), (2, (24, 20, 33), 4)])
+def test_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs):
+    pc.case_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs)
+
+
 def test_ground_mesh_and_point_queries(pkg, gpu, orc):
     pc.case_ground_mesh_and_point_queries(pkg, gpu, orc)
 

@@ -161,6 +161,11 @@ def test_grid_row_strips(pkg, emul, orc, mode, nx, ny, nstrips):
     pc.case_grid_row_strips(pkg, emul, orc, mode, nx, ny, nstrips)
 
 
+@pytest.mark.parametrize("gen_mode,shape,nslabs", [(0, (20, 13, 17), 3), (1, (8, 9, 6), 2)])
+def test_voxel_slabs(pkg, emul, orc, gen_mode, shape, nslabs):
+    pc.case_voxel_slabs(pkg, emul, orc, gen_mode, shape, nslabs)
+
+
 def test_generator_protocol(pkg, emul, orc):
     pc.case_generator_protocol(pkg, emul, orc)
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""dense whole-map erosion (BASELINE config 3 with config_heightmap.txt's real droplet count): ring size x slice sweep; prints the scheduler's report"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3dworld_amd")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+combos = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[3] if len(sys.argv) > 3 else "2048:1024,8192:64,16384:64,16384:32,16384:128").split(",")]
+t = pkg.Terra(0)
+st = t.init_scene(pkg.make_config(mesh_gen_mode=0))
+z = t.alloc(N * N * 4); zc = t.alloc(N * N * 4)
+mn, mx = t.gen_grid_minmax_dev(zc.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+lib = t.lib
+for (w, sl) in combos:
+    t.set_erosion_tuning(window=w)
+    t.set_erosion_slice_steps(sl)
+    for rep in range(2):
+        lib.terra_memcpy_h2d  # noqa
+        import ctypes
+        # device-to-device copy through the library's own stream: re-generate instead (cheap)
+        t.gen_grid_dev(z.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        t.synchronize()
+        t0 = time.perf_counter()
+        t.apply_erosion_dev(z.ptr, N, N, mn, D, pkg.ERODE_MINZ_IS_MIN)
+        t.synchronize()
+        dt = time.perf_counter() - t0
+    r = t.erosion_report().as_dict()
+    print(f"W {w} slice {sl}: {dt*1e3:.1f} ms rounds {r['rounds']} traces {r['traces']} steps {r['steps']} traced {r['traced_steps']} fallbacks {r['serial_fallbacks']}  us/round {dt*1e6/max(1,r['rounds']):.0f}", flush=True)
