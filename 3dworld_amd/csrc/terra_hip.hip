@@ -219,6 +219,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (bytes > tile_acc_bytes) {if (tile_acc) {sync(); (void)hipFree(tile_acc);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_acc, bytes)); tile_acc_bytes = bytes;}
 		hipLaunchKernelGGL(terra::k_tile_post_init, dim3((n*terra::TP_ACC + 255)/256), dim3(256), 0, stream, tile_acc, n);
 		hipLaunchKernelGGL(terra::k_tile_post, dim3(n*4), dim3(terra::TP_THREADS), 0, stream, refs, z, st, nm, mnz, tile_acc, wpz, rad_c, dxv, dyv, dxy);
+		hipLaunchKernelGGL(terra::k_tile_post_final, dim3((n + 255)/256), dim3(256), 0, stream, refs, n, st, mnz, tile_acc, rad_c, nm ? 1 : 0);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {

@@ -382,7 +382,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // One block per (tile, band of 32 texel rows): 4 x more blocks than tiles and 17.7 KB of LDS each (the whole-tile version staged 67.6 KB: two blocks per CU,
 // every block's load, compute and store phases in sequence).  Band yy owns sub-block row yy completely (rows 32*yy .. 32*yy + 32), so the 4 x 4 sub-block
 // ranges are written by exactly one block each; what spans the tile (mzmin / mzmax / radius, the water bbox, min_normal_z) is folded through 8 words of
-// global scratch per tile with atomics, and the band that arrives last (a ticket counter) writes the tile's totals.
+// global scratch per tile with atomics and written by a one-thread-per-tile kernel afterwards.
 constexpr unsigned TP_THREADS = 256, TP_BAND_ROWS = 34, TP_ACC = 8; // acc: {-, -, bbox x1, y1, x2, y2, min normal z bits, ticket}
 __global__ __launch_bounds__(256) void k_tile_post_init(uint32_t *__restrict__ acc, uint32_t n) {
 	uint32_t const i = blockIdx.x*blockDim.x + threadIdx.x;
@@ -444,35 +444,31 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 	}
 	if (nout) {mnz = wave_min_u32(mnz); if ((tid & 63) == 0) {atomicMin(&s_mnz, mnz);}}
 	__syncthreads();
-	if (tid == 0) { // one thread publishes the band's results, fences, then takes the ticket: the finalising band sees all of them
+	if (tid == 0) { // the band's results; the tile's totals are folded by k_tile_post_final after this kernel (a device-wide fence per block, the
+		// alternative, writes back the XCD's L2 every time on this chip: measured 3 x slower than the whole pass)
 		uint32_t *a = acc + (size_t)t*TP_ACC;
 		if (stats) {
 			for (int k = 0; k < 4; ++k) {stats[t].sub_zmin[yy*4 + k] = ord2f(s_lo[k]); stats[t].sub_zmax[yy*4 + k] = ord2f(~s_hi[k]);}
 			atomicMin((int *)&a[2], s_bb[0]); atomicMin((int *)&a[3], s_bb[1]); atomicMax((int *)&a[4], s_bb[2]); atomicMax((int *)&a[5], s_bb[3]);
 		}
 		if (nout) {atomicMin(&a[6], s_mnz);}
-		__threadfence();
-		if (atomicAdd(&a[7], 1u) == 3u) { // the last band of the tile: every other band's contribution is in the accumulators
-			__threadfence();
-			if (stats) {
-				// mzmin / mzmax fold the 16 sub-block ranges in the reference's order with its std::min / std::max (src/tiled_mesh.cpp:536-538); the other bands'
-				// values are read through to L2 (they were plain stores of other blocks)
-				float mzmin = 100.0f, mzmax = -100.0f;
-				uint32_t const *smin = (uint32_t const *)stats[t].sub_zmin, *smax = (uint32_t const *)stats[t].sub_zmax;
-				for (int k = 0; k < 16; ++k) {
-					uint32_t const ul = __hip_atomic_load(&smin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), uh = __hip_atomic_load(&smax[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					float fl, fh; memcpy(&fl, &ul, 4); memcpy(&fh, &uh, 4);
-					mzmin = min_std(mzmin, fl); mzmax = max_std(mzmax, fh);
-				}
-				stats[t].mzmin = mzmin; stats[t].mzmax = mzmax;
-				stats[t].radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
-				int const b0 = (int)__hip_atomic_load(&a[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = (int)__hip_atomic_load(&a[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				int const b2 = (int)__hip_atomic_load(&a[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b3 = (int)__hip_atomic_load(&a[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				stats[t].wx1 = imin(b0, x1 + 128); stats[t].wy1 = imin(b1, y1 + 128); stats[t].wx2 = imax(b2, x1); stats[t].wy2 = imax(b3, y1);
-			}
-			if (min_nz && nout) {float f; uint32_t const u = __hip_atomic_load(&a[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); memcpy(&f, &u, 4); min_nz[t] = f;}
-		}
 	}
+}
+// one thread per tile: mzmin / mzmax fold the 16 sub-block ranges in the reference's order with its std::min / std::max (src/tiled_mesh.cpp:536-538), radius, water bbox, min_normal_z
+__global__ __launch_bounds__(256) void k_tile_post_final(tile_ref_pod_t const *__restrict__ refs, uint32_t n, terra_tile_stats *__restrict__ stats, float *__restrict__ min_nz, uint32_t const *__restrict__ acc, float rad_c, int have_normals) {
+	uint32_t const t = blockIdx.x*blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	uint32_t const *a = acc + (size_t)t*TP_ACC;
+	if (stats) {
+		tile_ref_pod_t const r = refs[t];
+		int const x1 = r.tx*128, y1 = r.ty*128;
+		float mzmin = 100.0f, mzmax = -100.0f;
+		for (int k = 0; k < 16; ++k) {mzmin = min_std(mzmin, stats[t].sub_zmin[k]); mzmax = max_std(mzmax, stats[t].sub_zmax[k]);}
+		stats[t].mzmin = mzmin; stats[t].mzmax = mzmax;
+		stats[t].radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
+		stats[t].wx1 = imin((int)a[2], x1 + 128); stats[t].wy1 = imin((int)a[3], y1 + 128); stats[t].wx2 = imax((int)a[4], x1); stats[t].wy2 = imax((int)a[5], y1);
+	}
+	if (min_nz && have_normals) {float f; uint32_t const u = a[6]; memcpy(&f, &u, 4); min_nz[t] = f;}
 }
 
 // ------------------------------------------------------------------ row f1: tile AO lighting (tile_t::calc_mesh_ao_lighting, src/tiled_mesh.cpp:634-659)
