@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace terra {
 
@@ -604,6 +605,8 @@ template<class BE> struct terra_engine {
 		ec.max_path_len = 4u*(unsigned)ec.NX*(unsigned)ec.NY;
 		ec.erode_amount = erode_amount; ec.water_thresh = water_plane_z - HALF_DXY;
 		ec.relh_adj_tex = relh_adj_tex; ec.zmin = zmin; ec.zrange = zmax - zmin; ec.clip_hd1 = clip_hd1; ec.two_pi = two_pi; ec.min_zval = min_zval;
+		ec.lead_mode = 2;
+		if (char const *lm = getenv("TERRA_ERO_LEAD")) {int const v = atoi(lm); if (v >= 0 && v <= 2) ec.lead_mode = v;} // where a recentred window lies never changes a result (it is a cache)
 		return ec;
 	}
 
@@ -759,6 +762,7 @@ template<class BE> struct terra_engine {
 		spec_logs_base = base; spec_logs_w = W; spec_logs_cap = sb.cap_log2;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
+		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;
 		if (!record_touched) return false;
 		uint32_t const ntouched = hc.touched;
 		if (ntouched > sb.touched_cap) return false; // record overflowed: the caller clamps the whole grid

@@ -52,6 +52,7 @@ struct erosion_consts_t {
 	float relh_adj_tex, zmin, zrange, clip_hd1; // get_bare_ls_tid (src/Textures.cpp:1284-1287): zrange = zmax - zmin
 	float two_pi;               // float(2.0*PI)
 	float min_zval;
+	int   lead_mode;            // placement of a recentred LDS window: 0 centred on the droplet, 1 always ahead of it, 2 ahead only when the last window lasted (speed only)
 };
 
 struct droplet_result_t {unsigned steps; int nan_seen;};
@@ -436,8 +437,12 @@ struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
 
 // ---- big grids: a WS x WS window of the grid follows the droplet in LDS; BACK is where cells come from / go to.
 constexpr int EW = 32; // window edge (cells): 4 KiB of LDS per droplet; a droplet moves one cell per step, so a centred window lasts >= 13 steps
+constexpr unsigned SPEC_BLOOM_WORDS = 256; // 8192 bits: a few hundred logged cells per trace -> a few percent false positives
+TERRA_HD uint32_t spec_bloom_bit(uint32_t cell) {return (cell*2246822519u) >> (32 - 13);}
 struct wave_shared_t { // per-wave LDS scratch
 	uint32_t nlog, flags, pad_;
+	uint32_t n_shift, n_own, n_ver, n_store; // diagnostics of the trace (terra_erosion_report)
+	uint32_t bloom[SPEC_BLOOM_WORDS];        // one bit per hash of a cell this trace has written back to its log: a clear bit spares the look-up of the log (a hash probe through L2)
 	unsigned long long chk;
 	uint8_t blk_shared[64];
 };
@@ -446,6 +451,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	float *win, *win_alt; uint8_t *dirty, *dirty_alt; // LDS: EW*EW each, double-buffered so a window shift copies the overlap LDS -> LDS
 	int wx0, wz0, NX, NY; bool have;
 	int lead_x = 0, lead_z = 0; // where the droplet is heading (-1, 0, 1 per axis): a recentred window is placed ahead of it
+	int lead_mode = 2, steps_in_window = 0; // a window that lasted only a few steps means the droplet turned back (it circles in a pit): centre the next one instead
 	BACK back;
 	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; win_alt = w + EW*EW; dirty = d; dirty_alt = d + EW*EW; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
 	TERRA_HD bool in_window(int X, int Z) const {return have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;}
@@ -465,7 +471,8 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD void recenter(int cx, int cz) {
 		// the droplet sits a quarter of the window behind the centre, in the direction it came from: ~21 instead of ~13 steps until its brush box leaves again.
 		// Where the window lies never changes a result (it is a cache of the backing store), only how often it moves.
-		cx += lead_x*(EW/4); cz += lead_z*(EW/4);
+		if (lead_mode == 1 || (lead_mode == 2 && (!have || steps_in_window >= 10))) {cx += lead_x*(EW/4); cz += lead_z*(EW/4);}
+		steps_in_window = 0;
 		int const nx0 = clampi(cx - EW/2, imax(NX - EW, 0)), nz0 = clampi(cz - EW/2, imax(NY - EW, 0));
 		if (have) {
 			TERRA_LANES(i, EW*EW) {
@@ -525,7 +532,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD bool hot_ready(int xi, int zi) {
 		if (!(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) return false;
 		if (!back.begin_step(xi, zi)) return false; // idempotent: the general step may record the same blocks again
-		wx0 = wave_uniform(wx0); wz0 = wave_uniform(wz0);
+		wx0 = wave_uniform(wx0); wz0 = wave_uniform(wz0); steps_in_window = wave_uniform(steps_in_window) + 1;
 		return have && xi-1 >= wx0 && xi+2 < wx0 + EW && zi-1 >= wz0 && zi+2 < wz0 + EW;
 	}
 	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
@@ -583,6 +590,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t ndirty;       // entries of dirty_list
 	uint32_t pad_;
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
+	unsigned long long n_shift, n_own, n_ver, n_store; // diagnostics summed over all traces
 };
 struct spec_resume_t {uint32_t nblk, nlog, flags, bc[4], be[4], bwmask, far_last; int own_x0, own_z0, own_x1, own_z1; unsigned long long chk;}; // spec_back_t state of a suspended trace
 
@@ -680,8 +688,13 @@ struct spec_back_t {
 			bc0 = rs->bc[0]; bc1 = rs->bc[1]; bc2 = rs->bc[2]; bc3 = rs->bc[3]; be0 = rs->be[0]; be1 = rs->be[1]; be2 = rs->be[2]; be3 = rs->be[3];
 			bwmask = rs->bwmask; far_last = rs->far_last;
 		}
-		if (TERRA_LANE0) {sh->nlog = rs ? rs->nlog : 0; sh->flags = rs ? rs->flags : 0; sh->chk = rs ? rs->chk : 0;}
+		if (TERRA_LANE0) {sh->nlog = rs ? rs->nlog : 0; sh->flags = rs ? rs->flags : 0; sh->chk = rs ? rs->chk : 0; sh->n_shift = sh->n_own = sh->n_ver = sh->n_store = 0;}
+		TERRA_LANES(w, SPEC_BLOOM_WORDS) {sh->bloom[w] = 0u;}
 		TERRA_WAVE_SYNC();
+		if (rs && rs->nlog) { // a resumed trace: the filter is rebuilt from the log written so far
+			TERRA_LANES(e, rs->nlog) {uint32_t const bb = spec_bloom_bit(my_keys[my_used[e]]); TERRA_ATOMIC_OR(&sh->bloom[bb >> 5], 1u << (bb & 31u));}
+			TERRA_WAVE_SYNC();
+		}
 	}
 	TERRA_HD void save(spec_resume_t &rs) const {
 		rs.nblk = nblk; rs.nlog = sh->nlog; rs.flags = sh->flags; rs.chk = sh->chk;
@@ -737,6 +750,7 @@ struct spec_back_t {
 	TERRA_HD bool lower_version(uint32_t j) const {return sb->has_ver[j] && sb->it[j] < iter;}
 	// which blocks under the new window are also in a LOWER droplet's footprint (only those need the multi-version lookup)
 	TERRA_HD void prepare_window(int wx0, int wz0) {
+		if (TERRA_LANE0) {sh->n_shift += 1;}
 		wbx0 = wx0 >> sb->bshift; wbz0 = wz0 >> sb->bshift;
 		TERRA_LANES(i, wnb*wnb) {
 			uint8_t shared = 0;
@@ -765,8 +779,15 @@ struct spec_back_t {
 	TERRA_HD float lookup(int X, int Z, float b) const {
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
 		float v;
-		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1 && spec_log_find<true>(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
+		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1) {
+			uint32_t const bb = spec_bloom_bit(cell);
+			if (sh->bloom[bb >> 5] & (1u << (bb & 31u))) { // possibly written back earlier by this trace
+				TERRA_ATOMIC_ADD(&sh->n_own, 1u);
+				if (spec_log_find<true>(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
+			}
+		}
 		if (block_flag(X, Z)) {
+			TERRA_ATOMIC_ADD(&sh->n_ver, 1u);
 			uint32_t best = SPEC_NIL; // droplet number of the best writer so far
 			size_t const cap = (size_t)1 << sb->cap_log2;
 			uint32_t const blk = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
@@ -786,7 +807,9 @@ struct spec_back_t {
 	// called from lanes in parallel, each with a distinct cell.  sh->chk = sum over the log's cells of a non-linear term of (cell, latest value):
 	// a function of the log CONTENT only, so two traces of a droplet compare equal however their write-backs were scheduled
 	TERRA_HD void store(int X, int Z, float val) {
+		TERRA_ATOMIC_ADD(&sh->n_store, 1u);
 		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
+		{uint32_t const bb = spec_bloom_bit(cell); TERRA_ATOMIC_OR(&sh->bloom[bb >> 5], 1u << (bb & 31u));}
 		uint32_t const mask = (1u << sb->cap_log2) - 1, limit = mask - (uint32_t)(EW*EW) - 64u;
 		uint32_t h = spec_hash(cell, sb->cap_log2);
 		for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
@@ -831,6 +854,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	if (ph != SPEC_FRESH && ph != SPEC_RUNNING) return;
 	window_mem_t<spec_back_t> mem;
 	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
+	mem.lead_mode = sb.ec.lead_mode;
 	droplet_state_t d;
 	bool finished = false;
 	if (ph == SPEC_FRESH) {
@@ -902,6 +926,10 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		}
 		if (ph == SPEC_FRESH) {TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u);}
 		TERRA_ATOMIC_ADD(&sb.ctl->traced_steps, (unsigned long long)(d.numMoves - steps_before));
+		if (ws.sh->n_shift) {TERRA_ATOMIC_ADD(&sb.ctl->n_shift, (unsigned long long)ws.sh->n_shift);}
+		if (ws.sh->n_own)   {TERRA_ATOMIC_ADD(&sb.ctl->n_own,   (unsigned long long)ws.sh->n_own);}
+		if (ws.sh->n_ver)   {TERRA_ATOMIC_ADD(&sb.ctl->n_ver,   (unsigned long long)ws.sh->n_ver);}
+		if (ws.sh->n_store) {TERRA_ATOMIC_ADD(&sb.ctl->n_store, (unsigned long long)ws.sh->n_store);}
 	}
 }
 
@@ -911,6 +939,7 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 {
 	window_mem_t<grid_back_t> mem;
 	mem.init(ws.win, ws.dirty, ec.NX, ec.NY);
+	mem.lead_mode = ec.lead_mode;
 	mem.back.g = g; mem.back.touched = touched; mem.back.touched_count = touched_count; mem.back.touched_cap = touched_cap;
 	droplet_result_t const r = simulate_droplet((int)iter, mem, ec);
 	mem.finish();

@@ -57,7 +57,8 @@ GRASS_BLOCK_DTYPE = np.dtype([("ix", np.uint32), ("zmin", np.float32), ("zmax", 
 
 class ErosionReport(C.Structure):  # terra_erosion_report
     _fields_ = [("droplets", C.c_uint32), ("windows", C.c_uint32), ("rounds", C.c_uint32), ("traces", C.c_uint32),
-                ("serial_fallbacks", C.c_uint32), ("nan_droplets", C.c_uint32), ("steps", C.c_uint64), ("traced_steps", C.c_uint64)]
+                ("serial_fallbacks", C.c_uint32), ("nan_droplets", C.c_uint32), ("steps", C.c_uint64), ("traced_steps", C.c_uint64),
+                ("window_shifts", C.c_uint64), ("own_lookups", C.c_uint64), ("version_lookups", C.c_uint64), ("log_stores", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -77,6 +77,11 @@ typedef struct terra_erosion_report {
 	uint32_t droplets, windows /* ring generations = ceil(droplets / slots) */, rounds, traces, serial_fallbacks, nan_droplets;
 	uint64_t steps;          /* droplet steps of the final (committed) traces */
 	uint64_t traced_steps;   /* droplet steps actually simulated, re-traces included */
+	/* where a trace's time goes besides the steps themselves (speculative scheduler only) */
+	uint64_t window_shifts;  /* times the 32 x 32 LDS window was moved */
+	uint64_t own_lookups;    /* cells entering a window that were looked up in the droplet's own write-back log */
+	uint64_t version_lookups;/* cells entering a window that were looked up in lower droplets' published versions */
+	uint64_t log_stores;     /* cells written back from a window to the version's log */
 } terra_erosion_report;
 
 /* The globals tile_t::create_texture and tile_t::update_terrain_params read beyond terra_config; the defaults are the reference's. */

@@ -26,4 +26,4 @@ for (w, sl) in combos:
         t.synchronize()
         dt = time.perf_counter() - t0
     r = t.erosion_report().as_dict()
-    print(f"W {w} slice {sl}: {dt*1e3:.1f} ms rounds {r['rounds']} traces {r['traces']} steps {r['steps']} traced {r['traced_steps']} fallbacks {r['serial_fallbacks']}  us/round {dt*1e6/max(1,r['rounds']):.0f}", flush=True)
+    print(f"W {w} slice {sl}: {dt*1e3:.1f} ms rounds {r['rounds']} traces {r['traces']} steps {r['steps']} traced {r['traced_steps']} fallbacks {r['serial_fallbacks']}  us/round {dt*1e6/max(1,r['rounds']):.0f}  shifts {r['window_shifts']} own_lookups {r['own_lookups']} version_lookups {r['version_lookups']} log_stores {r['log_stores']}", flush=True)
