@@ -237,7 +237,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			else {tile_erosion_windowed(n, zvals, ec, iters, tile_pad);}
 			return;
 		}
-		uint32_t const *d_order = nullptr;
+		uint32_t const *d_order = nullptr, *d_landc = nullptr;
 		if (n > 512 && (uint64_t)n*iters >= (1u << 16)) { // more tiles than the chip holds at once (2 per CU): longest predicted chains first
 			size_t const bytes = (size_t)n*2*sizeof(uint32_t);
 			if (bytes > tile_order_bytes) {if (tile_order) {sync(); (void)hipFree(tile_order);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_order, bytes)); tile_order_bytes = bytes;}
@@ -250,9 +250,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			for (uint32_t i = 0; i < n; ++i) {ord[i] = i;}
 			std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {return land[a] > land[b];});
 			h2d(d_ord, ord.data(), (size_t)n*4);
-			d_order = d_ord;
+			d_order = d_ord; d_landc = d_land;
 		}
-		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters, d_order);
+		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters, d_order, d_landc);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void minmax(float const *vals, size_t n, uint32_t *d) {

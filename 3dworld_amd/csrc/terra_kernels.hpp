@@ -339,17 +339,23 @@ template<int MODE> __global__ __launch_bounds__(256) void k_noise_tiles(tile_ref
 __global__ __launch_bounds__(256) void k_tile_land_cells(float const *__restrict__ zvals, uint32_t cells, float water_thresh, uint32_t *__restrict__ land) {
 	float const *z = zvals + (size_t)blockIdx.x*cells;
 	uint32_t cnt = 0;
-	for (uint32_t i = threadIdx.x; i < cells; i += 256) {cnt += (z[i] >= water_thresh) ? 1u : 0u;}
+	for (uint32_t i = threadIdx.x; i < cells; i += 256) {cnt += !(z[i] < water_thresh) ? 1u : 0u;} // a NaN counts as land: it does not pass the ocean test either
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) {cnt += __shfl_down(cnt, off, 64);}
 	if ((threadIdx.x & 63) == 0 && cnt) {atomicAdd(&land[blockIdx.x], cnt);}
 }
 // `order` (or null): the tile each block takes.  Blocks are dispatched in index order and only two tiles fit a CU, so the batch is a list-scheduling
 // problem: handing out the longest chains first keeps the heavy land tiles from forming the tail of the launch.
-__global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters, uint32_t const *__restrict__ order) {
+__global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters, uint32_t const *__restrict__ order, uint32_t const *__restrict__ land) {
 	extern __shared__ __attribute__((aligned(16))) float te_pad[];
 	int const NX = ec.NX, NY = ec.NY, xs = ec.xsize, ys = ec.ysize;
-	float *z = zvals + (size_t)(order ? order[blockIdx.x] : blockIdx.x)*xs*ys;
+	uint32_t const tile = order ? order[blockIdx.x] : blockIdx.x;
+	float *z = zvals + (size_t)tile*xs*ys;
+	if (land && land[tile] == 0) { // every cell (and so every clamp-padded copy) is below the ocean threshold: each droplet stops at its first step without a write
+		// (src/erosion.cpp:98), so apply_erosion reduces to its final clamp -- no need to hold one of the chip's 512 LDS tile slots for a thousand such droplets
+		for (int i = threadIdx.x; i < xs*ys; i += 64) {z[i] = max_std(ec.min_zval, z[i]);}
+		return;
+	}
 	for (int i = threadIdx.x; i < NX*NY; i += 64) { // clamp-padded copy (src/erosion.cpp:31-37), coalesced rows
 		int const X = i % NX, Z = i / NX;
 		te_pad[i] = z[(size_t)imax(imin(Z - EROSION_PAD, ys-1), 0)*xs + imax(imin(X - EROSION_PAD, xs-1), 0)];
