@@ -96,6 +96,24 @@ def test_two_ranks_one_heightmap_as_row_strips(emul_lib, orc, tmp_path, mode, nx
         assert mm[0] == ref.min() and mm[1] == ref.max()
 
 
+@pytest.mark.gpu
+def test_two_ranks_one_heightmap_as_row_strips_on_the_hip_library(orc, tmp_path):
+    """the same through libterra_hip.so (both ranks on GPU 0 of the test box, gloo for the one-float all_reduce; under RCCL the tensor lives on the device):
+    the product path of bench.py's strips workload, not the host emulation"""
+    import torch.multiprocessing as mp
+    import orclib
+    mode, nx, ny = 0, 1030, 517
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_strips_worker, args=(2, port, None, str(tmp_path), mode, nx, ny), nprocs=2, join=True)
+    z = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(2)])
+    s = orc.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+    ref = orc.gen_grid(-nx / 2, -ny / 2, s.DX_VAL, s.DY_VAL, nx, ny, 1)
+    orclib.assert_bit_equal(ref, z, "union of the row strips (HIP)")
+    for r in range(2):
+        mm = np.load(tmp_path / f"mm_{r}.npy")
+        assert mm[0] == ref.min() and mm[1] == ref.max()
+
+
 def test_strip_rows_cover_the_grid_once():
     dmod = importlib.import_module("3dworld_amd.dist")
     for ny in (1, 5, 130, 16384):
