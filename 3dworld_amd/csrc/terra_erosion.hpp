@@ -671,6 +671,7 @@ struct spec_back_t {
 	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
 	int own_x0, own_z0, own_x1, own_z1; // bounding box of the cells this droplet may already have written back
+	int lx0 = INT_MIN, lx1 = INT_MIN, lz0 = INT_MIN, lz1 = INT_MIN; // block range of the previous step's brush box
 
 	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_, uint32_t iter_, wave_shared_t *sh_, spec_resume_t const *rs) {
 		sb = sb_; slot = slot_; iter = iter_; sh = sh_;
@@ -682,6 +683,7 @@ struct spec_back_t {
 		my_used = sb->log_used[nb] + (size_t)slot*cap;
 		nblk = 0; bc0 = bc1 = bc2 = bc3 = SPEC_NIL; be0 = be1 = be2 = be3 = 0; bwmask = 0; far_last = SPEC_NIL;
 		blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
+		lx0 = lx1 = lz0 = lz1 = INT_MIN;
 		own_x0 = own_z0 = INT_MAX; own_x1 = own_z1 = INT_MIN;
 		if (rs) { // resume a suspended trace
 			nblk = rs->nblk; own_x0 = rs->own_x0; own_z0 = rs->own_z0; own_x1 = rs->own_x1; own_z1 = rs->own_z1;
@@ -733,10 +735,15 @@ struct spec_back_t {
 		++nblk;
 	}
 	TERRA_HD bool begin_step(int xi, int zi) { // footprint of one step = the 4x4 brush box, which also covers every read of that step
-		nblk = wave_uniform(nblk); bwmask = wave_uniform(bwmask); bc0 = wave_uniform(bc0); bc1 = wave_uniform(bc1); bc2 = wave_uniform(bc2); bc3 = wave_uniform(bc3);
-		be0 = wave_uniform(be0); be1 = wave_uniform(be1); be2 = wave_uniform(be2); be3 = wave_uniform(be3);
 		int const x0 = clampi(xi-1, sb->ec.NX-1) >> sb->bshift, x1 = clampi(xi+2, sb->ec.NX-1) >> sb->bshift;
 		int const z0 = clampi(zi-1, sb->ec.NY-1) >> sb->bshift, z1 = clampi(zi+2, sb->ec.NY-1) >> sb->bshift;
+		// a droplet moves at most one cell per step: most steps have the brush box in the same (at most four) blocks as the step before, which are then the
+		// newest entries of the cache -- nothing to record
+		lx0 = wave_uniform(lx0); lx1 = wave_uniform(lx1); lz0 = wave_uniform(lz0); lz1 = wave_uniform(lz1);
+		if (x0 == lx0 && x1 == lx1 && z0 == lz0 && z1 == lz1) {return !failed();}
+		lx0 = x0; lx1 = x1; lz0 = z0; lz1 = z1;
+		nblk = wave_uniform(nblk); bwmask = wave_uniform(bwmask); bc0 = wave_uniform(bc0); bc1 = wave_uniform(bc1); bc2 = wave_uniform(bc2); bc3 = wave_uniform(bc3);
+		be0 = wave_uniform(be0); be1 = wave_uniform(be1); be2 = wave_uniform(be2); be3 = wave_uniform(be3);
 		touch_block((uint32_t)z0*sb->nbx + x0);
 		if (x1 != x0) {touch_block((uint32_t)z0*sb->nbx + x1);}
 		if (z1 != z0) {
