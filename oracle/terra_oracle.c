@@ -579,7 +579,13 @@ typedef struct {
 } egrid_t;
 
 static inline int hmap_index(egrid_t const *e, int x, int y) {return e->NX*imax(imin(y, e->NY-1), 0) + imax(imin(x, e->NX-1), 0);}
+/* optional access trace of the droplet loop (analysis of the dependency structure between droplets, tools/erosion_deps.py): every padded-grid cell a droplet
+ * reads (corner fetches) or read-modify-writes (deposit / brush), as (cell << 1) | is_write, droplet by droplet */
+static uint32_t *ero_trace = NULL; static size_t ero_trace_cap = 0, ero_trace_n = 0;
+static inline void ero_tr(int ix, int wr) {if (ero_trace) {if (ero_trace_n < ero_trace_cap) {ero_trace[ero_trace_n] = ((uint32_t)ix << 1) | (uint32_t)wr;} ++ero_trace_n;}}
 
+static inline int ero_rd(egrid_t const *e, int x, int y) {int const ix = hmap_index(e, x, y); ero_tr(ix, 0); return ix;}
+static uint64_t *ero_trace_off = NULL; /* [num_iters + 1] start of each droplet's entries */
 static void erosion_impl(float *heightmap, int xsize, int ysize, float min_zval, unsigned num_iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet) {
 	if (num_iters == 0 || erode_amount <= 0.0f) return;
 	float const Kq=10, Kw=0.001f, Kr=0.9f, Kd=0.02f, Ki=0.1f, minSlope=0.05f, g=20, Kg=g*2;
@@ -593,11 +599,11 @@ static void erosion_impl(float *heightmap, int xsize, int ysize, float min_zval,
 		size_t const offset = (size_t)imax(imin(y-PAD, ysize-1), 0)*xsize;
 		for (int x = 0; x < NX; ++x) {mh_padded[(size_t)y*NX + x] = heightmap[imax(imin(x-PAD, xsize-1), 0) + offset];}
 	}
-#define HMAP(x, y) mh_padded[hmap_index(&e, (x), (y))]
+#define HMAP(x, y) mh_padded[ero_rd(&e, (x), (y))]
 #define DEPOSIT_AT(X, Z, W) { \
 	float const delta = ds*erode_amount*(W); \
 	int const ix = hmap_index(&e, (X), (Z)); \
-	if (!((X) < 0 || (Z) < 0 || (X) >= NX || (Z) >= NY)) {mh_padded[ix] += delta;} \
+	if (!((X) < 0 || (Z) < 0 || (X) >= NX || (Z) >= NY)) {mh_padded[ix] += delta; ero_tr(ix, 1);} \
 }
 #define DEPOSIT(H) \
 	DEPOSIT_AT(xi  , zi  , (1-xf)*(1-zf)) \
@@ -608,6 +614,7 @@ static void erosion_impl(float *heightmap, int xsize, int ysize, float min_zval,
 
 	/* serial order iter = 0,1,2,...: the only deterministic order of the reference (OMP_NUM_THREADS=1); see SURVEY section 7 */
 	for (int iter = 0; iter < (int)num_iters; ++iter) {
+		if (ero_trace_off) {ero_trace_off[iter] = ero_trace_n;}
 		rgen_t rgen;
 		rgen_set_state(&rgen, iter+11, 79*iter+121);
 		int xi = PAD + (rgen_rand(&rgen)%xsize);
@@ -670,7 +677,8 @@ static void erosion_impl(float *heightmap, int xsize, int ysize, float min_zval,
 						if (wb<=0) continue;
 						wb*=0.1591549430918953f;
 						float const delta=ds*erode_amount*wb;
-						mh_padded[hmap_index(&e, x, z)]-=delta;
+						int const bix=hmap_index(&e, x, z);
+						mh_padded[bix]-=delta; ero_tr(bix, 1);
 					}
 				}
 				dh-=ds;
@@ -777,6 +785,16 @@ void orc_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx, unsign
 		for (unsigned x = 0; x < nx; ++x) {out[(size_t)y*nx + x] = gc_eval_index(&g, x, y, min_start_sin, use_cache);}
 	}
 	gc_free(&g);
+}
+/* apply_erosion + the access trace: cells[] receives up to cap entries ((padded cell << 1) | is_write), offsets[iters + 1] each droplet's first entry; returns the
+ * number of entries the run produced (may exceed cap: then only the first cap were stored) */
+uint64_t orc_apply_erosion_trace(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, uint32_t *cells, uint64_t cap, uint64_t *offsets) {
+	ero_trace = cells; ero_trace_cap = (size_t)cap; ero_trace_n = 0; ero_trace_off = offsets;
+	erosion_impl(hmap, xsize, ysize, min_zval, iters, NULL, NULL);
+	if (offsets) {offsets[iters] = ero_trace_n;}
+	uint64_t const n = ero_trace_n;
+	ero_trace = NULL; ero_trace_off = NULL; ero_trace_cap = 0; ero_trace_n = 0;
+	return n;
 }
 void orc_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters) {erosion_impl(hmap, xsize, ysize, min_zval, iters, NULL, NULL);}
 void orc_apply_erosion_stats(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet) {
