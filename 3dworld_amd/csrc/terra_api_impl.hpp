@@ -6,6 +6,7 @@
 #include "terra_driver.hpp"
 #include "terra_png.hpp"
 #include <new>
+#include <mutex>
 
 namespace terra {
 static thread_local std::string g_last_error;
@@ -27,6 +28,7 @@ struct terra_gen { // mesh_xy_grid_cache_t (src/mesh.h:22-45)
 	// kstart; a caller that asks for another first term gets a grid evaluated with that one (one more launch, kept per first term)
 	int kstart = 0, sev = 0, gen_mode = 0;
 	std::map<int, std::vector<float>> alt_vals;
+	std::mutex mtx; // eval_index is const in the reference and called from its OpenMP workers (src/tiled_mesh.cpp:495, src/heightmap.cpp:139): the lazy read-back / re-evaluation here is serialised
 };
 
 #define TERRA_TRY   try {
@@ -147,6 +149,7 @@ int terra_gen_collect(terra_gen *g, float *host_out) {
 float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_sin, int use_cache) {
 	if (!g || !g->built || x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;} // assert(x < cur_nx && y < cur_ny), src/mesh_gen.cpp:756
 	try {
+		std::lock_guard<std::mutex> lock(g->mtx);
 		// which first sine term the reference would use (src/mesh_gen.cpp:759-770): cached values (cache_values at build time, filled with min_start_sin = 0)
 		// win when use_cache is set; the fBm modes have no sine terms
 		int want = g->kstart;
@@ -159,10 +162,7 @@ float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_s
 			float *d = (float *)be.alloc(count*sizeof(float));
 			std::vector<float> tmp(count);
 			try {
-				// start_eval_sin may have moved since build_arrays(): evaluate with the value the tables were built for
-				int const sev_now = g->ctx->eng.start_eval_sin; g->ctx->eng.start_eval_sin = g->sev;
-				try {g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE), want, d);} catch (...) {g->ctx->eng.start_eval_sin = sev_now; throw;}
-				g->ctx->eng.start_eval_sin = sev_now;
+				g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE), want, d); // first term = max(start_eval_sin, want)
 				be.d2h(tmp.data(), d, count*sizeof(float));
 			} catch (...) {be.free(d); g->alt_vals.erase(want); throw;}
 			be.free(d);

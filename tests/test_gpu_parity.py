@@ -231,6 +231,40 @@ def test_full_size_noise_modes_whole_grid_equals_oracle(pkg, gpu, orc, mode):
     assert np.float32(mn) == ref.min() and np.float32(mx) == ref.max()
 
 
+def test_dense_erosion_config3_equals_oracle(pkg, gpu, orc):
+    """BASELINE config 3 at its real density (config_heightmap.txt asks for 10^6 droplets; 10^5 here keeps the single-threaded oracle at ~0.2 s): 4096^2, every cell against the
+    oracle's serial droplet order -- the regime with ~120 scheduler rounds, multi-version look-ups and re-traces"""
+    N, droplets = 4096, 100000
+    st = gpu.init_scene(pkg.make_config(mesh_gen_mode=0))
+    orc.init(orclib.make_config(mesh_gen_mode=0))
+    a = gpu.alloc(N * N * 4)
+    mn, _ = gpu.gen_grid_minmax_dev(a.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+    gpu.apply_erosion_dev(a.ptr, N, N, mn, droplets, pkg.ERODE_MINZ_IS_MIN)
+    rep = gpu.erosion_report().as_dict()
+    z = a.download(np.float32, (N, N)); a.free()
+    ref = orc.gen_grid(-N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 1)
+    st_o = orc.apply_erosion_stats(ref, float(ref.min()), droplets)
+    diff = z.view(np.uint32) != ref.view(np.uint32)
+    assert not diff.any(), f"{int(diff.sum())} cells differ"
+    assert rep["steps"] == st_o[0].steps and rep["rounds"] > 50 and rep["traces"] > droplets, rep
+
+
+def test_full_size_row_strips_tile_the_grid(pkg, gpu):
+    """16384^2 as 8 row strips (what 8 ranks of bench.py's strips workload evaluate) == the single-call grid, bit for bit; the strips' minima fold to the grid's"""
+    N, W = 16384, 8
+    st = gpu.init_scene(pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    a, b = gpu.alloc(N * N * 4), gpu.alloc(N * N * 4)
+    mn, mx = gpu.gen_grid_minmax_dev(a.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+    mns = []
+    for r in range(W):
+        r0, r1 = r * N // W, (r + 1) * N // W
+        m, _ = gpu.gen_grid_rows_minmax_dev(b.ptr + r0 * N * 4, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, r0, r1 - r0, pkg.GEN_GLACIATE)
+        mns.append(m)
+    za, zb = a.download(np.float32, (N, N)), b.download(np.float32, (N, N))
+    a.free(); b.free()
+    assert (za.view(np.uint32) == zb.view(np.uint32)).all() and min(mns) == mn
+
+
 def test_full_size_erosion_speculative_equals_serial_walk(pkg, gpu):
     """16384^2 + 1000 droplets: the multi-version fixed point must equal the single-lane serial walk bit for bit."""
     N = 16384
