@@ -203,13 +203,12 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_CHAIN_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	bool tile_ao_overlays() const {return !simple_kernels;} // k_tile_ao takes the tile's own zvals itself: the caller need not copy them into the context first
-	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz, bool overlay) {
+	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {
 		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz); return;}
 		use();
 		unsigned const nbands = (terra::AO_TEX + terra::AO_BAND - 1)/terra::AO_BAND;
 		size_t const lds = (size_t)(terra::AO_BAND + terra::AO_RL)*terra::AO_CS*sizeof(float);
-		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(256), lds, stream, z, ctx, ao, dz, overlay ? 1 : 0);
+		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(256), lds, stream, z, ctx, ao, dz);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	uint32_t *tile_acc = nullptr; size_t tile_acc_bytes = 0; // k_tile_post's per-tile accumulators

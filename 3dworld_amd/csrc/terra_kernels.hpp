@@ -494,8 +494,9 @@ template<int DX, int DY> __device__ __forceinline__ unsigned ao_march(float cons
 	for (int s = 7; s >= 0; --s) {att = (smp[s] > zr[s]) ? (unsigned)(8 - s) : att;}
 	return att;
 }
-// overlay: inside the tile the context IS the tile's own (possibly eroded) zvals (src/tiled_mesh.cpp:622): taken from `zvals` while staging, which spares a copy pass over the batch
-__global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz, int overlay) {
+// (Taking the tile's own zvals from `zvals` while staging, instead of the caller's copy pass into the context, was measured: the extra index work in the staging loop costs more
+// than the 170 us copy kernel saves -- 1.95 vs 1.87 ms for the row.)
+__global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
 	extern __shared__ __attribute__((aligned(16))) float s_ao_ctx[];
 	unsigned const nbands = (AO_TEX + AO_BAND - 1)/AO_BAND, t = blockIdx.x/nbands, band = blockIdx.x % nbands, tid = threadIdx.x;
 	unsigned const y0 = band*AO_BAND, rows = (AO_TEX - y0 < AO_BAND) ? AO_TEX - y0 : AO_BAND, ntex = rows*AO_TEX;
@@ -512,14 +513,7 @@ __global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals
 		unsigned const row0 = pass ? y0 + AO_RL : y0, nfl = (rows + AO_RL)*AO_CS;
 		__syncthreads();
 		float const *src = c + (size_t)row0*AO_CS;
-		if (!overlay) {for (unsigned i = tid; i < nfl; i += 256) {s_ao_ctx[i] = src[i];}}
-		else {
-			for (unsigned i = tid; i < nfl; i += 256) {
-				unsigned const r = row0 + i/AO_CS, cc = i % AO_CS; // context coordinates = tile cell + 36
-				bool const inside = (r - AO_RL) < 130u && (cc - AO_RL) < 130u;
-				s_ao_ctx[i] = inside ? z[(r - AO_RL)*130 + (cc - AO_RL)] : src[i];
-			}
-		}
+		for (unsigned i = tid; i < nfl; i += 256) {s_ao_ctx[i] = src[i];}
 		__syncthreads();
 #pragma unroll
 		for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
