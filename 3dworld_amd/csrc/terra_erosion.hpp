@@ -599,6 +599,7 @@ struct spec_buffers_t {
 	erosion_consts_t ec;
 	uint32_t num_iters;    // droplets of the whole run
 	uint32_t W;            // ring slots; droplet `it` lives in slot it % W, in-flight droplets are [base, base + W)
+	uint32_t near_count;   // the first near_count in-flight droplets (the next to commit) trace without a step budget; the others are sliced (0: all sliced)
 	uint32_t cap_log2;     // log capacity = 1 << cap_log2
 	uint32_t maxb;         // block-list capacity per droplet
 	uint32_t bshift;       // block edge = 1 << bshift cells (>= 3)
@@ -859,6 +860,9 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	if (!spec_slot_active(sb, slot, iter)) return;
 	uint32_t const ph = sb.phase[slot];
 	if (ph != SPEC_FRESH && ph != SPEC_RUNNING) return;
+	// the droplets next in line for the commit finish now (nothing behind them can be committed before they are); the ones further back advance a slice per
+	// round, so that a long path has made most of its way by the time it is the one everybody waits for
+	if (sb.near_count && iter - sb.ctl->base < sb.near_count) {budget = DROPLET_NO_BUDGET;}
 	window_mem_t<spec_back_t> mem;
 	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
 	mem.lead_mode = sb.ec.lead_mode;

@@ -176,7 +176,8 @@ int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
 /* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots; default automatic from the grid size, 0xFFFFFFFF restores that),
  * log2 of the per-droplet write-log capacity (>= 12),
  * per-droplet block-list capacity.  A droplet that overflows either runs alone, in order, directly on the grid (still exact).
- * slice_steps: while droplets wait for a slot a trace advances at most this many steps per round (default 1024).  Results never depend on any of these. */
+ * slice_steps: while droplets wait for a slot a trace advances at most this many steps per round (default 128), except the 512 droplets next in line for the
+ * commit, which trace to the end.  Results never depend on any of these. */
 int  terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t log_capacity_log2, uint32_t block_list_capacity);
 int  terra_set_erosion_slice_steps(terra_ctx *ctx, uint32_t slice_steps);
 
