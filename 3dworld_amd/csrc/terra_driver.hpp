@@ -768,6 +768,11 @@ template<class BE> struct terra_engine {
 		be.d2h(&hc, sb.ctl, sizeof(hc));
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;
+		report.critical_steps = hc.crit_steps; report.critical_shifts = hc.crit_shifts;
+		report.clk_wave = hc.clk_wave; report.clk_init = hc.clk_init; report.clk_shift = hc.clk_shift; report.clk_tail = hc.clk_tail; report.clk_critical = hc.clk_crit;
+		report.clk_shift_flush = hc.clk_sh_flush; report.clk_shift_prep = hc.clk_sh_prep; report.clk_shift_load = hc.clk_sh_load;
+		report.crit_clk_flush = hc.crit_own_flush; report.crit_clk_load = hc.crit_own_load; report.crit_clk_prep = hc.crit_own_prep;
+		report.crit_clk_shift = hc.crit_own_shift; report.crit_clk_edge = hc.crit_own_edge; report.crit_steps_own = hc.crit_own_steps;
 		if (!record_touched) return false;
 		uint32_t const ntouched = hc.touched;
 		if (ntouched > sb.touched_cap) return false; // record overflowed: the caller clamps the whole grid

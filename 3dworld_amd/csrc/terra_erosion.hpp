@@ -333,6 +333,7 @@ struct direct_mem_t {
 // divergence); TERRA_LANES splits the memory-heavy parts across lanes.  On the host (test emulator) a "wave" is one
 // call and TERRA_LANES is a plain loop in lane order, which visits brush cells in the reference's z-major order.
 #if defined(__HIP_DEVICE_COMPILE__)
+#define TERRA_CLOCK() ((unsigned long long)wall_clock64()) // 100 MHz constant-rate counter (diagnostics only)
 #define TERRA_LANES(l, n) for (int l = (int)(threadIdx.x & 63); l < (int)(n); l += 64)
 #define TERRA_EACH_LANE(l) for (int l = (int)(threadIdx.x & 63), l##_once = 1; l##_once; l##_once = 0)
 #define TERRA_LANE0 ((threadIdx.x & 63) == 0)
@@ -344,6 +345,7 @@ struct direct_mem_t {
 #define TERRA_ATOMIC_EXCH(p, v) atomicExch((p), (v))
 #define TERRA_ATOMIC_CAS(p, c, v) atomicCAS((p), (c), (v))
 #else
+#define TERRA_CLOCK() 0ull
 #define TERRA_LANES(l, n) for (int l = 0; l < (int)(n); ++l)
 #define TERRA_EACH_LANE(l) for (int l = 0; l < 64; ++l)
 #define TERRA_LANE0 true
@@ -451,6 +453,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	float *win, *win_alt; uint8_t *dirty, *dirty_alt; // LDS: EW*EW each, double-buffered so a window shift copies the overlap LDS -> LDS
 	int wx0, wz0, NX, NY; bool have;
 	int lead_x = 0, lead_z = 0; // where the droplet is heading (-1, 0, 1 per axis): a recentred window is placed ahead of it
+	unsigned long long clk_shift = 0, clk_sh_flush = 0, clk_sh_prep = 0, clk_sh_load = 0; // time inside recenter() and its parts (diagnostics)
 	int lead_mode = 2, steps_in_window = 0; // a window that lasted only a few steps means the droplet turned back (it circles in a pit): centre the next one instead
 	BACK back;
 	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; win_alt = w + EW*EW; dirty = d; dirty_alt = d + EW*EW; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
@@ -471,6 +474,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD void recenter(int cx, int cz) {
 		// the droplet sits a quarter of the window behind the centre, in the direction it came from: ~21 instead of ~13 steps until its brush box leaves again.
 		// Where the window lies never changes a result (it is a cache of the backing store), only how often it moves.
+		unsigned long long const clk0 = TERRA_CLOCK();
 		if (lead_mode == 1 || (lead_mode == 2 && (!have || steps_in_window >= 10))) {cx += lead_x*(EW/4); cz += lead_z*(EW/4);}
 		steps_in_window = 0;
 		int const nx0 = clampi(cx - EW/2, imax(NX - EW, 0)), nz0 = clampi(cz - EW/2, imax(NY - EW, 0));
@@ -484,7 +488,10 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 			back.note_written_rect(wx0, wz0);
 			TERRA_WAVE_SYNC();
 		}
+		unsigned long long const clk1 = TERRA_CLOCK();
 		back.prepare_window(nx0, nz0);
+		unsigned long long const clk2 = TERRA_CLOCK();
+		unsigned long long clk3 = clk2;
 		constexpr int PER_LANE = EW*EW/64;
 		TERRA_EACH_LANE(lane) {
 			float gv[PER_LANE];
@@ -494,6 +501,9 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
 				gv[k] = (!in_old && X < NX && Z < NY) ? back.base(X, Z) : 0.0f;
 			}
+#if defined(__HIP_DEVICE_COMPILE__)
+			{float acc = 0.0f; for (int k = 0; k < PER_LANE; ++k) {acc += gv[k];} asm volatile("" :: "v"(acc)); clk3 = TERRA_CLOCK();} // diagnostics: the plain loads have landed
+#endif
 #pragma unroll
 			for (int k = 0; k < PER_LANE; ++k) {
 				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
@@ -508,6 +518,8 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		uint8_t *td = dirty; dirty = dirty_alt; dirty_alt = td;
 		wx0 = nx0; wz0 = nz0; have = true;
 		TERRA_WAVE_SYNC();
+		unsigned long long const clk4 = TERRA_CLOCK();
+		clk_shift += clk4 - clk0; clk_sh_flush += clk1 - clk0; clk_sh_prep += clk2 - clk1; clk_sh_load += clk3 - clk2;
 	}
 	TERRA_HD bool begin_step(int xi, int zi) {
 		xi = sati(xi, NX); zi = sati(zi, NY);
@@ -588,9 +600,16 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t touched;      // cells recorded for the sparse clamp (may exceed the capacity)
 	uint32_t fb_steps, fb_nan; // fall-back droplet
 	uint32_t ndirty;       // entries of dirty_list
-	uint32_t pad_;
+	uint32_t round_max_steps, round_max_shifts; // most steps / window moves of one trace in this round (diagnostics)
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
 	unsigned long long n_shift, n_own, n_ver, n_store; // diagnostics summed over all traces
+	unsigned long long crit_steps, crit_shifts;         // round_max_* summed over the rounds
+	unsigned long long clk_wave, clk_init, clk_shift, clk_tail; // 10 ns ticks summed over all traces: whole wave body / before the first step / window moves / after the last step
+	unsigned long long clk_sh_flush, clk_sh_prep, clk_sh_load; // parts of clk_shift: write-back of leaving cells / block flags / plain grid loads (the rest: look-ups + LDS fill)
+	unsigned long long clk_crit, round_max_clk;          // longest wave body of a round, summed over the rounds
+	unsigned long long round_max_pack;                   // the round's longest wave body: its ticks << 44 | ticks in window moves << 24 | ticks before + after the steps << 10 | steps/4
+	unsigned long long crit_own_shift, crit_own_edge, crit_own_steps; // the packed fields summed over the rounds
+	unsigned long long round_max_pack2, crit_own_flush, crit_own_load, crit_own_prep; // same key: ticks << 44 | write-back << 28 | plain loads << 14 | block flags
 };
 struct spec_resume_t {uint32_t nblk, nlog, flags, bc[4], be[4], bwmask, far_last; int own_x0, own_z0, own_x1, own_z1; unsigned long long chk;}; // spec_back_t state of a suspended trace
 
@@ -860,6 +879,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	if (!spec_slot_active(sb, slot, iter)) return;
 	uint32_t const ph = sb.phase[slot];
 	if (ph != SPEC_FRESH && ph != SPEC_RUNNING) return;
+	unsigned long long const clk_a = TERRA_CLOCK();
 	// the droplets next in line for the commit finish now (nothing behind them can be committed before they are); the ones further back advance a slice per
 	// round, so that a long path has made most of its way by the time it is the one everybody waits for
 	if (sb.near_count && iter - sb.ctl->base < sb.near_count) {budget = DROPLET_NO_BUDGET;}
@@ -883,7 +903,9 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		d = sb.state[slot];
 		mem.back.init(&sb, slot, iter, ws.sh, &sb.resume[slot]);
 	}
+	unsigned long long const clk_b = TERRA_CLOCK();
 	if (!finished) {finished = droplet_run_fast(d, mem, sb.ec, budget);}
+	unsigned long long const clk_c = TERRA_CLOCK();
 	unsigned const steps_before = (ph == SPEC_FRESH) ? 0u : sb.state[slot].numMoves;
 	mem.finish(); // the window's dirty cells go to the log: a suspended trace keeps nothing in LDS
 	mem.back.flush_block_flags();
@@ -937,6 +959,18 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		}
 		if (ph == SPEC_FRESH) {TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u);}
 		TERRA_ATOMIC_ADD(&sb.ctl->traced_steps, (unsigned long long)(d.numMoves - steps_before));
+		TERRA_ATOMIC_MAX(&sb.ctl->round_max_steps, (uint32_t)(d.numMoves - steps_before));
+		TERRA_ATOMIC_MAX(&sb.ctl->round_max_shifts, ws.sh->n_shift);
+		unsigned long long const clk_d = TERRA_CLOCK();
+		TERRA_ATOMIC_ADD(&sb.ctl->clk_wave, clk_d - clk_a); TERRA_ATOMIC_ADD(&sb.ctl->clk_init, clk_b - clk_a);
+		TERRA_ATOMIC_ADD(&sb.ctl->clk_shift, mem.clk_shift); TERRA_ATOMIC_ADD(&sb.ctl->clk_tail, clk_d - clk_c);
+		TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_flush, mem.clk_sh_flush); TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_prep, mem.clk_sh_prep); TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_load, mem.clk_sh_load);
+		TERRA_ATOMIC_MAX(&sb.ctl->round_max_clk, clk_d - clk_a);
+		{
+			auto sat = [](unsigned long long v, unsigned bits) {unsigned long long const m = (1ull << bits) - 1; return (v < m) ? v : m;};
+			TERRA_ATOMIC_MAX(&sb.ctl->round_max_pack2, (sat(clk_d - clk_a, 20) << 44) | (sat(mem.clk_sh_flush, 16) << 28) | (sat(mem.clk_sh_load, 14) << 14) | sat(mem.clk_sh_prep, 14));
+			TERRA_ATOMIC_MAX(&sb.ctl->round_max_pack, (sat(clk_d - clk_a, 20) << 44) | (sat(mem.clk_shift, 20) << 24) | (sat((clk_b - clk_a) + (clk_d - clk_c), 14) << 10) | sat((d.numMoves - steps_before) >> 2, 10));
+		}
 		if (ws.sh->n_shift) {TERRA_ATOMIC_ADD(&sb.ctl->n_shift, (unsigned long long)ws.sh->n_shift);}
 		if (ws.sh->n_own)   {TERRA_ATOMIC_ADD(&sb.ctl->n_own,   (unsigned long long)ws.sh->n_own);}
 		if (ws.sh->n_ver)   {TERRA_ATOMIC_ADD(&sb.ctl->n_ver,   (unsigned long long)ws.sh->n_ver);}
@@ -1070,6 +1104,10 @@ TERRA_HD void spec_advance_body(spec_buffers_t const &sb) {
 	uint64_t const nb = (uint64_t)c.base + sb.W;
 	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;
 	c.stop_at = c.new_stop; c.new_stop = SPEC_NIL; c.unfinished = 0; c.ndirty = 0;
+	c.crit_steps += c.round_max_steps; c.crit_shifts += c.round_max_shifts; c.round_max_steps = 0; c.round_max_shifts = 0;
+	c.clk_crit += c.round_max_clk; c.round_max_clk = 0;
+	c.crit_own_shift += (c.round_max_pack >> 24) & 0xFFFFFu; c.crit_own_edge += (c.round_max_pack >> 10) & 0x3FFFu; c.crit_own_steps += (c.round_max_pack & 0x3FFu) << 2; c.round_max_pack = 0;
+	c.crit_own_flush += (c.round_max_pack2 >> 28) & 0xFFFFu; c.crit_own_load += (c.round_max_pack2 >> 14) & 0x3FFFu; c.crit_own_prep += c.round_max_pack2 & 0x3FFFu; c.round_max_pack2 = 0;
 }
 // after the fall-back droplet `base` ran directly on the grid: it is committed and every other in-flight trace starts over (the grid
 // changed under them without a version to compare against).  One thread per slot, then spec_fallback_advance_body.

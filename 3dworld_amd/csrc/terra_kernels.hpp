@@ -290,17 +290,37 @@ constexpr unsigned NG_ROWS = 16; // rows per block of k_noise_grid
 template<int MODE> __global__ __launch_bounds__(256) void k_noise_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, uint32_t *__restrict__ mm,
 	uint32_t const *__restrict__ lut, noise_oct_t oc)
 {
+	// Perlin sums on a regular grid: every sample position is a grid position, so the lattice cells a block touches are known up front and their four gradients
+	// can be gathered once per block (noise_blocktab_build).  Measured on MI355X at 16384^2, 8 octaves: Perlin 80.3 -> 87.4 Gcells/s.  The same for simplex
+	// LOSES (68.3 -> 61.0): its three-corner look-up saves less than building the records of the skewed lattice's bounding box costs; the warped sums of the
+	// domain warp have no regular footprint at all.  Both keep the per-cell table path.
+	constexpr bool REGULAR = (MODE == MGEN_PERLIN);
 	__shared__ __attribute__((aligned(16))) uint32_t s_lut[noise_lut_dwords<MODE>()];
+	__shared__ float s_brec[REGULAR ? NOISE_BT_FLOATS : 1];
+	__shared__ noise_bt_meta_t s_bmeta[NUM_FREQ_COMP];
 	noise_tab_t const ns = noise_stage_lut<MODE>(lut, s_lut);
 	// two neighbouring cells of a row per lane: the lattice noise runs on register pairs (v_pk_mul_f32 / v_pk_add_f32), see terra_noise.hpp.
 	// A block walks NG_ROWS rows, 4 at a time (one per wave), so the table staging is paid once per NG_ROWS x 128 cells.
 	unsigned const x = (blockIdx.x*64 + (threadIdx.x & 63))*2;
+	bool bt_ok = false; // block-uniform
+	if (REGULAR) { // the gradient terms of every lattice cell under this block's 128 x NG_ROWS cells, per octave (noise_blocktab_build): the cells then skip the hash chains
+		float const xy_scale = 0.0007f*nc.mesh_scale;
+		if (job.mdx >= 0.0f && job.mdy >= 0.0f && nc.DX_VAL_INV >= 0.0f && nc.DY_VAL_INV >= 0.0f && xy_scale >= 0.0f) { // positions do not decrease along x and y: the block's corners bound them
+			unsigned const bx0 = blockIdx.x*128, by0 = blockIdx.y*NG_ROWS + job.row0;
+			float const vx0 = xy_scale*(((float)bx0*job.mdx + job.mx0)*nc.DX_VAL_INV), vx1 = xy_scale*(((float)(bx0 + 127)*job.mdx + job.mx0)*nc.DX_VAL_INV);
+			float const vy0 = xy_scale*(((float)by0*job.mdy + job.my0)*nc.DY_VAL_INV), vy1 = xy_scale*(((float)(by0 + NG_ROWS - 1)*job.mdy + job.my0)*nc.DY_VAL_INV);
+			bt_ok = noise_blocktab_build<(MODE != MGEN_PERLIN)>(vx0, vy0, vx1, vy1, oc, (char const *)s_lut, s_brec, s_bmeta, threadIdx.x, 256);
+		}
+	}
+	noise_btab_t const bt{s_brec, s_bmeta};
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu;
 	for (unsigned ry = 0; ry < NG_ROWS; ry += 4) {
 		unsigned const y = blockIdx.y*NG_ROWS + ry + (threadIdx.x >> 6);
 		if (x < job.nx && y < job.ny) {
 			float const xv0 = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, xv1 = ((float)(x + 1)*job.mdx + job.mx0)*nc.DX_VAL_INV, yval = ((float)(y + job.row0)*job.mdy + job.my0)*nc.DY_VAL_INV;
-			nv2 const zz = noise_zval_tab<MODE>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, oc, ns);
+			nv2 zz;
+			if constexpr (REGULAR) {zz = bt_ok ? noise_zval_bt<MODE>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, oc, bt) : noise_zval_tab<MODE>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, oc, ns);}
+			else {zz = noise_zval_tab<MODE>(nv2{xv0, xv1}, nv2{yval, yval}, job.shape, nc, oc, ns);}
 			float const z0 = finish_cell(zz[0], job, nc, L, smx, smy, x, y);
 			out[(size_t)y*job.nx + x] = z0;
 			minmax_acc(z0, mm_lo, mm_hi);

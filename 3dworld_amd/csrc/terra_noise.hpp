@@ -468,6 +468,139 @@ template<bool SIMPLEX> TERRA_HD nv2 fbm2_tab(nv2 xv, nv2 yv, int shape, noise_oc
 	}
 	return zval;
 }
+// ---- block tables for REGULAR fBm sums.  When the sample positions of a block of cells are a grid (every fBm sum except the domain-warped ones), the lattice cells it touches in
+// octave i form a small rectangle [cxmin, cxmax] x [cymin, cymax] of (skewed, for simplex) lattice coordinates: the floating-point expressions that lead from a cell index to its
+// lattice coordinate are monotone in x and in y (positive steps and scales, rounding is monotone), so the rectangle's corners are the lattice cells of the block's first and last cell.
+// The block then builds, once per sum, one record per lattice cell and octave with the gradient terms of its four lattice points -- fetched through the very look-up chain of
+// simplex2_lut / perlin2_lut, so the same bits -- and a cell only converts its lattice coordinate into a record index: no mod 289, no permute tables, no per-point index sums.
+// Record: simplex 12 floats {A(a0,h,n), B1 = (1,0), B2 = (0,1), C}; Perlin 8 floats {g00(gxn,gyn), g10, g01, g11}.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TERRA_BLOCK_SYNC() __syncthreads()
+#else
+#define TERRA_BLOCK_SYNC() do {} while (0)
+#endif
+constexpr unsigned NOISE_BT_FLOATS = 6144; // 24 KB of records per block
+struct noise_bt_meta_t {int cxmin, cymin, nxl, off;}; // per octave: lattice origin, cells per record row, first float of the octave's records
+struct noise_btab_t {float const *rec; noise_bt_meta_t const *meta;};
+// lattice coordinate of a sample position in octave i (the expressions of simplex2_lut / perlin2_lut)
+template<bool SIMPLEX> TERRA_HD void noise_lattice_of(float vx, float vy, noise_oct_t const &oc, unsigned i, float &cx, float &cy) {
+	float const qx = oc.freq[i]*vx + oc.rx[i], qy = oc.freq[i]*vy + oc.ry[i];
+	if (SIMPLEX) {float const C1 = 0.366025403784439f, skew = qx*C1 + qy*C1; cx = floorf(qx + skew); cy = floorf(qy + skew);}
+	else {cx = floorf(qx); cy = floorf(qy);}
+}
+// (vx0, vy0) / (vx1, vy1): sample positions of the block's first / last cell (the caller guarantees the monotone mapping).  Called by every thread of the block;
+// returns false (for all of them alike) when the records do not fit or a lattice coordinate is not a small integer: the caller then uses the per-cell tables.
+template<bool SIMPLEX> TERRA_HD bool noise_bt_octave(float vx0, float vy0, float vx1, float vy1, noise_oct_t const &oc, unsigned i, unsigned &total, noise_bt_meta_t &m) {
+	constexpr int RF = SIMPLEX ? 12 : 8;
+	float ax, ay, bx, by;
+	noise_lattice_of<SIMPLEX>(vx0, vy0, oc, i, ax, ay); noise_lattice_of<SIMPLEX>(vx1, vy1, oc, i, bx, by);
+	if (!(fabsf(ax) < 4194304.0f && fabsf(ay) < 4194304.0f && fabsf(bx) < 4194304.0f && fabsf(by) < 4194304.0f && ax <= bx && ay <= by)) return false;
+	int const nxl = (int)(bx - ax) + 1, nyl = (int)(by - ay) + 1;
+	if (nxl > 4096 || nyl > 4096) return false;
+	m.cxmin = (int)ax; m.cymin = (int)ay; m.nxl = nxl; m.off = (int)total;
+	total += (unsigned)(nxl*nyl*RF);
+	return total <= NOISE_BT_FLOATS;
+}
+template<bool SIMPLEX> TERRA_HD bool noise_blocktab_build(float vx0, float vy0, float vx1, float vy1, noise_oct_t const &oc, char const *lut, float *rec, noise_bt_meta_t *meta, unsigned tid, unsigned nthreads) {
+	constexpr int RF = SIMPLEX ? 12 : 8;
+	unsigned total = 0;
+	noise_bt_meta_t m;
+	for (unsigned i = 0; i < oc.end_octave; ++i) {if (!noise_bt_octave<SIMPLEX>(vx0, vy0, vx1, vy1, oc, i, total, m)) return false;} // the same answer in every thread
+	TERRA_BLOCK_SYNC(); // the previous sum's records and metadata are no longer read
+	if (tid == 0) {unsigned t2 = 0; for (unsigned i = 0; i < oc.end_octave; ++i) {noise_bt_octave<SIMPLEX>(vx0, vy0, vx1, vy1, oc, i, t2, m); meta[i] = m;}}
+	TERRA_BLOCK_SYNC();
+	unsigned const ncorner = SIMPLEX ? total/3u : total/2u; // one entry per (cell, lattice point): 3 floats (simplex) / 2 floats (Perlin)
+	for (unsigned e = tid; e < ncorner; e += nthreads) {
+		unsigned const f = e*(SIMPLEX ? 3u : 2u); // first float of the entry
+		unsigned i = 0;
+		while (i + 1 < oc.end_octave && (unsigned)meta[i + 1].off <= f) {++i;}
+		noise_bt_meta_t const mi = meta[i];
+		unsigned const rel = f - (unsigned)mi.off, cell = rel/(unsigned)RF, k = (rel % (unsigned)RF)/(SIMPLEX ? 3u : 2u);
+		int const lx = (int)(cell % (unsigned)mi.nxl), ly = (int)(cell/(unsigned)mi.nxl);
+		float const X = (float)(mi.cxmin + lx), Y = (float)(mi.cymin + ly);
+		if (SIMPLEX) { // the look-ups of simplex2_lut for cx = X, cy = Y
+			int const mx4 = (int)(gl_mod289_small(X)*4.0f), ry16 = (int)(gl_mod289_raw(Y)*16.0f);
+			nt_i4 const si = *(nt_i4 const *)(lut + ry16);
+			char const *g = lut + mx4;
+			char const *p = (k == 0) ? g + si.x : ((k == 1) ? g + si.y : ((k == 2) ? g + si.z : g + si.z + 4));
+			rec[f] = nt_ldf(p); rec[f + 1] = nt_ldf(p + NOISE_LUT_S_N*4); rec[f + 2] = nt_ldf(p + 2*NOISE_LUT_S_N*4);
+		}
+		else { // the look-ups of perlin2_lut for flx = X, fly = Y: k = 0..3 = (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+			int const rx4 = (int)(gl_mod289_raw(X)*4.0f), iy0 = (int)gl_mod289_small(Y);
+			int iy1 = iy0 + 1; iy1 = (iy1 == 289) ? 0 : iy1;
+			int const *pip = (int const *)(lut + rx4);
+			char const *p = lut + (((k >> 1) ? iy1 : iy0) << 2) + ((k & 1u) ? pip[1] : pip[0]);
+			rec[f] = nt_ldf(p); rec[f + 1] = nt_ldf(p + NOISE_LUT_P_N*4);
+		}
+	}
+	TERRA_BLOCK_SYNC();
+	return true;
+}
+// glm::simplex(vec2) for two cells of a regular sum, octave i, gradient terms from the block's records
+TERRA_HD nv2 simplex2_bt(nv2 vx, nv2 vy, noise_bt_meta_t const &m, float const *rec) {
+	float const C0 = 0.211324865405187f, C1 = 0.366025403784439f, C2 = -0.577350269189626f;
+	nv2 const one = nt_bc<nv2>(1.0f), zero = nt_bc<nv2>(0.0f);
+	nv2 const skew = vx*C1 + vy*C1;
+	nv2 const cx = nt_floor(vx + skew), cy = nt_floor(vy + skew);
+	nv2 const unskew = cx*C0 + cy*C0;
+	nv2 const ax = vx - cx + unskew, ay = vy - cy + unskew;
+	ni2 const lower = (ax > ay);
+	nv2 const ox = nt_sel(lower, one, zero), oy = one - ox;
+	nv2 const bx = (ax + C0) - ox, by = (ay + C0) - oy;
+	nv2 const ex = ax + C2, ey = ay + C2;
+	nv2 ma = nt_max0(0.5f - (ax*ax + ay*ay));
+	nv2 mb = nt_max0(0.5f - (bx*bx + by*by));
+	nv2 mc = nt_max0(0.5f - (ex*ex + ey*ey));
+	ma = ma*ma; mb = mb*mb; mc = mc*mc;
+	ma = ma*ma; mb = mb*mb; mc = mc*mc;
+	float const *r[2]; int bo[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int const lx = (int)cx[e] - m.cxmin, ly = (int)cy[e] - m.cymin;
+		r[e] = rec + m.off + (ly*m.nxl + lx)*12;
+		bo[e] = lower[e] ? 3 : 6;
+	}
+	nv2 const a0a = {r[0][0], r[1][0]}, ha = {r[0][1], r[1][1]}, na = {r[0][2], r[1][2]};
+	nv2 const a0b = {r[0][bo[0]], r[1][bo[1]]}, hb = {r[0][bo[0] + 1], r[1][bo[1] + 1]}, nb = {r[0][bo[0] + 2], r[1][bo[1] + 2]};
+	nv2 const a0c = {r[0][9], r[1][9]}, hc = {r[0][10], r[1][10]}, ncc = {r[0][11], r[1][11]};
+	ma *= na; mb *= nb; mc *= ncc;
+	nv2 const da = a0a*ax + ha*ay;
+	nv2 const db = a0b*bx + hb*by;
+	nv2 const dc = a0c*ex + hc*ey;
+	return 130.0f*(ma*da + mb*db + mc*dc);
+}
+TERRA_HD nv2 perlin2_bt(nv2 px, nv2 py, noise_bt_meta_t const &m, float const *rec) {
+	nv2 const flx = nt_floor(px), fly = nt_floor(py);
+	nv2 const frx = px - flx, fry = py - fly;
+	nv2 const fx0 = frx - 0.0f, fy0 = fry - 0.0f, fx1 = frx - 1.0f, fy1 = fry - 1.0f;
+	float const *r[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int const lx = (int)flx[e] - m.cxmin, ly = (int)fly[e] - m.cymin;
+		r[e] = rec + m.off + (ly*m.nxl + lx)*8;
+	}
+	nv2 const gx00 = {r[0][0], r[1][0]}, gy00 = {r[0][1], r[1][1]}, gx10 = {r[0][2], r[1][2]}, gy10 = {r[0][3], r[1][3]};
+	nv2 const gx01 = {r[0][4], r[1][4]}, gy01 = {r[0][5], r[1][5]}, gx11 = {r[0][6], r[1][6]}, gy11 = {r[0][7], r[1][7]};
+	nv2 const d00 = gx00*fx0 + gy00*fy0;
+	nv2 const d10 = gx10*fx1 + gy10*fy0;
+	nv2 const d01 = gx01*fx0 + gy01*fy1;
+	nv2 const d11 = gx11*fx1 + gy11*fy1;
+	nv2 const ux = gl_fade(fx0), uy = gl_fade(fy0);
+	nv2 const lo = gl_mix(d00, d10, ux), hi = gl_mix(d01, d11, ux);
+	return 2.3f*gl_mix(lo, hi, uy);
+}
+// the fBm sum of two cells inside the block the records were built for
+template<bool SIMPLEX> TERRA_HD nv2 fbm2_bt(nv2 xv, nv2 yv, int shape, noise_oct_t const &oc, noise_btab_t const &bt) {
+	nv2 zval = nt_bc<nv2>(0.0f);
+	for (unsigned i = 0; i < oc.end_octave; ++i) {
+		nv2 const qx = oc.freq[i]*xv + oc.rx[i], qy = oc.freq[i]*yv + oc.ry[i];
+		nv2 n = SIMPLEX ? simplex2_bt(qx, qy, bt.meta[i], bt.rec) : perlin2_bt(qx, qy, bt.meta[i], bt.rec);
+		if (shape != 0) {n = nt_octave_shape(n, shape);}
+		zval += oc.mag[i]*n;
+	}
+	return zval;
+}
+
 template<int MODE> TERRA_HD nv2 noise_zval_tab(nv2 xval, nv2 yval, int shape, noise_consts_t const &nc, noise_oct_t const &oc, noise_tab_t const &ns) {
 	constexpr bool SIMPLEX = (MODE != MGEN_PERLIN);
 	float const xy_scale = 0.0007f*nc.mesh_scale; // MESH_SCALE_FACTOR
@@ -482,6 +615,15 @@ template<int MODE> TERRA_HD nv2 noise_zval_tab(nv2 xval, nv2 yval, int shape, no
 		xv += scale*dx2; yv += scale*dy2;
 	}
 	nv2 z = fbm2_tab<SIMPLEX>(xv, yv, shape, oc, ns);
+	z = nt_postproc(z, nc.hp);
+	return z*hmap_scale(MODE, nc);
+}
+
+// the same for a cell pair inside a block whose records are built (simplex / Perlin sums only: the warped sums of the domain warp have no regular lattice footprint)
+template<int MODE> TERRA_HD nv2 noise_zval_bt(nv2 xval, nv2 yval, int shape, noise_consts_t const &nc, noise_oct_t const &oc, noise_btab_t const &bt) {
+	static_assert(MODE != MGEN_DWARP_GPU, "regular sums only");
+	float const xy_scale = 0.0007f*nc.mesh_scale;
+	nv2 z = fbm2_bt<(MODE != MGEN_PERLIN)>(xy_scale*xval, xy_scale*yval, shape, oc, bt);
 	z = nt_postproc(z, nc.hp);
 	return z*hmap_scale(MODE, nc);
 }

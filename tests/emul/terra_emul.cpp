@@ -162,6 +162,51 @@ extern "C" unsigned long long terra_emul_noise_lut_mismatches(unsigned n, uint32
 	return bad;
 }
 
+// the block records of the regular fBm sums (noise_blocktab_build / fbm2_bt) against the direct evaluation: a "block" = a rows x cols patch of a regular grid with
+// random origin, cell spacing and octave count; every cell of the patch must give the bits of fbm2_t.  Also counts how often the records did not fit (the caller's fall-back).
+extern "C" unsigned long long terra_emul_noise_blocktab_mismatches(unsigned nblocks, uint32_t seed, unsigned *fallbacks) {
+	unsigned long long bad = 0;
+	std::vector<uint32_t> tab(terra::NOISE_LUT_DWORDS + 4);
+	uint32_t *t = (uint32_t *)(((uintptr_t)tab.data() + 15) & ~(uintptr_t)15);
+	for (unsigned i = 0; i < terra::NOISE_LUT_DWORDS; ++i) {t[i] = terra::noise_lut_fill(i);}
+	char const *stab = (char const *)t, *ptab = (char const *)(t + terra::NOISE_LUT_S_DWORDS);
+	std::vector<float> rec(terra::NOISE_BT_FLOATS);
+	terra::noise_bt_meta_t meta[terra::NUM_FREQ_COMP];
+	auto rnd = [&]() {seed = seed*1664525u + 1013904223u; return seed;};
+	auto rf = [&](float lo, float hi) {return lo + (hi - lo)*(float)(rnd() >> 8)*(1.0f/16777216.0f);};
+	auto same = [&](float a, float b) {return memcmp(&a, &b, 4) == 0 || (a != a && b != b);};
+	unsigned nfall = 0;
+	for (unsigned b = 0; b < nblocks; ++b) {
+		terra::noise_consts_t nc{};
+		nc.mesh_scale = 1.0f; nc.start_eval_sin = 10*(int)(rnd() % 4); nc.rx = rf(1.0f, 2.0f); nc.ry = rf(1.0f, 2.0f);
+		terra::noise_oct_t const oc = terra::make_noise_oct(nc);
+		unsigned const cols = 128, rows = 16;
+		float const step = (b % 5 == 4) ? rf(0.0005f, 0.01f) : 0.0007f*rf(0.5f, 2.0f); // noise-space distance between cells (mesh_scale 0.5 .. 2; sometimes far coarser: the records may not fit)
+		float const ox = (b % 7 == 6) ? (float)((int)(rnd() % 41) - 20)*289.0f/oc.freq[oc.end_octave - 1] : rf(-3000.0f, 3000.0f)*step, oy = rf(-3000.0f, 3000.0f)*step; // some origins next to a mod-289 wrap column
+		auto vx = [&](unsigned x) {return ox + (float)x*step;};
+		auto vy = [&](unsigned y) {return oy + (float)y*step;};
+		int const shape = (int)(b % 3);
+		for (int simplex = 0; simplex < 2; ++simplex) {
+			bool const ok = simplex ? terra::noise_blocktab_build<true>(vx(0), vy(0), vx(cols - 1), vy(rows - 1), oc, stab, rec.data(), meta, 0, 1)
+			                        : terra::noise_blocktab_build<false>(vx(0), vy(0), vx(cols - 1), vy(rows - 1), oc, ptab, rec.data(), meta, 0, 1);
+			if (!ok) {++nfall; continue;}
+			terra::noise_btab_t const bt{rec.data(), meta};
+			for (unsigned y = 0; y < rows; ++y) {
+				for (unsigned x = 0; x < cols; x += 2) {
+					terra::nv2 const xs = {vx(x), vx(x + 1)}, ys = {vy(y), vy(y)};
+					terra::nv2 const a = simplex ? terra::fbm2_bt<true>(xs, ys, shape, oc, bt) : terra::fbm2_bt<false>(xs, ys, shape, oc, bt);
+					for (int e = 0; e < 2; ++e) {
+						float const d = simplex ? terra::fbm2<true>(xs[e], ys[e], shape, oc.end_octave, nc.rx, nc.ry) : terra::fbm2<false>(xs[e], ys[e], shape, oc.end_octave, nc.rx, nc.ry);
+						if (!same(a[e], d)) ++bad;
+					}
+				}
+			}
+		}
+	}
+	if (fallbacks) *fallbacks = nfall;
+	return bad;
+}
+
 // the two-cells-per-lane instantiation of the 2-D lattice noise against the one-cell instantiation (must be bit-identical)
 extern "C" unsigned long long terra_emul_noise_x2_mismatches(unsigned n, uint32_t seed) {
 	unsigned long long bad = 0;

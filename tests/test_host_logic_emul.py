@@ -48,6 +48,18 @@ def test_lattice_table_noise_equals_direct_evaluation(emul_lib):
     assert lib.terra_emul_noise_lut_mismatches(400000, 11) == 0
 
 
+def test_block_records_of_regular_fbm_sums_equal_direct_evaluation(emul_lib):
+    """regular fBm sums read their gradient terms from per-block records (one per lattice cell and octave, terra_noise.hpp: noise_blocktab_build / fbm2_bt):
+    every cell of random 128 x 16 patches (random origin incl. the mod-289 wrap columns, spacing, octave count, shape) gives the bits of the direct sum"""
+    import ctypes
+    lib = ctypes.CDLL(emul_lib)
+    lib.terra_emul_noise_blocktab_mismatches.restype = ctypes.c_ulonglong
+    lib.terra_emul_noise_blocktab_mismatches.argtypes = [ctypes.c_uint, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint)]
+    fb = ctypes.c_uint(0)
+    assert lib.terra_emul_noise_blocktab_mismatches(400, 5, ctypes.byref(fb)) == 0
+    assert fb.value < 400  # most patches fit the records; the coarse ones exercise the fall-back decision
+
+
 def test_powf_restatement_matches_libm(emul_lib):
     """glaciate's pow(relh, custom_glaciate_exp) is libm powf in the reference; 3dworld_amd/csrc/terra_powf.hpp restates glibc's algorithm so the
     device gets the same bits (ocml powf does not).  4*10^6 arguments here, 5*10^7 when the header was written."""

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""scheduler statistics of the dense whole-map erosion on the HOST emulator (tests/emul): rounds, re-traces and the serial chain (critical_steps) for a
+(ring, slice, near) setting -- the quantities the GPU time is made of (time ~ rounds*overhead + critical_steps*step latency), without spending GPU minutes.
+usage: ero_emul_model.py N D W:slice:near[,W:slice:near...]"""
+import importlib, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3dworld_amd")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+combos = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[3] if len(sys.argv) > 3 else "2048:128:512").split(",")]
+src = os.path.join(ROOT, "tests", "emul", "terra_emul.cpp"); out = os.path.join(ROOT, "tests", "emul", "libterra_emul.so")
+csrc = os.path.join(ROOT, "3dworld_amd", "csrc")
+deps = [src, os.path.join(ROOT, "include", "terra.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src, "-lz"], check=True)
+t = pkg.Terra(0, out)
+st = t.init_scene(pkg.make_config(mesh_gen_mode=0))
+z = t.alloc(N * N * 4)
+mn, mx = t.gen_grid_minmax_dev(z.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+for (w, sl, near) in combos:
+    os.environ["TERRA_ERO_NEAR"] = str(near)
+    t.set_erosion_tuning(window=w if w else 0xFFFFFFFF)
+    t.set_erosion_slice_steps(sl)
+    t.gen_grid_dev(z.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+    t0 = time.perf_counter()
+    t.apply_erosion_dev(z.ptr, N, N, mn, D, pkg.ERODE_MINZ_IS_MIN)
+    dt = time.perf_counter() - t0
+    r = t.erosion_report().as_dict()
+    print(f"W {w} slice {sl} near {near}: rounds {r['rounds']} traces {r['traces']} steps {r['steps']} traced {r['traced_steps']} critical_steps {r['critical_steps']} critical_shifts {r['critical_shifts']} "
+          f"shifts {r['window_shifts']} version_lookups {r['version_lookups']} fallbacks {r['serial_fallbacks']} (host {dt:.1f}s)", flush=True)

@@ -52,3 +52,24 @@ for name, dep in (("cell", dep_cell), ("8x8 block", dep_blk)):
             level[j] = level[dep[j]] + 1   # only the LATEST conflicting writer: a lower bound of the true depth, exact for chains through last writers
     dist = (np.arange(D) - dep)[dep >= 0]
     print(f"{name}: DAG depth (through latest writers) {level.max()}, distance to the latest conflicting lower droplet: median {np.median(dist):.0f}, 10% {np.percentile(dist, 10):.0f}, within 2048: {(dist < 2048).mean() * 100:.1f}%, within 16384: {(dist < 16384).mean() * 100:.1f}%")
+
+# ---- the same through ALL conflicting lower writers (a droplet waits for every one of them), and weighted with the droplets' lengths: the serial chain
+# in droplet STEPS that an exact scheduler which re-runs a droplet from its spawn once its inputs are final cannot go below
+steps = np.zeros(D, np.int64)
+for name, shift in (("cell", 0), ("8x8 block", 3)):
+    nbb = (NX >> shift) + 1
+    lvl = np.zeros(nbb * nbb, np.int64); tw = np.zeros(nbb * nbb, np.int64)
+    depth = 0; chain = 0
+    for j in range(D):
+        a = cells[off[j]:off[j + 1]]
+        if len(a) == 0:
+            continue
+        c = (a >> 1).astype(np.int64); w = (a & 1).astype(bool)
+        steps[j] = max(1, (len(a) - int(w.sum())) // 4)
+        u = np.unique((c // NX >> shift) * nbb + (c % NX >> shift))
+        lj = lvl[u].max() + 1; tj = tw[u].max() + steps[j]
+        if w.any():
+            wu = np.unique((c[w] // NX >> shift) * nbb + (c[w] % NX >> shift))
+            lvl[wu] = np.maximum(lvl[wu], lj); tw[wu] = np.maximum(tw[wu], tj)   # a later reader waits for every writer so far, not only the last
+        depth = max(depth, lj); chain = max(chain, tj)
+    print(f"{name}: depth through all lower writers {depth}; longest dependency chain weighted with droplet lengths: {chain} steps (total steps {steps.sum()}, longest droplet {steps.max()})")
