@@ -231,7 +231,7 @@ int terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t cap_log2,
 	TERRA_CHECK_CTX
 	if ((cap_log2 && (cap_log2 < 12 || cap_log2 > 20)) || (maxb && (maxb < 8 || maxb > 65536)) || (window > (1u << 20) && window != 0xFFFFFFFFu)) return terra::fail(TERRA_ERR_ARG, "terra_set_erosion_tuning: value out of range");
 	if (window) ctx->eng.spec_cfg.window = (window == 0xFFFFFFFFu) ? 0 : window; // 0xFFFFFFFF: back to the automatic choice
-	if (cap_log2) ctx->eng.spec_cfg.cap_log2 = cap_log2;
+	(void)cap_log2; // versions are stored as one 64-float page per footprint block since round 2: there is no hashed log to size any more (accepted for compatibility)
 	if (maxb) ctx->eng.spec_cfg.maxb = maxb;
 	return TERRA_OK;
 }

@@ -257,7 +257,6 @@ template<class BE> struct terra_engine {
 	uint8_t const *hmap_pix = nullptr; int hmap_w = 0, hmap_h = 0, hmap_nc = 0; // terrain_hmap_manager's image (device memory, owned by the caller)
 	float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;                          // src/mesh_gen.cpp:41, set by set_mesh_height_scales_for_zval_range
 	uint32_t *spec_blocks_clean = nullptr; size_t spec_blocks_n = 0; // s_spec_blocks is known to be all-NIL for this pointer / block count
-	uint8_t *spec_logs_base = nullptr; uint32_t spec_logs_w = 0, spec_logs_cap = 0; // the log tables in s_spec satisfy their invariant for this layout
 	template<class T> T *scratch(scratch_t &s, size_t count) {
 		size_t const bytes = std::max<size_t>(count*sizeof(T), 256);
 		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
@@ -615,7 +614,7 @@ template<class BE> struct terra_engine {
 	static constexpr uint32_t MAX_EROSION_ITERS = 27182812u;
 	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27182812 droplets (the reference's int seed 79*iter+121 overflows)");}
 
-	struct spec_cfg_t {uint32_t window = 0 /* auto */, cap_log2 = 12, maxb = 256, bshift = 3, slice_steps = 128, max_rounds = 4000000, near_count = 512;} spec_cfg;
+	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 128, max_rounds = 4000000, near_count = 512;} spec_cfg;
 
 	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
 		require_scene();
@@ -667,22 +666,20 @@ template<class BE> struct terra_engine {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
 		// ring slots: more droplets in flight = more parallel work but also more speculation on stale cells; measured best (MI355X, 10^5..10^6 droplets
-		// on 4096^2..16384^2) near one slot per 16K cells.  64 KiB of log per slot and buffer: 16384 slots = 2 GiB of the 288.
+		// on 4096^2..16384^2) near one slot per 16K cells.  256 pages of 64 floats per slot and buffer: 16384 slots = 2 GiB of the 288.
 		uint32_t const auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)ec.NX*ec.NY) >> 14, 2048), 16384);
 		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
-		sb.W = W; sb.cap_log2 = spec_cfg.cap_log2;
-		sb.maxb = spec_cfg.maxb; sb.bshift = std::max<uint32_t>(spec_cfg.bshift, 3);
+		sb.W = W;
+		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block
 		if (char const *nc = getenv("TERRA_ERO_NEAR")) {int const v = atoi(nc); sb.near_count = (v >= 0) ? (uint32_t)v : W/(uint32_t)(-v);} // experiment knob (negative: a fraction of the ring); results never depend on it
-		if (((size_t)1 << sb.cap_log2) < (size_t)4*EW*EW) throw std::logic_error("speculative erosion: log capacity too small for the window");
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
-		size_t const cap = (size_t)1 << sb.cap_log2, nblocks = (size_t)sb.nbx*sb.nby;
+		size_t const nblocks = (size_t)sb.nbx*sb.nby;
 		// carve one allocation
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
-		size_t o_keys[2], o_vals[2], o_used[2], o_lc[2], o_bl[2], o_bc[2], o_chk[2];
-		for (int b = 0; b < 2; ++b) {o_keys[b] = carve(W*cap*4); o_used[b] = carve(W*cap*4); o_lc[b] = carve(W*4);} // first, at offsets that depend on (W, cap) only: they carry state from run to run
-		for (int b = 0; b < 2; ++b) {o_vals[b] = carve(W*cap*4); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
+		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_chk[2];
+		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
 		size_t const o_slot = carve((size_t)W*4*9); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps
 		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
 		size_t const o_next = carve((size_t)W*sb.maxb*4), o_nodeblk = carve((size_t)W*sb.maxb*4), o_dlist = carve((size_t)W*sb.maxb*8), o_ctl = carve(sizeof(spec_ctl_t));
@@ -690,8 +687,7 @@ template<class BE> struct terra_engine {
 		size_t const o_touched = carve((size_t)touched_cap*4 + 4);
 		uint8_t *base = scratch<uint8_t>(s_spec, off);
 		for (int b = 0; b < 2; ++b) {
-			sb.log_keys[b] = (uint32_t *)(base + o_keys[b]); sb.log_vals[b] = (float *)(base + o_vals[b]);
-			sb.log_used[b] = (uint32_t *)(base + o_used[b]); sb.log_cnt[b] = (uint32_t *)(base + o_lc[b]);
+			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]); // nothing to initialise: only entries below a version's count are ever read
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]); sb.chk[b] = (uint64_t *)(base + o_chk[b]);
 		}
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
@@ -706,13 +702,6 @@ template<class BE> struct terra_engine {
 		sb.head = blk_arrays; sb.dirty_min = blk_arrays + nblocks;
 		if (spec_blocks_clean != blk_arrays || spec_blocks_n != nblocks) {be.fill32(blk_arrays, SPEC_NIL, 2*nblocks);}
 		spec_blocks_clean = nullptr; // not clean again until this run has taken its lists apart
-		// log tables: empty except at the positions listed in log_used[0 .. log_cnt) -- an invariant every kernel keeps, so only a fresh (or
-		// re-shaped) allocation pays the O(slots x capacity) initialisation
-		if (spec_logs_base != base || spec_logs_w != W || spec_logs_cap != sb.cap_log2) {
-			for (int b = 0; b < 2; ++b) {be.fill32(sb.log_keys[b], SPEC_EMPTY, (size_t)W*cap); be.fill32(sb.log_cnt[b], 0, W);}
-		}
-		spec_logs_base = nullptr;
-
 		spec_buffers_t const s = sb;
 		be.fill32(slot_arrays, 0, (size_t)W*9);
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
@@ -764,7 +753,6 @@ template<class BE> struct terra_engine {
 		}
 		be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);}); // leave head[] all-NIL (dirty_min[] already is)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
-		spec_logs_base = base; spec_logs_w = W; spec_logs_cap = sb.cap_log2;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;

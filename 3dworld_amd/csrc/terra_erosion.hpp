@@ -364,6 +364,15 @@ template<class T> inline T terra_host_atomic_cas(T *p, T c, T v) {T o = *p; if (
 #define TERRA_ATOMIC_CAS(p, c, v) terra_host_atomic_cas((p), (c), (v))
 #endif
 
+// L2 load: read through to L2.  A trace's OWN pages are written by the other lanes of its wave (plain stores) in the same kernel; the CU's vector L1 may
+// still hold the line from an earlier read, so those reads must not hit L1.  Other droplets' versions were written by earlier kernels (the boundary makes
+// them visible) and use plain cached loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TERRA_L2_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define TERRA_L2_LOAD(p) (*(p))
+#endif
+
 // lane-parallel deposit / brush on a cell store addressed through DERIVED::cell(X,Z) (an LDS pointer), + DERIVED::mark(X,Z)
 template<class DERIVED> struct wave_cell_ops {
 	TERRA_HD DERIVED &self() {return *static_cast<DERIVED *>(this);}
@@ -439,14 +448,22 @@ struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
 
 // ---- big grids: a WS x WS window of the grid follows the droplet in LDS; BACK is where cells come from / go to.
 constexpr int EW = 32; // window edge (cells): 4 KiB of LDS per droplet; a droplet moves one cell per step, so a centred window lasts >= 13 steps
-constexpr unsigned SPEC_BLOOM_WORDS = 256; // 8192 bits: a few hundred logged cells per trace -> a few percent false positives
-TERRA_HD uint32_t spec_bloom_bit(uint32_t cell) {return (cell*2246822519u) >> (32 - 13);}
+constexpr unsigned SPEC_MAXB = 256;      // most blocks a droplet's footprint may hold (their write masks and the block -> entry map live in LDS)
+constexpr unsigned SPEC_MAP_SLOTS = 512; // open-addressed block -> entry map of the running trace, load factor <= 1/2
+constexpr unsigned SPEC_PAGE = 64;       // cells of an 8 x 8 block = floats of a version page
+constexpr unsigned SPEC_WIN_BLOCKS = ((EW >> 3) + 1)*((EW >> 3) + 1); // blocks a window can overlap
+constexpr unsigned SPEC_CAND = 4, SPEC_CAND_MANY = 255;
+constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu, SPEC_SRC_NONE = 0xFFFFFFFEu;
+struct spec_cand_t {uint32_t page, it; unsigned long long mask;}; // page = slot*maxb + entry, bit 31: the version buffer
 struct wave_shared_t { // per-wave LDS scratch
-	uint32_t nlog, flags, pad_;
+	uint32_t flags, pad_;
 	uint32_t n_shift, n_own, n_ver, n_store; // diagnostics of the trace (terra_erosion_report)
-	uint32_t bloom[SPEC_BLOOM_WORDS];        // one bit per hash of a cell this trace has written back to its log: a clear bit spares the look-up of the log (a hash probe through L2)
 	unsigned long long chk;
-	uint8_t blk_shared[64];
+	uint8_t blk_shared[64];                  // per block under the window: number of published LOWER versions that wrote it (SPEC_CAND_MANY: more than fit below)
+	spec_cand_t cand[SPEC_WIN_BLOCKS][SPEC_CAND]; // those versions, highest droplet first: a cell's value comes from the first whose mask has the cell
+	uint32_t map_keys[SPEC_MAP_SLOTS];       // block id (SPEC_NIL: free)
+	uint8_t  map_ent[SPEC_MAP_SLOTS];        // its entry in the trace's block list = its page
+	unsigned long long masks[SPEC_MAXB];     // per entry: which cells of the block this trace has written back to its page
 };
 
 template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
@@ -491,27 +508,45 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		unsigned long long const clk1 = TERRA_CLOCK();
 		back.prepare_window(nx0, nz0);
 		unsigned long long const clk2 = TERRA_CLOCK();
-		unsigned long long clk3 = clk2;
+		unsigned long long clk3 = clk2; (void)clk3;
 		constexpr int PER_LANE = EW*EW/64;
 		TERRA_EACH_LANE(lane) {
 			float gv[PER_LANE];
 #pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) { // all plain grid loads of the lane first: they are independent and overlap in flight
+			for (int k = 0; k < PER_LANE; ++k) { // the plain grid loads of all entering cells first: independent, they overlap in flight (one memory latency per move) ...
 				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
 				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
 				gv[k] = (!in_old && X < NX && Z < NY) ? back.base(X, Z) : 0.0f;
 			}
-#if defined(__HIP_DEVICE_COMPILE__)
-			{float acc = 0.0f; for (int k = 0; k < PER_LANE; ++k) {acc += gv[k];} asm volatile("" :: "v"(acc)); clk3 = TERRA_CLOCK();} // diagnostics: the plain loads have landed
-#endif
+			constexpr int CH = 8; // (all 16 cells in one piece cost too many registers)
 #pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) {
-				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
-				float val = gv[k]; uint8_t d = 0;
-				if (in_old) {int const o = (Z - wz0)*EW + (X - wx0); val = win[o]; d = dirty[o];}
-				else if (X < NX && Z < NY && back.needs_lookup(X, Z)) {val = back.lookup(X, Z, val);}
-				win_alt[i] = val; dirty_alt[i] = d;
+			for (int k0 = 0; k0 < PER_LANE; k0 += CH) {
+				float av[CH]; unsigned slow_mask = 0, alt_mask = 0;
+#pragma unroll
+				for (int k = 0; k < CH; ++k) { // ... and while they are under way, which of the cells have a newer value in a version page (LDS tests only): those loads join the others
+					int const i = (k0 + k)*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
+					bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
+					av[k] = 0.0f;
+					if (!in_old && X < NX && Z < NY) {
+						bool slow = false, own = false;
+						uint32_t const code = back.source(X, Z, slow, own);
+						if (slow) {slow_mask |= 1u << k;}
+						if (code != SPEC_SRC_GRID) {
+							alt_mask |= 1u << k;
+							float const *p = back.source_ptr(code, X, Z);
+							av[k] = own ? TERRA_L2_LOAD(p) : *p; // own: written back earlier in this kernel, the line may be stale in L1
+						}
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < CH; ++k) {
+					int const i = (k0 + k)*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
+					bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
+					float val = ((alt_mask >> k) & 1u) ? av[k] : gv[k0 + k]; uint8_t d = 0;
+					if (in_old) {int const o = (Z - wz0)*EW + (X - wx0); val = win[o]; d = dirty[o];}
+					else if (TERRA_UNLIKELY((slow_mask >> k) & 1u)) {val = back.lookup(X, Z, val);} // a block with many lower versions: walk its list
+					win_alt[i] = val; dirty_alt[i] = d;
+				}
 			}
 		}
 		float *tw = win; win = win_alt; win_alt = tw;
@@ -519,7 +554,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		wx0 = nx0; wz0 = nz0; have = true;
 		TERRA_WAVE_SYNC();
 		unsigned long long const clk4 = TERRA_CLOCK();
-		clk_shift += clk4 - clk0; clk_sh_flush += clk1 - clk0; clk_sh_prep += clk2 - clk1; clk_sh_load += clk3 - clk2;
+		clk_shift += clk4 - clk0; clk_sh_flush += clk1 - clk0; clk_sh_prep += clk2 - clk1; clk_sh_load += 0;
 	}
 	TERRA_HD bool begin_step(int xi, int zi) {
 		xi = sati(xi, NX); zi = sati(zi, NY);
@@ -571,6 +606,8 @@ struct grid_back_t {
 	TERRA_HD float base(int X, int Z) const {return *g.at(X, Z);}
 	TERRA_HD bool needs_lookup(int, int) const {return false;}
 	TERRA_HD float lookup(int, int, float b) const {return b;}
+	TERRA_HD uint32_t source(int, int, bool &slow, bool &own) const {slow = false; own = false; return SPEC_SRC_GRID;}
+	TERRA_HD float const *source_ptr(uint32_t, int X, int Z) const {return g.at(X, Z);}
 	TERRA_HD void store(int X, int Z, float v) {
 		*g.at(X, Z) = v;
 		if (touched) {uint32_t const k = TERRA_ATOMIC_ADD(touched_count, 1u); if (k < touched_cap) {touched[k] = (uint32_t)Z*(uint32_t)g.NX + (uint32_t)X;}}
@@ -611,7 +648,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	unsigned long long crit_own_shift, crit_own_edge, crit_own_steps; // the packed fields summed over the rounds
 	unsigned long long round_max_pack2, crit_own_flush, crit_own_load, crit_own_prep; // same key: ticks << 44 | write-back << 28 | plain loads << 14 | block flags
 };
-struct spec_resume_t {uint32_t nblk, nlog, flags, bc[4], be[4], bwmask, far_last; int own_x0, own_z0, own_x1, own_z1; unsigned long long chk;}; // spec_back_t state of a suspended trace
+struct spec_resume_t {uint32_t nblk, flags;}; // spec_back_t state of a suspended trace (its masks and pages are in the version buffer)
 
 struct spec_buffers_t {
 	grid_view_t grid;
@@ -619,17 +656,17 @@ struct spec_buffers_t {
 	uint32_t num_iters;    // droplets of the whole run
 	uint32_t W;            // ring slots; droplet `it` lives in slot it % W, in-flight droplets are [base, base + W)
 	uint32_t near_count;   // the first near_count in-flight droplets (the next to commit) trace without a step budget; the others are sliced (0: all sliced)
-	uint32_t cap_log2;     // log capacity = 1 << cap_log2
-	uint32_t maxb;         // block-list capacity per droplet
-	uint32_t bshift;       // block edge = 1 << bshift cells (>= 3)
+	uint32_t maxb;         // block-list capacity per droplet (<= SPEC_MAXB)
+	uint32_t bshift;       // block edge = 1 << bshift cells (3: a page holds the 8 x 8 cells of a block)
 	uint32_t nbx, nby;     // blocks per row / column of the padded grid
-	uint32_t *log_keys[2]; // [W][cap]
-	float    *log_vals[2]; // [W][cap]
-	uint32_t *log_used[2]; // [W][cap] hash positions in insertion order: clearing and flushing a log cost O(entries), not O(capacity)
-	uint32_t *log_cnt[2];  // [W] entries of log_used; invariant between kernels: a buffer's keys are SPEC_EMPTY except at its listed positions
-	uint32_t *blk_list[2]; // [W][maxb]
+	// a version = what one trace of a droplet wrote, stored by block: entry e of the block list names the block, page e holds its 64 cells, mask e says which
+	// of them were written.  No hashing and no read-modify-write on the way in (a write-back is one plain store), and a reader that found the writer of a
+	// block through the block lists reads the cell directly.
+	float    *page_vals[2];// [W][maxb][64]
+	unsigned long long *page_mask[2]; // [W][maxb], valid for entries < blk_cnt (finished version) / run_nblk (suspended trace)
+	uint32_t *blk_list[2]; // [W][maxb] distinct blocks, in the order the trace met them
 	uint32_t *blk_cnt[2];  // [W]
-	uint64_t *chk[2];      // [W] checksum of the version's final log content (+ step count)
+	uint64_t *chk[2];      // [W] checksum of the version's content (+ step count)
 	uint32_t *it;          // [W] droplet number held by the slot (SPEC_NIL: none)
 	uint32_t *phase;       // [W]
 	uint32_t *has_ver;     // [W] buffer cur[] holds a published finished version (visible to higher droplets)
@@ -658,112 +695,110 @@ TERRA_HD uint64_t spec_mix64(uint64_t x) {
 	return x;
 }
 TERRA_HD uint64_t spec_term(uint32_t cell, float val) {uint32_t vb; memcpy(&vb, &val, 4); return spec_mix64(((uint64_t)cell << 32) | vb);}
-TERRA_HD uint32_t spec_hash(uint32_t cell, uint32_t cap_log2) {return (cell*2654435761u) >> (32 - cap_log2);}
-
-// L2LOAD: read through to L2.  A droplet's OWN log is written by the other lanes of its wave (CAS + plain stores) in the same
-// kernel; the CU's vector L1 may still hold the line from an earlier probe that saw SPEC_EMPTY, so those probes must not hit L1.
-// Other droplets' logs were written by earlier kernels (the boundary makes them visible) and use plain cached loads.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TERRA_L2_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
-#define TERRA_L2_LOAD(p) (*(p))
-#endif
-template<bool L2LOAD> TERRA_HD bool spec_log_find(uint32_t const *keys, float const *vals, uint32_t cap_log2, uint32_t cell, float &out) {
-	uint32_t const mask = (1u << cap_log2) - 1;
-	uint32_t h = spec_hash(cell, cap_log2);
-	for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
-		uint32_t const k = L2LOAD ? TERRA_L2_LOAD(&keys[h]) : keys[h];
-		if (k == cell) {out = L2LOAD ? TERRA_L2_LOAD(&vals[h]) : vals[h]; return true;}
-		if (k == SPEC_EMPTY) return false;
-	}
-	return false;
-}
 
 struct spec_back_t {
 	spec_buffers_t const *sb;
 	wave_shared_t *sh;     // LDS
 	uint32_t slot, iter;
-	uint32_t *my_keys; float *my_vals; uint32_t *my_blks, *my_used; // the version being built (buffer 1 - cur)
+	float *my_pages; unsigned long long *my_masks; uint32_t *my_blks; // the version being built (buffer 1 - cur)
 	uint32_t nblk;
-	// the four most recently recorded brush-box blocks with their list entries (plain registers: an indexed array would live in scratch memory);
-	// bit k of bwmask: cache position k was written to since it entered the cache
-	uint32_t bc0, bc1, bc2, bc3, be0, be1, be2, be3, bwmask, far_last;
 	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
-	int own_x0, own_z0, own_x1, own_z1; // bounding box of the cells this droplet may already have written back
 	int lx0 = INT_MIN, lx1 = INT_MIN, lz0 = INT_MIN, lz1 = INT_MIN; // block range of the previous step's brush box
 
+	TERRA_HD static uint32_t map_hash(uint32_t b) {return (b*2654435761u) >> (32 - 9);}
+	TERRA_HD static uint32_t page_cell(int X, int Z) {return (uint32_t)((Z & 7) << 3) | (uint32_t)(X & 7);}
+	// entry of block b in this trace's list, or SPEC_NIL.  Inserts are done by lane 0 (map_add) and followed by a wave sync.
+	TERRA_HD uint32_t map_find(uint32_t b) const {
+		for (uint32_t h = map_hash(b), n = 0; n < SPEC_MAP_SLOTS; ++n, h = (h + 1) & (SPEC_MAP_SLOTS - 1)) {
+			uint32_t const k = sh->map_keys[h];
+			if (k == b) return sh->map_ent[h];
+			if (k == SPEC_NIL) return SPEC_NIL;
+		}
+		return SPEC_NIL;
+	}
+	TERRA_HD void map_add(uint32_t b, uint32_t e) { // one lane; b is not in the map; at most SPEC_MAXB = SPEC_MAP_SLOTS/2 blocks: a free slot exists
+		uint32_t h = map_hash(b);
+		while (sh->map_keys[h] != SPEC_NIL) {h = (h + 1) & (SPEC_MAP_SLOTS - 1);}
+		sh->map_keys[h] = b; sh->map_ent[h] = (uint8_t)e;
+	}
 	TERRA_HD void init(spec_buffers_t const *sb_, uint32_t slot_, uint32_t iter_, wave_shared_t *sh_, spec_resume_t const *rs) {
 		sb = sb_; slot = slot_; iter = iter_; sh = sh_;
 		uint32_t const nb = 1u - sb->cur[slot];
-		size_t const cap = (size_t)1 << sb->cap_log2;
-		my_keys = sb->log_keys[nb] + (size_t)slot*cap;
-		my_vals = sb->log_vals[nb] + (size_t)slot*cap;
-		my_blks = sb->blk_list[nb] + (size_t)slot*sb->maxb;
-		my_used = sb->log_used[nb] + (size_t)slot*cap;
-		nblk = 0; bc0 = bc1 = bc2 = bc3 = SPEC_NIL; be0 = be1 = be2 = be3 = 0; bwmask = 0; far_last = SPEC_NIL;
+		my_pages = sb->page_vals[nb] + (size_t)slot*sb->maxb*SPEC_PAGE;
+		my_masks = sb->page_mask[nb] + (size_t)slot*sb->maxb;
+		my_blks  = sb->blk_list[nb] + (size_t)slot*sb->maxb;
+		nblk = rs ? rs->nblk : 0;
 		blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
 		lx0 = lx1 = lz0 = lz1 = INT_MIN;
-		own_x0 = own_z0 = INT_MAX; own_x1 = own_z1 = INT_MIN;
-		if (rs) { // resume a suspended trace
-			nblk = rs->nblk; own_x0 = rs->own_x0; own_z0 = rs->own_z0; own_x1 = rs->own_x1; own_z1 = rs->own_z1;
-			bc0 = rs->bc[0]; bc1 = rs->bc[1]; bc2 = rs->bc[2]; bc3 = rs->bc[3]; be0 = rs->be[0]; be1 = rs->be[1]; be2 = rs->be[2]; be3 = rs->be[3];
-			bwmask = rs->bwmask; far_last = rs->far_last;
-		}
-		if (TERRA_LANE0) {sh->nlog = rs ? rs->nlog : 0; sh->flags = rs ? rs->flags : 0; sh->chk = rs ? rs->chk : 0; sh->n_shift = sh->n_own = sh->n_ver = sh->n_store = 0;}
-		TERRA_LANES(w, SPEC_BLOOM_WORDS) {sh->bloom[w] = 0u;}
+		if (TERRA_LANE0) {sh->flags = rs ? rs->flags : 0; sh->chk = 0; sh->n_shift = sh->n_own = sh->n_ver = sh->n_store = 0;}
+		TERRA_LANES(h, SPEC_MAP_SLOTS) {sh->map_keys[h] = SPEC_NIL;}
+		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nblk) ? my_masks[e] : 0ull;} // a resumed trace: what it has written back so far (saved by suspend())
 		TERRA_WAVE_SYNC();
-		if (rs && rs->nlog) { // a resumed trace: the filter is rebuilt from the log written so far
-			TERRA_LANES(e, rs->nlog) {uint32_t const bb = spec_bloom_bit(my_keys[my_used[e]]); TERRA_ATOMIC_OR(&sh->bloom[bb >> 5], 1u << (bb & 31u));}
+		if (nblk) { // a resumed trace: the map is rebuilt from the block list (distinct blocks: every lane claims a free slot for each of its entries)
+			TERRA_LANES(e, nblk) {
+				uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN;
+				for (uint32_t h = map_hash(b);; h = (h + 1) & (SPEC_MAP_SLOTS - 1)) {
+					if (TERRA_ATOMIC_CAS(&sh->map_keys[h], SPEC_NIL, b) == SPEC_NIL) {sh->map_ent[h] = (uint8_t)e; break;}
+				}
+			}
 			TERRA_WAVE_SYNC();
 		}
 	}
-	TERRA_HD void save(spec_resume_t &rs) const {
-		rs.nblk = nblk; rs.nlog = sh->nlog; rs.flags = sh->flags; rs.chk = sh->chk;
-		rs.bc[0] = bc0; rs.bc[1] = bc1; rs.bc[2] = bc2; rs.bc[3] = bc3; rs.be[0] = be0; rs.be[1] = be1; rs.be[2] = be2; rs.be[3] = be3;
-		rs.bwmask = bwmask; rs.far_last = far_last;
-		rs.own_x0 = own_x0; rs.own_z0 = own_z0; rs.own_x1 = own_x1; rs.own_z1 = own_z1;
+	TERRA_HD void save(spec_resume_t &rs) const {rs.nblk = nblk; rs.flags = sh->flags;}
+	// the trace stops (finished or suspended): masks to global memory, written flags into the block list
+	TERRA_HD void publish_masks() const {
+		TERRA_LANES(e, nblk) {
+			unsigned long long const m = sh->masks[e];
+			my_masks[e] = m;
+			uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN;
+			my_blks[e] = m ? (b | SPEC_BLK_WRITTEN) : b; // only written blocks can invalidate a reader
+		}
+		TERRA_WAVE_SYNC();
+	}
+	// sum over the written cells of a non-linear term of (cell, value): a function of the version's CONTENT only, so two traces of a droplet compare equal
+	// however their write-backs were scheduled
+	TERRA_HD unsigned long long content_checksum() const {
+		if (TERRA_LANE0) {sh->chk = 0;}
+		TERRA_WAVE_SYNC();
+		TERRA_EACH_LANE(c) {
+			unsigned long long acc = 0;
+			for (uint32_t e = 0; e < nblk; ++e) {
+				unsigned long long const m = sh->masks[e];
+				if (!((m >> c) & 1ull)) continue;
+				uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN, bx = b % sb->nbx, bz = b / sb->nbx;
+				uint32_t const cell = ((bz << 3) + ((uint32_t)c >> 3))*(uint32_t)sb->ec.NX + (bx << 3) + ((uint32_t)c & 7u);
+				acc += spec_term(cell, TERRA_L2_LOAD(&my_pages[(size_t)e*SPEC_PAGE + c]));
+			}
+			if (acc) {TERRA_ATOMIC_ADD(&sh->chk, acc);}
+		}
+		TERRA_WAVE_SYNC();
+		return sh->chk;
 	}
 	// sh->flags only changes inside window write-backs, which end with a wave sync; blk_overflow is a wave-uniform register
 	TERRA_HD bool failed() const {return blk_overflow || (sh->flags & SPEC_F_LOG_OVERFLOW) != 0;}
-	// Footprint bookkeeping (wave-uniform; lane 0 owns the global writes).  Every write of a step lands in the step's brush box, whose
-	// (at most four) blocks are all in the cache after begin_step(): a deposit / brush therefore flags the whole cache as written
-	// (a superset is fine).  The flag reaches the list entry when the block leaves the cache or the trace stops.
+	// Footprint bookkeeping (wave-uniform; lane 0 owns the writes): every block the trace reads or writes gets one list entry, and with it a page
 	TERRA_HD void touch_block(uint32_t b) {
-		if (b == bc0 || b == bc1 || b == bc2 || b == bc3) return;
+		if (map_find(b) != SPEC_NIL) return;
 		if (TERRA_UNLIKELY(nblk >= sb->maxb)) {blk_overflow = true; return;}
-		if ((bwmask & 8u) && bc3 != SPEC_NIL && TERRA_LANE0) {my_blks[be3] = bc3 | SPEC_BLK_WRITTEN;}
-		bc3 = bc2; bc2 = bc1; bc1 = bc0; bc0 = b; be3 = be2; be2 = be1; be1 = be0; be0 = nblk; bwmask = (bwmask << 1) & 0xFu;
-		if (TERRA_LANE0) {my_blks[nblk] = b;}
+		if (TERRA_LANE0) {my_blks[nblk] = b; map_add(b, nblk);}
 		++nblk;
+		TERRA_WAVE_SYNC(); // the new map entry is visible to every lane
 	}
-	TERRA_HD void note_write() {bwmask = 0xFu;}
-	TERRA_HD void flush_block_flags() const { // the trace stops (finished or suspended)
-		if (!TERRA_LANE0) return;
-		if ((bwmask & 1u) && bc0 != SPEC_NIL) {my_blks[be0] = bc0 | SPEC_BLK_WRITTEN;}
-		if ((bwmask & 2u) && bc1 != SPEC_NIL) {my_blks[be1] = bc1 | SPEC_BLK_WRITTEN;}
-		if ((bwmask & 4u) && bc2 != SPEC_NIL) {my_blks[be2] = bc2 | SPEC_BLK_WRITTEN;}
-		if ((bwmask & 8u) && bc3 != SPEC_NIL) {my_blks[be3] = bc3 | SPEC_BLK_WRITTEN;}
-	}
-	// reads outside the window (only after a NaN position): read-only entries that stay out of the brush-box cache
+	TERRA_HD void note_write() {}
+	// reads outside the window (only after a NaN position): part of the footprint like any other block
 	TERRA_HD void note_far_read(int X, int Z) {
-		uint32_t const b = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
-		if (b == far_last || b == bc0 || b == bc1 || b == bc2 || b == bc3) return;
-		if (nblk >= sb->maxb) {blk_overflow = true; return;}
-		far_last = b;
-		if (TERRA_LANE0) {my_blks[nblk] = b;}
-		++nblk;
+		nblk = wave_uniform(nblk);
+		touch_block((uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift));
 	}
 	TERRA_HD bool begin_step(int xi, int zi) { // footprint of one step = the 4x4 brush box, which also covers every read of that step
 		int const x0 = clampi(xi-1, sb->ec.NX-1) >> sb->bshift, x1 = clampi(xi+2, sb->ec.NX-1) >> sb->bshift;
 		int const z0 = clampi(zi-1, sb->ec.NY-1) >> sb->bshift, z1 = clampi(zi+2, sb->ec.NY-1) >> sb->bshift;
-		// a droplet moves at most one cell per step: most steps have the brush box in the same (at most four) blocks as the step before, which are then the
-		// newest entries of the cache -- nothing to record
+		// a droplet moves at most one cell per step: most steps have the brush box in the same (at most four) blocks as the step before -- nothing to record
 		lx0 = wave_uniform(lx0); lx1 = wave_uniform(lx1); lz0 = wave_uniform(lz0); lz1 = wave_uniform(lz1);
-		if (x0 == lx0 && x1 == lx1 && z0 == lz0 && z1 == lz1) {return !failed();}
+		if (x0 == lx0 && x1 == lx1 && z0 == lz0 && z1 == lz1) {return !blk_overflow;} // (a write-back failure is noticed at the next window move / at the end)
 		lx0 = x0; lx1 = x1; lz0 = z0; lz1 = z1;
-		nblk = wave_uniform(nblk); bwmask = wave_uniform(bwmask); bc0 = wave_uniform(bc0); bc1 = wave_uniform(bc1); bc2 = wave_uniform(bc2); bc3 = wave_uniform(bc3);
-		be0 = wave_uniform(be0); be1 = wave_uniform(be1); be2 = wave_uniform(be2); be3 = wave_uniform(be3);
+		nblk = wave_uniform(nblk);
 		touch_block((uint32_t)z0*sb->nbx + x0);
 		if (x1 != x0) {touch_block((uint32_t)z0*sb->nbx + x1);}
 		if (z1 != z0) {
@@ -775,91 +810,98 @@ struct spec_back_t {
 	// a list node counts when its slot holds a published version of a LOWER droplet (nodes of slots that were re-assigned since the lists
 	// were built have no published version yet)
 	TERRA_HD bool lower_version(uint32_t j) const {return sb->has_ver[j] && sb->it[j] < iter;}
-	// which blocks under the new window are also in a LOWER droplet's footprint (only those need the multi-version lookup)
+	// which published LOWER versions wrote the blocks under the new window (only those blocks need the multi-version look-up): one lane per block walks the
+	// block's writer list once and leaves the versions in LDS, highest droplet first, so that a cell's look-up is a mask test there plus one load
 	TERRA_HD void prepare_window(int wx0, int wz0) {
 		if (TERRA_LANE0) {sh->n_shift += 1;}
 		wbx0 = wx0 >> sb->bshift; wbz0 = wz0 >> sb->bshift;
 		TERRA_LANES(i, wnb*wnb) {
-			uint8_t shared = 0;
+			uint32_t cnt = 0;
 			uint32_t const bx = (uint32_t)(wbx0 + i % wnb), bz = (uint32_t)(wbz0 + i / wnb);
 			if (bx < sb->nbx && bz < sb->nby) {
-				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {if (lower_version(node / sb->maxb)) {shared = 1; break;}}
+				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {
+					uint32_t const j = node / sb->maxb;
+					if (!lower_version(j)) continue;
+					if (cnt == SPEC_CAND) {cnt = SPEC_CAND_MANY; break;}
+					uint32_t const ij = sb->it[j], cb = sb->cur[j];
+					spec_cand_t nc; nc.page = node | (cb << 31); nc.it = ij; nc.mask = sb->page_mask[cb][node];
+					uint32_t k = cnt; // insertion by descending droplet number
+					for (; k > 0 && sh->cand[i][k-1].it < ij; --k) {sh->cand[i][k] = sh->cand[i][k-1];}
+					sh->cand[i][k] = nc;
+					++cnt;
+				}
 			}
-			sh->blk_shared[i] = shared;
+			sh->blk_shared[i] = (uint8_t)cnt;
 		}
 		TERRA_WAVE_SYNC();
 	}
-	TERRA_HD void note_written_rect(int wx0, int wz0) { // the droplet's own write-backs all lie inside the union of its past windows
-		own_x0 = imin(own_x0, wx0); own_z0 = imin(own_z0, wz0); own_x1 = imax(own_x1, wx0 + EW - 1); own_z1 = imax(own_z1, wz0 + EW - 1);
-	}
+	TERRA_HD void note_written_rect(int, int) {}
 	TERRA_HD float base(int X, int Z) const {return *sb->grid.at(X, Z);}
 	TERRA_HD bool block_flag(int X, int Z) const { // is the cell's block also in a LOWER droplet's footprint?
 		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
 		if ((unsigned)bx < (unsigned)wnb && (unsigned)bz < (unsigned)wnb) return sh->blk_shared[bz*wnb + bx] != 0;
 		return true; // outside the prepared window (far read): look the block up directly
 	}
-	TERRA_HD bool needs_lookup(int X, int Z) const {
-		bool const own = sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1;
-		return own || block_flag(X, Z);
+	TERRA_HD uint32_t block_of(int X, int Z) const {return (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);}
+	TERRA_HD bool own_written(int X, int Z, uint32_t &e) const { // has this trace written the cell back to its page?
+		e = map_find(block_of(X, Z));
+		return e != SPEC_NIL && ((sh->masks[e] >> page_cell(X, Z)) & 1ull);
 	}
+	TERRA_HD bool needs_lookup(int X, int Z) const {uint32_t e; return own_written(X, Z, e) || block_flag(X, Z);}
+	// where the current value of a cell that enters the window is read from, as a 32-bit code (the lane keeps sixteen of them in registers): SPEC_SRC_GRID, or
+	// a float index into the two version buffers (bit 31: buffer; this trace's own page included -- own: it was written in this kernel, read it through to L2).
+	// slow: the block has more lower versions than the candidate list holds -- the caller reads the grid value and passes it through lookup()
+	TERRA_HD uint32_t source(int X, int Z, bool &slow, bool &own) const {
+		uint32_t const c = page_cell(X, Z);
+		uint32_t e;
+		slow = false; own = false;
+		if (own_written(X, Z, e)) {TERRA_ATOMIC_ADD(&sh->n_own, 1u); own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);}
+		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
+		uint32_t const bi = (uint32_t)(bz*wnb + bx), cnt = sh->blk_shared[bi]; // inside the prepared window by construction
+		if (cnt) {
+			TERRA_ATOMIC_ADD(&sh->n_ver, 1u);
+			if (cnt == SPEC_CAND_MANY) {slow = true;}
+			else {
+				for (uint32_t k = 0; k < cnt; ++k) {
+					spec_cand_t const &cd = sh->cand[bi][k];
+					if ((cd.mask >> c) & 1ull) return (cd.page & 0x80000000u) | ((cd.page & 0x7FFFFFFFu)*SPEC_PAGE + c);
+				}
+			}
+		}
+		return SPEC_SRC_GRID;
+	}
+	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code == SPEC_SRC_GRID) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x7FFFFFFFu);}
 	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`
 	TERRA_HD float lookup(int X, int Z, float b) const {
-		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
-		float v;
-		if (sh->nlog && X >= own_x0 && X <= own_x1 && Z >= own_z0 && Z <= own_z1) {
-			uint32_t const bb = spec_bloom_bit(cell);
-			if (sh->bloom[bb >> 5] & (1u << (bb & 31u))) { // possibly written back earlier by this trace
-				TERRA_ATOMIC_ADD(&sh->n_own, 1u);
-				if (spec_log_find<true>(my_keys, my_vals, sb->cap_log2, cell, v)) return v;
-			}
+		uint32_t const c = page_cell(X, Z);
+		uint32_t e;
+		if (own_written(X, Z, e)) {
+			TERRA_ATOMIC_ADD(&sh->n_own, 1u);
+			return TERRA_L2_LOAD(&my_pages[(size_t)e*SPEC_PAGE + c]);
 		}
 		if (block_flag(X, Z)) {
 			TERRA_ATOMIC_ADD(&sh->n_ver, 1u);
 			uint32_t best = SPEC_NIL; // droplet number of the best writer so far
-			size_t const cap = (size_t)1 << sb->cap_log2;
-			uint32_t const blk = (uint32_t)(Z >> sb->bshift)*sb->nbx + (uint32_t)(X >> sb->bshift);
-			for (uint32_t node = sb->head[blk]; node != SPEC_NIL; node = sb->next[node]) {
+			float v = b;
+			for (uint32_t node = sb->head[block_of(X, Z)]; node != SPEC_NIL; node = sb->next[node]) {
 				uint32_t const j = node / sb->maxb;
 				if (!lower_version(j)) continue;
 				uint32_t const ij = sb->it[j];
 				if (best != SPEC_NIL && ij <= best) continue;
 				uint32_t const cb = sb->cur[j];
-				float vj;
-				if (spec_log_find<false>(sb->log_keys[cb] + (size_t)j*cap, sb->log_vals[cb] + (size_t)j*cap, sb->cap_log2, cell, vj)) {best = ij; v = vj;}
+				if ((sb->page_mask[cb][node] >> c) & 1ull) {best = ij; v = sb->page_vals[cb][(size_t)node*SPEC_PAGE + c];} // node = slot*maxb + entry = index of the page
 			}
-			if (best != SPEC_NIL) return v;
+			return v;
 		}
 		return b;
 	}
-	// called from lanes in parallel, each with a distinct cell.  sh->chk = sum over the log's cells of a non-linear term of (cell, latest value):
-	// a function of the log CONTENT only, so two traces of a droplet compare equal however their write-backs were scheduled
+	// called from lanes in parallel, each with a distinct cell (several may share a page: the mask is updated atomically)
 	TERRA_HD void store(int X, int Z, float val) {
 		TERRA_ATOMIC_ADD(&sh->n_store, 1u);
-		uint32_t const cell = (uint32_t)Z*sb->ec.NX + X;
-		{uint32_t const bb = spec_bloom_bit(cell); TERRA_ATOMIC_OR(&sh->bloom[bb >> 5], 1u << (bb & 31u));}
-		uint32_t const mask = (1u << sb->cap_log2) - 1, limit = mask - (uint32_t)(EW*EW) - 64u;
-		uint32_t h = spec_hash(cell, sb->cap_log2);
-		for (uint32_t n = 0; n <= mask; ++n, h = (h + 1) & mask) {
-			uint32_t k = my_keys[h];
-			if (k == SPEC_EMPTY) {
-				k = TERRA_ATOMIC_CAS(&my_keys[h], SPEC_EMPTY, cell);
-				if (k == SPEC_EMPTY) {
-					my_vals[h] = val;
-					TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)spec_term(cell, val));
-					uint32_t const idx = TERRA_ATOMIC_ADD(&sh->nlog, 1u);
-					my_used[idx] = h; // idx < capacity: one entry per occupied slot of the table
-					if (idx >= limit) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);}
-					return;
-				}
-			}
-			if (k == cell) {
-				float const old = TERRA_L2_LOAD(&my_vals[h]);
-				my_vals[h] = val;
-				TERRA_ATOMIC_ADD(&sh->chk, (unsigned long long)(spec_term(cell, val) - spec_term(cell, old)));
-				return;
-			}
-		}
-		TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW);
+		uint32_t const e = map_find(block_of(X, Z)), c = page_cell(X, Z);
+		if (TERRA_UNLIKELY(e == SPEC_NIL)) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW); return;} // every written cell lies in a recorded brush box: never happens
+		my_pages[(size_t)e*SPEC_PAGE + c] = val;
+		TERRA_ATOMIC_OR(&sh->masks[e], 1ull << c);
 	}
 };
 
@@ -889,13 +931,6 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	droplet_state_t d;
 	bool finished = false;
 	if (ph == SPEC_FRESH) {
-		{ // a trace starts with an empty version buffer: remove what the buffer's previous trace (abandoned, superseded or committed) left
-			uint32_t const nbuf = 1u - sb.cur[slot], cnt = sb.log_cnt[nbuf][slot];
-			uint32_t *keys = sb.log_keys[nbuf] + ((size_t)slot << sb.cap_log2);
-			uint32_t const *used = sb.log_used[nbuf] + ((size_t)slot << sb.cap_log2);
-			TERRA_LANES(e, cnt) {keys[used[e]] = SPEC_EMPTY;}
-			TERRA_WAVE_SYNC();
-		}
 		mem.back.init(&sb, slot, iter, ws.sh, nullptr);
 		finished = !droplet_start((int)iter, mem, sb.ec, d);
 	}
@@ -907,32 +942,41 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	if (!finished) {finished = droplet_run_fast(d, mem, sb.ec, budget);}
 	unsigned long long const clk_c = TERRA_CLOCK();
 	unsigned const steps_before = (ph == SPEC_FRESH) ? 0u : sb.state[slot].numMoves;
-	mem.finish(); // the window's dirty cells go to the log: a suspended trace keeps nothing in LDS
-	mem.back.flush_block_flags();
+	mem.finish(); // the window's dirty cells go to the pages: a suspended trace keeps nothing but its masks in LDS, and those are saved next
+	mem.back.publish_masks();
 	// "unchanged" is decided by the content checksum; before a version is declared equal to the published one (which spares every higher droplet a
-	// re-trace) the two logs are compared entry by entry, so a checksum collision can cost time but never a wrong result.  Only the unchanged path pays.
+	// re-trace) the two versions are compared page by page, so a checksum collision can cost time but never a wrong result.  Only the unchanged path pays.
+	uint64_t chk_new = 0;
 	{
 		uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 		uint32_t const fl0 = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
-		uint64_t const chk0 = (uint64_t)ws.sh->chk ^ ((uint64_t)d.numMoves << 40);
-		bool const verify = finished && !(fl0 & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) && sb.has_ver[slot] && sb.chk[ob][slot] == chk0 && sb.blk_cnt[ob][slot] == mem.back.nblk;
+		bool const sound = finished && !(fl0 & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW));
+		if (sound) {chk_new = (uint64_t)mem.back.content_checksum() ^ ((uint64_t)d.numMoves << 40);}
+		bool const verify = sound && sb.has_ver[slot] && sb.chk[ob][slot] == chk_new && sb.blk_cnt[ob][slot] == mem.back.nblk;
 		if (TERRA_LANE0) {ws.sh->pad_ = 0;}
 		TERRA_WAVE_SYNC();
-		if (verify) {
-			uint32_t const nlog = ws.sh->nlog;
-			size_t const cap = (size_t)1 << sb.cap_log2;
-			uint32_t const *okeys = sb.log_keys[ob] + (size_t)slot*cap; float const *ovals = sb.log_vals[ob] + (size_t)slot*cap;
-			uint32_t const *nkeys = sb.log_keys[nb] + (size_t)slot*cap, *nused = sb.log_used[nb] + (size_t)slot*cap; float const *nvals = sb.log_vals[nb] + (size_t)slot*cap;
-			if (sb.log_cnt[ob][slot] != nlog) {if (TERRA_LANE0) {ws.sh->pad_ = 1;}}
-			else {
-				TERRA_LANES(e, nlog) { // this trace's log was written by the wave's own lanes in this kernel: read it through to L2
-					uint32_t const h = TERRA_L2_LOAD(&nused[e]), cell = TERRA_L2_LOAD(&nkeys[h]);
-					float const val = TERRA_L2_LOAD(&nvals[h]);
-					float vo; uint32_t a, b;
-					bool const found = spec_log_find<false>(okeys, ovals, sb.cap_log2, cell, vo);
-					memcpy(&a, &val, 4); memcpy(&b, &vo, 4);
-					if (!found || a != b) {TERRA_ATOMIC_OR(&ws.sh->pad_, 1u);}
+		if (verify) { // every written page of the new version has a page of the same block with the same mask and the same values in the published one (and, the
+			// checksums being equal, hardly ever anything else).  Both lists hold distinct blocks and have the same length.
+			size_t const pbase = (size_t)slot*sb.maxb;
+			uint32_t const *oblk = sb.blk_list[ob] + pbase; unsigned long long const *omask = sb.page_mask[ob] + pbase; float const *oval = sb.page_vals[ob] + pbase*SPEC_PAGE;
+			uint32_t const *nblkl = sb.blk_list[nb] + pbase; float const *nval = sb.page_vals[nb] + pbase*SPEC_PAGE;
+			uint32_t const n = mem.back.nblk;
+			TERRA_EACH_LANE(c) {
+				uint32_t bad = 0;
+				for (uint32_t e = 0; e < n; ++e) {
+					unsigned long long const m = ws.sh->masks[e];
+					uint32_t const b = TERRA_L2_LOAD(&nblkl[e]) & ~SPEC_BLK_WRITTEN;
+					uint32_t oe = SPEC_NIL;
+					for (uint32_t k = 0; k < n; ++k) {if ((oblk[(e + k) % n] & ~SPEC_BLK_WRITTEN) == b) {oe = (e + k) % n; break;}} // same path => same position: found at k = 0
+					unsigned long long const mo = (oe != SPEC_NIL) ? omask[oe] : 0ull;
+					if (mo != m) {bad = 1; break;}
+					if ((m >> c) & 1ull) {
+						float const vn = TERRA_L2_LOAD(&nval[(size_t)e*SPEC_PAGE + c]), vo = oval[(size_t)oe*SPEC_PAGE + c];
+						uint32_t x, y; memcpy(&x, &vn, 4); memcpy(&y, &vo, 4);
+						if (x != y) {bad = 1; break;}
+					}
 				}
+				if (bad) {TERRA_ATOMIC_OR(&ws.sh->pad_, 1u);}
 			}
 			TERRA_WAVE_SYNC();
 		}
@@ -942,9 +986,8 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
 		bool const failed = (fl & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) != 0;
 		sb.run_nblk[slot] = mem.back.nblk;
-		sb.log_cnt[nb][slot] = ws.sh->nlog;
 		if (finished || failed) {
-			uint64_t const chk = (uint64_t)ws.sh->chk ^ ((uint64_t)d.numMoves << 40);
+			uint64_t const chk = chk_new;
 			sb.blk_cnt[nb][slot] = mem.back.nblk;
 			sb.chk[nb][slot]     = chk;
 			sb.nsteps[slot]      = d.numMoves;
@@ -1061,26 +1104,26 @@ TERRA_HD void spec_scan_body(spec_buffers_t const &sb, uint32_t slot) {
 TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 	uint32_t const iter = sb.it[slot], nbase = sb.ctl->new_base;
 	if (iter == SPEC_NIL || iter >= nbase) return;
-	uint32_t const cb = sb.cur[slot];
-	size_t const cap = (size_t)1 << sb.cap_log2;
-	uint32_t const *keys = sb.log_keys[cb] + (size_t)slot*cap, *used = sb.log_used[cb] + (size_t)slot*cap;
-	float const *vals = sb.log_vals[cb] + (size_t)slot*cap;
-	TERRA_LANES(u, sb.log_cnt[cb][slot]) {
-		uint32_t const entry = used[u], cell = keys[entry];
-		uint32_t const X = cell % (uint32_t)sb.ec.NX, Z = cell / (uint32_t)sb.ec.NX;
-		uint32_t const b = (Z >> sb.bshift)*sb.nbx + (X >> sb.bshift);
-		bool owner = true;
-		for (uint32_t node = sb.head[b]; node != SPEC_NIL; node = sb.next[node]) {
+	uint32_t const cb = sb.cur[slot], n = sb.blk_cnt[cb][slot];
+	size_t const pbase = (size_t)slot*sb.maxb;
+	TERRA_LANES(e, n) { // one page per lane: the dependent loads of the ownership test (list walk, masks) of different pages overlap; the cell stores need no reply
+		uint32_t const ent = sb.blk_list[cb][pbase + e];
+		if (!(ent & SPEC_BLK_WRITTEN)) continue;
+		uint32_t const b = ent & ~SPEC_BLK_WRITTEN;
+		unsigned long long mine = sb.page_mask[cb][pbase + e];
+		for (uint32_t node = sb.head[b]; node != SPEC_NIL && mine; node = sb.next[node]) { // a later committed droplet owns the final value of the cells it wrote
 			uint32_t const j = node / sb.maxb, ij = sb.it[j];
 			if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
-			uint32_t const jb = sb.cur[j];
-			// a later committed droplet owns the final value
-			float vj;
-			if (spec_log_find<false>(sb.log_keys[jb] + (size_t)j*cap, sb.log_vals[jb] + (size_t)j*cap, sb.cap_log2, cell, vj)) {owner = false; break;}
+			mine &= ~sb.page_mask[sb.cur[j]][node];
 		}
-		if (!owner) continue;
-		*sb.grid.at((int)X, (int)Z) = vals[entry];
-		if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.ctl->touched, 1u); if (k < sb.touched_cap) {sb.touched[k] = cell;}}
+		uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
+		float const *page = sb.page_vals[cb] + (pbase + e)*SPEC_PAGE;
+		for (; mine; mine &= mine - 1) {
+			uint32_t const c = (uint32_t)__builtin_ctzll(mine);
+			uint32_t const X = (bx << 3) + (c & 7u), Z = (bz << 3) + (c >> 3);
+			*sb.grid.at((int)X, (int)Z) = page[c];
+			if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.ctl->touched, 1u); if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}}
+		}
 	}
 }
 // hand a slot to the next droplet of the ring
