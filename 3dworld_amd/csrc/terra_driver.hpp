@@ -614,6 +614,7 @@ template<class BE> struct terra_engine {
 	static constexpr uint32_t MAX_EROSION_ITERS = 27182812u;
 	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27182812 droplets (the reference's int seed 79*iter+121 overflows)");}
 
+	uint32_t spec_batch_override = getenv("TERRA_ERO_BATCH") ? (uint32_t)std::max(1, atoi(getenv("TERRA_ERO_BATCH"))) : 0u; // experiment knob: rounds per host read-back
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 128, max_rounds = 4000000, near_count = 512;} spec_cfg;
 
 	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
@@ -712,35 +713,50 @@ template<class BE> struct terra_engine {
 		});
 		report.windows = (num_iters + W - 1)/W;
 		uint32_t const slice = std::max<uint32_t>(spec_cfg.slice_steps, 1);
-		uint32_t host_base = 0;
+		uint32_t host_base = 0, launched = 0;
 		spec_ctl_t hc{};
-		for (uint32_t round = 0; host_base < num_iters; ++round) {
-			if (round >= spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
-			++report.rounds;
-			uint32_t const budget = ((uint64_t)host_base + W >= num_iters) ? DROPLET_NO_BUDGET : slice; // nobody is waiting for a slot: run to the end
-			// the round is a fixed sequence of 11 small dependent launches: captured into a hipGraph once per (buffers, budget) and replayed
-			struct {spec_buffers_t s; uint32_t budget; uint32_t tag;} gkey;
-			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.budget = budget; gkey.tag = 0x524e4431u;
-			if (!be.graph_replay(&gkey, sizeof(gkey))) {
-				bool const cap = be.graph_begin();
-				try {
-					be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, budget, ws);});
-					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_flip_body(s, (uint32_t)i);});
-					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);});
-					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-					be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_mark_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
-					be.launch((size_t)W*sb.maxb*2, [=] TERRA_LAMBDA (size_t i) {spec_undirty_body(s, (uint32_t)i);});
-					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_scan_body(s, (uint32_t)i);});
-					be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_flush_wave(s, (uint32_t)i);});
-					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
-					be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
-				} catch (...) {be.graph_abort(); throw;}
-				if (cap) {be.graph_end(&gkey, sizeof(gkey));}
+		size_t const nse = (size_t)W*sb.maxb;
+		// One round = 8 dependent launches (the trace waves, five bookkeeping passes, the commit waves, the end-of-round bookkeeping), captured once into a hipGraph and
+		// replayed.  Nothing in a round needs a host decision -- the step budget, the commit point and the pause behind a failed droplet are all taken from the
+		// device-resident control block -- so the host queues rounds in batches and reads the control block back once per batch; a round after the end (or while the
+		// lowest droplet waits for its serial fall-back) finds nothing to do.
+		auto one_round = [&]() {
+			struct {spec_buffers_t s; uint32_t slice; uint32_t tag;} gkey;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.slice = slice; gkey.tag = 0x524e4432u;
+			if (be.graph_replay(&gkey, sizeof(gkey))) return;
+			bool const cap = be.graph_begin();
+			try {
+				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, slice, ws);});
+				be.launch(nse, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+				be.launch(nse, [=] TERRA_LAMBDA (size_t i) { // publish the finished versions; take the writer lists apart (both after the dirty marks were made from the OLD published versions)
+					spec_unlink_body(s, (uint32_t)i);
+					if (i < s.W) {spec_flip_body(s, (uint32_t)i);}
+				});
+				be.launch(nse, [=] TERRA_LAMBDA (size_t i) { // rebuild the writer lists from the published versions; who must start over
+					spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));
+					spec_mark_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));
+				});
+				be.launch(nse*2, [=] TERRA_LAMBDA (size_t i) { // apply the restarts, find the commit point; reset the dirty marks
+					spec_undirty_body(s, (uint32_t)i);
+					if (i < s.W) {spec_scan_body(s, (uint32_t)i);}
+				});
+				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_flush_wave(s, (uint32_t)i);});
+				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
+				be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
+			} catch (...) {be.graph_abort(); throw;}
+			if (cap) {be.graph_end(&gkey, sizeof(gkey));}
+		};
+		while (host_base < num_iters) {
+			// the first batch is short (a sparse map is done after two rounds); later ones amortise the read-back over 8 rounds
+			uint32_t batch = (launched == 0) ? 2u : 8u;
+			if (spec_batch_override) {batch = spec_batch_override;}
+			for (uint32_t r = 0; r < batch; ++r) {
+				if (launched >= spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
+				one_round(); ++launched;
 			}
-			be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of the round
+			be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of the batch
 			host_base = hc.base;
-			if (host_base < num_iters && hc.stop_at == host_base) { // the lowest uncommitted droplet overflowed its log / block list: it runs alone, directly on the grid
+			if (host_base < num_iters && hc.stop_at == host_base) { // the lowest uncommitted droplet overflowed its block list: it runs alone, directly on the grid
 				uint32_t const it = host_base;
 				grid_view_t const gg = g; erosion_consts_t const ee = ec;
 				uint32_t *fb = &sb.ctl->fb_steps, *tcount = &sb.ctl->touched;
@@ -754,6 +770,7 @@ template<class BE> struct terra_engine {
 		be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);}); // leave head[] all-NIL (dirty_min[] already is)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
+		report.rounds = hc.rounds;
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;
 		report.critical_steps = hc.crit_steps; report.critical_shifts = hc.crit_shifts;

@@ -453,7 +453,9 @@ constexpr unsigned SPEC_MAP_SLOTS = 512; // open-addressed block -> entry map of
 constexpr unsigned SPEC_PAGE = 64;       // cells of an 8 x 8 block = floats of a version page
 constexpr unsigned SPEC_WIN_BLOCKS = ((EW >> 3) + 1)*((EW >> 3) + 1); // blocks a window can overlap
 constexpr unsigned SPEC_CAND = 4, SPEC_CAND_MANY = 255;
-constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu, SPEC_SRC_NONE = 0xFFFFFFFEu;
+// where a cell entering the window is read from: the grid, nothing (it stays in the window / lies outside the grid), the grid + a walk of the block's writer list,
+// or float index (bits 0..29) into version buffer (bit 31); bit 30: the page is this trace's own
+constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu, SPEC_SRC_NONE = 0xFFFFFFFEu, SPEC_SRC_SLOW = 0xFFFFFFFDu, SPEC_SRC_OWN_BIT = 0x40000000u;
 struct spec_cand_t {uint32_t page, it; unsigned long long mask;}; // page = slot*maxb + entry, bit 31: the version buffer
 struct wave_shared_t { // per-wave LDS scratch
 	uint32_t flags, pad_;
@@ -608,6 +610,7 @@ struct grid_back_t {
 	TERRA_HD float lookup(int, int, float b) const {return b;}
 	TERRA_HD uint32_t source(int, int, bool &slow, bool &own) const {slow = false; own = false; return SPEC_SRC_GRID;}
 	TERRA_HD float const *source_ptr(uint32_t, int X, int Z) const {return g.at(X, Z);}
+	TERRA_HD bool source_is_own(uint32_t) const {return false;}
 	TERRA_HD void store(int X, int Z, float v) {
 		*g.at(X, Z) = v;
 		if (touched) {uint32_t const k = TERRA_ATOMIC_ADD(touched_count, 1u); if (k < touched_cap) {touched[k] = (uint32_t)Z*(uint32_t)g.NX + (uint32_t)X;}}
@@ -638,6 +641,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t fb_steps, fb_nan; // fall-back droplet
 	uint32_t ndirty;       // entries of dirty_list
 	uint32_t round_max_steps, round_max_shifts; // most steps / window moves of one trace in this round (diagnostics)
+	uint32_t rounds, pad2_;                     // rounds that had work to do (the host launches them in batches and may overshoot the end)
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
 	unsigned long long n_shift, n_own, n_ver, n_store; // diagnostics summed over all traces
 	unsigned long long crit_steps, crit_shifts;         // round_max_* summed over the rounds
@@ -855,7 +859,7 @@ struct spec_back_t {
 		uint32_t const c = page_cell(X, Z);
 		uint32_t e;
 		slow = false; own = false;
-		if (own_written(X, Z, e)) {TERRA_ATOMIC_ADD(&sh->n_own, 1u); own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);}
+		if (own_written(X, Z, e)) {TERRA_ATOMIC_ADD(&sh->n_own, 1u); own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);} // (the caller adds SPEC_SRC_OWN_BIT)
 		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
 		uint32_t const bi = (uint32_t)(bz*wnb + bx), cnt = sh->blk_shared[bi]; // inside the prepared window by construction
 		if (cnt) {
@@ -870,7 +874,8 @@ struct spec_back_t {
 		}
 		return SPEC_SRC_GRID;
 	}
-	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code == SPEC_SRC_GRID) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x7FFFFFFFu);}
+	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code >= SPEC_SRC_SLOW) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x3FFFFFFFu);}
+	TERRA_HD bool source_is_own(uint32_t code) const {return code < SPEC_SRC_SLOW && (code & SPEC_SRC_OWN_BIT) != 0;}
 	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`
 	TERRA_HD float lookup(int X, int Z, float b) const {
 		uint32_t const c = page_cell(X, Z);
@@ -925,6 +930,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	// the droplets next in line for the commit finish now (nothing behind them can be committed before they are); the ones further back advance a slice per
 	// round, so that a long path has made most of its way by the time it is the one everybody waits for
 	if (sb.near_count && iter - sb.ctl->base < sb.near_count) {budget = DROPLET_NO_BUDGET;}
+	if ((uint64_t)sb.ctl->base + sb.W >= sb.num_iters) {budget = DROPLET_NO_BUDGET;} // nobody is waiting for a slot any more: run to the end
 	window_mem_t<spec_back_t> mem;
 	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
 	mem.lead_mode = sb.ec.lead_mode;
@@ -1143,6 +1149,7 @@ TERRA_HD void spec_admit_body(spec_buffers_t const &sb, uint32_t slot) {
 // end of round (one thread)
 TERRA_HD void spec_advance_body(spec_buffers_t const &sb) {
 	spec_ctl_t &c = *sb.ctl;
+	if (c.base < sb.num_iters && c.stop_at != c.base) {++c.rounds;} // (a round after the end, or while the lowest droplet waits for its serial fall-back, is empty)
 	c.base = c.new_base;
 	uint64_t const nb = (uint64_t)c.base + sb.W;
 	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;

@@ -79,9 +79,9 @@ typedef struct terra_erosion_report {
 	uint64_t traced_steps;   /* droplet steps actually simulated, re-traces included */
 	/* where a trace's time goes besides the steps themselves (speculative scheduler only) */
 	uint64_t window_shifts;  /* times the 32 x 32 LDS window was moved */
-	uint64_t own_lookups;    /* cells entering a window that were looked up in the droplet's own write-back log */
-	uint64_t version_lookups;/* cells entering a window that were looked up in lower droplets' published versions */
-	uint64_t log_stores;     /* cells written back from a window to the version's log */
+	uint64_t own_lookups;    /* cells entering a window that were read back from the droplet's own version pages */
+	uint64_t version_lookups;/* cells entering a window that lie in a block some lower in-flight droplet wrote (their value may come from its pages) */
+	uint64_t log_stores;     /* cells written back from a window to the version's pages */
 	uint64_t critical_steps; /* sum over the rounds of the most steps any one trace made in the round: the scheduler's serial chain, in droplet steps */
 	uint64_t critical_shifts;/* the same for window moves */
 	/* device time in 10 ns ticks, summed over all traces: a trace's whole wave body / before its first step / inside window moves / after its last step;
@@ -182,8 +182,9 @@ int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int 
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
 /* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots; default automatic from the grid size, 0xFFFFFFFF restores that),
- * log2 of the per-droplet write-log capacity (>= 12),
- * per-droplet block-list capacity.  A droplet that overflows either runs alone, in order, directly on the grid (still exact).
+ * log_capacity_log2: ignored (range-checked only) -- a droplet's writes are kept as one 64-cell page per 8x8 block of its footprint, there is no hashed log to size,
+ * per-droplet block-list capacity = pages per droplet (16 .. 256, larger values mean 256).  A droplet whose footprint overflows it runs alone, in order, directly on
+ * the grid (still exact).
  * slice_steps: while droplets wait for a slot a trace advances at most this many steps per round (default 128), except the 512 droplets next in line for the
  * commit, which trace to the end.  Results never depend on any of these. */
 int  terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t log_capacity_log2, uint32_t block_list_capacity);
