@@ -770,7 +770,7 @@ template<class BE> struct terra_engine {
 		be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);}); // leave head[] all-NIL (dirty_min[] already is)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
-		report.rounds = hc.rounds;
+		report.rounds = hc.rounds; report.retraces_same = hc.retraces_same;
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;
 		report.critical_steps = hc.crit_steps; report.critical_shifts = hc.crit_shifts;

@@ -641,7 +641,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t fb_steps, fb_nan; // fall-back droplet
 	uint32_t ndirty;       // entries of dirty_list
 	uint32_t round_max_steps, round_max_shifts; // most steps / window moves of one trace in this round (diagnostics)
-	uint32_t rounds, pad2_;                     // rounds that had work to do (the host launches them in batches and may overshoot the end)
+	uint32_t rounds, retraces_same;             // rounds that had work to do (the host launches them in batches and may overshoot the end); re-traces that reproduced the published version
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
 	unsigned long long n_shift, n_own, n_ver, n_store; // diagnostics summed over all traces
 	unsigned long long crit_steps, crit_shifts;         // round_max_* summed over the rounds
@@ -998,6 +998,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 			sb.chk[nb][slot]     = chk;
 			sb.nsteps[slot]      = d.numMoves;
 			sb.flags[slot]       = fl | (d.nan_seen ? SPEC_F_NAN : 0);
+			if (sb.has_ver[slot] && !(sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk || ws.sh->pad_ != 0)) {TERRA_ATOMIC_ADD(&sb.ctl->retraces_same, 1u);}
 			sb.changed[slot]     = (!sb.has_ver[slot] || sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk || ws.sh->pad_ != 0) ? 1u : 0u;
 			sb.phase[slot]       = failed ? (uint32_t)SPEC_FAILED : (uint32_t)SPEC_DONE_NEW;
 		}

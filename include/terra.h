@@ -82,12 +82,13 @@ typedef struct terra_erosion_report {
 	uint64_t own_lookups;    /* cells entering a window that were read back from the droplet's own version pages */
 	uint64_t version_lookups;/* cells entering a window that lie in a block some lower in-flight droplet wrote (their value may come from its pages) */
 	uint64_t log_stores;     /* cells written back from a window to the version's pages */
+	uint64_t retraces_same;  /* re-traces that reproduced the published version bit for bit (the conflict that caused them was one of blocks, not of cells read) */
 	uint64_t critical_steps; /* sum over the rounds of the most steps any one trace made in the round: the scheduler's serial chain, in droplet steps */
 	uint64_t critical_shifts;/* the same for window moves */
 	/* device time in 10 ns ticks, summed over all traces: a trace's whole wave body / before its first step / inside window moves / after its last step;
 	 * clk_critical: the longest wave body of each round, summed over the rounds */
 	uint64_t clk_wave, clk_init, clk_shift, clk_tail, clk_critical;
-	uint64_t clk_shift_flush, clk_shift_prep, clk_shift_load; /* parts of clk_shift: write-back of the cells that leave / block flags / plain grid loads; the rest is look-ups + filling the window */
+	uint64_t clk_shift_flush, clk_shift_prep, clk_shift_load; /* parts of clk_shift: write-back of the cells that leave / block flags (candidate versions per block); clk_shift_load is 0 since the grid loads are in flight during the look-ups and are not timed apart: the rest of clk_shift is loads + look-ups + filling the window */
 	uint64_t crit_clk_flush, crit_clk_load, crit_clk_prep; /* the parts of crit_clk_shift */
 	uint64_t crit_clk_shift, crit_clk_edge, crit_steps_own; /* of each round's longest wave body: ticks in window moves, ticks before + after its steps, its steps (multiple of 4) */
 } terra_erosion_report;
