@@ -50,9 +50,9 @@ def test_erosion_serial_flags_and_overflow_fallback(pkg, gpu, orc):
     assert r.serial_fallbacks >= 1 and r.windows >= 7
 
 
-@pytest.mark.parametrize("n,iters,window,slice_steps,blk_cap", [(256, 3000, 64, 16, 0), (256, 1200, 48, 8, 12), (512, 20000, 512, 8, 0), (1024, 30000, 4096, 64, 0)])
-def test_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_cap):
-    r, _ = pc.case_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_cap)
+@pytest.mark.parametrize("n,iters,window,slice_steps,blk_cap,near", [(256, 3000, 64, 16, 0, 0), (256, 1200, 48, 8, 12, 0), (512, 20000, 512, 8, 0, 16), (1024, 30000, 4096, 64, 0, 512), (512, 8000, 256, 32, 0, 100000)])
+def test_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_cap, near):
+    r, _ = pc.case_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_cap, near=near)
     assert r.rounds > r.windows
     if blk_cap:
         assert r.serial_fallbacks >= 1

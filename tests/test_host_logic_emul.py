@@ -92,9 +92,9 @@ def test_erosion_serial_flag_and_overflow_fallback(pkg, emul, orc):
     assert r.serial_fallbacks >= 1 and r.windows >= 7
 
 
-@pytest.mark.parametrize("n,iters,window,slice_steps,blk_cap", [(128, 2000, 32, 4, 0), (256, 3000, 64, 16, 0), (96, 1500, 16, 1, 0), (256, 1200, 48, 8, 12), (192, 900, 7, 3, 0)])
-def test_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk_cap):
-    r, _ = pc.case_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk_cap)
+@pytest.mark.parametrize("n,iters,window,slice_steps,blk_cap,near", [(128, 2000, 32, 4, 0, 0), (256, 3000, 64, 16, 0, 8), (96, 1500, 16, 1, 0, 0), (256, 1200, 48, 8, 12, 0), (192, 900, 7, 3, 0, 2), (256, 2500, 64, 16, 0, 100000)])
+def test_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk_cap, near):
+    r, _ = pc.case_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk_cap, near=near)
     assert r.rounds > r.windows
     if blk_cap:
         assert r.serial_fallbacks >= 1
