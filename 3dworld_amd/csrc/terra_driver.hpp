@@ -666,9 +666,12 @@ template<class BE> struct terra_engine {
 	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched) {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
-		// ring slots: more droplets in flight = more parallel work but also more speculation on stale cells; measured best (MI355X, 10^5..10^6 droplets
-		// on 4096^2..16384^2) near one slot per 16K cells.  256 pages of 64 floats per slot and buffer: 16384 slots = 2 GiB of the 288.
-		uint32_t const auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)ec.NX*ec.NY) >> 14, 2048), 16384);
+		// ring slots: more droplets in flight = more parallel work and fewer rounds, but also more speculation on stale cells and longer writer lists.  Measured
+		// (MI355X, 10^5..10^6 droplets, profiles/r02_erosion_ring_size_sweep.txt): best near one slot per 8K cells on sparse maps (8192^2: 8192 slots, 16384^2: 32768),
+		// 3072-4096 slots on a dense 4096^2, 2048 on 1024^2 (4096 slots there double the re-traces).  256 pages of 64 floats per slot and buffer: 32768 slots = 4.4 GiB of the 288.
+		uint64_t const ncells = (uint64_t)ec.NX*ec.NY;
+		uint32_t auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ncells >> 13, 2048), 32768);
+		if (ncells >= (1ull << 24)) {auto_w = std::max<uint32_t>(auto_w, 4096);}
 		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
 		sb.W = W;

@@ -337,6 +337,8 @@ struct direct_mem_t {
 #define TERRA_LANES(l, n) for (int l = (int)(threadIdx.x & 63); l < (int)(n); l += 64)
 #define TERRA_EACH_LANE(l) for (int l = (int)(threadIdx.x & 63), l##_once = 1; l##_once; l##_once = 0)
 #define TERRA_LANE0 ((threadIdx.x & 63) == 0)
+#define TERRA_LANE_SLOTS 1          // per-lane values that live across a wave sync: registers on the device ...
+#define TERRA_LANE_SLOT(l) 0
 #define TERRA_WAVE_SYNC() __syncthreads()
 #define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define TERRA_ATOMIC_MAX(p, v) atomicMax((p), (v))
@@ -349,6 +351,8 @@ struct direct_mem_t {
 #define TERRA_LANES(l, n) for (int l = 0; l < (int)(n); ++l)
 #define TERRA_EACH_LANE(l) for (int l = 0; l < 64; ++l)
 #define TERRA_LANE0 true
+#define TERRA_LANE_SLOTS 64         // ... one array row per lane on the host, where the lanes of a TERRA_EACH_LANE loop run one after another
+#define TERRA_LANE_SLOT(l) (l)
 #define TERRA_WAVE_SYNC() do {} while (0)
 template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
 template<class T> inline T terra_host_atomic_max(T *p, T v) {T o = *p; if (v > o) *p = v; return o;}
@@ -469,13 +473,13 @@ struct wave_shared_t { // per-wave LDS scratch
 };
 
 template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
-	float *win, *win_alt; uint8_t *dirty, *dirty_alt; // LDS: EW*EW each, double-buffered so a window shift copies the overlap LDS -> LDS
+	float *win; uint8_t *dirty; // LDS: EW*EW each.  A window move shifts the overlap in place (old cells to registers, wave sync, new positions)
 	int wx0, wz0, NX, NY; bool have;
 	int lead_x = 0, lead_z = 0; // where the droplet is heading (-1, 0, 1 per axis): a recentred window is placed ahead of it
 	unsigned long long clk_shift = 0, clk_sh_flush = 0, clk_sh_prep = 0, clk_sh_load = 0; // time inside recenter() and its parts (diagnostics)
 	int lead_mode = 2, steps_in_window = 0; // a window that lasted only a few steps means the droplet turned back (it circles in a pit): centre the next one instead
 	BACK back;
-	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; win_alt = w + EW*EW; dirty = d; dirty_alt = d + EW*EW; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
+	TERRA_HD void init(float *w, uint8_t *d, int nx, int ny) {win = w; dirty = d; NX = nx; NY = ny; wx0 = wz0 = 0; have = false;}
 	TERRA_HD bool in_window(int X, int Z) const {return have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;}
 	TERRA_HD float *cell(int X, int Z) const {return win + (Z - wz0)*EW + (X - wx0);}
 	TERRA_HD void mark(int X, int Z) {dirty[(Z - wz0)*EW + (X - wx0)] = 1;}
@@ -512,13 +516,16 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		unsigned long long const clk2 = TERRA_CLOCK();
 		unsigned long long clk3 = clk2; (void)clk3;
 		constexpr int PER_LANE = EW*EW/64;
+		float gv[TERRA_LANE_SLOTS][PER_LANE]; uint32_t dbits[TERRA_LANE_SLOTS]; // a lane's 16 cells of the new window and their dirty bits
 		TERRA_EACH_LANE(lane) {
-			float gv[PER_LANE];
+			float (&g)[PER_LANE] = gv[TERRA_LANE_SLOT(lane)];
+			uint32_t db = 0;
 #pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) { // the plain grid loads of all entering cells first: independent, they overlap in flight (one memory latency per move) ...
+			for (int k = 0; k < PER_LANE; ++k) { // the plain grid loads of all entering cells first: independent, they overlap in flight (one memory latency per move); cells that stay come from the old window
 				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
 				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
-				gv[k] = (!in_old && X < NX && Z < NY) ? back.base(X, Z) : 0.0f;
+				if (in_old) {int const o = (Z - wz0)*EW + (X - wx0); g[k] = win[o]; db |= (uint32_t)(dirty[o] != 0) << k;}
+				else {g[k] = (X < NX && Z < NY) ? back.base(X, Z) : 0.0f;}
 			}
 			constexpr int CH = 8; // (all 16 cells in one piece cost too many registers)
 #pragma unroll
@@ -542,17 +549,22 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 				}
 #pragma unroll
 				for (int k = 0; k < CH; ++k) {
-					int const i = (k0 + k)*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-					bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
-					float val = ((alt_mask >> k) & 1u) ? av[k] : gv[k0 + k]; uint8_t d = 0;
-					if (in_old) {int const o = (Z - wz0)*EW + (X - wx0); val = win[o]; d = dirty[o];}
-					else if (TERRA_UNLIKELY((slow_mask >> k) & 1u)) {val = back.lookup(X, Z, val);} // a block with many lower versions: walk its list
-					win_alt[i] = val; dirty_alt[i] = d;
+					if ((alt_mask >> k) & 1u) {g[k0 + k] = av[k];}
+					else if (TERRA_UNLIKELY((slow_mask >> k) & 1u)) { // a block with many lower versions: walk its list
+						int const i = (k0 + k)*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
+						g[k0 + k] = back.lookup(X, Z, g[k0 + k]);
+					}
 				}
 			}
+			dbits[TERRA_LANE_SLOT(lane)] = db;
 		}
-		float *tw = win; win = win_alt; win_alt = tw;
-		uint8_t *td = dirty; dirty = dirty_alt; dirty_alt = td;
+		TERRA_WAVE_SYNC(); // every lane has taken what it needs from the old window: the new one goes into the same LDS
+		TERRA_EACH_LANE(lane) {
+			float const (&g)[PER_LANE] = gv[TERRA_LANE_SLOT(lane)];
+			uint32_t const db = dbits[TERRA_LANE_SLOT(lane)];
+#pragma unroll
+			for (int k = 0; k < PER_LANE; ++k) {int const i = k*64 + lane; win[i] = g[k]; dirty[i] = (uint8_t)((db >> k) & 1u);}
+		}
 		wx0 = nx0; wz0 = nz0; have = true;
 		TERRA_WAVE_SYNC();
 		unsigned long long const clk4 = TERRA_CLOCK();
@@ -913,7 +925,7 @@ struct spec_back_t {
 // ---- wave bodies: one call per droplet-wave (device: one 64-lane workgroup; host: one call)
 
 // LDS scratch a wave body needs; the kernels / the emulator provide it
-struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;}; // win / dirty hold 2*EW*EW entries (double-buffered window)
+struct wave_scratch_t {float *win; uint8_t *dirty; wave_shared_t *sh;}; // win / dirty hold EW*EW entries
 
 TERRA_HD bool spec_slot_active(spec_buffers_t const &sb, uint32_t slot, uint32_t &iter) { // holds a droplet that is not paused
 	iter = sb.it[slot];

@@ -20,8 +20,8 @@ template<class F> __global__ void k_generic(size_t n, F f) {
 
 // one 64-lane workgroup (= one wave) per item, with the per-wave LDS scratch of the droplet window (terra_erosion.hpp)
 template<class F> __global__ __launch_bounds__(64) void k_waves(F f, unsigned first) {
-	__shared__ __attribute__((aligned(16))) float win[2*EW*EW];
-	__shared__ uint8_t dirty[2*EW*EW];
+	__shared__ __attribute__((aligned(16))) float win[EW*EW];
+	__shared__ uint8_t dirty[EW*EW];
 	__shared__ wave_shared_t sh;
 	wave_scratch_t const ws{win, dirty, &sh};
 	f((size_t)blockIdx.x + first, ws);

@@ -37,7 +37,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	template<class F> void launch(size_t n, F f, int = 256) {for (size_t i = 0; i < n; ++i) f(i);}
 	// a "wave" is one call; its LDS scratch is a few stack arrays
 	template<class F> void launch_waves(size_t n, F f) {
-		std::vector<float> win(2*terra::EW*terra::EW); std::vector<uint8_t> dirty(2*terra::EW*terra::EW); terra::wave_shared_t sh;
+		std::vector<float> win(terra::EW*terra::EW); std::vector<uint8_t> dirty(terra::EW*terra::EW); terra::wave_shared_t sh;
 		terra::wave_scratch_t const ws{win.data(), dirty.data(), &sh};
 		for (size_t i = 0; i < n; ++i) f(i, ws);
 	}
