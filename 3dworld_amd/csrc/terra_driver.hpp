@@ -674,6 +674,8 @@ template<class BE> struct terra_engine {
 		if (ncells >= (1ull << 24)) {auto_w = std::max<uint32_t>(auto_w, 4096);}
 		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
+		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = 8;
+		if (char const *ck = getenv("TERRA_ERO_CK")) {int a = 0, b = 0; if (sscanf(ck, "%d:%d", &a, &b) == 2 && a >= 1 && b >= 0 && b <= (int)SPEC_CK_MAX) {sb.ck_steps = (uint32_t)a; sb.ck_max = (uint32_t)b;}} // experiment knob "steps:max"; results never depend on it
 		sb.W = W;
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block
 		if (char const *nc = getenv("TERRA_ERO_NEAR")) {int const v = atoi(nc); sb.near_count = (v >= 0) ? (uint32_t)v : W/(uint32_t)(-v);} // experiment knob (negative: a fraction of the ring); results never depend on it
@@ -682,9 +684,13 @@ template<class BE> struct terra_engine {
 		// carve one allocation
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
-		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_chk[2];
+		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_chk[2], o_cks[2], o_ckn[2], o_cku[2], o_ckm[2], o_ckc[2], o_ui[2], o_uv[2], o_un[2];
 		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
-		size_t const o_slot = carve((size_t)W*4*9); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps
+		for (int b = 0; b < 2; ++b) {
+			o_cks[b] = carve((size_t)W*SPEC_CK_MAX*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*SPEC_CK_MAX*4); o_cku[b] = carve((size_t)W*SPEC_CK_MAX*4);
+			o_ckm[b] = carve((size_t)W*SPEC_CK_MAX*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_uv[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_un[b] = carve(W*4);
+		}
+		size_t const o_slot = carve((size_t)W*4*12); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, rsrc, rat, rentry
 		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
 		size_t const o_next = carve((size_t)W*sb.maxb*4), o_nodeblk = carve((size_t)W*sb.maxb*4), o_dlist = carve((size_t)W*sb.maxb*8), o_ctl = carve(sizeof(spec_ctl_t));
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
@@ -692,11 +698,15 @@ template<class BE> struct terra_engine {
 		uint8_t *base = scratch<uint8_t>(s_spec, off);
 		for (int b = 0; b < 2; ++b) {
 			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]); // nothing to initialise: only entries below a version's count are ever read
+			sb.ck_state[b] = (droplet_state_t *)(base + o_cks[b]); sb.ck_nblk[b] = (uint32_t *)(base + o_ckn[b]); sb.ck_undo[b] = (uint32_t *)(base + o_cku[b]);
+			sb.ck_masks[b] = (unsigned long long *)(base + o_ckm[b]); sb.ck_cnt[b] = (uint32_t *)(base + o_ckc[b]);
+			sb.undo_idx[b] = (uint32_t *)(base + o_ui[b]); sb.undo_val[b] = (float *)(base + o_uv[b]); sb.undo_n[b] = (uint32_t *)(base + o_un[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]); sb.chk[b] = (uint64_t *)(base + o_chk[b]);
 		}
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
 		sb.it = slot_arrays; sb.phase = slot_arrays + W; sb.has_ver = slot_arrays + 2*(size_t)W; sb.cur = slot_arrays + 3*(size_t)W; sb.changed = slot_arrays + 4*(size_t)W;
 		sb.restart = slot_arrays + 5*(size_t)W; sb.run_nblk = slot_arrays + 6*(size_t)W; sb.flags = slot_arrays + 7*(size_t)W; sb.nsteps = slot_arrays + 8*(size_t)W;
+		sb.rsrc = slot_arrays + 9*(size_t)W; sb.rat = slot_arrays + 10*(size_t)W; sb.rentry = slot_arrays + 11*(size_t)W;
 		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
 		sb.next = (uint32_t *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.ctl = (spec_ctl_t *)(base + o_ctl);
@@ -707,8 +717,10 @@ template<class BE> struct terra_engine {
 		if (spec_blocks_clean != blk_arrays || spec_blocks_n != nblocks) {be.fill32(blk_arrays, SPEC_NIL, 2*nblocks);}
 		spec_blocks_clean = nullptr; // not clean again until this run has taken its lists apart
 		spec_buffers_t const s = sb;
-		be.fill32(slot_arrays, 0, (size_t)W*9);
+		be.fill32(slot_arrays, 0, (size_t)W*10);
+		be.fill32(sb.rat, SPEC_NIL, (size_t)W*2); // rat, rentry
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
+		for (int b = 0; b < 2; ++b) {be.fill32(sb.ck_cnt[b], 0, W); be.fill32(sb.undo_n[b], 0, W);}
 		be.fill32(sb.node_blk, SPEC_NIL, (size_t)W*sb.maxb);
 		be.launch(W, [=] TERRA_LAMBDA (size_t i) { // the first W droplets take the slots (num_iters >= W)
 			s.it[i] = (uint32_t)i; s.phase[i] = SPEC_FRESH;
@@ -773,7 +785,7 @@ template<class BE> struct terra_engine {
 		be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);}); // leave head[] all-NIL (dirty_min[] already is)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
-		report.rounds = hc.rounds; report.retraces_same = hc.retraces_same;
+		report.rounds = hc.rounds; report.retraces_same = hc.retraces_same; report.checkpoint_resumes = hc.ck_resumes; report.checkpoint_steps_saved = hc.ck_steps_saved;
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;
 		report.critical_steps = hc.crit_steps; report.critical_shifts = hc.crit_shifts;

@@ -457,12 +457,16 @@ constexpr unsigned SPEC_MAP_SLOTS = 512; // open-addressed block -> entry map of
 constexpr unsigned SPEC_PAGE = 64;       // cells of an 8 x 8 block = floats of a version page
 constexpr unsigned SPEC_WIN_BLOCKS = ((EW >> 3) + 1)*((EW >> 3) + 1); // blocks a window can overlap
 constexpr unsigned SPEC_CAND = 4, SPEC_CAND_MANY = 255;
+// checkpoints of a trace: every SPEC_CK_STEPS steps the window's dirty cells are written back and the droplet state, the footprint length, the write masks and
+// the position in the undo log are saved, so that a re-trace can resume from the last checkpoint whose inputs are still valid instead of from the spawn
+constexpr unsigned SPEC_CK_STEPS = 64, SPEC_CK_MAX = 16, SPEC_UNDO_MAX = 4096; // (defaults: spec_buffers_t::ck_steps / ck_max are the values in force, ck_max <= SPEC_CK_MAX)
 // where a cell entering the window is read from: the grid, nothing (it stays in the window / lies outside the grid), the grid + a walk of the block's writer list,
 // or float index (bits 0..29) into version buffer (bit 31); bit 30: the page is this trace's own
 constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu, SPEC_SRC_NONE = 0xFFFFFFFEu, SPEC_SRC_SLOW = 0xFFFFFFFDu, SPEC_SRC_OWN_BIT = 0x40000000u;
 struct spec_cand_t {uint32_t page, it; unsigned long long mask;}; // page = slot*maxb + entry, bit 31: the version buffer
 struct wave_shared_t { // per-wave LDS scratch
 	uint32_t flags, pad_;
+	uint32_t undo_n, pad1_;                  // entries of the trace's undo log
 	uint32_t n_shift, n_own, n_ver, n_store; // diagnostics of the trace (terra_erosion_report)
 	unsigned long long chk;
 	uint8_t blk_shared[64];                  // per block under the window: number of published LOWER versions that wrote it (SPEC_CAND_MANY: more than fit below)
@@ -632,7 +636,7 @@ struct grid_back_t {
 // ------------------------------------------------------------------ speculative (multi-version) backing store
 constexpr uint32_t SPEC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SPEC_NIL   = 0xFFFFFFFFu;
-enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4};
+enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4, SPEC_F_UNDO_OVERFLOW = 8};
 constexpr uint32_t SPEC_BLK_WRITTEN = 0x80000000u; // block-list entry flag: the droplet may have WRITTEN cells of the block (else it only read them)
 // life of a ring slot: FRESH (trace from the spawn) -> RUNNING (trace suspended at a step boundary, state saved) -> DONE_NEW (finished in
 // this round, not published yet) -> IDLE (its finished version is published and believed valid); FAILED = the trace overflowed its log or
@@ -653,6 +657,8 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t fb_steps, fb_nan; // fall-back droplet
 	uint32_t ndirty;       // entries of dirty_list
 	uint32_t round_max_steps, round_max_shifts; // most steps / window moves of one trace in this round (diagnostics)
+	uint32_t ck_resumes, pad4_;                 // re-traces that resumed from a checkpoint
+	unsigned long long ck_steps_saved;          // steps those did not have to repeat
 	uint32_t rounds, retraces_same;             // rounds that had work to do (the host launches them in batches and may overshoot the end); re-traces that reproduced the published version
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
 	unsigned long long n_shift, n_own, n_ver, n_store; // diagnostics summed over all traces
@@ -664,13 +670,14 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	unsigned long long crit_own_shift, crit_own_edge, crit_own_steps; // the packed fields summed over the rounds
 	unsigned long long round_max_pack2, crit_own_flush, crit_own_load, crit_own_prep; // same key: ticks << 44 | write-back << 28 | plain loads << 14 | block flags
 };
-struct spec_resume_t {uint32_t nblk, flags;}; // spec_back_t state of a suspended trace (its masks and pages are in the version buffer)
+struct spec_resume_t {uint32_t nblk, flags, undo_n, nck;}; // spec_back_t state of a suspended trace (its masks and pages are in the version buffer)
 
 struct spec_buffers_t {
 	grid_view_t grid;
 	erosion_consts_t ec;
 	uint32_t num_iters;    // droplets of the whole run
 	uint32_t W;            // ring slots; droplet `it` lives in slot it % W, in-flight droplets are [base, base + W)
+	uint32_t ck_steps, ck_max; // steps between checkpoints of a trace, most checkpoints per trace (0: no checkpoints)
 	uint32_t near_count;   // the first near_count in-flight droplets (the next to commit) trace without a step budget; the others are sliced (0: all sliced)
 	uint32_t maxb;         // block-list capacity per droplet (<= SPEC_MAXB)
 	uint32_t bshift;       // block edge = 1 << bshift cells (3: a page holds the 8 x 8 cells of a block)
@@ -683,6 +690,17 @@ struct spec_buffers_t {
 	uint32_t *blk_list[2]; // [W][maxb] distinct blocks, in the order the trace met them
 	uint32_t *blk_cnt[2];  // [W]
 	uint64_t *chk[2];      // [W] checksum of the version's content (+ step count)
+	// checkpoints of the trace in each buffer (see SPEC_CK_STEPS) and its undo log: (float index into the slot's pages, value it held) of every write-back that
+	// changed a cell written back before, in order -- rolling the pages back to a checkpoint = its masks + the log entries after it, newest first
+	droplet_state_t *ck_state[2];       // [W][SPEC_CK_MAX]
+	uint32_t *ck_nblk[2], *ck_undo[2];  // [W][SPEC_CK_MAX] footprint length / undo-log length at the checkpoint
+	unsigned long long *ck_masks[2];    // [W][SPEC_CK_MAX][maxb]
+	uint32_t *ck_cnt[2];                // [W] checkpoints of the buffer's trace (0: none usable)
+	uint32_t *undo_idx[2]; float *undo_val[2]; // [W][SPEC_UNDO_MAX]
+	uint32_t *undo_n[2];                // [W] log length when the trace stopped
+	uint32_t *rentry;      // [W] lowest footprint entry of the slot's trace that a changed lower version touched this round (mark pass; SPEC_NIL: none)
+	uint32_t *rsrc;        // [W] pending re-trace: 0 = from the spawn, 1 = may resume from a checkpoint of the published version, 2 = of the suspended trace
+	uint32_t *rat;         // [W] ... whose footprint is valid below this entry
 	uint32_t *it;          // [W] droplet number held by the slot (SPEC_NIL: none)
 	uint32_t *phase;       // [W]
 	uint32_t *has_ver;     // [W] buffer cur[] holds a published finished version (visible to higher droplets)
@@ -717,7 +735,9 @@ struct spec_back_t {
 	wave_shared_t *sh;     // LDS
 	uint32_t slot, iter;
 	float *my_pages; unsigned long long *my_masks; uint32_t *my_blks; // the version being built (buffer 1 - cur)
+	uint32_t *my_undo_idx; float *my_undo_val;
 	uint32_t nblk;
+	bool log_undo = false; // the trace has a checkpoint: write-backs that change a cell written back before are logged
 	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
 	int lx0 = INT_MIN, lx1 = INT_MIN, lz0 = INT_MIN, lz1 = INT_MIN; // block range of the previous step's brush box
@@ -744,24 +764,77 @@ struct spec_back_t {
 		my_pages = sb->page_vals[nb] + (size_t)slot*sb->maxb*SPEC_PAGE;
 		my_masks = sb->page_mask[nb] + (size_t)slot*sb->maxb;
 		my_blks  = sb->blk_list[nb] + (size_t)slot*sb->maxb;
+		my_undo_idx = sb->undo_idx[nb] + (size_t)slot*SPEC_UNDO_MAX; my_undo_val = sb->undo_val[nb] + (size_t)slot*SPEC_UNDO_MAX;
+		log_undo = rs ? (rs->nck != 0) : false;
 		nblk = rs ? rs->nblk : 0;
 		blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
 		lx0 = lx1 = lz0 = lz1 = INT_MIN;
-		if (TERRA_LANE0) {sh->flags = rs ? rs->flags : 0; sh->chk = 0; sh->n_shift = sh->n_own = sh->n_ver = sh->n_store = 0;}
-		TERRA_LANES(h, SPEC_MAP_SLOTS) {sh->map_keys[h] = SPEC_NIL;}
-		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nblk) ? my_masks[e] : 0ull;} // a resumed trace: what it has written back so far (saved by suspend())
+		if (TERRA_LANE0) {sh->flags = rs ? rs->flags : 0; sh->undo_n = rs ? rs->undo_n : 0; sh->chk = 0; sh->n_shift = sh->n_own = sh->n_ver = sh->n_store = 0;}
+		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nblk) ? my_masks[e] : 0ull;} // a resumed trace: what it has written back so far (saved when it was suspended)
 		TERRA_WAVE_SYNC();
-		if (nblk) { // a resumed trace: the map is rebuilt from the block list (distinct blocks: every lane claims a free slot for each of its entries)
-			TERRA_LANES(e, nblk) {
-				uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN;
-				for (uint32_t h = map_hash(b);; h = (h + 1) & (SPEC_MAP_SLOTS - 1)) {
-					if (TERRA_ATOMIC_CAS(&sh->map_keys[h], SPEC_NIL, b) == SPEC_NIL) {sh->map_ent[h] = (uint8_t)e; break;}
-				}
+		rebuild_map(); // (empty for a new trace)
+	}
+	TERRA_HD void save(spec_resume_t &rs, uint32_t nck) const {rs.nblk = nblk; rs.flags = sh->flags; rs.undo_n = (sh->undo_n < SPEC_UNDO_MAX) ? sh->undo_n : SPEC_UNDO_MAX; rs.nck = nck;}
+	TERRA_HD void rebuild_map() { // from my_blks[0 .. nblk): distinct blocks, every lane claims a free slot for each of its entries
+		TERRA_LANES(h, SPEC_MAP_SLOTS) {sh->map_keys[h] = SPEC_NIL;}
+		TERRA_WAVE_SYNC();
+		TERRA_LANES(e, nblk) {
+			uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN;
+			for (uint32_t h = map_hash(b);; h = (h + 1) & (SPEC_MAP_SLOTS - 1)) {
+				if (TERRA_ATOMIC_CAS(&sh->map_keys[h], SPEC_NIL, b) == SPEC_NIL) {sh->map_ent[h] = (uint8_t)e; break;}
 			}
+		}
+		TERRA_WAVE_SYNC();
+	}
+	// checkpoint k of this trace (the window's dirty cells have just been written back): footprint length, masks, undo-log length, droplet state
+	TERRA_HD void ck_save(uint32_t k, droplet_state_t const &d) {
+		uint32_t const nb = 1u - sb->cur[slot];
+		size_t const cbase = (size_t)slot*SPEC_CK_MAX + k;
+		unsigned long long *ckm = sb->ck_masks[nb] + cbase*sb->maxb;
+		TERRA_LANES(e, nblk) {ckm[e] = sh->masks[e];}
+		if (TERRA_LANE0) {sb->ck_state[nb][cbase] = d; sb->ck_nblk[nb][cbase] = nblk; sb->ck_undo[nb][cbase] = (sh->undo_n < SPEC_UNDO_MAX) ? sh->undo_n : SPEC_UNDO_MAX;}
+		TERRA_WAVE_SYNC();
+	}
+	// Start this trace from checkpoint k of the slot's trace in buffer `sbuf`: either the suspended trace in this trace's own buffer (rolled back in place) or the
+	// published version in the other buffer (copied: readers keep using it until the new version is published).  Afterwards footprint, masks, pages, undo log and
+	// the checkpoints 0 .. k of this trace are what they were when that checkpoint was taken; the LDS window is empty and is fetched afresh.
+	TERRA_HD void ck_restore(uint32_t sbuf, uint32_t k, droplet_state_t &d) {
+		uint32_t const nb = 1u - sb->cur[slot];
+		bool const copy = (sbuf != nb);
+		size_t const pbase = (size_t)slot*sb->maxb, cb0 = (size_t)slot*SPEC_CK_MAX, ub = (size_t)slot*SPEC_UNDO_MAX;
+		float const *s_pages = sb->page_vals[sbuf] + pbase*SPEC_PAGE;
+		uint32_t const *s_blks = sb->blk_list[sbuf] + pbase, *s_uidx = sb->undo_idx[sbuf] + ub;
+		float const *s_uval = sb->undo_val[sbuf] + ub;
+		uint32_t const nk = sb->ck_nblk[sbuf][cb0 + k], uk = sb->ck_undo[sbuf][cb0 + k], un = sb->undo_n[sbuf][slot];
+		d = sb->ck_state[sbuf][cb0 + k];
+		unsigned long long const *s_ckm = sb->ck_masks[sbuf] + (cb0 + k)*sb->maxb;
+		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nk) ? s_ckm[e] : 0ull;}
+		TERRA_WAVE_SYNC();
+		if (copy) {
+			TERRA_LANES(e, nk) {my_blks[e] = s_blks[e] & ~SPEC_BLK_WRITTEN;}
+			for (uint32_t e = 0; e < nk; ++e) { // page by page, lane c = cell c
+				unsigned long long const m = sh->masks[e];
+				if (!m) continue;
+				TERRA_EACH_LANE(c) {if ((m >> c) & 1ull) {my_pages[(size_t)e*SPEC_PAGE + c] = s_pages[(size_t)e*SPEC_PAGE + c];}}
+			}
+			TERRA_LANES(i, (k + 1)*sb->maxb) {sb->ck_masks[nb][cb0*sb->maxb + i] = sb->ck_masks[sbuf][cb0*sb->maxb + i];}
+			TERRA_LANES(i, k + 1) {sb->ck_state[nb][cb0 + i] = sb->ck_state[sbuf][cb0 + i]; sb->ck_nblk[nb][cb0 + i] = sb->ck_nblk[sbuf][cb0 + i]; sb->ck_undo[nb][cb0 + i] = sb->ck_undo[sbuf][cb0 + i];}
+			TERRA_LANES(q, uk) {my_undo_idx[q] = s_uidx[q]; my_undo_val[q] = s_uval[q];}
 			TERRA_WAVE_SYNC();
 		}
+		// the log entries after the checkpoint, newest first: a cell rewritten since gets back what it held at the checkpoint (the oldest entry after it, applied last)
+		if (TERRA_LANE0) {
+			for (uint32_t q = un; q-- > uk;) {
+				uint32_t const idx = s_uidx[q], e = idx / SPEC_PAGE;
+				if (e < nk && ((sh->masks[e] >> (idx % SPEC_PAGE)) & 1ull)) {my_pages[idx] = s_uval[q];}
+			}
+		}
+		TERRA_WAVE_SYNC();
+		nblk = nk;
+		if (TERRA_LANE0) {sh->undo_n = uk;}
+		rebuild_map();
+		log_undo = true;
 	}
-	TERRA_HD void save(spec_resume_t &rs) const {rs.nblk = nblk; rs.flags = sh->flags;}
 	// the trace stops (finished or suspended): masks to global memory, written flags into the block list
 	TERRA_HD void publish_masks() const {
 		TERRA_LANES(e, nblk) {
@@ -917,7 +990,17 @@ struct spec_back_t {
 		TERRA_ATOMIC_ADD(&sh->n_store, 1u);
 		uint32_t const e = map_find(block_of(X, Z)), c = page_cell(X, Z);
 		if (TERRA_UNLIKELY(e == SPEC_NIL)) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW); return;} // every written cell lies in a recorded brush box: never happens
-		my_pages[(size_t)e*SPEC_PAGE + c] = val;
+		uint32_t const idx = e*SPEC_PAGE + c;
+		if (log_undo && ((sh->masks[e] >> c) & 1ull)) { // the cell was written back before, possibly before a checkpoint: remember what it held
+			float const old = TERRA_L2_LOAD(&my_pages[idx]);
+			uint32_t ob, nbits; memcpy(&ob, &old, 4); memcpy(&nbits, &val, 4);
+			if (ob != nbits) {
+				uint32_t const q = TERRA_ATOMIC_ADD(&sh->undo_n, 1u);
+				if (q < SPEC_UNDO_MAX) {my_undo_idx[q] = idx; my_undo_val[q] = old;}
+				else {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_UNDO_OVERFLOW);}
+			}
+		}
+		my_pages[idx] = val;
 		TERRA_ATOMIC_OR(&sh->masks[e], 1ull << c);
 	}
 };
@@ -948,18 +1031,51 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	mem.lead_mode = sb.ec.lead_mode;
 	droplet_state_t d;
 	bool finished = false;
+	uint32_t nck = 0;            // checkpoints of this trace so far
+	unsigned steps_before = 0;   // the droplet's step count when this wave took over
 	if (ph == SPEC_FRESH) {
 		mem.back.init(&sb, slot, iter, ws.sh, nullptr);
-		finished = !droplet_start((int)iter, mem, sb.ec, d);
+		bool resumed = false;
+		uint32_t const rs = sb.rsrc[slot];
+		if (rs) { // a re-trace: the slot's previous trace is valid up to the footprint entry the mark pass found; its last checkpoint before that entry is where this one starts
+			uint32_t const sbuf = (rs == 1u) ? sb.cur[slot] : 1u - sb.cur[slot], cnt = sb.ck_cnt[sbuf][slot], upto = sb.rat[slot];
+			uint32_t k = SPEC_NIL;
+			for (uint32_t i = 0; i < cnt; ++i) {if (sb.ck_nblk[sbuf][(size_t)slot*SPEC_CK_MAX + i] <= upto) {k = i;}} // footprint lengths grow with the checkpoint number
+			if (k != SPEC_NIL) {
+				mem.back.ck_restore(sbuf, k, d);
+				nck = k + 1; steps_before = d.numMoves; resumed = true;
+				if (TERRA_LANE0) {TERRA_ATOMIC_ADD(&sb.ctl->ck_resumes, 1u); TERRA_ATOMIC_ADD(&sb.ctl->ck_steps_saved, (unsigned long long)d.numMoves);}
+			}
+		}
+		if (!resumed) {finished = !droplet_start((int)iter, mem, sb.ec, d);}
 	}
 	else {
 		d = sb.state[slot];
 		mem.back.init(&sb, slot, iter, ws.sh, &sb.resume[slot]);
+		nck = sb.resume[slot].nck; steps_before = d.numMoves;
 	}
 	unsigned long long const clk_b = TERRA_CLOCK();
-	if (!finished) {finished = droplet_run_fast(d, mem, sb.ec, budget);}
+	{ // the trace runs from checkpoint to checkpoint; a checkpoint = all dirty cells of the window written back (the window stays) + the state saved
+		unsigned used_total = 0;
+		unsigned last_ck = nck ? sb.ck_state[1u - sb.cur[slot]][(size_t)slot*SPEC_CK_MAX + nck - 1].numMoves : 0u;
+		bool ck_on = true;
+		while (!finished) {
+			unsigned seg = DROPLET_NO_BUDGET;
+			if (ck_on && nck < sb.ck_max) {unsigned const since = d.numMoves - last_ck; seg = (since >= sb.ck_steps) ? 1u : sb.ck_steps - since;}
+			if (budget != DROPLET_NO_BUDGET) {unsigned const left = budget - used_total; seg = (seg < left) ? seg : left;}
+			unsigned const before = d.numMoves;
+			finished = droplet_run_fast(d, mem, sb.ec, seg);
+			used_total += d.numMoves - before;
+			if (finished || mem.back.failed()) break;
+			if (budget != DROPLET_NO_BUDGET && used_total >= budget) break; // suspended until the next round
+			if (!(ck_on && nck < sb.ck_max) || d.numMoves - last_ck < sb.ck_steps) continue;
+			mem.flush();
+			if (ws.sh->flags & SPEC_F_UNDO_OVERFLOW) {ck_on = false; nck = 0; mem.back.log_undo = false;} // the log is incomplete: no checkpoint of this trace can be restored
+			else {mem.back.ck_save(nck, d); ++nck; last_ck = d.numMoves; mem.back.log_undo = true;}
+		}
+		if (ws.sh->flags & SPEC_F_UNDO_OVERFLOW) {nck = 0;}
+	}
 	unsigned long long const clk_c = TERRA_CLOCK();
-	unsigned const steps_before = (ph == SPEC_FRESH) ? 0u : sb.state[slot].numMoves;
 	mem.finish(); // the window's dirty cells go to the pages: a suspended trace keeps nothing but its masks in LDS, and those are saved next
 	mem.back.publish_masks();
 	// "unchanged" is decided by the content checksum; before a version is declared equal to the published one (which spares every higher droplet a
@@ -1004,6 +1120,9 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
 		bool const failed = (fl & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW)) != 0;
 		sb.run_nblk[slot] = mem.back.nblk;
+		sb.ck_cnt[nb][slot] = failed ? 0u : nck;
+		sb.undo_n[nb][slot] = (ws.sh->undo_n < SPEC_UNDO_MAX) ? ws.sh->undo_n : SPEC_UNDO_MAX;
+		if (ph == SPEC_FRESH) {sb.rsrc[slot] = 0;}
 		if (finished || failed) {
 			uint64_t const chk = chk_new;
 			sb.blk_cnt[nb][slot] = mem.back.nblk;
@@ -1016,7 +1135,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		}
 		else {
 			sb.state[slot] = d;
-			mem.back.save(sb.resume[slot]);
+			mem.back.save(sb.resume[slot], nck);
 			sb.phase[slot] = SPEC_RUNNING;
 		}
 		if (ph == SPEC_FRESH) {TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u);}
@@ -1102,18 +1221,23 @@ TERRA_HD void spec_unlink_body(spec_buffers_t const &sb, uint32_t node) {
 TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
 	uint32_t const iter = sb.it[slot];
 	if (iter == SPEC_NIL) return;
-	uint32_t const ph = sb.phase[slot], cb = sb.cur[slot];
+	uint32_t const ph = sb.phase[slot], cb = sb.cur[slot], rs = sb.rsrc[slot];
 	uint32_t const *bl; uint32_t cnt;
-	if (ph == SPEC_RUNNING || ph == SPEC_FAILED) {bl = sb.blk_list[1u - cb] + (size_t)slot*sb.maxb; cnt = sb.run_nblk[slot];}
-	else if (ph == SPEC_IDLE && sb.has_ver[slot]) {bl = sb.blk_list[cb] + (size_t)slot*sb.maxb; cnt = sb.blk_cnt[cb][slot];}
+	if (ph == SPEC_RUNNING || ph == SPEC_FAILED || (ph == SPEC_FRESH && rs == 2u)) {bl = sb.blk_list[1u - cb] + (size_t)slot*sb.maxb; cnt = sb.run_nblk[slot];} // (a pending re-trace that has not run yet -- the slot is
+	else if ((ph == SPEC_IDLE || (ph == SPEC_FRESH && rs == 1u)) && sb.has_ver[slot]) {bl = sb.blk_list[cb] + (size_t)slot*sb.maxb; cnt = sb.blk_cnt[cb][slot];}  // paused -- still answers for the trace it wants to resume)
 	else return;
-	if (entry < cnt && sb.dirty_min[bl[entry] & ~SPEC_BLK_WRITTEN] < iter) {sb.restart[slot] = 1;}
+	if (entry < cnt && sb.dirty_min[bl[entry] & ~SPEC_BLK_WRITTEN] < iter) {sb.restart[slot] = 1; TERRA_ATOMIC_MIN(&sb.rentry[slot], entry);} // entries are in first-touch order: the trace is valid below the lowest one hit
 }
 // apply the restarts, find the commit point and the lowest failed droplet: one thread per slot
 TERRA_HD void spec_scan_body(spec_buffers_t const &sb, uint32_t slot) {
 	uint32_t const iter = sb.it[slot];
 	if (iter == SPEC_NIL) return;
-	if (sb.restart[slot]) {sb.restart[slot] = 0; sb.phase[slot] = SPEC_FRESH;}
+	if (sb.restart[slot]) {
+		uint32_t const hit = sb.rentry[slot], ph0 = sb.phase[slot];
+		sb.restart[slot] = 0; sb.rentry[slot] = SPEC_NIL;
+		if (ph0 == SPEC_FRESH) {if (hit < sb.rat[slot]) {sb.rat[slot] = hit;}} // a re-trace that is still waiting to run: its valid prefix got shorter
+		else {sb.rsrc[slot] = (ph0 == SPEC_IDLE) ? 1u : ((ph0 == SPEC_RUNNING) ? 2u : 0u); sb.rat[slot] = hit; sb.phase[slot] = SPEC_FRESH;}
+	}
 	uint32_t const ph = sb.phase[slot];
 	if (ph == SPEC_FAILED) {TERRA_ATOMIC_MIN(&sb.ctl->new_stop, iter);}
 	if (!(ph == SPEC_IDLE && sb.has_ver[slot])) {TERRA_ATOMIC_MIN(&sb.ctl->new_base, iter); TERRA_ATOMIC_ADD(&sb.ctl->unfinished, 1u);}
@@ -1150,6 +1274,7 @@ TERRA_HD void spec_reassign(spec_buffers_t const &sb, uint32_t slot, uint32_t it
 	uint64_t const nit = (uint64_t)iter + sb.W;
 	sb.it[slot] = (nit < sb.num_iters) ? (uint32_t)nit : SPEC_NIL;
 	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
+	sb.rsrc[slot] = 0; sb.rentry[slot] = SPEC_NIL; sb.rat[slot] = SPEC_NIL; sb.ck_cnt[0][slot] = 0; sb.ck_cnt[1][slot] = 0;
 }
 // committed droplets leave, their slots are handed to the next droplets: one thread per slot
 TERRA_HD void spec_admit_body(spec_buffers_t const &sb, uint32_t slot) {
@@ -1179,6 +1304,7 @@ TERRA_HD void spec_fallback_reset_body(spec_buffers_t const &sb, uint32_t slot) 
 	if (iter == SPEC_NIL) return;
 	if (iter == sb.ctl->base) {spec_reassign(sb, slot, iter); return;}
 	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
+	sb.rsrc[slot] = 0; sb.rentry[slot] = SPEC_NIL; sb.rat[slot] = SPEC_NIL; sb.ck_cnt[0][slot] = 0; sb.ck_cnt[1][slot] = 0; // the grid changed under every trace: nothing to resume from
 }
 TERRA_HD void spec_fallback_advance_body(spec_buffers_t const &sb) {
 	spec_ctl_t &c = *sb.ctl;

@@ -83,6 +83,8 @@ typedef struct terra_erosion_report {
 	uint64_t version_lookups;/* cells entering a window that lie in a block some lower in-flight droplet wrote (their value may come from its pages) */
 	uint64_t log_stores;     /* cells written back from a window to the version's pages */
 	uint64_t retraces_same;  /* re-traces that reproduced the published version bit for bit (the conflict that caused them was one of blocks, not of cells read) */
+	uint64_t checkpoint_resumes;     /* re-traces that started from a checkpoint of the droplet's previous trace instead of from its spawn */
+	uint64_t checkpoint_steps_saved; /* steps those re-traces did not have to repeat */
 	uint64_t critical_steps; /* sum over the rounds of the most steps any one trace made in the round: the scheduler's serial chain, in droplet steps */
 	uint64_t critical_shifts;/* the same for window moves */
 	/* device time in 10 ns ticks, summed over all traces: a trace's whole wave body / before its first step / inside window moves / after its last step;

@@ -27,5 +27,5 @@ for (w, sl, near) in combos:
     t.apply_erosion_dev(z.ptr, N, N, mn, D, pkg.ERODE_MINZ_IS_MIN)
     dt = time.perf_counter() - t0
     r = t.erosion_report().as_dict()
-    print(f"W {w} slice {sl} near {near}: rounds {r['rounds']} traces {r['traces']} (same again {r['retraces_same']}) steps {r['steps']} traced {r['traced_steps']} critical_steps {r['critical_steps']} critical_shifts {r['critical_shifts']} "
+    print(f"W {w} slice {sl} near {near}: rounds {r['rounds']} traces {r['traces']} (same again {r['retraces_same']}, from a checkpoint {r['checkpoint_resumes']} saving {r['checkpoint_steps_saved']} steps) steps {r['steps']} traced {r['traced_steps']} critical_steps {r['critical_steps']} critical_shifts {r['critical_shifts']} "
           f"shifts {r['window_shifts']} version_lookups {r['version_lookups']} fallbacks {r['serial_fallbacks']} (host {dt:.1f}s)", flush=True)
