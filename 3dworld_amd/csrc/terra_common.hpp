@@ -15,9 +15,11 @@
 #include <hip/hip_runtime.h>
 #define TERRA_HD __host__ __device__ __forceinline__
 #define TERRA_D  __device__ __forceinline__
+#define TERRA_HD_COLD __host__ __device__ __attribute__((noinline)) // rarely executed and large: a real call keeps its registers out of the caller's hot loop
 #define TERRA_LAMBDA __host__ __device__
 #else
 #define TERRA_HD inline
+#define TERRA_HD_COLD inline
 #define TERRA_D  inline
 #define TERRA_LAMBDA
 #endif

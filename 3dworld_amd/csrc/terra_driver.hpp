@@ -674,7 +674,7 @@ template<class BE> struct terra_engine {
 		if (ncells >= (1ull << 24)) {auto_w = std::max<uint32_t>(auto_w, 4096);}
 		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
-		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = 8;
+		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = SPEC_CK_MAX;
 		if (char const *ck = getenv("TERRA_ERO_CK")) {int a = 0, b = 0; if (sscanf(ck, "%d:%d", &a, &b) == 2 && a >= 1 && b >= 0 && b <= (int)SPEC_CK_MAX) {sb.ck_steps = (uint32_t)a; sb.ck_max = (uint32_t)b;}} // experiment knob "steps:max"; results never depend on it
 		sb.W = W;
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block
@@ -684,8 +684,8 @@ template<class BE> struct terra_engine {
 		// carve one allocation
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
-		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_chk[2], o_cks[2], o_ckn[2], o_cku[2], o_ckm[2], o_ckc[2], o_ui[2], o_uv[2], o_un[2];
-		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4); o_chk[b] = carve(W*8);}
+		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_cks[2], o_ckn[2], o_cku[2], o_ckm[2], o_ckc[2], o_ui[2], o_uv[2], o_un[2];
+		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4);}
 		for (int b = 0; b < 2; ++b) {
 			o_cks[b] = carve((size_t)W*SPEC_CK_MAX*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*SPEC_CK_MAX*4); o_cku[b] = carve((size_t)W*SPEC_CK_MAX*4);
 			o_ckm[b] = carve((size_t)W*SPEC_CK_MAX*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_uv[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_un[b] = carve(W*4);
@@ -701,7 +701,7 @@ template<class BE> struct terra_engine {
 			sb.ck_state[b] = (droplet_state_t *)(base + o_cks[b]); sb.ck_nblk[b] = (uint32_t *)(base + o_ckn[b]); sb.ck_undo[b] = (uint32_t *)(base + o_cku[b]);
 			sb.ck_masks[b] = (unsigned long long *)(base + o_ckm[b]); sb.ck_cnt[b] = (uint32_t *)(base + o_ckc[b]);
 			sb.undo_idx[b] = (uint32_t *)(base + o_ui[b]); sb.undo_val[b] = (float *)(base + o_uv[b]); sb.undo_n[b] = (uint32_t *)(base + o_un[b]);
-			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]); sb.chk[b] = (uint64_t *)(base + o_chk[b]);
+			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]);
 		}
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
 		sb.it = slot_arrays; sb.phase = slot_arrays + W; sb.has_ver = slot_arrays + 2*(size_t)W; sb.cur = slot_arrays + 3*(size_t)W; sb.changed = slot_arrays + 4*(size_t)W;
@@ -731,7 +731,7 @@ template<class BE> struct terra_engine {
 		uint32_t host_base = 0, launched = 0;
 		spec_ctl_t hc{};
 		size_t const nse = (size_t)W*sb.maxb;
-		// One round = 8 dependent launches (the trace waves, five bookkeeping passes, the commit waves, the end-of-round bookkeeping), captured once into a hipGraph and
+		// One round = 8 dependent launches (the trace waves, five bookkeeping passes, the commit / checkpoint-resume waves, the end-of-round bookkeeping), captured once into a hipGraph and
 		// replayed.  Nothing in a round needs a host decision -- the step budget, the commit point and the pause behind a failed droplet are all taken from the
 		// device-resident control block -- so the host queues rounds in batches and reads the control block back once per batch; a round after the end (or while the
 		// lowest droplet waits for its serial fall-back) finds nothing to do.
@@ -742,7 +742,7 @@ template<class BE> struct terra_engine {
 			bool const cap = be.graph_begin();
 			try {
 				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, slice, ws);});
-				be.launch(nse, [=] TERRA_LAMBDA (size_t i) {spec_post_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));});
+				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_post_wave(s, (uint32_t)i);});
 				be.launch(nse, [=] TERRA_LAMBDA (size_t i) { // publish the finished versions; take the writer lists apart (both after the dirty marks were made from the OLD published versions)
 					spec_unlink_body(s, (uint32_t)i);
 					if (i < s.W) {spec_flip_body(s, (uint32_t)i);}
@@ -755,7 +755,10 @@ template<class BE> struct terra_engine {
 					spec_undirty_body(s, (uint32_t)i);
 					if (i < s.W) {spec_scan_body(s, (uint32_t)i);}
 				});
-				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_flush_wave(s, (uint32_t)i);});
+				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) { // commit; and a re-trace that can resume from a checkpoint becomes a suspended trace at that checkpoint
+					spec_flush_wave(s, (uint32_t)i);
+					spec_resume_wave(s, (uint32_t)i);
+				});
 				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
 				be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
 			} catch (...) {be.graph_abort(); throw;}

@@ -457,9 +457,9 @@ constexpr unsigned SPEC_MAP_SLOTS = 512; // open-addressed block -> entry map of
 constexpr unsigned SPEC_PAGE = 64;       // cells of an 8 x 8 block = floats of a version page
 constexpr unsigned SPEC_WIN_BLOCKS = ((EW >> 3) + 1)*((EW >> 3) + 1); // blocks a window can overlap
 constexpr unsigned SPEC_CAND = 4, SPEC_CAND_MANY = 255;
-// checkpoints of a trace: every SPEC_CK_STEPS steps the window's dirty cells are written back and the droplet state, the footprint length, the write masks and
+// checkpoints of a trace (measured: profiles/r02_erosion_checkpoint_sweep.txt): every SPEC_CK_STEPS steps the window's dirty cells are written back and the droplet state, the footprint length, the write masks and
 // the position in the undo log are saved, so that a re-trace can resume from the last checkpoint whose inputs are still valid instead of from the spawn
-constexpr unsigned SPEC_CK_STEPS = 64, SPEC_CK_MAX = 16, SPEC_UNDO_MAX = 4096; // (defaults: spec_buffers_t::ck_steps / ck_max are the values in force, ck_max <= SPEC_CK_MAX)
+constexpr unsigned SPEC_CK_STEPS = 32, SPEC_CK_MAX = 16, SPEC_UNDO_MAX = 4096; // (defaults: spec_buffers_t::ck_steps / ck_max are the values in force, ck_max <= SPEC_CK_MAX)
 // where a cell entering the window is read from: the grid, nothing (it stays in the window / lies outside the grid), the grid + a walk of the block's writer list,
 // or float index (bits 0..29) into version buffer (bit 31); bit 30: the page is this trace's own
 constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu, SPEC_SRC_NONE = 0xFFFFFFFEu, SPEC_SRC_SLOW = 0xFFFFFFFDu, SPEC_SRC_OWN_BIT = 0x40000000u;
@@ -637,7 +637,9 @@ struct grid_back_t {
 constexpr uint32_t SPEC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SPEC_NIL   = 0xFFFFFFFFu;
 enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4, SPEC_F_UNDO_OVERFLOW = 8};
-constexpr uint32_t SPEC_BLK_WRITTEN = 0x80000000u; // block-list entry flag: the droplet may have WRITTEN cells of the block (else it only read them)
+constexpr uint32_t SPEC_BLK_WRITTEN = 0x80000000u; // block-list entry flag: the trace has WRITTEN cells of the block (else it only read them)
+constexpr uint32_t SPEC_BLK_CHANGED = 0x40000000u; // ... and what it wrote there differs from what the droplet's previously published version wrote there (or there is no such version)
+constexpr uint32_t SPEC_BLK_ID      = 0x3FFFFFFFu; // the block number
 // life of a ring slot: FRESH (trace from the spawn) -> RUNNING (trace suspended at a step boundary, state saved) -> DONE_NEW (finished in
 // this round, not published yet) -> IDLE (its finished version is published and believed valid); FAILED = the trace overflowed its log or
 // block list and waits to become the lowest uncommitted droplet, which then runs alone directly on the grid.
@@ -689,7 +691,6 @@ struct spec_buffers_t {
 	unsigned long long *page_mask[2]; // [W][maxb], valid for entries < blk_cnt (finished version) / run_nblk (suspended trace)
 	uint32_t *blk_list[2]; // [W][maxb] distinct blocks, in the order the trace met them
 	uint32_t *blk_cnt[2];  // [W]
-	uint64_t *chk[2];      // [W] checksum of the version's content (+ step count)
 	// checkpoints of the trace in each buffer (see SPEC_CK_STEPS) and its undo log: (float index into the slot's pages, value it held) of every write-back that
 	// changed a cell written back before, in order -- rolling the pages back to a checkpoint = its masks + the log entries after it, newest first
 	droplet_state_t *ck_state[2];       // [W][SPEC_CK_MAX]
@@ -721,14 +722,6 @@ struct spec_buffers_t {
 	uint32_t touched_cap;
 	spec_ctl_t *ctl;
 };
-
-// splitmix64 finaliser.  The per-cell terms of the log checksum must be mixed non-linearly: a lower droplet's change often moves
-// some cells up one ulp and others down one ulp, which a linear (multiplicative) term sum cannot see.
-TERRA_HD uint64_t spec_mix64(uint64_t x) {
-	x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
-	return x;
-}
-TERRA_HD uint64_t spec_term(uint32_t cell, float val) {uint32_t vb; memcpy(&vb, &val, 4); return spec_mix64(((uint64_t)cell << 32) | vb);}
 
 struct spec_back_t {
 	spec_buffers_t const *sb;
@@ -779,7 +772,7 @@ struct spec_back_t {
 		TERRA_LANES(h, SPEC_MAP_SLOTS) {sh->map_keys[h] = SPEC_NIL;}
 		TERRA_WAVE_SYNC();
 		TERRA_LANES(e, nblk) {
-			uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN;
+			uint32_t const b = my_blks[e] & SPEC_BLK_ID;
 			for (uint32_t h = map_hash(b);; h = (h + 1) & (SPEC_MAP_SLOTS - 1)) {
 				if (TERRA_ATOMIC_CAS(&sh->map_keys[h], SPEC_NIL, b) == SPEC_NIL) {sh->map_ent[h] = (uint8_t)e; break;}
 			}
@@ -798,7 +791,7 @@ struct spec_back_t {
 	// Start this trace from checkpoint k of the slot's trace in buffer `sbuf`: either the suspended trace in this trace's own buffer (rolled back in place) or the
 	// published version in the other buffer (copied: readers keep using it until the new version is published).  Afterwards footprint, masks, pages, undo log and
 	// the checkpoints 0 .. k of this trace are what they were when that checkpoint was taken; the LDS window is empty and is fetched afresh.
-	TERRA_HD void ck_restore(uint32_t sbuf, uint32_t k, droplet_state_t &d) {
+	TERRA_HD void ck_restore(uint32_t sbuf, uint32_t k, droplet_state_t &d) { // (no LDS: runs in the commit kernel's waves)
 		uint32_t const nb = 1u - sb->cur[slot];
 		bool const copy = (sbuf != nb);
 		size_t const pbase = (size_t)slot*sb->maxb, cb0 = (size_t)slot*SPEC_CK_MAX, ub = (size_t)slot*SPEC_UNDO_MAX;
@@ -808,61 +801,41 @@ struct spec_back_t {
 		uint32_t const nk = sb->ck_nblk[sbuf][cb0 + k], uk = sb->ck_undo[sbuf][cb0 + k], un = sb->undo_n[sbuf][slot];
 		d = sb->ck_state[sbuf][cb0 + k];
 		unsigned long long const *s_ckm = sb->ck_masks[sbuf] + (cb0 + k)*sb->maxb;
-		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nk) ? s_ckm[e] : 0ull;}
-		TERRA_WAVE_SYNC();
+		TERRA_LANES(e, nk) {my_masks[e] = s_ckm[e];} // what a resumed trace starts from (spec_back_t::init)
 		if (copy) {
-			TERRA_LANES(e, nk) {my_blks[e] = s_blks[e] & ~SPEC_BLK_WRITTEN;}
-			for (uint32_t e = 0; e < nk; ++e) { // page by page, lane c = cell c
-				unsigned long long const m = sh->masks[e];
-				if (!m) continue;
-				TERRA_EACH_LANE(c) {if ((m >> c) & 1ull) {my_pages[(size_t)e*SPEC_PAGE + c] = s_pages[(size_t)e*SPEC_PAGE + c];}}
+			TERRA_LANES(e, nk) {my_blks[e] = s_blks[e] & SPEC_BLK_ID;}
+			TERRA_LANES(i, nk*SPEC_PAGE) { // every cell the trace had written by then: independent copies
+				uint32_t const e = (uint32_t)i / SPEC_PAGE, c = (uint32_t)i % SPEC_PAGE;
+				if ((s_ckm[e] >> c) & 1ull) {my_pages[i] = s_pages[i];}
 			}
 			TERRA_LANES(i, (k + 1)*sb->maxb) {sb->ck_masks[nb][cb0*sb->maxb + i] = sb->ck_masks[sbuf][cb0*sb->maxb + i];}
 			TERRA_LANES(i, k + 1) {sb->ck_state[nb][cb0 + i] = sb->ck_state[sbuf][cb0 + i]; sb->ck_nblk[nb][cb0 + i] = sb->ck_nblk[sbuf][cb0 + i]; sb->ck_undo[nb][cb0 + i] = sb->ck_undo[sbuf][cb0 + i];}
 			TERRA_LANES(q, uk) {my_undo_idx[q] = s_uidx[q]; my_undo_val[q] = s_uval[q];}
-			TERRA_WAVE_SYNC();
 		}
-		// the log entries after the checkpoint, newest first: a cell rewritten since gets back what it held at the checkpoint (the oldest entry after it, applied last)
-		if (TERRA_LANE0) {
-			for (uint32_t q = un; q-- > uk;) {
-				uint32_t const idx = s_uidx[q], e = idx / SPEC_PAGE;
-				if (e < nk && ((sh->masks[e] >> (idx % SPEC_PAGE)) & 1ull)) {my_pages[idx] = s_uval[q];}
+		TERRA_WAVE_SYNC(); // the page copies are stored before the undo entries overwrite some of them
+		// the log entries after the checkpoint, newest first: a cell rewritten since gets back what it held at the checkpoint (the oldest entry after it, applied last).
+		// One lane per page walks the whole range and takes the entries of its page: their order is kept, the pages are independent.
+		TERRA_LANES(e, nk) {
+			unsigned long long const m = s_ckm[e];
+			if (m) {
+				for (uint32_t q = un; q-- > uk;) {
+					uint32_t const idx = s_uidx[q];
+					if (idx / SPEC_PAGE == (uint32_t)e && ((m >> (idx % SPEC_PAGE)) & 1ull)) {my_pages[idx] = s_uval[q];}
+				}
 			}
 		}
 		TERRA_WAVE_SYNC();
 		nblk = nk;
-		if (TERRA_LANE0) {sh->undo_n = uk;}
-		rebuild_map();
-		log_undo = true;
 	}
 	// the trace stops (finished or suspended): masks to global memory, written flags into the block list
 	TERRA_HD void publish_masks() const {
 		TERRA_LANES(e, nblk) {
 			unsigned long long const m = sh->masks[e];
 			my_masks[e] = m;
-			uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN;
+			uint32_t const b = my_blks[e] & SPEC_BLK_ID;
 			my_blks[e] = m ? (b | SPEC_BLK_WRITTEN) : b; // only written blocks can invalidate a reader
 		}
 		TERRA_WAVE_SYNC();
-	}
-	// sum over the written cells of a non-linear term of (cell, value): a function of the version's CONTENT only, so two traces of a droplet compare equal
-	// however their write-backs were scheduled
-	TERRA_HD unsigned long long content_checksum() const {
-		if (TERRA_LANE0) {sh->chk = 0;}
-		TERRA_WAVE_SYNC();
-		TERRA_EACH_LANE(c) {
-			unsigned long long acc = 0;
-			for (uint32_t e = 0; e < nblk; ++e) {
-				unsigned long long const m = sh->masks[e];
-				if (!((m >> c) & 1ull)) continue;
-				uint32_t const b = my_blks[e] & ~SPEC_BLK_WRITTEN, bx = b % sb->nbx, bz = b / sb->nbx;
-				uint32_t const cell = ((bz << 3) + ((uint32_t)c >> 3))*(uint32_t)sb->ec.NX + (bx << 3) + ((uint32_t)c & 7u);
-				acc += spec_term(cell, TERRA_L2_LOAD(&my_pages[(size_t)e*SPEC_PAGE + c]));
-			}
-			if (acc) {TERRA_ATOMIC_ADD(&sh->chk, acc);}
-		}
-		TERRA_WAVE_SYNC();
-		return sh->chk;
 	}
 	// sh->flags only changes inside window write-backs, which end with a wave sync; blk_overflow is a wave-uniform register
 	TERRA_HD bool failed() const {return blk_overflow || (sh->flags & SPEC_F_LOG_OVERFLOW) != 0;}
@@ -1035,19 +1008,7 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	unsigned steps_before = 0;   // the droplet's step count when this wave took over
 	if (ph == SPEC_FRESH) {
 		mem.back.init(&sb, slot, iter, ws.sh, nullptr);
-		bool resumed = false;
-		uint32_t const rs = sb.rsrc[slot];
-		if (rs) { // a re-trace: the slot's previous trace is valid up to the footprint entry the mark pass found; its last checkpoint before that entry is where this one starts
-			uint32_t const sbuf = (rs == 1u) ? sb.cur[slot] : 1u - sb.cur[slot], cnt = sb.ck_cnt[sbuf][slot], upto = sb.rat[slot];
-			uint32_t k = SPEC_NIL;
-			for (uint32_t i = 0; i < cnt; ++i) {if (sb.ck_nblk[sbuf][(size_t)slot*SPEC_CK_MAX + i] <= upto) {k = i;}} // footprint lengths grow with the checkpoint number
-			if (k != SPEC_NIL) {
-				mem.back.ck_restore(sbuf, k, d);
-				nck = k + 1; steps_before = d.numMoves; resumed = true;
-				if (TERRA_LANE0) {TERRA_ATOMIC_ADD(&sb.ctl->ck_resumes, 1u); TERRA_ATOMIC_ADD(&sb.ctl->ck_steps_saved, (unsigned long long)d.numMoves);}
-			}
-		}
-		if (!resumed) {finished = !droplet_start((int)iter, mem, sb.ec, d);}
+		finished = !droplet_start((int)iter, mem, sb.ec, d); // (a re-trace that can resume from a checkpoint was turned into a suspended trace by spec_resume_wave)
 	}
 	else {
 		d = sb.state[slot];
@@ -1078,43 +1039,6 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	unsigned long long const clk_c = TERRA_CLOCK();
 	mem.finish(); // the window's dirty cells go to the pages: a suspended trace keeps nothing but its masks in LDS, and those are saved next
 	mem.back.publish_masks();
-	// "unchanged" is decided by the content checksum; before a version is declared equal to the published one (which spares every higher droplet a
-	// re-trace) the two versions are compared page by page, so a checksum collision can cost time but never a wrong result.  Only the unchanged path pays.
-	uint64_t chk_new = 0;
-	{
-		uint32_t const ob = sb.cur[slot], nb = 1u - ob;
-		uint32_t const fl0 = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
-		bool const sound = finished && !(fl0 & (SPEC_F_LOG_OVERFLOW | SPEC_F_BLK_OVERFLOW));
-		if (sound) {chk_new = (uint64_t)mem.back.content_checksum() ^ ((uint64_t)d.numMoves << 40);}
-		bool const verify = sound && sb.has_ver[slot] && sb.chk[ob][slot] == chk_new && sb.blk_cnt[ob][slot] == mem.back.nblk;
-		if (TERRA_LANE0) {ws.sh->pad_ = 0;}
-		TERRA_WAVE_SYNC();
-		if (verify) { // every written page of the new version has a page of the same block with the same mask and the same values in the published one (and, the
-			// checksums being equal, hardly ever anything else).  Both lists hold distinct blocks and have the same length.
-			size_t const pbase = (size_t)slot*sb.maxb;
-			uint32_t const *oblk = sb.blk_list[ob] + pbase; unsigned long long const *omask = sb.page_mask[ob] + pbase; float const *oval = sb.page_vals[ob] + pbase*SPEC_PAGE;
-			uint32_t const *nblkl = sb.blk_list[nb] + pbase; float const *nval = sb.page_vals[nb] + pbase*SPEC_PAGE;
-			uint32_t const n = mem.back.nblk;
-			TERRA_EACH_LANE(c) {
-				uint32_t bad = 0;
-				for (uint32_t e = 0; e < n; ++e) {
-					unsigned long long const m = ws.sh->masks[e];
-					uint32_t const b = TERRA_L2_LOAD(&nblkl[e]) & ~SPEC_BLK_WRITTEN;
-					uint32_t oe = SPEC_NIL;
-					for (uint32_t k = 0; k < n; ++k) {if ((oblk[(e + k) % n] & ~SPEC_BLK_WRITTEN) == b) {oe = (e + k) % n; break;}} // same path => same position: found at k = 0
-					unsigned long long const mo = (oe != SPEC_NIL) ? omask[oe] : 0ull;
-					if (mo != m) {bad = 1; break;}
-					if ((m >> c) & 1ull) {
-						float const vn = TERRA_L2_LOAD(&nval[(size_t)e*SPEC_PAGE + c]), vo = oval[(size_t)oe*SPEC_PAGE + c];
-						uint32_t x, y; memcpy(&x, &vn, 4); memcpy(&y, &vo, 4);
-						if (x != y) {bad = 1; break;}
-					}
-				}
-				if (bad) {TERRA_ATOMIC_OR(&ws.sh->pad_, 1u);}
-			}
-			TERRA_WAVE_SYNC();
-		}
-	}
 	if (TERRA_LANE0) {
 		uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 		uint32_t const fl = ws.sh->flags | (mem.back.blk_overflow ? (uint32_t)SPEC_F_BLK_OVERFLOW : 0u);
@@ -1124,13 +1048,10 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		sb.undo_n[nb][slot] = (ws.sh->undo_n < SPEC_UNDO_MAX) ? ws.sh->undo_n : SPEC_UNDO_MAX;
 		if (ph == SPEC_FRESH) {sb.rsrc[slot] = 0;}
 		if (finished || failed) {
-			uint64_t const chk = chk_new;
 			sb.blk_cnt[nb][slot] = mem.back.nblk;
-			sb.chk[nb][slot]     = chk;
 			sb.nsteps[slot]      = d.numMoves;
 			sb.flags[slot]       = fl | (d.nan_seen ? SPEC_F_NAN : 0);
-			if (sb.has_ver[slot] && !(sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk || ws.sh->pad_ != 0)) {TERRA_ATOMIC_ADD(&sb.ctl->retraces_same, 1u);}
-			sb.changed[slot]     = (!sb.has_ver[slot] || sb.chk[ob][slot] != chk || sb.blk_cnt[ob][slot] != mem.back.nblk || ws.sh->pad_ != 0) ? 1u : 0u;
+			sb.changed[slot]     = 0u; // (spec_post_wave compares the version with the published one, block by block)
 			sb.phase[slot]       = failed ? (uint32_t)SPEC_FAILED : (uint32_t)SPEC_DONE_NEW;
 		}
 		else {
@@ -1159,6 +1080,35 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 	}
 }
 
+// Before the traces of a round: a pending re-trace whose previous trace is still valid up to some checkpoint becomes a suspended trace at that checkpoint
+// (state, footprint, masks, pages, undo log, checkpoints as they were then), which the trace kernel resumes like any other suspended trace.
+TERRA_HD void spec_resume_wave(spec_buffers_t const &sb, uint32_t slot) {
+	uint32_t iter;
+	if (!spec_slot_active(sb, slot, iter)) return;
+	uint32_t const rs = sb.rsrc[slot];
+	if (sb.phase[slot] != SPEC_FRESH || !rs) return;
+	uint32_t const sbuf = (rs == 1u) ? sb.cur[slot] : 1u - sb.cur[slot], cnt = sb.ck_cnt[sbuf][slot], upto = sb.rat[slot];
+	uint32_t k = SPEC_NIL;
+	for (uint32_t i = 0; i < cnt; ++i) {if (sb.ck_nblk[sbuf][(size_t)slot*SPEC_CK_MAX + i] <= upto) {k = i;}} // footprint lengths grow with the checkpoint number
+	if (k != SPEC_NIL) {
+		uint32_t const nb = 1u - sb.cur[slot];
+		spec_back_t back;
+		back.sb = &sb; back.sh = nullptr; back.slot = slot; back.iter = iter;
+		back.my_pages = sb.page_vals[nb] + (size_t)slot*sb.maxb*SPEC_PAGE; back.my_masks = sb.page_mask[nb] + (size_t)slot*sb.maxb; back.my_blks = sb.blk_list[nb] + (size_t)slot*sb.maxb;
+		back.my_undo_idx = sb.undo_idx[nb] + (size_t)slot*SPEC_UNDO_MAX; back.my_undo_val = sb.undo_val[nb] + (size_t)slot*SPEC_UNDO_MAX;
+		droplet_state_t d;
+		back.ck_restore(sbuf, k, d);
+		if (TERRA_LANE0) {
+			sb.state[slot] = d;
+			spec_resume_t r; r.nblk = back.nblk; r.flags = 0; r.undo_n = sb.ck_undo[nb][(size_t)slot*SPEC_CK_MAX + k]; r.nck = k + 1;
+			sb.resume[slot] = r;
+			sb.run_nblk[slot] = back.nblk; sb.ck_cnt[nb][slot] = k + 1; sb.undo_n[nb][slot] = r.undo_n;
+			sb.phase[slot] = SPEC_RUNNING;
+			TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u); TERRA_ATOMIC_ADD(&sb.ctl->ck_resumes, 1u); TERRA_ATOMIC_ADD(&sb.ctl->ck_steps_saved, (unsigned long long)d.numMoves);
+		}
+	}
+	if (TERRA_LANE0) {sb.rsrc[slot] = 0;}
+}
 // the lowest uncommitted droplet, alone, directly on the grid (overflow fall-back)
 TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &ec, uint32_t iter, uint32_t *out_steps_nan, wave_scratch_t const &ws,
 	uint32_t *touched = nullptr, uint32_t *touched_count = nullptr, uint32_t touched_cap = 0)
@@ -1181,20 +1131,56 @@ TERRA_HD void spec_dirty(spec_buffers_t const &sb, uint32_t blk, uint32_t iter) 
 TERRA_HD void spec_undirty_body(spec_buffers_t const &sb, uint32_t i) {
 	if (i < sb.ctl->ndirty) {sb.dirty_min[sb.dirty_list[i]] = SPEC_NIL;}
 }
-// a version finished this round and differs from the published one: its old and new footprints are dirty for every higher droplet.
-// One thread per (slot, block-list entry).
-TERRA_HD void spec_post_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
+// A version finished this round: which of its blocks differ in content (cells written, values) from the droplet's published version -- those, and the blocks
+// the published version wrote and the new one does not even touch, are dirty for every higher droplet.  A re-trace usually repeats most of its predecessor's
+// writes bit for bit (every block before the point where its inputs changed); a first version changes every block it wrote.  One wave per slot, no LDS.
+TERRA_HD void spec_post_wave(spec_buffers_t const &sb, uint32_t slot) {
 	uint32_t const iter = sb.it[slot];
-	if (iter == SPEC_NIL || sb.phase[slot] != SPEC_DONE_NEW || !sb.changed[slot]) return;
+	if (iter == SPEC_NIL || sb.phase[slot] != SPEC_DONE_NEW) return;
 	uint32_t const ob = sb.cur[slot], nb = 1u - ob;
-	if (sb.has_ver[slot] && entry < sb.blk_cnt[ob][slot]) {
-		uint32_t const e = sb.blk_list[ob][(size_t)slot*sb.maxb + entry];
-		if (e & SPEC_BLK_WRITTEN) {spec_dirty(sb, e & ~SPEC_BLK_WRITTEN, iter);} // only written blocks can invalidate a reader
+	size_t const pbase = (size_t)slot*sb.maxb;
+	uint32_t *nblkl = sb.blk_list[nb] + pbase, *oblk = sb.blk_list[ob] + pbase;
+	unsigned long long const *nmask = sb.page_mask[nb] + pbase, *omask = sb.page_mask[ob] + pbase;
+	float const *nval = sb.page_vals[nb] + pbase*SPEC_PAGE, *oval = sb.page_vals[ob] + pbase*SPEC_PAGE;
+	uint32_t const n = sb.blk_cnt[nb][slot], no = sb.has_ver[slot] ? sb.blk_cnt[ob][slot] : 0u;
+	TERRA_LANES(e, n) { // one lane per block of the new version (all loads of a lane's comparison are independent)
+		unsigned long long const m = nmask[e];
+		uint32_t const b = nblkl[e] & SPEC_BLK_ID;
+		uint32_t oe = SPEC_NIL;
+		for (uint32_t k = 0; k < no; ++k) {uint32_t const q = ((uint32_t)e + k) % no; if ((oblk[q] & SPEC_BLK_ID) == b) {oe = q; break;}} // same path => same position: found at k = 0
+		unsigned long long const mo = (oe != SPEC_NIL) ? omask[oe] : 0ull;
+		bool differs = (m != mo);
+		if (!differs && m) {
+			uint32_t acc = 0;
+			for (uint32_t c = 0; c < SPEC_PAGE; ++c) {
+				float const vn = nval[(size_t)e*SPEC_PAGE + c], vo = oval[(size_t)oe*SPEC_PAGE + c];
+				uint32_t x, y; memcpy(&x, &vn, 4); memcpy(&y, &vo, 4);
+				acc |= ((m >> c) & 1ull) ? (x ^ y) : 0u;
+			}
+			differs = (acc != 0);
+		}
+		if (differs) {nblkl[e] = nblkl[e] | SPEC_BLK_CHANGED;} // (each entry has one lane)
 	}
-	if (entry < sb.blk_cnt[nb][slot]) {
-		uint32_t const e = sb.blk_list[nb][(size_t)slot*sb.maxb + entry];
-		if (e & SPEC_BLK_WRITTEN) {spec_dirty(sb, e & ~SPEC_BLK_WRITTEN, iter);}
+	TERRA_LANES(q, no) { // blocks the published version wrote and the new one does not even touch
+		uint32_t const ent = oblk[q];
+		bool gone = false;
+		if (omask[q]) {
+			gone = true;
+			uint32_t const b = ent & SPEC_BLK_ID;
+			for (uint32_t k = 0; k < n; ++k) {if ((nblkl[(q + k) % n] & SPEC_BLK_ID) == b) {gone = false; break;}}
+		}
+		oblk[q] = gone ? (ent | SPEC_BLK_CHANGED) : (ent & ~SPEC_BLK_CHANGED);
 	}
+	TERRA_WAVE_SYNC();
+	uint32_t const lim = (n > no) ? n : no;
+	TERRA_LANES(q, lim) { // the dirty marks (the flags were set by other lanes of this wave, through atomics: read them at L2)
+		bool any = false;
+		if ((uint32_t)q < no) {uint32_t const e = TERRA_L2_LOAD(&oblk[q]); if (e & SPEC_BLK_CHANGED) {spec_dirty(sb, e & SPEC_BLK_ID, iter); any = true;}}
+		if ((uint32_t)q < n)  {uint32_t const e = TERRA_L2_LOAD(&nblkl[q]); if (e & SPEC_BLK_CHANGED) {spec_dirty(sb, e & SPEC_BLK_ID, iter); any = true;}}
+		if (any) {TERRA_ATOMIC_OR(&sb.changed[slot], 1u);}
+	}
+	TERRA_WAVE_SYNC();
+	if (TERRA_LANE0 && sb.has_ver[slot] && TERRA_L2_LOAD(&sb.changed[slot]) == 0u) {TERRA_ATOMIC_ADD(&sb.ctl->retraces_same, 1u);}
 }
 // publish the versions finished this round
 TERRA_HD void spec_flip_body(spec_buffers_t const &sb, uint32_t slot) {
@@ -1208,7 +1194,7 @@ TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t e
 	if (entry >= sb.blk_cnt[cb][slot]) return;
 	uint32_t const e = sb.blk_list[cb][(size_t)slot*sb.maxb + entry];
 	if (!(e & SPEC_BLK_WRITTEN)) return; // the lists answer "who wrote here": read-only entries stay out
-	uint32_t const node = slot*sb.maxb + entry, b = e & ~SPEC_BLK_WRITTEN;
+	uint32_t const node = slot*sb.maxb + entry, b = e & SPEC_BLK_ID;
 	sb.node_blk[node] = b;
 	sb.next[node] = TERRA_ATOMIC_EXCH(&sb.head[b], node);
 }
@@ -1226,7 +1212,7 @@ TERRA_HD void spec_mark_body(spec_buffers_t const &sb, uint32_t slot, uint32_t e
 	if (ph == SPEC_RUNNING || ph == SPEC_FAILED || (ph == SPEC_FRESH && rs == 2u)) {bl = sb.blk_list[1u - cb] + (size_t)slot*sb.maxb; cnt = sb.run_nblk[slot];} // (a pending re-trace that has not run yet -- the slot is
 	else if ((ph == SPEC_IDLE || (ph == SPEC_FRESH && rs == 1u)) && sb.has_ver[slot]) {bl = sb.blk_list[cb] + (size_t)slot*sb.maxb; cnt = sb.blk_cnt[cb][slot];}  // paused -- still answers for the trace it wants to resume)
 	else return;
-	if (entry < cnt && sb.dirty_min[bl[entry] & ~SPEC_BLK_WRITTEN] < iter) {sb.restart[slot] = 1; TERRA_ATOMIC_MIN(&sb.rentry[slot], entry);} // entries are in first-touch order: the trace is valid below the lowest one hit
+	if (entry < cnt && sb.dirty_min[bl[entry] & SPEC_BLK_ID] < iter) {sb.restart[slot] = 1; TERRA_ATOMIC_MIN(&sb.rentry[slot], entry);} // entries are in first-touch order: the trace is valid below the lowest one hit
 }
 // apply the restarts, find the commit point and the lowest failed droplet: one thread per slot
 TERRA_HD void spec_scan_body(spec_buffers_t const &sb, uint32_t slot) {
@@ -1252,7 +1238,7 @@ TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 	TERRA_LANES(e, n) { // one page per lane: the dependent loads of the ownership test (list walk, masks) of different pages overlap; the cell stores need no reply
 		uint32_t const ent = sb.blk_list[cb][pbase + e];
 		if (!(ent & SPEC_BLK_WRITTEN)) continue;
-		uint32_t const b = ent & ~SPEC_BLK_WRITTEN;
+		uint32_t const b = ent & SPEC_BLK_ID;
 		unsigned long long mine = sb.page_mask[cb][pbase + e];
 		for (uint32_t node = sb.head[b]; node != SPEC_NIL && mine; node = sb.next[node]) { // a later committed droplet owns the final value of the cells it wrote
 			uint32_t const j = node / sb.maxb, ij = sb.it[j];
