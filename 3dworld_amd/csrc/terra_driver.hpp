@@ -675,6 +675,7 @@ template<class BE> struct terra_engine {
 		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
 		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = SPEC_CK_MAX;
+		{char const *dg = getenv("TERRA_ERO_DIAG"); sb.diag = (dg && dg[0] == '1') ? 1u : 0u;}
 		if (char const *ck = getenv("TERRA_ERO_CK")) {int a = 0, b = 0; if (sscanf(ck, "%d:%d", &a, &b) == 2 && a >= 1 && b >= 0 && b <= (int)SPEC_CK_MAX) {sb.ck_steps = (uint32_t)a; sb.ck_max = (uint32_t)b;}} // experiment knob "steps:max"; results never depend on it
 		sb.W = W;
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block

@@ -679,6 +679,7 @@ struct spec_buffers_t {
 	erosion_consts_t ec;
 	uint32_t num_iters;    // droplets of the whole run
 	uint32_t W;            // ring slots; droplet `it` lives in slot it % W, in-flight droplets are [base, base + W)
+	uint32_t diag;         // collect the device-clock breakdown (terra_erosion_report clk_* / crit_clk_*)
 	uint32_t ck_steps, ck_max; // steps between checkpoints of a trace, most checkpoints per trace (0: no checkpoints)
 	uint32_t near_count;   // the first near_count in-flight droplets (the next to commit) trace without a step budget; the others are sliced (0: all sliced)
 	uint32_t maxb;         // block-list capacity per droplet (<= SPEC_MAXB)
@@ -1061,22 +1062,22 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 		}
 		if (ph == SPEC_FRESH) {TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u);}
 		TERRA_ATOMIC_ADD(&sb.ctl->traced_steps, (unsigned long long)(d.numMoves - steps_before));
-		TERRA_ATOMIC_MAX(&sb.ctl->round_max_steps, (uint32_t)(d.numMoves - steps_before));
-		TERRA_ATOMIC_MAX(&sb.ctl->round_max_shifts, ws.sh->n_shift);
-		unsigned long long const clk_d = TERRA_CLOCK();
-		TERRA_ATOMIC_ADD(&sb.ctl->clk_wave, clk_d - clk_a); TERRA_ATOMIC_ADD(&sb.ctl->clk_init, clk_b - clk_a);
-		TERRA_ATOMIC_ADD(&sb.ctl->clk_shift, mem.clk_shift); TERRA_ATOMIC_ADD(&sb.ctl->clk_tail, clk_d - clk_c);
-		TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_flush, mem.clk_sh_flush); TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_prep, mem.clk_sh_prep); TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_load, mem.clk_sh_load);
-		TERRA_ATOMIC_MAX(&sb.ctl->round_max_clk, clk_d - clk_a);
-		{
+		if (sb.diag) { // the serial chain and the device-clock breakdown of the traces (TERRA_ERO_DIAG=1): ~20 more atomics on the control block -- ONE cache line for the whole chip -- per trace
+			TERRA_ATOMIC_MAX(&sb.ctl->round_max_steps, (uint32_t)(d.numMoves - steps_before));
+			TERRA_ATOMIC_MAX(&sb.ctl->round_max_shifts, ws.sh->n_shift);
+			if (ws.sh->n_shift) {TERRA_ATOMIC_ADD(&sb.ctl->n_shift, (unsigned long long)ws.sh->n_shift);}
+			if (ws.sh->n_own)   {TERRA_ATOMIC_ADD(&sb.ctl->n_own,   (unsigned long long)ws.sh->n_own);}
+			if (ws.sh->n_ver)   {TERRA_ATOMIC_ADD(&sb.ctl->n_ver,   (unsigned long long)ws.sh->n_ver);}
+			if (ws.sh->n_store) {TERRA_ATOMIC_ADD(&sb.ctl->n_store, (unsigned long long)ws.sh->n_store);}
+			unsigned long long const clk_d = TERRA_CLOCK();
+			TERRA_ATOMIC_ADD(&sb.ctl->clk_wave, clk_d - clk_a); TERRA_ATOMIC_ADD(&sb.ctl->clk_init, clk_b - clk_a);
+			TERRA_ATOMIC_ADD(&sb.ctl->clk_shift, mem.clk_shift); TERRA_ATOMIC_ADD(&sb.ctl->clk_tail, clk_d - clk_c);
+			TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_flush, mem.clk_sh_flush); TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_prep, mem.clk_sh_prep); TERRA_ATOMIC_ADD(&sb.ctl->clk_sh_load, mem.clk_sh_load);
+			TERRA_ATOMIC_MAX(&sb.ctl->round_max_clk, clk_d - clk_a);
 			auto sat = [](unsigned long long v, unsigned bits) {unsigned long long const m = (1ull << bits) - 1; return (v < m) ? v : m;};
 			TERRA_ATOMIC_MAX(&sb.ctl->round_max_pack2, (sat(clk_d - clk_a, 20) << 44) | (sat(mem.clk_sh_flush, 16) << 28) | (sat(mem.clk_sh_load, 14) << 14) | sat(mem.clk_sh_prep, 14));
 			TERRA_ATOMIC_MAX(&sb.ctl->round_max_pack, (sat(clk_d - clk_a, 20) << 44) | (sat(mem.clk_shift, 20) << 24) | (sat((clk_b - clk_a) + (clk_d - clk_c), 14) << 10) | sat((d.numMoves - steps_before) >> 2, 10));
 		}
-		if (ws.sh->n_shift) {TERRA_ATOMIC_ADD(&sb.ctl->n_shift, (unsigned long long)ws.sh->n_shift);}
-		if (ws.sh->n_own)   {TERRA_ATOMIC_ADD(&sb.ctl->n_own,   (unsigned long long)ws.sh->n_own);}
-		if (ws.sh->n_ver)   {TERRA_ATOMIC_ADD(&sb.ctl->n_ver,   (unsigned long long)ws.sh->n_ver);}
-		if (ws.sh->n_store) {TERRA_ATOMIC_ADD(&sb.ctl->n_store, (unsigned long long)ws.sh->n_store);}
 	}
 }
 
@@ -1245,13 +1246,15 @@ TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 			if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
 			mine &= ~sb.page_mask[sb.cur[j]][node];
 		}
+		if (!mine) continue;
 		uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
 		float const *page = sb.page_vals[cb] + (pbase + e)*SPEC_PAGE;
-		for (; mine; mine &= mine - 1) {
+		uint32_t k = sb.touched ? TERRA_ATOMIC_ADD(&sb.ctl->touched, (uint32_t)__builtin_popcountll(mine)) : 0u; // one reservation per page, not per cell: the counter is a single address for the whole chip
+		for (; mine; mine &= mine - 1, ++k) {
 			uint32_t const c = (uint32_t)__builtin_ctzll(mine);
 			uint32_t const X = (bx << 3) + (c & 7u), Z = (bz << 3) + (c >> 3);
 			*sb.grid.at((int)X, (int)Z) = page[c];
-			if (sb.touched) {uint32_t const k = TERRA_ATOMIC_ADD(&sb.ctl->touched, 1u); if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}}
+			if (sb.touched && k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
 		}
 	}
 }

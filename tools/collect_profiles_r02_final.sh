@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): refresh of round 2's evidence after the erosion rework (block-page versions, 8 launches per round) and the Perlin block records.
 set -u
+export TERRA_ERO_DIAG=1
 R=${1:-r02f}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R

@@ -3,6 +3,7 @@
 (ring, slice, near) setting -- the quantities the GPU time is made of (time ~ rounds*overhead + critical_steps*step latency), without spending GPU minutes.
 usage: ero_emul_model.py N D W:slice:near[,W:slice:near...]"""
 import importlib, os, subprocess, sys, time
+os.environ.setdefault("TERRA_ERO_DIAG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("3dworld_amd")

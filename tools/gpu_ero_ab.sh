@@ -1,5 +1,6 @@
 #!/bin/bash
 set -u
+export TERRA_ERO_DIAG=1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-eroab}
 mkdir -p $OUT

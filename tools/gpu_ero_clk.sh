@@ -1,6 +1,7 @@
 #!/bin/bash
 # where the time of a dense-erosion trace goes (device clocks in the scheduler report)
 set -u
+export TERRA_ERO_DIAG=1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-eroclk}
 mkdir -p $OUT
