@@ -791,7 +791,7 @@ template<class BE> struct terra_engine {
 		be.d2h(&hc, sb.ctl, sizeof(hc));
 		report.rounds = hc.rounds; report.retraces_same = hc.retraces_same; report.checkpoint_resumes = hc.ck_resumes; report.checkpoint_steps_saved = hc.ck_steps_saved;
 		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
-		report.window_shifts = hc.n_shift; report.own_lookups = hc.n_own; report.version_lookups = hc.n_ver; report.log_stores = hc.n_store;
+		report.window_shifts = hc.n_shift;
 		report.critical_steps = hc.crit_steps; report.critical_shifts = hc.crit_shifts;
 		report.clk_wave = hc.clk_wave; report.clk_init = hc.clk_init; report.clk_shift = hc.clk_shift; report.clk_tail = hc.clk_tail; report.clk_critical = hc.clk_crit;
 		report.clk_shift_flush = hc.clk_sh_flush; report.clk_shift_prep = hc.clk_sh_prep; report.clk_shift_load = hc.clk_sh_load;

@@ -467,7 +467,7 @@ struct spec_cand_t {uint32_t page, it; unsigned long long mask;}; // page = slot
 struct wave_shared_t { // per-wave LDS scratch
 	uint32_t flags, pad_;
 	uint32_t undo_n, pad1_;                  // entries of the trace's undo log
-	uint32_t n_shift, n_own, n_ver, n_store; // diagnostics of the trace (terra_erosion_report)
+	uint32_t n_shift, pad2_;                 // window moves of the trace (terra_erosion_report)
 	unsigned long long chk;
 	uint8_t blk_shared[64];                  // per block under the window: number of published LOWER versions that wrote it (SPEC_CAND_MANY: more than fit below)
 	spec_cand_t cand[SPEC_WIN_BLOCKS][SPEC_CAND]; // those versions, highest droplet first: a cell's value comes from the first whose mask has the cell
@@ -663,7 +663,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	unsigned long long ck_steps_saved;          // steps those did not have to repeat
 	uint32_t rounds, retraces_same;             // rounds that had work to do (the host launches them in batches and may overshoot the end); re-traces that reproduced the published version
 	unsigned long long traced_steps, steps; // steps simulated (restarts included) / steps of committed droplets
-	unsigned long long n_shift, n_own, n_ver, n_store; // diagnostics summed over all traces
+	unsigned long long n_shift;                        // window moves summed over all traces (diagnostics)
 	unsigned long long crit_steps, crit_shifts;         // round_max_* summed over the rounds
 	unsigned long long clk_wave, clk_init, clk_shift, clk_tail; // 10 ns ticks summed over all traces: whole wave body / before the first step / window moves / after the last step
 	unsigned long long clk_sh_flush, clk_sh_prep, clk_sh_load; // parts of clk_shift: write-back of leaving cells / block flags / plain grid loads (the rest: look-ups + LDS fill)
@@ -763,7 +763,7 @@ struct spec_back_t {
 		nblk = rs ? rs->nblk : 0;
 		blk_overflow = false; wbx0 = wbz0 = 0; wnb = (EW >> sb->bshift) + 1;
 		lx0 = lx1 = lz0 = lz1 = INT_MIN;
-		if (TERRA_LANE0) {sh->flags = rs ? rs->flags : 0; sh->undo_n = rs ? rs->undo_n : 0; sh->chk = 0; sh->n_shift = sh->n_own = sh->n_ver = sh->n_store = 0;}
+		if (TERRA_LANE0) {sh->flags = rs ? rs->flags : 0; sh->undo_n = rs ? rs->undo_n : 0; sh->chk = 0; sh->n_shift = 0;}
 		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nblk) ? my_masks[e] : 0ull;} // a resumed trace: what it has written back so far (saved when it was suspended)
 		TERRA_WAVE_SYNC();
 		rebuild_map(); // (empty for a new trace)
@@ -918,11 +918,11 @@ struct spec_back_t {
 		uint32_t const c = page_cell(X, Z);
 		uint32_t e;
 		slow = false; own = false;
-		if (own_written(X, Z, e)) {TERRA_ATOMIC_ADD(&sh->n_own, 1u); own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);} // (the caller adds SPEC_SRC_OWN_BIT)
+		if (own_written(X, Z, e)) {own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);} // (the caller adds SPEC_SRC_OWN_BIT)
 		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
 		uint32_t const bi = (uint32_t)(bz*wnb + bx), cnt = sh->blk_shared[bi]; // inside the prepared window by construction
 		if (cnt) {
-			TERRA_ATOMIC_ADD(&sh->n_ver, 1u);
+
 			if (cnt == SPEC_CAND_MANY) {slow = true;}
 			else {
 				for (uint32_t k = 0; k < cnt; ++k) {
@@ -940,11 +940,11 @@ struct spec_back_t {
 		uint32_t const c = page_cell(X, Z);
 		uint32_t e;
 		if (own_written(X, Z, e)) {
-			TERRA_ATOMIC_ADD(&sh->n_own, 1u);
+
 			return TERRA_L2_LOAD(&my_pages[(size_t)e*SPEC_PAGE + c]);
 		}
 		if (block_flag(X, Z)) {
-			TERRA_ATOMIC_ADD(&sh->n_ver, 1u);
+
 			uint32_t best = SPEC_NIL; // droplet number of the best writer so far
 			float v = b;
 			for (uint32_t node = sb->head[block_of(X, Z)]; node != SPEC_NIL; node = sb->next[node]) {
@@ -961,7 +961,7 @@ struct spec_back_t {
 	}
 	// called from lanes in parallel, each with a distinct cell (several may share a page: the mask is updated atomically)
 	TERRA_HD void store(int X, int Z, float val) {
-		TERRA_ATOMIC_ADD(&sh->n_store, 1u);
+
 		uint32_t const e = map_find(block_of(X, Z)), c = page_cell(X, Z);
 		if (TERRA_UNLIKELY(e == SPEC_NIL)) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW); return;} // every written cell lies in a recorded brush box: never happens
 		uint32_t const idx = e*SPEC_PAGE + c;
@@ -1066,9 +1066,6 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 			TERRA_ATOMIC_MAX(&sb.ctl->round_max_steps, (uint32_t)(d.numMoves - steps_before));
 			TERRA_ATOMIC_MAX(&sb.ctl->round_max_shifts, ws.sh->n_shift);
 			if (ws.sh->n_shift) {TERRA_ATOMIC_ADD(&sb.ctl->n_shift, (unsigned long long)ws.sh->n_shift);}
-			if (ws.sh->n_own)   {TERRA_ATOMIC_ADD(&sb.ctl->n_own,   (unsigned long long)ws.sh->n_own);}
-			if (ws.sh->n_ver)   {TERRA_ATOMIC_ADD(&sb.ctl->n_ver,   (unsigned long long)ws.sh->n_ver);}
-			if (ws.sh->n_store) {TERRA_ATOMIC_ADD(&sb.ctl->n_store, (unsigned long long)ws.sh->n_store);}
 			unsigned long long const clk_d = TERRA_CLOCK();
 			TERRA_ATOMIC_ADD(&sb.ctl->clk_wave, clk_d - clk_a); TERRA_ATOMIC_ADD(&sb.ctl->clk_init, clk_b - clk_a);
 			TERRA_ATOMIC_ADD(&sb.ctl->clk_shift, mem.clk_shift); TERRA_ATOMIC_ADD(&sb.ctl->clk_tail, clk_d - clk_c);

@@ -58,8 +58,8 @@ GRASS_BLOCK_DTYPE = np.dtype([("ix", np.uint32), ("zmin", np.float32), ("zmax", 
 class ErosionReport(C.Structure):  # terra_erosion_report
     _fields_ = [("droplets", C.c_uint32), ("windows", C.c_uint32), ("rounds", C.c_uint32), ("traces", C.c_uint32),
                 ("serial_fallbacks", C.c_uint32), ("nan_droplets", C.c_uint32), ("steps", C.c_uint64), ("traced_steps", C.c_uint64),
-                ("window_shifts", C.c_uint64), ("own_lookups", C.c_uint64), ("version_lookups", C.c_uint64), ("log_stores", C.c_uint64),
-                ("retraces_same", C.c_uint64), ("checkpoint_resumes", C.c_uint64), ("checkpoint_steps_saved", C.c_uint64), ("critical_steps", C.c_uint64), ("critical_shifts", C.c_uint64),
+                ("retraces_same", C.c_uint64), ("checkpoint_resumes", C.c_uint64), ("checkpoint_steps_saved", C.c_uint64),
+                ("window_shifts", C.c_uint64), ("critical_steps", C.c_uint64), ("critical_shifts", C.c_uint64),
                 ("clk_wave", C.c_uint64), ("clk_init", C.c_uint64), ("clk_shift", C.c_uint64), ("clk_tail", C.c_uint64), ("clk_critical", C.c_uint64),
                 ("clk_shift_flush", C.c_uint64), ("clk_shift_prep", C.c_uint64), ("clk_shift_load", C.c_uint64),
                 ("crit_clk_flush", C.c_uint64), ("crit_clk_load", C.c_uint64), ("crit_clk_prep", C.c_uint64),

@@ -77,18 +77,15 @@ typedef struct terra_erosion_report {
 	uint32_t droplets, windows /* ring generations = ceil(droplets / slots) */, rounds, traces, serial_fallbacks, nan_droplets;
 	uint64_t steps;          /* droplet steps of the final (committed) traces */
 	uint64_t traced_steps;   /* droplet steps actually simulated, re-traces included */
-	/* where a trace's time goes besides the steps themselves (speculative scheduler only).  Everything from here down to the end is collected only with
-	 * TERRA_ERO_DIAG=1 in the environment (0 otherwise): the counters live in one cache line that every trace of the chip would update */
-	uint64_t window_shifts;  /* times the 32 x 32 LDS window was moved */
-	uint64_t own_lookups;    /* cells entering a window that were read back from the droplet's own version pages */
-	uint64_t version_lookups;/* cells entering a window that lie in a block some lower in-flight droplet wrote (their value may come from its pages) */
-	uint64_t log_stores;     /* cells written back from a window to the version's pages */
 	uint64_t retraces_same;  /* re-traces that reproduced the published version bit for bit (the conflict that caused them was one of blocks, not of cells read) */
 	uint64_t checkpoint_resumes;     /* re-traces that started from a checkpoint of the droplet's previous trace instead of from its spawn */
 	uint64_t checkpoint_steps_saved; /* steps those re-traces did not have to repeat */
+	/* where the time goes (speculative scheduler only).  Everything from here down to the end is collected only with TERRA_ERO_DIAG=1 in the environment
+	 * (0 otherwise): the counters live in one cache line that every trace of the chip would have to update */
+	uint64_t window_shifts;  /* times the 32 x 32 LDS window was moved */
 	uint64_t critical_steps; /* sum over the rounds of the most steps any one trace made in the round: the scheduler's serial chain, in droplet steps */
 	uint64_t critical_shifts;/* the same for window moves */
-	/* (collected with TERRA_ERO_DIAG=1 in the environment, else 0) device time in 10 ns ticks, summed over all traces: a trace's whole wave body / before its first step / inside window moves / after its last step;
+	/* device time in 10 ns ticks, summed over all traces: a trace's whole wave body / before its first step / inside window moves / after its last step;
 	 * clk_critical: the longest wave body of each round, summed over the rounds */
 	uint64_t clk_wave, clk_init, clk_shift, clk_tail, clk_critical;
 	uint64_t clk_shift_flush, clk_shift_prep, clk_shift_load; /* parts of clk_shift: write-back of the cells that leave / block flags (candidate versions per block); clk_shift_load is 0 since the grid loads are in flight during the look-ups and are not timed apart: the rest of clk_shift is loads + look-ups + filling the window */

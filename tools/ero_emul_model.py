@@ -29,4 +29,4 @@ for (w, sl, near) in combos:
     dt = time.perf_counter() - t0
     r = t.erosion_report().as_dict()
     print(f"W {w} slice {sl} near {near}: rounds {r['rounds']} traces {r['traces']} (same again {r['retraces_same']}, from a checkpoint {r['checkpoint_resumes']} saving {r['checkpoint_steps_saved']} steps) steps {r['steps']} traced {r['traced_steps']} critical_steps {r['critical_steps']} critical_shifts {r['critical_shifts']} "
-          f"shifts {r['window_shifts']} version_lookups {r['version_lookups']} fallbacks {r['serial_fallbacks']} (host {dt:.1f}s)", flush=True)
+          f"shifts {r['window_shifts']} fallbacks {r['serial_fallbacks']} (host {dt:.1f}s)", flush=True)

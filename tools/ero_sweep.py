@@ -26,7 +26,7 @@ for (w, sl) in combos:
         t.synchronize()
         dt = time.perf_counter() - t0
     r = t.erosion_report().as_dict()
-    print(f"W {w} slice {sl}: {dt*1e3:.1f} ms rounds {r['rounds']} traces {r['traces']} steps {r['steps']} traced {r['traced_steps']} fallbacks {r['serial_fallbacks']}  us/round {dt*1e6/max(1,r['rounds']):.0f}  shifts {r['window_shifts']} own_lookups {r['own_lookups']} version_lookups {r['version_lookups']} log_stores {r['log_stores']}", flush=True)
+    print(f"W {w} slice {sl}: {dt*1e3:.1f} ms rounds {r['rounds']} traces {r['traces']} steps {r['steps']} traced {r['traced_steps']} fallbacks {r['serial_fallbacks']}  us/round {dt*1e6/max(1,r['rounds']):.0f}  shifts {r['window_shifts']}", flush=True)
     tk = 0.01  # us per tick
     print(f"    critical_steps {r['critical_steps']} critical_shifts {r['critical_shifts']} | device us: waves {r['clk_wave']*tk:.0f} init {r['clk_init']*tk:.0f} shifts {r['clk_shift']*tk:.0f} tail {r['clk_tail']*tk:.0f} critical {r['clk_critical']*tk:.0f}"
           f" | per shift {r['clk_shift']*tk/max(1,r['window_shifts']):.2f} us, per step (run - shifts) {(r['clk_wave']-r['clk_init']-r['clk_tail']-r['clk_shift'])*tk/max(1,r['traced_steps']):.3f} us, init/trace {r['clk_init']*tk/max(1,r['traces']):.2f} tail/trace {r['clk_tail']*tk/max(1,r['traces']):.2f}", flush=True)
