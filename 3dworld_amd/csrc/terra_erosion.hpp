@@ -368,6 +368,25 @@ template<class T> inline T terra_host_atomic_cas(T *p, T c, T v) {T o = *p; if (
 #define TERRA_ATOMIC_CAS(p, c, v) terra_host_atomic_cas((p), (c), (v))
 #endif
 
+// n slots each for the lanes of a wave out of a counter that the whole chip shares, with ONE atomic for the wave (every lane of the wave must call it, n may be 0;
+// on the host the lanes come one after another and simply take theirs).  Chip-wide counters in one cache line serialise at L2: 26 M single increments of the
+// written-cells counter were 15 % of a dense erosion run.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t *ctr, uint32_t n) {
+	unsigned const lane = threadIdx.x & 63u;
+	uint32_t incl = n;
+#pragma unroll
+	for (unsigned off = 1; off < 64; off <<= 1) {uint32_t const t = __shfl_up(incl, off, 64); if (lane >= off) {incl += t;}}
+	uint32_t const total = __shfl(incl, 63, 64);
+	uint32_t base = 0;
+	if (lane == 63u && total) {base = atomicAdd(ctr, total);}
+	base = __shfl(base, 63, 64);
+	return base + incl - n;
+}
+#else
+inline uint32_t wave_reserve(uint32_t *ctr, uint32_t n) {uint32_t const o = *ctr; *ctr = o + n; return o;}
+#endif
+
 // L2 load: read through to L2.  A trace's OWN pages are written by the other lanes of its wave (plain stores) in the same kernel; the CU's vector L1 may
 // still hold the line from an earlier read, so those reads must not hit L1.  Other droplets' versions were written by earlier kernels (the boundary makes
 // them visible) and use plain cached loads.
@@ -1122,10 +1141,6 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 
 // ---- per-logical-thread bodies of the bookkeeping kernels (one round = clear, trace, post, flip, link, mark, scan, flush, admit, advance)
 
-TERRA_HD void spec_dirty(spec_buffers_t const &sb, uint32_t blk, uint32_t iter) { // remember the block so that spec_undirty_body can reset it (no O(grid) fill)
-	TERRA_ATOMIC_MIN(&sb.dirty_min[blk], iter);
-	sb.dirty_list[TERRA_ATOMIC_ADD(&sb.ctl->ndirty, 1u)] = blk;
-}
 TERRA_HD void spec_undirty_body(spec_buffers_t const &sb, uint32_t i) {
 	if (i < sb.ctl->ndirty) {sb.dirty_min[sb.dirty_list[i]] = SPEC_NIL;}
 }
@@ -1171,11 +1186,18 @@ TERRA_HD void spec_post_wave(spec_buffers_t const &sb, uint32_t slot) {
 	}
 	TERRA_WAVE_SYNC();
 	uint32_t const lim = (n > no) ? n : no;
-	TERRA_LANES(q, lim) { // the dirty marks (the flags were set by other lanes of this wave, through atomics: read them at L2)
-		bool any = false;
-		if ((uint32_t)q < no) {uint32_t const e = TERRA_L2_LOAD(&oblk[q]); if (e & SPEC_BLK_CHANGED) {spec_dirty(sb, e & SPEC_BLK_ID, iter); any = true;}}
-		if ((uint32_t)q < n)  {uint32_t const e = TERRA_L2_LOAD(&nblkl[q]); if (e & SPEC_BLK_CHANGED) {spec_dirty(sb, e & SPEC_BLK_ID, iter); any = true;}}
-		if (any) {TERRA_ATOMIC_OR(&sb.changed[slot], 1u);}
+	for (uint32_t q0 = 0; q0 < lim; q0 += 64) { // the dirty marks (the flags were set by other lanes of this wave: read them at L2); list slots for the whole wave with one atomic
+		TERRA_EACH_LANE(l) {
+			uint32_t const q = q0 + (uint32_t)l;
+			uint32_t b0 = SPEC_NIL, b1 = SPEC_NIL;
+			if (q < no) {uint32_t const e = TERRA_L2_LOAD(&oblk[q]); if (e & SPEC_BLK_CHANGED) {b0 = e & SPEC_BLK_ID;}}
+			if (q < n)  {uint32_t const e = TERRA_L2_LOAD(&nblkl[q]); if (e & SPEC_BLK_CHANGED) {b1 = e & SPEC_BLK_ID;}}
+			uint32_t const cnt = (b0 != SPEC_NIL ? 1u : 0u) + (b1 != SPEC_NIL ? 1u : 0u);
+			uint32_t k = wave_reserve(&sb.ctl->ndirty, cnt);
+			if (b0 != SPEC_NIL) {TERRA_ATOMIC_MIN(&sb.dirty_min[b0], iter); sb.dirty_list[k++] = b0;}
+			if (b1 != SPEC_NIL) {TERRA_ATOMIC_MIN(&sb.dirty_min[b1], iter); sb.dirty_list[k++] = b1;}
+			if (cnt) {TERRA_ATOMIC_OR(&sb.changed[slot], 1u);}
+		}
 	}
 	TERRA_WAVE_SYNC();
 	if (TERRA_LANE0 && sb.has_ver[slot] && TERRA_L2_LOAD(&sb.changed[slot]) == 0u) {TERRA_ATOMIC_ADD(&sb.ctl->retraces_same, 1u);}
@@ -1233,25 +1255,32 @@ TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 	if (iter == SPEC_NIL || iter >= nbase) return;
 	uint32_t const cb = sb.cur[slot], n = sb.blk_cnt[cb][slot];
 	size_t const pbase = (size_t)slot*sb.maxb;
-	TERRA_LANES(e, n) { // one page per lane: the dependent loads of the ownership test (list walk, masks) of different pages overlap; the cell stores need no reply
-		uint32_t const ent = sb.blk_list[cb][pbase + e];
-		if (!(ent & SPEC_BLK_WRITTEN)) continue;
-		uint32_t const b = ent & SPEC_BLK_ID;
-		unsigned long long mine = sb.page_mask[cb][pbase + e];
-		for (uint32_t node = sb.head[b]; node != SPEC_NIL && mine; node = sb.next[node]) { // a later committed droplet owns the final value of the cells it wrote
-			uint32_t const j = node / sb.maxb, ij = sb.it[j];
-			if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
-			mine &= ~sb.page_mask[sb.cur[j]][node];
-		}
-		if (!mine) continue;
-		uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
-		float const *page = sb.page_vals[cb] + (pbase + e)*SPEC_PAGE;
-		uint32_t k = sb.touched ? TERRA_ATOMIC_ADD(&sb.ctl->touched, (uint32_t)__builtin_popcountll(mine)) : 0u; // one reservation per page, not per cell: the counter is a single address for the whole chip
-		for (; mine; mine &= mine - 1, ++k) {
-			uint32_t const c = (uint32_t)__builtin_ctzll(mine);
-			uint32_t const X = (bx << 3) + (c & 7u), Z = (bz << 3) + (c >> 3);
-			*sb.grid.at((int)X, (int)Z) = page[c];
-			if (sb.touched && k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
+	for (uint32_t e0 = 0; e0 < n; e0 += 64) { // one page per lane: the dependent loads of the ownership test (list walk, masks) of different pages overlap; the cell stores need no reply
+		TERRA_EACH_LANE(l) {
+			uint32_t const e = e0 + (uint32_t)l;
+			unsigned long long mine = 0;
+			uint32_t b = 0;
+			if (e < n) {
+				uint32_t const ent = sb.blk_list[cb][pbase + e];
+				if (ent & SPEC_BLK_WRITTEN) {
+					b = ent & SPEC_BLK_ID;
+					mine = sb.page_mask[cb][pbase + e];
+					for (uint32_t node = sb.head[b]; node != SPEC_NIL && mine; node = sb.next[node]) { // a later committed droplet owns the final value of the cells it wrote
+						uint32_t const j = node / sb.maxb, ij = sb.it[j];
+						if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
+						mine &= ~sb.page_mask[sb.cur[j]][node];
+					}
+				}
+			}
+			uint32_t k = wave_reserve(&sb.ctl->touched, sb.touched ? (uint32_t)__builtin_popcountll(mine) : 0u); // (the record of written cells for the sparse final clamp)
+			uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
+			float const *page = sb.page_vals[cb] + (pbase + e)*SPEC_PAGE;
+			for (; mine; mine &= mine - 1, ++k) {
+				uint32_t const c = (uint32_t)__builtin_ctzll(mine);
+				uint32_t const X = (bx << 3) + (c & 7u), Z = (bz << 3) + (c >> 3);
+				*sb.grid.at((int)X, (int)Z) = page[c];
+				if (sb.touched && k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
+			}
 		}
 	}
 }
