@@ -1245,8 +1245,8 @@ TERRA_HD void spec_scan_body(spec_buffers_t const &sb, uint32_t slot) {
 		else {sb.rsrc[slot] = (ph0 == SPEC_IDLE) ? 1u : ((ph0 == SPEC_RUNNING) ? 2u : 0u); sb.rat[slot] = hit; sb.phase[slot] = SPEC_FRESH;}
 	}
 	uint32_t const ph = sb.phase[slot];
-	if (ph == SPEC_FAILED) {TERRA_ATOMIC_MIN(&sb.ctl->new_stop, iter);}
-	if (!(ph == SPEC_IDLE && sb.has_ver[slot])) {TERRA_ATOMIC_MIN(&sb.ctl->new_base, iter); TERRA_ATOMIC_ADD(&sb.ctl->unfinished, 1u);}
+	if (ph == SPEC_FAILED && iter < TERRA_L2_LOAD(&sb.ctl->new_stop)) {TERRA_ATOMIC_MIN(&sb.ctl->new_stop, iter);}
+	if (!(ph == SPEC_IDLE && sb.has_ver[slot]) && iter < TERRA_L2_LOAD(&sb.ctl->new_base)) {TERRA_ATOMIC_MIN(&sb.ctl->new_base, iter);} // look first: thousands of slots fold into one word, and only the lowest few can lower it
 }
 // flush the committed droplets [base, new_base): the highest-numbered committed writer of a cell stores it.  One wave per slot; the
 // flushed buffer is left empty for the slot's next droplet.
