@@ -479,9 +479,8 @@ constexpr unsigned SPEC_CAND = 4, SPEC_CAND_MANY = 255;
 // checkpoints of a trace (measured: profiles/r02_erosion_checkpoint_sweep.txt): every SPEC_CK_STEPS steps the window's dirty cells are written back and the droplet state, the footprint length, the write masks and
 // the position in the undo log are saved, so that a re-trace can resume from the last checkpoint whose inputs are still valid instead of from the spawn
 constexpr unsigned SPEC_CK_STEPS = 32, SPEC_CK_MAX = 16, SPEC_UNDO_MAX = 4096; // (defaults: spec_buffers_t::ck_steps / ck_max are the values in force, ck_max <= SPEC_CK_MAX)
-// where a cell entering the window is read from: the grid, nothing (it stays in the window / lies outside the grid), the grid + a walk of the block's writer list,
-// or float index (bits 0..29) into version buffer (bit 31); bit 30: the page is this trace's own
-constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu, SPEC_SRC_NONE = 0xFFFFFFFEu, SPEC_SRC_SLOW = 0xFFFFFFFDu, SPEC_SRC_OWN_BIT = 0x40000000u;
+// where a cell entering the window is read from: the grid, or float index (bits 0..30) into version buffer (bit 31)
+constexpr uint32_t SPEC_SRC_GRID = 0xFFFFFFFFu;
 struct spec_cand_t {uint32_t page, it; unsigned long long mask;}; // page = slot*maxb + entry, bit 31: the version buffer
 struct wave_shared_t { // per-wave LDS scratch
 	uint32_t flags, pad_;
@@ -641,11 +640,9 @@ struct grid_back_t {
 	TERRA_HD void note_write() {}
 	TERRA_HD void note_written_rect(int, int) {}
 	TERRA_HD float base(int X, int Z) const {return *g.at(X, Z);}
-	TERRA_HD bool needs_lookup(int, int) const {return false;}
 	TERRA_HD float lookup(int, int, float b) const {return b;}
 	TERRA_HD uint32_t source(int, int, bool &slow, bool &own) const {slow = false; own = false; return SPEC_SRC_GRID;}
 	TERRA_HD float const *source_ptr(uint32_t, int X, int Z) const {return g.at(X, Z);}
-	TERRA_HD bool source_is_own(uint32_t) const {return false;}
 	TERRA_HD void store(int X, int Z, float v) {
 		*g.at(X, Z) = v;
 		if (touched) {uint32_t const k = TERRA_ATOMIC_ADD(touched_count, 1u); if (k < touched_cap) {touched[k] = (uint32_t)Z*(uint32_t)g.NX + (uint32_t)X;}}
@@ -929,7 +926,6 @@ struct spec_back_t {
 		e = map_find(block_of(X, Z));
 		return e != SPEC_NIL && ((sh->masks[e] >> page_cell(X, Z)) & 1ull);
 	}
-	TERRA_HD bool needs_lookup(int X, int Z) const {uint32_t e; return own_written(X, Z, e) || block_flag(X, Z);}
 	// where the current value of a cell that enters the window is read from, as a 32-bit code (the lane keeps sixteen of them in registers): SPEC_SRC_GRID, or
 	// a float index into the two version buffers (bit 31: buffer; this trace's own page included -- own: it was written in this kernel, read it through to L2).
 	// slow: the block has more lower versions than the candidate list holds -- the caller reads the grid value and passes it through lookup()
@@ -937,7 +933,7 @@ struct spec_back_t {
 		uint32_t const c = page_cell(X, Z);
 		uint32_t e;
 		slow = false; own = false;
-		if (own_written(X, Z, e)) {own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);} // (the caller adds SPEC_SRC_OWN_BIT)
+		if (own_written(X, Z, e)) {own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);}
 		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
 		uint32_t const bi = (uint32_t)(bz*wnb + bx), cnt = sh->blk_shared[bi]; // inside the prepared window by construction
 		if (cnt) {
@@ -952,8 +948,7 @@ struct spec_back_t {
 		}
 		return SPEC_SRC_GRID;
 	}
-	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code >= SPEC_SRC_SLOW) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x3FFFFFFFu);}
-	TERRA_HD bool source_is_own(uint32_t code) const {return code < SPEC_SRC_SLOW && (code & SPEC_SRC_OWN_BIT) != 0;}
+	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code == SPEC_SRC_GRID) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x7FFFFFFFu);}
 	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`
 	TERRA_HD float lookup(int X, int Z, float b) const {
 		uint32_t const c = page_cell(X, Z);
