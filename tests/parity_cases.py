@@ -128,22 +128,25 @@ def case_erosion_vs_oracle(pkg, t, orc, n, iters, mode=0, flags=0, seed=1):
     return r, stats
 
 
-def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_cap=0, seed=1, near=0):
+def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_cap=0, seed=1, near=0, ck=None):
     """many more droplets than ring slots, traces suspended every `slice_steps` steps (all but the `near` droplets next in line for the commit): commits, slot
     hand-over, resumed traces (their block map and write masks rebuilt from the version buffer), restarts of suspended traces and (blk_cap) overflow fall-backs
     in the middle of the ring -- still the serial result, bit for bit."""
     import os
     t.set_erosion_tuning(window=window, block_list_capacity=blk_cap)
     t.set_erosion_slice_steps(slice_steps)
-    old = os.environ.get("TERRA_ERO_NEAR")
+    old = {k: os.environ.get(k) for k in ("TERRA_ERO_NEAR", "TERRA_ERO_CK")}
     os.environ["TERRA_ERO_NEAR"] = str(near)  # the default (512) is larger than these rings: nothing would ever be sliced
+    if ck is not None:
+        os.environ["TERRA_ERO_CK"] = ck       # "steps:max" -- checkpoint spacing of a trace: re-traces resume from checkpoints (copy / roll-back + undo log)
     try:
         r, stats = case_erosion_vs_oracle(pkg, t, orc, n, iters, seed=seed)
     finally:
-        if old is None:
-            del os.environ["TERRA_ERO_NEAR"]
-        else:
-            os.environ["TERRA_ERO_NEAR"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         t.set_erosion_tuning(window=0xFFFFFFFF, block_list_capacity=256)
         t.set_erosion_slice_steps(1024)
     assert r.windows == -(-iters // window)

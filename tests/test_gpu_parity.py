@@ -58,6 +58,12 @@ def test_erosion_sliding_ring(pkg, gpu, orc, n, iters, window, slice_steps, blk_
         assert r.serial_fallbacks >= 1
 
 
+@pytest.mark.parametrize("ck,near,window,slice_steps", [("1:16", 0, 64, 16), ("4:16", 100000, 256, 32), ("7:3", 8, 128, 9)])
+def test_erosion_checkpointed_retraces(pkg, gpu, orc, ck, near, window, slice_steps):
+    r, _ = pc.case_erosion_sliding_ring(pkg, gpu, orc, 256, 6000, window, slice_steps, near=near, ck=ck)
+    assert r.checkpoint_resumes > 0 and r.checkpoint_steps_saved > 0
+
+
 def test_grid_degenerate_shapes(pkg, gpu, orc):
     pc.case_grid_degenerate_shapes(pkg, gpu, orc)
 

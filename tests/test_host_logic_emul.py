@@ -100,6 +100,18 @@ def test_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk
         assert r.serial_fallbacks >= 1
 
 
+@pytest.mark.parametrize("ck,near,window,slice_steps", [("1:16", 0, 64, 16), ("2:16", 8, 48, 5), ("4:16", 100000, 64, 16), ("7:3", 0, 32, 9), ("32:0", 4, 64, 16), ("3:16", 2, 200, 64)])
+def test_erosion_checkpointed_retraces(pkg, emul, orc, ck, near, window, slice_steps):
+    """re-traces that resume from a checkpoint of the droplet's previous trace: dense droplets on a small map (every droplet conflicts with its neighbours in the ring),
+    checkpoints every few steps so that the copy-from-the-published-version and the roll-back-in-place paths, the undo log (with one step per checkpoint nearly every
+    write-back rewrites a cell) and checkpoint exhaustion all occur -- still the serial result, bit for bit"""
+    r, _ = pc.case_erosion_sliding_ring(pkg, emul, orc, 160, 2500, window, slice_steps, near=near, ck=ck)
+    if not ck.endswith(":0"):
+        assert r.checkpoint_resumes > 0 and r.checkpoint_steps_saved > 0
+    else:
+        assert r.checkpoint_resumes == 0
+
+
 def test_grid_degenerate_shapes(pkg, emul, orc):
     pc.case_grid_degenerate_shapes(pkg, emul, orc)
 
