@@ -13,7 +13,7 @@ The z grid never leaves HBM inside the timed region (there is no input grid; par
 eroded exactly like the reference erodes each tile alone on its clamp-padded copy (src/tiled_mesh.cpp:515): no data-path
 collective, weak scaling, `pipelines` heightmaps in flight per GPU.
 
-The same run also measures, under `detail` (all ranks take part, rank 0 reports; switch off with --no-extras):
+The same run also measures, under `detail` (incl. `dense_erosion`: 10^6 droplets on the bench grid and on BASELINE config 3's 4096^2 map) (all ranks take part, rank 0 reports; switch off with --no-extras):
   single   one heightmap in flight (no overlap of a map's erosion with the next map's noise): the latency of one map
   strips   STRONG scaling of ONE 16384^2 grid: rank r evaluates rows [r*N/W, (r+1)*N/W) (terra_gen_grid_rows_minmax_dev, bit-identical to the
            full grid), min(vals) = one float through all_reduce(min) over RCCL; erosion does not shard in the reference's semantics
@@ -350,6 +350,19 @@ def main():
                             "tflops_8d": round(fl * cells / (msn * 1e-3) / 1e12, 2), "frac_fp32_peak": round(fl * cells / (msn * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
             t.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
             detail["modes"] = md
+            # dense whole-map erosion (config_heightmap.txt:78 carries 10^6 droplets; BASELINE config 3 is the 4096^2 map): one run each, wall clock with a synchronize on both sides
+            de = {}
+            for nn, dd in ((N, 1000000), (4096, 1000000), (4096, 100000)):
+                zz = z[:nn * nn]
+                for rep in range(2):  # the first run of a shape allocates the scheduler's buffers (GBs for the 16384^2 ring): time the second
+                    mnd, _ = t.gen_grid_minmax_dev(zz.data_ptr(), -nn / 2, -nn / 2, st.DX_VAL, st.DY_VAL, nn, nn, pkg.GEN_GLACIATE)
+                    t.synchronize()
+                    t0 = time.perf_counter()
+                    t.apply_erosion_dev(zz.data_ptr(), nn, nn, mnd, dd, pkg.ERODE_MINZ_IS_MIN)
+                    t.synchronize()
+                    sec = time.perf_counter() - t0
+                de[f"{nn}x{nn}_{dd}_droplets"] = {"ms": round(sec * 1e3, 2), "mdroplets_s": round(dd / sec / 1e6, 3), "rounds": t.erosion_report().rounds}
+            detail["dense_erosion"] = de
     barrier()
 
     if rank == 0:
