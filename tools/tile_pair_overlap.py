@@ -39,3 +39,15 @@ for tx, ty in zip(args[0::2], args[1::2]):
             chain += steps[j] + steps[j + 1]; j += 2; continue   # overlap: the higher droplet re-runs after the lower one
         chain += steps[j]; j += 1
     print(f"tile ({tx},{ty}): {serial} steps in serial order, land droplets {(steps > 2).sum()}, neighbouring pairs disjoint at 4x4 granularity {ok}/{pairs} = {ok / max(1, pairs):.2f}, chain with pairs {chain} = {serial / max(1, chain):.2f}x shorter")
+    for lag in (1, 2, 3, 4, 5, 6, 7, 8, 16, 37, 64):
+        ok = sum(1 for j in range(D - lag) if not (foot[j] & foot[j + lag]))
+        print(f"    droplets (i, i+{lag}) disjoint: {ok / (D - lag):.3f}", end=";")
+    print()
+    for K in (2, 4, 8):
+        clean = 0; nb = 0
+        for b in range(0, D - K + 1, K):
+            nb += 1
+            clean += all(not (foot[b + i] & foot[b + j]) for i in range(K) for j in range(i + 1, K))
+        print(f"    batches of {K} consecutive droplets that are pairwise disjoint: {clean}/{nb}")
+    xs0 = [min(foot[j]) % 64 if foot[j] else -1 for j in range(12)]
+    print("    first coarse column of droplets 0..11:", xs0)
