@@ -691,7 +691,7 @@ template<class BE> struct terra_engine {
 			o_cks[b] = carve((size_t)W*SPEC_CK_MAX*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*SPEC_CK_MAX*4); o_cku[b] = carve((size_t)W*SPEC_CK_MAX*4);
 			o_ckm[b] = carve((size_t)W*SPEC_CK_MAX*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_uv[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_un[b] = carve(W*4);
 		}
-		size_t const o_slot = carve((size_t)W*4*12); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, rsrc, rat, rentry
+		size_t const o_slot = carve((size_t)W*4*13); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry
 		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
 		size_t const o_next = carve((size_t)W*sb.maxb*4), o_nodeblk = carve((size_t)W*sb.maxb*4), o_dlist = carve((size_t)W*sb.maxb*8), o_ctl = carve(sizeof(spec_ctl_t));
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
@@ -707,7 +707,7 @@ template<class BE> struct terra_engine {
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
 		sb.it = slot_arrays; sb.phase = slot_arrays + W; sb.has_ver = slot_arrays + 2*(size_t)W; sb.cur = slot_arrays + 3*(size_t)W; sb.changed = slot_arrays + 4*(size_t)W;
 		sb.restart = slot_arrays + 5*(size_t)W; sb.run_nblk = slot_arrays + 6*(size_t)W; sb.flags = slot_arrays + 7*(size_t)W; sb.nsteps = slot_arrays + 8*(size_t)W;
-		sb.rsrc = slot_arrays + 9*(size_t)W; sb.rat = slot_arrays + 10*(size_t)W; sb.rentry = slot_arrays + 11*(size_t)W;
+		sb.linked = slot_arrays + 9*(size_t)W; sb.rsrc = slot_arrays + 10*(size_t)W; sb.rat = slot_arrays + 11*(size_t)W; sb.rentry = slot_arrays + 12*(size_t)W;
 		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
 		sb.next = (uint32_t *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.ctl = (spec_ctl_t *)(base + o_ctl);
@@ -718,7 +718,7 @@ template<class BE> struct terra_engine {
 		if (spec_blocks_clean != blk_arrays || spec_blocks_n != nblocks) {be.fill32(blk_arrays, SPEC_NIL, 2*nblocks);}
 		spec_blocks_clean = nullptr; // not clean again until this run has taken its lists apart
 		spec_buffers_t const s = sb;
-		be.fill32(slot_arrays, 0, (size_t)W*10);
+		be.fill32(slot_arrays, 0, (size_t)W*11);
 		be.fill32(sb.rat, SPEC_NIL, (size_t)W*2); // rat, rentry
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
 		for (int b = 0; b < 2; ++b) {be.fill32(sb.ck_cnt[b], 0, W); be.fill32(sb.undo_n[b], 0, W);}
@@ -731,7 +731,6 @@ template<class BE> struct terra_engine {
 		uint32_t const slice = std::max<uint32_t>(spec_cfg.slice_steps, 1);
 		uint32_t host_base = 0, launched = 0;
 		spec_ctl_t hc{};
-		size_t const nse = (size_t)W*sb.maxb;
 		// One round = 8 dependent launches (the trace waves, five bookkeeping passes, the commit / checkpoint-resume waves, the end-of-round bookkeeping), captured once into a hipGraph and
 		// replayed.  Nothing in a round needs a host decision -- the step budget, the commit point and the pause behind a failed droplet are all taken from the
 		// device-resident control block -- so the host queues rounds in batches and reads the control block back once per batch; a round after the end (or while the
@@ -744,16 +743,22 @@ template<class BE> struct terra_engine {
 			try {
 				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, slice, ws);});
 				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_post_wave(s, (uint32_t)i);});
-				be.launch(nse, [=] TERRA_LAMBDA (size_t i) { // publish the finished versions; take the writer lists apart (both after the dirty marks were made from the OLD published versions)
-					spec_unlink_body(s, (uint32_t)i);
-					if (i < s.W) {spec_flip_body(s, (uint32_t)i);}
+				// the three passes below: 64 logical threads per slot that walk the slot's entries up to the count in use (a footprint holds ~30 of its 256 entries;
+				// one thread per (slot, entry) made these passes cost as much as the traces on a 32768-slot ring)
+				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // publish the finished versions; take the writer lists apart (both after the dirty marks were made from the OLD published versions)
+					uint32_t const slot = (uint32_t)(i >> 6), l = (uint32_t)(i & 63u), n = s.linked[slot];
+					for (uint32_t e = l; e < n; e += 64) {spec_unlink_body(s, slot*s.maxb + e);}
+					if (l == 0) {spec_flip_body(s, slot);}
 				});
-				be.launch(nse, [=] TERRA_LAMBDA (size_t i) { // rebuild the writer lists from the published versions; who must start over
-					spec_link_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));
-					spec_mark_body(s, (uint32_t)(i / s.maxb), (uint32_t)(i % s.maxb));
+				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // rebuild the writer lists from the published versions; who must start over
+					uint32_t const slot = (uint32_t)(i >> 6), l = (uint32_t)(i & 63u);
+					uint32_t const pub = (s.it[slot] != SPEC_NIL && s.has_ver[slot]) ? s.blk_cnt[s.cur[slot]][slot] : 0u, run = s.run_nblk[slot], n = (pub > run) ? pub : run;
+					for (uint32_t e = l; e < n; e += 64) {spec_link_body(s, slot, e); spec_mark_body(s, slot, e);}
+					if (l == 0) {s.linked[slot] = pub;}
 				});
-				be.launch(nse*2, [=] TERRA_LAMBDA (size_t i) { // apply the restarts, find the commit point; reset the dirty marks
-					spec_undirty_body(s, (uint32_t)i);
+				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // apply the restarts, find the commit point; reset the dirty marks
+					uint32_t const nd = s.ctl->ndirty;
+					for (size_t k = i; k < nd; k += (size_t)s.W*64) {spec_undirty_body(s, (uint32_t)k);}
 					if (i < s.W) {spec_scan_body(s, (uint32_t)i);}
 				});
 				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) { // commit; and a re-trace that can resume from a checkpoint becomes a suspended trace at that checkpoint

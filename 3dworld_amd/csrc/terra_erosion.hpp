@@ -716,6 +716,7 @@ struct spec_buffers_t {
 	uint32_t *ck_cnt[2];                // [W] checkpoints of the buffer's trace (0: none usable)
 	uint32_t *undo_idx[2]; float *undo_val[2]; // [W][SPEC_UNDO_MAX]
 	uint32_t *undo_n[2];                // [W] log length when the trace stopped
+	uint32_t *linked;      // [W] entries of the slot that may be linked into the block -> writers lists (set by the link pass: bounds the next unlink pass)
 	uint32_t *rentry;      // [W] lowest footprint entry of the slot's trace that a changed lower version touched this round (mark pass; SPEC_NIL: none)
 	uint32_t *rsrc;        // [W] pending re-trace: 0 = from the spawn, 1 = may resume from a checkpoint of the published version, 2 = of the suspended trace
 	uint32_t *rat;         // [W] ... whose footprint is valid below this entry
