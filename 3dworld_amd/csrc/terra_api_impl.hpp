@@ -271,6 +271,53 @@ int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height
 	TERRA_CATCH
 }
 
+// ---- the loaded-heightmap path (rest of row a12): heightmap_t::to_floats / from_floats / postprocess_height (src/heightmap.cpp:117-128,191-215)
+int terra_set_mesh_file_scale(terra_ctx *ctx, float mesh_file_scale, float mesh_file_tz) {
+	TERRA_CHECK_CTX
+	if (!(mesh_file_scale != 0.0f) || mesh_file_scale != mesh_file_scale || mesh_file_tz != mesh_file_tz) return terra::fail(TERRA_ERR_ARG, "terra_set_mesh_file_scale: scale must be a non-zero number");
+	ctx->eng.mesh_file_scale = mesh_file_scale; ctx->eng.mesh_file_tz = mesh_file_tz;
+	return TERRA_OK;
+}
+int terra_get_mesh_file_scale(terra_ctx *ctx, float *mesh_file_scale, float *mesh_file_tz) {
+	TERRA_CHECK_CTX
+	if (mesh_file_scale) *mesh_file_scale = ctx->eng.mesh_file_scale;
+	if (mesh_file_tz) *mesh_file_tz = ctx->eng.mesh_file_tz;
+	return TERRA_OK;
+}
+static int terra_check_image(uint32_t width, uint32_t height, int ncolors) {
+	if (width == 0 || height == 0 || (uint64_t)width*height >= (1ull << 31)) return terra::fail(TERRA_ERR_ARG, "heightmap image: bad size");
+	if (ncolors != 1 && ncolors != 2) return terra::fail(TERRA_ERR_ARG, "heightmap image: one or two byte grayscale only");
+	return TERRA_OK;
+}
+int terra_heightmap_to_floats_dev(terra_ctx *ctx, const uint8_t *d_pixels, uint32_t width, uint32_t height, int ncolors, float *d_vals) {
+	TERRA_CHECK_CTX if (!d_pixels || !d_vals) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (int const rc = terra_check_image(width, height, ncolors)) return rc;
+	TERRA_TRY ctx->eng.heightmap_to_floats_dev(d_pixels, (size_t)width*height, ncolors, d_vals); TERRA_CATCH
+}
+int terra_heightmap_from_floats_dev(terra_ctx *ctx, const float *d_vals, uint32_t width, uint32_t height, int ncolors, uint8_t *d_pixels, uint32_t *h_out_of_range) {
+	TERRA_CHECK_CTX if (!d_pixels || !d_vals) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (int const rc = terra_check_image(width, height, ncolors)) return rc;
+	TERRA_TRY
+		uint32_t const bad = ctx->eng.heightmap_from_floats_dev(d_vals, (size_t)width*height, ncolors, d_pixels);
+		if (h_out_of_range) {*h_out_of_range = bad;}
+		else if (bad) throw std::logic_error("heightmap from_floats: values outside [0, 256) pixel units (the reference asserts, src/heightmap.cpp:210)");
+	TERRA_CATCH
+}
+int terra_heightmap_postprocess_dev(terra_ctx *ctx, uint8_t *d_pixels, uint32_t width, uint32_t height, int ncolors, uint32_t erosion_iters_tt, float *d_vals, uint32_t *h_out_of_range) {
+	TERRA_CHECK_CTX if (!d_pixels) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (int const rc = terra_check_image(width, height, ncolors)) return rc;
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		float *vals = d_vals;
+		if (!vals && erosion_iters_tt) {vals = (float *)be.alloc((size_t)width*height*sizeof(float));}
+		uint32_t bad = 0;
+		try {bad = ctx->eng.heightmap_postprocess_dev(d_pixels, width, height, ncolors, erosion_iters_tt, vals); if (!d_vals) {be.sync();}} catch (...) {if (!d_vals && vals) be.free(vals); throw;}
+		if (!d_vals && vals) {be.free(vals);}
+		if (h_out_of_range) {*h_out_of_range = bad;}
+		else if (bad) throw std::logic_error("heightmap postprocess_height: eroded values outside [0, 256) pixel units (the reference asserts, src/heightmap.cpp:210)");
+	TERRA_CATCH
+}
+
 // ---- heightmap files (host): 8- / 16-bit grayscale PNG with the reference's row order and byte order (terra_png.hpp)
 int terra_heightmap_write_png(const char *path, const uint8_t *h_pixels, uint32_t width, uint32_t height, int ncolors) {
 	if (!path || !h_pixels) return terra::fail(TERRA_ERR_ARG, "null argument");

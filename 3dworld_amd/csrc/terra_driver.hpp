@@ -597,6 +597,82 @@ template<class BE> struct terra_engine {
 		be.quantize16(d_vals, n, val_add, val_div, d_pix);
 	}
 
+	// ---- the loaded-heightmap path: heightmap_t::to_floats / from_floats / postprocess_height (src/heightmap.cpp:117-128,191-215) with the pixel <-> height
+	// scale of get_mh_texture_mult() / get_mh_texture_add() (src/mesh_gen.cpp:122-123): mesh_file_scale / mesh_file_tz are the two numbers after the file name
+	// in the config line `mh_filename <png> <scale> <tz>` (src/3DWorld.cpp:2205), or what set_mesh_height_scales_for_zval_range left behind
+	float mh_texture_mult() const {float const READ_MESH_H_SCALE = 0.0008f; return READ_MESH_H_SCALE*mesh_height_scale*mesh_file_scale*mesh_scale_z_inv;}
+	float mh_texture_add() const {return mesh_file_tz*mesh_scale_z_inv;}
+	void heightmap_to_floats_dev(uint8_t const *d_pix, size_t n, int ncolors, float *d_vals) {
+		require_scene();
+		if (ncolors != 1 && ncolors != 2) throw std::invalid_argument("heightmap to_floats: one or two byte grayscale only"); // assert(ncolors == 1 || ncolors == 2), src/heightmap.cpp:122
+		if (n == 0) throw std::invalid_argument("heightmap to_floats: empty image");                                         // assert(!vals.empty()), :194
+		float const val_mult = mh_texture_mult(), val_add = mh_texture_add();
+		// HBM bound (1-2 B read, 4 B written per pixel): four pixels per thread, one 4- / 8-byte load and one 16-byte store where the pointers allow it
+		bool const wide = (((uintptr_t)d_pix & 7u) == 0) && (((uintptr_t)d_vals & 15u) == 0);
+		size_t const n4 = wide ? n/4 : 0;
+		if (n4) {
+			be.launch(n4, [=] TERRA_LAMBDA (size_t q) {
+				float o[4];
+				if (ncolors == 2) {
+					uint64_t w; memcpy(&w, d_pix + q*8, 8);
+					for (int k = 0; k < 4; ++k) {unsigned const lo = (unsigned)(w >> (16*k)) & 255u, hi = (unsigned)(w >> (16*k + 8)) & 255u; o[k] = val_mult*(float)((double)lo/256.0 + (double)hi) + val_add;}
+				}
+				else {
+					uint32_t w; memcpy(&w, d_pix + q*4, 4);
+					for (int k = 0; k < 4; ++k) {o[k] = val_mult*(float)((w >> (8*k)) & 255u) + val_add;}
+				}
+				memcpy(d_vals + q*4, o, 16);
+			});
+		}
+		size_t const done = n4*4;
+		be.launch(n - done, [=] TERRA_LAMBDA (size_t j) {
+			size_t const i = done + j;
+			float v = (ncolors == 2) ? (float)((double)d_pix[i<<1]/256.0 + (double)d_pix[(i<<1)+1]) : (float)d_pix[i];
+			d_vals[i] = val_mult*v + val_add;
+		});
+	}
+	// from_floats with the scale in force (NOT proc_gen's rescale to the value range); returns how many values fell outside [0, 256), where the reference asserts (:210)
+	uint32_t heightmap_from_floats_dev(float const *d_vals, size_t n, int ncolors, uint8_t *d_pix) {
+		require_scene();
+		if (ncolors != 1 && ncolors != 2) throw std::invalid_argument("heightmap from_floats: one or two byte grayscale only");
+		float const val_div = (float)(1.0/(double)mh_texture_mult()), val_add = mh_texture_add();
+		uint32_t *d_bad = scratch<uint32_t>(s_mm, 2);
+		be.fill32(d_bad, 0, 1);
+		be.launch((n + 3)/4, [=] TERRA_LAMBDA (size_t q) {
+			size_t const b = q*4, e = (b + 4 < n) ? b + 4 : n;
+			uint32_t bad = 0;
+			for (size_t i = b; i < e; ++i) {
+				float const v = (d_vals[i] - val_add)*val_div;
+				if (!(v >= 0.0f && v < 256.0f)) {++bad;}
+			}
+			if (bad) {TERRA_ATOMIC_ADD(d_bad, bad);}
+		});
+		if (ncolors == 2) {be.quantize16(d_vals, n, val_add, val_div, d_pix);}
+		else {
+			be.launch((n + 3)/4, [=] TERRA_LAMBDA (size_t q) {
+				size_t const b = q*4, e = (b + 4 < n) ? b + 4 : n;
+				for (size_t i = b; i < e; ++i) {d_pix[i] = (uint8_t)f2i_x86((d_vals[i] - val_add)*val_div);} // data[i] = (unsigned char)v
+			});
+		}
+		uint32_t bad = 0;
+		be.d2h(&bad, d_bad, 4);
+		return bad;
+	}
+	// heightmap_t::postprocess_height (src/heightmap.cpp:117-128), called right after the image was loaded (terrain_hmap_manager_t::load, :351): pixels -> floats ->
+	// run_erosion (min_zval = min(vals), erosion_iters_tt droplets over the whole image) -> [run_city_gen: other subsystem] -> pixels, in place.
+	// d_vals: width*height floats of device scratch supplied by the caller, left holding the eroded heights.
+	uint32_t heightmap_postprocess_dev(uint8_t *d_pix, uint32_t width, uint32_t height, int ncolors, uint32_t iters_tt, float *d_vals) {
+		require_scene();
+		if (iters_tt == 0) return 0; // "no erosion or cities => no need to update height values"
+		size_t const n = (size_t)width*height;
+		heightmap_to_floats_dev(d_pix, n, ncolors, d_vals);
+		if (erode_amount > 0.0f) { // (apply_erosion's own early-out, src/erosion.cpp:16)
+			float mn, mx; minmax_dev(d_vals, n, mn, mx);
+			apply_erosion_dev(d_vals, (int)width, (int)height, mn, iters_tt, TERRA_ERODE_MINZ_IS_MIN);
+		}
+		return heightmap_from_floats_dev(d_vals, n, ncolors, d_pix);
+	}
+
 	// ================================================================ erosion (a11)
 	erosion_consts_t make_erosion_consts(int xsize, int ysize, float min_zval) const {
 		erosion_consts_t ec;

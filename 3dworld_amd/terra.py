@@ -140,6 +140,11 @@ _PROTOS = {
     "terra_tiles_mesh_shadows_halo_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
     "terra_hmap_set_dev": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "terra_set_mesh_height_scales_for_zval_range": (_i32, [_vp, _f, _f]),
+    "terra_set_mesh_file_scale": (_i32, [_vp, _f, _f]),
+    "terra_get_mesh_file_scale": (_i32, [_vp, _f3, _f3]),
+    "terra_heightmap_to_floats_dev": (_i32, [_vp, _vp, _u32, _u32, _i32, _vp]),
+    "terra_heightmap_from_floats_dev": (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, C.POINTER(_u32)]),
+    "terra_heightmap_postprocess_dev": (_i32, [_vp, _vp, _u32, _u32, _i32, _u32, _vp, C.POINTER(_u32)]),
     "terra_hmap_apply_brushes_dev": (_i32, [_vp, _vp, _u32, _i32, _u32]),
     "terra_hmap_apply_mods_dev": (_i32, [_vp, _vp, _u32]),
     "terra_hmap_read_and_apply_mod_dev": (_i32, [_vp, C.c_char_p]),
@@ -181,6 +186,19 @@ def load_library(path=None):
         fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete
         fn.restype, fn.argtypes = res, args
     return lib
+
+
+def read_png(path, allow_two_byte_grayscale=True, lib=None):
+    """terra_heightmap_read_png without a context (host-only entry point): (h, w) or (h, w, 2) uint8, rows flipped like texture_t::load_png"""
+    lib = lib or load_library()
+    w, h, nc = _u32(), _u32(), _i32()
+    args = (str(path).encode(), int(allow_two_byte_grayscale), C.byref(w), C.byref(h), C.byref(nc))
+    if lib.terra_heightmap_read_png(*args, None, 0) < 0:
+        raise TerraError(-1, lib.terra_last_error().decode())
+    out = np.empty((h.value, w.value, 2) if nc.value == 2 else (h.value, w.value), np.uint8)
+    if lib.terra_heightmap_read_png(*args, out.ctypes.data, out.nbytes) < 0:
+        raise TerraError(-1, lib.terra_last_error().decode())
+    return out
 
 
 class DeviceBuffer:
@@ -305,6 +323,30 @@ class Terra:
         self._ck(self.lib.terra_hmap_set_dev(self.ctx, ptr, width, height, ncolors))
         if ptr and min_z is not None:
             self._ck(self.lib.terra_set_mesh_height_scales_for_zval_range(self.ctx, min_z, dz))
+
+    def set_mesh_file_scale(self, scale, tz):
+        """config `mh_filename <png> <scale> <tz>`: pixel value -> height"""
+        self._ck(self.lib.terra_set_mesh_file_scale(self.ctx, scale, tz))
+
+    def get_mesh_file_scale(self):
+        a, b = C.c_float(), C.c_float()
+        self._ck(self.lib.terra_get_mesh_file_scale(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def heightmap_to_floats_dev(self, pix_ptr, width, height, ncolors, vals_ptr):
+        self._ck(self.lib.terra_heightmap_to_floats_dev(self.ctx, pix_ptr, width, height, ncolors, vals_ptr))
+
+    def heightmap_from_floats_dev(self, vals_ptr, width, height, ncolors, pix_ptr):
+        """-> number of values outside [0, 256) pixel units (the reference asserts on those)"""
+        bad = _u32()
+        self._ck(self.lib.terra_heightmap_from_floats_dev(self.ctx, vals_ptr, width, height, ncolors, pix_ptr, C.byref(bad)))
+        return bad.value
+
+    def heightmap_postprocess_dev(self, pix_ptr, width, height, ncolors, erosion_iters_tt, vals_ptr=None):
+        """heightmap_t::postprocess_height in place on the device image -> number of out-of-range values"""
+        bad = _u32()
+        self._ck(self.lib.terra_heightmap_postprocess_dev(self.ctx, pix_ptr, width, height, ncolors, erosion_iters_tt, vals_ptr, C.byref(bad)))
+        return bad.value
 
     def tiles_mesh_shadows(self, tile_xy, zvals, light_pos):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)

@@ -19,6 +19,8 @@
  *     (src/tiled_mesh.h:277,281-284; src/tiled_mesh.cpp:467-546,865-880)
  *   heightmap_t::proc_gen / run_erosion / from_floats                       terra_heightmap_proc_gen[_dev], terra_quantize16_dev
  *     (src/heightmap.cpp:130-215, src/Textures.cpp:1889-1893)
+ *   heightmap_t::to_floats / postprocess_height (loaded heightmaps)         terra_heightmap_to_floats_dev, terra_heightmap_from_floats_dev,
+ *     (src/heightmap.cpp:117-128,191-203,351)                                 terra_heightmap_postprocess_dev, terra_set_mesh_file_scale
  *   voxel_manager::create_procedural                                        terra_voxel_fill[_dev]
  *     (src/voxels.cpp:278-346, src/upsurface.cpp:16-70)
  *
@@ -197,6 +199,23 @@ int  terra_set_erosion_slice_steps(terra_ctx *ctx, uint32_t slice_steps);
 int  terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height, uint32_t erosion_iters, float *d_vals, uint8_t *d_pixels16, float *h_range);
 int  terra_minmax_dev(terra_ctx *ctx, const float *d_vals, size_t n, float *h_min, float *h_max); /* synchronous */
 int  terra_quantize16_dev(terra_ctx *ctx, const float *d_vals, size_t n, float min_z, float dz, uint8_t *d_pixels16);
+
+/* ---- the loaded-heightmap path: heightmap_t::to_floats / from_floats / postprocess_height (src/heightmap.cpp:117-128,191-215), what
+ * terrain_hmap_manager_t::load runs right after reading the PNG (src/heightmap.cpp:351), e.g. scene_config/config_heightmap.txt:78-87.
+ * terra_set_mesh_file_scale = the two numbers of the config line `mh_filename <png> <mesh_file_scale> <mesh_file_tz>` (src/3DWorld.cpp:2205): a pixel value
+ * v in [0, 256) is the height get_mh_texture_mult()*v + get_mh_texture_add() (src/mesh_gen.cpp:122-123); terra_set_mesh_height_scales_for_zval_range sets the same pair.
+ * d_pixels: width*height pixels in device memory, 1 byte each or 2 = {fraction, integer}.
+ * to_floats: pixels -> heights.  from_floats: heights -> pixels with the scale in force (8-bit: truncation; 16-bit: write_pixel_16_bits).
+ * postprocess: to_floats -> run_erosion (apply_erosion over the whole image, min_zval = min(vals), erosion_iters_tt droplets) -> from_floats, in place;
+ *   nothing happens when erosion_iters_tt == 0 (run_city_gen is another subsystem).  d_vals: width*height floats of device scratch that is left holding the
+ *   eroded heights, or NULL (allocated internally).
+ * h_out_of_range (optional): number of values that map outside [0, 256) -- the reference asserts on those (src/heightmap.cpp:210); with NULL such an image is
+ * TERRA_ERR_STATE (the pixels are still written, with the x86 conversion's wrap-around). */
+int  terra_set_mesh_file_scale(terra_ctx *ctx, float mesh_file_scale, float mesh_file_tz);
+int  terra_get_mesh_file_scale(terra_ctx *ctx, float *mesh_file_scale, float *mesh_file_tz);
+int  terra_heightmap_to_floats_dev(terra_ctx *ctx, const uint8_t *d_pixels, uint32_t width, uint32_t height, int ncolors, float *d_vals);
+int  terra_heightmap_from_floats_dev(terra_ctx *ctx, const float *d_vals, uint32_t width, uint32_t height, int ncolors, uint8_t *d_pixels, uint32_t *h_out_of_range);
+int  terra_heightmap_postprocess_dev(terra_ctx *ctx, uint8_t *d_pixels, uint32_t width, uint32_t height, int ncolors, uint32_t erosion_iters_tt, float *d_vals, uint32_t *h_out_of_range);
 
 /* ---- tiles: tile_t::create_zvals batch, size = 128 (zvsize 130, stride 129).
  * tile_xy: n pairs (tile x, tile y) on the HOST.  d_zvals: n*130*130 floats.  d_stats: n terra_tile_stats (optional).

@@ -377,6 +377,66 @@ REF_API void ref_heightmap_proc_gen(int width, int height, unsigned iters, unsig
 	erosion_iters_tt = prev;
 }
 
+// rest of row a12: the reference's own heightmap_t::to_floats / from_floats (private members: this file is compiled with -fno-access-control) and
+// postprocess_height (src/heightmap.cpp:117-128,191-215) on an image the harness copies in; mesh_file_scale / mesh_file_tz as the config line
+// `mh_filename <png> <scale> <tz>` sets them (src/3DWorld.cpp:2205).  from_floats / postprocess_height assert on values outside [0, 256): the harness counts
+// them first and then lets the member run only when there are none (the count is what the oracle and the library report).
+REF_API void ref_set_mesh_file_scale(float scale, float tz) {mesh_file_scale = scale; mesh_file_tz = tz;}
+static void shim_load_image(heightmap_t &hm, unsigned char const *pixels, int ncolors) {
+	hm.ncolors = 1;
+	if (ncolors == 2) {hm.set_16_bit_grayscale();}
+	hm.alloc();
+	memcpy(hm.get_data(), pixels, hm.num_bytes());
+}
+REF_API void ref_heightmap_to_floats(unsigned char const *pixels, int width, int height, int ncolors, float *vals) {
+	heightmap_t hm(0, ((ncolors == 2) ? 8 : 7), width, height, "@harness", 0);
+	shim_load_image(hm, pixels, ncolors);
+	vector<float> v;
+	hm.to_floats(v);
+	memcpy(vals, v.data(), v.size()*sizeof(float));
+	hm.free_data();
+}
+static unsigned shim_count_out_of_range(float const *vals, size_t n) {
+	float const val_div(1.0/get_mh_texture_mult()), val_add(get_mh_texture_add());
+	unsigned bad(0);
+	for (size_t i = 0; i < n; ++i) {float const v((vals[i] - val_add)*val_div); if (!(v >= 0.0 && v < 256.0)) {++bad;}}
+	return bad;
+}
+REF_API unsigned ref_heightmap_from_floats(float const *vals, int width, int height, int ncolors, unsigned char *pixels) {
+	size_t const n(size_t(width)*height);
+	unsigned const bad(shim_count_out_of_range(vals, n));
+	if (bad) return bad; // the member would assert
+	heightmap_t hm(0, ((ncolors == 2) ? 8 : 7), width, height, "@harness", 0);
+	hm.ncolors = 1;
+	if (ncolors == 2) {hm.set_16_bit_grayscale();}
+	hm.alloc();
+	vector<float> v(vals, vals + n);
+	hm.from_floats(v);
+	memcpy(pixels, hm.get_data(), hm.num_bytes());
+	hm.free_data();
+	return 0;
+}
+REF_API unsigned ref_heightmap_postprocess(unsigned char *pixels, int width, int height, int ncolors, unsigned iters_tt) {
+	unsigned const prev(erosion_iters_tt);
+	int const nt(omp_get_max_threads());
+	omp_set_num_threads(1); // apply_erosion's OpenMP loop is a data race: the serial droplet order is the only defined result
+	erosion_iters_tt = iters_tt;
+	heightmap_t hm(0, ((ncolors == 2) ? 8 : 7), width, height, "@harness", 0);
+	shim_load_image(hm, pixels, ncolors);
+	unsigned bad(0);
+	{ // dry run of to_floats + run_erosion to see whether from_floats would assert
+		vector<float> v;
+		hm.to_floats(v);
+		if (iters_tt > 0) {hm.run_erosion(v);}
+		bad = shim_count_out_of_range(v.data(), v.size());
+	}
+	if (bad == 0) {hm.postprocess_height(); memcpy(pixels, hm.get_data(), hm.num_bytes());}
+	hm.free_data();
+	erosion_iters_tt = prev;
+	omp_set_num_threads(nt);
+	return bad;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (4) the tile functions: the reference's OWN tile_t members (src/tiled_mesh.cpp compiled in place; get_tids / update_lttex_ix / gen_tex_height_tables
 //     from src/Textures.cpp compiled in place).  The harness builds a tile_t, calls the member, copies the member data out.  GL entry points the members

@@ -1456,6 +1456,51 @@ void orc_heightmap_proc_gen(int width, int height, unsigned iters, unsigned char
 	file_scale_tz[0] = mesh_file_scale; file_scale_tz[1] = mesh_file_tz;
 	free(vals);
 }
+/* ---- the loaded-heightmap path: the config line `mh_filename <png> <mesh_file_scale> <mesh_file_tz>` (src/3DWorld.cpp:2205), heightmap_t::to_floats /
+ * from_floats (src/heightmap.cpp:191-215) with get_mh_texture_mult() / get_mh_texture_add() (src/mesh_gen.cpp:122-123) and postprocess_height (:117-128) */
+void orc_set_mesh_file_scale(float scale, float tz) {mesh_file_scale = scale; mesh_file_tz = tz;}
+static float get_mh_texture_mult(void) {float const READ_MESH_H_SCALE = 0.0008f; return READ_MESH_H_SCALE*mesh_height_scale*mesh_file_scale*mesh_scale_z_inv;}
+static float get_mh_texture_add(void) {return mesh_file_tz*mesh_scale_z_inv;}
+void orc_heightmap_to_floats(unsigned char const *pixels, int width, int height, int ncolors, float *vals) {
+	float const val_mult = get_mh_texture_mult(), val_add = get_mh_texture_add();
+	size_t const n = (size_t)width*height;
+	for (size_t i = 0; i < n; ++i) { /* convert from pixel to heightmap value; max value is 255.0 */
+		float v;
+		if (ncolors == 2) {v = (float)((double)pixels[i<<1]/256.0 + (double)pixels[(i<<1)+1]);} /* 16-bit */
+		else {v = (float)pixels[i];} /* 8-bit */
+		vals[i] = val_mult*v + val_add;
+	}
+}
+/* returns the number of values outside [0, 256), where the reference asserts (src/heightmap.cpp:210) */
+unsigned orc_heightmap_from_floats(float const *vals, int width, int height, int ncolors, unsigned char *pixels) {
+	float const val_div = (float)(1.0/(double)get_mh_texture_mult()), val_add = get_mh_texture_add();
+	size_t const n = (size_t)width*height;
+	unsigned bad = 0;
+	for (size_t i = 0; i < n; ++i) {
+		float const v = (vals[i] - val_add)*val_div;
+		if (!(v >= 0.0f && v < 256.0f)) {++bad;}
+		if (ncolors == 2) { /* write_pixel_16_bits (src/Textures.cpp:1889-1893) */
+			unsigned char const high_bits = (unsigned char)v;
+			pixels[(i<<1)+1] = high_bits;
+			pixels[i<<1]     = (unsigned char)(256.0f*(v - (float)high_bits));
+		}
+		else {pixels[i] = (unsigned char)v;}
+	}
+	return bad;
+}
+unsigned orc_heightmap_postprocess(unsigned char *pixels, int width, int height, int ncolors, unsigned iters_tt) {
+	if (iters_tt == 0) return 0; /* no erosion or cities => no need to update height values */
+	size_t const n = (size_t)width*height;
+	float *vals = (float *)malloc(n*sizeof(float));
+	orc_heightmap_to_floats(pixels, width, height, ncolors, vals);
+	float min_zval = vals[0]; /* run_erosion (src/heightmap.cpp:153-187) */
+	for (size_t i = 0; i < n; ++i) {min_zval = fmin_std(min_zval, vals[i]);}
+	orc_apply_erosion(vals, width, height, min_zval, iters_tt);
+	unsigned const bad = orc_heightmap_from_floats(vals, width, height, ncolors, pixels);
+	free(vals);
+	return bad;
+}
+
 /* write_map_mode_heightmap_image (src/map_view.cpp:409-442) from the image origin on: setup_height_gen_cached (src/tiled_mesh.cpp:452-457),
  * get_mesh_height (src/map_view.cpp:97-105), rows inverted, 16-bit pixels = (h - min_z)*(255/dz).  min_z_dz = {min_z, dz}. */
 void orc_export_heightmap(float xstart, float ystart, int width, int height, unsigned char *pixels, float *min_z_dz) {

@@ -97,6 +97,11 @@ int   orc_hmap_write_mod(char const *fn, orc_hmap_mod_t const *mods, unsigned n,
 int   orc_hmap_read_mod(char const *fn, orc_hmap_mod_t *mods, unsigned *n, orc_hmap_brush_t *brushes, unsigned *nb);
 int   orc_hmap_read_and_apply_mod(char const *fn);
 void  orc_heightmap_proc_gen(int width, int height, unsigned iters, unsigned char *pixels, float *file_scale_tz);
+/* rest of row a12: the loaded-heightmap path (src/heightmap.cpp:117-128,191-215; config `mh_filename <png> <scale> <tz>`, src/3DWorld.cpp:2205) */
+void  orc_set_mesh_file_scale(float mesh_file_scale, float mesh_file_tz);
+void  orc_heightmap_to_floats(unsigned char const *pixels, int width, int height, int ncolors, float *vals);
+unsigned orc_heightmap_from_floats(float const *vals, int width, int height, int ncolors, unsigned char *pixels);   /* -> values outside [0, 256) */
+unsigned orc_heightmap_postprocess(unsigned char *pixels, int width, int height, int ncolors, unsigned iters_tt);    /* in place; -> values outside [0, 256) */
 void  orc_export_heightmap(float xstart, float ystart, int width, int height, unsigned char *pixels, float *min_z_dz);
 void  orc_tile_ao_lighting(int tx, int ty, float const *zvals, unsigned char *ao);
 void  orc_calc_mesh_shadows(float lx, float ly, float lz, float const *mh, unsigned char *smask, int xsize, int ysize, float const *sh_in_x, float const *sh_in_y, float *sh_out_x, float *sh_out_y);

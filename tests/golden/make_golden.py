@@ -92,6 +92,31 @@ def main():
     p, sc, tz = R.heightmap_proc_gen(64, 48, 200)
     out["proc_gen_pix"] = p
     out["proc_gen_scale_tz"] = np.array([sc, tz], np.float32)
+    # rest of row a12: the reference's own heightmap_t::to_floats / from_floats / postprocess_height on the 8-bit island image of
+    # scene_config/config_heightmap.txt:84 (decoded by the library's PNG reader, itself checked against libpng in tests/test_png_io.py) and a random 16-bit image
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    pkg_ = importlib.import_module("3dworld_amd")
+    emul_so = os.path.join(os.path.dirname(HERE), "emul", "libterra_emul.so")
+    island = pkg_.terra.read_png(os.path.join(HERE, "heightmap_island_128.png"), lib=pkg_.terra.load_library(emul_so))
+    assert island.shape == (128, 128)
+    rng = np.random.default_rng(12)
+    # smooth random 16-bit terrain (a sum of a few sines, kept inside (8, 248) pixel units so that erosion cannot leave [0, 256))
+    yy, xx = np.mgrid[0:80, 0:96]
+    hgt = 128 + 50 * np.sin(xx * 0.11 + 1.0) * np.cos(yy * 0.09) + 40 * np.sin((xx + yy) * 0.05 + 2.0) + rng.uniform(-4, 4, xx.shape)
+    rand16 = np.stack([((hgt % 1.0) * 256).astype(np.uint8), hgt.astype(np.uint8)], axis=-1)
+    for key, pix, scale_tz, iters in (("island128", island, pc_.ISLAND_SCALE_TZ, 6000), ("rand16", np.ascontiguousarray(rand16), (170.0, -17.0), 3000)):
+        pc_.island_setup(R, pc_.island_cfg(orclib.make_config), scale_tz=scale_tz)
+        v = R.heightmap_to_floats(pix)
+        pc_.island_setup(R, pc_.island_cfg(orclib.make_config), (v.min(), v.max()), scale_tz)
+        o, bad = R.heightmap_postprocess(pix, iters)
+        assert bad == 0
+        f, badf = R.heightmap_from_floats(v, 2 if pix.ndim == 3 else 1)
+        assert badf == 0
+        out[f"pp_{key}_in"] = pix; out[f"pp_{key}_vals"] = v; out[f"pp_{key}_out"] = o; out[f"pp_{key}_from"] = f; out[f"pp_{key}_iters"] = np.int32(iters)
+        print(key, "pixels changed by postprocess_height:", int((o != pix).sum()), "of", pix.size)
+    s = R.init(orclib.make_config(mesh_gen_mode=0))
+    R.set_mesh_file_scale(float(sc), float(tz))  # as heightmap_proc_gen above left them
     # row f3: landscape weights texture (create_texture driver over the reference's build_arrays / eval_index / eval_mesh_sin_terms / lttex tables)
     R.set_landscape(orclib.make_landscape(grass_density=100))
     zt, _ = R.tile_create_zvals(-3, 2, 0)

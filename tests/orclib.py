@@ -172,6 +172,10 @@ class Checker:
         f("hmap_read_mod", C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint), C.c_void_p, C.POINTER(C.c_uint)])
         f("hmap_read_and_apply_mod", C.c_int, [C.c_char_p])
         f("heightmap_proc_gen", None, [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p])
+        f("set_mesh_file_scale", None, [C.c_float, C.c_float])
+        f("heightmap_to_floats", None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        f("heightmap_from_floats", C.c_uint, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        f("heightmap_postprocess", C.c_uint, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint])
         f("export_heightmap", None, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
         f("set_landscape", None, [C.POINTER(Landscape)])
         f("tile_terrain_params", None, [C.c_int, C.c_int, C.c_void_p])
@@ -330,6 +334,29 @@ class Checker:
         pix = np.zeros((height, width, 2), np.uint8); st = np.zeros(2, np.float32)
         self._heightmap_proc_gen(width, height, iters, pix.ctypes.data, st.ctypes.data)
         return pix, st[0], st[1]
+
+    def set_mesh_file_scale(self, scale, tz): self._set_mesh_file_scale(scale, tz)
+
+    def heightmap_to_floats(self, pixels):
+        """heightmap_t::to_floats: (h, w) or (h, w, 2) uint8 -> (h, w) float32"""
+        assert pixels.dtype == np.uint8 and pixels.flags.c_contiguous
+        out = np.zeros(pixels.shape[:2], np.float32)
+        self._heightmap_to_floats(pixels.ctypes.data, pixels.shape[1], pixels.shape[0], 2 if pixels.ndim == 3 else 1, out.ctypes.data)
+        return out
+
+    def heightmap_from_floats(self, vals, ncolors):
+        """heightmap_t::from_floats with the scale in force -> (pixels, number of values outside [0, 256))"""
+        vals = np.ascontiguousarray(vals, np.float32)
+        h, w = vals.shape
+        pix = np.zeros((h, w, 2) if ncolors == 2 else (h, w), np.uint8)
+        bad = self._heightmap_from_floats(vals.ctypes.data, w, h, ncolors, pix.ctypes.data)
+        return pix, bad
+
+    def heightmap_postprocess(self, pixels, iters_tt):
+        """heightmap_t::postprocess_height on a copy -> (pixels, number of values outside [0, 256))"""
+        pix = np.ascontiguousarray(pixels, np.uint8).copy()
+        bad = self._heightmap_postprocess(pix.ctypes.data, pix.shape[1], pix.shape[0], 2 if pix.ndim == 3 else 1, iters_tt)
+        return pix, bad
 
     def export_heightmap(self, xstart, ystart, width, height):
         """-> (pixels u8 [h,w,2], min_z, dz)"""

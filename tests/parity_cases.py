@@ -651,6 +651,108 @@ def case_proc_gen(pkg, t, orc, N, iters):
     assert (np.float32(qmn).view(np.uint32), np.float32(qdz).view(np.uint32)) == (np.float32(mn).view(np.uint32), np.float32(dz).view(np.uint32))
 
 
+# ---- rest of row a12: the loaded-heightmap path (heightmap_t::to_floats / from_floats / postprocess_height, src/heightmap.cpp:117-128,191-215)
+ISLAND_SCALE_TZ = (180.3, -18.75)  # scene_config/config_heightmap.txt:84: mh_filename heightmaps/heightmap_island_128.png 180.3 -18.75 0
+
+
+def island_cfg(make_config):
+    """the heightmap_island_eroded preset (scene_config/config_heightmap.txt:80-84 over config.txt)"""
+    c = make_config(mesh_gen_mode=0)
+    c.water_h_off = 9.0
+    c.relh_adj_tex = -0.22
+    c.erode_amount = 1.0
+    return c
+
+
+def island_setup(ck, cfg, vals_minmax=None, scale_tz=ISLAND_SCALE_TZ):
+    """scene + mesh_file_scale / tz; with the height range of the loaded image: set_zmax_est(max(-zmin, zmax)) + set_zvals as read_mesh does (src/mesh_gen.cpp:928-930)"""
+    st = ck.init(cfg) if hasattr(ck, "init") else ck.init_scene(cfg)
+    ck.set_mesh_file_scale(*scale_tz)
+    if vals_minmax is not None:
+        ck.set_zmax_est(float(max(-np.float32(vals_minmax[0]), np.float32(vals_minmax[1]))))
+        st = ck.state()
+    return st
+
+
+def gpu_to_floats(t, pix):
+    h, w = pix.shape[:2]
+    nc = 2 if pix.ndim == 3 else 1
+    dp = t.alloc(pix.nbytes).upload(pix)
+    dv = t.alloc(w * h * 4)
+    t.heightmap_to_floats_dev(dp.ptr, w, h, nc, dv.ptr)
+    v = dv.download(np.float32, (h, w))
+    dp.free(); dv.free()
+    return v
+
+
+def gpu_postprocess(t, pix, iters, own_scratch=True):
+    h, w = pix.shape[:2]
+    nc = 2 if pix.ndim == 3 else 1
+    dp = t.alloc(pix.nbytes).upload(pix)
+    dv = t.alloc(w * h * 4) if own_scratch else None
+    bad = t.heightmap_postprocess_dev(dp.ptr, w, h, nc, iters, dv.ptr if dv else None)
+    out = dp.download(np.uint8, pix.shape)
+    vals = dv.download(np.float32, (h, w)) if dv else None
+    dp.free()
+    if dv:
+        dv.free()
+    return out, bad, vals
+
+
+def case_heightmap_postprocess_golden(pkg, t):
+    """to_floats / from_floats / postprocess_height against the reference's own members (golden): the 8-bit island image of config_heightmap.txt and a random 16-bit image"""
+    G = golden()
+    for key, scale_tz in (("island128", ISLAND_SCALE_TZ), ("rand16", (170.0, -17.0))):
+        pix = G[f"pp_{key}_in"]
+        island_setup(t, island_cfg(pkg.make_config), scale_tz=scale_tz)
+        assert t.get_mesh_file_scale() == tuple(np.float32(scale_tz))
+        v = gpu_to_floats(t, pix)
+        assert_bit_equal(v, G[f"pp_{key}_vals"], f"to_floats {key}")
+        island_setup(t, island_cfg(pkg.make_config), (v.min(), v.max()), scale_tz)
+        iters = int(G[f"pp_{key}_iters"])
+        out, bad, vals = gpu_postprocess(t, pix, iters)
+        assert bad == 0 and (out == G[f"pp_{key}_out"]).all(), (key, int((out != G[f"pp_{key}_out"]).sum()))
+        assert (out != pix).any()  # the erosion did change pixels
+        out2, bad2, _ = gpu_postprocess(t, pix, iters, own_scratch=False)  # internal scratch
+        assert bad2 == 0 and (out2 == out).all()
+        out0, bad0, _ = gpu_postprocess(t, pix, 0)  # erosion_iters_tt == 0: nothing happens
+        assert bad0 == 0 and (out0 == pix).all()
+        # from_floats of the un-eroded heights (the 8-bit truncation may land one below the source pixel: the reference's own round trip does)
+        h, w = pix.shape[:2]
+        nc = 2 if pix.ndim == 3 else 1
+        dv = t.alloc(w * h * 4).upload(G[f"pp_{key}_vals"]); dp = t.alloc(pix.nbytes)
+        assert t.heightmap_from_floats_dev(dv.ptr, w, h, nc, dp.ptr) == 0
+        assert (dp.download(np.uint8, pix.shape) == G[f"pp_{key}_from"]).all()
+        # values outside [0, 256) pixel units are counted (the reference asserts there): shift the heights up by 300 pixel units
+        dv.upload(G[f"pp_{key}_vals"] + np.float32(300.0 * 0.0008 * 0.7 * scale_tz[0]))
+        assert t.heightmap_from_floats_dev(dv.ptr, w, h, nc, dp.ptr) == w * h
+        rc = t.lib.terra_heightmap_from_floats_dev(t.ctx, dv.ptr, w, h, nc, dp.ptr, None)
+        assert rc == -3, rc  # TERRA_ERR_STATE without a counter to report to
+        dv.free(); dp.free()
+
+
+def case_heightmap_postprocess_vs_oracle(pkg, t, orc, pix, iters, scale_tz=ISLAND_SCALE_TZ):
+    """postprocess_height of `pix` with `iters` droplets: to_floats bit-equal, every pixel of the eroded image equal to the oracle's"""
+    island_setup(orc, island_cfg(orclib.make_config), scale_tz=scale_tz)
+    island_setup(t, island_cfg(pkg.make_config), scale_tz=scale_tz)
+    vo = orc.heightmap_to_floats(pix)
+    assert_bit_equal(gpu_to_floats(t, pix), vo, "to_floats")
+    mm = (vo.min(), vo.max())
+    island_setup(orc, island_cfg(orclib.make_config), mm, scale_tz)
+    st = island_setup(t, island_cfg(pkg.make_config), mm, scale_tz)
+    so = orc.state()
+    assert np.float32(st.water_plane_z) == np.float32(so.water_plane_z) and np.float32(st.zmin) == np.float32(so.zmin)
+    ref_pix, ref_bad = orc.heightmap_postprocess(pix, iters)
+    out, bad, vals = gpu_postprocess(t, pix, iters)
+    assert bad == ref_bad
+    assert (out == ref_pix).all(), int((out != ref_pix).sum())
+    # the float heights left in the scratch are the oracle's eroded heights too
+    vr = vo.copy()
+    orc.apply_erosion(vr, float(vo.min()), iters)
+    assert_bit_equal(vals, vr, "eroded heights")
+    return int((out != pix).sum()), t.erosion_report()
+
+
 def case_quantize_golden(pkg, t):
     G = golden()
     t.init_scene(pkg.make_config(mesh_gen_mode=0))

@@ -1,0 +1,182 @@
+"""GPU parity at the sizes and in the execution modes bench.py TIMES: every value of every timed configuration against the
+oracle, computed on the GPU box's host cores.
+
+  config 5   voxel fields 512 x 512 x 64 (the reference's own config_voxel_params.txt:1-3) and 512^3, whole field; the 8-slab split of 512^3
+  config 4   the 64 x 64 tile batch with erosion_iters_tt = 1000: zvals + stats + normals of ALL 4096 tiles, then AO, landscape weights and mesh
+             shadows of the same eroded batch
+  headline   4 contexts on 4 host threads sharing the GPU (bench.py's pipelines), each generating and eroding its own 16384^2 regions for 3 steps
+  config 3   heightmap_t::postprocess_height on heightmaps/heightmap_island_1k.png (the heightmap_island_eroded preset)
+"""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import orclib
+from orclib import assert_bit_equal
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+BENCH_VOX = dict(lo=(-1.0, -1.0, -0.25), off=(0.0, 0.0, 0.0), mag=1.0, freq=1.0, rs1=123, rs2=456, zscale=0.0, normalize=1)  # bench.py's voxel_steps
+
+
+def host_threads():
+    return max(1, min(len(os.sched_getaffinity(0)), 128))
+
+
+def oracle_pool_map(orc, fn, items):
+    """fn(item) on a pool of host threads; every worker thread pins its own OpenMP team to one thread (ctypes releases the GIL; the oracle's per-tile
+    functions only read globals)"""
+    def run(it):
+        orc.set_num_threads(1)  # omp_set_num_threads is per calling thread
+        return fn(it)
+    with ThreadPoolExecutor(host_threads()) as ex:
+        out = list(ex.map(run, items))
+    return out
+
+
+@pytest.mark.parametrize("nz", [64, 512])
+def test_voxel_field_at_bench_size_equals_oracle(pkg, gpu, orc, nz):
+    """BASELINE config 5 as bench.py fills it (k_voxel_sines: one lane per z, column pairs): every voxel of 512 x 512 x nz against orc.voxel_fill;
+    nz = 512 also as the 8 y slabs 8 ranks would fill (terra_voxel_fill_slab_dev)"""
+    VN = 512
+    gpu.init_scene(pkg.make_config(mesh_gen_mode=0)); orc.init(orclib.make_config(mesh_gen_mode=0))
+    vsz = (2.0 / VN, 2.0 / VN, 0.5 / VN)
+    B = BENCH_VOX
+    ref = orc.voxel_fill(VN, VN, nz, B["lo"], vsz, B["off"], B["mag"], B["freq"], B["rs1"], B["rs2"], 0, B["zscale"], B["normalize"])
+    a = gpu.alloc(VN * VN * nz * 4)
+    gpu.voxel_fill_dev(a.ptr, VN, VN, nz, B["lo"], vsz, B["off"], B["mag"], B["freq"], B["rs1"], B["rs2"], 0, B["zscale"], B["normalize"])
+    v = a.download(np.float32, (VN, VN, nz))
+    diff = v.view(np.uint32) != ref.view(np.uint32)
+    assert not diff.any(), f"{int(diff.sum())} voxels differ, first at {np.argwhere(diff)[:3].tolist()}"
+    assert np.abs(ref).max() <= 1.0 and len(np.unique(ref[::37, ::41, ::5])) > 1000
+    if nz == 512:
+        for r in range(8):
+            y0, y1 = r * VN // 8, (r + 1) * VN // 8
+            gpu.voxel_fill_slab_dev(a.ptr, VN, VN, nz, B["lo"], vsz, B["off"], B["mag"], B["freq"], B["rs1"], B["rs2"], 0, B["zscale"], B["normalize"], y0, y1 - y0)
+            s = a.download(np.float32, (y1 - y0, VN, nz))
+            assert (s.view(np.uint32) == ref[y0:y1].view(np.uint32)).all(), f"slab {r}"
+    a.free()
+
+
+def test_tile_batch_64x64_eroded_1000_every_tile_equals_oracle(pkg, gpu, orc):
+    """BASELINE config 4 exactly as bench.py times it (`detail.tiles.erosion_1000`): tile_t::create_zvals of the 64 x 64 tiles with 1000 droplets each --
+    zvals, stats bytes, normal texels and min_normal_z of ALL 4096 tiles -- then the AO lighting, the landscape weights texture (+ grass blocks) and the mesh
+    shadows of that same eroded batch, every byte against the oracle (per-tile oracle calls spread over the host's cores)."""
+    tiles = [(tx, ty) for ty in range(-32, 32) for tx in range(-32, 32)]
+    n, iters = len(tiles), 1000
+    gpu.init_scene(pkg.make_config(mesh_gen_mode=0)); orc.init(orclib.make_config(mesh_gen_mode=0))
+    lkw = dict(grass_density=100)
+    gpu.set_landscape(pkg.make_landscape(**lkw)); orc.set_landscape(orclib.make_landscape(**lkw))
+    try:
+        z, st, nm, mnz = gpu.tiles_create_zvals(tiles, iters)
+        ao = gpu.tiles_ao_lighting(tiles, z)
+        w, gb, hg = gpu.tiles_create_weights(tiles, z)
+        light = (0.6, 0.5, 0.4)
+        sm = gpu.tiles_mesh_shadows(tiles, z, light)
+
+        def check(i):
+            tx, ty = tiles[i]
+            zo, so = orc.tile_create_zvals(tx, ty, iters)
+            bad = []
+            if not (zo.view(np.uint32) == z[i].view(np.uint32)).all():
+                bad.append("zvals")
+            if bytes(so) != bytes(st[i]):
+                bad.append("stats")
+            no, mo = orc.tile_normals(zo)
+            if not ((no == nm[i]).all() and np.float32(mo) == mnz[i]):
+                bad.append("normals")
+            if not (orc.tile_ao_lighting(tx, ty, zo) == ao[i]).all():
+                bad.append("ao")
+            wo, gbo, hgo = orc.tile_create_weights(tx, ty, zo)
+            if not ((wo == w[i]).all() and gbo.tobytes() == gb[i].tobytes() and bool(hg[i]) == hgo):
+                bad.append("weights")
+            return bad
+
+        res = oracle_pool_map(orc, check, range(n))
+        failures = [(tiles[i], r) for i, r in enumerate(res) if r]
+        assert not failures, f"{len(failures)} of {n} tiles differ: {failures[:5]}"
+        orc.set_num_threads(host_threads())
+        # the erosion did run: land tiles changed against the un-eroded batch
+        z0, _, _, _ = gpu.tiles_create_zvals(tiles, 0, stats=False, normals=False)
+        changed = (z0.view(np.uint32) != z.view(np.uint32)).reshape(n, -1).any(1)
+        assert 500 < changed.sum() < n, int(changed.sum())
+        # mesh shadows chain across the whole 64 x 64 batch (127 dependency levels): the oracle walks the tiles in the reference's order
+        smo = orc.tiles_mesh_shadows(tiles, z, light)
+        assert (smo == sm).all(), f"{int((smo != sm).any(axis=(1, 2)).sum())} tiles' shadow masks differ"
+        assert 0 < int((sm != 0).sum()) < sm.size
+    finally:
+        gpu.set_landscape(pkg.make_landscape()); orc.set_landscape(orclib.make_landscape())
+        orc.set_num_threads(host_threads())
+
+
+def test_headline_mode_four_contexts_in_flight_equal_oracle(pkg, orc):
+    """How the headline `value` is produced: bench.py keeps 4 heightmaps in flight per GPU -- 4 terra contexts on 4 host threads sharing the device (own
+    stream, scratch, hipGraph cache and speculation ring each).  Here every context runs 3 bench steps (terra_gen_grid_minmax_dev with the fused min +
+    terra_apply_erosion_dev with the sparse clamp) on regions of its own, concurrently, and ALL 12 grids are compared with the oracle bit for bit."""
+    N, droplets, P, steps = 16384, 1000, 4, 3
+    ctxs = [pkg.Terra(0) for _ in range(P)]
+    try:
+        cfg = pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1)
+        sts = [c.init_scene(cfg) for c in ctxs]
+        st = sts[0]
+        bufs = [[c.alloc(N * N * 4) for _ in range(steps)] for c in ctxs]
+        mins = [[None] * steps for _ in range(P)]
+        errs = []
+        start = threading.Barrier(P)
+
+        def region(p, s):
+            return (-N / 2 + (p + P * s) * N, -N / 2 - s * 4096.0)
+
+        def worker(p):
+            try:
+                start.wait()
+                for s in range(steps):
+                    x0, y0 = region(p, s)
+                    mn, mx = ctxs[p].gen_grid_minmax_dev(bufs[p][s].ptr, x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+                    ctxs[p].apply_erosion_dev(bufs[p][s].ptr, N, N, mn, droplets, pkg.ERODE_MINZ_IS_MIN)
+                    mins[p][s] = (mn, mx)
+                ctxs[p].synchronize()
+            except Exception as e:  # noqa: BLE001
+                errs.append((p, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+        for p in range(P):
+            for s in range(steps):
+                x0, y0 = region(p, s)
+                z = bufs[p][s].download(np.float32, (N, N))
+                bufs[p][s].free()
+                ref = orc.gen_grid(x0, y0, st.DX_VAL, st.DY_VAL, N, N, 1)
+                rmn, rmx = ref.min(), ref.max()
+                assert (np.float32(mins[p][s][0]), np.float32(mins[p][s][1])) == (rmn, rmx), (p, s)
+                orc.apply_erosion(ref, float(rmn), droplets)
+                diff = z.view(np.uint32) != ref.view(np.uint32)
+                assert not diff.any(), f"context {p} step {s}: {int(diff.sum())} cells differ, first at {np.argwhere(diff)[:3].tolist()}"
+                del z, ref
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("iters", [100000])
+def test_island_1k_postprocess_height_equals_oracle(pkg, gpu, orc, iters):
+    """BASELINE config 3's literal preset: the loaded island heightmap (heightmaps/heightmap_island_1k.png, `mh_filename ... 180.3 -18.75`) through
+    heightmap_t::postprocess_height -- pixels -> floats -> whole-image erosion -> pixels -- every pixel and every eroded height against the oracle"""
+    pix = pkg.terra.read_png(os.path.join(HERE, "golden", "heightmap_island_1k.png"), lib=gpu.lib)
+    assert pix.shape == (1024, 1024) and pix.dtype == np.uint8
+    changed, rep = pc.case_heightmap_postprocess_vs_oracle(pkg, gpu, orc, pix, iters)
+    assert changed > 100000 and rep.droplets == iters, (changed, rep.as_dict())
+
+
+def test_heightmap_postprocess_golden(pkg, gpu):
+    pc.case_heightmap_postprocess_golden(pkg, gpu)

@@ -208,3 +208,20 @@ def test_random_configs(pkg, emul, orc):
 
 def test_random_heightmap_textures(pkg, emul, orc):
     pc.case_random_heightmap_textures(pkg, emul, orc)
+
+
+def test_heightmap_postprocess_golden(pkg, emul):
+    """rest of row a12: to_floats / from_floats / postprocess_height through the host logic, against the reference's own members (golden)"""
+    pc.case_heightmap_postprocess_golden(pkg, emul)
+
+
+def test_heightmap_postprocess_vs_oracle(pkg, emul, orc):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:70, 0:53]  # odd sizes: the 4-pixel fast path ends in a scalar tail
+    hgt = 120 + 60 * np.sin(xx * 0.13) * np.cos(yy * 0.1 + 0.5) + rng.uniform(-3, 3, xx.shape)
+    pix8 = np.ascontiguousarray(hgt.astype(np.uint8))
+    pix16 = np.ascontiguousarray(np.stack([((hgt % 1.0) * 256).astype(np.uint8), hgt.astype(np.uint8)], axis=-1))
+    for pix in (pix8, pix16):
+        changed, rep = pc.case_heightmap_postprocess_vs_oracle(pkg, emul, orc, pix, 700)
+        assert changed > 0 and rep.droplets == 700

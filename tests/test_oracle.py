@@ -215,6 +215,54 @@ def test_oracle_matches_golden_hmap_edits(orc):
     assert (p == G["proc_gen_pix"]).all() and (np.array([sc, tz], np.float32).view(np.uint32) == G["proc_gen_scale_tz"].view(np.uint32)).all()
 
 
+def test_oracle_matches_golden_heightmap_postprocess(orc):
+    """rest of row a12 (heightmap_t::to_floats / from_floats / postprocess_height): the restatement against the reference's own members (golden)"""
+    G = golden()
+    for key, scale_tz in (("island128", pc.ISLAND_SCALE_TZ), ("rand16", (170.0, -17.0))):
+        pix = G[f"pp_{key}_in"]
+        pc.island_setup(orc, pc.island_cfg(orclib.make_config), scale_tz=scale_tz)
+        v = orc.heightmap_to_floats(pix)
+        assert_bit_equal(v, G[f"pp_{key}_vals"], key)
+        pc.island_setup(orc, pc.island_cfg(orclib.make_config), (v.min(), v.max()), scale_tz)
+        o, bad = orc.heightmap_postprocess(pix, int(G[f"pp_{key}_iters"]))
+        assert bad == 0 and (o == G[f"pp_{key}_out"]).all()
+        f, badf = orc.heightmap_from_floats(v, 2 if pix.ndim == 3 else 1)
+        assert badf == 0 and (f == G[f"pp_{key}_from"]).all()
+    orc.set_mesh_file_scale(1.0, 0.0)
+
+
+def test_oracle_vs_reference_heightmap_postprocess(orc, ref, pkg, emul_lib):
+    """the same against the reference's heightmap.cpp compiled in place, on the island image (8 bit) and random 8- / 16-bit images, incl. the out-of-range count"""
+    import os
+    island = pkg.terra.read_png(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "heightmap_island_128.png"), lib=pkg.terra.load_library(emul_lib))
+    assert (island == golden()["pp_island128_in"]).all()
+    rng = np.random.default_rng(21)
+    imgs = [(island, pc.ISLAND_SCALE_TZ, 2500)]
+    for k in range(3):
+        h, w = int(rng.integers(30, 90)), int(rng.integers(30, 90))
+        yy, xx = np.mgrid[0:h, 0:w]
+        hgt = 128 + rng.uniform(20, 70) * np.sin(xx * rng.uniform(0.05, 0.2)) * np.cos(yy * rng.uniform(0.05, 0.2)) + rng.uniform(-5, 5, xx.shape)
+        pix = hgt.astype(np.uint8) if k == 0 else np.stack([((hgt % 1.0) * 256).astype(np.uint8), hgt.astype(np.uint8)], axis=-1)
+        imgs.append((np.ascontiguousarray(pix), (float(rng.uniform(100, 250)), float(rng.uniform(-25, -10))), 900))
+    try:
+        for pix, scale_tz, iters in imgs:
+            for ck in (orc, ref):
+                pc.island_setup(ck, pc.island_cfg(orclib.make_config), scale_tz=scale_tz)
+            vo, vr = orc.heightmap_to_floats(pix), ref.heightmap_to_floats(pix)
+            assert_bit_equal(vo, vr, "to_floats")
+            for ck in (orc, ref):
+                pc.island_setup(ck, pc.island_cfg(orclib.make_config), (vo.min(), vo.max()), scale_tz)
+            oo, ob = orc.heightmap_postprocess(pix, iters); ro, rb = ref.heightmap_postprocess(pix, iters)
+            assert ob == rb == 0 and (oo == ro).all() and (oo != pix).any()
+            nc = 2 if pix.ndim == 3 else 1
+            fo, fb = orc.heightmap_from_floats(vo, nc); fr, fbr = ref.heightmap_from_floats(vo, nc)
+            assert fb == fbr == 0 and (fo == fr).all()
+            shifted = vo + np.float32(200.0 * 0.0008 * 0.7 * scale_tz[0])  # + 200 pixel units: many values above 256: both count them (the member itself would assert)
+            assert orc.heightmap_from_floats(shifted, nc)[1] == ref.heightmap_from_floats(shifted, nc)[1] > 0
+    finally:
+        orc.set_mesh_file_scale(1.0, 0.0); ref.set_mesh_file_scale(1.0, 0.0)
+
+
 def test_oracle_matches_golden_tile_weights(orc):
     G = pc.golden()
     orc.init(orclib.make_config(mesh_gen_mode=0))
