@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libterra_hip.so")
 SOURCES = ["terra_hip.hip"]
-HEADERS = ["terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_png.hpp", "terra_landscape.hpp", "terra_modmap.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
+HEADERS = ["terra_multi.hpp", "terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_png.hpp", "terra_landscape.hpp", "terra_modmap.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
 # -ffp-contract=off: the reference CPU path has no FMA; parity is bit-exact only without contraction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-result"]
@@ -20,12 +20,26 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
+HASH_FILE = LIB + ".srchash"
+
+
+def source_hash():
+    """sha256 over every source the library is made of (all of csrc/, include/terra.h) and the compiler flags: what the shipped .so must have been built from"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [os.path.join(os.path.dirname(HERE), "include", "terra.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """the library is missing, or was built from other sources than the tree holds now (keyed on content, not on mtimes: a checkout or a copy resets those)"""
+    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "terra.h")]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return open(HASH_FILE).read().strip() != source_hash()
 
 
 def build_library(force=False, verbose=False):
@@ -40,4 +54,6 @@ def build_library(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     if verbose and r.stderr:
         print(r.stderr)
+    with open(HASH_FILE, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB

@@ -15,6 +15,10 @@ inline int fail(int code, char const *what) {g_last_error = what ? what : "unkno
 
 struct terra_ctx {
 	terra::terra_engine<terra_backend_t> eng;
+	// A context is driven by one host thread at a time (include/terra.h).  The exception is the generator handle: eval_index is const in the reference and is called
+	// from its OpenMP workers (src/tiled_mesh.cpp:495, src/heightmap.cpp:139), and several handles share the context's engine (grow-only scratch, stream, the sine-table
+	// upload): every terra_gen_* call that touches the engine takes this lock, so handles of one context may be used from several threads
+	std::recursive_mutex eng_mtx;
 };
 
 struct terra_gen { // mesh_xy_grid_cache_t (src/mesh.h:22-45)
@@ -28,7 +32,8 @@ struct terra_gen { // mesh_xy_grid_cache_t (src/mesh.h:22-45)
 	// kstart; a caller that asks for another first term gets a grid evaluated with that one (one more launch, kept per first term)
 	int kstart = 0, sev = 0, gen_mode = 0;
 	std::map<int, std::vector<float>> alt_vals;
-	std::mutex mtx; // eval_index is const in the reference and called from its OpenMP workers (src/tiled_mesh.cpp:495, src/heightmap.cpp:139): the lazy read-back / re-evaluation here is serialised
+	std::mutex mtx; // eval_index is const in the reference and called from its OpenMP workers (src/tiled_mesh.cpp:495, src/heightmap.cpp:139): the handle's own state (lazy read-back, alternative
+	                // first terms) is serialised by this lock, the shared engine of the context by terra_ctx::eng_mtx
 };
 
 #define TERRA_TRY   try {
@@ -95,10 +100,12 @@ int terra_gen_create(terra_ctx *ctx, terra_gen **out) {
 }
 void terra_gen_destroy(terra_gen *g) {
 	if (!g) return;
-	try {if (g->d_vals) {g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);}} catch (...) {}
+	try {if (g->d_vals) {std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx); g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);}} catch (...) {}
 	delete g;
 }
 static void terra_gen_do_collect(terra_gen *g) {
+	if (g->collected) return;
+	std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
 	if (g->collected) return;
 	g->cached_vals.resize((size_t)g->nx*g->ny);
 	g->ctx->eng.be.d2h(g->cached_vals.data(), g->d_vals, g->cached_vals.size()*sizeof(float)); // blocks on the stream, like read_float_vals (src/shaders.cpp:1196-1235)
@@ -107,6 +114,8 @@ static void terra_gen_do_collect(terra_gen *g) {
 int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin) {
 	if (!g) return terra::fail(TERRA_ERR_ARG, "null terra_gen");
 	try {
+		std::lock_guard<std::mutex> lock(g->mtx);
+		std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
 		bool const no_wait = (flags & TERRA_GEN_NO_WAIT) != 0;
 		uint32_t const key = flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE);
 		int const sev = g->ctx->eng.start_eval_sin, kstart = terra::imax(sev, min_start_sin);
@@ -135,6 +144,8 @@ int terra_gen_enable_glaciate(terra_gen *g) {
 	if (!g->built) return terra::fail(TERRA_ERR_STATE, "enable_glaciate: build_arrays() must have been called first"); // assert(cur_nx > 0 && cur_ny > 0), src/mesh_gen.cpp:644
 	if (g->glaciated) return TERRA_OK;
 	TERRA_TRY
+		std::lock_guard<std::mutex> lock(g->mtx);
+		std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
 		// not fused at build time: re-evaluate with the glaciate epilogue (pure per-cell function, identical values)
 		g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags | TERRA_GEN_GLACIATE, g->kstart, g->d_vals);
 		g->flags |= TERRA_GEN_GLACIATE; g->glaciated = true; g->running = true; g->collected = false; g->alt_vals.clear();
@@ -144,7 +155,7 @@ int terra_gen_is_running(terra_gen *g) {return (g && g->running) ? 1 : 0;}
 int terra_gen_collect(terra_gen *g, float *host_out) {
 	if (!g || !host_out) return terra::fail(TERRA_ERR_ARG, "null argument");
 	if (!g->built) return terra::fail(TERRA_ERR_STATE, "collect: nothing was built");
-	TERRA_TRY terra_gen_do_collect(g); memcpy(host_out, g->cached_vals.data(), g->cached_vals.size()*sizeof(float)); TERRA_CATCH
+	TERRA_TRY std::lock_guard<std::mutex> lock(g->mtx); terra_gen_do_collect(g); memcpy(host_out, g->cached_vals.data(), g->cached_vals.size()*sizeof(float)); TERRA_CATCH
 }
 float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_sin, int use_cache) {
 	if (!g || !g->built || x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;} // assert(x < cur_nx && y < cur_ny), src/mesh_gen.cpp:756
@@ -157,6 +168,7 @@ float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_s
 		if (want == g->kstart) {terra_gen_do_collect(g); return g->cached_vals[(size_t)y*g->nx + x];}
 		std::vector<float> &alt = g->alt_vals[want];
 		if (alt.empty()) { // same grid from another first term: one more launch, kept for the following calls
+			std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
 			terra_backend_t &be = g->ctx->eng.be;
 			size_t const count = (size_t)g->nx*g->ny;
 			float *d = (float *)be.alloc(count*sizeof(float));
@@ -459,6 +471,13 @@ int terra_tiles_mesh_shadows_halo_dev(terra_ctx *ctx, const int32_t *tile_xy, ui
 	if ((h_edge_in == nullptr) != (h_edge_in_present == nullptr)) return terra::fail(TERRA_ERR_ARG, "edge_in and edge_in_present go together");
 	TERRA_TRY ctx->eng.tiles_mesh_shadows_dev(tile_xy, n, d_zvals, light_pos, d_smask, h_edge_in, h_edge_in_present, h_edge_out); TERRA_CATCH
 }
+int terra_tiles_mesh_shadows_edges_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask,
+	const float *d_edge_in, const uint8_t *h_edge_in_present, float *d_edge_out)
+{
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals || !d_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if ((d_edge_in == nullptr) != (h_edge_in_present == nullptr)) return terra::fail(TERRA_ERR_ARG, "edge_in and edge_in_present go together");
+	TERRA_TRY ctx->eng.tiles_mesh_shadows_dev(tile_xy, n, d_zvals, light_pos, d_smask, nullptr, h_edge_in_present, nullptr, d_edge_in, d_edge_out); TERRA_CATCH
+}
 int terra_tiles_mesh_shadows(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals || !h_smask || !light_pos)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	if (n == 0) return TERRA_OK;
@@ -537,3 +556,4 @@ int terra_timer_start(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.tim
 int terra_timer_stop(terra_ctx *ctx, float *ms) {TERRA_CHECK_CTX TERRA_TRY float const t = ctx->eng.be.timer_stop(); if (ms) *ms = t; TERRA_CATCH}
 
 } // extern "C"
+#include "terra_multi.hpp"

@@ -685,10 +685,12 @@ template<class BE> struct terra_engine {
 		return ec;
 	}
 
-	// the reference seeds droplet `iter` with (iter + 11, 79*iter + 121) in `int` (src/erosion.cpp:67-69): from iter = 27 182 813 on that is signed overflow
-	// (undefined behaviour in the reference binary), so there is nothing to be identical to -- refused instead of silently diverging
-	static constexpr uint32_t MAX_EROSION_ITERS = 27182812u;
-	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27182812 droplets (the reference's int seed 79*iter+121 overflows)");}
+	// the reference seeds droplet `iter` with (iter + 11, 79*iter + 121) in `int` (src/erosion.cpp:67-69): 79*iter + 121 first exceeds INT_MAX at iter = 27 183 336
+	// ((2^31 - 1 - 121)/79 = 27 183 335.8), from there on it is signed overflow (undefined behaviour in the reference binary), so there is nothing to be identical
+	// to -- refused instead of silently diverging.  Droplets 0 .. 27 183 335 are well defined: at most 27 183 336 droplets.
+	static constexpr uint32_t MAX_EROSION_ITERS = 27183336u;
+	static_assert(79ll*(MAX_EROSION_ITERS - 1) + 121 <= 2147483647ll && 79ll*MAX_EROSION_ITERS + 121 > 2147483647ll, "last droplet whose seed fits an int");
+	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27183336 droplets (the reference's int seed 79*iter+121 overflows)");}
 
 	uint32_t spec_batch_override = getenv("TERRA_ERO_BATCH") ? (uint32_t)std::max(1, atoi(getenv("TERRA_ERO_BATCH"))) : 0u; // experiment knob: rounds per host read-back
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 128, max_rounds = 4000000, near_count = 512;} spec_cfg;
@@ -744,17 +746,22 @@ template<class BE> struct terra_engine {
 		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
 		// ring slots: more droplets in flight = more parallel work and fewer rounds, but also more speculation on stale cells and longer writer lists.  Measured
 		// (MI355X, 10^5..10^6 droplets, profiles/r02_erosion_ring_size_sweep.txt): best near one slot per 8K cells on sparse maps (8192^2: 8192 slots, 16384^2: 32768),
-		// 3072-4096 slots on a dense 4096^2, 2048 on 1024^2 (4096 slots there double the re-traces).  256 pages of 64 floats per slot and buffer: 32768 slots = 4.4 GiB of the 288.
+		// 3072-4096 slots on a dense 4096^2, 2048 on 1024^2 (4096 slots there double the re-traces).  Per slot and buffer: 256 pages of 64 floats (64 KiB) + 256 masks and block ids
+		// (3 KiB) + up to 16 checkpoints (their masks: 32 KiB) + the undo log (32 KiB): ~133 KiB, twice = ~266 KiB per slot -- a 32768-slot ring (16384^2 map) is ~8.5 GiB of the 288
+		// (bench.py keeps 4 contexts in flight: ~34 GiB).  The checkpoint and undo arrays are sized by the checkpoint count in force (none with TERRA_ERO_CK=n:0).
 		uint64_t const ncells = (uint64_t)ec.NX*ec.NY;
 		uint32_t auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ncells >> 13, 2048), 32768);
 		if (ncells >= (1ull << 24)) {auto_w = std::max<uint32_t>(auto_w, 4096);}
-		uint32_t const W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
+		uint32_t W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
 		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = SPEC_CK_MAX;
 		{char const *dg = getenv("TERRA_ERO_DIAG"); sb.diag = (dg && dg[0] == '1') ? 1u : 0u;}
 		if (char const *ck = getenv("TERRA_ERO_CK")) {int a = 0, b = 0; if (sscanf(ck, "%d:%d", &a, &b) == 2 && a >= 1 && b >= 0 && b <= (int)SPEC_CK_MAX) {sb.ck_steps = (uint32_t)a; sb.ck_max = (uint32_t)b;}} // experiment knob "steps:max"; results never depend on it
-		sb.W = W;
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block
+		// where a cell is read from is a 31-bit float index into a version buffer, (slot*maxb + entry)*64 + cell, with bit 31 naming the buffer (spec_back_t::source,
+		// spec_cand_t::page): the ring must keep W*maxb*64 below 2^31 -- a larger request is served with the largest ring that does (results never depend on W)
+		{uint64_t const most = (((1ull << 31) - 1)/SPEC_PAGE)/sb.maxb; if (W > most) {W = (uint32_t)most;}}
+		sb.W = W;
 		if (char const *nc = getenv("TERRA_ERO_NEAR")) {int const v = atoi(nc); sb.near_count = (v >= 0) ? (uint32_t)v : W/(uint32_t)(-v);} // experiment knob (negative: a fraction of the ring); results never depend on it
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
 		size_t const nblocks = (size_t)sb.nbx*sb.nby;
@@ -764,8 +771,10 @@ template<class BE> struct terra_engine {
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_cks[2], o_ckn[2], o_cku[2], o_ckm[2], o_ckc[2], o_ui[2], o_uv[2], o_un[2];
 		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4);}
 		for (int b = 0; b < 2; ++b) {
-			o_cks[b] = carve((size_t)W*SPEC_CK_MAX*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*SPEC_CK_MAX*4); o_cku[b] = carve((size_t)W*SPEC_CK_MAX*4);
-			o_ckm[b] = carve((size_t)W*SPEC_CK_MAX*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_uv[b] = carve((size_t)W*SPEC_UNDO_MAX*4); o_un[b] = carve(W*4);
+			// (indexed with the stride SPEC_CK_MAX / SPEC_UNDO_MAX per slot; without checkpoints nothing is ever read or written there, so nothing is allocated)
+			size_t const ckn = sb.ck_max ? SPEC_CK_MAX : 0, unn = sb.ck_max ? SPEC_UNDO_MAX : 0;
+			o_cks[b] = carve((size_t)W*ckn*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*ckn*4); o_cku[b] = carve((size_t)W*ckn*4);
+			o_ckm[b] = carve((size_t)W*ckn*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*unn*4); o_uv[b] = carve((size_t)W*unn*4); o_un[b] = carve(W*4);
 		}
 		size_t const o_slot = carve((size_t)W*4*13); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry
 		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
@@ -1028,13 +1037,17 @@ template<class BE> struct terra_engine {
 	// edge_in / edge_in_present / edge_out (host, optional): the halo of a batch that is only part of the terrain (another GPU owns the rest).
 	// edge_in[i][0] = sh_in_x, edge_in[i][1] = sh_in_y of tile i, used where present[i][d] != 0 and the neighbour toward the light is not in the batch;
 	// edge_out[i][0..1] = the tile's sh_out_x / sh_out_y (MESH_MIN_Z where nothing was written), for the owner of the next tile away from the light.
+	// d_edge_in / d_edge_out (optional): the same halo arrays in DEVICE memory ([n][2][130] floats; d_edge_in is used with the host flags edge_in_present): a
+	// terrain spread over several GPUs of one process hands the border edges from device to device (hipMemcpyPeerAsync, terra_multi.hpp) without a host copy
 	void tiles_mesh_shadows_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, float const lpos[3], uint8_t *d_smask,
-		float const *edge_in = nullptr, uint8_t const *edge_in_present = nullptr, float *edge_out = nullptr)
+		float const *edge_in = nullptr, uint8_t const *edge_in_present = nullptr, float *edge_out = nullptr, float const *d_edge_in = nullptr, float *d_edge_out = nullptr)
 	{
 		require_scene();
 		if (n == 0) return;
 		uint32_t const zv = 130;
+		if (edge_in && d_edge_in) throw std::invalid_argument("tiles_mesh_shadows: incoming edges either on the host or on the device");
 		if (edge_out) {for (size_t i = 0; i < (size_t)n*2*zv; ++i) edge_out[i] = -1.0E6f;} // sh_out[l][d].resize(zvsize, MESH_MIN_Z)
+		if (d_edge_out) {float *eo = d_edge_out; be.launch((size_t)n*2*zv, [=] TERRA_LAMBDA (size_t i) {eo[i] = -1.0E6f;});}
 		float const lx = lpos[0], ly = lpos[1], lz = lpos[2];
 		bool const all_shadowed = (lz < zmin);
 		be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); // MESH_SHADOW (src/3DWorld.h:1403)
@@ -1059,13 +1072,15 @@ template<class BE> struct terra_engine {
 		// halo: a present incoming edge becomes a virtual neighbour slot n + k whose out-array holds the received heights
 		std::vector<unsigned long long> virt; // [nvirt][zv]
 		std::vector<std::pair<uint32_t, uint32_t>> virt_slot; // (which array: 0 = out_x, 1 = out_y ; slot)
-		if (edge_in && edge_in_present) {
+		std::vector<uint32_t> virt_src;                        // device edges: index (tile*2 + d) of the incoming array a virtual slot is filled from
+		if ((edge_in || d_edge_in) && edge_in_present) {
 			for (uint32_t i = 0; i < n; ++i) {
 				for (uint32_t d = 0; d < 2; ++d) { // d = 0: sh_in_x (from the y-neighbour, adj[2i+1]); d = 1: sh_in_y (from the x-neighbour, adj[2i])
 					int32_t &a = adj[2*i + (1 - d)];
 					if (a >= 0 || !edge_in_present[2*i + d]) continue;
 					a = (int32_t)(n + (uint32_t)virt_slot.size());
 					virt_slot.push_back(std::make_pair(d, (uint32_t)a));
+					if (d_edge_in) {virt_src.push_back(2*i + d); continue;}
 					float const *src = edge_in + ((size_t)i*2 + d)*zv;
 					for (uint32_t e = 0; e < zv; ++e) {uint32_t b; memcpy(&b, &src[e], 4); virt.push_back((src[e] > -1.0E6f) ? ((1ull << 32) | b) : 0ull);}
 				}
@@ -1094,7 +1109,14 @@ template<class BE> struct terra_engine {
 		be.h2d(d_order, order.data(), (size_t)n*4);
 		be.h2d(d_adj, adj.data(), adj.size()*4);
 		be.fill32(d_out, 0, (size_t)2*nslots*zv*2);
-		for (size_t k = 0; k < virt_slot.size(); ++k) {be.h2d(d_out + ((size_t)virt_slot[k].first*nslots + virt_slot[k].second)*zv, virt.data() + k*zv, (size_t)zv*8);}
+		for (size_t k = 0; k < virt_slot.size(); ++k) {
+			unsigned long long *dst = d_out + ((size_t)virt_slot[k].first*nslots + virt_slot[k].second)*zv;
+			if (d_edge_in) { // encode on the device: (1 << 32 | float bits) where a height was handed over, 0 = nothing
+				float const *src = d_edge_in + (size_t)virt_src[k]*zv;
+				be.launch(zv, [=] TERRA_LAMBDA (size_t e) {float const v = src[e]; uint32_t b; memcpy(&b, &v, 4); dst[e] = (v > -1.0E6f) ? ((1ull << 32) | b) : 0ull;}, 64);
+			}
+			else {be.h2d(dst, virt.data() + k*zv, (size_t)zv*8);}
+		}
 		uint32_t const npaths = 4*zv;
 		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*nslots*zv);
 		bool chained = false;
@@ -1107,6 +1129,14 @@ template<class BE> struct terra_engine {
 			while (last < n && level[order[last]] == level[order[first]]) ++last;
 			be.tile_shadows(c, last - first, d_order + first, d_adj, nslots, d_zvals, d_out, d_smask, npaths);
 			first = last;
+		}
+		if (d_edge_out) { // the tiles' own outgoing edges, decoded on the device
+			float *eo = d_edge_out; uint32_t const ns = nslots;
+			be.launch((size_t)n*2*zv, [=] TERRA_LAMBDA (size_t j) {
+				uint32_t const e = (uint32_t)(j % zv), d = (uint32_t)((j / zv) % 2), i = (uint32_t)(j / (2*zv));
+				unsigned long long const v = d_out[((size_t)d*ns + i)*zv + e];
+				if (v != 0) {uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); float f; memcpy(&f, &b, 4); eo[j] = f;}
+			});
 		}
 		if (edge_out) { // the tiles' own outgoing edges, decoded
 			std::vector<unsigned long long> h((size_t)2*nslots*zv);

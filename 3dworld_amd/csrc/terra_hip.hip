@@ -58,6 +58,21 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	// host buffers are ordinary pageable memory (often stack variables): copies are stream-ordered and then waited for
 	void h2d(void *d, void const *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	void d2h(void *h, void const *d, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
+	// device-to-device copies on this context's stream: inside the device, and from another context's device (several GPUs in one process, terra_multi.hpp)
+	void d2d(void *dst, void const *src, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));}
+	void copy_from_peer(void *dst, hip_backend_t &src_be, void const *src, size_t bytes) {
+		use();
+		if (src_be.device == device) {TERRA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));}
+		else {TERRA_HIP_CHECK(hipMemcpyPeerAsync(dst, device, src, src_be.device, bytes, stream));} // xGMI when peer access is on, staged through the host otherwise
+	}
+	void enable_peer(hip_backend_t &other) { // best effort
+		if (other.device == device) return;
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, device, other.device) != hipSuccess || !can) return;
+		if (hipSetDevice(device) != hipSuccess) return;
+		hipError_t const e = hipDeviceEnablePeerAccess(other.device, 0);
+		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {(void)hipGetLastError();}
+	}
 	void timer_start() {use(); TERRA_HIP_CHECK(hipEventRecord(ev0, stream));}
 	float timer_stop() {use(); TERRA_HIP_CHECK(hipEventRecord(ev1, stream)); TERRA_HIP_CHECK(hipEventSynchronize(ev1)); float ms = 0; TERRA_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); return ms;}
 

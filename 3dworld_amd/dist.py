@@ -36,7 +36,7 @@ def sharded_heightmap_strips(terra, dist, d_out_ptr, x0, y0, dx, dy, nx, ny, fla
     mn, mx = float("inf"), float("-inf")
     if r1 > r0:
         mn, mx = terra.gen_grid_rows_minmax_dev(d_out_ptr, x0, y0, dx, dy, nx, ny, r0, r1 - r0, flags, min_start_sin)
-    if world > 1:
+    if dist is not None and dist.is_initialized():  # also in a one-rank group: the collective then runs through the backend (RCCL on a 1-GPU box) instead of being skipped
         on_gpu = str(dist.get_backend()).lower() == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         a = torch.tensor([mn], dtype=torch.float32, device=dev); b = torch.tensor([mx], dtype=torch.float32, device=dev)

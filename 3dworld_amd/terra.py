@@ -167,6 +167,20 @@ _PROTOS = {
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_voxel_fill_slab_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32, _u32, _u32]),
     "terra_voxel_fill": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
+    "terra_multi_create": (_i32, [C.POINTER(_vp), C.POINTER(_i32), _u32]),
+    "terra_multi_destroy": (None, [_vp]),
+    "terra_multi_size": (_u32, [_vp]),
+    "terra_multi_ctx": (_vp, [_vp, _u32]),
+    "terra_multi_partition": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "terra_multi_foreach": (_i32, [_vp, _vp, _vp]),
+    "terra_multi_synchronize": (_i32, [_vp]),
+    "terra_multi_init_scene": (_i32, [_vp, C.POINTER(Config)]),
+    "terra_multi_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "terra_multi_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "terra_multi_gen_grid_rows_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _f3, _f3]),
+    "terra_multi_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
+    "terra_multi_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
+    "terra_tiles_mesh_shadows_edges_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
     "terra_malloc": (_i32, [_vp, C.POINTER(_vp), _sz]),
     "terra_free": (_i32, [_vp, _vp]),
     "terra_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
@@ -521,6 +535,96 @@ class Terra:
     # ---- async generator handle (mesh_xy_grid_cache_t protocol)
     def generator(self):
         return Generator(self)
+
+
+class TerraMulti:
+    """terra_multi: several contexts (one per entry of `devices`, indices may repeat) driven from this process, each by its own host thread inside a call."""
+
+    def __init__(self, devices, lib_path=None):
+        self.lib = load_library(lib_path)
+        m = _vp()
+        arr = (_i32 * len(devices))(*devices)
+        rc = self.lib.terra_multi_create(C.byref(m), arr, len(devices))
+        if rc != 0:
+            raise TerraError(rc, self.lib.terra_last_error().decode())
+        self.m = m
+        self.n = len(devices)
+        self.ctxs = []
+        for i in range(self.n):  # borrowed contexts: the plumbing (alloc / upload / download) of Terra works on them, close() is the multi handle's
+            t = Terra.__new__(Terra)
+            t.lib, t.ctx = self.lib, _vp(self.lib.terra_multi_ctx(self.m, i))
+            t.close = lambda: None
+            self.ctxs.append(t)
+
+    def close(self):
+        if getattr(self, "m", None):
+            for t in self.ctxs:
+                t.ctx = None
+            self.lib.terra_multi_destroy(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise TerraError(rc, self.lib.terra_last_error().decode())
+        return rc
+
+    def partition(self, n_units, part):
+        a, b = _u32(), _u32()
+        self.lib.terra_multi_partition(n_units, self.n, part, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def init_scene(self, cfg):
+        self._ck(self.lib.terra_multi_init_scene(self.m, C.byref(cfg)))
+        return self.ctxs[0].state()
+
+    def synchronize(self): self._ck(self.lib.terra_multi_synchronize(self.m))
+
+    def tiles_create_zvals(self, tile_xy, iters_tt=0):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        z = np.empty((n, 130, 130), np.float32); st = (TileStats * n)(); nm = np.empty((n, 129, 129, 4), np.uint8); mnz = np.empty(n, np.float32)
+        self._ck(self.lib.terra_multi_tiles_create_zvals(self.m, txy.ctypes.data, n, iters_tt, z.ctypes.data, C.addressof(st), nm.ctypes.data, mnz.ctypes.data))
+        return z, st, nm, mnz
+
+    def tiles_create_zvals_dev(self, tile_xy, iters_tt, z_ptrs, stats_ptrs=None, normals_ptrs=None, mnz_ptrs=None):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        arr = lambda ps: None if ps is None else (_vp * self.n)(*ps)
+        self._ck(self.lib.terra_multi_tiles_create_zvals_dev(self.m, txy.ctypes.data, len(txy), iters_tt, arr(z_ptrs), arr(stats_ptrs), arr(normals_ptrs), arr(mnz_ptrs)))
+
+    def gen_grid_rows_dev(self, ptrs, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
+        mn, mx = C.c_float(), C.c_float()
+        self._ck(self.lib.terra_multi_gen_grid_rows_dev(self.m, x0, y0, dx, dy, nx, ny, flags, min_start_sin, (_vp * self.n)(*ptrs), C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    def voxel_fill_dev(self, ptrs, nx, ny, nz, lo_pos, vsz, offset, mag, freq, rseed1, rseed2, gen_mode, zscale, normalize):
+        a = lambda v: (C.c_float * 3)(*v)
+        self._ck(self.lib.terra_multi_voxel_fill_dev(self.m, (_vp * self.n)(*ptrs), nx, ny, nz, a(lo_pos), a(vsz), a(offset), mag, freq, rseed1, rseed2, gen_mode, zscale, normalize))
+
+    def tiles_mesh_shadows(self, tile_xy, zvals, light_pos):
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        z = np.ascontiguousarray(zvals, np.float32).reshape(n, 130, 130)
+        sm = np.empty((n, 130, 130), np.uint8)
+        self._ck(self.lib.terra_multi_tiles_mesh_shadows(self.m, txy.ctypes.data, n, z.ctypes.data, (C.c_float * 3)(*light_pos), sm.ctypes.data))
+        return sm
+
+    def foreach(self, fn):
+        """fn(Terra, index) -> int on every context's host thread at once (the callback re-enters Python: the calls serialise on the GIL except inside the library)"""
+        cb_t = C.CFUNCTYPE(C.c_int, _vp, _u32, _vp)
+        def tramp(ctx, index, _user):
+            try:
+                r = fn(self.ctxs[index], index)
+                return 0 if r is None else int(r)
+            except Exception:  # noqa: BLE001
+                return -2
+        cb = cb_t(tramp)
+        self._ck(self.lib.terra_multi_foreach(self.m, C.cast(cb, _vp), None))
 
 
 class Generator:

@@ -6,8 +6,8 @@ semantics (src/heightmap.cpp:130-187): build_arrays + enable_glaciate + eval of 
 mesh_freq_filter 1 -> start_eval_sin 10), min(vals), apply_erosion(vals, N, N, min, 1000 droplets), all device resident.
 The z grid never leaves HBM inside the timed region (there is no input grid; parameters are a few hundred bytes).
 
-  python bench.py [--gpus N --steps K --warmup W --size 16384 --mode sine --droplets 1000]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W --size 16384 --mode sine --droplets 1000]   (N > 1: starts N ranks itself through torch.distributed.run)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU; WORLD_SIZE must equal --gpus)
 
 `value` (the headline): every rank owns one independent N x N region of the world (origin shifted by rank*N cells in x), generated and
 eroded exactly like the reference erodes each tile alone on its clamp-padded copy (src/tiled_mesh.cpp:515): no data-path
@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-rccl-world1", action="store_true", help="N = 1: do not create the one-rank RCCL group (the collectives of the sharded paths are then skipped)")
     p.add_argument("--cpu-size", type=int, default=0, help="grid edge of the CPU sample (default: the benchmark's own size)")
     return p.parse_args()
 
@@ -108,13 +109,38 @@ def cpu_baseline(args, mode):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_cmd(n, argv):
+    """the launcher line for N ranks on this node: the same one the driver uses for N > 1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU"""
+    cmd = launch_cmd(n, sys.argv[1:])
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)  # does not return
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: one rank per GPU, the line's n_gpus must be the N that was asked for")
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a HIP device (no CPU fall-back)")
@@ -122,15 +148,31 @@ def main():
     if backend == "nccl" and world > ndev:
         raise SystemExit(f"{world} ranks but {ndev} GPUs: one rank per GPU")
     local_rank %= ndev
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    rccl_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or world == 1, "launch one rank per GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    elif backend == "nccl" and not args.no_rccl_world1:
+        # N = 1: a one-rank RCCL group, so that the device-tensor collectives of the sharded paths (all_reduce(min) of the strips, the max over ranks of the
+        # step time, barriers) run through RCCL on the 1-GPU box too instead of being skipped; a failure to set it up is reported, not fatal
+        try:
+            t0 = time.perf_counter()
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
+            probe = torch.tensor([3.5], dtype=torch.float32, device=dev)
+            dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+            dist.barrier()
+            assert float(probe.item()) == 3.5
+            rccl_note = {"world1_group": "ok", "init_plus_first_all_reduce_ms": round((time.perf_counter() - t0) * 1e3, 1)}
+        except Exception as e:  # noqa: BLE001
+            rccl_note = {"world1_group": f"unavailable: {e!r}"[:300]}
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    have_group = dist.is_initialized()
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     pkg = importlib.import_module("3dworld_amd")
@@ -187,7 +229,7 @@ def main():
         torch.cuda.synchronize(dev)
         for c in ctxs:
             c.synchronize()
-        if world > 1:
+        if have_group:
             dist.barrier()
 
     def timed(fn, k, warm):
@@ -201,7 +243,7 @@ def main():
             c.synchronize()
         dt = time.perf_counter() - t0
         barrier()
-        if world > 1:
+        if have_group:
             tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -214,7 +256,7 @@ def main():
     def strips_steps(k):
         for _ in range(k):
             mn, _ = t.gen_grid_rows_minmax_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, r0, r1 - r0, pkg.GEN_GLACIATE)
-            if world > 1:
+            if have_group:
                 red[0] = mn
                 dist.all_reduce(red, op=dist.ReduceOp.MIN)  # min(vals) of the whole map: what run_erosion / from_floats need next
                 mn = float(red.item())
@@ -268,7 +310,7 @@ def main():
         value = cells * K / dt / 1e9
         scaling = "strong"
         workload = f"ONE {N}x{N} heightmap as {world} row strips, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals) by all_reduce(min); erosion excluded (does not shard: replicas only)"
-        par = f"{world} row strips of {N // world} rows, one 4-byte all_reduce(min) per step over RCCL"
+        par = f"{world} row strips of {N // world} rows, one 4-byte all_reduce(min) per step over " + (("RCCL" if backend == "nccl" else backend) if have_group else "nothing (no process group)")
     else:
         dt = timed(tiles_steps_fn(args.tile_droplets), K, max(W, 2))
         value = len(all_tiles) * 130 * 130 * K / dt / 1e9
@@ -287,7 +329,7 @@ def main():
         if args.workload != "strips":
             ds = timed(strips_steps, ke, 2)
             detail["strips"] = {"steps": ke, "ms_per_step": round(ds / ke * 1e3, 4), "gcells_s": round(cells * ke / ds / 1e9, 3), "scaling": "strong", "rows_per_rank": r1 - r0,
-                                "collective": "all_reduce(min) of one float per step" if world > 1 else "none (1 rank)", "erosion": "excluded: one shared grid in serial droplet order does not shard (replicas only)"}
+                                "collective": ("all_reduce(min) of one float per step over " + ("RCCL" if backend == "nccl" else backend) + (" (one-rank group)" if world == 1 else "")) if have_group else "none (no process group)", "erosion": "excluded: one shared grid in serial droplet order does not shard (replicas only)"}
         if args.workload != "tiles":
             dt0 = timed(tiles_steps_fn(0), ke, 2)
             kt = max(2, min(K, 3))
@@ -392,7 +434,7 @@ def main():
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if args.workload == "heightmap" else 1, "parallelism": par},
                "latency_ms_single": detail.get("single", {}).get("latency_ms_single", round(ms_step, 4) if P == 1 else None),
-               "roofline": roof, "detail": dict(detail, erosion=rep)}
+               "roofline": roof, "detail": dict(detail, erosion=rep, rccl=rccl_note)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, mode)
@@ -401,7 +443,7 @@ def main():
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

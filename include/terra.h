@@ -180,11 +180,12 @@ int  terra_eval_mesh_sin_terms(terra_ctx *ctx, float xv, float yv, float *out);
 int  terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop);
 
 /* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0.
- * num_iters (and erosion_iters_tt of the tile calls) above 27 182 812 is TERRA_ERR_ARG: the reference's `int` seed 79*iter+121 overflows there (undefined). */
+ * num_iters (and erosion_iters_tt of the tile calls) above 27 183 336 is TERRA_ERR_ARG: the reference's `int` seed 79*iter+121 of droplet iter = 27 183 336 overflows (undefined). */
 int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
-/* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots; default automatic from the grid size, 0xFFFFFFFF restores that),
+/* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots; default automatic from the grid size, 0xFFFFFFFF restores that; at most
+ * 2^20 is accepted, and a run uses at most (2^25 - 1)/block_list_capacity slots: version pages are addressed with 31-bit float indices),
  * log_capacity_log2: ignored (range-checked only) -- a droplet's writes are kept as one 64-cell page per 8x8 block of its footprint, there is no hashed log to size,
  * per-droplet block-list capacity = pages per droplet (16 .. 256, larger values mean 256).  A droplet whose footprint overflows it runs alone, in order, directly on
  * the grid (still exact).
@@ -310,6 +311,39 @@ int  terra_voxel_fill_slab_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32
                                float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1, uint32_t y0, uint32_t nys);
 int  terra_voxel_fill(terra_ctx *ctx, float *h_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
                       float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
+
+/* ---- several GPUs from ONE host process.  3DWorld is a single C++ process that keeps eight generator objects in flight and collects them as they finish
+ * (height_gens[8], src/tiled_mesh.h:418; src/tiled_mesh.cpp:2317,2367-2416).  terra_multi = N contexts, one per entry of device_indices (an index may repeat:
+ * several contexts on one GPU), each driven by its own host thread for the duration of a call.  Units are dealt out in contiguous blocks -- context i gets
+ * terra_multi_partition(n_units, size, i) -- of independent work: tiles (no neighbour data, src/tiled_mesh.cpp:515), rows of one heightmap
+ * (src/heightmap.cpp:139-143), y slabs of a voxel field; nothing there is collective.  In the *_dev forms the outputs are arrays of per-context device
+ * pointers (entry i lives on context i's device and holds its block).  terra_multi_foreach runs fn(ctx, index, user) on every context's thread at once for
+ * everything else (e.g. one heightmap region per GPU: terra_gen_grid_minmax_dev + terra_apply_erosion_dev); a negative return is the call's error.
+ * terra_multi_tiles_mesh_shadows: the one pass of the tile path with a cross-tile dependency (tile_t::calc_shadows_for_light, src/tiled_mesh.cpp:664-692) --
+ * tile columns in strips, one per context, rows pipelined through the strips, the border tiles' outgoing edges handed from device to device
+ * (hipMemcpyPeerAsync); host zvals in ([n][130][130]), host shadow masks out ([n][130][130]), same result as terra_tiles_mesh_shadows on one context. */
+typedef struct terra_multi terra_multi;
+int  terra_multi_create(terra_multi **out, const int *device_indices, uint32_t n);
+void terra_multi_destroy(terra_multi *m);
+uint32_t terra_multi_size(const terra_multi *m);
+terra_ctx *terra_multi_ctx(terra_multi *m, uint32_t i);
+void terra_multi_partition(uint32_t n_units, uint32_t n_parts, uint32_t part, uint32_t *first, uint32_t *count);
+int  terra_multi_foreach(terra_multi *m, int (*fn)(terra_ctx *ctx, uint32_t index, void *user), void *user);
+int  terra_multi_synchronize(terra_multi *m);
+int  terra_multi_init_scene(terra_multi *m, const terra_config *cfg);
+int  terra_multi_tiles_create_zvals_dev(terra_multi *m, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
+                                        float *const *d_zvals, terra_tile_stats *const *d_stats, uint8_t *const *d_normals, float *const *d_min_normal_z);
+int  terra_multi_tiles_create_zvals(terra_multi *m, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
+                                    float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
+int  terra_multi_gen_grid_rows_dev(terra_multi *m, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin,
+                                   float *const *d_out, float *h_min, float *h_max);
+int  terra_multi_voxel_fill_dev(terra_multi *m, float *const *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
+                                float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
+int  terra_multi_tiles_mesh_shadows(terra_multi *m, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask);
+/* the device-resident form of the halo arrays of terra_tiles_mesh_shadows_halo_dev: d_edge_in / d_edge_out are [n][2][130] floats in device memory
+ * (d_edge_in is read where h_edge_in_present says so); what terra_multi_tiles_mesh_shadows hands from GPU to GPU */
+int  terra_tiles_mesh_shadows_edges_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask,
+                                        const float *d_edge_in, const uint8_t *h_edge_in_present, float *d_edge_out);
 
 /* ---- plumbing for callers without a HIP runtime of their own (tests, ctypes) */
 int  terra_malloc(terra_ctx *ctx, void **d_ptr, size_t bytes);

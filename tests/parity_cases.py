@@ -148,7 +148,7 @@ def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_ca
             else:
                 os.environ[k] = v
         t.set_erosion_tuning(window=0xFFFFFFFF, block_list_capacity=256)
-        t.set_erosion_slice_steps(1024)
+        t.set_erosion_slice_steps(128)  # the shipped default (spec_cfg_t::slice_steps): later tests on a shared context run the default scheduler
     assert r.windows == -(-iters // window)
     return r, stats
 
@@ -925,8 +925,8 @@ def case_api_errors(pkg, t):
     with pytest.raises(pkg.TerraError):  # enable_glaciate before build_arrays
         g.enable_glaciate()
     g.close()
-    with pytest.raises(pkg.TerraError) as e:  # 79*iter+121 overflows the reference's int from iter 27 182 813 on: undefined there, refused here
-        t.apply_erosion(np.zeros((16, 16), np.float32), 0.0, 27182813)
+    with pytest.raises(pkg.TerraError) as e:  # 79*iter+121 overflows the reference's int from droplet iter = 27 183 336 on (a run of 27 183 337 droplets): undefined there, refused here
+        t.apply_erosion(np.zeros((16, 16), np.float32), 0.0, 27183337)
     assert e.value.code == -1
     # the rows added after the first hot path
     with pytest.raises(pkg.TerraError):
@@ -952,3 +952,81 @@ def case_api_errors(pkg, t):
     with pytest.raises(pkg.TerraError):
         t.export_heightmap_dev(0.0, 0.0, 0, 4, 1)
     t.init_scene(pkg.make_config())
+
+
+# ---- several contexts driven from one process (terra_multi_*, include/terra.h): the union of the contexts' blocks equals the single-context / oracle result
+def case_multi_contexts(pkg, lib_path, orc, ndev=3, big=False):
+    m = pkg.TerraMulti([0] * ndev, lib_path)
+    try:
+        cfg, ocfg = cfg_pair(pkg, mesh_gen_mode=0)
+        st = m.init_scene(cfg); orc.init(ocfg)
+        assert sum(m.partition(10, p)[1] for p in range(ndev)) == 10 and m.partition(10, 0)[0] == 0
+        # tiles, block-partitioned, host outputs
+        tiles = [(tx, ty) for ty in range(-2, 1) for tx in range(-3, 4)] if not big else [(tx, ty) for ty in range(-8, 8) for tx in range(-8, 8)]
+        iters = 60 if not big else 200
+        z, stt, nm, mnz = m.tiles_create_zvals(tiles, iters)
+        for i in (range(len(tiles)) if not big else range(0, len(tiles), 7)):
+            zo, so = orc.tile_create_zvals(*tiles[i], iters)
+            assert_bit_equal(zo, z[i], f"multi tile {tiles[i]}"); assert bytes(so) == bytes(stt[i])
+            no, mo = orc.tile_normals(zo)
+            assert (no == nm[i]).all() and np.float32(mo) == mnz[i]
+        # the same with per-context device outputs
+        bufs = [m.ctxs[p].alloc(max(1, m.partition(len(tiles), p)[1]) * 130 * 130 * 4) for p in range(ndev)]
+        m.tiles_create_zvals_dev(tiles, iters, [b.ptr for b in bufs])
+        for p in range(ndev):
+            f, c = m.partition(len(tiles), p)
+            if c:
+                assert (bufs[p].download(np.float32, (c, 130, 130)).view(np.uint32) == z[f:f + c].view(np.uint32)).all()
+            bufs[p].free()
+        # one heightmap as row strips + min / max of the whole map
+        nx, ny = (300, 131) if not big else (4096, 4096)
+        bufs = [m.ctxs[p].alloc(max(1, m.partition(ny, p)[1]) * nx * 4) for p in range(ndev)]
+        mn, mx = m.gen_grid_rows_dev([b.ptr for b in bufs], -nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)
+        ref = orc.gen_grid(-nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, 1)
+        got = np.concatenate([bufs[p].download(np.float32, (m.partition(ny, p)[1], nx)) for p in range(ndev) if m.partition(ny, p)[1]])
+        assert_bit_equal(ref, got, "multi row strips")
+        assert np.float32(mn) == ref.min() and np.float32(mx) == ref.max()
+        for b in bufs:
+            b.free()
+        # one voxel field as y slabs
+        vx, vy, vz = (20, 11, 33) if not big else (256, 256, 64)
+        bufs = [m.ctxs[p].alloc(max(1, m.partition(vy, p)[1]) * vx * vz * 4) for p in range(ndev)]
+        m.voxel_fill_dev([b.ptr for b in bufs], vx, vy, vz, VOX["lo"], VOX["vsz"], VOX["off"], 0.8, 1.3, 7, 9, 0, -0.02, 0)
+        refv = orc.voxel_fill(vx, vy, vz, VOX["lo"], VOX["vsz"], VOX["off"], 0.8, 1.3, 7, 9, 0, -0.02, 0)
+        gotv = np.concatenate([bufs[p].download(np.float32, (m.partition(vy, p)[1], vx, vz)) for p in range(ndev) if m.partition(vy, p)[1]])
+        assert_bit_equal(refv, gotv, "multi voxel slabs")
+        for b in bufs:
+            b.free()
+        # mesh shadows: column strips, rows pipelined, border edges device to device; full blocks, holes, lights from all four quadrants and axis-aligned
+        terrains = [[(tx, ty) for ty in range(-1, 3) for tx in range(-3, 4)],
+                    [(tx, ty) for ty in range(0, 3) for tx in range(0, 6) if (tx, ty) not in ((2, 1), (3, 1), (0, 2))] + [(9, 9)]]
+        if big:
+            terrains = [[(tx, ty) for ty in range(-8, 8) for tx in range(-8, 8)]]
+        for tl in terrains:
+            zt = np.stack([orc.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tl]) * np.float32(4.0)
+            for light in ((0.6, 0.5, 0.4), (-0.8, 0.3, 0.25), (0.2, -0.9, 0.15), (-0.5, -0.5, 0.8), (1.0, 0.0, 0.3), (0.0, 0.0, 1.0))[:(6 if not big else 2)]:
+                want = orc.tiles_mesh_shadows(tl, zt, light)
+                got = m.tiles_mesh_shadows(tl, zt, light)
+                assert (got == want).all(), (light, [tl[i] for i in np.argwhere((got != want).any(axis=(1, 2))).ravel()][:6])
+        # foreach: one independent heightmap region per context, all at once (bench.py's headline, from one process)
+        N = 96 if not big else 2048
+        outs = [None] * ndev
+        bufs = [m.ctxs[p].alloc(N * N * 4) for p in range(ndev)]
+        def region(t, p):
+            mnp, _ = t.gen_grid_minmax_dev(bufs[p].ptr, -N / 2 + p * N, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+            t.apply_erosion_dev(bufs[p].ptr, N, N, mnp, 150, pkg.ERODE_MINZ_IS_MIN)
+            outs[p] = mnp
+            return 0
+        m.foreach(region)
+        m.synchronize()
+        for p in range(ndev):
+            r = orc.gen_grid(-N / 2 + p * N, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 1)
+            assert np.float32(outs[p]) == r.min()
+            orc.apply_erosion(r, float(r.min()), 150)
+            assert_bit_equal(r, bufs[p].download(np.float32, (N, N)), f"multi region {p}")
+            bufs[p].free()
+        # errors: a failing context fails the call with its message
+        with pytest_raises(pkg.TerraError):
+            m.tiles_create_zvals_dev(tiles, 0, [0] * ndev)
+    finally:
+        m.close()

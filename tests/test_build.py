@@ -11,3 +11,14 @@ def test_hot_kernels_do_not_spill():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_kernel_resources.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_shipped_library_matches_the_sources():
+    """libterra_hip.so travels with the tree (built in place, git-ignored): its recorded source hash must be the hash of csrc/ + include/terra.h + flags as they
+    are now, so a stale library cannot pass for the current code (3dworld_amd/build.py)"""
+    import importlib, os
+    import pytest
+    bmod = importlib.import_module("3dworld_amd.build")
+    if not os.path.exists(bmod.LIB):
+        pytest.skip("library not built yet (__graft_entry__.build() does it)")
+    assert not bmod.needs_build(), "libterra_hip.so was built from other sources: run __graft_entry__.build()"

@@ -168,3 +168,112 @@ def test_two_ranks_mesh_shadows_with_edge_exchange(emul_lib, orc, tmp_path, ligh
             assert (sm[k] == want[tiles.index(tl)]).all(), f"rank {r} tile {tl}"
             seen += 1
     assert seen == len(tiles) and want.any()
+
+
+# ---- bench.py's launch contract: `python bench.py --gpus N` starts N ranks itself and the line it prints says n_gpus = N
+def _bench_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("terra_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_launch_command_and_world_check():
+    import subprocess
+    b = _bench_mod()
+    cmd = b.launch_cmd(4, ["--gpus", "4", "--steps", "3"])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    # a launcher that started a different number of ranks than --gpus asks for is refused (before any GPU work): the printed n_gpus is always the N asked for
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _last_json_line(text):
+    import json
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in: " + text[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: two ranks come up (both on GPU 0 of the 1-GPU test box, so gloo carries the barrier / max-over-ranks
+    instead of RCCL, which wants one device per rank) and rank 0's line reports n_gpus = 2 with the aggregate of both regions"""
+    import subprocess
+    env = dict(os.environ, TERRA_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--size", "2048", "--no-extras", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert abs(line["value"] - 2 * 2048 * 2048 / (line["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * line["value"]
+
+
+@pytest.mark.gpu
+def test_bench_world1_runs_its_collectives_through_rccl():
+    """N = 1 on the GPU box: bench.py creates a one-rank RCCL group, so the device-tensor all_reduce / barrier branches of the sharded paths execute through RCCL"""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TERRA_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--size", "2048", "--no-cpu-baseline", "--workload", "strips"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["detail"]["rccl"]["world1_group"] == "ok", line["detail"].get("rccl")
+    assert "RCCL" in line["config"]["parallelism"]
+
+
+def _nccl_world1_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pkg = importlib.import_module("3dworld_amd")
+    dmod = importlib.import_module("3dworld_amd.dist")
+    t = pkg.Terra(0)
+    st = t.init_scene(pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    nx, ny = 1030, 517
+    buf = t.alloc(nx * ny * 4)
+    r0, r1, mn, mx = dmod.sharded_heightmap_strips(t, dist, buf.ptr, -nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)  # all_reduce(min / max) on device tensors over RCCL
+    np.save(os.path.join(out_dir, "z.npy"), buf.download(np.float32, (ny, nx)))
+    np.save(os.path.join(out_dir, "mm.npy"), np.array([mn, mx, r0, r1], np.float64))
+    # the shadow pass of a one-strip terrain through the same helper (no neighbour strip: no send / recv, but the device staging branch is the RCCL one)
+    tiles = [(tx, ty) for ty in range(0, 2) for tx in range(0, 3)]
+    keep = {}
+    def make_zvals(mine):
+        z, _, _, _ = t.tiles_create_zvals(mine, 0, stats=False, normals=False)
+        keep["z"] = t.alloc(z.nbytes).upload(z)
+        return keep["z"].ptr
+    def alloc_smask(n):
+        keep["sm"] = t.alloc(n * 130 * 130)
+        return keep["sm"].ptr
+    mine, _ = dmod.sharded_tile_mesh_shadows(t, dist, tiles, (0.7, 0.4, 0.3), make_zvals, alloc_smask)
+    np.save(os.path.join(out_dir, "sm.npy"), keep["sm"].download(np.uint8, (len(mine), 130, 130)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_group_runs_the_device_collectives(orc, tmp_path):
+    """the `nccl` (= RCCL) branches of 3dworld_amd/dist.py on the 1-GPU box: a one-rank group, device tensors through all_reduce, results equal to the oracle's"""
+    import torch.multiprocessing as mp
+    import orclib
+    port = 37500 + os.getpid() % 2000
+    mp.spawn(_nccl_world1_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    nx, ny = 1030, 517
+    s = orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    ref = orc.gen_grid(-nx / 2, -ny / 2, s.DX_VAL, s.DY_VAL, nx, ny, 1)
+    orclib.assert_bit_equal(ref, np.load(tmp_path / "z.npy"), "strip through the RCCL group")
+    mm = np.load(tmp_path / "mm.npy")
+    assert np.float32(mm[0]) == ref.min() and np.float32(mm[1]) == ref.max() and (mm[2], mm[3]) == (0, ny)
+    orc.init(orclib.make_config(mesh_gen_mode=0))
+    tiles = [(tx, ty) for ty in range(0, 2) for tx in range(0, 3)]
+    z = np.stack([orc.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tiles])
+    assert (orc.tiles_mesh_shadows(tiles, z, (0.7, 0.4, 0.3)) == np.load(tmp_path / "sm.npy")).all()

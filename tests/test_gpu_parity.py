@@ -345,3 +345,10 @@ def test_tile_erosion_large_batch_launch_order(pkg, gpu, orc):
 
 def test_random_heightmap_textures(pkg, gpu, orc):
     pc.case_random_heightmap_textures(pkg, gpu, orc)
+
+
+@pytest.mark.parametrize("ndev,big", [(2, False), (3, True)])
+def test_multi_contexts_in_one_process(pkg, orc, ndev, big):
+    """terra_multi_* on the HIP library: several contexts on device 0 (the test box has one GPU; on a node every context gets its own), each driven by its own host
+    thread; the shadow edges travel between the contexts' buffers with the device-to-device copy the multi-GPU path uses"""
+    pc.case_multi_contexts(pkg, None, orc, ndev, big)

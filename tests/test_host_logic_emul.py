@@ -225,3 +225,9 @@ def test_heightmap_postprocess_vs_oracle(pkg, emul, orc):
     for pix in (pix8, pix16):
         changed, rep = pc.case_heightmap_postprocess_vs_oracle(pkg, emul, orc, pix, 700)
         assert changed > 0 and rep.droplets == 700
+
+
+def test_multi_contexts_in_one_process(pkg, emul_lib, orc):
+    """terra_multi_*: three contexts driven by three host threads -- tiles, row strips, voxel slabs, the row-pipelined mesh shadows with the edge hand-over,
+    one region per context -- the union equals the oracle"""
+    pc.case_multi_contexts(pkg, emul_lib, orc, 3)
