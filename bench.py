@@ -128,6 +128,25 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner on the C stdout when its first communicator comes up (buffered, so it would surface after the JSON line at exit): while this
+    is active the process's fd 1 is stderr, and the C buffers are flushed before fd 1 is put back -- stdout stays exactly ONE JSON line"""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -153,20 +172,25 @@ def main():
     rccl_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+        with c_stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)
+                warm = torch.zeros(1, dtype=torch.float32, device=dev)
+                dist.all_reduce(warm, op=dist.ReduceOp.MAX)  # the communicator (and RCCL's banner) comes up here, not inside the timed region
+                torch.cuda.synchronize(dev)
+            else:
+                dist.init_process_group(backend=backend)
     elif backend == "nccl" and not args.no_rccl_world1:
         # N = 1: a one-rank RCCL group, so that the device-tensor collectives of the sharded paths (all_reduce(min) of the strips, the max over ranks of the
         # step time, barriers) run through RCCL on the 1-GPU box too instead of being skipped; a failure to set it up is reported, not fatal
         try:
             t0 = time.perf_counter()
-            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
-            probe = torch.tensor([3.5], dtype=torch.float32, device=dev)
-            dist.all_reduce(probe, op=dist.ReduceOp.MIN)
-            dist.barrier()
-            assert float(probe.item()) == 3.5
+            with c_stdout_to_stderr():
+                dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
+                probe = torch.tensor([3.5], dtype=torch.float32, device=dev)
+                dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+                dist.barrier()
+                assert float(probe.item()) == 3.5
             rccl_note = {"world1_group": "ok", "init_plus_first_all_reduce_ms": round((time.perf_counter() - t0) * 1e3, 1)}
         except Exception as e:  # noqa: BLE001
             rccl_note = {"world1_group": f"unavailable: {e!r}"[:300]}
@@ -395,8 +419,8 @@ def main():
             # dense whole-map erosion (config_heightmap.txt:78 carries 10^6 droplets; BASELINE config 3 is the 4096^2 map): one run each, wall clock with a synchronize on both sides
             de = {}
             for nn, dd in ((N, 1000000), (4096, 1000000), (4096, 100000)):
-                zz = z[:nn * nn]
-                for rep in range(2):  # the first run of a shape allocates the scheduler's buffers (GBs for the 16384^2 ring): time the second
+                zz = z[:nn * nn] if nn * nn <= cells else torch.empty(nn * nn, dtype=torch.float32, device=dev)  # (a bench grid smaller than config 3's 4096^2 map)
+                for _pass in range(2):  # the first run of a shape allocates the scheduler's buffers (GBs for the 16384^2 ring): time the second
                     mnd, _ = t.gen_grid_minmax_dev(zz.data_ptr(), -nn / 2, -nn / 2, st.DX_VAL, st.DY_VAL, nn, nn, pkg.GEN_GLACIATE)
                     t.synchronize()
                     t0 = time.perf_counter()

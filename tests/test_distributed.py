@@ -192,11 +192,11 @@ def test_bench_launch_command_and_world_check():
 
 
 def _last_json_line(text):
+    """the contract: stdout is exactly ONE line, a JSON object (nothing from RCCL or anyone else around it)"""
     import json
-    for line in reversed(text.strip().splitlines()):
-        if line.startswith("{"):
-            return json.loads(line)
-    raise AssertionError("no JSON line in: " + text[-2000:])
+    lines = text.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be one JSON line, got: " + text[-2000:]
+    return json.loads(lines[0])
 
 
 @pytest.mark.gpu

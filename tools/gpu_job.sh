@@ -85,7 +85,9 @@ PY
 native)
 	mkdir -p tools/_bin
 	gcc -O2 -std=c99 -Iinclude tools/bench_native.c -L3dworld_amd -lterra_hip -lpthread -Wl,-rpath,"$ROOT/3dworld_amd" -o tools/_bin/bench_native && timeout 300 tools/_bin/bench_native 64 4 | tee "$OUT/bench_native.json"
-	gcc -O2 -std=c99 -Iinclude tools/bench_native_multi.c -L3dworld_amd -lterra_hip -lpthread -Wl,-rpath,"$ROOT/3dworld_amd" -o tools/_bin/bench_native_multi && timeout 600 tools/_bin/bench_native_multi "${@:-2 16 16384 --same-device}" | tee "$OUT/bench_native_multi.jsonl"
+	gcc -O2 -std=c99 -Iinclude tools/bench_native_multi.c -L3dworld_amd -lterra_hip -lpthread -Wl,-rpath,"$ROOT/3dworld_amd" -o tools/_bin/bench_native_multi || exit 1
+	if [ $# -eq 0 ]; then set -- 2 16 16384 --same-device; fi
+	timeout 600 tools/_bin/bench_native_multi "$@" | tee "$OUT/bench_native_multi.jsonl"
 	;;
 *) echo "unknown command $CMD"; exit 2 ;;
 esac
