@@ -680,6 +680,7 @@ template<class BE> struct terra_engine {
 		ec.max_path_len = 4u*(unsigned)ec.NX*(unsigned)ec.NY;
 		ec.erode_amount = erode_amount; ec.water_thresh = water_plane_z - HALF_DXY;
 		ec.relh_adj_tex = relh_adj_tex; ec.zmin = zmin; ec.zrange = zmax - zmin; ec.clip_hd1 = clip_hd1; ec.two_pi = two_pi; ec.min_zval = min_zval;
+		make_rock_threshold(ec);
 		ec.lead_mode = 2;
 		if (char const *lm = getenv("TERRA_ERO_LEAD")) {int const v = atoi(lm); if (v >= 0 && v <= 2) ec.lead_mode = v;} // where a recentred window lies never changes a result (it is a cache)
 		return ec;

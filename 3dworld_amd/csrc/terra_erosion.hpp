@@ -50,6 +50,11 @@ struct erosion_consts_t {
 	float erode_amount;
 	float water_thresh;         // water_plane_z - HALF_DXY
 	float relh_adj_tex, zmin, zrange, clip_hd1; // get_bare_ls_tid (src/Textures.cpp:1284-1287): zrange = zmax - zmin
+	// the rock test `relh_adj_tex + (nh - zmin)/zrange > clip_hd1` is monotone in t = nh - zmin when zrange > 0 (a correctly rounded division by a positive constant
+	// and a correctly rounded addition of a constant are both non-decreasing), so it is `t >= rock_t` for one threshold that the host finds by bisection over the
+	// floats with the very expression above (make_rock_threshold): a compare instead of an IEEE division on the step's dependent chain.  rock_div != 0: no such
+	// threshold (zrange <= 0 or NaN) -- the step divides.
+	float rock_t; int rock_div;
 	float two_pi;               // float(2.0*PI)
 	float min_zval;
 	int   lead_mode;            // placement of a recentred LDS window: 0 centred on the droplet, 1 always ahead of it, 2 ahead only when the last window lasted (speed only)
@@ -89,6 +94,24 @@ struct droplet_state_t {
 	rand_gen_t rgen;
 };
 constexpr unsigned DROPLET_NO_BUDGET = 0xFFFFFFFFu;
+
+// the rock test of a step (src/erosion.cpp:133, get_bare_ls_tid src/Textures.cpp:1284-1287) as the reference evaluates it
+TERRA_HD bool rock_test_div(erosion_consts_t const &ec, float t) {float const relh = ec.relh_adj_tex + t/ec.zrange; return relh > ec.clip_hd1;}
+TERRA_HD bool rock_test(erosion_consts_t const &ec, float nh) {
+	float const t = nh - ec.zmin;
+	return ec.rock_div ? rock_test_div(ec, t) : (t >= ec.rock_t);
+}
+// smallest float t with rock_test_div(t) (host, once per erosion call): bisection over the order-preserving integer image of the floats, -inf .. +inf
+inline void make_rock_threshold(erosion_consts_t &ec) {
+	ec.rock_t = 0.0f; ec.rock_div = 1;
+	if (!(ec.zrange > 0.0f) || ec.relh_adj_tex != ec.relh_adj_tex || ec.clip_hd1 != ec.clip_hd1) return;
+	auto key2f = [](uint32_t k) {uint32_t const u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &u, 4); return f;}; // increasing in k
+	uint32_t lo = 0x007FFFFFu /* -inf */, hi = 0xFF800000u /* +inf */;
+	if (rock_test_div(ec, key2f(lo))) {ec.rock_t = key2f(lo); ec.rock_div = 0; return;}        // true everywhere (NaN heights still fail the compare, as they fail the original)
+	if (!rock_test_div(ec, key2f(hi))) {ec.rock_t = NAN; ec.rock_div = 0; return;}             // never true: t >= NaN is false
+	while (hi - lo > 1) {uint32_t const mid = lo + (hi - lo)/2; if (rock_test_div(ec, key2f(mid))) {hi = mid;} else {lo = mid;}}
+	ec.rock_t = key2f(hi); ec.rock_div = 0;
+}
 
 // spawn (src/erosion.cpp:67-84); false => the memory policy aborted the trace before the first step
 template<class MEM> TERRA_HD bool droplet_start(int iter, MEM &mem, erosion_consts_t const &ec, droplet_state_t &d) {
@@ -163,8 +186,7 @@ template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, eros
 		else {
 			ds *= -Kr;
 			ds = min_std(ds, dh*0.99f);
-			float const relh = ec.relh_adj_tex + (nh - ec.zmin)/ec.zrange;
-			ds = (float)((double)ds*((relh > ec.clip_hd1) ? 0.5 : 2.0)); // rock erodes slower than dirt
+			ds = (float)((double)ds*(rock_test(ec, nh) ? 0.5 : 2.0)); // rock erodes slower than dirt
 			mem.erode(xi, zi, xp, zp, ds*ec.erode_amount);
 			dh -= ds;
 			s  += ds;
@@ -182,11 +204,18 @@ template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, eros
 }
 
 // ---- the common case as its own loop.  A step is "hot" when its 4x4 brush box is interior to the grid and resident (MEM::hot_ready), the
-// direction comes from the gradient and the new corners are resident too: then nothing is clamped and nothing has to be fetched, and the
-// step is the same arithmetic as in droplet_run().  Everything else (window shifts with their multi-version look-ups, the libm random
-// direction, brushes at the border, reads after a NaN position, the footprint overflowing) makes this loop stop BEFORE the step has had any
-// effect, and droplet_run() executes that one step.  The point is code layout: the loop below is a few hundred instructions in one piece,
-// while the general step drags ~100 KB of rarely executed code through the instruction cache of a wave that runs thousands of steps.
+// direction comes from the gradient and the new corners lie inside that box (a droplet moves one cell: they do, except after a NaN / a quotient a rounding
+// above 1): then nothing is clamped and nothing has to be fetched, and the step is the same arithmetic as in droplet_run().  Everything else (window shifts with
+// their multi-version look-ups, the libm random direction, brushes at the border, reads after a NaN position, the footprint overflowing) makes this loop stop
+// BEFORE the step has had any effect, and droplet_run() executes that one step.  A step is a chain of dependent instructions on ONE wave: every instruction is
+// ~4 cycles, every LDS round trip ~100, every taken branch a refetch -- so the loop is written for the length of that chain:
+//   * MEM::hot_ready fetches the step's 4x4 box, one cell per lane, at the TOP of the step; the four new corners are lane reads of that box (v_readlane), not a
+//     second LDS round trip; deposit / brush update the box in registers and store it (no read-modify-write round trip, no wait for the store: LDS executes a
+//     wave's instructions in order);
+//   * the position is carried as floor(xp) in float next to the integer cell: the new cell is the old one plus a small exact float difference, the box test is one
+//     compare per axis, a NaN fails it (no float -> int conversion of unchecked values, no range test against the grid: the box is interior);
+//   * the rock test is a compare against a threshold found on the host (rock_test above) instead of an IEEE division;
+//   * one step counter instead of separate path-length / budget tests; one compact run of instructions (the general step is ~100 KB of rarely executed code).
 enum {DROPLET_EV_DONE = 0, DROPLET_EV_BUDGET = 1, DROPLET_EV_GENERAL = 2};
 template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem, erosion_consts_t const &ec, unsigned budget, unsigned &used) {
 	float const Kq = 10, Kw = 0.001f, Kr = 0.9f, Kd = 0.02f, Ki = 0.1f, minSlope = 0.05f, g = 20, Kg = g*2;
@@ -198,20 +227,27 @@ template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem,
 	int nan_seen = d.nan_seen;
 	int ev = DROPLET_EV_GENERAL;
 	float c[4];
+	// steps this call may still make: the path-length limit (src/erosion.cpp:86) and the caller's budget folded into one counter
+	unsigned const room = (numMoves < ec.max_path_len) ? ec.max_path_len - numMoves : 0u, allow = (budget == DROPLET_NO_BUDGET) ? room : ((used < budget) ? budget - used : 0u);
+	unsigned left = (room < allow) ? room : allow, done = 0;
+	if (left == 0) {return (numMoves >= ec.max_path_len) ? DROPLET_EV_DONE : DROPLET_EV_BUDGET;}
+	float fxi = floorf(xp), fzi = floorf(zp); // == (float)xi, (float)zi for a position inside the grid (hot_ready refuses everything else)
 	for (;;) {
-		xi = wave_uniform(xi); zi = wave_uniform(zi); numMoves = wave_uniform(numMoves); used = wave_uniform(used);
-		if (numMoves >= ec.max_path_len) {ev = DROPLET_EV_DONE; break;}
-		if (used == budget) {ev = DROPLET_EV_BUDGET; break;}
+		xi = wave_uniform(xi); zi = wave_uniform(zi); left = wave_uniform(left);
+		if (left == 0) {ev = (numMoves + done >= ec.max_path_len) ? DROPLET_EV_DONE : DROPLET_EV_BUDGET; break;}
 		if (!mem.hot_ready(xi, zi)) {mem.set_travel(dx, dz); break;}
 		float const gx = h00+h01-h10-h11, gz = h00+h10-h01-h11;
 		float tdx = (dx-gx)*Ki+gx, tdz = (dz-gz)*Ki+gz;
 		float const dl = sqrtf(tdx*tdx+tdz*tdz);
-		if (dl <= FLT_EPSILON) break; // random direction: general step
+		if (!(dl > FLT_EPSILON)) break; // random direction (or a NaN): general step
 		tdx /= dl; tdz /= dl;
 		float const nxp = xp+tdx, nzp = zp+tdz;
-		int const nxi = f2i_x86(floorf(nxp)), nzi = f2i_x86(floorf(nzp));
-		float const nxf = nxp-(float)nxi, nzf = nzp-(float)nzi;
-		if (!mem.corners_hot(nxi, nzi, c)) break; // not resident (only after a NaN position): general step
+		float const nfx = floorf(nxp), nfz = floorf(nzp), ofx = nfx - fxi, ofz = nfz - fzi; // cell offsets -1, 0, 1 (exact: small integers), anything else leaves the box
+		if (!(fabsf(ofx) <= 1.0f && fabsf(ofz) <= 1.0f)) break; // (a NaN position fails too): general step
+		int const ox = wave_uniform((int)ofx), oz = wave_uniform((int)ofz);
+		mem.corners_hot(ox, oz, c);
+		int const nxi = xi + ox, nzi = zi + oz;
+		float const nxf = nxp-nfx, nzf = nzp-nfz; // nfx == (float)nxi
 		// ---- from here on the step is executed
 		float const nh00 = c[0], nh10 = c[1], nh01 = c[2], nh11 = c[3];
 		float const nh = (nh00*(1-nxf)+nh10*nxf)*(1-nzf)+(nh01*(1-nxf)+nh11*nxf)*nzf;
@@ -239,8 +275,7 @@ template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem,
 		else {
 			ds *= -Kr;
 			ds = min_std(ds, dh*0.99f);
-			float const relh = ec.relh_adj_tex + (nh - ec.zmin)/ec.zrange;
-			ds = (float)((double)ds*((relh > ec.clip_hd1) ? 0.5 : 2.0));
+			ds = (float)((double)ds*(rock_test(ec, nh) ? 0.5 : 2.0)); // rock erodes slower than dirt
 			mem.erode_hot(xi, zi, xp, zp, ds*ec.erode_amount);
 			dh -= ds;
 			s  += ds;
@@ -249,10 +284,11 @@ template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem,
 		if (v != v) {nan_seen = 1;}
 		w *= evap;
 		dx = tdx; dz = tdz;
-		xp = nxp; zp = nzp; xi = nxi; zi = nzi; xf = nxf; zf = nzf;
+		xp = nxp; zp = nzp; xi = nxi; zi = nzi; xf = nxf; zf = nzf; fxi = nfx; fzi = nfz;
 		h = nh; h00 = nh00; h10 = nh10; h01 = nh01; h11 = nh11;
-		++numMoves; ++used;
+		++done; --left;
 	}
+	numMoves += done; used += done;
 	d.xi = xi; d.zi = zi; d.xp = xp; d.zp = zp; d.xf = xf; d.zf = zf; d.s = s; d.v = v; d.w = w; d.dx = dx; d.dz = dz;
 	d.h = h; d.h00 = h00; d.h10 = h10; d.h01 = h01; d.h11 = h11;
 	d.numMoves = numMoves; d.nan_seen = nan_seen;
@@ -301,11 +337,11 @@ struct direct_mem_t {
 		out[0] = *g.at(x0, z0); out[1] = *g.at(x1, z0); out[2] = *g.at(x0, z1); out[3] = *g.at(x1, z1);
 	}
 	TERRA_HD void set_travel(float, float) {}
-	TERRA_HD bool hot_ready(int xi, int zi) const {return xi-1 >= 0 && zi-1 >= 0 && xi+2 <= g.NX-1 && zi+2 <= g.NY-1;}
-	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
-		if (!(x >= 0 && z >= 0 && x+1 <= g.NX-1 && z+1 <= g.NY-1)) return false;
+	int hx = 0, hz = 0; // cell of the hot step in progress
+	TERRA_HD bool hot_ready(int xi, int zi) {hx = xi; hz = zi; return xi-1 >= 0 && zi-1 >= 0 && xi+2 <= g.NX-1 && zi+2 <= g.NY-1;}
+	TERRA_HD void corners_hot(int ox, int oz, float out[4]) const { // corners at (hx + ox, hz + oz), ox, oz in -1 .. 1: inside the step's interior 4x4 box
+		int const x = hx + ox, z = hz + oz;
 		out[0] = *g.at(x, z); out[1] = *g.at(x+1, z); out[2] = *g.at(x, z+1); out[3] = *g.at(x+1, z+1);
-		return true;
 	}
 	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {deposit(xi, zi, xf, zf, dse);}
 	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {erode(xi, zi, xp, zp, dse);}
@@ -340,6 +376,11 @@ struct direct_mem_t {
 #define TERRA_LANE_SLOTS 1          // per-lane values that live across a wave sync: registers on the device ...
 #define TERRA_LANE_SLOT(l) 0
 #define TERRA_WAVE_SYNC() __syncthreads()
+// a value held by lane `l` of the wave (l wave-uniform), as a scalar
+#define TERRA_READLANE(arr, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (arr)[0]), (l)))
+// LDS executes one wave's instructions in order: a store by one lane is seen by a later load of another lane without waiting for anything.  The fence keeps the
+// COMPILER from moving memory operations across it and costs no instruction (wavefront scope)
+#define TERRA_WAVE_FENCE() do {__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();} while (0)
 #define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define TERRA_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define TERRA_ATOMIC_ADD(p, v) atomicAdd((p), (v))
@@ -354,6 +395,8 @@ struct direct_mem_t {
 #define TERRA_LANE_SLOTS 64         // ... one array row per lane on the host, where the lanes of a TERRA_EACH_LANE loop run one after another
 #define TERRA_LANE_SLOT(l) (l)
 #define TERRA_WAVE_SYNC() do {} while (0)
+#define TERRA_READLANE(arr, l) ((arr)[(l)])
+#define TERRA_WAVE_FENCE() do {} while (0)
 template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
 template<class T> inline T terra_host_atomic_max(T *p, T v) {T o = *p; if (v > o) *p = v; return o;}
 template<class T> inline T terra_host_atomic_add(T *p, T v) {T o = *p; *p = o + v; return o;}
@@ -407,21 +450,36 @@ template<class DERIVED> struct wave_cell_ops {
 		}
 		TERRA_WAVE_SYNC();
 	}
-	// the brush box is interior: no clamping, 4 / 16 distinct cells, one lane each
+	// ---- hot step: the brush box is interior and resident.  Lane l < 16 keeps cell (xi-1 + (l & 3), zi-1 + (l >> 2)) of the step's 4x4 box in a register from the
+	// top of the step on (box_load: one load per lane, in flight while the step's arithmetic runs); every read and write of the step lies inside that box
+	float boxv[TERRA_LANE_SLOTS];
+	float *boxp[TERRA_LANE_SLOTS]; // where the lane's cell lives (its address is computed once per step)
+	TERRA_HD void box_load(int xi, int zi) {
+		TERRA_WAVE_FENCE(); // after the stores of the step before
+		TERRA_LANES(l, 16) {float *p = self().cell(xi-1 + (l & 3), zi-1 + (l >> 2)); boxp[TERRA_LANE_SLOT(l)] = p; boxv[TERRA_LANE_SLOT(l)] = *p;}
+	}
+	// the four corners at the step's cell + (ox, oz), ox, oz in -1 .. 1, out of its box
+	TERRA_HD void box_corners(int ox, int oz, float out[4]) const {
+		int const l = (oz + 1)*4 + (ox + 1);
+		out[0] = TERRA_READLANE(boxv, l); out[1] = TERRA_READLANE(boxv, l + 1); out[2] = TERRA_READLANE(boxv, l + 4); out[3] = TERRA_READLANE(boxv, l + 5);
+	}
 	TERRA_HD void deposit_cells_hot(int xi, int zi, float xf, float zf, float dse) {
-		TERRA_LANES(q, 4) {
-			int const X = xi + (q & 1), Z = zi + (q >> 1);
-			*self().cell(X, Z) += dse*deposit_weight(q, xf, zf); self().mark(X, Z);
+		TERRA_LANES(l, 16) { // the four cells (xi + (q & 1), zi + (q >> 1)) are lanes 5, 6, 9, 10 of the box
+			int const bx = l & 3, bz = l >> 2;
+			if (bx == 0 || bx == 3 || bz == 0 || bz == 3) continue;
+			int const q = (bx - 1) | ((bz - 1) << 1);
+			float const nv = boxv[TERRA_LANE_SLOT(l)] + dse*deposit_weight(q, xf, zf);
+			boxv[TERRA_LANE_SLOT(l)] = nv; *boxp[TERRA_LANE_SLOT(l)] = nv; self().mark(xi + (q & 1), zi + (q >> 1));
 		}
-		TERRA_WAVE_SYNC();
+		TERRA_WAVE_FENCE();
 	}
 	TERRA_HD void erode_cells_hot(int xi, int zi, float xp, float zp, float dse) {
 		TERRA_LANES(l, 16) {
 			int const x = xi-1 + (l & 3), z = zi-1 + (l >> 2);
 			float const wb = brush_weight(x, z, xp, zp);
-			if (wb > 0) {*self().cell(x, z) -= dse*wb; self().mark(x, z);}
+			if (wb > 0) {float const nv = boxv[TERRA_LANE_SLOT(l)] - dse*wb; boxv[TERRA_LANE_SLOT(l)] = nv; *boxp[TERRA_LANE_SLOT(l)] = nv; self().mark(x, z);}
 		}
-		TERRA_WAVE_SYNC();
+		TERRA_WAVE_FENCE();
 	}
 	TERRA_HD void erode_cells(int xi, int zi, float xp, float zp, float dse, int NX, int NY) {
 		if (TERRA_LIKELY(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) { // interior: 16 distinct cells, one lane each
@@ -458,13 +516,12 @@ struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
 	TERRA_HD void deposit(int xi, int zi, float xf, float zf, float dse) {deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
 	TERRA_HD void erode(int xi, int zi, float xp, float zp, float dse) {erode_cells(xi, zi, xp, zp, dse, NX, NY);}
 	TERRA_HD void set_travel(float, float) {}
-	TERRA_HD bool hot_ready(int xi, int zi) const {return xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1;}
-	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
-		if (!(x >= 0 && z >= 0 && x+1 <= NX-1 && z+1 <= NY-1)) return false;
-		float const *p = cell(x, z);
-		out[0] = p[0]; out[1] = p[1]; out[2] = p[NX]; out[3] = p[NX+1];
+	TERRA_HD bool hot_ready(int xi, int zi) {
+		if (!(((unsigned)(xi-1) <= (unsigned)(NX-4)) & ((unsigned)(zi-1) <= (unsigned)(NY-4)))) return false; // xi-1 >= 0 && xi+2 <= NX-1, the same in z
+		box_load(xi, zi);
 		return true;
 	}
+	TERRA_HD void corners_hot(int ox, int oz, float out[4]) const {box_corners(ox, oz, out);}
 	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {deposit_cells_hot(xi, zi, xf, zf, dse);}
 	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {erode_cells_hot(xi, zi, xp, zp, dse);}
 };
@@ -616,14 +673,11 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		if (!(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) return false;
 		if (!back.begin_step(xi, zi)) return false; // idempotent: the general step may record the same blocks again
 		wx0 = wave_uniform(wx0); wz0 = wave_uniform(wz0); steps_in_window = wave_uniform(steps_in_window) + 1;
-		return have && xi-1 >= wx0 && xi+2 < wx0 + EW && zi-1 >= wz0 && zi+2 < wz0 + EW;
-	}
-	TERRA_HD bool corners_hot(int x, int z, float out[4]) const {
-		if (!(x >= 0 && z >= 0 && x+1 <= NX-1 && z+1 <= NY-1 && x >= wx0 && x+1 < wx0 + EW && z >= wz0 && z+1 < wz0 + EW)) return false;
-		float const *p = cell(x, z);
-		out[0] = wave_uniform(p[0]); out[1] = wave_uniform(p[1]); out[2] = wave_uniform(p[EW]); out[3] = wave_uniform(p[EW+1]);
+		if (!(have & ((unsigned)(xi-1 - wx0) <= (unsigned)(EW-4)) & ((unsigned)(zi-1 - wz0) <= (unsigned)(EW-4)))) return false; // xi-1 >= wx0 && xi+2 < wx0 + EW, the same in z
+		this->box_load(xi, zi);
 		return true;
 	}
+	TERRA_HD void corners_hot(int ox, int oz, float out[4]) const {this->box_corners(ox, oz, out);} // (inside the step's box, which lies inside the window)
 	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells_hot(xi, zi, xf, zf, dse);}
 	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {back.note_write(); this->erode_cells_hot(xi, zi, xp, zp, dse);}
 	TERRA_HD void finish() {flush();}

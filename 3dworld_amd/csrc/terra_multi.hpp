@@ -5,9 +5,10 @@
 // thread for the duration of a call.  Work is dealt out in contiguous blocks of independent units -- tiles (tile_t::create_zvals needs nothing from a
 // neighbour, src/tiled_mesh.cpp:515), rows of one heightmap (src/heightmap.cpp:139-143), y slabs of a voxel field -- so nothing in those paths is collective.
 // The one exchange of the tile path is the mesh-shadow pass (tile_t::calc_shadows_for_light, src/tiled_mesh.cpp:664-692): tile columns are cut into strips,
-// a strip walks its tile rows toward the light's far side and, after every row, hands the outgoing edge of its border tile to the next strip with a
-// device-to-device copy (hipMemcpyPeerAsync: one xGMI hop), which then runs the same row -- a software pipeline over (strips + rows) steps instead of
-// strips x rows.
+// a strip walks its tile rows toward the light's far side in chunks of about as many rows as it has columns and, after every chunk, hands the outgoing edges
+// of its border tiles to the next strip with device-to-device copies (hipMemcpyPeerAsync: one xGMI hop), which then runs the same chunk -- a software pipeline
+// over (strips + chunks) steps.  The pass is a wavefront over the terrain (127 dependency levels for 64 x 64 tiles, at most 64 tiles per level): it spreads the
+// DATA over the GPUs, it cannot run faster than on one.
 // Included by terra_api_impl.hpp (so both libterra_hip.so and the test-only host emulation build it).
 #pragma once
 #include <thread>
@@ -46,11 +47,9 @@ inline void multi_block(uint32_t n_units, uint32_t n_parts, uint32_t part, uint3
 // ---- mesh shadows of one terrain over several contexts: strips of tile columns, rows pipelined, border edges device to device
 struct shadow_strip_t {
 	std::vector<uint32_t> tiles;                 // indices into the caller's tile list, sorted by row (in processing order) then column
-	std::vector<std::pair<uint32_t, uint32_t>> rows; // [first, count) into `tiles` per processed row
-	std::vector<int32_t> row_y;                  // tile y of each processed row
 	float *d_z = nullptr, *d_ein = nullptr, *d_eout = nullptr; uint8_t *d_sm = nullptr;
-	// row hand-over to the next strip
-	std::mutex mtx; std::condition_variable cv; int rows_done = 0; bool failed = false;
+	// chunk hand-over to the next strip
+	std::mutex mtx; std::condition_variable cv; int rows_done = 0 /* chunks finished */; bool failed = false;
 };
 
 inline int multi_tiles_mesh_shadows(terra_multi *m, int32_t const *tile_xy, uint32_t n, float const *h_zvals, float const lpos[3], uint8_t *h_smask) {
@@ -75,18 +74,18 @@ inline int multi_tiles_mesh_shadows(terra_multi *m, int32_t const *tile_xy, uint
 			if (ya != yb) return ya > yb;
 			return (int64_t)sx*tile_xy[2*a] > (int64_t)sx*tile_xy[2*b];
 		});
-		for (uint32_t k = 0; k < st.tiles.size(); ++k) {
-			pos[st.tiles[k]] = k;
-			int32_t const y = tile_xy[2*st.tiles[k]+1];
-			if (st.rows.empty() || st.row_y.back() != y) {st.rows.push_back(std::make_pair(k, 1u)); st.row_y.push_back(y);}
-			else {++st.rows.back().second;}
-		}
+		for (uint32_t k = 0; k < st.tiles.size(); ++k) {pos[st.tiles[k]] = k;}
 	}
-	// every strip processes ALL rows of the terrain in the same order (rows it has no tile in are empty steps), so "row r of the previous strip is done" is one counter
+	// every strip walks the rows of the terrain in the same order, in CHUNKS of `chunk` consecutive rows (about as many rows as a strip has columns: a call then covers a
+	// square block of tiles, whose anti-diagonal dependency levels keep cols + chunk - 1 launches busy; one row per call would serialise a strip into rows x cols levels).
+	// "chunk c of the previous strip is done" is one counter; chunks a strip has no tile in are empty steps
 	std::vector<int32_t> all_rows;
 	for (uint32_t i = 0; i < n; ++i) {all_rows.push_back(tile_xy[2*i+1]);}
 	std::sort(all_rows.begin(), all_rows.end(), [&](int32_t a, int32_t b) {return (int64_t)sy*a > (int64_t)sy*b;});
 	all_rows.erase(std::unique(all_rows.begin(), all_rows.end()), all_rows.end());
+	size_t const chunk = (size_t)std::max<int64_t>(1, per), nchunks = (all_rows.size() + chunk - 1)/chunk;
+	std::map<int32_t, size_t> chunk_of_row;
+	for (size_t r = 0; r < all_rows.size(); ++r) {chunk_of_row[all_rows[r]] = r/chunk;}
 
 	int const rc = multi_run(m, [&](uint32_t s) {
 		shadow_strip_t &st = strips[s];
@@ -104,57 +103,50 @@ inline int multi_tiles_mesh_shadows(terra_multi *m, int32_t const *tile_xy, uint
 			st.d_ein = (float *)be.alloc((size_t)nt*2*zv*4); st.d_eout = (float *)be.alloc((size_t)nt*2*zv*4);
 			be.h2d(st.d_z, hz.data(), hz.size()*4);
 		}
-		{
-			size_t my_row = 0;
-			for (size_t r = 0; r < all_rows.size(); ++r) {
-				bool const have = my_row < st.rows.size() && st.row_y[my_row] == all_rows[r];
-				if (have) {
-					uint32_t const first = st.rows[my_row].first, cnt = st.rows[my_row].second;
-					std::vector<int32_t> txy(2*(size_t)cnt);
-					bool need_prev = false;
-					for (uint32_t k = 0; k < cnt; ++k) {
-						uint32_t const ti = st.tiles[first + k];
-						txy[2*k] = tile_xy[2*ti]; txy[2*k+1] = tile_xy[2*ti+1];
-						// sh_in_x: from the tile one row toward the light in the same column -- always in this strip, processed in an earlier row
-						auto up = index.find(std::make_pair(tile_xy[2*ti], tile_xy[2*ti+1] + sy));
-						if (up != index.end()) {
-							be.d2d(st.d_ein + ((size_t)(first + k)*2 + 0)*zv, st.d_eout + ((size_t)pos[up->second]*2 + 0)*zv, (size_t)zv*4);
-							present[(size_t)(first + k)*2 + 0] = 1;
-						}
-						// sh_in_y: from the tile one column toward the light; when that tile belongs to the previous strip its edge comes from that strip's device
-						auto side = index.find(std::make_pair(tile_xy[2*ti] + sx, tile_xy[2*ti+1]));
-						if (side != index.end() && owner[side->second] != s) {need_prev = true;}
+		uint32_t next = 0; // first tile of the strip (in its processing order) that has not been handed to the engine yet
+		for (size_t c = 0; c < nchunks; ++c) {
+			uint32_t const first = next;
+			while (next < nt && chunk_of_row[tile_xy[2*st.tiles[next]+1]] == c) {++next;}
+			uint32_t const cnt = next - first;
+			if (cnt) {
+				std::vector<int32_t> txy(2*(size_t)cnt);
+				bool waited = false;
+				for (uint32_t k = 0; k < cnt; ++k) {
+					uint32_t const ti = st.tiles[first + k];
+					txy[2*k] = tile_xy[2*ti]; txy[2*k+1] = tile_xy[2*ti+1];
+					// sh_in_x: from the tile one row toward the light in the same column -- always in this strip; when it lies in an EARLIER chunk its outgoing edge is
+					// copied in (inside the chunk the engine hands the edges on itself)
+					auto up = index.find(std::make_pair(tile_xy[2*ti], tile_xy[2*ti+1] + sy));
+					if (up != index.end() && pos[up->second] < first) {
+						be.d2d(st.d_ein + ((size_t)(first + k)*2 + 0)*zv, st.d_eout + ((size_t)pos[up->second]*2 + 0)*zv, (size_t)zv*4);
+						present[(size_t)(first + k)*2 + 0] = 1;
 					}
-					if (need_prev) {
-						for (uint32_t k = 0; k < cnt; ++k) {
-							uint32_t const ti = st.tiles[first + k];
-							auto side = index.find(std::make_pair(tile_xy[2*ti] + sx, tile_xy[2*ti+1]));
-							if (side == index.end() || owner[side->second] == s) continue;
-							shadow_strip_t &src = strips[owner[side->second]];
-							{ // the owner has finished this row (its kernels and its stream are drained before it counts the row)
-								std::unique_lock<std::mutex> l(src.mtx);
-								src.cv.wait(l, [&] {return src.rows_done > (int)r;});
-								if (src.failed) throw std::runtime_error("terra_multi_tiles_mesh_shadows: a neighbouring strip failed");
-							}
-							be.copy_from_peer(st.d_ein + ((size_t)(first + k)*2 + 1)*zv, m->ctxs[owner[side->second]]->eng.be, src.d_eout + ((size_t)pos[side->second]*2 + 1)*zv, (size_t)zv*4);
-							present[(size_t)(first + k)*2 + 1] = 1;
-						}
+					// sh_in_y: from the tile one column toward the light; when that tile belongs to the previous strip its edge comes from that strip's device
+					auto side = index.find(std::make_pair(tile_xy[2*ti] + sx, tile_xy[2*ti+1]));
+					if (side == index.end() || owner[side->second] == s) continue;
+					shadow_strip_t &src = strips[owner[side->second]];
+					if (!waited) { // the owner has finished this chunk (its kernels are drained before it counts the chunk)
+						std::unique_lock<std::mutex> l(src.mtx);
+						src.cv.wait(l, [&] {return src.rows_done > (int)c;});
+						if (src.failed) throw std::runtime_error("terra_multi_tiles_mesh_shadows: a neighbouring strip failed");
+						waited = true;
 					}
-					eng.tiles_mesh_shadows_dev(txy.data(), cnt, st.d_z + (size_t)first*zv*zv, lpos, st.d_sm + (size_t)first*zv*zv, nullptr, present.data() + (size_t)first*2, nullptr,
-						st.d_ein + (size_t)first*2*zv, st.d_eout + (size_t)first*2*zv);
-					be.sync(); // the row's outgoing edges are in memory before the next strip is told
-					++my_row;
+					be.copy_from_peer(st.d_ein + ((size_t)(first + k)*2 + 1)*zv, m->ctxs[owner[side->second]]->eng.be, src.d_eout + ((size_t)pos[side->second]*2 + 1)*zv, (size_t)zv*4);
+					present[(size_t)(first + k)*2 + 1] = 1;
 				}
-				{std::lock_guard<std::mutex> l(st.mtx); st.rows_done = (int)r + 1;}
-				st.cv.notify_all();
+				eng.tiles_mesh_shadows_dev(txy.data(), cnt, st.d_z + (size_t)first*zv*zv, lpos, st.d_sm + (size_t)first*zv*zv, nullptr, present.data() + (size_t)first*2, nullptr,
+					st.d_ein + (size_t)first*2*zv, st.d_eout + (size_t)first*2*zv);
+				be.sync(); // the chunk's outgoing edges are in memory before the next strip is told
 			}
-			if (nt) {
-				std::vector<uint8_t> sm((size_t)nt*zv*zv);
-				be.d2h(sm.data(), st.d_sm, sm.size());
-				for (uint32_t k = 0; k < nt; ++k) {memcpy(h_smask + (size_t)st.tiles[k]*zv*zv, sm.data() + (size_t)k*zv*zv, (size_t)zv*zv);}
-			}
-			guard.ok = true;
+			{std::lock_guard<std::mutex> l(st.mtx); st.rows_done = (int)c + 1;}
+			st.cv.notify_all();
 		}
+		if (nt) {
+			std::vector<uint8_t> sm((size_t)nt*zv*zv);
+			be.d2h(sm.data(), st.d_sm, sm.size());
+			for (uint32_t k = 0; k < nt; ++k) {memcpy(h_smask + (size_t)st.tiles[k]*zv*zv, sm.data() + (size_t)k*zv*zv, (size_t)zv*zv);}
+		}
+		guard.ok = true;
 	});
 	// the edge buffers are read by the neighbouring strip's peer copies: freed only when every thread is done
 	for (uint32_t s = 0; s < S; ++s) {

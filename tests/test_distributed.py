@@ -273,7 +273,6 @@ def test_rccl_one_rank_group_runs_the_device_collectives(orc, tmp_path):
     orclib.assert_bit_equal(ref, np.load(tmp_path / "z.npy"), "strip through the RCCL group")
     mm = np.load(tmp_path / "mm.npy")
     assert np.float32(mm[0]) == ref.min() and np.float32(mm[1]) == ref.max() and (mm[2], mm[3]) == (0, ny)
-    orc.init(orclib.make_config(mesh_gen_mode=0))
-    tiles = [(tx, ty) for ty in range(0, 2) for tx in range(0, 3)]
+    tiles = [(tx, ty) for ty in range(0, 2) for tx in range(0, 3)]  # (the worker's scene: mesh_freq_filter = 1, as the oracle still has it)
     z = np.stack([orc.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tiles])
     assert (orc.tiles_mesh_shadows(tiles, z, (0.7, 0.4, 0.3)) == np.load(tmp_path / "sm.npy")).all()

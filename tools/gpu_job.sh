@@ -7,6 +7,7 @@
 #   gpu_job.sh pmc     <tag> <driver.py args> -- <kernel substr ...>   FETCH_SIZE, WRITE_SIZE and the SQ set, one --pmc pass each, over tools/<driver>
 #   gpu_job.sh erosion <tag> "<grid> <droplets> <W:slice[,W:slice..]>" ...   dense-erosion timings (tools/ero_sweep.py); TERRA_ERO_* knobs pass through the environment
 #   gpu_job.sh multirank <tag>                       2 ranks on one GPU over gloo: bench.py self-launch + the sharded workloads
+#   gpu_job.sh stepcost <tag>                        ns per droplet step on one wave (tools/step_cost.hip) + the 64x64x1000 tile batch
 #   gpu_job.sh native  <tag> [args]                  tools/bench_native.c and tools/bench_native_multi.c (--same-device) built and run
 set -u
 CMD=${1:-check}; TAG=${2:-job}; shift; shift || true
@@ -88,6 +89,11 @@ native)
 	gcc -O2 -std=c99 -Iinclude tools/bench_native_multi.c -L3dworld_amd -lterra_hip -lpthread -Wl,-rpath,"$ROOT/3dworld_amd" -o tools/_bin/bench_native_multi || exit 1
 	if [ $# -eq 0 ]; then set -- 2 16 16384 --same-device; fi
 	timeout 600 tools/_bin/bench_native_multi "$@" | tee "$OUT/bench_native_multi.jsonl"
+	;;
+stepcost)
+	mkdir -p tools/_bin
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I3dworld_amd/csrc tools/step_cost.hip -o tools/_bin/step_cost 2> "$OUT/step_cost_build.log" && tools/_bin/step_cost | tee "$OUT/step_cost.txt"
+	timeout 300 python tools/prof_tile_erosion.py 1000 3 | tee "$OUT/tile_erosion.txt"
 	;;
 *) echo "unknown command $CMD"; exit 2 ;;
 esac

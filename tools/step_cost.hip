@@ -46,6 +46,7 @@ int main() {
 	erosion_consts_t ec{};
 	ec.xsize = N - 8; ec.ysize = N - 8; ec.NX = N; ec.NY = N; ec.max_path_len = 4u*N*N; ec.erode_amount = 1.0f; ec.water_thresh = -100.0f;
 	ec.relh_adj_tex = 0; ec.zmin = 0; ec.zrange = 10; ec.clip_hd1 = 0.5f; ec.two_pi = 6.2831855f; ec.min_zval = -100;
+	make_rock_threshold(ec);
 	hipFuncSetAttribute((void const *)k_steps<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024);
 	for (int variant = 0; variant < 2; ++variant) for (int rep = 0; rep < 3; ++rep) {
 		hipMemcpy(dg, h.data(), h.size()*4, hipMemcpyHostToDevice);
