@@ -516,6 +516,8 @@ int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n,
 	TERRA_CATCH
 }
 
+uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx) {return ctx ? ctx->eng.be.tile2_gave_up : 0;}
+
 // ---- voxels
 int terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo[3], const float vsz[3], const float off[3],
 	float mag, float freq, int rs1, int rs2, int gen_mode, float zscale, int normalize)

@@ -442,13 +442,14 @@ inline uint32_t wave_reserve(uint32_t *ctr, uint32_t n) {uint32_t const o = *ctr
 // lane-parallel deposit / brush on a cell store addressed through DERIVED::cell(X,Z) (an LDS pointer), + DERIVED::mark(X,Z)
 template<class DERIVED> struct wave_cell_ops {
 	TERRA_HD DERIVED &self() {return *static_cast<DERIVED *>(this);}
+	TERRA_HD void wsync() {TERRA_WAVE_SYNC();} // the wave's visibility point after a cooperative write (a policy whose workgroup holds more than one wave overrides it)
 	TERRA_HD void deposit_cells(int xi, int zi, float xf, float zf, float dse, int NX, int NY) {
 		TERRA_LANES(q, 4) { // the four cells are distinct: no write conflicts between lanes
 			int const X = xi + (q & 1), Z = zi + (q >> 1);
 			float const delta = dse*deposit_weight(q, xf, zf);
 			if (!(X < 0 || Z < 0 || X >= NX || Z >= NY)) {*self().cell(X, Z) += delta; self().mark(X, Z);}
 		}
-		TERRA_WAVE_SYNC();
+		self().wsync();
 	}
 	// ---- hot step: the brush box is interior and resident.  Lane l < 16 keeps cell (xi-1 + (l & 3), zi-1 + (l >> 2)) of the step's 4x4 box in a register from the
 	// top of the step on (box_load: one load per lane, in flight while the step's arithmetic runs); every read and write of the step lies inside that box
@@ -499,7 +500,7 @@ template<class DERIVED> struct wave_cell_ops {
 				}
 			}
 		}
-		TERRA_WAVE_SYNC();
+		self().wsync();
 	}
 };
 

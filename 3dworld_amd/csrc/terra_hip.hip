@@ -14,6 +14,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool simple_kernels = false; // TERRA_SIMPLE_KERNELS=1: run the one-thread-per-cell cross-check kernels instead of the LDS-tiled ones
 	float *tile_pad = nullptr; size_t tile_pad_bytes = 0;
+	void *tile_undo = nullptr; size_t tile_undo_bytes = 0; // k_tile_erosion2: undo logs of the speculative droplets + the list of tiles that gave up
+	bool tile_two_waves = false; // TERRA_TILE_WAVES=2: two waves per tile (k_tile_erosion2: exact, measured SLOWER than one wave per tile -- see DESIGN.md section 4 -- and therefore opt-in)
+	unsigned long long *t2_dbg = nullptr; // TERRA_T2_DIAG=1: eight counters of the two-wave tile kernel, printed to stderr after every batch
+	uint32_t t2_mode = 0; // TERRA_T2_MODE (test knob): 1 no speculation, 2 a speculative droplet waits instead of aborting itself when it meets the older one, 4 the primary makes the other abort at every step
+	uint32_t t2_undo_cap = terra::T2_UNDO_RECORDS; // TERRA_T2_UNDO: smaller logs (test knob: droplets then fall back to waiting for their turn more often)
 	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
 	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as one chained launch (k_tile_shadows_chain) instead of one launch per dependency level; measured slightly slower (11.0 vs 10.0 ms with the first per-level kernel for 64x64 tiles: a sweep is ~40-50 us of dependent steps either way), kept as an option
@@ -33,6 +38,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion2, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+		if (char const *tw = getenv("TERRA_TILE_WAVES")) {tile_two_waves = (tw[0] == '2');}
+		if (char const *tm = getenv("TERRA_T2_MODE")) {t2_mode = (uint32_t)atoi(tm);}
+		if (char const *td = getenv("TERRA_T2_DIAG")) {if (td[0] == '1') {TERRA_HIP_CHECK(hipMalloc((void **)&t2_dbg, 64));}}
+		if (char const *tu = getenv("TERRA_T2_UNDO")) {int const v = atoi(tu); if (v >= 2 && v <= (int)terra::T2_UNDO_RECORDS) t2_undo_cap = (uint32_t)v;}
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
@@ -40,6 +50,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	~hip_backend_t() {
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_order) (void)hipFree(tile_order);
+		if (tile_undo) (void)hipFree(tile_undo);
 		if (tile_acc) (void)hipFree(tile_acc);
 		if (tile_map) (void)hipFree(tile_map);
 		if (vox_p) (void)hipFree(vox_p);
@@ -267,9 +278,26 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			h2d(d_ord, ord.data(), (size_t)n*4);
 			d_order = d_ord; d_landc = d_land;
 		}
+		size_t const lds2 = lds + (size_t)2*ec.NY*terra::T2_ROW_DW*4 + sizeof(terra::tile2_ctl_t);
+		if (tile_two_waves && iters >= 2 && lds2 <= 80*1024) { // two droplets of every tile in flight (k_tile_erosion2); tiles whose block gave up are redone by the one-wave kernel
+			size_t const ub = (size_t)n*2*terra::T2_UNDO_RECORDS*16*sizeof(terra::tile2_undo_t), eb = ((size_t)n + 1)*4, bytes = ub + eb;
+			if (bytes > tile_undo_bytes) {if (tile_undo) {sync(); (void)hipFree(tile_undo);} TERRA_HIP_CHECK(hipMalloc(&tile_undo, bytes)); tile_undo_bytes = bytes;}
+			uint32_t *d_err = (uint32_t *)((uint8_t *)tile_undo + ub);
+			fill32(d_err, 0, 1);
+			if (t2_dbg) {fill32(t2_dbg, 0, 16);}
+			hipLaunchKernelGGL(terra::k_tile_erosion2, dim3(n), dim3(128), lds2, stream, zvals, ec, iters, d_order, d_landc, (terra::tile2_undo_t *)tile_undo, d_err, t2_undo_cap, t2_mode, t2_dbg);
+			TERRA_HIP_CHECK(hipGetLastError());
+			uint32_t nerr = 0;
+			d2h(&nerr, d_err, 4);
+			if (t2_dbg) {unsigned long long c[8]; d2h(c, t2_dbg, 64); fprintf(stderr, "[tile2] %u tiles x %u droplets: steps primary %llu speculative %llu | runs put back %llu (%llu records) | waits on overlap %llu | general steps %llu | droplets done again %llu | spins %llu\n", n, iters, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);}
+			tile2_gave_up += nerr;
+			if (nerr) {hipLaunchKernelGGL(terra::k_tile_erosion, dim3(nerr), dim3(64), lds, stream, zvals, ec, iters, d_err + 1, (uint32_t const *)nullptr); TERRA_HIP_CHECK(hipGetLastError());}
+			return;
+		}
 		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters, d_order, d_landc);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
+	uint64_t tile2_gave_up = 0; // tiles whose two-wave block timed out in a spin (never expected; counted so that a test can see it)
 	void minmax(float const *vals, size_t n, uint32_t *d) {
 		if (simple_kernels || ((uintptr_t)vals & 15)) {minmax_simple(vals, n, d); return;}
 		use();

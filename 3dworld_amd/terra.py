@@ -164,6 +164,7 @@ _PROTOS = {
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
     "terra_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "terra_get_tile_erosion_fallbacks": (C.c_uint64, [_vp]),
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_voxel_fill_slab_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32, _u32, _u32]),
     "terra_voxel_fill": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
@@ -331,6 +332,8 @@ class Terra:
                                                     C.addressof(st) if stats else None, nm.ctypes.data if normals else None,
                                                     mnz.ctypes.data if normals else None))
         return z, st, nm, mnz
+
+    def tile_erosion_fallbacks(self): return int(self.lib.terra_get_tile_erosion_fallbacks(self.ctx))
 
     def hmap_set_dev(self, ptr, width=0, height=0, ncolors=2, min_z=None, dz=None):
         """heightmap texture for the tile path (device pointer kept, not copied; None / 0 switches it off)"""

@@ -225,6 +225,9 @@ int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32
                                   float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_normal_z);
 int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
                               float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
+/* diagnostics: tiles (since the context was created) whose two-droplets-in-flight erosion block gave up on a spin time-out and were redone by the one-wave kernel
+ * (results are the same either way; expected to stay 0) */
+uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx);
 
 /* ---- heightmap files, host side: 8- / 16-bit grayscale PNG exactly as the reference reads / writes them through libpng (src/image_io.cpp:493-605):
  * write: rows in memory order, 16-bit pixels {fraction, integer} -> big-endian samples (heightmap_t::write_png, src/heightmap.cpp:375-378);

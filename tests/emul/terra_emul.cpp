@@ -14,6 +14,7 @@
 struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	std::chrono::steady_clock::time_point t0;
 	static int device_count() {return 1;}
+	uint64_t tile2_gave_up = 0; // (the two-wave tile kernel exists only on the device)
 	void init(int) {}
 	void set_stream(void *) {}
 	void sync() {}

@@ -352,3 +352,31 @@ def test_multi_contexts_in_one_process(pkg, orc, ndev, big):
     """terra_multi_* on the HIP library: several contexts on device 0 (the test box has one GPU; on a node every context gets its own), each driven by its own host
     thread; the shadow edges travel between the contexts' buffers with the device-to-device copy the multi-GPU path uses"""
     pc.case_multi_contexts(pkg, None, orc, ndev, big)
+
+
+def test_tile_erosion_two_waves_per_tile_equals_oracle(pkg, orc, monkeypatch):
+    """the opt-in tile kernel with two waves per tile (TERRA_TILE_WAVES=2: a primary droplet and a speculative run-ahead wave on one LDS tile, set-then-test footprint
+    protocol, undo log, in-order commit): every tile of a 16 x 16 batch with 400 droplets equals the oracle's serial loop, on repeated runs (the protocol's outcome
+    must not depend on the timing of the two waves), with small undo logs too (runs that stop speculating early), and no block gives up"""
+    tiles = [(tx, ty) for ty in range(-30, -14) for tx in range(-32, -16)]  # land tiles with converging valleys, among them (-27, -26): the tile whose droplets 267 / 268 cross
+    iters = 400
+    pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
+    orc.init(oc)
+    want = {}
+    for cap in ("", "6"):
+        monkeypatch.setenv("TERRA_TILE_WAVES", "2")
+        if cap:
+            monkeypatch.setenv("TERRA_T2_UNDO", cap)
+        t = pkg.Terra(0)
+        try:
+            t.init_scene(pc_)
+            for rep in range(4 if not cap else 1):
+                z, st, _, _ = t.tiles_create_zvals(tiles, iters)
+                for i in range(0, len(tiles), 3 if rep else 1):
+                    if i not in want:
+                        want[i] = orc.tile_create_zvals(tiles[i][0], tiles[i][1], iters)
+                    assert_bit_equal(z[i], want[i][0], f"tile {tiles[i]} run {rep} undo cap {cap or 'default'}")
+                    assert bytes(st[i]) == bytes(want[i][1])
+            assert t.tile_erosion_fallbacks() == 0
+        finally:
+            t.close()
