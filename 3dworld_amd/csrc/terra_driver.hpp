@@ -924,22 +924,26 @@ template<class BE> struct terra_engine {
 		// The batch is then ONE "virtual" (nux*tw) x (nuy*tw) sine grid whose cells are exactly the requested tiles' cells.
 		uint32_t const nxpv = round_up(nux*zv, 128), nypv = round_up(nuy*zv, 128);
 		size_t const tab_floats = (size_t)F_TABLE_SIZE*(nxpv + nypv), sm_floats = (size_t)(nux + nuy)*zv;
-		size_t const bytes = refs.size()*sizeof(tile_ref_t) + (nux + nuy)*sizeof(sine_k_t) + (tab_floats + sm_floats)*4 + 1024;
+		// one parameter block: tile references | origins of the distinct columns / rows | their per-k constants -- assembled on the host, ONE asynchronous upload
+		size_t const o_refs = 0, o_m0 = (refs.size()*sizeof(tile_ref_t) + 255) & ~(size_t)255, o_sk = o_m0 + (((size_t)(nux + nuy)*4 + 255) & ~(size_t)255);
+		size_t const par_bytes = o_sk + (((nux + nuy)*sizeof(sine_k_t) + 255) & ~(size_t)255);
+		size_t const bytes = par_bytes + (tab_floats + sm_floats)*4 + 1024;
 		uint8_t *base = scratch<uint8_t>(s_tiles, bytes);
-		tile_ref_t *d_refs = (tile_ref_t *)base;
-		sine_k_t *d_sk = (sine_k_t *)(base + ((refs.size()*sizeof(tile_ref_t) + 255) & ~(size_t)255));
-		float *d_tab = (float *)((uint8_t *)d_sk + (((nux + nuy)*sizeof(sine_k_t) + 255) & ~(size_t)255));
+		tile_ref_t *d_refs = (tile_ref_t *)(base + o_refs);
+		float *d_m0 = (float *)(base + o_m0);
+		sine_k_t *d_sk = (sine_k_t *)(base + o_sk);
+		float *d_tab = (float *)(base + par_bytes);
 		float *d_sm = d_tab + tab_floats;
-		be.h2d(d_refs, refs.data(), refs.size()*sizeof(tile_ref_t));
-		if (xy_scale == 0.0f) return d_refs;
+		std::vector<uint8_t> par((xy_scale == 0.0f) ? o_m0 : par_bytes, 0);
+		memcpy(par.data() + o_refs, refs.data(), refs.size()*sizeof(tile_ref_t));
+		if (xy_scale == 0.0f) {be.h2d_async(base, par.data(), par.size()); return d_refs;}
 		// per distinct tx / ty: build_arrays((x0 - MESH_X_SIZE/2), (y0 - MESH_Y_SIZE/2), DX_VAL, DY_VAL, tw, tw) with x0 = x1 - shift (src/tiled_mesh.cpp:458-464)
-		std::vector<sine_k_t> sks(nux + nuy);
-		std::vector<float> h_m0(nux + nuy);
-		for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)((ux[i]*(int)size - shift) - cfg.mesh_x/2); h_m0[i] = fdx*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, fdx, fdy);}
-		for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)((uy[i]*(int)size - shift) - cfg.mesh_y/2); h_m0[nux+i] = fdy*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], fdx, fdy);}
-		be.h2d(d_sk, sks.data(), sks.size()*sizeof(sine_k_t));
-		float *d_m0 = scratch<float>(s_misc, nux + nuy + 16);
-		be.h2d(d_m0, h_m0.data(), h_m0.size()*4);
+		{
+			float *h_m0 = (float *)(par.data() + o_m0); sine_k_t *sks = (sine_k_t *)(par.data() + o_sk);
+			for (uint32_t i = 0; i < nux; ++i) {float const x0 = (float)((ux[i]*(int)size - shift) - cfg.mesh_x/2); h_m0[i] = fdx*x0; sks[i] = make_sine_k(h_m0[i], 0.0f, fdx, fdy);}
+			for (uint32_t i = 0; i < nuy; ++i) {float const y0 = (float)((uy[i]*(int)size - shift) - cfg.mesh_y/2); h_m0[nux+i] = fdy*y0; sks[nux+i] = make_sine_k(0.0f, h_m0[nux+i], fdx, fdy);}
+		}
+		be.h2d_async(base, par.data(), par.size());
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
 		int const md = force_sine ? (int)MGEN_SINE : mode, shp = force_sine ? 0 : shape, kstart = imax(start_eval_sin, min_start_sin);
@@ -1107,8 +1111,8 @@ template<class BE> struct terra_engine {
 		uint32_t *d_order = (uint32_t *)base;
 		int32_t *d_adj = (int32_t *)(base + (((size_t)n*4 + 255) & ~(size_t)255));
 		unsigned long long *d_out = (unsigned long long *)((uint8_t *)d_adj + ((adj.size()*4 + 255) & ~(size_t)255)); // [2][n][zv]: (order << 32) | float bits, 0 = never written
-		be.h2d(d_order, order.data(), (size_t)n*4);
-		be.h2d(d_adj, adj.data(), adj.size()*4);
+		be.h2d_async(d_order, order.data(), (size_t)n*4);
+		be.h2d_async(d_adj, adj.data(), adj.size()*4);
 		be.fill32(d_out, 0, (size_t)2*nslots*zv*2);
 		for (size_t k = 0; k < virt_slot.size(); ++k) {
 			unsigned long long *dst = d_out + ((size_t)virt_slot[k].first*nslots + virt_slot[k].second)*zv;
@@ -1116,7 +1120,7 @@ template<class BE> struct terra_engine {
 				float const *src = d_edge_in + (size_t)virt_src[k]*zv;
 				be.launch(zv, [=] TERRA_LAMBDA (size_t e) {float const v = src[e]; uint32_t b; memcpy(&b, &v, 4); dst[e] = (v > -1.0E6f) ? ((1ull << 32) | b) : 0ull;}, 64);
 			}
-			else {be.h2d(dst, virt.data() + k*zv, (size_t)zv*8);}
+			else {be.h2d_async(dst, virt.data() + k*zv, (size_t)zv*8);}
 		}
 		uint32_t const npaths = 4*zv;
 		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*nslots*zv);

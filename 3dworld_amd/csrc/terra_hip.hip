@@ -21,7 +21,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	uint32_t t2_undo_cap = terra::T2_UNDO_RECORDS; // TERRA_T2_UNDO: smaller logs (test knob: droplets then fall back to waiting for their turn more often)
 	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
-	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as one chained launch (k_tile_shadows_chain) instead of one launch per dependency level; measured slightly slower (11.0 vs 10.0 ms with the first per-level kernel for 64x64 tiles: a sweep is ~40-50 us of dependent steps either way), kept as an option
+	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as ONE launch (k_tile_shadows_chain: the level kernel's LDS body, blocks wait for their neighbours' done flags after staging their tile) instead of one launch per dependency level.  Measured equal (5.4 vs 5.5 ms for 64x64 tiles: a level costs its ~260-step sweep chain, not its launch), so the per-level form, which also serves halo batches, stays the default
 	unsigned sg_rowgroup = 4; // TERRA_SG_ROWGROUP: tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
 	static int device_count() {int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n;}
@@ -45,9 +45,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (char const *tu = getenv("TERRA_T2_UNDO")) {int const v = atoi(tu); if (v >= 2 && v <= (int)terra::T2_UNDO_RECORDS) t2_undo_cap = (uint32_t)v;}
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
-		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 72*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 	}
 	~hip_backend_t() {
+		if (pin) (void)hipHostFree(pin);
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_order) (void)hipFree(tile_order);
 		if (tile_undo) (void)hipFree(tile_undo);
@@ -60,7 +61,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (own_stream) (void)hipStreamDestroy(own_stream);
 	}
 	void use() {TERRA_HIP_CHECK(hipSetDevice(device));}
-	void set_stream(void *s) {sync(); stream = s ? (hipStream_t)s : own_stream;} // cached graphs are stream-agnostic (the stream is given at launch)
+	void set_stream(void *s) {sync(); pin_off = 0; stream = s ? (hipStream_t)s : own_stream;} // cached graphs are stream-agnostic (the stream is given at launch)
 	void sync() {use(); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	void *alloc(size_t bytes) {use(); void *p = nullptr; TERRA_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1)); return p;}
 	void free(void *p) {use(); (void)hipFree(p);}
@@ -68,6 +69,20 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void fill32(void *p, uint32_t v, size_t count) {use(); if (count) TERRA_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)p, (int)v, count, stream));}
 	// host buffers are ordinary pageable memory (often stack variables): copies are stream-ordered and then waited for
 	void h2d(void *d, void const *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
+	// small parameter blocks (tile references, per-column constants, dependency orders): staged through a pinned ring and copied asynchronously, stream-ordered -- the
+	// host does not wait (a pageable hipMemcpyAsync + hipStreamSynchronize per upload was ~10 % of a 0.68 ms tile batch).  The ring drains the stream when it wraps.
+	uint8_t *pin = nullptr; size_t pin_bytes = 0, pin_off = 0;
+	void h2d_async(void *d, void const *h, size_t bytes) {
+		if (bytes == 0) return;
+		use();
+		if (!pin) {pin_bytes = (size_t)8 << 20; if (hipHostMalloc((void **)&pin, pin_bytes, hipHostMallocDefault) != hipSuccess) {pin = nullptr; pin_bytes = 0; (void)hipGetLastError();}}
+		size_t const need = (bytes + 255) & ~(size_t)255;
+		if (!pin || need > pin_bytes/2) {h2d(d, h, bytes); return;}
+		if (pin_off + need > pin_bytes) {TERRA_HIP_CHECK(hipStreamSynchronize(stream)); pin_off = 0;}
+		memcpy(pin + pin_off, h, bytes);
+		TERRA_HIP_CHECK(hipMemcpyAsync(d, pin + pin_off, bytes, hipMemcpyHostToDevice, stream));
+		pin_off += need;
+	}
 	void d2h(void *h, void const *d, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	// device-to-device copies on this context's stream: inside the device, and from another context's device (several GPUs in one process, terra_multi.hpp)
 	void d2d(void *dst, void const *src, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));}
@@ -214,10 +229,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	// whole batch in one launch (tiles in dependency order); false => not done (simple kernels requested), the caller goes level by level
 	bool tile_shadows_chain(terra::shadow_consts_t const &c, uint32_t n, uint32_t const *ord, int32_t const *adj, float const *z, unsigned long long *out, uint8_t *sm, uint32_t *flags, uint32_t np) {
-		if (simple_kernels || !shadow_chain) return false;
+		if (simple_kernels || !shadow_chain || ((uintptr_t)sm & 3)) return false;
 		use();
 		fill32(flags, 0, (size_t)n + 1); // done[n], err
-		hipLaunchKernelGGL(terra::k_tile_shadows_chain, dim3(n), dim3(terra::SH_CHAIN_THREADS), 130*130*sizeof(float), stream, c, n, ord, adj, z, out, sm, flags, flags + n, np);
+		hipLaunchKernelGGL(terra::k_tile_shadows_chain, dim3(n), dim3(terra::SH_CHAIN_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, flags, flags + n, np);
 		TERRA_HIP_CHECK(hipGetLastError());
 		uint32_t err = 0;
 		d2h(&err, flags + n, 4);

@@ -875,33 +875,6 @@ struct shadow_chain_out_t {
 	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], pack(order, v));}
 };
 constexpr unsigned SH_CHAIN_THREADS = 576; // 9 waves: all 520 sweeps of a tile in one round
-__global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_chain(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj, float const *__restrict__ zvals,
-	unsigned long long *out, uint8_t *smask, uint32_t *done, uint32_t *err, uint32_t npaths)
-{
-	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
-	unsigned const zv = 130, tid = threadIdx.x;
-	uint32_t const t = order[blockIdx.x];
-	int32_t const ax = adj[2*t], ay = adj[2*t + 1];
-	float const *z = zvals + (size_t)t*zv*zv;
-	for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}
-	if (tid == 0) {
-		int32_t const deps[2] = {ax, ay};
-		for (int k = 0; k < 2; ++k) {
-			if (deps[k] < 0) continue;
-			uint32_t spins = 0;
-			while (__hip_atomic_load(&done[deps[k]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-				if (++spins > (1u << 24)) {atomicExch(err, 1u); break;}
-				__builtin_amdgcn_s_sleep(32);
-			}
-		}
-	}
-	__syncthreads();
-	shadow_chain_in_t const in{(ay >= 0) ? out + ((size_t)0*n + ay)*zv : nullptr, (ax >= 0) ? out + ((size_t)1*n + ax)*zv : nullptr};
-	shadow_chain_out_t o{smask + (size_t)t*zv*zv, out + ((size_t)0*n + t)*zv, out + ((size_t)1*n + t)*zv, (int)zv};
-	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
-	__syncthreads();
-	if (tid == 0) {__hip_atomic_store(&done[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);}
-}
 
 // One dependency level of the tile mesh shadows: one block per tile of the level, one thread per sweep.  A sweep is a chain of ~260 dependent steps, so
 // what a step costs is latency: everything it reads AND writes lives in LDS -- the tile's heights, the two incoming edge arrays (decoded), the tile's
@@ -950,6 +923,59 @@ __global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_
 		unsigned long long const v = s_out[tid];
 		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
 	}
+}
+
+// The whole batch in ONE launch: the same block body, the tiles in dependency order (blockIdx = position in `order`, which is sorted by level, so a tile's two
+// neighbours toward the light were dispatched before it and are running or done: waiting for them cannot dead-lock).  A block stages its tile's heights and clears
+// its LDS arrays FIRST, then one thread waits for the neighbours' done flags (agent-scope acquire, s_sleep back-off), then the incoming edges are read (from L2:
+// they were written on another CU), the sweeps run, the results go out and the flag is released.  Against one launch per level this takes the launch gap and
+// the tile staging out of the serial chain of 127 levels: what is left per level is the ~260-step sweep chain and one flag round trip.
+__global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_chain(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj, float const *__restrict__ zvals,
+	unsigned long long *out, uint8_t *smask, uint32_t *done, uint32_t *err, uint32_t npaths)
+{
+	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
+	unsigned const zv = 130, tid = threadIdx.x;
+	uint32_t const t = order[blockIdx.x];
+	int32_t const ax = adj[2*t], ay = adj[2*t + 1];
+	float const *z = zvals + (size_t)t*zv*zv;
+	float *s_in = s_sh_mh + zv*zv;
+	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv);
+	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
+	if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}}
+	else {for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}}
+	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {s_mask[i] = 0u;}
+	if (tid == 0) { // (the neighbours are real tiles of this batch: indices below n; virtual halo slots are not used with this kernel)
+		int32_t const deps[2] = {ax, ay};
+		for (int k = 0; k < 2; ++k) {
+			if (deps[k] < 0) continue;
+			uint32_t spins = 0;
+			while (__hip_atomic_load(&done[deps[k]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+				if (++spins > (1u << 22)) {atomicExch(err, 1u); break;}
+				__builtin_amdgcn_s_sleep(4);
+			}
+		}
+	}
+	__syncthreads();
+	if (tid < 2*zv) {
+		bool const isx = tid < zv; unsigned const i = isx ? tid : tid - zv; int32_t const a = isx ? ay : ax;
+		unsigned long long v = 0ull;
+		if (a >= 0) {v = __hip_atomic_load(&out[((size_t)(isx ? 0 : 1)*n + a)*zv + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);} // written on another CU: read at L2
+		s_in[tid] = (a >= 0) ? shadow_chain_in_t::decode(v) : -1.0E6f;
+		s_out[tid] = 0ull;
+	}
+	__syncthreads();
+	shadow_lds_in_t const in{s_in, s_in + zv};
+	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
+	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+	__syncthreads();
+	if (tid < 2*zv) { // the outgoing edges first: they are what the next tiles wait for
+		unsigned long long const v = s_out[tid];
+		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
+	}
+	__syncthreads();
+	if (tid == 0) {__hip_atomic_store(&done[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);}
+	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv);
+	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {gm[i] = s_mask[i] | c.mask_fill;}
 }
 
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell

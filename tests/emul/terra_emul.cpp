@@ -22,6 +22,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void free(void *p) {::free(p);}
 	void fill32(void *p, uint32_t v, size_t count) {uint32_t *q = (uint32_t *)p; for (size_t i = 0; i < count; ++i) q[i] = v;}
 	void h2d(void *d, void const *h, size_t bytes) {memcpy(d, h, bytes);}
+	void h2d_async(void *d, void const *h, size_t bytes) {memcpy(d, h, bytes);}
 	void d2h(void *h, void const *d, size_t bytes) {memcpy(h, d, bytes);}
 	void d2d(void *dst, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void copy_from_peer(void *dst, cpu_backend_t &, void const *src, size_t bytes) {memcpy(dst, src, bytes);}

@@ -36,6 +36,27 @@ for D in (1000, 100000, 1000000):
     r = t.erosion_report().as_dict()
     out[f"C3_erosion_4096_{D}_droplets"] = {"ms": round(dt * 1e3, 2), "droplets_per_s": round(D / dt), "steps_per_s": round(r["steps"] / dt), "rounds": r["rounds"], "windows": r["windows"], "traces": r["traces"], "fallbacks": r["serial_fallbacks"]}
 z.free()
+# C3, literally: the heightmap_island_eroded preset -- heights loaded from heightmaps/heightmap_island_1k.png (`mh_filename ... 180.3 -18.75`, scene_config/
+# config_heightmap.txt:84) through heightmap_t::postprocess_height (pixels -> floats -> whole-image erosion -> pixels), 10^5 and 10^6 droplets (config_heightmap.txt:78)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import parity_cases as pc_
+png = os.path.join(ROOT, "tests", "golden", "heightmap_island_1k.png")
+if os.path.exists(png):
+    pix = pkg.terra.read_png(png, lib=t.lib)
+    hh, ww = pix.shape
+    pc_.island_setup(t, pc_.island_cfg(pkg.make_config))
+    dp = t.alloc(pix.nbytes); dv = t.alloc(ww * hh * 4)
+    dp.upload(pix); t.heightmap_to_floats_dev(dp.ptr, ww, hh, 1, dv.ptr)
+    mn_, mx_ = t.minmax_dev(dv.ptr, ww * hh)
+    pc_.island_setup(t, pc_.island_cfg(pkg.make_config), (mn_, mx_))
+    for D in (100000, 1000000):
+        for rep in range(2):
+            dp.upload(pix); t.synchronize(); t0 = time.perf_counter()
+            bad = t.heightmap_postprocess_dev(dp.ptr, ww, hh, 1, D, dv.ptr); t.synchronize()
+            dt = time.perf_counter() - t0
+        r = t.erosion_report().as_dict()
+        out[f"C3_island_1k_postprocess_height_{D}_droplets"] = {"ms": round(dt * 1e3, 2), "droplets_per_s": round(D / dt), "steps": r["steps"], "rounds": r["rounds"], "out_of_range_pixels": bad}
+    dp.free(); dv.free()
 # C4: 64x64 tiles of 128^2
 tiles = np.array([(tx, ty) for ty in range(-32, 32) for tx in range(-32, 32)], np.int32)
 n = len(tiles)
@@ -111,6 +132,16 @@ if "--no-cpu" not in sys.argv:
         g = g0.copy()
         dt, _ = wall(lambda: ck.apply_erosion(g, float(g0.min()), D))
         cpu[f"C3_erosion_4096_{D}_droplets_{thr}thr"] = {"ms": round(dt * 1e3, 1), "droplets_per_s": round(D / dt), "deterministic": thr == 1}
+    if os.path.exists(png):  # the reference's own heightmap_t::postprocess_height on the same image, one thread (the only deterministic droplet order)
+        ck.set_num_threads(1)
+        pc_.island_setup(ck, pc_.island_cfg(orclib.make_config))
+        v_ = ck.heightmap_to_floats(pix)
+        pc_.island_setup(ck, pc_.island_cfg(orclib.make_config), (v_.min(), v_.max()))
+        for D in (100000, 1000000):
+            dt, _ = wall(lambda: ck.heightmap_postprocess(pix, D))
+            cpu[f"C3_island_1k_postprocess_height_{D}_droplets_1thr"] = {"ms": round(dt * 1e3, 1), "droplets_per_s": round(D / dt)}
+        ck.set_mesh_file_scale(1.0, 0.0)
+        s_ = ck.init(orclib.make_config(mesh_gen_mode=0))
     ck.set_num_threads(8)  # 130 rows per tile: more threads only add fork/join cost (256 threads: 8 tiles/s)
     nt = 64
     dt, _ = wall(lambda: [ck.tile_create_zvals(tx, ty, 0) for ty in range(-4, 4) for tx in range(-4, 4)])

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Mesh shadows of the 64x64 tile batch: time of terra_tiles_mesh_shadows_dev.  usage: prof_shadows.py [reps=5]   (TERRA_SHADOW_CHAIN=0/1 selects per-level launches / one chained launch)"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+pkg = importlib.import_module("3dworld_amd")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+t = pkg.Terra(0)
+t.init_scene(pkg.make_config(mesh_gen_mode=0))
+tiles = np.array([(tx, ty) for ty in range(-32, 32) for tx in range(-32, 32)], np.int32)
+n = len(tiles)
+zt = t.alloc(n * 130 * 130 * 4); sm = t.alloc(n * 130 * 130)
+t.tiles_create_zvals_dev(tiles, 0, zt.ptr)
+for light in ((0.6, 0.5, 0.4), (-0.8, 0.3, 0.25)):
+    for _ in range(reps):
+        t.synchronize(); t0 = time.perf_counter()
+        t.tiles_mesh_shadows_dev(tiles, zt.ptr, light, sm.ptr); t.synchronize()
+        print(f"light {light}: shadows {1e3*(time.perf_counter()-t0):.2f} ms  (TERRA_SHADOW_CHAIN={os.environ.get('TERRA_SHADOW_CHAIN', 'default')})")
+m = sm.download(np.uint8, (n, 130, 130))
+print("shadowed cells", int((m != 0).sum()))
