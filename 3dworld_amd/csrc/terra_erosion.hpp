@@ -4,17 +4,20 @@
 // only deterministic semantics it has (its OpenMP loop is a data race) and droplet paths are chaotic, so the
 // GPU implementation keeps SERIAL SEMANTICS EXACTLY while still running droplets in parallel:
 //
-//   optimistic multi-version fixed point (big grids)
-//     round 1   every droplet of a window is traced in parallel against the untouched grid; its writes go to a private
-//               log (cell -> final value) and the 8x8-cell blocks it touched go to a private block list;
-//     round r   per-block linked lists (block -> droplets that touched it) are rebuilt; a droplet that shares a block with a
-//               *lower-numbered* droplet whose log changed is re-traced, now reading, for every cell, the value written by
-//               the highest-numbered lower droplet that wrote it (else the grid).  Logs are double-buffered so a round reads
-//               only the previous round's logs.
-//     stop      when no droplet needs a re-trace: every log then equals what the serial loop would have produced
-//               (induction on droplet number; the lowest dirty droplet becomes final every round).
-//     flush     for every logged cell the highest-numbered writer stores its value into the grid.
-//   serial (tiles, and the overflow fall-back): one lane walks the droplets in order directly on the (LDS or HBM) grid.
+//   optimistic multi-version fixed point over a sliding ring of W in-flight droplets (big grids; droplet i lives in slot i % W)
+//     trace     a droplet is one 64-lane wave that walks the reference's scalar state machine on a 32x32 LDS window which follows it; what it writes goes to a
+//               private VERSION: the distinct 8x8-cell blocks of its footprint in first-touch order, one 64-float PAGE and one 64-bit written-cells mask per block
+//               (a write-back is one plain store, nothing is hashed, nothing is cleared between traces); a cell that enters the window is read from the page of the
+//               highest-numbered LOWER droplet that has published a write of it, else from the grid;
+//     publish   finished versions are compared with the droplet's previously published one page by page; blocks whose content changed are dirty;
+//     re-trace  every higher droplet whose footprint contains a dirty block starts over -- from its last checkpoint before the first dirty block of its footprint
+//               (every 32 steps a trace saves its state, footprint length and masks and keeps an undo log of rewritten cells), not from its spawn;
+//     commit    the finished, valid prefix of the ring is flushed to the grid (highest committed writer of a cell stores it), its slots go to the next droplets;
+//     rounds    one round = trace waves + five bookkeeping passes + commit waves + end-of-round, captured once into a hipGraph; traces of droplets that wait for a
+//               slot are sliced (suspended at a step boundary, resumed next round); the lowest uncommitted droplet always has final inputs, so the fixed point
+//               -- every version equal to the serial loop's -- is reached (terra_driver.hpp: speculative_erosion).
+//   serial (the overflow fall-back, TERRA_ERODE_SERIAL*): one lane / one wave walks the droplets in order directly on the grid.
+//   tiles: the whole clamp-padded 138x138 tile in LDS, one wave, droplets in order (terra_kernels.hpp: k_tile_erosion; k_tile_erosion2 = two waves per tile, opt-in).
 //
 // All arithmetic is the reference's, operation for operation, in fp32 without FMA contraction; std::min/max NaN behaviour
 // and x86 float->int conversion are reproduced because the reference does produce NaNs (v = sqrtf(v*v + Kg*dh) with dh < 0).
@@ -217,82 +220,103 @@ template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, eros
 //   * the rock test is a compare against a threshold found on the host (rock_test above) instead of an IEEE division;
 //   * one step counter instead of separate path-length / budget tests; one compact run of instructions (the general step is ~100 KB of rarely executed code).
 enum {DROPLET_EV_DONE = 0, DROPLET_EV_BUDGET = 1, DROPLET_EV_GENERAL = 2};
-template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem, erosion_consts_t const &ec, unsigned budget, unsigned &used) {
+struct hot_pos_t {int xi, zi; float xp, zp, xf, zf, fxi, fzi, h, h00, h10, h01, h11, dx, dz;}; // what a step reads of where the droplet is and replaces when it has been made (fxi = floorf(xp) == (float)xi)
+struct hot_run_t {float s, v, w; unsigned left, done; int nan_seen, ev; bool ready;};          // what it updates in place; ready: the box of the step to come is interior, resident and on its way
+
+// One hot step from position `a`.  true: made, the droplet is at `b` (a is dead); false: not made -- run.ev says why -- and `a` is still the droplet's position.
+// The caller alternates two position records (a -> b, b -> a): a step has to keep the old position until its brush is written while it computes the new one, and
+// with a single record every field would be copied at the end of every step (a fifth of the loop's instructions were such moves).
+template<class MEM> TERRA_HD bool droplet_hot_step(hot_pos_t const &a, hot_pos_t &b, hot_run_t &run, MEM &mem, erosion_consts_t const &ec, unsigned numMoves) {
 	float const Kq = 10, Kw = 0.001f, Kr = 0.9f, Kd = 0.02f, Ki = 0.1f, minSlope = 0.05f, g = 20, Kg = g*2;
 	float const evap = 1 - Kw;
-	int xi = d.xi, zi = d.zi;
-	float xp = d.xp, zp = d.zp, xf = d.xf, zf = d.zf, s = d.s, v = d.v, w = d.w, dx = d.dx, dz = d.dz;
-	float h = d.h, h00 = d.h00, h10 = d.h10, h01 = d.h01, h11 = d.h11;
-	unsigned numMoves = d.numMoves;
-	int nan_seen = d.nan_seen;
-	int ev = DROPLET_EV_GENERAL;
+	int const xi = wave_uniform(a.xi), zi = wave_uniform(a.zi);
+	run.left = wave_uniform(run.left);
+	if (run.left == 0) {run.ev = (numMoves + run.done >= ec.max_path_len) ? DROPLET_EV_DONE : DROPLET_EV_BUDGET; return false;}
+	if (!run.ready) {mem.set_travel(a.dx, a.dz); run.ev = DROPLET_EV_GENERAL; return false;}
+	float const gx = a.h00+a.h01-a.h10-a.h11, gz = a.h00+a.h10-a.h01-a.h11;
+	float tdx = (a.dx-gx)*Ki+gx, tdz = (a.dz-gz)*Ki+gz;
+	float const dl = sqrtf(tdx*tdx+tdz*tdz);
+	if (TERRA_UNLIKELY(!(dl > FLT_EPSILON))) {run.ev = DROPLET_EV_GENERAL; return false;} // random direction (or a NaN): general step
+	tdx /= dl; tdz /= dl;
+	float const nxp = a.xp+tdx, nzp = a.zp+tdz;
+	float const nfx = floorf(nxp), nfz = floorf(nzp), ofx = nfx - a.fxi, ofz = nfz - a.fzi; // cell offsets -1, 0, 1 (exact: small integers), anything else leaves the box
+	if (TERRA_UNLIKELY(!(fabsf(ofx) <= 1.0f && fabsf(ofz) <= 1.0f))) {run.ev = DROPLET_EV_GENERAL; return false;} // (a NaN position fails too): general step
+	int const ox = wave_uniform((int)ofx), oz = wave_uniform((int)ofz);
 	float c[4];
+	mem.corners_hot(ox, oz, c);
+	int const nxi = xi + ox, nzi = zi + oz;
+	float const nxf = nxp-nfx, nzf = nzp-nfz; // nfx == (float)nxi
+	// ---- from here on the step is executed
+	float const nh00 = c[0], nh10 = c[1], nh01 = c[2], nh11 = c[3];
+	float const nh = (nh00*(1-nxf)+nh10*nxf)*(1-nzf)+(nh01*(1-nxf)+nh11*nxf)*nzf;
+	if (TERRA_UNLIKELY(max_std(max_std(nh00, nh10), max_std(nh01, nh11)) < ec.water_thresh)) {run.ev = DROPLET_EV_DONE; return false;}
+	float h = a.h, s = run.s, v = run.v;
+	if (nh >= h) { // `outside` is false: the box is interior
+		float ds = (nh-h)+0.001f;
+		if (ds >= s) {
+			mem.deposit_hot(xi, zi, a.xf, a.zf, s*ec.erode_amount);
+			run.s = 0;
+			run.ev = DROPLET_EV_DONE; return false;
+		}
+		mem.deposit_hot(xi, zi, a.xf, a.zf, ds*ec.erode_amount); h += ds;
+		s -= ds;
+		v = 0;
+	}
+	float dh = h-nh;
+	float const q = max_std(dh, minSlope)*v*run.w*Kq;
+	float ds = s-q;
+	if (ds >= 0) {
+		ds *= Kd;
+		mem.deposit_hot(xi, zi, a.xf, a.zf, ds*ec.erode_amount); dh += ds;
+		s -= ds;
+	}
+	else {
+		ds *= -Kr;
+		ds = min_std(ds, dh*0.99f);
+		ds = (float)((double)ds*(rock_test(ec, nh) ? 0.5 : 2.0)); // rock erodes slower than dirt
+		mem.erode_hot(xi, zi, a.xp, a.zp, ds*ec.erode_amount);
+		dh -= ds;
+		s  += ds;
+	}
+	v = sqrtf(v*v+Kg*dh);
+	if (v != v) {run.nan_seen = 1;}
+	run.s = s; run.v = v; run.w *= evap;
+	b.xi = nxi; b.zi = nzi; b.xp = nxp; b.zp = nzp; b.xf = nxf; b.zf = nzf; b.fxi = nfx; b.fzi = nfz;
+	b.h = nh; b.h00 = nh00; b.h10 = nh10; b.h01 = nh01; b.h11 = nh11; b.dx = tdx; b.dz = tdz;
+	++run.done; --run.left;
+	run.ready = wave_uniform((int)mem.hot_ready(nxi, nzi)) != 0; // the next step's box: its load is under way while this step's speed and the next step's direction are worked out
+	return true;
+}
+
+template<class MEM> TERRA_HD int droplet_hot_steps(droplet_state_t &d, MEM &mem, erosion_consts_t const &ec, unsigned budget, unsigned &used) {
+	unsigned numMoves = wave_uniform(d.numMoves);
+	used = wave_uniform(used);
 	// steps this call may still make: the path-length limit (src/erosion.cpp:86) and the caller's budget folded into one counter
 	unsigned const room = (numMoves < ec.max_path_len) ? ec.max_path_len - numMoves : 0u, allow = (budget == DROPLET_NO_BUDGET) ? room : ((used < budget) ? budget - used : 0u);
-	unsigned left = (room < allow) ? room : allow, done = 0;
-	if (left == 0) {return (numMoves >= ec.max_path_len) ? DROPLET_EV_DONE : DROPLET_EV_BUDGET;}
-	float fxi = floorf(xp), fzi = floorf(zp); // == (float)xi, (float)zi for a position inside the grid (hot_ready refuses everything else)
+	hot_run_t run;
+	run.left = (room < allow) ? room : allow; run.done = 0;
+	if (run.left == 0) {return (numMoves >= ec.max_path_len) ? DROPLET_EV_DONE : DROPLET_EV_BUDGET;}
+	run.s = d.s; run.v = d.v; run.w = d.w; run.nan_seen = d.nan_seen; run.ev = DROPLET_EV_GENERAL;
+	hot_pos_t p0, p1;
+	// (wave_uniform: the droplet's state IS the same in every lane, but the general step reads it through paths the compiler cannot prove uniform; with provably uniform
+	// values every test of the loop is a scalar branch instead of an exec-mask region)
+	run.s = wave_uniform(run.s); run.v = wave_uniform(run.v); run.w = wave_uniform(run.w);
+	p0.xi = wave_uniform(d.xi); p0.zi = wave_uniform(d.zi); p0.xp = wave_uniform(d.xp); p0.zp = wave_uniform(d.zp); p0.xf = wave_uniform(d.xf); p0.zf = wave_uniform(d.zf);
+	p0.dx = wave_uniform(d.dx); p0.dz = wave_uniform(d.dz);
+	p0.h = wave_uniform(d.h); p0.h00 = wave_uniform(d.h00); p0.h10 = wave_uniform(d.h10); p0.h01 = wave_uniform(d.h01); p0.h11 = wave_uniform(d.h11);
+	p0.fxi = floorf(p0.xp); p0.fzi = floorf(p0.zp); // == (float)xi, (float)zi for a position inside the grid (hot_ready refuses everything else)
+	run.ready = wave_uniform((int)mem.hot_ready(p0.xi, p0.zi)) != 0;
+	bool odd;
 	for (;;) {
-		xi = wave_uniform(xi); zi = wave_uniform(zi); left = wave_uniform(left);
-		if (left == 0) {ev = (numMoves + done >= ec.max_path_len) ? DROPLET_EV_DONE : DROPLET_EV_BUDGET; break;}
-		if (!mem.hot_ready(xi, zi)) {mem.set_travel(dx, dz); break;}
-		float const gx = h00+h01-h10-h11, gz = h00+h10-h01-h11;
-		float tdx = (dx-gx)*Ki+gx, tdz = (dz-gz)*Ki+gz;
-		float const dl = sqrtf(tdx*tdx+tdz*tdz);
-		if (!(dl > FLT_EPSILON)) break; // random direction (or a NaN): general step
-		tdx /= dl; tdz /= dl;
-		float const nxp = xp+tdx, nzp = zp+tdz;
-		float const nfx = floorf(nxp), nfz = floorf(nzp), ofx = nfx - fxi, ofz = nfz - fzi; // cell offsets -1, 0, 1 (exact: small integers), anything else leaves the box
-		if (!(fabsf(ofx) <= 1.0f && fabsf(ofz) <= 1.0f)) break; // (a NaN position fails too): general step
-		int const ox = wave_uniform((int)ofx), oz = wave_uniform((int)ofz);
-		mem.corners_hot(ox, oz, c);
-		int const nxi = xi + ox, nzi = zi + oz;
-		float const nxf = nxp-nfx, nzf = nzp-nfz; // nfx == (float)nxi
-		// ---- from here on the step is executed
-		float const nh00 = c[0], nh10 = c[1], nh01 = c[2], nh11 = c[3];
-		float const nh = (nh00*(1-nxf)+nh10*nxf)*(1-nzf)+(nh01*(1-nxf)+nh11*nxf)*nzf;
-		if (max_std(max_std(nh00, nh10), max_std(nh01, nh11)) < ec.water_thresh) {ev = DROPLET_EV_DONE; break;}
-		if (nh >= h) { // `outside` is false: the box is interior
-			float ds = (nh-h)+0.001f;
-			if (ds >= s) {
-				ds = s;
-				mem.deposit_hot(xi, zi, xf, zf, ds*ec.erode_amount); h += ds;
-				s = 0;
-				ev = DROPLET_EV_DONE; break;
-			}
-			mem.deposit_hot(xi, zi, xf, zf, ds*ec.erode_amount); h += ds;
-			s -= ds;
-			v = 0;
-		}
-		float dh = h-nh;
-		float const q = max_std(dh, minSlope)*v*w*Kq;
-		float ds = s-q;
-		if (ds >= 0) {
-			ds *= Kd;
-			mem.deposit_hot(xi, zi, xf, zf, ds*ec.erode_amount); dh += ds;
-			s -= ds;
-		}
-		else {
-			ds *= -Kr;
-			ds = min_std(ds, dh*0.99f);
-			ds = (float)((double)ds*(rock_test(ec, nh) ? 0.5 : 2.0)); // rock erodes slower than dirt
-			mem.erode_hot(xi, zi, xp, zp, ds*ec.erode_amount);
-			dh -= ds;
-			s  += ds;
-		}
-		v = sqrtf(v*v+Kg*dh);
-		if (v != v) {nan_seen = 1;}
-		w *= evap;
-		dx = tdx; dz = tdz;
-		xp = nxp; zp = nzp; xi = nxi; zi = nzi; xf = nxf; zf = nzf; fxi = nfx; fzi = nfz;
-		h = nh; h00 = nh00; h10 = nh10; h01 = nh01; h11 = nh11;
-		++done; --left;
+		if (!droplet_hot_step(p0, p1, run, mem, ec, numMoves)) {odd = false; break;}
+		if (!droplet_hot_step(p1, p0, run, mem, ec, numMoves)) {odd = true; break;}
 	}
-	numMoves += done; used += done;
-	d.xi = xi; d.zi = zi; d.xp = xp; d.zp = zp; d.xf = xf; d.zf = zf; d.s = s; d.v = v; d.w = w; d.dx = dx; d.dz = dz;
-	d.h = h; d.h00 = h00; d.h10 = h10; d.h01 = h01; d.h11 = h11;
-	d.numMoves = numMoves; d.nan_seen = nan_seen;
-	return ev;
+	hot_pos_t const &f = odd ? p1 : p0;
+	numMoves += run.done; used += run.done;
+	d.xi = f.xi; d.zi = f.zi; d.xp = f.xp; d.zp = f.zp; d.xf = f.xf; d.zf = f.zf; d.s = run.s; d.v = run.v; d.w = run.w; d.dx = f.dx; d.dz = f.dz;
+	d.h = f.h; d.h00 = f.h00; d.h10 = f.h10; d.h01 = f.h01; d.h11 = f.h11;
+	d.numMoves = numMoves; d.nan_seen = run.nan_seen;
+	return run.ev;
 }
 
 // at most `budget` steps: hot steps in their own loop, single general steps in between; true => the droplet is finished
@@ -482,6 +506,36 @@ template<class DERIVED> struct wave_cell_ops {
 		}
 		TERRA_WAVE_FENCE();
 	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	// The same three operations WITHOUT a divergent branch: all 64 lanes take part, lane l works on box cell l & 15 (four lanes per cell: they load the same word and
+	// store the same value), a cell the operation does not touch gets its old value stored back, DERIVED::mark_if takes the condition.  One wave issues one instruction
+	// per ~4.7 cycles whatever its kind and pays ~40 cycles per taken branch (tools/lat_probe.hip), so what a step costs is its instruction count: with no lane-dependent
+	// branch left in the hot loop the compiler does not structurize it (no exec save/restore, no Flow blocks, no copies of the droplet state at every merge).
+	TERRA_HD void box_load_all(int xi, int zi) {
+		TERRA_WAVE_FENCE();
+		int const l = (int)(threadIdx.x & 15u);
+		float *p = self().cell(xi-1 + (l & 3), zi-1 + (l >> 2)); boxp[0] = p; boxv[0] = *p;
+	}
+	TERRA_HD void deposit_cells_hot_all(int xi, int zi, float xf, float zf, float dse) {
+		int const l = (int)(threadIdx.x & 15u), bx = l & 3, bz = l >> 2;
+		bool const inner = ((unsigned)(bx - 1) < 2u) & ((unsigned)(bz - 1) < 2u);
+		int const q = ((bx - 1) & 1) | (((bz - 1) & 1) << 1);
+		float const nv = boxv[0] + dse*deposit_weight(q, xf, zf);
+		boxv[0] = inner ? nv : boxv[0]; *boxp[0] = boxv[0]; self().mark_if(xi + (q & 1), zi + (q >> 1), inner);
+		TERRA_WAVE_FENCE();
+	}
+	TERRA_HD void erode_cells_hot_all(int xi, int zi, float xp, float zp, float dse) {
+		int const l = (int)(threadIdx.x & 15u), x = xi-1 + (l & 3), z = zi-1 + (l >> 2);
+		float const wb = brush_weight(x, z, xp, zp), nv = boxv[0] - dse*wb;
+		bool const hit = wb > 0;
+		boxv[0] = hit ? nv : boxv[0]; *boxp[0] = boxv[0]; self().mark_if(x, z, hit);
+		TERRA_WAVE_FENCE();
+	}
+#else
+	TERRA_HD void box_load_all(int xi, int zi) {box_load(xi, zi);}
+	TERRA_HD void deposit_cells_hot_all(int xi, int zi, float xf, float zf, float dse) {deposit_cells_hot(xi, zi, xf, zf, dse);}
+	TERRA_HD void erode_cells_hot_all(int xi, int zi, float xp, float zp, float dse) {erode_cells_hot(xi, zi, xp, zp, dse);}
+#endif
 	TERRA_HD void erode_cells(int xi, int zi, float xp, float zp, float dse, int NX, int NY) {
 		if (TERRA_LIKELY(xi-1 >= 0 && zi-1 >= 0 && xi+2 <= NX-1 && zi+2 <= NY-1)) { // interior: 16 distinct cells, one lane each
 			TERRA_LANES(l, 16) {
@@ -509,6 +563,7 @@ struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
 	float *pad; int NX, NY;
 	TERRA_HD float *cell(int X, int Z) const {return pad + Z*NX + X;}
 	TERRA_HD void mark(int, int) {}
+	TERRA_HD void mark_if(int, int, bool) {}
 	TERRA_HD bool begin_step(int, int) {return true;}
 	TERRA_HD void corners(int x, int z, float out[4]) const {
 		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
@@ -519,12 +574,12 @@ struct wave_lds_mem_t : wave_cell_ops<wave_lds_mem_t> {
 	TERRA_HD void set_travel(float, float) {}
 	TERRA_HD bool hot_ready(int xi, int zi) {
 		if (!(((unsigned)(xi-1) <= (unsigned)(NX-4)) & ((unsigned)(zi-1) <= (unsigned)(NY-4)))) return false; // xi-1 >= 0 && xi+2 <= NX-1, the same in z
-		box_load(xi, zi);
+		box_load_all(xi, zi);
 		return true;
 	}
 	TERRA_HD void corners_hot(int ox, int oz, float out[4]) const {box_corners(ox, oz, out);}
-	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {deposit_cells_hot(xi, zi, xf, zf, dse);}
-	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {erode_cells_hot(xi, zi, xp, zp, dse);}
+	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {deposit_cells_hot_all(xi, zi, xf, zf, dse);}
+	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {erode_cells_hot_all(xi, zi, xp, zp, dse);}
 };
 
 // ---- big grids: a WS x WS window of the grid follows the droplet in LDS; BACK is where cells come from / go to.
@@ -675,12 +730,19 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		if (!back.begin_step(xi, zi)) return false; // idempotent: the general step may record the same blocks again
 		wx0 = wave_uniform(wx0); wz0 = wave_uniform(wz0); steps_in_window = wave_uniform(steps_in_window) + 1;
 		if (!(have & ((unsigned)(xi-1 - wx0) <= (unsigned)(EW-4)) & ((unsigned)(zi-1 - wz0) <= (unsigned)(EW-4)))) return false; // xi-1 >= wx0 && xi+2 < wx0 + EW, the same in z
-		this->box_load(xi, zi);
+		this->box_load_all(xi, zi);
+#if defined(__HIP_DEVICE_COMPILE__)
+		boxdp = dirty + (this->boxp[0] - win); boxd = *boxdp; // the lane's dirty flag travels with its cell: mark_if is an OR in a register and an unconditional byte store
+#endif
 		return true;
 	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint8_t *boxdp; uint8_t boxd;
+	TERRA_HD void mark_if(int, int, bool c) {boxd = (uint8_t)(boxd | (c ? 1 : 0)); *boxdp = boxd;}
+#endif
 	TERRA_HD void corners_hot(int ox, int oz, float out[4]) const {this->box_corners(ox, oz, out);} // (inside the step's box, which lies inside the window)
-	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells_hot(xi, zi, xf, zf, dse);}
-	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {back.note_write(); this->erode_cells_hot(xi, zi, xp, zp, dse);}
+	TERRA_HD void deposit_hot(int xi, int zi, float xf, float zf, float dse) {back.note_write(); this->deposit_cells_hot_all(xi, zi, xf, zf, dse);}
+	TERRA_HD void erode_hot(int xi, int zi, float xp, float zp, float dse) {back.note_write(); this->erode_cells_hot_all(xi, zi, xp, zp, dse);}
 	TERRA_HD void finish() {flush();}
 };
 
@@ -916,7 +978,7 @@ struct spec_back_t {
 	TERRA_HD void touch_block(uint32_t b) {
 		if (map_find(b) != SPEC_NIL) return;
 		if (TERRA_UNLIKELY(nblk >= sb->maxb)) {blk_overflow = true; return;}
-		if (TERRA_LANE0) {my_blks[nblk] = b; map_add(b, nblk);}
+		my_blks[nblk] = b; map_add(b, nblk); // (every lane does the same insert in lock step: same slots, same values -- no lane-dependent branch inside the hot step loop)
 		++nblk;
 		TERRA_WAVE_SYNC(); // the new map entry is visible to every lane
 	}

@@ -99,6 +99,24 @@ inline void use_heightmap_texture(unsigned char const *d_pixels, int width, int 
 	check(terra_hmap_set_dev(default_ctx(), d_pixels, width, height, ncolors), "terrain_hmap_manager");
 	if (d_pixels) {check(terra_set_mesh_height_scales_for_zval_range(default_ctx(), min_z, dz), "set_mesh_height_scales_for_zval_range");}
 }
+// ---- heightmap_t::postprocess_height (src/heightmap.cpp:117-128) on the loaded image: `data` = texture_t::data (width*height*ncolors bytes, host), eroded in place with
+// erosion_iters_tt droplets; mesh_file_scale / mesh_file_tz as the config line `mh_filename <png> <scale> <tz>` set them.  Asserts like the reference when a value leaves [0, 256)
+inline void heightmap_postprocess_height(unsigned char *data, unsigned width, unsigned height, int ncolors, unsigned erosion_iters_tt, float mesh_file_scale, float mesh_file_tz) {
+	if (erosion_iters_tt == 0) return; // no erosion or cities => no need to update height values
+	terra_ctx *ctx = default_ctx();
+	size_t const bytes = (size_t)width*height*(size_t)ncolors;
+	void *d_pixels = nullptr;
+	check(terra_set_mesh_file_scale(ctx, mesh_file_scale, mesh_file_tz), "mh_filename scale");
+	check(terra_malloc(ctx, &d_pixels, bytes), "postprocess_height");
+	int rc = terra_memcpy_h2d(ctx, d_pixels, data, bytes);
+	unsigned bad = 0;
+	if (rc == 0) {rc = terra_heightmap_postprocess_dev(ctx, (unsigned char *)d_pixels, width, height, ncolors, erosion_iters_tt, nullptr, &bad);}
+	if (rc == 0) {rc = terra_memcpy_d2h(ctx, data, d_pixels, bytes);}
+	terra_free(ctx, d_pixels);
+	check(rc, "postprocess_height");
+	assert(bad == 0); // assert(v >= 0.0 && v < 256.0), src/heightmap.cpp:210
+	(void)bad;
+}
 // ---- heightmap_t::write_png / texture_t::load_png for grayscale heightmaps (src/image_io.cpp:493-605)
 inline void write_heightmap_png(char const *fn, unsigned char const *pixels, unsigned width, unsigned height, int ncolors) {
 	check(terra_heightmap_write_png(fn, pixels, width, height, ncolors), "write_png");

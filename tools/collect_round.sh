@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/collect_round.sh <tag>: the evidence set of a round in one GPU call (bench lines, rocprofv3 kernel stats, PMC passes, secondary workloads, erosion timings).
+# Everything goes to gpurun_out/<tag>/; the summaries are then copied to profiles/<tag>_*.
+TAG=${1:-r03}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT"
+tools/gpu_job.sh bench $TAG
+tools/gpu_job.sh bench ${TAG}/driver --steps 20 --warmup 3
+tools/gpu_job.sh profile $TAG bench p1 tiles tile_erosion weights ao voxels noise erosion
+tools/gpu_job.sh pmc ${TAG}/pmc_sine prof_driver.py 16384 2 -- "k_sine_grid" "k_minmax" "quantize16" "speculative_erosion"
+tools/gpu_job.sh pmc ${TAG}/pmc_tile_erosion prof_tile_erosion.py 1000 1 -- "k_tile_erosion" "k_sine_grid"
+python tools/make_pmc_traffic.py gpurun_out/${TAG}/pmc_sine 16384 > gpurun_out/${TAG}/pmc_traffic.json 2>/dev/null
+tools/gpu_job.sh erosion $TAG "16384 1000 0:128" "4096 1000 0:128" "4096 100000 0:128" "4096 1000000 0:128" "8192 1000000 0:128" "16384 1000000 0:128" "1024 30000 0:128"
+tools/gpu_job.sh stepcost $TAG
+timeout 900 python tools/bench_extra.py > gpurun_out/${TAG}/bench_extra.json 2> gpurun_out/${TAG}/bench_extra.err; echo "bench_extra rc $?"
+tools/gpu_job.sh native $TAG
+find gpurun_out/${TAG} -name "*.csv" -size +1M -delete
