@@ -517,6 +517,15 @@ int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n,
 }
 
 uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx) {return ctx ? ctx->eng.be.tile2_gave_up : 0;}
+int terra_selftest_hot_sqrt(terra_ctx *ctx, uint32_t stride, uint64_t *mismatches) {
+	TERRA_CHECK_CTX
+	TERRA_TRY
+	if (!mismatches) throw std::invalid_argument("terra_selftest_hot_sqrt: null result pointer");
+	std::lock_guard<std::recursive_mutex> lk(ctx->eng_mtx);
+	*mismatches = ctx->eng.selftest_hot_sqrt(stride);
+	return TERRA_OK;
+	TERRA_CATCH
+}
 
 // ---- voxels
 int terra_voxel_fill_dev(terra_ctx *ctx, float *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo[3], const float vsz[3], const float off[3],

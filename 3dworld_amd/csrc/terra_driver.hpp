@@ -673,6 +673,36 @@ template<class BE> struct terra_engine {
 		return heightmap_from_floats_dev(d_vals, n, ncolors, d_pix);
 	}
 
+	// Self test of the droplet step's square roots (terra_erosion.hpp: sqrt_rn, sqrt_rn_direction) over every stride-th fp32 bit pattern: against the compiler's full sqrtf
+	// expansion and against the double-precision route (float)sqrt((double)x), which is correctly rounded (53 >= 2*24 + 2 bits).  Returns the number of disagreements.
+	uint64_t selftest_hot_sqrt(uint32_t stride) {
+		if (stride == 0) {stride = 1;}
+		uint32_t *d_bad = scratch<uint32_t>(s_mm, 2);
+		be.fill32(d_bad, 0, 2);
+		uint64_t const n = (0x100000000ull + stride - 1)/stride, per = 4096, nthreads = (n + per - 1)/per;
+		be.launch((size_t)nthreads, [=] TERRA_LAMBDA (size_t t) {
+			auto same = [](float a, float b) {uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4); return ua == ub || (a != a && b != b);};
+			uint32_t bad = 0;
+			uint64_t const k1 = ((t + 1)*per < n) ? (t + 1)*per : n;
+			for (uint64_t k = t*per; k < k1; ++k) {
+				uint32_t const bits = (uint32_t)(k*stride);
+				float x; memcpy(&x, &bits, 4);
+				float const a = sqrt_rn(x), b = sqrtf(x), c = (float)sqrt((double)x);
+				bad += (same(a, b) ? 0u : 1u) + (same(a, c) ? 0u : 1u);
+				if (!(x < 0.0f)) { // a sum of squares (or a NaN): the direction root only has to agree where it passes the FLT_EPSILON test, and on the test itself
+					float const r = sqrt_rn_direction(x);
+					bool const pr = r > FLT_EPSILON, pb = b > FLT_EPSILON;
+					bad += (pr != pb) ? 1u : 0u;
+					if (pr && !same(r, b)) {++bad;}
+				}
+			}
+			if (bad) {TERRA_ATOMIC_ADD(d_bad, bad);}
+		});
+		uint32_t bad = 0;
+		be.d2h(&bad, d_bad, 4);
+		return bad;
+	}
+
 	// ================================================================ erosion (a11)
 	erosion_consts_t make_erosion_consts(int xsize, int ysize, float min_zval) const {
 		erosion_consts_t ec;

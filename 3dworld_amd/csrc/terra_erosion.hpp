@@ -102,7 +102,8 @@ constexpr unsigned DROPLET_NO_BUDGET = 0xFFFFFFFFu;
 TERRA_HD bool rock_test_div(erosion_consts_t const &ec, float t) {float const relh = ec.relh_adj_tex + t/ec.zrange; return relh > ec.clip_hd1;}
 TERRA_HD bool rock_test(erosion_consts_t const &ec, float nh) {
 	float const t = nh - ec.zmin;
-	return ec.rock_div ? rock_test_div(ec, t) : (t >= ec.rock_t);
+	if (TERRA_UNLIKELY(ec.rock_div != 0)) return rock_test_div(ec, t);
+	return t >= ec.rock_t;
 }
 // smallest float t with rock_test_div(t) (host, once per erosion call): bisection over the order-preserving integer image of the floats, -inf .. +inf
 inline void make_rock_threshold(erosion_consts_t &ec) {
@@ -219,6 +220,27 @@ template<class MEM> TERRA_HD bool droplet_run(droplet_state_t &d, MEM &mem, eros
 //     compare per axis, a NaN fails it (no float -> int conversion of unchecked values, no range test against the grid: the box is interior);
 //   * the rock test is a compare against a threshold found on the host (rock_test above) instead of an IEEE division;
 //   * one step counter instead of separate path-length / budget tests; one compact run of instructions (the general step is ~100 KB of rarely executed code).
+// Correctly rounded fp32 square root of the hot step, WITHOUT the parts of the compiler's sqrtf expansion that only matter below 2^-96: that expansion is v_sqrt_f32 (1 ulp)
+// + one residual test against each neighbour (these seven instructions), wrapped in a scale-by-2^32 / unscale / class fix-up for tiny and special arguments (ten more
+// slots of the step's dependent chain, twice per step).  For x >= 2^-96 (and for +-0, +inf, negative and NaN arguments) the seven instructions alone give bit for bit
+// what the full expansion gives -- and tests/test_gpu_parity.py::test_hot_sqrt_equals_sqrtf checks that on the device; the host build is libm's sqrtf.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float sqrt_rn_core(float x) {
+	float s = __builtin_amdgcn_sqrtf(x);
+	float const sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1), sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+	float const rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+	s = (rm <= 0.0f) ? sm : s;
+	s = (rp > 0.0f) ? sp : s;
+	return s;
+}
+__device__ __forceinline__ float sqrt_rn(float x) {return TERRA_LIKELY(x >= 0x1p-96f) ? sqrt_rn_core(x) : sqrtf(x);} // (x < 2^-96, negative, NaN: the full expansion)
+// the argument is a sum of squares and the result is only used when it exceeds FLT_EPSILON: below 2^-96 whatever v_sqrt_f32 returns (<= 2^-47) fails that test like the exact root
+__device__ __forceinline__ float sqrt_rn_direction(float x) {return sqrt_rn_core(x);}
+#else
+inline float sqrt_rn(float x) {return sqrtf(x);}
+inline float sqrt_rn_direction(float x) {return sqrtf(x);}
+#endif
+
 enum {DROPLET_EV_DONE = 0, DROPLET_EV_BUDGET = 1, DROPLET_EV_GENERAL = 2};
 struct hot_pos_t {int xi, zi; float xp, zp, xf, zf, fxi, fzi, h, h00, h10, h01, h11, dx, dz;}; // what a step reads of where the droplet is and replaces when it has been made (fxi = floorf(xp) == (float)xi)
 struct hot_run_t {float s, v, w; unsigned left, done; int nan_seen, ev; bool ready;};          // what it updates in place; ready: the box of the step to come is interior, resident and on its way
@@ -235,7 +257,7 @@ template<class MEM> TERRA_HD bool droplet_hot_step(hot_pos_t const &a, hot_pos_t
 	if (!run.ready) {mem.set_travel(a.dx, a.dz); run.ev = DROPLET_EV_GENERAL; return false;}
 	float const gx = a.h00+a.h01-a.h10-a.h11, gz = a.h00+a.h10-a.h01-a.h11;
 	float tdx = (a.dx-gx)*Ki+gx, tdz = (a.dz-gz)*Ki+gz;
-	float const dl = sqrtf(tdx*tdx+tdz*tdz);
+	float const dl = sqrt_rn_direction(tdx*tdx+tdz*tdz);
 	if (TERRA_UNLIKELY(!(dl > FLT_EPSILON))) {run.ev = DROPLET_EV_GENERAL; return false;} // random direction (or a NaN): general step
 	tdx /= dl; tdz /= dl;
 	float const nxp = a.xp+tdx, nzp = a.zp+tdz;
@@ -273,12 +295,12 @@ template<class MEM> TERRA_HD bool droplet_hot_step(hot_pos_t const &a, hot_pos_t
 	else {
 		ds *= -Kr;
 		ds = min_std(ds, dh*0.99f);
-		ds = (float)((double)ds*(rock_test(ec, nh) ? 0.5 : 2.0)); // rock erodes slower than dirt
+		ds *= rock_test(ec, nh) ? 0.5f : 2.0f; // rock erodes slower than dirt.  (float)((double)ds*(rock ? 0.5 : 2.0)) in the reference: the double product is exact, so its rounding to float IS the float product
 		mem.erode_hot(xi, zi, a.xp, a.zp, ds*ec.erode_amount);
 		dh -= ds;
 		s  += ds;
 	}
-	v = sqrtf(v*v+Kg*dh);
+	v = sqrt_rn(v*v+Kg*dh);
 	if (v != v) {run.nan_seen = 1;}
 	run.s = s; run.v = v; run.w *= evap;
 	b.xi = nxi; b.zi = nzi; b.xp = nxp; b.zp = nzp; b.xf = nxf; b.zf = nzf; b.fxi = nfx; b.fzi = nfz;

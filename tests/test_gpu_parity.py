@@ -33,6 +33,12 @@ def test_sine_epilogue_variants(pkg, gpu, orc):
     pc.case_sine_epilogue_variants(pkg, gpu, orc)
 
 
+def test_hot_sqrt_equals_sqrtf(gpu):
+    """the shortened square-root sequence of the droplet step (csrc/terra_erosion.hpp: sqrt_rn / sqrt_rn_direction) over ALL 2^32 fp32 bit patterns: bit-equal to the
+    compiler's sqrtf and to the correctly rounded (float)sqrt((double)x)"""
+    assert gpu.selftest_hot_sqrt(1) == 0
+
+
 def test_erosion_golden(pkg, gpu):
     pc.case_erosion_golden(pkg, gpu)
 

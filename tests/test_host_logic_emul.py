@@ -231,3 +231,8 @@ def test_multi_contexts_in_one_process(pkg, emul_lib, orc):
     """terra_multi_*: three contexts driven by three host threads -- tiles, row strips, voxel slabs, the row-pipelined mesh shadows with the edge hand-over,
     one region per context -- the union equals the oracle"""
     pc.case_multi_contexts(pkg, emul_lib, orc, 3)
+
+
+def test_hot_sqrt_selftest_entry_point(emul):
+    """the self test's host plumbing (on the host sqrt_rn IS sqrtf; the device sequence is checked by tests/test_gpu_parity.py::test_hot_sqrt_equals_sqrtf)"""
+    assert emul.selftest_hot_sqrt(65521) == 0
