@@ -611,6 +611,7 @@ constexpr unsigned SPEC_MAP_SLOTS = 512; // open-addressed block -> entry map of
 constexpr unsigned SPEC_PAGE = 64;       // cells of an 8 x 8 block = floats of a version page
 constexpr unsigned SPEC_WIN_BLOCKS = ((EW >> 3) + 1)*((EW >> 3) + 1); // blocks a window can overlap
 constexpr unsigned SPEC_CAND = 4, SPEC_CAND_MANY = 255;
+constexpr unsigned SPEC_SEL_OWN = 5, SPEC_SEL_SLOW = 6, SPEC_OWN_NONE = 0xFFFFu; // (SPEC_CAND + 1, + 2)
 // checkpoints of a trace (measured: profiles/r02_erosion_checkpoint_sweep.txt): every SPEC_CK_STEPS steps the window's dirty cells are written back and the droplet state, the footprint length, the write masks and
 // the position in the undo log are saved, so that a re-trace can resume from the last checkpoint whose inputs are still valid instead of from the spawn
 constexpr unsigned SPEC_CK_STEPS = 32, SPEC_CK_MAX = 16, SPEC_UNDO_MAX = 4096; // (defaults: spec_buffers_t::ck_steps / ck_max are the values in force, ck_max <= SPEC_CK_MAX)
@@ -624,6 +625,9 @@ struct wave_shared_t { // per-wave LDS scratch
 	unsigned long long chk;
 	uint8_t blk_shared[64];                  // per block under the window: number of published LOWER versions that wrote it (SPEC_CAND_MANY: more than fit below)
 	spec_cand_t cand[SPEC_WIN_BLOCKS][SPEC_CAND]; // those versions, highest droplet first: a cell's value comes from the first whose mask has the cell
+	uint32_t blk_nonempty, pad3_;            // bit i: block i under the window has a lower version or a page of this trace (only those are resolved / looked at)
+	uint16_t blk_own[32];                    // per block under the window: its entry in THIS trace's block list (SPEC_OWN_NONE: not in the footprint)
+	uint8_t  sel[SPEC_WIN_BLOCKS][SPEC_PAGE]; // per cell of those blocks, resolved once per window move: 0 = the grid, k + 1 = candidate k, SPEC_SEL_OWN, SPEC_SEL_SLOW
 	uint32_t map_keys[SPEC_MAP_SLOTS];       // block id (SPEC_NIL: free)
 	uint8_t  map_ent[SPEC_MAP_SLOTS];        // its entry in the trace's block list = its page
 	unsigned long long masks[SPEC_MAXB];     // per entry: which cells of the block this trace has written back to its page
@@ -677,43 +681,47 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		TERRA_EACH_LANE(lane) {
 			float (&g)[PER_LANE] = gv[TERRA_LANE_SLOT(lane)];
 			uint32_t db = 0;
+			// Every cell of the new window: from the old window (LDS) if it stays, else ONE load from where its current value lives -- the grid or a version page (BACK::source: a
+			// byte look-up per cell, the sources are resolved per block in prepare_window).  The first loop only ISSUES: no branch, no use of a loaded value -- a lane whose cell
+			// stays (or lies outside the grid) loads some valid word it will not use -- so that the sixteen loads of a lane are in flight together: one memory latency per move.
+			// (Written as if / else per cell the compiler waits for every load before it issues the next: 16 latencies, 14 us per move on the critical path of a dense run.)
+			float gl[PER_LANE];
+			unsigned slow_mask = 0, own_mask = 0, old_mask = 0, in_mask = 0;
 #pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) { // the plain grid loads of all entering cells first: independent, they overlap in flight (one memory latency per move); cells that stay come from the old window
+			for (int k = 0; k < PER_LANE; ++k) {
 				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
-				if (in_old) {int const o = (Z - wz0)*EW + (X - wx0); g[k] = win[o]; db |= (uint32_t)(dirty[o] != 0) << k;}
-				else {g[k] = (X < NX && Z < NY) ? back.base(X, Z) : 0.0f;}
+				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW, inside = (X < NX && Z < NY), need = inside && !in_old;
+				int const o = in_old ? (Z - wz0)*EW + (X - wx0) : 0;
+				g[k] = win[o]; db |= (uint32_t)((dirty[o] != 0) & in_old) << k;
+				int const Xs = inside ? X : nx0, Zs = inside ? Z : nz0; // (nx0, nz0) is a cell of the grid and of the prepared window
+				bool slow = false, own = false;
+				uint32_t const code = back.source(Xs, Zs, slow, own);
+				gl[k] = *back.source_ptr(code, Xs, Zs);
+				old_mask |= (uint32_t)in_old << k; in_mask |= (uint32_t)inside << k;
+				slow_mask |= (uint32_t)(slow & need) << k; own_mask |= (uint32_t)(own & need) << k;
 			}
-			constexpr int CH = 8; // (all 16 cells in one piece cost too many registers)
 #pragma unroll
-			for (int k0 = 0; k0 < PER_LANE; k0 += CH) {
-				float av[CH]; unsigned slow_mask = 0, alt_mask = 0;
+			for (int k = 0; k < PER_LANE; ++k) {g[k] = ((old_mask >> k) & 1u) ? g[k] : (((in_mask >> k) & 1u) ? gl[k] : 0.0f);}
+			clk3 = TERRA_CLOCK();
+			if (TERRA_UNLIKELY(own_mask != 0)) { // the trace's own pages were written earlier in THIS kernel: the line may be stale in the CU's L1 -- read those cells again, through to L2
 #pragma unroll
-				for (int k = 0; k < CH; ++k) { // ... and while they are under way, which of the cells have a newer value in a version page (LDS tests only): those loads join the others
-					int const i = (k0 + k)*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-					bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW;
-					av[k] = 0.0f;
-					if (!in_old && X < NX && Z < NY) {
+				for (int k = 0; k < PER_LANE; ++k) {
+					if ((own_mask >> k) & 1u) {
+						int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
 						bool slow = false, own = false;
 						uint32_t const code = back.source(X, Z, slow, own);
-						if (slow) {slow_mask |= 1u << k;}
-						if (code != SPEC_SRC_GRID) {
-							alt_mask |= 1u << k;
-							float const *p = back.source_ptr(code, X, Z);
-							av[k] = own ? TERRA_L2_LOAD(p) : *p; // own: written back earlier in this kernel, the line may be stale in L1
-						}
+						g[k] = TERRA_L2_LOAD(back.source_ptr(code, X, Z));
 					}
 				}
+			}
+			if (TERRA_UNLIKELY(slow_mask != 0)) { // blocks with more lower versions than the candidate list holds: walk their lists (the grid value was loaded above)
 #pragma unroll
-				for (int k = 0; k < CH; ++k) {
-					if ((alt_mask >> k) & 1u) {g[k0 + k] = av[k];}
-					else if (TERRA_UNLIKELY((slow_mask >> k) & 1u)) { // a block with many lower versions: walk its list
-						int const i = (k0 + k)*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-						g[k0 + k] = back.lookup(X, Z, g[k0 + k]);
-					}
+				for (int k = 0; k < PER_LANE; ++k) {
+					if ((slow_mask >> k) & 1u) {int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW); g[k] = back.lookup(X, Z, g[k]);}
 				}
 			}
 			dbits[TERRA_LANE_SLOT(lane)] = db;
+			clk_sh_load += TERRA_CLOCK() - clk3; // (diagnostics: the look-up part -- source tests, page loads issued, list walks of crowded blocks)
 		}
 		TERRA_WAVE_SYNC(); // every lane has taken what it needs from the old window: the new one goes into the same LDS
 		TERRA_EACH_LANE(lane) {
@@ -725,7 +733,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		wx0 = nx0; wz0 = nz0; have = true;
 		TERRA_WAVE_SYNC();
 		unsigned long long const clk4 = TERRA_CLOCK();
-		clk_shift += clk4 - clk0; clk_sh_flush += clk1 - clk0; clk_sh_prep += clk2 - clk1; clk_sh_load += 0;
+		clk_shift += clk4 - clk0; clk_sh_flush += clk1 - clk0; clk_sh_prep += clk2 - clk1;
 	}
 	TERRA_HD bool begin_step(int xi, int zi) {
 		xi = sati(xi, NX); zi = sati(zi, NY);
@@ -890,6 +898,7 @@ struct spec_back_t {
 	bool log_undo = false; // the trace has a checkpoint: write-backs that change a cell written back before are logged
 	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
+	uint32_t nonempty = 0; // wave_shared_t::blk_nonempty of the prepared window, in a register
 	int lx0 = INT_MIN, lx1 = INT_MIN, lz0 = INT_MIN, lz1 = INT_MIN; // block range of the previous step's brush box
 
 	TERRA_HD static uint32_t map_hash(uint32_t b) {return (b*2654435761u) >> (32 - 9);}
@@ -1032,7 +1041,7 @@ struct spec_back_t {
 	// which published LOWER versions wrote the blocks under the new window (only those blocks need the multi-version look-up): one lane per block walks the
 	// block's writer list once and leaves the versions in LDS, highest droplet first, so that a cell's look-up is a mask test there plus one load
 	TERRA_HD void prepare_window(int wx0, int wz0) {
-		if (TERRA_LANE0) {sh->n_shift += 1;}
+		if (TERRA_LANE0) {sh->n_shift += 1; sh->blk_nonempty = 0;} // (LDS executes a wave's instructions in order: the zero is in place before the ORs below)
 		wbx0 = wx0 >> sb->bshift; wbz0 = wz0 >> sb->bshift;
 		TERRA_LANES(i, wnb*wnb) {
 			uint32_t cnt = 0;
@@ -1051,6 +1060,25 @@ struct spec_back_t {
 				}
 			}
 			sh->blk_shared[i] = (uint8_t)cnt;
+			uint32_t const oe = (bx < sb->nbx && bz < sb->nby) ? map_find(bz*sb->nbx + bx) : SPEC_NIL;
+			sh->blk_own[i] = (uint16_t)((oe == SPEC_NIL) ? SPEC_OWN_NONE : oe);
+			if (cnt != 0 || oe != SPEC_NIL) {TERRA_ATOMIC_OR(&sh->blk_nonempty, 1u << i);}
+		}
+		TERRA_WAVE_SYNC();
+		// Resolve every cell of those blocks ONCE, all 64 cells of a block in parallel: which source a cell that enters the window is read from.  (Per entering cell this was a
+		// hash probe for the trace's own page plus a walk over the candidates' masks: 16 cells per lane, each a chain of dependent LDS round trips -- 12 of the 19 us of a
+		// window move on the critical path of a dense run, profiles/r03_erosion_clock_breakdown.txt.)  Now a cell's look-up is one byte.
+		nonempty = wave_uniform(sh->blk_nonempty);
+		for (uint32_t m = nonempty; m; m &= m - 1) {
+			uint32_t const i = (uint32_t)__builtin_ctz(m), cnt = sh->blk_shared[i], oe = sh->blk_own[i];
+			unsigned long long const om = (oe != SPEC_OWN_NONE) ? sh->masks[oe] : 0ull;
+			TERRA_LANES(c, SPEC_PAGE) {
+				uint32_t sel = 0;
+				if (cnt == SPEC_CAND_MANY) {sel = SPEC_SEL_SLOW;}
+				else {for (uint32_t k = cnt; k-- > 0;) {if ((sh->cand[i][k].mask >> c) & 1ull) {sel = k + 1;}}} // the first (highest droplet) whose mask has the cell
+				if ((om >> c) & 1ull) {sel = SPEC_SEL_OWN;} // own earlier write-backs first
+				sh->sel[i][c] = (uint8_t)sel;
+			}
 		}
 		TERRA_WAVE_SYNC();
 	}
@@ -1069,24 +1097,16 @@ struct spec_back_t {
 	// where the current value of a cell that enters the window is read from, as a 32-bit code (the lane keeps sixteen of them in registers): SPEC_SRC_GRID, or
 	// a float index into the two version buffers (bit 31: buffer; this trace's own page included -- own: it was written in this kernel, read it through to L2).
 	// slow: the block has more lower versions than the candidate list holds -- the caller reads the grid value and passes it through lookup()
-	TERRA_HD uint32_t source(int X, int Z, bool &slow, bool &own) const {
+	TERRA_HD uint32_t source(int X, int Z, bool &slow, bool &own) const { // (no branch, unconditional LDS reads: the caller issues sixteen of these back to back)
 		uint32_t const c = page_cell(X, Z);
-		uint32_t e;
-		slow = false; own = false;
-		if (own_written(X, Z, e)) {own = true; return ((1u - sb->cur[slot]) << 31) | (uint32_t)((slot*sb->maxb + e)*SPEC_PAGE + c);}
 		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
-		uint32_t const bi = (uint32_t)(bz*wnb + bx), cnt = sh->blk_shared[bi]; // inside the prepared window by construction
-		if (cnt) {
-
-			if (cnt == SPEC_CAND_MANY) {slow = true;}
-			else {
-				for (uint32_t k = 0; k < cnt; ++k) {
-					spec_cand_t const &cd = sh->cand[bi][k];
-					if ((cd.mask >> c) & 1ull) return (cd.page & 0x80000000u) | ((cd.page & 0x7FFFFFFFu)*SPEC_PAGE + c);
-				}
-			}
-		}
-		return SPEC_SRC_GRID;
+		uint32_t const bi = (uint32_t)(bz*wnb + bx); // inside the prepared window by construction
+		uint32_t const sel = ((nonempty >> bi) & 1u) ? (uint32_t)sh->sel[bi][c] : 0u; // (rows of blocks without content are not filled in)
+		slow = (sel == SPEC_SEL_SLOW); own = (sel == SPEC_SEL_OWN);
+		uint32_t const cpage = sh->cand[bi][(sel - 1u) & (SPEC_CAND - 1u)].page, opage = ((1u - sb->cur[slot]) << 31) | (uint32_t)(slot*sb->maxb + (sh->blk_own[bi] & 0xFFu));
+		uint32_t const page = own ? opage : cpage;
+		uint32_t const code = (page & 0x80000000u) | ((page & 0x7FFFFFFFu)*SPEC_PAGE + c);
+		return (sel == 0 || slow) ? SPEC_SRC_GRID : code;
 	}
 	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code == SPEC_SRC_GRID) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x7FFFFFFFu);}
 	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`

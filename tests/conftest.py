@@ -59,6 +59,8 @@ def ref():
 @pytest.fixture(scope="session")
 def emul_lib():
     """tests/emul/libterra_emul.so: host emulation of the kernel bodies (test infrastructure, see tests/emul/terra_emul.cpp)."""
+    if os.environ.get("TERRA_EMUL_LIB"):  # a pre-built variant, e.g. the -fsanitize=address,undefined build (run pytest with LD_PRELOAD=libasan.so:libubsan.so)
+        return os.environ["TERRA_EMUL_LIB"]
     src = os.path.join(ROOT, "tests", "emul", "terra_emul.cpp")
     out = os.path.join(ROOT, "tests", "emul", "libterra_emul.so")
     csrc = os.path.join(ROOT, "3dworld_amd", "csrc")

@@ -31,5 +31,5 @@ for (w, sl) in combos:
     print(f"    critical_steps {r['critical_steps']} critical_shifts {r['critical_shifts']} | device us: waves {r['clk_wave']*tk:.0f} init {r['clk_init']*tk:.0f} shifts {r['clk_shift']*tk:.0f} tail {r['clk_tail']*tk:.0f} critical {r['clk_critical']*tk:.0f}"
           f" | per shift {r['clk_shift']*tk/max(1,r['window_shifts']):.2f} us, per step (run - shifts) {(r['clk_wave']-r['clk_init']-r['clk_tail']-r['clk_shift'])*tk/max(1,r['traced_steps']):.3f} us, init/trace {r['clk_init']*tk/max(1,r['traces']):.2f} tail/trace {r['clk_tail']*tk/max(1,r['traces']):.2f}", flush=True)
     ns = max(1, r['window_shifts'])
-    print(f"    per window move: write-back {r['clk_shift_flush']*tk/ns:.2f} us, block flags {r['clk_shift_prep']*tk/ns:.2f}, loads + look-ups + fill {(r['clk_shift']-r['clk_shift_flush']-r['clk_shift_prep']-r['clk_shift_load'])*tk/ns:.2f}", flush=True)
-    print(f"    longest wave per round, summed: {r['clk_critical']*tk:.0f} us = window moves {r['crit_clk_shift']*tk:.0f} + before/after {r['crit_clk_edge']*tk:.0f} + steps {(r['clk_critical']-r['crit_clk_shift']-r['crit_clk_edge'])*tk:.0f} us for {r['crit_steps_own']} steps; its window moves: write-back {r['crit_clk_flush']*tk:.0f} us, block flags {r['crit_clk_prep']*tk:.0f}, loads + look-ups + fill {(r['crit_clk_shift']-r['crit_clk_flush']-r['crit_clk_load']-r['crit_clk_prep'])*tk:.0f}", flush=True)
+    print(f"    per window move: write-back {r['clk_shift_flush']*tk/ns:.2f} us, block flags {r['clk_shift_prep']*tk/ns:.2f}, look-ups {r['clk_shift_load']*tk/ns:.2f}, grid loads + fill {(r['clk_shift']-r['clk_shift_flush']-r['clk_shift_prep']-r['clk_shift_load'])*tk/ns:.2f}", flush=True)
+    print(f"    longest wave per round, summed: {r['clk_critical']*tk:.0f} us = window moves {r['crit_clk_shift']*tk:.0f} + before/after {r['crit_clk_edge']*tk:.0f} + steps {(r['clk_critical']-r['crit_clk_shift']-r['crit_clk_edge'])*tk:.0f} us for {r['crit_steps_own']} steps; its window moves: write-back {r['crit_clk_flush']*tk:.0f} us, block flags {r['crit_clk_prep']*tk:.0f}, look-ups {r['crit_clk_load']*tk:.0f}, grid loads + fill {(r['crit_clk_shift']-r['crit_clk_flush']-r['crit_clk_load']-r['crit_clk_prep'])*tk:.0f}", flush=True)
