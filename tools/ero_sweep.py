@@ -13,7 +13,7 @@ z = t.alloc(N * N * 4); zc = t.alloc(N * N * 4)
 mn, mx = t.gen_grid_minmax_dev(zc.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
 lib = t.lib
 for (w, sl) in combos:
-    t.set_erosion_tuning(window=w if w else 0xFFFFFFFF)
+    t.set_erosion_tuning(window=w if w else 0xFFFFFFFF, **({'block_list_capacity': int(os.environ['ERO_SWEEP_MAXB'])} if os.environ.get('ERO_SWEEP_MAXB') else {}))
     t.set_erosion_slice_steps(sl)
     for rep in range(2):
         lib.terra_memcpy_h2d  # noqa
