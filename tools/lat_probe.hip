@@ -21,6 +21,8 @@ __global__ __launch_bounds__(64) void k_probe(float *io, unsigned long long *out
 	case 6: for (int i = 0; i < N_IT; ++i) {int l = __builtin_amdgcn_readfirstlane(__float_as_int(x)) & 15; x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)) + b;} break; // readlane with data-dependent lane
 	case 7: for (int i = 0; i < N_IT; ++i) {x = floorf(x*a) + b;} break;
 	case 8: for (int i = 0; i < N_IT; ++i) {x = (x < a) ? x + b : x*a;} break; // cmp + cndmask chain
+	case 9: if (threadIdx.x < 16) {for (int i = 0; i < N_IT; ++i) {x = floorf(x*a) + b;}} break; // the same chain as 7 with 16 of the 64 lanes active (does the SIMD skip empty quarter-waves?)
+	case 10: if (threadIdx.x < 1) {for (int i = 0; i < N_IT; ++i) {x = floorf(x*a) + b;}} break; // ... one lane
 	}
 	unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
 	io[threadIdx.x] = x;
@@ -29,8 +31,8 @@ __global__ __launch_bounds__(64) void k_probe(float *io, unsigned long long *out
 int main() {
 	float h[66]; for (int i = 0; i < 64; ++i) h[i] = 1.5f + 0.01f*i; h[64] = 1.0001f; h[65] = 0.25f;
 	float *d; unsigned long long *o; (void)hipMalloc(&d, sizeof h); (void)hipMalloc(&o, 16);
-	char const *names[] = {"mul+add (2 dependent VALU)", "sqrtf + add", "a/x + add", "readfirstlane, s_add, v_add", "LDS store, fence, load, add", "readfirstlane + uniform branch", "readfirstlane, readlane, add", "mul, floor, add", "cmp, 2 ops, cndmask"};
-	for (int w = 0; w < 9; ++w) for (int rep = 0; rep < 2; ++rep) {
+	char const *names[] = {"mul+add (2 dependent VALU)", "sqrtf + add", "a/x + add", "readfirstlane, s_add, v_add", "LDS store, fence, load, add", "readfirstlane + uniform branch", "readfirstlane, readlane, add", "mul, floor, add", "cmp, 2 ops, cndmask", "mul, floor, add, lanes 0-15 only", "mul, floor, add, lane 0 only"};
+	for (int w = 0; w < 11; ++w) for (int rep = 0; rep < 2; ++rep) {
 		(void)hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
 		hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, d, o, w);
 		unsigned long long r[2]; (void)hipMemcpy(r, o, 16, hipMemcpyDeviceToHost);
