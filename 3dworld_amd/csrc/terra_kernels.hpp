@@ -425,12 +425,15 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 	float *pad; int NX, NY;
 	tile2_ctl_t *ctl; uint32_t *bm_mine, *bm_other; tile2_undo_t *undo; // LDS control block, the two footprint bitmaps (LDS), this wave's undo log (HBM)
 	uint32_t w, run_first, undo_n, undo_cap, mode; bool spec, aborted, bm_dirty, failed;
+	bool prim = false, done_set = false; // this run is known to be the primary's (`done` only grows, so it stays that way until run_first changes) / `done` already covers what this wave finished before cur_droplet
 	uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // diagnostics: steps as the primary / speculative, runs put back, log records put back, waits on an overlapping box, general steps, droplets done again, spin iterations
 	__device__ float *cell(int X, int Z) const {return pad + Z*NX + X;}
 	__device__ void mark(int, int) {}
 	__device__ void wsync() {__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();}
 	__device__ uint32_t ld(uint32_t const *p) const {return wave_uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));}
-	__device__ void st(uint32_t *p, uint32_t v) const {if (TERRA_LANE0) {__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);}}
+	__device__ void st(uint32_t *p, uint32_t v) const {__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);} // every lane stores the same word: no lane-dependent branch in the step loop
+	__device__ void mark_if(int, int, bool) {}
+	__device__ void new_run(uint32_t first) {run_first = first; prim = false;}
 	__device__ static uint32_t pack(int xi, int zi) {return ((uint32_t)zi << 16) | (uint32_t)xi;}
 	// the oldest unfinished droplet is this wave's: every droplet before its run is committed
 	__device__ bool is_primary() const {return ld(&ctl->done) >= run_first;}
@@ -441,30 +444,28 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 		d = b0 >> 5;
 		return ((1ull << (b1 - b0 + 1)) - 1ull) << (b0 & 31);
 	}
-	__device__ bool box_hits(uint32_t const *bm, int xi, int zi) const {
-		unsigned const l = threadIdx.x & 63u;
-		uint32_t hit = 0;
-		if (l < 4) {
-			int d; unsigned long long const m = row_mask(xi - 1, d);
-			int const row = zi - 1 + (int)l;
-			hit = bm[row*T2_ROW_DW + d] & (uint32_t)m;
-			if ((uint32_t)(m >> 32)) {hit |= bm[row*T2_ROW_DW + d + 1] & (uint32_t)(m >> 32);}
-		}
+	__device__ uint32_t box_hit_bits(uint32_t const *bm, int xi, int zi) const { // per lane: the bits of row l & 3 of the box that are set in `bm` (the caller folds them with a ballot)
+		int d; unsigned long long const m = row_mask(xi - 1, d);
+		int const row = zi - 1 + (int)(threadIdx.x & 3u), d1 = (d + 1 < T2_ROW_DW) ? d + 1 : d;
+		return (bm[row*T2_ROW_DW + d] & (uint32_t)m) | (bm[row*T2_ROW_DW + d1] & (uint32_t)(m >> 32));
+	}
+	__device__ bool box_hits(uint32_t const *bm, int xi, int zi) const { // (every lane works: lane l on row l & 3 of the box, no branch)
+		int d; unsigned long long const m = row_mask(xi - 1, d);
+		int const row = zi - 1 + (int)(threadIdx.x & 3u), d1 = (d + 1 < T2_ROW_DW) ? d + 1 : d;
+		uint32_t const hit = (bm[row*T2_ROW_DW + d] & (uint32_t)m) | (bm[row*T2_ROW_DW + d1] & (uint32_t)(m >> 32));
 		return __ballot(hit != 0) != 0ull;
 	}
 	__device__ void box_set(int xi, int zi) {
-		unsigned const l = threadIdx.x & 63u;
-		if (l < 4) {
-			int d; unsigned long long const m = row_mask(xi - 1, d);
-			int const row = zi - 1 + (int)l;
-			atomicOr(&bm_mine[row*T2_ROW_DW + d], (uint32_t)m);
-			if ((uint32_t)(m >> 32)) {atomicOr(&bm_mine[row*T2_ROW_DW + d + 1], (uint32_t)(m >> 32));}
-		}
+		int d; unsigned long long const m = row_mask(xi - 1, d);
+		int const row = zi - 1 + (int)(threadIdx.x & 3u), d1 = (d + 1 < T2_ROW_DW) ? d + 1 : d;
+		atomicOr(&bm_mine[row*T2_ROW_DW + d], (uint32_t)m);
+		atomicOr(&bm_mine[row*T2_ROW_DW + d1], (uint32_t)(m >> 32)); // (an OR with 0 when the box does not reach into the next word)
 		bm_dirty = true;
 	}
 	__device__ void bitmap_clear() {
 		if (!bm_dirty) return;
-		for (int i = threadIdx.x & 63; i < NY*T2_ROW_DW; i += 64) {bm_mine[i] = 0u;}
+		int const n = NY*T2_ROW_DW;
+		for (int i0 = 0; i0 < n; i0 += 64) {int const i = i0 + (int)(threadIdx.x & 63u); bm_mine[(i < n) ? i : n - 1] = 0u;} // (same trip count in every lane)
 		bm_dirty = false;
 		wsync();
 	}
@@ -489,12 +490,13 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 		wsync();
 		return true;
 	}
-	__device__ void rollback() { // newest record first; the 16 cells of one record are distinct
+	__device__ void rollback() { // newest record first; a record holds all 16 cells of a box as they were before the write (lanes 16 .. 63 repeat lanes 0 .. 15)
 		wsync();
 		if (undo_n) {dbg[2] += 1; dbg[3] += undo_n;}
-		unsigned const l = threadIdx.x & 63u;
+		unsigned const l = threadIdx.x & 15u;
 		for (uint32_t r = undo_n; r-- > 0;) {
-			if (l < 16) {tile2_undo_t const u = undo[(size_t)r*16 + l]; if (u.off != T2_NONE) {pad[u.off] = u.old;}}
+			tile2_undo_t const u = undo[(size_t)r*16 + l];
+			pad[u.off] = u.old;
 			wsync();
 		}
 		undo_n = 0;
@@ -502,15 +504,19 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 		bitmap_clear();
 		aborted = true;
 	}
-	// the protocol step for the box at (xi, zi); false: the droplet cannot go on speculatively (aborted, or the log is full)
+	// the protocol step for the box at (xi, zi); false: the droplet cannot go on speculatively (aborted, or the log is full).
+	// Nothing here waits for LDS except to look at a value: the order of this wave's LDS operations IS their program order (one in-order pipeline per CU), which is all the
+	// set-then-test argument needs -- my publish / my bits are in place before my test executes; TERRA_WAVE_FENCE keeps the compiler from reordering, costs no instruction.
 	__device__ bool acquire(int xi, int zi) {
 		st(&ctl->pos[w], pack(xi, zi));
-		spec = !is_primary();
+		TERRA_WAVE_FENCE();
+		if (!prim) {prim = is_primary();}
+		spec = !prim;
 		if (spec) {
 			if (serve_abort_request()) return false;
 			if (undo_n + 2u > undo_cap || (mode & 1u)) return false; // (the caller waits for the run's turn and goes on as the primary)
 			box_set(xi, zi);
-			wsync();
+			TERRA_WAVE_FENCE();
 			for (uint32_t n = 0; spec; ++n) {
 				uint32_t const op = ld(&ctl->pos[1u - w]);
 				if (op == T2_NONE) break;
@@ -518,19 +524,20 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 				if (!(dx >= -3 && dx <= 3 && dz >= -3 && dz <= 3)) break;
 				// the boxes overlap.  `done` was read before that box was: if the other wave has meanwhile committed everything before this run, the box is a
 				// YOUNGER droplet's (it was published after `done` moved) and this wave is the primary: it does not yield
-				if (is_primary()) {spec = false; break;}
+				if (is_primary()) {prim = true; spec = false; break;}
 				// wait until the older droplet has moved on (it makes this run abort if it comes this way: the bits are set)
 				if (n == 0) {dbg[4] += 1;}
 				if (serve_abort_request()) return false;
 				if (n > T2_SPIN) {failed = true; st(&ctl->err, 4u); return false;}
 				__builtin_amdgcn_s_sleep(1);
 			}
-			wsync();
-			if (spec) {dbg[1] += 1; return true;}
+			if (spec) {return true;}
 		}
-		dbg[0] += 1;
-		{uint32_t const d = ld(&ctl->done); if (d < cur_droplet) {st(&ctl->done, cur_droplet);}} // everything this wave finished while running ahead is final
-		wsync();
+		if (!done_set) { // once per droplet: everything this wave finished while running ahead is final
+			uint32_t const d = ld(&ctl->done); if (d < cur_droplet) {st(&ctl->done, cur_droplet);}
+			done_set = true;
+			TERRA_WAVE_FENCE();
+		}
 		if (box_hits(bm_other, xi, zi)) {abort_other();}
 		return !failed;
 	}
@@ -544,7 +551,7 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 			if (n > T2_SPIN) {failed = true; st(&ctl->err, 2u); break;}
 			__builtin_amdgcn_s_sleep(1);
 		}
-		spec = false;
+		spec = false; prim = true;
 		return ok && !aborted;
 	}
 	// ---- droplet_hot_steps / droplet_run hooks
@@ -553,21 +560,20 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 	__device__ bool hot_ready(int xi, int zi) {
 		if (!(((unsigned)(xi-1) <= (unsigned)(NX-4)) & ((unsigned)(zi-1) <= (unsigned)(NY-4)))) return false;
 		if (!acquire(xi, zi)) return false;
-		box_load(xi, zi);
+		box_load_all(xi, zi);
 		return true;
 	}
 	__device__ void corners_hot(int ox, int oz, float out[4]) const {box_corners(ox, oz, out);}
-	__device__ void log_box(bool deposit_only) { // before a speculative write: what the box cells hold now
-		unsigned const l = threadIdx.x & 63u;
-		if (l < 16) {
-			bool const mine = !deposit_only || l == 5 || l == 6 || l == 9 || l == 10;
-			tile2_undo_t u; u.off = mine ? (uint32_t)(boxp[0] - pad) : T2_NONE; u.old = boxv[0];
-			undo[(size_t)undo_n*16 + l] = u;
-		}
+	__device__ void log_box(bool deposit_only) { // before a speculative write: what the box cells hold now (lanes 16 .. 63 repeat lanes 0 .. 15: same record, same words)
+		// (all 16 cells, written or not: the footprint bits cover the whole box, so nobody else changes an unwritten one before a rollback puts its own value back)
+		unsigned const l = threadIdx.x & 15u;
+		(void)deposit_only;
+		tile2_undo_t u; u.off = (uint32_t)(boxp[0] - pad); u.old = boxv[0];
+		undo[(size_t)undo_n*16 + l] = u;
 		++undo_n;
 	}
-	__device__ void deposit_hot(int xi, int zi, float xf, float zf, float dse) {if (spec) {log_box(true);} deposit_cells_hot(xi, zi, xf, zf, dse);}
-	__device__ void erode_hot(int xi, int zi, float xp, float zp, float dse) {if (spec) {log_box(false);} erode_cells_hot(xi, zi, xp, zp, dse);}
+	__device__ void deposit_hot(int xi, int zi, float xf, float zf, float dse) {if (spec) {log_box(true);} deposit_cells_hot_all(xi, zi, xf, zf, dse);}
+	__device__ void erode_hot(int xi, int zi, float xp, float zp, float dse) {if (spec) {log_box(false);} erode_cells_hot_all(xi, zi, xp, zp, dse);}
 	// general step (only ever as the primary, the other wave made to abort first): plain LDS accesses
 	__device__ void corners(int x, int z, float out[4]) const {
 		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
@@ -577,6 +583,50 @@ struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
 	__device__ void erode(int xi, int zi, float xp, float zp, float dse) {erode_cells(xi, zi, xp, zp, dse, NX, NY);}
 };
 
+// The step loop's view of the tile, one type per ROLE, so that the loop a wave spends its time in carries nothing but the droplet: the protocol's fast path per step, no spin, no
+// role flag, no counters.  Whatever needs more -- the other wave's box in the way, a request to abort, the run becoming the primary's, a full log, a step for the general code --
+// makes hot_ready() return false: the loop ends before that step and tile2_attempt() sorts it out with tile2_mem_t::acquire() (the complete protocol, with its waits).
+//   primary:      publish the cell, read the other wave's footprint bits for the box, load the box (in that order; one wait for both reads), hit -> out;
+//   speculative:  publish, set the box's bits, then read {abort request, abort answer, done, the other wave's cell} in one go; log the box before every write.
+template<bool SPEC> struct tile2_hot_t : wave_cell_ops<tile2_hot_t<SPEC>> {
+	tile2_mem_t &m;
+	__device__ explicit tile2_hot_t(tile2_mem_t &m_) : m(m_) {}
+	__device__ float *cell(int X, int Z) const {return m.pad + Z*m.NX + X;}
+	__device__ void mark(int, int) {}
+	__device__ void mark_if(int, int, bool) {}
+	__device__ bool begin_step(int, int) {return true;}
+	__device__ void set_travel(float, float) {}
+	__device__ bool hot_ready(int xi, int zi) {
+		if (!(((unsigned)(xi-1) <= (unsigned)(m.NX-4)) & ((unsigned)(zi-1) <= (unsigned)(m.NY-4)))) return false;
+		m.st(&m.ctl->pos[m.w], tile2_mem_t::pack(xi, zi));
+		if (SPEC) {
+			if (m.mode & 1u) return false;
+			m.box_set(xi, zi); // (before the tests: a footprint that is a superset of the cells touched is harmless)
+			TERRA_WAVE_FENCE();
+			uint32_t const r0 = __hip_atomic_load(&m.ctl->abort_req[m.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r1 = __hip_atomic_load(&m.ctl->abort_ack[m.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+				r2 = __hip_atomic_load(&m.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r3 = __hip_atomic_load(&m.ctl->pos[1u - m.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			this->box_load_all(xi, zi);
+			uint32_t const req = wave_uniform(r0), ack = wave_uniform(r1), dn = wave_uniform(r2), op = wave_uniform(r3);
+			int const dx = (int)(op & 0xFFFFu) - xi, dz = (int)(op >> 16) - zi;
+			bool const near_other = (op != T2_NONE) & (dx >= -3) & (dx <= 3) & (dz >= -3) & (dz <= 3);
+			return !((req != ack) | (dn >= m.run_first) | (m.undo_n + 2u > m.undo_cap) | near_other);
+		}
+		TERRA_WAVE_FENCE();
+		uint32_t const hit = m.box_hit_bits(m.bm_other, xi, zi);
+		this->box_load_all(xi, zi);
+		return __ballot(hit != 0) == 0ull;
+	}
+	__device__ void corners_hot(int ox, int oz, float out[4]) const {this->box_corners(ox, oz, out);}
+	__device__ void log_box() { // before a speculative write: all 16 cells of the box as they are (see tile2_mem_t::rollback)
+		unsigned const l = threadIdx.x & 15u;
+		tile2_undo_t u; u.off = (uint32_t)(this->boxp[0] - m.pad); u.old = this->boxv[0];
+		m.undo[(size_t)m.undo_n*16 + l] = u;
+		++m.undo_n;
+	}
+	__device__ void deposit_hot(int xi, int zi, float xf, float zf, float dse) {if (SPEC) {log_box();} this->deposit_cells_hot_all(xi, zi, xf, zf, dse);}
+	__device__ void erode_hot(int xi, int zi, float xp, float zp, float dse) {if (SPEC) {log_box();} this->erode_cells_hot_all(xi, zi, xp, zp, dse);}
+};
+
 // one attempt at droplet `it` from its spawn; false: the wave's run was aborted (everything put back)
 __device__ __forceinline__ bool tile2_attempt(tile2_mem_t &m, erosion_consts_t const &ec, uint32_t it) {
 	droplet_state_t d;
@@ -584,7 +634,7 @@ __device__ __forceinline__ bool tile2_attempt(tile2_mem_t &m, erosion_consts_t c
 	d.xi = EROSION_PAD + (d.rgen.rand() % ec.xsize);
 	d.zi = EROSION_PAD + (d.rgen.rand() % ec.ysize);
 	d.xp = (float)d.xi; d.zp = (float)d.zi; d.xf = 0; d.zf = 0; d.s = 0; d.v = 0; d.w = 1; d.dx = 0; d.dz = 0; d.numMoves = 0; d.nan_seen = 0;
-	m.cur_droplet = it;
+	m.cur_droplet = it; m.done_set = false;
 	// the spawn reads the four corners at (xi, zi): a step of its own for the protocol (always interior: the start cell lies PAD = 4 cells inside the padded grid)
 	if (!m.acquire(d.xi, d.zi)) {
 		if (m.failed) return true;
@@ -592,13 +642,24 @@ __device__ __forceinline__ bool tile2_attempt(tile2_mem_t &m, erosion_consts_t c
 		m.abort_other();
 	}
 	{float c[4]; m.corners(d.xi, d.zi, c); d.h = c[0]; d.h00 = c[0]; d.h10 = c[1]; d.h01 = c[2]; d.h11 = c[3];}
-	unsigned used = 0;
+	unsigned used = 0, last_moves = 0xFFFFFFFFu, tries = 0;
 	for (;;) {
-		int const ev = droplet_hot_steps(d, m, ec, DROPLET_NO_BUDGET, used);
+		unsigned const before = used;
+		int ev;
+		if (m.prim) {tile2_hot_t<false> h(m); ev = droplet_hot_steps(d, h, ec, DROPLET_NO_BUDGET, used); m.dbg[0] += used - before;}
+		else        {tile2_hot_t<true>  h(m); ev = droplet_hot_steps(d, h, ec, DROPLET_NO_BUDGET, used); m.dbg[1] += used - before;}
 		if (m.failed) return true;
 		if (ev == DROPLET_EV_DONE) break;
-		if (m.aborted) return false;
-		// a general step (or a full log): wait for the run's turn, make the other wave abort, run that one step on the tile itself
+		// the loop stopped before a step: the protocol wants attention, or the step is one for the general code
+		if (d.numMoves != last_moves) {tries = 0; last_moves = d.numMoves;}
+		bool const interior = ((unsigned)(d.xi-1) <= (unsigned)(m.NX-4)) & ((unsigned)(d.zi-1) <= (unsigned)(m.NY-4));
+		if (interior && tries < 4) { // (a step that keeps stopping the loop without a protocol reason is one for the general code: direction from the random generator, a NaN)
+			++tries;
+			if (m.acquire(d.xi, d.zi)) continue; // sorted out (waited for the other box to move on, took over as the primary, made the other wave abort): back into the loop of its role
+			if (m.failed) return true;
+			if (m.aborted) return false;
+			// a full log: no further ahead -- wait for the run's turn, then one step with the general code
+		}
 		if (!m.wait_primary()) return false;
 		if (m.failed) return true;
 		m.abort_other(); m.dbg[5] += 1;
@@ -642,7 +703,7 @@ __global__ __launch_bounds__(128) void k_tile_erosion2(float *__restrict__ zvals
 	// this wave's run: droplets [run_first, owned_last], all claimed by it and consecutive; cur = the one in progress (below owned_last only while an aborted run is
 	// done again); pending = a droplet claimed for the NEXT run while the current one still has to be done again
 	uint32_t cur = claim(), owned_last = cur, pending = T2_NONE;
-	m.run_first = cur;
+	m.new_run(cur);
 	while (cur < iters && !m.failed) {
 		m.aborted = false;
 		bool const finished = tile2_attempt(m, ec, cur);
@@ -656,7 +717,7 @@ __global__ __launch_bounds__(128) void k_tile_erosion2(float *__restrict__ zvals
 		m.st(&ctl->pos[w], T2_NONE);
 		if (cur < owned_last) { // doing an aborted run again (as the primary): commit this droplet, on to the next one of the run
 			m.wsync(); m.st(&ctl->done, cur + 1); m.wsync();
-			++cur; m.run_first = cur;
+			++cur; m.new_run(cur);
 			continue;
 		}
 		bool primary = m.is_primary();
@@ -676,7 +737,7 @@ __global__ __launch_bounds__(128) void k_tile_erosion2(float *__restrict__ zvals
 			m.bitmap_clear(); m.undo_n = 0;
 			if (c >= iters) {m.st(&ctl->alive[w], 0u);}
 			m.wsync(); m.st(&ctl->done, cur + 1); m.wsync();
-			m.run_first = c;
+			m.new_run(c);
 		}
 		cur = owned_last = c; // (speculative: the run grows by one droplet; primary: a new run starts)
 	}

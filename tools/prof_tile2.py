@@ -14,6 +14,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "run":
         t.tiles_create_zvals(tiles, 1000, stats=False, normals=False)
         print(f"  {len(tiles)} tiles x 1000 droplets: {(time.perf_counter() - t0)*1e3:.1f} ms (host clock, incl. the download)", flush=True)
     print(f"  tiles redone by the one-wave kernel after a spin time-out: {t.tile_erosion_fallbacks()}")
+    import numpy as np
+    one = np.array([(24, 28)], np.int32)  # the batch's heaviest tile: all land, 103 756 droplet steps in the serial order
+    zt = t.alloc(130 * 130 * 4)
+    for rep in range(2):
+        t.synchronize(); t0 = time.perf_counter(); t.tiles_create_zvals_dev(one, 0, zt.ptr); t.synchronize(); t1 = time.perf_counter()
+        t.tiles_create_zvals_dev(one, 1000, zt.ptr); t.synchronize(); t2 = time.perf_counter()
+    print(f"  tile (24, 28) alone, 1000 droplets: {((t2 - t1) - (t1 - t0))*1e3:.1f} ms", flush=True)
     sys.exit(0)
 for label, env in (("one wave per tile (default)", {}), ("two waves per tile (TERRA_TILE_WAVES=2)", {"TERRA_TILE_WAVES": "2"}), ("two waves per tile with counters (TERRA_T2_DIAG=1)", {"TERRA_TILE_WAVES": "2", "TERRA_T2_DIAG": "1"})):
     print("==", label, flush=True)
