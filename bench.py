@@ -228,7 +228,7 @@ def main():
         c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                   # run_erosion passes min(vals): only written cells can need the clamp
 
     def run_steps(k, npipe):
-        """k steps in total, dealt round-robin to npipe pipelines (one host thread each: the library calls release the GIL)."""
+        """k steps in total on npipe pipelines (one host thread each: the library calls release the GIL)."""
         if npipe == 1:
             for _ in range(k):
                 step(0)
@@ -236,12 +236,24 @@ def main():
         # the pipelines start one noise phase apart (worker p issues its first step when worker p-1's first noise call has returned): started together
         # they run in lockstep -- four noise kernels sharing the chip, then four erosions leaving it idle -- and only drift into an overlapping
         # pattern after dozens of steps
+        # The k steps are a shared queue: a pipeline takes the next one when it is free (the GPU does not serve the four streams evenly -- a host-clock trace shows one stream's
+        # noise kernel waiting behind a dozen of the others' -- so fixed shares would leave that pipeline's steps for the end of the run; measured equal on average).
         first_noise_done = [threading.Event() for _ in range(npipe)]
+        lock = threading.Lock()
+        left = [k]
+        def take():
+            with lock:
+                if left[0] <= 0:
+                    return False
+                left[0] -= 1
+                return True
         def worker(p):
-            for i, _ in enumerate(range(p, k, npipe)):
-                if i == 0 and p > 0:
-                    first_noise_done[p - 1].wait()
-                step(p, first_noise_done[p] if i == 0 else None)
+            first = True
+            if p > 0:
+                first_noise_done[p - 1].wait()
+            while take():
+                step(p, first_noise_done[p] if first else None)
+                first = False
             first_noise_done[p].set()  # also when this worker had no step at all
         th = [threading.Thread(target=worker, args=(p,)) for p in range(npipe)]
         for x in th:
