@@ -7,6 +7,7 @@
 #include "terra_png.hpp"
 #include <new>
 #include <mutex>
+#include <atomic>
 
 namespace terra {
 static thread_local std::string g_last_error;
@@ -25,7 +26,8 @@ struct terra_gen { // mesh_xy_grid_cache_t (src/mesh.h:22-45)
 	terra_ctx *ctx = nullptr;
 	float x0 = 0, y0 = 0, dx = 0, dy = 0;
 	uint32_t nx = 0, ny = 0, flags = 0;
-	bool built = false, running = false, glaciated = false, collected = false;
+	bool built = false, running = false, glaciated = false;
+	std::atomic<bool> collected{false}; // release-stored after cached_vals is filled: eval_index's fast path reads the grid without the lock once this is set
 	float *d_vals = nullptr; size_t d_count = 0;
 	std::vector<float> cached_vals;
 	// eval_index(x, y, min_start_sin): the sine sum starts at max(start_eval_sin, min_start_sin) (src/mesh_gen.cpp:770); the device grid was evaluated with
@@ -103,13 +105,12 @@ void terra_gen_destroy(terra_gen *g) {
 	try {if (g->d_vals) {std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx); g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);}} catch (...) {}
 	delete g;
 }
-static void terra_gen_do_collect(terra_gen *g) {
-	if (g->collected) return;
+static void terra_gen_do_collect(terra_gen *g) { // caller holds g->mtx
+	if (g->collected.load(std::memory_order_acquire)) return;
 	std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
-	if (g->collected) return;
 	g->cached_vals.resize((size_t)g->nx*g->ny);
 	g->ctx->eng.be.d2h(g->cached_vals.data(), g->d_vals, g->cached_vals.size()*sizeof(float)); // blocks on the stream, like read_float_vals (src/shaders.cpp:1196-1235)
-	g->running = false; g->collected = true;
+	g->running = false; g->collected.store(true, std::memory_order_release);
 }
 int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin) {
 	if (!g) return terra::fail(TERRA_ERR_ARG, "null terra_gen");
@@ -124,10 +125,11 @@ int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy,
 		if (!was_running) { // launch the job (run_gpu_simplex, src/mesh_gen.cpp:652-681)
 			size_t const count = (size_t)nx*ny;
 			if (count == 0) return terra::fail(TERRA_ERR_ARG, "build_arrays: nx, ny must be > 0");
+			g->collected.store(false, std::memory_order_release); // before the geometry changes: eval_index's lock-free path is only valid while this is set
 			if (count > g->d_count) {if (g->d_vals) {g->ctx->eng.be.sync(); g->ctx->eng.be.free(g->d_vals);} g->d_vals = (float *)g->ctx->eng.be.alloc(count*sizeof(float)); g->d_count = count;}
 			g->x0 = x0; g->y0 = y0; g->dx = dx; g->dy = dy; g->nx = nx; g->ny = ny; g->flags = flags;
 			g->ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, g->d_vals);
-			g->built = true; g->running = true; g->collected = false; g->glaciated = (flags & TERRA_GEN_GLACIATE) != 0;
+			g->built = true; g->running = true; g->collected.store(false, std::memory_order_release); g->glaciated = (flags & TERRA_GEN_GLACIATE) != 0;
 			g->kstart = kstart; g->sev = sev; g->gen_mode = (flags & TERRA_GEN_FORCE_SINE) ? (int)terra::MGEN_SINE : g->ctx->eng.mode;
 			g->cached_vals.clear(); g->alt_vals.clear();
 		}
@@ -141,26 +143,40 @@ int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy,
 }
 int terra_gen_enable_glaciate(terra_gen *g) {
 	if (!g) return terra::fail(TERRA_ERR_ARG, "null terra_gen");
-	if (!g->built) return terra::fail(TERRA_ERR_STATE, "enable_glaciate: build_arrays() must have been called first"); // assert(cur_nx > 0 && cur_ny > 0), src/mesh_gen.cpp:644
-	if (g->glaciated) return TERRA_OK;
 	TERRA_TRY
-		std::lock_guard<std::mutex> lock(g->mtx);
+		std::lock_guard<std::mutex> lock(g->mtx); // the handle's state is read under its lock: a build_arrays on another thread may be rewriting it
+		if (!g->built) throw std::logic_error("enable_glaciate: build_arrays() must have been called first"); // assert(cur_nx > 0 && cur_ny > 0), src/mesh_gen.cpp:644
+		if (g->glaciated) return TERRA_OK;
 		std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
 		// not fused at build time: re-evaluate with the glaciate epilogue (pure per-cell function, identical values)
 		g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags | TERRA_GEN_GLACIATE, g->kstart, g->d_vals);
-		g->flags |= TERRA_GEN_GLACIATE; g->glaciated = true; g->running = true; g->collected = false; g->alt_vals.clear();
+		g->flags |= TERRA_GEN_GLACIATE; g->glaciated = true; g->running = true; g->collected.store(false, std::memory_order_release); g->alt_vals.clear();
 	TERRA_CATCH
 }
 int terra_gen_is_running(terra_gen *g) {return (g && g->running) ? 1 : 0;}
 int terra_gen_collect(terra_gen *g, float *host_out) {
 	if (!g || !host_out) return terra::fail(TERRA_ERR_ARG, "null argument");
-	if (!g->built) return terra::fail(TERRA_ERR_STATE, "collect: nothing was built");
-	TERRA_TRY std::lock_guard<std::mutex> lock(g->mtx); terra_gen_do_collect(g); memcpy(host_out, g->cached_vals.data(), g->cached_vals.size()*sizeof(float)); TERRA_CATCH
+	TERRA_TRY
+		std::lock_guard<std::mutex> lock(g->mtx);
+		if (!g->built) throw std::logic_error("collect: nothing was built");
+		terra_gen_do_collect(g); memcpy(host_out, g->cached_vals.data(), g->cached_vals.size()*sizeof(float));
+	TERRA_CATCH
 }
 float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_sin, int use_cache) {
-	if (!g || !g->built || x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;} // assert(x < cur_nx && y < cur_ny), src/mesh_gen.cpp:756
+	if (!g) {terra::fail(TERRA_ERR_ARG, "eval_index: null terra_gen"); return 0.0f;}
 	try {
+		// fast path, lock-free: the reference's OpenMP workers all call eval_index on one collected grid (src/tiled_mesh.cpp:495, src/heightmap.cpp:139).  Once `collected`
+		// is set (release) the handle's geometry and cached_vals do not change until the next build_arrays, which the caller must not overlap with eval_index on the
+		// same handle (the reference's build_arrays is main-thread only, src/mesh.h:40) -- concurrent builds of OTHER handles are fine
+		if (g->collected.load(std::memory_order_acquire)) {
+			int const want0 = (g->gen_mode == (int)terra::MGEN_SINE) ? ((use_cache && (g->flags & TERRA_GEN_CACHE_VALUES)) ? g->sev : terra::imax(g->sev, min_start_sin)) : g->kstart;
+			if (want0 == g->kstart) {
+				if (x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;}
+				return g->cached_vals[(size_t)y*g->nx + x];
+			}
+		}
 		std::lock_guard<std::mutex> lock(g->mtx);
+		if (!g->built || x >= g->nx || y >= g->ny) {terra::fail(TERRA_ERR_ARG, "eval_index: out of range"); return 0.0f;} // assert(x < cur_nx && y < cur_ny), src/mesh_gen.cpp:756
 		// which first sine term the reference would use (src/mesh_gen.cpp:759-770): cached values (cache_values at build time, filled with min_start_sin = 0)
 		// win when use_cache is set; the fBm modes have no sine terms
 		int want = g->kstart;

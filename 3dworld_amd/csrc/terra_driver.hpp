@@ -677,7 +677,8 @@ template<class BE> struct terra_engine {
 	// expansion and against the double-precision route (float)sqrt((double)x), which is correctly rounded (53 >= 2*24 + 2 bits).  Returns the number of disagreements.
 	uint64_t selftest_hot_sqrt(uint32_t stride) {
 		if (stride == 0) {stride = 1;}
-		uint32_t *d_bad = scratch<uint32_t>(s_mm, 2);
+		// 64-bit counter: up to 4 disagreements per input x 2^32 inputs would wrap a 32-bit one (a sqrt_rn that is wrong everywhere would add up to 0 mod 2^32)
+		unsigned long long *d_bad = (unsigned long long *)scratch<uint32_t>(s_mm, 2);
 		be.fill32(d_bad, 0, 2);
 		uint64_t const n = (0x100000000ull + stride - 1)/stride, per = 4096, nthreads = (n + per - 1)/per;
 		be.launch((size_t)nthreads, [=] TERRA_LAMBDA (size_t t) {
@@ -696,11 +697,11 @@ template<class BE> struct terra_engine {
 					if (pr && !same(r, b)) {++bad;}
 				}
 			}
-			if (bad) {TERRA_ATOMIC_ADD(d_bad, bad);}
+			if (bad) {TERRA_ATOMIC_ADD(d_bad, (unsigned long long)bad);}
 		});
-		uint32_t bad = 0;
-		be.d2h(&bad, d_bad, 4);
-		return bad;
+		unsigned long long bad = 0;
+		be.d2h(&bad, d_bad, 8);
+		return (uint64_t)bad;
 	}
 
 	// ================================================================ erosion (a11)

@@ -52,6 +52,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_order) (void)hipFree(tile_order);
 		if (tile_undo) (void)hipFree(tile_undo);
+		if (t2_dbg) (void)hipFree(t2_dbg);
 		if (tile_acc) (void)hipFree(tile_acc);
 		if (tile_map) (void)hipFree(tile_map);
 		if (vox_p) (void)hipFree(vox_p);
@@ -71,11 +72,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void h2d(void *d, void const *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
 	// small parameter blocks (tile references, per-column constants, dependency orders): staged through a pinned ring and copied asynchronously, stream-ordered -- the
 	// host does not wait (a pageable hipMemcpyAsync + hipStreamSynchronize per upload was ~10 % of a 0.68 ms tile batch).  The ring drains the stream when it wraps.
-	uint8_t *pin = nullptr; size_t pin_bytes = 0, pin_off = 0;
+	uint8_t *pin = nullptr; size_t pin_bytes = 0, pin_off = 0; bool pin_failed = false; // pin_failed: the pinned allocation was refused once -- not retried on every upload
 	void h2d_async(void *d, void const *h, size_t bytes) {
 		if (bytes == 0) return;
 		use();
-		if (!pin) {pin_bytes = (size_t)8 << 20; if (hipHostMalloc((void **)&pin, pin_bytes, hipHostMallocDefault) != hipSuccess) {pin = nullptr; pin_bytes = 0; (void)hipGetLastError();}}
+		if (!pin && !pin_failed) {pin_bytes = (size_t)8 << 20; if (hipHostMalloc((void **)&pin, pin_bytes, hipHostMallocDefault) != hipSuccess) {pin = nullptr; pin_bytes = 0; pin_failed = true; (void)hipGetLastError();}}
 		size_t const need = (bytes + 255) & ~(size_t)255;
 		if (!pin || need > pin_bytes/2) {h2d(d, h, bytes); return;}
 		if (pin_off + need > pin_bytes) {TERRA_HIP_CHECK(hipStreamSynchronize(stream)); pin_off = 0;}

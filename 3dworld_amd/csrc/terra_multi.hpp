@@ -32,16 +32,21 @@ template<class F> int multi_run(terra_multi *m, F f) {
 		catch (std::logic_error const &e) {std::lock_guard<std::mutex> l(mtx); if (code == TERRA_OK) {code = TERRA_ERR_STATE; msg = e.what();}}
 		catch (std::bad_alloc const &) {std::lock_guard<std::mutex> l(mtx); if (code == TERRA_OK) {code = TERRA_ERR_LIMIT; msg = "out of memory";}}
 		catch (std::exception const &e) {std::lock_guard<std::mutex> l(mtx); if (code == TERRA_OK) {code = TERRA_ERR_HIP; msg = e.what();}}
+		catch (...) {std::lock_guard<std::mutex> l(mtx); if (code == TERRA_OK) {code = TERRA_ERR_HIP; msg = "unknown exception in a context thread";}} // nothing may leave a thread (std::terminate inside a C ABI call)
 	};
-	for (size_t i = 1; i < n; ++i) {th.emplace_back(body, i);}
-	body(0); // the caller's thread drives context 0
+	th.reserve(n);
+	size_t started = 1;
+	try {for (; started < n; ++started) {th.emplace_back(body, started);}}
+	catch (...) {std::lock_guard<std::mutex> l(mtx); if (code == TERRA_OK) {code = TERRA_ERR_LIMIT; msg = "could not start a host thread per context";}} // the threads already running are joined below
+	if (started == n) {body(0);} // the caller's thread drives context 0 (skipped when the call already failed: the contexts that did start still finish their share)
 	for (std::thread &t : th) {t.join();}
 	if (code != TERRA_OK) return fail(code, msg.c_str());
 	return TERRA_OK;
 }
 inline void multi_block(uint32_t n_units, uint32_t n_parts, uint32_t part, uint32_t &first, uint32_t &count) { // the same contiguous blocks as 3dworld_amd/dist.py
-	uint32_t const per = (n_units + n_parts - 1)/(n_parts ? n_parts : 1), lo = std::min(part*per, n_units), hi = std::min((part + 1)*per, n_units);
-	first = lo; count = hi - lo;
+	uint64_t const parts = n_parts ? n_parts : 1, per = ((uint64_t)n_units + parts - 1)/parts; // 64-bit: n_units near 2^32 must not wrap
+	uint64_t const lo = std::min<uint64_t>((uint64_t)part*per, n_units), hi = std::min<uint64_t>(((uint64_t)part + 1)*per, n_units);
+	first = (uint32_t)lo; count = (uint32_t)(hi - lo);
 }
 
 // ---- mesh shadows of one terrain over several contexts: strips of tile columns, rows pipelined, border edges device to device
@@ -84,8 +89,9 @@ inline int multi_tiles_mesh_shadows(terra_multi *m, int32_t const *tile_xy, uint
 	std::sort(all_rows.begin(), all_rows.end(), [&](int32_t a, int32_t b) {return (int64_t)sy*a > (int64_t)sy*b;});
 	all_rows.erase(std::unique(all_rows.begin(), all_rows.end()), all_rows.end());
 	size_t const chunk = (size_t)std::max<int64_t>(1, per), nchunks = (all_rows.size() + chunk - 1)/chunk;
-	std::map<int32_t, size_t> chunk_of_row;
-	for (size_t r = 0; r < all_rows.size(); ++r) {chunk_of_row[all_rows[r]] = r/chunk;}
+	std::map<int32_t, size_t> chunk_of_row_w;
+	for (size_t r = 0; r < all_rows.size(); ++r) {chunk_of_row_w[all_rows[r]] = r/chunk;}
+	std::map<int32_t, size_t> const &chunk_of_row = chunk_of_row_w; // read-only from here on: the strip threads share it
 
 	int const rc = multi_run(m, [&](uint32_t s) {
 		shadow_strip_t &st = strips[s];
@@ -106,7 +112,7 @@ inline int multi_tiles_mesh_shadows(terra_multi *m, int32_t const *tile_xy, uint
 		uint32_t next = 0; // first tile of the strip (in its processing order) that has not been handed to the engine yet
 		for (size_t c = 0; c < nchunks; ++c) {
 			uint32_t const first = next;
-			while (next < nt && chunk_of_row[tile_xy[2*st.tiles[next]+1]] == c) {++next;}
+			while (next < nt && chunk_of_row.at(tile_xy[2*st.tiles[next]+1]) == c) {++next;}
 			uint32_t const cnt = next - first;
 			if (cnt) {
 				std::vector<int32_t> txy(2*(size_t)cnt);

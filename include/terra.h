@@ -29,6 +29,11 @@
  *
  * Threading: one terra_ctx per host thread / GPU (one process per GPU in multi-GPU runs).  All *_dev work is enqueued
  * on the context's HIP stream (its own, or the caller's via terra_set_stream) and is asynchronous unless noted.
+ * The terra_gen_* handles are the one exception (the reference calls eval_index from its OpenMP workers): handles of one context may be
+ * used from several threads at once, terra_gen_eval_index on a collected grid takes no lock at all; what may NOT overlap is (a) any other
+ * terra_* call on the same context with a terra_gen_* call that launches work (build_arrays, enable_glaciate, collect, an eval_index that
+ * needs another first sine term), and (b) terra_gen_build_arrays with terra_gen_eval_index on the SAME handle (build_arrays is main-thread
+ * only in the reference too, src/mesh.h:40).
  */
 #ifndef TERRA_H
 #define TERRA_H
