@@ -273,6 +273,17 @@ REF_API void ref_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx
 	}
 }
 
+// the same over a rectangle of the grid only (the generator object is built for the whole nx x ny grid, eval_index is called inside the rectangle)
+REF_API void ref_gen_grid_rect(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int min_start_sin, unsigned rx0, unsigned ry0, unsigned rw, unsigned rh, float *out) {
+	mesh_xy_grid_cache_t height_gen;
+	height_gen.build_arrays(x0, y0, dx, dy, nx, ny);
+	if (glaciate) {height_gen.enable_glaciate();}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)rh; ++y) {
+		for (unsigned x = 0; x < rw; ++x) {out[size_t(y)*rw + x] = height_gen.eval_index(rx0 + x, ry0 + y, min_start_sin);}
+	}
+}
+
 REF_API void ref_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters) {apply_erosion(hmap, xsize, ysize, min_zval, iters);}
 REF_API float ref_get_noise_zval(float x, float y, int mode, int shape) {return get_noise_zval(x, y, mode, shape);}
 REF_API float ref_gen_noise(float x, float y, int mode, int shape) {return gen_noise(x, y, mode, shape);}

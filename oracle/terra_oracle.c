@@ -786,6 +786,19 @@ void orc_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx, unsign
 	}
 	gc_free(&g);
 }
+/* a rectangle [rx0, rx0 + rw) x [ry0, ry0 + rh) of the nx x ny grid: build_arrays for the WHOLE grid (the tables and cell positions are those of the full grid, so the
+ * values are bit for bit the ones the full double loop gives there), eval_index only inside the rectangle -- parity checks of interior rows / columns of grids
+ * too large to evaluate whole on the host in the fBm modes */
+void orc_gen_grid_rect(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int min_start_sin, unsigned rx0, unsigned ry0, unsigned rw, unsigned rh, float *out) {
+	grid_cache_t g;
+	gc_build_arrays(&g, x0, y0, dx, dy, nx, ny, 0, 0);
+	if (glaciate) {gc_enable_glaciate(&g);}
+#pragma omp parallel for schedule(static,1)
+	for (int y = 0; y < (int)rh; ++y) {
+		for (unsigned x = 0; x < rw; ++x) {out[(size_t)y*rw + x] = gc_eval_index(&g, rx0 + x, ry0 + (unsigned)y, min_start_sin, 1);}
+	}
+	gc_free(&g);
+}
 /* apply_erosion + the access trace: cells[] receives up to cap entries ((padded cell << 1) | is_write), offsets[iters + 1] each droplet's first entry; returns the
  * number of entries the run produced (may exceed cap: then only the first cap were stored) */
 uint64_t orc_apply_erosion_trace(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, uint32_t *cells, uint64_t cap, uint64_t *offsets) {

@@ -66,6 +66,7 @@ void  orc_set_num_threads(int n);
 void  orc_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int min_start_sin, float *out);
 uint64_t orc_apply_erosion_trace(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, uint32_t *cells, uint64_t cap, uint64_t *offsets);
 void  orc_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int force_sine_mode, int min_start_sin, int use_cache, float *out);
+void  orc_gen_grid_rect(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int min_start_sin, unsigned rx0, unsigned ry0, unsigned rw, unsigned rh, float *out);
 void  orc_apply_erosion(float *hmap, int xsize, int ysize, float min_zval, unsigned iters);
 void  orc_apply_erosion_stats(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, orc_erosion_stats_t *st, uint32_t *steps_per_droplet);
 float orc_get_noise_zval(float x, float y, int mode, int shape);

@@ -141,6 +141,7 @@ class Checker:
         f("set_num_threads", None, [C.c_int])
         f("gen_grid", None, [C.c_float] * 4 + [C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p])
         f("gen_grid_ex", None, [C.c_float] * 4 + [C.c_uint, C.c_uint] + [C.c_int] * 5 + [C.c_void_p])
+        f("gen_grid_rect", None, [C.c_float] * 4 + [C.c_uint, C.c_uint, C.c_int, C.c_int] + [C.c_uint] * 4 + [C.c_void_p])
         f("apply_erosion", None, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint])
         f("get_noise_zval", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
         f("gen_noise", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
@@ -225,6 +226,13 @@ class Checker:
             self._gen_grid_ex(x0, y0, dx, dy, nx, ny, glaciate, cache_values, int(force_sine), min_start_sin, int(use_cache), out.ctypes.data)
         else:
             self._gen_grid(x0, y0, dx, dy, nx, ny, glaciate, cache_values, min_start_sin, out.ctypes.data)
+        return out
+
+    def gen_grid_rect(self, x0, y0, dx, dy, nx, ny, rx0, ry0, rw, rh, glaciate=1, min_start_sin=0):
+        """cells [ry0, ry0 + rh) x [rx0, rx0 + rw) of the nx x ny grid (tables of the whole grid, eval_index inside the rectangle only)"""
+        assert rx0 + rw <= nx and ry0 + rh <= ny
+        out = np.zeros((rh, rw), np.float32)
+        self._gen_grid_rect(x0, y0, dx, dy, nx, ny, glaciate, min_start_sin, rx0, ry0, rw, rh, out.ctypes.data)
         return out
 
     def apply_erosion(self, hmap, min_zval, iters):

@@ -236,3 +236,9 @@ def test_multi_contexts_in_one_process(pkg, emul_lib, orc):
 def test_hot_sqrt_selftest_entry_point(emul):
     """the self test's host plumbing (on the host sqrt_rn IS sqrtf; the device sequence is checked by tests/test_gpu_parity.py::test_hot_sqrt_equals_sqrtf)"""
     assert emul.selftest_hot_sqrt(65521) == 0
+
+
+def test_mesh_seed_zero_static_generator_continues_emul(pkg, emul):
+    """mesh_seed 0 (src/mesh_gen.cpp:213-216,238-239): the host logic of terra_init_scene against a fresh oracle process (the GPU form: tests/test_gpu_timed_sizes.py)"""
+    from test_gpu_timed_sizes import check_seed0_sequence
+    check_seed0_sequence(pkg, emul)

@@ -503,3 +503,27 @@ def test_oracle_vs_reference_random_heightmap_textures(orc, ref):
     finally:
         for c in (ref, orc):
             c.hmap_set(None)
+
+
+def test_oracle_vs_reference_grid_rectangles(orc, ref):
+    """orc.gen_grid_rect (eval_index inside a rectangle of a large grid's generator) against the reference's own mesh_xy_grid_cache_t, and against the full double loop"""
+    for mode, n in ((0, 700), (1, 300), (4, 130)):
+        cfg = orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1)
+        sr, so = ref.init(cfg), orc.init(cfg)
+        full = orc.gen_grid(-n / 2, -n / 2, sr.DX_VAL, sr.DY_VAL, n, n, 1)
+        for rx0, ry0, rw, rh in ((0, 0, n, 3), (0, n - 5, n, 5), (n // 3, 0, 4, n), (17, 29, 100, 64)):
+            a = ref.gen_grid_rect(-n / 2, -n / 2, sr.DX_VAL, sr.DY_VAL, n, n, rx0, ry0, rw, rh)
+            b = orc.gen_grid_rect(-n / 2, -n / 2, sr.DX_VAL, sr.DY_VAL, n, n, rx0, ry0, rw, rh)
+            assert_bit_equal(a, b, f"rect mode {mode}")
+            assert_bit_equal(b, full[ry0:ry0 + rh, rx0:rx0 + rw], f"rect vs full mode {mode}")
+
+
+def test_oracle_vs_reference_mesh_seed_zero_fresh_process(ref):
+    """mesh_seed 0: the reference's function-static generator (src/mesh_gen.cpp:238) and the oracle's, each in a fresh process, over the same four scene starts"""
+    from test_gpu_timed_sizes import seed0_oracle_sequence
+    a, b = seed0_oracle_sequence("ref"), seed0_oracle_sequence("orc")
+    assert len(a) == len(b) == 4
+    for k in range(4):
+        for key in ("sinTable", "rx", "ry", "zmax_est", "grid"):
+            assert a[k][key] == b[k][key], (k, key)
+    assert a[0]["sinTable"] != a[1]["sinTable"]

@@ -9,6 +9,8 @@
 #   gpu_job.sh multirank <tag>                       2 ranks on one GPU over gloo: bench.py self-launch + the sharded workloads
 #   gpu_job.sh stepcost <tag>                        ns per droplet step on one wave (tools/step_cost.hip) + the 64x64x1000 tile batch
 #   gpu_job.sh native  <tag> [args]                  tools/bench_native.c and tools/bench_native_multi.c (--same-device) built and run
+#   gpu_job.sh timeline <tag> [bench.py args]        rocprofv3 kernel trace of the headline run with the driver's flags -> tools/timeline.py (who ran when, idle time, overlap)
+#   gpu_job.sh clock   <tag> <driver.py args>        GRBM_GUI_ACTIVE per dispatch: the clock a kernel actually ran at (cycles / duration)
 set -u
 CMD=${1:-check}; TAG=${2:-job}; shift; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -94,6 +96,31 @@ stepcost)
 	mkdir -p tools/_bin
 	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I3dworld_amd/csrc tools/step_cost.hip -o tools/_bin/step_cost 2> "$OUT/step_cost_build.log" && tools/_bin/step_cost | tee "$OUT/step_cost.txt"
 	timeout 300 python tools/prof_tile_erosion.py 1000 3 | tee "$OUT/tile_erosion.txt"
+	;;
+timeline)
+	if [ $# -eq 0 ]; then set -- --steps 20 --warmup 5; fi
+	(cd /tmp && timeout -k 5 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --no-rccl-world1 "$@" > "$OUT/trace_bench_line.json" 2> "$OUT/trace.err")
+	python tools/timeline.py "$OUT/trace" --last-ms 24 > "$OUT/timeline.txt" 2>&1; cat "$OUT/timeline.txt"
+	python tools/summarize_rocprof.py "$OUT/trace" > "$OUT/trace_kernel_stats.txt" 2>&1
+	find "$OUT/trace" -name "*kernel_trace.csv" -size +2M -delete
+	;;
+clock)
+	(cd /tmp && timeout -k 5 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_clock" -- python "$ROOT/tools/$1" "${@:2}" > "$OUT/pmc_clock.log" 2>&1)
+	python - <<PY
+import csv, glob, collections
+d = "$OUT/pmc_clock"
+dur = {}
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"][:48])
+agg = collections.defaultdict(lambda: [0, 0.0, 0])
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] in dur and dur[r["Dispatch_Id"]][0] > 50000:
+            a = agg[dur[r["Dispatch_Id"]][1]]; a[0] += dur[r["Dispatch_Id"]][0]; a[1] += float(r["Counter_Value"]); a[2] += 1
+for k, (ns, cyc, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print(f"{k:50s} {n:4d} dispatches  avg {ns / n / 1e3:9.1f} us  GRBM_GUI_ACTIVE / duration = {cyc / ns:6.3f} GHz (per-XCD counter summed? divide by 8 if ~16-20)")
+PY
 	;;
 *) echo "unknown command $CMD"; exit 2 ;;
 esac
