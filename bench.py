@@ -55,11 +55,14 @@ def parse():
     p.add_argument("--droplets", type=int, default=1000)
     p.add_argument("--octaves", type=int, default=8)
     p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
+    p.add_argument("--erosion-cus", type=int, default=-1, help="CUs the erosion of a heightmap in flight is confined to (terra_set_erosion_cus); -1 = the library's setting (TERRA_ERO_CUS or off)")
+    p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "strips", "tiles"], help="which measurement is the headline `value`")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-rccl-world1", action="store_true", help="N = 1: do not create the one-rank RCCL group (the collectives of the sharded paths are then skipped)")
+    p.add_argument("--clock-warmup-ms", type=float, default=150.0, help="untimed steps run for this long right before every timed region so that it runs at the chip's sustained clock (a cold MI355X needs ~30 ms of load to get there, an idle gap of 5 ms already costs 12 %%: profiles/r04_clock_ramp.txt); 0 = only the W warm-up steps")
     p.add_argument("--cpu-size", type=int, default=0, help="grid edge of the CPU sample (default: the benchmark's own size)")
     return p.parse_args()
 
@@ -212,6 +215,9 @@ def main():
     # (VALU-bound, whole chip) runs beside it.  The reference keeps 8 generator objects in flight for the same reason (src/tiled_mesh.h:418).
     ctxs = [pkg.Terra(local_rank) for _ in range(P)]
     sts = [c.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves)) for c in ctxs]
+    if args.erosion_cus >= 0:
+        for c in ctxs:
+            c.set_erosion_cus(args.erosion_cus)
     st = sts[0]
     t = ctxs[0]
     zs = [torch.empty(cells, dtype=torch.float32, device=dev) for _ in range(P)]
@@ -268,9 +274,27 @@ def main():
         if have_group:
             dist.barrier()
 
-    def timed(fn, k, warm):
-        """warm untimed calls, then EXACTLY k timed ones between barrier + synchronize on both sides; max over ranks (seconds)."""
-        fn(warm)
+    spin_log = {}
+
+    def spin_up(fn, warm, what):
+        """untimed steps until --clock-warmup-ms have passed (at least `warm`): the chip's clocks ramp up over ~30 ms of load and fall back within a few ms of idling, and
+        everything timed here lasts only 5-20 ms -- without this the timed region of a 20-step run IS the ramp (1.05 instead of 0.9 ms per step)"""
+        t_s, n = time.perf_counter(), 0
+        fn(warm); n += warm
+        while True:
+            el = (time.perf_counter() - t_s) * 1e3
+            if world > 1:  # the steps of some workloads contain collectives: every rank must run the same number of them, so the ranks agree on "enough" (4 bytes, untimed)
+                e = torch.tensor([el], dtype=torch.float32, device=coll_dev)
+                dist.all_reduce(e, op=dist.ReduceOp.MIN)
+                el = float(e.item())
+            if el >= args.clock_warmup_ms:
+                break
+            fn(max(1, warm)); n += max(1, warm)
+        spin_log[what] = n
+
+    def timed(fn, k, warm, what="headline"):
+        """warm untimed calls (+ the clock spin-up), then EXACTLY k timed ones between barrier + synchronize on both sides; max over ranks (seconds)."""
+        spin_up(fn, warm, what)
         barrier()
         t0 = time.perf_counter()
         fn(k)
@@ -354,22 +378,32 @@ def main():
         workload = f"64x64 tiles of 128^2 (tile_t::create_zvals + sub-block stats + normals, {args.tile_droplets} droplets per tile), block-partitioned over {world} GPUs"
         par = f"{nt} tiles on rank 0 of {len(all_tiles)}, no collective"
     rep = t.erosion_report().as_dict()
+    if args.headline_only:
+        barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
+                              "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling, "config": {"workload": workload, "parallelism": par, "erosion_cus": args.erosion_cus}, "headline_only": True}), flush=True)
+        for c in ctxs:
+            c.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     # ---- the other measurements of the same run
     if not args.no_extras:
         ke = max(4, min(K, 16))
         if args.workload != "heightmap" or P > 1:
-            d1 = timed(lambda k: run_steps(k, 1), ke, 2)
+            d1 = timed(lambda k: run_steps(k, 1), ke, 2, "single")
             detail["single"] = {"pipelines": 1, "steps": ke, "latency_ms_single": round(d1 / ke * 1e3, 4), "gcells_s": round(world * cells * ke / d1 / 1e9, 3), "scaling": "weak",
                                 "note": "one heightmap in flight per GPU: noise and erosion of a map do not overlap with another map's"}
         if args.workload != "strips":
-            ds = timed(strips_steps, ke, 2)
+            ds = timed(strips_steps, ke, 2, "strips")
             detail["strips"] = {"steps": ke, "ms_per_step": round(ds / ke * 1e3, 4), "gcells_s": round(cells * ke / ds / 1e9, 3), "scaling": "strong", "rows_per_rank": r1 - r0,
                                 "collective": ("all_reduce(min) of one float per step over " + ("RCCL" if backend == "nccl" else backend) + (" (one-rank group)" if world == 1 else "")) if have_group else "none (no process group)", "erosion": "excluded: one shared grid in serial droplet order does not shard (replicas only)"}
         if args.workload != "tiles":
-            dt0 = timed(tiles_steps_fn(0), ke, 2)
+            dt0 = timed(tiles_steps_fn(0), ke, 2, "tiles_0")
             kt = max(2, min(K, 3))
-            dt1 = timed(tiles_steps_fn(1000), kt, 1)
+            dt1 = timed(tiles_steps_fn(1000), kt, 1, "tiles_1000")
             tc = len(all_tiles) * 130 * 130
             detail["tiles"] = {"tiles": len(all_tiles), "tiles_per_rank": nt, "scaling": "strong", "collective": "none",
                                "erosion_0": {"steps": ke, "ms_per_batch": round(dt0 / ke * 1e3, 4), "gcells_s": round(tc * ke / dt0 / 1e9, 3), "mtiles_s": round(len(all_tiles) * ke / dt0 / 1e6, 3)},
@@ -377,13 +411,16 @@ def main():
 
     if not args.no_extras:
         kv = max(4, min(K, 16))
-        dv = timed(voxel_steps, kv, 2)
+        dv = timed(voxel_steps, kv, 2, "voxels")
         detail["voxels"] = {"grid": f"{VN}^3", "steps": kv, "ms_per_field": round(dv / kv * 1e3, 4), "gvoxels_s": round(VN ** 3 * kv / dv / 1e9, 2), "scaling": "strong", "y_rows_per_rank": v1 - v0, "collective": "none"}
         vox_buf.clear()
 
     # ---- per-kernel times, live, HIP events on the library's stream (rank 0 only; the other ranks wait at the barrier below)
     if rank == 0:
         reps = max(3, min(K, 16))
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.clock_warmup_ms:  # the kernel times below are quoted at the sustained clock, like the headline
+            t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
         t.timer_start()
         for _ in range(reps):
             t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
@@ -415,7 +452,10 @@ def main():
                     continue
                 t.init_scene(pkg.make_config(mesh_gen_mode=m, mesh_freq_filter=9 - args.octaves))
                 mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-                rr = 2
+                t_s = time.perf_counter()
+                while (time.perf_counter() - t_s) * 1e3 < 0.5 * args.clock_warmup_ms:  # init_scene above left the chip idle for a few ms
+                    t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+                rr = 4
                 t.timer_start()
                 for _ in range(rr):
                     mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
@@ -470,7 +510,9 @@ def main():
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if args.workload == "heightmap" else 1, "parallelism": par},
                "latency_ms_single": detail.get("single", {}).get("latency_ms_single", round(ms_step, 4) if P == 1 else None),
-               "roofline": roof, "detail": dict(detail, erosion=rep, rccl=rccl_note)}
+               "roofline": roof, "detail": dict(detail, erosion=rep, rccl=rccl_note,
+                                                  clock_warmup={"ms": args.clock_warmup_ms, "untimed_steps_run": spin_log,
+                                                                "why": "a cold MI355X reaches its sustained clock after ~30 ms of load and loses it again within ~5 ms of idling (profiles/r04_clock_ramp.txt); every timed region is preceded by untimed steps of the same kind for this long, with < 1 ms between them and the timed steps"})}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, mode)

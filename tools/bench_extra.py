@@ -9,8 +9,11 @@ pkg = importlib.import_module("3dworld_amd")
 t = pkg.Terra(0)
 out = {}
 
-def timed(fn, reps=3, warm=1):
+def timed(fn, reps=3, warm=1, spin_ms=100.0):
+    # warm calls for at least spin_ms: a cold or briefly idle chip runs 15-20 % below its sustained clock for the first ~30 ms of load (profiles/r04_clock_ramp.txt)
+    t_s = time.perf_counter()
     for _ in range(warm): fn()
+    while (time.perf_counter() - t_s) * 1e3 < spin_ms: fn()
     t.synchronize(); t.timer_start()
     for _ in range(reps): fn()
     return t.timer_stop() / reps

@@ -99,8 +99,8 @@ stepcost)
 	;;
 timeline)
 	if [ $# -eq 0 ]; then set -- --steps 20 --warmup 5; fi
-	(cd /tmp && timeout -k 5 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --no-rccl-world1 "$@" > "$OUT/trace_bench_line.json" 2> "$OUT/trace.err")
-	python tools/timeline.py "$OUT/trace" --last-ms 24 > "$OUT/timeline.txt" 2>&1; cat "$OUT/timeline.txt"
+	(cd /tmp && timeout -k 5 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --no-rccl-world1 --headline-only "$@" > "$OUT/trace_bench_line.json" 2> "$OUT/trace.err")
+	python tools/timeline.py "$OUT/trace" --timed-steps "${TL_STEPS:-20}" > "$OUT/timeline.txt" 2>&1; cat "$OUT/timeline.txt"; cat "$OUT/trace_bench_line.json"
 	python tools/summarize_rocprof.py "$OUT/trace" > "$OUT/trace_kernel_stats.txt" 2>&1
 	find "$OUT/trace" -name "*kernel_trace.csv" -size +2M -delete
 	;;

@@ -72,6 +72,11 @@ def main():
         return
     t_end = max(r[1] for r in rows)
     t0 = t_end - int(last_ms * 1e6)
+    if "--timed-steps" in sys.argv:  # a --headline-only run: the timed region starts with the K-th last noise kernel (one per step)
+        k = int(sys.argv[sys.argv.index("--timed-steps") + 1])
+        ns = sorted(r[0] for r in rows if klass(r[2]) == "noise" and r[1] - r[0] > 100_000)
+        if len(ns) >= k:
+            t0 = ns[-k] - 20_000
     rows = [r for r in rows if r[1] > t0]
     t0 = max(t0, min(r[0] for r in rows))
     span = t_end - t0
