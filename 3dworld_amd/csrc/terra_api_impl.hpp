@@ -67,6 +67,17 @@ void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (.
 int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
 int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
 
+// ---- events: stream-level ordering between contexts
+struct terra_event {void *ev = nullptr;};
+int terra_event_create(terra_ctx *ctx, terra_event **out) {
+	TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out");
+	*out = nullptr;
+	TERRA_TRY terra_event *e = new terra_event(); try {e->ev = ctx->eng.be.event_create();} catch (...) {delete e; throw;} *out = e; TERRA_CATCH
+}
+int terra_event_record(terra_ctx *ctx, terra_event *ev) {TERRA_CHECK_CTX if (!ev) return terra::fail(TERRA_ERR_ARG, "null event"); TERRA_TRY ctx->eng.be.event_record(ev->ev); TERRA_CATCH}
+int terra_event_wait(terra_ctx *ctx, terra_event *ev) {TERRA_CHECK_CTX if (!ev) return terra::fail(TERRA_ERR_ARG, "null event"); TERRA_TRY ctx->eng.be.event_wait(ev->ev); TERRA_CATCH}
+void terra_event_destroy(terra_event *ev) {if (ev) {terra_backend_t::event_destroy(ev->ev); delete ev;}}
+
 int terra_init_scene(terra_ctx *ctx, const terra_config *cfg) {
 	TERRA_CHECK_CTX
 	if (!cfg) return terra::fail(TERRA_ERR_ARG, "terra_init_scene: null config");
@@ -210,6 +221,10 @@ int terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, floa
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY float mm[2]; ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out, mm); if (h_min) *h_min = mm[0]; if (h_max) *h_max = mm[1]; TERRA_CATCH
 }
+int terra_gen_grid_minmax_async_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *d_minmax) {
+	TERRA_CHECK_CTX if (!d_out || !d_minmax) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out, nullptr, 0, 0xFFFFFFFFu, d_minmax); TERRA_CATCH
+}
 int terra_gen_grid_rows_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, uint32_t row0, uint32_t nrows, float *d_out, float *h_min, float *h_max) {
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY
@@ -243,6 +258,10 @@ int terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_t
 int terra_apply_erosion_dev(terra_ctx *ctx, float *d, int xs, int ys, float min_zval, uint32_t iters, uint32_t flags) {
 	TERRA_CHECK_CTX if (!d) return terra::fail(TERRA_ERR_ARG, "null heightmap");
 	TERRA_TRY ctx->eng.apply_erosion_dev(d, xs, ys, min_zval, iters, flags); TERRA_CATCH
+}
+int terra_apply_erosion_devmin_dev(terra_ctx *ctx, float *d, int xs, int ys, const float *d_min_zval, uint32_t iters, uint32_t flags) {
+	TERRA_CHECK_CTX if (!d || !d_min_zval) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.apply_erosion_dev(d, xs, ys, 0.0f, iters, flags, d_min_zval); TERRA_CATCH
 }
 int terra_apply_erosion(terra_ctx *ctx, float *h, int xs, int ys, float min_zval, uint32_t iters) {
 	TERRA_CHECK_CTX if (!h) return terra::fail(TERRA_ERR_ARG, "null heightmap");

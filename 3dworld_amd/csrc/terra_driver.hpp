@@ -474,7 +474,8 @@ template<class BE> struct terra_engine {
 	// row0 / nrows (optional): only rows [row0, row0 + nrows) of the nx x ny grid, written to d_out as an nrows x nx array -- every value is the one the
 	// full-grid call produces (the tables and cell coordinates use the row's index in the whole grid), so row strips evaluated on different GPUs tile the
 	// heightmap exactly (heightmap_t::proc_gen's loop is row-independent, src/heightmap.cpp:139-143)
-	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu) {
+	// d_minmax (optional): DEVICE float[2] that receives {min, max} without the host ever seeing them (an enqueue-only proc_gen step: terra_apply_erosion_devmin_dev reads it)
+	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu, float *d_minmax = nullptr) {
 		require_scene();
 		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
 		if (nrows == 0xFFFFFFFFu) {if (row0 != 0) throw std::invalid_argument("gen_grid rows: row0 without a row count"); nrows = ny;}
@@ -493,7 +494,7 @@ template<class BE> struct terra_engine {
 		sin_lut_t const L = lut();
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
 		uint32_t *d_mm = nullptr;
-		if (h_minmax) {d_mm = scratch<uint32_t>(s_mm, 2); be.fill32(d_mm, 0xFFFFFFFFu, 2);}
+		if (h_minmax || d_minmax) {d_mm = scratch<uint32_t>(s_mm, 2); be.fill32(d_mm, 0xFFFFFFFFu, 2);}
 		bool fused;
 		if (job.use_sine_mag) { // enable_glaciate (src/mesh_gen.cpp:640-650)
 			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
@@ -535,8 +536,9 @@ template<class BE> struct terra_engine {
 			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, d_mm);
 		}
 		else {fused = be.noise_grid(job, nc, L, smx, smy, d_out, d_mm, d_noise_lut);}
+		if ((h_minmax || d_minmax) && !fused) {be.minmax(d_out, (size_t)nx*ny, d_mm);}
+		if (d_minmax) {uint32_t const *mm = d_mm; be.launch(1, [=] TERRA_LAMBDA (size_t) {d_minmax[0] = ord2f(mm[0]); d_minmax[1] = ord2f(~mm[1]);}, 64);}
 		if (h_minmax) {
-			if (!fused) {be.minmax(d_out, (size_t)nx*ny, d_mm);}
 			uint32_t out[2];
 			be.d2h(out, d_mm, sizeof(out));
 			h_minmax[0] = ord2f(out[0]); h_minmax[1] = ord2f(~out[1]);
@@ -727,8 +729,11 @@ template<class BE> struct terra_engine {
 	uint32_t spec_batch_override = getenv("TERRA_ERO_BATCH") ? (uint32_t)std::max(1, atoi(getenv("TERRA_ERO_BATCH"))) : 0u; // experiment knob: rounds per host read-back
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 128, max_rounds = 4000000, near_count = 512;} spec_cfg;
 
-	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags) {
+	// d_min (optional): min_zval is read from this DEVICE float when the final clamp runs (the only place apply_erosion uses it, src/erosion.cpp:158-162) -- the caller's
+	// noise kernel left it there (gen_grid_dev's d_minmax), no host round trip between a heightmap's noise and its erosion
+	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags, float const *d_min = nullptr) {
 		require_scene();
+		if (d_min) {min_zval = 0.0f;} // (kept out of every launch argument and of the hipGraph key: a new minimum must not mean a new capture)
 		report = terra_erosion_report{};
 		if (num_iters == 0 || erode_amount <= 0.0f) return; // erosion disabled (src/erosion.cpp:16)
 		if (xsize <= 0 || ysize <= 0 || (uint64_t)(xsize + 8)*(uint64_t)(ysize + 8) >= (1ull << 30)) throw std::invalid_argument("apply_erosion: bad grid size");
@@ -756,13 +761,14 @@ template<class BE> struct terra_engine {
 		}
 		else {
 			bool const sparse = (flags & TERRA_ERODE_MINZ_IS_MIN) != 0;
-			if (speculative_erosion(g, ec, num_iters, sparse)) return; // sparse clamp already applied to every written cell
+			if (speculative_erosion(g, ec, num_iters, sparse, d_min)) return; // sparse clamp already applied to every written cell
 		}
 		// remove padding and clamp to min_zval (src/erosion.cpp:158-162): in place, so only the clamp remains
 		size_t const n = (size_t)xsize*ysize;
 		be.launch((n + 3)/4, [=] TERRA_LAMBDA (size_t q) {
 			size_t const b = q*4, e = (b + 4 < n) ? b + 4 : n;
-			for (size_t i = b; i < e; ++i) {d_hmap[i] = max_std(min_zval, d_hmap[i]);}
+			float const mz = d_min ? *d_min : min_zval;
+			for (size_t i = b; i < e; ++i) {d_hmap[i] = max_std(mz, d_hmap[i]);}
 		});
 	}
 
@@ -773,7 +779,7 @@ template<class BE> struct terra_engine {
 	// slots are handed to the next droplets.  While droplets are waiting for a slot the traces are sliced, so that one long path (they run
 	// to thousands of steps at ~1 us each) does not hold up a whole window; once everything is admitted the remaining traces run to the end.
 	// returns true when the final clamp was applied sparsely (record_touched and the record did not overflow)
-	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched) {
+	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched, float const *d_min = nullptr) {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
 		// ring slots: more droplets in flight = more parallel work and fewer rounds, but also more speculation on stale cells and longer writer lists.  Measured
@@ -923,7 +929,7 @@ template<class BE> struct terra_engine {
 		uint32_t const ntouched = hc.touched;
 		if (ntouched > sb.touched_cap) return false; // record overflowed: the caller clamps the whole grid
 		uint32_t const *tch = sb.touched; float const mz = ec.min_zval; grid_view_t const gg = g;
-		be.launch(ntouched, [=] TERRA_LAMBDA (size_t i) {touched_clamp_body(gg, tch, (uint32_t)i, mz);});
+		be.launch(ntouched, [=] TERRA_LAMBDA (size_t i) {touched_clamp_body(gg, tch, (uint32_t)i, d_min ? *d_min : mz);});
 		return true;
 	}
 

@@ -100,6 +100,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipError_t const e = hipDeviceEnablePeerAccess(other.device, 0);
 		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {(void)hipGetLastError();}
 	}
+	// stream-level ordering between contexts (terra_event_*): an event recorded on one context's stream, waited for by another's -- the host never blocks
+	void *event_create() {use(); hipEvent_t e = nullptr; TERRA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return (void *)e;}
+	void event_record(void *e) {use(); TERRA_HIP_CHECK(hipEventRecord((hipEvent_t)e, stream));}
+	void event_wait(void *e) {use(); TERRA_HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)e, 0));}
+	static void event_destroy(void *e) {if (e) (void)hipEventDestroy((hipEvent_t)e);}
 	void timer_start() {use(); TERRA_HIP_CHECK(hipEventRecord(ev0, stream));}
 	float timer_stop() {use(); TERRA_HIP_CHECK(hipEventRecord(ev1, stream)); TERRA_HIP_CHECK(hipEventSynchronize(ev1)); float ms = 0; TERRA_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); return ms;}
 

@@ -129,6 +129,12 @@ _PROTOS = {
     "terra_glaciate_mesh_dev": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp]),
     "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
+    "terra_event_create": (_i32, [_vp, C.POINTER(_vp)]),
+    "terra_event_record": (_i32, [_vp, _vp]),
+    "terra_event_wait": (_i32, [_vp, _vp]),
+    "terra_event_destroy": (None, [_vp]),
+    "terra_apply_erosion_devmin_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32]),
+    "terra_gen_grid_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _vp]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
@@ -504,6 +510,23 @@ class Terra:
         r = (C.c_float * 2)()
         self._ck(self.lib.terra_glaciate_mesh_dev(self.ctx, ptr, nx, ny, xoff2, yoff2, C.addressof(r)))
         return r[0], r[1]
+
+    def gen_grid_minmax_async_dev(self, ptr, x0, y0, dx, dy, nx, ny, minmax_ptr, flags=GEN_GLACIATE, min_start_sin=0):
+        """noise (+ glaciate) with {min, max} left in device memory at minmax_ptr (2 floats); nothing is read back, the call only enqueues"""
+        self._ck(self.lib.terra_gen_grid_minmax_async_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr, minmax_ptr))
+
+    def apply_erosion_devmin_dev(self, ptr, xsize, ysize, min_ptr, iters, flags=0):
+        """apply_erosion with min_zval read from device memory (one float) when the final clamp runs"""
+        self._ck(self.lib.terra_apply_erosion_devmin_dev(self.ctx, ptr, xsize, ysize, min_ptr, iters, flags))
+
+    def event_create(self):
+        e = C.c_void_p()
+        self._ck(self.lib.terra_event_create(self.ctx, C.byref(e)))
+        return e
+
+    def event_record(self, ev): self._ck(self.lib.terra_event_record(self.ctx, ev))
+    def event_wait(self, ev): self._ck(self.lib.terra_event_wait(self.ctx, ev))
+    def event_destroy(self, ev): self.lib.terra_event_destroy(ev)
 
     def apply_erosion_dev(self, ptr, xsize, ysize, min_zval, iters, flags=0):
         self._ck(self.lib.terra_apply_erosion_dev(self.ctx, ptr, xsize, ysize, min_zval, iters, flags))

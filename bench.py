@@ -55,8 +55,10 @@ def parse():
     p.add_argument("--droplets", type=int, default=1000)
     p.add_argument("--octaves", type=int, default=8)
     p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
-    p.add_argument("--erosion-cus", type=int, default=-1, help="CUs the erosion of a heightmap in flight is confined to (terra_set_erosion_cus); -1 = the library's setting (TERRA_ERO_CUS or off)")
     p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
+    p.add_argument("--schedule", default="streamed", choices=["streamed", "threads"], help="how the heightmaps in flight are driven: streamed = one context enqueues every map's noise on its stream (the noise "
+                   "kernels run one after another at full speed, nothing is read back), the pipelines' contexts erode the maps as their noise completes (terra_event_*: stream-level "
+                   "ordering, min(vals) stays in HBM); threads = every pipeline runs noise + erosion itself with a host read-back of the min in between (round 3)")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "strips", "tiles"], help="which measurement is the headline `value`")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
@@ -215,9 +217,6 @@ def main():
     # (VALU-bound, whole chip) runs beside it.  The reference keeps 8 generator objects in flight for the same reason (src/tiled_mesh.h:418).
     ctxs = [pkg.Terra(local_rank) for _ in range(P)]
     sts = [c.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves)) for c in ctxs]
-    if args.erosion_cus >= 0:
-        for c in ctxs:
-            c.set_erosion_cus(args.erosion_cus)
     st = sts[0]
     t = ctxs[0]
     zs = [torch.empty(cells, dtype=torch.float32, device=dev) for _ in range(P)]
@@ -267,8 +266,57 @@ def main():
         for x in th:
             x.join()
 
+    # ---- the streamed schedule: a producer context for the noise, the P pipelines' contexts consume (erode)
+    nctx = pkg.Terra(local_rank)
+    nctx.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
+    mms = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(P)]       # {min, max} of the map in slot p, written by its noise kernel, read by its erosion's clamp
+    ev_noise = [nctx.event_create() for _ in range(P)]                               # "the noise of the map in slot p is complete"
+    ev_free = [ctxs[p].event_create() for p in range(P)]                             # "the erosion of the map in slot p is complete": the slot may be overwritten
+
+    def run_steps_streamed(k, npipe):
+        """k heightmaps through npipe slots.  This thread enqueues noise i (terra_gen_grid_minmax_async_dev: kernels only) into slot i % npipe on the producer's stream as soon
+        as the slot's previous erosion has been ENQUEUED (its completion is waited for on the stream, not here); eroder thread p takes the maps of slot p: its stream waits for
+        the noise event, then terra_apply_erosion_devmin_dev (the erosion's own control-block read-backs block only that thread)."""
+        ready = [threading.Semaphore(0) for _ in range(npipe)]
+        free = [threading.Semaphore(1) for _ in range(npipe)]
+        errs = []
+
+        def eroder(p):
+            try:
+                for _i in range(p, k, npipe):
+                    ready[p].acquire()
+                    ctxs[p].event_wait(ev_noise[p])
+                    ctxs[p].apply_erosion_devmin_dev(zs[p].data_ptr(), N, N, mms[p].data_ptr(), args.droplets, pkg.ERODE_MINZ_IS_MIN)
+                    ctxs[p].event_record(ev_free[p])
+                    free[p].release()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+                free[p].release()
+        th = [threading.Thread(target=eroder, args=(p,)) for p in range(min(npipe, k))]
+        for x in th:
+            x.start()
+        for i in range(k):
+            p = i % npipe
+            free[p].acquire()
+            if errs:
+                break
+            if i >= npipe:
+                nctx.event_wait(ev_free[p])
+            nctx.gen_grid_minmax_async_dev(zs[p].data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, mms[p].data_ptr(), pkg.GEN_GLACIATE)
+            nctx.event_record(ev_noise[p])
+            ready[p].release()
+        for x in th:
+            x.join()
+        if errs:
+            raise RuntimeError("; ".join(errs))
+
+    if args.schedule == "streamed":
+        run_steps_threads = run_steps
+        run_steps = run_steps_streamed  # noqa: F811
+
     def barrier():
         torch.cuda.synchronize(dev)
+        nctx.synchronize()
         for c in ctxs:
             c.synchronize()
         if have_group:
@@ -299,6 +347,7 @@ def main():
         t0 = time.perf_counter()
         fn(k)
         torch.cuda.synchronize(dev)
+        nctx.synchronize()
         for c in ctxs:
             c.synchronize()
         dt = time.perf_counter() - t0
@@ -364,7 +413,7 @@ def main():
         value = world * cells * K / dt / 1e9
         scaling = "weak"
         workload = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
-        par = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU"
+        par = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU ({args.schedule} schedule)"
     elif args.workload == "strips":
         dt = timed(strips_steps, K, max(W, 2))
         value = cells * K / dt / 1e9
@@ -382,7 +431,8 @@ def main():
         barrier()
         if rank == 0:
             print(json.dumps({"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
-                              "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling, "config": {"workload": workload, "parallelism": par, "erosion_cus": args.erosion_cus}, "headline_only": True}), flush=True)
+                              "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling, "config": {"workload": workload, "parallelism": par}, "headline_only": True}), flush=True)
+        nctx.close()
         for c in ctxs:
             c.close()
         if dist.is_initialized():
@@ -519,6 +569,9 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
+    for e in ev_noise + ev_free:
+        nctx.event_destroy(e)
+    nctx.close()
     for c in ctxs:
         c.close()
     if dist.is_initialized():

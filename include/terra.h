@@ -137,6 +137,16 @@ void terra_destroy(terra_ctx *ctx);
 int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  terra_synchronize(terra_ctx *ctx);
 
+/* ---- events: stream-level ordering between contexts (hipEventRecord / hipStreamWaitEvent; the host never blocks).  The engine keeps several generator objects in
+ * flight (height_gens[8], src/tiled_mesh.h:418); here one context can produce (noise of map i, recorded) what another consumes (erosion of map i, its stream waits):
+ * terra_event_record marks everything enqueued so far on ctx's stream, terra_event_wait makes everything enqueued on ctx's stream from now on wait for the last
+ * record of ev.  Record before you wait (host order is the caller's business).  An event may be recorded again once its waits have been enqueued. */
+typedef struct terra_event terra_event;
+int  terra_event_create(terra_ctx *ctx, terra_event **out);
+int  terra_event_record(terra_ctx *ctx, terra_event *ev);
+int  terra_event_wait(terra_ctx *ctx, terra_event *ev);
+void terra_event_destroy(terra_event *ev);
+
 /* ---- scene / globals.  terra_init_scene = main()'s start-up sequence for this path (src/3DWorld.cpp:2393-2460 -> gen_mesh). */
 int  terra_init_scene(terra_ctx *ctx, const terra_config *cfg);
 int  terra_set_config(terra_ctx *ctx, const terra_config *cfg);   /* store the config-file values only (engine integration: follow with terra_set_state) */
@@ -170,6 +180,9 @@ const float *terra_gen_device_values(terra_gen *g);                /* device poi
 int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out);
 /* same, plus min(vals)/max(vals) folded into the grid kernel (what heightmap_t::run_erosion / get_heightmap_z_range compute next); synchronous */
 int  terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max);
+/* the same with min / max left in DEVICE memory (d_minmax: 2 floats) and nothing read back: asynchronous.  With terra_apply_erosion_devmin_dev the whole
+ * heightmap_t::proc_gen step (src/heightmap.cpp:135-169: eval loop, min(vals), apply_erosion) is enqueued without a host round trip in between */
+int  terra_gen_grid_minmax_async_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *d_minmax);
 int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out);
 /* rows [row0, row0 + nrows) of the nx x ny grid only, d_out = nrows*nx floats; bit-identical to the same rows of the full-grid call (heightmap_t::proc_gen's
  * row loop is independent per row, src/heightmap.cpp:139-143): one heightmap as row strips on several GPUs.  h_min / h_max (optional, synchronous when given):
@@ -187,6 +200,9 @@ int  terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_
 /* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0.
  * num_iters (and erosion_iters_tt of the tile calls) above 27 183 336 is TERRA_ERR_ARG: the reference's `int` seed 79*iter+121 of droplet iter = 27 183 336 overflows (undefined). */
 int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags);
+/* min_zval read from device memory (one float, e.g. d_minmax of terra_gen_grid_minmax_async_dev -- possibly written by ANOTHER context's stream that this context's
+ * stream was made to wait for) when the final clamp runs, the only use apply_erosion makes of it (src/erosion.cpp:158-162) */
+int  terra_apply_erosion_devmin_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, const float *d_min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
 /* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots; default automatic from the grid size, 0xFFFFFFFF restores that; at most

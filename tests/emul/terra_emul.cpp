@@ -27,6 +27,10 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void d2d(void *dst, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void copy_from_peer(void *dst, cpu_backend_t &, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void enable_peer(cpu_backend_t &) {}
+	void *event_create() {return malloc(1);} // every "launch" has finished when it returns: events order nothing here
+	void event_record(void *) {}
+	void event_wait(void *) {}
+	static void event_destroy(void *e) {::free(e);}
 	void timer_start() {t0 = std::chrono::steady_clock::now();}
 	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
 	template<class F> void launch_waves_nolds(size_t n, F f) {for (size_t i = 0; i < n; ++i) f(i);}

@@ -1030,3 +1030,75 @@ def case_multi_contexts(pkg, lib_path, orc, ndev=3, big=False):
             m.tiles_create_zvals_dev(tiles, 0, [0] * ndev)
     finally:
         m.close()
+
+
+def case_streamed_pipeline(pkg, make_ctx, orc, N=768, maps=7, P=3, droplets=(400, 0, 2500)):
+    """bench.py's streamed schedule in small: ONE producer context enqueues every map's noise (terra_gen_grid_minmax_async_dev: {min, max} stay in device memory), P consumer
+    contexts erode the maps of their slot (terra_event_wait on the producer's event, terra_apply_erosion_devmin_dev), the producer waits for a slot's previous erosion the
+    same way.  Every map is downloaded between its erosion and the slot's reuse and compared with the oracle bit for bit, and so are the device-resident {min, max}."""
+    import threading
+    nctx = make_ctx()
+    ctxs = [make_ctx() for _ in range(P)]
+    try:
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, mesh_freq_filter=1)
+        st = nctx.init_scene(pc_)
+        for c in ctxs:
+            c.init_scene(pc_)
+        orc.init(oc)
+        zs = [nctx.alloc(N * N * 4) for _ in range(P)]
+        mms = [nctx.alloc(8) for _ in range(P)]
+        ev_noise = [nctx.event_create() for _ in range(P)]
+        ev_free = [ctxs[p].event_create() for p in range(P)]
+        ready = [threading.Semaphore(0) for _ in range(P)]
+        free = [threading.Semaphore(1) for _ in range(P)]
+        got, errs = {}, []
+
+        def origin(i):
+            return (-N / 2 + i * 300.0, -N / 2 - i * 77.0)
+
+        def eroder(p):
+            try:
+                for i in range(p, maps, P):
+                    ready[p].acquire()
+                    ctxs[p].event_wait(ev_noise[p])
+                    d = droplets[i % len(droplets)]
+                    ctxs[p].apply_erosion_devmin_dev(zs[p].ptr, N, N, mms[p].ptr, d, pkg.ERODE_MINZ_IS_MIN if i % 2 == 0 else 0)
+                    ctxs[p].synchronize()  # the erosion's last kernels (the clamp) are done: the copies below go through the allocating context's stream
+                    got[i] = (zs[p].download(np.float32, (N, N)), mms[p].download(np.float32, (2,)))
+                    ctxs[p].event_record(ev_free[p])
+                    free[p].release()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e)); free[p].release()
+
+        th = [threading.Thread(target=eroder, args=(p,)) for p in range(P)]
+        for x in th:
+            x.start()
+        for i in range(maps):
+            p = i % P
+            free[p].acquire()
+            if i >= P:
+                nctx.event_wait(ev_free[p])
+            x0, y0 = origin(i)
+            nctx.gen_grid_minmax_async_dev(zs[p].ptr, x0, y0, st.DX_VAL, st.DY_VAL, N, N, mms[p].ptr, pkg.GEN_GLACIATE)
+            nctx.event_record(ev_noise[p])
+            ready[p].release()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for i in range(maps):
+            x0, y0 = origin(i)
+            ref = orc.gen_grid(x0, y0, st.DX_VAL, st.DY_VAL, N, N, 1)
+            mn, mx = ref.min(), ref.max()
+            assert (got[i][1][0], got[i][1][1]) == (mn, mx), (i, got[i][1], mn, mx)
+            d = droplets[i % len(droplets)]
+            if d:
+                orc.apply_erosion(ref, float(mn), d)
+            assert_bit_equal(ref, got[i][0], f"streamed map {i} ({d} droplets)")
+        for e in ev_noise + ev_free:
+            nctx.event_destroy(e)
+        for b in zs + mms:
+            b.free()
+    finally:
+        nctx.close()
+        for c in ctxs:
+            c.close()

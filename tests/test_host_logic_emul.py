@@ -242,3 +242,8 @@ def test_mesh_seed_zero_static_generator_continues_emul(pkg, emul):
     """mesh_seed 0 (src/mesh_gen.cpp:213-216,238-239): the host logic of terra_init_scene against a fresh oracle process (the GPU form: tests/test_gpu_timed_sizes.py)"""
     from test_gpu_timed_sizes import check_seed0_sequence
     check_seed0_sequence(pkg, emul)
+
+
+def test_streamed_pipeline_device_min_and_events_emul(pkg, emul_lib, orc):
+    """terra_gen_grid_minmax_async_dev + terra_event_* + terra_apply_erosion_devmin_dev through the C ABI (bench.py's streamed schedule), host logic"""
+    pc.case_streamed_pipeline(pkg, lambda: pkg.Terra(0, emul_lib), orc, N=200, maps=5, P=2, droplets=(150, 0, 600))
