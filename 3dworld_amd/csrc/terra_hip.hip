@@ -61,6 +61,19 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		for (graph_slot_t &g : graphs) {graph_drop(g);}
 		if (own_stream) (void)hipStreamDestroy(own_stream);
 	}
+	// level > 0: the context's own stream is re-created at the device's highest priority (its workgroups are dispatched first when resources free up: a latency-bound
+	// erosion beside another context's chip-filling noise kernel), < 0: lowest, 0: default
+	void set_priority(int level) {
+		use();
+		if (stream != own_stream) throw std::logic_error("terra_set_stream_priority: the context runs on a caller-owned stream");
+		int least = 0, greatest = 0;
+		TERRA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest)); // numerically lower = higher priority
+		int const prio = (level > 0) ? greatest : (level < 0) ? least : 0;
+		hipStream_t ns = nullptr;
+		TERRA_HIP_CHECK(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, prio));
+		(void)hipStreamSynchronize(own_stream); (void)hipStreamDestroy(own_stream);
+		own_stream = stream = ns; pin_off = 0;
+	}
 	void use() {TERRA_HIP_CHECK(hipSetDevice(device));}
 	void set_stream(void *s) {sync(); pin_off = 0; stream = s ? (hipStream_t)s : own_stream;} // cached graphs are stream-agnostic (the stream is given at launch)
 	void sync() {use(); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}

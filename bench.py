@@ -56,9 +56,10 @@ def parse():
     p.add_argument("--octaves", type=int, default=8)
     p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
     p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
-    p.add_argument("--schedule", default="streamed", choices=["streamed", "threads"], help="how the heightmaps in flight are driven: streamed = one context enqueues every map's noise on its stream (the noise "
-                   "kernels run one after another at full speed, nothing is read back), the pipelines' contexts erode the maps as their noise completes (terra_event_*: stream-level "
-                   "ordering, min(vals) stays in HBM); threads = every pipeline runs noise + erosion itself with a host read-back of the min in between (round 3)")
+    p.add_argument("--schedule", default="threads", choices=["streamed", "threads"], help="how the heightmaps in flight are driven: threads = every pipeline (own context + host thread) runs its maps' noise + "
+                   "erosion itself, the min read back in between (the default: measured fastest, profiles/r04_schedule_ab.txt); streamed = one context enqueues every map's noise on its "
+                   "stream (kernels only, min(vals) stays in HBM), the pipelines' contexts erode the maps as their noise completes (terra_event_*: stream-level ordering)")
+    p.add_argument("--priorities", default="erosion-high", choices=["none", "erosion-high", "noise-low"], help="streamed schedule: stream priorities of the eroding contexts / the noise producer")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "strips", "tiles"], help="which measurement is the headline `value`")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
@@ -269,6 +270,14 @@ def main():
     # ---- the streamed schedule: a producer context for the noise, the P pipelines' contexts consume (erode)
     nctx = pkg.Terra(local_rank)
     nctx.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
+    if args.schedule == "streamed" and args.priorities != "none":
+        # a map's erosion is ~1000 short-lived waves on a dependent chain; beside the producer's chip-filling noise kernel its workgroups must be dispatched as soon as
+        # a noise block leaves a CU, or the erosion only starts in the noise kernel's tail (rocprofv3 timeline: profiles/r04_timeline_streamed_*.txt)
+        if args.priorities == "erosion-high":
+            for c in ctxs:
+                c.set_stream_priority(1)
+        else:
+            nctx.set_stream_priority(-1)
     mms = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(P)]       # {min, max} of the map in slot p, written by its noise kernel, read by its erosion's clamp
     ev_noise = [nctx.event_create() for _ in range(P)]                               # "the noise of the map in slot p is complete"
     ev_free = [ctxs[p].event_create() for p in range(P)]                             # "the erosion of the map in slot p is complete": the slot may be overwritten

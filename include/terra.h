@@ -135,6 +135,10 @@ int  terra_device_count(void);
 int  terra_create(terra_ctx **out, int device_index);
 void terra_destroy(terra_ctx *ctx);
 int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
+/* priority of the context's OWN stream: level > 0 highest, < 0 lowest, 0 default (hipStreamCreateWithPriority; the stream is drained and re-created).  With several
+ * contexts in flight on one GPU, the latency-bound work (a heightmap's erosion: ~1000 short-lived waves) goes on a high-priority context so that its workgroups are
+ * dispatched as soon as resources free up beside another context's chip-filling noise kernel.  Never changes a result. */
+int  terra_set_stream_priority(terra_ctx *ctx, int level);
 int  terra_synchronize(terra_ctx *ctx);
 
 /* ---- events: stream-level ordering between contexts (hipEventRecord / hipStreamWaitEvent; the host never blocks).  The engine keeps several generator objects in

@@ -17,6 +17,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	uint64_t tile2_gave_up = 0; // (the two-wave tile kernel exists only on the device)
 	void init(int) {}
 	void set_stream(void *) {}
+	void set_priority(int) {}
 	void sync() {}
 	void *alloc(size_t bytes) {void *p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p;}
 	void free(void *p) {::free(p);}
