@@ -604,3 +604,4 @@ int terra_timer_stop(terra_ctx *ctx, float *ms) {TERRA_CHECK_CTX TERRA_TRY float
 
 } // extern "C"
 #include "terra_multi.hpp"
+#include "terra_dgrid.hpp"

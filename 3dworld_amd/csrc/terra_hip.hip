@@ -113,6 +113,30 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipError_t const e = hipDeviceEnablePeerAccess(other.device, 0);
 		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {(void)hipGetLastError();}
 	}
+	// ---- virtual memory management (terra_dgrid: ONE grid whose row strips live on several GPUs, mapped back to back in one address range).
+	// A strip is a physical allocation on its device (hipMemCreate) that can leave the process as a POSIX file descriptor; every process (or every device of one
+	// process) reserves a range, maps all strips into it in order and enables access for its own device: kernels then address the whole grid through one plain pointer and
+	// rows that live on another GPU are reached over xGMI by ordinary loads and stores.
+	hipMemAllocationProp vm_prop() const {
+		hipMemAllocationProp p; memset(&p, 0, sizeof(p));
+		p.type = hipMemAllocationTypePinned; p.requestedHandleTypes = hipMemHandleTypePosixFileDescriptor;
+		p.location.type = hipMemLocationTypeDevice; p.location.id = device;
+		return p;
+	}
+	size_t vm_granularity() {use(); hipMemAllocationProp const p = vm_prop(); size_t g = 0; TERRA_HIP_CHECK(hipMemGetAllocationGranularity(&g, &p, hipMemAllocationGranularityRecommended)); return g ? g : ((size_t)2 << 20);}
+	void *vm_create(size_t bytes) {use(); hipMemAllocationProp const p = vm_prop(); hipMemGenericAllocationHandle_t h = nullptr; TERRA_HIP_CHECK(hipMemCreate(&h, bytes, &p, 0)); return (void *)h;}
+	int vm_export_fd(void *h) {use(); int fd = -1; TERRA_HIP_CHECK(hipMemExportToShareableHandle((void *)&fd, (hipMemGenericAllocationHandle_t)h, hipMemHandleTypePosixFileDescriptor, 0)); return fd;}
+	void *vm_import_fd(int fd) {use(); hipMemGenericAllocationHandle_t h = nullptr; TERRA_HIP_CHECK(hipMemImportFromShareableHandle(&h, (void *)&fd, hipMemHandleTypePosixFileDescriptor)); return (void *)h;}
+	void *vm_reserve(size_t total, size_t align) {use(); void *p = nullptr; TERRA_HIP_CHECK(hipMemAddressReserve(&p, total, align, nullptr, 0)); return p;}
+	void vm_map(void *base, size_t off, void *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemMap((uint8_t *)base + off, bytes, 0, (hipMemGenericAllocationHandle_t)h, 0));}
+	static void vm_set_access(void *base, size_t total, int const *devices, size_t n) {
+		std::vector<hipMemAccessDesc> d(n);
+		for (size_t i = 0; i < n; ++i) {memset(&d[i], 0, sizeof(d[i])); d[i].location.type = hipMemLocationTypeDevice; d[i].location.id = devices[i]; d[i].flags = hipMemAccessFlagsProtReadWrite;}
+		TERRA_HIP_CHECK(hipMemSetAccess(base, total, d.data(), n));
+	}
+	static void vm_unmap(void *base, size_t off, size_t bytes) {(void)hipMemUnmap((uint8_t *)base + off, bytes);}
+	static void vm_release(void *h) {if (h) (void)hipMemRelease((hipMemGenericAllocationHandle_t)h);}
+	static void vm_free(void *base, size_t total) {if (base) (void)hipMemAddressFree(base, total);}
 	// stream-level ordering between contexts (terra_event_*): an event recorded on one context's stream, waited for by another's -- the host never blocks
 	void *event_create() {use(); hipEvent_t e = nullptr; TERRA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return (void *)e;}
 	void event_record(void *e) {use(); TERRA_HIP_CHECK(hipEventRecord((hipEvent_t)e, stream));}

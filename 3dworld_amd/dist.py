@@ -93,3 +93,197 @@ def sharded_tile_mesh_shadows(terra, dist, tiles, light_pos, make_zvals, alloc_s
         if rows:
             dist.send(torch.from_numpy(np.ascontiguousarray(edge_out[rows, 1])).to(dev), dst=dst)
     return mine, sm_ptr
+
+
+# ---------------------------------------------------------------- ONE heightmap on several GPUs, erosion included (terra_dgrid)
+
+def exchange_fds(rank, world, fd, tag):
+    """every rank hands the file descriptor of its strip to every other rank of the node over unix sockets (SCM_RIGHTS): returns {rank: fd} of the peers.
+    `tag` names the rendezvous (unique per grid and job, e.g. f"{MASTER_PORT}_{k}"); the caller runs a barrier before (nobody connects to a stale socket of an earlier
+    job) -- a rank starts listening, then connects to the others with retries, so no barrier is needed in between."""
+    import os
+    import socket
+    import time
+    base = os.environ.get("TERRA_DGRID_SOCKDIR", "/tmp")
+    def path(r):
+        return os.path.join(base, f"terra_dgrid_{tag}_{r}.sock")
+    got = {}
+    if world == 1:
+        return got
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        os.unlink(path(rank))
+    except FileNotFoundError:
+        pass
+    srv.bind(path(rank))
+    srv.listen(world)
+    try:
+        for peer in range(world):  # send mine to everybody else
+            if peer == rank:
+                continue
+            deadline = time.time() + 120.0
+            while True:
+                c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    c.connect(path(peer))
+                    break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    c.close()
+                    if time.time() > deadline:
+                        raise TimeoutError(f"terra_dgrid: rank {peer} never opened its socket")
+                    time.sleep(0.01)
+            socket.send_fds(c, [rank.to_bytes(4, "little")], [fd])
+            c.close()
+        srv.settimeout(120.0)
+        while len(got) < world - 1:  # and take theirs
+            conn, _ = srv.accept()
+            msg, fds, _, _ = socket.recv_fds(conn, 4, 1)
+            conn.close()
+            got[int.from_bytes(msg, "little")] = fds[0]
+    finally:
+        srv.close()
+        try:
+            os.unlink(path(rank))
+        except FileNotFoundError:
+            pass
+    return got
+
+
+def strip_rows_aligned(terra_mod, terra, nx, ny, world):
+    """row strips of an nx x ny float grid whose byte sizes are multiples of the mapping granularity (terra_dgrid_granularity: 2 MiB on MI355X): rows per strip rounded
+    up to the next multiple that satisfies it; the last strips may be short or empty.  Returns [(r0, r1)] * world and the padded strip size in bytes."""
+    import math
+    gran = terra_mod.DistributedGrid.granularity(terra)
+    row_bytes = nx * 4
+    unit = gran // math.gcd(gran, row_bytes)           # rows per granule-aligned block
+    per = -(-ny // world)
+    per = -(-per // unit) * unit
+    rows = [(min(r * per, ny), min((r + 1) * per, ny)) for r in range(world)]
+    return rows, per * row_bytes
+
+
+def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag):
+    """ONE nx x ny float grid over all ranks of `dist`: this rank's rows live in its HBM, everybody maps the whole grid (see include/terra.h, terra_dgrid_*).
+    Returns (grid, rows) with grid.ptr the mapped device pointer and rows[r] = (r0, r1) of rank r."""
+    import os
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
+    rows, strip_bytes = strip_rows_aligned(terra_mod, terra, nx, ny, world)
+    g = terra_mod.DistributedGrid(terra, [strip_bytes] * world, rank)
+    if world > 1:
+        dist.barrier()
+        fd = g.export_fd()
+        peers = exchange_fds(rank, world, fd, tag)
+        os.close(fd)
+        for r, pfd in peers.items():
+            g.import_fd(r, pfd)
+            os.close(pfd)
+    g.map()
+    if world > 1:
+        dist.barrier()
+    return g, rows
+
+
+class OneHeightmapPipeline:
+    """STRONG scaling of the whole hot path on ONE grid: every step produces one nx x ny heightmap with heightmap_t::proc_gen semantics (src/heightmap.cpp:130-187: eval loop,
+    min(vals), apply_erosion over the whole map in serial droplet order) on all ranks together.
+
+      noise     rank r evaluates its row strip of the step's grid into its own HBM (terra_gen_grid_rows_minmax_dev: bit-identical to those rows of a single-GPU grid)
+      min       min(vals) of the whole map = all_reduce(min) of one float (RCCL over xGMI under "nccl", gloo in the CPU test); the collective is also the step's barrier:
+                when it returns, every strip of the step's grid is written
+      erosion   the step's grid is a terra_dgrid (all strips mapped back to back on every rank): rank s % world runs terra_apply_erosion_dev over the mapped pointer on one of
+                its eroder contexts while everybody goes on with the next steps' noise; droplets that start in another rank's rows reach them over xGMI.  Serial droplet
+                order, the single-GPU kernels: the result is the single-GPU result bit for bit.
+      reuse     `grids` grids are in flight; before a rank contributes to the all_reduce of step s it waits (host) until the erosion of step s - grids + 1 is complete if
+                it was that step's eroder -- so when the all_reduce of step s returns anywhere, that erosion is complete everywhere and step s + 1 may overwrite its grid."""
+
+    def __init__(self, terra_mod, make_ctx, cfg, dist, nx, ny, droplets, tag, grids=8, eroders=2, coll_device="cpu"):
+        import threading
+        self.pkg, self.dist, self.nx, self.ny, self.droplets = terra_mod, dist, nx, ny, droplets
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
+        self.nctx = make_ctx()
+        self.st = self.nctx.init_scene(cfg)
+        self.ectx = [make_ctx() for _ in range(eroders)]
+        for c in self.ectx:
+            c.init_scene(cfg)
+        self.G = grids
+        self.grids, self.rows = [], None
+        for g in range(grids):
+            dg, rows = create_distributed_grid(terra_mod, self.nctx, dist, nx, ny, f"{tag}_{g}")
+            self.grids.append(dg)
+            self.rows = rows
+        self.coll_device = coll_device
+        self._threading = threading
+
+    def close(self):
+        for c in [self.nctx] + self.ectx:
+            c.synchronize()
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.barrier()  # nobody unmaps a strip a peer may still be reading
+        for g in self.grids:
+            g.destroy()
+        self.nctx.close()
+        for c in self.ectx:
+            c.close()
+
+    def _all_reduce_min(self, v):
+        if self.dist is None or not self.dist.is_initialized():
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float32, device=self.coll_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def run(self, k, origin=None, collect=None):
+        """k steps.  origin(s) -> (x0, y0) of step s's grid (default: the nx x ny grid centred on the origin); collect(s, ptr) is called on the eroding rank when step s's
+        grid is final (before it can be overwritten)."""
+        import queue
+        pkg, N = self.pkg, self.nx
+        r0, r1 = self.rows[self.rank]
+        done = {}
+        jobs = [queue.Queue() for _ in self.ectx]
+        errs = []
+
+        def eroder(i):
+            c = self.ectx[i]
+            while True:
+                job = jobs[i].get()
+                if job is None:
+                    return
+                s, g, mn = job
+                try:
+                    c.apply_erosion_dev(self.grids[g].ptr, self.nx, self.ny, mn, self.droplets, pkg.ERODE_MINZ_IS_MIN)
+                    c.synchronize()
+                    if collect is not None:
+                        collect(s, self.grids[g].ptr)
+                except Exception as e:  # noqa: BLE001
+                    errs.append(repr(e))
+                finally:
+                    done[s].set()
+        th = [self._threading.Thread(target=eroder, args=(i,)) for i in range(len(self.ectx))]
+        for x in th:
+            x.start()
+        mine = 0
+        try:
+            for s in range(k):
+                g = s % self.G
+                x0, y0 = origin(s) if origin is not None else (-self.nx / 2, -self.ny / 2)
+                mn = float("inf")
+                if r1 > r0:
+                    mn, _ = self.nctx.gen_grid_rows_minmax_dev(self.grids[g].ptr + r0 * N * 4, x0, y0, self.st.DX_VAL, self.st.DY_VAL, self.nx, self.ny, r0, r1 - r0, pkg.GEN_GLACIATE)
+                j = s - self.G + 1
+                if j >= 0 and j % self.world == self.rank:
+                    done[j].wait()  # my erosion of the grid that step s + 1 overwrites is complete before I let all_reduce(s) complete anywhere
+                mn = self._all_reduce_min(mn)
+                if errs:
+                    break
+                if s % self.world == self.rank:
+                    done[s] = self._threading.Event()
+                    jobs[mine % len(jobs)].put((s, g, mn))
+                    mine += 1
+        finally:
+            for q in jobs:
+                q.put(None)
+            for x in th:
+                x.join()
+        if errs:
+            raise RuntimeError("; ".join(errs))

@@ -189,6 +189,13 @@ _PROTOS = {
     "terra_multi_gen_grid_rows_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _f3, _f3]),
     "terra_multi_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_multi_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
+    "terra_dgrid_granularity": (_sz, [_vp]),
+    "terra_dgrid_create": (_i32, [_vp, _u32, C.POINTER(_sz), _u32, C.POINTER(_vp)]),
+    "terra_dgrid_export_fd": (_i32, [_vp, C.POINTER(_i32)]),
+    "terra_dgrid_import_fd": (_i32, [_vp, _u32, _i32]),
+    "terra_dgrid_map": (_i32, [_vp, C.POINTER(_vp)]),
+    "terra_dgrid_destroy": (None, [_vp]),
+    "terra_multi_dgrid_create": (_i32, [_vp, C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_vp)]),
     "terra_tiles_mesh_shadows_edges_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
     "terra_malloc": (_i32, [_vp, C.POINTER(_vp), _sz]),
     "terra_free": (_i32, [_vp, _vp]),
@@ -571,6 +578,44 @@ class Terra:
         return Generator(self)
 
 
+class DistributedGrid:
+    """terra_dgrid: ONE array whose strips live on several GPUs, mapped back to back in this rank's address space (HIP virtual memory management).
+    rank r: g = DistributedGrid(terra, strip_bytes, r); fd = g.export_fd() -> peers; g.import_fd(j, fd_j) for every other strip; ptr = g.map()"""
+
+    def __init__(self, terra, strip_bytes, local_strip):
+        self.t = terra
+        arr = (_sz * len(strip_bytes))(*[int(b) for b in strip_bytes])
+        h = _vp()
+        terra._ck(terra.lib.terra_dgrid_create(terra.ctx, len(strip_bytes), arr, local_strip, C.byref(h)))
+        self.h, self.strip_bytes, self.local, self.ptr = h, [int(b) for b in strip_bytes], local_strip, None
+
+    @staticmethod
+    def granularity(terra):
+        return int(terra.lib.terra_dgrid_granularity(terra.ctx))
+
+    def export_fd(self):
+        fd = _i32()
+        self.t._ck(self.t.lib.terra_dgrid_export_fd(self.h, C.byref(fd)))
+        return fd.value
+
+    def import_fd(self, strip, fd):
+        self.t._ck(self.t.lib.terra_dgrid_import_fd(self.h, strip, fd))
+
+    def map(self):
+        p = _vp()
+        self.t._ck(self.t.lib.terra_dgrid_map(self.h, C.byref(p)))
+        self.ptr = p.value
+        return self.ptr
+
+    def strip_ptr(self, i):
+        return self.ptr + sum(self.strip_bytes[:i])
+
+    def destroy(self):
+        if self.h:
+            self.t.lib.terra_dgrid_destroy(self.h)
+            self.h = None
+
+
 class TerraMulti:
     """terra_multi: several contexts (one per entry of `devices`, indices may repeat) driven from this process, each by its own host thread inside a call."""
 
@@ -618,6 +663,15 @@ class TerraMulti:
         return self.ctxs[0].state()
 
     def synchronize(self): self._ck(self.lib.terra_multi_synchronize(self.m))
+
+    def dgrid_create(self, strip_bytes):
+        """strip i on context i's device, all mapped back to back: (handle, device pointer valid on every context's device); free with dgrid_destroy"""
+        arr = (_sz * self.n)(*[int(b) for b in strip_bytes])
+        h, p = _vp(), _vp()
+        self._ck(self.lib.terra_multi_dgrid_create(self.m, arr, C.byref(h), C.byref(p)))
+        return h, p.value
+
+    def dgrid_destroy(self, h): self.lib.terra_dgrid_destroy(h)
 
     def tiles_create_zvals(self, tile_xy, iters_tt=0):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)

@@ -376,6 +376,23 @@ int  terra_multi_tiles_mesh_shadows(terra_multi *m, const int32_t *tile_xy, uint
 int  terra_tiles_mesh_shadows_edges_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask,
                                         const float *d_edge_in, const uint8_t *h_edge_in_present, float *d_edge_out);
 
+/* ---- ONE grid whose row strips live on several GPUs ("erosion on one big grid").  apply_erosion works on one shared array in serial droplet order
+ * (src/erosion.cpp:66-155): the droplets cannot be dealt out, the MEMORY can.  Strip i is a physical allocation on its owner's device; every rank maps all strips back
+ * to back into one address range (HIP virtual memory management; a strip crosses a process boundary as a POSIX file descriptor, e.g. over a unix socket with
+ * SCM_RIGHTS -- 3dworld_amd/dist.py).  Each rank then fills its own rows with terra_gen_grid_rows_minmax_dev at HBM speed, and ONE rank runs terra_apply_erosion_dev on the
+ * mapped pointer: rows that live on another GPU are read and written over xGMI by the same kernels -- bit for bit the single-GPU result.
+ *   rank r:  terra_dgrid_create(ctx, W, strip_bytes, r, &g); terra_dgrid_export_fd(g, &fd) -> send fd to the peers; terra_dgrid_import_fd(g, j, fd_j) for j != r;
+ *            terra_dgrid_map(g, &d_grid)                 strip sizes must be multiples of terra_dgrid_granularity(ctx) (2 MiB on MI355X)
+ * terra_multi_dgrid_create: the same inside one process -- strip i on context i's device, one pointer that every context's device may use. */
+typedef struct terra_dgrid terra_dgrid;
+size_t terra_dgrid_granularity(terra_ctx *ctx);
+int  terra_dgrid_create(terra_ctx *ctx, uint32_t n_strips, const size_t *strip_bytes, uint32_t local_strip, terra_dgrid **out);
+int  terra_dgrid_export_fd(terra_dgrid *g, int *fd);                    /* a new descriptor of the local strip (the caller closes it after sending) */
+int  terra_dgrid_import_fd(terra_dgrid *g, uint32_t strip, int fd);     /* a peer's strip (the descriptor may be closed afterwards) */
+int  terra_dgrid_map(terra_dgrid *g, void **d_base);
+void terra_dgrid_destroy(terra_dgrid *g);
+int  terra_multi_dgrid_create(terra_multi *m, const size_t *strip_bytes, terra_dgrid **out, void **d_base);
+
 /* ---- plumbing for callers without a HIP runtime of their own (tests, ctypes) */
 int  terra_malloc(terra_ctx *ctx, void **d_ptr, size_t bytes);
 int  terra_free(terra_ctx *ctx, void *d_ptr);

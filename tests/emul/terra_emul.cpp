@@ -10,6 +10,8 @@
 #include <chrono>
 #include <stdlib.h>
 #include <omp.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	std::chrono::steady_clock::time_point t0;
@@ -28,6 +30,26 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void d2d(void *dst, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void copy_from_peer(void *dst, cpu_backend_t &, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void enable_peer(cpu_backend_t &) {}
+	// the host analog of the device's virtual memory management (terra_dgrid): a strip is a memfd, a grid a PROT_NONE reservation that the strips are mapped into
+	// (MAP_SHARED | MAP_FIXED), the shareable handle the file descriptor itself -- so two emulator PROCESSES really share a grid, like two ranks share HBM
+	int device = 0;
+	struct vm_handle_t {int fd;};
+	size_t vm_granularity() {return (size_t)sysconf(_SC_PAGESIZE);}
+	void *vm_create(size_t bytes) {
+		int const fd = memfd_create("terra_dgrid_strip", 0);
+		if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {if (fd >= 0) close(fd); throw std::runtime_error("memfd_create / ftruncate failed");}
+		return new vm_handle_t{fd};
+	}
+	int vm_export_fd(void *h) {int const fd = dup(((vm_handle_t *)h)->fd); if (fd < 0) throw std::runtime_error("dup failed"); return fd;}
+	void *vm_import_fd(int fd) {int const d = dup(fd); if (d < 0) throw std::runtime_error("dup failed"); return new vm_handle_t{d};}
+	void *vm_reserve(size_t total, size_t) {void *p = mmap(nullptr, total, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); if (p == MAP_FAILED) throw std::bad_alloc(); return p;}
+	void vm_map(void *base, size_t off, void *h, size_t bytes) {
+		if (mmap((uint8_t *)base + off, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, ((vm_handle_t *)h)->fd, 0) == MAP_FAILED) throw std::runtime_error("mmap of a strip failed");
+	}
+	static void vm_set_access(void *, size_t, int const *, size_t) {}
+	static void vm_unmap(void *base, size_t off, size_t bytes) {(void)mmap((uint8_t *)base + off, bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED | MAP_NORESERVE, -1, 0);}
+	static void vm_release(void *h) {if (h) {close(((vm_handle_t *)h)->fd); delete (vm_handle_t *)h;}}
+	static void vm_free(void *base, size_t total) {if (base) munmap(base, total);}
 	void *event_create() {return malloc(1);} // every "launch" has finished when it returns: events order nothing here
 	void event_record(void *) {}
 	void event_wait(void *) {}

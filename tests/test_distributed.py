@@ -276,3 +276,98 @@ def test_rccl_one_rank_group_runs_the_device_collectives(orc, tmp_path):
     tiles = [(tx, ty) for ty in range(0, 2) for tx in range(0, 3)]  # (the worker's scene: mesh_freq_filter = 1, as the oracle still has it)
     z = np.stack([orc.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tiles])
     assert (orc.tiles_mesh_shadows(tiles, z, (0.7, 0.4, 0.3)) == np.load(tmp_path / "sm.npy")).all()
+
+
+# ---------------------------------------------------------------- ONE heightmap on several ranks, erosion included (terra_dgrid + OneHeightmapPipeline)
+
+def _dgrid_download(t, ptr, shape):
+    out = np.empty(shape, np.float32)
+    t._ck(t.lib.terra_memcpy_d2h(t.ctx, out.ctypes.data, ptr, out.nbytes))
+    return out
+
+
+def _one_grid_worker(rank, world, port, lib, out_dir, nx, ny, droplets, steps, grids):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("3dworld_amd")
+    dmod = importlib.import_module("3dworld_amd.dist")
+    pipe = dmod.OneHeightmapPipeline(pkg, lambda: pkg.Terra(0, lib), pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1), dist, nx, ny, droplets, tag=f"t{port}", grids=grids, eroders=2)
+    assert pipe.rows[0][0] == 0 and pipe.rows[-1][1] == ny and all(a[1] == b[0] for a, b in zip(pipe.rows, pipe.rows[1:]))
+
+    def collect(s, ptr):  # on the rank that eroded step s: the WHOLE grid through the mapped pointer (the other rank's rows included)
+        np.save(os.path.join(out_dir, f"grid_{s}.npy"), _dgrid_download(pipe.ectx[0], ptr, (ny, nx)))
+
+    pipe.run(steps, origin=lambda s: (-nx / 2 + 40.0 * s, -ny / 2 - 25.0 * s), collect=collect)
+    dist.barrier()
+    # every rank sees the same final contents of the last grids through its own mapping (rank 1 reads rows rank 0 owns and the other way round)
+    for g in range(min(grids, steps)):
+        s_last = max(s for s in range(steps) if s % grids == g)
+        np.save(os.path.join(out_dir, f"view_{rank}_{s_last}.npy"), _dgrid_download(pipe.nctx, pipe.grids[g].ptr, (ny, nx)))
+    pipe.close()
+    dist.destroy_process_group()
+
+
+def _check_one_grid(orc, out_dir, nx, ny, droplets, steps, grids, world):
+    import orclib
+    s_ = orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    for s in range(steps):
+        ref = orc.gen_grid(-nx / 2 + 40.0 * s, -ny / 2 - 25.0 * s, s_.DX_VAL, s_.DY_VAL, nx, ny, 1)
+        orc.apply_erosion(ref, float(ref.min()), droplets)
+        orclib.assert_bit_equal(ref, np.load(os.path.join(out_dir, f"grid_{s}.npy")), f"step {s}: the eroded grid as its eroder sees it")
+        if s >= steps - grids:
+            for r in range(world):
+                f = os.path.join(out_dir, f"view_{r}_{s}.npy")
+                if os.path.exists(f):
+                    orclib.assert_bit_equal(ref, np.load(f), f"step {s}: rank {r}'s view of the grid")
+
+
+def test_two_ranks_erode_one_heightmap_whose_strips_live_on_both(emul_lib, orc, tmp_path):
+    """SURVEY 8e row 3, the exact form: ONE heightmap per step on two ranks -- each evaluates its row strip into its own memory, min(vals) by all_reduce, the step's
+    eroder runs apply_erosion over the mapped grid (the other rank's rows included), eroders alternate, three grids in flight.  Here the strips are memfds mapped into
+    both emulator processes; on the GPU box they are hipMemCreate allocations (tests/test_distributed.py::test_two_ranks_erode_one_heightmap_on_the_hip_library)."""
+    import torch.multiprocessing as mp
+    nx, ny, droplets, steps, grids = 256, 100, 300, 7, 3
+    port = 36500 + os.getpid() % 2000
+    mp.spawn(_one_grid_worker, args=(2, port, emul_lib, str(tmp_path), nx, ny, droplets, steps, grids), nprocs=2, join=True)
+    _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
+
+
+@pytest.mark.gpu
+def test_two_ranks_erode_one_heightmap_on_the_hip_library(orc, tmp_path):
+    """the same through libterra_hip.so: two processes on GPU 0, every strip a hipMemCreate allocation exported as a file descriptor, imported and mapped by the peer
+    (hipMemImportFromShareableHandle / hipMemMap / hipMemSetAccess) -- the erosion kernels run over memory that belongs to another process"""
+    import torch.multiprocessing as mp
+    nx, ny, droplets, steps, grids = 2048, 1024, 1000, 6, 3
+    port = 37500 + os.getpid() % 2000
+    mp.spawn(_one_grid_worker, args=(2, port, None, str(tmp_path), nx, ny, droplets, steps, grids), nprocs=2, join=True)
+    _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
+
+
+@pytest.mark.gpu
+def test_in_process_distributed_grid_two_contexts(pkg, orc):
+    """terra_multi_dgrid_create: two contexts of one process, strip i allocated by context i, one pointer for both -- context 0 fills its rows, context 1 its rows,
+    context 1 erodes the whole grid"""
+    import orclib
+    nx, ny, droplets = 2048, 1024, 2000
+    m = pkg.TerraMulti([0, 0])
+    try:
+        st = m.init_scene(pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+        h, ptr = m.dgrid_create([nx * (ny // 2) * 4] * 2)
+        mins = []
+        for i in range(2):
+            r0 = i * (ny // 2)
+            mn, _ = m.ctxs[i].gen_grid_rows_minmax_dev(ptr + r0 * nx * 4, -nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, r0, ny // 2, pkg.GEN_GLACIATE)
+            mins.append(mn)
+        m.synchronize()
+        m.ctxs[1].apply_erosion_dev(ptr, nx, ny, min(mins), droplets, pkg.ERODE_MINZ_IS_MIN)
+        z = _dgrid_download(m.ctxs[1], ptr, (ny, nx))
+        m.dgrid_destroy(h)
+        s_ = orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+        ref = orc.gen_grid(-nx / 2, -ny / 2, s_.DX_VAL, s_.DY_VAL, nx, ny, 1)
+        assert np.float32(min(mins)) == ref.min()
+        orc.apply_erosion(ref, float(ref.min()), droplets)
+        orclib.assert_bit_equal(ref, z, "one grid over two contexts")
+    finally:
+        m.close()
