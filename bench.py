@@ -9,20 +9,23 @@ The z grid never leaves HBM inside the timed region (there is no input grid; par
   python bench.py [--gpus N --steps K --warmup W --size 16384 --mode sine --droplets 1000]   (N > 1: starts N ranks itself through torch.distributed.run)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU; WORLD_SIZE must equal --gpus)
 
-`value` (the headline): every rank owns one independent N x N region of the world (origin shifted by rank*N cells in x), generated and
-eroded exactly like the reference erodes each tile alone on its clamp-padded copy (src/tiled_mesh.cpp:515): no data-path
-collective, weak scaling, `pipelines` heightmaps in flight per GPU.
+`value` (the headline):
+  N = 1   one 16384^2 heightmap per step on the GPU, `pipelines` heightmaps in flight (own context / stream / host thread each).
+  N > 1   ONE 16384^2 heightmap per step on all N GPUs TOGETHER, erosion included -- STRONG scaling (`value_strong`): rank r evaluates its row strip into its own HBM, min(vals)
+          is one float through all_reduce(min) over RCCL, and the step's grid is a terra_dgrid (every rank's strip mapped back to back on every rank, HIP virtual memory
+          management): rank (step mod N) erodes the whole grid in serial droplet order over the mapped pointer, reaching the other ranks' rows over xGMI, while the next steps'
+          noise runs everywhere (3dworld_amd/dist.py::OneHeightmapPipeline).  Bit-identical to the single-GPU heightmap.  The independent-regions number of round 1-3 (every
+          rank its own N x N region, no collective, weak scaling) is measured in the same run and printed as `value_weak` / detail.regions.
 
 The same run also measures, under `detail` (incl. `dense_erosion`: 10^6 droplets on the bench grid and on BASELINE config 3's 4096^2 map) (all ranks take part, rank 0 reports; switch off with --no-extras):
   single   one heightmap in flight (no overlap of a map's erosion with the next map's noise): the latency of one map
-  strips   STRONG scaling of ONE 16384^2 grid: rank r evaluates rows [r*N/W, (r+1)*N/W) (terra_gen_grid_rows_minmax_dev, bit-identical to the
-           full grid), min(vals) = one float through all_reduce(min) over RCCL; erosion does not shard in the reference's semantics
-           (one shared grid, serial droplet order: replicas only) and is excluded from that line
+  strips   the noise + min part of the one-grid line alone: rank r evaluates rows [r*N/W, (r+1)*N/W) (terra_gen_grid_rows_minmax_dev, bit-identical to the
+           full grid), min(vals) = one float through all_reduce(min) over RCCL; no erosion
   tiles    STRONG scaling of BASELINE config 4: the 64 x 64 tiles of 128^2 block-partitioned over the ranks
            (tile_t::create_zvals + stats + normals; with 0 and with 1000 droplets per tile), no collective
   voxels   STRONG scaling of BASELINE config 5: one 512^3 voxel noise field as y slabs (terra_voxel_fill_slab_dev), no collective
   modes    the same 16384^2 step with simplex / Perlin / domain-warp noise (rank 0)
-`--workload strips|tiles` makes one of those the headline `value` instead (for a scaling sweep of that mode alone).
+`--workload onegrid|regions|strips|tiles` makes one of those the headline `value` instead (for a scaling sweep of that mode alone; onegrid also at N = 1).
 
 Prints ONE JSON line on rank 0.  `roofline` = dominant kernel, measured with HIP events on the library's stream;
 `cpu_baseline` = the reference's own CPU code (oracle/_ref) or the C restatement (oracle/) timed on this host, rank 0, N=1.
@@ -60,7 +63,10 @@ def parse():
                    "erosion itself, the min read back in between (the default: measured fastest, profiles/r04_schedule_ab.txt); streamed = one context enqueues every map's noise on its "
                    "stream (kernels only, min(vals) stays in HBM), the pipelines' contexts erode the maps as their noise completes (terra_event_*: stream-level ordering)")
     p.add_argument("--priorities", default="erosion-high", choices=["none", "erosion-high", "noise-low"], help="streamed schedule: stream priorities of the eroding contexts / the noise producer")
-    p.add_argument("--workload", default="heightmap", choices=["heightmap", "strips", "tiles"], help="which measurement is the headline `value`")
+    p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
+                   help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
+                        "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
+    p.add_argument("--grids-in-flight", type=int, default=8, help="onegrid: distributed grids in flight (a grid is reused this many steps later)")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -416,13 +422,34 @@ def main():
 
     K, W = args.steps, args.warmup
     detail = {}
+    value_weak = value_strong = None
+    # ---- ONE heightmap per step on all ranks together, erosion included: the strips live in their owners' HBM and are mapped back to back on every rank
+    # (terra_dgrid), min(vals) is one float through all_reduce(min), rank s % world erodes step s's grid over the mapped pointer (remote rows over xGMI) while the next
+    # steps' noise runs; 3dworld_amd/dist.py::OneHeightmapPipeline.  Bit-identical to the single-GPU heightmap (tests/test_distributed.py).
+    want_onegrid = args.workload == "onegrid" or (args.workload == "heightmap" and world > 1)
+    pipe = None
+    if want_onegrid:
+        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid() if world == 1 else 'job'}"
+        pipe = dmod.OneHeightmapPipeline(pkg, lambda: pkg.Terra(local_rank), pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves), dist if have_group and world > 1 else None,
+                                         N, N, args.droplets, tag=tag, grids=max(2, args.grids_in_flight), eroders=2, coll_device=coll_dev)
     # ---- the headline
-    if args.workload == "heightmap":
-        dt = timed(lambda k: run_steps(k, P), K, max(W, 2 * P))  # at least two untimed steps per pipeline: first-use allocations, graph captures and clocks settle
-        value = world * cells * K / dt / 1e9
-        scaling = "weak"
-        workload = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
-        par = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU ({args.schedule} schedule)"
+    if args.workload in ("heightmap", "regions", "onegrid"):
+        workload_w = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
+        par_w = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU ({args.schedule} schedule)"
+        workload_s = (f"ONE {N}x{N} heightmap per step on {world} GPU(s) together: {args.mode} noise {args.octaves} octaves + glaciate/islands as row strips in their owners' HBM, min(vals) by "
+                      f"all_reduce(min), {args.droplets}-droplet erosion of the whole grid in serial droplet order by rank (step mod {world}) over the mapped strips (heightmap_t::proc_gen semantics)")
+        par_s = (f"{world} row strips of {N // world} rows mapped back to back on every rank (terra_dgrid, HIP virtual memory management; remote rows over xGMI), one 4-byte all_reduce(min) per step over "
+                 + (("RCCL" if backend == "nccl" else backend) if have_group else "nothing (one rank)") + f", {max(2, args.grids_in_flight)} grids in flight, eroders rotate over the ranks")
+        if args.workload != "onegrid":
+            dt = timed(lambda k: run_steps(k, P), K, max(W, 2 * P))  # at least two untimed steps per pipeline: first-use allocations, graph captures and clocks settle
+            value_weak = world * cells * K / dt / 1e9
+            value, scaling, workload, par = value_weak, "weak", workload_w, par_w
+        if pipe is not None:
+            dts = timed(lambda k: pipe.run(k), K, max(W, 2), "onegrid")
+            value_strong = cells * K / dts / 1e9
+            if value_weak is not None:
+                detail["regions"] = {"value_weak": round(value_weak, 4), "ms_per_step": round(dt / K * 1e3, 4), "scaling": "weak", "workload": workload_w, "parallelism": par_w}
+            dt, value, scaling, workload, par = dts, value_strong, "strong", workload_s, par_s
     elif args.workload == "strips":
         dt = timed(strips_steps, K, max(W, 2))
         value = cells * K / dt / 1e9
@@ -440,7 +467,10 @@ def main():
         barrier()
         if rank == 0:
             print(json.dumps({"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
+                              "value_strong": None if value_strong is None else round(value_strong, 4), "value_weak": None if value_weak is None else round(value_weak, 4),
                               "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling, "config": {"workload": workload, "parallelism": par}, "headline_only": True}), flush=True)
+        if pipe is not None:
+            pipe.close()
         nctx.close()
         for c in ctxs:
             c.close()
@@ -566,8 +596,9 @@ def main():
                 "nofma_peak_tops": VALU_NOFMA_TOPS, "nofma_frac": round(tflops / VALU_NOFMA_TOPS, 4),
                 "note": "fp32 VALU bound; the peak counts fused multiply-adds, which bit-parity with the FMA-free CPU reference forbids (mul and add issue separately): nofma_frac is the fraction of the reachable rate"}
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
+               "value_strong": None if value_strong is None else round(value_strong, 4), "value_weak": None if value_weak is None else round(value_weak, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if args.workload == "heightmap" else 1, "parallelism": par},
+               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if (args.workload in ("heightmap", "regions") and scaling == "weak") else 1, "parallelism": par},
                "latency_ms_single": detail.get("single", {}).get("latency_ms_single", round(ms_step, 4) if P == 1 else None),
                "roofline": roof, "detail": dict(detail, erosion=rep, rccl=rccl_note,
                                                   clock_warmup={"ms": args.clock_warmup_ms, "untimed_steps_run": spin_log,
@@ -578,6 +609,8 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
+    if pipe is not None:
+        pipe.close()
     for e in ev_noise + ev_free:
         nctx.event_destroy(e)
     nctx.close()
