@@ -252,7 +252,7 @@ template<class BE> struct terra_engine {
 
 	// grow-only device scratch
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
-	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_shadow, s_vox, s_sk, s_mm;
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_shadow, s_shadow_map, s_shadow_gather, s_vox, s_sk, s_mm;
 	bool tiled_mesh_ao = false; // enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778)
 	uint8_t const *hmap_pix = nullptr; int hmap_w = 0, hmap_h = 0, hmap_nc = 0; // terrain_hmap_manager's image (device memory, owned by the caller)
 	float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;                          // src/mesh_gen.cpp:41, set by set_mesh_height_scales_for_zval_range
@@ -263,7 +263,7 @@ template<class BE> struct terra_engine {
 		return (T *)s.p;
 	}
 	~terra_engine() {
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 		if (d_noise_lut) be.free(d_noise_lut);
 		if (d_sinTable) be.free(d_sinTable);
@@ -1151,13 +1151,23 @@ template<class BE> struct terra_engine {
 		be.h2d_async(d_order, order.data(), (size_t)n*4);
 		be.h2d_async(d_adj, adj.data(), adj.size()*4);
 		be.fill32(d_out, 0, (size_t)2*nslots*zv*2);
-		for (size_t k = 0; k < virt_slot.size(); ++k) {
-			unsigned long long *dst = d_out + ((size_t)virt_slot[k].first*nslots + virt_slot[k].second)*zv;
-			if (d_edge_in) { // encode on the device: (1 << 32 | float bits) where a height was handed over, 0 = nothing
-				float const *src = d_edge_in + (size_t)virt_src[k]*zv;
-				be.launch(zv, [=] TERRA_LAMBDA (size_t e) {float const v = src[e]; uint32_t b; memcpy(&b, &v, 4); dst[e] = (v > -1.0E6f) ? ((1ull << 32) | b) : 0ull;}, 64);
+		if (d_edge_in && !virt_slot.empty()) { // encode on the device, ONE launch for all virtual slots: (1 << 32 | float bits) where a height was handed over, 0 = nothing
+			std::vector<uint32_t> vmap(2*virt_slot.size()); // (destination row of d_out, source row of d_edge_in) per virtual slot
+			for (size_t k = 0; k < virt_slot.size(); ++k) {vmap[2*k] = virt_slot[k].first*nslots + virt_slot[k].second; vmap[2*k+1] = virt_src[k];}
+			uint32_t *d_vmap = scratch<uint32_t>(s_shadow_map, vmap.size());
+			be.h2d_async(d_vmap, vmap.data(), vmap.size()*4);
+			float const *ein = d_edge_in;
+			be.launch(virt_slot.size()*zv, [=] TERRA_LAMBDA (size_t j) {
+				uint32_t const k = (uint32_t)(j / zv), e = (uint32_t)(j % zv);
+				float const v = ein[(size_t)d_vmap[2*k+1]*zv + e]; uint32_t b; memcpy(&b, &v, 4);
+				d_out[(size_t)d_vmap[2*k]*zv + e] = (v > -1.0E6f) ? ((1ull << 32) | b) : 0ull;
+			});
+		}
+		else {
+			for (size_t k = 0; k < virt_slot.size(); ++k) {
+				unsigned long long *dst = d_out + ((size_t)virt_slot[k].first*nslots + virt_slot[k].second)*zv;
+				be.h2d_async(dst, virt.data() + k*zv, (size_t)zv*8);
 			}
-			else {be.h2d_async(dst, virt.data() + k*zv, (size_t)zv*8);}
 		}
 		uint32_t const npaths = 4*zv;
 		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*nslots*zv);

@@ -105,14 +105,17 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (src_be.device == device) {TERRA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));}
 		else {TERRA_HIP_CHECK(hipMemcpyPeerAsync(dst, device, src, src_be.device, bytes, stream));} // xGMI when peer access is on, staged through the host otherwise
 	}
+	std::vector<int> peers_mapped; // devices whose memory this device's kernels may address (hipDeviceEnablePeerAccess succeeded)
 	void enable_peer(hip_backend_t &other) { // best effort
 		if (other.device == device) return;
 		int can = 0;
 		if (hipDeviceCanAccessPeer(&can, device, other.device) != hipSuccess || !can) return;
 		if (hipSetDevice(device) != hipSuccess) return;
 		hipError_t const e = hipDeviceEnablePeerAccess(other.device, 0);
-		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {(void)hipGetLastError();}
+		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {(void)hipGetLastError(); return;}
+		if (std::find(peers_mapped.begin(), peers_mapped.end(), other.device) == peers_mapped.end()) {peers_mapped.push_back(other.device);}
 	}
+	bool can_map(hip_backend_t const &other) const {return other.device == device || std::find(peers_mapped.begin(), peers_mapped.end(), other.device) != peers_mapped.end();}
 	// ---- virtual memory management (terra_dgrid: ONE grid whose row strips live on several GPUs, mapped back to back in one address range).
 	// A strip is a physical allocation on its device (hipMemCreate) that can leave the process as a POSIX file descriptor; every process (or every device of one
 	// process) reserves a range, maps all strips into it in order and enables access for its own device: kernels then address the whole grid through one plain pointer and

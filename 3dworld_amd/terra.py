@@ -189,6 +189,8 @@ _PROTOS = {
     "terra_multi_gen_grid_rows_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _f3, _f3]),
     "terra_multi_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_multi_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
+    "terra_multi_shadow_layout": (_i32, [_vp, _vp, _u32, _f3, _vp, _vp, _vp]),
+    "terra_multi_tiles_mesh_shadows_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_dgrid_granularity": (_sz, [_vp]),
     "terra_dgrid_create": (_i32, [_vp, _u32, C.POINTER(_sz), _u32, C.POINTER(_vp)]),
     "terra_dgrid_export_fd": (_i32, [_vp, C.POINTER(_i32)]),
@@ -701,6 +703,20 @@ class TerraMulti:
         sm = np.empty((n, 130, 130), np.uint8)
         self._ck(self.lib.terra_multi_tiles_mesh_shadows(self.m, txy.ctypes.data, n, z.ctypes.data, (C.c_float * 3)(*light_pos), sm.ctypes.data))
         return sm
+
+    def shadow_layout(self, tile_xy, light_pos):
+        """where the device-resident mesh-shadow pass wants the tiles: (ctx_of_tile, pos_in_ctx, tiles_per_ctx)"""
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        n = len(txy)
+        a, b, c = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(self.n, np.uint32)
+        self._ck(self.lib.terra_multi_shadow_layout(self.m, txy.ctypes.data, n, (C.c_float * 3)(*light_pos), a.ctypes.data, b.ctypes.data, c.ctypes.data))
+        return a, b, c
+
+    def tiles_mesh_shadows_dev(self, tile_xy, z_ptrs, light_pos, smask_ptrs):
+        """z_ptrs[s] / smask_ptrs[s]: context s's strip in the order of shadow_layout, on its device"""
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        zp = (_vp * self.n)(*z_ptrs); sp = (_vp * self.n)(*smask_ptrs)
+        self._ck(self.lib.terra_multi_tiles_mesh_shadows_dev(self.m, txy.ctypes.data, len(txy), zp, (C.c_float * 3)(*light_pos), sp))
 
     def foreach(self, fn):
         """fn(Terra, index) -> int on every context's host thread at once (the callback re-enters Python: the calls serialise on the GIL except inside the library)"""

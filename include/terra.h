@@ -371,6 +371,12 @@ int  terra_multi_gen_grid_rows_dev(terra_multi *m, float x0, float y0, float dx,
 int  terra_multi_voxel_fill_dev(terra_multi *m, float *const *d_out, uint32_t nx, uint32_t ny, uint32_t nz, const float lo_pos[3], const float vsz[3], const float offset[3],
                                 float mag, float freq, int rseed1, int rseed2, int gen_mode, float zscale, int normalize_to_1);
 int  terra_multi_tiles_mesh_shadows(terra_multi *m, const int32_t *tile_xy, uint32_t n, const float *h_zvals, const float light_pos[3], uint8_t *h_smask);
+/* the device-resident form: the terrain already lies on the GPUs as strips of tile columns.  terra_multi_shadow_layout tells where: tile i belongs to context
+ * ctx_of_tile[i] and is the pos_in_ctx[i]-th tile of that context's arrays (tiles_per_ctx[s] tiles on context s: rows toward the light first); d_zvals[s] / d_smask[s] are
+ * [tiles_per_ctx[s]][130][130] on context s's device.  Between strips only the border tiles' 130-float edges move, device to device: an event behind a chunk's kernels, the
+ * next strip's stream waits for it and gathers the edges out of the peer's buffer in one launch (xGMI; staged copies when the devices cannot map each other). */
+int  terra_multi_shadow_layout(terra_multi *m, const int32_t *tile_xy, uint32_t n, const float light_pos[3], uint32_t *ctx_of_tile, uint32_t *pos_in_ctx, uint32_t *tiles_per_ctx);
+int  terra_multi_tiles_mesh_shadows_dev(terra_multi *m, const int32_t *tile_xy, uint32_t n, float *const *d_zvals, const float light_pos[3], uint8_t *const *d_smask);
 /* the device-resident form of the halo arrays of terra_tiles_mesh_shadows_halo_dev: d_edge_in / d_edge_out are [n][2][130] floats in device memory
  * (d_edge_in is read where h_edge_in_present says so); what terra_multi_tiles_mesh_shadows hands from GPU to GPU */
 int  terra_tiles_mesh_shadows_edges_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, const float light_pos[3], uint8_t *d_smask,

@@ -30,6 +30,8 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void d2d(void *dst, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void copy_from_peer(void *dst, cpu_backend_t &, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void enable_peer(cpu_backend_t &) {}
+	bool can_map(cpu_backend_t const &) const {return map_peers;} // TERRA_EMUL_NO_PEER_MAP=1: take the staged-copy path of the multi-context mesh shadows
+	bool map_peers = !(getenv("TERRA_EMUL_NO_PEER_MAP") && getenv("TERRA_EMUL_NO_PEER_MAP")[0] == '1');
 	// the host analog of the device's virtual memory management (terra_dgrid): a strip is a memfd, a grid a PROT_NONE reservation that the strips are mapped into
 	// (MAP_SHARED | MAP_FIXED), the shareable handle the file descriptor itself -- so two emulator PROCESSES really share a grid, like two ranks share HBM
 	int device = 0;

@@ -1008,6 +1008,26 @@ def case_multi_contexts(pkg, lib_path, orc, ndev=3, big=False):
                 want = orc.tiles_mesh_shadows(tl, zt, light)
                 got = m.tiles_mesh_shadows(tl, zt, light)
                 assert (got == want).all(), (light, [tl[i] for i in np.argwhere((got != want).any(axis=(1, 2))).ravel()][:6])
+                # the device-resident form: every context holds its strip of tile columns in the layout's order; twice (the edge buffers are kept between calls)
+                owner, pos, per = m.shadow_layout(tl, light)
+                assert int(per.sum()) == len(tl) and all(sorted(pos[owner == s_]) == list(range(per[s_])) for s_ in range(ndev))
+                zb = [m.ctxs[s_].alloc(max(1, int(per[s_])) * 130 * 130 * 4) for s_ in range(ndev)]
+                sb = [m.ctxs[s_].alloc(max(1, int(per[s_])) * 130 * 130) for s_ in range(ndev)]
+                for s_ in range(ndev):
+                    if per[s_]:
+                        zs_ = np.empty((int(per[s_]), 130, 130), np.float32)
+                        zs_[pos[owner == s_]] = zt[owner == s_]
+                        zb[s_].upload(zs_)
+                for _rep in range(2):
+                    m.tiles_mesh_shadows_dev(tl, [b.ptr for b in zb], light, [b.ptr for b in sb])
+                    m.synchronize()
+                    got2 = np.empty_like(want)
+                    for s_ in range(ndev):
+                        if per[s_]:
+                            got2[owner == s_] = sb[s_].download(np.uint8, (int(per[s_]), 130, 130))[pos[owner == s_]]
+                    assert (got2 == want).all(), ("device-resident", light)
+                for b in zb + sb:
+                    b.free()
         # foreach: one independent heightmap region per context, all at once (bench.py's headline, from one process)
         N = 96 if not big else 2048
         outs = [None] * ndev

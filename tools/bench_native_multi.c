@@ -116,7 +116,41 @@ int main(int argc, char **argv) {
 		CK(terra_multi_tiles_mesh_shadows(m, tiles, NT, hz, light, hs));
 		dt = now() - t0;
 		size_t shadowed = 0; for (size_t i = 0; i < (size_t)NT*130*130; ++i) {shadowed += hs[i] != 0;}
-		printf("{\"what\": \"mesh shadows 64x64 tiles\", \"gpus\": %d, \"ms\": %.2f, \"shadowed_cells\": %zu, \"exchange\": \"border edges device to device per tile row\"}\n", G, 1e3*dt, shadowed);
+		printf("{\"what\": \"mesh shadows 64x64 tiles, host zvals in / host masks out (277 MB up, 69 MB down)\", \"gpus\": %d, \"ms\": %.2f, \"shadowed_cells\": %zu}\n", G, 1e3*dt, shadowed);
+		/* the device-resident form: the terrain lies on the GPUs as strips of tile columns (terra_multi_shadow_layout), only the border edges move */
+		uint32_t *own = (uint32_t *)malloc(NT*4), *pos = (uint32_t *)malloc(NT*4), per[MAXG];
+		CK(terra_multi_shadow_layout(m, tiles, NT, light, own, pos, per));
+		float *sz[MAXG]; uint8_t *ssm[MAXG];
+		for (int g = 0; g < G; ++g) {
+			terra_ctx *ctx = terra_multi_ctx(m, (uint32_t)g);
+			size_t const k = per[g] ? per[g] : 1;
+			CK(terra_malloc(ctx, (void **)&sz[g], k*130*130*4)); CK(terra_malloc(ctx, (void **)&ssm[g], k*130*130));
+		}
+		for (uint32_t i = 0; i < NT; ++i) {CK(terra_memcpy_h2d(terra_multi_ctx(m, own[i]), sz[own[i]] + (size_t)pos[i]*130*130, hz + (size_t)i*130*130, (size_t)130*130*4));}
+		CK(terra_multi_tiles_mesh_shadows_dev(m, tiles, NT, sz, light, ssm)); CK(terra_multi_synchronize(m));
+		int const sreps = 4;
+		t0 = now();
+		for (int r = 0; r < sreps; ++r) {CK(terra_multi_tiles_mesh_shadows_dev(m, tiles, NT, sz, light, ssm));}
+		CK(terra_multi_synchronize(m));
+		dt = (now() - t0)/sreps;
+		size_t shadowed2 = 0;
+		{uint8_t *tmp = (uint8_t *)malloc((size_t)130*130);
+		 for (uint32_t i = 0; i < NT; ++i) {CK(terra_memcpy_d2h(terra_multi_ctx(m, own[i]), tmp, ssm[own[i]] + (size_t)pos[i]*130*130, (size_t)130*130)); for (int j = 0; j < 130*130; ++j) {shadowed2 += tmp[j] != 0;}}
+		 free(tmp);}
+		printf("{\"what\": \"mesh shadows 64x64 tiles, device resident strips\", \"gpus\": %d, \"ms\": %.2f, \"shadowed_cells\": %zu, \"same_as_host_form\": %d, \"exchange\": \"event + one gather launch per chunk over peer-mapped edge buffers\"}\n", G, 1e3*dt, shadowed2, shadowed2 == shadowed);
+		{ /* one context, the same terrain (terra_tiles_mesh_shadows_dev): what not sharding costs */
+			terra_ctx *c0 = terra_multi_ctx(m, 0); float *z1; uint8_t *s1;
+			CK(terra_malloc(c0, (void **)&z1, (size_t)NT*130*130*4)); CK(terra_malloc(c0, (void **)&s1, (size_t)NT*130*130));
+			CK(terra_memcpy_h2d(c0, z1, hz, (size_t)NT*130*130*4));
+			CK(terra_tiles_mesh_shadows_dev(c0, tiles, NT, z1, light, s1)); CK(terra_synchronize(c0));
+			t0 = now();
+			for (int r = 0; r < sreps; ++r) {CK(terra_tiles_mesh_shadows_dev(c0, tiles, NT, z1, light, s1));}
+			CK(terra_synchronize(c0));
+			printf("{\"what\": \"mesh shadows 64x64 tiles, ONE context\", \"ms\": %.2f}\n", 1e3*(now() - t0)/sreps);
+			terra_free(c0, z1); terra_free(c0, s1);
+		}
+		for (int g = 0; g < G; ++g) {terra_free(terra_multi_ctx(m, (uint32_t)g), sz[g]); terra_free(terra_multi_ctx(m, (uint32_t)g), ssm[g]);}
+		free(own); free(pos);
 		free(hz); free(hs);
 	}
 	for (int g = 0; g < G; ++g) {terra_ctx *ctx = terra_multi_ctx(m, (uint32_t)g); terra_free(ctx, dz[g]); terra_free(ctx, dst[g]); terra_free(ctx, dnm[g]); terra_free(ctx, dmn[g]);}
