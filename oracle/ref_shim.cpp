@@ -209,7 +209,46 @@ REF_API void ref_set_num_threads(int n) {omp_set_num_threads(n);}
 // Mirrors main(): create_sin_table(); set_scene_constants(); load config; init_terrain_mesh(); gen_scene()->gen_mesh()
 // (src/3DWorld.cpp:2393-2460, src/build_world.cpp:628). gen_mesh() generates the 128^2 ground mesh, which is what
 // seeds zmin/zmax before estimate_zminmax() -> zmax_est (src/mesh_gen.cpp:337-343,447-485).
+#ifdef TERRA_ENGINE_LOOP
+// ---- engine in the loop (oracle/Makefile target `engine`): this build of the harness links the PATCHED mesh_gen.cpp / erosion.cpp of oracle/engine_patch.py (INTEGRATION.md
+// sections 2, 3) against a terra library.  terra_sync_globals is INTEGRATION.md section 1 verbatim: the engine hands its config values and derived globals over once after
+// gen_scene(); ref_set_use_hip_terrain is the config key.  Everything else the tests call is the reference's own code: heightmap_t::proc_gen, tile_t::create_zvals ...
+#include "terra_cxx.hpp"
+extern bool use_hip_terrain;
+extern float MESH_START_MAG, MESH_START_FREQ, MESH_MAG_MULT, MESH_FREQ_MULT;
+void gen_rx_ry(float &rx, float &ry);
+static void terra_sync_globals() {
+	terra_config c = {};
+	c.mesh_x = MESH_X_SIZE; c.mesh_y = MESH_Y_SIZE; c.scene_x = X_SCENE_SIZE; c.scene_y = Y_SCENE_SIZE; c.scene_z = Z_SCENE_SIZE;
+	c.mesh_height = mesh_height_scale; c.mesh_scale = mesh_scale; c.mesh_seed = mesh_seed; c.mesh_freq_filter = mesh_freq_filter;
+	c.mesh_gen_mode = mesh_gen_mode; c.mesh_gen_shape = mesh_gen_shape; c.glaciate = GLACIATE; c.custom_glaciate_exp = custom_glaciate_exp;
+	memcpy(c.hmap, &hmap_params, sizeof(c.hmap));   // 14 floats, src/mesh.h:84-88
+	c.erode_amount = erode_amount; c.water_h_off = water_h_off; c.water_h_off_rel = water_h_off_rel; c.relh_adj_tex = relh_adj_tex; c.ocean_wave_height = ocean_wave_height;
+	c.start_mag = MESH_START_MAG; c.start_freq = MESH_START_FREQ; c.mag_mult = MESH_MAG_MULT; c.freq_mult = MESH_FREQ_MULT;
+	terra_state s = {};
+	memcpy(s.sinTable, sinTable, sizeof(s.sinTable)); s.start_eval_sin = start_eval_sin;
+	s.MESH_HEIGHT = MESH_HEIGHT; s.DX_VAL = DX_VAL; s.DY_VAL = DY_VAL; s.DX_VAL_INV = DX_VAL_INV; s.DY_VAL_INV = DY_VAL_INV; s.HALF_DXY = HALF_DXY; s.dxdy = dxdy; s.XY_SCENE_SIZE = XY_SCENE_SIZE;
+	s.mesh_scale = mesh_scale; s.mesh_scale_z_inv = mesh_scale_z_inv; s.mesh_height_scale = mesh_height_scale;
+	s.zmax_est = zmax_est; s.zmin = zmin; s.zmax = zmax; s.water_plane_z = water_plane_z; s.glaciate_exp = glaciate_exp; s.clip_hd1 = clip_hd1; s.relh_adj_tex = relh_adj_tex;
+	gen_rx_ry(s.rx, s.ry);
+	terra_cxx::set_engine_state(c, s);
+}
+static void ref_init_engine(ref_config_t const *c);
+REF_API void ref_init(ref_config_t const *c) { // the engine derives its globals with its own CPU path (gen_scene), THEN hands them over
+	bool const hip(use_hip_terrain);
+	use_hip_terrain = 0;
+	ref_init_engine(c);
+	use_hip_terrain = hip;
+	if (hip) {terra_sync_globals();}
+}
+REF_API void ref_set_use_hip_terrain(int v) {use_hip_terrain = (v != 0); if (use_hip_terrain) {terra_sync_globals();}}
+REF_API int  ref_get_use_hip_terrain() {return use_hip_terrain ? 1 : 0;}
+extern unsigned hip_terrain_calls;
+REF_API unsigned ref_hip_terrain_calls() {return hip_terrain_calls;} // build_arrays + apply_erosion calls that went through include/terra.h
+static void ref_init_engine(ref_config_t const *c) {
+#else
 REF_API void ref_init(ref_config_t const *c) {
+#endif
 	MESH_X_SIZE = c->mesh_x; MESH_Y_SIZE = c->mesh_y;
 	X_SCENE_SIZE = c->scene_x; Y_SCENE_SIZE = c->scene_y; Z_SCENE_SIZE = c->scene_z;
 	create_sin_table();
@@ -243,11 +282,16 @@ REF_API void ref_get_state(ref_state_t *s) {
 	gen_rx_ry(s->rx, s->ry);
 }
 
-REF_API void ref_set_zmax_est(float v) {set_zmax_est(v); zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height();}
-REF_API void ref_set_water_plane_z(float v) {water_plane_z = v;}
-REF_API void ref_set_mode(int mode, int shape) {mesh_gen_mode = mode; mesh_gen_shape = shape;}
-REF_API void ref_set_start_eval_sin(int v) {start_eval_sin = v;}
-REF_API void ref_set_erode_amount(float v) {erode_amount = v;}
+#ifdef TERRA_ENGINE_LOOP
+#define TERRA_RESYNC if (use_hip_terrain) {terra_sync_globals();}
+#else
+#define TERRA_RESYNC
+#endif
+REF_API void ref_set_zmax_est(float v) {set_zmax_est(v); zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height(); TERRA_RESYNC}
+REF_API void ref_set_water_plane_z(float v) {water_plane_z = v; TERRA_RESYNC}
+REF_API void ref_set_mode(int mode, int shape) {mesh_gen_mode = mode; mesh_gen_shape = shape; TERRA_RESYNC}
+REF_API void ref_set_start_eval_sin(int v) {start_eval_sin = v; TERRA_RESYNC}
+REF_API void ref_set_erode_amount(float v) {erode_amount = v; TERRA_RESYNC}
 REF_API void ref_get_ground_mesh(float *out) {memcpy(out, mesh_height_store.data(), mesh_height_store.size()*sizeof(float));}
 REF_API float ref_sin_table(int i) {return sin_table[i];}
 

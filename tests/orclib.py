@@ -110,6 +110,13 @@ def build_oracle():
     subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.DEVNULL)
 
 
+def engine_lib(which):
+    """oracle/_ref/libengine_<emul|hip>.so: the reference's own mesh_gen / heightmap / tiled_mesh ... with the INTEGRATION.md patch applied, linked against the host
+    emulation library or against libterra_hip.so (oracle/Makefile: engine); None when it was not built (no /root/reference here and nothing prebuilt)"""
+    p = os.path.join(ORACLE_DIR, "_ref", f"libengine_{which}.so")
+    return p if os.path.exists(p) else None
+
+
 def ref_available():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "liboracle_ref.so"))
 
@@ -120,9 +127,11 @@ _fp = C.POINTER(C.c_float)
 class Checker:
     """Thin wrapper; kind = 'orc' (C restatement) or 'ref' (reference TUs)."""
 
-    def __init__(self, kind="orc"):
+    def __init__(self, kind="orc", path=None):
+        """path: another build of the "ref" harness, e.g. oracle/_ref/libengine_emul.so (the reference's callers compiled against include/terra.h, see engine_available())"""
         self.kind = kind
-        path = os.path.join(ORACLE_DIR, "liboracle.so" if kind == "orc" else os.path.join("_ref", "liboracle_ref.so"))
+        if path is None:
+            path = os.path.join(ORACLE_DIR, "liboracle.so" if kind == "orc" else os.path.join("_ref", "liboracle_ref.so"))
         if not os.path.exists(path):
             build_oracle()
         self.lib = C.CDLL(path)
@@ -184,6 +193,10 @@ class Checker:
         f("quantize16", None, [C.c_void_p, C.c_size_t, C.c_void_p, _fp, _fp])
         f("voxel_fill", None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int])
         f("voxel_rdata", None, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p])
+        if hasattr(self.lib, "ref_set_use_hip_terrain"):  # the engine-in-the-loop build (oracle/Makefile: engine)
+            f("set_use_hip_terrain", None, [C.c_int])
+            f("get_use_hip_terrain", C.c_int, [])
+            f("hip_terrain_calls", C.c_uint, [])
         if kind == "orc":
             f("apply_erosion_stats", None, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint, C.POINTER(ErosionStats), C.c_void_p])
 
@@ -208,6 +221,7 @@ class Checker:
     def set_mode(self, mode, shape=0): self._set_mode(mode, shape)
     def set_start_eval_sin(self, v): self._set_start_eval_sin(v)
     def set_erode_amount(self, v): self._set_erode_amount(v)
+    def set_use_hip_terrain(self, v): self._set_use_hip_terrain(int(v))
     def set_num_threads(self, n): self._set_num_threads(n)
     def num_threads(self): return self._num_threads()
     def get_max_sea_level(self): return self._get_max_sea_level()

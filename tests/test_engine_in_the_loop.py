@@ -1,0 +1,119 @@
+"""Engine in the loop: the reference's OWN callers -- heightmap_t::proc_gen (src/heightmap.cpp:130-151), tile_t::create_zvals
+(src/tiled_mesh.cpp:467-546), the mesh_xy_grid_cache_t call pattern of tile_t::create_texture (build_arrays(..., force_sine_mode) + eval_index(x, y, 50),
+src/tiled_mesh.cpp:1099,1114), gen_mesh -- compiled from a scratch copy of the reference with the patch of INTEGRATION.md sections 1-3 applied (oracle/engine_patch.py,
+oracle/Makefile target `engine`) and linked against a terra library.  With `use_hip_terrain` on, every mesh_xy_grid_cache_t::build_arrays and every apply_erosion of those
+callers goes through include/terra.h; the outputs must equal the unpatched reference build (oracle/_ref/liboracle_ref.so) bit for bit.
+
+  CPU box   oracle/_ref/libengine_emul.so  (terra = tests/emul/libterra_emul.so: the same driver and kernel bodies as host loops)
+  GPU box   oracle/_ref/libengine_hip.so   (terra = 3dworld_amd/libterra_hip.so, the product; prebuilt here, travels like liboracle_ref.so)
+
+Also here: include/terra_cxx.hpp EXECUTED (not just parsed) -- tests/cxx_mirror_run.cpp drives terra_cxx::mesh_xy_grid_cache_t / apply_erosion / tiles_create_zvals and
+the values it prints are compared with the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orclib
+from orclib import assert_bit_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def engine_vs_reference(eng, ref, modes=((0, 0), (1, 0), (0, 1))):
+    """the same harness calls on the patched engine (terra behind build_arrays / apply_erosion) and on the unpatched reference"""
+    ref.set_num_threads(1)  # the reference's erosion loop is only defined single-threaded
+    eng.set_num_threads(1)
+    calls0 = eng._hip_terrain_calls()
+    for mode, shape in modes:
+        cfg = orclib.make_config(mesh_gen_mode=mode, mesh_gen_shape=shape, mesh_seed=3, mesh_freq_filter=1)
+        eng.set_use_hip_terrain(1)
+        se, sr = eng.init(cfg), ref.init(cfg)  # the engine derives its globals with its own CPU code, then hands them over
+        assert bytes(se.sinTable) == bytes(sr.sinTable) and se.zmax_est == sr.zmax_est and se.water_plane_z == sr.water_plane_z
+        # heightmap_t::proc_gen: build_arrays + enable_glaciate + eval_index loop, run_erosion -> apply_erosion, from_floats
+        for w, h, iters in ((96, 64, 0), (160, 128, 400)):
+            pe, se_, te_ = eng.heightmap_proc_gen(w, h, iters)
+            pr, sr_, tr_ = ref.heightmap_proc_gen(w, h, iters)
+            assert (pe == pr).all() and (se_, te_) == (sr_, tr_), f"proc_gen {w}x{h} iters {iters} mode {mode}"
+        # tile_t::create_zvals: the tile's generator object, the eval loop, apply_erosion on the tile, sub-block stats
+        for tx, ty, iters in ((0, 0, 0), (-3, 2, 120), (5, -7, 60)):
+            ze, ste = eng.tile_create_zvals(tx, ty, iters)
+            zr, str_ = ref.tile_create_zvals(tx, ty, iters)
+            assert_bit_equal(zr, ze, f"tile ({tx}, {ty}) iters {iters} mode {mode}")
+            assert bytes(ste) == bytes(str_)
+        # the generator object with every argument in play, incl. eval_index(x, y, 50) of create_texture's noise field (first sine term above start_eval_sin)
+        for fs, cv, mss, uc in ((True, 0, 50, True), (False, 0, 0, True), (True, 1, 50, False), (False, 0, 30, True)):
+            a = eng.gen_grid(-64, 64, 80 * sr.DX_VAL, 80 * sr.DY_VAL, 129, 129, 0, cv, mss, force_sine=fs, use_cache=uc)
+            b = ref.gen_grid(-64, 64, 80 * sr.DX_VAL, 80 * sr.DY_VAL, 129, 129, 0, cv, mss, force_sine=fs, use_cache=uc)
+            if fs or mode == 0 or mss == 0:
+                assert_bit_equal(b, a, f"gen_grid_ex mode {mode} {fs} {cv} {mss} {uc}")
+        # landscape weights texture: tile_t::create_texture drives its second noise field through build_arrays(force_sine) + eval_index(x, y, 50)
+        z0, _ = ref.tile_create_zvals(1, 1, 0)
+        we, ge, he = eng.tile_create_weights(1, 1, z0)
+        wr, gr, hr = ref.tile_create_weights(1, 1, z0)
+        assert (we == wr).all() and ge.tobytes() == gr.tobytes() and he == hr
+        # the calls above really crossed the boundary: 2 proc_gen (2 build_arrays + 1 erosion), 3 tiles (3 + 2), 4 generator objects, create_texture's noise field
+        assert eng._hip_terrain_calls() - calls0 >= 13, eng._hip_terrain_calls() - calls0
+        calls0 = eng._hip_terrain_calls()
+        # the patched engine with the key off is the reference
+        eng.set_use_hip_terrain(0)
+        ze, _ = eng.tile_create_zvals(2, 2, 50); zr, _ = ref.tile_create_zvals(2, 2, 50)
+        assert_bit_equal(zr, ze, "use_hip_terrain off")
+        assert eng._hip_terrain_calls() == calls0
+
+
+def test_engine_in_the_loop_emul(ref, emul_lib):
+    lib = orclib.engine_lib("emul")
+    if lib is None:
+        pytest.skip("oracle/_ref/libengine_emul.so not built (needs /root/reference)")
+    eng = orclib.Checker("ref", lib)
+    engine_vs_reference(eng, ref)
+
+
+@pytest.mark.gpu
+def test_engine_in_the_loop_hip(ref):
+    """the reference's callers against the PRODUCT: libengine_hip.so links 3dworld_amd/libterra_hip.so (no emulation anywhere in this test)"""
+    lib = orclib.engine_lib("hip")
+    assert lib is not None, "oracle/_ref/libengine_hip.so did not travel with the repo (build it with `make -C oracle engine` where /root/reference exists)"
+    needed = os.popen(f"readelf -d {lib}").read()
+    assert "libterra_hip.so" in needed and "emul" not in needed
+    eng = orclib.Checker("ref", lib)
+    engine_vs_reference(eng, ref, modes=((0, 0), (1, 0), (4, 0), (0, 1)))
+
+
+# ---- include/terra_cxx.hpp executed
+
+def _run_cxx_mirror(tmp_path, libdir, libname, extra_env=None):
+    exe = str(tmp_path / "cxx_mirror_run")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx_mirror_run.cpp"), "-L", libdir, f"-l{libname}",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
+    env = dict(os.environ, **(extra_env or {}))
+    r = subprocess.run([exe, str(tmp_path / "out.bin")], check=True, capture_output=True, text=True, env=env)
+    assert "cxx mirror ok" in r.stdout, r.stdout + r.stderr
+    return np.fromfile(tmp_path / "out.bin", np.float32)
+
+
+def _check_cxx_mirror(vals, orc):
+    """tests/cxx_mirror_run.cpp writes: a 70 x 50 glaciated grid through mesh_xy_grid_cache_t (build_arrays + enable_glaciate + eval_index), the same grid eroded with 300
+    droplets through terra_cxx::apply_erosion, eval_mesh_sin_terms at 3 points, the zvals of tile (2, -1) with 80 droplets"""
+    s = orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+    g = orc.gen_grid(-35.0, -25.0, s.DX_VAL, s.DY_VAL, 70, 50, 1)
+    k = 70 * 50
+    assert_bit_equal(g.reshape(-1), vals[:k], "terra_cxx::mesh_xy_grid_cache_t")
+    e = g.copy(); orc.apply_erosion(e, float(g.min()), 300)
+    assert_bit_equal(e.reshape(-1), vals[k:2 * k], "terra_cxx::apply_erosion")
+    pts = [(0.5, 0.5), (-10.25, 3.0), (100.0, -77.5)]
+    assert_bit_equal(np.array([orc.eval_mesh_sin_terms(x, y) for x, y in pts], np.float32), vals[2 * k:2 * k + 3], "terra_cxx::eval_mesh_sin_terms")
+    zt, _ = orc.tile_create_zvals(2, -1, 80)
+    assert_bit_equal(zt.reshape(-1), vals[2 * k + 3:2 * k + 3 + 130 * 130], "terra_cxx::tiles_create_zvals")
+
+
+def test_cxx_mirror_header_runs_emul(orc, emul_lib, tmp_path):
+    _check_cxx_mirror(_run_cxx_mirror(tmp_path, os.path.dirname(emul_lib), "terra_emul"), orc)
+
+
+@pytest.mark.gpu
+def test_cxx_mirror_header_runs_hip(orc, tmp_path):
+    _check_cxx_mirror(_run_cxx_mirror(tmp_path, os.path.join(ROOT, "3dworld_amd"), "terra_hip"), orc)
