@@ -65,6 +65,7 @@ int terra_create(terra_ctx **out, int device_index) {
 }
 void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (...) {} delete ctx;}}
 int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
+int terra_release_scratch(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.release_scratch(); TERRA_CATCH}
 int terra_set_stream_priority(terra_ctx *ctx, int level) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_priority(level); TERRA_CATCH}
 int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
 

@@ -262,6 +262,13 @@ template<class BE> struct terra_engine {
 		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
 		return (T *)s.p;
 	}
+	// every grow-only device buffer of the context back to the allocator (they grow again on demand): the erosion ring of a 16384^2 map alone is ~8.5 GiB
+	void release_scratch() {
+		be.sync();
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm}) {if (s->p) {be.free(s->p); s->p = nullptr; s->bytes = 0;}}
+		spec_blocks_clean = nullptr; spec_blocks_n = 0;
+		be.release_scratch();
+	}
 	~terra_engine() {
 		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
@@ -803,22 +810,37 @@ template<class BE> struct terra_engine {
 		if (char const *nc = getenv("TERRA_ERO_NEAR")) {int const v = atoi(nc); sb.near_count = (v >= 0) ? (uint32_t)v : W/(uint32_t)(-v);} // experiment knob (negative: a fraction of the ring); results never depend on it
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
 		size_t const nblocks = (size_t)sb.nbx*sb.nby;
-		// carve one allocation
+		// carve one allocation.  The ring is the one big buffer of the library (~266 KiB per slot): it must fit what the device has free right now -- several contexts share
+		// a GPU (bench.py keeps 4 heightmaps in flight), and a result never depends on W -- so a ring that would not fit is made smaller until it does
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_cks[2], o_ckn[2], o_cku[2], o_ckm[2], o_ckc[2], o_ui[2], o_uv[2], o_un[2];
-		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4);}
-		for (int b = 0; b < 2; ++b) {
-			// (indexed with the stride SPEC_CK_MAX / SPEC_UNDO_MAX per slot; without checkpoints nothing is ever read or written there, so nothing is allocated)
-			size_t const ckn = sb.ck_max ? SPEC_CK_MAX : 0, unn = sb.ck_max ? SPEC_UNDO_MAX : 0;
-			o_cks[b] = carve((size_t)W*ckn*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*ckn*4); o_cku[b] = carve((size_t)W*ckn*4);
-			o_ckm[b] = carve((size_t)W*ckn*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*unn*4); o_uv[b] = carve((size_t)W*unn*4); o_un[b] = carve(W*4);
-		}
-		size_t const o_slot = carve((size_t)W*4*13); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry
-		size_t const o_state = carve((size_t)W*sizeof(droplet_state_t)), o_resume = carve((size_t)W*sizeof(spec_resume_t));
-		size_t const o_next = carve((size_t)W*sb.maxb*4), o_nodeblk = carve((size_t)W*sb.maxb*4), o_dlist = carve((size_t)W*sb.maxb*8), o_ctl = carve(sizeof(spec_ctl_t));
+		size_t o_slot = 0, o_state = 0, o_resume = 0, o_next = 0, o_nodeblk = 0, o_dlist = 0, o_ctl = 0, o_touched = 0;
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
-		size_t const o_touched = carve((size_t)touched_cap*4 + 4);
+		auto layout = [&](uint32_t W) {
+			off = 0;
+			for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)W*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)W*sb.maxb*8); o_bl[b] = carve((size_t)W*sb.maxb*4); o_bc[b] = carve(W*4);}
+			for (int b = 0; b < 2; ++b) {
+				// (indexed with the stride SPEC_CK_MAX / SPEC_UNDO_MAX per slot; without checkpoints nothing is ever read or written there, so nothing is allocated)
+				size_t const ckn = sb.ck_max ? SPEC_CK_MAX : 0, unn = sb.ck_max ? SPEC_UNDO_MAX : 0;
+				o_cks[b] = carve((size_t)W*ckn*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*ckn*4); o_cku[b] = carve((size_t)W*ckn*4);
+				o_ckm[b] = carve((size_t)W*ckn*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*unn*4); o_uv[b] = carve((size_t)W*unn*4); o_un[b] = carve(W*4);
+			}
+			o_slot = carve((size_t)W*4*13); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry
+			o_state = carve((size_t)W*sizeof(droplet_state_t)); o_resume = carve((size_t)W*sizeof(spec_resume_t));
+			o_next = carve((size_t)W*sb.maxb*4); o_nodeblk = carve((size_t)W*sb.maxb*4); o_dlist = carve((size_t)W*sb.maxb*8); o_ctl = carve(sizeof(spec_ctl_t));
+			o_touched = carve((size_t)touched_cap*4 + 4);
+			return off;
+		};
+		{
+			size_t need = layout(W);
+			if (need > s_spec.bytes) { // it has to grow: what is free now + what the old ring gives back, minus a reserve for everybody else's next allocation
+				size_t avail = be.mem_free() + s_spec.bytes, reserve = (size_t)1 << 30;
+				if (char const *mb = getenv("TERRA_ERO_MEM_BUDGET")) {avail = (size_t)strtoull(mb, nullptr, 10); reserve = 0;} // test knob: pretend this many bytes are free
+				while (W > 256 && need + reserve > avail) {W = W - W/4; need = layout(W);}
+				sb.W = W;
+			}
+		}
 		uint8_t *base = scratch<uint8_t>(s_spec, off);
 		for (int b = 0; b < 2; ++b) {
 			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]); // nothing to initialise: only entries below a version's count are ever read

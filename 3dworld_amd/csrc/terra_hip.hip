@@ -74,6 +74,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		(void)hipStreamSynchronize(own_stream); (void)hipStreamDestroy(own_stream);
 		own_stream = stream = ns; pin_off = 0;
 	}
+	size_t mem_free() {use(); size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) != hipSuccess) {(void)hipGetLastError(); return ~(size_t)0 >> 1;} return f;}
+	void release_scratch() { // the backend's own grow-only buffers (the caller has drained the stream)
+		for (void **p : {(void **)&tile_pad, (void **)&tile_undo, (void **)&tile_order, (void **)&tile_acc, (void **)&tile_map, (void **)&vox_p}) {if (*p) {(void)hipFree(*p); *p = nullptr;}}
+		tile_pad_bytes = tile_undo_bytes = tile_order_bytes = tile_acc_bytes = vox_p_bytes = 0; tile_map_count = 0;
+	}
 	void use() {TERRA_HIP_CHECK(hipSetDevice(device));}
 	void set_stream(void *s) {sync(); pin_off = 0; stream = s ? (hipStream_t)s : own_stream;} // cached graphs are stream-agnostic (the stream is given at launch)
 	void sync() {use(); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}

@@ -130,6 +130,7 @@ _PROTOS = {
     "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
     "terra_set_stream_priority": (_i32, [_vp, _i32]),
+    "terra_release_scratch": (_i32, [_vp]),
     "terra_event_create": (_i32, [_vp, C.POINTER(_vp)]),
     "terra_event_record": (_i32, [_vp, _vp]),
     "terra_event_wait": (_i32, [_vp, _vp]),
@@ -305,6 +306,7 @@ class Terra:
     def set_start_eval_sin(self, v): self._ck(self.lib.terra_set_start_eval_sin(self.ctx, v))
     def set_erode_amount(self, v): self._ck(self.lib.terra_set_erode_amount(self.ctx, v))
     def set_stream(self, stream_ptr): self._ck(self.lib.terra_set_stream(self.ctx, stream_ptr))
+    def release_scratch(self): self._ck(self.lib.terra_release_scratch(self.ctx))
     def set_stream_priority(self, level): self._ck(self.lib.terra_set_stream_priority(self.ctx, level))
     def synchronize(self): self._ck(self.lib.terra_synchronize(self.ctx))
     def max_sea_level(self): return self.lib.terra_get_max_sea_level(self.ctx)

@@ -140,6 +140,9 @@ int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's h
  * dispatched as soon as resources free up beside another context's chip-filling noise kernel.  Never changes a result. */
 int  terra_set_stream_priority(terra_ctx *ctx, int level);
 int  terra_synchronize(terra_ctx *ctx);
+/* give every grow-only work buffer of the context back to the device (synchronises first; they grow again on demand).  The one that matters is the speculation ring of
+ * terra_apply_erosion_dev: ~266 KiB per droplet in flight, 8.5 GiB for a 16384^2 map -- its size is also capped by the memory that is free when it has to grow. */
+int  terra_release_scratch(terra_ctx *ctx);
 
 /* ---- events: stream-level ordering between contexts (hipEventRecord / hipStreamWaitEvent; the host never blocks).  The engine keeps several generator objects in
  * flight (height_gens[8], src/tiled_mesh.h:418); here one context can produce (noise of map i, recorded) what another consumes (erosion of map i, its stream waits):

@@ -20,6 +20,8 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void init(int) {}
 	void set_stream(void *) {}
 	void set_priority(int) {}
+	size_t mem_free() {return ~(size_t)0 >> 1;}
+	void release_scratch() {}
 	void sync() {}
 	void *alloc(size_t bytes) {void *p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p;}
 	void free(void *p) {::free(p);}

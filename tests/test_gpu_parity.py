@@ -389,7 +389,7 @@ def test_tile_erosion_two_waves_per_tile_equals_oracle(pkg, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"TERRA_GRAPHS": "0"}, {"TERRA_ERO_CK": "1:16", "TERRA_ERO_NEAR": "4"}, {"TERRA_ERO_CK": "40:0", "TERRA_ERO_LEAD": "0"}, {"TERRA_ERO_BATCH": "1", "TERRA_ERO_LEAD": "1"},
-                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SHADOW_CHAIN": "1", "TERRA_SG_ROWGROUP": "2"}])
+                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SHADOW_CHAIN": "1", "TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}])
 def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
     """the environment knobs of DESIGN.md section 5 choose schedules, launch forms and cross-check kernels, never values: a whole-map erosion with re-traces, an eroded tile
     batch and its mesh shadows under each of them, bit for bit against the oracle (the knobs are read when a context is created)"""
@@ -404,9 +404,11 @@ def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
         z, st, nm, mnz = t.tiles_create_zvals(tiles, 150)
         zo = np.stack([orc.tile_create_zvals(tx, ty, 150)[0] for tx, ty in tiles])
         assert_bit_equal(z, zo, f"eroded tiles under {env}")
+        t.release_scratch()  # every grow-only buffer back to the device: the next calls allocate afresh
         sm = t.tiles_mesh_shadows(tiles, z, (0.6, 0.5, 0.4))
         so = orc.tiles_mesh_shadows(tiles, zo, (0.6, 0.5, 0.4))
         assert np.array_equal(np.asarray(sm), np.asarray(so)), f"mesh shadows under {env}"
+        pc.case_erosion_vs_oracle(pkg, t, orc, 384, 1500)
     finally:
         t.close()
 

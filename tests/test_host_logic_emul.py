@@ -1,6 +1,7 @@
 """CPU tests of the HOST LOGIC of libterra_hip (scene start-up, kernel sequencing, speculative erosion rounds, tile batching,
 C-ABI argument checking) through tests/emul/libterra_emul.so -- the same driver and kernel bodies with a host-loop backend.
 This is test infrastructure, not a product path; the product (libterra_hip.so) is exercised by tests/test_gpu_parity.py."""
+import numpy as np
 import pytest
 
 import parity_cases as pc
@@ -247,3 +248,22 @@ def test_mesh_seed_zero_static_generator_continues_emul(pkg, emul):
 def test_streamed_pipeline_device_min_and_events_emul(pkg, emul_lib, orc):
     """terra_gen_grid_minmax_async_dev + terra_event_* + terra_apply_erosion_devmin_dev through the C ABI (bench.py's streamed schedule), host logic"""
     pc.case_streamed_pipeline(pkg, lambda: pkg.Terra(0, emul_lib), orc, N=200, maps=5, P=2, droplets=(150, 0, 600))
+
+
+def test_erosion_ring_is_capped_by_free_memory_and_scratch_can_be_released(pkg, emul_lib, orc, monkeypatch):
+    """the speculation ring shrinks to what the device has free (TERRA_ERO_MEM_BUDGET pretends a small device) -- more ring generations, the same result; and
+    terra_release_scratch between calls changes nothing either"""
+    monkeypatch.setenv("TERRA_ERO_MEM_BUDGET", str(96 << 20))
+    t = pkg.Terra(0, emul_lib)
+    try:
+        pc.case_erosion_vs_oracle(pkg, t, orc, 160, 3000)
+        rep = t.erosion_report().as_dict()
+        assert rep["windows"] >= 8, rep  # 3000 droplets through a ring of at most ~360 slots (96 MiB / 266 KiB)
+        t.release_scratch()
+        pc.case_erosion_vs_oracle(pkg, t, orc, 160, 700)
+        z, st, nm, mnz = t.tiles_create_zvals([(0, 0), (1, -1)], 50)
+        t.release_scratch()
+        z2, _, _, _ = t.tiles_create_zvals([(0, 0), (1, -1)], 50)
+        assert (z.view(np.uint32) == z2.view(np.uint32)).all()
+    finally:
+        t.close()
