@@ -582,19 +582,23 @@ def main():
         tflops = fl * cells / (ms_k * 1e-3) / 1e12
         hbm = 4.0 * cells / (ms_k * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, profiles/*_pmc_traffic.json), only for the configuration they were taken on
-        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic_source = None
+        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]["k_sine_grid"]
                 if mode == 0 and N == 16384 and args.octaves == 8:
                     traffic = pm["hbm_bytes_per_launch"]
+                    traffic_source = f"profiles/{fn} (2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over tools/prof_driver.py: a recorded constant of this configuration, not measured in this run)"
                     break
             except Exception:
                 pass
         roof = {"bound": "valu", "kernel": "k_sine_grid (+table kernels)" if mode == 0 else f"k_noise_grid<{args.mode}>", "achieved": round(tflops, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "algorithmic_flops": fl * cells, "algorithmic_bytes": 4 * cells,
+                "frac": round(tflops / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "algorithmic_flops": fl * cells, "algorithmic_bytes": 4 * cells,
                 "hbm_achieved_gbs": round(hbm, 2), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm / HBM_PEAK_GBS, 4),
                 "nofma_peak_tops": VALU_NOFMA_TOPS, "nofma_frac": round(tflops / VALU_NOFMA_TOPS, 4),
-                "note": "fp32 VALU bound; the peak counts fused multiply-adds, which bit-parity with the FMA-free CPU reference forbids (mul and add issue separately): nofma_frac is the fraction of the reachable rate"}
+                "note": "fp32 VALU bound; the peak counts fused multiply-adds at 2.4 GHz.  Bit-parity with the FMA-free CPU reference forbids fusing (mul and add issue separately): nofma_frac is the "
+                        "fraction of that rate; and the chip sustains ~1.94 GHz under this kernel (GRBM_GUI_ACTIVE / duration, profiles/r04_clock_ramp.txt): at the clock it gets, its 6041 "
+                        "VALU instructions per wave keep the vector ALUs issuing ~90 % of the time (profiles/r04_pmc_summary.txt)"}
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
                "value_strong": None if value_strong is None else round(value_strong, 4), "value_weak": None if value_weak is None else round(value_weak, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
