@@ -202,7 +202,8 @@ def _last_json_line(text):
 @pytest.mark.gpu
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it: two ranks come up (both on GPU 0 of the 1-GPU test box, so gloo carries the barrier / max-over-ranks
-    instead of RCCL, which wants one device per rank) and rank 0's line reports n_gpus = 2 with the aggregate of both regions"""
+    instead of RCCL, which wants one device per rank).  At N > 1 the headline is the STRONG one -- ONE heightmap per step on both ranks together, erosion included, its strips
+    hipMemCreate allocations exchanged as file descriptors and mapped on both ranks -- with the independent-regions aggregate beside it as value_weak"""
     import subprocess
     env = dict(os.environ, TERRA_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -211,8 +212,17 @@ def test_bench_self_launches_two_ranks():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _last_json_line(r.stdout)
-    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["value"] > 0
-    assert abs(line["value"] - 2 * 2048 * 2048 / (line["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * line["value"]
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["value"] == line["value_strong"] and line["value_weak"] > 0 and "ONE 2048x2048 heightmap per step on 2 GPU" in line["config"]["workload"]
+    assert abs(line["value"] - 2048 * 2048 / (line["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * line["value"]                      # one grid per step, not one per rank
+    reg = line["detail"]["regions"]
+    assert reg["scaling"] == "weak" and abs(reg["value_weak"] - 2 * 2048 * 2048 / (reg["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * reg["value_weak"]
+    # --workload regions keeps the weak line as the headline (a scaling sweep of that mode alone)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--size", "2048", "--no-extras", "--no-cpu-baseline", "--workload", "regions"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] == line["value_weak"] and line["value_strong"] is None
 
 
 @pytest.mark.gpu
