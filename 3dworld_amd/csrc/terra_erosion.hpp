@@ -44,6 +44,19 @@ struct grid_view_t {
 		size_t const side = (size_t)2*EROSION_PAD*NX + (size_t)z*(2*EROSION_PAD);
 		return border + side + ((X < EROSION_PAD) ? X : (X - xsize));                                   // X - xsize in [PAD, 2*PAD)
 	}
+	// the same address without a branch (selects only): for loops that issue many loads back to back -- at()'s four-way branch costs an exec-mask region per cell, and
+	// every region re-reads the view's fields when the view sits behind a pointer
+	TERRA_HD float *at_sel(int X, int Z) const {
+		int const x = X - EROSION_PAD, z = Z - EROSION_PAD;
+		bool const in = ((unsigned)x < (unsigned)xsize) & ((unsigned)z < (unsigned)ysize);
+		long long const io = (long long)z*xsize + x;                                              // interior (meaningless when !in)
+		long long const top = (long long)Z*NX + X, bot = (long long)(Z - ysize)*NX + X;           // the two bands of the ring store
+		long long const side = (long long)2*EROSION_PAD*NX + (long long)z*(2*EROSION_PAD) + ((X < EROSION_PAD) ? X : (X - xsize));
+		long long const ro = (Z < EROSION_PAD) ? top : ((Z >= EROSION_PAD + ysize) ? bot : side);
+		float *const dense = interior + top;                                                        // border == nullptr: `interior` IS the dense padded array
+		float *const ring = in ? (interior + io) : (border + ro);
+		return (border == nullptr) ? dense : ring;
+	}
 	TERRA_HD static size_t border_floats(int xsize, int ysize) {return (size_t)2*EROSION_PAD*(xsize + 2*EROSION_PAD) + (size_t)2*EROSION_PAD*ysize;}
 };
 
@@ -677,6 +690,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		unsigned long long const clk2 = TERRA_CLOCK();
 		unsigned long long clk3 = clk2; (void)clk3;
 		constexpr int PER_LANE = EW*EW/64;
+		typename BACK::src_t const S = back.src_snapshot(); // (after prepare_window: the candidate tables of the new window are in LDS)
 		float gv[TERRA_LANE_SLOTS][PER_LANE]; uint32_t dbits[TERRA_LANE_SLOTS]; // a lane's 16 cells of the new window and their dirty bits
 		TERRA_EACH_LANE(lane) {
 			float (&g)[PER_LANE] = gv[TERRA_LANE_SLOT(lane)];
@@ -687,6 +701,9 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 			// (Written as if / else per cell the compiler waits for every load before it issues the next: 16 latencies, 14 us per move on the critical path of a dense run.)
 			float gl[PER_LANE];
 			unsigned slow_mask = 0, own_mask = 0, old_mask = 0, in_mask = 0;
+			// One pass, free of branches and of waits for memory: per cell the old window's value and dirty flag, the source byte (LDS), what it points to (LDS), the load
+			// (HBM / L2) -- all from the snapshot S, nothing through a pointer to the argument block, so no cell waits for another cell's load.
+			uint32_t selv[PER_LANE];
 #pragma unroll
 			for (int k = 0; k < PER_LANE; ++k) {
 				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
@@ -695,8 +712,8 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 				g[k] = win[o]; db |= (uint32_t)((dirty[o] != 0) & in_old) << k;
 				int const Xs = inside ? X : nx0, Zs = inside ? Z : nz0; // (nx0, nz0) is a cell of the grid and of the prepared window
 				bool slow = false, own = false;
-				uint32_t const code = back.source(Xs, Zs, slow, own);
-				gl[k] = *back.source_ptr(code, Xs, Zs);
+				selv[k] = S.sel(Xs, Zs);
+				gl[k] = *S.ptr(S.code(Xs, Zs, selv[k], slow, own), Xs, Zs);
 				old_mask |= (uint32_t)in_old << k; in_mask |= (uint32_t)inside << k;
 				slow_mask |= (uint32_t)(slow & need) << k; own_mask |= (uint32_t)(own & need) << k;
 			}
@@ -709,8 +726,7 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 					if ((own_mask >> k) & 1u) {
 						int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
 						bool slow = false, own = false;
-						uint32_t const code = back.source(X, Z, slow, own);
-						g[k] = TERRA_L2_LOAD(back.source_ptr(code, X, Z));
+						g[k] = TERRA_L2_LOAD(S.ptr(S.code(X, Z, selv[k], slow, own), X, Z));
 					}
 				}
 			}
@@ -790,6 +806,14 @@ struct grid_back_t {
 	TERRA_HD float lookup(int, int, float b) const {return b;}
 	TERRA_HD uint32_t source(int, int, bool &slow, bool &own) const {slow = false; own = false; return SPEC_SRC_GRID;}
 	TERRA_HD float const *source_ptr(uint32_t, int X, int Z) const {return g.at(X, Z);}
+	// what a window move needs to find the sources of its entering cells, as plain values (see spec_back_t::src_t)
+	struct src_t {
+		grid_view_t g;
+		TERRA_HD uint32_t sel(int, int) const {return 0u;}
+		TERRA_HD uint32_t code(int, int, uint32_t, bool &slow, bool &own) const {slow = false; own = false; return SPEC_SRC_GRID;}
+		TERRA_HD float const *ptr(uint32_t, int X, int Z) const {return g.at_sel(X, Z);}
+	};
+	TERRA_HD src_t src_snapshot() const {return src_t{g};}
 	TERRA_HD void store(int X, int Z, float v) {
 		*g.at(X, Z) = v;
 		if (touched) {uint32_t const k = TERRA_ATOMIC_ADD(touched_count, 1u); if (k < touched_cap) {touched[k] = (uint32_t)Z*(uint32_t)g.NX + (uint32_t)X;}}
@@ -1109,6 +1133,36 @@ struct spec_back_t {
 		return (sel == 0 || slow) ? SPEC_SRC_GRID : code;
 	}
 	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code == SPEC_SRC_GRID) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x7FFFFFFFu);}
+	// The same three questions for the sixteen cells a lane brings into a new window, asked of a SNAPSHOT: everything they need as plain wave-uniform values taken once per
+	// move.  Through `sb` (a pointer to the kernel's argument block) every field was a scalar load + s_waitcnt lgkmcnt(0) per use -- which also drains the LDS reads in
+	// flight -- and `sb->page_vals[code >> 31]` was a VECTOR load of the pointer + s_waitcnt vmcnt(0) per cell, i.e. every cell waited for the previous cell's data load:
+	// the sixteen loads of a lane ran one after another (6.5 us per move on average, 11 us on a round's longest wave; tools/ab_build.sh instr1, TERRA_ERO_DIAG).
+	struct src_t {
+		grid_view_t g; float *pv0, *pv1; wave_shared_t const *sh;
+		int wbx0, wbz0, wnb, bshift; uint32_t nonempty, own_base; // own_base: bit 31 = the buffer this trace builds, low bits = slot*maxb
+		TERRA_HD uint32_t bi(int X, int Z) const {return (uint32_t)(((Z >> bshift) - wbz0)*wnb + ((X >> bshift) - wbx0));} // inside the prepared window by construction
+		TERRA_HD uint32_t sel(int X, int Z) const {uint32_t const b = bi(X, Z); return ((nonempty >> b) & 1u) ? (uint32_t)sh->sel[b][page_cell(X, Z)] : 0u;} // (rows of blocks without content are not filled in)
+		TERRA_HD uint32_t code(int X, int Z, uint32_t sl, bool &slow, bool &own) const {
+			uint32_t const c = page_cell(X, Z), b = bi(X, Z);
+			slow = (sl == SPEC_SEL_SLOW); own = (sl == SPEC_SEL_OWN);
+			uint32_t const cpage = sh->cand[b][(sl - 1u) & (SPEC_CAND - 1u)].page, opage = own_base + (uint32_t)(sh->blk_own[b] & 0xFFu);
+			uint32_t const page = own ? opage : cpage;
+			uint32_t const cd = (page & 0x80000000u) | ((page & 0x7FFFFFFFu)*SPEC_PAGE + c);
+			return (sl == 0 || slow) ? SPEC_SRC_GRID : cd;
+		}
+		TERRA_HD float const *ptr(uint32_t cd, int X, int Z) const {
+			float const *const gp = g.at_sel(X, Z);
+			float const *const pp = ((cd >> 31) ? pv1 : pv0) + (cd & 0x7FFFFFFFu);
+			return (cd == SPEC_SRC_GRID) ? gp : pp;
+		}
+	};
+	TERRA_HD src_t src_snapshot() const {
+		src_t t;
+		t.g = sb->grid; t.pv0 = sb->page_vals[0]; t.pv1 = sb->page_vals[1]; t.sh = sh;
+		t.wbx0 = wbx0; t.wbz0 = wbz0; t.wnb = wnb; t.bshift = (int)sb->bshift; t.nonempty = nonempty;
+		t.own_base = ((1u - sb->cur[slot]) << 31) | (uint32_t)(slot*sb->maxb);
+		return t;
+	}
 	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`
 	TERRA_HD float lookup(int X, int Z, float b) const {
 		uint32_t const c = page_cell(X, Z);

@@ -90,7 +90,8 @@ def make_config(mesh_gen_mode=0, mesh_gen_shape=0, mesh_seed=1, mesh_freq_filter
 
 
 def default_lib_path():
-    return os.path.join(HERE, "libterra_hip.so")
+    """3dworld_amd/libterra_hip.so; TERRA_LIB names another build of the same library (A/B experiments with tools/ab_build.sh -- never set in tests or bench runs)"""
+    return os.environ.get("TERRA_LIB") or os.path.join(HERE, "libterra_hip.so")
 
 
 _vp, _f, _u32, _i32, _sz = C.c_void_p, C.c_float, C.c_uint32, C.c_int, C.c_size_t
