@@ -554,13 +554,6 @@ int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n,
 }
 
 uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx) {return ctx ? ctx->eng.be.tile2_gave_up : 0;}
-int terra_selftest_shared_div(terra_ctx *ctx, uint64_t count, uint64_t *mismatches) {
-	TERRA_CHECK_CTX
-	TERRA_TRY
-	if (!mismatches) throw std::invalid_argument("terra_selftest_shared_div: null result pointer");
-	*mismatches = (uint64_t)ctx->eng.be.selftest_shared_div((unsigned long long)count);
-	TERRA_CATCH
-}
 int terra_selftest_hot_sqrt(terra_ctx *ctx, uint32_t stride, uint64_t *mismatches) {
 	TERRA_CHECK_CTX
 	TERRA_TRY

@@ -363,18 +363,6 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters, d_order, d_landc);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	unsigned long long selftest_shared_div(unsigned long long n) { // k_tile_post's shared-reciprocal division and byte conversion against the plain expressions; -> disagreements
-		use();
-		unsigned long long *d_bad = nullptr, bad = 0;
-		TERRA_HIP_CHECK(hipMalloc((void **)&d_bad, 8));
-		TERRA_HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, stream));
-		hipLaunchKernelGGL(terra::k_selftest_shared_div, dim3(256*8), dim3(256), 0, stream, n, d_bad);
-		hipError_t const e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, stream);
-		hipError_t const e2 = (e == hipSuccess) ? hipStreamSynchronize(stream) : e;
-		(void)hipFree(d_bad);
-		TERRA_HIP_CHECK(e2);
-		return bad;
-	}
 	uint64_t tile2_gave_up = 0; // tiles whose two-wave block timed out in a spin (never expected; counted so that a test can see it)
 	void minmax(float const *vals, size_t n, uint32_t *d) {
 		if (simple_kernels || ((uintptr_t)vals & 15)) {minmax_simple(vals, n, d); return;}

@@ -769,80 +769,6 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // every block's load, compute and store phases in sequence).  Band yy owns sub-block row yy completely (rows 32*yy .. 32*yy + 32), so the 4 x 4 sub-block
 // ranges are written by exactly one block each; what spans the tile (mzmin / mzmax / radius, the water bbox, min_normal_z) is folded through 8 words of
 // global scratch per tile with atomics and written by a one-thread-per-tile kernel afterwards.
-// ---- the texel's normal with fewer issue slots, same bits (k_tile_post is bound by exactly these sequences: SQ_WAIT_INST_ANY 0.56, profiles/r04_pmc_tiles_summary.txt)
-// (1) three IEEE divisions by ONE magnitude.  The compiler expands a / d into v_div_scale (x 2), v_rcp, two FMAs that refine the reciprocal, mul + three FMAs that refine the
-//     quotient, v_div_fmas, v_div_fixup.  When no scaling applies -- d and a non-zero numerator within [2^-40, 2^40], so neither operand nor their ratio comes near the
-//     exponent limits v_div_scale guards -- v_div_scale returns its operand, v_div_fmas is a plain FMA, and the first three instructions depend on d alone: they are
-//     shared here, the rest is the compiler's own sequence, instruction for instruction.  Anything outside the range takes the plain operator.  Checked against the
-//     operator on the device over pseudo-random and hand-picked operands (terra_selftest_shared_div).
-// (2) sqrtf through sqrt_rn (terra_erosion.hpp: v_sqrt_f32 + one residual test per neighbour; equal to sqrtf on all 2^32 inputs, terra_selftest_hot_sqrt).
-// (3) the byte (unsigned char)(127.0*(n + 1.0)), double arithmetic in the reference: t = fmaf(127, n, 127) is the exact value rounded once to 24 bits (error <= 2^-17), the
-//     double expression is the exact value within 6e-14; when t's fraction lies in [2^-12, 1 - 2^-12] both floors are floor(t).  Otherwise (and for n = 0, +-1, which
-//     flat terrain produces everywhere, handled as constants) the reference's double expression itself runs.
-__device__ __forceinline__ bool div_unscaled_num(float a) {float const m = fabsf(a); return (m == 0.0f) | ((m >= 0x1p-40f) & (m <= 0x1p40f));}
-__device__ __forceinline__ float div_shared_step(float n, float d, float r1) { // n / d given the refined reciprocal r1 of d (no scaling case)
-	float const q0 = n*r1;
-	float const e1 = __builtin_fmaf(-d, q0, n);
-	float const q1 = __builtin_fmaf(e1, r1, q0);
-	float const e2 = __builtin_fmaf(-d, q1, n);
-	float const q = __builtin_fmaf(e2, r1, q1);
-	return __builtin_amdgcn_div_fixupf(q, d, n);
-}
-__device__ __forceinline__ void div3_shared(float &a, float &b, float &c, float d) { // a /= d, b /= d, c /= d, correctly rounded like the operator
-	if (TERRA_LIKELY((d >= 0x1p-40f) & (d <= 0x1p40f) & div_unscaled_num(a) & div_unscaled_num(b) & div_unscaled_num(c))) {
-		float const r0 = __builtin_amdgcn_rcpf(d);
-		float const e0 = __builtin_fmaf(-d, r0, 1.0f);
-		float const r1 = __builtin_fmaf(e0, r0, r0);
-		a = div_shared_step(a, d, r1); b = div_shared_step(b, d, r1); c = div_shared_step(c, d, r1);
-	}
-	else {a /= d; b /= d; c /= d;}
-}
-__device__ __forceinline__ uint32_t normal_byte(float n) { // (unsigned char)(127.0*((double)n + 1.0))
-	float const t = __builtin_fmaf(127.0f, n, 127.0f), fl = floorf(t), fr = t - fl;
-	bool const safe = (fr >= 0x1p-12f) & (fr <= 1.0f - 0x1p-12f) & (t >= 0.0f) & (t < 255.0f);
-	uint32_t b = (uint32_t)(int)fl;
-	b = (n == 0.0f) ? 127u : b; b = (n == 1.0f) ? 254u : b; b = (n == -1.0f) ? 0u : b;
-	if (TERRA_UNLIKELY(!(safe | (n == 0.0f) | (n == 1.0f) | (n == -1.0f)))) {b = (uint8_t)(127.0*((double)n + 1.0));}
-	return b;
-}
-__device__ __forceinline__ void tile_normal_fast(float const *z, unsigned x, unsigned y, float dxv, float dyv, float dxy, float nv[3]) { // tile_normal (terra_driver.hpp), same bits
-	unsigned const zv = 130, ix2 = y*zv + x;
-	nv[0] = dyv*(z[ix2] - z[ix2 + 1]); nv[1] = dxv*(z[ix2] - z[ix2 + zv]); nv[2] = dxy;
-#if defined(__HIP_DEVICE_COMPILE__)
-	float const mag = sqrt_rn(nv[0]*nv[0] + nv[1]*nv[1] + nv[2]*nv[2]);
-#else
-	float const mag = sqrtf(nv[0]*nv[0] + nv[1]*nv[1] + nv[2]*nv[2]); // (the host pass of hipcc only parses this)
-#endif
-	if (!(mag < 1.0E-12f)) {div3_shared(nv[0], nv[1], nv[2], mag);}
-}
-// self test of div3_shared against the operator: pairs (numerator, denominator) from a counter-based generator, half of them inside the no-scaling range, the rest anywhere
-// (raw bit patterns: denormals, infinities, NaNs, zeros), plus numerators tied to the denominator (|n| <= d, as a normal's components are).  Counts disagreeing results.
-__global__ __launch_bounds__(256) void k_selftest_shared_div(unsigned long long n, unsigned long long *bad) {
-	unsigned long long const i0 = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x, step = (unsigned long long)gridDim.x*blockDim.x;
-	unsigned long long mism = 0;
-	auto same = [](float p, float q) {return __builtin_bit_cast(uint32_t, p) == __builtin_bit_cast(uint32_t, q) || (p != p && q != q);};
-	for (unsigned long long i = i0; i < n; i += step) {
-		unsigned long long h = i*0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
-		uint32_t const u0 = (uint32_t)h, u1 = (uint32_t)(h >> 32), sel = (uint32_t)(i & 3u);
-		float d, a, b, c;
-		if (sel < 2) { // inside the range: exponent of d in [-40, 40), mantissas random; numerators: one tied to d (a fraction of it), one free in range, one exact zero / +-d
-			d = __builtin_bit_cast(float, ((127u - 40u + (u0 >> 23) % 80u) << 23) | (u0 & 0x7FFFFFu));
-			float const fr = __builtin_bit_cast(float, 0x3F000000u | (u1 & 0x7FFFFFu)); // [0.5, 1)
-			a = ((u1 >> 31) ? -d : d)*fr*__builtin_bit_cast(float, (127u - ((u1 >> 23) & 31u)) << 23);
-			b = __builtin_bit_cast(float, ((u1 & 0x80000000u)) | ((127u - 40u + (u1 >> 8) % 80u) << 23) | ((u0 ^ u1) & 0x7FFFFFu));
-			c = (sel == 0) ? 0.0f : ((u0 & 1u) ? d : -d);
-		}
-		else {d = __builtin_bit_cast(float, u0 & 0x7FFFFFFFu); a = __builtin_bit_cast(float, u1); b = __builtin_bit_cast(float, u0 ^ (u1 << 7)); c = __builtin_bit_cast(float, u1 ^ (u0 >> 3));}
-		float qa = a, qb = b, qc = c;
-		div3_shared(qa, qb, qc, d);
-		mism += (same(qa, a/d) ? 0u : 1u) + (same(qb, b/d) ? 0u : 1u) + (same(qc, c/d) ? 0u : 1u);
-		// and the byte conversion on values in [-1, 1] (the quotient of the tied numerator) and a little beyond
-		float const nn = (sel < 2) ? qa : __builtin_bit_cast(float, (u1 & 0x80000000u) | (0x3F800000u - (u0 >> 9)));
-		if (nn >= -1.0f && nn <= 1.0f) {mism += (normal_byte(nn) == (uint32_t)(uint8_t)(127.0*((double)nn + 1.0))) ? 0u : 1u;}
-	}
-	if (mism) {atomicAdd(bad, mism);}
-}
-
 constexpr unsigned TP_THREADS = 256, TP_BAND_ROWS = 34, TP_ACC = 8; // acc: {-, -, bbox x1, y1, x2, y2, min normal z bits, ticket}
 __global__ __launch_bounds__(256) void k_tile_post_init(uint32_t *__restrict__ acc, uint32_t n) {
 	uint32_t const i = blockIdx.x*blockDim.x + threadIdx.x;
@@ -892,8 +818,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 		}
 		if (nout && y < nrows) {
 			float nv[3];
-			tile_normal_fast(z, x, y, dxv, dyv, dxy, nv);
-			uint32_t const b0 = normal_byte(nv[0]), b1 = normal_byte(nv[1]), b2 = normal_byte(nv[2]);
+			tile_normal(z, x, y, dxv, dyv, dxy, nv);
+			uint32_t const b0 = (uint8_t)(127.0*((double)nv[0] + 1.0)), b1 = (uint8_t)(127.0*((double)nv[1] + 1.0)), b2 = (uint8_t)(127.0*((double)nv[2] + 1.0));
 			nout[p] = b0 | (b1 << 8) | (b2 << 16); // A = 0
 			if (nv[2] < 1.0f) {uint32_t u; memcpy(&u, &nv[2], 4); mnz = (u < mnz) ? u : mnz;} // positive floats order like their bit patterns
 		}

@@ -175,7 +175,6 @@ _PROTOS = {
     "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_get_tile_erosion_fallbacks": (C.c_uint64, [_vp]),
     "terra_selftest_hot_sqrt": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
-    "terra_selftest_shared_div": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_voxel_fill_slab_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32, _u32, _u32]),
     "terra_voxel_fill": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
@@ -356,11 +355,6 @@ class Terra:
         return z, st, nm, mnz
 
     def tile_erosion_fallbacks(self): return int(self.lib.terra_get_tile_erosion_fallbacks(self.ctx))
-    def selftest_shared_div(self, count=1 << 32):
-        n = C.c_uint64(0)
-        self._ck(self.lib.terra_selftest_shared_div(self.ctx, count, C.byref(n)))
-        return n.value
-
     def selftest_hot_sqrt(self, stride=1):
         """disagreements of the droplet step's square roots with sqrtf / the correctly rounded root over every stride-th fp32 bit pattern (must be 0)"""
         n = C.c_uint64(0)

@@ -259,9 +259,6 @@ uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx);
 /* self test: the droplet step takes its two square roots per step with a shortened instruction sequence (csrc/terra_erosion.hpp: sqrt_rn); this runs it over every
  * stride-th fp32 bit pattern (stride 1: all 2^32, a few ms on the GPU) against sqrtf and against the correctly rounded double-precision route.  *mismatches must be 0. */
 int  terra_selftest_hot_sqrt(terra_ctx *ctx, uint32_t stride, uint64_t *mismatches);
-/* self test: the tile normals divide three components by one magnitude with a shared reciprocal refinement and convert to bytes in float where that is provably the double
- * result (csrc/terra_kernels.hpp: div3_shared, normal_byte); this runs `count` operand sets (in and out of the shortcut's range) against the plain expressions.  *mismatches must be 0. */
-int  terra_selftest_shared_div(terra_ctx *ctx, uint64_t count, uint64_t *mismatches);
 
 /* ---- heightmap files, host side: 8- / 16-bit grayscale PNG exactly as the reference reads / writes them through libpng (src/image_io.cpp:493-605):
  * write: rows in memory order, 16-bit pixels {fraction, integer} -> big-endian samples (heightmap_t::write_png, src/heightmap.cpp:375-378);

@@ -21,7 +21,6 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void set_stream(void *) {}
 	void set_priority(int) {}
 	size_t mem_free() {return ~(size_t)0 >> 1;}
-	unsigned long long selftest_shared_div(unsigned long long) {return 0;} // (the shared-reciprocal sequence exists only on the device)
 	void release_scratch() {}
 	void sync() {}
 	void *alloc(size_t bytes) {void *p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p;}

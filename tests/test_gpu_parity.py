@@ -39,12 +39,6 @@ def test_hot_sqrt_equals_sqrtf(gpu):
     assert gpu.selftest_hot_sqrt(1) == 0
 
 
-def test_shared_reciprocal_division_and_float_byte_equal_the_plain_expressions(gpu):
-    """k_tile_post's normals: a / d, b / d, c / d through one refined reciprocal (the compiler's own division sequence with its denominator-only part shared) and the byte
-    conversion in float where it provably equals the reference's double expression -- 2^32 operand sets on the device, in and out of the shortcut's range"""
-    assert gpu.selftest_shared_div(1 << 32) == 0
-
-
 def test_erosion_golden(pkg, gpu):
     pc.case_erosion_golden(pkg, gpu)
 
