@@ -162,24 +162,47 @@ def strip_rows_aligned(terra_mod, terra, nx, ny, world):
     return rows, per * row_bytes
 
 
-def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag):
+def _all_ok(dist, ok, coll_device="cpu"):
+    """every rank learns whether EVERY rank succeeded (one all_reduce(min) of a flag): a failure is raised on all ranks together, never on one rank while the others wait"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return ok
+    import torch
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=coll_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item()) > 0.5
+
+
+def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cpu"):
     """ONE nx x ny float grid over all ranks of `dist`: this rank's rows live in its HBM, everybody maps the whole grid (see include/terra.h, terra_dgrid_*).
-    Returns (grid, rows) with grid.ptr the mapped device pointer and rows[r] = (r0, r1) of rank r."""
+    Returns (grid, rows) with grid.ptr the mapped device pointer and rows[r] = (r0, r1) of rank r.  Raises RuntimeError on EVERY rank when any rank failed (a runtime
+    without virtual memory management, devices that cannot map each other ...): the two steps end in an agreement, so nobody is left waiting in a collective."""
     import os
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
-    rows, strip_bytes = strip_rows_aligned(terra_mod, terra, nx, ny, world)
-    g = terra_mod.DistributedGrid(terra, [strip_bytes] * world, rank)
-    if world > 1:
-        dist.barrier()
-        fd = g.export_fd()
-        peers = exchange_fds(rank, world, fd, tag)
-        os.close(fd)
-        for r, pfd in peers.items():
-            g.import_fd(r, pfd)
-            os.close(pfd)
-    g.map()
-    if world > 1:
-        dist.barrier()
+    g, fd, err = None, -1, None
+    try:  # step 1: the local strip and its descriptor
+        rows, strip_bytes = strip_rows_aligned(terra_mod, terra, nx, ny, world)
+        g = terra_mod.DistributedGrid(terra, [strip_bytes] * world, rank)
+        if world > 1:
+            fd = g.export_fd()
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    if not _all_ok(dist, err is None, coll_device):
+        if g is not None:
+            g.destroy()
+        raise RuntimeError(f"terra_dgrid: allocation / export failed on some rank ({err or 'another rank'})")
+    try:  # step 2: everybody's strips, mapped
+        if world > 1:
+            peers = exchange_fds(rank, world, fd, tag)
+            os.close(fd)
+            for r, pfd in peers.items():
+                g.import_fd(r, pfd)
+                os.close(pfd)
+        g.map()
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    if not _all_ok(dist, err is None, coll_device):
+        g.destroy()
+        raise RuntimeError(f"terra_dgrid: import / map failed on some rank ({err or 'another rank'})")
     return g, rows
 
 
@@ -208,7 +231,15 @@ class OneHeightmapPipeline:
         self.G = grids
         self.grids, self.rows = [], None
         for g in range(grids):
-            dg, rows = create_distributed_grid(terra_mod, self.nctx, dist, nx, ny, f"{tag}_{g}")
+            try:
+                dg, rows = create_distributed_grid(terra_mod, self.nctx, dist, nx, ny, f"{tag}_{g}", coll_device)
+            except Exception:
+                for x in self.grids:
+                    x.destroy()
+                self.nctx.close()
+                for c in self.ectx:
+                    c.close()
+                raise
             self.grids.append(dg)
             self.rows = rows
         self.coll_device = coll_device
