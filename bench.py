@@ -426,7 +426,7 @@ def main():
     # ---- ONE heightmap per step on all ranks together, erosion included: the strips live in their owners' HBM and are mapped back to back on every rank
     # (terra_dgrid), min(vals) is one float through all_reduce(min), rank s % world erodes step s's grid over the mapped pointer (remote rows over xGMI) while the next
     # steps' noise runs; 3dworld_amd/dist.py::OneHeightmapPipeline.  Bit-identical to the single-GPU heightmap (tests/test_distributed.py).
-    want_onegrid = args.workload == "onegrid" or (args.workload == "heightmap" and world > 1)
+    want_onegrid = args.workload == "onegrid" or (args.workload == "heightmap" and (world > 1 or not args.no_extras))  # at N = 1 it is measured too (value_strong), so that 1 -> N compares like with like
     pipe = None
     if want_onegrid:
         tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid() if world == 1 else 'job'}"
@@ -454,7 +454,10 @@ def main():
             value_strong = cells * K / dts / 1e9
             if value_weak is not None:
                 detail["regions"] = {"value_weak": round(value_weak, 4), "ms_per_step": round(dt / K * 1e3, 4), "scaling": "weak", "workload": workload_w, "parallelism": par_w}
-            dt, value, scaling, workload, par = dts, value_strong, "strong", workload_s, par_s
+            if world > 1 or args.workload == "onegrid":
+                dt, value, scaling, workload, par = dts, value_strong, "strong", workload_s, par_s
+            else:  # N = 1: the region and the one grid are the same heightmap; the headline stays the 4-pipeline form, the one-grid pipeline (1 rank) is printed beside it
+                detail["onegrid"] = {"value_strong": round(value_strong, 4), "ms_per_step": round(dts / K * 1e3, 4), "scaling": "strong", "workload": workload_s, "parallelism": par_s}
     elif args.workload == "strips":
         dt = timed(strips_steps, K, max(W, 2))
         value = cells * K / dt / 1e9

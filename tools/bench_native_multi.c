@@ -168,6 +168,35 @@ int main(int argc, char **argv) {
 		printf("{\"what\": \"one heightmap as row strips\", \"gpus\": %d, \"grid\": %d, \"ms\": %.4f, \"gcells_per_s\": %.2f, \"min\": %.9g, \"max\": %.9g, \"scaling\": \"strong\"}\n", G, n, 1e3*dt/steps, (double)n*(double)n*steps/dt/1e9, mn, mx);
 		for (int g = 0; g < G; ++g) {terra_free(terra_multi_ctx(m, (uint32_t)g), strip[g]);}
 	}
+	/* (c2) ONE heightmap with its erosion: the row strips are physical allocations on their GPUs mapped back to back (terra_multi_dgrid_create), every context fills its
+	 * rows, context (step mod G) erodes the whole map through the one pointer -- remote rows over xGMI */
+	{
+		terra_state st; CK(terra_get_state(terra_multi_ctx(m, 0), &st));
+		size_t const gran = terra_dgrid_granularity(terra_multi_ctx(m, 0));
+		size_t sb[MAXG]; uint32_t r0[MAXG], rn[MAXG];
+		int ok = 1;
+		for (int g = 0; g < G; ++g) {terra_multi_partition((uint32_t)n, (uint32_t)G, (uint32_t)g, &r0[g], &rn[g]); sb[g] = (size_t)rn[g]*(size_t)n*4; if (sb[g] == 0 || sb[g] % gran) ok = 0;}
+		if (ok) {
+			terra_dgrid *dg = NULL; void *base = NULL;
+			CK(terra_multi_dgrid_create(m, sb, &dg, &base));
+			float *grid = (float *)base;
+			double tsum = 0.0;
+			for (int r = 0; r < steps + 2; ++r) {
+				double const ta = now();
+				float mn = 1e30f;
+				for (int g = 0; g < G; ++g) { /* (a 3DWorld process would drive these from its worker threads; here one after another: the timing is the eroded map's, not the strips') */
+					float a = 0.0f, b = 0.0f;
+					CK(terra_gen_grid_rows_minmax_dev(terra_multi_ctx(m, (uint32_t)g), -0.5f*(float)n, -0.5f*(float)n, st.DX_VAL, st.DY_VAL, (uint32_t)n, (uint32_t)n, TERRA_GEN_GLACIATE, 0, r0[g], rn[g], grid + (size_t)r0[g]*(size_t)n, &a, &b));
+					if (a < mn) mn = a;
+				}
+				terra_ctx *e = terra_multi_ctx(m, (uint32_t)(r % G));
+				CK(terra_apply_erosion_dev(e, grid, n, n, mn, 1000, TERRA_ERODE_MINZ_IS_MIN)); CK(terra_synchronize(e));
+				if (r >= 2) tsum += now() - ta;
+			}
+			printf("{\"what\": \"one heightmap on a distributed grid, noise strips + whole-map erosion by one context, serial\", \"gpus\": %d, \"grid\": %d, \"ms\": %.4f, \"gcells_per_s\": %.2f}\n", G, n, 1e3*tsum/steps, (double)n*(double)n*steps/tsum/1e9);
+			terra_dgrid_destroy(dg);
+		}
+	}
 	/* (d) one 512^3 voxel field as y slabs */
 	{
 		uint32_t const VN = 512;
