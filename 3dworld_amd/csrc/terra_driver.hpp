@@ -503,41 +503,44 @@ template<class BE> struct terra_engine {
 		uint32_t *d_mm = nullptr;
 		if (h_minmax || d_minmax) {d_mm = scratch<uint32_t>(s_mm, 2); be.fill32(d_mm, 0xFFFFFFFFu, 2);}
 		bool fused;
-		if (job.use_sine_mag) { // enable_glaciate (src/mesh_gen.cpp:640-650)
-			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
+		bool const sm_on = job.use_sine_mag != 0;
+		float const sm_scale = hp.sine_mag*mesh_scale_z_inv, sm_freq = mesh_scale*hp.sine_freq, dxi = DX_VAL_INV, dyi = DY_VAL_INV; // enable_glaciate (src/mesh_gen.cpp:640-650)
+		if (sm_on && job.mode != MGEN_SINE) { // (sine mode: folded into the table launch below)
 			float const mx0 = job.mx0, my0 = job.my0, mdx = dx, mdy = dy;
 			uint32_t const nxp = job.nxp, nyp = job.nyp; // zero padding up to the tile grid: the sine kernel reads whole float4 groups
 			be.launch((size_t)nxp + nyp, [=] TERRA_LAMBDA (size_t i) {
-				if (i < nxp) {smx[i] = (i < nx) ? sm_scale*L.COSF(((float)(unsigned)i*mdx + mx0)*dxi*freq) : 0.0f;}
-				else {unsigned const y = (unsigned)(i - nxp); smy[y] = (y < ny) ? L.COSF(((float)(y + row0)*mdy + my0)*dyi*freq) : 0.0f;}
+				if (i < nxp) {smx[i] = (i < nx) ? sm_scale*L.COSF(((float)(unsigned)i*mdx + mx0)*dxi*sm_freq) : 0.0f;}
+				else {unsigned const y = (unsigned)(i - nxp); smy[y] = (y < ny) ? L.COSF(((float)(y + row0)*mdy + my0)*dyi*sm_freq) : 0.0f;}
 			});
 		}
 		if (job.mode == MGEN_SINE) {
-			sine_k_t *d_skp = scratch<sine_k_t>(s_sk, 1); // per-k constants live in device memory: a by-value kernel argument indexed per lane would be spilled to scratch
-			{ // make_sine_k on the device: the same fp32 expressions in the same order (no contraction on either side), so the same bits without a blocking upload per call
-				float const *st = sinTable_dev();
-				float const msx = mesh_scale*DX_VAL_INV, msy = mesh_scale*DY_VAL_INV, ms2 = (float)(0.5*(double)mesh_scale), mszi = mesh_scale_z_inv, jmx0 = job.mx0, jmy0 = job.my0;
-				be.launch((size_t)F_TABLE_SIZE, [=] TERRA_LAMBDA (size_t k) {
-					float const *stk = st + 5*k;
-					float const x_mult = msx*stk[4], y_mult = msy*stk[3];
-					d_skp->yscale[k] = mszi*stk[0];
-					d_skp->xconst[k] = ms2*stk[4] + stk[2] + x_mult*jmx0;
-					d_skp->yconst[k] = ms2*stk[3] + stk[1] + y_mult*jmy0;
-					d_skp->xmdx[k] = x_mult*dx; d_skp->ymdy[k] = y_mult*dy;
-				}, 128);
-			}
+			// ONE launch builds everything the grid kernel reads: the k-major tables xt[k*nxp + x] = SINF(xmdx*x + x_const), yt[k*nyp + y] = y_scale*SINF(ymdy*y + y_const) (zero
+			// padded) and the island tables smx / smy.  The per-k constants of build_arrays (src/mesh_gen.cpp:607-613) are derived by every thread from the device copy of sinTable
+			// -- the same fp32 expressions in the same order as make_sine_k, no contraction on either side, so the same bits -- instead of by a 90-thread launch of their own in
+			// front of this one (three dependent launches per grid were ~25 us of a 0.88 ms step).
+			float const *st = sinTable_dev();
+			float const msx = mesh_scale*DX_VAL_INV, msy = mesh_scale*DY_VAL_INV, ms2 = (float)(0.5*(double)mesh_scale), mszi = mesh_scale_z_inv, jmx0 = job.mx0, jmy0 = job.my0, mdx = dx, mdy = dy;
 			float *xt = scratch<float>(s_xt, (size_t)F_TABLE_SIZE*job.nxp), *yt = scratch<float>(s_yt, (size_t)F_TABLE_SIZE*job.nyp);
 			uint32_t const nxp = job.nxp, nyp = job.nyp;
-			// tables, k-major: xt[k*nxp + x] = SINF(xmdx*x + x_const), yt[k*nyp + y] = y_scale*SINF(ymdy*y + y_const); zero padding
-			be.launch((size_t)F_TABLE_SIZE*(nxp + nyp), [=] TERRA_LAMBDA (size_t i) {
+			size_t const ntab = (size_t)F_TABLE_SIZE*(nxp + nyp);
+			be.launch(ntab + (sm_on ? (size_t)nxp + nyp : 0), [=] TERRA_LAMBDA (size_t i) {
 				if (i < (size_t)F_TABLE_SIZE*nxp) {
 					unsigned const k = (unsigned)(i / nxp), x = (unsigned)(i % nxp);
-					xt[i] = (x < nx) ? L.SINF(d_skp->xmdx[k]*(float)x + d_skp->xconst[k]) : 0.0f;
+					float const *stk = st + 5*k;
+					float const x_mult = msx*stk[4], xconst = ms2*stk[4] + stk[2] + x_mult*jmx0, xmdx = x_mult*mdx;
+					xt[i] = (x < nx) ? L.SINF(xmdx*(float)x + xconst) : 0.0f;
 				}
-				else {
+				else if (i < ntab) {
 					size_t const j = i - (size_t)F_TABLE_SIZE*nxp;
 					unsigned const k = (unsigned)(j / nyp), y = (unsigned)(j % nyp);
-					yt[j] = (y < ny) ? d_skp->yscale[k]*L.SINF(d_skp->ymdy[k]*(float)(y + row0) + d_skp->yconst[k]) : 0.0f;
+					float const *stk = st + 5*k;
+					float const y_mult = msy*stk[3], yscale = mszi*stk[0], yconst = ms2*stk[3] + stk[1] + y_mult*jmy0, ymdy = y_mult*mdy;
+					yt[j] = (y < ny) ? yscale*L.SINF(ymdy*(float)(y + row0) + yconst) : 0.0f;
+				}
+				else {
+					size_t const q = i - ntab;
+					if (q < nxp) {smx[q] = (q < nx) ? sm_scale*L.COSF(((float)(unsigned)q*mdx + jmx0)*dxi*sm_freq) : 0.0f;}
+					else {unsigned const y = (unsigned)(q - nxp); smy[y] = (y < ny) ? L.COSF(((float)(y + row0)*mdy + jmy0)*dyi*sm_freq) : 0.0f;}
 				}
 			});
 			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, d_mm);
