@@ -383,6 +383,43 @@ int terra_heightmap_read_png(const char *path, int allow_two_byte_grayscale, uin
 	TERRA_CATCH
 }
 
+// ---- the ground mesh's text file (host): read_mesh / write_mesh, src/mesh_gen.cpp:895-965
+int terra_read_mesh(terra_ctx *ctx, const char *filename, float zmm, float *h_mesh, uint32_t nx, uint32_t ny, float *h_zbottom_ztop) {
+	TERRA_CHECK_CTX
+	if (!filename || !h_mesh || nx == 0 || ny == 0) return terra::fail(TERRA_ERR_ARG, "terra_read_mesh: null or empty argument");
+	FILE *fp = fopen(filename, "r");
+	if (!fp) return terra::fail(TERRA_ERR_ARG, (std::string("terra_read_mesh: cannot open ") + filename).c_str());
+	int xsize = 0, ysize = 0;
+	if (fscanf(fp, "%i%i", &xsize, &ysize) != 2) {fclose(fp); return terra::fail(TERRA_ERR_ARG, "terra_read_mesh: error reading the size header");}
+	if (xsize != (int)nx || ysize != (int)ny) {fclose(fp); return terra::fail(TERRA_ERR_ARG, "terra_read_mesh: the mesh size in the file is not the scene's");}
+	float const fscale = ctx->eng.mesh_file_scale, ftz = ctx->eng.mesh_file_tz;
+	for (size_t i = 0; i < (size_t)nx*ny; ++i) {
+		float height;
+		if (fscanf(fp, "%f", &height) != 1) {fclose(fp); return terra::fail(TERRA_ERR_ARG, "terra_read_mesh: error reading mesh heights");}
+		h_mesh[i] = fscale*height + ftz;
+	}
+	fclose(fp);
+	float mn = h_mesh[0], mx = h_mesh[0]; // matrix_min_max (src/mesh_gen.cpp:84-94): std::min / std::max, so a NaN never replaces a number
+	for (size_t i = 0; i < (size_t)nx*ny; ++i) {float const v = h_mesh[i]; mn = (v < mn) ? v : mn; mx = (mx < v) ? v : mx;}
+	if (h_zbottom_ztop) {h_zbottom_ztop[0] = mn; h_zbottom_ztop[1] = mx;}
+	float const neg = -mn;
+	ctx->eng.set_zmax_est((zmm != 0.0f) ? zmm : ((neg < mx) ? mx : neg)); // max(-zmin, zmax)
+	ctx->eng.set_zvals();
+	return TERRA_OK;
+}
+int terra_write_mesh(const char *filename, const float *h_mesh, uint32_t nx, uint32_t ny) {
+	if (!filename || !h_mesh) return terra::fail(TERRA_ERR_ARG, "terra_write_mesh: null argument");
+	FILE *fp = fopen(filename, "w");
+	if (!fp) return terra::fail(TERRA_ERR_ARG, (std::string("terra_write_mesh: cannot open ") + filename).c_str());
+	bool ok = fprintf(fp, "%i %i\n", (int)nx, (int)ny) > 0;
+	for (uint32_t i = 0; i < ny && ok; ++i) {
+		for (uint32_t j = 0; j < nx && ok; ++j) {ok = fprintf(fp, "%f ", (double)h_mesh[(size_t)i*nx + j]) > 0;}
+		ok = ok && fprintf(fp, "\n") > 0;
+	}
+	ok = (fclose(fp) == 0) && ok;
+	return ok ? TERRA_OK : terra::fail(TERRA_ERR_ARG, "terra_write_mesh: write error");
+}
+
 // ---- tiles
 int terra_hmap_set_dev(terra_ctx *ctx, const uint8_t *d_pixels, int width, int height, int ncolors) {
 	TERRA_CHECK_CTX

@@ -144,6 +144,8 @@ _PROTOS = {
     "terra_set_tiled_mesh_ao": (_i32, [_vp, _i32]),
     "terra_heightmap_write_png": (_i32, [C.c_char_p, _vp, _u32, _u32, _i32]),
     "terra_heightmap_read_png": (_i32, [C.c_char_p, _i32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_i32), _vp, C.c_size_t]),
+    "terra_read_mesh": (_i32, [_vp, C.c_char_p, _f, _vp, _u32, _u32, _vp]),
+    "terra_write_mesh": (_i32, [C.c_char_p, _vp, _u32, _u32]),
     "terra_tiles_mesh_shadows_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_tiles_mesh_shadows": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp]),
     "terra_tiles_mesh_shadows_halo_dev": (_i32, [_vp, _vp, _u32, _vp, _f3, _vp, _vp, _vp, _vp]),
@@ -429,6 +431,18 @@ class Terra:
         out = np.empty((h.value, w.value, 2) if nc.value == 2 else (h.value, w.value), np.uint8)
         self._ck(self.lib.terra_heightmap_read_png(str(path).encode(), int(allow_two_byte_grayscale), C.byref(w), C.byref(h), C.byref(nc), out.ctypes.data, out.nbytes))
         return out
+
+    def read_mesh(self, path, nx, ny, zmm=0.0):
+        """read_mesh (src/mesh_gen.cpp:895-933): -> (mesh [ny, nx] float32 = mesh_file_scale*height + mesh_file_tz, (zbottom, ztop)); the context's zmax_est / zmin / zmax /
+        water_plane_z are updated as the reference's globals are"""
+        out = np.empty((ny, nx), np.float32)
+        zz = np.zeros(2, np.float32)
+        self._ck(self.lib.terra_read_mesh(self.ctx, os.fsencode(str(path)), float(zmm), out.ctypes.data, nx, ny, zz.ctypes.data))
+        return out, (zz[0], zz[1])
+
+    def write_mesh(self, path, mesh):
+        m = np.ascontiguousarray(mesh, np.float32)
+        self._ck(self.lib.terra_write_mesh(os.fsencode(str(path)), m.ctypes.data, m.shape[1], m.shape[0]))
 
     def set_tiled_mesh_ao(self, enable):
         self._ck(self.lib.terra_set_tiled_mesh_ao(self.ctx, int(bool(enable))))

@@ -246,6 +246,17 @@ int  terra_heightmap_to_floats_dev(terra_ctx *ctx, const uint8_t *d_pixels, uint
 int  terra_heightmap_from_floats_dev(terra_ctx *ctx, const float *d_vals, uint32_t width, uint32_t height, int ncolors, uint8_t *d_pixels, uint32_t *h_out_of_range);
 int  terra_heightmap_postprocess_dev(terra_ctx *ctx, uint8_t *d_pixels, uint32_t width, uint32_t height, int ncolors, uint32_t erosion_iters_tt, float *d_vals, uint32_t *h_out_of_range);
 
+/* ---- the ground mesh's text file: read_mesh / write_mesh (src/mesh_gen.cpp:895-965), e.g. BASELINE config 1's `mesh_file mapx/mesh128.txt` (src/3DWorld.cpp:2206).
+ * Format: "nx ny" then ny rows of nx heights (written with "%f ").  Host functions, like the PNG ones: the file is a few hundred KB and is parsed with the C library's
+ * own fscanf, so every height has the bits the reference reads.
+ * terra_read_mesh: the header must equal (nx, ny) = the scene's MESH_X_SIZE x MESH_Y_SIZE (the reference refuses other sizes); h_mesh[i*nx + j] = mesh_file_scale*height +
+ *   mesh_file_tz (terra_set_mesh_file_scale); then calc_zminmax, set_zmax_est(zmm != 0 ? zmm : max(-zmin, zmax)) and set_zvals: the context's zmin / zmax / zmax_est /
+ *   water_plane_z are what the engine's globals are after read_mesh (terra_get_state).  h_zbottom_ztop (optional) receives the mesh's own {min, max} (set_zvals' zbottom / ztop).
+ *   Returns TERRA_ERR_ARG for a missing file, a short file or a size mismatch (the reference prints an error and returns 0); h_mesh may then be partly written, the state is untouched.
+ * terra_write_mesh: the inverse (no scale is applied, as in the reference). */
+int  terra_read_mesh(terra_ctx *ctx, const char *filename, float zmm, float *h_mesh, uint32_t nx, uint32_t ny, float *h_zbottom_ztop);
+int  terra_write_mesh(const char *filename, const float *h_mesh, uint32_t nx, uint32_t ny);
+
 /* ---- tiles: tile_t::create_zvals batch, size = 128 (zvsize 130, stride 129).
  * tile_xy: n pairs (tile x, tile y) on the HOST.  d_zvals: n*130*130 floats.  d_stats: n terra_tile_stats (optional).
  * d_normals: n*129*129*4 bytes RGBA8 with A = 0 (optional); d_min_normal_z: n floats (optional). */

@@ -122,6 +122,24 @@ inline void write_heightmap_png(char const *fn, unsigned char const *pixels, uns
 	check(terra_heightmap_write_png(fn, pixels, width, height, ncolors), "write_png");
 }
 
+// ---- read_mesh / write_mesh (src/mesh_gen.cpp:895-965): the ground mesh's text file.  Same return value as the reference (0: the file is missing, short or of another size);
+// mesh_height is the engine's float ** matrix of MESH_Y_SIZE rows.  After read_mesh copy zmin / zmax / zmax_est / water_plane_z back from terra_get_state().
+inline bool read_mesh(char const *filename, float zmm, float **mesh_height, unsigned mesh_x_size, unsigned mesh_y_size, float &zbottom, float &ztop) {
+	if (filename == nullptr) return 0;
+	std::vector<float> m((size_t)mesh_x_size*mesh_y_size);
+	float zz[2];
+	if (terra_read_mesh(default_ctx(), filename, zmm, m.data(), mesh_x_size, mesh_y_size, zz) != TERRA_OK) {std::fprintf(stderr, "read_mesh: %s\n", terra_last_error()); return 0;}
+	for (unsigned i = 0; i < mesh_y_size; ++i) {for (unsigned j = 0; j < mesh_x_size; ++j) {mesh_height[i][j] = m[(size_t)i*mesh_x_size + j];}}
+	zbottom = zz[0]; ztop = zz[1];
+	return 1;
+}
+inline bool write_mesh(char const *filename, float const *const *mesh_height, unsigned mesh_x_size, unsigned mesh_y_size) {
+	if (filename == nullptr || mesh_height == nullptr) return 0;
+	std::vector<float> m((size_t)mesh_x_size*mesh_y_size);
+	for (unsigned i = 0; i < mesh_y_size; ++i) {for (unsigned j = 0; j < mesh_x_size; ++j) {m[(size_t)i*mesh_x_size + j] = mesh_height[i][j];}}
+	return terra_write_mesh(filename, m.data(), mesh_x_size, mesh_y_size) == TERRA_OK;
+}
+
 // ---- tile_t::calc_mesh_ao_lighting (src/tiled_mesh.cpp:586-661) for a batch: zvals [n][130][130] -> ao_lighting [n][129][129]
 inline void tiles_ao_lighting(int const *tile_xy, unsigned n, float const *zvals, unsigned char *ao) {
 	check(terra_tiles_ao_lighting(default_ctx(), tile_xy, n, zvals, ao), "calc_mesh_ao_lighting");

@@ -294,6 +294,18 @@ REF_API void ref_set_start_eval_sin(int v) {start_eval_sin = v; TERRA_RESYNC}
 REF_API void ref_set_erode_amount(float v) {erode_amount = v; TERRA_RESYNC}
 REF_API void ref_get_ground_mesh(float *out) {memcpy(out, mesh_height_store.data(), mesh_height_store.size()*sizeof(float));}
 REF_API float ref_sin_table(int i) {return sin_table[i];}
+// read_mesh / write_mesh themselves (src/mesh_gen.cpp:895-965); zbottom / ztop are what set_zvals left
+bool read_mesh(const char *filename, float zmm);
+bool write_mesh(const char *filename);
+extern float zbottom, ztop;
+REF_API int ref_read_mesh(const char *filename, float zmm, float *zbottom_ztop) {
+	bool const ok(read_mesh(filename, zmm));
+	if (ok && zbottom_ztop) {zbottom_ztop[0] = zbottom; zbottom_ztop[1] = ztop;}
+	if (ok) {TERRA_RESYNC}
+	return ok;
+}
+REF_API int ref_write_mesh(const char *filename) {return write_mesh(filename);}
+REF_API void ref_set_ground_mesh(const float *in) {memcpy(mesh_height_store.data(), in, mesh_height_store.size()*sizeof(float));}
 
 // mesh_xy_grid_cache_t::build_arrays + enable_glaciate + the caller's eval_index double loop
 // (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:455-464,495-514)

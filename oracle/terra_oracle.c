@@ -761,6 +761,46 @@ void  orc_set_start_eval_sin(int v) {start_eval_sin = v;}
 void  orc_set_erode_amount(float v) {erode_amount = v;}
 void  orc_get_ground_mesh(float *out) {memcpy(out, ground_mesh, (size_t)MESH_X_SIZE*MESH_Y_SIZE*sizeof(float));}
 float orc_sin_table(int i) {return sin_table[i];}
+
+/* read_mesh / write_mesh (src/mesh_gen.cpp:895-965): "nx ny" + ny rows of nx heights; mesh_height = mesh_file_scale*height + mesh_file_tz, then calc_zminmax (matrix_min_max,
+ * :84-98), set_zmax_est((zmm != 0.0) ? zmm : max(-zmin, zmax)) and set_zvals (:494-504).  Returns 1 like the reference, 0 on its error paths.  zbottom_ztop: set_zvals' zbottom / ztop. */
+static float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f; /* src/mesh_gen.cpp:41 */
+int orc_read_mesh(const char *filename, float zmm, float *zbottom_ztop) {
+	FILE *fp = filename ? fopen(filename, "r") : NULL;
+	int xsize, ysize;
+	float height;
+	if (!fp) return 0;
+	if (fscanf(fp, "%i%i", &xsize, &ysize) != 2) {fclose(fp); return 0;}
+	if (xsize != MESH_X_SIZE || ysize != MESH_Y_SIZE) {fclose(fp); return 0;}
+	for (int i = 0; i < MESH_Y_SIZE; ++i) {
+		for (int j = 0; j < MESH_X_SIZE; ++j) {
+			if (fscanf(fp, "%f", &height) != 1) {fclose(fp); return 0;}
+			ground_mesh[(size_t)i*MESH_X_SIZE + j] = mesh_file_scale*height + mesh_file_tz;
+		}
+	}
+	fclose(fp);
+	{ /* calc_zminmax: std::min / std::max */
+		float mn = ground_mesh[0], mx = ground_mesh[0];
+		for (size_t k = 0; k < (size_t)MESH_X_SIZE*MESH_Y_SIZE; ++k) {float const v = ground_mesh[k]; mn = (v < mn) ? v : mn; mx = (mx < v) ? v : mx;}
+		zmin = mn; zmax = mx;
+	}
+	set_zmax_est((zmm != 0.0f) ? zmm : ((-zmin < zmax) ? zmax : -zmin));
+	if (zbottom_ztop) {zbottom_ztop[0] = zmin; zbottom_ztop[1] = zmax;}
+	zmin = -zmax_est; zmax = zmax_est; water_plane_z = get_water_z_height(); /* set_zvals */
+	return 1;
+}
+int orc_write_mesh(const char *filename) {
+	FILE *fp = filename ? fopen(filename, "w") : NULL;
+	if (!fp) return 0;
+	if (!fprintf(fp, "%i %i\n", MESH_X_SIZE, MESH_Y_SIZE)) {fclose(fp); return 0;}
+	for (int i = 0; i < MESH_Y_SIZE; ++i) {
+		for (int j = 0; j < MESH_X_SIZE; ++j) {if (!fprintf(fp, "%f ", ground_mesh[(size_t)i*MESH_X_SIZE + j])) {fclose(fp); return 0;}}
+		fprintf(fp, "\n");
+	}
+	fclose(fp);
+	return 1;
+}
+void orc_set_ground_mesh(const float *in) {memcpy(ground_mesh, in, (size_t)MESH_X_SIZE*MESH_Y_SIZE*sizeof(float));}
 int   orc_num_threads(void) {return omp_get_max_threads();}
 void  orc_set_num_threads(int n) {omp_set_num_threads(n);}
 
@@ -831,7 +871,7 @@ void  orc_rand_uniforms(long s1, long s2, float a, float b, int n, float *out) {
  * grayscale image, scaled by scale_mh_texture_val (src/mesh_gen.cpp:120-131).  The oracle keeps its own copy (brushes and mods edit it). */
 static unsigned char *hm_data = NULL;
 static int hm_width = 0, hm_height = 0, hm_ncolors = 0;
-static float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;
+/* (mesh_file_scale / mesh_file_tz: defined with orc_read_mesh above) */
 #define HMAP_DETAIL_SCALE 16.0f /* src/heightmap.h:8-9 */
 #define HMAP_DETAIL_MAG   0.01f
 void orc_hmap_set(unsigned char const *pixels, int width, int height, int ncolors) {

@@ -100,6 +100,9 @@ int   orc_hmap_read_and_apply_mod(char const *fn);
 void  orc_heightmap_proc_gen(int width, int height, unsigned iters, unsigned char *pixels, float *file_scale_tz);
 /* rest of row a12: the loaded-heightmap path (src/heightmap.cpp:117-128,191-215; config `mh_filename <png> <scale> <tz>`, src/3DWorld.cpp:2205) */
 void  orc_set_mesh_file_scale(float mesh_file_scale, float mesh_file_tz);
+int   orc_read_mesh(const char *filename, float zmm, float *zbottom_ztop); /* read_mesh, src/mesh_gen.cpp:895-933 */
+int   orc_write_mesh(const char *filename);                                /* write_mesh, :936-965 */
+void  orc_set_ground_mesh(const float *in);
 void  orc_heightmap_to_floats(unsigned char const *pixels, int width, int height, int ncolors, float *vals);
 unsigned orc_heightmap_from_floats(float const *vals, int width, int height, int ncolors, unsigned char *pixels);   /* -> values outside [0, 256) */
 unsigned orc_heightmap_postprocess(unsigned char *pixels, int width, int height, int ncolors, unsigned iters_tt);    /* in place; -> values outside [0, 256) */

@@ -146,6 +146,26 @@ def main():
     out["rand_floats_1_12345"] = R.rand_floats(1, 12345, 256)
     out["rand_uniforms_1_12345"] = R.rand_uniforms(1, 12345, 0.2, 1.0, 256)
     out["sin_table"] = R.sin_table()
+    # read_mesh / write_mesh (src/mesh_gen.cpp:895-965; BASELINE config 1's `mesh_file mapx/mesh128.txt`): the reference's own file through its own reader, with the default and
+    # with a non-trivial mesh_file_scale / mesh_file_tz / read_mesh_zmm; and the text its writer produces for a generated ground mesh
+    import tempfile
+    mesh_txt = "/root/reference/mapx/mesh128.txt"
+    out["rm_mesh128_txt"] = np.frombuffer(open(mesh_txt, "rb").read(), np.uint8).copy()
+    for key, (scale, tz, zmm) in (("plain", (1.0, 0.0, 0.0)), ("scaled", (2.5, -0.75, 3.0))):
+        R.init(orclib.make_config(mesh_gen_mode=0))
+        R.set_mesh_file_scale(scale, tz)
+        ok, zz = R.read_mesh(mesh_txt, zmm)
+        assert ok
+        out[f"rm_{key}_mesh"] = R.ground_mesh()
+        out[f"rm_{key}_zbottom_ztop"] = np.array(zz, np.float32)
+        for k, v in state_dict(R.state()).items():
+            if k in ("zmin", "zmax", "zmax_est", "water_plane_z"):
+                out[f"rm_{key}_state_{k}"] = v
+    R.set_mesh_file_scale(1.0, 0.0)
+    R.init(orclib.make_config(mesh_gen_mode=0))
+    with tempfile.TemporaryDirectory() as td:
+        assert R.write_mesh(os.path.join(td, "m.txt"), out["m0_ground"])
+        out["wm_m0_ground_txt"] = np.frombuffer(open(os.path.join(td, "m.txt"), "rb").read(), np.uint8).copy()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")), "bytes;", len(out), "arrays")
 

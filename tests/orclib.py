@@ -145,6 +145,9 @@ class Checker:
         f("set_start_eval_sin", None, [C.c_int])
         f("set_erode_amount", None, [C.c_float])
         f("get_ground_mesh", None, [C.c_void_p])
+        f("set_ground_mesh", None, [C.c_void_p])
+        f("read_mesh", C.c_int, [C.c_char_p, C.c_float, C.c_void_p])
+        f("write_mesh", C.c_int, [C.c_char_p])
         f("sin_table", C.c_float, [C.c_int])
         f("num_threads", C.c_int, [])
         f("set_num_threads", None, [C.c_int])
@@ -230,6 +233,17 @@ class Checker:
         out = np.zeros((n, n), np.float32)
         self._get_ground_mesh(out.ctypes.data)
         return out
+
+    def read_mesh(self, path, zmm=0.0):
+        """read_mesh (src/mesh_gen.cpp:895-933) -> (ok, mesh [MESH_Y, MESH_X] or None, (zbottom, ztop))"""
+        zz = np.zeros(2, np.float32)
+        ok = bool(self._read_mesh(os.fsencode(path), zmm, zz.ctypes.data))
+        return ok, (tuple(zz) if ok else None)
+
+    def write_mesh(self, path, mesh):
+        mesh = np.ascontiguousarray(mesh, np.float32)
+        self._set_ground_mesh(mesh.ctypes.data)
+        return bool(self._write_mesh(os.fsencode(path)))
 
     def sin_table(self):
         return np.array([self._sin_table(i) for i in range(65536)], np.float32)

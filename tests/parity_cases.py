@@ -785,6 +785,63 @@ def case_ground_mesh_and_point_queries(pkg, t, orc):
     assert_bit_equal(got, G["sin_terms"], "eval_mesh_sin_terms")
 
 
+def case_mesh_text_file(pkg, t, orc, tmp_path):
+    """config 1's literal plumbing: read_mesh / write_mesh (src/mesh_gen.cpp:895-965).  Golden = the reference's own reader on its own mapx/mesh128.txt (the file's bytes travel in
+    the fixture) and its own writer's text; then a write -> read round trip against the checker at hand, and the error paths (missing file, wrong size, short file)."""
+    G = golden()
+    src = tmp_path / "mesh128.txt"
+    src.write_bytes(G["rm_mesh128_txt"].tobytes())
+    for key, (scale, tz, zmm) in (("plain", (1.0, 0.0, 0.0)), ("scaled", (2.5, -0.75, 3.0))):
+        t.init_scene(pkg.make_config(mesh_gen_mode=0))
+        t.set_mesh_file_scale(scale, tz)
+        m, zz = t.read_mesh(src, 128, 128, zmm)
+        assert_bit_equal(m, G[f"rm_{key}_mesh"], f"read_mesh {key}")
+        assert_bit_equal(np.array(zz, np.float32), G[f"rm_{key}_zbottom_ztop"], f"read_mesh {key} zbottom/ztop")
+        st = t.state()
+        for k in ("zmin", "zmax", "zmax_est", "water_plane_z"):
+            assert np.float32(getattr(st, k)).tobytes() == G[f"rm_{key}_state_{k}"].tobytes(), (key, k, getattr(st, k), G[f"rm_{key}_state_{k}"])
+        # the same through the checker (the C restatement, or the reference's read_mesh itself)
+        orc.init(orclib.make_config(mesh_gen_mode=0))
+        orc.set_mesh_file_scale(scale, tz)
+        ok, ozz = orc.read_mesh(str(src), zmm)
+        assert ok
+        assert_bit_equal(orc.ground_mesh(), m, f"checker read_mesh {key}")
+        assert tuple(np.float32(ozz)) == tuple(np.float32(zz))
+    t.set_mesh_file_scale(1.0, 0.0); orc.set_mesh_file_scale(1.0, 0.0)
+    # write_mesh: byte-identical text; reading it back gives the "%f"-rounded mesh, the same through both
+    dst, odst = tmp_path / "out.txt", tmp_path / "out_orc.txt"
+    t.write_mesh(dst, G["m0_ground"])
+    assert dst.read_bytes() == G["wm_m0_ground_txt"].tobytes()
+    assert orc.write_mesh(str(odst), G["m0_ground"]) and odst.read_bytes() == dst.read_bytes()
+    t.init_scene(pkg.make_config(mesh_gen_mode=0))
+    back, _ = t.read_mesh(dst, 128, 128)
+    assert np.abs(back - G["m0_ground"]).max() <= 5.1e-7 and (back != G["m0_ground"]).any()
+    ok, _ = orc.read_mesh(str(dst))
+    assert ok
+    assert_bit_equal(orc.ground_mesh(), back, "round trip")
+    # a non-square mesh keeps its row order
+    r = np.arange(5 * 3, dtype=np.float32).reshape(5, 3) / 7
+    t.write_mesh(tmp_path / "r.txt", r)
+    rb, rzz = t.read_mesh(tmp_path / "r.txt", 3, 5)
+    assert np.abs(rb - r).max() < 1e-6 and rb.shape == (5, 3) and rzz == (rb.min(), rb.max())
+    # error paths: the reference prints a message and returns 0; here TERRA_ERR_ARG, and the scene state is left alone
+    st0 = t.state()
+    for bad, shape in ((tmp_path / "missing.txt", (128, 128)), (dst, (64, 128)), (tmp_path / "short.txt", (128, 128)), (tmp_path / "nohdr.txt", (128, 128))):
+        if bad.name == "short.txt":
+            bad.write_bytes(dst.read_bytes()[:2000])
+        if bad.name == "nohdr.txt":
+            bad.write_text("x y\n1 2 3\n")
+        try:
+            t.read_mesh(bad, shape[0], shape[1])
+        except pkg.TerraError as e:
+            assert e.code == -1, e  # TERRA_ERR_ARG
+        else:
+            raise AssertionError(f"read_mesh accepted {bad.name}")
+    st1 = t.state()
+    assert all(getattr(st0, k) == getattr(st1, k) for k in ("zmin", "zmax", "zmax_est", "water_plane_z"))
+    assert not orc.read_mesh(str(tmp_path / "missing.txt"))[0] and not orc.read_mesh(str(tmp_path / "short.txt"))[0]
+
+
 def case_gen_grid_minmax(pkg, t, orc, mode, n):
     pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode)
     st = t.init_scene(pc_)

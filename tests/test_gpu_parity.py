@@ -161,6 +161,10 @@ def test_ground_mesh_and_point_queries(pkg, gpu, orc):
     pc.case_ground_mesh_and_point_queries(pkg, gpu, orc)
 
 
+def test_mesh_text_file_read_write(pkg, gpu, orc, tmp_path):
+    pc.case_mesh_text_file(pkg, gpu, orc, tmp_path)
+
+
 def test_generator_protocol(pkg, gpu, orc):
     pc.case_generator_protocol(pkg, gpu, orc)
 

@@ -181,6 +181,10 @@ def test_ground_mesh_and_point_queries(pkg, emul, orc):
     pc.case_ground_mesh_and_point_queries(pkg, emul, orc)
 
 
+def test_mesh_text_file_read_write(pkg, emul, orc, tmp_path):
+    pc.case_mesh_text_file(pkg, emul, orc, tmp_path)
+
+
 @pytest.mark.parametrize("mode,nx,ny,nstrips", [(0, 300, 200, 3), (1, 90, 70, 4), (4, 40, 33, 2)])
 def test_grid_row_strips(pkg, emul, orc, mode, nx, ny, nstrips):
     pc.case_grid_row_strips(pkg, emul, orc, mode, nx, ny, nstrips)

@@ -527,3 +527,41 @@ def test_oracle_vs_reference_mesh_seed_zero_fresh_process(ref):
         for key in ("sinTable", "rx", "ry", "zmax_est", "grid"):
             assert a[k][key] == b[k][key], (k, key)
     assert a[0]["sinTable"] != a[1]["sinTable"]
+
+
+def test_oracle_read_write_mesh_vs_golden_and_reference(orc, ref, tmp_path):
+    """read_mesh / write_mesh (src/mesh_gen.cpp:895-965): the restatement against the reference's own reader on its own mapx/mesh128.txt (golden; the real file too when
+    the reference tree is here), the writer's text byte for byte, and a mesh with extreme values through both"""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    src = tmp_path / "mesh128.txt"
+    src.write_bytes(G["rm_mesh128_txt"].tobytes())
+    real = "/root/reference/mapx/mesh128.txt"
+    for key, (scale, tz, zmm) in (("plain", (1.0, 0.0, 0.0)), ("scaled", (2.5, -0.75, 3.0))):
+        for path in [str(src)] + ([real] if os.path.exists(real) else []):
+            for ck in (orc, ref):
+                ck.init(orclib.make_config(mesh_gen_mode=0))
+                ck.set_mesh_file_scale(scale, tz)
+                ok, zz = ck.read_mesh(path, zmm)
+                assert ok
+                assert ck.ground_mesh().tobytes() == G[f"rm_{key}_mesh"].tobytes(), (key, ck.kind)
+                assert np.array(zz, np.float32).tobytes() == G[f"rm_{key}_zbottom_ztop"].tobytes()
+                st = ck.state()
+                for k in ("zmin", "zmax", "zmax_est", "water_plane_z"):
+                    assert np.float32(getattr(st, k)).tobytes() == G[f"rm_{key}_state_{k}"].tobytes(), (key, ck.kind, k)
+    rng = np.random.default_rng(5)
+    m = (rng.standard_normal((128, 128)) * 10.0 ** rng.integers(-8, 9, (128, 128))).astype(np.float32)
+    texts = []
+    for ck in (orc, ref):
+        ck.init(orclib.make_config(mesh_gen_mode=0))
+        ck.set_mesh_file_scale(1.0, 0.0)
+        p = tmp_path / f"w_{ck.kind}.txt"
+        assert ck.write_mesh(str(p), m)
+        texts.append(p.read_bytes())
+    assert texts[0] == texts[1]
+    backs = []
+    for ck in (orc, ref):
+        ok, zz = ck.read_mesh(str(tmp_path / "w_orc.txt"))
+        assert ok
+        backs.append((ck.ground_mesh().tobytes(), tuple(zz), ck.state().zmax_est))
+    assert backs[0] == backs[1]
+    assert not orc.read_mesh(str(tmp_path / "nope.txt"))[0] and not ref.read_mesh(str(tmp_path / "nope.txt"))[0]
