@@ -737,7 +737,7 @@ template<class BE> struct terra_engine {
 	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27183336 droplets (the reference's int seed 79*iter+121 overflows)");}
 
 	uint32_t spec_batch_override = getenv("TERRA_ERO_BATCH") ? (uint32_t)std::max(1, atoi(getenv("TERRA_ERO_BATCH"))) : 0u; // experiment knob: rounds per host read-back
-	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 128, max_rounds = 4000000, near_count = 512;} spec_cfg;
+	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 96, max_rounds = 4000000, near_count = 128;} spec_cfg;
 
 	// d_min (optional): min_zval is read from this DEVICE float when the final clamp runs (the only place apply_erosion uses it, src/erosion.cpp:158-162) -- the caller's
 	// noise kernel left it there (gen_grid_dev's d_minmax), no host round trip between a heightmap's noise and its erosion
@@ -803,6 +803,8 @@ template<class BE> struct terra_engine {
 		uint32_t W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
 		sb.near_count = spec_cfg.near_count;
 		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = SPEC_CK_MAX;
+		sb.live_partial = 1u;
+		if (char const *lv = getenv("TERRA_ERO_LIVE")) {sb.live_partial = (lv[0] != '0') ? 1u : 0u;} // experiment knob; results never depend on it
 		{char const *dg = getenv("TERRA_ERO_DIAG"); sb.diag = (dg && dg[0] == '1') ? 1u : 0u;}
 		if (char const *ck = getenv("TERRA_ERO_CK")) {int a = 0, b = 0; if (sscanf(ck, "%d:%d", &a, &b) == 2 && a >= 1 && b >= 0 && b <= (int)SPEC_CK_MAX) {sb.ck_steps = (uint32_t)a; sb.ck_max = (uint32_t)b;}} // experiment knob "steps:max"; results never depend on it
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block
@@ -829,9 +831,9 @@ template<class BE> struct terra_engine {
 				o_cks[b] = carve((size_t)W*ckn*sizeof(droplet_state_t)); o_ckn[b] = carve((size_t)W*ckn*4); o_cku[b] = carve((size_t)W*ckn*4);
 				o_ckm[b] = carve((size_t)W*ckn*sb.maxb*8); o_ckc[b] = carve(W*4); o_ui[b] = carve((size_t)W*unn*4); o_uv[b] = carve((size_t)W*unn*4); o_un[b] = carve(W*4);
 			}
-			o_slot = carve((size_t)W*4*13); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry
+			o_slot = carve((size_t)W*4*14); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry, vbuf
 			o_state = carve((size_t)W*sizeof(droplet_state_t)); o_resume = carve((size_t)W*sizeof(spec_resume_t));
-			o_next = carve((size_t)W*sb.maxb*4); o_nodeblk = carve((size_t)W*sb.maxb*4); o_dlist = carve((size_t)W*sb.maxb*8); o_ctl = carve(sizeof(spec_ctl_t));
+			o_next = carve((size_t)W*sb.maxb*4); o_nodeblk = carve((size_t)W*sb.maxb*4); o_dlist = carve((size_t)W*sb.maxb*16); o_ctl = carve(sizeof(spec_ctl_t));
 			o_touched = carve((size_t)touched_cap*4 + 4);
 			return off;
 		};
@@ -855,10 +857,10 @@ template<class BE> struct terra_engine {
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
 		sb.it = slot_arrays; sb.phase = slot_arrays + W; sb.has_ver = slot_arrays + 2*(size_t)W; sb.cur = slot_arrays + 3*(size_t)W; sb.changed = slot_arrays + 4*(size_t)W;
 		sb.restart = slot_arrays + 5*(size_t)W; sb.run_nblk = slot_arrays + 6*(size_t)W; sb.flags = slot_arrays + 7*(size_t)W; sb.nsteps = slot_arrays + 8*(size_t)W;
-		sb.linked = slot_arrays + 9*(size_t)W; sb.rsrc = slot_arrays + 10*(size_t)W; sb.rat = slot_arrays + 11*(size_t)W; sb.rentry = slot_arrays + 12*(size_t)W;
+		sb.linked = slot_arrays + 9*(size_t)W; sb.rsrc = slot_arrays + 10*(size_t)W; sb.rat = slot_arrays + 11*(size_t)W; sb.rentry = slot_arrays + 12*(size_t)W; sb.vbuf = slot_arrays + 13*(size_t)W;
 		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
-		sb.next = (uint32_t *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.ctl = (spec_ctl_t *)(base + o_ctl);
+		sb.next = (uint32_t *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.dirty_list2[0] = sb.dirty_list + 2*(size_t)W*sb.maxb; sb.dirty_list2[1] = sb.dirty_list + 3*(size_t)W*sb.maxb; sb.ctl = (spec_ctl_t *)(base + o_ctl);
 		// block -> list head and block -> dirty mark: one entry per 8x8 block of the padded grid.  Every run resets exactly the entries it set
 		// (spec_unlink_body / spec_undirty_body), so the O(grid) fill is paid only when the arrays are (re)allocated or the grid shape changes.
 		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks);
@@ -868,6 +870,7 @@ template<class BE> struct terra_engine {
 		spec_buffers_t const s = sb;
 		be.fill32(slot_arrays, 0, (size_t)W*11);
 		be.fill32(sb.rat, SPEC_NIL, (size_t)W*2); // rat, rentry
+		be.fill32(sb.vbuf, SPEC_VIS_NONE, W);
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
 		for (int b = 0; b < 2; ++b) {be.fill32(sb.ck_cnt[b], 0, W); be.fill32(sb.undo_n[b], 0, W);}
 		be.fill32(sb.node_blk, SPEC_NIL, (size_t)W*sb.maxb);
@@ -900,12 +903,12 @@ template<class BE> struct terra_engine {
 				});
 				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // rebuild the writer lists from the published versions; who must start over
 					uint32_t const slot = (uint32_t)(i >> 6), l = (uint32_t)(i & 63u);
-					uint32_t const pub = (s.it[slot] != SPEC_NIL && s.has_ver[slot]) ? s.blk_cnt[s.cur[slot]][slot] : 0u, run = s.run_nblk[slot], n = (pub > run) ? pub : run;
+					uint32_t const pub = spec_visible_count(s, slot), run = s.run_nblk[slot], n = (pub > run) ? pub : run; // (pub: entries of the version higher droplets read)
 					for (uint32_t e = l; e < n; e += 64) {spec_link_body(s, slot, e); spec_mark_body(s, slot, e);}
 					if (l == 0) {s.linked[slot] = pub;}
 				});
 				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // apply the restarts, find the commit point; reset the dirty marks
-					uint32_t const nd = s.ctl->ndirty;
+					uint32_t const nd1 = s.ctl->ndirty, nd2 = (s.ctl->par & 1u) ? s.ctl->nd2[0] : s.ctl->nd2[1], nd = (nd1 > nd2) ? nd1 : nd2;
 					for (size_t k = i; k < nd; k += (size_t)s.W*64) {spec_undirty_body(s, (uint32_t)k);}
 					if (i < s.W) {spec_scan_body(s, (uint32_t)i);}
 				});

@@ -644,6 +644,7 @@ struct wave_shared_t { // per-wave LDS scratch
 	uint32_t map_keys[SPEC_MAP_SLOTS];       // block id (SPEC_NIL: free)
 	uint8_t  map_ent[SPEC_MAP_SLOTS];        // its entry in the trace's block list = its page
 	unsigned long long masks[SPEC_MAXB];     // per entry: which cells of the block this trace has written back to its page
+	uint32_t wrote[SPEC_MAXB/32];            // bit e: entry e was written back to in THIS slice (spec_back_t::store)
 };
 
 template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
@@ -826,7 +827,9 @@ constexpr uint32_t SPEC_NIL   = 0xFFFFFFFFu;
 enum {SPEC_F_LOG_OVERFLOW = 1, SPEC_F_BLK_OVERFLOW = 2, SPEC_F_NAN = 4, SPEC_F_UNDO_OVERFLOW = 8};
 constexpr uint32_t SPEC_BLK_WRITTEN = 0x80000000u; // block-list entry flag: the trace has WRITTEN cells of the block (else it only read them)
 constexpr uint32_t SPEC_BLK_CHANGED = 0x40000000u; // ... and what it wrote there differs from what the droplet's previously published version wrote there (or there is no such version)
-constexpr uint32_t SPEC_BLK_ID      = 0x3FFFFFFFu; // the block number
+constexpr uint32_t SPEC_BLK_NOW     = 0x20000000u; // ... the trace wrote cells of the block back during its LATEST slice (set for every entry when the trace stops; a version that is visible while it grows changes exactly there)
+constexpr uint32_t SPEC_BLK_ID      = 0x1FFFFFFFu; // the block number
+constexpr uint32_t SPEC_VIS_NONE    = 2u;          // spec_buffers_t::vbuf: the slot has no version a higher droplet may read
 // life of a ring slot: FRESH (trace from the spawn) -> RUNNING (trace suspended at a step boundary, state saved) -> DONE_NEW (finished in
 // this round, not published yet) -> IDLE (its finished version is published and believed valid); FAILED = the trace overflowed its log or
 // block list and waits to become the lowest uncommitted droplet, which then runs alone directly on the grid.
@@ -845,6 +848,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	uint32_t touched;      // cells recorded for the sparse clamp (may exceed the capacity)
 	uint32_t fb_steps, fb_nan; // fall-back droplet
 	uint32_t ndirty;       // entries of dirty_list
+	uint32_t nd2[2], par;  // entries of dirty_list2[]; this round's resume pass appends to dirty_list2[par], its scan pass resets the marks of dirty_list2[par ^ 1] (made a round ago)
 	uint32_t round_max_steps, round_max_shifts; // most steps / window moves of one trace in this round (diagnostics)
 	uint32_t ck_resumes, pad4_;                 // re-traces that resumed from a checkpoint
 	unsigned long long ck_steps_saved;          // steps those did not have to repeat
@@ -868,6 +872,7 @@ struct spec_buffers_t {
 	uint32_t W;            // ring slots; droplet `it` lives in slot it % W, in-flight droplets are [base, base + W)
 	uint32_t diag;         // collect the device-clock breakdown (terra_erosion_report clk_* / crit_clk_*)
 	uint32_t ck_steps, ck_max; // steps between checkpoints of a trace, most checkpoints per trace (0: no checkpoints)
+	uint32_t live_partial; // a first trace is visible to higher droplets while it grows, slice by slice (0: versions appear when their trace has finished; experiment knob, results never depend on it)
 	uint32_t near_count;   // the first near_count in-flight droplets (the next to commit) trace without a step budget; the others are sliced (0: all sliced)
 	uint32_t maxb;         // block-list capacity per droplet (<= SPEC_MAXB)
 	uint32_t bshift;       // block edge = 1 << bshift cells (3: a page holds the 8 x 8 cells of a block)
@@ -894,6 +899,8 @@ struct spec_buffers_t {
 	uint32_t *it;          // [W] droplet number held by the slot (SPEC_NIL: none)
 	uint32_t *phase;       // [W]
 	uint32_t *has_ver;     // [W] buffer cur[] holds a published finished version (visible to higher droplets)
+	uint32_t *vbuf;        // [W] the buffer higher droplets read this slot's version from: cur[] when has_ver, else 1 - cur[] while a first trace is suspended (its pages so far: the version
+	                       //     is visible while it grows), else SPEC_VIS_NONE.  Changes only between trace passes (spec_flip_body, spec_resume_wave, re-assignment)
 	uint32_t *cur;         // [W] which buffer holds the published version; a (re)trace builds the other one
 	uint32_t *changed;     // [W] the version finished this round differs from the published one
 	uint32_t *restart;     // [W] set by the mark pass
@@ -907,6 +914,7 @@ struct spec_buffers_t {
 	uint32_t *dirty_min;   // [nbx*nby] lowest droplet whose published version changed in a way that touches the block, this round
 	uint32_t *node_blk;    // [W*maxb]  block a node is currently linked under (SPEC_NIL: not linked): head[] is reset through it, not by an O(grid) fill
 	uint32_t *dirty_list;  // [2*W*maxb] blocks whose dirty_min was lowered this round (duplicates allowed), ctl->ndirty entries
+	uint32_t *dirty_list2[2]; // [W*maxb] each: blocks dirtied AFTER a round's mark pass (a growing version rolled back or dropped, spec_resume_wave) for the NEXT round's; ctl->nd2[], ctl->par
 	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp)
 	uint32_t touched_cap;
 	spec_ctl_t *ctl;
@@ -954,6 +962,7 @@ struct spec_back_t {
 		lx0 = lx1 = lz0 = lz1 = INT_MIN;
 		if (TERRA_LANE0) {sh->flags = rs ? rs->flags : 0; sh->undo_n = rs ? rs->undo_n : 0; sh->chk = 0; sh->n_shift = 0;}
 		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = ((uint32_t)e < nblk) ? my_masks[e] : 0ull;} // a resumed trace: what it has written back so far (saved when it was suspended)
+		TERRA_LANES(q, SPEC_MAXB/32) {sh->wrote[q] = 0u;}
 		TERRA_WAVE_SYNC();
 		rebuild_map(); // (empty for a new trace)
 	}
@@ -981,7 +990,7 @@ struct spec_back_t {
 	// Start this trace from checkpoint k of the slot's trace in buffer `sbuf`: either the suspended trace in this trace's own buffer (rolled back in place) or the
 	// published version in the other buffer (copied: readers keep using it until the new version is published).  Afterwards footprint, masks, pages, undo log and
 	// the checkpoints 0 .. k of this trace are what they were when that checkpoint was taken; the LDS window is empty and is fetched afresh.
-	TERRA_HD void ck_restore(uint32_t sbuf, uint32_t k, droplet_state_t &d) { // (no LDS: runs in the commit kernel's waves)
+	TERRA_HD void ck_restore(uint32_t sbuf, uint32_t k, droplet_state_t &d, uint32_t had_nblk = 0) { // (no LDS: runs in the commit kernel's waves)
 		uint32_t const nb = 1u - sb->cur[slot];
 		bool const copy = (sbuf != nb);
 		size_t const pbase = (size_t)slot*sb->maxb, cb0 = (size_t)slot*SPEC_CK_MAX, ub = (size_t)slot*SPEC_UNDO_MAX;
@@ -992,6 +1001,7 @@ struct spec_back_t {
 		d = sb->ck_state[sbuf][cb0 + k];
 		unsigned long long const *s_ckm = sb->ck_masks[sbuf] + (cb0 + k)*sb->maxb;
 		TERRA_LANES(e, nk) {my_masks[e] = s_ckm[e];} // what a resumed trace starts from (spec_back_t::init)
+		if (!copy) {TERRA_LANES(e, had_nblk) {if ((uint32_t)e >= nk) {my_masks[e] = 0ull;}}} // the entries after the checkpoint are gone: a reader that still finds their nodes in the writer lists sees no cell
 		if (copy) {
 			TERRA_LANES(e, nk) {my_blks[e] = s_blks[e] & SPEC_BLK_ID;}
 			TERRA_LANES(i, nk*SPEC_PAGE) { // every cell the trace had written by then: independent copies
@@ -1023,7 +1033,8 @@ struct spec_back_t {
 			unsigned long long const m = sh->masks[e];
 			my_masks[e] = m;
 			uint32_t const b = my_blks[e] & SPEC_BLK_ID;
-			my_blks[e] = m ? (b | SPEC_BLK_WRITTEN) : b; // only written blocks can invalidate a reader
+			bool const now = ((sh->wrote[(uint32_t)e >> 5] >> ((uint32_t)e & 31u)) & 1u) != 0;
+			my_blks[e] = (m ? (b | SPEC_BLK_WRITTEN) : b) | (now ? SPEC_BLK_NOW : 0u); // only written blocks can invalidate a reader
 		}
 		TERRA_WAVE_SYNC();
 	}
@@ -1061,7 +1072,7 @@ struct spec_back_t {
 	}
 	// a list node counts when its slot holds a published version of a LOWER droplet (nodes of slots that were re-assigned since the lists
 	// were built have no published version yet)
-	TERRA_HD bool lower_version(uint32_t j) const {return sb->has_ver[j] && sb->it[j] < iter;}
+	TERRA_HD bool lower_version(uint32_t j) const {return sb->vbuf[j] != SPEC_VIS_NONE && sb->it[j] < iter;}
 	// which published LOWER versions wrote the blocks under the new window (only those blocks need the multi-version look-up): one lane per block walks the
 	// block's writer list once and leaves the versions in LDS, highest droplet first, so that a cell's look-up is a mask test there plus one load
 	TERRA_HD void prepare_window(int wx0, int wz0) {
@@ -1075,7 +1086,7 @@ struct spec_back_t {
 					uint32_t const j = node / sb->maxb;
 					if (!lower_version(j)) continue;
 					if (cnt == SPEC_CAND) {cnt = SPEC_CAND_MANY; break;}
-					uint32_t const ij = sb->it[j], cb = sb->cur[j];
+					uint32_t const ij = sb->it[j], cb = sb->vbuf[j];
 					spec_cand_t nc; nc.page = node | (cb << 31); nc.it = ij; nc.mask = sb->page_mask[cb][node];
 					uint32_t k = cnt; // insertion by descending droplet number
 					for (; k > 0 && sh->cand[i][k-1].it < ij; --k) {sh->cand[i][k] = sh->cand[i][k-1];}
@@ -1180,7 +1191,7 @@ struct spec_back_t {
 				if (!lower_version(j)) continue;
 				uint32_t const ij = sb->it[j];
 				if (best != SPEC_NIL && ij <= best) continue;
-				uint32_t const cb = sb->cur[j];
+				uint32_t const cb = sb->vbuf[j];
 				if ((sb->page_mask[cb][node] >> c) & 1ull) {best = ij; v = sb->page_vals[cb][(size_t)node*SPEC_PAGE + c];} // node = slot*maxb + entry = index of the page
 			}
 			return v;
@@ -1204,6 +1215,7 @@ struct spec_back_t {
 		}
 		my_pages[idx] = val;
 		TERRA_ATOMIC_OR(&sh->masks[e], 1ull << c);
+		TERRA_ATOMIC_OR(&sh->wrote[e >> 5], 1u << (e & 31u));
 	}
 };
 
@@ -1311,19 +1323,52 @@ TERRA_HD void spec_trace_wave(spec_buffers_t const &sb, uint32_t slot, uint32_t 
 TERRA_HD void spec_resume_wave(spec_buffers_t const &sb, uint32_t slot) {
 	uint32_t iter;
 	if (!spec_slot_active(sb, slot, iter)) return;
+	if (sb.phase[slot] != SPEC_FRESH) return;
 	uint32_t const rs = sb.rsrc[slot];
-	if (sb.phase[slot] != SPEC_FRESH || !rs) return;
-	uint32_t const sbuf = (rs == 1u) ? sb.cur[slot] : 1u - sb.cur[slot], cnt = sb.ck_cnt[sbuf][slot], upto = sb.rat[slot];
+	// a first trace that higher droplets have been reading while it grew (vbuf) is about to be rolled back to a checkpoint, or dropped: what it showed changes NOW, after this
+	// round's mark pass -- the blocks concerned are marked for the next round's (dirty_list2).  (A paused slot keeps what it shows until it is active again.)
+	bool const vis = !sb.has_ver[slot] && sb.vbuf[slot] != SPEC_VIS_NONE;
+	if (!rs && !vis) return;
+	uint32_t const nb = 1u - sb.cur[slot];
+	uint32_t const sbuf = (rs == 1u) ? sb.cur[slot] : nb, cnt = rs ? sb.ck_cnt[sbuf][slot] : 0u, upto = sb.rat[slot];
 	uint32_t k = SPEC_NIL;
 	for (uint32_t i = 0; i < cnt; ++i) {if (sb.ck_nblk[sbuf][(size_t)slot*SPEC_CK_MAX + i] <= upto) {k = i;}} // footprint lengths grow with the checkpoint number
+	uint32_t const had = sb.run_nblk[slot];
+	if (vis) {
+		size_t const pbase = (size_t)slot*sb.maxb, cb0 = (size_t)slot*SPEC_CK_MAX;
+		uint32_t const *bl = sb.blk_list[nb] + pbase;
+		unsigned long long const *msk = sb.page_mask[nb] + pbase;
+		bool const inplace = (k != SPEC_NIL); // (rs == 2: a slot without a published version has no other trace to resume from)
+		uint32_t const nk = inplace ? sb.ck_nblk[nb][cb0 + k] : 0u, uk = inplace ? sb.ck_undo[nb][cb0 + k] : 0u, un = inplace ? sb.undo_n[nb][slot] : 0u;
+		unsigned long long const *ckm = sb.ck_masks[nb] + (cb0 + (inplace ? k : 0u))*sb.maxb;
+		uint32_t const *uidx = sb.undo_idx[nb] + (size_t)slot*SPEC_UNDO_MAX;
+		bool const odd = (sb.ctl->par & 1u) != 0;
+		uint32_t *const cnt2 = odd ? &sb.ctl->nd2[1] : &sb.ctl->nd2[0], *const lst2 = odd ? sb.dirty_list2[1] : sb.dirty_list2[0];
+		for (uint32_t q0 = 0; q0 < had; q0 += 64) {
+			TERRA_EACH_LANE(l) {
+				uint32_t const e = q0 + (uint32_t)l;
+				uint32_t b = SPEC_NIL;
+				if (e < had) {
+					uint32_t const ent = bl[e];
+					if (ent & SPEC_BLK_WRITTEN) {
+						bool ch = (e >= nk) || (msk[e] != ckm[e]); // gone, or cells written back since the checkpoint
+						if (!ch) {for (uint32_t q = uk; q < un; ++q) {if (uidx[q]/SPEC_PAGE == e) {ch = true; break;}}} // or a cell that gets back what it held then
+						if (ch) {b = ent & SPEC_BLK_ID;}
+					}
+				}
+				uint32_t const kk = wave_reserve(cnt2, (b != SPEC_NIL) ? 1u : 0u);
+				if (b != SPEC_NIL) {TERRA_ATOMIC_MIN(&sb.dirty_min[b], iter); lst2[kk] = b;}
+			}
+		}
+		TERRA_WAVE_SYNC();
+	}
 	if (k != SPEC_NIL) {
-		uint32_t const nb = 1u - sb.cur[slot];
 		spec_back_t back;
 		back.sb = &sb; back.sh = nullptr; back.slot = slot; back.iter = iter;
 		back.my_pages = sb.page_vals[nb] + (size_t)slot*sb.maxb*SPEC_PAGE; back.my_masks = sb.page_mask[nb] + (size_t)slot*sb.maxb; back.my_blks = sb.blk_list[nb] + (size_t)slot*sb.maxb;
 		back.my_undo_idx = sb.undo_idx[nb] + (size_t)slot*SPEC_UNDO_MAX; back.my_undo_val = sb.undo_val[nb] + (size_t)slot*SPEC_UNDO_MAX;
 		droplet_state_t d;
-		back.ck_restore(sbuf, k, d);
+		back.ck_restore(sbuf, k, d, had);
 		if (TERRA_LANE0) {
 			sb.state[slot] = d;
 			spec_resume_t r; r.nblk = back.nblk; r.flags = 0; r.undo_n = sb.ck_undo[nb][(size_t)slot*SPEC_CK_MAX + k]; r.nck = k + 1;
@@ -1333,7 +1378,10 @@ TERRA_HD void spec_resume_wave(spec_buffers_t const &sb, uint32_t slot) {
 			TERRA_ATOMIC_ADD(&sb.ctl->traces, 1u); TERRA_ATOMIC_ADD(&sb.ctl->ck_resumes, 1u); TERRA_ATOMIC_ADD(&sb.ctl->ck_steps_saved, (unsigned long long)d.numMoves);
 		}
 	}
-	if (TERRA_LANE0) {sb.rsrc[slot] = 0;}
+	if (TERRA_LANE0) {
+		sb.rsrc[slot] = 0;
+		if (vis) {sb.vbuf[slot] = (k != SPEC_NIL) ? nb : SPEC_VIS_NONE;} // rolled back in place: still there, as it was at the checkpoint; else the next trace starts from the spawn
+	}
 }
 // the lowest uncommitted droplet, alone, directly on the grid (overflow fall-back)
 TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &ec, uint32_t iter, uint32_t *out_steps_nan, wave_scratch_t const &ws,
@@ -1352,13 +1400,46 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 
 TERRA_HD void spec_undirty_body(spec_buffers_t const &sb, uint32_t i) {
 	if (i < sb.ctl->ndirty) {sb.dirty_min[sb.dirty_list[i]] = SPEC_NIL;}
+	// (the two lists are selected, not indexed: `sb.dirty_list2[par ^ 1]` -- a run-time index into an array inside the by-value kernel argument -- read a wrong pointer on gfx950
+	// with this compiler and reset marks that had not been looked at yet; found by bisecting a GPU-only parity failure)
+	bool const odd = (sb.ctl->par & 1u) != 0; // the marks the previous round's resume pass made for this round's mark pass: list par ^ 1
+	uint32_t const n2 = odd ? sb.ctl->nd2[0] : sb.ctl->nd2[1];
+	uint32_t const *l2 = odd ? sb.dirty_list2[0] : sb.dirty_list2[1];
+	if (i < n2) {sb.dirty_min[l2[i]] = SPEC_NIL;}
 }
 // A version finished this round: which of its blocks differ in content (cells written, values) from the droplet's published version -- those, and the blocks
 // the published version wrote and the new one does not even touch, are dirty for every higher droplet.  A re-trace usually repeats most of its predecessor's
 // writes bit for bit (every block before the point where its inputs changed); a first version changes every block it wrote.  One wave per slot, no LDS.
+// A droplet without a published finished version: its FIRST trace, visible to higher droplets while it grows (vbuf = the buffer it is built in) -- they read the pages
+// it has written back as of the end of the previous round.  What changes under them in a round is exactly what the trace wrote back during this round's slice
+// (SPEC_BLK_NOW, set by publish_masks), whether the trace stopped at a slice boundary or at its end; a trace that failed is withdrawn, with everything it had shown.
+TERRA_HD void spec_post_growing(spec_buffers_t const &sb, uint32_t slot, uint32_t iter) {
+	uint32_t const ph = sb.phase[slot], nb = 1u - sb.cur[slot];
+	bool const live = sb.live_partial != 0, withdrawn = (ph == SPEC_FAILED && sb.vbuf[slot] != SPEC_VIS_NONE);
+	if (!(ph == SPEC_DONE_NEW || (live && ph == SPEC_RUNNING) || withdrawn)) return;
+	uint32_t const n = (ph == SPEC_DONE_NEW) ? sb.blk_cnt[nb][slot] : sb.run_nblk[slot];
+	uint32_t *bl = sb.blk_list[nb] + (size_t)slot*sb.maxb;
+	for (uint32_t q0 = 0; q0 < n; q0 += 64) {
+		TERRA_EACH_LANE(l) {
+			uint32_t const q = q0 + (uint32_t)l;
+			uint32_t b = SPEC_NIL;
+			if (q < n) {
+				uint32_t const e = bl[q];
+				bool const hit = (withdrawn || !live) ? ((e & SPEC_BLK_WRITTEN) != 0) : ((e & SPEC_BLK_NOW) != 0); // (not live: the version appears now, with everything it wrote)
+				if (hit) {b = e & SPEC_BLK_ID;}
+				if (ph == SPEC_DONE_NEW) {bl[q] = hit ? (e | SPEC_BLK_CHANGED) : (e & ~SPEC_BLK_CHANGED);}
+			}
+			uint32_t const k = wave_reserve(&sb.ctl->ndirty, (b != SPEC_NIL) ? 1u : 0u);
+			if (b != SPEC_NIL) {TERRA_ATOMIC_MIN(&sb.dirty_min[b], iter); sb.dirty_list[k] = b; TERRA_ATOMIC_OR(&sb.changed[slot], 1u);}
+		}
+	}
+	TERRA_WAVE_SYNC();
+}
 TERRA_HD void spec_post_wave(spec_buffers_t const &sb, uint32_t slot) {
 	uint32_t const iter = sb.it[slot];
-	if (iter == SPEC_NIL || sb.phase[slot] != SPEC_DONE_NEW) return;
+	if (iter == SPEC_NIL) return;
+	if (!sb.has_ver[slot]) {spec_post_growing(sb, slot, iter); return;}
+	if (sb.phase[slot] != SPEC_DONE_NEW) return;
 	uint32_t const ob = sb.cur[slot], nb = 1u - ob;
 	size_t const pbase = (size_t)slot*sb.maxb;
 	uint32_t *nblkl = sb.blk_list[nb] + pbase, *oblk = sb.blk_list[ob] + pbase;
@@ -1413,14 +1494,21 @@ TERRA_HD void spec_post_wave(spec_buffers_t const &sb, uint32_t slot) {
 }
 // publish the versions finished this round
 TERRA_HD void spec_flip_body(spec_buffers_t const &sb, uint32_t slot) {
-	if (sb.it[slot] == SPEC_NIL || sb.phase[slot] != SPEC_DONE_NEW) return;
-	sb.cur[slot] = 1u - sb.cur[slot]; sb.has_ver[slot] = 1; sb.phase[slot] = SPEC_IDLE;
+	if (sb.it[slot] == SPEC_NIL) return;
+	if (sb.phase[slot] == SPEC_DONE_NEW) {sb.cur[slot] = 1u - sb.cur[slot]; sb.has_ver[slot] = 1; sb.phase[slot] = SPEC_IDLE;}
+	// what higher droplets read from this slot in the next trace pass: the published version, else the pages of a suspended first trace
+	sb.vbuf[slot] = sb.has_ver[slot] ? sb.cur[slot] : ((sb.phase[slot] == SPEC_RUNNING && sb.live_partial && sb.run_nblk[slot] != 0) ? 1u - sb.cur[slot] : SPEC_VIS_NONE);
+}
+// entries of the version higher droplets may read (after spec_flip_body)
+TERRA_HD uint32_t spec_visible_count(spec_buffers_t const &sb, uint32_t slot) {
+	if (sb.it[slot] == SPEC_NIL || sb.vbuf[slot] == SPEC_VIS_NONE) return 0u;
+	return sb.has_ver[slot] ? sb.blk_cnt[sb.cur[slot]][slot] : sb.run_nblk[slot];
 }
 // rebuild block -> writer lists from the published footprints (head[] was reset to SPEC_NIL before): one thread per (slot, entry)
 TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t entry) {
-	if (sb.it[slot] == SPEC_NIL || !sb.has_ver[slot]) return;
-	uint32_t const cb = sb.cur[slot];
-	if (entry >= sb.blk_cnt[cb][slot]) return;
+	uint32_t const cb = sb.vbuf[slot];
+	if (sb.it[slot] == SPEC_NIL || cb == SPEC_VIS_NONE) return;
+	if (entry >= spec_visible_count(sb, slot)) return;
 	uint32_t const e = sb.blk_list[cb][(size_t)slot*sb.maxb + entry];
 	if (!(e & SPEC_BLK_WRITTEN)) return; // the lists answer "who wrote here": read-only entries stay out
 	uint32_t const node = slot*sb.maxb + entry, b = e & SPEC_BLK_ID;
@@ -1497,7 +1585,7 @@ TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 TERRA_HD void spec_reassign(spec_buffers_t const &sb, uint32_t slot, uint32_t iter) {
 	uint64_t const nit = (uint64_t)iter + sb.W;
 	sb.it[slot] = (nit < sb.num_iters) ? (uint32_t)nit : SPEC_NIL;
-	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
+	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.vbuf[slot] = SPEC_VIS_NONE; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
 	sb.rsrc[slot] = 0; sb.rentry[slot] = SPEC_NIL; sb.rat[slot] = SPEC_NIL; sb.ck_cnt[0][slot] = 0; sb.ck_cnt[1][slot] = 0;
 }
 // committed droplets leave, their slots are handed to the next droplets: one thread per slot
@@ -1516,6 +1604,8 @@ TERRA_HD void spec_advance_body(spec_buffers_t const &sb) {
 	uint64_t const nb = (uint64_t)c.base + sb.W;
 	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;
 	c.stop_at = c.new_stop; c.new_stop = SPEC_NIL; c.unfinished = 0; c.ndirty = 0;
+	if (c.par & 1u) {c.nd2[0] = 0;} else {c.nd2[1] = 0;}
+	c.par ^= 1u; // the marks of dirty_list2[par ^ 1] were consumed and reset in this round; the next round consumes the ones its resume pass has just made
 	c.crit_steps += c.round_max_steps; c.crit_shifts += c.round_max_shifts; c.round_max_steps = 0; c.round_max_shifts = 0;
 	c.clk_crit += c.round_max_clk; c.round_max_clk = 0;
 	c.crit_own_shift += (c.round_max_pack >> 24) & 0xFFFFFu; c.crit_own_edge += (c.round_max_pack >> 10) & 0x3FFFu; c.crit_own_steps += (c.round_max_pack & 0x3FFu) << 2; c.round_max_pack = 0;
@@ -1527,7 +1617,7 @@ TERRA_HD void spec_fallback_reset_body(spec_buffers_t const &sb, uint32_t slot) 
 	uint32_t const iter = sb.it[slot];
 	if (iter == SPEC_NIL) return;
 	if (iter == sb.ctl->base) {spec_reassign(sb, slot, iter); return;}
-	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
+	sb.phase[slot] = SPEC_FRESH; sb.has_ver[slot] = 0; sb.vbuf[slot] = SPEC_VIS_NONE; sb.blk_cnt[0][slot] = 0; sb.blk_cnt[1][slot] = 0; sb.run_nblk[slot] = 0; sb.restart[slot] = 0;
 	sb.rsrc[slot] = 0; sb.rentry[slot] = SPEC_NIL; sb.rat[slot] = SPEC_NIL; sb.ck_cnt[0][slot] = 0; sb.ck_cnt[1][slot] = 0; // the grid changed under every trace: nothing to resume from
 }
 TERRA_HD void spec_fallback_advance_body(spec_buffers_t const &sb) {

@@ -217,8 +217,9 @@ int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
  * log_capacity_log2: ignored (range-checked only) -- a droplet's writes are kept as one 64-cell page per 8x8 block of its footprint, there is no hashed log to size,
  * per-droplet block-list capacity = pages per droplet (16 .. 256, larger values mean 256).  A droplet whose footprint overflows it runs alone, in order, directly on
  * the grid (still exact).
- * slice_steps: while droplets wait for a slot a trace advances at most this many steps per round (default 128), except the 512 droplets next in line for the
- * commit, which trace to the end.  Results never depend on any of these. */
+ * slice_steps: while droplets wait for a slot a trace advances at most this many steps per round (default 96), except the 128 droplets next in line for the
+ * commit, which trace to the end; a droplet's first trace is visible to the droplets after it from its first slice on (what it has written back so far).
+ * Results never depend on any of these. */
 int  terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t log_capacity_log2, uint32_t block_list_capacity);
 int  terra_set_erosion_slice_steps(terra_ctx *ctx, uint32_t slice_steps);
 
