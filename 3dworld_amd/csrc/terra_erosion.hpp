@@ -624,7 +624,7 @@ constexpr unsigned SPEC_MAP_SLOTS = 512; // open-addressed block -> entry map of
 constexpr unsigned SPEC_PAGE = 64;       // cells of an 8 x 8 block = floats of a version page
 constexpr unsigned SPEC_WIN_BLOCKS = ((EW >> 3) + 1)*((EW >> 3) + 1); // blocks a window can overlap
 constexpr unsigned SPEC_CAND = 16, SPEC_CAND_MANY = 255; // (power of two.  4 -> 16: 30 000 droplets on 1024^2 320 -> 212 ms, sparse runs unchanged; 32: 196 ms but 24 KB of LDS per wave cost the 16384^2 run 4 %)
-constexpr unsigned SPEC_SEL_OWN = SPEC_CAND + 1, SPEC_SEL_SLOW = SPEC_CAND + 2, SPEC_OWN_NONE = 0xFFFFu;
+constexpr unsigned SPEC_OWN_NONE = 0xFFFFu;
 // checkpoints of a trace (measured: profiles/r02_erosion_checkpoint_sweep.txt): every SPEC_CK_STEPS steps the window's dirty cells are written back and the droplet state, the footprint length, the write masks and
 // the position in the undo log are saved, so that a re-trace can resume from the last checkpoint whose inputs are still valid instead of from the spawn
 constexpr unsigned SPEC_CK_STEPS = 32, SPEC_CK_MAX = 16, SPEC_UNDO_MAX = 4096; // (defaults: spec_buffers_t::ck_steps / ck_max are the values in force, ck_max <= SPEC_CK_MAX)
@@ -640,7 +640,9 @@ struct wave_shared_t { // per-wave LDS scratch
 	spec_cand_t cand[SPEC_WIN_BLOCKS][SPEC_CAND]; // those versions, highest droplet first: a cell's value comes from the first whose mask has the cell
 	uint32_t blk_nonempty, pad3_;            // bit i: block i under the window has a lower version or a page of this trace (only those are resolved / looked at)
 	uint16_t blk_own[32];                    // per block under the window: its entry in THIS trace's block list (SPEC_OWN_NONE: not in the footprint)
-	uint8_t  sel[SPEC_WIN_BLOCKS][SPEC_PAGE]; // per cell of those blocks, resolved once per window move: 0 = the grid, k + 1 = candidate k, SPEC_SEL_OWN, SPEC_SEL_SLOW
+	uint32_t src[SPEC_WIN_BLOCKS][SPEC_PAGE]; // per cell of those blocks, resolved once per window move: where a cell that enters the window is read from -- SPEC_SRC_GRID, or the float index
+	                                          // (bit 31: buffer) of the highest lower version's value.  Cells this trace wrote back itself and crowded blocks are patched after the pass (blk_special)
+	uint32_t blk_special, pad5_;             // bit i: block i holds cells of this trace's own pages, or has more lower versions than the candidate list holds
 	uint32_t map_keys[SPEC_MAP_SLOTS];       // block id (SPEC_NIL: free)
 	uint8_t  map_ent[SPEC_MAP_SLOTS];        // its entry in the trace's block list = its page
 	unsigned long long masks[SPEC_MAXB];     // per entry: which cells of the block this trace has written back to its page
@@ -669,6 +671,30 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	// (no global traffic, no log look-up); dirty cells that leave are written back; cells that enter are fetched with all plain grid
 	// loads of a lane issued back to back (one HBM latency per shift), then patched where a multi-version look-up is needed.
 	TERRA_HD void set_travel(float dx, float dz) {lead_x = (dx > 0.35f) ? 1 : ((dx < -0.35f) ? -1 : 0); lead_z = (dz > 0.35f) ? 1 : ((dz < -0.35f) ? -1 : 0);}
+	// the sixteen cells (k*64 + lane) of a lane in the new window at (nx0, nz0): values into g[], dirty bits returned
+	template<bool FAST, class SRC> TERRA_HD uint32_t load_pass(SRC const &S, int lane, int nx0, int nz0, float (&g)[EW*EW/64]) {
+		constexpr int PER_LANE = EW*EW/64;
+		float gl[PER_LANE];
+		uint32_t db = 0, old_mask = 0, in_mask = 0;
+		int const lx = lane % EW, lz = lane / EW, X = nx0 + lx; // i = k*64 + lane: column lx, row 2 k + lz
+		bool const col_in = X < NX, col_old = have && (unsigned)(X - wx0) < (unsigned)EW;
+		float const *const p0 = S.interior_ptr(col_in ? X : nx0, nz0 + lz); // FAST: the cell of row 2 k + lz is p0 + k*S.row_step()
+#pragma unroll
+		for (int k = 0; k < PER_LANE; ++k) {
+			int const Z = nz0 + 2*k + lz;
+			bool const in_old = col_old && (unsigned)(Z - wz0) < (unsigned)EW, inside = col_in && Z < NY;
+			int const o = in_old ? (Z - wz0)*EW + (X - wx0) : 0;
+			g[k] = win[o]; db |= (uint32_t)((dirty[o] != 0) & in_old) << k;
+			int const Xs = inside ? X : nx0, Zs = inside ? Z : nz0; // (nx0, nz0) is a cell of the grid and of the prepared window
+			uint32_t const cd = S.code(Xs, Zs);
+			float const *const gp = FAST ? ((inside ? p0 + (size_t)k*S.row_step() : S.interior_ptr(nx0, nz0))) : S.g.at_sel(Xs, Zs);
+			gl[k] = *S.ptr(cd, gp);
+			old_mask |= (uint32_t)in_old << k; in_mask |= (uint32_t)inside << k;
+		}
+#pragma unroll
+		for (int k = 0; k < PER_LANE; ++k) {g[k] = ((old_mask >> k) & 1u) ? g[k] : (((in_mask >> k) & 1u) ? gl[k] : 0.0f);}
+		return db;
+	}
 	TERRA_HD void recenter(int cx, int cz) {
 		// the droplet sits a quarter of the window behind the centre, in the direction it came from: ~21 instead of ~13 steps until its brush box leaves again.
 		// Where the window lies never changes a result (it is a cache of the backing store), only how often it moves.
@@ -691,55 +717,21 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 		unsigned long long const clk2 = TERRA_CLOCK();
 		unsigned long long clk3 = clk2; (void)clk3;
 		constexpr int PER_LANE = EW*EW/64;
-		typename BACK::src_t const S = back.src_snapshot(); // (after prepare_window: the candidate tables of the new window are in LDS)
+		typename BACK::src_t const S = back.src_snapshot(); // (after prepare_window: the sources of the new window's cells are in LDS)
 		float gv[TERRA_LANE_SLOTS][PER_LANE]; uint32_t dbits[TERRA_LANE_SLOTS]; // a lane's 16 cells of the new window and their dirty bits
+		// Every cell of the new window: from the old window (LDS) if it stays, else ONE load from where its current value lives -- the grid or a lower version's page (S.code: one
+		// LDS word per cell of a block that has versions, resolved per block in prepare_window).  No branch and no use of a loaded value inside the pass -- a lane whose cell stays (or
+		// lies outside the grid) loads some valid word it will not use -- so the sixteen loads of a lane are in flight together: one memory latency per move.  A window that lies
+		// inside the caller's array (all but the ones at the map's rim) addresses the grid with one add per cell.  (As first written -- grid_view_t::at_sel and the candidate /
+		// own-page resolution per cell -- the pass was 2400 instructions, 5-10 us per move: profiles/r04_erosion_recenter_isa.txt.)
+		bool const fast = S.interior_window(nx0, nz0);
+		int const owx0 = wx0, owz0 = wz0; bool const had = have;
 		TERRA_EACH_LANE(lane) {
 			float (&g)[PER_LANE] = gv[TERRA_LANE_SLOT(lane)];
-			uint32_t db = 0;
-			// Every cell of the new window: from the old window (LDS) if it stays, else ONE load from where its current value lives -- the grid or a version page (BACK::source: a
-			// byte look-up per cell, the sources are resolved per block in prepare_window).  The first loop only ISSUES: no branch, no use of a loaded value -- a lane whose cell
-			// stays (or lies outside the grid) loads some valid word it will not use -- so that the sixteen loads of a lane are in flight together: one memory latency per move.
-			// (Written as if / else per cell the compiler waits for every load before it issues the next: 16 latencies, 14 us per move on the critical path of a dense run.)
-			float gl[PER_LANE];
-			unsigned slow_mask = 0, own_mask = 0, old_mask = 0, in_mask = 0;
-			// One pass, free of branches and of waits for memory: per cell the old window's value and dirty flag, the source byte (LDS), what it points to (LDS), the load
-			// (HBM / L2) -- all from the snapshot S, nothing through a pointer to the argument block, so no cell waits for another cell's load.
-			uint32_t selv[PER_LANE];
-#pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) {
-				int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-				bool const in_old = have && (unsigned)(X - wx0) < (unsigned)EW && (unsigned)(Z - wz0) < (unsigned)EW, inside = (X < NX && Z < NY), need = inside && !in_old;
-				int const o = in_old ? (Z - wz0)*EW + (X - wx0) : 0;
-				g[k] = win[o]; db |= (uint32_t)((dirty[o] != 0) & in_old) << k;
-				int const Xs = inside ? X : nx0, Zs = inside ? Z : nz0; // (nx0, nz0) is a cell of the grid and of the prepared window
-				bool slow = false, own = false;
-				selv[k] = S.sel(Xs, Zs);
-				gl[k] = *S.ptr(S.code(Xs, Zs, selv[k], slow, own), Xs, Zs);
-				old_mask |= (uint32_t)in_old << k; in_mask |= (uint32_t)inside << k;
-				slow_mask |= (uint32_t)(slow & need) << k; own_mask |= (uint32_t)(own & need) << k;
-			}
-#pragma unroll
-			for (int k = 0; k < PER_LANE; ++k) {g[k] = ((old_mask >> k) & 1u) ? g[k] : (((in_mask >> k) & 1u) ? gl[k] : 0.0f);}
-			clk3 = TERRA_CLOCK();
-			if (TERRA_UNLIKELY(own_mask != 0)) { // the trace's own pages were written earlier in THIS kernel: the line may be stale in the CU's L1 -- read those cells again, through to L2
-#pragma unroll
-				for (int k = 0; k < PER_LANE; ++k) {
-					if ((own_mask >> k) & 1u) {
-						int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW);
-						bool slow = false, own = false;
-						g[k] = TERRA_L2_LOAD(S.ptr(S.code(X, Z, selv[k], slow, own), X, Z));
-					}
-				}
-			}
-			if (TERRA_UNLIKELY(slow_mask != 0)) { // blocks with more lower versions than the candidate list holds: walk their lists (the grid value was loaded above)
-#pragma unroll
-				for (int k = 0; k < PER_LANE; ++k) {
-					if ((slow_mask >> k) & 1u) {int const i = k*64 + lane, X = nx0 + (i % EW), Z = nz0 + (i / EW); g[k] = back.lookup(X, Z, g[k]);}
-				}
-			}
-			dbits[TERRA_LANE_SLOT(lane)] = db;
-			clk_sh_load += TERRA_CLOCK() - clk3; // (diagnostics: the look-up part -- source tests, page loads issued, list walks of crowded blocks)
+			if (fast) {dbits[TERRA_LANE_SLOT(lane)] = load_pass<true>(S, lane, nx0, nz0, g);}
+			else {dbits[TERRA_LANE_SLOT(lane)] = load_pass<false>(S, lane, nx0, nz0, g);}
 		}
+		clk3 = TERRA_CLOCK();
 		TERRA_WAVE_SYNC(); // every lane has taken what it needs from the old window: the new one goes into the same LDS
 		TERRA_EACH_LANE(lane) {
 			float const (&g)[PER_LANE] = gv[TERRA_LANE_SLOT(lane)];
@@ -747,6 +739,21 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 #pragma unroll
 			for (int k = 0; k < PER_LANE; ++k) {int const i = k*64 + lane; win[i] = g[k]; dirty[i] = (uint8_t)((db >> k) & 1u);}
 		}
+		TERRA_WAVE_SYNC();
+		// the rare sources, block by block with one lane per cell: cells this trace wrote back to its own pages earlier (written in THIS kernel: read through to L2) and blocks
+		// with more lower versions than the candidate list holds (their writer lists are walked); only cells that ENTER the window -- the others hold what the droplet left there
+		for (uint32_t m = back.special_blocks(); m; m &= m - 1) {
+			uint32_t const bi = (uint32_t)__builtin_ctz(m);
+			TERRA_LANES(c, SPEC_PAGE) {
+				int X, Z;
+				back.special_cell(bi, (uint32_t)c, X, Z);
+				bool const in_new = (unsigned)(X - nx0) < (unsigned)EW && (unsigned)(Z - nz0) < (unsigned)EW && X < NX && Z < NY;
+				bool const in_old = had && (unsigned)(X - owx0) < (unsigned)EW && (unsigned)(Z - owz0) < (unsigned)EW;
+				if (in_new && !in_old) {int const o = (Z - nz0)*EW + (X - nx0); win[o] = back.special_value(bi, (uint32_t)c, X, Z, win[o]);}
+			}
+		}
+		if (back.special_blocks()) {TERRA_WAVE_SYNC();}
+		clk_sh_load += TERRA_CLOCK() - clk3; // (diagnostics: the fill and the rare sources)
 		wx0 = nx0; wz0 = nz0; have = true;
 		TERRA_WAVE_SYNC();
 		unsigned long long const clk4 = TERRA_CLOCK();
@@ -793,6 +800,10 @@ template<class BACK> struct window_mem_t : wave_cell_ops<window_mem_t<BACK>> {
 	TERRA_HD void finish() {flush();}
 };
 
+// does the EW x EW window at (nx0, nz0) lie inside the caller's array (no cell of the pad ring)?  Then cell (X, Z) is interior[(Z - PAD)*xsize + (X - PAD)]
+TERRA_HD bool grid_interior_window(grid_view_t const &g, int nx0, int nz0) {
+	return g.border != nullptr && nx0 >= EROSION_PAD && nz0 >= EROSION_PAD && nx0 + EW <= EROSION_PAD + g.xsize && nz0 + EW <= EROSION_PAD + g.ysize;
+}
 // backing store = the grid itself (serial fall-back droplet: it is the lowest uncommitted droplet, nothing to speculate about)
 struct grid_back_t {
 	grid_view_t g;
@@ -810,11 +821,16 @@ struct grid_back_t {
 	// what a window move needs to find the sources of its entering cells, as plain values (see spec_back_t::src_t)
 	struct src_t {
 		grid_view_t g;
-		TERRA_HD uint32_t sel(int, int) const {return 0u;}
-		TERRA_HD uint32_t code(int, int, uint32_t, bool &slow, bool &own) const {slow = false; own = false; return SPEC_SRC_GRID;}
-		TERRA_HD float const *ptr(uint32_t, int X, int Z) const {return g.at_sel(X, Z);}
+		TERRA_HD bool interior_window(int nx0, int nz0) const {return grid_interior_window(g, nx0, nz0);}
+		TERRA_HD float const *interior_ptr(int X, int Z) const {return g.interior + (size_t)(Z - EROSION_PAD)*g.xsize + (X - EROSION_PAD);}
+		TERRA_HD size_t row_step() const {return (size_t)2*g.xsize;}
+		TERRA_HD uint32_t code(int, int) const {return SPEC_SRC_GRID;}
+		TERRA_HD float const *ptr(uint32_t, float const *gp) const {return gp;}
 	};
 	TERRA_HD src_t src_snapshot() const {return src_t{g};}
+	TERRA_HD uint32_t special_blocks() const {return 0u;}
+	TERRA_HD void special_cell(uint32_t, uint32_t, int &X, int &Z) const {X = Z = 0;}
+	TERRA_HD float special_value(uint32_t, uint32_t, int, int, float v) const {return v;}
 	TERRA_HD void store(int X, int Z, float v) {
 		*g.at(X, Z) = v;
 		if (touched) {uint32_t const k = TERRA_ATOMIC_ADD(touched_count, 1u); if (k < touched_cap) {touched[k] = (uint32_t)Z*(uint32_t)g.NX + (uint32_t)X;}}
@@ -930,7 +946,7 @@ struct spec_back_t {
 	bool log_undo = false; // the trace has a checkpoint: write-backs that change a cell written back before are logged
 	bool blk_overflow;
 	int wbx0, wbz0, wnb;   // window origin in blocks, blocks per window edge
-	uint32_t nonempty = 0; // wave_shared_t::blk_nonempty of the prepared window, in a register
+	uint32_t nonempty = 0, special = 0; // wave_shared_t::blk_nonempty / blk_special of the prepared window, in registers
 	int lx0 = INT_MIN, lx1 = INT_MIN, lz0 = INT_MIN, lz1 = INT_MIN; // block range of the previous step's brush box
 
 	TERRA_HD static uint32_t map_hash(uint32_t b) {return (b*2654435761u) >> (32 - 9);}
@@ -1076,7 +1092,7 @@ struct spec_back_t {
 	// which published LOWER versions wrote the blocks under the new window (only those blocks need the multi-version look-up): one lane per block walks the
 	// block's writer list once and leaves the versions in LDS, highest droplet first, so that a cell's look-up is a mask test there plus one load
 	TERRA_HD void prepare_window(int wx0, int wz0) {
-		if (TERRA_LANE0) {sh->n_shift += 1; sh->blk_nonempty = 0;} // (LDS executes a wave's instructions in order: the zero is in place before the ORs below)
+		if (TERRA_LANE0) {sh->n_shift += 1; sh->blk_nonempty = 0; sh->blk_special = 0;} // (LDS executes a wave's instructions in order: the zeros are in place before the ORs below)
 		wbx0 = wx0 >> sb->bshift; wbz0 = wz0 >> sb->bshift;
 		TERRA_LANES(i, wnb*wnb) {
 			uint32_t cnt = 0;
@@ -1098,21 +1114,23 @@ struct spec_back_t {
 			uint32_t const oe = (bx < sb->nbx && bz < sb->nby) ? map_find(bz*sb->nbx + bx) : SPEC_NIL;
 			sh->blk_own[i] = (uint16_t)((oe == SPEC_NIL) ? SPEC_OWN_NONE : oe);
 			if (cnt != 0 || oe != SPEC_NIL) {TERRA_ATOMIC_OR(&sh->blk_nonempty, 1u << i);}
+			if (cnt == SPEC_CAND_MANY || (oe != SPEC_NIL && sh->masks[oe] != 0ull)) {TERRA_ATOMIC_OR(&sh->blk_special, 1u << i);}
 		}
 		TERRA_WAVE_SYNC();
 		// Resolve every cell of those blocks ONCE, all 64 cells of a block in parallel: which source a cell that enters the window is read from.  (Per entering cell this was a
 		// hash probe for the trace's own page plus a walk over the candidates' masks: 16 cells per lane, each a chain of dependent LDS round trips -- 12 of the 19 us of a
 		// window move on the critical path of a dense run, profiles/r03_erosion_clock_breakdown.txt.)  Now a cell's look-up is one byte.
-		nonempty = wave_uniform(sh->blk_nonempty);
+		nonempty = wave_uniform(sh->blk_nonempty); special = wave_uniform(sh->blk_special);
 		for (uint32_t m = nonempty; m; m &= m - 1) {
-			uint32_t const i = (uint32_t)__builtin_ctz(m), cnt = sh->blk_shared[i], oe = sh->blk_own[i];
-			unsigned long long const om = (oe != SPEC_OWN_NONE) ? sh->masks[oe] : 0ull;
+			uint32_t const i = (uint32_t)__builtin_ctz(m), cnt = sh->blk_shared[i];
 			TERRA_LANES(c, SPEC_PAGE) {
-				uint32_t sel = 0;
-				if (cnt == SPEC_CAND_MANY) {sel = SPEC_SEL_SLOW;}
-				else {for (uint32_t k = cnt; k-- > 0;) {if ((sh->cand[i][k].mask >> c) & 1ull) {sel = k + 1;}}} // the first (highest droplet) whose mask has the cell
-				if ((om >> c) & 1ull) {sel = SPEC_SEL_OWN;} // own earlier write-backs first
-				sh->sel[i][c] = (uint8_t)sel;
+				uint32_t code = SPEC_SRC_GRID; // (a crowded block: the grid value, patched through lookup(); a cell of this trace's own page: patched too -- special_value)
+				if (cnt != SPEC_CAND_MANY) {
+					uint32_t sel = 0;
+					for (uint32_t k = cnt; k-- > 0;) {if ((sh->cand[i][k].mask >> c) & 1ull) {sel = k + 1;}} // the first (highest droplet) whose mask has the cell
+					if (sel) {uint32_t const page = sh->cand[i][sel - 1].page; code = (page & 0x80000000u) | ((page & 0x7FFFFFFFu)*SPEC_PAGE + (uint32_t)c);}
+				}
+				sh->src[i][c] = code;
 			}
 		}
 		TERRA_WAVE_SYNC();
@@ -1129,40 +1147,20 @@ struct spec_back_t {
 		e = map_find(block_of(X, Z));
 		return e != SPEC_NIL && ((sh->masks[e] >> page_cell(X, Z)) & 1ull);
 	}
-	// where the current value of a cell that enters the window is read from, as a 32-bit code (the lane keeps sixteen of them in registers): SPEC_SRC_GRID, or
-	// a float index into the two version buffers (bit 31: buffer; this trace's own page included -- own: it was written in this kernel, read it through to L2).
-	// slow: the block has more lower versions than the candidate list holds -- the caller reads the grid value and passes it through lookup()
-	TERRA_HD uint32_t source(int X, int Z, bool &slow, bool &own) const { // (no branch, unconditional LDS reads: the caller issues sixteen of these back to back)
-		uint32_t const c = page_cell(X, Z);
-		int const bx = (X >> sb->bshift) - wbx0, bz = (Z >> sb->bshift) - wbz0;
-		uint32_t const bi = (uint32_t)(bz*wnb + bx); // inside the prepared window by construction
-		uint32_t const sel = ((nonempty >> bi) & 1u) ? (uint32_t)sh->sel[bi][c] : 0u; // (rows of blocks without content are not filled in)
-		slow = (sel == SPEC_SEL_SLOW); own = (sel == SPEC_SEL_OWN);
-		uint32_t const cpage = sh->cand[bi][(sel - 1u) & (SPEC_CAND - 1u)].page, opage = ((1u - sb->cur[slot]) << 31) | (uint32_t)(slot*sb->maxb + (sh->blk_own[bi] & 0xFFu));
-		uint32_t const page = own ? opage : cpage;
-		uint32_t const code = (page & 0x80000000u) | ((page & 0x7FFFFFFFu)*SPEC_PAGE + c);
-		return (sel == 0 || slow) ? SPEC_SRC_GRID : code;
-	}
-	TERRA_HD float const *source_ptr(uint32_t code, int X, int Z) const {return (code == SPEC_SRC_GRID) ? sb->grid.at(X, Z) : sb->page_vals[code >> 31] + (code & 0x7FFFFFFFu);}
-	// The same three questions for the sixteen cells a lane brings into a new window, asked of a SNAPSHOT: everything they need as plain wave-uniform values taken once per
-	// move.  Through `sb` (a pointer to the kernel's argument block) every field was a scalar load + s_waitcnt lgkmcnt(0) per use -- which also drains the LDS reads in
-	// flight -- and `sb->page_vals[code >> 31]` was a VECTOR load of the pointer + s_waitcnt vmcnt(0) per cell, i.e. every cell waited for the previous cell's data load:
-	// the sixteen loads of a lane ran one after another (6.5 us per move on average, 11 us on a round's longest wave; tools/ab_build.sh instr1, TERRA_ERO_DIAG).
+	// What a window move needs to find where its entering cells are read from, as a SNAPSHOT of plain wave-uniform values taken once per move.  Through `sb` (a pointer to the
+	// kernel's argument block) every field was a scalar load + s_waitcnt lgkmcnt(0) per use -- which also drains the LDS reads in flight -- and `sb->page_vals[code >> 31]` was a
+	// VECTOR load of the pointer + s_waitcnt vmcnt(0) per cell, i.e. every cell waited for the previous cell's data load (tools/ab_build.sh instr1, TERRA_ERO_DIAG).
 	struct src_t {
 		grid_view_t g; float *pv0, *pv1; wave_shared_t const *sh;
-		int wbx0, wbz0, wnb, bshift; uint32_t nonempty, own_base; // own_base: bit 31 = the buffer this trace builds, low bits = slot*maxb
+		int wbx0, wbz0, wnb, bshift; uint32_t nonempty;
+		TERRA_HD bool interior_window(int nx0, int nz0) const {return grid_interior_window(g, nx0, nz0);}
+		TERRA_HD float const *interior_ptr(int X, int Z) const {return g.interior + (size_t)(Z - EROSION_PAD)*g.xsize + (X - EROSION_PAD);}
+		TERRA_HD size_t row_step() const {return (size_t)2*g.xsize;}
 		TERRA_HD uint32_t bi(int X, int Z) const {return (uint32_t)(((Z >> bshift) - wbz0)*wnb + ((X >> bshift) - wbx0));} // inside the prepared window by construction
-		TERRA_HD uint32_t sel(int X, int Z) const {uint32_t const b = bi(X, Z); return ((nonempty >> b) & 1u) ? (uint32_t)sh->sel[b][page_cell(X, Z)] : 0u;} // (rows of blocks without content are not filled in)
-		TERRA_HD uint32_t code(int X, int Z, uint32_t sl, bool &slow, bool &own) const {
-			uint32_t const c = page_cell(X, Z), b = bi(X, Z);
-			slow = (sl == SPEC_SEL_SLOW); own = (sl == SPEC_SEL_OWN);
-			uint32_t const cpage = sh->cand[b][(sl - 1u) & (SPEC_CAND - 1u)].page, opage = own_base + (uint32_t)(sh->blk_own[b] & 0xFFu);
-			uint32_t const page = own ? opage : cpage;
-			uint32_t const cd = (page & 0x80000000u) | ((page & 0x7FFFFFFFu)*SPEC_PAGE + c);
-			return (sl == 0 || slow) ? SPEC_SRC_GRID : cd;
-		}
-		TERRA_HD float const *ptr(uint32_t cd, int X, int Z) const {
-			float const *const gp = g.at_sel(X, Z);
+		// SPEC_SRC_GRID, or the float index (bit 31: buffer) of the value in a lower version's page: one LDS word, read whether or not the block has versions (rows of blocks without
+		// content are not filled in: the bit decides)
+		TERRA_HD uint32_t code(int X, int Z) const {uint32_t const b = bi(X, Z), v = sh->src[b][page_cell(X, Z)]; return ((nonempty >> b) & 1u) ? v : SPEC_SRC_GRID;}
+		TERRA_HD float const *ptr(uint32_t cd, float const *gp) const {
 			float const *const pp = ((cd >> 31) ? pv1 : pv0) + (cd & 0x7FFFFFFFu);
 			return (cd == SPEC_SRC_GRID) ? gp : pp;
 		}
@@ -1171,8 +1169,19 @@ struct spec_back_t {
 		src_t t;
 		t.g = sb->grid; t.pv0 = sb->page_vals[0]; t.pv1 = sb->page_vals[1]; t.sh = sh;
 		t.wbx0 = wbx0; t.wbz0 = wbz0; t.wnb = wnb; t.bshift = (int)sb->bshift; t.nonempty = nonempty;
-		t.own_base = ((1u - sb->cur[slot]) << 31) | (uint32_t)(slot*sb->maxb);
 		return t;
+	}
+	// the blocks under the prepared window whose entering cells are not (all) covered by src[]: one lane per cell of such a block
+	TERRA_HD uint32_t special_blocks() const {return special;}
+	TERRA_HD void special_cell(uint32_t bi, uint32_t c, int &X, int &Z) const {
+		X = ((wbx0 + (int)(bi % (uint32_t)wnb)) << sb->bshift) + (int)(c & 7u); Z = ((wbz0 + (int)(bi / (uint32_t)wnb)) << sb->bshift) + (int)(c >> 3);
+	}
+	// v: what the pass put into the window for the cell (the grid value in a crowded block)
+	TERRA_HD float special_value(uint32_t bi, uint32_t c, int X, int Z, float v) const {
+		uint32_t const oe = sh->blk_own[bi];
+		if (oe != SPEC_OWN_NONE && ((sh->masks[oe] >> c) & 1ull)) {return TERRA_L2_LOAD(&my_pages[(size_t)oe*SPEC_PAGE + c]);} // written earlier in THIS kernel by other lanes: not through L1
+		if (sh->blk_shared[bi] == SPEC_CAND_MANY) {return lookup(X, Z, v);}
+		return v;
 	}
 	// own earlier write-backs first, then the value written by the highest-numbered lower droplet, else the grid value `b`
 	TERRA_HD float lookup(int X, int Z, float b) const {
