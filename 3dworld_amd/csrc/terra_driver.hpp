@@ -833,7 +833,7 @@ template<class BE> struct terra_engine {
 			}
 			o_slot = carve((size_t)W*4*14); // it, phase, has_ver, cur, changed, restart, run_nblk, flags, nsteps, linked, rsrc, rat, rentry, vbuf
 			o_state = carve((size_t)W*sizeof(droplet_state_t)); o_resume = carve((size_t)W*sizeof(spec_resume_t));
-			o_next = carve((size_t)W*sb.maxb*4); o_nodeblk = carve((size_t)W*sb.maxb*4); o_dlist = carve((size_t)W*sb.maxb*16); o_ctl = carve(sizeof(spec_ctl_t));
+			o_next = carve((size_t)W*sb.maxb*sizeof(spec_u32x4)); o_nodeblk = carve((size_t)W*sb.maxb*4); o_dlist = carve((size_t)W*sb.maxb*16); o_ctl = carve(sizeof(spec_ctl_t));
 			o_touched = carve((size_t)touched_cap*4 + 4);
 			return off;
 		};
@@ -860,7 +860,7 @@ template<class BE> struct terra_engine {
 		sb.linked = slot_arrays + 9*(size_t)W; sb.rsrc = slot_arrays + 10*(size_t)W; sb.rat = slot_arrays + 11*(size_t)W; sb.rentry = slot_arrays + 12*(size_t)W; sb.vbuf = slot_arrays + 13*(size_t)W;
 		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
-		sb.next = (uint32_t *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.dirty_list2[0] = sb.dirty_list + 2*(size_t)W*sb.maxb; sb.dirty_list2[1] = sb.dirty_list + 3*(size_t)W*sb.maxb; sb.ctl = (spec_ctl_t *)(base + o_ctl);
+		sb.node_rec = (spec_u32x4 *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.dirty_list2[0] = sb.dirty_list + 2*(size_t)W*sb.maxb; sb.dirty_list2[1] = sb.dirty_list + 3*(size_t)W*sb.maxb; sb.ctl = (spec_ctl_t *)(base + o_ctl);
 		// block -> list head and block -> dirty mark: one entry per 8x8 block of the padded grid.  Every run resets exactly the entries it set
 		// (spec_unlink_body / spec_undirty_body), so the O(grid) fill is paid only when the arrays are (re)allocated or the grid shape changes.
 		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks);

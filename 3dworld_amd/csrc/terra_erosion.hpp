@@ -926,7 +926,8 @@ struct spec_buffers_t {
 	droplet_state_t *state;// [W] suspended traces
 	spec_resume_t *resume; // [W]
 	uint32_t *head;        // [nbx*nby] block -> first node
-	uint32_t *next;        // [W*maxb]  node -> next node ; node id = slot*maxb + entry
+	spec_u32x4 *node_rec;  // [W*maxb]  node id = slot*maxb + entry -> {next node, the droplet, its write mask of the block (2 words)} as of the link pass: a list walk is ONE
+	                       //           16-byte load per node (+ vbuf[] of its slot, independent of it) instead of five loads that wait for one another (profiles/r04_erosion_recenter_isa.txt)
 	uint32_t *dirty_min;   // [nbx*nby] lowest droplet whose published version changed in a way that touches the block, this round
 	uint32_t *node_blk;    // [W*maxb]  block a node is currently linked under (SPEC_NIL: not linked): head[] is reset through it, not by an O(grid) fill
 	uint32_t *dirty_list;  // [2*W*maxb] blocks whose dirty_min was lowered this round (duplicates allowed), ctl->ndirty entries
@@ -1098,12 +1099,15 @@ struct spec_back_t {
 			uint32_t cnt = 0;
 			uint32_t const bx = (uint32_t)(wbx0 + i % wnb), bz = (uint32_t)(wbz0 + i / wnb);
 			if (bx < sb->nbx && bz < sb->nby) {
-				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL; node = sb->next[node]) {
-					uint32_t const j = node / sb->maxb;
-					if (!lower_version(j)) continue;
+				spec_u32x4 const *const nrec = sb->node_rec; uint32_t const *const vbufs = sb->vbuf; uint32_t const maxb = sb->maxb;
+				for (uint32_t node = sb->head[bz*sb->nbx + bx]; node != SPEC_NIL;) {
+					uint32_t const this_node = node;
+					spec_u32x4 const r = nrec[node]; uint32_t const cb = vbufs[node / maxb]; // (two independent loads: one memory latency per node)
+					node = r.x;
+					uint32_t const ij = r.y;
+					if (!(cb != SPEC_VIS_NONE && ij < iter)) continue; // lower_version(): a slot that was re-assigned since the lists were built shows nothing
 					if (cnt == SPEC_CAND) {cnt = SPEC_CAND_MANY; break;}
-					uint32_t const ij = sb->it[j], cb = sb->vbuf[j];
-					spec_cand_t nc; nc.page = node | (cb << 31); nc.it = ij; nc.mask = sb->page_mask[cb][node];
+					spec_cand_t nc; nc.page = this_node | (cb << 31); nc.it = ij; nc.mask = (unsigned long long)r.z | ((unsigned long long)r.w << 32);
 					uint32_t k = cnt; // insertion by descending droplet number
 					for (; k > 0 && sh->cand[i][k-1].it < ij; --k) {sh->cand[i][k] = sh->cand[i][k-1];}
 					sh->cand[i][k] = nc;
@@ -1195,13 +1199,15 @@ struct spec_back_t {
 
 			uint32_t best = SPEC_NIL; // droplet number of the best writer so far
 			float v = b;
-			for (uint32_t node = sb->head[block_of(X, Z)]; node != SPEC_NIL; node = sb->next[node]) {
-				uint32_t const j = node / sb->maxb;
-				if (!lower_version(j)) continue;
-				uint32_t const ij = sb->it[j];
+			for (uint32_t node = sb->head[block_of(X, Z)]; node != SPEC_NIL;) {
+				uint32_t const this_node = node;
+				spec_u32x4 const r = sb->node_rec[node]; uint32_t const cb = sb->vbuf[node / sb->maxb];
+				node = r.x;
+				uint32_t const ij = r.y;
+				if (!(cb != SPEC_VIS_NONE && ij < iter)) continue;
 				if (best != SPEC_NIL && ij <= best) continue;
-				uint32_t const cb = sb->vbuf[j];
-				if ((sb->page_mask[cb][node] >> c) & 1ull) {best = ij; v = sb->page_vals[cb][(size_t)node*SPEC_PAGE + c];} // node = slot*maxb + entry = index of the page
+				unsigned long long const m = (unsigned long long)r.z | ((unsigned long long)r.w << 32);
+				if ((m >> c) & 1ull) {best = ij; v = (cb ? sb->page_vals[1] : sb->page_vals[0])[(size_t)this_node*SPEC_PAGE + c];} // node = slot*maxb + entry = index of the page
 			}
 			return v;
 		}
@@ -1522,7 +1528,9 @@ TERRA_HD void spec_link_body(spec_buffers_t const &sb, uint32_t slot, uint32_t e
 	if (!(e & SPEC_BLK_WRITTEN)) return; // the lists answer "who wrote here": read-only entries stay out
 	uint32_t const node = slot*sb.maxb + entry, b = e & SPEC_BLK_ID;
 	sb.node_blk[node] = b;
-	sb.next[node] = TERRA_ATOMIC_EXCH(&sb.head[b], node);
+	uint32_t const prev = TERRA_ATOMIC_EXCH(&sb.head[b], node);
+	unsigned long long const m = (cb ? sb.page_mask[1] : sb.page_mask[0])[node];
+	sb.node_rec[node] = spec_u32x4{prev, sb.it[slot], (uint32_t)m, (uint32_t)(m >> 32)};
 }
 // take the lists apart again (before they are rebuilt, and at the end of the run: head[] is left all-NIL for the next run)
 TERRA_HD void spec_unlink_body(spec_buffers_t const &sb, uint32_t node) {
@@ -1571,10 +1579,11 @@ TERRA_HD void spec_flush_wave(spec_buffers_t const &sb, uint32_t slot) {
 				if (ent & SPEC_BLK_WRITTEN) {
 					b = ent & SPEC_BLK_ID;
 					mine = sb.page_mask[cb][pbase + e];
-					for (uint32_t node = sb.head[b]; node != SPEC_NIL && mine; node = sb.next[node]) { // a later committed droplet owns the final value of the cells it wrote
-						uint32_t const j = node / sb.maxb, ij = sb.it[j];
-						if (ij == SPEC_NIL || !sb.has_ver[j] || ij <= iter || ij >= nbase) continue;
-						mine &= ~sb.page_mask[sb.cur[j]][node];
+					for (uint32_t node = sb.head[b]; node != SPEC_NIL && mine;) { // a later committed droplet owns the final value of the cells it wrote
+						spec_u32x4 const r = sb.node_rec[node]; // (written by this round's link pass: the droplet its slot holds now; a droplet below new_base is idle with its finished version published)
+						node = r.x;
+						if (r.y <= iter || r.y >= nbase) continue;
+						mine &= ~((unsigned long long)r.z | ((unsigned long long)r.w << 32));
 					}
 				}
 			}

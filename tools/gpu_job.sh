@@ -59,7 +59,7 @@ profile)
 		ao) prof ao python "$ROOT/tools/prof_ao.py" ;;
 		voxels) prof voxels python "$ROOT/tools/prof_voxels.py" ;;
 		noise) prof noise16384 python "$ROOT/tools/prof_noise.py" 16384 2 1,2,4 ;;
-		erosion) prof erosion_dense python "$ROOT/tools/ero_sweep.py" 4096 200000 "0:128" ;;
+		erosion) prof erosion_dense python "$ROOT/tools/prof_erosion.py" 4096 1000000 ;;
 		esac
 	done
 	;;
