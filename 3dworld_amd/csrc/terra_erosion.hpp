@@ -1021,11 +1021,34 @@ struct spec_back_t {
 		if (!copy) {TERRA_LANES(e, had_nblk) {if ((uint32_t)e >= nk) {my_masks[e] = 0ull;}}} // the entries after the checkpoint are gone: a reader that still finds their nodes in the writer lists sees no cell
 		if (copy) {
 			TERRA_LANES(e, nk) {my_blks[e] = s_blks[e] & SPEC_BLK_ID;}
-			TERRA_LANES(i, nk*SPEC_PAGE) { // every cell the trace had written by then: independent copies
-				uint32_t const e = (uint32_t)i / SPEC_PAGE, c = (uint32_t)i % SPEC_PAGE;
-				if ((s_ckm[e] >> c) & 1ull) {my_pages[i] = s_pages[i];}
+			// every cell the trace had written by then: independent copies, eight pages of a lane's column at a time -- the eight reads are in flight together (one by one every store
+			// waited for its own load: one memory latency per page of the footprint, the longest wave of the commit pass)
+			TERRA_EACH_LANE(c) {
+				for (uint32_t e0 = 0; e0 < nk; e0 += 8) {
+					float v[8]; bool w[8];
+#pragma unroll
+					for (uint32_t u = 0; u < 8; ++u) {
+						uint32_t const e = (e0 + u < nk) ? e0 + u : e0;
+						w[u] = (e0 + u < nk) && ((s_ckm[e] >> (uint32_t)c) & 1ull);
+						v[u] = s_pages[(size_t)e*SPEC_PAGE + (uint32_t)c];
+					}
+#pragma unroll
+					for (uint32_t u = 0; u < 8; ++u) {if (w[u]) {my_pages[(size_t)(e0 + u)*SPEC_PAGE + (uint32_t)c] = v[u];}}
+				}
 			}
-			TERRA_LANES(i, (k + 1)*sb->maxb) {sb->ck_masks[nb][cb0*sb->maxb + i] = sb->ck_masks[sbuf][cb0*sb->maxb + i];}
+			{ // the masks of the checkpoints 0 .. k, four words of a lane at a time
+				unsigned long long const *const sm = sb->ck_masks[sbuf] + cb0*sb->maxb; unsigned long long *const dm = sb->ck_masks[nb] + cb0*sb->maxb;
+				uint32_t const total = (k + 1)*sb->maxb;
+				TERRA_EACH_LANE(l) {
+					for (uint32_t i0 = 0; i0 < total; i0 += 256) {
+						unsigned long long v[4];
+#pragma unroll
+						for (uint32_t u = 0; u < 4; ++u) {uint32_t const i = i0 + u*64 + (uint32_t)l; v[u] = sm[(i < total) ? i : 0u];}
+#pragma unroll
+						for (uint32_t u = 0; u < 4; ++u) {uint32_t const i = i0 + u*64 + (uint32_t)l; if (i < total) {dm[i] = v[u];}}
+					}
+				}
+			}
 			TERRA_LANES(i, k + 1) {sb->ck_state[nb][cb0 + i] = sb->ck_state[sbuf][cb0 + i]; sb->ck_nblk[nb][cb0 + i] = sb->ck_nblk[sbuf][cb0 + i]; sb->ck_undo[nb][cb0 + i] = sb->ck_undo[sbuf][cb0 + i];}
 			TERRA_LANES(q, uk) {my_undo_idx[q] = s_uidx[q]; my_undo_val[q] = s_uval[q];}
 		}
