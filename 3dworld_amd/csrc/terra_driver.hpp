@@ -892,7 +892,9 @@ template<class BE> struct terra_engine {
 			if (be.graph_replay(&gkey, sizeof(gkey))) return;
 			bool const cap = be.graph_begin();
 			try {
-				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)i, slice, ws);});
+				// workgroups are dispatched in index order and a ring has more droplets than the chip holds waves: workgroup i takes the i-th in-flight droplet (slot (base + i) % W), so
+				// that the droplets next in line for the commit -- the long, unbudgeted traces everybody waits for -- start first instead of wherever their slot number falls
+				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)(((uint64_t)s.ctl->base + i) % s.W), slice, ws);});
 				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_post_wave(s, (uint32_t)i);});
 				// the three passes below: 64 logical threads per slot that walk the slot's entries up to the count in use (a footprint holds ~30 of its 256 entries;
 				// one thread per (slot, entry) made these passes cost as much as the traces on a 32768-slot ring)

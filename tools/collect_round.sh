@@ -12,10 +12,10 @@ tools/gpu_job.sh pmc ${TAG}/pmc_tile_erosion prof_tile_erosion.py 1000 1 -- "k_t
 tools/gpu_job.sh pmc ${TAG}/pmc_noise prof_noise.py 16384 1 1,2,4 -- "k_noise_grid<1>" "k_noise_grid<2>" "k_noise_grid<4>"
 tools/gpu_job.sh pmc ${TAG}/pmc_tiles prof_tiles.py 0 1 -- "k_tile_post" "k_tile_ao" "k_tile_shadows"
 tools/gpu_job.sh pmc ${TAG}/pmc_voxels prof_voxels.py 512 -- "k_voxel_sines"
-tools/gpu_job.sh pmc ${TAG}/pmc_erosion_dense ero_sweep.py 4096 200000 0:128 -- "speculative_erosion"
+tools/gpu_job.sh pmc ${TAG}/pmc_erosion_dense ero_sweep.py 4096 1000000 0:0 -- "speculative_erosion"
 tools/gpu_job.sh clock ${TAG}/clock prof_driver.py 16384 3
 python tools/make_pmc_traffic.py gpurun_out/${TAG}/pmc_sine 16384 > gpurun_out/${TAG}/pmc_traffic.json 2>/dev/null
-tools/gpu_job.sh erosion $TAG "16384 1000 0:128" "4096 1000 0:128" "4096 100000 0:128" "4096 1000000 0:128" "8192 1000000 0:128" "16384 1000000 0:128" "1024 30000 0:128"
+tools/gpu_job.sh erosion $TAG "16384 1000 0:0" "4096 1000 0:0" "4096 100000 0:0" "4096 1000000 0:0" "8192 1000000 0:0" "16384 1000000 0:0" "1024 30000 0:0" "2048 1000000 0:0"
 tools/gpu_job.sh stepcost $TAG
 timeout 900 python tools/bench_extra.py > gpurun_out/${TAG}/bench_extra.json 2> gpurun_out/${TAG}/bench_extra.err; echo "bench_extra rc $?"
 tools/gpu_job.sh native $TAG

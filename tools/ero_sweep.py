@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dense whole-map erosion (BASELINE config 3 with config_heightmap.txt's real droplet count): ring size x slice sweep; prints the scheduler's report"""
+"""dense whole-map erosion (BASELINE config 3 with config_heightmap.txt's real droplet count): ring size x slice sweep ("W:slice,..."; 0 = the library's default); prints the scheduler's report"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +14,8 @@ mn, mx = t.gen_grid_minmax_dev(zc.ptr, -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, 
 lib = t.lib
 for (w, sl) in combos:
     t.set_erosion_tuning(window=w if w else 0xFFFFFFFF, **({'block_list_capacity': int(os.environ['ERO_SWEEP_MAXB'])} if os.environ.get('ERO_SWEEP_MAXB') else {}))
-    t.set_erosion_slice_steps(sl)
+    if sl:  # 0: the library's default
+        t.set_erosion_slice_steps(sl)
     for rep in range(2):
         lib.terra_memcpy_h2d  # noqa
         import ctypes
