@@ -795,7 +795,7 @@ template<class BE> struct terra_engine {
 		// ring slots: more droplets in flight = more parallel work and fewer rounds, but also more speculation on stale cells and longer writer lists.  Measured
 		// (MI355X, 10^5..10^6 droplets, profiles/r02_erosion_ring_size_sweep.txt): best near one slot per 8K cells on sparse maps (8192^2: 8192 slots, 16384^2: 32768),
 		// 3072-4096 slots on a dense 4096^2, 2048 on 1024^2 (4096 slots there double the re-traces).  Per slot and buffer: 256 pages of 64 floats (64 KiB) + 256 masks and block ids
-		// (3 KiB) + up to 16 checkpoints (their masks: 32 KiB) + the undo log (32 KiB): ~133 KiB, twice = ~266 KiB per slot -- a 32768-slot ring (16384^2 map) is ~8.5 GiB of the 288
+		// (3 KiB) + up to 16 checkpoints (their masks: 32 KiB) + the undo log (32 KiB): ~133 KiB, twice = ~266 KiB per slot (+ 6 KiB of list records and dirty lists) -- a 32768-slot ring (16384^2 map) is ~8.5 GiB of the 288
 		// (bench.py keeps 4 contexts in flight: ~34 GiB).  The checkpoint and undo arrays are sized by the checkpoint count in force (none with TERRA_ERO_CK=n:0).
 		uint64_t const ncells = (uint64_t)ec.NX*ec.NY;
 		uint32_t auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ncells >> 13, 2048), 32768);
