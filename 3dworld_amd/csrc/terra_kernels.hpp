@@ -274,166 +274,6 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 	}
 }
 
-// ------------------------------------------------------------------ K1 on both arithmetic pipes (TERRA_SINE_PIPES=both)
-// The same sum with the PRODUCTS taken from the matrix pipe and the ADDS kept on the vector ALU.  v_mfma_f32_32x32x1_2b_f32 with K = 1 and C = 0 is two
-// 32 x 32 outer products: D[i][j] = fma(A[i], B[j], +0) = RN(A[i]*B[j]), one IEEE rounding per product, subnormals kept (guide: "bit for bit a k-ordered fmaf chain",
-// C / D never flush, A / B follow MODE.denorm = keep) -- exactly the value v_pk_mul_f32 writes.  (A zero product comes out as +0 where the multiply gives -0; the running
-// sum starts at +0 and a sum of floats is never -0 unless both operands are, so no accumulator can tell the two apart.)  Nothing is accumulated inside the instruction:
-// every product is added to the running sum by v_pk_add_f32 in k order, the same two roundings per term as the CPU's mul-then-add.  The matrix pipe is a second
-// multiplier array here, not a GEMM: the instruction count on the vector ALU halves (2560 adds per wave-tile column instead of 5120 multiplies and adds) while the
-// products of the NEXT k come out of the other pipe.
-// Tiling: the same 128 x 128 block, K staged through LDS the same way; a wave owns 64 x 64 cells = two instructions per k (A = 64 rows of Y, B = 32 columns of X for
-// both blocks); product sets alternate between two register sets so that the adds of step k run while step k + 1 multiplies.
-// Layout of a result set (C / D map of the 32 x 32 shapes, block b in registers 16 b ..): lane l, register v: row 32 (v >> 4) + 8 ((v & 15) >> 2) + 4 (l >> 5) + (v & 3), column l & 31.
-typedef float sg_v32f __attribute__((ext_vector_type(32)));
-// The k loop of one LDS chunk, written out: register numbers are fixed (sums v[64:127], the four product sets v[128:255]) because the schedule IS the kernel --
-// the compiler's own allocation merged sums and product sets, added the odd halves with scalar v_add_f32 and put the products in accumulation registers behind
-// 32 v_accvgpr_read per step.  Hazards are the author's here: a product set is read by the vector ALU no sooner than 32 instructions after the matrix instruction that
-// writes it was issued (the hardware wants 18-20 wait states for a 16-pass instruction and does not interlock), the one place where that is not so by construction --
-// right after the first two instructions of a chunk -- waits in s_nop.  Operand registers alternate between steps, so an operand is overwritten one matrix instruction
-// after the one that read it at the earliest.
-#define TERRA_SG_ADD16(ACC, P) /* ACC[0..31] += P[0..31], 16 x v_pk_add_f32; ACC / P = first register number */ \
-	TERRA_SG_ADD4(ACC, P, 0) TERRA_SG_ADD4(ACC, P, 8) TERRA_SG_ADD4(ACC, P, 16) TERRA_SG_ADD4(ACC, P, 24)
-#define TERRA_SG_STR2(x) #x
-#define TERRA_SG_STR(x) TERRA_SG_STR2(x)
-#define TERRA_SG_ADD1(ACC, P, O) "v_pk_add_f32 v[" TERRA_SG_STR(ACC) "+" TERRA_SG_STR(O) ":" TERRA_SG_STR(ACC) "+" TERRA_SG_STR(O) "+1], v[" TERRA_SG_STR(ACC) "+" TERRA_SG_STR(O) ":" TERRA_SG_STR(ACC) "+" TERRA_SG_STR(O) "+1], v[" TERRA_SG_STR(P) "+" TERRA_SG_STR(O) ":" TERRA_SG_STR(P) "+" TERRA_SG_STR(O) "+1]\n\t"
-#define TERRA_SG_ADD4(ACC, P, O) TERRA_SG_ADD1(ACC, P, O) TERRA_SG_ADD1(ACC, P, O+2) TERRA_SG_ADD1(ACC, P, O+4) TERRA_SG_ADD1(ACC, P, O+6)
-#define TERRA_SG_MUL(P, A, B) "v_mfma_f32_32x32x1_2b_f32 v[" TERRA_SG_STR(P) ":" TERRA_SG_STR(P) "+31], " A ", " B ", 0\n\t"
-// pa / pb: LDS byte addresses of the wave's Y operand (lane l: row l) and X operand (lane l: column l & 31) of the chunk's first k; kn >= 1 steps
-__device__ __forceinline__ void sg_chunk_both_pipes(sg_v32f &acc0, sg_v32f &acc1, unsigned pa, unsigned pb, int kn) {
-	float a, b0, b1, a2, b2, b3; int left;
-	asm volatile(
-		"ds_read_b32 %[a], %[pa]\n\t"
-		"ds_read_b32 %[b0], %[pb]\n\t"
-		"ds_read_b32 %[b1], %[pb] offset:128\n\t"
-		"s_sub_i32 %[left], %[kn], 1\n\t" // steps still to multiply
-		"s_waitcnt lgkmcnt(0)\n\t"
-		TERRA_SG_MUL(128, "%[a]", "%[b0]")
-		TERRA_SG_MUL(160, "%[a]", "%[b1]")
-		"ds_read_b32 %[a], %[pa] offset:512\n\t" // step 1 (rows kn, kn + 1 exist in LDS and are never used)
-		"ds_read_b32 %[b0], %[pb] offset:512\n\t"
-		"ds_read_b32 %[b1], %[pb] offset:640\n\t"
-		"s_nop 15\n\t"
-		"s_nop 7\n\t"
-		"s_cmp_lt_i32 %[left], 2\n\t"
-		"s_cbranch_scc1 .Lsg_drain_%=\n"
-		".Lsg_loop_%=:\n\t" // products of step k - 1 in v[128:191], operands of step k arriving, at least two steps left
-		"s_waitcnt lgkmcnt(0)\n\t"
-		TERRA_SG_MUL(192, "%[a]", "%[b0]")
-		TERRA_SG_ADD16(64, 128)
-		TERRA_SG_MUL(224, "%[a]", "%[b1]")
-		"ds_read_b32 %[a2], %[pa] offset:1024\n\t"
-		"ds_read_b32 %[b2], %[pb] offset:1024\n\t"
-		"ds_read_b32 %[b3], %[pb] offset:1152\n\t"
-		TERRA_SG_ADD16(96, 160)
-		"s_waitcnt lgkmcnt(0)\n\t"
-		TERRA_SG_MUL(128, "%[a2]", "%[b2]")
-		TERRA_SG_ADD16(64, 192)
-		TERRA_SG_MUL(160, "%[a2]", "%[b3]")
-		"ds_read_b32 %[a], %[pa] offset:1536\n\t"
-		"ds_read_b32 %[b0], %[pb] offset:1536\n\t"
-		"ds_read_b32 %[b1], %[pb] offset:1664\n\t"
-		"v_add_u32 %[pa], 0x400, %[pa]\n\t"
-		"v_add_u32 %[pb], 0x400, %[pb]\n\t"
-		TERRA_SG_ADD16(96, 224)
-		"s_sub_i32 %[left], %[left], 2\n\t"
-		"s_cmp_ge_i32 %[left], 2\n\t"
-		"s_cbranch_scc1 .Lsg_loop_%=\n"
-		".Lsg_drain_%=:\n\t"
-		"s_cmp_lt_i32 %[left], 1\n\t"
-		"s_cbranch_scc1 .Lsg_last_%=\n\t"
-		"s_waitcnt lgkmcnt(0)\n\t" // one step left to multiply
-		TERRA_SG_MUL(192, "%[a]", "%[b0]")
-		TERRA_SG_ADD16(64, 128)
-		TERRA_SG_MUL(224, "%[a]", "%[b1]")
-		TERRA_SG_ADD16(96, 160)
-		TERRA_SG_ADD16(64, 192)
-		TERRA_SG_ADD16(96, 224)
-		"s_branch .Lsg_done_%=\n"
-		".Lsg_last_%=:\n\t"
-		TERRA_SG_ADD16(64, 128)
-		TERRA_SG_ADD16(96, 160)
-		".Lsg_done_%=:\n\t"
-		"s_waitcnt lgkmcnt(0)\n\t" // the look-ahead operand reads have landed before the registers are given back
-		: "+{v[64:95]}"(acc0), "+{v[96:127]}"(acc1), [a] "=&v"(a), [b0] "=&v"(b0), [b1] "=&v"(b1), [a2] "=&v"(a2), [b2] "=&v"(b2), [b3] "=&v"(b3), [pa] "+v"(pa), [pb] "+v"(pb), [left] "=&s"(left)
-		: [kn] "s"(kn)
-		: "scc", "memory",
-		  "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",
-		  "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191",
-		  "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",
-		  "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
-}
-// the short epilogue of k_sine_grid<false, false> (the host proved that no cell leaves it), same expressions, two rows of one column per instruction.
-// GL / SM: glaciate / sine-mag islands (launch-time constants here); CHECK: the block sticks out of the grid
-template<bool GL, bool SM, bool CHECK> __device__ __forceinline__ void sg_mx_finish(sg_v32f const &acc0, sg_v32f const &acc1, grid_job_t const &job, noise_consts_t const &nc,
-	float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned xw, unsigned yw, float &fmn, float &fmx)
-{
-	typedef sg_v2f v2f;
-	v2f const zme = {nc.zmax_est, nc.zmax_est}, inv = {nc.zmax_est2_inv, nc.zmax_est2_inv}, z2 = {nc.zmax_est2, nc.zmax_est2}, off = {job.sine_offset, job.sine_offset};
-	float const sx0 = SM ? smx[xw] : 0.0f, sx1 = SM ? smx[xw + 32] : 0.0f; // the island tables are zero-padded to the tile grid
-	float *const o0 = out + (size_t)yw*job.nx + xw;
-#pragma unroll
-	for (int g = 0; g < 8; ++g) { // register group g: rows yw + 32 (g >> 2) + 8 (g & 3) + {0, 1, 2, 3}
-		unsigned const yo = 32u*(unsigned)(g >> 2) + 8u*(unsigned)(g & 3);
-		float4 const sy4 = SM ? *(float4 const *)(smy + yw + yo) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-		for (int half = 0; half < 2; ++half) {
-			v2f const sxv = half ? v2f{sx1, sx1} : v2f{sx0, sx0};
-#pragma unroll
-			for (int rp = 0; rp < 4; rp += 2) {
-				v2f z = half ? v2f{acc1[4*g + rp], acc1[4*g + rp + 1]} : v2f{acc0[4*g + rp], acc0[4*g + rp + 1]};
-				if (GL) {v2f const r = (z + zme)*inv; z = ((r*r)*r)*z2 - zme;}
-				if (SM) {v2f const syv = rp ? v2f{sy4.z, sy4.w} : v2f{sy4.x, sy4.y}; z = z + (sxv*syv + off);}
-				float *const o = o0 + (size_t)(yo + (unsigned)rp)*job.nx + 32*half;
-				if (!CHECK) {
-					o[0] = z.x; o[job.nx] = z.y;
-					fmn = sg_min3(fmn, z.x, z.y); fmx = sg_max3(fmx, z.x, z.y); // v_min3 / v_max3 skip NaNs, like min_eq / max_eq never let a NaN win
-				}
-				else if (xw + 32u*(unsigned)half < job.nx) {
-					if (yw + yo + (unsigned)rp < job.ny)      {o[0] = z.x;      fmn = sg_min3(fmn, z.x, z.x); fmx = sg_max3(fmx, z.x, z.x);}
-					if (yw + yo + (unsigned)rp + 1u < job.ny) {o[job.nx] = z.y; fmn = sg_min3(fmn, z.y, z.y); fmx = sg_max3(fmx, z.y, z.y);}
-				}
-			}
-		}
-	}
-}
-template<bool GL, bool SM> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid_mx(grid_job_t job, noise_consts_t nc, float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy,
-	float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm, unsigned rowgroup)
-{
-	__shared__ __attribute__((aligned(16))) float sX[(SG_KC + 2)*SG_BX];
-	__shared__ __attribute__((aligned(16))) float sY[(SG_KC + 2)*SG_BY];
-	unsigned bxi, byi;
-	if (!sg_tile_of_block(blockIdx.x, ntx, nty, rowgroup, bxi, byi)) return;
-	unsigned const tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, bx0 = bxi*SG_BX, by0 = byi*SG_BY;
-	unsigned const wx0 = (wave & 1u)*64u, wy0 = (wave >> 1)*64u; // the wave's 64 x 64 cells inside the block
-	sg_v32f acc0, acc1; // columns wx0 + 0..31 / wx0 + 32..63
-#pragma unroll
-	for (int v = 0; v < 32; ++v) {acc0[v] = 0.0f; acc1[v] = 0.0f;}
-	unsigned const pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(sY + wy0 + lane);          // A: rows wy0 + lane
-	unsigned const pb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(sX + wx0 + (lane & 31u)); // B: columns wx0 + (lane & 31) (+ 32 for the second instruction), the same for both blocks
-	int const nk = F_TABLE_SIZE - job.kstart, nchunks = (nk + SG_KC - 1)/SG_KC, per_chunk = (nk + nchunks - 1)/nchunks;
-	for (int c = 0; c < nchunks; ++c) { // terms are summed in k order across chunks, exactly like the CPU loop
-		int const k0 = job.kstart + c*per_chunk, kn = ((k0 + per_chunk > F_TABLE_SIZE) ? F_TABLE_SIZE - k0 : per_chunk);
-		if (c > 0) {__syncthreads();}
-		for (int idx = tid; idx < kn*(SG_BX/4); idx += SG_THREADS) { // tables are zero-padded to a multiple of 128 columns / rows
-			int const k = idx/(SG_BX/4), q = idx % (SG_BX/4);
-			*(float4 *)&sX[k*SG_BX + q*4] = *(float4 const *)&xt[(size_t)(k0 + k)*job.nxp + bx0 + q*4];
-			*(float4 *)&sY[k*SG_BY + q*4] = *(float4 const *)&yt[(size_t)(k0 + k)*job.nyp + by0 + q*4];
-		}
-		__syncthreads();
-		sg_chunk_both_pipes(acc0, acc1, pa, pb, kn);
-	}
-	unsigned const xw = bx0 + wx0 + (lane & 31u), yw = by0 + wy0 + 4u*(lane >> 5); // the lane's column (+ 32) and the row of its register 0
-	float fmn = INFINITY, fmx = -INFINITY;
-	if (bx0 + SG_BX <= job.nx && by0 + SG_BY <= job.ny) {sg_mx_finish<GL, SM, false>(acc0, acc1, job, nc, smx, smy, out, xw, yw, fmn, fmx);}
-	else {sg_mx_finish<GL, SM, true>(acc0, acc1, job, nc, smx, smy, out, xw, yw, fmn, fmx);}
-	if (mm) { // fused min(vals) / max(vals) (heightmap_t::run_erosion, get_heightmap_z_range)
-		uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu;
-		if (fmn <= fmx) {mm_lo = f2ord(fmn); mm_hi = ~f2ord(fmx);}
-		wave_minmax_publish(mm_lo, mm_hi, mm);
-	}
-}
-
 // ------------------------------------------------------------------ K2/K3: fBm / domain-warp grid
 // fp32-VALU bound lattice noise.  Two cells of a row per lane (packed arithmetic, terra_noise.hpp); everything that depends on the hashed lattice
 // point only -- the second permute and the gradient / normalisation terms, ~25 of the ~60 instructions per lattice point -- comes from a table in

@@ -417,31 +417,6 @@ def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
         t.close()
 
 
-@pytest.mark.parametrize("pipes", ["both", "valu"])
-def test_sine_grid_on_either_pipe_choice_equals_oracle(pkg, orc, monkeypatch, pipes):
-    """TERRA_SINE_PIPES: the 80-term sum with its products from the matrix pipe (k_sine_grid_mx: v_mfma_f32_32x32x1 with C = 0, one rounding per product, every add on the
-    vector ALU in k order) or with everything on the vector ALU (k_sine_grid) -- the same bits: ragged grids (blocks that stick out), every chunk length parity and the
-    1 / 2 / 3 / 4-term tails (min_start_sin), glaciate and islands on and off, the fused min / max"""
-    monkeypatch.setenv("TERRA_SINE_PIPES", pipes)
-    t = pkg.Terra(0)
-    try:
-        pc.case_grid_vs_oracle(pkg, t, orc, 0, 1030)
-        pc.case_sine_epilogue_variants(pkg, t, orc)
-        pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
-        st = t.init_scene(pc_); orc.init(oc)
-        for mss in (89, 88, 87, 86, 80, 57, 45, 44, 43, 11, 0):
-            a = orc.gen_grid(-77, 12, st.DX_VAL, st.DY_VAL, 391, 262, 1, 0, mss)
-            b = t.gen_grid(-77, 12, st.DX_VAL, st.DY_VAL, 391, 262, pkg.GEN_GLACIATE, mss)
-            assert_bit_equal(a, b, f"sine grid, min_start_sin {mss}, pipes {pipes}")
-        for glac in (0, 1):
-            a = orc.gen_grid(-300, -200, st.DX_VAL, st.DY_VAL, 512, 384, glac)
-            b = t.gen_grid(-300, -200, st.DX_VAL, st.DY_VAL, 512, 384, pkg.GEN_GLACIATE if glac else 0)
-            assert_bit_equal(a, b, f"sine grid whole blocks, glaciate {glac}, pipes {pipes}")
-        pc.case_gen_grid_minmax(pkg, t, orc, 0, 700)
-    finally:
-        t.close()
-
-
 def test_streamed_pipeline_device_min_and_events(pkg, orc):
     """bench.py's streamed schedule: a producer context's noise kernels back to back, {min, max} left in HBM, three consumer contexts eroding as the events fire"""
     pc.case_streamed_pipeline(pkg, lambda: pkg.Terra(0), orc, N=2048, maps=9, P=3, droplets=(1000, 0, 6000))

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: ran against the commit that carried k_sine_grid_mx; results in profiles/r04_sine_matrix_pipe.txt)
 # tools/gpu_round4b.sh <tag>: the second half of round 4 in one GPU call -- (1) what the matrix pipe can be for the sine sum (tools/mfma_products.hip), (2) the GPU suite
 # on the default build and again with TERRA_SINE_PIPES=both (products of k_sine_grid from the matrix pipe), (3) the headline with either choice on the same box,
 # kernel stats of both, (4) the dense-erosion timings of the final scheduler.

@@ -1,4 +1,4 @@
-// What the matrix pipe can be for a sum that must round like mul-then-add (k_sine_grid_mx, TERRA_SINE_PIPES=both):
+// What the matrix pipe can be for a sum that must round like mul-then-add (the k_sine_grid_mx experiment of round 4: profiles/r04_sine_matrix_pipe.txt):
 //   A  exactness + layout: v_mfma_f32_32x32x1_2b_f32 with C = 0 against the host's float multiply, bit for bit, over random operand sets that include subnormal
 //      inputs / products, zeros, infinities and NaNs; the register -> (row, column) map the kernel's epilogue assumes
 //   B  rates: one matrix instruction (2048 products) beside 16 v_pk_add_f32 / 32 v_add_f32, against 16 v_pk_mul_f32 + 16 v_pk_add_f32 on the vector ALU alone,
