@@ -22,6 +22,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
 	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as ONE launch (k_tile_shadows_chain: the level kernel's LDS body, blocks wait for their neighbours' done flags after staging their tile) instead of one launch per dependency level.  Measured equal (5.4 vs 5.5 ms for 64x64 tiles: a level costs its ~260-step sweep chain, not its launch), so the per-level form, which also serves halo batches, stays the default
+	int sg_kc = 27; // TERRA_SG_KC: terms per LDS chunk of the heightmap's sine kernel (27: 3 chunks of <= 27 for 8 octaves, 29.7 KB per block; 45: 2 chunks, 48 KB)
 	unsigned sg_rowgroup = 4; // TERRA_SG_ROWGROUP: tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
 	static int device_count() {int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n;}
@@ -35,6 +36,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		simple_kernels = (s && s[0] == '1');
 		if (char const *sc = getenv("TERRA_SHADOW_CHAIN")) {shadow_chain = (sc[0] != '0');}
 		if (char const *gr = getenv("TERRA_GRAPHS")) {graphs_enabled = (gr[0] != '0');}
+		if (char const *kc = getenv("TERRA_SG_KC")) {int const v = atoi(kc); if (v == 45 || v == 27 || v == 20) sg_kc = v;} // experiment knob: the same sum, chunked differently
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
@@ -219,7 +221,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
 		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup, 0};
-		if (job.plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<false, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);}
+		if (job.plain_only) {
+			auto const go = [&](auto kern) {hipLaunchKernelGGL(kern, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);};
+			if (sg_kc == 27) go(terra::k_sine_grid<false, false, 27>); else if (sg_kc == 20) go(terra::k_sine_grid<false, false, 20>); else go(terra::k_sine_grid<false, false, 45>);
+		}
 		else                {hipLaunchKernelGGL((terra::k_sine_grid<false, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;

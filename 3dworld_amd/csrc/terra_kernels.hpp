@@ -69,13 +69,6 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup; uint32_t tw;}; // tw: cells per tile edge of the virtual grid (130 zvals, 201 AO context)
 
 typedef float sg_v2f __attribute__((ext_vector_type(2)));
-struct sg_operands_t {float4 xa, xb, ya, yb;};
-__device__ __forceinline__ sg_operands_t sg_load(float const *px, float const *py, int k) {
-	sg_operands_t o;
-	o.xa = *(float4 const *)(px + k*SG_BX); o.xb = *(float4 const *)(px + k*SG_BX + 64);
-	o.ya = *(float4 const *)(py + k*SG_BY); o.yb = *(float4 const *)(py + k*SG_BY + 64);
-	return o;
-}
 // Two rows x eight columns per call: r0[jp] += {x0*y0, x1*y0}, r1[jp] += {x0*y1, x1*y1} with (y0,y1) = one register pair straight from ds_read_b128.
 // v_pk_mul_f32 broadcasts the row's y from either half of the pair through op_sel, so no operand is ever copied (the compiler's own selection
 // moves half of the broadcast operands into fresh registers every step), and the mul/mul/add/add order keeps one independent instruction
@@ -92,21 +85,22 @@ __device__ __forceinline__ void sg_mul_add_2x8(sg_v2f (&r0)[SG_TX/2], sg_v2f (&r
 	    : "v"(xp[0]), "v"(xp[1]), "v"(xp[2]), "v"(yp), "v"(xp[3]));
 #undef TERRA_SG_2X2
 }
-// acc[i][jp] holds cells (row i, columns 2*jp, 2*jp+1) of the thread's 8 x 8 patch
-__device__ __forceinline__ void sg_accumulate(sg_v2f (&acc)[SG_TY][SG_TX/2], sg_operands_t const &o) {
-	sg_v2f const xp[4] = {{o.xa.x, o.xa.y}, {o.xa.z, o.xa.w}, {o.xb.x, o.xb.y}, {o.xb.z, o.xb.w}};
-	sg_v2f const yp[4] = {{o.ya.x, o.ya.y}, {o.ya.z, o.ya.w}, {o.yb.x, o.yb.y}, {o.yb.z, o.yb.w}};
-#pragma unroll
-	for (int ip = 0; ip < 4; ++ip) {sg_mul_add_2x8(acc[2*ip], acc[2*ip + 1], xp, yp[ip]);}
+// acc[i][jp] holds cells (row i, columns 2*jp, 2*jp+1) of the thread's 8 x 8 patch; one call = the four rows that one 16-byte Y read feeds (rows 4 h .. 4 h + 3)
+struct sg_xop_t {float4 a, b;};
+__device__ __forceinline__ sg_xop_t sg_load_x(float const *px, int k) {return sg_xop_t{*(float4 const *)(px + k*SG_BX), *(float4 const *)(px + k*SG_BX + 64)};}
+__device__ __forceinline__ void sg_accumulate_half(sg_v2f (&acc)[SG_TY][SG_TX/2], sg_xop_t const &x, float4 const &y, int h) {
+	sg_v2f const xp[4] = {{x.a.x, x.a.y}, {x.a.z, x.a.w}, {x.b.x, x.b.y}, {x.b.z, x.b.w}};
+	sg_mul_add_2x8(acc[4*h], acc[4*h + 1], xp, sg_v2f{y.x, y.y});
+	sg_mul_add_2x8(acc[4*h + 2], acc[4*h + 3], xp, sg_v2f{y.z, y.w});
 }
 
 // GENERAL = false: the host proved that every cell takes the short epilogue (terra_engine::sine_plain_only), so finish_cell() -- 64 inlined
 // copies of the plateau / crater / crack / volcano / powf code, ~340 KB of instructions the hot path would otherwise be threaded through -- is left out
-template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
+template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(SG_THREADS) void k_sine_grid(grid_job_t job, noise_consts_t nc, sin_lut_t L,
 	float const *__restrict__ xt, float const *__restrict__ yt, float const *__restrict__ smx, float const *__restrict__ smy, float *__restrict__ out, unsigned ntx, unsigned nty, uint32_t *__restrict__ mm, sg_tiles_t tiles)
 {
-	__shared__ __attribute__((aligned(16))) float sX[(SG_KC + 2)*SG_BX];
-	__shared__ __attribute__((aligned(16))) float sY[(SG_KC + 2)*SG_BY];
+	__shared__ __attribute__((aligned(16))) float sX[(KC + 2)*SG_BX];
+	__shared__ __attribute__((aligned(16))) float sY[(KC + 2)*SG_BY];
 	unsigned bxi, byi;
 	if (!sg_tile_of_block(blockIdx.x, ntx, nty, tiles.rowgroup, bxi, byi)) return;
 	uint32_t mm_lo = 0xFFFFFFFFu, mm_hi = 0xFFFFFFFFu; // fused min(vals)/max(vals) (heightmap_t::run_erosion, get_heightmap_z_range): saves a 4 B/cell read pass
@@ -121,7 +115,7 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 #pragma unroll
 		for (int jp = 0; jp < SG_TX/2; ++jp) {acc[i][jp] = sg_v2f{0.0f, 0.0f};}
 	}
-	int const nk = F_TABLE_SIZE - job.kstart, nchunks = (nk + SG_KC - 1)/SG_KC, per_chunk = (nk + nchunks - 1)/nchunks;
+	int const nk = F_TABLE_SIZE - job.kstart, nchunks = (nk + KC - 1)/KC, per_chunk = (nk + nchunks - 1)/nchunks;
 	for (int c = 0; c < nchunks; ++c) { // terms are summed in k order across chunks, exactly like the CPU loop
 		int const k0 = job.kstart + c*per_chunk, kn = ((k0 + per_chunk > F_TABLE_SIZE) ? F_TABLE_SIZE - k0 : per_chunk);
 		if (c > 0) {__syncthreads();} // everyone is done reading the previous chunk
@@ -131,16 +125,21 @@ template<bool TILES, bool GENERAL> __global__ __launch_bounds__(SG_THREADS) void
 			*(float4 *)&sY[k*SG_BY + q*4] = *(float4 const *)&yt[(size_t)(k0 + k)*job.nyp + by0 + q*4];
 		}
 		__syncthreads();
-		// two operand sets in ping-pong.  A set is reloaded right AFTER its accumulate (the scheduling barrier keeps the compiler from hoisting
-		// the loads above it), so the new values can land in the same registers -- no copies at the loop back-edge -- and have the other
-		// set's 128 packed instructions (~512 cycles) to arrive from LDS.
-		sg_operands_t A = sg_load(px, py, 0), B = sg_load(px, py, 1); // rows kn, kn+1 may be read but are never used (SG_KC + 2 rows are allocated)
+		// Operand registers: X (the eight columns, used by all eight rows of a step) in two sets that alternate between steps; Y (four rows per 16-byte read) in ONE set --
+		// a Y read is reloaded with the next step's values right after the four rows that use it, half a step (64 packed instructions, ~256 cycles) before it is needed
+		// again, an X set right after its step, a whole step ahead.  24 operand registers instead of 32: the kernel stays under 120 VGPRs, so that two of its waves fit on a
+		// SIMD beside a droplet wave of another heightmap's erosion (264 registers), where one did before.  The scheduling barriers keep the loads where they are written
+		// (the compiler would hoist them above the multiplies whose operands they replace, and copy).  Rows kn, kn + 1 may be read but are never used (KC + 2 rows are allocated).
+		sg_xop_t XA = sg_load_x(px, 0), XB = sg_load_x(px, 1);
+		float4 ya = *(float4 const *)py, yb = *(float4 const *)(py + 64);
 		int k = 0;
 		for (; k + 1 < kn; k += 2) {
-			sg_accumulate(acc, A); __builtin_amdgcn_sched_barrier(0); A = sg_load(px, py, k + 2);
-			sg_accumulate(acc, B); __builtin_amdgcn_sched_barrier(0); B = sg_load(px, py, k + 3);
+			sg_accumulate_half(acc, XA, ya, 0); __builtin_amdgcn_sched_barrier(0); ya = *(float4 const *)(py + (k + 1)*SG_BY);
+			sg_accumulate_half(acc, XA, yb, 1); __builtin_amdgcn_sched_barrier(0); yb = *(float4 const *)(py + (k + 1)*SG_BY + 64); XA = sg_load_x(px, k + 2);
+			sg_accumulate_half(acc, XB, ya, 0); __builtin_amdgcn_sched_barrier(0); ya = *(float4 const *)(py + (k + 2)*SG_BY);
+			sg_accumulate_half(acc, XB, yb, 1); __builtin_amdgcn_sched_barrier(0); yb = *(float4 const *)(py + (k + 2)*SG_BY + 64); XB = sg_load_x(px, k + 3);
 		}
-		if (k < kn) {sg_accumulate(acc, A);}
+		if (k < kn) {sg_accumulate_half(acc, XA, ya, 0); sg_accumulate_half(acc, XA, yb, 1);}
 	}
 	// ---- epilogue (eval_index's tail, src/mesh_gen.cpp:781-790): shape / post-process, glaciate, sine-mag islands, volcano.
 	// The common configuration (linear shape, no plateau/crater/crack, no volcano) takes a short path with the island terms of the
