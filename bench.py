@@ -62,6 +62,9 @@ def parse():
     p.add_argument("--schedule", default="threads", choices=["streamed", "threads"], help="how the heightmaps in flight are driven: threads = every pipeline (own context + host thread) runs its maps' noise + "
                    "erosion itself, the min read back in between (the default: measured fastest, profiles/r04_schedule_ab.txt); streamed = one context enqueues every map's noise on its "
                    "stream (kernels only, min(vals) stays in HBM), the pipelines' contexts erode the maps as their noise completes (terra_event_*: stream-level ordering)")
+    p.add_argument("--noise-slots", type=int, default=1, help="threads schedule: how many heightmaps may be in their noise phase at once (a host semaphore around the noise call; the other pipelines "
+                   "erode meanwhile).  0 = no limit: every pipeline issues its noise whenever it is free, and they fall into lockstep -- four noise kernels sharing the chip, then four erosions that leave "
+                   "its vector ALUs idle (profiles/r04_noise_slots_ab.txt)")
     p.add_argument("--priorities", default="erosion-high", choices=["none", "erosion-high", "noise-low"], help="streamed schedule: stream priorities of the eroding contexts / the noise producer")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
@@ -231,10 +234,16 @@ def main():
     x0 = -N / 2 + rank * N  # each rank owns its own N x N region of the world
     y0 = -N / 2
 
+    noise_turn = threading.Semaphore(args.noise_slots) if args.noise_slots > 0 else None
+
     def step(p=0, noise_done=None):
         # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
         c, zz = ctxs[p], zs[p]
-        mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
+        if noise_turn is not None:
+            with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
+                mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        else:
+            mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
         if noise_done is not None:
             noise_done.set()
         c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                   # run_erosion passes min(vals): only written cells can need the clamp

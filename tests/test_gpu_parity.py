@@ -393,7 +393,7 @@ def test_tile_erosion_two_waves_per_tile_equals_oracle(pkg, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"TERRA_GRAPHS": "0"}, {"TERRA_ERO_CK": "1:16", "TERRA_ERO_NEAR": "4"}, {"TERRA_ERO_CK": "40:0", "TERRA_ERO_LEAD": "0"}, {"TERRA_ERO_BATCH": "1", "TERRA_ERO_LEAD": "1"},
-                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SHADOW_CHAIN": "1", "TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}])
+                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SHADOW_CHAIN": "1", "TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}])
 def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
     """the environment knobs of DESIGN.md section 5 choose schedules, launch forms and cross-check kernels, never values: a whole-map erosion with re-traces, an eroded tile
     batch and its mesh shadows under each of them, bit for bit against the oracle (the knobs are read when a context is created)"""
@@ -402,6 +402,10 @@ def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
     t = pkg.Terra(0)
     try:
         pc.case_erosion_vs_oracle(pkg, t, orc, 512, 4000)
+        if "TERRA_SG_KC" in env or "TERRA_SG_ROWGROUP" in env:  # the heightmap's sine kernel: ragged grid, a late first term (odd chunk lengths), the fused min / max
+            pc.case_grid_vs_oracle(pkg, t, orc, 0, 1030)
+            pc.case_grid_vs_oracle(pkg, t, orc, 0, 300, 50)
+            pc.case_gen_grid_minmax(pkg, t, orc, 0, 700)
         pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
         t.init_scene(pc_); orc.init(oc)
         tiles = [(tx, ty) for ty in range(-28, -25) for tx in range(-29, -26)]
