@@ -65,6 +65,8 @@ def parse():
     p.add_argument("--noise-slots", type=int, default=1, help="threads schedule: how many heightmaps may be in their noise phase at once (a host semaphore around the noise call; the other pipelines "
                    "erode meanwhile).  0 = no limit: every pipeline issues its noise whenever it is free, and they fall into lockstep -- four noise kernels sharing the chip, then four erosions that leave "
                    "its vector ALUs idle (profiles/r04_noise_slots_ab.txt)")
+    p.add_argument("--build-ahead", type=int, default=0, choices=[0, 1], help="threads schedule with --noise-slots: build the next map's tables (terra_gen_grid_build_arrays_dev) while the pipeline waits for its noise turn, "
+                   "so that the turn itself is the eval kernel only (the same work per step, one dependent launch less between two noise kernels; measured equal: profiles/r04_noise_slots_ab.txt)")
     p.add_argument("--priorities", default="erosion-high", choices=["none", "erosion-high", "noise-low"], help="streamed schedule: stream priorities of the eroding contexts / the noise producer")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
@@ -240,6 +242,8 @@ def main():
         # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
         c, zz = ctxs[p], zs[p]
         if noise_turn is not None:
+            if args.build_ahead:
+                c.gen_grid_build_arrays_dev(x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # build_arrays now (a few microseconds beside another map's eval kernel), eval when it is this map's turn
             with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
                 mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
         else:
@@ -614,8 +618,9 @@ def main():
                 "hbm_achieved_gbs": round(hbm, 2), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm / HBM_PEAK_GBS, 4),
                 "nofma_peak_tops": VALU_NOFMA_TOPS, "nofma_frac": round(tflops / VALU_NOFMA_TOPS, 4),
                 "note": "fp32 VALU bound; the peak counts fused multiply-adds at 2.4 GHz.  Bit-parity with the FMA-free CPU reference forbids fusing (mul and add issue separately): nofma_frac is the "
-                        "fraction of that rate; and the chip sustains ~1.94 GHz under this kernel (GRBM_GUI_ACTIVE / duration, profiles/r04_clock_ramp.txt): at the clock it gets, its 6041 "
-                        "VALU instructions per wave keep the vector ALUs issuing ~90 % of the time (profiles/r04_pmc_summary.txt)"}
+                        "fraction of that rate; and the chip sustains ~1.94 GHz under this kernel (GRBM_GUI_ACTIVE / duration, profiles/r04_clock_ramp.txt): at the clock it gets, its ~6000 "
+                        "VALU instructions per wave (5120 of them the sum) keep the vector ALUs issuing ~90 % of the time (profiles/r04_pmc_summary.txt); the f32 matrix instructions share that datapath "
+                        "(profiles/r04_sine_matrix_pipe.txt)"}
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
                "value_strong": None if value_strong is None else round(value_strong, 4), "value_weak": None if value_weak is None else round(value_weak, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -157,6 +157,10 @@ def test_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs):
     pc.case_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs)
 
 
+def test_build_arrays_ahead_of_the_eval_call(pkg, gpu, orc):
+    pc.case_build_arrays_ahead(pkg, gpu, orc)
+
+
 def test_ground_mesh_and_point_queries(pkg, gpu, orc):
     pc.case_ground_mesh_and_point_queries(pkg, gpu, orc)
 
