@@ -119,10 +119,20 @@ template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(
 	for (int c = 0; c < nchunks; ++c) { // terms are summed in k order across chunks, exactly like the CPU loop
 		int const k0 = job.kstart + c*per_chunk, kn = ((k0 + per_chunk > F_TABLE_SIZE) ? F_TABLE_SIZE - k0 : per_chunk);
 		if (c > 0) {__syncthreads();} // everyone is done reading the previous chunk
-		for (int idx = tid; idx < kn*(SG_BX/4); idx += SG_THREADS) { // tables are zero-padded to a multiple of 128 columns / rows
-			int const k = idx/(SG_BX/4), q = idx % (SG_BX/4);
-			*(float4 *)&sX[k*SG_BX + q*4] = *(float4 const *)&xt[(size_t)(k0 + k)*job.nxp + bx0 + q*4];
-			*(float4 *)&sY[k*SG_BY + q*4] = *(float4 const *)&yt[(size_t)(k0 + k)*job.nyp + by0 + q*4];
+		{	// stage the chunk: thread (kr, q) copies 16-byte group q of rows kr, kr + 8, ... of both tables.  All loads of a table's chunk are issued before its first LDS write (two
+			// HBM / L2 latencies per chunk instead of one per row group), addresses advance by a uniform stride (tables are zero-padded to a multiple of 128 columns / rows)
+			constexpr int ITERS = (KC*(SG_BX/4) + SG_THREADS - 1)/SG_THREADS;
+			unsigned const kr = tid >> 5, q4 = (tid & 31u)*4u;
+			float const *const gx = xt + (size_t)(k0 + (int)kr)*job.nxp + bx0 + q4, *const gy = yt + (size_t)(k0 + (int)kr)*job.nyp + by0 + q4;
+#pragma unroll
+			for (int tab = 0; tab < 2; ++tab) { // X, then Y: ITERS 16-byte loads in flight per thread (both tables at once would not fit the register budget of four waves per SIMD)
+				float const *const g = tab ? gy : gx; size_t const stride = tab ? job.nyp : job.nxp; float *const sT = tab ? sY : sX;
+				float4 v[ITERS];
+#pragma unroll
+				for (int it = 0; it < ITERS; ++it) {v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); if ((int)kr + 8*it < kn) {v[it] = *(float4 const *)(g + (size_t)(8*it)*stride);}}
+#pragma unroll
+				for (int it = 0; it < ITERS; ++it) {if ((int)kr + 8*it < kn) {*(float4 *)&sT[(kr + 8u*it)*SG_BX + q4] = v[it];}}
+			}
 		}
 		__syncthreads();
 		// Operand registers: X (the eight columns, used by all eight rows of a step) in two sets that alternate between steps; Y (four rows per 16-byte read) in ONE set --

@@ -29,7 +29,7 @@ case $CMD in
 check)
 	timeout 1700 python -m pytest tests -m gpu -x -q --durations=8 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$OUT/pytest_gpu.log"; tail -14 "$OUT/pytest_gpu.log"
 	timeout 600 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc $?"; tail -2 "$OUT/smoke.log"
-	timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench_driver_flags_line.json" 2> "$OUT/bench.err"; echo "bench rc $?"; tail -c 1500 "$OUT/bench_driver_flags_line.json" | head -c 1500; echo
+	timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags_line.json" 2> "$OUT/bench.err"; echo "bench rc $?"; tail -c 1500 "$OUT/bench_driver_flags_line.json" | head -c 1500; echo
 	;;
 tests)
 	timeout 1700 python -m pytest -m gpu -x -q --durations=8 "$@" > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$OUT/pytest_gpu.log"; tail -25 "$OUT/pytest_gpu.log"
