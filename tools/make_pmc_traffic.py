@@ -28,7 +28,7 @@ out = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --outp
        "unit": "KB as reported by rocprofv3; fetch bytes = 2 x FETCH_SIZE on gfx950 (guide, HBM section), checked on k_minmax's known read below; WRITE_SIZE checked on k_quantize16's known write",
        "kernels": {}}
 cells = N * N
-for name, pat in (("k_sine_grid", "k_sine_grid<false, false>"), ("k_minmax", "k_minmax"), ("k_quantize16", "k_quantize16")):
+for name, pat in (("k_sine_grid", "k_sine_grid<false, false"), ("k_minmax", "k_minmax"), ("k_quantize16", "k_quantize16")):
     f, w = pick(fetch, pat), pick(write, pat)
     if f is None or w is None:
         continue
