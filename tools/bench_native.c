@@ -12,12 +12,15 @@
 
 typedef struct {terra_ctx *ctx; float *z; terra_state st; int first, steps, stride, n, droplets, rc;} pipe_t;
 
+static pthread_mutex_t noise_turn = PTHREAD_MUTEX_INITIALIZER; /* one heightmap in its noise phase at a time, the others erode meanwhile (bench.py --noise-slots 1; profiles/r04_noise_slots_ab.txt) */
 static double now(void) {struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9*(double)t.tv_nsec;}
 static void *worker(void *arg) {
 	pipe_t *p = (pipe_t *)arg;
 	for (int s = p->first; s < p->steps && p->rc == 0; s += p->stride) { /* heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion in place */
 		float mn = 0.0f, mx = 0.0f;
+		pthread_mutex_lock(&noise_turn);
 		p->rc = terra_gen_grid_minmax_dev(p->ctx, -0.5f*(float)p->n, -0.5f*(float)p->n, p->st.DX_VAL, p->st.DY_VAL, (uint32_t)p->n, (uint32_t)p->n, TERRA_GEN_GLACIATE, 0, p->z, &mn, &mx);
+		pthread_mutex_unlock(&noise_turn);
 		if (p->rc == 0) {p->rc = terra_apply_erosion_dev(p->ctx, p->z, p->n, p->n, mn, (uint32_t)p->droplets, TERRA_ERODE_MINZ_IS_MIN);}
 	}
 	if (p->rc == 0) {p->rc = terra_synchronize(p->ctx);}
