@@ -65,6 +65,8 @@ def parse():
     p.add_argument("--noise-slots", type=int, default=1, help="threads schedule: how many heightmaps may be in their noise phase at once (a host semaphore around the noise call; the other pipelines "
                    "erode meanwhile).  0 = no limit: every pipeline issues its noise whenever it is free, and they fall into lockstep -- four noise kernels sharing the chip, then four erosions that leave "
                    "its vector ALUs idle (profiles/r04_noise_slots_ab.txt)")
+    p.add_argument("--noise-split", type=float, default=0.0, help="threads schedule with --noise-slots: issue a map's noise as two row strips (terra_gen_grid_rows_minmax_dev, bit-identical rows): the first "
+                   "this fraction of the rows inside the noise turn, the rest after it -- the next map's noise begins under the tail of this one.  0 = one launch")
     p.add_argument("--build-ahead", type=int, default=0, choices=[0, 1], help="threads schedule with --noise-slots: build the next map's tables (terra_gen_grid_build_arrays_dev) while the pipeline waits for its noise turn, "
                    "so that the turn itself is the eval kernel only (the same work per step, one dependent launch less between two noise kernels; measured equal: profiles/r04_noise_slots_ab.txt)")
     p.add_argument("--priorities", default="erosion-high", choices=["none", "erosion-high", "noise-low"], help="streamed schedule: stream priorities of the eroding contexts / the noise producer")
@@ -237,6 +239,7 @@ def main():
     y0 = -N / 2
 
     noise_turn = threading.Semaphore(args.noise_slots) if args.noise_slots > 0 else None
+    split_rows = min(N - 128, max(128, int(round(N * args.noise_split / 128.0)) * 128)) if (args.noise_split > 0.0 and N >= 256) else 0
 
     def step(p=0, noise_done=None):
         # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
@@ -244,8 +247,14 @@ def main():
         if noise_turn is not None:
             if args.build_ahead:
                 c.gen_grid_build_arrays_dev(x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # build_arrays now (a few microseconds beside another map's eval kernel), eval when it is this map's turn
-            with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
-                mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+            if split_rows:
+                with noise_turn:
+                    mn, _ = c.gen_grid_rows_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, 0, split_rows, pkg.GEN_GLACIATE)
+                mn2, _ = c.gen_grid_rows_minmax_dev(zz.data_ptr() + 4 * split_rows * N, x0, y0, st.DX_VAL, st.DY_VAL, N, N, split_rows, N - split_rows, pkg.GEN_GLACIATE)
+                mn = min(mn, mn2)  # min(vals) of the map = the minimum over its strips
+            else:
+                with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
+                    mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
         else:
             mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
         if noise_done is not None:
