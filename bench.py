@@ -462,7 +462,8 @@ def main():
     # ---- the headline
     if args.workload in ("heightmap", "regions", "onegrid"):
         workload_w = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
-        par_w = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU ({args.schedule} schedule)"
+        noise_turn_note = f", at most {args.noise_slots} in its noise phase at a time" if (args.schedule == "threads" and args.noise_slots > 0 and P > 1) else ""
+        par_w = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU ({args.schedule} schedule{noise_turn_note})"
         workload_s = (f"ONE {N}x{N} heightmap per step on {world} GPU(s) together: {args.mode} noise {args.octaves} octaves + glaciate/islands as row strips in their owners' HBM, min(vals) by "
                       f"all_reduce(min), {args.droplets}-droplet erosion of the whole grid in serial droplet order by rank (step mod {world}) over the mapped strips (heightmap_t::proc_gen semantics)")
         par_s = (f"{world} row strips of {N // world} rows mapped back to back on every rank (terra_dgrid, HIP virtual memory management; remote rows over xGMI), one 4-byte all_reduce(min) per step over "
