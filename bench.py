@@ -238,7 +238,7 @@ def main():
     x0 = -N / 2 + rank * N  # each rank owns its own N x N region of the world
     y0 = -N / 2
 
-    noise_turn = threading.Semaphore(args.noise_slots) if args.noise_slots > 0 else None
+    noise_turn = threading.Semaphore(args.noise_slots) if args.noise_slots > 0 else None  # (a threading.Lock for one slot measured the same: the hand-over is not Python's)
     split_rows = min(N - 128, max(128, int(round(N * args.noise_split / 128.0)) * 128)) if (args.noise_split > 0.0 and N >= 256) else 0
 
     def step(p=0, noise_done=None):
