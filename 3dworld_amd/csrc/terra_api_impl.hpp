@@ -66,7 +66,6 @@ int terra_create(terra_ctx **out, int device_index) {
 void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (...) {} delete ctx;}}
 int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
 int terra_release_scratch(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.release_scratch(); TERRA_CATCH}
-int terra_set_stream_priority(terra_ctx *ctx, int level) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_priority(level); TERRA_CATCH}
 int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
 
 // ---- events: stream-level ordering between contexts
@@ -218,10 +217,6 @@ const float *terra_gen_device_values(terra_gen *g) {return (g && g->built) ? g->
 int terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out) {
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out); TERRA_CATCH
-}
-int terra_gen_grid_build_arrays_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin) {
-	TERRA_CHECK_CTX
-	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, nullptr, nullptr, 0, 0xFFFFFFFFu, nullptr, true); TERRA_CATCH
 }
 int terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max) {
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
@@ -594,7 +589,6 @@ int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n,
 	TERRA_CATCH
 }
 
-uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx) {return ctx ? ctx->eng.be.tile2_gave_up : 0;}
 int terra_selftest_hot_sqrt(terra_ctx *ctx, uint32_t stride, uint64_t *mismatches) {
 	TERRA_CHECK_CTX
 	TERRA_TRY

@@ -14,7 +14,8 @@ struct terra_dgrid {
 	std::vector<void *> handles;             // one physical allocation per strip (owned: created here or imported)
 	std::vector<size_t> bytes;               // strip sizes (multiples of the granularity)
 	std::vector<int> devices;                // devices that get access to the mapping (in-process form: every context's device)
-	void *base = nullptr; size_t total = 0; bool mapped = false;
+	void *base = nullptr; size_t total = 0; bool mapped = false; // mapped: every strip is mapped AND accessible (set last)
+	size_t n_mapped = 0;                     // strips 0 .. n_mapped-1 are mapped into `base` (what dgrid_release / a failed terra_dgrid_map take apart)
 	uint32_t local = 0;
 };
 
@@ -22,7 +23,7 @@ namespace terra {
 inline void dgrid_release(terra_dgrid *g) {
 	if (!g) return;
 	if (g->base) {
-		if (g->mapped) {size_t off = 0; for (size_t i = 0; i < g->bytes.size(); ++i) {if (g->handles[i]) terra_backend_t::vm_unmap(g->base, off, g->bytes[i]); off += g->bytes[i];}}
+		{size_t off = 0; for (size_t i = 0; i < g->n_mapped; ++i) {terra_backend_t::vm_unmap(g->base, off, g->bytes[i]); off += g->bytes[i];}}
 		terra_backend_t::vm_free(g->base, g->total);
 	}
 	for (void *h : g->handles) {terra_backend_t::vm_release(h);}
@@ -70,10 +71,17 @@ int terra_dgrid_map(terra_dgrid *g, void **d_base) {
 		auto &be = g->ctx->eng.be;
 		size_t const gran = be.vm_granularity();
 		if (!g->base) {g->base = be.vm_reserve(g->total, gran);}
-		size_t off = 0;
-		g->mapped = true; // (from here on the destructor unmaps whatever was mapped)
-		for (size_t i = 0; i < g->handles.size(); ++i) {be.vm_map(g->base, off, g->handles[i], g->bytes[i]); off += g->bytes[i];}
-		terra_backend_t::vm_set_access(g->base, g->total, g->devices.data(), g->devices.size());
+		try {
+			size_t off = 0;
+			for (size_t i = 0; i < g->handles.size(); ++i) {be.vm_map(g->base, off, g->handles[i], g->bytes[i]); g->n_mapped = i + 1; off += g->bytes[i];}
+			terra_backend_t::vm_set_access(g->base, g->total, g->devices.data(), g->devices.size());
+		} catch (...) { // leave the handle as it was before the call: nothing mapped, the call may be repeated
+			size_t off = 0;
+			for (size_t i = 0; i < g->n_mapped; ++i) {terra_backend_t::vm_unmap(g->base, off, g->bytes[i]); off += g->bytes[i];}
+			g->n_mapped = 0;
+			throw;
+		}
+		g->mapped = true;
 		*d_base = g->base;
 	TERRA_CATCH
 }

@@ -246,10 +246,6 @@ template<class BE> struct terra_engine {
 	bool scene_ready = false, have_config = false;
 	std::vector<float> h_sin_table;
 	float *d_sin_table = nullptr;
-	// terra_gen_grid_build_arrays_dev: the tables of the NEXT sine grid built ahead of its eval call.  The key holds everything the table launch reads or writes; any difference
-	// (another grid, a scene / state change, scratch that moved) makes the eval call build them itself.  One-shot: a prepared set is used by one eval call.
-	struct sine_prep_key_t {float f[12]; uint32_t u[6]; uint64_t sin_epoch; void const *p[6];};
-	sine_prep_key_t prep_key; bool prep_valid = false; uint64_t sin_epoch = 0;
 	float *d_sinTable = nullptr; bool sinTable_dev_valid = false; // device copy of sinTable[90][5]: the per-grid constants of build_arrays are derived on the device (no upload per call)
 	uint32_t *d_noise_lut = nullptr; // lattice tables of the fBm kernels (terra_noise.hpp: noise_lut_fill), built once per context on the device
 	terra_erosion_report report{};
@@ -268,7 +264,6 @@ template<class BE> struct terra_engine {
 	}
 	// every grow-only device buffer of the context back to the allocator (they grow again on demand): the erosion ring of a 16384^2 map alone is ~8.5 GiB
 	void release_scratch() {
-		prep_valid = false;
 		be.sync();
 		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm}) {if (s->p) {be.free(s->p); s->p = nullptr; s->bytes = 0;}}
 		spec_blocks_clean = nullptr; spec_blocks_n = 0;
@@ -326,7 +321,7 @@ template<class BE> struct terra_engine {
 		return d_sinTable;
 	}
 	void gen_rand_sine_table_entries(float scaled_height) { // src/mesh_gen.cpp:219-254
-		sinTable_dev_valid = false; ++sin_epoch;
+		sinTable_dev_valid = false;
 		float xf_scale = (float)cfg.mesh_y/(float)cfg.mesh_x, yf_scale = (float)(1.0/(double)xf_scale);
 		if (cfg.scene_x > cfg.scene_y) yf_scale *= cfg.scene_y/cfg.scene_x;
 		if (cfg.scene_y > cfg.scene_x) xf_scale *= cfg.scene_x/cfg.scene_y;
@@ -449,7 +444,7 @@ template<class BE> struct terra_engine {
 	void set_state(terra_state const &s) {
 		if (!have_config) throw std::logic_error("terra_set_state: call terra_set_config (or terra_init_scene) first: hmap_params, modes and erosion scalars are not part of terra_state");
 		create_sin_table();
-		memcpy(sinTable, s.sinTable, sizeof(sinTable)); sinTable_dev_valid = false; ++sin_epoch;
+		memcpy(sinTable, s.sinTable, sizeof(sinTable)); sinTable_dev_valid = false;
 		start_eval_sin = s.start_eval_sin; MESH_HEIGHT = s.MESH_HEIGHT; DX_VAL = s.DX_VAL; DY_VAL = s.DY_VAL; DX_VAL_INV = s.DX_VAL_INV; DY_VAL_INV = s.DY_VAL_INV;
 		HALF_DXY = s.HALF_DXY; dxdy = s.dxdy; XY_SCENE_SIZE = s.XY_SCENE_SIZE; mesh_scale = s.mesh_scale; mesh_scale_z_inv = s.mesh_scale_z_inv; mesh_height_scale = s.mesh_height_scale;
 		set_zmax_est(s.zmax_est); zmin = s.zmin; zmax = s.zmax; water_plane_z = s.water_plane_z; glaciate_exp = s.glaciate_exp; clip_hd1 = s.clip_hd1; relh_adj_tex = s.relh_adj_tex;
@@ -487,7 +482,7 @@ template<class BE> struct terra_engine {
 	// full-grid call produces (the tables and cell coordinates use the row's index in the whole grid), so row strips evaluated on different GPUs tile the
 	// heightmap exactly (heightmap_t::proc_gen's loop is row-independent, src/heightmap.cpp:139-143)
 	// d_minmax (optional): DEVICE float[2] that receives {min, max} without the host ever seeing them (an enqueue-only proc_gen step: terra_apply_erosion_devmin_dev reads it)
-	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu, float *d_minmax = nullptr, bool build_arrays_only = false) {
+	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu, float *d_minmax = nullptr) {
 		require_scene();
 		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
 		if (nrows == 0xFFFFFFFFu) {if (row0 != 0) throw std::invalid_argument("gen_grid rows: row0 without a row count"); nrows = ny;}
@@ -507,7 +502,6 @@ template<class BE> struct terra_engine {
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
 		uint32_t *d_mm = nullptr;
 		bool const sine = (job.mode == MGEN_SINE);
-		if (build_arrays_only && !sine) return; // the fBm modes have no tables
 		if (h_minmax || d_minmax || sine) {d_mm = scratch<uint32_t>(s_mm, 2); if (!sine) {be.fill32(d_mm, 0xFFFFFFFFu, 2);}} // (sine mode: reset by the table launch)
 		bool fused;
 		bool const sm_on = job.use_sine_mag != 0;
@@ -530,14 +524,8 @@ template<class BE> struct terra_engine {
 			float *xt = scratch<float>(s_xt, (size_t)F_TABLE_SIZE*job.nxp), *yt = scratch<float>(s_yt, (size_t)F_TABLE_SIZE*job.nyp);
 			uint32_t const nxp = job.nxp, nyp = job.nyp;
 			size_t const ntab = (size_t)F_TABLE_SIZE*(nxp + nyp);
-			sine_prep_key_t key; memset(&key, 0, sizeof(key));
-			{float const kf[12] = {msx, msy, ms2, mszi, jmx0, jmy0, mdx, mdy, sm_scale, sm_freq, dxi, dyi}; memcpy(key.f, kf, sizeof(kf));}
-			{uint32_t const ku[6] = {nx, ny, row0, nxp, nyp, sm_on ? 1u : 0u}; memcpy(key.u, ku, sizeof(ku));}
-			key.sin_epoch = sin_epoch; key.p[0] = xt; key.p[1] = yt; key.p[2] = smx; key.p[3] = smy; key.p[4] = d_mm; key.p[5] = st;
-			bool const have_tables = prep_valid && memcmp(&key, &prep_key, sizeof(key)) == 0; // built by terra_gen_grid_build_arrays_dev for exactly this grid
-			prep_valid = false;
 			uint32_t *const mmz = d_mm;
-			if (!have_tables) be.launch(ntab + (sm_on ? (size_t)nxp + nyp : 0), [=] TERRA_LAMBDA (size_t i) {
+			be.launch(ntab + (sm_on ? (size_t)nxp + nyp : 0), [=] TERRA_LAMBDA (size_t i) {
 				if (i == 0) {mmz[0] = 0xFFFFFFFFu; mmz[1] = 0xFFFFFFFFu;} // the fused min / max of the grid kernel start here (one launch less than a fill of its own)
 				if (i < (size_t)F_TABLE_SIZE*nxp) {
 					unsigned const k = (unsigned)(i / nxp), x = (unsigned)(i % nxp);
@@ -558,7 +546,6 @@ template<class BE> struct terra_engine {
 					else {unsigned const y = (unsigned)(q - nxp); smy[y] = (y < ny) ? L.COSF(((float)(y + row0)*mdy + jmy0)*dyi*sm_freq) : 0.0f;}
 				}
 			});
-			if (build_arrays_only) {prep_key = key; prep_valid = true; return;}
 			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, (h_minmax || d_minmax) ? d_mm : nullptr);
 		}
 		else {fused = be.noise_grid(job, nc, L, smx, smy, d_out, (h_minmax || d_minmax) ? d_mm : nullptr, d_noise_lut);}
@@ -664,7 +651,7 @@ template<class BE> struct terra_engine {
 		require_scene();
 		if (ncolors != 1 && ncolors != 2) throw std::invalid_argument("heightmap from_floats: one or two byte grayscale only");
 		float const val_div = (float)(1.0/(double)mh_texture_mult()), val_add = mh_texture_add();
-		prep_valid = false; uint32_t *d_bad = scratch<uint32_t>(s_mm, 2);
+		uint32_t *d_bad = scratch<uint32_t>(s_mm, 2);
 		be.fill32(d_bad, 0, 1);
 		be.launch((n + 3)/4, [=] TERRA_LAMBDA (size_t q) {
 			size_t const b = q*4, e = (b + 4 < n) ? b + 4 : n;
@@ -706,7 +693,7 @@ template<class BE> struct terra_engine {
 	uint64_t selftest_hot_sqrt(uint32_t stride) {
 		if (stride == 0) {stride = 1;}
 		// 64-bit counter: up to 4 disagreements per input x 2^32 inputs would wrap a 32-bit one (a sqrt_rn that is wrong everywhere would add up to 0 mod 2^32)
-		prep_valid = false; unsigned long long *d_bad = (unsigned long long *)scratch<uint32_t>(s_mm, 2);
+		unsigned long long *d_bad = (unsigned long long *)scratch<uint32_t>(s_mm, 2);
 		be.fill32(d_bad, 0, 2);
 		uint64_t const n = (0x100000000ull + stride - 1)/stride, per = 4096, nthreads = (n + per - 1)/per;
 		be.launch((size_t)nthreads, [=] TERRA_LAMBDA (size_t t) {
@@ -1216,13 +1203,7 @@ template<class BE> struct terra_engine {
 			}
 		}
 		uint32_t const npaths = 4*zv;
-		uint32_t *d_flags = (uint32_t *)(d_out + (size_t)2*nslots*zv);
-		bool chained = false;
-		if (level[order[n - 1]] >= 2 && virt_slot.empty()) {
-			chained = be.tile_shadows_chain(c, n, d_order, d_adj, d_zvals, d_out, d_smask, d_flags, npaths); // one launch for the whole chain (opt-in)
-			if (!chained) {be.fill8(d_smask, all_shadowed ? 0x02 : 0x00, (size_t)n*zv*zv); be.fill32(d_out, 0, (size_t)2*nslots*zv*2);} // not used / gave up: start over
-		}
-		for (uint32_t first = 0; first < n && !chained;) {
+		for (uint32_t first = 0; first < n;) {
 			uint32_t last = first;
 			while (last < n && level[order[last]] == level[order[first]]) ++last;
 			be.tile_shadows(c, last - first, d_order + first, d_adj, nslots, d_zvals, d_out, d_smask, npaths);

@@ -14,14 +14,8 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool simple_kernels = false; // TERRA_SIMPLE_KERNELS=1: run the one-thread-per-cell cross-check kernels instead of the LDS-tiled ones
 	float *tile_pad = nullptr; size_t tile_pad_bytes = 0;
-	void *tile_undo = nullptr; size_t tile_undo_bytes = 0; // k_tile_erosion2: undo logs of the speculative droplets + the list of tiles that gave up
-	bool tile_two_waves = false; // TERRA_TILE_WAVES=2: two waves per tile (k_tile_erosion2: exact, measured SLOWER than one wave per tile -- see DESIGN.md section 4 -- and therefore opt-in)
-	unsigned long long *t2_dbg = nullptr; // TERRA_T2_DIAG=1: eight counters of the two-wave tile kernel, printed to stderr after every batch
-	uint32_t t2_mode = 0; // TERRA_T2_MODE (test knob): 1 no speculation, 2 a speculative droplet waits instead of aborting itself when it meets the older one, 4 the primary makes the other abort at every step
-	uint32_t t2_undo_cap = terra::T2_UNDO_RECORDS; // TERRA_T2_UNDO: smaller logs (test knob: droplets then fall back to waiting for their turn more often)
 	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
-	bool shadow_chain = false; // TERRA_SHADOW_CHAIN=1: the whole batch as ONE launch (k_tile_shadows_chain: the level kernel's LDS body, blocks wait for their neighbours' done flags after staging their tile) instead of one launch per dependency level.  Measured equal (5.4 vs 5.5 ms for 64x64 tiles: a level costs its ~260-step sweep chain, not its launch), so the per-level form, which also serves halo batches, stays the default
 	int sg_kc = 27; // TERRA_SG_KC: terms per LDS chunk of the heightmap's sine kernel (27: 3 chunks of <= 27 for 8 octaves, 29.7 KB per block; 45: 2 chunks, 48 KB)
 	unsigned sg_rowgroup = 4; // TERRA_SG_ROWGROUP: tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
@@ -34,27 +28,18 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipEventCreate(&ev0)); TERRA_HIP_CHECK(hipEventCreate(&ev1));
 		char const *s = getenv("TERRA_SIMPLE_KERNELS");
 		simple_kernels = (s && s[0] == '1');
-		if (char const *sc = getenv("TERRA_SHADOW_CHAIN")) {shadow_chain = (sc[0] != '0');}
 		if (char const *gr = getenv("TERRA_GRAPHS")) {graphs_enabled = (gr[0] != '0');}
 		if (char const *kc = getenv("TERRA_SG_KC")) {int const v = atoi(kc); if (v == 45 || v == 27 || v == 20) sg_kc = v;} // experiment knob: the same sum, chunked differently
 		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
-		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion2, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
-		if (char const *tw = getenv("TERRA_TILE_WAVES")) {tile_two_waves = (tw[0] == '2');}
-		if (char const *tm = getenv("TERRA_T2_MODE")) {t2_mode = (uint32_t)atoi(tm);}
-		if (char const *td = getenv("TERRA_T2_DIAG")) {if (td[0] == '1') {TERRA_HIP_CHECK(hipMalloc((void **)&t2_dbg, 64));}}
-		if (char const *tu = getenv("TERRA_T2_UNDO")) {int const v = atoi(tu); if (v >= 2 && v <= (int)terra::T2_UNDO_RECORDS) t2_undo_cap = (uint32_t)v;}
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
-		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 	}
 	~hip_backend_t() {
 		if (pin) (void)hipHostFree(pin);
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_order) (void)hipFree(tile_order);
-		if (tile_undo) (void)hipFree(tile_undo);
-		if (t2_dbg) (void)hipFree(t2_dbg);
 		if (tile_acc) (void)hipFree(tile_acc);
 		if (tile_map) (void)hipFree(tile_map);
 		if (vox_p) (void)hipFree(vox_p);
@@ -63,23 +48,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		for (graph_slot_t &g : graphs) {graph_drop(g);}
 		if (own_stream) (void)hipStreamDestroy(own_stream);
 	}
-	// level > 0: the context's own stream is re-created at the device's highest priority (its workgroups are dispatched first when resources free up: a latency-bound
-	// erosion beside another context's chip-filling noise kernel), < 0: lowest, 0: default
-	void set_priority(int level) {
-		use();
-		if (stream != own_stream) throw std::logic_error("terra_set_stream_priority: the context runs on a caller-owned stream");
-		int least = 0, greatest = 0;
-		TERRA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest)); // numerically lower = higher priority
-		int const prio = (level > 0) ? greatest : (level < 0) ? least : 0;
-		hipStream_t ns = nullptr;
-		TERRA_HIP_CHECK(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, prio));
-		(void)hipStreamSynchronize(own_stream); (void)hipStreamDestroy(own_stream);
-		own_stream = stream = ns; pin_off = 0;
-	}
 	size_t mem_free() {use(); size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) != hipSuccess) {(void)hipGetLastError(); return ~(size_t)0 >> 1;} return f;}
 	void release_scratch() { // the backend's own grow-only buffers (the caller has drained the stream)
-		for (void **p : {(void **)&tile_pad, (void **)&tile_undo, (void **)&tile_order, (void **)&tile_acc, (void **)&tile_map, (void **)&vox_p}) {if (*p) {(void)hipFree(*p); *p = nullptr;}}
-		tile_pad_bytes = tile_undo_bytes = tile_order_bytes = tile_acc_bytes = vox_p_bytes = 0; tile_map_count = 0;
+		for (void **p : {(void **)&tile_pad, (void **)&tile_order, (void **)&tile_acc, (void **)&tile_map, (void **)&vox_p}) {if (*p) {(void)hipFree(*p); *p = nullptr;}}
+		tile_pad_bytes = tile_order_bytes = tile_acc_bytes = vox_p_bytes = 0; tile_map_count = 0;
 	}
 	void use() {TERRA_HIP_CHECK(hipSetDevice(device));}
 	void set_stream(void *s) {sync(); pin_off = 0; stream = s ? (hipStream_t)s : own_stream;} // cached graphs are stream-agnostic (the stream is given at launch)
@@ -283,21 +255,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	// whole batch in one launch (tiles in dependency order); false => not done (simple kernels requested), the caller goes level by level
-	bool tile_shadows_chain(terra::shadow_consts_t const &c, uint32_t n, uint32_t const *ord, int32_t const *adj, float const *z, unsigned long long *out, uint8_t *sm, uint32_t *flags, uint32_t np) {
-		if (simple_kernels || !shadow_chain || ((uintptr_t)sm & 3)) return false;
-		use();
-		fill32(flags, 0, (size_t)n + 1); // done[n], err
-		hipLaunchKernelGGL(terra::k_tile_shadows_chain, dim3(n), dim3(terra::SH_CHAIN_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, flags, flags + n, np);
-		TERRA_HIP_CHECK(hipGetLastError());
-		uint32_t err = 0;
-		d2h(&err, flags + n, 4);
-		return err == 0;
-	}
 	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {
 		if (simple_kernels || ((uintptr_t)sm & 3)) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np); return;} // the block ORs its mask out a word at a time
 		use();
-		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_CHAIN_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
+		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {
@@ -349,26 +310,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			h2d(d_ord, ord.data(), (size_t)n*4);
 			d_order = d_ord; d_landc = d_land;
 		}
-		size_t const lds2 = lds + (size_t)2*ec.NY*terra::T2_ROW_DW*4 + sizeof(terra::tile2_ctl_t);
-		if (tile_two_waves && iters >= 2 && lds2 <= 80*1024) { // two droplets of every tile in flight (k_tile_erosion2); tiles whose block gave up are redone by the one-wave kernel
-			size_t const ub = (size_t)n*2*terra::T2_UNDO_RECORDS*16*sizeof(terra::tile2_undo_t), eb = ((size_t)n + 1)*4, bytes = ub + eb;
-			if (bytes > tile_undo_bytes) {if (tile_undo) {sync(); (void)hipFree(tile_undo);} TERRA_HIP_CHECK(hipMalloc(&tile_undo, bytes)); tile_undo_bytes = bytes;}
-			uint32_t *d_err = (uint32_t *)((uint8_t *)tile_undo + ub);
-			fill32(d_err, 0, 1);
-			if (t2_dbg) {fill32(t2_dbg, 0, 16);}
-			hipLaunchKernelGGL(terra::k_tile_erosion2, dim3(n), dim3(128), lds2, stream, zvals, ec, iters, d_order, d_landc, (terra::tile2_undo_t *)tile_undo, d_err, t2_undo_cap, t2_mode, t2_dbg);
-			TERRA_HIP_CHECK(hipGetLastError());
-			uint32_t nerr = 0;
-			d2h(&nerr, d_err, 4);
-			if (t2_dbg) {unsigned long long c[8]; d2h(c, t2_dbg, 64); fprintf(stderr, "[tile2] %u tiles x %u droplets: steps primary %llu speculative %llu | runs put back %llu (%llu records) | waits on overlap %llu | general steps %llu | droplets done again %llu | spins %llu\n", n, iters, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);}
-			tile2_gave_up += nerr;
-			if (nerr) {hipLaunchKernelGGL(terra::k_tile_erosion, dim3(nerr), dim3(64), lds, stream, zvals, ec, iters, d_err + 1, (uint32_t const *)nullptr); TERRA_HIP_CHECK(hipGetLastError());}
-			return;
-		}
 		hipLaunchKernelGGL(terra::k_tile_erosion, dim3(n), dim3(64), lds, stream, zvals, ec, iters, d_order, d_landc);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	uint64_t tile2_gave_up = 0; // tiles whose two-wave block timed out in a spin (never expected; counted so that a test can see it)
 	void minmax(float const *vals, size_t n, uint32_t *d) {
 		if (simple_kernels || ((uintptr_t)vals & 15)) {minmax_simple(vals, n, d); return;}
 		use();

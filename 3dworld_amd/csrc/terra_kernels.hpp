@@ -406,364 +406,6 @@ __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, 
 	}
 }
 
-// ---- two waves per tile.  A tile's droplets are one serial chain (~0.6 us per step, 50-90 K steps on a land tile) and LDS holds only two
-// 76 KB tiles per CU: half the SIMDs idle and the batch lasts as long as its heaviest tile.  Two droplets of one tile have disjoint footprints in 92-99 % of the
-// cases (profiles/r02_tile_droplet_overlap.txt).  A block of TWO waves works on one LDS tile: the waves claim droplets from a counter; the wave that holds the oldest
-// unfinished droplet is the PRIMARY -- its droplet runs exactly as in the serial loop -- and the other wave RUNS AHEAD speculatively through the droplets after it,
-// one after another (its own droplets are in order among themselves).  Serial semantics are kept by a set-then-test protocol at the top of every step, over the
-// step's 4x4 box (which covers every read and write of a hot step):
-//   every wave        publishes the cell of its step (ctl.pos[w]);
-//   the speculative   sets the box's bits in its footprint bitmap (which accumulates over its whole run), THEN reads the other wave's published cell: while the
-//                     boxes overlap it waits (the primary moves on, or makes it abort);
-//   the primary       publishes, THEN tests the other wave's bitmap against its box: overlap -> it asks the speculative wave to abort and waits for the answer.
-// LDS is one in-order pipeline for the two waves of the block, so of two conflicting steps at least one side sees the other.  An aborted run puts back every cell it
-// wrote (undo log in HBM: plain stores on the way in, read only on an abort), clears its bitmap and waits until every droplet before it is committed; its droplets
-// are then run again, in order, as the primary.  When the primary finishes its droplet, `done` moves on; the run-ahead wave finds that it now holds the oldest
-// droplet: everything it has finished is final (`done` jumps to its current droplet) and it goes on as the primary without restarting, while the other wave claims
-// the next droplet and runs ahead.  Only hot steps (terra_erosion.hpp: droplet_hot_steps) run speculatively; a step that needs the general code (border brush,
-// random direction, NaN position) waits until the wave is the primary and first makes the other wave abort.  A wave decides its role from `done`; a speculative wave
-// that meets the other wave's box looks at `done` again before it yields, because the box may belong to a YOUNGER droplet started after its own became the oldest
-// (yielding to a younger droplet would undo writes that the younger one has already seen).  Every spin is bounded (T2_SPIN): on a time-out the block flags an
-// error and the host re-runs the tile with the one-wave kernel.
-constexpr int T2_ROW_DW = 3;                 // footprint bits per padded row: one bit per PAIR of columns (69 bits), so that two blocks fit the CU's 160 KB of LDS
-constexpr uint32_t T2_NONE = 0xFFFFFFFFu;
-constexpr uint32_t T2_SPIN = 1u << 24;
-constexpr uint32_t T2_UNDO_RECORDS = 512;    // per wave, x 16 lanes x 8 bytes: 128 KB of HBM per tile for its two waves
-struct tile2_ctl_t {uint32_t done, next, pos[2], abort_req[2], abort_ack[2], alive[2], err;};
-struct tile2_undo_t {uint32_t off; float old;}; // LDS dword offset of the cell (T2_NONE: the lane wrote nothing in this record), the value it held
-
-#if defined(__HIP_DEVICE_COMPILE__) // (device code only: wave intrinsics)
-struct tile2_mem_t : wave_cell_ops<tile2_mem_t> {
-	float *pad; int NX, NY;
-	tile2_ctl_t *ctl; uint32_t *bm_mine, *bm_other; tile2_undo_t *undo; // LDS control block, the two footprint bitmaps (LDS), this wave's undo log (HBM)
-	uint32_t w, run_first, undo_n, undo_cap, mode; bool spec, aborted, bm_dirty, failed;
-	bool prim = false, done_set = false; // this run is known to be the primary's (`done` only grows, so it stays that way until run_first changes) / `done` already covers what this wave finished before cur_droplet
-	uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // diagnostics: steps as the primary / speculative, runs put back, log records put back, waits on an overlapping box, general steps, droplets done again, spin iterations
-	__device__ float *cell(int X, int Z) const {return pad + Z*NX + X;}
-	__device__ void mark(int, int) {}
-	__device__ void wsync() {__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();}
-	__device__ uint32_t ld(uint32_t const *p) const {return wave_uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));}
-	__device__ void st(uint32_t *p, uint32_t v) const {__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);} // every lane stores the same word: no lane-dependent branch in the step loop
-	__device__ void mark_if(int, int, bool) {}
-	__device__ void new_run(uint32_t first) {run_first = first; prim = false;}
-	__device__ static uint32_t pack(int xi, int zi) {return ((uint32_t)zi << 16) | (uint32_t)xi;}
-	// the oldest unfinished droplet is this wave's: every droplet before its run is committed
-	__device__ bool is_primary() const {return ld(&ctl->done) >= run_first;}
-	// lanes 0 .. 3: does row zi-1+l of the box at (xi, zi) hit a set bit of `bm` / set the box's bits
-	// the bits of columns xi-1 .. xi+2 in a bitmap row: bit b stands for columns 2b, 2b+1
-	__device__ static unsigned long long row_mask(int X0, int &d) {
-		int const b0 = X0 >> 1, b1 = (X0 + 3) >> 1; // 2 or 3 bits
-		d = b0 >> 5;
-		return ((1ull << (b1 - b0 + 1)) - 1ull) << (b0 & 31);
-	}
-	__device__ uint32_t box_hit_bits(uint32_t const *bm, int xi, int zi) const { // per lane: the bits of row l & 3 of the box that are set in `bm` (the caller folds them with a ballot)
-		int d; unsigned long long const m = row_mask(xi - 1, d);
-		int const row = zi - 1 + (int)(threadIdx.x & 3u), d1 = (d + 1 < T2_ROW_DW) ? d + 1 : d;
-		return (bm[row*T2_ROW_DW + d] & (uint32_t)m) | (bm[row*T2_ROW_DW + d1] & (uint32_t)(m >> 32));
-	}
-	__device__ bool box_hits(uint32_t const *bm, int xi, int zi) const { // (every lane works: lane l on row l & 3 of the box, no branch)
-		int d; unsigned long long const m = row_mask(xi - 1, d);
-		int const row = zi - 1 + (int)(threadIdx.x & 3u), d1 = (d + 1 < T2_ROW_DW) ? d + 1 : d;
-		uint32_t const hit = (bm[row*T2_ROW_DW + d] & (uint32_t)m) | (bm[row*T2_ROW_DW + d1] & (uint32_t)(m >> 32));
-		return __ballot(hit != 0) != 0ull;
-	}
-	__device__ void box_set(int xi, int zi) {
-		int d; unsigned long long const m = row_mask(xi - 1, d);
-		int const row = zi - 1 + (int)(threadIdx.x & 3u), d1 = (d + 1 < T2_ROW_DW) ? d + 1 : d;
-		atomicOr(&bm_mine[row*T2_ROW_DW + d], (uint32_t)m);
-		atomicOr(&bm_mine[row*T2_ROW_DW + d1], (uint32_t)(m >> 32)); // (an OR with 0 when the box does not reach into the next word)
-		bm_dirty = true;
-	}
-	__device__ void bitmap_clear() {
-		if (!bm_dirty) return;
-		int const n = NY*T2_ROW_DW;
-		for (int i0 = 0; i0 < n; i0 += 64) {int const i = i0 + (int)(threadIdx.x & 63u); bm_mine[(i < n) ? i : n - 1] = 0u;} // (same trip count in every lane)
-		bm_dirty = false;
-		wsync();
-	}
-	// make the other wave give up its speculative run (it puts its writes back and clears its bitmap before it answers)
-	__device__ void abort_other() {
-		if (!ld(&ctl->alive[1u - w])) return;
-		uint32_t const token = ld(&ctl->abort_ack[1u - w]) + 1u;
-		st(&ctl->abort_req[1u - w], token);
-		wsync();
-		for (uint32_t n = 0; ld(&ctl->abort_ack[1u - w]) != token; ++n) {
-			if (n > T2_SPIN || !ld(&ctl->alive[1u - w])) {if (n > T2_SPIN) {failed = true; st(&ctl->err, 1u);} break;}
-			__builtin_amdgcn_s_sleep(1);
-		}
-		wsync();
-	}
-	// a pending request from the primary: put everything back, answer
-	__device__ bool serve_abort_request() {
-		uint32_t const req = ld(&ctl->abort_req[w]);
-		if (req == ld(&ctl->abort_ack[w])) return false;
-		rollback();
-		st(&ctl->abort_ack[w], req);
-		wsync();
-		return true;
-	}
-	__device__ void rollback() { // newest record first; a record holds all 16 cells of a box as they were before the write (lanes 16 .. 63 repeat lanes 0 .. 15)
-		wsync();
-		if (undo_n) {dbg[2] += 1; dbg[3] += undo_n;}
-		unsigned const l = threadIdx.x & 15u;
-		for (uint32_t r = undo_n; r-- > 0;) {
-			tile2_undo_t const u = undo[(size_t)r*16 + l];
-			pad[u.off] = u.old;
-			wsync();
-		}
-		undo_n = 0;
-		st(&ctl->pos[w], T2_NONE);
-		bitmap_clear();
-		aborted = true;
-	}
-	// the protocol step for the box at (xi, zi); false: the droplet cannot go on speculatively (aborted, or the log is full).
-	// Nothing here waits for LDS except to look at a value: the order of this wave's LDS operations IS their program order (one in-order pipeline per CU), which is all the
-	// set-then-test argument needs -- my publish / my bits are in place before my test executes; TERRA_WAVE_FENCE keeps the compiler from reordering, costs no instruction.
-	__device__ bool acquire(int xi, int zi) {
-		st(&ctl->pos[w], pack(xi, zi));
-		TERRA_WAVE_FENCE();
-		if (!prim) {prim = is_primary();}
-		spec = !prim;
-		if (spec) {
-			if (serve_abort_request()) return false;
-			if (undo_n + 2u > undo_cap || (mode & 1u)) return false; // (the caller waits for the run's turn and goes on as the primary)
-			box_set(xi, zi);
-			TERRA_WAVE_FENCE();
-			for (uint32_t n = 0; spec; ++n) {
-				uint32_t const op = ld(&ctl->pos[1u - w]);
-				if (op == T2_NONE) break;
-				int const dx = (int)(op & 0xFFFFu) - xi, dz = (int)(op >> 16) - zi;
-				if (!(dx >= -3 && dx <= 3 && dz >= -3 && dz <= 3)) break;
-				// the boxes overlap.  `done` was read before that box was: if the other wave has meanwhile committed everything before this run, the box is a
-				// YOUNGER droplet's (it was published after `done` moved) and this wave is the primary: it does not yield
-				if (is_primary()) {prim = true; spec = false; break;}
-				// wait until the older droplet has moved on (it makes this run abort if it comes this way: the bits are set)
-				if (n == 0) {dbg[4] += 1;}
-				if (serve_abort_request()) return false;
-				if (n > T2_SPIN) {failed = true; st(&ctl->err, 4u); return false;}
-				__builtin_amdgcn_s_sleep(1);
-			}
-			if (spec) {return true;}
-		}
-		if (!done_set) { // once per droplet: everything this wave finished while running ahead is final
-			uint32_t const d = ld(&ctl->done); if (d < cur_droplet) {st(&ctl->done, cur_droplet);}
-			done_set = true;
-			TERRA_WAVE_FENCE();
-		}
-		if (box_hits(bm_other, xi, zi)) {abort_other();}
-		return !failed;
-	}
-	uint32_t cur_droplet; // the droplet in progress (>= run_first)
-	// spin until every droplet before this wave's run is committed; false: the run was aborted on the way
-	__device__ bool wait_primary() {
-		bool ok = true;
-		for (uint32_t n = 0; !is_primary(); ++n) {
-			dbg[7] += 1;
-			if (serve_abort_request()) {ok = false;}
-			if (n > T2_SPIN) {failed = true; st(&ctl->err, 2u); break;}
-			__builtin_amdgcn_s_sleep(1);
-		}
-		spec = false; prim = true;
-		return ok && !aborted;
-	}
-	// ---- droplet_hot_steps / droplet_run hooks
-	__device__ bool begin_step(int, int) {return true;}
-	__device__ void set_travel(float, float) {}
-	__device__ bool hot_ready(int xi, int zi) {
-		if (!(((unsigned)(xi-1) <= (unsigned)(NX-4)) & ((unsigned)(zi-1) <= (unsigned)(NY-4)))) return false;
-		if (!acquire(xi, zi)) return false;
-		box_load_all(xi, zi);
-		return true;
-	}
-	__device__ void corners_hot(int ox, int oz, float out[4]) const {box_corners(ox, oz, out);}
-	__device__ void log_box(bool deposit_only) { // before a speculative write: what the box cells hold now (lanes 16 .. 63 repeat lanes 0 .. 15: same record, same words)
-		// (all 16 cells, written or not: the footprint bits cover the whole box, so nobody else changes an unwritten one before a rollback puts its own value back)
-		unsigned const l = threadIdx.x & 15u;
-		(void)deposit_only;
-		tile2_undo_t u; u.off = (uint32_t)(boxp[0] - pad); u.old = boxv[0];
-		undo[(size_t)undo_n*16 + l] = u;
-		++undo_n;
-	}
-	__device__ void deposit_hot(int xi, int zi, float xf, float zf, float dse) {if (spec) {log_box(true);} deposit_cells_hot_all(xi, zi, xf, zf, dse);}
-	__device__ void erode_hot(int xi, int zi, float xp, float zp, float dse) {if (spec) {log_box(false);} erode_cells_hot_all(xi, zi, xp, zp, dse);}
-	// general step (only ever as the primary, the other wave made to abort first): plain LDS accesses
-	__device__ void corners(int x, int z, float out[4]) const {
-		int const x0 = clampi(x, NX-1), x1 = clampi(x+1, NX-1), z0 = clampi(z, NY-1), z1 = clampi(z+1, NY-1);
-		out[0] = *cell(x0, z0); out[1] = *cell(x1, z0); out[2] = *cell(x0, z1); out[3] = *cell(x1, z1);
-	}
-	__device__ void deposit(int xi, int zi, float xf, float zf, float dse) {deposit_cells(xi, zi, xf, zf, dse, NX, NY);}
-	__device__ void erode(int xi, int zi, float xp, float zp, float dse) {erode_cells(xi, zi, xp, zp, dse, NX, NY);}
-};
-
-// The step loop's view of the tile, one type per ROLE, so that the loop a wave spends its time in carries nothing but the droplet: the protocol's fast path per step, no spin, no
-// role flag, no counters.  Whatever needs more -- the other wave's box in the way, a request to abort, the run becoming the primary's, a full log, a step for the general code --
-// makes hot_ready() return false: the loop ends before that step and tile2_attempt() sorts it out with tile2_mem_t::acquire() (the complete protocol, with its waits).
-//   primary:      publish the cell, read the other wave's footprint bits for the box, load the box (in that order; one wait for both reads), hit -> out;
-//   speculative:  publish, set the box's bits, then read {abort request, abort answer, done, the other wave's cell} in one go; log the box before every write.
-template<bool SPEC> struct tile2_hot_t : wave_cell_ops<tile2_hot_t<SPEC>> {
-	tile2_mem_t &m;
-	__device__ explicit tile2_hot_t(tile2_mem_t &m_) : m(m_) {}
-	__device__ float *cell(int X, int Z) const {return m.pad + Z*m.NX + X;}
-	__device__ void mark(int, int) {}
-	__device__ void mark_if(int, int, bool) {}
-	__device__ bool begin_step(int, int) {return true;}
-	__device__ void set_travel(float, float) {}
-	__device__ bool hot_ready(int xi, int zi) {
-		if (!(((unsigned)(xi-1) <= (unsigned)(m.NX-4)) & ((unsigned)(zi-1) <= (unsigned)(m.NY-4)))) return false;
-		m.st(&m.ctl->pos[m.w], tile2_mem_t::pack(xi, zi));
-		if (SPEC) {
-			if (m.mode & 1u) return false;
-			m.box_set(xi, zi); // (before the tests: a footprint that is a superset of the cells touched is harmless)
-			TERRA_WAVE_FENCE();
-			uint32_t const r0 = __hip_atomic_load(&m.ctl->abort_req[m.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r1 = __hip_atomic_load(&m.ctl->abort_ack[m.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-				r2 = __hip_atomic_load(&m.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r3 = __hip_atomic_load(&m.ctl->pos[1u - m.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			this->box_load_all(xi, zi);
-			uint32_t const req = wave_uniform(r0), ack = wave_uniform(r1), dn = wave_uniform(r2), op = wave_uniform(r3);
-			int const dx = (int)(op & 0xFFFFu) - xi, dz = (int)(op >> 16) - zi;
-			bool const near_other = (op != T2_NONE) & (dx >= -3) & (dx <= 3) & (dz >= -3) & (dz <= 3);
-			return !((req != ack) | (dn >= m.run_first) | (m.undo_n + 2u > m.undo_cap) | near_other);
-		}
-		TERRA_WAVE_FENCE();
-		uint32_t const hit = m.box_hit_bits(m.bm_other, xi, zi);
-		this->box_load_all(xi, zi);
-		return __ballot(hit != 0) == 0ull;
-	}
-	__device__ void corners_hot(int ox, int oz, float out[4]) const {this->box_corners(ox, oz, out);}
-	__device__ void log_box() { // before a speculative write: all 16 cells of the box as they are (see tile2_mem_t::rollback)
-		unsigned const l = threadIdx.x & 15u;
-		tile2_undo_t u; u.off = (uint32_t)(this->boxp[0] - m.pad); u.old = this->boxv[0];
-		m.undo[(size_t)m.undo_n*16 + l] = u;
-		++m.undo_n;
-	}
-	__device__ void deposit_hot(int xi, int zi, float xf, float zf, float dse) {if (SPEC) {log_box();} this->deposit_cells_hot_all(xi, zi, xf, zf, dse);}
-	__device__ void erode_hot(int xi, int zi, float xp, float zp, float dse) {if (SPEC) {log_box();} this->erode_cells_hot_all(xi, zi, xp, zp, dse);}
-};
-
-// one attempt at droplet `it` from its spawn; false: the wave's run was aborted (everything put back)
-__device__ __forceinline__ bool tile2_attempt(tile2_mem_t &m, erosion_consts_t const &ec, uint32_t it) {
-	droplet_state_t d;
-	d.rgen.set_state((int64_t)it + 11, 79*(int64_t)it + 121);
-	d.xi = EROSION_PAD + (d.rgen.rand() % ec.xsize);
-	d.zi = EROSION_PAD + (d.rgen.rand() % ec.ysize);
-	d.xp = (float)d.xi; d.zp = (float)d.zi; d.xf = 0; d.zf = 0; d.s = 0; d.v = 0; d.w = 1; d.dx = 0; d.dz = 0; d.numMoves = 0; d.nan_seen = 0;
-	m.cur_droplet = it; m.done_set = false;
-	// the spawn reads the four corners at (xi, zi): a step of its own for the protocol (always interior: the start cell lies PAD = 4 cells inside the padded grid)
-	if (!m.acquire(d.xi, d.zi)) {
-		if (m.failed) return true;
-		if (!m.wait_primary()) return false; // aborted -- or the log is full: go on when it is this run's turn
-		m.abort_other();
-	}
-	{float c[4]; m.corners(d.xi, d.zi, c); d.h = c[0]; d.h00 = c[0]; d.h10 = c[1]; d.h01 = c[2]; d.h11 = c[3];}
-	unsigned used = 0, last_moves = 0xFFFFFFFFu, tries = 0;
-	for (;;) {
-		unsigned const before = used;
-		int ev;
-		if (m.prim) {tile2_hot_t<false> h(m); ev = droplet_hot_steps(d, h, ec, DROPLET_NO_BUDGET, used); m.dbg[0] += used - before;}
-		else        {tile2_hot_t<true>  h(m); ev = droplet_hot_steps(d, h, ec, DROPLET_NO_BUDGET, used); m.dbg[1] += used - before;}
-		if (m.failed) return true;
-		if (ev == DROPLET_EV_DONE) break;
-		// the loop stopped before a step: the protocol wants attention, or the step is one for the general code
-		if (d.numMoves != last_moves) {tries = 0; last_moves = d.numMoves;}
-		bool const interior = ((unsigned)(d.xi-1) <= (unsigned)(m.NX-4)) & ((unsigned)(d.zi-1) <= (unsigned)(m.NY-4));
-		if (interior && tries < 4) { // (a step that keeps stopping the loop without a protocol reason is one for the general code: direction from the random generator, a NaN)
-			++tries;
-			if (m.acquire(d.xi, d.zi)) continue; // sorted out (waited for the other box to move on, took over as the primary, made the other wave abort): back into the loop of its role
-			if (m.failed) return true;
-			if (m.aborted) return false;
-			// a full log: no further ahead -- wait for the run's turn, then one step with the general code
-		}
-		if (!m.wait_primary()) return false;
-		if (m.failed) return true;
-		m.abort_other(); m.dbg[5] += 1;
-		if (droplet_run(d, m, ec, 1u)) break;
-		++used;
-	}
-	return !m.aborted;
-}
-#endif
-
-__global__ __launch_bounds__(128) void k_tile_erosion2(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters, uint32_t const *__restrict__ order, uint32_t const *__restrict__ land,
-	tile2_undo_t *__restrict__ undo_all, uint32_t *__restrict__ err_list /* [0]: number of tiles that gave up, then their indices */, uint32_t undo_cap, uint32_t mode, unsigned long long *__restrict__ dbg_out)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	extern __shared__ __attribute__((aligned(16))) float te_pad[];
-	int const NX = ec.NX, NY = ec.NY, xs = ec.xsize, ys = ec.ysize;
-	uint32_t const tile = order ? order[blockIdx.x] : blockIdx.x;
-	float *z = zvals + (size_t)tile*xs*ys;
-	if (land && land[tile] == 0) { // all ocean: every droplet stops at its first step without a write (see k_tile_erosion)
-		for (int i = threadIdx.x; i < xs*ys; i += 128) {z[i] = max_std(ec.min_zval, z[i]);}
-		return;
-	}
-	uint32_t *bm = (uint32_t *)(te_pad + NX*NY);
-	tile2_ctl_t *ctl = (tile2_ctl_t *)(bm + 2*NY*T2_ROW_DW);
-	for (int i = threadIdx.x; i < NX*NY; i += 128) {
-		int const X = i % NX, Z = i / NX;
-		te_pad[i] = z[(size_t)imax(imin(Z - EROSION_PAD, ys-1), 0)*xs + imax(imin(X - EROSION_PAD, xs-1), 0)];
-	}
-	for (int i = threadIdx.x; i < 2*NY*T2_ROW_DW; i += 128) {bm[i] = 0u;}
-	uint32_t const w = threadIdx.x >> 6;
-	if (threadIdx.x == 0) {ctl->done = 0; ctl->next = 0; ctl->pos[0] = ctl->pos[1] = T2_NONE; ctl->abort_req[0] = ctl->abort_req[1] = 0; ctl->abort_ack[0] = ctl->abort_ack[1] = 0; ctl->alive[0] = ctl->alive[1] = 1; ctl->err = 0;}
-	__syncthreads();
-	tile2_mem_t m;
-	m.pad = te_pad; m.NX = NX; m.NY = NY; m.ctl = ctl; m.bm_mine = bm + w*NY*T2_ROW_DW; m.bm_other = bm + (1u - w)*NY*T2_ROW_DW;
-	m.undo = undo_all + ((size_t)tile*2 + w)*T2_UNDO_RECORDS*16; m.w = w; m.undo_n = 0; m.undo_cap = undo_cap; m.mode = mode; m.spec = false; m.aborted = false; m.bm_dirty = false; m.failed = false;
-	auto claim = [&]() -> uint32_t { // the next droplet nobody has taken (one lane asks, the wave shares the answer)
-		uint32_t c = 0;
-		if (TERRA_LANE0) {c = atomicAdd(&ctl->next, 1u);}
-		return wave_uniform(c);
-	};
-	// this wave's run: droplets [run_first, owned_last], all claimed by it and consecutive; cur = the one in progress (below owned_last only while an aborted run is
-	// done again); pending = a droplet claimed for the NEXT run while the current one still has to be done again
-	uint32_t cur = claim(), owned_last = cur, pending = T2_NONE;
-	m.new_run(cur);
-	while (cur < iters && !m.failed) {
-		m.aborted = false;
-		bool const finished = tile2_attempt(m, ec, cur);
-		if (m.failed) break;
-		if (!finished) { // the run was aborted: all its writes are put back; when every droplet before it is committed its droplets run again, in order, as the primary
-			m.wait_primary();
-			m.dbg[6] += cur - m.run_first + 1;
-			cur = m.run_first;
-			continue;
-		}
-		m.st(&ctl->pos[w], T2_NONE);
-		if (cur < owned_last) { // doing an aborted run again (as the primary): commit this droplet, on to the next one of the run
-			m.wsync(); m.st(&ctl->done, cur + 1); m.wsync();
-			++cur; m.new_run(cur);
-			continue;
-		}
-		bool primary = m.is_primary();
-		if (!primary && m.undo_n + 128u > m.undo_cap) { // little room left in the log: no further ahead, wait for the run's turn
-			primary = m.wait_primary();
-			if (m.failed) break;
-			if (!primary) {cur = m.run_first; continue;}
-		}
-		uint32_t c;
-		if (pending != T2_NONE) {c = pending; pending = T2_NONE;} else {c = claim();}
-		if (!primary && (c != cur + 1 || c >= iters)) { // not the next droplet (the other wave claimed in between: it has committed its run), or none left: this run has to be committed first
-			primary = m.wait_primary();
-			if (m.failed) break;
-			if (!primary) {pending = c; cur = m.run_first; continue;} // aborted while waiting: the run first, then droplet c
-		}
-		if (primary) { // everything up to and including `cur` is final.  From the commit on the other wave is the primary: it must not find this wave's old footprint
-			m.bitmap_clear(); m.undo_n = 0;
-			if (c >= iters) {m.st(&ctl->alive[w], 0u);}
-			m.wsync(); m.st(&ctl->done, cur + 1); m.wsync();
-			m.new_run(c);
-		}
-		cur = owned_last = c; // (speculative: the run grows by one droplet; primary: a new run starts)
-	}
-	if (m.failed) {m.st(&ctl->alive[w], 0u); m.st(&ctl->err, 3u);}
-	if (dbg_out && TERRA_LANE0) {for (int k = 0; k < 8; ++k) {atomicAdd(&dbg_out[k], (unsigned long long)m.dbg[k]);}}
-	__syncthreads();
-	if (ctl->err) {if (threadIdx.x == 0) {err_list[1u + atomicAdd(err_list, 1u)] = tile;} return;} // the tile is left as it came in (zvals untouched): the host runs the one-wave kernel on it
-	for (int i = threadIdx.x; i < xs*ys; i += 128) {
-		int const x = i % xs, y = i / xs;
-		z[i] = max_std(ec.min_zval, te_pad[(y + EROSION_PAD)*NX + (x + EROSION_PAD)]);
-	}
-#endif
-}
-
 // ------------------------------------------------------------------ K6+K7: tile post-pass, one 256-thread block per tile
 // sub-block z ranges, water bbox (ints), mzmin/mzmax/radius (src/tiled_mesh.cpp:517-541) and RGBA8 normals + min_normal_z (src/tiled_mesh.cpp:865-880).
 // HBM-bound: 4 B read + 4 B written per cell; reductions go through LDS atomics on order-preserving uints.
@@ -929,27 +571,13 @@ __global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals
 	}
 }
 
-// ------------------------------------------------------------------ row f2: mesh shadows of a whole tile batch in ONE launch
-// Block b works on tile order[b] (tiles sorted by dependency level, so every tile's two neighbours toward the light have smaller block
-// numbers and -- workgroups being dispatched in index order -- are already resident or finished when it starts).  The block stages its 130 x 130
-// heights in LDS, lane 0 waits for the neighbours' done flags (acquire), the 520 sweeps run at once (576 threads) reading the neighbours' outgoing edge
-// heights from L2, and the block publishes its own flag (release).  The chain of 2*64-1 levels costs one kernel instead of 127 launches.
-// A bounded spin (~seconds) sets *err instead of hanging the device should the dispatch-order assumption ever fail; the host then redoes the
-// batch level by level.
-struct shadow_chain_in_t {
-	unsigned long long const *ix, *iy;
+// ------------------------------------------------------------------ row f2: mesh shadows, one launch per dependency level
+// An outgoing edge height travels between tiles as (dependency order << 32 | float bits) under a 64-bit max; 0 = nothing arrived (MESH_MIN_Z).
+struct shadow_edge_t {
 	__device__ static float decode(unsigned long long v) {if (v == 0) return -1.0E6f; uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); float f; memcpy(&f, &b, 4); return f;}
-	__device__ float x(int i) const {return ix ? decode(__hip_atomic_load(&ix[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1.0E6f;}
-	__device__ float y(int i) const {return iy ? decode(__hip_atomic_load(&iy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1.0E6f;}
-};
-struct shadow_chain_out_t {
-	uint8_t *sm; unsigned long long *ox, *oy; int xsize;
-	__device__ void shadow(int x, int y) {size_t const o = (size_t)y*xsize + x; atomicOr((unsigned int *)(sm + (o & ~(size_t)3)), 0x02u << (8u*(unsigned)(o & 3)));}
 	__device__ static unsigned long long pack(uint32_t order, float v) {uint32_t b; memcpy(&b, &v, 4); return ((unsigned long long)order << 32) | b;}
-	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], pack(order, v));}
-	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], pack(order, v));}
 };
-constexpr unsigned SH_CHAIN_THREADS = 576; // 9 waves: all 520 sweeps of a tile in one round
+constexpr unsigned SH_LEVEL_THREADS = 576; // 9 waves: all 520 sweeps of a tile in one round
 
 // One dependency level of the tile mesh shadows: one block per tile of the level, one thread per sweep.  A sweep is a chain of ~260 dependent steps, so
 // what a step costs is latency: everything it reads AND writes lives in LDS -- the tile's heights, the two incoming edge arrays (decoded), the tile's
@@ -964,11 +592,11 @@ struct shadow_lds_in_t {
 struct shadow_lds_out_t {
 	uint8_t *sm; unsigned long long *ox, *oy; int xsize; // all LDS
 	__device__ void shadow(int x, int y) {sm[y*xsize + x] = 0x02;} // MESH_SHADOW: every writer stores the same byte
-	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], shadow_chain_out_t::pack(order, v));}
-	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], shadow_chain_out_t::pack(order, v));}
+	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], shadow_edge_t::pack(order, v));}
+	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], shadow_edge_t::pack(order, v));}
 };
 constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130; // heights, in edges, out edges, shadow bytes = 87 660 bytes
-__global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
+__global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
 	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths)
 {
 	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
@@ -979,78 +607,25 @@ __global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_level(shadow_
 	float *s_in = s_sh_mh + zv*zv;
 	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv); // byte offset 68 640: 8-byte aligned
 	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
-	if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}} // 67 600 bytes per tile
-	else {for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}}
-	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {s_mask[i] = 0u;}
+	if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}} // 67 600 bytes per tile
+	else {for (unsigned i = tid; i < zv*zv; i += SH_LEVEL_THREADS) {s_sh_mh[i] = z[i];}}
+	for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {s_mask[i] = 0u;}
 	if (tid < 2*zv) { // in.x(i) = the y-neighbour's out_x, in.y(i) = the x-neighbour's out_y (src/tiled_mesh.cpp:676-687); earlier levels have finished
 		bool const isx = tid < zv; unsigned const i = isx ? tid : tid - zv; int32_t const a = isx ? ay : ax;
-		s_in[tid] = (a >= 0) ? shadow_chain_in_t::decode(out[((size_t)(isx ? 0 : 1)*n + a)*zv + i]) : -1.0E6f;
+		s_in[tid] = (a >= 0) ? shadow_edge_t::decode(out[((size_t)(isx ? 0 : 1)*n + a)*zv + i]) : -1.0E6f;
 		s_out[tid] = 0ull; // 0 = never written
 	}
 	__syncthreads();
 	shadow_lds_in_t const in{s_in, s_in + zv};
 	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+	for (unsigned p = tid; p < npaths; p += SH_LEVEL_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
-	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {gm[i] = s_mask[i] | c.mask_fill;} // plain stores: nobody else writes this tile's mask
+	for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {gm[i] = s_mask[i] | c.mask_fill;} // plain stores: nobody else writes this tile's mask
 	if (tid < 2*zv) {
 		unsigned long long const v = s_out[tid];
 		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
 	}
-}
-
-// The whole batch in ONE launch: the same block body, the tiles in dependency order (blockIdx = position in `order`, which is sorted by level, so a tile's two
-// neighbours toward the light were dispatched before it and are running or done: waiting for them cannot dead-lock).  A block stages its tile's heights and clears
-// its LDS arrays FIRST, then one thread waits for the neighbours' done flags (agent-scope acquire, s_sleep back-off), then the incoming edges are read (from L2:
-// they were written on another CU), the sweeps run, the results go out and the flag is released.  Against one launch per level this takes the launch gap and
-// the tile staging out of the serial chain of 127 levels: what is left per level is the ~260-step sweep chain and one flag round trip.
-__global__ __launch_bounds__(SH_CHAIN_THREADS) void k_tile_shadows_chain(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj, float const *__restrict__ zvals,
-	unsigned long long *out, uint8_t *smask, uint32_t *done, uint32_t *err, uint32_t npaths)
-{
-	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
-	unsigned const zv = 130, tid = threadIdx.x;
-	uint32_t const t = order[blockIdx.x];
-	int32_t const ax = adj[2*t], ay = adj[2*t + 1];
-	float const *z = zvals + (size_t)t*zv*zv;
-	float *s_in = s_sh_mh + zv*zv;
-	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv);
-	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
-	if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}}
-	else {for (unsigned i = tid; i < zv*zv; i += SH_CHAIN_THREADS) {s_sh_mh[i] = z[i];}}
-	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {s_mask[i] = 0u;}
-	if (tid == 0) { // (the neighbours are real tiles of this batch: indices below n; virtual halo slots are not used with this kernel)
-		int32_t const deps[2] = {ax, ay};
-		for (int k = 0; k < 2; ++k) {
-			if (deps[k] < 0) continue;
-			uint32_t spins = 0;
-			while (__hip_atomic_load(&done[deps[k]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-				if (++spins > (1u << 22)) {atomicExch(err, 1u); break;}
-				__builtin_amdgcn_s_sleep(4);
-			}
-		}
-	}
-	__syncthreads();
-	if (tid < 2*zv) {
-		bool const isx = tid < zv; unsigned const i = isx ? tid : tid - zv; int32_t const a = isx ? ay : ax;
-		unsigned long long v = 0ull;
-		if (a >= 0) {v = __hip_atomic_load(&out[((size_t)(isx ? 0 : 1)*n + a)*zv + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);} // written on another CU: read at L2
-		s_in[tid] = (a >= 0) ? shadow_chain_in_t::decode(v) : -1.0E6f;
-		s_out[tid] = 0ull;
-	}
-	__syncthreads();
-	shadow_lds_in_t const in{s_in, s_in + zv};
-	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-	for (unsigned p = tid; p < npaths; p += SH_CHAIN_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
-	__syncthreads();
-	if (tid < 2*zv) { // the outgoing edges first: they are what the next tiles wait for
-		unsigned long long const v = s_out[tid];
-		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
-	}
-	__syncthreads();
-	if (tid == 0) {__hip_atomic_store(&done[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);}
-	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv);
-	for (unsigned i = tid; i < zv*zv/4; i += SH_CHAIN_THREADS) {gm[i] = s_mask[i] | c.mask_fill;}
 }
 
 // ------------------------------------------------------------------ min / max reduction (run_erosion's min(vals), get_heightmap_z_range): HBM-bound, 4 B read per cell

@@ -97,14 +97,17 @@ def sharded_tile_mesh_shadows(terra, dist, tiles, light_pos, make_zvals, alloc_s
 
 # ---------------------------------------------------------------- ONE heightmap on several GPUs, erosion included (terra_dgrid)
 
-def exchange_fds(rank, world, fd, tag):
+def exchange_fds(rank, world, fd, tag, sockdir=None):
     """every rank hands the file descriptor of its strip to every other rank of the node over unix sockets (SCM_RIGHTS): returns {rank: fd} of the peers.
-    `tag` names the rendezvous (unique per grid and job, e.g. f"{MASTER_PORT}_{k}"); the caller runs a barrier before (nobody connects to a stale socket of an earlier
-    job) -- a rank starts listening, then connects to the others with retries, so no barrier is needed in between."""
+    `tag` names the rendezvous (unique per grid and job, e.g. f"{MASTER_PORT}_{k}"); `sockdir` is a directory only this user can enter (create_distributed_grid makes one
+    per job with mkdtemp and tells the other ranks through the process group).  A rank starts listening, then connects to the others with retries, so no barrier is
+    needed in between.  A connection from another user (SO_PEERCRED), a message without exactly one descriptor or with a rank out of range is refused; on any failure
+    the descriptors received so far are closed."""
     import os
     import socket
+    import struct
     import time
-    base = os.environ.get("TERRA_DGRID_SOCKDIR", "/tmp")
+    base = sockdir or os.environ.get("TERRA_DGRID_SOCKDIR", "/tmp")
     def path(r):
         return os.path.join(base, f"terra_dgrid_{tag}_{r}.sock")
     got = {}
@@ -116,7 +119,9 @@ def exchange_fds(rank, world, fd, tag):
     except FileNotFoundError:
         pass
     srv.bind(path(rank))
+    os.chmod(path(rank), 0o600)
     srv.listen(world)
+    ok = False
     try:
         for peer in range(world):  # send mine to everybody else
             if peer == rank:
@@ -132,20 +137,35 @@ def exchange_fds(rank, world, fd, tag):
                     if time.time() > deadline:
                         raise TimeoutError(f"terra_dgrid: rank {peer} never opened its socket")
                     time.sleep(0.01)
-            socket.send_fds(c, [rank.to_bytes(4, "little")], [fd])
-            c.close()
+            try:
+                socket.send_fds(c, [rank.to_bytes(4, "little")], [fd])
+            finally:
+                c.close()
         srv.settimeout(120.0)
         while len(got) < world - 1:  # and take theirs
             conn, _ = srv.accept()
-            msg, fds, _, _ = socket.recv_fds(conn, 4, 1)
-            conn.close()
-            got[int.from_bytes(msg, "little")] = fds[0]
+            try:
+                uid = struct.unpack("3i", conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))[1]
+                msg, fds, _, _ = socket.recv_fds(conn, 4, 4)
+            finally:
+                conn.close()
+            peer = int.from_bytes(msg, "little") if len(msg) == 4 else -1
+            if uid != os.getuid() or len(fds) != 1 or not (0 <= peer < world) or peer == rank or peer in got:
+                for f in fds:
+                    os.close(f)
+                raise RuntimeError(f"terra_dgrid: refused a descriptor message (uid {uid}, {len(fds)} descriptors, rank {peer})")
+            got[peer] = fds[0]
+        ok = True
     finally:
         srv.close()
         try:
             os.unlink(path(rank))
         except FileNotFoundError:
             pass
+        if not ok:
+            for f in got.values():
+                os.close(f)
+            got.clear()
     return got
 
 
@@ -190,17 +210,42 @@ def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cp
         if g is not None:
             g.destroy()
         raise RuntimeError(f"terra_dgrid: allocation / export failed on some rank ({err or 'another rank'})")
+    sockdir = None
+    if world > 1:  # a directory only this user can enter, made by rank 0 and announced through the process group
+        import tempfile
+        box = [None]
+        try:
+            if rank == 0 and "TERRA_DGRID_SOCKDIR" not in os.environ:
+                box[0] = tempfile.mkdtemp(prefix="terra_dgrid_")
+        except OSError:
+            box[0] = None
+        dist.broadcast_object_list(box, src=0)
+        sockdir = box[0]
+    peers = {}
     try:  # step 2: everybody's strips, mapped
         if world > 1:
-            peers = exchange_fds(rank, world, fd, tag)
-            os.close(fd)
-            for r, pfd in peers.items():
-                g.import_fd(r, pfd)
-                os.close(pfd)
+            try:
+                peers = exchange_fds(rank, world, fd, tag, sockdir)
+            finally:
+                os.close(fd)
+            for r in sorted(peers):
+                g.import_fd(r, peers[r])
         g.map()
     except Exception as e:  # noqa: BLE001
         err = repr(e)
-    if not _all_ok(dist, err is None, coll_device):
+    finally:
+        for pfd in peers.values():
+            try:
+                os.close(pfd)
+            except OSError:
+                pass
+    all_ok = _all_ok(dist, err is None, coll_device)  # (also: every rank is done with the sockets)
+    if sockdir is not None and rank == 0:
+        try:
+            os.rmdir(sockdir)
+        except OSError:
+            pass
+    if not all_ok:
         g.destroy()
         raise RuntimeError(f"terra_dgrid: import / map failed on some rank ({err or 'another rank'})")
     return g, rows
@@ -256,17 +301,21 @@ class OneHeightmapPipeline:
         for c in self.ectx:
             c.close()
 
-    def _all_reduce_min(self, v):
+    def _all_reduce_min(self, v, ok=True):
+        """min over the ranks of (v, ok flag): one collective per step carries the map's min(vals) AND whether any rank has seen an error, so that every rank
+        leaves the step loop on the same step (a rank that raised alone would leave the others waiting in the next all_reduce)"""
         if self.dist is None or not self.dist.is_initialized():
-            return v
+            return v, ok
         import torch
-        t = torch.tensor([v], dtype=torch.float32, device=self.coll_device)
+        t = torch.tensor([v, 1.0 if ok else 0.0], dtype=torch.float32, device=self.coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return float(t.item())
+        h = t.tolist()
+        return float(h[0]), h[1] > 0.5
 
     def run(self, k, origin=None, collect=None):
         """k steps.  origin(s) -> (x0, y0) of step s's grid (default: the nx x ny grid centred on the origin); collect(s, ptr) is called on the eroding rank when step s's
-        grid is final (before it can be overwritten)."""
+        grid is final (before it can be overwritten).  Returns when the erosions of ALL ranks are complete (one more collective after the loop): run() may be
+        called again at once."""
         import queue
         pkg, N = self.pkg, self.nx
         r0, r1 = self.rows[self.rank]
@@ -300,12 +349,17 @@ class OneHeightmapPipeline:
                 x0, y0 = origin(s) if origin is not None else (-self.nx / 2, -self.ny / 2)
                 mn = float("inf")
                 if r1 > r0:
-                    mn, _ = self.nctx.gen_grid_rows_minmax_dev(self.grids[g].ptr + r0 * N * 4, x0, y0, self.st.DX_VAL, self.st.DY_VAL, self.nx, self.ny, r0, r1 - r0, pkg.GEN_GLACIATE)
+                    try:
+                        mn, _ = self.nctx.gen_grid_rows_minmax_dev(self.grids[g].ptr + r0 * N * 4, x0, y0, self.st.DX_VAL, self.st.DY_VAL, self.nx, self.ny, r0, r1 - r0, pkg.GEN_GLACIATE)
+                    except Exception as e:  # noqa: BLE001 -- reported through the step's collective like an eroder's failure
+                        errs.append(repr(e))
                 j = s - self.G + 1
                 if j >= 0 and j % self.world == self.rank:
                     done[j].wait()  # my erosion of the grid that step s + 1 overwrites is complete before I let all_reduce(s) complete anywhere
-                mn = self._all_reduce_min(mn)
-                if errs:
+                mn, ok = self._all_reduce_min(mn, not errs)
+                if not ok:  # on EVERY rank in this step
+                    if not errs:
+                        errs.append("an erosion failed on another rank")
                     break
                 if s % self.world == self.rank:
                     done[s] = self._threading.Event()
@@ -316,5 +370,8 @@ class OneHeightmapPipeline:
                 q.put(None)
             for x in th:
                 x.join()
-        if errs:
-            raise RuntimeError("; ".join(errs))
+        # the erosions of the last steps ran on their ranks after the loop's last collective: agree that they are all complete (a peer may still have been reading and
+        # writing this rank's strips over xGMI -- the next run() writes noise into grid 0 at once) and that none of them failed
+        _, ok = self._all_reduce_min(0.0, not errs)
+        if errs or not ok:
+            raise RuntimeError("; ".join(errs) if errs else "an erosion failed on another rank")

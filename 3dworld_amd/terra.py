@@ -130,14 +130,12 @@ _PROTOS = {
     "terra_glaciate_mesh_dev": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp]),
     "terra_apply_erosion_dev": (_i32, [_vp, _vp, _i32, _i32, _f, _u32, _u32]),
     "terra_apply_erosion": (_i32, [_vp, _vp, _i32, _i32, _f, _u32]),
-    "terra_set_stream_priority": (_i32, [_vp, _i32]),
     "terra_release_scratch": (_i32, [_vp]),
     "terra_event_create": (_i32, [_vp, C.POINTER(_vp)]),
     "terra_event_record": (_i32, [_vp, _vp]),
     "terra_event_wait": (_i32, [_vp, _vp]),
     "terra_event_destroy": (None, [_vp]),
     "terra_apply_erosion_devmin_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32]),
-    "terra_gen_grid_build_arrays_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32]),
     "terra_gen_grid_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _vp]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
@@ -176,7 +174,6 @@ _PROTOS = {
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
     "terra_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
-    "terra_get_tile_erosion_fallbacks": (C.c_uint64, [_vp]),
     "terra_selftest_hot_sqrt": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
     "terra_voxel_fill_slab_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32, _u32, _u32]),
@@ -311,7 +308,6 @@ class Terra:
     def set_erode_amount(self, v): self._ck(self.lib.terra_set_erode_amount(self.ctx, v))
     def set_stream(self, stream_ptr): self._ck(self.lib.terra_set_stream(self.ctx, stream_ptr))
     def release_scratch(self): self._ck(self.lib.terra_release_scratch(self.ctx))
-    def set_stream_priority(self, level): self._ck(self.lib.terra_set_stream_priority(self.ctx, level))
     def synchronize(self): self._ck(self.lib.terra_synchronize(self.ctx))
     def max_sea_level(self): return self.lib.terra_get_max_sea_level(self.ctx)
     def alloc(self, nbytes): return DeviceBuffer(self, nbytes)
@@ -357,7 +353,6 @@ class Terra:
                                                     mnz.ctypes.data if normals else None))
         return z, st, nm, mnz
 
-    def tile_erosion_fallbacks(self): return int(self.lib.terra_get_tile_erosion_fallbacks(self.ctx))
     def selftest_hot_sqrt(self, stride=1):
         """disagreements of the droplet step's square roots with sqrtf / the correctly rounded root over every stride-th fp32 bit pattern (must be 0)"""
         n = C.c_uint64(0)
@@ -539,10 +534,6 @@ class Terra:
         r = (C.c_float * 2)()
         self._ck(self.lib.terra_glaciate_mesh_dev(self.ctx, ptr, nx, ny, xoff2, yoff2, C.addressof(r)))
         return r[0], r[1]
-
-    def gen_grid_build_arrays_dev(self, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
-        """build_arrays of the next gen_grid_* call with the same arguments, ahead of it (asynchronous; that call then only evaluates)"""
-        self._ck(self.lib.terra_gen_grid_build_arrays_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin))
 
     def gen_grid_minmax_async_dev(self, ptr, x0, y0, dx, dy, nx, ny, minmax_ptr, flags=GEN_GLACIATE, min_start_sin=0):
         """noise (+ glaciate) with {min, max} left in device memory at minmax_ptr (2 floats); nothing is read back, the call only enqueues"""

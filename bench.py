@@ -59,17 +59,9 @@ def parse():
     p.add_argument("--octaves", type=int, default=8)
     p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
     p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
-    p.add_argument("--schedule", default="threads", choices=["streamed", "threads"], help="how the heightmaps in flight are driven: threads = every pipeline (own context + host thread) runs its maps' noise + "
-                   "erosion itself, the min read back in between (the default: measured fastest, profiles/r04_schedule_ab.txt); streamed = one context enqueues every map's noise on its "
-                   "stream (kernels only, min(vals) stays in HBM), the pipelines' contexts erode the maps as their noise completes (terra_event_*: stream-level ordering)")
     p.add_argument("--noise-slots", type=int, default=1, help="threads schedule: how many heightmaps may be in their noise phase at once (a host semaphore around the noise call; the other pipelines "
                    "erode meanwhile).  0 = no limit: every pipeline issues its noise whenever it is free, and they fall into lockstep -- four noise kernels sharing the chip, then four erosions that leave "
                    "its vector ALUs idle (profiles/r04_noise_slots_ab.txt)")
-    p.add_argument("--noise-split", type=float, default=0.0, help="threads schedule with --noise-slots: issue a map's noise as two row strips (terra_gen_grid_rows_minmax_dev, bit-identical rows): the first "
-                   "this fraction of the rows inside the noise turn, the rest after it -- the next map's noise begins under the tail of this one.  0 = one launch")
-    p.add_argument("--build-ahead", type=int, default=0, choices=[0, 1], help="threads schedule with --noise-slots: build the next map's tables (terra_gen_grid_build_arrays_dev) while the pipeline waits for its noise turn, "
-                   "so that the turn itself is the eval kernel only (the same work per step, one dependent launch less between two noise kernels; measured equal: profiles/r04_noise_slots_ab.txt)")
-    p.add_argument("--priorities", default="erosion-high", choices=["none", "erosion-high", "noise-low"], help="streamed schedule: stream priorities of the eroding contexts / the noise producer")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
                         "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
@@ -189,28 +181,45 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_note = None
+    # Rendezvous without name resolution: the ranks of one node meet in a FileStore under /tmp (N = 1: an in-process HashStore), RCCL / gloo bootstrap over the loopback
+    # interface.  torch's TCPStore looks the client's host name up for every connection; on a box whose resolver does not answer that alone took 105 s for the one-rank
+    # group (BENCH_r04: "hostname of the client socket cannot be retrieved").  Bounded: a group that is not up after the timeout is reported (N = 1) or fatal (N > 1).
+    import datetime
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+
+    def init_group(timeout_s):
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        if world == 1:
+            store = dist.HashStore()
+        else:  # every local rank has the same launcher as its parent: one file per launch, never a stale one
+            store = dist.FileStore(os.path.join("/tmp", f"terra_bench_store_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{world}"), world)
+        dist.init_process_group(backend=backend, store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+        probe = torch.tensor([3.5 + rank], dtype=torch.float32, device=dev if backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(probe, op=dist.ReduceOp.MIN)  # the communicator (and RCCL's banner) comes up here, not inside the timed region
+        if backend == "nccl":
+            torch.cuda.synchronize(dev)
+        assert float(probe.item()) == 3.5
+
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with c_stdout_to_stderr():
-            if backend == "nccl":
-                dist.init_process_group(backend="nccl", device_id=dev)
-                warm = torch.zeros(1, dtype=torch.float32, device=dev)
-                dist.all_reduce(warm, op=dist.ReduceOp.MAX)  # the communicator (and RCCL's banner) comes up here, not inside the timed region
-                torch.cuda.synchronize(dev)
-            else:
-                dist.init_process_group(backend=backend)
+            try:
+                init_group(180)
+            except Exception as e:  # noqa: BLE001 -- e.g. /tmp not shared by the ranks: the launcher's own store (env://) is the fall-back
+                print(f"[bench] FileStore rendezvous failed ({e!r}); falling back to env://", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     elif backend == "nccl" and not args.no_rccl_world1:
         # N = 1: a one-rank RCCL group, so that the device-tensor collectives of the sharded paths (all_reduce(min) of the strips, the max over ranks of the
         # step time, barriers) run through RCCL on the 1-GPU box too instead of being skipped; a failure to set it up is reported, not fatal
         try:
             t0 = time.perf_counter()
             with c_stdout_to_stderr():
-                dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
-                probe = torch.tensor([3.5], dtype=torch.float32, device=dev)
-                dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+                init_group(10)
                 dist.barrier()
-                assert float(probe.item()) == 3.5
-            rccl_note = {"world1_group": "ok", "init_plus_first_all_reduce_ms": round((time.perf_counter() - t0) * 1e3, 1)}
+            rccl_note = {"world1_group": "ok", "store": "HashStore (no sockets, no name resolution)", "init_plus_first_all_reduce_ms": round((time.perf_counter() - t0) * 1e3, 1)}
         except Exception as e:  # noqa: BLE001
             rccl_note = {"world1_group": f"unavailable: {e!r}"[:300]}
             if dist.is_initialized():
@@ -239,22 +248,12 @@ def main():
     y0 = -N / 2
 
     noise_turn = threading.Semaphore(args.noise_slots) if args.noise_slots > 0 else None  # (a threading.Lock for one slot measured the same: the hand-over is not Python's)
-    split_rows = min(N - 128, max(128, int(round(N * args.noise_split / 128.0)) * 128)) if (args.noise_split > 0.0 and N >= 256) else 0
-
     def step(p=0, noise_done=None):
         # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
         c, zz = ctxs[p], zs[p]
         if noise_turn is not None:
-            if args.build_ahead:
-                c.gen_grid_build_arrays_dev(x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # build_arrays now (a few microseconds beside another map's eval kernel), eval when it is this map's turn
-            if split_rows:
-                with noise_turn:
-                    mn, _ = c.gen_grid_rows_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, 0, split_rows, pkg.GEN_GLACIATE)
-                mn2, _ = c.gen_grid_rows_minmax_dev(zz.data_ptr() + 4 * split_rows * N, x0, y0, st.DX_VAL, st.DY_VAL, N, N, split_rows, N - split_rows, pkg.GEN_GLACIATE)
-                mn = min(mn, mn2)  # min(vals) of the map = the minimum over its strips
-            else:
-                with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
-                    mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+            with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
+                mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
         else:
             mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
         if noise_done is not None:
@@ -295,65 +294,8 @@ def main():
         for x in th:
             x.join()
 
-    # ---- the streamed schedule: a producer context for the noise, the P pipelines' contexts consume (erode)
-    nctx = pkg.Terra(local_rank)
-    nctx.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
-    if args.schedule == "streamed" and args.priorities != "none":
-        # a map's erosion is ~1000 short-lived waves on a dependent chain; beside the producer's chip-filling noise kernel its workgroups must be dispatched as soon as
-        # a noise block leaves a CU, or the erosion only starts in the noise kernel's tail (rocprofv3 timeline: profiles/r04_timeline_streamed_*.txt)
-        if args.priorities == "erosion-high":
-            for c in ctxs:
-                c.set_stream_priority(1)
-        else:
-            nctx.set_stream_priority(-1)
-    mms = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(P)]       # {min, max} of the map in slot p, written by its noise kernel, read by its erosion's clamp
-    ev_noise = [nctx.event_create() for _ in range(P)]                               # "the noise of the map in slot p is complete"
-    ev_free = [ctxs[p].event_create() for p in range(P)]                             # "the erosion of the map in slot p is complete": the slot may be overwritten
-
-    def run_steps_streamed(k, npipe):
-        """k heightmaps through npipe slots.  This thread enqueues noise i (terra_gen_grid_minmax_async_dev: kernels only) into slot i % npipe on the producer's stream as soon
-        as the slot's previous erosion has been ENQUEUED (its completion is waited for on the stream, not here); eroder thread p takes the maps of slot p: its stream waits for
-        the noise event, then terra_apply_erosion_devmin_dev (the erosion's own control-block read-backs block only that thread)."""
-        ready = [threading.Semaphore(0) for _ in range(npipe)]
-        free = [threading.Semaphore(1) for _ in range(npipe)]
-        errs = []
-
-        def eroder(p):
-            try:
-                for _i in range(p, k, npipe):
-                    ready[p].acquire()
-                    ctxs[p].event_wait(ev_noise[p])
-                    ctxs[p].apply_erosion_devmin_dev(zs[p].data_ptr(), N, N, mms[p].data_ptr(), args.droplets, pkg.ERODE_MINZ_IS_MIN)
-                    ctxs[p].event_record(ev_free[p])
-                    free[p].release()
-            except Exception as e:  # noqa: BLE001
-                errs.append(repr(e))
-                free[p].release()
-        th = [threading.Thread(target=eroder, args=(p,)) for p in range(min(npipe, k))]
-        for x in th:
-            x.start()
-        for i in range(k):
-            p = i % npipe
-            free[p].acquire()
-            if errs:
-                break
-            if i >= npipe:
-                nctx.event_wait(ev_free[p])
-            nctx.gen_grid_minmax_async_dev(zs[p].data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, mms[p].data_ptr(), pkg.GEN_GLACIATE)
-            nctx.event_record(ev_noise[p])
-            ready[p].release()
-        for x in th:
-            x.join()
-        if errs:
-            raise RuntimeError("; ".join(errs))
-
-    if args.schedule == "streamed":
-        run_steps_threads = run_steps
-        run_steps = run_steps_streamed  # noqa: F811
-
     def barrier():
         torch.cuda.synchronize(dev)
-        nctx.synchronize()
         for c in ctxs:
             c.synchronize()
         if have_group:
@@ -384,7 +326,6 @@ def main():
         t0 = time.perf_counter()
         fn(k)
         torch.cuda.synchronize(dev)
-        nctx.synchronize()
         for c in ctxs:
             c.synchronize()
         dt = time.perf_counter() - t0
@@ -462,8 +403,8 @@ def main():
     # ---- the headline
     if args.workload in ("heightmap", "regions", "onegrid"):
         workload_w = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
-        noise_turn_note = f", at most {args.noise_slots} in its noise phase at a time" if (args.schedule == "threads" and args.noise_slots > 0 and P > 1) else ""
-        par_w = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU ({args.schedule} schedule{noise_turn_note})"
+        noise_turn_note = f", at most {args.noise_slots} in its noise phase at a time" if (args.noise_slots > 0 and P > 1) else ""
+        par_w = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU (one host thread each{noise_turn_note})"
         workload_s = (f"ONE {N}x{N} heightmap per step on {world} GPU(s) together: {args.mode} noise {args.octaves} octaves + glaciate/islands as row strips in their owners' HBM, min(vals) by "
                       f"all_reduce(min), {args.droplets}-droplet erosion of the whole grid in serial droplet order by rank (step mod {world}) over the mapped strips (heightmap_t::proc_gen semantics)")
         par_s = (f"{world} row strips of {N // world} rows mapped back to back on every rank (terra_dgrid, HIP virtual memory management; remote rows over xGMI), one 4-byte all_reduce(min) per step over "
@@ -502,7 +443,6 @@ def main():
                               "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling, "config": {"workload": workload, "parallelism": par}, "headline_only": True}), flush=True)
         if pipe is not None:
             pipe.close()
-        nctx.close()
         for c in ctxs:
             c.close()
         if dist.is_initialized():
@@ -647,9 +587,6 @@ def main():
         print(json.dumps(out), flush=True)
     if pipe is not None:
         pipe.close()
-    for e in ev_noise + ev_free:
-        nctx.event_destroy(e)
-    nctx.close()
     for c in ctxs:
         c.close()
     if dist.is_initialized():

@@ -135,10 +135,6 @@ int  terra_device_count(void);
 int  terra_create(terra_ctx **out, int device_index);
 void terra_destroy(terra_ctx *ctx);
 int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
-/* priority of the context's OWN stream: level > 0 highest, < 0 lowest, 0 default (hipStreamCreateWithPriority; the stream is drained and re-created).  With several
- * contexts in flight on one GPU, the latency-bound work (a heightmap's erosion: ~1000 short-lived waves) goes on a high-priority context so that its workgroups are
- * dispatched as soon as resources free up beside another context's chip-filling noise kernel.  Never changes a result. */
-int  terra_set_stream_priority(terra_ctx *ctx, int level);
 int  terra_synchronize(terra_ctx *ctx);
 /* give every grow-only work buffer of the context back to the device (synchronises first; they grow again on demand).  The one that matters is the speculation ring of
  * terra_apply_erosion_dev: ~266 KiB per droplet in flight, 8.5 GiB for a 16384^2 map -- its size is also capped by the memory that is free when it has to grow. */
@@ -185,11 +181,6 @@ const float *terra_gen_device_values(terra_gen *g);                /* device poi
 
 /* one-shot: build_arrays + [enable_glaciate] + the caller's eval_index double loop (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:495-514) */
 int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out);
-/* the build_arrays half of the one-shot calls on its own (mesh_xy_grid_cache_t::build_arrays, src/mesh_gen.cpp:589-631: the per-term sine tables, + enable_glaciate's island
- * tables): asynchronous, a few microseconds of device work.  The next terra_gen_grid_* call of this context with the SAME arguments evaluates from these tables instead of
- * building them first -- a caller with several grids in flight builds the next grid's tables while another grid's eval kernel owns the chip.  Anything else in between
- * (other arguments, a scene / state change) simply makes that call build its own; fBm modes have no tables (no-op). */
-int  terra_gen_grid_build_arrays_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin);
 /* same, plus min(vals)/max(vals) folded into the grid kernel (what heightmap_t::run_erosion / get_heightmap_z_range compute next); synchronous */
 int  terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max);
 /* the same with min / max left in DEVICE memory (d_minmax: 2 floats) and nothing read back: asynchronous.  With terra_apply_erosion_devmin_dev the whole
@@ -270,9 +261,6 @@ int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32
                                   float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_normal_z);
 int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
                               float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
-/* diagnostics: tiles (since the context was created) whose two-droplets-in-flight erosion block gave up on a spin time-out and were redone by the one-wave kernel
- * (results are the same either way; expected to stay 0) */
-uint64_t terra_get_tile_erosion_fallbacks(terra_ctx *ctx);
 /* self test: the droplet step takes its two square roots per step with a shortened instruction sequence (csrc/terra_erosion.hpp: sqrt_rn); this runs it over every
  * stride-th fp32 bit pattern (stride 1: all 2^32, a few ms on the GPU) against sqrtf and against the correctly rounded double-precision route.  *mismatches must be 0. */
 int  terra_selftest_hot_sqrt(terra_ctx *ctx, uint32_t stride, uint64_t *mismatches);

@@ -16,10 +16,8 @@
 struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	std::chrono::steady_clock::time_point t0;
 	static int device_count() {return 1;}
-	uint64_t tile2_gave_up = 0; // (the two-wave tile kernel exists only on the device)
 	void init(int) {}
 	void set_stream(void *) {}
-	void set_priority(int) {}
 	size_t mem_free() {return ~(size_t)0 >> 1;}
 	void release_scratch() {}
 	void sync() {}
@@ -64,7 +62,6 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {tile_ao_simple(n, z, ctx, ao, dz);}
 	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np);}
 	void fill8(void *p, uint8_t v, size_t count) {memset(p, v, count);}
-	bool tile_shadows_chain(terra::shadow_consts_t const &, uint32_t, uint32_t const *, int32_t const *, float const *, unsigned long long *, uint8_t *, uint32_t *, uint32_t) {return false;}
 	bool graph_replay(void const *, size_t) {return false;} // no graphs here: every launch runs at once
 	bool graph_begin() {return false;}
 	void graph_end(void const *, size_t) {}

@@ -94,16 +94,6 @@ def test_tile_mesh_shadows(pkg, gpu, orc):
     pc.case_tile_mesh_shadows(pkg, gpu, orc)
 
 
-def test_tile_mesh_shadows_chained_kernel(pkg, orc, monkeypatch):
-    """the opt-in single-launch variant (blocks wait on their neighbours' done flags) gives the same masks"""
-    monkeypatch.setenv("TERRA_SHADOW_CHAIN", "1")
-    t = pkg.Terra(0)
-    try:
-        pc.case_tile_mesh_shadows(pkg, t, orc, lights=pc.SHADOW_LIGHTS[:4])
-    finally:
-        t.close()
-
-
 def test_tile_mesh_shadows_halo_interface(pkg, gpu, orc):
     pc.case_tile_mesh_shadows_halo(pkg, gpu, orc)
 
@@ -155,10 +145,6 @@ def test_grid_row_strips(pkg, gpu, orc, mode, nx, ny, nstrips):
 @pytest.mark.parametrize("gen_mode,shape,nslabs", [(0, (96, 64, 64), 8), (0, (17, 9, 300), 2), (1, (24, 20, 33), 3), (2, (24, 20, 33), 4)])
 def test_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs):
     pc.case_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs)
-
-
-def test_build_arrays_ahead_of_the_eval_call(pkg, gpu, orc):
-    pc.case_build_arrays_ahead(pkg, gpu, orc)
 
 
 def test_ground_mesh_and_point_queries(pkg, gpu, orc):
@@ -368,36 +354,8 @@ def test_multi_contexts_in_one_process(pkg, orc, ndev, big):
     pc.case_multi_contexts(pkg, None, orc, ndev, big)
 
 
-def test_tile_erosion_two_waves_per_tile_equals_oracle(pkg, orc, monkeypatch):
-    """the opt-in tile kernel with two waves per tile (TERRA_TILE_WAVES=2: a primary droplet and a speculative run-ahead wave on one LDS tile, set-then-test footprint
-    protocol, undo log, in-order commit): every tile of a 16 x 16 batch with 400 droplets equals the oracle's serial loop, on repeated runs (the protocol's outcome
-    must not depend on the timing of the two waves), with small undo logs too (runs that stop speculating early), and no block gives up"""
-    tiles = [(tx, ty) for ty in range(-30, -14) for tx in range(-32, -16)]  # land tiles with converging valleys, among them (-27, -26): the tile whose droplets 267 / 268 cross
-    iters = 400
-    pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
-    orc.init(oc)
-    want = {}
-    for cap in ("", "6"):
-        monkeypatch.setenv("TERRA_TILE_WAVES", "2")
-        if cap:
-            monkeypatch.setenv("TERRA_T2_UNDO", cap)
-        t = pkg.Terra(0)
-        try:
-            t.init_scene(pc_)
-            for rep in range(4 if not cap else 1):
-                z, st, _, _ = t.tiles_create_zvals(tiles, iters)
-                for i in range(0, len(tiles), 3 if rep else 1):
-                    if i not in want:
-                        want[i] = orc.tile_create_zvals(tiles[i][0], tiles[i][1], iters)
-                    assert_bit_equal(z[i], want[i][0], f"tile {tiles[i]} run {rep} undo cap {cap or 'default'}")
-                    assert bytes(st[i]) == bytes(want[i][1])
-            assert t.tile_erosion_fallbacks() == 0
-        finally:
-            t.close()
-
-
 @pytest.mark.parametrize("env", [{"TERRA_GRAPHS": "0"}, {"TERRA_ERO_CK": "1:16", "TERRA_ERO_NEAR": "4"}, {"TERRA_ERO_CK": "40:0", "TERRA_ERO_LEAD": "0"}, {"TERRA_ERO_BATCH": "1", "TERRA_ERO_LEAD": "1"},
-                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SHADOW_CHAIN": "1", "TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}])
+                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}])
 def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
     """the environment knobs of DESIGN.md section 5 choose schedules, launch forms and cross-check kernels, never values: a whole-map erosion with re-traces, an eroded tile
     batch and its mesh shadows under each of them, bit for bit against the oracle (the knobs are read when a context is created)"""

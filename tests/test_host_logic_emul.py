@@ -177,10 +177,6 @@ def test_gen_grid_minmax(pkg, emul, orc, mode, n):
     pc.case_gen_grid_minmax(pkg, emul, orc, mode, n)
 
 
-def test_build_arrays_ahead_of_the_eval_call(pkg, emul, orc):
-    pc.case_build_arrays_ahead(pkg, emul, orc)
-
-
 def test_ground_mesh_and_point_queries(pkg, emul, orc):
     pc.case_ground_mesh_and_point_queries(pkg, emul, orc)
 

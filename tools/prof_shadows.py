@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mesh shadows of the 64x64 tile batch: time of terra_tiles_mesh_shadows_dev.  usage: prof_shadows.py [reps=5]   (TERRA_SHADOW_CHAIN=0/1 selects per-level launches / one chained launch)"""
+"""Mesh shadows of the 64x64 tile batch: time of terra_tiles_mesh_shadows_dev.  usage: prof_shadows.py [reps=5]"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
