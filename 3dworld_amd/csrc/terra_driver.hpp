@@ -774,7 +774,13 @@ template<class BE> struct terra_engine {
 		}
 		else {
 			bool const sparse = (flags & TERRA_ERODE_MINZ_IS_MIN) != 0;
-			if (speculative_erosion(g, ec, num_iters, sparse, d_min)) return; // sparse clamp already applied to every written cell
+			// a few droplets on a big map: lean traces on the grid + one round per conflicted droplet (sparse_erosion); whatever it leaves -- everything, when it is not
+			// tried -- goes through the multi-version scheduler, which then clamps the whole grid (its record of written cells starts where it starts)
+			uint32_t first = 0;
+			if (sparse_wanted(ec, num_iters)) {
+				if (sparse_erosion(g, ec, num_iters, sparse, d_min, first)) return; // complete, sparse clamp applied
+			}
+			if (first < num_iters && speculative_erosion(g, ec, num_iters, sparse && first == 0, d_min, first)) return; // sparse clamp already applied to every written cell
 		}
 		// remove padding and clamp to min_zval (src/erosion.cpp:158-162): in place, so only the clamp remains
 		size_t const n = (size_t)xsize*ysize;
@@ -785,6 +791,91 @@ template<class BE> struct terra_engine {
 		});
 	}
 
+	// ---- the sparse scheduler (terra_erosion.hpp: "sparse regime").  Tried when the expected number of conflicting droplet pairs is small: droplets are ~uniform over the map and
+	// two of them meet when their footprints (some tens of 8x8 blocks each) share a block -- measured ~1 pair in 5*10^5 at 1000 droplets on 16384^2, i.e. pairs*8.4/blocks;
+	// with N^2 <= 2*blocks that is at most ~8 expected conflicts, each one round (a re-trace, a check, a commit).  TERRA_ERO_SPARSE=0 / 1 (read per call): never / always try
+	// it (tests); TERRA_ERO_SPARSE_RETRACES: re-traces before it gives up (default 8).  Results never depend on either.
+	static constexpr uint32_t SPARSE_MAX_DROPLETS = 8192, SPARSE_MAX_RETRACES = 8;
+	bool sparse_wanted(erosion_consts_t const &ec, uint32_t num_iters) const {
+		if (num_iters > SPARSE_MAX_DROPLETS) return false;
+		if (char const *sp = getenv("TERRA_ERO_SPARSE")) {if (sp[0] == '0') return false; if (sp[0] == '1') return true;}
+		uint64_t const nblocks = (uint64_t)(((uint32_t)ec.NX >> 3) + 1)*(((uint32_t)ec.NY >> 3) + 1);
+		return (uint64_t)num_iters*num_iters <= 2*nblocks;
+	}
+	// true: all droplets are committed and the clamp is applied (sparsely).  false: droplets [0, first) are on the grid, the caller continues from `first` with the
+	// general scheduler (and clamps the whole grid) -- first == num_iters: only the clamp is left.
+	bool sparse_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t N, bool record_touched, float const *d_min, uint32_t &first) {
+		sparse_buffers_t sb{};
+		sb.grid = g; sb.ec = ec; sb.N = N;
+		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB);
+		sb.nbx = ((uint32_t)ec.NX >> 3) + 1; sb.nby = ((uint32_t)ec.NY >> 3) + 1;
+		sb.max_retraces = SPARSE_MAX_RETRACES;
+		if (char const *mr = getenv("TERRA_ERO_SPARSE_RETRACES")) {int const v = atoi(mr); if (v >= 0) sb.max_retraces = (uint32_t)v;}
+		size_t const nblocks = (size_t)sb.nbx*sb.nby;
+		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)N*1024u + 65536u, 64u << 20) : 0u;
+		size_t off = 0;
+		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
+		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2];
+		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)N*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)N*sb.maxb*8); o_bl[b] = carve((size_t)N*sb.maxb*4); o_bc[b] = carve((size_t)N*4);}
+		size_t const o_slot = carve((size_t)N*4*4), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
+		uint8_t *base = scratch<uint8_t>(s_spec, off); // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
+		for (int b = 0; b < 2; ++b) {
+			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]);
+			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]);
+		}
+		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
+		sb.cur = slot_arrays; sb.state = slot_arrays + N; sb.nsteps = slot_arrays + 2*(size_t)N; sb.nan = slot_arrays + 3*(size_t)N;
+		sb.ctl = (sparse_ctl_t *)(base + o_ctl);
+		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
+		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks); // [head | dirty_min] of the general scheduler, all SPEC_NIL between runs: wmin borrows the second half
+		if (spec_blocks_clean != blk_arrays || spec_blocks_n != nblocks) {be.fill32(blk_arrays, SPEC_NIL, 2*nblocks);}
+		spec_blocks_clean = nullptr;
+		sb.wmin = blk_arrays + nblocks;
+		sparse_buffers_t const s = sb;
+		auto rounds = [&](bool with_first) { // [init, trace everything, check, commit,] then twice: re-trace the lowest conflicted droplet, check, commit -- one hipGraph each way
+			struct {sparse_buffers_t s; uint32_t with_first; uint32_t tag;} gkey;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.with_first = with_first ? 1u : 0u; gkey.tag = 0x53505253u;
+			if (be.graph_replay(&gkey, sizeof(gkey))) return;
+			bool const cap = be.graph_begin();
+			try {
+				if (with_first) {
+					be.launch(N, [=] TERRA_LAMBDA (size_t i) {
+						s.cur[i] = 0; s.state[i] = SPARSE_TRACED; s.blk_cnt[0][i] = 0; s.blk_cnt[1][i] = 0;
+						if (i == 0) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}
+					});
+					be.launch_waves_lean(N, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
+					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_body(s, (uint32_t)i);});
+					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
+				}
+				for (int r = 0; r < 2; ++r) {
+					be.launch_waves_lean(1, [=] TERRA_LAMBDA (size_t, lean_scratch_t const &ws) {sparse_retrace_wave(s, ws);});
+					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_body(s, (uint32_t)i);});
+					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
+				}
+			} catch (...) {be.graph_abort(); throw;}
+			if (cap) {be.graph_end(&gkey, sizeof(gkey));}
+		};
+		sparse_ctl_t hc{};
+		rounds(true);
+		be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of a run with at most two conflicted droplets
+		uint32_t batches = 1;
+		while (hc.c < N && !hc.bail) { // after the last commit: [base, c) is on the grid, c is conflicted
+			if (batches++ > N) throw std::runtime_error("sparse erosion: no progress");
+			rounds(false);
+			be.d2h(&hc, sb.ctl, sizeof(hc));
+		}
+		bool const complete = (hc.c >= N) && !hc.bail;
+		first = complete ? N : (hc.bail ? hc.base : hc.c);
+		be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_body(s, (uint32_t)i);}); // wmin[] all SPEC_NIL again (head[] was never touched)
+		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
+		report.rounds = 1 + hc.retraces; report.traces = N + hc.retraces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
+		report.windows = 1; report.sparse_droplets = first; report.sparse_retraces = hc.retraces;
+		if (!complete || !record_touched || hc.touched > sb.touched_cap) return false; // (record overflowed: the caller clamps the whole grid)
+		uint32_t const *tch = sb.touched; float const mz = ec.min_zval; grid_view_t const gg = g;
+		be.launch(hc.touched, [=] TERRA_LAMBDA (size_t i) {touched_clamp_body(gg, tch, (uint32_t)i, d_min ? *d_min : mz);});
+		return true;
+	}
+
 	// Defaults from the measurements in profiles/r02_erosion_near_far_sweep.txt: the 512 droplets next in line for the commit trace to the end, the rest of the ring
 	// advances 128 steps per round (13 % faster on 4096^2 with 10^6 droplets than "everybody to the end", 37 % on 1024^2 with 30 000, neutral on sparse maps).
 	// Sliding ring of W in-flight droplets (terra_erosion.hpp).  One round = every unfinished droplet advances by at most `slice` steps,
@@ -792,7 +883,8 @@ template<class BE> struct terra_engine {
 	// slots are handed to the next droplets.  While droplets are waiting for a slot the traces are sliced, so that one long path (they run
 	// to thousands of steps at ~1 us each) does not hold up a whole window; once everything is admitted the remaining traces run to the end.
 	// returns true when the final clamp was applied sparsely (record_touched and the record did not overflow)
-	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched, float const *d_min = nullptr) {
+	// first: droplets [0, first) are already on the grid (committed by sparse_erosion); the run covers [first, num_iters) and adds its counts to `report`
+	bool speculative_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t num_iters, bool record_touched, float const *d_min = nullptr, uint32_t first = 0) {
 		spec_buffers_t sb{};
 		sb.grid = g; sb.ec = ec; sb.num_iters = num_iters;
 		// ring slots: more droplets in flight = more parallel work and fewer rounds, but also more speculation on stale cells and longer writer lists.  Measured
@@ -803,7 +895,7 @@ template<class BE> struct terra_engine {
 		uint64_t const ncells = (uint64_t)ec.NX*ec.NY;
 		uint32_t auto_w = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ncells >> 13, 2048), 32768);
 		if (ncells >= (1ull << 24)) {auto_w = std::max<uint32_t>(auto_w, 4096);}
-		uint32_t W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters);
+		uint32_t W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters - first);
 		sb.near_count = spec_cfg.near_count;
 		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = SPEC_CK_MAX;
 		sb.live_partial = 1u;
@@ -877,13 +969,14 @@ template<class BE> struct terra_engine {
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
 		for (int b = 0; b < 2; ++b) {be.fill32(sb.ck_cnt[b], 0, W); be.fill32(sb.undo_n[b], 0, W);}
 		be.fill32(sb.node_blk, SPEC_NIL, (size_t)W*sb.maxb);
-		be.launch(W, [=] TERRA_LAMBDA (size_t i) { // the first W droplets take the slots (num_iters >= W)
-			s.it[i] = (uint32_t)i; s.phase[i] = SPEC_FRESH;
-			if (i == 0) {spec_ctl_t c{}; c.base = 0; c.new_base = s.W; c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; *s.ctl = c;}
+		be.launch(W, [=] TERRA_LAMBDA (size_t i) { // the first W droplets take the slots (num_iters - first >= W); droplet `it` lives in slot it % W
+			uint32_t const it = first + (uint32_t)i, slot = it % s.W;
+			s.it[slot] = it; s.phase[slot] = SPEC_FRESH;
+			if (i == 0) {spec_ctl_t c{}; c.base = first; c.new_base = first + s.W; c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; *s.ctl = c;}
 		});
-		report.windows = (num_iters + W - 1)/W;
+		report.windows = (num_iters - first + W - 1)/W;
 		uint32_t const slice = std::max<uint32_t>(spec_cfg.slice_steps, 1);
-		uint32_t host_base = 0, launched = 0;
+		uint32_t host_base = first, launched = 0;
 		spec_ctl_t hc{};
 		// One round = 8 dependent launches (the trace waves, five bookkeeping passes, the commit / checkpoint-resume waves, the end-of-round bookkeeping), captured once into a hipGraph and
 		// replayed.  Nothing in a round needs a host decision -- the step budget, the commit point and the pause behind a failed droplet are all taken from the
@@ -950,8 +1043,8 @@ template<class BE> struct terra_engine {
 		be.launch((size_t)W*sb.maxb, [=] TERRA_LAMBDA (size_t i) {spec_unlink_body(s, (uint32_t)i);}); // leave head[] all-NIL (dirty_min[] already is)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		be.d2h(&hc, sb.ctl, sizeof(hc));
-		report.rounds = hc.rounds; report.retraces_same = hc.retraces_same; report.checkpoint_resumes = hc.ck_resumes; report.checkpoint_steps_saved = hc.ck_steps_saved;
-		report.traces = hc.traces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
+		report.rounds += hc.rounds; report.retraces_same = hc.retraces_same; report.checkpoint_resumes = hc.ck_resumes; report.checkpoint_steps_saved = hc.ck_steps_saved;
+		report.traces += hc.traces; report.traced_steps += hc.traced_steps; report.steps += hc.steps; report.nan_droplets += hc.nan_droplets; // (+=: sparse_erosion may have committed a prefix)
 		report.window_shifts = hc.n_shift;
 		report.critical_steps = hc.crit_steps; report.critical_shifts = hc.crit_shifts;
 		report.clk_wave = hc.clk_wave; report.clk_init = hc.clk_init; report.clk_shift = hc.clk_shift; report.clk_tail = hc.clk_tail; report.clk_critical = hc.clk_crit;

@@ -1434,6 +1434,237 @@ TERRA_HD void direct_droplet_wave(grid_view_t const &g, erosion_consts_t const &
 	if (TERRA_LANE0 && out_steps_nan) {out_steps_nan[0] = r.steps; out_steps_nan[1] = (uint32_t)r.nan_seen;}
 }
 
+// ================================================================== sparse regime: a few droplets on a big map (the headline: 1000 droplets on 16384^2)
+// Two droplets of such a run almost never meet (one pair in ~5*10^5), so nearly every trace made on the ORIGINAL grid is already the serial loop's trace.  The machinery above
+// pays for the dense regime on every wave -- candidate lists and per-cell source words (13 KB of LDS), version look-ups, checkpoints, an undo log: 22.7 KB of LDS and 264
+// registers per droplet wave, which is what another heightmap's noise kernel has to share its CU with.  The sparse scheduler needs none of it:
+//   trace    every droplet, one LEAN wave each, reads the grid only and writes to private pages (same page / mask / block-list format as a version above): 9.8 KB of LDS;
+//            at its end the wave lowers wmin[b] to its droplet number for every block b it wrote;
+//   check    droplet j is CONFLICTED when a block of its footprint was written by a lower droplet (wmin[b] < j); c = the lowest conflicted droplet;
+//   commit   droplets [base, c) are exact -- by induction: no lower droplet wrote anything they read, and marks are never taken back, so that holds for committed droplets'
+//            writes too -- and their written blocks are pairwise disjoint: their pages go to the grid in parallel;
+//   re-trace droplet c is now the lowest uncommitted one: ONE wave traces it again on the grid as it stands (exact by definition; it is FINAL and never checked again),
+//            marks what it wrote, and check / commit run again from base = c.
+// One round per conflicted droplet: fine for a handful (the headline has one), hopeless for a dense run -- after SPARSE_MAX_CONFLICTS re-traces, or when a lean trace
+// overflows its block list, the host hands the rest [base, N) to the multi-version scheduler above, which starts from the grid as committed so far.
+struct lean_shared_t { // per-wave LDS of a lean trace, beside its window (4 KB) and dirty bytes (1 KB)
+	uint32_t flags, special;                 // SPEC_F_*; bit i: block i under the window holds cells this trace has written back to its pages
+	uint16_t blk_own[32];                    // per block under the window: its entry in this trace's block list (SPEC_OWN_NONE: not in the footprint)
+	uint32_t map_keys[SPEC_MAP_SLOTS];       // block id (SPEC_NIL: free)
+	uint8_t  map_ent[SPEC_MAP_SLOTS];
+	unsigned long long masks[SPEC_MAXB];     // per entry: cells written back
+};
+struct lean_scratch_t {float *win; uint8_t *dirty; lean_shared_t *sh;};
+
+enum {SPARSE_TRACED = 0, SPARSE_FINAL = 1, SPARSE_COMMITTED = 2, SPARSE_FAILED = 3};
+struct sparse_ctl_t {
+	uint32_t base;        // droplets below are committed
+	uint32_t c;           // lowest conflicted droplet >= base as of the last check (N: none -- after the commit that follows, everything is on the grid)
+	uint32_t nconf;       // conflicted droplets found by the last check
+	uint32_t retraces;    // re-traces made so far
+	uint32_t bail;        // the re-trace pass gave up: too many conflicts, or droplet `base` overflowed its block list (the host continues with the general scheduler from `base`)
+	uint32_t touched;     // cells recorded for the sparse clamp
+	uint32_t nan_droplets, pad_;
+	unsigned long long steps, traced_steps;
+};
+struct sparse_buffers_t {
+	grid_view_t grid;
+	erosion_consts_t ec;
+	uint32_t N, maxb, nbx, nby, max_retraces;
+	float *page_vals[2]; unsigned long long *page_mask[2]; uint32_t *blk_list[2], *blk_cnt[2]; // [N][maxb][64], [N][maxb], [N][maxb], [N]: a droplet's trace, and its re-trace in the other buffer
+	uint32_t *cur, *state, *nsteps, *nan; // [N]
+	uint32_t *wmin;       // [nbx*nby] lowest droplet that wrote the block in any of its traces (SPEC_NIL: nobody); reset through the block lists at the end of the run
+	uint32_t *touched; uint32_t touched_cap;
+	sparse_ctl_t *ctl;
+};
+
+// backing store of a lean trace: reads = the grid (+ what this trace wrote back earlier), writes = private pages
+struct lean_back_t {
+	grid_view_t g; lean_shared_t *sh;
+	float *my_pages; unsigned long long *my_masks; uint32_t *my_blks;
+	uint32_t nblk, maxb, nbx, nby;
+	int NXm1, NYm1;
+	bool blk_overflow;
+	int wbx0, wbz0;
+	uint32_t special = 0;
+	int lx0 = INT_MIN, lx1 = INT_MIN, lz0 = INT_MIN, lz1 = INT_MIN;
+	static constexpr int wnb = (EW >> 3) + 1;
+
+	TERRA_HD uint32_t map_find(uint32_t b) const {
+		for (uint32_t h = spec_back_t::map_hash(b), n = 0; n < SPEC_MAP_SLOTS; ++n, h = (h + 1) & (SPEC_MAP_SLOTS - 1)) {
+			uint32_t const k = sh->map_keys[h];
+			if (k == b) return sh->map_ent[h];
+			if (k == SPEC_NIL) return SPEC_NIL;
+		}
+		return SPEC_NIL;
+	}
+	TERRA_HD void init(sparse_buffers_t const &sb, uint32_t iter, uint32_t buf, lean_shared_t *sh_) {
+		g = sb.grid; sh = sh_; maxb = sb.maxb; nbx = sb.nbx; nby = sb.nby; NXm1 = sb.ec.NX - 1; NYm1 = sb.ec.NY - 1;
+		my_pages = sb.page_vals[buf] + (size_t)iter*sb.maxb*SPEC_PAGE; my_masks = sb.page_mask[buf] + (size_t)iter*sb.maxb; my_blks = sb.blk_list[buf] + (size_t)iter*sb.maxb;
+		nblk = 0; blk_overflow = false; wbx0 = wbz0 = 0; special = 0;
+		if (TERRA_LANE0) {sh->flags = 0; sh->special = 0;}
+		TERRA_LANES(e, SPEC_MAXB) {sh->masks[e] = 0ull;}
+		TERRA_LANES(h, SPEC_MAP_SLOTS) {sh->map_keys[h] = SPEC_NIL;}
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD bool failed() const {return blk_overflow || (sh->flags & SPEC_F_LOG_OVERFLOW) != 0;}
+	TERRA_HD void touch_block(uint32_t b) {
+		if (map_find(b) != SPEC_NIL) return;
+		if (TERRA_UNLIKELY(nblk >= maxb)) {blk_overflow = true; return;}
+		my_blks[nblk] = b; // (every lane does the same insert in lock step, as in spec_back_t::touch_block)
+		uint32_t h = spec_back_t::map_hash(b);
+		while (sh->map_keys[h] != SPEC_NIL) {h = (h + 1) & (SPEC_MAP_SLOTS - 1);}
+		sh->map_keys[h] = b; sh->map_ent[h] = (uint8_t)nblk;
+		++nblk;
+		TERRA_WAVE_SYNC();
+	}
+	TERRA_HD void note_write() {}
+	TERRA_HD void note_written_rect(int, int) {}
+	TERRA_HD void note_far_read(int X, int Z) {nblk = wave_uniform(nblk); touch_block((uint32_t)(Z >> 3)*nbx + (uint32_t)(X >> 3));}
+	TERRA_HD bool begin_step(int xi, int zi) { // the step's 4x4 brush box covers every read and write of the step
+		int const x0 = clampi(xi-1, NXm1) >> 3, x1 = clampi(xi+2, NXm1) >> 3, z0 = clampi(zi-1, NYm1) >> 3, z1 = clampi(zi+2, NYm1) >> 3;
+		lx0 = wave_uniform(lx0); lx1 = wave_uniform(lx1); lz0 = wave_uniform(lz0); lz1 = wave_uniform(lz1);
+		if (x0 == lx0 && x1 == lx1 && z0 == lz0 && z1 == lz1) {return !blk_overflow;}
+		lx0 = x0; lx1 = x1; lz0 = z0; lz1 = z1;
+		nblk = wave_uniform(nblk);
+		touch_block((uint32_t)z0*nbx + x0);
+		if (x1 != x0) {touch_block((uint32_t)z0*nbx + x1);}
+		if (z1 != z0) {
+			touch_block((uint32_t)z1*nbx + x0);
+			if (x1 != x0) {touch_block((uint32_t)z1*nbx + x1);}
+		}
+		return !failed();
+	}
+	// the only cells of a new window that do not come from the grid: the ones this trace wrote back to its own pages when they left an earlier window
+	TERRA_HD void prepare_window(int wx0, int wz0) {
+		if (TERRA_LANE0) {sh->special = 0;}
+		wbx0 = wx0 >> 3; wbz0 = wz0 >> 3;
+		TERRA_LANES(i, wnb*wnb) {
+			uint32_t const bx = (uint32_t)(wbx0 + i % wnb), bz = (uint32_t)(wbz0 + i / wnb);
+			uint32_t const oe = (bx < nbx && bz < nby) ? map_find(bz*nbx + bx) : SPEC_NIL;
+			sh->blk_own[i] = (uint16_t)((oe == SPEC_NIL) ? SPEC_OWN_NONE : oe);
+			if (oe != SPEC_NIL && sh->masks[oe] != 0ull) {TERRA_ATOMIC_OR(&sh->special, 1u << i);}
+		}
+		TERRA_WAVE_SYNC();
+		special = wave_uniform(sh->special);
+	}
+	TERRA_HD float base(int X, int Z) const {return *g.at(X, Z);}
+	TERRA_HD float lookup(int X, int Z, float b) const { // (a read outside the window: only after a NaN position)
+		uint32_t const e = map_find((uint32_t)(Z >> 3)*nbx + (uint32_t)(X >> 3)), c = spec_back_t::page_cell(X, Z);
+		if (e != SPEC_NIL && ((sh->masks[e] >> c) & 1ull)) {return TERRA_L2_LOAD(&my_pages[(size_t)e*SPEC_PAGE + c]);}
+		return b;
+	}
+	typedef grid_back_t::src_t src_t;
+	TERRA_HD src_t src_snapshot() const {return src_t{g};}
+	TERRA_HD uint32_t special_blocks() const {return special;}
+	TERRA_HD void special_cell(uint32_t bi, uint32_t c, int &X, int &Z) const {X = ((wbx0 + (int)(bi % (uint32_t)wnb)) << 3) + (int)(c & 7u); Z = ((wbz0 + (int)(bi / (uint32_t)wnb)) << 3) + (int)(c >> 3);}
+	TERRA_HD float special_value(uint32_t bi, uint32_t c, int, int, float v) const {
+		uint32_t const oe = sh->blk_own[bi];
+		if (oe != SPEC_OWN_NONE && ((sh->masks[oe] >> c) & 1ull)) {return TERRA_L2_LOAD(&my_pages[(size_t)oe*SPEC_PAGE + c]);} // written earlier in THIS kernel by other lanes: not through L1
+		return v;
+	}
+	TERRA_HD void store(int X, int Z, float val) { // lanes in parallel, distinct cells
+		uint32_t const e = map_find((uint32_t)(Z >> 3)*nbx + (uint32_t)(X >> 3)), c = spec_back_t::page_cell(X, Z);
+		if (TERRA_UNLIKELY(e == SPEC_NIL)) {TERRA_ATOMIC_OR(&sh->flags, (uint32_t)SPEC_F_LOG_OVERFLOW); return;} // every written cell lies in a recorded brush box: never happens
+		my_pages[(size_t)e*SPEC_PAGE + c] = val;
+		TERRA_ATOMIC_OR(&sh->masks[e], 1ull << c);
+	}
+};
+
+// one lean trace of droplet `iter` into buffer `buf` (on the grid as it stands); marks what it wrote
+TERRA_HD void sparse_trace_droplet(sparse_buffers_t const &sb, uint32_t iter, uint32_t buf, uint32_t new_state, lean_scratch_t const &ws) {
+	window_mem_t<lean_back_t> mem;
+	mem.init(ws.win, ws.dirty, sb.ec.NX, sb.ec.NY);
+	mem.lead_mode = sb.ec.lead_mode;
+	mem.back.init(sb, iter, buf, ws.sh);
+	droplet_state_t d;
+	if (droplet_start((int)iter, mem, sb.ec, d)) {droplet_run_fast(d, mem, sb.ec, DROPLET_NO_BUDGET);}
+	mem.finish();
+	bool const failed = mem.back.failed();
+	uint32_t const n = mem.back.nblk;
+	TERRA_LANES(e, n) {
+		unsigned long long const m = ws.sh->masks[e];
+		uint32_t const b = mem.back.my_blks[e] & SPEC_BLK_ID;
+		mem.back.my_masks[e] = m;
+		mem.back.my_blks[e] = m ? (b | SPEC_BLK_WRITTEN) : b;
+		if (m && !failed) {TERRA_ATOMIC_MIN(&sb.wmin[b], iter);}
+	}
+	if (TERRA_LANE0) {
+		sb.blk_cnt[buf][iter] = n; sb.cur[iter] = buf;
+		sb.nsteps[iter] = d.numMoves; sb.nan[iter] = (uint32_t)d.nan_seen;
+		sb.state[iter] = failed ? (uint32_t)SPARSE_FAILED : new_state;
+		TERRA_ATOMIC_ADD(&sb.ctl->traced_steps, (unsigned long long)d.numMoves);
+	}
+	TERRA_WAVE_SYNC();
+}
+// round 0: every droplet
+TERRA_HD void sparse_trace_wave(sparse_buffers_t const &sb, uint32_t iter, lean_scratch_t const &ws) {sparse_trace_droplet(sb, iter, 0u, SPARSE_TRACED, ws);}
+// a later round (ONE wave): everything below the lowest conflicted droplet is committed; that droplet is traced again on the grid as it stands now
+TERRA_HD void sparse_retrace_wave(sparse_buffers_t const &sb, lean_scratch_t const &ws) {
+	sparse_ctl_t &c = *sb.ctl;
+	uint32_t const base = wave_uniform(c.c), bail = wave_uniform(c.bail), done = wave_uniform(c.retraces), pending = wave_uniform(c.nconf);
+	TERRA_WAVE_SYNC(); // (every lane has read the control block)
+	if (bail) return;
+	if (TERRA_LANE0) {c.base = base; c.c = sb.N; c.nconf = 0;}
+	if (base >= sb.N) return;
+	// one round per conflicted droplet: when more of them are waiting than the run may still re-trace, the multi-version scheduler is the better tool -- now, not after the last allowed round
+	if (wave_uniform(sb.state[base]) == (uint32_t)SPARSE_FAILED || (uint64_t)done + pending > sb.max_retraces) {if (TERRA_LANE0) {c.bail = 1;} return;}
+	if (TERRA_LANE0) {c.retraces = done + 1;}
+	sparse_trace_droplet(sb, base, 1u - wave_uniform(sb.cur[base]), SPARSE_FINAL, ws);
+	if (wave_uniform(sb.state[base]) == (uint32_t)SPARSE_FAILED) {if (TERRA_LANE0) {c.bail = 1;}} // (its footprint grew past the block list on the changed grid)
+}
+// one thread per droplet: is it conflicted?
+TERRA_HD void sparse_check_body(sparse_buffers_t const &sb, uint32_t j) {
+	sparse_ctl_t &c = *sb.ctl;
+	if (c.bail || j < c.base) return;
+	uint32_t const st = sb.state[j];
+	if (st == SPARSE_COMMITTED || st == SPARSE_FINAL) return;
+	bool hit = (st == SPARSE_FAILED);
+	if (!hit) {
+		uint32_t const buf = sb.cur[j], n = sb.blk_cnt[buf][j];
+		uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
+		for (uint32_t e = 0; e < n; ++e) {hit = hit || (sb.wmin[bl[e] & SPEC_BLK_ID] < j);}
+	}
+	if (hit) {TERRA_ATOMIC_MIN(&c.c, j); TERRA_ATOMIC_ADD(&c.nconf, 1u);}
+}
+// one wave per droplet: the droplets [base, c) are exact and write disjoint blocks -- their pages go to the grid
+TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t j) {
+	sparse_ctl_t &c = *sb.ctl;
+	if (c.bail || j < c.base || j >= c.c || sb.state[j] == SPARSE_COMMITTED) return;
+	uint32_t const buf = sb.cur[j], n = sb.blk_cnt[buf][j];
+	size_t const pbase = (size_t)j*sb.maxb;
+	for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+		TERRA_EACH_LANE(l) {
+			uint32_t const e = e0 + (uint32_t)l;
+			unsigned long long m = 0; uint32_t b = 0;
+			if (e < n) {uint32_t const ent = sb.blk_list[buf][pbase + e]; if (ent & SPEC_BLK_WRITTEN) {b = ent & SPEC_BLK_ID; m = sb.page_mask[buf][pbase + e];}}
+			uint32_t k = wave_reserve(&c.touched, sb.touched ? (uint32_t)__builtin_popcountll(m) : 0u);
+			uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
+			float const *page = sb.page_vals[buf] + (pbase + e)*SPEC_PAGE;
+			for (; m; m &= m - 1, ++k) {
+				uint32_t const cc = (uint32_t)__builtin_ctzll(m);
+				uint32_t const X = (bx << 3) + (cc & 7u), Z = (bz << 3) + (cc >> 3);
+				*sb.grid.at((int)X, (int)Z) = page[cc];
+				if (sb.touched && k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
+			}
+		}
+	}
+	TERRA_WAVE_SYNC();
+	if (TERRA_LANE0) {
+		sb.state[j] = SPARSE_COMMITTED;
+		TERRA_ATOMIC_ADD(&c.steps, (unsigned long long)sb.nsteps[j]);
+		if (sb.nan[j]) {TERRA_ATOMIC_ADD(&c.nan_droplets, 1u);}
+	}
+}
+// end of the run (also before the general scheduler takes over): every mark is reset through the block lists, both traces of a re-traced droplet
+TERRA_HD void sparse_unmark_body(sparse_buffers_t const &sb, uint32_t j) {
+	for (uint32_t buf = 0; buf < 2; ++buf) {
+		uint32_t const n = sb.blk_cnt[buf][j];
+		uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
+		for (uint32_t e = 0; e < n; ++e) {if (bl[e] & SPEC_BLK_WRITTEN) {sb.wmin[bl[e] & SPEC_BLK_ID] = SPEC_NIL;}}
+	}
+}
+
 // ---- per-logical-thread bodies of the bookkeeping kernels (one round = clear, trace, post, flip, link, mark, scan, flush, admit, advance)
 
 TERRA_HD void spec_undirty_body(spec_buffers_t const &sb, uint32_t i) {

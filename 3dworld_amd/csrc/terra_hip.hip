@@ -178,6 +178,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 
+	template<class F> void launch_waves_lean(size_t n, F f) { // one 64-lane workgroup per item with the lean droplet scratch (terra_kernels.hpp: k_waves_lean)
+		if (n == 0) return;
+		use();
+		if (n > 0x7FFFFFFFull) throw std::invalid_argument("launch_waves: grid too large");
+		hipLaunchKernelGGL(terra::k_waves_lean<F>, dim3((unsigned)n), dim3(64), 0, stream, f);
+		TERRA_HIP_CHECK(hipGetLastError());
+	}
+
 	template<class F> void launch_waves_nolds(size_t n, F f) { // one 64-lane workgroup per item, no LDS scratch (does not compete with LDS-heavy kernels for a CU)
 		if (n == 0) return;
 		use();

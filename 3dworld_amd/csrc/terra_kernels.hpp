@@ -29,6 +29,17 @@ template<class F> __global__ __launch_bounds__(64) void k_waves(F f, unsigned fi
 
 template<class F> __global__ __launch_bounds__(64) void k_waves_nolds(F f) {f((size_t)blockIdx.x);}
 
+// the same for the lean traces of the sparse erosion scheduler (terra_erosion.hpp: lean_back_t): window + dirty bytes + 4.6 KB of footprint bookkeeping = 9.8 KB of LDS, and
+// at most 128 registers (four waves per SIMD requested) -- beside a k_sine_grid block of another heightmap (29.7 KB, 120 registers per wave) a SIMD then holds three of that
+// kernel's waves and one of these, and a CU four of its blocks and four of these; the general trace wave (22.7 KB, 260 registers) leaves room for two and two
+template<class F> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_waves_lean(F f) {
+	__shared__ __attribute__((aligned(16))) float win[EW*EW];
+	__shared__ uint8_t dirty[EW*EW];
+	__shared__ lean_shared_t sh;
+	lean_scratch_t const ws{win, dirty, &sh};
+	f((size_t)blockIdx.x, ws);
+}
+
 // fold a thread's (min,max) of order-preserving uints over its wave and publish with two atomics per wave
 __device__ __forceinline__ void wave_minmax_publish(uint32_t lo, uint32_t hi, uint32_t *mm) {
 #pragma unroll

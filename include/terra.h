@@ -98,6 +98,9 @@ typedef struct terra_erosion_report {
 	uint64_t clk_shift_flush, clk_shift_prep, clk_shift_load; /* parts of clk_shift: write-back of the cells that leave / block flags (candidate versions per block); clk_shift_load is 0 since the grid loads are in flight during the look-ups and are not timed apart: the rest of clk_shift is loads + look-ups + filling the window */
 	uint64_t crit_clk_flush, crit_clk_load, crit_clk_prep; /* the parts of crit_clk_shift */
 	uint64_t crit_clk_shift, crit_clk_edge, crit_steps_own; /* of each round's longest wave body: ticks in window moves, ticks before + after its steps, its steps (multiple of 4) */
+	/* the sparse scheduler (few droplets on a big map: lean traces on the grid itself, one round per conflicting droplet): droplets it committed (0: not tried; `droplets`: the
+	 * whole run -- anything less: the multi-version scheduler did the rest) and the re-traces that took */
+	uint64_t sparse_droplets, sparse_retraces;
 } terra_erosion_report;
 
 /* The globals tile_t::create_texture and tile_t::update_terrain_params read beyond terra_config; the defaults are the reference's. */

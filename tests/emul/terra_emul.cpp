@@ -75,6 +75,12 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 		for (size_t i = 0; i < n; ++i) f(i, ws);
 	}
 
+	template<class F> void launch_waves_lean(size_t n, F f) {
+		std::vector<float> win(terra::EW*terra::EW); std::vector<uint8_t> dirty(terra::EW*terra::EW); terra::lean_shared_t sh;
+		terra::lean_scratch_t const ws{win.data(), dirty.data(), &sh};
+		for (size_t i = 0; i < n; ++i) f(i, ws);
+	}
+
 	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *, uint32_t const *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,

@@ -153,6 +153,29 @@ def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_ca
     return r, stats
 
 
+def case_erosion_sparse(pkg, t, orc, n, iters, force="1", retraces=None, flags=0):
+    """the sparse scheduler (lean traces on the grid itself, one round per conflicting droplet: csrc/terra_erosion.hpp "sparse regime"): forced on (TERRA_ERO_SPARSE=1) on
+    maps where droplets DO meet, with a re-trace allowance that makes it finish alone (every conflict resolved by a re-trace on the grid), give up at once (0), or give up
+    part-way -- the multi-version scheduler then continues from the committed prefix.  Always the serial result, bit for bit, and the step counts of both parts add up."""
+    import os
+    old = {k: os.environ.get(k) for k in ("TERRA_ERO_SPARSE", "TERRA_ERO_SPARSE_RETRACES")}
+    try:
+        for k, v in (("TERRA_ERO_SPARSE", force), ("TERRA_ERO_SPARSE_RETRACES", retraces)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        r, stats = case_erosion_vs_oracle(pkg, t, orc, n, iters, flags=flags)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert r.sparse_droplets <= iters and r.traces >= iters
+    return r, stats
+
+
 def case_erosion_context_reuse(pkg, t, orc):
     """one context, many runs: the scheduler keeps its block tables and log tables between runs (only the entries a run set are reset), so a
     sequence that changes grid size, ring size, block-list capacity, log capacity and droplet count exercises every re-use / re-init decision."""

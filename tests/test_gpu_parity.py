@@ -102,6 +102,16 @@ def test_tiles_from_heightmap_texture(pkg, gpu, orc):
     pc.case_tiles_from_heightmap(pkg, gpu, orc)
 
 
+@pytest.mark.parametrize("n,iters,retraces,flags", [(512, 400, 100000, 0), (384, 300, 100000, 2), (256, 500, 3, 0), (128, 120, 0, 2), (1024, 300, 2, 2), (2048, 2000, 40, 2), (1024, 60, None, 0)])
+def test_sparse_erosion_scheduler(pkg, gpu, orc, n, iters, retraces, flags):
+    """the lean trace kernel + check / commit / re-trace rounds of the sparse scheduler, forced onto maps where droplets meet"""
+    r, _ = pc.case_erosion_sparse(pkg, gpu, orc, n, iters, "1", retraces, flags)
+    if retraces == 100000:
+        assert r.sparse_droplets == iters and r.sparse_retraces > 0 and r.rounds == 1 + r.sparse_retraces
+    elif retraces is not None:
+        assert 0 < r.sparse_droplets < iters and r.sparse_retraces <= retraces
+
+
 def test_erosion_context_reuse(pkg, gpu, orc):
     pc.case_erosion_context_reuse(pkg, gpu, orc)
 
@@ -219,6 +229,7 @@ def test_bench_step_full_size_equals_oracle(pkg, gpu, orc):
     diff = z.view(np.uint32) != ref.view(np.uint32)
     assert not diff.any(), f"{int(diff.sum())} cells differ, first at {np.argwhere(diff)[:4].tolist()}"
     assert rep["droplets"] == droplets
+    assert rep["sparse_droplets"] == droplets, rep  # the timed configuration goes through the sparse scheduler alone (lean traces; its one conflicting pair is a re-trace round)
     print("erosion report", rep)
 
 
@@ -355,7 +366,7 @@ def test_multi_contexts_in_one_process(pkg, orc, ndev, big):
 
 
 @pytest.mark.parametrize("env", [{"TERRA_GRAPHS": "0"}, {"TERRA_ERO_CK": "1:16", "TERRA_ERO_NEAR": "4"}, {"TERRA_ERO_CK": "40:0", "TERRA_ERO_LEAD": "0"}, {"TERRA_ERO_BATCH": "1", "TERRA_ERO_LEAD": "1"},
-                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}])
+                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_SPARSE": "1", "TERRA_ERO_SPARSE_RETRACES": "12"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}])
 def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
     """the environment knobs of DESIGN.md section 5 choose schedules, launch forms and cross-check kernels, never values: a whole-map erosion with re-traces, an eroded tile
     batch and its mesh shadows under each of them, bit for bit against the oracle (the knobs are read when a context is created)"""

@@ -145,6 +145,24 @@ def test_tiles_from_heightmap_texture(pkg, emul, orc):
     pc.case_tiles_from_heightmap(pkg, emul, orc)
 
 
+@pytest.mark.parametrize("n,iters,retraces,flags", [(512, 400, 100000, 0), (384, 300, 100000, 2), (256, 500, 3, 0), (128, 120, 0, 2), (1024, 300, 2, 2), (1024, 60, None, 0)])
+def test_sparse_erosion_scheduler(pkg, emul, orc, n, iters, retraces, flags):
+    r, _ = pc.case_erosion_sparse(pkg, emul, orc, n, iters, "1", retraces, flags)
+    if retraces == 100000:
+        assert r.sparse_droplets == iters and r.sparse_retraces > 0 and r.rounds == 1 + r.sparse_retraces  # every conflict resolved by a re-trace on the grid
+    elif retraces is not None:
+        assert 0 < r.sparse_droplets < iters and r.sparse_retraces <= retraces                              # a committed prefix, the rest by the multi-version scheduler
+
+
+def test_sparse_erosion_is_chosen_by_density_and_can_be_switched_off(pkg, emul, orc):
+    r, _ = pc.case_erosion_sparse(pkg, emul, orc, 2048, 40, None)     # 40^2 <= 2 * 257^2 blocks: tried
+    assert r.sparse_droplets > 0
+    r, _ = pc.case_erosion_sparse(pkg, emul, orc, 2048, 40, "0")      # switched off
+    assert r.sparse_droplets == 0
+    r, _ = pc.case_erosion_sparse(pkg, emul, orc, 256, 300, None)     # dense: not tried
+    assert r.sparse_droplets == 0
+
+
 def test_erosion_context_reuse(pkg, emul, orc):
     pc.case_erosion_context_reuse(pkg, emul, orc)
 

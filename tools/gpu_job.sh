@@ -11,6 +11,8 @@
 #   gpu_job.sh native  <tag> [args]                  tools/bench_native.c and tools/bench_native_multi.c (--same-device) built and run
 #   gpu_job.sh timeline <tag> [bench.py args]        rocprofv3 kernel trace of the headline run with the driver's flags -> tools/timeline.py (who ran when, idle time, overlap)
 #   gpu_job.sh clock   <tag> <driver.py args>        GRBM_GUI_ACTIVE per dispatch: the clock a kernel actually ran at (cycles / duration)
+#   gpu_job.sh ab      <tag> <reps> "name|ENV=..|bench args" ...   alternating same-box A/B of the headline under environment / argument variants
+#   gpu_job.sh batch   <tag> "<subcommand> <args>" ...  several of the above in one gpurun call
 set -u
 CMD=${1:-check}; TAG=${2:-job}; shift; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -121,6 +123,22 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
 for k, (ns, cyc, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print(f"{k:50s} {n:4d} dispatches  avg {ns / n / 1e3:9.1f} us  GRBM_GUI_ACTIVE / duration = {cyc / ns:6.3f} GHz (per-XCD counter summed? divide by 8 if ~16-20)")
 PY
+	;;
+ab)
+	# gpu_job.sh ab <tag> <reps> "<name>|<ENV=.. ENV=..>|<bench.py args>" ...   the headline (--headline-only) under each variant, alternating, <reps> times: same-box A/B
+	REPS=$1; shift
+	: > "$OUT/ab.txt"
+	for rep in $(seq 1 "$REPS"); do
+		for v in "$@"; do
+			IFS='|' read -r NAME ENVS ARGS <<< "$v"
+			line=$(env $ENVS timeout 120 python bench.py --headline-only --no-cpu-baseline --no-rccl-world1 $ARGS 2>> "$OUT/ab.err" | tail -1)
+			echo "$NAME | $(python -c "import json,sys; d=json.loads(sys.argv[1]); print(d['value'], 'Gcells/s', d['ms_per_step'], 'ms/step')" "$line" 2>/dev/null || echo "FAILED: $line")" | tee -a "$OUT/ab.txt"
+		done
+	done
+	;;
+batch)
+	# gpu_job.sh batch <tag> "<subcommand> <args...>" ...   several subcommands in ONE gpurun call (each under <tag>/<subcommand>)
+	for job in "$@"; do set -- $job; sub=$1; shift; echo "=== $sub $*"; "$ROOT/tools/gpu_job.sh" "$sub" "$TAG/$sub" "$@"; done
 	;;
 *) echo "unknown command $CMD"; exit 2 ;;
 esac
