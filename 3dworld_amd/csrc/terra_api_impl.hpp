@@ -67,6 +67,13 @@ void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (.
 int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
 int terra_release_scratch(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.release_scratch(); TERRA_CATCH}
 int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
+void *terra_host_alloc(size_t bytes) {void *p = terra_backend_t::host_alloc(bytes); if (!p) {terra::fail(TERRA_ERR_HIP, "terra_host_alloc: out of pinned host memory");} return p;}
+void terra_host_free(void *p) {terra_backend_t::host_free(p);}
+int terra_download_async(terra_ctx *ctx, const void *d_src, void *h_dst, size_t bytes) {
+	TERRA_CHECK_CTX if (!d_src || !h_dst) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.be.download_async(d_src, h_dst, bytes); TERRA_CATCH
+}
+int terra_download_wait(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.download_wait(); TERRA_CATCH}
 
 // ---- events: stream-level ordering between contexts
 struct terra_event {void *ev = nullptr;};
@@ -240,9 +247,8 @@ int terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint3
 	TERRA_TRY
 		size_t const bytes = (size_t)nx*ny*sizeof(float);
 		if (bytes == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0");
-		float *d = (float *)ctx->eng.be.alloc(bytes);
-		try {ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d); ctx->eng.be.d2h(h_out, d, bytes);} catch (...) {ctx->eng.be.free(d); throw;}
-		ctx->eng.be.free(d);
+		float *d = ctx->eng.host_grid_scratch(bytes);
+		ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d); ctx->eng.be.d2h(h_out, d, bytes);
 	TERRA_CATCH
 }
 
@@ -270,9 +276,8 @@ int terra_apply_erosion(terra_ctx *ctx, float *h, int xs, int ys, float min_zval
 		if (iters == 0 || ctx->eng.erode_amount <= 0.0f) return TERRA_OK;
 		if (xs <= 0 || ys <= 0) throw std::invalid_argument("apply_erosion: bad grid size");
 		size_t const bytes = (size_t)xs*ys*sizeof(float);
-		float *d = (float *)ctx->eng.be.alloc(bytes);
-		try {ctx->eng.be.h2d(d, h, bytes); ctx->eng.apply_erosion_dev(d, xs, ys, min_zval, iters, 0); ctx->eng.be.d2h(h, d, bytes);} catch (...) {ctx->eng.be.free(d); throw;}
-		ctx->eng.be.free(d);
+		float *d = ctx->eng.host_grid_scratch(bytes); // grow-only (a 1 GiB hipMalloc + hipFree per call cost more than the erosion)
+		ctx->eng.be.h2d(d, h, bytes); ctx->eng.apply_erosion_dev(d, xs, ys, min_zval, iters, 0); ctx->eng.be.d2h(h, d, bytes);
 	TERRA_CATCH
 }
 int terra_set_erosion_tuning(terra_ctx *ctx, uint32_t window, uint32_t cap_log2, uint32_t maxb) {

@@ -252,7 +252,7 @@ template<class BE> struct terra_engine {
 
 	// grow-only device scratch
 	struct scratch_t {void *p = nullptr; size_t bytes = 0;};
-	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_shadow, s_shadow_map, s_shadow_gather, s_vox, s_sk, s_mm;
+	scratch_t s_xt, s_yt, s_smx, s_smy, s_misc, s_border, s_spec, s_spec_blocks, s_tiles, s_ao, s_shadow, s_shadow_map, s_shadow_gather, s_vox, s_sk, s_mm, s_hostgrid;
 	bool tiled_mesh_ao = false; // enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778)
 	uint8_t const *hmap_pix = nullptr; int hmap_w = 0, hmap_h = 0, hmap_nc = 0; // terrain_hmap_manager's image (device memory, owned by the caller)
 	float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;                          // src/mesh_gen.cpp:41, set by set_mesh_height_scales_for_zval_range
@@ -262,15 +262,16 @@ template<class BE> struct terra_engine {
 		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
 		return (T *)s.p;
 	}
+	float *host_grid_scratch(size_t bytes) {return (float *)scratch<uint8_t>(s_hostgrid, bytes);} // device copy of a caller's host array (the host-pointer entry points)
 	// every grow-only device buffer of the context back to the allocator (they grow again on demand): the erosion ring of a 16384^2 map alone is ~8.5 GiB
 	void release_scratch() {
 		be.sync();
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm}) {if (s->p) {be.free(s->p); s->p = nullptr; s->bytes = 0;}}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm, &s_hostgrid}) {if (s->p) {be.free(s->p); s->p = nullptr; s->bytes = 0;}}
 		spec_blocks_clean = nullptr; spec_blocks_n = 0;
 		be.release_scratch();
 	}
 	~terra_engine() {
-		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm}) {if (s->p) be.free(s->p);}
+		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm, &s_hostgrid}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 		if (d_noise_lut) be.free(d_noise_lut);
 		if (d_sinTable) be.free(d_sinTable);

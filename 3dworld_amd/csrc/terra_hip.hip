@@ -4,6 +4,7 @@
 // (see 3dworld_amd/build.py).  There is no host execution path in this library: every entry point needs a HIP device.
 #include "terra_kernels.hpp"
 #include "terra_simple_paths.hpp"
+#include "terra_xfer.hpp"
 #include <stdlib.h>
 
 #define TERRA_HIP_CHECK(expr) do {hipError_t const e_ = (expr); if (e_ != hipSuccess) {throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));}} while (0)
@@ -61,7 +62,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void fill8(void *p, uint8_t v, size_t count) {use(); if (count) TERRA_HIP_CHECK(hipMemsetAsync(p, v, count, stream));}
 	void fill32(void *p, uint32_t v, size_t count) {use(); if (count) TERRA_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)p, (int)v, count, stream));}
 	// host buffers are ordinary pageable memory (often stack variables): copies are stream-ordered and then waited for
-	void h2d(void *d, void const *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
+	void h2d(void *d, void const *h, size_t bytes) {
+		use();
+		if (bytes >= BIG_XFER) {xfer.submit(device, stream, const_cast<void *>(h), d, bytes, true); xfer.wait_all(); return;} // (the host waits: later kernels of any stream see the data)
+		TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	// small parameter blocks (tile references, per-column constants, dependency orders): staged through a pinned ring and copied asynchronously, stream-ordered -- the
 	// host does not wait (a pageable hipMemcpyAsync + hipStreamSynchronize per upload was ~10 % of a 0.68 ms tile batch).  The ring drains the stream when it wraps.
 	uint8_t *pin = nullptr; size_t pin_bytes = 0, pin_off = 0; bool pin_failed = false; // pin_failed: the pinned allocation was refused once -- not retried on every upload
@@ -76,7 +81,18 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipMemcpyAsync(d, pin + pin_off, bytes, hipMemcpyHostToDevice, stream));
 		pin_off += need;
 	}
-	void d2h(void *h, void const *d, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));}
+	void d2h(void *h, void const *d, size_t bytes) {
+		use();
+		if (bytes >= BIG_XFER) {download_async(d, h, bytes); download_wait(); return;} // whole grids: banded, K streams, pinned staging (terra_xfer.hpp)
+		TERRA_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));
+	}
+	// ---- big host <-> device transfers (terra_xfer.hpp): stream-ordered behind the work enqueued so far, asynchronous to the host and to the context's later kernels
+	static constexpr size_t BIG_XFER = (size_t)16 << 20;
+	terra::xfer_engine_t xfer;
+	void download_async(void const *d, void *h, size_t bytes) {use(); xfer.submit(device, stream, h, const_cast<void *>(d), bytes, false);}
+	void download_wait() {xfer.wait_all();}
+	static void *host_alloc(size_t bytes) {void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {(void)hipGetLastError(); return nullptr;} return p;}
+	static void host_free(void *p) {if (p) (void)hipHostFree(p);}
 	// device-to-device copies on this context's stream: inside the device, and from another context's device (several GPUs in one process, terra_multi.hpp)
 	void d2d(void *dst, void const *src, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));}
 	void copy_from_peer(void *dst, hip_backend_t &src_be, void const *src, size_t bytes) {

@@ -105,6 +105,10 @@ _PROTOS = {
     "terra_destroy": (None, [_vp]),
     "terra_set_stream": (_i32, [_vp, _vp]),
     "terra_synchronize": (_i32, [_vp]),
+    "terra_host_alloc": (_vp, [_sz]),
+    "terra_host_free": (None, [_vp]),
+    "terra_download_async": (_i32, [_vp, _vp, _vp, _sz]),
+    "terra_download_wait": (_i32, [_vp]),
     "terra_init_scene": (_i32, [_vp, C.POINTER(Config)]),
     "terra_set_config": (_i32, [_vp, C.POINTER(Config)]),
     "terra_get_state": (_i32, [_vp, C.POINTER(State)]),
@@ -263,6 +267,25 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class PinnedArray:
+    """A numpy array over pinned host memory from terra_host_alloc: the DMA target of downloads (no staging copy).  free() it explicitly."""
+
+    def __init__(self, lib, shape, dtype=np.float32):
+        self.lib = lib
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        lib.terra_host_alloc.restype = _vp
+        self.ptr = lib.terra_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise TerraError(-1, lib.terra_last_error().decode())
+        self.array = np.frombuffer((C.c_uint8 * n).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.lib.terra_host_free(self.ptr)
+            self.ptr = None
+
+
 class Terra:
     """One terra_ctx (one GPU, one stream)."""
 
@@ -310,6 +333,14 @@ class Terra:
     def set_stream(self, stream_ptr): self._ck(self.lib.terra_set_stream(self.ctx, stream_ptr))
     def release_scratch(self): self._ck(self.lib.terra_release_scratch(self.ctx))
     def synchronize(self): self._ck(self.lib.terra_synchronize(self.ctx))
+    def pinned(self, shape, dtype=np.float32): return PinnedArray(self.lib, shape, dtype)
+
+    def download_async(self, dev_ptr, host_arr):
+        """device -> host array (numpy, C-contiguous; pageable or PinnedArray.array) behind everything enqueued so far; returns at once -- complete after download_wait()"""
+        assert host_arr.flags["C_CONTIGUOUS"]
+        self._ck(self.lib.terra_download_async(self.ctx, dev_ptr, host_arr.ctypes.data, host_arr.nbytes))
+
+    def download_wait(self): self._ck(self.lib.terra_download_wait(self.ctx))
     def max_sea_level(self): return self.lib.terra_get_max_sea_level(self.ctx)
     def alloc(self, nbytes): return DeviceBuffer(self, nbytes)
     def timer_start(self): self._ck(self.lib.terra_timer_start(self.ctx))

@@ -139,6 +139,15 @@ int  terra_create(terra_ctx **out, int device_index);
 void terra_destroy(terra_ctx *ctx);
 int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  terra_synchronize(terra_ctx *ctx);
+/* ---- whole grids between host and device.  The reference's callers own HOST arrays (cached_vals of build_arrays, src/mesh_gen.cpp:597-603; apply_erosion's float*,
+ * src/erosion.cpp:14; heightmap_t's pixels, src/heightmap.cpp:130-151), 1 GiB at 16384^2.  Every host-pointer entry point moves arrays of >= 16 MiB in 8 MiB bands on four
+ * streams at once through pinned staging (csrc/terra_xfer.hpp); an array allocated with terra_host_alloc (pinned) is the DMA target itself, no staging copy.
+ * terra_download_async: d_src -> h_dst behind everything enqueued on ctx so far, without blocking the host or the context's later kernels (the next map's noise runs
+ * beside the copy); h_dst is complete when terra_download_wait returns.  One context = one thread at a time, as everywhere. */
+void *terra_host_alloc(size_t bytes);   /* NULL + terra_last_error() when pinned memory is exhausted */
+void terra_host_free(void *p);
+int  terra_download_async(terra_ctx *ctx, const void *d_src, void *h_dst, size_t bytes);
+int  terra_download_wait(terra_ctx *ctx);
 /* give every grow-only work buffer of the context back to the device (synchronises first; they grow again on demand).  The one that matters is the speculation ring of
  * terra_apply_erosion_dev: ~266 KiB per droplet in flight, 8.5 GiB for a 16384^2 map -- its size is also capped by the memory that is free when it has to grow. */
 int  terra_release_scratch(terra_ctx *ctx);

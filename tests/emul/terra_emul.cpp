@@ -28,6 +28,10 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void h2d_async(void *d, void const *h, size_t bytes) {memcpy(d, h, bytes);}
 	void d2h(void *h, void const *d, size_t bytes) {memcpy(h, d, bytes);}
 	void d2d(void *dst, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
+	void download_async(void const *d, void *h, size_t bytes) {memcpy(h, d, bytes);} // every "launch" has finished when it returns
+	void download_wait() {}
+	static void *host_alloc(size_t bytes) {return malloc(bytes ? bytes : 1);}
+	static void host_free(void *p) {::free(p);}
 	void copy_from_peer(void *dst, cpu_backend_t &, void const *src, size_t bytes) {memcpy(dst, src, bytes);}
 	void enable_peer(cpu_backend_t &) {}
 	bool can_map(cpu_backend_t const &) const {return map_peers;} // TERRA_EMUL_NO_PEER_MAP=1: take the staged-copy path of the multi-context mesh shadows

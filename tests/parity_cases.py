@@ -1132,6 +1132,45 @@ def case_multi_contexts(pkg, lib_path, orc, ndev=3, big=False):
         m.close()
 
 
+def case_big_transfers(pkg, t, orc, sizes=((4096, 4096), (2051, 2047), (300, 200))):
+    """host <-> device transfers of whole grids (csrc/terra_xfer.hpp: bands on several streams through pinned staging, or straight into a pinned array): an overlapped
+    download -- started behind a grid's kernels, the next grid's kernels enqueued before it is waited for -- delivers the same bytes as the synchronous one, into pageable
+    and into pinned memory, at sizes above and below the banded path's threshold and with ragged last bands; uploads round-trip."""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    st = t.init_scene(pc_); orc.init(oc)
+    for nx, ny in sizes:
+        a, b = t.alloc(nx * ny * 4), t.alloc(nx * ny * 4)
+        pin = t.pinned((ny, nx))
+        try:
+            t.gen_grid_dev(a.ptr, -nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)
+            sync = a.download(np.float32, (ny, nx))                      # synchronous (terra_memcpy_d2h)
+            if nx * ny <= 300 * 200:
+                assert_bit_equal(orc.gen_grid(-nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, 1), sync, "small grid")
+            t.gen_grid_dev(a.ptr, -nx / 2, -ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)
+            pag = np.full((ny, nx), -7.0, np.float32)
+            t.download_async(a.ptr, pag)                                   # behind the kernels above ...
+            t.download_async(a.ptr, pin.array)
+            t.gen_grid_dev(b.ptr, 11.0, -3.0, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE)  # ... and beside these
+            t.download_wait()
+            assert_bit_equal(sync, pag, f"overlapped download, pageable {nx}x{ny}")
+            assert_bit_equal(sync, pin.array, f"overlapped download, pinned {nx}x{ny}")
+            other = b.download(np.float32, (ny, nx))
+            assert not np.array_equal(other, sync)
+            b.upload(pag)                                                  # upload (banded above the threshold), then back
+            assert_bit_equal(sync, b.download(np.float32, (ny, nx)), f"upload round trip {nx}x{ny}")
+            b.upload(pin.array[::-1].copy())
+            assert_bit_equal(sync[::-1], b.download(np.float32, (ny, nx)), "second upload")
+            t.download_wait()                                              # nothing pending: returns at once
+        finally:
+            pin.free(); a.free(); b.free()
+    # the host-pointer entry points ride the same engine: terra_apply_erosion on a host array of 16 MiB+
+    n = 2100
+    g = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+    h = g.copy(); orc.apply_erosion(g, float(g.min()), 200); t.apply_erosion(h, float(h.min()), 200)
+    assert_bit_equal(g, h, "terra_apply_erosion on a 17 MiB host array")
+    assert_bit_equal(orc.gen_grid(5.0, 9.0, st.DX_VAL, st.DY_VAL, n, n, 1), t.gen_grid(5.0, 9.0, st.DX_VAL, st.DY_VAL, n, n, pkg.GEN_GLACIATE), "terra_gen_grid to the host")
+
+
 def case_streamed_pipeline(pkg, make_ctx, orc, N=768, maps=7, P=3, droplets=(400, 0, 2500)):
     """bench.py's streamed schedule in small: ONE producer context enqueues every map's noise (terra_gen_grid_minmax_async_dev: {min, max} stay in device memory), P consumer
     contexts erode the maps of their slot (terra_event_wait on the producer's event, terra_apply_erosion_devmin_dev), the producer waits for a slot's previous erosion the

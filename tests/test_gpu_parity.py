@@ -394,6 +394,10 @@ def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
         t.close()
 
 
+def test_overlapped_download_equals_synchronous(pkg, gpu, orc):
+    pc.case_big_transfers(pkg, gpu, orc)
+
+
 def test_streamed_pipeline_device_min_and_events(pkg, orc):
     """bench.py's streamed schedule: a producer context's noise kernels back to back, {min, max} left in HBM, three consumer contexts eroding as the events fire"""
     pc.case_streamed_pipeline(pkg, lambda: pkg.Terra(0), orc, N=2048, maps=9, P=3, droplets=(1000, 0, 6000))

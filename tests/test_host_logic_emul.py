@@ -163,6 +163,10 @@ def test_sparse_erosion_is_chosen_by_density_and_can_be_switched_off(pkg, emul, 
     assert r.sparse_droplets == 0
 
 
+def test_download_api_host_logic(pkg, emul, orc):
+    pc.case_big_transfers(pkg, emul, orc, sizes=((700, 300), (64, 33)))
+
+
 def test_erosion_context_reuse(pkg, emul, orc):
     pc.case_erosion_context_reuse(pkg, emul, orc)
 

@@ -12,7 +12,6 @@
 #   gpu_job.sh timeline <tag> [bench.py args]        rocprofv3 kernel trace of the headline run with the driver's flags -> tools/timeline.py (who ran when, idle time, overlap)
 #   gpu_job.sh clock   <tag> <driver.py args>        GRBM_GUI_ACTIVE per dispatch: the clock a kernel actually ran at (cycles / duration)
 #   gpu_job.sh ab      <tag> <reps> "name|ENV=..|bench args" ...   alternating same-box A/B of the headline under environment / argument variants
-#   gpu_job.sh batch   <tag> "<subcommand> <args>" ...  several of the above in one gpurun call
 set -u
 CMD=${1:-check}; TAG=${2:-job}; shift; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -135,10 +134,6 @@ ab)
 			echo "$NAME | $(python -c "import json,sys; d=json.loads(sys.argv[1]); print(d['value'], 'Gcells/s', d['ms_per_step'], 'ms/step')" "$line" 2>/dev/null || echo "FAILED: $line")" | tee -a "$OUT/ab.txt"
 		done
 	done
-	;;
-batch)
-	# gpu_job.sh batch <tag> "<subcommand> <args...>" ...   several subcommands in ONE gpurun call (each under <tag>/<subcommand>)
-	for job in "$@"; do set -- $job; sub=$1; shift; echo "=== $sub $*"; "$ROOT/tools/gpu_job.sh" "$sub" "$TAG/$sub" "$@"; done
 	;;
 *) echo "unknown command $CMD"; exit 2 ;;
 esac
