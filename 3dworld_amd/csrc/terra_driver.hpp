@@ -845,12 +845,12 @@ template<class BE> struct terra_engine {
 						if (i == 0) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}
 					});
 					be.launch_waves_lean(N, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
-					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_body(s, (uint32_t)i);});
+					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_wave(s, (uint32_t)i);});
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
 				}
 				for (int r = 0; r < 2; ++r) {
 					be.launch_waves_lean(1, [=] TERRA_LAMBDA (size_t, lean_scratch_t const &ws) {sparse_retrace_wave(s, ws);});
-					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_body(s, (uint32_t)i);});
+					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_wave(s, (uint32_t)i);});
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
 				}
 			} catch (...) {be.graph_abort(); throw;}

@@ -1613,21 +1613,31 @@ TERRA_HD void sparse_retrace_wave(sparse_buffers_t const &sb, lean_scratch_t con
 	sparse_trace_droplet(sb, base, 1u - wave_uniform(sb.cur[base]), SPARSE_FINAL, ws);
 	if (wave_uniform(sb.state[base]) == (uint32_t)SPARSE_FAILED) {if (TERRA_LANE0) {c.bail = 1;}} // (its footprint grew past the block list on the changed grid)
 }
-// one thread per droplet: is it conflicted?
-TERRA_HD void sparse_check_body(sparse_buffers_t const &sb, uint32_t j) {
+// one WAVE per droplet, a lane per footprint entry: is it conflicted?  (One thread per droplet walked its list with two dependent loads per entry: ~45 us for the longest
+// droplet of the headline run beside another map's noise kernel -- profiles/r05_timeline_sparse_v1.txt -- for a check that is a few hundred loads.)
+TERRA_HD void sparse_check_wave(sparse_buffers_t const &sb, uint32_t j) {
 	sparse_ctl_t &c = *sb.ctl;
 	if (c.bail || j < c.base) return;
 	uint32_t const st = sb.state[j];
 	if (st == SPARSE_COMMITTED || st == SPARSE_FINAL) return;
-	bool hit = (st == SPARSE_FAILED);
-	if (!hit) {
-		uint32_t const buf = sb.cur[j], n = sb.blk_cnt[buf][j];
-		uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
-		for (uint32_t e = 0; e < n; ++e) {hit = hit || (sb.wmin[bl[e] & SPEC_BLK_ID] < j);}
+	uint32_t const buf = sb.cur[j], n = (st == SPARSE_FAILED) ? 0u : sb.blk_cnt[buf][j];
+	uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
+	uint32_t hits[TERRA_LANE_SLOTS] = {};
+	TERRA_EACH_LANE(l) {
+		uint32_t h = 0;
+		for (uint32_t e = (uint32_t)l; e < n; e += 64) {h |= (sb.wmin[bl[e] & SPEC_BLK_ID] < j) ? 1u : 0u;}
+		hits[TERRA_LANE_SLOT(l)] = h;
 	}
-	if (hit) {TERRA_ATOMIC_MIN(&c.c, j); TERRA_ATOMIC_ADD(&c.nconf, 1u);}
+	bool hit = (st == SPARSE_FAILED);
+#if defined(__HIP_DEVICE_COMPILE__)
+	hit = hit || (__ballot(hits[0] != 0) != 0ull);
+#else
+	for (int l = 0; l < 64; ++l) {hit = hit || hits[l] != 0;}
+#endif
+	if (hit && TERRA_LANE0) {TERRA_ATOMIC_MIN(&c.c, j); TERRA_ATOMIC_ADD(&c.nconf, 1u);}
 }
-// one wave per droplet: the droplets [base, c) are exact and write disjoint blocks -- their pages go to the grid
+// one wave per droplet: the droplets [base, c) are exact and write disjoint blocks -- their pages go to the grid.  A lane takes a page: all of its 64 floats are loaded first
+// (independent 16-byte loads: one memory latency), then the written ones are stored
 TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t j) {
 	sparse_ctl_t &c = *sb.ctl;
 	if (c.bail || j < c.base || j >= c.c || sb.state[j] == SPARSE_COMMITTED) return;
@@ -1639,13 +1649,29 @@ TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t j) {
 			unsigned long long m = 0; uint32_t b = 0;
 			if (e < n) {uint32_t const ent = sb.blk_list[buf][pbase + e]; if (ent & SPEC_BLK_WRITTEN) {b = ent & SPEC_BLK_ID; m = sb.page_mask[buf][pbase + e];}}
 			uint32_t k = wave_reserve(&c.touched, sb.touched ? (uint32_t)__builtin_popcountll(m) : 0u);
-			uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
-			float const *page = sb.page_vals[buf] + (pbase + e)*SPEC_PAGE;
-			for (; m; m &= m - 1, ++k) {
-				uint32_t const cc = (uint32_t)__builtin_ctzll(m);
-				uint32_t const X = (bx << 3) + (cc & 7u), Z = (bz << 3) + (cc >> 3);
-				*sb.grid.at((int)X, (int)Z) = page[cc];
-				if (sb.touched && k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
+			if (m) {
+				uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
+				spec_u32x4 const *page = (spec_u32x4 const *)(sb.page_vals[buf] + (pbase + e)*SPEC_PAGE); // 256-byte aligned
+				for (uint32_t half = 0; half < 2; ++half) { // 32 cells at a time: eight loads in flight, 32 value registers (the wave has to fit beside a noise kernel's waves)
+					if (!(uint32_t)(m >> (32*half))) continue;
+					spec_u32x4 v[SPEC_PAGE/8];
+#pragma unroll
+					for (uint32_t q = 0; q < SPEC_PAGE/8; ++q) {v[q] = page[half*(SPEC_PAGE/8) + q];}
+#pragma unroll
+					for (uint32_t q = 0; q < SPEC_PAGE/8; ++q) {
+						uint32_t const w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+						for (uint32_t u = 0; u < 4; ++u) {
+							uint32_t const cc = 32*half + 4*q + u;
+							if ((m >> cc) & 1ull) {
+								uint32_t const X = (bx << 3) + (cc & 7u), Z = (bz << 3) + (cc >> 3);
+								float f; memcpy(&f, &w[u], 4);
+								*sb.grid.at((int)X, (int)Z) = f;
+								if (sb.touched) {if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;} ++k;}
+							}
+						}
+					}
+				}
 			}
 		}
 	}

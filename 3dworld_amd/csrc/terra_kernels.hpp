@@ -20,6 +20,7 @@ template<class F> __global__ void k_generic(size_t n, F f) {
 
 // one 64-lane workgroup (= one wave) per item, with the per-wave LDS scratch of the droplet window (terra_erosion.hpp)
 template<class F> __global__ __launch_bounds__(64) void k_waves(F f, unsigned first) {
+	__builtin_amdgcn_s_setprio(3); // (see k_waves_lean)
 	__shared__ __attribute__((aligned(16))) float win[EW*EW];
 	__shared__ uint8_t dirty[EW*EW];
 	__shared__ wave_shared_t sh;
@@ -33,6 +34,7 @@ template<class F> __global__ __launch_bounds__(64) void k_waves_nolds(F f) {f((s
 // at most 128 registers (four waves per SIMD requested) -- beside a k_sine_grid block of another heightmap (29.7 KB, 120 registers per wave) a SIMD then holds three of that
 // kernel's waves and one of these, and a CU four of its blocks and four of these; the general trace wave (22.7 KB, 260 registers) leaves room for two and two
 template<class F> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_waves_lean(F f) {
+	__builtin_amdgcn_s_setprio(3); // a droplet is a chain of dependent instructions: beside three waves of another kernel on its SIMD it should never wait for an issue slot (it asks for one every ~5 cycles)
 	__shared__ __attribute__((aligned(16))) float win[EW*EW];
 	__shared__ uint8_t dirty[EW*EW];
 	__shared__ lean_shared_t sh;

@@ -25,7 +25,7 @@ def load(d):
 def klass(name):
     if "k_sine_grid" in name or "k_noise_grid" in name:
         return "noise"
-    if "speculative_erosion" in name or "apply_erosion" in name or "direct_droplet" in name or "k_erosion" in name:
+    if "speculative_erosion" in name or "sparse_erosion" in name or "apply_erosion" in name or "direct_droplet" in name or "k_erosion" in name:
         return "erosion"
     if "gen_grid_dev" in name:
         return "tables"
