@@ -83,6 +83,7 @@ int terra_event_create(terra_ctx *ctx, terra_event **out) {
 	TERRA_TRY terra_event *e = new terra_event(); try {e->ev = ctx->eng.be.event_create();} catch (...) {delete e; throw;} *out = e; TERRA_CATCH
 }
 int terra_event_record(terra_ctx *ctx, terra_event *ev) {TERRA_CHECK_CTX if (!ev) return terra::fail(TERRA_ERR_ARG, "null event"); TERRA_TRY ctx->eng.be.event_record(ev->ev); TERRA_CATCH}
+int terra_event_synchronize(terra_event *ev) {if (!ev) return terra::fail(TERRA_ERR_ARG, "null event"); TERRA_TRY terra_backend_t::event_synchronize(ev->ev); TERRA_CATCH}
 int terra_event_wait(terra_ctx *ctx, terra_event *ev) {TERRA_CHECK_CTX if (!ev) return terra::fail(TERRA_ERR_ARG, "null event"); TERRA_TRY ctx->eng.be.event_wait(ev->ev); TERRA_CATCH}
 void terra_event_destroy(terra_event *ev) {if (ev) {terra_backend_t::event_destroy(ev->ev); delete ev;}}
 

@@ -835,7 +835,7 @@ template<class BE> struct terra_engine {
 		sparse_buffers_t const s = sb;
 		auto rounds = [&](bool with_first) { // [init, trace everything, check, commit,] then twice: re-trace the lowest conflicted droplet, check, commit -- one hipGraph each way
 			struct {sparse_buffers_t s; uint32_t with_first; uint32_t tag;} gkey;
-			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.with_first = with_first ? 1u : 0u; gkey.tag = 0x53505253u;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.s.ec.min_zval = 0.0f; gkey.with_first = with_first ? 1u : 0u; gkey.tag = 0x53505253u; // (min_zval: read by the clamp only, which is not part of the graph)
 			if (be.graph_replay(&gkey, sizeof(gkey))) return;
 			bool const cap = be.graph_begin();
 			try {
@@ -856,25 +856,34 @@ template<class BE> struct terra_engine {
 			} catch (...) {be.graph_abort(); throw;}
 			if (cap) {be.graph_end(&gkey, sizeof(gkey));}
 		};
+		// behind the rounds, BEFORE the host knows how they went: reset the marks and clamp the written cells if the run turns out complete (both look at the control block on
+		// the device and do nothing otherwise) -- in the usual case the control block read-back below is the last thing the call waits for
+		float const mz = ec.min_zval;
+		uint32_t const clamp_threads = record_touched ? std::min<uint32_t>(touched_cap, 1u << 18) : 0u;
+		auto finish = [&](bool force) {
+			be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, force);});
+			if (clamp_threads) {be.launch(clamp_threads, [=] TERRA_LAMBDA (size_t i) {sparse_clamp_body(s, (uint32_t)i, clamp_threads, d_min ? *d_min : mz, false);});} // (never forced: an incomplete run's clamp is the caller's, at the end)
+		};
 		sparse_ctl_t hc{};
 		rounds(true);
+		finish(false);
 		be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of a run with at most two conflicted droplets
 		uint32_t batches = 1;
+		bool finished_on_device = (hc.c >= N) && !hc.bail;
 		while (hc.c < N && !hc.bail) { // after the last commit: [base, c) is on the grid, c is conflicted
 			if (batches++ > N) throw std::runtime_error("sparse erosion: no progress");
 			rounds(false);
+			finish(false);
 			be.d2h(&hc, sb.ctl, sizeof(hc));
+			finished_on_device = (hc.c >= N) && !hc.bail;
 		}
 		bool const complete = (hc.c >= N) && !hc.bail;
 		first = complete ? N : (hc.bail ? hc.base : hc.c);
-		be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_body(s, (uint32_t)i);}); // wmin[] all SPEC_NIL again (head[] was never touched)
+		if (!finished_on_device) {be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, true);});} // handed over: wmin[] all SPEC_NIL again (head[] was never touched)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		report.rounds = 1 + hc.retraces; report.traces = N + hc.retraces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.windows = 1; report.sparse_droplets = first; report.sparse_retraces = hc.retraces;
-		if (!complete || !record_touched || hc.touched > sb.touched_cap) return false; // (record overflowed: the caller clamps the whole grid)
-		uint32_t const *tch = sb.touched; float const mz = ec.min_zval; grid_view_t const gg = g;
-		be.launch(hc.touched, [=] TERRA_LAMBDA (size_t i) {touched_clamp_body(gg, tch, (uint32_t)i, d_min ? *d_min : mz);});
-		return true;
+		return complete && record_touched && hc.touched <= sb.touched_cap; // (else the caller clamps the whole grid: handed over, no record wanted, or the record overflowed)
 	}
 
 	// Defaults from the measurements in profiles/r02_erosion_near_far_sweep.txt: the 512 droplets next in line for the commit trace to the end, the rest of the ring
@@ -985,7 +994,7 @@ template<class BE> struct terra_engine {
 		// lowest droplet waits for its serial fall-back) finds nothing to do.
 		auto one_round = [&]() {
 			struct {spec_buffers_t s; uint32_t slice; uint32_t tag;} gkey;
-			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.slice = slice; gkey.tag = 0x524e4432u;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.s.ec.min_zval = 0.0f; gkey.slice = slice; gkey.tag = 0x524e4432u; // (min_zval: read by the clamp only, which is not part of the graph)
 			if (be.graph_replay(&gkey, sizeof(gkey))) return;
 			bool const cap = be.graph_begin();
 			try {

@@ -1682,13 +1682,32 @@ TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t j) {
 		if (sb.nan[j]) {TERRA_ATOMIC_ADD(&c.nan_droplets, 1u);}
 	}
 }
-// end of the run (also before the general scheduler takes over): every mark is reset through the block lists, both traces of a re-traced droplet
-TERRA_HD void sparse_unmark_body(sparse_buffers_t const &sb, uint32_t j) {
+// sparse version of "clamp to min_zval" (src/erosion.cpp:158-162) when min_zval <= every untouched cell: one thread per recorded write
+TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, uint32_t i, float min_zval) {
+	uint32_t const cell = touched[i];
+	int const X = (int)(cell % (uint32_t)g.NX), Z = (int)(cell / (uint32_t)g.NX);
+	int const x = X - EROSION_PAD, z = Z - EROSION_PAD;
+	if ((unsigned)x < (unsigned)g.xsize && (unsigned)z < (unsigned)g.ysize) {float *p = g.interior + (size_t)z*g.xsize + x; *p = max_std(min_zval, *p);} // idempotent: duplicates are harmless
+}
+
+// after a check + commit pair: is everything on the grid?  (c.c = N: the check found no conflicted droplet in [base, N), the commit that followed covered all of it)
+TERRA_HD bool sparse_done(sparse_buffers_t const &sb) {return sb.ctl->c >= sb.N && !sb.ctl->bail;}
+// end of the run (also before the general scheduler takes over): every mark is reset through the block lists, both traces of a re-traced droplet.  One wave per droplet, a lane
+// per entry.  Launched right behind the rounds, before the host has read the control block: when the run is NOT complete yet (more rounds or the hand-over follow) and the
+// launch is not the final one (`force`), it does nothing
+TERRA_HD void sparse_unmark_wave(sparse_buffers_t const &sb, uint32_t j, bool force) {
+	if (!force && !sparse_done(sb)) return;
 	for (uint32_t buf = 0; buf < 2; ++buf) {
 		uint32_t const n = sb.blk_cnt[buf][j];
 		uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
-		for (uint32_t e = 0; e < n; ++e) {if (bl[e] & SPEC_BLK_WRITTEN) {sb.wmin[bl[e] & SPEC_BLK_ID] = SPEC_NIL;}}
+		TERRA_LANES(e, n) {uint32_t const ent = bl[e]; if (ent & SPEC_BLK_WRITTEN) {sb.wmin[ent & SPEC_BLK_ID] = SPEC_NIL;}}
 	}
+}
+// the sparse clamp (touched_clamp_body) over the cells the commits recorded, count taken on the device; thread i of nth.  Idempotent.
+TERRA_HD void sparse_clamp_body(sparse_buffers_t const &sb, uint32_t i, uint32_t nth, float min_zval, bool force) {
+	if (!sb.touched || (!force && !sparse_done(sb))) return;
+	uint32_t const n = (sb.ctl->touched < sb.touched_cap) ? sb.ctl->touched : sb.touched_cap;
+	for (uint32_t k = i; k < n; k += nth) {touched_clamp_body(sb.grid, sb.touched, k, min_zval);}
 }
 
 // ---- per-logical-thread bodies of the bookkeeping kernels (one round = clear, trace, post, flip, link, mark, scan, flush, admit, advance)
@@ -1926,14 +1945,6 @@ TERRA_HD void spec_fallback_advance_body(spec_buffers_t const &sb) {
 	c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; c.unfinished = 0;
 	c.steps += c.fb_steps; c.traced_steps += c.fb_steps; c.nan_droplets += c.fb_nan;
 }
-// sparse version of "clamp to min_zval" (src/erosion.cpp:158-162) when min_zval <= every untouched cell: one thread per recorded write
-TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, uint32_t i, float min_zval) {
-	uint32_t const cell = touched[i];
-	int const X = (int)(cell % (uint32_t)g.NX), Z = (int)(cell / (uint32_t)g.NX);
-	int const x = X - EROSION_PAD, z = Z - EROSION_PAD;
-	if ((unsigned)x < (unsigned)g.xsize && (unsigned)z < (unsigned)g.ysize) {float *p = g.interior + (size_t)z*g.xsize + x; *p = max_std(min_zval, *p);} // idempotent: duplicates are harmless
-}
-
 // ring initialisation = the clamp-padded copy of src/erosion.cpp:31-37 restricted to the ring; one thread per ring float
 TERRA_HD void border_init_body(grid_view_t const &g, size_t i) {
 	int const PAD = EROSION_PAD;

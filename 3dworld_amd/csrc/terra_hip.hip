@@ -140,6 +140,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void event_record(void *e) {use(); TERRA_HIP_CHECK(hipEventRecord((hipEvent_t)e, stream));}
 	void event_wait(void *e) {use(); TERRA_HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)e, 0));}
 	static void event_destroy(void *e) {if (e) (void)hipEventDestroy((hipEvent_t)e);}
+	static void event_synchronize(void *e) {TERRA_HIP_CHECK(hipEventSynchronize((hipEvent_t)e));}
 	void timer_start() {use(); TERRA_HIP_CHECK(hipEventRecord(ev0, stream));}
 	float timer_stop() {use(); TERRA_HIP_CHECK(hipEventRecord(ev1, stream)); TERRA_HIP_CHECK(hipEventSynchronize(ev1)); float ms = 0; TERRA_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); return ms;}
 

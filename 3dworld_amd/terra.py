@@ -139,6 +139,7 @@ _PROTOS = {
     "terra_event_create": (_i32, [_vp, C.POINTER(_vp)]),
     "terra_event_record": (_i32, [_vp, _vp]),
     "terra_event_wait": (_i32, [_vp, _vp]),
+    "terra_event_synchronize": (_i32, [_vp]),
     "terra_event_destroy": (None, [_vp]),
     "terra_apply_erosion_devmin_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32]),
     "terra_gen_grid_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _vp]),
@@ -582,6 +583,7 @@ class Terra:
 
     def event_record(self, ev): self._ck(self.lib.terra_event_record(self.ctx, ev))
     def event_wait(self, ev): self._ck(self.lib.terra_event_wait(self.ctx, ev))
+    def event_synchronize(self, ev): self._ck(self.lib.terra_event_synchronize(ev))
     def event_destroy(self, ev): self.lib.terra_event_destroy(ev)
 
     def apply_erosion_dev(self, ptr, xsize, ysize, min_zval, iters, flags=0):

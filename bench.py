@@ -37,10 +37,13 @@ import os
 import sys
 import threading
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench_detail  # noqa: E402 -- the secondary measurements of the same run (detail.*)
+from bench_detail import flops_per_cell  # noqa: E402
 
 MODES = {"sine": 0, "simplex": 1, "perlin": 2, "dwarp": 4}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
@@ -59,9 +62,9 @@ def parse():
     p.add_argument("--octaves", type=int, default=8)
     p.add_argument("--pipelines", type=int, default=4, help="heightmaps in flight per GPU (each on its own HIP stream, like the reference's height_gens[8])")
     p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
-    p.add_argument("--noise-slots", type=int, default=1, help="threads schedule: how many heightmaps may be in their noise phase at once (a host semaphore around the noise call; the other pipelines "
-                   "erode meanwhile).  0 = no limit: every pipeline issues its noise whenever it is free, and they fall into lockstep -- four noise kernels sharing the chip, then four erosions that leave "
-                   "its vector ALUs idle (profiles/r04_noise_slots_ab.txt)")
+    p.add_argument("--handoff", default="event", choices=["event", "semaphore", "none"], help="how the heightmaps in flight take turns in their noise phase: event = the next map's thread waits on the host for the "
+                   "GPU event behind the previous map's noise kernel, min(vals) stays in HBM (3dworld_amd/pipeline.py); semaphore = a host semaphore around a synchronous noise call (rounds 1-4); none = no turns")
+    p.add_argument("--active-wait-us", type=int, default=2000, help="ROC_ACTIVE_WAIT_TIMEOUT for this process (microseconds a completion wait spins before it blocks; 0 = the runtime's default)")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
                         "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
@@ -72,12 +75,9 @@ def parse():
     p.add_argument("--no-rccl-world1", action="store_true", help="N = 1: do not create the one-rank RCCL group (the collectives of the sharded paths are then skipped)")
     p.add_argument("--clock-warmup-ms", type=float, default=150.0, help="untimed steps run for this long right before every timed region so that it runs at the chip's sustained clock (a cold MI355X needs ~30 ms of load to get there, an idle gap of 5 ms already costs 12 %%: profiles/r04_clock_ramp.txt); 0 = only the W warm-up steps")
     p.add_argument("--cpu-size", type=int, default=0, help="grid edge of the CPU sample (default: the benchmark's own size)")
+    p.add_argument("--simulate-world", type=int, default=8, help="detail.onegrid_rank_floor: what one rank of the one-grid line does per step at this world size (its 1/W row strip of noise + the "
+                   "all_reduce(min) + every W-th step an erosion), measured on this GPU: the floor of the N = W step and the prediction that follows from it")
     return p.parse_args()
-
-
-def flops_per_cell(mode, octaves):
-    """sine 2 flop per term (10 terms per octave); fBm 70 flop per octave and evaluation, domain warp = 5 evaluations."""
-    return 20.0 * octaves if mode == 0 else 70.0 * octaves * (5 if mode == 4 else 1)
 
 
 def cpu_baseline(args, mode):
@@ -160,6 +160,10 @@ class c_stdout_to_stderr:
 
 def main():
     args = parse()
+    # the runtime's completion waits (hipEventSynchronize of the noise hand-over, the read-backs) spin this long before they block: a blocked thread costs a wake-up of tens of
+    # microseconds on the step's critical path, a spinning one a few (a serving process pins a core per heightmap in flight; profiles/r05_handoff_ab.txt)
+    if args.active_wait_us > 0:
+        os.environ.setdefault("ROC_ACTIVE_WAIT_TIMEOUT", str(args.active_wait_us))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -247,18 +251,28 @@ def main():
     x0 = -N / 2 + rank * N  # each rank owns its own N x N region of the world
     y0 = -N / 2
 
-    noise_turn = threading.Semaphore(args.noise_slots) if args.noise_slots > 0 else None  # (a threading.Lock for one slot measured the same: the hand-over is not Python's)
+    pmod = importlib.import_module("3dworld_amd.pipeline")
+    noise_turn = threading.Semaphore(1) if args.handoff == "semaphore" else None
+    turns = pmod.NoiseTurns() if args.handoff == "event" else None
+    evs = [c.event_create() for c in ctxs]                                           # "the noise kernel of pipeline p's current map has finished"
+    mms = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(P)]         # {min, max} of the map in pipeline p: written by its noise kernel, read by its erosion's clamp
+
     def step(p=0, noise_done=None):
-        # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place)
+        # heightmap_t::proc_gen on the device: noise + glaciate (+ fused min) -> erosion (in place); one map's noise phase at a time (3dworld_amd/pipeline.py)
         c, zz = ctxs[p], zs[p]
+        if args.handoff == "event":
+            pmod.proc_gen_step(pkg, c, turns if P > 1 else None, evs[p], zz.data_ptr(), mms[p].data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, args.droplets,
+                               on_noise_enqueued=noise_done.set if noise_done is not None else None)
+            return
+        # --handoff semaphore / none (round 1-4's schedules, kept for the A/B): min(vals) read back by the host, a host semaphore around the noise call / nothing
         if noise_turn is not None:
-            with noise_turn:  # the noise kernel fills the chip's vector ALUs on its own: more of them at once only finish together and leave the erosions that follow without one beside them
+            with noise_turn:
                 mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
         else:
-            mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # min(vals) is folded into the grid kernel
+            mn, _ = c.gen_grid_minmax_dev(zz.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
         if noise_done is not None:
             noise_done.set()
-        c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)                   # run_erosion passes min(vals): only written cells can need the clamp
+        c.apply_erosion_dev(zz.data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)
 
     def run_steps(k, npipe):
         """k steps in total on npipe pipelines (one host thread each: the library calls release the GIL)."""
@@ -336,52 +350,12 @@ def main():
             dt = float(tt.item())
         return dt
 
-    # ---- strong scaling of ONE grid: row strips + all_reduce(min) of one float
-    r0, r1 = dmod.strip_rows(N, rank, world)
-    red = torch.zeros(1, dtype=torch.float32, device=coll_dev)
-
-    def strips_steps(k):
-        for _ in range(k):
-            mn, _ = t.gen_grid_rows_minmax_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, r0, r1 - r0, pkg.GEN_GLACIATE)
-            if have_group:
-                red[0] = mn
-                dist.all_reduce(red, op=dist.ReduceOp.MIN)  # min(vals) of the whole map: what run_erosion / from_floats need next
-                mn = float(red.item())
-        return None
-
-    # ---- strong scaling of the tile batch of BASELINE config 4: 64 x 64 tiles block-partitioned, no collective
     all_tiles = [(tx, ty) for ty in range(-32, 32) for tx in range(-32, 32)]
-    my_tiles = dmod.partition_tiles(all_tiles, rank, world)
-    nt = len(my_tiles)
-    tile_bufs = {}
-
-    def tiles_steps_fn(droplets):
-        def fn(k):
-            if nt == 0:
-                return
-            if not tile_bufs:
-                tile_bufs["z"] = torch.empty(nt * 130 * 130, dtype=torch.float32, device=dev)
-                tile_bufs["st"] = torch.empty(nt * 39 * 4, dtype=torch.uint8, device=dev)
-                tile_bufs["nm"] = torch.empty(nt * 129 * 129 * 4, dtype=torch.uint8, device=dev)
-                tile_bufs["mnz"] = torch.empty(nt, dtype=torch.float32, device=dev)
-            for _ in range(k):
-                t.tiles_create_zvals_dev(my_tiles, droplets, tile_bufs["z"].data_ptr(), tile_bufs["st"].data_ptr(), tile_bufs["nm"].data_ptr(), tile_bufs["mnz"].data_ptr())
-            t.synchronize()
-        return fn
-
-    # ---- strong scaling of BASELINE config 5: ONE 512^3 voxel field (voxel_manager::create_procedural, sine mode) as y slabs, no collective
-    VN = 512
-    v0, v1 = dmod.strip_rows(VN, rank, world)
-    vox_buf = {}
-
-    def voxel_steps(k):
-        if v1 <= v0:
-            return
-        if not vox_buf:
-            vox_buf["v"] = torch.empty((v1 - v0) * VN * VN, dtype=torch.float32, device=dev)
-        for _ in range(k):
-            t.voxel_fill_slab_dev(vox_buf["v"].data_ptr(), VN, VN, VN, (-1.0, -1.0, -0.25), (2.0 / VN, 2.0 / VN, 0.5 / VN), (0.0, 0.0, 0.0), 1.0, 1.0, 123, 456, 0, 0.0, 1, v0, v1 - v0)
-        t.synchronize()
+    env = types.SimpleNamespace(args=args, pkg=pkg, dmod=dmod, dist=dist, torch=torch, dev=dev, rank=rank, world=world, have_group=have_group, coll_dev=coll_dev, ctxs=ctxs, zs=zs,
+                                st=st, t=t, z=z, N=N, cells=cells, mode=mode, MODES=MODES, P=P, x0=x0, y0=y0, timed=timed, backend_name=("RCCL" if backend == "nccl" else backend),
+                                all_tiles=all_tiles, my_tiles=dmod.partition_tiles(all_tiles, rank, world), tile_bufs={}, local_rank=local_rank)
+    strips_steps, _ = bench_detail.strips_steps_fn(env)
+    nt = len(env.my_tiles)
 
     K, W = args.steps, args.warmup
     detail = {}
@@ -403,7 +377,7 @@ def main():
     # ---- the headline
     if args.workload in ("heightmap", "regions", "onegrid"):
         workload_w = f"{N}x{N} heightmap per GPU, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals), {args.droplets}-droplet erosion (heightmap_t::proc_gen semantics), device resident"
-        noise_turn_note = f", at most {args.noise_slots} in its noise phase at a time" if (args.noise_slots > 0 and P > 1) else ""
+        noise_turn_note = f", one in its noise phase at a time (hand-over: {args.handoff})" if (args.handoff != "none" and P > 1) else ""
         par_w = f"{world} independent regions (one per GPU), no collective; {P} heightmaps in flight per GPU (one host thread each{noise_turn_note})"
         workload_s = (f"ONE {N}x{N} heightmap per step on {world} GPU(s) together: {args.mode} noise {args.octaves} octaves + glaciate/islands as row strips in their owners' HBM, min(vals) by "
                       f"all_reduce(min), {args.droplets}-droplet erosion of the whole grid in serial droplet order by rank (step mod {world}) over the mapped strips (heightmap_t::proc_gen semantics)")
@@ -429,7 +403,7 @@ def main():
         workload = f"ONE {N}x{N} heightmap as {world} row strips, {args.mode} noise {args.octaves} octaves + glaciate/islands, min(vals) by all_reduce(min); erosion excluded (does not shard: replicas only)"
         par = f"{world} row strips of {N // world} rows, one 4-byte all_reduce(min) per step over " + (("RCCL" if backend == "nccl" else backend) if have_group else "nothing (no process group)")
     else:
-        dt = timed(tiles_steps_fn(args.tile_droplets), K, max(W, 2))
+        dt = timed(bench_detail.tiles_steps_fn(env, args.tile_droplets), K, max(W, 2))
         value = len(all_tiles) * 130 * 130 * K / dt / 1e9
         scaling = "strong"
         workload = f"64x64 tiles of 128^2 (tile_t::create_zvals + sub-block stats + normals, {args.tile_droplets} droplets per tile), block-partitioned over {world} GPUs"
@@ -449,31 +423,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- the other measurements of the same run
+    # ---- the other measurements of the same run (bench_detail.py): all ranks take part
     if not args.no_extras:
-        ke = max(4, min(K, 16))
-        if args.workload != "heightmap" or P > 1:
-            d1 = timed(lambda k: run_steps(k, 1), ke, 2, "single")
-            detail["single"] = {"pipelines": 1, "steps": ke, "latency_ms_single": round(d1 / ke * 1e3, 4), "gcells_s": round(world * cells * ke / d1 / 1e9, 3), "scaling": "weak",
-                                "note": "one heightmap in flight per GPU: noise and erosion of a map do not overlap with another map's"}
-        if args.workload != "strips":
-            ds = timed(strips_steps, ke, 2, "strips")
-            detail["strips"] = {"steps": ke, "ms_per_step": round(ds / ke * 1e3, 4), "gcells_s": round(cells * ke / ds / 1e9, 3), "scaling": "strong", "rows_per_rank": r1 - r0,
-                                "collective": ("all_reduce(min) of one float per step over " + ("RCCL" if backend == "nccl" else backend) + (" (one-rank group)" if world == 1 else "")) if have_group else "none (no process group)", "erosion": "excluded: one shared grid in serial droplet order does not shard (replicas only)"}
-        if args.workload != "tiles":
-            dt0 = timed(tiles_steps_fn(0), ke, 2, "tiles_0")
-            kt = max(2, min(K, 3))
-            dt1 = timed(tiles_steps_fn(1000), kt, 1, "tiles_1000")
-            tc = len(all_tiles) * 130 * 130
-            detail["tiles"] = {"tiles": len(all_tiles), "tiles_per_rank": nt, "scaling": "strong", "collective": "none",
-                               "erosion_0": {"steps": ke, "ms_per_batch": round(dt0 / ke * 1e3, 4), "gcells_s": round(tc * ke / dt0 / 1e9, 3), "mtiles_s": round(len(all_tiles) * ke / dt0 / 1e6, 3)},
-                               "erosion_1000": {"steps": kt, "ms_per_batch": round(dt1 / kt * 1e3, 3), "gcells_s": round(tc * kt / dt1 / 1e9, 4), "ktiles_s": round(len(all_tiles) * kt / dt1 / 1e3, 2)}}
-
-    if not args.no_extras:
-        kv = max(4, min(K, 16))
-        dv = timed(voxel_steps, kv, 2, "voxels")
-        detail["voxels"] = {"grid": f"{VN}^3", "steps": kv, "ms_per_field": round(dv / kv * 1e3, 4), "gvoxels_s": round(VN ** 3 * kv / dv / 1e9, 2), "scaling": "strong", "y_rows_per_rank": v1 - v0, "collective": "none"}
-        vox_buf.clear()
+        bench_detail.sharded(env, detail, run_steps)
 
     # ---- per-kernel times, live, HIP events on the library's stream (rank 0 only; the other ranks wait at the barrier below)
     if rank == 0:
@@ -504,43 +456,11 @@ def main():
             ms_ero += t.timer_stop() / reps
         del zc
         detail.update({"ms_noise_kernels": round(ms_gen, 4), "ms_grid_kernel": round(ms_grid, 4), "ms_minmax_unfused": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)})
-        if not args.no_extras:  # the same step in the other noise modes (BASELINE config 2 names Perlin + domain warp): one heightmap, HIP events
-            md = {}
-            for name, m in MODES.items():
-                if m == mode:
-                    md[name] = {"ms_noise": round(ms_gen, 4), "ms_erosion": round(ms_ero, 4), "gcells_s": round(cells / (ms_gen + ms_ero) / 1e6, 3), "gcells_s_noise_only": round(cells / ms_gen / 1e6, 3)}
-                    continue
-                t.init_scene(pkg.make_config(mesh_gen_mode=m, mesh_freq_filter=9 - args.octaves))
-                mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-                t_s = time.perf_counter()
-                while (time.perf_counter() - t_s) * 1e3 < 0.5 * args.clock_warmup_ms:  # init_scene above left the chip idle for a few ms
-                    t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-                rr = 4
-                t.timer_start()
-                for _ in range(rr):
-                    mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-                msn = t.timer_stop() / rr
-                t.timer_start()
-                t.apply_erosion_dev(z.data_ptr(), N, N, mnm, args.droplets, pkg.ERODE_MINZ_IS_MIN)
-                mse = t.timer_stop()
-                fl = flops_per_cell(m, args.octaves)
-                md[name] = {"ms_noise": round(msn, 4), "ms_erosion": round(mse, 4), "gcells_s": round(cells / (msn + mse) / 1e6, 3), "gcells_s_noise_only": round(cells / msn / 1e6, 3),
-                            "tflops_8d": round(fl * cells / (msn * 1e-3) / 1e12, 2), "frac_fp32_peak": round(fl * cells / (msn * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
-            t.init_scene(pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves))
-            detail["modes"] = md
-            # dense whole-map erosion (config_heightmap.txt:78 carries 10^6 droplets; BASELINE config 3 is the 4096^2 map): one run each, wall clock with a synchronize on both sides
-            de = {}
-            for nn, dd in ((N, 1000000), (4096, 1000000), (4096, 100000)):
-                zz = z[:nn * nn] if nn * nn <= cells else torch.empty(nn * nn, dtype=torch.float32, device=dev)  # (a bench grid smaller than config 3's 4096^2 map)
-                for _pass in range(2):  # the first run of a shape allocates the scheduler's buffers (GBs for the 16384^2 ring): time the second
-                    mnd, _ = t.gen_grid_minmax_dev(zz.data_ptr(), -nn / 2, -nn / 2, st.DX_VAL, st.DY_VAL, nn, nn, pkg.GEN_GLACIATE)
-                    t.synchronize()
-                    t0 = time.perf_counter()
-                    t.apply_erosion_dev(zz.data_ptr(), nn, nn, mnd, dd, pkg.ERODE_MINZ_IS_MIN)
-                    t.synchronize()
-                    sec = time.perf_counter() - t0
-                de[f"{nn}x{nn}_{dd}_droplets"] = {"ms": round(sec * 1e3, 2), "mdroplets_s": round(dd / sec / 1e6, 3), "rounds": t.erosion_report().rounds}
-            detail["dense_erosion"] = de
+        if not args.no_extras:
+            bench_detail.modes_and_dense(env, detail, ms_gen, ms_ero)
+            if world == 1:  # (rank 0 alone runs these: no collective with another rank inside)
+                bench_detail.end_to_end(env, detail)
+                bench_detail.onegrid_rank_floor(env, detail, args.simulate_world)
     barrier()
 
     if rank == 0:
@@ -566,7 +486,7 @@ def main():
         roof = {"bound": "valu", "kernel": "k_sine_grid (+table kernels)" if mode == 0 else f"k_noise_grid<{args.mode}>", "achieved": round(tflops, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "algorithmic_flops": fl * cells, "algorithmic_bytes": 4 * cells,
                 "hbm_achieved_gbs": round(hbm, 2), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm / HBM_PEAK_GBS, 4),
-                "nofma_peak_tops": VALU_NOFMA_TOPS, "nofma_frac": round(tflops / VALU_NOFMA_TOPS, 4),
+                "nofma_peak_tops": VALU_NOFMA_TOPS, "nofma_frac": round(tflops / VALU_NOFMA_TOPS, 4), "operative_ceiling": "nofma_frac (bit parity forbids the fused multiply-add the fp32 peak counts)",
                 "note": "fp32 VALU bound; the peak counts fused multiply-adds at 2.4 GHz.  Bit-parity with the FMA-free CPU reference forbids fusing (mul and add issue separately): nofma_frac is the "
                         "fraction of that rate; and the chip sustains ~1.94 GHz under this kernel (GRBM_GUI_ACTIVE / duration, profiles/r04_clock_ramp.txt): at the clock it gets, its ~6000 "
                         "VALU instructions per wave (5120 of them the sum) keep the vector ALUs issuing ~90 % of the time (profiles/r04_pmc_summary.txt); the f32 matrix instructions share that datapath "
@@ -574,7 +494,8 @@ def main():
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
                "value_strong": None if value_strong is None else round(value_strong, 4), "value_weak": None if value_weak is None else round(value_weak, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if (args.workload in ("heightmap", "regions") and scaling == "weak") else 1, "parallelism": par},
+               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if (args.workload in ("heightmap", "regions") and scaling == "weak") else 1, "handoff": args.handoff,
+                          "ROC_ACTIVE_WAIT_TIMEOUT": os.environ.get("ROC_ACTIVE_WAIT_TIMEOUT"), "parallelism": par},
                "latency_ms_single": detail.get("single", {}).get("latency_ms_single", round(ms_step, 4) if P == 1 else None),
                "roofline": roof, "detail": dict(detail, erosion=rep, rccl=rccl_note,
                                                   clock_warmup={"ms": args.clock_warmup_ms, "untimed_steps_run": spin_log,

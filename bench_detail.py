@@ -1,0 +1,257 @@
+"""bench_detail.py -- the measurements bench.py reports under `detail` beside the headline (same run, same contexts): the sharded workloads (strips / tiles / voxels),
+one heightmap in flight, the other noise modes, dense erosion, the END-TO-END rates with the z grid delivered to host memory, and the per-rank step floor of the
+one-grid line at a simulated world size.  `env` is bench.py's namespace of the run (contexts, grids, the timed() helper ...)."""
+import os
+import time
+
+FP32_PEAK_TFLOPS = 157.3
+
+
+def flops_per_cell(mode, octaves):
+    """sine 2 flop per term (10 terms per octave); fBm 70 flop per octave and evaluation, domain warp = 5 evaluations."""
+    return 20.0 * octaves if mode == 0 else 70.0 * octaves * (5 if mode == 4 else 1)
+
+
+def strips_steps_fn(env):
+    """strong scaling of ONE grid, the noise + min half: row strips + all_reduce(min) of one float"""
+    pkg, t, z, st, N, dist = env.pkg, env.t, env.z, env.st, env.N, env.dist
+    r0, r1 = env.dmod.strip_rows(N, env.rank, env.world)
+    red = env.torch.zeros(1, dtype=env.torch.float32, device=env.coll_dev)
+
+    def fn(k):
+        for _ in range(k):
+            mn, _ = t.gen_grid_rows_minmax_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, r0, r1 - r0, pkg.GEN_GLACIATE)
+            if env.have_group:
+                red[0] = mn
+                dist.all_reduce(red, op=dist.ReduceOp.MIN)  # min(vals) of the whole map: what run_erosion / from_floats need next
+                mn = float(red.item())
+    return fn, r1 - r0
+
+
+def tiles_steps_fn(env, droplets):
+    """strong scaling of BASELINE config 4: 64 x 64 tiles block-partitioned, no collective"""
+    torch, t, dev = env.torch, env.t, env.dev
+    my_tiles, bufs = env.my_tiles, env.tile_bufs
+    nt = len(my_tiles)
+
+    def fn(k):
+        if nt == 0:
+            return
+        if not bufs:
+            bufs["z"] = torch.empty(nt * 130 * 130, dtype=torch.float32, device=dev)
+            bufs["st"] = torch.empty(nt * 39 * 4, dtype=torch.uint8, device=dev)
+            bufs["nm"] = torch.empty(nt * 129 * 129 * 4, dtype=torch.uint8, device=dev)
+            bufs["mnz"] = torch.empty(nt, dtype=torch.float32, device=dev)
+        for _ in range(k):
+            t.tiles_create_zvals_dev(my_tiles, droplets, bufs["z"].data_ptr(), bufs["st"].data_ptr(), bufs["nm"].data_ptr(), bufs["mnz"].data_ptr())
+        t.synchronize()
+    return fn
+
+
+def sharded(env, detail, run_steps):
+    """single / strips / tiles / voxels: all ranks take part"""
+    args, K, P, world, cells = env.args, env.args.steps, env.P, env.world, env.cells
+    ke = max(4, min(K, 16))
+    if args.workload != "heightmap" or P > 1:
+        d1 = env.timed(lambda k: run_steps(k, 1), ke, 2, "single")
+        detail["single"] = {"pipelines": 1, "steps": ke, "latency_ms_single": round(d1 / ke * 1e3, 4), "gcells_s": round(world * cells * ke / d1 / 1e9, 3), "scaling": "weak",
+                            "note": "one heightmap in flight per GPU: noise and erosion of a map do not overlap with another map's"}
+    if args.workload != "strips":
+        fn, rows = strips_steps_fn(env)
+        ds = env.timed(fn, ke, 2, "strips")
+        coll = ("all_reduce(min) of one float per step over " + env.backend_name + (" (one-rank group)" if world == 1 else "")) if env.have_group else "none (no process group)"
+        detail["strips"] = {"steps": ke, "ms_per_step": round(ds / ke * 1e3, 4), "gcells_s": round(cells * ke / ds / 1e9, 3), "scaling": "strong", "rows_per_rank": rows, "collective": coll,
+                            "erosion": "excluded: one shared grid in serial droplet order does not shard (replicas only)"}
+    if args.workload != "tiles":
+        dt0 = env.timed(tiles_steps_fn(env, 0), ke, 2, "tiles_0")
+        kt = max(2, min(K, 3))
+        dt1 = env.timed(tiles_steps_fn(env, 1000), kt, 1, "tiles_1000")
+        ntile = len(env.all_tiles)
+        tc = ntile * 130 * 130
+        detail["tiles"] = {"tiles": ntile, "tiles_per_rank": len(env.my_tiles), "scaling": "strong", "collective": "none",
+                           "erosion_0": {"steps": ke, "ms_per_batch": round(dt0 / ke * 1e3, 4), "gcells_s": round(tc * ke / dt0 / 1e9, 3), "mtiles_s": round(ntile * ke / dt0 / 1e6, 3)},
+                           "erosion_1000": {"steps": kt, "ms_per_batch": round(dt1 / kt * 1e3, 3), "gcells_s": round(tc * kt / dt1 / 1e9, 4), "ktiles_s": round(ntile * kt / dt1 / 1e3, 2)}}
+    # BASELINE config 5: ONE 512^3 voxel field (voxel_manager::create_procedural, sine mode) as y slabs, no collective
+    VN = 512
+    v0, v1 = env.dmod.strip_rows(VN, env.rank, world)
+    buf = {}
+
+    def voxel_steps(k):
+        if v1 <= v0:
+            return
+        if not buf:
+            buf["v"] = env.torch.empty((v1 - v0) * VN * VN, dtype=env.torch.float32, device=env.dev)
+        for _ in range(k):
+            env.t.voxel_fill_slab_dev(buf["v"].data_ptr(), VN, VN, VN, (-1.0, -1.0, -0.25), (2.0 / VN, 2.0 / VN, 0.5 / VN), (0.0, 0.0, 0.0), 1.0, 1.0, 123, 456, 0, 0.0, 1, v0, v1 - v0)
+        env.t.synchronize()
+    dv = env.timed(voxel_steps, ke, 2, "voxels")
+    detail["voxels"] = {"grid": f"{VN}^3", "steps": ke, "ms_per_field": round(dv / ke * 1e3, 4), "gvoxels_s": round(VN ** 3 * ke / dv / 1e9, 2), "scaling": "strong", "y_rows_per_rank": v1 - v0, "collective": "none"}
+
+
+def modes_and_dense(env, detail, ms_gen, ms_ero):
+    """rank 0: the same 16384^2 step in the other noise modes (BASELINE config 2 names Perlin + domain warp); dense whole-map erosion (config_heightmap.txt:78, BASELINE config 3)"""
+    pkg, t, z, st, N, cells, args, torch = env.pkg, env.t, env.z, env.st, env.N, env.cells, env.args, env.torch
+    x0, y0 = env.x0, env.y0
+    md = {}
+    for name, m in env.MODES.items():
+        if m == env.mode:
+            md[name] = {"ms_noise": round(ms_gen, 4), "ms_erosion": round(ms_ero, 4), "gcells_s": round(cells / (ms_gen + ms_ero) / 1e6, 3), "gcells_s_noise_only": round(cells / ms_gen / 1e6, 3)}
+            continue
+        t.init_scene(pkg.make_config(mesh_gen_mode=m, mesh_freq_filter=9 - args.octaves))
+        mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < 0.5 * args.clock_warmup_ms:  # init_scene above left the chip idle for a few ms
+            t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        rr = 4
+        t.timer_start()
+        for _ in range(rr):
+            mnm, _ = t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+        msn = t.timer_stop() / rr
+        t.timer_start()
+        t.apply_erosion_dev(z.data_ptr(), N, N, mnm, args.droplets, pkg.ERODE_MINZ_IS_MIN)
+        mse = t.timer_stop()
+        fl = flops_per_cell(m, args.octaves)
+        md[name] = {"ms_noise": round(msn, 4), "ms_erosion": round(mse, 4), "gcells_s": round(cells / (msn + mse) / 1e6, 3), "gcells_s_noise_only": round(cells / msn / 1e6, 3),
+                    "tflops_8d": round(fl * cells / (msn * 1e-3) / 1e12, 2), "frac_fp32_peak": round(fl * cells / (msn * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}
+    t.init_scene(pkg.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - args.octaves))
+    detail["modes"] = md
+    de = {}
+    for nn, dd in ((N, 1000000), (4096, 1000000), (4096, 100000)):
+        zz = z[:nn * nn] if nn * nn <= cells else torch.empty(nn * nn, dtype=torch.float32, device=env.dev)  # (a bench grid smaller than config 3's 4096^2 map)
+        for _pass in range(2):  # the first run of a shape allocates the scheduler's buffers (GBs for the 16384^2 ring): time the second
+            mnd, _ = t.gen_grid_minmax_dev(zz.data_ptr(), -nn / 2, -nn / 2, st.DX_VAL, st.DY_VAL, nn, nn, pkg.GEN_GLACIATE)
+            t.synchronize()
+            t0 = time.perf_counter()
+            t.apply_erosion_dev(zz.data_ptr(), nn, nn, mnd, dd, pkg.ERODE_MINZ_IS_MIN)
+            t.synchronize()
+            sec = time.perf_counter() - t0
+        de[f"{nn}x{nn}_{dd}_droplets"] = {"ms": round(sec * 1e3, 2), "mdroplets_s": round(dd / sec / 1e6, 3), "rounds": t.erosion_report().rounds}
+    detail["dense_erosion"] = de
+
+
+def end_to_end(env, detail):
+    """SURVEY 8(d) "(ii) end-to-end incl. D2H z": the z grid of every heightmap delivered to HOST memory.  (a) the library: noise + min + erosion on the device, map i
+    on the PCIe link (terra_download_async: bands on four streams, csrc/terra_xfer.hpp) while map i + 1 is computed -- into a pinned array (terra_host_alloc) and into an ordinary
+    one; the link's own speed (one hipMemcpyAsync into pinned memory) beside it.  (b) the reference's OWN caller, heightmap_t::proc_gen (src/heightmap.cpp:130-151), from the
+    patched engine build (oracle/_ref/libengine_hip.so: build_arrays and apply_erosion go through include/terra.h, everything else -- the eval_index loop, from_floats -- is the
+    reference's CPU code) against the unpatched reference (oracle/_ref/liboracle_ref.so), same process, all host cores.  Rank 0, N = 1."""
+    import numpy as np
+    pkg, t, st, N, torch, dev, args = env.pkg, env.t, env.st, env.N, env.torch, env.dev, env.args
+    nbytes = N * N * 4
+    out = {}
+    g = env.z
+    hp = torch.empty(N * N, dtype=torch.float32, pin_memory=True)
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(dev); t0 = time.perf_counter(); hp.copy_(g, non_blocking=True); torch.cuda.synchronize(dev); best = min(best, time.perf_counter() - t0)
+    out["hipMemcpy_pinned_d2h_gbs"] = round(nbytes / best / 1e9, 2)
+    del hp
+    zs = [env.zs[0], env.zs[1 % len(env.zs)]] if len(env.zs) > 1 else [env.zs[0], torch.empty(N * N, dtype=torch.float32, device=dev)]
+    K = max(4, min(args.steps, 8))
+
+    def run(dsts, k):
+        for i in range(k):
+            s = i & 1
+            mn, _ = t.gen_grid_minmax_dev(zs[s].data_ptr(), env.x0, env.y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
+            t.apply_erosion_dev(zs[s].data_ptr(), N, N, mn, args.droplets, pkg.ERODE_MINZ_IS_MIN)
+            t.download_wait()                      # map i - 1 has landed: its copy ran beside this map's kernels
+            t.download_async(zs[s].data_ptr(), dsts[s])
+        t.download_wait()
+    pins = [t.pinned((N, N)) for _ in range(2)]
+    pags = [np.zeros((N, N), np.float32) for _ in range(2)]
+    for name, dsts in (("pinned", [p.array for p in pins]), ("pageable", pags)):
+        run(dsts, 2)
+        t0 = time.perf_counter(); run(dsts, K); dt = time.perf_counter() - t0
+        out[name] = {"steps": K, "ms_per_map": round(dt / K * 1e3, 3), "gcells_s": round(N * N * K / dt / 1e9, 3), "link_gbs": round(nbytes * K / dt / 1e9, 2),
+                     "frac_of_hipMemcpy_pinned": round(nbytes * K / dt / 1e9 / out["hipMemcpy_pinned_d2h_gbs"], 3)}
+    same = bool((pins[(K - 1) & 1].array == pags[(K - 1) & 1]).all())
+    out["pinned_equals_pageable"] = same
+    for p in pins:
+        p.free()
+    del pags
+    out["bound"] = "PCIe: 4 B per cell over the host link; the device side of a map (noise + erosion, ~1.5 ms at 16384^2) hides under the previous map's copy (~19 ms)"
+    # (b) engine in the loop
+    try:
+        import orclib
+        lib = orclib.engine_lib("hip")
+        if lib is None or not orclib.ref_available():
+            out["engine_proc_gen"] = {"unavailable": "oracle/_ref/libengine_hip.so / liboracle_ref.so did not travel with the repo"}
+        else:
+            eng, ref = orclib.Checker("ref", lib), orclib.Checker("ref")
+            cfg = orclib.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - args.octaves)
+            res = {"cores": ref.num_threads(), "droplets": args.droplets}
+            for n in (4096, N):
+                row = {}
+                for name, ck, hip in (("reference_cpu", ref, 0), ("engine_hip", eng, 1)):
+                    if hip:
+                        ck.set_use_hip_terrain(1)
+                    ck.init(cfg)
+                    if hip:
+                        ck.heightmap_proc_gen(256, 256, 10)  # first use: library context, scratch
+                    t0 = time.perf_counter()
+                    pix, _, _ = ck.heightmap_proc_gen(n, n, args.droplets)
+                    sec = time.perf_counter() - t0
+                    row[name] = {"s": round(sec, 4), "gcells_s": round(n * n / sec / 1e9, 4)}
+                    del pix
+                row["speedup"] = round(row["reference_cpu"]["s"] / row["engine_hip"]["s"], 2)
+                res[f"{n}x{n}"] = row
+            res["note"] = ("heightmap_t::proc_gen as the engine calls it: host vector in, 16-bit pixels out.  engine_hip = the patched reference: the grid crosses PCIe three times "
+                           "(terra_gen_collect, terra_apply_erosion in and out) and the eval_index copy loop and from_floats stay the reference's OpenMP code")
+            out["engine_proc_gen"] = res
+    except Exception as e:  # noqa: BLE001 -- reported, never fatal for the line
+        out["engine_proc_gen"] = {"error": repr(e)[:300]}
+    detail["end_to_end"] = out
+
+
+def onegrid_rank_floor(env, detail, sim_world):
+    """What ONE rank of the one-grid line does per step at world size `sim_world`, measured on this GPU: its 1/sim_world row strip of noise (table launch + grid kernel), the
+    all_reduce(min) of one float over the (one-rank) group and the host read-back -- and, every sim_world-th step, a whole-grid erosion on an eroder context beside it.  The
+    slowest of the two is the floor of the N = sim_world step: the predicted one-grid value at that world size is cells / floor (xGMI window traffic of remote droplets not
+    included: a few thousand 4 KiB loads per erosion)."""
+    pkg, N, st, torch, dist = env.pkg, env.N, env.st, env.torch, env.dist
+    t = env.t
+    rows = -(-N // sim_world)
+    z = env.z
+    K = max(16, env.args.steps)
+    red = torch.zeros(1, dtype=torch.float32, device=env.coll_dev)
+
+    def noise_steps(k, erode_every=0, ectx=None):
+        import threading
+        th = None
+        for s in range(k):
+            mn, _ = t.gen_grid_rows_minmax_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 0, rows, pkg.GEN_GLACIATE)
+            if env.have_group:
+                red[0] = mn
+                dist.all_reduce(red, op=dist.ReduceOp.MIN)
+                mn = float(red.item())
+            if erode_every and s % erode_every == 0:
+                if th is not None:
+                    th.join()
+                th = threading.Thread(target=lambda m=env.full_min: ectx.apply_erosion_dev(env.ez.data_ptr(), N, N, m, env.args.droplets, pkg.ERODE_MINZ_IS_MIN))
+                th.start()
+        if th is not None:
+            th.join()
+    t.synchronize()
+    noise_steps(8)
+    t0 = time.perf_counter(); noise_steps(K); t.synchronize(); d_noise = (time.perf_counter() - t0) / K
+    t.timer_start()
+    for _ in range(K):
+        t.gen_grid_rows_minmax_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 0, rows, pkg.GEN_GLACIATE)
+    ms_dev = t.timer_stop() / K
+    own = len(env.ctxs) < 2  # (one context = one thread at a time: the eroding thread needs a context that is not the noise loop's)
+    ectx = env.ctxs[-1]
+    if own:
+        ectx = pkg.Terra(env.local_rank); ectx.init_scene(pkg.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - env.args.octaves))
+    env.ez = env.zs[-1] if len(env.zs) > 1 else torch.empty(N * N, dtype=torch.float32, device=env.dev)
+    env.full_min, _ = ectx.gen_grid_minmax_dev(env.ez.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # a real heightmap for the erosions
+    noise_steps(sim_world, sim_world, ectx)
+    t0 = time.perf_counter(); noise_steps(K, sim_world, ectx); t.synchronize(); ectx.synchronize(); d_both = (time.perf_counter() - t0) / K
+    if own:
+        ectx.close()
+    detail["onegrid_rank_floor"] = {"simulated_world": sim_world, "rows_per_rank": rows, "steps": K,
+                                    "ms_strip_noise_device": round(ms_dev, 4), "ms_step_noise_allreduce_item": round(d_noise * 1e3, 4),
+                                    "host_and_collective_share": round(1.0 - ms_dev / (d_noise * 1e3), 3),
+                                    "ms_step_with_every_%dth_erosion" % sim_world: round(d_both * 1e3, 4),
+                                    "predicted_gcells_s_at_that_world": round(N * N / max(d_both, d_noise) / 1e9, 1),
+                                    "collective": ("all_reduce(min) over " + env.backend_name + " (one-rank group on this box)") if env.have_group else "none (no process group)",
+                                    "note": "a prediction from measured parts, not a measurement of N GPUs: remote window traffic over xGMI and the slowest-rank effect are not in it"}

@@ -160,6 +160,9 @@ typedef struct terra_event terra_event;
 int  terra_event_create(terra_ctx *ctx, terra_event **out);
 int  terra_event_record(terra_ctx *ctx, terra_event *ev);
 int  terra_event_wait(terra_ctx *ctx, terra_event *ev);
+/* the HOST waits until everything before the last record of ev has completed (hipEventSynchronize; returns at once for an event that was never recorded).  A thread that
+ * drives the next heightmap can wait for the previous map's noise kernel itself -- not for the thread that launched it to wake up, notice and tell it */
+int  terra_event_synchronize(terra_event *ev);
 void terra_event_destroy(terra_event *ev);
 
 /* ---- scene / globals.  terra_init_scene = main()'s start-up sequence for this path (src/3DWorld.cpp:2393-2460 -> gen_mesh). */

@@ -60,6 +60,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void event_record(void *) {}
 	void event_wait(void *) {}
 	static void event_destroy(void *e) {::free(e);}
+	static void event_synchronize(void *) {}
 	void timer_start() {t0 = std::chrono::steady_clock::now();}
 	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
 	template<class F> void launch_waves_nolds(size_t n, F f) {for (size_t i = 0; i < n; ++i) f(i);}

@@ -7,6 +7,7 @@ oracle, computed on the GPU box's host cores.
   headline   4 contexts on 4 host threads sharing the GPU (bench.py's pipelines), each generating and eroding its own 16384^2 regions for 3 steps
   config 3   heightmap_t::postprocess_height on heightmaps/heightmap_island_1k.png (the heightmap_island_eroded preset)
 """
+import importlib
 import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -116,8 +117,8 @@ def test_tile_batch_64x64_eroded_1000_every_tile_equals_oracle(pkg, gpu, orc):
 
 def test_headline_mode_four_contexts_in_flight_equal_oracle(pkg, orc):
     """How the headline `value` is produced: bench.py keeps 4 heightmaps in flight per GPU -- 4 terra contexts on 4 host threads sharing the device (own
-    stream, scratch, hipGraph cache and speculation ring each).  Here every context runs 3 bench steps (terra_gen_grid_minmax_dev with the fused min +
-    terra_apply_erosion_dev with the sparse clamp) on regions of its own, concurrently, and ALL 12 grids are compared with the oracle bit for bit."""
+    stream, scratch, hipGraph cache and erosion buffers each), the noise turn handed over by GPU events, min(vals) kept in HBM (3dworld_amd/pipeline.py: proc_gen_step --
+    the function bench.py times).  Here every context runs 3 of those steps on regions of its own, concurrently, and ALL 12 grids are compared with the oracle bit for bit."""
     N, droplets, P, steps = 16384, 1000, 4, 3
     ctxs = [pkg.Terra(0) for _ in range(P)]
     try:
@@ -126,6 +127,10 @@ def test_headline_mode_four_contexts_in_flight_equal_oracle(pkg, orc):
         st = sts[0]
         bufs = [[c.alloc(N * N * 4) for _ in range(steps)] for c in ctxs]
         mins = [[None] * steps for _ in range(P)]
+        pmod = importlib.import_module("3dworld_amd.pipeline")
+        turns = pmod.NoiseTurns()
+        evs = [c.event_create() for c in ctxs]
+        mms = [[c.alloc(8) for _ in range(steps)] for c in ctxs]
         errs = []
         start = threading.Barrier(P)
 
@@ -137,9 +142,8 @@ def test_headline_mode_four_contexts_in_flight_equal_oracle(pkg, orc):
                 start.wait()
                 for s in range(steps):
                     x0, y0 = region(p, s)
-                    mn, mx = ctxs[p].gen_grid_minmax_dev(bufs[p][s].ptr, x0, y0, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)
-                    ctxs[p].apply_erosion_dev(bufs[p][s].ptr, N, N, mn, droplets, pkg.ERODE_MINZ_IS_MIN)
-                    mins[p][s] = (mn, mx)
+                    pmod.proc_gen_step(pkg, ctxs[p], turns, evs[p], bufs[p][s].ptr, mms[p][s].ptr, x0, y0, st.DX_VAL, st.DY_VAL, N, N, droplets)  # bench.py's step, verbatim
+                    mins[p][s] = tuple(mms[p][s].download(np.float32, (2,)))
                 ctxs[p].synchronize()
             except Exception as e:  # noqa: BLE001
                 errs.append((p, repr(e)))

@@ -276,6 +276,47 @@ def test_streamed_pipeline_device_min_and_events_emul(pkg, emul_lib, orc):
     pc.case_streamed_pipeline(pkg, lambda: pkg.Terra(0, emul_lib), orc, N=200, maps=5, P=2, droplets=(150, 0, 600))
 
 
+def test_pipeline_step_with_event_handoff_emul(pkg, emul_lib, orc):
+    """3dworld_amd/pipeline.py (what bench.py times): three contexts on three threads, the noise turn handed over by events, min(vals) in device memory; host logic"""
+    import importlib
+    import threading
+    import orclib
+    pmod = importlib.import_module("3dworld_amd.pipeline")
+    N, P, steps, droplets = 160, 3, 3, 200
+    ctxs = [pkg.Terra(0, emul_lib) for _ in range(P)]
+    try:
+        cfg = pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1)
+        st = [c.init_scene(cfg) for c in ctxs][0]
+        turns = pmod.NoiseTurns()
+        evs = [c.event_create() for c in ctxs]
+        z = [[c.alloc(N * N * 4) for _ in range(steps)] for c in ctxs]
+        mm = [[c.alloc(8) for _ in range(steps)] for c in ctxs]
+        errs = []
+
+        def worker(p):
+            try:
+                for s in range(steps):
+                    pmod.proc_gen_step(pkg, ctxs[p], turns, evs[p], z[p][s].ptr, mm[p][s].ptr, -N / 2 + (p + P * s) * N, -N / 2, st.DX_VAL, st.DY_VAL, N, N, droplets)
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
+        [x.start() for x in th]; [x.join() for x in th]
+        assert not errs, errs
+        orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+        for p in range(P):
+            for s in range(steps):
+                ref = orc.gen_grid(-N / 2 + (p + P * s) * N, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 1)
+                mn, mx = mm[p][s].download(np.float32, (2,))
+                assert (mn, mx) == (ref.min(), ref.max())
+                orc.apply_erosion(ref, float(ref.min()), droplets)
+                orclib.assert_bit_equal(ref, z[p][s].download(np.float32, (N, N)), f"pipeline {p} step {s}")
+        for c, e in zip(ctxs, evs):
+            c.event_destroy(e)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_erosion_ring_is_capped_by_free_memory_and_scratch_can_be_released(pkg, emul_lib, orc, monkeypatch):
     """the speculation ring shrinks to what the device has free (TERRA_ERO_MEM_BUDGET pretends a small device) -- more ring generations, the same result; and
     terra_release_scratch between calls changes nothing either"""
