@@ -47,6 +47,8 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
 		for (graph_slot_t &g : graphs) {graph_drop(g);}
+		if (relay_ev) (void)hipEventDestroy(relay_ev);
+		if (side_stream) (void)hipStreamDestroy(side_stream);
 		if (own_stream) (void)hipStreamDestroy(own_stream);
 	}
 	size_t mem_free() {use(); size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) != hipSuccess) {(void)hipGetLastError(); return ~(size_t)0 >> 1;} return f;}
@@ -137,7 +139,17 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	static void vm_free(void *base, size_t total) {if (base) (void)hipMemAddressFree(base, total);}
 	// stream-level ordering between contexts (terra_event_*): an event recorded on one context's stream, waited for by another's -- the host never blocks
 	void *event_create() {use(); hipEvent_t e = nullptr; TERRA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return (void *)e;}
-	void event_record(void *e) {use(); TERRA_HIP_CHECK(hipEventRecord((hipEvent_t)e, stream));}
+	// An event that another THREAD may wait for on the host (terra_event_synchronize) must not be "last recorded" in a stream that later enters graph capture -- the runtime
+	// then refuses the wait and poisons the capture (hipErrorStreamCaptureUnsupported; the erosion schedulers capture their rounds on first use) -- so the record goes through
+	// a side stream of the context that never captures: [stream: relay event] -> [side stream: wait relay, record e]
+	hipStream_t side_stream = nullptr; hipEvent_t relay_ev = nullptr;
+	void event_record(void *e) {
+		use();
+		if (!side_stream) {TERRA_HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking)); TERRA_HIP_CHECK(hipEventCreateWithFlags(&relay_ev, hipEventDisableTiming));}
+		TERRA_HIP_CHECK(hipEventRecord(relay_ev, stream));
+		TERRA_HIP_CHECK(hipStreamWaitEvent(side_stream, relay_ev, 0));
+		TERRA_HIP_CHECK(hipEventRecord((hipEvent_t)e, side_stream));
+	}
 	void event_wait(void *e) {use(); TERRA_HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)e, 0));}
 	static void event_destroy(void *e) {if (e) (void)hipEventDestroy((hipEvent_t)e);}
 	static void event_synchronize(void *e) {TERRA_HIP_CHECK(hipEventSynchronize((hipEvent_t)e));}

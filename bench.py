@@ -64,7 +64,6 @@ def parse():
     p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
     p.add_argument("--handoff", default="event", choices=["event", "semaphore", "none"], help="how the heightmaps in flight take turns in their noise phase: event = the next map's thread waits on the host for the "
                    "GPU event behind the previous map's noise kernel, min(vals) stays in HBM (3dworld_amd/pipeline.py); semaphore = a host semaphore around a synchronous noise call (rounds 1-4); none = no turns")
-    p.add_argument("--active-wait-us", type=int, default=2000, help="ROC_ACTIVE_WAIT_TIMEOUT for this process (microseconds a completion wait spins before it blocks; 0 = the runtime's default)")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
                         "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
@@ -160,10 +159,6 @@ class c_stdout_to_stderr:
 
 def main():
     args = parse()
-    # the runtime's completion waits (hipEventSynchronize of the noise hand-over, the read-backs) spin this long before they block: a blocked thread costs a wake-up of tens of
-    # microseconds on the step's critical path, a spinning one a few (a serving process pins a core per heightmap in flight; profiles/r05_handoff_ab.txt)
-    if args.active_wait_us > 0:
-        os.environ.setdefault("ROC_ACTIVE_WAIT_TIMEOUT", str(args.active_wait_us))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -294,19 +289,27 @@ def main():
                     return False
                 left[0] -= 1
                 return True
+        errs = []
+
         def worker(p):
             first = True
-            if p > 0:
-                first_noise_done[p - 1].wait()
-            while take():
-                step(p, first_noise_done[p] if first else None)
-                first = False
-            first_noise_done[p].set()  # also when this worker had no step at all
+            try:
+                if p > 0:
+                    first_noise_done[p - 1].wait()
+                while not errs and take():
+                    step(p, first_noise_done[p] if first else None)
+                    first = False
+            except Exception as e:  # noqa: BLE001 -- reported by the caller's thread; nobody is left waiting for this worker
+                errs.append(repr(e))
+            finally:
+                first_noise_done[p].set()  # also when this worker had no step at all
         th = [threading.Thread(target=worker, args=(p,)) for p in range(npipe)]
         for x in th:
             x.start()
         for x in th:
             x.join()
+        if errs:
+            raise RuntimeError("pipeline worker failed: " + "; ".join(errs))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -494,8 +497,7 @@ def main():
         out = {"metric": "heightmap Gcells/sec (noise+erosion), 16384^2 grid", "value": round(value, 4), "unit": "Gcells/s", "n_gpus": world, "steps": K, "warmup": W,
                "value_strong": None if value_strong is None else round(value_strong, 4), "value_weak": None if value_weak is None else round(value_weak, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if (args.workload in ("heightmap", "regions") and scaling == "weak") else 1, "handoff": args.handoff,
-                          "ROC_ACTIVE_WAIT_TIMEOUT": os.environ.get("ROC_ACTIVE_WAIT_TIMEOUT"), "parallelism": par},
+               "config": {"workload": workload, "mesh_gen_mode": mode, "octaves": args.octaves, "droplets": args.droplets, "grid": N, "pipelines_per_gpu": P if (args.workload in ("heightmap", "regions") and scaling == "weak") else 1, "handoff": args.handoff, "parallelism": par},
                "latency_ms_single": detail.get("single", {}).get("latency_ms_single", round(ms_step, 4) if P == 1 else None),
                "roofline": roof, "detail": dict(detail, erosion=rep, rccl=rccl_note,
                                                   clock_warmup={"ms": args.clock_warmup_ms, "untimed_steps_run": spin_log,

@@ -398,6 +398,55 @@ def test_overlapped_download_equals_synchronous(pkg, gpu, orc):
     pc.case_big_transfers(pkg, gpu, orc)
 
 
+def test_host_wait_on_an_event_while_its_context_captures_a_graph(pkg, orc):
+    """terra_event_synchronize from another thread while the recording context captures erosion rounds into hipGraphs (first use of every new grid shape / droplet count):
+    the runtime refuses a host wait on an event "last recorded in a capturing stream" and poisons the capture, so terra_event_record goes through a side stream that never
+    captures.  One thread records + erodes with a new graph key every time, the other waits on every event; nothing fails, every grid equals the oracle."""
+    import threading
+    a, b = pkg.Terra(0), pkg.Terra(0)
+    try:
+        pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
+        st = a.init_scene(pc_); b.init_scene(pc_); orc.init(oc)
+        n, rounds = 384, 12
+        bufs = [a.alloc(n * n * 4) for _ in range(rounds)]
+        mm = a.alloc(8)
+        ev = a.event_create()
+        recorded = [threading.Event() for _ in range(rounds)]
+        errs = []
+
+        def producer():
+            try:
+                for i in range(rounds):
+                    a.gen_grid_minmax_async_dev(bufs[i].ptr, -n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, mm.ptr, pkg.GEN_GLACIATE)
+                    a.event_record(ev); recorded[i].set()
+                    a.apply_erosion_devmin_dev(bufs[i].ptr, n, n, mm.ptr, 50 + 37 * i, 0)  # a droplet count never seen before: its rounds are captured now
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+            finally:
+                for r in recorded:
+                    r.set()
+
+        def waiter():
+            try:
+                for i in range(rounds):
+                    recorded[i].wait()
+                    for _ in range(200):
+                        b.event_synchronize(ev)
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=producer), threading.Thread(target=waiter)]
+        [x.start() for x in th]; [x.join() for x in th]
+        assert not errs, errs
+        a.synchronize()
+        ref0 = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+        for i in (0, 5, rounds - 1):
+            ref = ref0.copy(); orc.apply_erosion(ref, float(ref0.min()), 50 + 37 * i)
+            assert_bit_equal(ref, bufs[i].download(np.float32, (n, n)), f"grid {i}")
+        a.event_destroy(ev)
+    finally:
+        a.close(); b.close()
+
+
 def test_streamed_pipeline_device_min_and_events(pkg, orc):
     """bench.py's streamed schedule: a producer context's noise kernels back to back, {min, max} left in HBM, three consumer contexts eroding as the events fire"""
     pc.case_streamed_pipeline(pkg, lambda: pkg.Terra(0), orc, N=2048, maps=9, P=3, droplets=(1000, 0, 6000))

@@ -28,12 +28,12 @@ prof() { # prof <name> <command...>: kernel trace + stats, summarised
 cd "$ROOT"
 case $CMD in
 check)
-	timeout 1700 python -m pytest tests -m gpu -x -q --durations=8 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$OUT/pytest_gpu.log"; tail -14 "$OUT/pytest_gpu.log"
+	timeout 600 python -m pytest tests -m gpu -x -q --durations=8 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$OUT/pytest_gpu.log"; tail -14 "$OUT/pytest_gpu.log"
 	timeout 600 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc $?"; tail -2 "$OUT/smoke.log"
 	timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags_line.json" 2> "$OUT/bench.err"; echo "bench rc $?"; tail -c 1500 "$OUT/bench_driver_flags_line.json" | head -c 1500; echo
 	;;
 tests)
-	timeout 1700 python -m pytest -m gpu -x -q --durations=8 "$@" > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$OUT/pytest_gpu.log"; tail -25 "$OUT/pytest_gpu.log"
+	timeout ${TESTS_TIMEOUT:-500} python -m pytest -m gpu -x -q --durations=8 "$@" > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$OUT/pytest_gpu.log"; tail -25 "$OUT/pytest_gpu.log"
 	;;
 bench)
 	if [ $# -eq 0 ]; then
@@ -130,7 +130,7 @@ ab)
 	for rep in $(seq 1 "$REPS"); do
 		for v in "$@"; do
 			IFS='|' read -r NAME ENVS ARGS <<< "$v"
-			line=$(env $ENVS timeout 120 python bench.py --headline-only --no-cpu-baseline --no-rccl-world1 $ARGS 2>> "$OUT/ab.err" | tail -1)
+			line=$(env $ENVS timeout 60 python bench.py --headline-only --no-cpu-baseline --no-rccl-world1 $ARGS 2>> "$OUT/ab.err" | tail -1)
 			echo "$NAME | $(python -c "import json,sys; d=json.loads(sys.argv[1]); print(d['value'], 'Gcells/s', d['ms_per_step'], 'ms/step')" "$line" 2>/dev/null || echo "FAILED: $line")" | tee -a "$OUT/ab.txt"
 		done
 	done
