@@ -325,6 +325,20 @@ int terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height
 	TERRA_CATCH
 }
 
+// host form: what heightmap_t::proc_gen leaves in the texture's pixel buffer (src/heightmap.cpp:130-151) -- 2 bytes per cell cross the host link, nothing else
+int terra_heightmap_proc_gen(terra_ctx *ctx, uint32_t width, uint32_t height, uint32_t erosion_iters, uint8_t *h_pix, float *h_range) {
+	TERRA_CHECK_CTX if (!h_pix) return terra::fail(TERRA_ERR_ARG, "null output");
+	if (width == 0 || height == 0) return terra::fail(TERRA_ERR_ARG, "terra_heightmap_proc_gen: empty map");
+	TERRA_TRY
+		size_t const n = (size_t)width*height;
+		uint8_t *d = (uint8_t *)ctx->eng.host_grid_scratch(n*6 + 512); // floats, then the 16-bit pixels (16-byte aligned)
+		uint8_t *d_pix = d + ((n*4 + 255) & ~(size_t)255);
+		int const rc = terra_heightmap_proc_gen_dev(ctx, width, height, erosion_iters, (float *)d, d_pix, h_range);
+		if (rc != TERRA_OK) return rc;
+		ctx->eng.be.d2h(h_pix, d_pix, n*2);
+	TERRA_CATCH
+}
+
 // ---- the loaded-heightmap path (rest of row a12): heightmap_t::to_floats / from_floats / postprocess_height (src/heightmap.cpp:117-128,191-215)
 int terra_set_mesh_file_scale(terra_ctx *ctx, float mesh_file_scale, float mesh_file_tz) {
 	TERRA_CHECK_CTX

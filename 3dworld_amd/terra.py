@@ -175,6 +175,7 @@ _PROTOS = {
     "terra_tiles_create_weights": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_ao_lighting_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "terra_tiles_ao_lighting": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "terra_heightmap_proc_gen": (_i32, [_vp, _u32, _u32, _u32, _vp, _f3]),
     "terra_heightmap_proc_gen_dev": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "terra_minmax_dev": (_i32, [_vp, _vp, _sz, _f3, _f3]),
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
@@ -593,6 +594,13 @@ class Terra:
         rng = (C.c_float * 2)()
         self._ck(self.lib.terra_heightmap_proc_gen_dev(self.ctx, width, height, erosion_iters, ptr, pix_ptr, C.addressof(rng)))
         return rng[0], rng[1]
+
+    def heightmap_proc_gen(self, width, height, erosion_iters):
+        """-> (pixels u8 [h, w, 2], min_z, dz): heightmap_t::proc_gen's texture on the host"""
+        pix = np.empty((height, width, 2), np.uint8)
+        rng = (C.c_float * 2)()
+        self._ck(self.lib.terra_heightmap_proc_gen(self.ctx, width, height, erosion_iters, pix.ctypes.data, rng))
+        return pix, rng[0], rng[1]
 
     def minmax_dev(self, ptr, n):
         mn, mx = C.c_float(), C.c_float()

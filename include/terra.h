@@ -238,6 +238,9 @@ int  terra_set_erosion_slice_steps(terra_ctx *ctx, uint32_t slice_steps);
  * d_vals: width*height floats (final z); d_pixels16: optional 2 bytes per pixel {lo, hi} (from_floats/write_pixel_16_bits);
  * h_range: optional {min_z, dz} used for the 16-bit scale. */
 int  terra_heightmap_proc_gen_dev(terra_ctx *ctx, uint32_t width, uint32_t height, uint32_t erosion_iters, float *d_vals, uint8_t *d_pixels16, float *h_range);
+/* the same with the 16-bit pixels delivered to HOST memory (h_pixels16: 2*width*height bytes, what proc_gen leaves in the texture): the drop-in for the whole body of
+ * heightmap_t::proc_gen when there are no cities -- 2 bytes per cell cross the host link instead of three float grids */
+int  terra_heightmap_proc_gen(terra_ctx *ctx, uint32_t width, uint32_t height, uint32_t erosion_iters, uint8_t *h_pixels16, float *h_range);
 int  terra_minmax_dev(terra_ctx *ctx, const float *d_vals, size_t n, float *h_min, float *h_max); /* synchronous */
 int  terra_quantize16_dev(terra_ctx *ctx, const float *d_vals, size_t n, float min_z, float dz, uint8_t *d_pixels16);
 

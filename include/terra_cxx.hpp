@@ -72,6 +72,13 @@ inline void apply_erosion(float *heightmap, int xsize, int ysize, float min_zval
 	check(terra_apply_erosion(default_ctx(), heightmap, xsize, ysize, min_zval, num_iters), "apply_erosion");
 }
 
+// heightmap_t::proc_gen (src/heightmap.cpp:130-151) as one call: the texture's 16-bit pixels + {min_z, dz} for set_mesh_height_scales_for_zval_range(min_z, dz/255)
+inline void heightmap_proc_gen(unsigned width, unsigned height, unsigned erosion_iters, unsigned char *pixels16, float &min_z, float &dz) {
+	float range[2] = {0.0f, 0.0f};
+	check(terra_heightmap_proc_gen(default_ctx(), width, height, erosion_iters, pixels16, range), "heightmap_proc_gen");
+	min_z = range[0]; dz = range[1];
+}
+
 // tile_t::create_zvals for a batch of tiles (src/tiled_mesh.cpp:467-546): zvals n*130*130, stats n, normals n*129*129*4 (optional)
 // ---- eval_mesh_sin_terms (src/mesh_gen.cpp:797-805): point query, evaluated on the host
 inline float eval_mesh_sin_terms(float xv, float yv) {

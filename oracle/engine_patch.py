@@ -11,6 +11,7 @@ What is patched (every anchor must be found exactly once, otherwise the script f
   src/mesh_gen.cpp  `bool use_hip_terrain`; build_arrays(): the HIP backend beside the GL one -- launch / no_wait / collect into cached_vals;
                     eval_index(): a first sine term above start_eval_sin goes through terra_gen_eval_index; clear_context(): destroy the handle   (section 2)
   src/erosion.cpp   apply_erosion(): one line that hands the call to terra_cxx::apply_erosion                                               (section 3)
+  src/heightmap.cpp heightmap_t::proc_gen(): the whole body as one call (terra_cxx::heightmap_proc_gen) when there are no cities                    (section 4)
 """
 import os
 import shutil
@@ -70,6 +71,20 @@ def main(ref, out):
                  '#include "terra_cxx.hpp"\nextern bool use_hip_terrain;\nextern unsigned hip_terrain_calls;\n\n'
                  "void apply_erosion(float *heightmap, int xsize, int ysize, float min_zval, unsigned num_iters) {\n"
                  "\tif (use_hip_terrain) {++hip_terrain_calls; terra_cxx::apply_erosion(heightmap, xsize, ysize, min_zval, num_iters); return;} // serial-order-exact\n", "apply_erosion")
+    open(p, "w").write(t)
+    # ---- heightmap.cpp (section 4): the whole of proc_gen on the device when there are no cities -- the texture's pixels are the only thing that crosses the host link
+    p = os.path.join(out, "heightmap.cpp")
+    t = open(p).read()
+    t = sub_once(t, "void heightmap_t::proc_gen() {\n\tset_16_bit_grayscale();\n\talloc();\n",
+                 '#include "terra_cxx.hpp"\nextern bool use_hip_terrain;\nextern unsigned hip_terrain_calls;\nbool use_hip_proc_gen(1); // (test only: 0 keeps proc_gen\'s own body, whose build_arrays / apply_erosion then go through sections 2 and 3)\n\n'
+                 "void heightmap_t::proc_gen() {\n\tset_16_bit_grayscale();\n\talloc();\n"
+                 "\tif (use_hip_terrain && use_hip_proc_gen && !have_cities()) { // eval loop, min, erosion, z range and from_floats in one call\n"
+                 "\t\t++hip_terrain_calls;\n"
+                 "\t\tfloat min_z(0), dz(0);\n"
+                 "\t\tterra_cxx::heightmap_proc_gen(width, height, erosion_iters_tt, get_data(), min_z, dz);\n"
+                 "\t\tset_mesh_height_scales_for_zval_range(min_z, dz/255.0);\n"
+                 "\t\treturn;\n"
+                 "\t}\n", "proc_gen")
     open(p, "w").write(t)
     print(f"engine_patch: {out} ready ({len(os.listdir(out))} files)")
 

@@ -244,6 +244,8 @@ REF_API void ref_init(ref_config_t const *c) { // the engine derives its globals
 REF_API void ref_set_use_hip_terrain(int v) {use_hip_terrain = (v != 0); if (use_hip_terrain) {terra_sync_globals();}}
 REF_API int  ref_get_use_hip_terrain() {return use_hip_terrain ? 1 : 0;}
 extern unsigned hip_terrain_calls;
+extern bool use_hip_proc_gen;
+REF_API void ref_set_use_hip_proc_gen(int v) {use_hip_proc_gen = (v != 0);}
 REF_API unsigned ref_hip_terrain_calls() {return hip_terrain_calls;} // build_arrays + apply_erosion calls that went through include/terra.h
 static void ref_init_engine(ref_config_t const *c) {
 #else

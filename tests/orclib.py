@@ -200,6 +200,7 @@ class Checker:
             f("set_use_hip_terrain", None, [C.c_int])
             f("get_use_hip_terrain", C.c_int, [])
             f("hip_terrain_calls", C.c_uint, [])
+            f("set_use_hip_proc_gen", None, [C.c_int])
         if kind == "orc":
             f("apply_erosion_stats", None, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint, C.POINTER(ErosionStats), C.c_void_p])
 
@@ -225,6 +226,7 @@ class Checker:
     def set_start_eval_sin(self, v): self._set_start_eval_sin(v)
     def set_erode_amount(self, v): self._set_erode_amount(v)
     def set_use_hip_terrain(self, v): self._set_use_hip_terrain(int(v))
+    def set_use_hip_proc_gen(self, v): self._set_use_hip_proc_gen(int(v))
     def set_num_threads(self, n): self._set_num_threads(n)
     def num_threads(self): return self._num_threads()
     def get_max_sea_level(self): return self._get_max_sea_level()

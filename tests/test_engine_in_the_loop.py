@@ -33,10 +33,15 @@ def engine_vs_reference(eng, ref, modes=((0, 0), (1, 0), (0, 1))):
         se, sr = eng.init(cfg), ref.init(cfg)  # the engine derives its globals with its own CPU code, then hands them over
         assert bytes(se.sinTable) == bytes(sr.sinTable) and se.zmax_est == sr.zmax_est and se.water_plane_z == sr.water_plane_z
         # heightmap_t::proc_gen: build_arrays + enable_glaciate + eval_index loop, run_erosion -> apply_erosion, from_floats
-        for w, h, iters in ((96, 64, 0), (160, 128, 400)):
-            pe, se_, te_ = eng.heightmap_proc_gen(w, h, iters)
-            pr, sr_, tr_ = ref.heightmap_proc_gen(w, h, iters)
-            assert (pe == pr).all() and (se_, te_) == (sr_, tr_), f"proc_gen {w}x{h} iters {iters} mode {mode}"
+        # -- as ONE call (the texture's pixels are all that crosses the host link), and with proc_gen's own body kept (its build_arrays and
+        # apply_erosion then cross the boundary one by one: sections 2 and 3)
+        for whole in (1, 0):
+            eng.set_use_hip_proc_gen(whole)
+            for w, h, iters in ((96, 64, 0), (160, 128, 400)):
+                pe, se_, te_ = eng.heightmap_proc_gen(w, h, iters)
+                pr, sr_, tr_ = ref.heightmap_proc_gen(w, h, iters)
+                assert (pe == pr).all() and (se_, te_) == (sr_, tr_), f"proc_gen {w}x{h} iters {iters} mode {mode} whole {whole}"
+        eng.set_use_hip_proc_gen(1)
         # tile_t::create_zvals: the tile's generator object, the eval loop, apply_erosion on the tile, sub-block stats
         for tx, ty, iters in ((0, 0, 0), (-3, 2, 120), (5, -7, 60)):
             ze, ste = eng.tile_create_zvals(tx, ty, iters)
@@ -54,8 +59,8 @@ def engine_vs_reference(eng, ref, modes=((0, 0), (1, 0), (0, 1))):
         we, ge, he = eng.tile_create_weights(1, 1, z0)
         wr, gr, hr = ref.tile_create_weights(1, 1, z0)
         assert (we == wr).all() and ge.tobytes() == gr.tobytes() and he == hr
-        # the calls above really crossed the boundary: 2 proc_gen (2 build_arrays + 1 erosion), 3 tiles (3 + 2), 4 generator objects, create_texture's noise field
-        assert eng._hip_terrain_calls() - calls0 >= 13, eng._hip_terrain_calls() - calls0
+        # the calls above really crossed the boundary: 2 proc_gen as one call each + 2 piecewise (2 build_arrays + 1 erosion), 3 tiles (3 + 2), 4 generator objects, create_texture's noise field
+        assert eng._hip_terrain_calls() - calls0 >= 15, eng._hip_terrain_calls() - calls0
         calls0 = eng._hip_terrain_calls()
         # the patched engine with the key off is the reference
         eng.set_use_hip_terrain(0)

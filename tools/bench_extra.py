@@ -70,6 +70,11 @@ for name, mode in (("sine", 0), ("simplex", 1)):
         if mode == 1 and it: continue
         ms = timed(lambda: t.tiles_create_zvals_dev(tiles, it, zt.ptr, stt.ptr, nm.ptr, mz.ptr), reps=2)
         out[f"C4_tiles64x64_{name}_{it}iters"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3), "gcells_s": round(n * 130 * 130 / ms / 1e6, 3)}
+# the same batch with NO ocean (water plane far below the terrain): every droplet of every tile walks until it deposits -- the worst case for a kernel that holds two tiles per CU
+t.init_scene(pkg.make_config(mesh_gen_mode=0))
+t.set_water_plane_z(-1.0e3)
+ms = timed(lambda: t.tiles_create_zvals_dev(tiles, 1000, zt.ptr, stt.ptr, nm.ptr, mz.ptr), reps=2, spin_ms=0.0)
+out["C4_tiles64x64_sine_1000iters_all_land"] = {"ms": round(ms, 2), "tiles_per_s": round(n / ms * 1e3), "gcells_s": round(n * 130 * 130 / ms / 1e6, 3)}
 # row f1: AO lighting for the same 64x64 tiles (201^2 context per tile + 8 x 8 ray march per texel)
 t.init_scene(pkg.make_config(mesh_gen_mode=0))
 t.tiles_create_zvals_dev(tiles, 0, zt.ptr, stt.ptr, nm.ptr, mz.ptr)
@@ -162,9 +167,42 @@ if "--no-cpu" not in sys.argv:
     tl_ = [(tx, ty) for ty in range(-4, 4) for tx in range(-4, 4)]
     dt, _ = wall(lambda: ck.tiles_mesh_shadows(tl_, np.stack([ck.tile_create_zvals(tx, ty, 0)[0] for tx, ty in tl_]), (0.6, 0.5, 0.4)))
     cpu["F2_tile_mesh_shadows_tiles_per_s_incl_zvals"] = round(len(tl_) / dt, 1)
+    # ---- the same rows with ALL host cores: the engine makes tiles one after another, each with an OpenMP loop over its 130 rows (src/tiled_mesh.cpp:495, 2408-2413) -- that is
+    # the "_8thr" numbers above (more threads only add fork/join cost).  The best a CPU port could do is a tile per core: a pool of host threads, one tile each, OpenMP off.
+    from concurrent.futures import ThreadPoolExecutor
+    pool_n = max(1, min(len(os.sched_getaffinity(0)), 128))
+    def pool_map(fn, items):
+        def run(it):
+            ck.set_num_threads(1)  # omp_set_num_threads is per calling thread
+            return fn(it)
+        with ThreadPoolExecutor(pool_n) as ex:
+            return list(ex.map(run, items))
+    cpu["allthr_pool_threads"] = pool_n
+    tl2 = [(tx, ty) for ty in range(-8, 8) for tx in range(-16, 16)]  # 512 tiles around the origin (land and ocean mixed, like the GPU batch)
+    dt, zs2 = wall(lambda: pool_map(lambda xy: ck.tile_create_zvals(xy[0], xy[1], 0)[0], tl2))
+    cpu["C4_tiles_sine_0iters_tiles_per_s_allthr"] = round(len(tl2) / dt)
+    dt, _ = wall(lambda: pool_map(lambda xy: ck.tile_create_zvals(xy[0], xy[1], 1000), tl2))
+    cpu["C4_tiles_sine_1000iters_tiles_per_s_allthr"] = round(len(tl2) / dt, 1)
+    dt, _ = wall(lambda: pool_map(lambda i: ck.tile_ao_lighting(tl2[i][0], tl2[i][1], zs2[i]), range(len(tl2))))
+    cpu["F1_tile_ao_tiles_per_s_allthr"] = round(len(tl2) / dt, 1)
+    ck.set_landscape(orclib.make_landscape(grass_density=100))
+    dt, _ = wall(lambda: pool_map(lambda i: ck.tile_create_weights(tl2[i][0], tl2[i][1], zs2[i]), range(len(tl2))))
+    cpu["F3_tile_weights_tiles_per_s_allthr"] = round(len(tl2) / dt, 1)
+    ck.set_landscape(orclib.make_landscape())
+    ck.set_num_threads(cores)
+    dt, _ = wall(lambda: ck.tiles_mesh_shadows(tl2, np.stack(zs2), (0.6, 0.5, 0.4)))  # the sweeps chain from tile to tile (sh_out -> sh_in, src/tiled_mesh.cpp:664-692): serial in the reference too
+    cpu["F2_tile_mesh_shadows_tiles_per_s_zvals_given"] = round(len(tl2) / dt, 1)
+    for name, mode, nn in (("simplex", 1, 4096), ("perlin", 2, 4096), ("dwarp", 4, 2048)):  # (the fBm rows above are all-core already: OpenMP over the rows of one grid; larger grids so that 256 threads have rows to share)
+        s_ = ck.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
+        dt, _ = wall(lambda: ck.gen_grid(-nn / 2, -nn / 2, s_.DX_VAL, s_.DY_VAL, nn, nn, 1))
+        cpu[f"C2_{name}_8oct_{nn}_gcells_s_allthr"] = round(nn * nn / dt / 1e9, 5)
+    s_ = ck.init(orclib.make_config(mesh_gen_mode=0))
     ck.set_num_threads(cores)
     dims = (256, 256, 64)
     dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, 0, 0.01, 1))
     cpu["C5_voxels_256x256x64_sines_gvoxels_s"] = round(dims[0] * dims[1] * dims[2] / dt / 1e9, 4)
+    dims = (512, 512, 64)  # (OpenMP over y, src/voxels.cpp:312: 512 rows for the host's threads)
+    dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, 0, 0.01, 1))
+    cpu["C5_voxels_512x512x64_sines_gvoxels_s_allthr"] = round(dims[0] * dims[1] * dims[2] / dt / 1e9, 4)
     out["cpu"] = cpu
 print(json.dumps(out))
