@@ -818,14 +818,15 @@ template<class BE> struct terra_engine {
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2];
 		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)N*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)N*sb.maxb*8); o_bl[b] = carve((size_t)N*sb.maxb*4); o_bc[b] = carve((size_t)N*4);}
-		size_t const o_slot = carve((size_t)N*4*4), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
+		size_t const o_slot = carve((size_t)N*4*5), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
 		uint8_t *base = scratch<uint8_t>(s_spec, off); // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
 		for (int b = 0; b < 2; ++b) {
 			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]);
 		}
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
-		sb.cur = slot_arrays; sb.state = slot_arrays + N; sb.nsteps = slot_arrays + 2*(size_t)N; sb.nan = slot_arrays + 3*(size_t)N;
+		sb.cur = slot_arrays; sb.state = slot_arrays + N; sb.nsteps = slot_arrays + 2*(size_t)N; sb.nan = slot_arrays + 3*(size_t)N; sb.work = slot_arrays + 4*(size_t)N;
+		sb.trace_groups = (N <= 64) ? N : std::max<uint32_t>(64, N/4); // a quarter of the droplets at most get a wave of their own at once: enough for a map with some ocean, and a fully dry map's waves then take four droplets each
 		sb.ctl = (sparse_ctl_t *)(base + o_ctl);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
 		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks); // [head | dirty_min] of the general scheduler, all SPEC_NIL between runs: wmin borrows the second half
@@ -840,11 +841,9 @@ template<class BE> struct terra_engine {
 			bool const cap = be.graph_begin();
 			try {
 				if (with_first) {
-					be.launch(N, [=] TERRA_LAMBDA (size_t i) {
-						s.cur[i] = 0; s.state[i] = SPARSE_TRACED; s.blk_cnt[0][i] = 0; s.blk_cnt[1][i] = 0;
-						if (i == 0) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}
-					});
-					be.launch_waves_lean(N, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
+					be.launch(1, [=] TERRA_LAMBDA (size_t) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}, 64);
+					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_probe_body(s, (uint32_t)i);}); // the first step of every droplet: most end there
+					be.launch_waves_lean(s.trace_groups, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_wave(s, (uint32_t)i);});
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
 				}
@@ -882,7 +881,7 @@ template<class BE> struct terra_engine {
 		if (!finished_on_device) {be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, true);});} // handed over: wmin[] all SPEC_NIL again (head[] was never touched)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		report.rounds = 1 + hc.retraces; report.traces = N + hc.retraces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
-		report.windows = 1; report.sparse_droplets = first; report.sparse_retraces = hc.retraces;
+		report.windows = 1; report.sparse_droplets = first; report.sparse_retraces = hc.retraces; report.sparse_probe_only = N - hc.nwork;
 		return complete && record_touched && hc.touched <= sb.touched_cap; // (else the caller clamps the whole grid: handed over, no record wanted, or the record overflowed)
 	}
 

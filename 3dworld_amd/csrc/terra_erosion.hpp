@@ -1464,7 +1464,8 @@ struct sparse_ctl_t {
 	uint32_t retraces;    // re-traces made so far
 	uint32_t bail;        // the re-trace pass gave up: too many conflicts, or droplet `base` overflowed its block list (the host continues with the general scheduler from `base`)
 	uint32_t touched;     // cells recorded for the sparse clamp
-	uint32_t nan_droplets, pad_;
+	uint32_t nan_droplets;
+	uint32_t nwork;       // droplets the probe pass left for the trace waves (sparse_buffers_t::work)
 	unsigned long long steps, traced_steps;
 };
 struct sparse_buffers_t {
@@ -1473,6 +1474,8 @@ struct sparse_buffers_t {
 	uint32_t N, maxb, nbx, nby, max_retraces;
 	float *page_vals[2]; unsigned long long *page_mask[2]; uint32_t *blk_list[2], *blk_cnt[2]; // [N][maxb][64], [N][maxb], [N][maxb], [N]: a droplet's trace, and its re-trace in the other buffer
 	uint32_t *cur, *state, *nsteps, *nan; // [N]
+	uint32_t *work;       // [N] the droplets that take a step or write (probe pass): only these get a trace wave
+	uint32_t trace_groups; // workgroups of the trace launch: group i takes work[i], work[i + trace_groups], ...
 	uint32_t *wmin;       // [nbx*nby] lowest droplet that wrote the block in any of its traces (SPEC_NIL: nobody); reset through the block lists at the end of the run
 	uint32_t *touched; uint32_t touched_cap;
 	sparse_ctl_t *ctl;
@@ -1597,8 +1600,45 @@ TERRA_HD void sparse_trace_droplet(sparse_buffers_t const &sb, uint32_t iter, ui
 	}
 	TERRA_WAVE_SYNC();
 }
-// round 0: every droplet
-TERRA_HD void sparse_trace_wave(sparse_buffers_t const &sb, uint32_t iter, lean_scratch_t const &ws) {sparse_trace_droplet(sb, iter, 0u, SPARSE_TRACED, ws);}
+// ---- round 0.  Most droplets of a map that is mostly ocean end at their first step: the cell they would move to lies under water (src/erosion.cpp:98) -- 849 of the
+// headline's 1000.  A trace WAVE for such a droplet is all overhead (LDS set-up, a 4 KB window fetched for two corner reads) and, worse, takes the registers of a quarter
+// of a CU from another heightmap's noise kernel while it lives (128 registers do not fit beside four 120-register waves on a SIMD: the CU runs three noise blocks instead of
+// four).  So one THREAD per droplet first walks that first step directly on the grid, with the reference's own loop (droplet_start + one iteration of droplet_run): a droplet
+// that ends there without having written anything is complete -- its footprint (the blocks of its 4x4 box: every cell it read) goes into its block list like a trace's --
+// and only the others are queued for a trace wave.
+struct probe_mem_t {
+	grid_view_t g; uint32_t *blks; uint32_t nblk, nbx; int NXm1, NYm1; bool wrote;
+	TERRA_HD void add(uint32_t b) {for (uint32_t i = 0; i < nblk; ++i) {if (blks[i] == b) return;} blks[nblk++] = b;} // (at most four blocks per box)
+	TERRA_HD bool begin_step(int xi, int zi) {
+		xi = sati(xi, NXm1 + 1); zi = sati(zi, NYm1 + 1);
+		int const x0 = clampi(xi-1, NXm1) >> 3, x1 = clampi(xi+2, NXm1) >> 3, z0 = clampi(zi-1, NYm1) >> 3, z1 = clampi(zi+2, NYm1) >> 3;
+		add((uint32_t)z0*nbx + x0); add((uint32_t)z0*nbx + x1); add((uint32_t)z1*nbx + x0); add((uint32_t)z1*nbx + x1);
+		return true;
+	}
+	TERRA_HD void corners(int x, int z, float out[4]) const {
+		int const x0 = clampi(x, NXm1), x1 = clampi(x+1, NXm1), z0 = clampi(z, NYm1), z1 = clampi(z+1, NYm1);
+		out[0] = *g.at(x0, z0); out[1] = *g.at(x1, z0); out[2] = *g.at(x0, z1); out[3] = *g.at(x1, z1);
+	}
+	TERRA_HD void deposit(int, int, float, float, float) {wrote = true;} // the probe never changes anything: a droplet that would write is left to its trace wave
+	TERRA_HD void erode(int, int, float, float, float) {wrote = true;}
+};
+TERRA_HD void sparse_probe_body(sparse_buffers_t const &sb, uint32_t j) {
+	probe_mem_t m;
+	m.g = sb.grid; m.blks = sb.blk_list[0] + (size_t)j*sb.maxb; m.nblk = 0; m.nbx = sb.nbx; m.NXm1 = sb.ec.NX - 1; m.NYm1 = sb.ec.NY - 1; m.wrote = false;
+	droplet_state_t d;
+	bool done = !droplet_start((int)j, m, sb.ec, d);
+	if (!done) {done = droplet_run(d, m, sb.ec, 1u);} // the first iteration of the step loop; false: it made the step (the budget ended it)
+	sb.cur[j] = 0; sb.blk_cnt[1][j] = 0;
+	if (done && !m.wrote && d.numMoves == 0 && sb.maxb >= 4) { // complete: nothing written, only the box was read
+		sb.blk_cnt[0][j] = m.nblk; sb.nsteps[j] = 0; sb.nan[j] = 0; sb.state[j] = SPARSE_TRACED;
+	}
+	else {sb.blk_cnt[0][j] = 0; sb.state[j] = SPARSE_TRACED; sb.work[TERRA_ATOMIC_ADD(&sb.ctl->nwork, 1u)] = j;}
+}
+// the queued droplets, one trace wave each (workgroup i of trace_groups takes every trace_groups-th)
+TERRA_HD void sparse_trace_wave(sparse_buffers_t const &sb, uint32_t group, lean_scratch_t const &ws) {
+	uint32_t const n = wave_uniform(sb.ctl->nwork);
+	for (uint32_t k = group; k < n; k += sb.trace_groups) {sparse_trace_droplet(sb, wave_uniform(sb.work[k]), 0u, SPARSE_TRACED, ws);}
+}
 // a later round (ONE wave): everything below the lowest conflicted droplet is committed; that droplet is traced again on the grid as it stands now
 TERRA_HD void sparse_retrace_wave(sparse_buffers_t const &sb, lean_scratch_t const &ws) {
 	sparse_ctl_t &c = *sb.ctl;

@@ -64,7 +64,7 @@ class ErosionReport(C.Structure):  # terra_erosion_report
                 ("clk_shift_flush", C.c_uint64), ("clk_shift_prep", C.c_uint64), ("clk_shift_load", C.c_uint64),
                 ("crit_clk_flush", C.c_uint64), ("crit_clk_load", C.c_uint64), ("crit_clk_prep", C.c_uint64),
                 ("crit_clk_shift", C.c_uint64), ("crit_clk_edge", C.c_uint64), ("crit_steps_own", C.c_uint64),
-                ("sparse_droplets", C.c_uint64), ("sparse_retraces", C.c_uint64)]
+                ("sparse_droplets", C.c_uint64), ("sparse_retraces", C.c_uint64), ("sparse_probe_only", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

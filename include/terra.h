@@ -101,6 +101,7 @@ typedef struct terra_erosion_report {
 	/* the sparse scheduler (few droplets on a big map: lean traces on the grid itself, one round per conflicting droplet): droplets it committed (0: not tried; `droplets`: the
 	 * whole run -- anything less: the multi-version scheduler did the rest) and the re-traces that took */
 	uint64_t sparse_droplets, sparse_retraces;
+	uint64_t sparse_probe_only; /* droplets of such a run that ended at their first step without writing (ocean): settled by one thread each, no trace wave */
 } terra_erosion_report;
 
 /* The globals tile_t::create_texture and tile_t::update_terrain_params read beyond terra_config; the defaults are the reference's. */

@@ -176,6 +176,40 @@ def case_erosion_sparse(pkg, t, orc, n, iters, force="1", retraces=None, flags=0
     return r, stats
 
 
+def case_erosion_edge_sparse(pkg, t, orc):
+    """the edge cases of case_erosion_edge under the sparse scheduler: all ocean (every droplet is settled by the probe pass), flat land (every first step takes the
+    random-direction branch and writes: nobody is), a coast (both kinds mixed, droplets that die on their first step next to ones that walk)"""
+    import os
+    old = {k: os.environ.get(k) for k in ("TERRA_ERO_SPARSE", "TERRA_ERO_SPARSE_RETRACES")}
+    os.environ["TERRA_ERO_SPARSE"] = "1"; os.environ["TERRA_ERO_SPARSE_RETRACES"] = "100000"
+    try:
+        case_erosion_edge(pkg, t, orc)
+        r = t.erosion_report()
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+        st = t.init_scene(pc_); orc.init(oc)
+        h = np.full((96, 96), 1.5, np.float32)
+        orc.set_water_plane_z(10.0); t.set_water_plane_z(10.0)
+        a, b = h.copy(), h.copy()
+        orc.apply_erosion(a, 0.5, 70); t.apply_erosion(b, 0.5, 70)
+        assert_bit_equal(a, b, "all ocean, sparse"); r = t.erosion_report(); assert r.sparse_droplets == 70 and r.sparse_probe_only == 70, r.as_dict()
+        orc.set_water_plane_z(-10.0); t.set_water_plane_z(-10.0)
+        a, b = h.copy(), h.copy()
+        orc.apply_erosion(a, 0.5, 70); t.apply_erosion(b, 0.5, 70)
+        assert_bit_equal(a, b, "flat land, sparse"); r = t.erosion_report(); assert r.sparse_droplets == 70 and r.sparse_probe_only == 0, r.as_dict()
+        n = 640  # a real coast
+        t.init_scene(pc_); orc.init(oc)
+        g = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+        a, b = g.copy(), g.copy()
+        orc.apply_erosion(a, float(g.min()), 250); t.apply_erosion(b, float(g.min()), 250)
+        assert_bit_equal(a, b, "coast, sparse"); r = t.erosion_report(); assert r.sparse_droplets == 250 and 0 < r.sparse_probe_only < 250, r.as_dict()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def case_erosion_context_reuse(pkg, t, orc):
     """one context, many runs: the scheduler keeps its block tables and log tables between runs (only the entries a run set are reset), so a
     sequence that changes grid size, ring size, block-list capacity, log capacity and droplet count exercises every re-use / re-init decision."""

@@ -112,6 +112,10 @@ def test_sparse_erosion_scheduler(pkg, gpu, orc, n, iters, retraces, flags):
         assert 0 < r.sparse_droplets < iters and r.sparse_retraces <= retraces
 
 
+def test_sparse_erosion_edge_cases_and_probe_pass(pkg, gpu, orc):
+    pc.case_erosion_edge_sparse(pkg, gpu, orc)
+
+
 def test_erosion_context_reuse(pkg, gpu, orc):
     pc.case_erosion_context_reuse(pkg, gpu, orc)
 
@@ -229,6 +233,7 @@ def test_bench_step_full_size_equals_oracle(pkg, gpu, orc):
     diff = z.view(np.uint32) != ref.view(np.uint32)
     assert not diff.any(), f"{int(diff.sum())} cells differ, first at {np.argwhere(diff)[:4].tolist()}"
     assert rep["droplets"] == droplets
+    assert 600 < rep["sparse_probe_only"] <= 849, rep  # (the oracle's step counts: 849 of this map's 1000 droplets take no step -- under water at once, or an uphill first move that deposits nothing and ends)
     assert rep["sparse_droplets"] == droplets, rep  # the timed configuration goes through the sparse scheduler alone (lean traces; its one conflicting pair is a re-trace round)
     print("erosion report", rep)
 

@@ -154,6 +154,10 @@ def test_sparse_erosion_scheduler(pkg, emul, orc, n, iters, retraces, flags):
         assert 0 < r.sparse_droplets < iters and r.sparse_retraces <= retraces                              # a committed prefix, the rest by the multi-version scheduler
 
 
+def test_sparse_erosion_edge_cases_and_probe_pass(pkg, emul, orc):
+    pc.case_erosion_edge_sparse(pkg, emul, orc)
+
+
 def test_sparse_erosion_is_chosen_by_density_and_can_be_switched_off(pkg, emul, orc):
     r, _ = pc.case_erosion_sparse(pkg, emul, orc, 2048, 40, None)     # 40^2 <= 2 * 257^2 blocks: tried
     assert r.sparse_droplets > 0
