@@ -226,10 +226,6 @@ int terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, u
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out); TERRA_CATCH
 }
-int terra_gen_grid_build_arrays_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin) {
-	TERRA_CHECK_CTX
-	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, nullptr, nullptr, 0, 0xFFFFFFFFu, nullptr, true); TERRA_CATCH
-}
 int terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max) {
 	TERRA_CHECK_CTX if (!d_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY float mm[2]; ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out, mm); if (h_min) *h_min = mm[0]; if (h_max) *h_max = mm[1]; TERRA_CATCH

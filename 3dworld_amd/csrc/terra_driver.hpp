@@ -257,14 +257,7 @@ template<class BE> struct terra_engine {
 	uint8_t const *hmap_pix = nullptr; int hmap_w = 0, hmap_h = 0, hmap_nc = 0; // terrain_hmap_manager's image (device memory, owned by the caller)
 	float mesh_file_scale = 1.0f, mesh_file_tz = 0.0f;                          // src/mesh_gen.cpp:41, set by set_mesh_height_scales_for_zval_range
 	uint32_t *spec_blocks_clean = nullptr; size_t spec_blocks_n = 0; // s_spec_blocks is known to be all-NIL for this pointer / block count
-	// build_arrays ahead of its eval call (terra_gen_grid_build_arrays_dev): the tables of the next sine grid, built while the context would otherwise wait (for its turn among
-	// several heightmaps in flight).  What makes them usable is that NOTHING touched what they are made of or stored in since: `table_epoch` moves whenever one of the table
-	// buffers is handed out (scratch() below: every user, this file or not, gets its pointers there) and whenever the sine table, the LUT or the scene change; a prepared set is
-	// used only by the very next call, only when that call computes the same key (every scalar the table launch reads) and finds the epoch where the prep left it.
-	struct table_prep_t {float f[12]; uint32_t u[6]; void const *p[6]; uint64_t epoch; bool valid;} prep{};
-	uint64_t table_epoch = 0;
 	template<class T> T *scratch(scratch_t &s, size_t count) {
-		if (&s == &s_xt || &s == &s_yt || &s == &s_smx || &s == &s_smy || &s == &s_mm) {++table_epoch;}
 		size_t const bytes = std::max<size_t>(count*sizeof(T), 256);
 		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
 		return (T *)s.p;
@@ -274,7 +267,7 @@ template<class BE> struct terra_engine {
 	void release_scratch() {
 		be.sync();
 		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm, &s_hostgrid}) {if (s->p) {be.free(s->p); s->p = nullptr; s->bytes = 0;}}
-		spec_blocks_clean = nullptr; spec_blocks_n = 0; ++table_epoch; prep.valid = false;
+		spec_blocks_clean = nullptr; spec_blocks_n = 0;
 		be.release_scratch();
 	}
 	~terra_engine() {
@@ -329,7 +322,7 @@ template<class BE> struct terra_engine {
 		return d_sinTable;
 	}
 	void gen_rand_sine_table_entries(float scaled_height) { // src/mesh_gen.cpp:219-254
-		sinTable_dev_valid = false; ++table_epoch;
+		sinTable_dev_valid = false;
 		float xf_scale = (float)cfg.mesh_y/(float)cfg.mesh_x, yf_scale = (float)(1.0/(double)xf_scale);
 		if (cfg.scene_x > cfg.scene_y) yf_scale *= cfg.scene_y/cfg.scene_x;
 		if (cfg.scene_y > cfg.scene_x) xf_scale *= cfg.scene_x/cfg.scene_y;
@@ -452,7 +445,7 @@ template<class BE> struct terra_engine {
 	void set_state(terra_state const &s) {
 		if (!have_config) throw std::logic_error("terra_set_state: call terra_set_config (or terra_init_scene) first: hmap_params, modes and erosion scalars are not part of terra_state");
 		create_sin_table();
-		memcpy(sinTable, s.sinTable, sizeof(sinTable)); sinTable_dev_valid = false; ++table_epoch;
+		memcpy(sinTable, s.sinTable, sizeof(sinTable)); sinTable_dev_valid = false;
 		start_eval_sin = s.start_eval_sin; MESH_HEIGHT = s.MESH_HEIGHT; DX_VAL = s.DX_VAL; DY_VAL = s.DY_VAL; DX_VAL_INV = s.DX_VAL_INV; DY_VAL_INV = s.DY_VAL_INV;
 		HALF_DXY = s.HALF_DXY; dxdy = s.dxdy; XY_SCENE_SIZE = s.XY_SCENE_SIZE; mesh_scale = s.mesh_scale; mesh_scale_z_inv = s.mesh_scale_z_inv; mesh_height_scale = s.mesh_height_scale;
 		set_zmax_est(s.zmax_est); zmin = s.zmin; zmax = s.zmax; water_plane_z = s.water_plane_z; glaciate_exp = s.glaciate_exp; clip_hd1 = s.clip_hd1; relh_adj_tex = s.relh_adj_tex;
@@ -490,10 +483,8 @@ template<class BE> struct terra_engine {
 	// full-grid call produces (the tables and cell coordinates use the row's index in the whole grid), so row strips evaluated on different GPUs tile the
 	// heightmap exactly (heightmap_t::proc_gen's loop is row-independent, src/heightmap.cpp:139-143)
 	// d_minmax (optional): DEVICE float[2] that receives {min, max} without the host ever seeing them (an enqueue-only proc_gen step: terra_apply_erosion_devmin_dev reads it)
-	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu, float *d_minmax = nullptr, bool tables_only = false) {
+	void gen_grid_dev(float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_minmax = nullptr, uint32_t row0 = 0, uint32_t nrows = 0xFFFFFFFFu, float *d_minmax = nullptr) {
 		require_scene();
-		uint64_t const epoch_in = table_epoch; // (before this call hands out any table buffer)
-		table_prep_t const had = prep; prep.valid = false; // one-shot: whatever this call is, a prepared set does not survive it
 		if (nx == 0 || ny == 0) throw std::invalid_argument("build_arrays: nx, ny must be > 0"); // assert(nx > 0 && ny > 0), src/mesh_gen.cpp:589
 		if (nrows == 0xFFFFFFFFu) {if (row0 != 0) throw std::invalid_argument("gen_grid rows: row0 without a row count"); nrows = ny;}
 		if (nrows == 0 || row0 >= ny || nrows > ny - row0) throw std::invalid_argument("gen_grid rows: [row0, row0 + nrows) must be a non-empty range inside the grid");
@@ -512,7 +503,6 @@ template<class BE> struct terra_engine {
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
 		uint32_t *d_mm = nullptr;
 		bool const sine = (job.mode == MGEN_SINE);
-		if (tables_only && !sine) return; // the fBm modes have no tables
 		if (h_minmax || d_minmax || sine) {d_mm = scratch<uint32_t>(s_mm, 2); if (!sine) {be.fill32(d_mm, 0xFFFFFFFFu, 2);}} // (sine mode: reset by the table launch)
 		bool fused;
 		bool const sm_on = job.use_sine_mag != 0;
@@ -536,12 +526,7 @@ template<class BE> struct terra_engine {
 			uint32_t const nxp = job.nxp, nyp = job.nyp;
 			size_t const ntab = (size_t)F_TABLE_SIZE*(nxp + nyp);
 			uint32_t *const mmz = d_mm;
-			table_prep_t key{};
-			{float const kf[12] = {msx, msy, ms2, mszi, jmx0, jmy0, mdx, mdy, sm_scale, sm_freq, dxi, dyi}; memcpy(key.f, kf, sizeof(kf));}
-			{uint32_t const ku[6] = {nx, ny, row0, nxp, nyp, sm_on ? 1u : 0u}; memcpy(key.u, ku, sizeof(ku));}
-			key.p[0] = xt; key.p[1] = yt; key.p[2] = smx; key.p[3] = smy; key.p[4] = d_mm; key.p[5] = st;
-			bool const have_tables = had.valid && had.epoch == epoch_in && memcmp(had.f, key.f, sizeof(key.f)) == 0 && memcmp(had.u, key.u, sizeof(key.u)) == 0 && memcmp(had.p, key.p, sizeof(key.p)) == 0;
-			if (!have_tables) be.launch(ntab + (sm_on ? (size_t)nxp + nyp : 0), [=] TERRA_LAMBDA (size_t i) {
+			be.launch(ntab + (sm_on ? (size_t)nxp + nyp : 0), [=] TERRA_LAMBDA (size_t i) {
 				if (i == 0) {mmz[0] = 0xFFFFFFFFu; mmz[1] = 0xFFFFFFFFu;} // the fused min / max of the grid kernel start here (one launch less than a fill of its own)
 				if (i < (size_t)F_TABLE_SIZE*nxp) {
 					unsigned const k = (unsigned)(i / nxp), x = (unsigned)(i % nxp);
@@ -562,7 +547,6 @@ template<class BE> struct terra_engine {
 					else {unsigned const y = (unsigned)(q - nxp); smy[y] = (y < ny) ? L.COSF(((float)(y + row0)*mdy + jmy0)*dyi*sm_freq) : 0.0f;}
 				}
 			});
-			if (tables_only) {prep = key; prep.epoch = table_epoch; prep.valid = true; return;}
 			fused = be.sine_grid(job, nc, L, xt, yt, smx, smy, d_out, (h_minmax || d_minmax) ? d_mm : nullptr);
 		}
 		else {fused = be.noise_grid(job, nc, L, smx, smy, d_out, (h_minmax || d_minmax) ? d_mm : nullptr, d_noise_lut);}

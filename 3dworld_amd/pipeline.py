@@ -25,12 +25,10 @@ class NoiseTurns:
         return prev[0], prev[1], mine
 
 
-def proc_gen_step(pkg, ctx, turns, ev, z_ptr, mm_ptr, x0, y0, dx, dy, nx, ny, droplets, flags=None, on_noise_enqueued=None, build_ahead=True):
+def proc_gen_step(pkg, ctx, turns, ev, z_ptr, mm_ptr, x0, y0, dx, dy, nx, ny, droplets, flags=None, on_noise_enqueued=None):
     """one heightmap: wait for the noise turn, enqueue noise (+ min / max into mm_ptr: 2 device floats), hand the turn on, erode.  Returns when the map is complete in z_ptr."""
     prev_ev, prev_flag, my_flag = turns.take(ev) if turns is not None else (None, None, None)
     try:
-        if build_ahead and turns is not None:
-            ctx.gen_grid_build_arrays_dev(x0, y0, dx, dy, nx, ny, pkg.GEN_GLACIATE if flags is None else flags)  # build_arrays now, beside the previous map's eval kernel: the turn itself is the eval kernel only
         if prev_flag is not None:
             prev_flag.wait()             # the previous map's noise has been enqueued and its event recorded (long ago, in the steady state)
             ctx.event_synchronize(prev_ev)   # ... and has left the chip

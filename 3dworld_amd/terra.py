@@ -142,7 +142,6 @@ _PROTOS = {
     "terra_event_synchronize": (_i32, [_vp]),
     "terra_event_destroy": (None, [_vp]),
     "terra_apply_erosion_devmin_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32]),
-    "terra_gen_grid_build_arrays_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32]),
     "terra_gen_grid_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _vp]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
@@ -569,10 +568,6 @@ class Terra:
         r = (C.c_float * 2)()
         self._ck(self.lib.terra_glaciate_mesh_dev(self.ctx, ptr, nx, ny, xoff2, yoff2, C.addressof(r)))
         return r[0], r[1]
-
-    def gen_grid_build_arrays_dev(self, x0, y0, dx, dy, nx, ny, flags=GEN_GLACIATE, min_start_sin=0):
-        """build_arrays of the next gen_grid_* call with the same arguments, ahead of it (asynchronous; that call then only evaluates)"""
-        self._ck(self.lib.terra_gen_grid_build_arrays_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin))
 
     def gen_grid_minmax_async_dev(self, ptr, x0, y0, dx, dy, nx, ny, minmax_ptr, flags=GEN_GLACIATE, min_start_sin=0):
         """noise (+ glaciate) with {min, max} left in device memory at minmax_ptr (2 floats); nothing is read back, the call only enqueues"""

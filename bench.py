@@ -64,7 +64,6 @@ def parse():
     p.add_argument("--headline-only", action="store_true", help="stop after the timed headline run (for kernel traces of exactly that region): no per-kernel section, no roofline in the line")
     p.add_argument("--handoff", default="event", choices=["event", "semaphore", "none"], help="how the heightmaps in flight take turns in their noise phase: event = the next map's thread waits on the host for the "
                    "GPU event behind the previous map's noise kernel, min(vals) stays in HBM (3dworld_amd/pipeline.py); semaphore = a host semaphore around a synchronous noise call (rounds 1-4); none = no turns")
-    p.add_argument("--build-ahead", type=int, default=1, choices=[0, 1], help="event hand-over: build the next map's sine tables (terra_gen_grid_build_arrays_dev, ~20 us) before waiting for the noise turn, so that the turn is the eval kernel alone")
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
                         "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
@@ -258,7 +257,7 @@ def main():
         c, zz = ctxs[p], zs[p]
         if args.handoff == "event":
             pmod.proc_gen_step(pkg, c, turns if P > 1 else None, evs[p], zz.data_ptr(), mms[p].data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, args.droplets,
-                               on_noise_enqueued=noise_done.set if noise_done is not None else None, build_ahead=bool(args.build_ahead))
+                               on_noise_enqueued=noise_done.set if noise_done is not None else None)
             return
         # --handoff semaphore / none (round 1-4's schedules, kept for the A/B): min(vals) read back by the host, a host semaphore around the noise call / nothing
         if noise_turn is not None:

@@ -197,11 +197,6 @@ const float *terra_gen_device_values(terra_gen *g);                /* device poi
 
 /* one-shot: build_arrays + [enable_glaciate] + the caller's eval_index double loop (src/heightmap.cpp:135-143, src/tiled_mesh.cpp:495-514) */
 int  terra_gen_grid_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out);
-/* the build_arrays half of the one-shot calls on its own (mesh_xy_grid_cache_t::build_arrays, src/mesh_gen.cpp:589-631: the per-term sine tables, + enable_glaciate's island
- * tables): asynchronous, ~20 us of device work.  The NEXT terra_gen_grid_* call of this context evaluates from these tables instead of building them first when it has the
- * SAME arguments and nothing in between touched the scene, the state or any table buffer (any other call of the context does: the tables are then simply built again) --
- * a caller with several grids in flight builds the next grid's tables while another grid's eval kernel owns the chip (3dworld_amd/pipeline.py).  fBm modes: no tables, no-op. */
-int  terra_gen_grid_build_arrays_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin);
 /* same, plus min(vals)/max(vals) folded into the grid kernel (what heightmap_t::run_erosion / get_heightmap_z_range compute next); synchronous */
 int  terra_gen_grid_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *d_out, float *h_min, float *h_max);
 /* the same with min / max left in DEVICE memory (d_minmax: 2 floats) and nothing read back: asynchronous.  With terra_apply_erosion_devmin_dev the whole

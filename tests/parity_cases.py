@@ -911,63 +911,6 @@ def case_gen_grid_minmax(pkg, t, orc, mode, n):
     assert np.float32(mn) == a.min() and np.float32(mx) == a.max(), (mn, mx, a.min(), a.max())
 
 
-def case_build_arrays_ahead(pkg, t, orc):
-    """terra_gen_grid_build_arrays_dev: the tables of a grid built ahead of its eval call -- used when the next call has the same arguments, rebuilt by that call when anything
-    differs (other grid, other first term is fine: the tables hold every term; scene change; a second eval after the one-shot set was used); fBm modes: a no-op"""
-    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
-    st = t.init_scene(pc_)
-    orc.init(oc)
-    G = lambda x0, y0, nx, ny, mss=0: orc.gen_grid(x0, y0, st.DX_VAL, st.DY_VAL, nx, ny, 1, 0, mss)
-    def dev(x0, y0, nx, ny, mss=0):
-        buf = t.alloc(nx * ny * 4)
-        mn, mx = t.gen_grid_minmax_dev(buf.ptr, x0, y0, st.DX_VAL, st.DY_VAL, nx, ny, pkg.GEN_GLACIATE, mss)
-        z = buf.download(np.float32, (ny, nx)); buf.free()
-        assert np.float32(mn) == z.min() and np.float32(mx) == z.max(), (mn, mx, z.min(), z.max())
-        return z
-    t.gen_grid_build_arrays_dev(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, pkg.GEN_GLACIATE)
-    assert_bit_equal(G(-90, 31, 300, 200), dev(-90, 31, 300, 200), "tables built ahead, same arguments")
-    assert_bit_equal(G(-90, 31, 300, 200), dev(-90, 31, 300, 200), "second eval: builds its own")
-    t.gen_grid_build_arrays_dev(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, pkg.GEN_GLACIATE)
-    assert_bit_equal(G(-90, 31, 300, 200, 40), dev(-90, 31, 300, 200, 40), "tables built ahead, later first term")
-    t.gen_grid_build_arrays_dev(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, pkg.GEN_GLACIATE)
-    assert_bit_equal(G(17, -5, 300, 200), dev(17, -5, 300, 200), "tables built ahead for ANOTHER origin")
-    t.gen_grid_build_arrays_dev(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, pkg.GEN_GLACIATE)
-    assert_bit_equal(G(-90, 31, 260, 200), dev(-90, 31, 260, 200), "tables built ahead for ANOTHER size")
-    t.gen_grid_build_arrays_dev(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, pkg.GEN_GLACIATE)
-    pc2, oc2 = cfg_pair(pkg, mesh_gen_mode=0, mesh_freq_filter=3)  # scene change in between: other tables, same grid arguments
-    st = t.init_scene(pc2); orc.init(oc2)
-    assert_bit_equal(G(-90, 31, 300, 200), dev(-90, 31, 300, 200), "scene changed after the tables were built")
-    t.gen_grid_build_arrays_dev(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, 0)
-    a = orc.gen_grid(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, 0)
-    b = t.gen_grid(-90, 31, st.DX_VAL, st.DY_VAL, 300, 200, 0)
-    assert_bit_equal(a, b, "tables built ahead, no glaciate, host output")
-    pc3, oc3 = cfg_pair(pkg, mesh_gen_mode=1)
-    st = t.init_scene(pc3); orc.init(oc3)
-    t.gen_grid_build_arrays_dev(-20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE)  # simplex: nothing to build
-    assert_bit_equal(G(-20, 3, 96, 64), dev(-20, 3, 96, 64), "fBm mode after a build_arrays call")
-    # ADVICE r04: an fBm call between the build and the sine eval (it overwrites the island tables and the min / max words): the eval must build its own tables
-    t.gen_grid_build_arrays_dev(-20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE | pkg.GEN_FORCE_SINE)
-    assert_bit_equal(G(300, -77, 96, 64), dev(300, -77, 96, 64), "an fBm grid elsewhere, between build and eval")
-    orc.set_mode(0, 0)
-    want = orc.gen_grid(-20, 3, st.DX_VAL, st.DY_VAL, 96, 64, 1)
-    orc.set_mode(1, 0)
-    buf = t.alloc(96 * 64 * 4)
-    mn, mx = t.gen_grid_minmax_dev(buf.ptr, -20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE | pkg.GEN_FORCE_SINE)
-    got = buf.download(np.float32, (64, 96)); buf.free()
-    assert_bit_equal(want, got, "forced-sine eval after an fBm call in between")
-    assert np.float32(mn) == want.min() and np.float32(mx) == want.max(), (mn, mx, want.min(), want.max())
-    # ... and a minmax of some other buffer (it uses the same two words), and released scratch
-    t.gen_grid_build_arrays_dev(-20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE | pkg.GEN_FORCE_SINE)
-    tmp = t.alloc(4096 * 4).upload(np.arange(4096, dtype=np.float32)); assert t.minmax_dev(tmp.ptr, 4096) == (0.0, 4095.0); tmp.free()
-    buf = t.alloc(96 * 64 * 4)
-    mn, mx = t.gen_grid_minmax_dev(buf.ptr, -20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE | pkg.GEN_FORCE_SINE)
-    assert_bit_equal(want, buf.download(np.float32, (64, 96)), "a minmax call in between"); assert np.float32(mn) == want.min()
-    t.gen_grid_build_arrays_dev(-20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE | pkg.GEN_FORCE_SINE)
-    t.release_scratch()
-    mn, mx = t.gen_grid_minmax_dev(buf.ptr, -20, 3, st.DX_VAL, st.DY_VAL, 96, 64, pkg.GEN_GLACIATE | pkg.GEN_FORCE_SINE)
-    assert_bit_equal(want, buf.download(np.float32, (64, 96)), "scratch released in between"); buf.free()
-
-
 def case_voxel_slabs(pkg, t, orc, gen_mode, shape, nslabs):
     """one voxel field as y slabs (terra_voxel_fill_slab_dev): the slabs tile the full field bit for bit"""
     nx, ny, nz = shape

@@ -116,10 +116,6 @@ def test_sparse_erosion_edge_cases_and_probe_pass(pkg, gpu, orc):
     pc.case_erosion_edge_sparse(pkg, gpu, orc)
 
 
-def test_build_arrays_ahead_of_the_eval_call(pkg, gpu, orc):
-    pc.case_build_arrays_ahead(pkg, gpu, orc)
-
-
 def test_erosion_context_reuse(pkg, gpu, orc):
     pc.case_erosion_context_reuse(pkg, gpu, orc)
 

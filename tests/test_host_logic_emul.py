@@ -171,10 +171,6 @@ def test_download_api_host_logic(pkg, emul, orc):
     pc.case_big_transfers(pkg, emul, orc, sizes=((700, 300), (64, 33)))
 
 
-def test_build_arrays_ahead_of_the_eval_call(pkg, emul, orc):
-    pc.case_build_arrays_ahead(pkg, emul, orc)
-
-
 def test_erosion_context_reuse(pkg, emul, orc):
     pc.case_erosion_context_reuse(pkg, emul, orc)
 
