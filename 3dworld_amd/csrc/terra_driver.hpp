@@ -818,14 +818,14 @@ template<class BE> struct terra_engine {
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2];
 		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)N*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)N*sb.maxb*8); o_bl[b] = carve((size_t)N*sb.maxb*4); o_bc[b] = carve((size_t)N*4);}
-		size_t const o_slot = carve((size_t)N*4*5), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
+		size_t const o_slot = carve((size_t)N*4*6), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
 		uint8_t *base = scratch<uint8_t>(s_spec, off); // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
 		for (int b = 0; b < 2; ++b) {
 			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]);
 		}
 		uint32_t *slot_arrays = (uint32_t *)(base + o_slot);
-		sb.cur = slot_arrays; sb.state = slot_arrays + N; sb.nsteps = slot_arrays + 2*(size_t)N; sb.nan = slot_arrays + 3*(size_t)N; sb.work = slot_arrays + 4*(size_t)N;
+		sb.cur = slot_arrays; sb.state = slot_arrays + N; sb.nsteps = slot_arrays + 2*(size_t)N; sb.nan = slot_arrays + 3*(size_t)N; sb.work = slot_arrays + 4*(size_t)N; sb.queued = slot_arrays + 5*(size_t)N;
 		sb.trace_groups = (N <= 64) ? N : std::max<uint32_t>(64, N/4); // a quarter of the droplets at most get a wave of their own at once: enough for a map with some ocean, and a fully dry map's waves then take four droplets each
 		sb.ctl = (sparse_ctl_t *)(base + o_ctl);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
@@ -834,7 +834,7 @@ template<class BE> struct terra_engine {
 		spec_blocks_clean = nullptr;
 		sb.wmin = blk_arrays + nblocks;
 		sparse_buffers_t const s = sb;
-		auto rounds = [&](bool with_first) { // [init, trace everything, check, commit,] then twice: re-trace the lowest conflicted droplet, check, commit -- one hipGraph each way
+		auto rounds = [&](bool with_first) { // [control block, probe, trace, check, commit,] then: re-trace the lowest conflicted droplet, check, commit -- one hipGraph each way
 			struct {sparse_buffers_t s; uint32_t with_first; uint32_t tag;} gkey;
 			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.s.ec.min_zval = 0.0f; gkey.with_first = with_first ? 1u : 0u; gkey.tag = 0x53505253u; // (min_zval: read by the clamp only, which is not part of the graph)
 			if (be.graph_replay(&gkey, sizeof(gkey))) return;
@@ -845,12 +845,12 @@ template<class BE> struct terra_engine {
 					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_probe_body(s, (uint32_t)i);}); // the first step of every droplet: most end there
 					be.launch_waves_lean(s.trace_groups, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_wave(s, (uint32_t)i);});
-					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
+					be.launch_waves_nolds(s.trace_groups, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
 				}
-				for (int r = 0; r < 2; ++r) {
+				for (int r = 0; r < 1; ++r) { // one more conflicted droplet per replay (the usual run has none or one: its read-back is then the only host round trip)
 					be.launch_waves_lean(1, [=] TERRA_LAMBDA (size_t, lean_scratch_t const &ws) {sparse_retrace_wave(s, ws);});
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_wave(s, (uint32_t)i);});
-					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
+					be.launch_waves_nolds(s.trace_groups, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
 				}
 			} catch (...) {be.graph_abort(); throw;}
 			if (cap) {be.graph_end(&gkey, sizeof(gkey));}
@@ -860,13 +860,13 @@ template<class BE> struct terra_engine {
 		float const mz = ec.min_zval;
 		uint32_t const clamp_threads = record_touched ? std::min<uint32_t>(touched_cap, 1u << 18) : 0u;
 		auto finish = [&](bool force) {
-			be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, force);});
+			be.launch_waves_nolds(s.trace_groups, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, force);});
 			if (clamp_threads) {be.launch(clamp_threads, [=] TERRA_LAMBDA (size_t i) {sparse_clamp_body(s, (uint32_t)i, clamp_threads, d_min ? *d_min : mz, false);});} // (never forced: an incomplete run's clamp is the caller's, at the end)
 		};
 		sparse_ctl_t hc{};
 		rounds(true);
 		finish(false);
-		be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of a run with at most two conflicted droplets
+		be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of a run with at most one conflicted droplet
 		uint32_t batches = 1;
 		bool finished_on_device = (hc.c >= N) && !hc.bail;
 		while (hc.c < N && !hc.bail) { // after the last commit: [base, c) is on the grid, c is conflicted
@@ -878,7 +878,7 @@ template<class BE> struct terra_engine {
 		}
 		bool const complete = (hc.c >= N) && !hc.bail;
 		first = complete ? N : (hc.bail ? hc.base : hc.c);
-		if (!finished_on_device) {be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, true);});} // handed over: wmin[] all SPEC_NIL again (head[] was never touched)
+		if (!finished_on_device) {be.launch_waves_nolds(s.trace_groups, [=] TERRA_LAMBDA (size_t i) {sparse_unmark_wave(s, (uint32_t)i, true);});} // handed over: wmin[] all SPEC_NIL again (head[] was never touched)
 		spec_blocks_clean = blk_arrays; spec_blocks_n = nblocks;
 		report.rounds = 1 + hc.retraces; report.traces = N + hc.retraces; report.traced_steps = hc.traced_steps; report.steps = hc.steps; report.nan_droplets = hc.nan_droplets;
 		report.windows = 1; report.sparse_droplets = first; report.sparse_retraces = hc.retraces; report.sparse_probe_only = N - hc.nwork;

@@ -1474,7 +1474,8 @@ struct sparse_buffers_t {
 	uint32_t N, maxb, nbx, nby, max_retraces;
 	float *page_vals[2]; unsigned long long *page_mask[2]; uint32_t *blk_list[2], *blk_cnt[2]; // [N][maxb][64], [N][maxb], [N][maxb], [N]: a droplet's trace, and its re-trace in the other buffer
 	uint32_t *cur, *state, *nsteps, *nan; // [N]
-	uint32_t *work;       // [N] the droplets that take a step or write (probe pass): only these get a trace wave
+	uint32_t *work;       // [N] the droplets that take a step or write (probe pass) or were traced again: only these get trace / commit / unmark waves
+	uint32_t *queued;     // [N] 1: the droplet is in work[]
 	uint32_t trace_groups; // workgroups of the trace launch: group i takes work[i], work[i + trace_groups], ...
 	uint32_t *wmin;       // [nbx*nby] lowest droplet that wrote the block in any of its traces (SPEC_NIL: nobody); reset through the block lists at the end of the run
 	uint32_t *touched; uint32_t touched_cap;
@@ -1632,7 +1633,8 @@ TERRA_HD void sparse_probe_body(sparse_buffers_t const &sb, uint32_t j) {
 	if (done && !m.wrote && d.numMoves == 0 && sb.maxb >= 4) { // complete: nothing written, only the box was read
 		sb.blk_cnt[0][j] = m.nblk; sb.nsteps[j] = 0; sb.nan[j] = 0; sb.state[j] = SPARSE_TRACED;
 	}
-	else {sb.blk_cnt[0][j] = 0; sb.state[j] = SPARSE_TRACED; sb.work[TERRA_ATOMIC_ADD(&sb.ctl->nwork, 1u)] = j;}
+	else {sb.blk_cnt[0][j] = 0; sb.state[j] = SPARSE_TRACED; sb.queued[j] = 1; sb.work[TERRA_ATOMIC_ADD(&sb.ctl->nwork, 1u)] = j; return;}
+	sb.queued[j] = 0;
 }
 // the queued droplets, one trace wave each (workgroup i of trace_groups takes every trace_groups-th)
 TERRA_HD void sparse_trace_wave(sparse_buffers_t const &sb, uint32_t group, lean_scratch_t const &ws) {
@@ -1649,7 +1651,10 @@ TERRA_HD void sparse_retrace_wave(sparse_buffers_t const &sb, lean_scratch_t con
 	if (base >= sb.N) return;
 	// one round per conflicted droplet: when more of them are waiting than the run may still re-trace, the multi-version scheduler is the better tool -- now, not after the last allowed round
 	if (wave_uniform(sb.state[base]) == (uint32_t)SPARSE_FAILED || (uint64_t)done + pending > sb.max_retraces) {if (TERRA_LANE0) {c.bail = 1;} return;}
-	if (TERRA_LANE0) {c.retraces = done + 1;}
+	if (TERRA_LANE0) {
+		c.retraces = done + 1;
+		if (!sb.queued[base]) {sb.queued[base] = 1; sb.work[c.nwork] = base; c.nwork = c.nwork + 1;} // (settled by the probe pass until now: from here on it has pages to commit and marks to reset)
+	}
 	sparse_trace_droplet(sb, base, 1u - wave_uniform(sb.cur[base]), SPARSE_FINAL, ws);
 	if (wave_uniform(sb.state[base]) == (uint32_t)SPARSE_FAILED) {if (TERRA_LANE0) {c.bail = 1;}} // (its footprint grew past the block list on the changed grid)
 }
@@ -1678,9 +1683,9 @@ TERRA_HD void sparse_check_wave(sparse_buffers_t const &sb, uint32_t j) {
 }
 // one wave per droplet: the droplets [base, c) are exact and write disjoint blocks -- their pages go to the grid.  A lane takes a page: all of its 64 floats are loaded first
 // (independent 16-byte loads: one memory latency), then the written ones are stored
-TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t j) {
+TERRA_HD void sparse_commit_droplet(sparse_buffers_t const &sb, uint32_t j) {
 	sparse_ctl_t &c = *sb.ctl;
-	if (c.bail || j < c.base || j >= c.c || sb.state[j] == SPARSE_COMMITTED) return;
+	if (j < c.base || j >= c.c || sb.state[j] == SPARSE_COMMITTED) return;
 	uint32_t const buf = sb.cur[j], n = sb.blk_cnt[buf][j];
 	size_t const pbase = (size_t)j*sb.maxb;
 	for (uint32_t e0 = 0; e0 < n; e0 += 64) {
@@ -1722,6 +1727,12 @@ TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t j) {
 		if (sb.nan[j]) {TERRA_ATOMIC_ADD(&c.nan_droplets, 1u);}
 	}
 }
+// only a droplet of the work list can have pages (the ones the probe pass settled wrote nothing): workgroup `group` of trace_groups takes every trace_groups-th of them
+TERRA_HD void sparse_commit_wave(sparse_buffers_t const &sb, uint32_t group) {
+	if (sb.ctl->bail) return;
+	uint32_t const n = wave_uniform(sb.ctl->nwork);
+	for (uint32_t k = group; k < n; k += sb.trace_groups) {sparse_commit_droplet(sb, wave_uniform(sb.work[k]));}
+}
 // sparse version of "clamp to min_zval" (src/erosion.cpp:158-162) when min_zval <= every untouched cell: one thread per recorded write
 TERRA_HD void touched_clamp_body(grid_view_t const &g, uint32_t const *touched, uint32_t i, float min_zval) {
 	uint32_t const cell = touched[i];
@@ -1735,12 +1746,16 @@ TERRA_HD bool sparse_done(sparse_buffers_t const &sb) {return sb.ctl->c >= sb.N 
 // end of the run (also before the general scheduler takes over): every mark is reset through the block lists, both traces of a re-traced droplet.  One wave per droplet, a lane
 // per entry.  Launched right behind the rounds, before the host has read the control block: when the run is NOT complete yet (more rounds or the hand-over follow) and the
 // launch is not the final one (`force`), it does nothing
-TERRA_HD void sparse_unmark_wave(sparse_buffers_t const &sb, uint32_t j, bool force) {
+TERRA_HD void sparse_unmark_wave(sparse_buffers_t const &sb, uint32_t group, bool force) {
 	if (!force && !sparse_done(sb)) return;
-	for (uint32_t buf = 0; buf < 2; ++buf) {
-		uint32_t const n = sb.blk_cnt[buf][j];
-		uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
-		TERRA_LANES(e, n) {uint32_t const ent = bl[e]; if (ent & SPEC_BLK_WRITTEN) {sb.wmin[ent & SPEC_BLK_ID] = SPEC_NIL;}}
+	uint32_t const nw = wave_uniform(sb.ctl->nwork);
+	for (uint32_t k = group; k < nw; k += sb.trace_groups) { // (only a droplet of the work list can have written anything)
+		uint32_t const j = wave_uniform(sb.work[k]);
+		for (uint32_t buf = 0; buf < 2; ++buf) {
+			uint32_t const n = sb.blk_cnt[buf][j];
+			uint32_t const *bl = sb.blk_list[buf] + (size_t)j*sb.maxb;
+			TERRA_LANES(e, n) {uint32_t const ent = bl[e]; if (ent & SPEC_BLK_WRITTEN) {sb.wmin[ent & SPEC_BLK_ID] = SPEC_NIL;}}
+		}
 	}
 }
 // the sparse clamp (touched_clamp_body) over the cells the commits recorded, count taken on the device; thread i of nth.  Idempotent.

@@ -219,8 +219,16 @@ def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cp
                 box[0] = tempfile.mkdtemp(prefix="terra_dgrid_")
         except OSError:
             box[0] = None
-        dist.broadcast_object_list(box, src=0)
-        sockdir = box[0]
+        # rank 0's path to everybody: one all_reduce(sum) of its bytes (the other ranks contribute zeros) -- the same kind of collective, on the same device, as every
+        # other one of this module (no pickling, no object collectives)
+        import torch
+        raw = (box[0] or "").encode()[:255]
+        buf = torch.zeros(256, dtype=torch.int32, device=coll_device)
+        if rank == 0:
+            buf[:len(raw)] = torch.tensor(list(raw), dtype=torch.int32)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        path = bytes(int(v) for v in buf.tolist() if int(v) != 0).decode()
+        sockdir = path or None
     peers = {}
     try:  # step 2: everybody's strips, mapped
         if world > 1:
