@@ -1697,6 +1697,11 @@ TERRA_HD void sparse_commit_droplet(sparse_buffers_t const &sb, uint32_t j) {
 			if (m) {
 				uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
 				spec_u32x4 const *page = (spec_u32x4 const *)(sb.page_vals[buf] + (pbase + e)*SPEC_PAGE); // 256-byte aligned
+				// a block that lies inside the caller's array (all but the ones on the map's rim): cell (cx, cz) is p0[cz*xsize + cx] -- no address case analysis per cell
+				int const X0 = (int)(bx << 3), Z0 = (int)(bz << 3);
+				bool const inner = sb.grid.border != nullptr && X0 >= EROSION_PAD && Z0 >= EROSION_PAD && X0 + 8 <= EROSION_PAD + sb.grid.xsize && Z0 + 8 <= EROSION_PAD + sb.grid.ysize;
+				float *const p0 = inner ? sb.grid.interior + (size_t)(Z0 - EROSION_PAD)*sb.grid.xsize + (X0 - EROSION_PAD) : nullptr;
+				size_t const xs = (size_t)sb.grid.xsize;
 				for (uint32_t half = 0; half < 2; ++half) { // 32 cells at a time: eight loads in flight, 32 value registers (the wave has to fit beside a noise kernel's waves)
 					if (!(uint32_t)(m >> (32*half))) continue;
 					spec_u32x4 v[SPEC_PAGE/8];
@@ -1711,7 +1716,7 @@ TERRA_HD void sparse_commit_droplet(sparse_buffers_t const &sb, uint32_t j) {
 							if ((m >> cc) & 1ull) {
 								uint32_t const X = (bx << 3) + (cc & 7u), Z = (bz << 3) + (cc >> 3);
 								float f; memcpy(&f, &w[u], 4);
-								*sb.grid.at((int)X, (int)Z) = f;
+								if (inner) {p0[(size_t)(cc >> 3)*xs + (cc & 7u)] = f;} else {*sb.grid.at((int)X, (int)Z) = f;}
 								if (sb.touched) {if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;} ++k;}
 							}
 						}
