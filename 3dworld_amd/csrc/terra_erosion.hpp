@@ -1688,39 +1688,31 @@ TERRA_HD void sparse_commit_droplet(sparse_buffers_t const &sb, uint32_t j) {
 	if (j < c.base || j >= c.c || sb.state[j] == SPARSE_COMMITTED) return;
 	uint32_t const buf = sb.cur[j], n = sb.blk_cnt[buf][j];
 	size_t const pbase = (size_t)j*sb.maxb;
-	for (uint32_t e0 = 0; e0 < n; e0 += 64) {
-		TERRA_EACH_LANE(l) {
-			uint32_t const e = e0 + (uint32_t)l;
-			unsigned long long m = 0; uint32_t b = 0;
-			if (e < n) {uint32_t const ent = sb.blk_list[buf][pbase + e]; if (ent & SPEC_BLK_WRITTEN) {b = ent & SPEC_BLK_ID; m = sb.page_mask[buf][pbase + e];}}
-			uint32_t k = wave_reserve(&c.touched, sb.touched ? (uint32_t)__builtin_popcountll(m) : 0u);
-			if (m) {
-				uint32_t const bx = b % sb.nbx, bz = b / sb.nbx;
-				spec_u32x4 const *page = (spec_u32x4 const *)(sb.page_vals[buf] + (pbase + e)*SPEC_PAGE); // 256-byte aligned
-				// a block that lies inside the caller's array (all but the ones on the map's rim): cell (cx, cz) is p0[cz*xsize + cx] -- no address case analysis per cell
-				int const X0 = (int)(bx << 3), Z0 = (int)(bz << 3);
-				bool const inner = sb.grid.border != nullptr && X0 >= EROSION_PAD && Z0 >= EROSION_PAD && X0 + 8 <= EROSION_PAD + sb.grid.xsize && Z0 + 8 <= EROSION_PAD + sb.grid.ysize;
-				float *const p0 = inner ? sb.grid.interior + (size_t)(Z0 - EROSION_PAD)*sb.grid.xsize + (X0 - EROSION_PAD) : nullptr;
-				size_t const xs = (size_t)sb.grid.xsize;
-				for (uint32_t half = 0; half < 2; ++half) { // 32 cells at a time: eight loads in flight, 32 value registers (the wave has to fit beside a noise kernel's waves)
-					if (!(uint32_t)(m >> (32*half))) continue;
-					spec_u32x4 v[SPEC_PAGE/8];
-#pragma unroll
-					for (uint32_t q = 0; q < SPEC_PAGE/8; ++q) {v[q] = page[half*(SPEC_PAGE/8) + q];}
-#pragma unroll
-					for (uint32_t q = 0; q < SPEC_PAGE/8; ++q) {
-						uint32_t const w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-						for (uint32_t u = 0; u < 4; ++u) {
-							uint32_t const cc = 32*half + 4*q + u;
-							if ((m >> cc) & 1ull) {
-								uint32_t const X = (bx << 3) + (cc & 7u), Z = (bz << 3) + (cc >> 3);
-								float f; memcpy(&f, &w[u], 4);
-								if (inner) {p0[(size_t)(cc >> 3)*xs + (cc & 7u)] = f;} else {*sb.grid.at((int)X, (int)Z) = f;}
-								if (sb.touched) {if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;} ++k;}
-							}
-						}
-					}
+	uint32_t const *bl = sb.blk_list[buf] + pbase;
+	unsigned long long const *pm = sb.page_mask[buf] + pbase;
+	float const *pv = sb.page_vals[buf] + pbase*SPEC_PAGE;
+	// a lane per CELL, the pages one after another (entry and mask are the same for the whole wave: scalar loads; the 64 values of a page are one coalesced load): a handful of
+	// registers, so the wave is dispatched beside a noise kernel's four waves per SIMD without waiting for one of them to leave -- the lane-per-page form (75 registers) spent
+	// 40 of its 45 us beside a noise kernel waiting for slots (profiles/r05_timeline_sparse_v3.txt)
+	for (uint32_t e = 0; e < n; ++e) {
+		uint32_t const ent = wave_uniform(bl[e]);
+		if (!(ent & SPEC_BLK_WRITTEN)) continue;
+		unsigned long long const m = pm[e];
+		uint32_t const m_lo = wave_uniform((uint32_t)m), m_hi = wave_uniform((uint32_t)(m >> 32));
+		unsigned long long const mu = (unsigned long long)m_lo | ((unsigned long long)m_hi << 32);
+		uint32_t const b = ent & SPEC_BLK_ID, bx = b % sb.nbx, bz = b / sb.nbx;
+		uint32_t k0 = 0;
+		if (sb.touched) {
+			if (TERRA_LANE0) {k0 = TERRA_ATOMIC_ADD(&c.touched, (uint32_t)__builtin_popcountll(mu));}
+			k0 = wave_uniform(k0);
+		}
+		TERRA_LANES(cc, SPEC_PAGE) {
+			if ((mu >> cc) & 1ull) {
+				uint32_t const X = (bx << 3) + ((uint32_t)cc & 7u), Z = (bz << 3) + ((uint32_t)cc >> 3);
+				*sb.grid.at_sel((int)X, (int)Z) = pv[(size_t)e*SPEC_PAGE + (uint32_t)cc];
+				if (sb.touched) {
+					uint32_t const k = k0 + (uint32_t)__builtin_popcountll(mu & ((1ull << cc) - 1ull));
+					if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
 				}
 			}
 		}
