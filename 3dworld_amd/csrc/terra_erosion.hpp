@@ -437,6 +437,7 @@ struct direct_mem_t {
 #define TERRA_WAVE_SYNC() __syncthreads()
 // a value held by lane `l` of the wave (l wave-uniform), as a scalar
 #define TERRA_READLANE(arr, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (arr)[0]), (l)))
+#define TERRA_READLANE_U32(arr, l) ((uint32_t)__builtin_amdgcn_readlane((int)(arr)[0], (int)wave_uniform((uint32_t)(l))))
 // LDS executes one wave's instructions in order: a store by one lane is seen by a later load of another lane without waiting for anything.  The fence keeps the
 // COMPILER from moving memory operations across it and costs no instruction (wavefront scope)
 #define TERRA_WAVE_FENCE() do {__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();} while (0)
@@ -455,6 +456,7 @@ struct direct_mem_t {
 #define TERRA_LANE_SLOT(l) (l)
 #define TERRA_WAVE_SYNC() do {} while (0)
 #define TERRA_READLANE(arr, l) ((arr)[(l)])
+#define TERRA_READLANE_U32(arr, l) ((arr)[(l)])
 #define TERRA_WAVE_FENCE() do {} while (0)
 template<class T> inline T terra_host_atomic_min(T *p, T v) {T o = *p; if (v < o) *p = v; return o;}
 template<class T> inline T terra_host_atomic_max(T *p, T v) {T o = *p; if (v > o) *p = v; return o;}
@@ -1691,28 +1693,35 @@ TERRA_HD void sparse_commit_droplet(sparse_buffers_t const &sb, uint32_t j) {
 	uint32_t const *bl = sb.blk_list[buf] + pbase;
 	unsigned long long const *pm = sb.page_mask[buf] + pbase;
 	float const *pv = sb.page_vals[buf] + pbase*SPEC_PAGE;
-	// a lane per CELL, the pages one after another (entry and mask are the same for the whole wave: scalar loads; the 64 values of a page are one coalesced load): a handful of
-	// registers, so the wave is dispatched beside a noise kernel's four waves per SIMD without waiting for one of them to leave -- the lane-per-page form (75 registers) spent
-	// 40 of its 45 us beside a noise kernel waiting for slots (profiles/r05_timeline_sparse_v3.txt)
-	for (uint32_t e = 0; e < n; ++e) {
-		uint32_t const ent = wave_uniform(bl[e]);
-		if (!(ent & SPEC_BLK_WRITTEN)) continue;
-		unsigned long long const m = pm[e];
-		uint32_t const m_lo = wave_uniform((uint32_t)m), m_hi = wave_uniform((uint32_t)(m >> 32));
-		unsigned long long const mu = (unsigned long long)m_lo | ((unsigned long long)m_hi << 32);
-		uint32_t const b = ent & SPEC_BLK_ID, bx = b % sb.nbx, bz = b / sb.nbx;
-		uint32_t k0 = 0;
-		if (sb.touched) {
-			if (TERRA_LANE0) {k0 = TERRA_ATOMIC_ADD(&c.touched, (uint32_t)__builtin_popcountll(mu));}
-			k0 = wave_uniform(k0);
+	// Sixty-four entries at a time: lane l fetches entry l and its mask (one memory latency for all of them) and the wave reserves their record slots with one atomic; then
+	// the pages one after another, a lane per CELL -- entry, mask and slot come out of lane i's registers (v_readlane: no memory), the 64 values of a page are one coalesced
+	// load, independent of the page before.  A handful of registers: the wave is dispatched beside a noise kernel's four waves per SIMD without waiting for one of them to
+	// leave (the lane-per-page form, 75 registers, spent 40 of its 45 us beside a noise kernel waiting for slots; a first lane-per-cell form that loaded entry and mask page by
+	// page took 77 us: four dependent latencies per page -- profiles/r05_timeline_sparse_v3.txt)
+	for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+		uint32_t ent_l[TERRA_LANE_SLOTS], mlo_l[TERRA_LANE_SLOTS], mhi_l[TERRA_LANE_SLOTS], k_l[TERRA_LANE_SLOTS];
+		TERRA_EACH_LANE(l) {
+			uint32_t const e = e0 + (uint32_t)l;
+			uint32_t ent = 0; unsigned long long m = 0;
+			if (e < n) {ent = bl[e]; if (ent & SPEC_BLK_WRITTEN) {m = pm[e];}}
+			ent_l[TERRA_LANE_SLOT(l)] = ent; mlo_l[TERRA_LANE_SLOT(l)] = (uint32_t)m; mhi_l[TERRA_LANE_SLOT(l)] = (uint32_t)(m >> 32);
+			k_l[TERRA_LANE_SLOT(l)] = wave_reserve(&c.touched, sb.touched ? (uint32_t)__builtin_popcountll(m) : 0u);
 		}
-		TERRA_LANES(cc, SPEC_PAGE) {
-			if ((mu >> cc) & 1ull) {
-				uint32_t const X = (bx << 3) + ((uint32_t)cc & 7u), Z = (bz << 3) + ((uint32_t)cc >> 3);
-				*sb.grid.at_sel((int)X, (int)Z) = pv[(size_t)e*SPEC_PAGE + (uint32_t)cc];
-				if (sb.touched) {
-					uint32_t const k = k0 + (uint32_t)__builtin_popcountll(mu & ((1ull << cc) - 1ull));
-					if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
+		uint32_t const cnt = (n - e0 < 64u) ? n - e0 : 64u;
+		for (uint32_t i = 0; i < cnt; ++i) {
+			uint32_t const ent = TERRA_READLANE_U32(ent_l, i), m_lo = TERRA_READLANE_U32(mlo_l, i), m_hi = TERRA_READLANE_U32(mhi_l, i), k0 = TERRA_READLANE_U32(k_l, i);
+			unsigned long long const mu = (unsigned long long)m_lo | ((unsigned long long)m_hi << 32);
+			if (!mu) continue;
+			uint32_t const b = ent & SPEC_BLK_ID, bx = b % sb.nbx, bz = b / sb.nbx;
+			float const *page = pv + (size_t)(e0 + i)*SPEC_PAGE;
+			TERRA_LANES(cc, SPEC_PAGE) {
+				if ((mu >> cc) & 1ull) {
+					uint32_t const X = (bx << 3) + ((uint32_t)cc & 7u), Z = (bz << 3) + ((uint32_t)cc >> 3);
+					*sb.grid.at_sel((int)X, (int)Z) = page[cc];
+					if (sb.touched) {
+						uint32_t const k = k0 + (uint32_t)__builtin_popcountll(mu & ((1ull << cc) - 1ull));
+						if (k < sb.touched_cap) {sb.touched[k] = Z*(uint32_t)sb.ec.NX + X;}
+					}
 				}
 			}
 		}
