@@ -223,11 +223,23 @@ template<class CTX> TERRA_HD uint8_t tile_ao_texel(float z_start, int x, int y, 
 }
 
 // tile_t::get_norm (src/tiled_mesh.h:281-284): n = normalize(DY*(z - z[+1]), DX*(z - z[+zvsize]), dxdy), pointT::get_norm (src/3DWorld.h:297-300, TOLERANCE :50)
-TERRA_HD void tile_normal(float const *z, unsigned x, unsigned y, float dxv, float dyv, float dxy, float nv[3]) {
-	unsigned const zv = 130, ix2 = y*zv + x;
-	nv[0] = dyv*(z[ix2] - z[ix2 + 1]); nv[1] = dxv*(z[ix2] - z[ix2 + zv]); nv[2] = dxy;
+// v_rsq_f32 for k_tile_post's byte test (terra_kernels.hpp): the proof there needs |rsq(x)*sqrt(x) - 1| <= 2^-23 for normal x > 0 -- checked over every fp32 input by
+// terra_selftest_hot_sqrt.  The host build (tests/emul) never runs that kernel; it gets a value with the same property.
+TERRA_HD float rsq_approx(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_rsqf(x);
+#else
+	return (float)(1.0/sqrt((double)x));
+#endif
+}
+TERRA_HD void tile_normal_v(float zc, float zr, float zd, float dxv, float dyv, float dxy, float nv[3]) { // zc = z[ix], zr = z[ix + 1], zd = z[ix + zvsize]
+	nv[0] = dyv*(zc - zr); nv[1] = dxv*(zc - zd); nv[2] = dxy;
 	float const mag = sqrtf(nv[0]*nv[0] + nv[1]*nv[1] + nv[2]*nv[2]);
 	if (!(mag < 1.0E-12f)) {nv[0] /= mag; nv[1] /= mag; nv[2] /= mag;}
+}
+TERRA_HD void tile_normal(float const *z, unsigned x, unsigned y, float dxv, float dyv, float dxy, float nv[3]) {
+	unsigned const zv = 130, ix2 = y*zv + x;
+	tile_normal_v(z[ix2], z[ix2 + 1], z[ix2 + zv], dxv, dyv, dxy, nv);
 }
 
 template<class BE> struct terra_engine {
@@ -690,7 +702,8 @@ template<class BE> struct terra_engine {
 	}
 
 	// Self test of the droplet step's square roots (terra_erosion.hpp: sqrt_rn, sqrt_rn_direction) over every stride-th fp32 bit pattern: against the compiler's full sqrtf
-	// expansion and against the double-precision route (float)sqrt((double)x), which is correctly rounded (53 >= 2*24 + 2 bits).  Returns the number of disagreements.
+	// expansion and against the double-precision route (float)sqrt((double)x), which is correctly rounded (53 >= 2*24 + 2 bits); and of the error bound k_tile_post assumes
+	// for v_rsq_f32.  Returns the number of disagreements.
 	uint64_t selftest_hot_sqrt(uint32_t stride) {
 		if (stride == 0) {stride = 1;}
 		// 64-bit counter: up to 4 disagreements per input x 2^32 inputs would wrap a 32-bit one (a sqrt_rn that is wrong everywhere would add up to 0 mod 2^32)
@@ -711,6 +724,10 @@ template<class BE> struct terra_engine {
 					bool const pr = r > FLT_EPSILON, pb = b > FLT_EPSILON;
 					bad += (pr != pb) ? 1u : 0u;
 					if (pr && !same(r, b)) {++bad;}
+				}
+				if (x >= 0x1p-126f && x < INFINITY) { // k_tile_post: the reciprocal square root it decides a normal's bytes with is within 2^-23 (relative) of the real one
+					double const rel = (double)rsq_approx(x)*sqrt((double)x) - 1.0;
+					bad += (rel > 0x1p-23 || rel < -0x1p-23) ? 1u : 0u;
 				}
 			}
 			if (bad) {TERRA_ATOMIC_ADD(d_bad, (unsigned long long)bad);}

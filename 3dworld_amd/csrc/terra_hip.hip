@@ -308,13 +308,21 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	uint32_t *tile_acc = nullptr; size_t tile_acc_bytes = 0; // k_tile_post's per-tile accumulators
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {
-		if (simple_kernels || ((uintptr_t)z & 15) || ((uintptr_t)nm & 3)) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;} // the LDS staging reads 16 bytes at a time, texels are stored as words
+		float const c2 = dxy*dxy;
+		// k_tile_post takes min_normal_z from the largest |n|^2 and never looks at get_norm's "mag < TOLERANCE" branch: a texel's mag is >= sqrtf(dxdy*dxdy) (a sum that only grows, monotone roundings)
+		bool const normalized = !(sqrtf(c2) < 1.0E-12f) && dxy > 0.0f;
+		if (simple_kernels || ((uintptr_t)z & 15) || ((uintptr_t)nm & 3) || !normalized) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy); return;} // the LDS staging reads 16 bytes at a time, texels are stored as words
 		use();
+		uint32_t flat_word; // the texel of a flat cell (n = (+-0, +-0, dxdy): the ocean floor), by the reference's statements
+		{
+			float nv[3]; terra::tile_normal_v(0.0f, 0.0f, 0.0f, dxv, dyv, dxy, nv);
+			flat_word = (uint32_t)(uint8_t)(127.0*((double)nv[0] + 1.0)) | ((uint32_t)(uint8_t)(127.0*((double)nv[1] + 1.0)) << 8) | ((uint32_t)(uint8_t)(127.0*((double)nv[2] + 1.0)) << 16);
+		}
 		size_t const bytes = (size_t)n*terra::TP_ACC*sizeof(uint32_t);
 		if (bytes > tile_acc_bytes) {if (tile_acc) {sync(); (void)hipFree(tile_acc);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_acc, bytes)); tile_acc_bytes = bytes;}
 		hipLaunchKernelGGL(terra::k_tile_post_init, dim3((n*terra::TP_ACC + 255)/256), dim3(256), 0, stream, tile_acc, n);
-		hipLaunchKernelGGL(terra::k_tile_post, dim3(n*4), dim3(terra::TP_THREADS), 0, stream, refs, z, st, nm, mnz, tile_acc, wpz, rad_c, dxv, dyv, dxy);
-		hipLaunchKernelGGL(terra::k_tile_post_final, dim3((n + 255)/256), dim3(256), 0, stream, refs, n, st, mnz, tile_acc, rad_c, nm ? 1 : 0);
+		hipLaunchKernelGGL(terra::k_tile_post, dim3(n*4), dim3(terra::TP_THREADS), 0, stream, refs, z, st, nm, tile_acc, wpz, dxv, dyv, dxy, c2, flat_word);
+		hipLaunchKernelGGL(terra::k_tile_post_final, dim3((n + 255)/256), dim3(256), 0, stream, refs, n, st, mnz, tile_acc, rad_c, dxy, nm ? 1 : 0);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {

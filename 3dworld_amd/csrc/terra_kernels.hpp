@@ -432,22 +432,52 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 	for (int off = 32; off > 0; off >>= 1) {int const o = __shfl_down(v, off, 64); v = (o < v) ? o : v;}
 	return v;
 }
-// One block per (tile, band of 32 texel rows): 4 x more blocks than tiles and 17.7 KB of LDS each (the whole-tile version staged 67.6 KB: two blocks per CU,
-// every block's load, compute and store phases in sequence).  Band yy owns sub-block row yy completely (rows 32*yy .. 32*yy + 32), so the 4 x 4 sub-block
-// ranges are written by exactly one block each; what spans the tile (mzmin / mzmax / radius, the water bbox, min_normal_z) is folded through 8 words of
-// global scratch per tile with atomics and written by a one-thread-per-tile kernel afterwards.
-constexpr unsigned TP_THREADS = 256, TP_BAND_ROWS = 34, TP_ACC = 8; // acc: {-, -, bbox x1, y1, x2, y2, min normal z bits, ticket}
+// One block per (tile, band of 32 texel rows): 4 x more blocks than tiles and 17.7 KB of LDS each.  Band yy owns sub-block row yy completely (rows 32*yy .. 32*yy + 32), so the
+// 4 x 4 sub-block ranges are written by exactly one block each; what spans the tile (the water bbox, min_normal_z) is folded through 8 words of global scratch per tile with
+// atomics and written by a one-thread-per-tile kernel afterwards.
+//
+// Round 5: the kernel was instruction-bound (127 per texel: three IEEE divisions, a square root, three double-precision byte conversions, an index division).  Now a WAVE walks
+// rows -- lane = column, both halves of a row per step, column 128 in one extra pass -- so the row / water bookkeeping is scalar, and a texel's three bytes come from ~40 instructions:
+//   * the bytes are floor(127*(n_i/|n| + 1)).  t_i = fma(127, n_i*rsq(s), 127) is within 4.6e-5 of the double-precision value the reference truncates (rsq <= 2^-23 relative:
+//     terra_selftest_hot_sqrt checks every fp32 input; RN(n/RN(sqrt(s))) is within 2^-23 relative of n/sqrt(s); the fma rounds once, <= 2^-17), so when every t_i of a wave's step
+//     is further than TP_EPS = 2^-14 from an integer, floor(t_i) IS the reference's byte.  Otherwise (a few percent of the steps, and every NaN / Inf) the whole step is redone
+//     with the reference's own statements (tile_normal_v + the double conversion).  Exactly flat texels (n_x = n_y = 0: ocean floor) would always land on an integer: their word
+//     is a launch constant, computed by the host with the same statements.
+//   * min_normal_z = min over texels of RN(dxdy/RN(sqrt(s))) is monotone in s: the wave keeps max(s) (NaN never wins, as in std::min) and k_tile_post_final takes the one square
+//     root and division.  The reference's "mag < TOLERANCE: leave unnormalized" branch cannot be taken when sqrtf(dxdy*dxdy) >= TOLERANCE, which the host checks (else: simple path).
+constexpr unsigned TP_THREADS = 256, TP_BAND_ROWS = 34, TP_ACC = 8; // acc: {-, -, bbox x1, y1, x2, y2, max |n|^2 bits, -}
+constexpr float TP_EPS = 0x1p-14f;
 __global__ __launch_bounds__(256) void k_tile_post_init(uint32_t *__restrict__ acc, uint32_t n) {
 	uint32_t const i = blockIdx.x*blockDim.x + threadIdx.x;
 	if (i >= n*TP_ACC) return;
 	uint32_t const f = i % TP_ACC;
-	acc[i] = (f < 2) ? 0xFFFFFFFFu : ((f < 4) ? 0x7FFFFFFFu : ((f < 6) ? 0x80000000u : ((f == 6) ? 0x3F800000u : 0u)));
+	acc[i] = (f < 2) ? 0xFFFFFFFFu : ((f < 4) ? 0x7FFFFFFFu : ((f < 6) ? 0x80000000u : 0u));
+}
+// the reference's texel, statement by statement (src/tiled_mesh.cpp:865-880)
+__device__ __forceinline__ uint32_t tp_word_exact(float zc, float zr, float zd, float dxv, float dyv, float dxy) {
+	float nv[3];
+	tile_normal_v(zc, zr, zd, dxv, dyv, dxy, nv);
+	uint32_t const b0 = (uint8_t)(127.0*((double)nv[0] + 1.0)), b1 = (uint8_t)(127.0*((double)nv[1] + 1.0)), b2 = (uint8_t)(127.0*((double)nv[2] + 1.0));
+	return b0 | (b1 << 8) | (b2 << 16); // A = 0
+}
+// the short form: word and |n|^2; returns false when a byte is not certain
+__device__ __forceinline__ bool tp_word_fast(float zc, float zr, float zd, float dxv, float dyv, float dxy, float c2, uint32_t flat_word, uint32_t &word, float &s) {
+	float const n0 = dyv*(zc - zr), n1 = dxv*(zc - zd);
+	s = n0*n0 + n1*n1 + c2; // the reference's sum, in its order; c2 = dxdy*dxdy
+	float const r = rsq_approx(s);
+	float const t0 = __builtin_fmaf(127.0f, n0*r, 127.0f), t1 = __builtin_fmaf(127.0f, n1*r, 127.0f), t2 = __builtin_fmaf(127.0f, dxy*r, 127.0f);
+	float const lim = 0.5f - TP_EPS;
+	bool const sure = (__builtin_fabsf(__builtin_amdgcn_fractf(t0) - 0.5f) < lim) & (__builtin_fabsf(__builtin_amdgcn_fractf(t1) - 0.5f) < lim) & (__builtin_fabsf(__builtin_amdgcn_fractf(t2) - 0.5f) < lim); // false for NaN
+	bool const flat = (n0 == 0.0f) & (n1 == 0.0f);
+	uint32_t const w = (uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16);
+	word = flat ? flat_word : w;
+	return sure | flat;
 }
 __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, terra_tile_stats *__restrict__ stats,
-	uint8_t *__restrict__ normals, float *__restrict__ min_nz, uint32_t *__restrict__ acc, float wpz_max, float rad_c, float dxv, float dyv, float dxy)
+	uint8_t *__restrict__ normals, uint32_t *__restrict__ acc, float wpz_max, float dxv, float dyv, float dxy, float c2, uint32_t flat_word)
 {
 	__shared__ __attribute__((aligned(16))) float tp_z[TP_BAND_ROWS*130];
-	__shared__ uint32_t s_lo[4], s_hi[4], s_mnz;
+	__shared__ uint32_t s_lo[4], s_hi[4], s_smax;
 	__shared__ int s_bb[4];
 	unsigned const t = blockIdx.x >> 2, yy = blockIdx.x & 3u, tid = threadIdx.x, zv = 130, stride = 129, bs = 32, row0 = yy*bs;
 	tile_ref_pod_t const r = refs[t];
@@ -456,59 +486,93 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 		float4 const *src = (float4 const *)(zvals + (size_t)t*zv*zv + (size_t)row0*zv); // 67600 bytes per tile, 16640 per band: 16-byte aligned
 		for (unsigned i = tid; i < TP_BAND_ROWS*zv/4; i += TP_THREADS) {((float4 *)tp_z)[i] = src[i];}
 	}
-	if (tid == 0) {s_mnz = 0x3F800000u; s_bb[0] = x1 + 128; s_bb[1] = y1 + 128; s_bb[2] = x1; s_bb[3] = y1;} // water bbox starts denormalized
+	if (tid < 4) {s_lo[tid] = f2ord(100.0f); s_hi[tid] = ~f2ord(-100.0f);} // folds start at szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
+	if (tid == 0) {s_smax = 0u; s_bb[0] = x1 + 128; s_bb[1] = y1 + 128; s_bb[2] = x1; s_bb[3] = y1;} // water bbox starts denormalized
 	__syncthreads();
-	float const *z = tp_z;
-	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) + (size_t)row0*stride : nullptr;
-	if (stats) { // sub-block (xx, yy) covers cells [32*xx, 32*xx + 32] x [32*yy, 32*yy + 32] (shared edges belong to both): one wave per sub-block
-		unsigned const xx = tid >> 6;
-		uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
-		for (unsigned q = tid & 63; q < (bs + 1)*(bs + 1); q += 64) {
-			unsigned const y = q/(bs + 1), x = xx*bs + q % (bs + 1);
-			float const v = z[y*zv + x];
-			if (v == v) {uint32_t const o = f2ord(v); lo = (o < lo) ? o : lo; hi = (~o < hi) ? ~o : hi;} // std::min / std::max never let a NaN win
-		}
-		lo = wave_min_u32(lo); hi = wave_min_u32(hi);
-		if ((tid & 63) == 0) {uint32_t const l0 = f2ord(100.0f), h0 = ~f2ord(-100.0f); s_lo[xx] = (lo < l0) ? lo : l0; s_hi[xx] = (hi < h0) ? hi : h0;} // folds start at szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
-	}
-	int bx0 = x1 + 128, by0 = y1 + 128, bx1n = -x1, by1n = -y1; // water bbox as four minima (max = -min(-v))
-	uint32_t mnz = 0x3F800000u;
+	unsigned const w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63; // the wave index as a scalar: rows, row tests and the water rows stay on the scalar unit
 	unsigned const nrows = (yy == 3) ? bs + 1 : bs; // texel rows of this band: 32, the last band also row 128
-	for (unsigned p = tid; p < (bs + 1)*stride; p += TP_THREADS) { // cells 0..128 of rows row0 .. row0 + 32: what sub-block row yy visits; texels of rows row0 .. row0 + nrows - 1
-		unsigned const y = p/stride, x = p - y*stride;
-		if (stats) {
-			float const v = z[y*zv + x];
-			if (v < wpz_max) {
-				int const wx = x1 + (int)x, wy = y1 + (int)(row0 + y);
-				bx0 = (wx < bx0) ? wx : bx0; by0 = (wy < by0) ? wy : by0; bx1n = (-wx < bx1n) ? -wx : bx1n; by1n = (-wy < by1n) ? -wy : by1n;
-			}
+	uint32_t *nout = normals ? (uint32_t *)(normals + (size_t)t*stride*stride*4) + (size_t)row0*stride : nullptr;
+	bool const want_stats = stats != nullptr;
+	// rows [ya, yb) of the band's 33 cell rows belong to this wave; lane = cell column x (first half) and 64 + x (second half)
+	unsigned const ya = w*8, yb = (w == 3) ? bs + 1 : ya + 8;
+	float loA = 100.0f, hiA = -100.0f, loB = 100.0f, hiB = -100.0f, smax = 0.0f;
+	unsigned long long wetA = 0, wetB = 0; // columns with a cell under wpz_max
+	int wy0 = 0x7FFFFFFF, wy1 = -1; // first / last such row (band coordinates)
+	float const *zl = tp_z + lane;
+	float cA = zl[ya*zv], cB = zl[ya*zv + 64];
+	for (unsigned y = ya; y < yb; ++y) {
+		float const *row = zl + y*zv;
+		float const rA = row[1], rB = row[65], dA = row[zv], dB = row[zv + 64];
+		if (want_stats) {
+			loA = (cA < loA) ? cA : loA; hiA = (cA > hiA) ? cA : hiA; loB = (cB < loB) ? cB : loB; hiB = (cB > hiB) ? cB : hiB; // std::min / std::max: a NaN never wins
+			unsigned long long const mA = __builtin_amdgcn_ballot_w64(cA < wpz_max), mB = __builtin_amdgcn_ballot_w64(cB < wpz_max);
+			wetA |= mA; wetB |= mB;
+			if (mA | mB) {wy0 = (wy0 < (int)y) ? wy0 : (int)y; wy1 = (int)y;}
 		}
 		if (nout && y < nrows) {
-			float nv[3];
-			tile_normal(z, x, y, dxv, dyv, dxy, nv);
-			uint32_t const b0 = (uint8_t)(127.0*((double)nv[0] + 1.0)), b1 = (uint8_t)(127.0*((double)nv[1] + 1.0)), b2 = (uint8_t)(127.0*((double)nv[2] + 1.0));
-			nout[p] = b0 | (b1 << 8) | (b2 << 16); // A = 0
-			if (nv[2] < 1.0f) {uint32_t u; memcpy(&u, &nv[2], 4); mnz = (u < mnz) ? u : mnz;} // positive floats order like their bit patterns
+			uint32_t wA, wB; float sA, sB;
+			bool const okA = tp_word_fast(cA, rA, dA, dxv, dyv, dxy, c2, flat_word, wA, sA), okB = tp_word_fast(cB, rB, dB, dxv, dyv, dxy, c2, flat_word, wB, sB);
+			if (__builtin_amdgcn_ballot_w64(!(okA & okB)) != 0) {wA = tp_word_exact(cA, rA, dA, dxv, dyv, dxy); wB = tp_word_exact(cB, rB, dB, dxv, dyv, dxy);}
+			nout[y*stride + lane] = wA; nout[y*stride + lane + 64] = wB;
+			smax = __builtin_fmaxf(smax, __builtin_fmaxf(sA, sB));
+		}
+		cA = dA; cB = dB;
+	}
+	if (want_stats) { // sub-block xx covers columns [32*xx, 32*xx + 32]: the shared columns 32, 64, 96 count on both sides
+		uint32_t la = f2ord(loA), ha = ~f2ord(hiA), lb = f2ord(loB), hb = ~f2ord(hiB);
+		uint32_t const la0 = la, ha0 = ha, lb0 = lb, hb0 = hb;
+#pragma unroll
+		for (int off = 16; off > 0; off >>= 1) { // minima over each half of the wave
+			uint32_t o;
+			o = __shfl_xor(la, off, 64); la = (o < la) ? o : la; o = __shfl_xor(ha, off, 64); ha = (o < ha) ? o : ha;
+			o = __shfl_xor(lb, off, 64); lb = (o < lb) ? o : lb; o = __shfl_xor(hb, off, 64); hb = (o < hb) ? o : hb;
+		}
+		if (lane == 0)  {atomicMin(&s_lo[0], la); atomicMin(&s_hi[0], ha); atomicMin(&s_lo[2], lb); atomicMin(&s_hi[2], hb); atomicMin(&s_lo[1], lb0); atomicMin(&s_hi[1], hb0);} // column 64 also closes sub-block 1
+		if (lane == 32) {atomicMin(&s_lo[1], la); atomicMin(&s_hi[1], ha); atomicMin(&s_lo[3], lb); atomicMin(&s_hi[3], hb); atomicMin(&s_lo[0], la0); atomicMin(&s_hi[0], ha0); atomicMin(&s_lo[2], lb0); atomicMin(&s_hi[2], hb0);} // columns 32 and 96 close sub-blocks 0 and 2
+	}
+	int wx0 = 0x7FFFFFFF, wx1 = -1;
+	if (wetA) {wx0 = __builtin_ctzll(wetA); wx1 = 63 - __builtin_clzll(wetA);}
+	if (wetB) {int const f = 64 + __builtin_ctzll(wetB); wx0 = (wx0 < f) ? wx0 : f; wx1 = 127 - __builtin_clzll(wetB);}
+	if (w == 1) { // column 128: a lane per row
+		unsigned const y = lane;
+		bool const in = y <= bs;
+		float const *c = tp_z + (in ? y : 0u)*zv + 128;
+		float const zc = c[0], zr = c[1], zd = c[zv];
+		if (want_stats) {
+			if (in && zc == zc) {uint32_t const o = f2ord(zc); atomicMin(&s_lo[3], o); atomicMin(&s_hi[3], ~o);}
+			unsigned long long const m = __builtin_amdgcn_ballot_w64(in && zc < wpz_max);
+			if (m) {
+				int const f = __builtin_ctzll(m), l = 63 - __builtin_clzll(m);
+				wx1 = 128; wx0 = (wx0 < 128) ? wx0 : 128; wy0 = (wy0 < f) ? wy0 : f; wy1 = (wy1 > l) ? wy1 : l;
+			}
+		}
+		if (nout) {
+			uint32_t wd; float s;
+			bool const ok = tp_word_fast(zc, zr, zd, dxv, dyv, dxy, c2, flat_word, wd, s);
+			if (__builtin_amdgcn_ballot_w64(!ok) != 0) {wd = tp_word_exact(zc, zr, zd, dxv, dyv, dxy);}
+			if (y < nrows) {nout[y*stride + 128] = wd; smax = __builtin_fmaxf(smax, s);}
 		}
 	}
-	if (stats) {
-		bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1n = wave_min_i32(bx1n); by1n = wave_min_i32(by1n);
-		if ((tid & 63) == 0) {atomicMin(&s_bb[0], bx0); atomicMin(&s_bb[1], by0); atomicMax(&s_bb[2], -bx1n); atomicMax(&s_bb[3], -by1n);}
+	if (want_stats && lane == 0 && wx1 >= 0) {atomicMin(&s_bb[0], x1 + wx0); atomicMin(&s_bb[1], y1 + (int)row0 + wy0); atomicMax(&s_bb[2], x1 + wx1); atomicMax(&s_bb[3], y1 + (int)row0 + wy1);}
+	if (nout) { // s >= 0: positive floats order like their bit patterns
+		uint32_t u; memcpy(&u, &smax, 4);
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {uint32_t const o = __shfl_xor(u, off, 64); u = (o > u) ? o : u;}
+		if (lane == 0) {atomicMax(&s_smax, u);}
 	}
-	if (nout) {mnz = wave_min_u32(mnz); if ((tid & 63) == 0) {atomicMin(&s_mnz, mnz);}}
 	__syncthreads();
 	if (tid == 0) { // the band's results; the tile's totals are folded by k_tile_post_final after this kernel (a device-wide fence per block, the
 		// alternative, writes back the XCD's L2 every time on this chip: measured 3 x slower than the whole pass)
 		uint32_t *a = acc + (size_t)t*TP_ACC;
-		if (stats) {
+		if (want_stats) {
 			for (int k = 0; k < 4; ++k) {stats[t].sub_zmin[yy*4 + k] = ord2f(s_lo[k]); stats[t].sub_zmax[yy*4 + k] = ord2f(~s_hi[k]);}
 			atomicMin((int *)&a[2], s_bb[0]); atomicMin((int *)&a[3], s_bb[1]); atomicMax((int *)&a[4], s_bb[2]); atomicMax((int *)&a[5], s_bb[3]);
 		}
-		if (nout) {atomicMin(&a[6], s_mnz);}
+		if (nout) {atomicMax(&a[6], s_smax);}
 	}
 }
 // one thread per tile: mzmin / mzmax fold the 16 sub-block ranges in the reference's order with its std::min / std::max (src/tiled_mesh.cpp:536-538), radius, water bbox, min_normal_z
-__global__ __launch_bounds__(256) void k_tile_post_final(tile_ref_pod_t const *__restrict__ refs, uint32_t n, terra_tile_stats *__restrict__ stats, float *__restrict__ min_nz, uint32_t const *__restrict__ acc, float rad_c, int have_normals) {
+__global__ __launch_bounds__(256) void k_tile_post_final(tile_ref_pod_t const *__restrict__ refs, uint32_t n, terra_tile_stats *__restrict__ stats, float *__restrict__ min_nz, uint32_t const *__restrict__ acc, float rad_c, float dxy, int have_normals) {
 	uint32_t const t = blockIdx.x*blockDim.x + threadIdx.x;
 	if (t >= n) return;
 	uint32_t const *a = acc + (size_t)t*TP_ACC;
@@ -521,7 +585,11 @@ __global__ __launch_bounds__(256) void k_tile_post_final(tile_ref_pod_t const *_
 		stats[t].radius = (float)(0.5*sqrt((double)(rad_c + (mzmax - mzmin)*(mzmax - mzmin))));
 		stats[t].wx1 = imin((int)a[2], x1 + 128); stats[t].wy1 = imin((int)a[3], y1 + 128); stats[t].wx2 = imax((int)a[4], x1); stats[t].wy2 = imax((int)a[5], y1);
 	}
-	if (min_nz && have_normals) {float f; uint32_t const u = a[6]; memcpy(&f, &u, 4); min_nz[t] = f;}
+	if (min_nz && have_normals) { // min_normal_z = min(1.0, min over texels of dxdy/mag) = dxdy / (the largest mag), both roundings monotone; a NaN never wins (src/tiled_mesh.cpp:874)
+		float smax; uint32_t const u = a[6]; memcpy(&smax, &u, 4);
+		float const nz = dxy/sqrtf(smax);
+		min_nz[t] = (nz < 1.0f) ? nz : 1.0f;
+	}
 }
 
 // ------------------------------------------------------------------ row f1: tile AO lighting (tile_t::calc_mesh_ao_lighting, src/tiled_mesh.cpp:634-659)

@@ -281,7 +281,8 @@ int  terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32
 int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t erosion_iters_tt,
                               float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z);
 /* self test: the droplet step takes its two square roots per step with a shortened instruction sequence (csrc/terra_erosion.hpp: sqrt_rn); this runs it over every
- * stride-th fp32 bit pattern (stride 1: all 2^32, a few ms on the GPU) against sqrtf and against the correctly rounded double-precision route.  *mismatches must be 0. */
+ * stride-th fp32 bit pattern (stride 1: all 2^32, a few ms on the GPU) against sqrtf and against the correctly rounded double-precision route; the tile normals' byte test
+ * (csrc/terra_kernels.hpp: k_tile_post) relies on the hardware's reciprocal square root being within 2^-23 of the real one, checked over the same inputs.  *mismatches must be 0. */
 int  terra_selftest_hot_sqrt(terra_ctx *ctx, uint32_t stride, uint64_t *mismatches);
 
 /* ---- heightmap files, host side: 8- / 16-bit grayscale PNG exactly as the reference reads / writes them through libpng (src/image_io.cpp:493-605):
