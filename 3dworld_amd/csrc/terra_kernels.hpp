@@ -800,18 +800,37 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 	for (unsigned k = 0; k < VOX_SINES/2; ++k) {zv[k] = sg_v2f{zcol[(size_t)(2*k)*nz], zcol[(size_t)(2*k + 1)*nz]};}
 	float const zterm = __fmul_rn((float)z, zscale);
 	size_t const c0 = (size_t)blockIdx.x*VX_PER_BLOCK, ncol = (size_t)nx*ny;
+	if (c0 >= ncol) return;
+	// The P stream is software-pipelined by hand.  Scalar loads return out of order, so the only usable wait is lgkmcnt(0) -- left to the compiler, every second 64-byte load was
+	// issued directly in front of such a wait (its whole latency exposed: SQ_WAIT_ANY 0.65 of the wave cycles).  Here a stage is TWO 64-byte loads (16 k of a column pair), in
+	// flight while the 32 packed instructions of the previous stage run: wait, issue the next stage into the other buffers, compute.  The buffers are asm operands from issue
+	// to use, nothing else touches them.  P itself streams from HBM (63 MB at 512^3, no reuse): each wave first touches its share of the block's 8 KB slice with ONE vector load
+	// (a lane per 64-byte line), so that the scalar loads find the lines in the L2 instead of paying the HBM latency chunk by chunk.
+	size_t const last_pair = (ncol - 1) >> 1;
+	float const *pp = P + (c0 >> 1)*VX_PSTRIDE; // chunk 0 of this block's first column pair
+	float touched;
+	{
+		unsigned const line = (threadIdx.x >> 6)*32u + (threadIdx.x & 31u); // 4 waves x 32 lines x 64 B = 16 column pairs x 512 B
+		size_t const pair = (c0 >> 1) + (line >> 3);
+		float const *tp = P + ((pair <= last_pair) ? pair : last_pair)*VX_PSTRIDE + (line & 7u)*16u;
+		asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(tp));
+	}
+	vx_v16f b0, b1, b2, b3;
+	asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(b0), "=&s"(b1) : "s"(pp));
+#define VX_NEXT(CA, CB, NA, NB, ADDR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %2, %4, 0x0\n\ts_load_dwordx16 %3, %4, 0x40" : "+s"(CA), "+s"(CB), "=&s"(NA), "=&s"(NB) : "s"(ADDR))
+#define VX_STEP(BUF, Q, J, LO, HI) if (Q*8 + J < VOX_SINES) {vx_mul_add<(J & 1)>(val, sg_v2f{BUF.LO, BUF.HI}, zv[(Q*8 + J) >> 1]);}
+#define VX_CHUNK(BUF, Q) VX_STEP(BUF, Q, 0, s0, s1) VX_STEP(BUF, Q, 1, s2, s3) VX_STEP(BUF, Q, 2, s4, s5) VX_STEP(BUF, Q, 3, s6, s7) VX_STEP(BUF, Q, 4, s8, s9) VX_STEP(BUF, Q, 5, sa, sb) VX_STEP(BUF, Q, 6, sc, sd) VX_STEP(BUF, Q, 7, se, sf)
 	for (int c = 0; c < VX_PER_BLOCK; c += 2) {
 		size_t const col = c0 + c; // = x + y*nx of the pair's first column (even), wave-uniform
 		if (col >= ncol) break;
-		vx_v16f const *p = (vx_v16f const *)(P + (col >> 1)*VX_PSTRIDE);
-		sg_v2f val = {0.0f, 0.0f};
-#pragma unroll
-		for (unsigned q = 0; q < 8; ++q) { // (xv*yv)*zv, summed in k order; 8 pairs per 64-byte scalar load
-			vx_v16f const pc = p[q];
-#define VX_STEP(J, LO, HI) if (q*8 + J < VOX_SINES) {vx_mul_add<(J & 1)>(val, sg_v2f{pc.LO, pc.HI}, zv[(q*8 + J) >> 1]);}
-			VX_STEP(0, s0, s1) VX_STEP(1, s2, s3) VX_STEP(2, s4, s5) VX_STEP(3, s6, s7) VX_STEP(4, s8, s9) VX_STEP(5, sa, sb) VX_STEP(6, sc, sd) VX_STEP(7, se, sf)
-#undef VX_STEP
-		}
+		size_t const np = ((col >> 1) + 1 <= last_pair) ? (col >> 1) + 1 : last_pair; // the pair whose first stage is fetched under this pair's last one (past the end: any valid address)
+		float const *pn = P + np*VX_PSTRIDE;
+		sg_v2f val = {0.0f, 0.0f}; // (xv*yv)*zv, summed in k order; 8 pairs per 64-byte scalar load
+		VX_NEXT(b0, b1, b2, b3, pp + 32); VX_CHUNK(b0, 0) VX_CHUNK(b1, 1)
+		VX_NEXT(b2, b3, b0, b1, pp + 64); VX_CHUNK(b2, 2) VX_CHUNK(b3, 3)
+		VX_NEXT(b0, b1, b2, b3, pp + 96); VX_CHUNK(b0, 4) VX_CHUNK(b1, 5)
+		VX_NEXT(b2, b3, b0, b1, pn);      VX_CHUNK(b2, 6) VX_CHUNK(b3, 7)
+		pp = pn;
 		float va = __fadd_rn(val.x, zterm), vb = __fadd_rn(val.y, zterm);
 		if (normalize) {va = clip_pm1(va); vb = clip_pm1(vb);}
 		if (active) {
@@ -819,6 +838,10 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 			if (col + 1 < ncol) {__builtin_nontemporal_store(vb, &out[(col + 1)*nz + z]);}
 		}
 	}
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(touched)); // the last prefetch and the touch load land before the wave ends
+#undef VX_CHUNK
+#undef VX_STEP
+#undef VX_NEXT
 }
 
 } // namespace terra
