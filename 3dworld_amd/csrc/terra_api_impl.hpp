@@ -243,6 +243,10 @@ int terra_gen_grid_rows_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx,
 		if (h_max) *h_max = mm[1];
 	TERRA_CATCH
 }
+int terra_gen_grid_rows_minmax_async_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, uint32_t row0, uint32_t nrows, float *d_out, float *d_minmax) {
+	TERRA_CHECK_CTX if (!d_out || !d_minmax) return terra::fail(TERRA_ERR_ARG, "null output");
+	TERRA_TRY ctx->eng.gen_grid_dev(x0, y0, dx, dy, nx, ny, flags, min_start_sin, d_out, nullptr, row0, nrows, d_minmax); TERRA_CATCH
+}
 int terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin, float *h_out) {
 	TERRA_CHECK_CTX if (!h_out) return terra::fail(TERRA_ERR_ARG, "null output");
 	TERRA_TRY

@@ -126,7 +126,22 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	size_t vm_granularity() {use(); hipMemAllocationProp const p = vm_prop(); size_t g = 0; TERRA_HIP_CHECK(hipMemGetAllocationGranularity(&g, &p, hipMemAllocationGranularityRecommended)); return g ? g : ((size_t)2 << 20);}
 	void *vm_create(size_t bytes) {use(); hipMemAllocationProp const p = vm_prop(); hipMemGenericAllocationHandle_t h = nullptr; TERRA_HIP_CHECK(hipMemCreate(&h, bytes, &p, 0)); return (void *)h;}
 	int vm_export_fd(void *h) {use(); int fd = -1; TERRA_HIP_CHECK(hipMemExportToShareableHandle((void *)&fd, (hipMemGenericAllocationHandle_t)h, hipMemHandleTypePosixFileDescriptor, 0)); return fd;}
-	void *vm_import_fd(int fd) {use(); hipMemGenericAllocationHandle_t h = nullptr; TERRA_HIP_CHECK(hipMemImportFromShareableHandle(&h, (void *)&fd, hipMemHandleTypePosixFileDescriptor)); return (void *)h;}
+	// The runtime that PyTorch 2.10 brings along (HIP 7.0: what a process that imported torch runs on) takes a POINTER to the descriptor; the system runtime of ROCm 7.2 (what a
+	// plain C / C++ process such as 3DWorld links) takes the descriptor itself, as CUDA does, and reports the pointer form as "invalid argument" -- found with
+	// tools/bench_native_onegrid.c.  The pointer form is tried first (the value form would make an older runtime dereference a small integer).
+	void *vm_import_fd(int fd) {
+		use();
+		hipMemGenericAllocationHandle_t h = nullptr;
+		hipError_t e = hipMemImportFromShareableHandle(&h, (void *)&fd, hipMemHandleTypePosixFileDescriptor);
+		int ver = 0;
+		if (e == hipErrorInvalidValue && hipRuntimeGetVersion(&ver) == hipSuccess && ver >= 70200000) {
+			(void)hipGetLastError();
+			h = nullptr;
+			e = hipMemImportFromShareableHandle(&h, (void *)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
+		}
+		if (e != hipSuccess) {throw std::runtime_error(std::string("hipMemImportFromShareableHandle (descriptor by pointer and by value): ") + hipGetErrorString(e));}
+		return (void *)h;
+	}
 	void *vm_reserve(size_t total, size_t align) {use(); void *p = nullptr; TERRA_HIP_CHECK(hipMemAddressReserve(&p, total, align, nullptr, 0)); return p;}
 	void vm_map(void *base, size_t off, void *h, size_t bytes) {use(); TERRA_HIP_CHECK(hipMemMap((uint8_t *)base + off, bytes, 0, (hipMemGenericAllocationHandle_t)h, 0));}
 	static void vm_set_access(void *base, size_t total, int const *devices, size_t n) {

@@ -143,6 +143,7 @@ _PROTOS = {
     "terra_event_destroy": (None, [_vp]),
     "terra_apply_erosion_devmin_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32]),
     "terra_gen_grid_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _vp]),
+    "terra_gen_grid_rows_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _u32, _u32, _vp, _vp]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
     "terra_set_erosion_tuning": (_i32, [_vp, _u32, _u32, _u32]),
     "terra_set_erosion_slice_steps": (_i32, [_vp, _u32]),
@@ -572,6 +573,10 @@ class Terra:
     def gen_grid_minmax_async_dev(self, ptr, x0, y0, dx, dy, nx, ny, minmax_ptr, flags=GEN_GLACIATE, min_start_sin=0):
         """noise (+ glaciate) with {min, max} left in device memory at minmax_ptr (2 floats); nothing is read back, the call only enqueues"""
         self._ck(self.lib.terra_gen_grid_minmax_async_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, ptr, minmax_ptr))
+
+    def gen_grid_rows_minmax_async_dev(self, ptr, x0, y0, dx, dy, nx, ny, row0, nrows, minmax_ptr, flags=GEN_GLACIATE, min_start_sin=0):
+        """rows [row0, row0 + nrows) with the strip's {min, max} left in device memory at minmax_ptr; the call only enqueues"""
+        self._ck(self.lib.terra_gen_grid_rows_minmax_async_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, row0, nrows, ptr, minmax_ptr))
 
     def apply_erosion_devmin_dev(self, ptr, xsize, ysize, min_ptr, iters, flags=0):
         """apply_erosion with min_zval read from device memory (one float) when the final clamp runs"""

@@ -208,6 +208,11 @@ int  terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint
  * min / max of the strip -- min(vals) of the whole map is the minimum over the strips (one float through ncclAllReduce(min), see bench.py --workload strips). */
 int  terra_gen_grid_rows_minmax_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin,
                                     uint32_t row0, uint32_t nrows, float *d_out, float *h_min, float *h_max);
+/* the same with the strip's {min, max} left in DEVICE memory (d_minmax: 2 floats), nothing read back: the call only enqueues.  One rank's part of a step of the one-grid
+ * pipeline with no host round trip: the strip's noise, ncclAllReduce(min) of d_minmax[0] on the same stream, terra_apply_erosion_devmin_dev on the eroding rank
+ * (tools/bench_native_onegrid.c) */
+int  terra_gen_grid_rows_minmax_async_dev(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint32_t nx, uint32_t ny, uint32_t flags, int min_start_sin,
+                                          uint32_t row0, uint32_t nrows, float *d_out, float *d_minmax);
 
 /* ---- point query and ground-mode post-pass
  * eval_mesh_sin_terms (src/mesh_gen.cpp:797-805): non-separable point query used for biome parameters / collision height; evaluated on the host.

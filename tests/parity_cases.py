@@ -935,15 +935,22 @@ def case_grid_row_strips(pkg, t, orc, mode, nx, ny, nstrips):
     orc.init(oc)
     ref = orc.gen_grid(-nx / 2, 7 - ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, 1)
     bounds = [round(i * ny / nstrips) for i in range(nstrips + 1)]
-    buf = t.alloc(nx * ny * 4)
+    buf = t.alloc(nx * ny * 4); buf2 = t.alloc(nx * ny * 4); mm = t.alloc(8)
     mns, mxs = [], []
     for r0, r1 in zip(bounds[:-1], bounds[1:]):
         if r1 == r0:
             continue
         mn, mx = t.gen_grid_rows_minmax_dev(buf.ptr + r0 * nx * 4, -nx / 2, 7 - ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, r0, r1 - r0, pkg.GEN_GLACIATE)
         mns.append(mn); mxs.append(mx)
+        # the enqueue-only form: same rows, {min, max} of the strip in device memory
+        t.gen_grid_rows_minmax_async_dev(buf2.ptr + r0 * nx * 4, -nx / 2, 7 - ny / 2, st.DX_VAL, st.DY_VAL, nx, ny, r0, r1 - r0, mm.ptr, pkg.GEN_GLACIATE)
+        t.synchronize()
+        dmm = mm.download(np.float32, (2,))
+        assert dmm[0] == np.float32(mn) and dmm[1] == np.float32(mx)
     z = buf.download(np.float32, (ny, nx)); buf.free()
     assert_bit_equal(ref, z, f"row strips mode {mode}")
+    z2 = buf2.download(np.float32, (ny, nx)); buf2.free(); mm.free()
+    assert_bit_equal(ref, z2, f"row strips (enqueue-only form) mode {mode}")
     assert np.float32(min(mns)) == ref.min() and np.float32(max(mxs)) == ref.max()
     import pytest
     with pytest.raises(pkg.TerraError):
