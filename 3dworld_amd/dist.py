@@ -297,6 +297,18 @@ class OneHeightmapPipeline:
             self.rows = rows
         self.coll_device = coll_device
         self._threading = threading
+        # A collective that runs on the device (RCCL) lets a step be enqueued without a host round trip -- the form tools/bench_native_onegrid.c has in C: the strip's
+        # {min, max} stay in HBM (terra_gen_grid_rows_minmax_async_dev), all_reduce(min) works on that float on the noise context's stream, the eroding context's
+        # stream waits for an event behind it and the final clamp reads min(vals) from HBM (terra_apply_erosion_devmin_dev).  Measured on one GPU at a simulated world
+        # of 8: 0.15-0.16 ms per rank and step against 0.21-0.24 ms with the read-back (profiles/r05_onegrid_native.jsonl, bench.py detail.onegrid_rank_floor).
+        self._dev_paced = str(coll_device).startswith("cuda")
+        if self._dev_paced:
+            import torch
+            self._torch = torch
+            self._tstream = torch.cuda.Stream(device=coll_device)  # the noise context works on it, the process group orders its collective against it
+            self.nctx.set_stream(self._tstream.cuda_stream)
+            self._mm = torch.zeros((grids, 2), dtype=torch.float32, device=coll_device)
+            self._ev = [self.nctx.event_create() for _ in range(grids)]
 
     def close(self):
         for c in [self.nctx] + self.ectx:
@@ -305,6 +317,10 @@ class OneHeightmapPipeline:
             self.dist.barrier()  # nobody unmaps a strip a peer may still be reading
         for g in self.grids:
             g.destroy()
+        if self._dev_paced:
+            for e in self._ev:
+                self.nctx.event_destroy(e)
+            self.nctx.set_stream(None)
         self.nctx.close()
         for c in self.ectx:
             c.close()
@@ -321,6 +337,79 @@ class OneHeightmapPipeline:
         return float(h[0]), h[1] > 0.5
 
     def run(self, k, origin=None, collect=None):
+        """k steps (see _run_host_paced for the arguments); with a collective that runs on the device the steps are only enqueued (_run_device_paced)."""
+        return self._run_device_paced(k, origin, collect) if self._dev_paced else self._run_host_paced(k, origin, collect)
+
+    def _run_device_paced(self, k, origin=None, collect=None):
+        """The same steps with nothing read back inside a step.  A failure on one rank cannot leave the others waiting: every rank enqueues all k collectives whatever
+        happens to its own work, and the closing collective (host) carries the error flag -- all ranks raise together, after the loop."""
+        import queue
+        pkg, N, torch = self.pkg, self.nx, self._torch
+        r0, r1 = self.rows[self.rank]
+        group = self.dist is not None and self.dist.is_initialized()
+        done, errs = {}, []
+        jobs = [queue.Queue() for _ in self.ectx]
+
+        def eroder(i):
+            c = self.ectx[i]
+            while True:
+                job = jobs[i].get()
+                if job is None:
+                    return
+                s, g = job
+                try:
+                    c.event_wait(self._ev[g])  # behind the step's noise and its all_reduce, on the device
+                    c.apply_erosion_devmin_dev(self.grids[g].ptr, self.nx, self.ny, self._mm[g].data_ptr(), self.droplets, pkg.ERODE_MINZ_IS_MIN)
+                    c.synchronize()
+                    if collect is not None:
+                        collect(s, self.grids[g].ptr)
+                except Exception as e:  # noqa: BLE001
+                    errs.append(repr(e))
+                finally:
+                    done[s].set()
+        th = [self._threading.Thread(target=eroder, args=(i,)) for i in range(len(self.ectx))]
+        for x in th:
+            x.start()
+        mine = 0
+        try:
+            with torch.cuda.stream(self._tstream):
+                for s in range(k):
+                    g = s % self.G
+                    x0, y0 = origin(s) if origin is not None else (-self.nx / 2, -self.ny / 2)
+                    j = s - self.G + 1
+                    if j >= 0 and j % self.world == self.rank and j in done:
+                        done[j].wait()  # my erosion of the grid that step s + 1 overwrites is complete before all_reduce(s) can complete anywhere
+                    try:
+                        if r1 > r0 and not errs:
+                            self.nctx.gen_grid_rows_minmax_async_dev(self.grids[g].ptr + r0 * N * 4, x0, y0, self.st.DX_VAL, self.st.DY_VAL, self.nx, self.ny, r0, r1 - r0,
+                                                                     self._mm[g].data_ptr(), pkg.GEN_GLACIATE)
+                        else:
+                            self._mm[g, 0].fill_(float("inf"))
+                    except Exception as e:  # noqa: BLE001
+                        errs.append(repr(e))
+                    if group:
+                        self.dist.all_reduce(self._mm[g, 0:1], op=self.dist.ReduceOp.MIN)  # enqueued: ordered behind the strip's kernels and in front of the record below
+                    self.nctx.event_record(self._ev[g])
+                    if s % self.world == self.rank and not errs:
+                        done[s] = self._threading.Event()
+                        jobs[mine % len(jobs)].put((s, g))
+                        mine += 1
+        except Exception as e:  # noqa: BLE001 -- (a failing collective: nothing left to keep in step with)
+            errs.append(repr(e))
+        finally:
+            for q in jobs:
+                q.put(None)
+            for x in th:
+                x.join()
+        try:
+            self.nctx.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+        _, ok = self._all_reduce_min(0.0, not errs)  # every rank's erosions are complete, and whether any of them failed
+        if errs or not ok:
+            raise RuntimeError("; ".join(errs) if errs else "a step failed on another rank")
+
+    def _run_host_paced(self, k, origin=None, collect=None):
         """k steps.  origin(s) -> (x0, y0) of step s's grid (default: the nx x ny grid centred on the origin); collect(s, ptr) is called on the eroding rank when step s's
         grid is final (before it can be overwritten).  Returns when the erosions of ALL ranks are complete (one more collective after the loop): run() may be
         called again at once."""

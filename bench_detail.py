@@ -251,12 +251,53 @@ def onegrid_rank_floor(env, detail, sim_world):
     env.full_min, _ = ectx.gen_grid_minmax_dev(env.ez.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE)  # a real heightmap for the erosions
     noise_steps(sim_world, sim_world, ectx)
     t0 = time.perf_counter(); noise_steps(K, sim_world, ectx); t.synchronize(); ectx.synchronize(); d_both = (time.perf_counter() - t0) / K
+    # the same step as OneHeightmapPipeline enqueues it under RCCL (dist.py::_run_device_paced, tools/bench_native_onegrid.c): nothing read back -- the strip's min stays in
+    # HBM, the all_reduce works on it on the noise stream, the eroding context waits for an event behind it
+    d_dev = d_dev_both = None
+    if str(env.coll_dev).startswith("cuda"):
+        stream = torch.cuda.Stream(device=env.dev)
+        mm = torch.zeros(2, dtype=torch.float32, device=env.dev)
+        ev = t.event_create()
+
+        def dev_steps(k, erode_every=0):
+            import threading
+            th = None
+            with torch.cuda.stream(stream):
+                for s in range(k):
+                    t.gen_grid_rows_minmax_async_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 0, rows, mm.data_ptr(), pkg.GEN_GLACIATE)
+                    if env.have_group:
+                        dist.all_reduce(mm[0:1], op=dist.ReduceOp.MIN)
+                    t.event_record(ev)
+                    if erode_every and s % erode_every == 0:
+                        if th is not None:
+                            th.join()
+
+                        def job(m=env.full_min):
+                            ectx.event_wait(ev)
+                            ectx.apply_erosion_dev(env.ez.data_ptr(), N, N, m, env.args.droplets, pkg.ERODE_MINZ_IS_MIN)
+                        th = threading.Thread(target=job)
+                        th.start()
+            if th is not None:
+                th.join()
+        t.synchronize(); t.set_stream(stream.cuda_stream)
+        try:
+            dev_steps(8)
+            t.synchronize()
+            t0 = time.perf_counter(); dev_steps(K); t.synchronize(); d_dev = (time.perf_counter() - t0) / K
+            dev_steps(sim_world, sim_world); t.synchronize(); ectx.synchronize()
+            t0 = time.perf_counter(); dev_steps(K, sim_world); t.synchronize(); ectx.synchronize(); d_dev_both = (time.perf_counter() - t0) / K
+        finally:
+            t.synchronize(); t.set_stream(None); t.event_destroy(ev)
     if own:
         ectx.close()
+    floor = max(d_both, d_noise) if d_dev is None else max(d_dev, d_dev_both)
     detail["onegrid_rank_floor"] = {"simulated_world": sim_world, "rows_per_rank": rows, "steps": K,
                                     "ms_strip_noise_device": round(ms_dev, 4), "ms_step_noise_allreduce_item": round(d_noise * 1e3, 4),
                                     "host_and_collective_share": round(1.0 - ms_dev / (d_noise * 1e3), 3),
                                     "ms_step_with_every_%dth_erosion" % sim_world: round(d_both * 1e3, 4),
-                                    "predicted_gcells_s_at_that_world": round(N * N / max(d_both, d_noise) / 1e9, 1),
+                                    "ms_step_enqueue_only": None if d_dev is None else round(d_dev * 1e3, 4),
+                                    "ms_step_enqueue_only_with_every_%dth_erosion" % sim_world: None if d_dev_both is None else round(d_dev_both * 1e3, 4),
+                                    "predicted_gcells_s_at_that_world": round(N * N / floor / 1e9, 1),
+                                    "predicted_from": "the read-back step (gloo / no device collective)" if d_dev is None else "the enqueue-only step (what the pipeline runs under RCCL)",
                                     "collective": ("all_reduce(min) over " + env.backend_name + " (one-rank group on this box)") if env.have_group else "none (no process group)",
                                     "note": "a prediction from measured parts, not a measurement of N GPUs: remote window traffic over xGMI and the slowest-rank effect are not in it"}

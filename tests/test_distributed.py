@@ -355,6 +355,38 @@ def test_two_ranks_erode_one_heightmap_on_the_hip_library(orc, tmp_path):
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
 
+def _one_grid_device_paced_worker(rank, world, out_dir, nx, ny, droplets, steps, grids):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", store=dist.HashStore(), rank=rank, world_size=world)
+    pkg = importlib.import_module("3dworld_amd")
+    dmod = importlib.import_module("3dworld_amd.dist")
+    pipe = dmod.OneHeightmapPipeline(pkg, lambda: pkg.Terra(0), pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1), dist, nx, ny, droplets, tag=f"d{os.getpid()}", grids=grids, eroders=2,
+                                     coll_device=torch.device("cuda:0"))
+    assert pipe._dev_paced
+
+    def collect(s, ptr):
+        np.save(os.path.join(out_dir, f"grid_{s}.npy"), _dgrid_download(pipe.ectx[0], ptr, (ny, nx)))
+
+    origin = lambda s: (-nx / 2 + 40.0 * s, -ny / 2 - 25.0 * s)  # noqa: E731
+    pipe.run(steps, origin=origin, collect=collect)
+    pipe.run(2, origin=origin)  # (run() may be called again at once)
+    pipe.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_one_rank_device_paced_pipeline_over_rccl_equals_oracle(orc, tmp_path):
+    """OneHeightmapPipeline with a collective that runs on the device (RCCL, a one-rank group on the one-GPU box): the steps are only enqueued -- strip min in HBM,
+    all_reduce(min) on the noise stream, the erosion's clamp reads it from HBM -- and every step's eroded grid equals the oracle's"""
+    import torch.multiprocessing as mp
+    nx, ny, droplets, steps, grids = 2048, 1024, 1000, 7, 3
+    mp.spawn(_one_grid_device_paced_worker, args=(1, str(tmp_path), nx, ny, droplets, steps, grids), nprocs=1, join=True)
+    _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 0)
+
+
 @pytest.mark.gpu
 def test_in_process_distributed_grid_two_contexts(pkg, orc):
     """terra_multi_dgrid_create: two contexts of one process, strip i allocated by context i, one pointer for both -- context 0 fills its rows, context 1 its rows,
