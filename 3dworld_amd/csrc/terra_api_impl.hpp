@@ -594,6 +594,10 @@ int terra_tiles_create_zvals_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.tiles_create_zvals_dev(tile_xy, n, iters_tt, d_zvals, d_stats, d_normals, d_min_nz); TERRA_CATCH
 }
+int terra_tiles_post_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	TERRA_TRY ctx->eng.tiles_post_dev(tile_xy, n, d_zvals, d_stats, d_normals, d_min_nz); TERRA_CATCH
+}
 int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t iters_tt, float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_nz) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	if (n == 0) return TERRA_OK;

@@ -1225,6 +1225,15 @@ template<class BE> struct terra_engine {
 		}
 	}
 
+	// the post pass alone over the caller's zvals (terra_tiles_post_dev)
+	void tiles_post_dev(int32_t const *tile_xy, uint32_t n, float const *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_nz) {
+		require_scene();
+		if (n == 0 || !(d_stats || d_normals)) return;
+		tile_ref_pod_t const *d_refs = tile_fields_dev(tile_xy, n, 130, 0, nullptr, 0.0f); // (only the tile references)
+		float const dxv = DX_VAL, dyv = DY_VAL, rad_c = (dxv*dxv + dyv*dyv)*128*128;
+		be.tile_post(n, d_refs, d_zvals, d_stats, d_normals, d_min_nz, get_max_sea_level(), rad_c, dxv, dyv, dxdy);
+	}
+
 	// tile_t::calc_shadows_for_light + calc_mesh_shadows (src/tiled_mesh.cpp:664-692, src/visibility.cpp:510-520) for a batch and one directional light:
 	// smask[n][130][130] gets the MESH_SHADOW bit.  A tile's sweeps start from the edge heights its two neighbours toward the light left behind
 	// (sh_out -> sh_in), so the batch is processed in dependency levels (anti-diagonals); tiles of one level run in parallel, every sweep of a tile too.

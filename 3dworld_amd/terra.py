@@ -181,6 +181,7 @@ _PROTOS = {
     "terra_minmax_dev": (_i32, [_vp, _vp, _sz, _f3, _f3]),
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
     "terra_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "terra_tiles_post_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_selftest_hot_sqrt": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),
@@ -618,6 +619,11 @@ class Terra:
     def tiles_create_zvals_dev(self, tile_xy, iters_tt, z_ptr, stats_ptr=None, normals_ptr=None, mnz_ptr=None):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
         self._ck(self.lib.terra_tiles_create_zvals_dev(self.ctx, txy.ctypes.data, len(txy), iters_tt, z_ptr, stats_ptr, normals_ptr, mnz_ptr))
+
+    def tiles_post_dev(self, tile_xy, z_ptr, stats_ptr=None, normals_ptr=None, mnz_ptr=None):
+        """sub-block ranges / water bbox / radius and normals of zvals the caller has (tile_t::create_zvals' last loop + upload_normal_texture)"""
+        txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)
+        self._ck(self.lib.terra_tiles_post_dev(self.ctx, txy.ctypes.data, len(txy), z_ptr, stats_ptr, normals_ptr, mnz_ptr))
 
     def tiles_create_weights_dev(self, tile_xy, z_ptr, weights_ptr, blocks_ptr=None, has_grass_ptr=None):
         txy = np.ascontiguousarray(tile_xy, np.int32).reshape(-1, 2)

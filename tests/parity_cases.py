@@ -269,6 +269,78 @@ def case_tiles(pkg, t, orc, mode, iters, tiles=((0, 0), (-3, 7), (20, -31), (5, 
         assert np.float32(mo).view(np.uint32) == mnz[i].view(np.uint32)
 
 
+def np_tile_stats(z, tx, ty, wpz_max, dxv, dyv):
+    """tile_t::create_zvals' last loop (src/tiled_mesh.cpp:517-541) in numpy, for zvals that the engine did not make itself: 4 x 4 sub-block ranges with
+    std::min / std::max (a NaN never wins; folds start at +-FAR_DISTANCE = +-100), tile range, radius, water bbox (starts denormalized)"""
+    f = np.float32
+    smin = np.empty(16, f); smax = np.empty(16, f)
+    with np.errstate(all="ignore"):
+        for yy in range(4):
+            for xx in range(4):
+                b = z[32 * yy:32 * yy + 33, 32 * xx:32 * xx + 33]
+                smin[4 * yy + xx] = np.fmin(f(100.0), np.fmin.reduce(b, axis=None))
+                smax[4 * yy + xx] = np.fmax(f(-100.0), np.fmax.reduce(b, axis=None))
+        mzmin, mzmax = f(min(f(100.0), smin.min())), f(max(f(-100.0), smax.max()))
+        rad_c = f(f(f(f(dxv) * f(dxv)) + f(f(dyv) * f(dyv))) * f(128.0)) * f(128.0)
+        d = f(mzmax - mzmin)
+        radius = f(0.5 * np.sqrt(np.float64(f(rad_c + f(d * d)))))
+        x1, y1 = tx * 128, ty * 128
+        wet = z[:129, :129] < f(wpz_max)
+    ys, xs = np.nonzero(wet)
+    wx1, wy1, wx2, wy2 = x1 + 128, y1 + 128, x1, y1
+    if len(xs):
+        wx1, wy1, wx2, wy2 = min(wx1, x1 + int(xs.min())), min(wy1, y1 + int(ys.min())), max(wx2, x1 + int(xs.max())), max(wy2, y1 + int(ys.max()))
+    return smin, smax, mzmin, mzmax, radius, (wx1, wy1, wx2, wy2)
+
+
+def case_tiles_post_adversarial(pkg, t, orc):
+    """terra_tiles_post_dev on zvals the terrain generator never makes: flat tiles (the constant-word path of k_tile_post), slopes of 1e-7 (nz within an ulp of 1: the byte
+    test cannot decide, the reference's statements run), |n|^2 overflowing to +inf, NaN and +-inf cells, cliffs (n_x / |n| near -1 and +1), heights around the sea level
+    (water bbox), a tile whose last row / column alone is special -- normals and min_normal_z against the oracle's tile_normals, the stats against np_tile_stats"""
+    import ctypes as C
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    st = t.init_scene(pc_); orc.init(oc)
+    wpz = t.max_sea_level()
+    rng = np.random.default_rng(5)
+    f = np.float32
+    walk = lambda sc: np.cumsum(np.cumsum(rng.standard_normal((130, 130)), 0), 1).astype(f) * f(sc)  # noqa: E731
+    tiles = [(0, 0), (-3, 2), (5, -7), (1, 1), (2, 2), (-1, -1), (4, 4), (7, 0), (-9, -9), (3, -3)]
+    z = np.empty((len(tiles), 130, 130), f)
+    z[0] = walk(1e-3)
+    z[1] = f(-0.3)
+    z[2] = walk(2e-3); z[2][:, 70:] = z[2][0, 70]
+    z[3] = f(1.0) + (rng.random((130, 130)) * 1e-7).astype(f)
+    z[4] = (rng.standard_normal((130, 130)) * 1e18).astype(f)
+    z[5] = walk(1e-3); m = rng.random((130, 130)); z[5][m < 0.01] = np.nan; z[5][(m > 0.01) & (m < 0.013)] = np.inf; z[5][(m > 0.013) & (m < 0.016)] = -np.inf
+    z[6] = np.where(rng.random((130, 130)) < 0.5, f(-100.0), f(100.0)).astype(f)
+    z[7] = f(wpz) + (rng.standard_normal((130, 130)) * 1e-3).astype(f)
+    z[8] = f(0.25); z[8][128:, :] = walk(1e-2)[128:, :]; z[8][:, 128:] = walk(1e-2)[:, 128:]
+    z[9] = np.nan
+    zb = t.alloc(z.nbytes).upload(z); sb = t.alloc(len(tiles) * C.sizeof(pkg.TileStats)); nb = t.alloc(len(tiles) * 129 * 129 * 4); mb = t.alloc(len(tiles) * 4)
+    try:
+        for with_stats, with_normals in ((True, True), (True, False), (False, True)):
+            nb.upload(np.full(len(tiles) * 129 * 129 * 4, 7, np.uint8)); mb.upload(np.full(len(tiles), 5.0, f)); sb.upload(np.zeros(len(tiles) * C.sizeof(pkg.TileStats), np.uint8))
+            t.tiles_post_dev(tiles, zb.ptr, sb.ptr if with_stats else None, nb.ptr if with_normals else None, mb.ptr if with_normals else None)
+            assert (zb.download(f, z.shape).view(np.uint32) == z.view(np.uint32)).all(), "the zvals are not written"
+            nm = nb.download(np.uint8, (len(tiles), 129, 129, 4)); mnz = mb.download(f, (len(tiles),))
+            sraw = sb.download(np.uint8, (len(tiles), C.sizeof(pkg.TileStats)))
+            for i, (tx, ty) in enumerate(tiles):
+                if with_normals:
+                    no, mo = orc.tile_normals(z[i])
+                    assert (nm[i] == no).all(), f"adversarial tile {i}: {int((nm[i] != no).any(axis=2).sum())} normals differ"
+                    assert f(mo).view(np.uint32) == mnz[i].view(np.uint32), f"adversarial tile {i}: min_normal_z {mnz[i]} vs {mo}"
+                if with_stats:
+                    s = pkg.TileStats.from_buffer_copy(sraw[i].tobytes())
+                    smin, smax, mzmin, mzmax, radius, bbox = np_tile_stats(z[i], tx, ty, wpz, st.DX_VAL, st.DY_VAL)
+                    got = np.array(list(s.sub_zmin) + list(s.sub_zmax) + [s.mzmin, s.mzmax, s.radius], f)
+                    want = np.concatenate([smin, smax, np.array([mzmin, mzmax, radius], f)])
+                    assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"adversarial tile {i}: stats {got} vs {want}"
+                    assert (s.wx1, s.wy1, s.wx2, s.wy2) == bbox, f"adversarial tile {i}: water bbox"
+    finally:
+        for b in (zb, sb, nb, mb):
+            b.free()
+
+
 def case_tile_golden(pkg, t):
     G = golden()
     t.init_scene(pkg.make_config(mesh_gen_mode=0))

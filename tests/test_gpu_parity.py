@@ -98,6 +98,10 @@ def test_tile_mesh_shadows_halo_interface(pkg, gpu, orc):
     pc.case_tile_mesh_shadows_halo(pkg, gpu, orc)
 
 
+def test_tiles_post_pass_on_adversarial_zvals(pkg, gpu, orc):
+    pc.case_tiles_post_adversarial(pkg, gpu, orc)
+
+
 def test_tiles_from_heightmap_texture(pkg, gpu, orc):
     pc.case_tiles_from_heightmap(pkg, gpu, orc)
 

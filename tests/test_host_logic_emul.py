@@ -141,6 +141,10 @@ def test_tile_mesh_shadows_halo_interface(pkg, emul, orc):
     pc.case_tile_mesh_shadows_halo(pkg, emul, orc)
 
 
+def test_tiles_post_pass_on_adversarial_zvals(pkg, emul, orc):
+    pc.case_tiles_post_adversarial(pkg, emul, orc)
+
+
 def test_tiles_from_heightmap_texture(pkg, emul, orc):
     pc.case_tiles_from_heightmap(pkg, emul, orc)
 
