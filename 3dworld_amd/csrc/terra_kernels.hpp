@@ -13,6 +13,9 @@
 
 namespace terra {
 
+typedef float    st_f4 __attribute__((ext_vector_type(4))); // native vector types: what the nontemporal load / store builtins take
+typedef uint32_t st_u4 __attribute__((ext_vector_type(4)));
+
 template<class F> __global__ void k_generic(size_t n, F f) {
 	size_t const i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
 	if (i < n) {f(i);}
@@ -483,8 +486,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 	tile_ref_pod_t const r = refs[t];
 	int const x1 = r.tx*128, y1 = r.ty*128;
 	{
-		float4 const *src = (float4 const *)(zvals + (size_t)t*zv*zv + (size_t)row0*zv); // 67600 bytes per tile, 16640 per band: 16-byte aligned
-		for (unsigned i = tid; i < TP_BAND_ROWS*zv/4; i += TP_THREADS) {((float4 *)tp_z)[i] = src[i];}
+		st_f4 const *src = (st_f4 const *)(zvals + (size_t)t*zv*zv + (size_t)row0*zv); // 67600 bytes per tile, 16640 per band: 16-byte aligned
+		for (unsigned i = tid; i < TP_BAND_ROWS*zv/4; i += TP_THREADS) {((st_f4 *)tp_z)[i] = __builtin_nontemporal_load(src + i);} // read once (measured: 127.2 -> 125.5 us with the stores below)
 	}
 	if (tid < 4) {s_lo[tid] = f2ord(100.0f); s_hi[tid] = ~f2ord(-100.0f);} // folds start at szmin = FAR_DISTANCE, szmax = -FAR_DISTANCE
 	if (tid == 0) {s_smax = 0u; s_bb[0] = x1 + 128; s_bb[1] = y1 + 128; s_bb[2] = x1; s_bb[3] = y1;} // water bbox starts denormalized
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_post(tile_ref_pod_t const *
 			uint32_t wA, wB; float sA, sB;
 			bool const okA = tp_word_fast(cA, rA, dA, dxv, dyv, dxy, c2, flat_word, wA, sA), okB = tp_word_fast(cB, rB, dB, dxv, dyv, dxy, c2, flat_word, wB, sB);
 			if (__builtin_amdgcn_ballot_w64(!(okA & okB)) != 0) {wA = tp_word_exact(cA, rA, dA, dxv, dyv, dxy); wB = tp_word_exact(cB, rB, dB, dxv, dyv, dxy);}
-			nout[y*stride + lane] = wA; nout[y*stride + lane + 64] = wB;
+			__builtin_nontemporal_store(wA, &nout[y*stride + lane]); __builtin_nontemporal_store(wB, &nout[y*stride + lane + 64]); // written once, read by nobody here
 			smax = __builtin_fmaxf(smax, __builtin_fmaxf(sA, sB));
 		}
 		cA = dA; cB = dB;
@@ -714,8 +717,6 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 // to the chip (256 CUs x 8 blocks of 256 threads) so a 16384^2 grid is ~8 trips of 64 bytes per thread; wave shuffle reduction, then look-before-atomic
 // like the fused variant.  d[0] = min f2ord(v), d[1] = min ~f2ord(v); NaNs are skipped.
 constexpr int MM_UNROLL = 4;
-typedef float    st_f4 __attribute__((ext_vector_type(4))); // native vector types: what the nontemporal load / store builtins take
-typedef uint32_t st_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void minmax_acc4(st_f4 const v, float &lo, float &hi) {
 	// fminf / fmaxf drop NaNs (v_min_f32 / v_max_f32 with IEEE mode return the non-NaN operand): the same set of values as the `v == v` filter
 	lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 	vx_v16f b0, b1, b2, b3;
 	asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(b0), "=&s"(b1) : "s"(pp));
 #define VX_NEXT(CA, CB, NA, NB, ADDR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %2, %4, 0x0\n\ts_load_dwordx16 %3, %4, 0x40" : "+s"(CA), "+s"(CB), "=&s"(NA), "=&s"(NB) : "s"(ADDR))
-#define VX_STEP(BUF, Q, J, LO, HI) if (Q*8 + J < VOX_SINES) {vx_mul_add<(J & 1)>(val, sg_v2f{BUF.LO, BUF.HI}, zv[(Q*8 + J) >> 1]);}
+#define VX_STEP(BUF, Q, J, LO, HI) if (Q*8 + J < VOX_SINES) {vx_mul_add<(J & 1)>(val, sg_v2f{BUF.LO, BUF.HI}, zv[(Q*8 + J < VOX_SINES) ? ((Q*8 + J) >> 1) : 0]);}
 #define VX_CHUNK(BUF, Q) VX_STEP(BUF, Q, 0, s0, s1) VX_STEP(BUF, Q, 1, s2, s3) VX_STEP(BUF, Q, 2, s4, s5) VX_STEP(BUF, Q, 3, s6, s7) VX_STEP(BUF, Q, 4, s8, s9) VX_STEP(BUF, Q, 5, sa, sb) VX_STEP(BUF, Q, 6, sc, sd) VX_STEP(BUF, Q, 7, se, sf)
 	for (int c = 0; c < VX_PER_BLOCK; c += 2) {
 		size_t const col = c0 + c; // = x + y*nx of the pair's first column (even), wave-uniform
