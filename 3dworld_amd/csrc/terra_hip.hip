@@ -303,7 +303,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
 		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup, tw};
 		job.plain_only = plain_only ? 1 : 0;
-		if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
+		static int const kc_tiles = [] {char const *e = getenv("TERRA_SG_KC_TILES"); return e ? atoi(e) : 27;}(); // 27: three chunks, 29.7 KB per block (measured on the 64 x 64 batch: 291.8 -> 283.9 us, the 201-wide AO context 735 -> 706 us); TERRA_SG_KC_TILES=45: two chunks, 48 KB.  The same sum either way
+		if (plain_only && kc_tiles == 27) {hipLaunchKernelGGL((terra::k_sine_grid<true, false, 27>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
+		else if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}

@@ -68,7 +68,7 @@ __device__ __forceinline__ void minmax_acc(float v, uint32_t &lo, uint32_t &hi) 
 // Tiling: 128 x 128 cells per 256-thread block, 8 x 8 cells per thread (64 independent accumulator chains), the K range staged
 // through LDS in chunks of <= KC terms (template parameter; the heightmap kernel uses 27: three chunks for 8 octaves, 29.7 KB per block,
 // 118 VGPRs -> 4 blocks = 16 waves per CU alone, and two waves per SIMD beside a 264-register droplet wave of another map's erosion;
-// the tile variants keep SG_KC = 45: two chunks, 48 KB), operands of the next step prefetched from LDS while this one is multiplied.
+// the plain tile variant uses 27 as well, the general one keeps SG_KC = 45: two chunks, 48 KB), operands of the next step prefetched from LDS while this one is multiplied.
 // Per k a thread issues four ds_read_b128 (conflict-free / broadcast) for 64 mul + 64 add.  The f32 matrix instructions cannot take the
 // products: exact with K = 1, C = 0, but they share the packed-f32 datapath (profiles/r04_sine_matrix_pipe.txt).
 constexpr int SG_BX = 128, SG_BY = 128, SG_TX = 8, SG_TY = 8, SG_THREADS = 256, SG_KC = 45; // 16 x 16 threads
