@@ -320,7 +320,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const nbands = (terra::AO_TEX + terra::AO_BAND - 1)/terra::AO_BAND;
 		size_t const lds = (size_t)(terra::AO_BAND + terra::AO_RL)*terra::AO_CS*sizeof(float);
-		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(256), lds, stream, z, ctx, ao, dz);
+		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(terra::AO_THREADS), lds, stream, z, ctx, ao, dz);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	uint32_t *tile_acc = nullptr; size_t tile_acc_bytes = 0; // k_tile_post's per-tile accumulators

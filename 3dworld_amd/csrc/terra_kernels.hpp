@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k_tile_post_final(tile_ref_pod_t const *_
 // rays going up or sideways need context rows [y0, y0 + band + 35], rays going down rows [y0 + 36, y0 + band + 71] (context coordinates =
 // texel + 36) -- 68 rows x 201 floats = 54.7 KB each time, so two blocks share a CU.  A thread owns up to 17 texels and keeps their
 // attenuation sums in registers across the passes.  Same integer sums as the one-thread-per-texel version (tile_ao_simple).
-constexpr unsigned AO_BAND = 33, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_PER_THREAD = (AO_BAND*AO_TEX + 255)/256;
+constexpr unsigned AO_BAND = 33, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_THREADS = 256, AO_ROWS_W = (AO_BAND + 3)/4, AO_STAGE = ((AO_BAND + AO_RL)*AO_CS + AO_THREADS - 1)/AO_THREADS;
 // one ray, branch-free: the eight samples sit at fixed offsets 1,3,6,...,36 steps from the texel (immediate ds_read offsets after unrolling),
 // are all requested before the first compare, and the first hit is selected backwards (hit at step s attenuates by 8 - s)
 template<int DX, int DY> __device__ __forceinline__ unsigned ao_march(float const *s_base, float const (&zr)[8]) {
@@ -612,47 +612,82 @@ template<int DX, int DY> __device__ __forceinline__ unsigned ao_march(float cons
 	for (int s = 7; s >= 0; --s) {att = (smp[s] > zr[s]) ? (unsigned)(8 - s) : att;}
 	return att;
 }
+// the rays of one pass from the texel at sb (pass 0: up and sideways, pass 1: down)
+template<int PASS> __device__ __forceinline__ unsigned ao_rays(float const *sb, float z0, float dz) {
+	float zr[8];
+#pragma unroll
+	for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;} // every ray rises by dz per step: sequential float adds, as in the reference
+	if (PASS == 0) {return ao_march<-1, -1>(sb, zr) + ao_march<0, -1>(sb, zr) + ao_march<1, -1>(sb, zr) + ao_march<-1, 0>(sb, zr) + ao_march<1, 0>(sb, zr);}
+	return ao_march<-1, 1>(sb, zr) + ao_march<0, 1>(sb, zr) + ao_march<1, 1>(sb, zr);
+}
+__device__ __forceinline__ uint8_t ao_byte(unsigned atten) {float const ao_scale = (float)(1.0 - (double)((float)atten/(float)64)); return (uint8_t)(255.0*(double)ao_scale);}
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: xcd_ordered() renumbers the blocks so that an XCD walks a CONTIGUOUS range of logical blocks (a tile's
+// four bands, whose staging passes overlap each other's rows, run on one XCD one after another).  (Measured equal for this kernel: its context rows come out of the
+// infinity cache either way; kept because it is free.)
+__device__ __forceinline__ unsigned xcd_ordered(unsigned b, unsigned nb) {
+	unsigned const xcd = b & 7u, j = b >> 3, per = nb >> 3, rem = nb & 7u; // XCD k owns blocks k, k + 8, ...: per + (k < rem) of them
+	return ((xcd < rem) ? xcd*(per + 1u) : rem*(per + 1u) + (xcd - rem)*per) + j;
+}
 // (Taking the tile's own zvals from `zvals` while staging, instead of the caller's copy pass into the context, was measured: the extra index work in the staging loop costs more
 // than the 170 us copy kernel saves -- 1.95 vs 1.87 ms for the row.)
-__global__ __launch_bounds__(256) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
+// The kernel is bound by its LDS reads (64 per texel).  A WAVE owns texel rows (every fourth row of the band); a lane is a column: x = lane and 64 + lane, column 128 is one
+// extra pass with a lane per row (row stride 201 = 9 mod 32: distinct banks).  With texels dealt out linearly (p = tid + 256 k) a wave's 64 texels crossed a row end and
+// the part behind the wrap met the part before it in the banks: half of the LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.53).
+__global__ __launch_bounds__(AO_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
 	extern __shared__ __attribute__((aligned(16))) float s_ao_ctx[];
-	unsigned const nbands = (AO_TEX + AO_BAND - 1)/AO_BAND, t = blockIdx.x/nbands, band = blockIdx.x % nbands, tid = threadIdx.x;
-	unsigned const y0 = band*AO_BAND, rows = (AO_TEX - y0 < AO_BAND) ? AO_TEX - y0 : AO_BAND, ntex = rows*AO_TEX;
+	unsigned const lb = xcd_ordered(blockIdx.x, gridDim.x);
+	unsigned const nbands = (AO_TEX + AO_BAND - 1)/AO_BAND, t = lb/nbands, band = lb % nbands, tid = threadIdx.x;
+	unsigned const w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
+	unsigned const y0 = band*AO_BAND, rows = (AO_TEX - y0 < AO_BAND) ? AO_TEX - y0 : AO_BAND;
 	float const *c = ctx + (size_t)t*AO_CS*AO_CS, *z = zvals + (size_t)t*130*130;
-	unsigned atten[AO_PER_THREAD];
-	float zs[AO_PER_THREAD];
+	uint8_t *out = ao + (size_t)t*AO_TEX*AO_TEX;
+	unsigned attA[AO_ROWS_W], attB[AO_ROWS_W], attC = 0; // rows w, w + 4, ...: columns lane and 64 + lane; column 128 of row `lane` (wave 3, which has a row less than wave 0)
+	float zA[AO_ROWS_W], zB[AO_ROWS_W], zC = 0.0f;
 #pragma unroll
-	for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
-		unsigned const p = tid + k*256;
-		atten[k] = 0;
-		zs[k] = (p < ntex) ? z[(y0 + p/AO_TEX)*130 + p % AO_TEX] : 0.0f;
+	for (unsigned i = 0; i < AO_ROWS_W; ++i) {
+		unsigned const yl = w + 4*i;
+		attA[i] = attB[i] = 0;
+		float const *zr = z + (size_t)(y0 + ((yl < rows) ? yl : 0u))*130;
+		zA[i] = zr[lane]; zB[i] = zr[64 + lane];
 	}
+	if (w == 3) {zC = z[(size_t)(y0 + ((lane < rows) ? lane : 0u))*130 + 128];}
+	// Staging: a pass's rows (<= 69 x 201 floats) are 55 loads per thread, ALL issued back to back into registers, then stored (as a plain copy loop, a few at a time between
+	// LDS stores, two blocks per CU kept ~8 KB in flight per CU: 775 -> 740 us)
+	unsigned const nfl = (rows + AO_RL)*AO_CS;
 	for (int pass = 0; pass < 2; ++pass) {
-		unsigned const row0 = pass ? y0 + AO_RL : y0, nfl = (rows + AO_RL)*AO_CS;
-		__syncthreads();
-		float const *src = c + (size_t)row0*AO_CS;
-		for (unsigned i = tid; i < nfl; i += 256) {s_ao_ctx[i] = src[i];}
-		__syncthreads();
+		unsigned const row0 = pass ? y0 + AO_RL : y0;
+		{
+			float stg[AO_STAGE];
+			float const *src = c + (size_t)row0*AO_CS;
 #pragma unroll
-		for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
-			unsigned const p = tid + k*256;
-			if (p >= ntex) continue;
-			unsigned const y = y0 + p/AO_TEX, x = p % AO_TEX;
-			float const *sb = s_ao_ctx + ((y + AO_RL) - row0)*AO_CS + (x + AO_RL); // the texel itself in the staged context
-			float zr[8], z0 = zs[k];
+			for (unsigned k = 0; k < AO_STAGE; ++k) {unsigned const i = tid + k*AO_THREADS; stg[k] = src[(i < nfl) ? i : 0u];}
+			__syncthreads(); // everybody is done with the previous pass's rows
 #pragma unroll
-			for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;} // every ray rises by dz per step: sequential float adds, as in the reference
-			if (pass == 0) {atten[k] += ao_march<-1, -1>(sb, zr) + ao_march<0, -1>(sb, zr) + ao_march<1, -1>(sb, zr) + ao_march<-1, 0>(sb, zr) + ao_march<1, 0>(sb, zr);}
-			else           {atten[k] += ao_march<-1, 1>(sb, zr) + ao_march<0, 1>(sb, zr) + ao_march<1, 1>(sb, zr);}
+			for (unsigned k = 0; k < AO_STAGE; ++k) {unsigned const i = tid + k*AO_THREADS; if (i < nfl) {s_ao_ctx[i] = stg[k];}}
+			__syncthreads();
+		}
+		unsigned const lrow = pass ? 0u : AO_RL; // LDS row of the band's first texel row
+#pragma unroll
+		for (unsigned i = 0; i < AO_ROWS_W; ++i) {
+			unsigned const yl = w + 4*i;
+			if (yl >= rows) break; // (wave-uniform)
+			float const *sb = s_ao_ctx + (yl + lrow)*AO_CS + AO_RL + lane; // the texel itself in the staged context
+			if (pass == 0) {attA[i] += ao_rays<0>(sb, zA[i], dz); attB[i] += ao_rays<0>(sb + 64, zB[i], dz);}
+			else           {attA[i] += ao_rays<1>(sb, zA[i], dz); attB[i] += ao_rays<1>(sb + 64, zB[i], dz);}
+		}
+		if (w == 3) {
+			float const *sb = s_ao_ctx + (((lane < rows) ? lane : 0u) + lrow)*AO_CS + AO_RL + 128;
+			attC += (pass == 0) ? ao_rays<0>(sb, zC, dz) : ao_rays<1>(sb, zC, dz);
 		}
 	}
 #pragma unroll
-	for (unsigned k = 0; k < AO_PER_THREAD; ++k) {
-		unsigned const p = tid + k*256;
-		if (p >= ntex) continue;
-		float const ao_scale = (float)(1.0 - (double)((float)atten[k]/(float)64));
-		ao[(size_t)t*AO_TEX*AO_TEX + (size_t)y0*AO_TEX + p] = (uint8_t)(255.0*(double)ao_scale);
+	for (unsigned i = 0; i < AO_ROWS_W; ++i) {
+		unsigned const yl = w + 4*i;
+		if (yl >= rows) break;
+		uint8_t *o = out + (size_t)(y0 + yl)*AO_TEX;
+		o[lane] = ao_byte(attA[i]); o[64 + lane] = ao_byte(attB[i]);
 	}
+	if (w == 3 && lane < rows) {out[(size_t)(y0 + lane)*AO_TEX + 128] = ao_byte(attC);}
 }
 
 // ------------------------------------------------------------------ row f2: mesh shadows, one launch per dependency level
