@@ -10,7 +10,7 @@ tools/gpu_job.sh profile $TAG bench p1 tiles tile_erosion weights ao voxels nois
 tools/gpu_job.sh pmc ${TAG}/pmc_sine prof_driver.py 16384 2 -- "k_sine_grid" "k_minmax" "quantize16" "sparse_erosion"
 tools/gpu_job.sh pmc ${TAG}/pmc_tile_erosion prof_tile_erosion.py 1000 1 -- "k_tile_erosion" "k_sine_grid"
 tools/gpu_job.sh pmc ${TAG}/pmc_noise prof_noise.py 16384 1 1,2,4 -- "k_noise_grid<1>" "k_noise_grid<2>" "k_noise_grid<4>"
-tools/gpu_job.sh pmc ${TAG}/pmc_tiles prof_tiles.py 0 1 -- "k_tile_post" "k_tile_ao" "k_tile_shadows"
+tools/gpu_job.sh pmc ${TAG}/pmc_tiles prof_tiles.py 0 1 -- "k_tile_post(" "k_tile_ao" "k_tile_shadows"
 tools/gpu_job.sh pmc ${TAG}/pmc_voxels prof_voxels.py 512 -- "k_voxel_sines"
 tools/gpu_job.sh pmc ${TAG}/pmc_erosion_dense ero_sweep.py 4096 1000000 0:0 -- "speculative_erosion"
 tools/gpu_job.sh clock ${TAG}/clock prof_driver.py 16384 3

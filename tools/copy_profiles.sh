@@ -7,7 +7,7 @@ for k in bench_default bench_pipelines1; do f=$(find $S/stats_$k -name "*kernel_
 cp $S/pmc_sine/pmc_summary.txt $P/${R}_pmc_summary.txt; cp $S/pmc_tile_erosion/pmc_summary.txt $P/${R}_pmc_tile_erosion_summary.txt; cp $S/pmc_traffic.json $P/${R}_pmc_traffic.json
 for k in noise tiles voxels erosion_dense; do [ -f $S/pmc_$k/pmc_summary.txt ] && cp $S/pmc_$k/pmc_summary.txt $P/${R}_pmc_${k}_summary.txt; done
 cp $S/erosion_timings.txt $P/${R}_erosion_timings.txt; cat $S/step_cost.txt $S/tile_erosion.txt > $P/${R}_step_cost.txt
-cp $S/bench_extra.json $P/${R}_bench_extra.json; cat $S/bench_native.json $S/bench_native_multi.jsonl > $P/${R}_bench_native.jsonl
+cp $S/bench_extra.json $P/${R}_bench_extra.json; cat $S/bench_native.json $S/bench_native_multi.jsonl > $P/${R}_bench_native.jsonl; [ -f $S/bench_native_onegrid.jsonl ] && cp $S/bench_native_onegrid.jsonl $P/${R}_onegrid_native.jsonl
 for w in gloo strips tiles; do [ -f $S/bench_2rank_$w.json ] && cp $S/bench_2rank_$w.json $P/${R}_bench_2rank_$w.json; done
 [ -f $S/tile_two_waves.txt ] && cp $S/tile_two_waves.txt $P/${R}_tile_two_waves.txt
 ls $P | grep -c "^${R}_"
