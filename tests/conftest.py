@@ -66,7 +66,9 @@ def emul_lib():
     csrc = os.path.join(ROOT, "3dworld_amd", "csrc")
     deps = [src, os.path.join(ROOT, "include", "terra.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src, "-lz"], check=True)
+        tmp = f"{out}.{os.getpid()}.tmp"  # several xdist workers may find it stale at once: each builds its own file, the rename is atomic
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", tmp, src, "-lz"], check=True)
+        os.replace(tmp, out)
     return out
 
 
