@@ -308,6 +308,7 @@ class OneHeightmapPipeline:
             self._tstream = torch.cuda.Stream(device=coll_device)  # the noise context works on it, the process group orders its collective against it
             self.nctx.set_stream(self._tstream.cuda_stream)
             self._mm = torch.zeros((grids, 2), dtype=torch.float32, device=coll_device)
+            torch.cuda.current_stream(coll_device).synchronize()  # (the fill ran on the current stream; everything else touches _mm on _tstream)
             self._ev = [self.nctx.event_create() for _ in range(grids)]
 
     def close(self):
