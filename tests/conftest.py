@@ -65,10 +65,15 @@ def emul_lib():
     out = os.path.join(ROOT, "tests", "emul", "libterra_emul.so")
     csrc = os.path.join(ROOT, "3dworld_amd", "csrc")
     deps = [src, os.path.join(ROOT, "include", "terra.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        tmp = f"{out}.{os.getpid()}.tmp"  # several xdist workers may find it stale at once: each builds its own file, the rename is atomic
-        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", tmp, src, "-lz"], check=True)
-        os.replace(tmp, out)
+    stale = lambda: not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)  # noqa: E731
+    if stale():  # several xdist workers may find it stale at once: one builds (to a temporary file, renamed when complete), the others wait for the lock and find it fresh
+        import fcntl
+        with open(out + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                tmp = f"{out}.{os.getpid()}.tmp"
+                subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", tmp, src, "-lz"], check=True)
+                os.replace(tmp, out)
     return out
 
 

@@ -107,7 +107,10 @@ def make_config(mesh_gen_mode=0, mesh_gen_shape=0, mesh_seed=1, mesh_freq_filter
 
 def build_oracle():
     """make oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
-    subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lk:  # one make at a time: several xdist workers may find the targets stale at once
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.DEVNULL)
 
 
 def engine_lib(which):
