@@ -598,6 +598,24 @@ int terra_tiles_post_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, con
 	TERRA_CHECK_CTX if (n && (!tile_xy || !d_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.tiles_post_dev(tile_xy, n, d_zvals, d_stats, d_normals, d_min_nz); TERRA_CATCH
 }
+int terra_tiles_post(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_nz) {
+	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (n == 0) return TERRA_OK;
+	TERRA_TRY
+		auto &be = ctx->eng.be;
+		size_t const zb = (size_t)n*130*130*4, sb = (size_t)n*sizeof(terra_tile_stats), nb = (size_t)n*129*129*4, mb = (size_t)n*4;
+		uint8_t *d = (uint8_t *)be.alloc(zb + sb + nb + mb + 1024);
+		float *dz = (float *)d; terra_tile_stats *ds = (terra_tile_stats *)(d + zb); uint8_t *dn = d + zb + sb; float *dm = (float *)(d + zb + sb + nb);
+		try {
+			be.h2d(dz, h_zvals, zb);
+			ctx->eng.tiles_post_dev(tile_xy, n, dz, h_stats ? ds : nullptr, h_normals ? dn : nullptr, (h_normals && h_min_nz) ? dm : nullptr);
+			if (h_stats) be.d2h(h_stats, ds, sb);
+			if (h_normals) be.d2h(h_normals, dn, nb);
+			if (h_normals && h_min_nz) be.d2h(h_min_nz, dm, mb);
+		} catch (...) {be.free(d); throw;}
+		be.free(d);
+	TERRA_CATCH
+}
 int terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, uint32_t iters_tt, float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_nz) {
 	TERRA_CHECK_CTX if (n && (!tile_xy || !h_zvals)) return terra::fail(TERRA_ERR_ARG, "null argument");
 	if (n == 0) return TERRA_OK;

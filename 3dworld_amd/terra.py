@@ -182,6 +182,7 @@ _PROTOS = {
     "terra_quantize16_dev": (_i32, [_vp, _vp, _sz, _f, _f, _vp]),
     "terra_tiles_create_zvals_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_post_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "terra_tiles_post": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "terra_tiles_create_zvals": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "terra_selftest_hot_sqrt": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "terra_voxel_fill_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _f3, _f3, _f3, _f, _f, _i32, _i32, _i32, _f, _i32]),

@@ -289,6 +289,7 @@ int  terra_tiles_create_zvals(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n
  * tile_t::create_zvals (src/tiled_mesh.cpp:517-541) and tile_t::upload_normal_texture (src/tiled_mesh.cpp:865-880), which the engine also runs on its own whenever a
  * tile's heights changed.  d_zvals is not written.  Outputs as above (each optional). */
 int  terra_tiles_post_dev(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *d_zvals, terra_tile_stats *d_stats, uint8_t *d_normals, float *d_min_normal_z);
+int  terra_tiles_post(terra_ctx *ctx, const int32_t *tile_xy, uint32_t n, const float *h_zvals, terra_tile_stats *h_stats, uint8_t *h_normals, float *h_min_normal_z); /* host arrays */
 /* self test: the droplet step takes its two square roots per step with a shortened instruction sequence (csrc/terra_erosion.hpp: sqrt_rn); this runs it over every
  * stride-th fp32 bit pattern (stride 1: all 2^32, a few ms on the GPU) against sqrtf and against the correctly rounded double-precision route; the tile normals' byte test
  * (csrc/terra_kernels.hpp: k_tile_post) relies on the hardware's reciprocal square root being within 2^-23 of the real one, checked over the same inputs.  *mismatches must be 0. */

@@ -97,6 +97,11 @@ inline void tiles_create_zvals(int const *tile_xy, unsigned n, unsigned erosion_
 	check(terra_tiles_create_zvals(default_ctx(), tile_xy, n, erosion_iters_tt, zvals, stats, normals, min_normal_z), "tiles_create_zvals");
 }
 
+// ---- tile_t::upload_normal_texture (src/tiled_mesh.cpp:865-880) and the sub-block / water-bbox loop of create_zvals (:517-541) over zvals the engine already has
+inline void tiles_upload_normal_texture(int const *tile_xy, unsigned n, float const *zvals, terra_tile_stats *stats, unsigned char *normals, float *min_normal_z=nullptr) {
+	check(terra_tiles_post(default_ctx(), tile_xy, n, zvals, stats, normals, min_normal_z), "upload_normal_texture");
+}
+
 // ---- tile_t::calc_shadows_for_light (src/tiled_mesh.cpp:664-692) for a batch and one light: smask [n][130][130] gets the MESH_SHADOW bits
 inline void tiles_mesh_shadows(int const *tile_xy, unsigned n, float const *zvals, float const lpos[3], unsigned char *smask) {
 	check(terra_tiles_mesh_shadows(default_ctx(), tile_xy, n, zvals, lpos, smask), "calc_mesh_shadows");

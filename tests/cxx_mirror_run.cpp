@@ -42,8 +42,11 @@ int main(int argc, char **argv) {
 	{
 		int const txy[2] = {2, -1};
 		std::vector<float> z(130*130); terra_tile_stats ts;
-		tiles_create_zvals(txy, 1, 80, z.data(), &ts);
+		std::vector<unsigned char> nm(129*129*4), nm2(129*129*4); float mnz = 0.0f, mnz2 = 0.0f; terra_tile_stats ts2;
+		tiles_create_zvals(txy, 1, 80, z.data(), &ts, nm.data(), &mnz);
 		out.insert(out.end(), z.begin(), z.end());
+		tiles_upload_normal_texture(txy, 1, z.data(), &ts2, nm2.data(), &mnz2); // the post pass alone over those zvals: the same stats, normals and min_normal_z
+		if (std::memcmp(&ts, &ts2, sizeof(ts)) != 0 || nm != nm2 || std::memcmp(&mnz, &mnz2, sizeof(float)) != 0) return 6;
 	}
 	FILE *f = std::fopen(argv[1], "wb");
 	if (!f) return 5;
