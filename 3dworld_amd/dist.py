@@ -273,6 +273,7 @@ class OneHeightmapPipeline:
                 it was that step's eroder -- so when the all_reduce of step s returns anywhere, that erosion is complete everywhere and step s + 1 may overwrite its grid."""
 
     def __init__(self, terra_mod, make_ctx, cfg, dist, nx, ny, droplets, tag, grids=8, eroders=2, coll_device="cpu"):
+        import os
         import threading
         self.pkg, self.dist, self.nx, self.ny, self.droplets = terra_mod, dist, nx, ny, droplets
         self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
@@ -301,7 +302,7 @@ class OneHeightmapPipeline:
         # {min, max} stay in HBM (terra_gen_grid_rows_minmax_async_dev), all_reduce(min) works on that float on the noise context's stream, the eroding context's
         # stream waits for an event behind it and the final clamp reads min(vals) from HBM (terra_apply_erosion_devmin_dev).  Measured on one GPU at a simulated world
         # of 8: 0.15-0.16 ms per rank and step against 0.21-0.24 ms with the read-back (profiles/r05_onegrid_native.jsonl, bench.py detail.onegrid_rank_floor).
-        self._dev_paced = str(coll_device).startswith("cuda")
+        self._dev_paced = str(coll_device).startswith("cuda") and os.environ.get("TERRA_ONEGRID_PACING", "device") != "host"  # (host: the read-back step, whatever the collective runs on)
         if self._dev_paced:
             import torch
             self._torch = torch
