@@ -52,6 +52,12 @@ def test_c_driver_refuses_bad_arguments(emul_driver):
     assert r.returncode == 2
 
 
+def test_c_driver_a_failing_rank_ends_the_job(emul_driver):
+    """40 ranks on a 256-row grid: the last ranks own no rows and give up; the launcher takes the others (which would wait for them in a barrier) down with them"""
+    r = subprocess.run([emul_driver, "40", "2", "256", "50", "--coll", "shm", "--same-device", "--grids", "2", "--warmup", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no rows for this rank" in r.stderr
+
+
 @pytest.fixture(scope="module")
 def hip_driver(tmp_path_factory):
     return build(os.path.join(ROOT, "tools", "_bin", "bench_native_onegrid"), os.path.join(ROOT, "3dworld_amd"), "terra_hip")
