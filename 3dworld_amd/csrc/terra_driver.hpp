@@ -1368,14 +1368,11 @@ template<class BE> struct terra_engine {
 		uint32_t const zv = 130, cs = AO_CTX, rl = AO_RAY_LEN;
 		float *d_ctx = scratch<float>(s_ao, (size_t)n*cs*cs);
 		if (using_hmap()) {tile_hmap_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);} else {tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);}
-		if (using_hmap() || !ao_context_zvals()) { // inside the tile the context is the tile's own zvals (src/tiled_mesh.cpp:622)
-			be.launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
-				d_ctx[(size_t)t*cs*cs + (size_t)(y + rl)*cs + (x + rl)] = d_zvals[i];
-			});
-		}
+		// inside the tile the context is the tile's own zvals (src/tiled_mesh.cpp:622): the kernel takes those cells from d_zvals while it stages the context (a copy pass
+		// into d_ctx first was 168 us for 4096 tiles)
+		bool const own = using_hmap() || !ao_context_zvals();
 		float const dz = (float)(0.5*(double)HALF_DXY);
-		be.tile_ao(n, d_zvals, d_ctx, d_ao, dz);
+		be.tile_ao(n, d_zvals, d_ctx, d_ao, dz, own);
 	}
 
 	// ================================================================ height edits of the heightmap texture and the map exporter (rest of f4)

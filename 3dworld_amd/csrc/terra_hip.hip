@@ -35,7 +35,8 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
-		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 	}
 	~hip_backend_t() {
 		if (pin) (void)hipHostFree(pin);
@@ -315,12 +316,13 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {
-		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz); return;}
+	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz, bool own) {
+		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz, own); return;}
 		use();
 		unsigned const nbands = (terra::AO_TEX + terra::AO_BAND - 1)/terra::AO_BAND;
 		size_t const lds = (size_t)(terra::AO_BAND + terra::AO_RL)*terra::AO_CS*sizeof(float);
-		hipLaunchKernelGGL(terra::k_tile_ao, dim3(n*nbands), dim3(terra::AO_THREADS), lds, stream, z, ctx, ao, dz);
+		if (own) {hipLaunchKernelGGL(terra::k_tile_ao<true>, dim3(n*nbands), dim3(terra::AO_THREADS), lds, stream, z, ctx, ao, dz);}
+		else {hipLaunchKernelGGL(terra::k_tile_ao<false>, dim3(n*nbands), dim3(terra::AO_THREADS), lds, stream, z, ctx, ao, dz);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	uint32_t *tile_acc = nullptr; size_t tile_acc_bytes = 0; // k_tile_post's per-tile accumulators

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k_tile_post_final(tile_ref_pod_t const *_
 // rays going up or sideways need context rows [y0, y0 + band + 35], rays going down rows [y0 + 36, y0 + band + 71] (context coordinates =
 // texel + 36) -- 68 rows x 201 floats = 54.7 KB each time, so two blocks share a CU.  A thread owns up to 17 texels and keeps their
 // attenuation sums in registers across the passes.  Same integer sums as the one-thread-per-texel version (tile_ao_simple).
-constexpr unsigned AO_BAND = 33, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_THREADS = 256, AO_ROWS_W = (AO_BAND + 3)/4, AO_STAGE = ((AO_BAND + AO_RL)*AO_CS + AO_THREADS - 1)/AO_THREADS;
+constexpr unsigned AO_BAND = 33, AO_CS = 201, AO_RL = 36, AO_TEX = 129, AO_THREADS = 256, AO_ROWS_W = (AO_BAND + 3)/4, AO_HALF = (AO_BAND + AO_RL + 1)/2;
 // one ray, branch-free: the eight samples sit at fixed offsets 1,3,6,...,36 steps from the texel (immediate ds_read offsets after unrolling),
 // are all requested before the first compare, and the first hit is selected backwards (hit at step s attenuates by 8 - s)
 template<int DX, int DY> __device__ __forceinline__ unsigned ao_march(float const *s_base, float const (&zr)[8]) {
@@ -633,7 +633,8 @@ __device__ __forceinline__ unsigned xcd_ordered(unsigned b, unsigned nb) {
 // The kernel is bound by its LDS reads (64 per texel).  A WAVE owns texel rows (every fourth row of the band); a lane is a column: x = lane and 64 + lane, column 128 is one
 // extra pass with a lane per row (row stride 201 = 9 mod 32: distinct banks).  With texels dealt out linearly (p = tid + 256 k) a wave's 64 texels crossed a row end and
 // the part behind the wrap met the part before it in the banks: half of the LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.53).
-__global__ __launch_bounds__(AO_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
+// OWN: the context cells inside the tile are taken from zvals (the tile's own, possibly eroded / edited heights) instead of ctx while the context is staged.
+template<bool OWN> __global__ __launch_bounds__(AO_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_tile_ao(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
 	extern __shared__ __attribute__((aligned(16))) float s_ao_ctx[];
 	unsigned const lb = xcd_ordered(blockIdx.x, gridDim.x);
 	unsigned const nbands = (AO_TEX + AO_BAND - 1)/AO_BAND, t = lb/nbands, band = lb % nbands, tid = threadIdx.x;
@@ -651,21 +652,30 @@ __global__ __launch_bounds__(AO_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 		zA[i] = zr[lane]; zB[i] = zr[64 + lane];
 	}
 	if (w == 3) {zC = z[(size_t)(y0 + ((lane < rows) ? lane : 0u))*130 + 128];}
-	// Staging: a pass's rows (<= 69 x 201 floats) are 55 loads per thread, ALL issued back to back into registers, then stored (as a plain copy loop, a few at a time between
-	// LDS stores, two blocks per CU kept ~8 KB in flight per CU: 775 -> 740 us)
-	unsigned const nfl = (rows + AO_RL)*AO_CS;
+	// Staging: a pass's rows (<= 69 x 201 floats), thread = context column (threads 201 .. 255 idle), the rows in two halves of <= 35 loads per thread, each half ALL in
+	// flight before its first LDS store (as a plain copy loop, a few loads at a time between LDS stores, two blocks per CU kept ~8 KB in flight per CU: 775 -> 740 us).
+	// By rows, which source a cell has (OWN) is one compare per row and one per thread.  Measured for 4096 tiles: linear staging (thread = element i, i + 256, ...) without OWN
+	// 663 us + the 168 us copy pass it needs = 831; this form 763; linear staging with an index division per element for OWN: 2813 (its 55 unrolled divisions spill).
+	unsigned const nrow = rows + AO_RL;
+	bool const col_ok = tid < AO_CS, col_own = OWN && (tid - AO_RL) < 130u;
 	for (int pass = 0; pass < 2; ++pass) {
 		unsigned const row0 = pass ? y0 + AO_RL : y0;
-		{
-			float stg[AO_STAGE];
-			float const *src = c + (size_t)row0*AO_CS;
 #pragma unroll
-			for (unsigned k = 0; k < AO_STAGE; ++k) {unsigned const i = tid + k*AO_THREADS; stg[k] = src[(i < nfl) ? i : 0u];}
-			__syncthreads(); // everybody is done with the previous pass's rows
+		for (unsigned h = 0; h < 2; ++h) {
+			float stg[AO_HALF];
 #pragma unroll
-			for (unsigned k = 0; k < AO_STAGE; ++k) {unsigned const i = tid + k*AO_THREADS; if (i < nfl) {s_ao_ctx[i] = stg[k];}}
-			__syncthreads();
+			for (unsigned k = 0; k < AO_HALF; ++k) {
+				unsigned const r = h*AO_HALF + k, gr = row0 + r;
+				bool const ok = col_ok && r < nrow;
+				float const *p = c + (size_t)(ok ? gr : 0u)*AO_CS + (col_ok ? tid : 0u);
+				if (OWN) {bool const in = col_own && (gr - AO_RL) < 130u && ok; p = in ? z + (size_t)(gr - AO_RL)*130 + (tid - AO_RL) : p;}
+				stg[k] = *p;
+			}
+			if (h == 0) {__syncthreads();} // everybody is done with the previous pass's rows
+#pragma unroll
+			for (unsigned k = 0; k < AO_HALF; ++k) {unsigned const r = h*AO_HALF + k; if (col_ok && r < nrow) {s_ao_ctx[r*AO_CS + tid] = stg[k];}}
 		}
+		__syncthreads();
 		unsigned const lrow = pass ? 0u : AO_RL; // LDS row of the band's first texel row
 #pragma unroll
 		for (unsigned i = 0; i < AO_ROWS_W; ++i) {

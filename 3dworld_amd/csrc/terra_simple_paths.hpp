@@ -74,12 +74,16 @@ template<class DERIVED> struct simple_paths {
 		});
 	}
 	// AO lighting, simple form: one logical thread per texel, context read from global memory
-	void tile_ao_simple(uint32_t n, float const *d_zvals, float const *d_ctx, uint8_t *d_ao, float dz) {
-		unsigned const stride = 129, zv = 130, cs = 201;
+	// own: inside the tile the context is the tile's own zvals (src/tiled_mesh.cpp:622) -- read from d_zvals, whatever d_ctx holds there
+	void tile_ao_simple(uint32_t n, float const *d_zvals, float const *d_ctx, uint8_t *d_ao, float dz, bool own) {
+		unsigned const stride = 129, zv = 130, cs = 201, rl = 36;
 		self().launch((size_t)n*stride*stride, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const t = (unsigned)(i / (stride*stride)), p = (unsigned)(i % (stride*stride)), y = p / stride, x = p % stride;
-			float const *c = d_ctx + (size_t)t*cs*cs;
-			d_ao[i] = tile_ao_texel(d_zvals[(size_t)t*zv*zv + y*zv + x], (int)x, (int)y, dz, [=] TERRA_LAMBDA (int cx, int cy) {return c[cy*(int)cs + cx];});
+			float const *c = d_ctx + (size_t)t*cs*cs, *z = d_zvals + (size_t)t*zv*zv;
+			d_ao[i] = tile_ao_texel(z[y*zv + x], (int)x, (int)y, dz, [=] TERRA_LAMBDA (int cx, int cy) {
+				bool const in = own && (unsigned)(cx - (int)rl) < zv && (unsigned)(cy - (int)rl) < zv;
+				return in ? z[(cy - (int)rl)*(int)zv + (cx - (int)rl)] : c[cy*(int)cs + cx];
+			});
 		});
 	}
 	// tile post-pass, simple form: sub-block ranges + water bbox (one logical thread per (tile, sub-block) then per tile), normals (one per texel)

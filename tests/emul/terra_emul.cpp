@@ -64,7 +64,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void timer_start() {t0 = std::chrono::steady_clock::now();}
 	float timer_stop() {return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();}
 	template<class F> void launch_waves_nolds(size_t n, F f) {for (size_t i = 0; i < n; ++i) f(i);}
-	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz) {tile_ao_simple(n, z, ctx, ao, dz);}
+	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz, bool own) {tile_ao_simple(n, z, ctx, ao, dz, own);}
 	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np);}
 	void fill8(void *p, uint8_t v, size_t count) {memset(p, v, count);}
 	bool graph_replay(void const *, size_t) {return false;} // no graphs here: every launch runs at once
