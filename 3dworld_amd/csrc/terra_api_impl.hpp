@@ -67,6 +67,10 @@ void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (.
 int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
 int terra_release_scratch(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.release_scratch(); TERRA_CATCH}
 int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
+int terra_set_option(terra_ctx *ctx, const char *key, const char *value) {
+	TERRA_CHECK_CTX if (!key || !value) return terra::fail(TERRA_ERR_ARG, "terra_set_option: null key / value");
+	TERRA_TRY std::lock_guard<std::recursive_mutex> lk(ctx->eng_mtx); ctx->eng.set_option(key, value); TERRA_CATCH
+}
 void *terra_host_alloc(size_t bytes) {void *p = terra_backend_t::host_alloc(bytes); if (!p) {terra::fail(TERRA_ERR_HIP, "terra_host_alloc: out of pinned host memory");} return p;}
 void terra_host_free(void *p) {terra_backend_t::host_free(p);}
 int terra_download_async(terra_ctx *ctx, const void *d_src, void *h_dst, size_t bytes) {

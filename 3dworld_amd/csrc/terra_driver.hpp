@@ -33,6 +33,7 @@ struct grid_job_t { // one build_arrays() + eval loop
 	int mode, shape, kstart, glaciate, use_sine_mag;
 	float sine_offset;
 	int plain_only; // sine mode: no cell can leave the short epilogue (see terra_engine::sine_plain_only): the kernel variant without finish_cell() is exact
+	int fused = 0; // TERRA_GEN_FUSED (tolerance mode; sine mode with plain_only): every multiply-add of the sum and of the tail rounds once (sine_cell_fused / finish_cell_fused)
 	uint32_t row0 = 0; // the job covers rows [row0, row0 + ny) of a taller grid (row strips of one heightmap on several GPUs): cell row y is eval_index's y + row0
 };
 
@@ -58,6 +59,21 @@ TERRA_HD float finish_cell(float z, grid_job_t const &job, noise_consts_t const 
 	if (job.glaciate) {
 		float const xg = ((float)x*job.mdx + job.mx0)*nc.DX_VAL_INV, yg = ((float)(y + job.row0)*job.mdy + job.my0)*nc.DY_VAL_INV;
 		z = glaciate_epilogue(z, job.use_sine_mag ? smx[x] : 0.0f, job.use_sine_mag ? smy[y] : 0.0f, job.sine_offset, xg, yg, nc, L);
+	}
+	return z;
+}
+// TERRA_GEN_FUSED: the reference's expression tree (src/mesh_gen.cpp:766-790) with every a*b + c contracted into one fused multiply-add -- the sum's 80 terms, glaciate's
+// last step, the island term -- and nothing else changed.  Only for jobs whose every cell takes the short epilogue (plain_only): k_sine_grid_mx (terra_fused.hpp) is this
+// function on the matrix pipe, bit for bit (the matrix instruction accumulates in k order, one rounding per term).
+TERRA_HD float sine_cell_fused(grid_job_t const &job, float const *xt, float const *yt, unsigned x, unsigned y) {
+	float z = 0.0f;
+	for (int k = job.kstart; k < F_TABLE_SIZE; ++k) {z = fmaf(xt[(size_t)k*job.nxp + x], yt[(size_t)k*job.nyp + y], z);}
+	return z;
+}
+TERRA_HD float finish_cell_fused(float z, grid_job_t const &job, noise_consts_t const &nc, float const *smx, float const *smy, unsigned x, unsigned y) {
+	if (job.glaciate) {
+		if (nc.glaciate) {float const relh = (z + nc.zmax_est)*nc.zmax_est2_inv; z = fmaf((relh*relh)*relh, nc.zmax_est2, -nc.zmax_est);} // (custom_glaciate_exp == 0: plain_only)
+		if (job.use_sine_mag) {z = z + fmaf(smx[x], smy[y], job.sine_offset);}
 	}
 	return z;
 }
@@ -242,8 +258,67 @@ TERRA_HD void tile_normal(float const *z, unsigned x, unsigned y, float dxv, flo
 	tile_normal_v(z[ix2], z[ix2 + 1], z[ix2 + zv], dxv, dyv, dxy, nv);
 }
 
+// ---- terra_set_option (include/terra.h): every behaviour switch of the library in one place.  Nothing in the library reads the process environment; tests and tools
+// translate their TERRA_* variables into these calls (3dworld_amd/terra.py: options_from_env).  Except "gen.fused", no option changes a result.
+struct options_t {
+	int gen_fused = 0;            // "gen.fused" 0 / 1: every generator call behaves as if TERRA_GEN_FUSED were given (the calls without a flags argument: tiles, voxels)
+	int ero_lead = 2;             // "ero.lead" 0..2: where a recentred droplet window lies (a cache placement)
+	int ero_batch = 0;            // "ero.batch" >= 1: rounds per host read-back of the multi-version scheduler (0: automatic)
+	int ero_sparse = -1;          // "ero.sparse" 0 / 1: never / always try the sparse scheduler (-1 = "auto": by droplet density)
+	int ero_sparse_retraces = -1; // "ero.sparse_retraces" >= 0: re-traces before the sparse scheduler hands over (-1: default 8)
+	int ero_live = 1;             // "ero.live" 0 / 1: a droplet's first trace is visible to higher droplets while it grows
+	int ero_diag = 0;             // "ero.diag" 0 / 1: per-round clock diagnostics in the erosion report
+	int ero_ck_steps = 0, ero_ck_max = -1; // "ero.ck" "steps:max": checkpoint spacing / count (default SPEC_CK_STEPS : SPEC_CK_MAX)
+	bool ero_near_set = false; int ero_near = 0; // "ero.near" n (negative: ring / -n): droplets next in line for the commit that trace to the end
+	long long ero_mem_budget = -1; // "ero.mem_budget" bytes: pretend this much device memory is free when the ring has to grow (tests)
+	int simple_kernels = 0;       // "kernels.simple" 0 / 1: the one-thread-per-cell cross-check kernels instead of the tiled ones
+	int graphs = 1;               // "graphs" 0 / 1: replay the erosion rounds as hipGraphs
+	int sg_kc = 27, sg_kc_tiles = 27; // "sg.kc" 20 / 27 / 45, "sg.kc_tiles" 27 / 45: terms per LDS chunk of k_sine_grid (heightmap / tile batch)
+	int sg_rowgroup = 4;          // "sg.rowgroup" 1..1024: tile rows walked together by k_sine_grid
+	int tile_erosion_window = 0;  // "tile_erosion" "lds" / "window": tile erosion through the 32 x 32 window over an HBM copy instead of the whole tile in LDS
+	int weights_simple = 0;       // "weights.simple" 0 / 1: the per-texel form of the weights-texture pass (cross-check of k_tile_weights)
+	int shadows_levels = 0;       // "shadows.levels" 0 / 1: one launch per dependency level instead of the one dataflow launch (cross-check)
+	// returns false for an unknown key or a value outside the key's range (nothing is changed then)
+	bool set(char const *key, char const *value) {
+		if (!key || !value) return false;
+		std::string const k(key), v(value);
+		char *end = nullptr;
+		long long const n = strtoll(value, &end, 10);
+		bool const is_int = (end != value && *end == '\0');
+		auto const flag = [&](int &dst) {if (!is_int || (n != 0 && n != 1)) return false; dst = (int)n; return true;};
+		if (k == "gen.fused") return flag(gen_fused);
+		if (k == "ero.lead") {if (!is_int || n < 0 || n > 2) return false; ero_lead = (int)n; return true;}
+		if (k == "ero.batch") {if (!is_int || n < 0 || n > (1 << 20)) return false; ero_batch = (int)n; return true;}
+		if (k == "ero.sparse") {if (v == "auto") {ero_sparse = -1; return true;} return flag(ero_sparse);}
+		if (k == "ero.sparse_retraces") {if (!is_int || n < -1 || n > (1 << 20)) return false; ero_sparse_retraces = (int)n; return true;}
+		if (k == "ero.live") return flag(ero_live);
+		if (k == "ero.diag") return flag(ero_diag);
+		if (k == "ero.ck") {int a = 0, b = 0; if (v == "default") {ero_ck_steps = 0; ero_ck_max = -1; return true;} if (sscanf(value, "%d:%d", &a, &b) != 2 || a < 1 || b < 0 || b > (int)SPEC_CK_MAX) return false; ero_ck_steps = a; ero_ck_max = b; return true;}
+		if (k == "ero.near") {if (v == "default") {ero_near_set = false; return true;} if (!is_int || n < -(1 << 20) || n > (1 << 20)) return false; ero_near_set = true; ero_near = (int)n; return true;}
+		if (k == "ero.mem_budget") {if (!is_int || n < -1) return false; ero_mem_budget = n; return true;}
+		if (k == "kernels.simple") return flag(simple_kernels);
+		if (k == "graphs") return flag(graphs);
+		if (k == "sg.kc") {if (!is_int || (n != 20 && n != 27 && n != 45)) return false; sg_kc = (int)n; return true;}
+		if (k == "sg.kc_tiles") {if (!is_int || (n != 27 && n != 45)) return false; sg_kc_tiles = (int)n; return true;}
+		if (k == "sg.rowgroup") {if (!is_int || n < 1 || n > 1024) return false; sg_rowgroup = (int)n; return true;}
+		if (k == "tile_erosion") {if (v == "lds") {tile_erosion_window = 0; return true;} if (v == "window") {tile_erosion_window = 1; return true;} return false;}
+		if (k == "weights.simple") return flag(weights_simple);
+		if (k == "shadows.levels") return flag(shadows_levels);
+		return false;
+	}
+};
+
 template<class BE> struct terra_engine {
 	BE be;
+	options_t opt;
+	terra_engine() {be.opt = &opt;}
+	void set_option(char const *key, char const *value) {
+		options_t o = opt;
+		if (!o.set(key, value)) throw std::invalid_argument(std::string("terra_set_option: unknown key or bad value: ") + (key ? key : "(null)") + " = " + (value ? value : "(null)"));
+		be.sync(); // (kernels in flight were launched under the old options)
+		opt = o;
+		be.options_changed();
+	}
 	terra_config cfg{};
 	// ---- derived globals (the reference's process globals for this path)
 	float MESH_HEIGHT = 0, XY_SCENE_SIZE = 0, DX_VAL = 0, DY_VAL = 0, HALF_DXY = 0, DX_VAL_INV = 0, DY_VAL_INV = 0, dxdy = 0;
@@ -510,6 +585,7 @@ template<class BE> struct terra_engine {
 		job.use_sine_mag = (job.glaciate && hp.sine_mag > 0.0f) ? 1 : 0;
 		job.sine_offset = hp.sine_bias*mesh_scale_z_inv;
 		job.plain_only = (job.mode == MGEN_SINE && sine_plain_only(job.shape, job.kstart)) ? 1 : 0;
+		job.fused = (((flags & TERRA_GEN_FUSED) || opt.gen_fused) && job.plain_only) ? 1 : 0; // a permission, not a command: configurations without a fused kernel get the exact one
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
@@ -745,8 +821,7 @@ template<class BE> struct terra_engine {
 		ec.erode_amount = erode_amount; ec.water_thresh = water_plane_z - HALF_DXY;
 		ec.relh_adj_tex = relh_adj_tex; ec.zmin = zmin; ec.zrange = zmax - zmin; ec.clip_hd1 = clip_hd1; ec.two_pi = two_pi; ec.min_zval = min_zval;
 		make_rock_threshold(ec);
-		ec.lead_mode = 2;
-		if (char const *lm = getenv("TERRA_ERO_LEAD")) {int const v = atoi(lm); if (v >= 0 && v <= 2) ec.lead_mode = v;} // where a recentred window lies never changes a result (it is a cache)
+		ec.lead_mode = opt.ero_lead; // where a recentred window lies never changes a result (it is a cache)
 		return ec;
 	}
 
@@ -757,7 +832,7 @@ template<class BE> struct terra_engine {
 	static_assert(79ll*(MAX_EROSION_ITERS - 1) + 121 <= 2147483647ll && 79ll*MAX_EROSION_ITERS + 121 > 2147483647ll, "last droplet whose seed fits an int");
 	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27183336 droplets (the reference's int seed 79*iter+121 overflows)");}
 
-	uint32_t spec_batch_override = getenv("TERRA_ERO_BATCH") ? (uint32_t)std::max(1, atoi(getenv("TERRA_ERO_BATCH"))) : 0u; // experiment knob: rounds per host read-back
+	uint32_t spec_batch_override() const {return (uint32_t)opt.ero_batch;} // "ero.batch": rounds per host read-back (0: automatic)
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 96, max_rounds = 4000000, near_count = 128;} spec_cfg;
 
 	// d_min (optional): min_zval is read from this DEVICE float when the final clamp runs (the only place apply_erosion uses it, src/erosion.cpp:158-162) -- the caller's
@@ -816,7 +891,8 @@ template<class BE> struct terra_engine {
 	static constexpr uint32_t SPARSE_MAX_DROPLETS = 8192, SPARSE_MAX_RETRACES = 8;
 	bool sparse_wanted(erosion_consts_t const &ec, uint32_t num_iters) const {
 		if (num_iters > SPARSE_MAX_DROPLETS) return false;
-		if (char const *sp = getenv("TERRA_ERO_SPARSE")) {if (sp[0] == '0') return false; if (sp[0] == '1') return true;}
+		if (opt.ero_sparse == 0) return false;
+		if (opt.ero_sparse == 1) return true;
 		uint64_t const nblocks = (uint64_t)(((uint32_t)ec.NX >> 3) + 1)*(((uint32_t)ec.NY >> 3) + 1);
 		return (uint64_t)num_iters*num_iters <= 2*nblocks;
 	}
@@ -828,7 +904,7 @@ template<class BE> struct terra_engine {
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB);
 		sb.nbx = ((uint32_t)ec.NX >> 3) + 1; sb.nby = ((uint32_t)ec.NY >> 3) + 1;
 		sb.max_retraces = SPARSE_MAX_RETRACES;
-		if (char const *mr = getenv("TERRA_ERO_SPARSE_RETRACES")) {int const v = atoi(mr); if (v >= 0) sb.max_retraces = (uint32_t)v;}
+		if (opt.ero_sparse_retraces >= 0) {sb.max_retraces = (uint32_t)opt.ero_sparse_retraces;}
 		size_t const nblocks = (size_t)sb.nbx*sb.nby;
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)N*1024u + 65536u, 64u << 20) : 0u;
 		size_t off = 0;
@@ -924,16 +1000,15 @@ template<class BE> struct terra_engine {
 		uint32_t W = std::min<uint32_t>(spec_cfg.window ? spec_cfg.window : auto_w, num_iters - first);
 		sb.near_count = spec_cfg.near_count;
 		sb.ck_steps = SPEC_CK_STEPS; sb.ck_max = SPEC_CK_MAX;
-		sb.live_partial = 1u;
-		if (char const *lv = getenv("TERRA_ERO_LIVE")) {sb.live_partial = (lv[0] != '0') ? 1u : 0u;} // experiment knob; results never depend on it
-		{char const *dg = getenv("TERRA_ERO_DIAG"); sb.diag = (dg && dg[0] == '1') ? 1u : 0u;}
-		if (char const *ck = getenv("TERRA_ERO_CK")) {int a = 0, b = 0; if (sscanf(ck, "%d:%d", &a, &b) == 2 && a >= 1 && b >= 0 && b <= (int)SPEC_CK_MAX) {sb.ck_steps = (uint32_t)a; sb.ck_max = (uint32_t)b;}} // experiment knob "steps:max"; results never depend on it
+		sb.live_partial = opt.ero_live ? 1u : 0u; // (options "ero.live", "ero.diag", "ero.ck": results never depend on them)
+		sb.diag = opt.ero_diag ? 1u : 0u;
+		if (opt.ero_ck_steps >= 1) {sb.ck_steps = (uint32_t)opt.ero_ck_steps; sb.ck_max = (uint32_t)opt.ero_ck_max;}
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB); sb.bshift = 3; // a version page is the 8 x 8 cells of a block
 		// where a cell is read from is a 31-bit float index into a version buffer, (slot*maxb + entry)*64 + cell, with bit 31 naming the buffer (spec_back_t::source,
 		// spec_cand_t::page): the ring must keep W*maxb*64 below 2^31 -- a larger request is served with the largest ring that does (results never depend on W)
 		{uint64_t const most = (((1ull << 31) - 1)/SPEC_PAGE)/sb.maxb; if (W > most) {W = (uint32_t)most;}}
 		sb.W = W;
-		if (char const *nc = getenv("TERRA_ERO_NEAR")) {int const v = atoi(nc); sb.near_count = (v >= 0) ? (uint32_t)v : W/(uint32_t)(-v);} // experiment knob (negative: a fraction of the ring); results never depend on it
+		if (opt.ero_near_set) {int const v = opt.ero_near; sb.near_count = (v >= 0) ? (uint32_t)v : W/(uint32_t)(-v);} // "ero.near" (negative: a fraction of the ring); results never depend on it
 		sb.nbx = ((uint32_t)ec.NX >> sb.bshift) + 1; sb.nby = ((uint32_t)ec.NY >> sb.bshift) + 1;
 		size_t const nblocks = (size_t)sb.nbx*sb.nby;
 		// carve one allocation.  The ring is the one big buffer of the library (~266 KiB per slot): it must fit what the device has free right now -- several contexts share
@@ -962,7 +1037,7 @@ template<class BE> struct terra_engine {
 			size_t need = layout(W);
 			if (need > s_spec.bytes) { // it has to grow: what is free now + what the old ring gives back, minus a reserve for everybody else's next allocation
 				size_t avail = be.mem_free() + s_spec.bytes, reserve = (size_t)1 << 30;
-				if (char const *mb = getenv("TERRA_ERO_MEM_BUDGET")) {avail = (size_t)strtoull(mb, nullptr, 10); reserve = 0;} // test knob: pretend this many bytes are free
+				if (opt.ero_mem_budget >= 0) {avail = (size_t)opt.ero_mem_budget; reserve = 0;} // "ero.mem_budget" (tests): pretend this many bytes are free
 				while (W > 256 && need + reserve > avail) {W = W - W/4; need = layout(W);}
 				sb.W = W;
 			}
@@ -1048,7 +1123,7 @@ template<class BE> struct terra_engine {
 		while (host_base < num_iters) {
 			// the first batch is short (a sparse map is done after two rounds); later ones amortise the read-back over 8 rounds
 			uint32_t batch = (launched == 0) ? 2u : 8u;
-			if (spec_batch_override) {batch = spec_batch_override;}
+			if (spec_batch_override()) {batch = spec_batch_override();}
 			for (uint32_t r = 0; r < batch; ++r) {
 				if (launched >= spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
 				one_round(); ++launched;
@@ -1161,7 +1236,8 @@ template<class BE> struct terra_engine {
 			});
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, md == MGEN_SINE && sine_plain_only(shp, kstart), tw, unique_tiles, glac, d_noise_lut);
+		bool const plain = md == MGEN_SINE && sine_plain_only(shp, kstart);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, tw, unique_tiles, glac, d_noise_lut, opt.gen_fused && plain);
 		return d_refs;
 	}
 

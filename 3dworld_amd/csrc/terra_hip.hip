@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off terra_hip.hip -o libterra_hip.so
 // (see 3dworld_amd/build.py).  There is no host execution path in this library: every entry point needs a HIP device.
 #include "terra_kernels.hpp"
+#include "terra_fused.hpp"
 #include "terra_simple_paths.hpp"
 #include "terra_xfer.hpp"
 #include <stdlib.h>
@@ -13,12 +14,14 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	int device = -1;
 	hipStream_t stream = nullptr, own_stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	bool simple_kernels = false; // TERRA_SIMPLE_KERNELS=1: run the one-thread-per-cell cross-check kernels instead of the LDS-tiled ones
+	terra::options_t const *opt = nullptr; // the engine's options (terra_set_option); the members below are copies taken by options_changed()
+	bool simple_kernels = false; // "kernels.simple": run the one-thread-per-cell cross-check kernels instead of the LDS-tiled ones
+	int num_cus = 256;
 	float *tile_pad = nullptr; size_t tile_pad_bytes = 0;
 	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
-	int sg_kc = 27; // TERRA_SG_KC: terms per LDS chunk of the heightmap's sine kernel (27: 3 chunks of <= 27 for 8 octaves, 29.7 KB per block; 45: 2 chunks, 48 KB)
-	unsigned sg_rowgroup = 4; // TERRA_SG_ROWGROUP: tile rows walked together by k_sine_grid (L2 reuse of table slices)
+	int sg_kc = 27; // "sg.kc": terms per LDS chunk of the heightmap's sine kernel (27: 3 chunks of <= 27 for 8 octaves, 29.7 KB per block; 45: 2 chunks, 48 KB)
+	unsigned sg_rowgroup = 4; // "sg.rowgroup": tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
 	static int device_count() {int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n;}
 	void init(int dev) {
@@ -27,16 +30,18 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
 		stream = own_stream;
 		TERRA_HIP_CHECK(hipEventCreate(&ev0)); TERRA_HIP_CHECK(hipEventCreate(&ev1));
-		char const *s = getenv("TERRA_SIMPLE_KERNELS");
-		simple_kernels = (s && s[0] == '1');
-		if (char const *gr = getenv("TERRA_GRAPHS")) {graphs_enabled = (gr[0] != '0');}
-		if (char const *kc = getenv("TERRA_SG_KC")) {int const v = atoi(kc); if (v == 45 || v == 27 || v == 20) sg_kc = v;} // experiment knob: the same sum, chunked differently
-		if (char const *rg = getenv("TERRA_SG_ROWGROUP")) {int const v = atoi(rg); if (v >= 1 && v <= 1024) sg_rowgroup = (unsigned)v;}
+		{int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) {num_cus = n;} else {(void)hipGetLastError();}}
+		options_changed();
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
+	}
+	void options_changed() { // (the engine has drained the stream)
+		if (!opt) return;
+		simple_kernels = opt->simple_kernels != 0; sg_kc = opt->sg_kc; sg_rowgroup = (unsigned)opt->sg_rowgroup;
+		if (graphs_enabled != (opt->graphs != 0)) {for (graph_slot_t &g : graphs) {graph_drop(g);} graphs_enabled = opt->graphs != 0;}
 	}
 	~hip_backend_t() {
 		if (pin) (void)hipHostFree(pin);
@@ -245,6 +250,15 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY;
 		unsigned const nb = ntx*nty, grid = ((nb + 7)/8)*8;
+		if (job.fused) { // TERRA_GEN_FUSED: the sum on the f32 matrix pipe, persistent blocks (two per CU: 225 registers per lane)
+			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
+			J.xt = xt; J.yt = yt; J.smx = smx; J.smy = smy; J.out = out; J.mm = mm; J.nx = job.nx; J.ny = job.ny; J.nxp = job.nxp; J.nyp = job.nyp; J.ntx = ntx; J.nty = nty; J.rowgroup = sg_rowgroup;
+			J.kstart = job.kstart; J.glaciate = (job.glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (job.glaciate && job.use_sine_mag) ? 1 : 0;
+			J.zmax_est = nc.zmax_est; J.zmax_est2 = nc.zmax_est2; J.zmax_est2_inv = nc.zmax_est2_inv; J.sine_offset = job.sine_offset;
+			hipLaunchKernelGGL(terra::k_sine_grid_mx<false>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
+			TERRA_HIP_CHECK(hipGetLastError());
+			return true;
+		}
 		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup, 0};
 		if (job.plain_only) {
 			auto const go = [&](auto kern) {hipLaunchKernelGGL(kern, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);};
@@ -270,7 +284,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr, bool fused = false)
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
@@ -291,7 +305,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
 		}
-		if (simple_kernels || md != terra::MGEN_SINE || !unique_tiles || (uint64_t)n*2 < (uint64_t)nux*nuy || ((uintptr_t)zvals & 7)) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate); return;}
+		if (simple_kernels || md != terra::MGEN_SINE || !unique_tiles || (uint64_t)n*2 < (uint64_t)nux*nuy || ((uintptr_t)zvals & 7)) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate, fused); return;}
 		use();
 		size_t const cnt = (size_t)nux*nuy;
 		if (cnt > tile_map_count) {if (tile_map) {sync(); (void)hipFree(tile_map);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_map, cnt*sizeof(int32_t))); tile_map_count = cnt;}
@@ -304,7 +318,17 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
 		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup, tw};
 		job.plain_only = plain_only ? 1 : 0;
-		static int const kc_tiles = [] {char const *e = getenv("TERRA_SG_KC_TILES"); return e ? atoi(e) : 27;}(); // 27: three chunks, 29.7 KB per block (measured on the 64 x 64 batch: 291.8 -> 283.9 us, the 201-wide AO context 735 -> 706 us); TERRA_SG_KC_TILES=45: two chunks, 48 KB.  The same sum either way
+		if (fused && plain_only) { // "gen.fused": the batch's virtual grid on the matrix pipe, scattered into the per-tile layout
+			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
+			J.xt = xt; J.yt = yt; J.smx = d_sm; J.smy = d_sm + (size_t)nux*tw; J.out = zvals; J.mm = nullptr; J.nx = job.nx; J.ny = job.ny; J.nxp = job.nxp; J.nyp = job.nyp; J.ntx = ntx; J.nty = nty; J.rowgroup = sg_rowgroup;
+			J.kstart = kstart; J.glaciate = (glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (glaciate && use_sm) ? 1 : 0;
+			J.zmax_est = nc.zmax_est; J.zmax_est2 = nc.zmax_est2; J.zmax_est2_inv = nc.zmax_est2_inv; J.sine_offset = so;
+			J.tile_map = tm; J.nux = nux; J.tw = tw;
+			hipLaunchKernelGGL(terra::k_sine_grid_mx<true>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
+			TERRA_HIP_CHECK(hipGetLastError());
+			return;
+		}
+		int const kc_tiles = opt ? opt->sg_kc_tiles : 27; // 27: three chunks, 29.7 KB per block (measured on the 64 x 64 batch: 291.8 -> 283.9 us, the 201-wide AO context 735 -> 706 us); "sg.kc_tiles" 45: two chunks, 48 KB.  The same sum either way
 		if (plain_only && kc_tiles == 27) {hipLaunchKernelGGL((terra::k_sine_grid<true, false, 27>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		else if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
@@ -348,10 +372,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		use();
 		size_t const lds = (size_t)ec.NX*ec.NY*sizeof(float);
 		// default: the whole clamp-padded tile resident in LDS (76 KB, 2 tiles per CU; measured 126 ms for 4096 tiles x 1000 droplets);
-		// TERRA_TILE_EROSION=window: a 32x32 LDS window over an HBM/L2-resident copy (10 KB, ~15 tiles per CU; 141 ms: the batch is bound by its
+		// option "tile_erosion" = "window": a 32x32 LDS window over an HBM/L2-resident copy (10 KB, ~15 tiles per CU; 141 ms: the batch is bound by its
 		// heaviest land tiles, ~50k dependent droplet steps each, not by occupancy).  Grids too large for LDS always use the window.
-		char const *sel = getenv("TERRA_TILE_EROSION");
-		bool const use_lds = !(sel && sel[0] == 'w') && lds <= 96*1024;
+		bool const use_lds = !(opt && opt->tile_erosion_window) && lds <= 96*1024;
 		if (!use_lds) {
 			size_t const bytes = (size_t)n*lds;
 			if (bytes > tile_pad_bytes) {if (tile_pad) {sync(); (void)hipFree(tile_pad);} TERRA_HIP_CHECK(hipMalloc((void **)&tile_pad, bytes)); tile_pad_bytes = bytes;}

@@ -12,7 +12,7 @@ template<class DERIVED> struct simple_paths {
 	void sine_grid_simple(grid_job_t const &job, noise_consts_t const &nc, sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out) {
 		self().launch((size_t)job.nx*job.ny, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const x = (unsigned)(i % job.nx), y = (unsigned)(i / job.nx);
-			out[i] = finish_cell(sine_cell(job, xt, yt, x, y), job, nc, L, smx, smy, x, y);
+			out[i] = job.fused ? finish_cell_fused(sine_cell_fused(job, xt, yt, x, y), job, nc, smx, smy, x, y) : finish_cell(sine_cell(job, xt, yt, x, y), job, nc, L, smx, smy, x, y);
 		});
 	}
 	void noise_grid_simple(grid_job_t const &job, noise_consts_t const &nc, sin_lut_t const &L, float const *smx, float const *smy, float *out) {
@@ -24,7 +24,7 @@ template<class DERIVED> struct simple_paths {
 	// tiles: xt / yt = k-major tables of all distinct tile columns / rows side by side (row lengths nxpv / nypv), d_sm = [nux + nuy][zv] sine-mag terms,
 	// d_m0 = per distinct tx / ty grid origin (mx0 / my0)
 	void tile_grid_simple(uint32_t n, tile_ref_pod_t const *refs, uint32_t nux, uint32_t /*nuy*/, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv,
-		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals, uint32_t zv, bool glaciate = true)
+		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals, uint32_t zv, bool glaciate = true, bool fused = false)
 	{
 		self().launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
@@ -33,6 +33,7 @@ template<class DERIVED> struct simple_paths {
 			job.mx0 = d_m0[r.xi]; job.my0 = d_m0[nux + r.yi]; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = zv; job.nxp = nxpv; job.nyp = nypv;
 			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = glaciate ? 1 : 0; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = sine_offset;
 			float z;
+			if (md == MGEN_SINE && fused) {zvals[i] = finish_cell_fused(sine_cell_fused(job, xt, yt, r.xi*zv + x, r.yi*zv + y), job, nc, d_sm + (size_t)r.xi*zv, d_sm + (size_t)(nux + r.yi)*zv, x, y); return;}
 			if (md == MGEN_SINE) {z = sine_cell(job, xt, yt, r.xi*zv + x, r.yi*zv + y);}
 			else {z = noise_cell(job, nc, x, y);}
 			zvals[i] = finish_cell(z, job, nc, L, d_sm + (size_t)r.xi*zv, d_sm + (size_t)(nux + r.yi)*zv, x, y);

@@ -5,7 +5,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES = 1, 2, 4, 8
+GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES, GEN_FUSED = 1, 2, 4, 8, 16
 ERODE_SERIAL, ERODE_MINZ_IS_MIN, ERODE_SERIAL_WAVE = 1, 2, 4
 MGEN_SINE, MGEN_SIMPLEX, MGEN_PERLIN, MGEN_SIMPLEX_GPU, MGEN_DWARP_GPU = range(5)
 
@@ -105,6 +105,7 @@ _PROTOS = {
     "terra_destroy": (None, [_vp]),
     "terra_set_stream": (_i32, [_vp, _vp]),
     "terra_synchronize": (_i32, [_vp]),
+    "terra_set_option": (_i32, [_vp, C.c_char_p, C.c_char_p]),
     "terra_host_alloc": (_vp, [_sz]),
     "terra_host_free": (None, [_vp]),
     "terra_download_async": (_i32, [_vp, _vp, _vp, _sz]),
@@ -291,16 +292,43 @@ class PinnedArray:
             self.ptr = None
 
 
+# The library reads no environment variable.  Tests and tools keep their TERRA_* experiment variables: this table turns them into terra_set_option calls
+# (variable -> (option key, value when the variable is unset)); Terra.apply_env_options() is called at construction and by whoever changes a variable afterwards.
+ENV_OPTIONS = {
+    "TERRA_GEN_FUSED": ("gen.fused", "0"), "TERRA_SIMPLE_KERNELS": ("kernels.simple", "0"), "TERRA_GRAPHS": ("graphs", "1"),
+    "TERRA_SG_KC": ("sg.kc", "27"), "TERRA_SG_KC_TILES": ("sg.kc_tiles", "27"), "TERRA_SG_ROWGROUP": ("sg.rowgroup", "4"), "TERRA_TILE_EROSION": ("tile_erosion", "lds"),
+    "TERRA_WEIGHTS_SIMPLE": ("weights.simple", "0"), "TERRA_SHADOWS_LEVELS": ("shadows.levels", "0"),
+    "TERRA_ERO_SPARSE": ("ero.sparse", "auto"), "TERRA_ERO_SPARSE_RETRACES": ("ero.sparse_retraces", "-1"), "TERRA_ERO_LEAD": ("ero.lead", "2"), "TERRA_ERO_BATCH": ("ero.batch", "0"),
+    "TERRA_ERO_LIVE": ("ero.live", "1"), "TERRA_ERO_DIAG": ("ero.diag", "0"), "TERRA_ERO_CK": ("ero.ck", "default"), "TERRA_ERO_NEAR": ("ero.near", "default"),
+    "TERRA_ERO_MEM_BUDGET": ("ero.mem_budget", "-1"),
+}
+
+
 class Terra:
     """One terra_ctx (one GPU, one stream)."""
 
-    def __init__(self, device=0, lib_path=None):
+    def __init__(self, device=0, lib_path=None, env_options=True):
         self.lib = load_library(lib_path)
         ctx = _vp()
         rc = self.lib.terra_create(C.byref(ctx), device)
         if rc != 0:
             raise TerraError(rc, self.lib.terra_last_error().decode())
         self.ctx = ctx
+        self._env_applied = {}
+        if env_options:
+            self.apply_env_options()
+
+    def set_option(self, key, value):
+        """terra_set_option: every behaviour switch of the library (include/terra.h lists the keys)"""
+        self._ck(self.lib.terra_set_option(self.ctx, str(key).encode(), str(value).encode()))
+
+    def apply_env_options(self):
+        """experiment knobs of tests / tools: TERRA_* variables -> options (a variable that is unset puts its option back to the default)"""
+        for var, (key, default) in ENV_OPTIONS.items():
+            val = os.environ.get(var, default)
+            if self._env_applied.get(key, default) != val:
+                self.set_option(key, val)
+                self._env_applied[key] = val
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -127,6 +127,15 @@ typedef struct terra_gen terra_gen;
 #define TERRA_GEN_FORCE_SINE   2u  /* force_sine_mode */
 #define TERRA_GEN_NO_WAIT      4u  /* no_wait: return 0 right after launch */
 #define TERRA_GEN_CACHE_VALUES 8u  /* cache_values: every cell is always evaluated on the device; the flag only decides what eval_index(.., use_cache=1) returns */
+/* TOLERANCE mode (opt-in; everything else in this library is bit-identical to the reference's CPU path).  The reference binary has no fused multiply-add, so the exact
+ * kernels pay a multiply AND an add per term of eval_index's sum (src/mesh_gen.cpp:777-779) and can never pass half of the chip's fp32 rate.  With this flag every a*b + c of
+ * the sum and of eval_index's tail (glaciate's last step, the island term; src/mesh_gen.cpp:380-385,781-790) rounds ONCE: the value is the reference's expression tree
+ * evaluated with fmaf, exactly (pinned against that restatement in the tests' checker: orc_set_fused), and within 1e-5 * zmax_est of the reference (BASELINE's bar; measured
+ * max 3e-7 * zmax_est on the 16384^2 grid).  The sine tables are the exact mode's (SINF indices pinned).  The sum runs on the f32 matrix pipe (csrc/terra_fused.hpp).  It is a
+ * permission, not a command: a configuration without a fused kernel (fBm modes, shapes / plateau / crater / volcano set-ups whose cells can leave the short tail) is
+ * evaluated by the exact kernel.  Do not feed fused heights to apply_erosion when the droplet paths must be the reference's: erosion amplifies a last-bit difference.
+ * The calls without a flags argument (tiles, voxels) take it from terra_set_option(ctx, "gen.fused", "1"). */
+#define TERRA_GEN_FUSED        16u
 /* flags of terra_apply_erosion*_dev */
 #define TERRA_ERODE_SERIAL        1u /* walk droplets one by one on one lane (reference order, no speculation): debugging / tiny grids */
 #define TERRA_ERODE_SERIAL_WAVE   4u /* droplets one after another, each simulated by a whole wave through the LDS window (no speculation) */
@@ -140,6 +149,18 @@ int  terra_create(terra_ctx **out, int device_index);
 void terra_destroy(terra_ctx *ctx);
 int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  terra_synchronize(terra_ctx *ctx);
+/* ---- options: every behaviour switch of the library (nothing in it reads the process environment).  Values are strings; an unknown key or a value outside the key's
+ * range is TERRA_ERR_ARG and changes nothing.  The call drains the context's stream first.  Only "gen.fused" changes a result.
+ *   "gen.fused"            "0" | "1"      every generator call of this context behaves as if TERRA_GEN_FUSED were given (tile batches and voxel fields have no flags argument)
+ *   "kernels.simple"       "0" | "1"      one-thread-per-cell cross-check kernels instead of the tiled ones (tests)
+ *   "graphs"               "0" | "1"      replay the erosion rounds as hipGraphs (default 1)
+ *   "sg.kc" "20"|"27"|"45", "sg.kc_tiles" "27"|"45", "sg.rowgroup" "1".."1024"      LDS chunking / tile walk of the exact sine kernel
+ *   "tile_erosion"         "lds" | "window"   the whole padded tile in LDS (default) or a 32 x 32 window over a copy in HBM
+ *   "weights.simple"       "0" | "1"      per-texel form of the weights-texture pass;   "shadows.levels" "0" | "1"   one launch per dependency level of the mesh shadows
+ *   "ero.sparse"           "0" | "1" | "auto"   never / always / by droplet density try the sparse erosion scheduler;   "ero.sparse_retraces" n
+ *   "ero.lead" "0".."2", "ero.batch" n, "ero.live" "0"|"1", "ero.diag" "0"|"1", "ero.ck" "steps:max"|"default", "ero.near" n|"default", "ero.mem_budget" bytes|"-1"
+ *                                          scheduling knobs of the multi-version erosion scheduler (terra_set_erosion_tuning has the documented ones) */
+int  terra_set_option(terra_ctx *ctx, const char *key, const char *value);
 /* ---- whole grids between host and device.  The reference's callers own HOST arrays (cached_vals of build_arrays, src/mesh_gen.cpp:597-603; apply_erosion's float*,
  * src/erosion.cpp:14; heightmap_t's pixels, src/heightmap.cpp:130-151), 1 GiB at 16384^2.  Every host-pointer entry point moves arrays of >= 16 MiB in 8 MiB bands on four
  * streams at once through pinned staging (csrc/terra_xfer.hpp); an array allocated with terra_host_alloc (pinned) is the DMA target itself, no staging copy.

@@ -454,8 +454,26 @@ static void gc_enable_glaciate(grid_cache_t *g) { /* src/mesh_gen.cpp:640-650 */
 }
 static void gc_free(grid_cache_t *g) {free(g->xyterms); free(g->sine_mag_terms); free(g->cached_vals); memset(g, 0, sizeof(*g));}
 
+/* The TOLERANCE mode of the product (TERRA_GEN_FUSED, include/terra.h) restated: eval_index's expression tree (src/mesh_gen.cpp:766-790) with every a*b + c -- the terms of
+ * the sum, the last step of apply_glaciate, the island term -- evaluated as ONE fused multiply-add, nothing else changed.  There is no reference for it (3DWorld's binary has
+ * no FMA): this restatement is what the HIP path must equal bit for bit, and the tests bound its distance to the exact function (pinned to the reference) by BASELINE's
+ * 1e-5 * zmax_est.  Sine mode, linear shape, no custom glaciate exponent, no volcano: the configurations the product has a fused kernel for (it falls back to exact otherwise). */
+static int g_fused = 0;
+void orc_set_fused(int on) {g_fused = on;}
 static float gc_eval_index(grid_cache_t const *g, unsigned x, unsigned y, int min_start_sin, int use_cache) { /* src/mesh_gen.cpp:754-792 */
 	float zval = 0.0f;
+	if (g_fused && g->gen_mode == ORC_MGEN_SINE && g->gen_shape == 0 && custom_glaciate_exp == 0.0f && !(hp.volcano_width > 0.0f && hp.volcano_height > 0.0f) && !((use_cache || g->gen_mode >= ORC_MGEN_SIMPLEX_GPU) && g->cached_vals)) {
+		float const *const xptr = g->xyterms + (size_t)x*F_TABLE_SIZE;
+		float const *const yptr = g->xyterms + g->yterms_start + (size_t)y*F_TABLE_SIZE;
+		int const start_ix = imax(start_eval_sin, min_start_sin);
+		for (int i = start_ix; i < F_TABLE_SIZE; ++i) {zval = fmaf(xptr[i], yptr[i], zval);}
+		apply_noise_shape_final(&zval, g->gen_shape); /* (the identity wherever the product uses its fused kernel) */
+		if (g->do_glaciate) {
+			if (GLACIATE) {float const relh = (zval + zmax_est)*zmax_est2_inv; zval = fmaf((relh*relh)*relh, zmax_est2, -zmax_est);}
+			if (hp.sine_mag > 0.0f) {zval = zval + fmaf(g->sine_mag_terms[x], g->sine_mag_terms[g->cur_nx + y], g->sine_offset);}
+		}
+		return zval;
+	}
 	if ((use_cache || g->gen_mode >= ORC_MGEN_SIMPLEX_GPU) && g->cached_vals) {
 		zval += g->cached_vals[(size_t)y*g->cur_nx + x];
 	}

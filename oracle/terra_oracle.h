@@ -63,6 +63,8 @@ float orc_sin_table(int i);
 int   orc_num_threads(void);
 void  orc_set_num_threads(int n);
 
+/* 1: gen_grid / tiles evaluate the product's TOLERANCE mode (terra_oracle.c: g_fused) instead of the reference's arithmetic; 0 (default): the reference's */
+void  orc_set_fused(int on);
 void  orc_gen_grid(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int min_start_sin, float *out);
 uint64_t orc_apply_erosion_trace(float *hmap, int xsize, int ysize, float min_zval, unsigned iters, uint32_t *cells, uint64_t cap, uint64_t *offsets);
 void  orc_gen_grid_ex(float x0, float y0, float dx, float dy, unsigned nx, unsigned ny, int glaciate, int cache_values, int force_sine_mode, int min_start_sin, int use_cache, float *out);

@@ -145,6 +145,8 @@ class Checker:
         f("set_zmax_est", None, [C.c_float])
         f("set_water_plane_z", None, [C.c_float])
         f("set_mode", None, [C.c_int, C.c_int])
+        if kind == "orc":
+            f("set_fused", None, [C.c_int])  # the product's TOLERANCE mode restated (oracle/terra_oracle.c: g_fused); the reference has no such mode
         f("set_start_eval_sin", None, [C.c_int])
         f("set_erode_amount", None, [C.c_float])
         f("get_ground_mesh", None, [C.c_void_p])
@@ -226,6 +228,7 @@ class Checker:
     def set_zmax_est(self, v): self._set_zmax_est(v)
     def set_water_plane_z(self, v): self._set_water_plane_z(v)
     def set_mode(self, mode, shape=0): self._set_mode(mode, shape)
+    def set_fused(self, on): self._set_fused(int(bool(on)))
     def set_start_eval_sin(self, v): self._set_start_eval_sin(v)
     def set_erode_amount(self, v): self._set_erode_amount(v)
     def set_use_hip_terrain(self, v): self._set_use_hip_terrain(int(v))

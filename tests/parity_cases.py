@@ -140,6 +140,7 @@ def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_ca
     if ck is not None:
         os.environ["TERRA_ERO_CK"] = ck       # "steps:max" -- checkpoint spacing of a trace: re-traces resume from checkpoints (copy / roll-back + undo log)
     try:
+        t.apply_env_options()  # (the library reads no environment: the binding turns the variables into terra_set_option calls)
         r, stats = case_erosion_vs_oracle(pkg, t, orc, n, iters, seed=seed)
     finally:
         for k, v in old.items():
@@ -147,6 +148,7 @@ def case_erosion_sliding_ring(pkg, t, orc, n, iters, window, slice_steps, blk_ca
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        t.apply_env_options()
         t.set_erosion_tuning(window=0xFFFFFFFF, block_list_capacity=256)
         t.set_erosion_slice_steps(128)  # the shipped default (spec_cfg_t::slice_steps): later tests on a shared context run the default scheduler
     assert r.windows == -(-iters // window)
@@ -165,6 +167,7 @@ def case_erosion_sparse(pkg, t, orc, n, iters, force="1", retraces=None, flags=0
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = str(v)
+        t.apply_env_options()
         r, stats = case_erosion_vs_oracle(pkg, t, orc, n, iters, flags=flags)
     finally:
         for k, v in old.items():
@@ -172,6 +175,7 @@ def case_erosion_sparse(pkg, t, orc, n, iters, force="1", retraces=None, flags=0
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        t.apply_env_options()
     assert r.sparse_droplets <= iters and r.traces >= iters
     return r, stats
 
@@ -183,6 +187,7 @@ def case_erosion_edge_sparse(pkg, t, orc):
     old = {k: os.environ.get(k) for k in ("TERRA_ERO_SPARSE", "TERRA_ERO_SPARSE_RETRACES")}
     os.environ["TERRA_ERO_SPARSE"] = "1"; os.environ["TERRA_ERO_SPARSE_RETRACES"] = "100000"
     try:
+        t.apply_env_options()
         case_erosion_edge(pkg, t, orc)
         r = t.erosion_report()
         pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
@@ -208,6 +213,7 @@ def case_erosion_edge_sparse(pkg, t, orc):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        t.apply_env_options()
 
 
 def case_erosion_context_reuse(pkg, t, orc):
