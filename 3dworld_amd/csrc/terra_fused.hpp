@@ -109,7 +109,8 @@ __device__ __forceinline__ void sgf_store_group(sgf_pending_t const &P, __amdgpu
 template<bool TILES> __global__ __launch_bounds__(256, 2) void k_sine_grid_mx(sgf_job_t const J) {
 	unsigned const lane = threadIdx.x & 63u, half = lane >> 5, c = lane & 31u;
 	unsigned const w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, and the compiler knows it
-	int const nk = SGF_TERMS_END - J.kstart, kbase = J.kstart - (nk & 1), npairs = (nk + 1) >> 1, last = npairs - 1;
+	// (no term at all, min_start_sin >= 90: the operand loads still run -- of the table's last pair, never multiplied)
+	int const nk = (J.kstart < SGF_TERMS_END) ? SGF_TERMS_END - J.kstart : 0, kbase = (nk > 0) ? J.kstart - (nk & 1) : SGF_TERMS_END - 2, npairs = (nk + 1) >> 1, last = (npairs > 0) ? npairs - 1 : 0;
 	uint32_t const sa = 8u*J.nyp, sb = 8u*J.nxp; // bytes per k pair
 	uint32_t const va0 = (half*J.nyp + c)*4u, va1 = va0 + 128u, vb0 = (half*J.nxp + c)*4u, vb1 = vb0 + 128u; // the lane's byte offsets into a table slice: the same for every tile
 	uint32_t const row_bytes = 4u*J.nx;

@@ -1360,3 +1360,100 @@ def case_streamed_pipeline(pkg, make_ctx, orc, N=768, maps=7, P=3, droplets=(400
         nctx.close()
         for c in ctxs:
             c.close()
+
+
+# ---- the TOLERANCE mode (TERRA_GEN_FUSED / option "gen.fused"; include/terra.h).  Two bars for every output:
+#   (1) bit-equal to the checker's restatement of the mode (orc.set_fused(1): the reference's expression tree with fmaf),
+#   (2) within BASELINE's 1e-5 * zmax_est of the REFERENCE's arithmetic (orc with fused off, pinned to the compiled reference TUs).
+FUSED_REL_TOL = 1e-5
+
+
+def fused_pair(orc, fn):
+    """fn() evaluated by the oracle twice: the reference's arithmetic, then the restated tolerance mode"""
+    exact = fn()
+    orc.set_fused(1)
+    try:
+        fz = fn()
+    finally:
+        orc.set_fused(0)
+    return exact, fz
+
+
+def case_fused_grids(pkg, t, orc, sizes=((260, 150), (129, 131), (1, 1), (64, 64), (1000, 517)), exact_bits=True):
+    """gen_grid with TERRA_GEN_FUSED on both sides of the `is there a fused kernel` decision: glaciate on / off, islands on / off, even / odd term counts
+    (mesh_freq_filter, min_start_sin), ragged sizes; a plateau configuration (no fused kernel: the exact values come back)"""
+    base = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 0, 0]
+    no_islands = list(base); no_islands[9] = 0.0
+    worst = 0.0
+    for kw, mss in ((dict(hmap=base), 0), (dict(hmap=base, mesh_freq_filter=1), 0), (dict(hmap=no_islands, mesh_freq_filter=3), 0), (dict(hmap=base, glaciate=0), 0),
+                    (dict(hmap=base), 7), (dict(hmap=base, mesh_freq_filter=1), 89), (dict(hmap=base), 90)):
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, **kw)
+        st = t.init_scene(pc_); orc.init(oc)
+        tol = FUSED_REL_TOL*float(st.zmax_est)
+        for (nx, ny) in sizes:
+            for glac in (1, 0):
+                print(f"fused grid {kw} {nx}x{ny} glaciate {glac} min_start_sin {mss}", flush=True)
+                exact, fz = fused_pair(orc, lambda: orc.gen_grid(-0.37*nx, 11.0 - ny, st.DX_VAL, st.DY_VAL, nx, ny, glac, 0, mss))
+                b = t.gen_grid(-0.37*nx, 11.0 - ny, st.DX_VAL, st.DY_VAL, nx, ny, (pkg.GEN_GLACIATE if glac else 0) | pkg.GEN_FUSED, mss)
+                if exact_bits:
+                    assert_bit_equal(fz, b, f"fused grid {kw} {nx}x{ny} glaciate {glac} min_start_sin {mss}")
+                d = float(np.abs(b.astype(np.float64) - exact).max())
+                assert d <= tol, (kw, nx, ny, glac, d, tol)
+                worst = max(worst, d/float(st.zmax_est))
+    # no fused kernel for this configuration (cells can leave the short tail): a permission, not a command -- the exact values
+    plat = list(base); plat[0], plat[1], plat[2], plat[3] = 0.1, 0.5, 2.0, 0.2
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, hmap=plat)
+    st = t.init_scene(pc_); orc.init(oc)
+    assert_bit_equal(orc.gen_grid(-50, -50, st.DX_VAL, st.DY_VAL, 100, 90, 1), t.gen_grid(-50, -50, st.DX_VAL, st.DY_VAL, 100, 90, pkg.GEN_GLACIATE | pkg.GEN_FUSED), "plateau: exact kernel")
+    return worst
+
+
+def case_fused_minmax_and_option(pkg, t, orc, n=300):
+    """the fused kernel's own {min, max} (terra_gen_grid_minmax_dev) and the context-wide switch terra_set_option("gen.fused")"""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0, mesh_freq_filter=1)
+    st = t.init_scene(pc_); orc.init(oc)
+    exact, fz = fused_pair(orc, lambda: orc.gen_grid(-n/2, 5.0, st.DX_VAL, st.DY_VAL, n, n - 9, 1))
+    buf = t.alloc(n*(n - 9)*4)
+    try:
+        mn, mx = t.gen_grid_minmax_dev(buf.ptr, -n/2, 5.0, st.DX_VAL, st.DY_VAL, n, n - 9, pkg.GEN_GLACIATE | pkg.GEN_FUSED)
+        assert_bit_equal(fz, buf.download(np.float32, (n - 9, n)), "fused grid (minmax call)")
+        assert (np.float32(mn), np.float32(mx)) == (fz.min(), fz.max())
+        t.set_option("gen.fused", "1")
+        try:
+            t.gen_grid_dev(buf.ptr, -n/2, 5.0, st.DX_VAL, st.DY_VAL, n, n - 9, pkg.GEN_GLACIATE)
+            assert_bit_equal(fz, buf.download(np.float32, (n - 9, n)), "option gen.fused = 1")
+        finally:
+            t.set_option("gen.fused", "0")
+        t.gen_grid_dev(buf.ptr, -n/2, 5.0, st.DX_VAL, st.DY_VAL, n, n - 9, pkg.GEN_GLACIATE)
+        assert_bit_equal(exact, buf.download(np.float32, (n - 9, n)), "option gen.fused = 0")
+    finally:
+        buf.free()
+    with pytest_raises(pkg.TerraError):
+        t.set_option("gen.fused", "2")
+    with pytest_raises(pkg.TerraError):
+        t.set_option("no.such.key", "1")
+
+
+def case_fused_tiles(pkg, t, orc, tiles=((0, 0), (-3, 7), (20, -31), (5, 5), (5, -2), (-32, -32), (6, 5), (6, -2))):
+    """tile_t::create_zvals under option "gen.fused": zvals bit-equal to the restated mode and within tolerance of the reference; the integer outputs (water bbox)
+    and the normal bytes are those of the reference's functions applied to the fused heights -> (boundary flips of the bbox vs the exact tiles, normal bytes that differ)"""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    st0 = t.init_scene(pc_); orc.init(oc)
+    tol = FUSED_REL_TOL*float(st0.zmax_est)
+    t.set_option("gen.fused", "1")
+    try:
+        z, st, nm, mnz = t.tiles_create_zvals(tiles, 0)
+    finally:
+        t.set_option("gen.fused", "0")
+    flips = nbytes = 0
+    for i, (tx, ty) in enumerate(tiles):
+        (zo, so), (zf, sf) = fused_pair(orc, lambda: orc.tile_create_zvals(tx, ty, 0))
+        assert_bit_equal(zf, z[i], f"fused tile ({tx},{ty}) zvals")
+        assert bytes(sf) == bytes(st[i]), f"fused tile ({tx},{ty}) stats"
+        nf, mf = orc.tile_normals(zf)
+        assert (nf == nm[i]).all() and np.float32(mf).view(np.uint32) == mnz[i].view(np.uint32)
+        assert float(np.abs(z[i].astype(np.float64) - zo).max()) <= tol
+        flips += int((so.wx1, so.wy1, so.wx2, so.wy2) != (sf.wx1, sf.wy1, sf.wx2, sf.wy2))
+        no, _ = orc.tile_normals(zo)
+        nbytes += int((no != nf).sum())
+    return flips, nbytes

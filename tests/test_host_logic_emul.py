@@ -342,3 +342,12 @@ def test_erosion_ring_is_capped_by_free_memory_and_scratch_can_be_released(pkg, 
         assert (z.view(np.uint32) == z2.view(np.uint32)).all()
     finally:
         t.close()
+
+
+def test_fused_tolerance_mode_host_logic(pkg, emul, orc):
+    """TERRA_GEN_FUSED / option "gen.fused" through the emulator (the per-cell form of the mode, sine_cell_fused): the flag plumbing, the `no fused kernel` fall-back,
+    the option switch, and both bars -- bit-equal to the restated mode, within 1e-5 * zmax_est of the reference's arithmetic"""
+    worst = pc.case_fused_grids(pkg, emul, orc, sizes=((260, 150), (1, 1), (64, 64)))
+    assert worst < 2e-6, worst
+    pc.case_fused_minmax_and_option(pkg, emul, orc, n=200)
+    pc.case_fused_tiles(pkg, emul, orc, tiles=((0, 0), (-3, 7), (5, 5)))
