@@ -1690,7 +1690,7 @@ template<class BE> struct terra_engine {
 				if (d == 0) {v *= rd.v[index2];}
 				d_tab[i] = v;
 			});
-			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize);
+			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize, opt.gen_fused != 0);
 		}
 		else {
 			float const l0 = lo[0], l1 = lo[1], l2 = lo[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2], o0 = off[0], o1 = off[1], o2 = off[2];

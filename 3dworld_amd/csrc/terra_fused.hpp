@@ -26,13 +26,14 @@ struct sgf_job_t {
 	float *out;
 	uint32_t *mm;            // order-preserving {min, ~max} words, or null
 	uint32_t nx, ny, nxp, nyp, ntx, nty, rowgroup;
-	int32_t kstart;          // first term; terms kstart .. 89
+	int32_t kstart, kend;    // terms kstart .. kend - 1 (rows of xt / yt)
 	int32_t glaciate, sine_mag;
 	float zmax_est, zmax_est2, zmax_est2_inv, sine_offset;
-	int32_t const *tile_map; uint32_t nux, tw; // TILES: scatter into the per-tile layout [tile][tw][tw]
+	int32_t const *tile_map; uint32_t nux, tw; // SGF_TILES: scatter into the per-tile layout [tile][tw][tw]
+	float zscale; int32_t normalize;           // SGF_VOXELS: the tail of voxel_manager::create_procedural (src/voxels.cpp:340-343)
 };
+enum {SGF_GRID = 0, SGF_TILES = 1, SGF_VOXELS = 2};
 
-constexpr int SGF_TERMS_END = 90; // F_TABLE_SIZE
 #ifndef SGF_STAGES_N
 #define SGF_STAGES_N 4
 #endif
@@ -106,11 +107,14 @@ __device__ __forceinline__ void sgf_store_group(sgf_pending_t const &P, __amdgpu
 		__builtin_amdgcn_sched_barrier(0); \
 	}
 
-template<bool TILES> __global__ __launch_bounds__(256, 2) void k_sine_grid_mx(sgf_job_t const J) {
+// KIND: SGF_GRID (a heightmap, row-major), SGF_TILES (a tile batch's virtual grid, scattered), SGF_VOXELS (noise_gen_3d's field: "rows" are the (x, y) columns with the
+// products xv*yv as their table, "columns" the z cells -- src/upsurface.cpp:60-70 is the same rank-k contraction with a different tail)
+template<int KIND> __global__ __launch_bounds__(256, 2) void k_sine_grid_mx(sgf_job_t const J) {
+	constexpr bool TILES = (KIND == SGF_TILES), VOX = (KIND == SGF_VOXELS);
 	unsigned const lane = threadIdx.x & 63u, half = lane >> 5, c = lane & 31u;
 	unsigned const w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, and the compiler knows it
 	// (no term at all, min_start_sin >= 90: the operand loads still run -- of the table's last pair, never multiplied)
-	int const nk = (J.kstart < SGF_TERMS_END) ? SGF_TERMS_END - J.kstart : 0, kbase = (nk > 0) ? J.kstart - (nk & 1) : SGF_TERMS_END - 2, npairs = (nk + 1) >> 1, last = (npairs > 0) ? npairs - 1 : 0;
+	int const nk = (J.kstart < J.kend) ? J.kend - J.kstart : 0, kbase = (nk > 0) ? J.kstart - (nk & 1) : J.kend - 2, npairs = (nk + 1) >> 1, last = (npairs > 0) ? npairs - 1 : 0;
 	uint32_t const sa = 8u*J.nyp, sb = 8u*J.nxp; // bytes per k pair
 	uint32_t const va0 = (half*J.nyp + c)*4u, va1 = va0 + 128u, vb0 = (half*J.nxp + c)*4u, vb1 = vb0 + 128u; // the lane's byte offsets into a table slice: the same for every tile
 	uint32_t const row_bytes = 4u*J.nx;
@@ -120,7 +124,17 @@ template<bool TILES> __global__ __launch_bounds__(256, 2) void k_sine_grid_mx(sg
 	bool const gl = J.glaciate != 0, sm = J.sine_mag != 0;
 	sgf_v2 const zme = {J.zmax_est, J.zmax_est}, inv = {J.zmax_est2_inv, J.zmax_est2_inv}, z2 = {J.zmax_est2, J.zmax_est2}, off = {J.sine_offset, J.sine_offset};
 	// eval_index's tail for the common configuration (src/mesh_gen.cpp:358-386,781-790), contraction allowed; two cells (rows r, r + 1 of a column) per instruction
+	sgf_v2 const zsc = {J.zscale, J.zscale};
+	bool const norm = J.normalize != 0;
 	auto const finish = [&](sgf_v2 z, sgf_v2 sx, sgf_v2 sy) -> sgf_v2 {
+		if (VOX) { // val += z*zscale; CLIP_TO_pm1 (std::min / std::max: a NaN becomes 1); sx = (float)z of the column
+			z = __builtin_elementwise_fma(sx, zsc, z);
+			if (norm) {
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {float const m = (z[e] < 1.0f) ? z[e] : 1.0f; z[e] = (-1.0f < m) ? m : -1.0f;}
+			}
+			return z;
+		}
 		if (gl) {sgf_v2 const rel = (z + zme)*inv; z = __builtin_elementwise_fma((rel*rel)*rel, z2, -zme);}
 		if (sm) {z = z + __builtin_elementwise_fma(sx, sy, off);}
 		return z;
@@ -194,7 +208,8 @@ template<bool TILES> __global__ __launch_bounds__(256, 2) void k_sine_grid_mx(sg
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {sy4[i][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);}
 		}
-		if (sm) { // the island terms of the wave's 2 x 32 columns and 64 rows (tables zero padded to the block grid)
+		if (VOX) {sxv[0] = (float)(cx0 + c); sxv[1] = (float)(cx0 + 32u + c);}
+		else if (sm) { // the island terms of the wave's 2 x 32 columns and 64 rows (tables zero padded to the block grid)
 			sxv[0] = J.smx[cx0 + c]; sxv[1] = J.smx[cx0 + 32u + c];
 #pragma unroll
 			for (int i = 0; i < 2; ++i) {

@@ -253,9 +253,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (job.fused) { // TERRA_GEN_FUSED: the sum on the f32 matrix pipe, persistent blocks (two per CU: 225 registers per lane)
 			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
 			J.xt = xt; J.yt = yt; J.smx = smx; J.smy = smy; J.out = out; J.mm = mm; J.nx = job.nx; J.ny = job.ny; J.nxp = job.nxp; J.nyp = job.nyp; J.ntx = ntx; J.nty = nty; J.rowgroup = sg_rowgroup;
-			J.kstart = job.kstart; J.glaciate = (job.glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (job.glaciate && job.use_sine_mag) ? 1 : 0;
+			J.kstart = job.kstart; J.kend = terra::F_TABLE_SIZE; J.glaciate = (job.glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (job.glaciate && job.use_sine_mag) ? 1 : 0;
 			J.zmax_est = nc.zmax_est; J.zmax_est2 = nc.zmax_est2; J.zmax_est2_inv = nc.zmax_est2_inv; J.sine_offset = job.sine_offset;
-			hipLaunchKernelGGL(terra::k_sine_grid_mx<false>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
+			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_GRID>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
 			TERRA_HIP_CHECK(hipGetLastError());
 			return true;
 		}
@@ -321,10 +321,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (fused && plain_only) { // "gen.fused": the batch's virtual grid on the matrix pipe, scattered into the per-tile layout
 			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
 			J.xt = xt; J.yt = yt; J.smx = d_sm; J.smy = d_sm + (size_t)nux*tw; J.out = zvals; J.mm = nullptr; J.nx = job.nx; J.ny = job.ny; J.nxp = job.nxp; J.nyp = job.nyp; J.ntx = ntx; J.nty = nty; J.rowgroup = sg_rowgroup;
-			J.kstart = kstart; J.glaciate = (glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (glaciate && use_sm) ? 1 : 0;
+			J.kstart = kstart; J.kend = terra::F_TABLE_SIZE; J.glaciate = (glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (glaciate && use_sm) ? 1 : 0;
 			J.zmax_est = nc.zmax_est; J.zmax_est2 = nc.zmax_est2; J.zmax_est2_inv = nc.zmax_est2_inv; J.sine_offset = so;
 			J.tile_map = tm; J.nux = nux; J.tw = tw;
-			hipLaunchKernelGGL(terra::k_sine_grid_mx<true>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
+			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_TILES>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
 		}
@@ -417,9 +417,37 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		}
 		quantize16_simple(vals + n8*8, n - n8*8, val_add, val_div, pix + n8*16); // the tail (or everything, unaligned / cross-check)
 	}
-	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {
-		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize); return;}
+	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, bool fused = false) {
+		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused); return;}
 		use();
+		if (fused && (uint64_t)nx*ny <= 0x7FFFFF80ull) { // "gen.fused": the field as a (columns x 60) x (60 x nz) product on the f32 matrix pipe (terra_fused.hpp)
+			size_t const ncol = (size_t)nx*ny;
+			uint32_t const nyp = (uint32_t)((ncol + 127)/128*128), nxp = (nz + 127)/128*128;
+			size_t const np = (size_t)terra::VOX_SINES*((size_t)nyp + nxp);
+			if (np*4 > vox_p_bytes) {if (vox_p) {sync(); (void)hipFree(vox_p);} TERRA_HIP_CHECK(hipMalloc((void **)&vox_p, np*4)); vox_p_bytes = np*4;}
+			float *const pt = vox_p, *const zt = vox_p + (size_t)terra::VOX_SINES*nyp;
+			// PT[k][column] = xv[x][k]*yv[y][k] (the product rounds as in the reference, src/upsurface.cpp:66; only the multiply-add with zv is fused), ZT[k][z]: both k-major, zero padded
+			launch(np, [=] TERRA_LAMBDA (size_t i) {
+				if (i < (size_t)terra::VOX_SINES*nyp) {
+					uint32_t const k = (uint32_t)(i / nyp); size_t const c = i % nyp;
+					float v = 0.0f;
+					if (c < ncol) {uint32_t const x = (uint32_t)(c % nx), y = (uint32_t)(c / nx); v = __fmul_rn(d_tab[(size_t)x*terra::VOX_SINES + k], d_tab[((size_t)nx + y)*terra::VOX_SINES + k]);}
+					pt[i] = v;
+				}
+				else {
+					size_t const j = i - (size_t)terra::VOX_SINES*nyp;
+					uint32_t const k = (uint32_t)(j / nxp), z = (uint32_t)(j % nxp);
+					zt[j] = (z < nz) ? d_tab[((size_t)nx + ny + z)*terra::VOX_SINES + k] : 0.0f;
+				}
+			});
+			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
+			J.xt = zt; J.yt = pt; J.out = out; J.nx = nz; J.ny = (uint32_t)ncol; J.nxp = nxp; J.nyp = nyp; J.ntx = nxp/128; J.nty = nyp/128; J.rowgroup = sg_rowgroup;
+			J.kstart = 0; J.kend = terra::VOX_SINES; J.zscale = zscale; J.normalize = normalize;
+			unsigned const nb = J.ntx*J.nty, grid = ((nb + 7)/8)*8;
+			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_VOXELS>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
+			TERRA_HIP_CHECK(hipGetLastError());
+			return;
+		}
 		size_t const ncol2 = ((size_t)nx*ny + 1) & ~(size_t)1, np = (ncol2/2)*terra::VX_PSTRIDE + (size_t)nz*terra::VOX_SINES, nprod = (ncol2 + nz)*terra::VOX_SINES; // column pairs + transposed z table
 		if (np*4 > vox_p_bytes) {if (vox_p) {sync(); (void)hipFree(vox_p);} TERRA_HIP_CHECK(hipMalloc((void **)&vox_p, np*4)); vox_p_bytes = np*4;}
 		hipLaunchKernelGGL(terra::k_voxel_P, dim3((unsigned)((nprod + 255)/256)), dim3(256), 0, stream, vox_p, vox_p + (ncol2/2)*terra::VX_PSTRIDE, nx, ny, nz, d_tab);

@@ -204,11 +204,19 @@ template<class DERIVED> struct simple_paths {
 		});
 	}
 	// voxel sine field: val = sum_k xv[k]*yv[k]*zv[k] (src/upsurface.cpp:60-70); d_tab = [nx + ny + nz][60]
-	void voxel_sines_simple(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize) {
+	// fused ("gen.fused"): (xv*yv) rounds as in the reference, its multiply-add with zv and the z term round once each (k_sine_grid_mx<SGF_VOXELS> is this, bit for bit)
+	void voxel_sines_simple(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, bool fused = false) {
 		self().launch((size_t)nx*ny*nz, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const z = (unsigned)(i % nz), x = (unsigned)((i / nz) % nx), y = (unsigned)(i / ((size_t)nz*nx));
 			float const *xv = d_tab + (size_t)x*VOX_SINES, *yv = d_tab + ((size_t)nx + y)*VOX_SINES, *zvp = d_tab + ((size_t)nx + ny + z)*VOX_SINES;
 			float val = 0.0f;
+			if (fused) {
+				for (unsigned k = 0; k < VOX_SINES; ++k) {val = fmaf(xv[k]*yv[k], zvp[k], val);}
+				val = fmaf((float)z, zscale, val);
+				if (normalize) {val = clip_pm1(val);}
+				out[i] = val;
+				return;
+			}
 			for (unsigned k = 0; k < VOX_SINES; ++k) {val += xv[k]*yv[k]*zvp[k];}
 			val += (float)z*zscale;
 			if (normalize) {val = clip_pm1(val);}

@@ -1645,7 +1645,8 @@ void orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float con
 				float val = 0.0f;
 				if (gen_mode == ORC_MGEN_SINE) { /* get_val, src/upsurface.cpp:60-70 */
 					float const *xv = xyz_vals[0] + (size_t)x*num_sines, *yv = xyz_vals[1] + (size_t)y*num_sines, *zv = xyz_vals[2] + (size_t)z*num_sines;
-					for (unsigned k = 0; k < num_sines; ++k) {val += xv[k]*yv[k]*zv[k];}
+					if (g_fused) {for (unsigned k = 0; k < num_sines; ++k) {val = fmaf(xv[k]*yv[k], zv[k], val);}} /* the product's TOLERANCE mode restated (see g_fused) */
+					else {for (unsigned k = 0; k < num_sines; ++k) {val += xv[k]*yv[k]*zv[k];}}
 				}
 				else {
 					float const px = ((float)x*vsz[0] + lo_pos[0]) + offset[0], py = ((float)y*vsz[1] + lo_pos[1]) + offset[1], pz = ((float)z*vsz[2] + lo_pos[2]) + offset[2];
@@ -1659,7 +1660,8 @@ void orc_voxel_fill(float *out, unsigned nx, unsigned ny, unsigned nz, float con
 						nfreq *= lacunarity;
 					}
 				}
-				val += (float)z*zscale;
+				if (g_fused && gen_mode == ORC_MGEN_SINE) {val = fmaf((float)z, zscale, val);}
+				else {val += (float)z*zscale;}
 				if (normalize_to_1) {val = clip_pm1(val);}
 				out[z + (x + (size_t)y*nx)*nz] = val;
 			}

@@ -1457,3 +1457,32 @@ def case_fused_tiles(pkg, t, orc, tiles=((0, 0), (-3, 7), (20, -31), (5, 5), (5,
         no, _ = orc.tile_normals(zo)
         nbytes += int((no != nf).sum())
     return flips, nbytes
+
+
+def case_fused_voxels(pkg, t, orc, shapes=((40, 24, 32), (7, 5, 200), (33, 31, 129), (1, 1, 1))):
+    """noise_gen_3d's sine field under option "gen.fused" (slabs included): bit-equal to the restated mode, within 1e-5 * max(|field|, mag) of the reference's arithmetic"""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc_); orc.init(oc)
+    worst = 0.0
+    for (nx, ny, nz) in shapes:
+        for (zscale, normalize, mag) in ((0.01, 1, 1.0), (-0.02, 0, 0.8)):
+            args = (nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], mag, 1.3, 7, 9, 0, zscale, normalize)
+            exact, fz = fused_pair(orc, lambda: orc.voxel_fill(*args))
+            t.set_option("gen.fused", "1")
+            try:
+                b = t.voxel_fill(*args)
+                if ny >= 4:
+                    buf = t.alloc(nx*ny*nz*4)
+                    y0, nys = ny//4, ny - ny//4 - 1
+                    t.voxel_fill_slab_dev(buf.ptr, *args[:13], y0, nys)
+                    slab = buf.download(np.float32, (nys, nx, nz)); buf.free()
+                    assert_bit_equal(fz[y0:y0 + nys], slab, f"fused voxel slab {nx, ny, nz}")
+            finally:
+                t.set_option("gen.fused", "0")
+            assert_bit_equal(fz, b, f"fused voxels {nx, ny, nz} zscale {zscale} normalize {normalize}")
+            tol = FUSED_REL_TOL*max(float(np.abs(exact).max()), mag)
+            d = float(np.abs(b.astype(np.float64) - exact).max())
+            assert d <= tol, (nx, ny, nz, d, tol)
+            worst = max(worst, d/max(float(np.abs(exact).max()), mag))
+    assert_bit_equal(orc.voxel_fill(*args), t.voxel_fill(*args), "option off again: the exact field")
+    return worst

@@ -29,6 +29,34 @@ def test_fused_tiles(pkg, gpu, orc):
     pc.case_fused_tiles(pkg, gpu, orc)
 
 
+def test_fused_voxels_small_and_slabs(pkg, gpu, orc):
+    worst = pc.case_fused_voxels(pkg, gpu, orc)
+    assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("nz", [64, 512])
+def test_fused_voxel_field_at_bench_size(pkg, gpu, orc, nz):
+    """BASELINE config 5 (512 x 512 x 64 of config_voxel_params.txt and the 512^3 showcase) in the tolerance mode: every voxel against both bars"""
+    from test_gpu_at_size import BENCH_VOX as B
+    VN = 512
+    gpu.init_scene(pkg.make_config(mesh_gen_mode=0)); orc.init(orclib.make_config(mesh_gen_mode=0))
+    vsz = (2.0 / VN, 2.0 / VN, 0.5 / VN)
+    args = (VN, VN, nz, B["lo"], vsz, B["off"], B["mag"], B["freq"], B["rs1"], B["rs2"], 0, B["zscale"], B["normalize"])
+    exact, fz = pc.fused_pair(orc, lambda: orc.voxel_fill(*args))
+    a = gpu.alloc(VN * VN * nz * 4)
+    gpu.set_option("gen.fused", "1")
+    try:
+        gpu.voxel_fill_dev(a.ptr, *args)
+    finally:
+        gpu.set_option("gen.fused", "0")
+    v = a.download(np.float32, (VN, VN, nz)); a.free()
+    diff = v.view(np.uint32) != fz.view(np.uint32)
+    assert not diff.any(), f"{int(diff.sum())} voxels differ from the restated mode, first at {np.argwhere(diff)[:3].tolist()}"
+    d = float(np.abs(v - exact).max())
+    assert d <= pc.FUSED_REL_TOL*max(float(np.abs(exact).max()), B["mag"]), d
+    assert int((v.view(np.uint32) != exact.view(np.uint32)).sum()) > v.size//10
+
+
 def test_fused_headline_grid_16384_every_cell(pkg, gpu, orc):
     """the whole 16384^2 headline grid (8 octaves, glaciate + islands) in the tolerance mode: every cell bit-equal to the restated mode and within 1e-5 * zmax_est of the
     reference's arithmetic; then the same 1000 droplets on both grids -- the count of ERODED cells beyond the tolerance decides whether the mode may feed the erosion"""

@@ -351,3 +351,4 @@ def test_fused_tolerance_mode_host_logic(pkg, emul, orc):
     assert worst < 2e-6, worst
     pc.case_fused_minmax_and_option(pkg, emul, orc, n=200)
     pc.case_fused_tiles(pkg, emul, orc, tiles=((0, 0), (-3, 7), (5, 5)))
+    pc.case_fused_voxels(pkg, emul, orc, shapes=((40, 24, 32), (7, 5, 50), (1, 1, 1)))
