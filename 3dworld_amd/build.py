@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libterra_hip.so")
-SOURCES = ["terra_hip.hip"]
+SOURCES = ["terra_hip.hip", "terra_fz.hip"]  # terra_fz.hip: the contraction-allowed build of the noise kernels (the tolerance mode)
 HEADERS = ["terra_multi.hpp", "terra_common.hpp", "terra_sincosf.hpp", "terra_powf.hpp", "terra_png.hpp", "terra_landscape.hpp", "terra_modmap.hpp", "terra_noise.hpp", "terra_erosion.hpp", "terra_driver.hpp", "terra_simple_paths.hpp", "terra_api_impl.hpp", "terra_kernels.hpp"]
 # -ffp-contract=off: the reference CPU path has no FMA; parity is bit-exact only without contraction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",

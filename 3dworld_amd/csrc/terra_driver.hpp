@@ -308,6 +308,22 @@ struct options_t {
 	}
 };
 
+// voxel_manager::create_procedural's lattice field (src/voxels.cpp:312-345): what one voxel needs
+struct vox_noise_job_t {float l0, l1, l2, v0, v1, v2, o0, o1, o2, frx, fry, mag, freq, zscale; int32_t nn, normalize; uint32_t nx, nz, y0;};
+TERRA_HD float voxel_noise_cell(size_t i, vox_noise_job_t const &J, bool perlin) {
+	unsigned const z = (unsigned)(i % J.nz), x = (unsigned)((i / J.nz) % J.nx), y = (unsigned)(i / ((size_t)J.nz*J.nx)) + J.y0;
+	float const px = ((float)x*J.v0 + J.l0) + J.o0, py = ((float)y*J.v1 + J.l1) + J.o1, pz = ((float)z*J.v2 + J.l2) + J.o2; // get_pt_at (src/voxels.h:146) + offset
+	float val = 0.0f, nmag = J.mag, nfreq = (float)(0.25*(double)J.freq);
+	for (int n = 0; n < J.nn; ++n) {
+		float const ax = nfreq*px + J.frx, ay = nfreq*py + J.fry, az = nfreq*pz + (J.frx - J.fry);
+		val += nmag*(perlin ? perlin3(ax, ay, az) : simplex3(ax, ay, az));
+		nmag *= 0.5f; nfreq *= 1.92f;
+	}
+	val += (float)z*J.zscale;
+	if (J.normalize) {val = clip_pm1(val);}
+	return val;
+}
+
 template<class BE> struct terra_engine {
 	BE be;
 	options_t opt;
@@ -585,7 +601,7 @@ template<class BE> struct terra_engine {
 		job.use_sine_mag = (job.glaciate && hp.sine_mag > 0.0f) ? 1 : 0;
 		job.sine_offset = hp.sine_bias*mesh_scale_z_inv;
 		job.plain_only = (job.mode == MGEN_SINE && sine_plain_only(job.shape, job.kstart)) ? 1 : 0;
-		job.fused = (((flags & TERRA_GEN_FUSED) || opt.gen_fused) && job.plain_only) ? 1 : 0; // a permission, not a command: configurations without a fused kernel get the exact one
+		job.fused = (((flags & TERRA_GEN_FUSED) || opt.gen_fused) && fused_kernel_exists(job.mode, job.plain_only != 0)) ? 1 : 0; // a permission, not a command
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
@@ -833,6 +849,10 @@ template<class BE> struct terra_engine {
 	static void check_erosion_iters(uint32_t num_iters) {if (num_iters > MAX_EROSION_ITERS) throw std::invalid_argument("apply_erosion: more than 27183336 droplets (the reference's int seed 79*iter+121 overflows)");}
 
 	uint32_t spec_batch_override() const {return (uint32_t)opt.ero_batch;} // "ero.batch": rounds per host read-back (0: automatic)
+	// TERRA_GEN_FUSED is honoured where a fused kernel meets BASELINE's 1e-5 * zmax_est: sine sums whose every cell takes the short tail (k_sine_grid_mx), simplex / Perlin fBm
+	// (terra_fz.hip).  NOT the domain warp (src/mesh_gen.cpp:734-751): its outer sum is sampled at positions the inner sums displace, so their last-bit differences come back
+	// multiplied by the outer field's slope -- measured 1.25e-5 * zmax_est on a 300 x 283 grid with contraction allowed throughout, for 1.12x.  It keeps the exact kernel.
+	static bool fused_kernel_exists(int mode, bool sine_plain_only_) {return (mode == MGEN_SINE) ? sine_plain_only_ : (mode != MGEN_DWARP_GPU);}
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 96, max_rounds = 4000000, near_count = 128;} spec_cfg;
 
 	// d_min (optional): min_zval is read from this DEVICE float when the final clamp runs (the only place apply_erosion uses it, src/erosion.cpp:158-162) -- the caller's
@@ -1237,7 +1257,7 @@ template<class BE> struct terra_engine {
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
 		bool const plain = md == MGEN_SINE && sine_plain_only(shp, kstart);
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, tw, unique_tiles, glac, d_noise_lut, opt.gen_fused && plain);
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, tw, unique_tiles, glac, d_noise_lut, opt.gen_fused && fused_kernel_exists(md, plain));
 		return d_refs;
 	}
 
@@ -1697,19 +1717,10 @@ template<class BE> struct terra_engine {
 			float const frx = rx, fry = ry;
 			int const nn = imax(1, 5 - cfg.mesh_freq_filter); // MAX_FREQ_BINS - mesh_freq_filter (src/voxels.cpp:332)
 			bool const perlin = (gen_mode == MGEN_PERLIN);
-			be.launch(nvox, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const z = (unsigned)(i % nz), x = (unsigned)((i / nz) % nx), y = (unsigned)(i / ((size_t)nz*nx)) + y0;
-				float const px = ((float)x*v0 + l0) + o0, py = ((float)y*v1 + l1) + o1, pz = ((float)z*v2 + l2) + o2; // get_pt_at (src/voxels.h:146) + offset
-				float val = 0.0f, nmag = mag, nfreq = (float)(0.25*(double)freq);
-				for (int n = 0; n < nn; ++n) {
-					float const ax = nfreq*px + frx, ay = nfreq*py + fry, az = nfreq*pz + (frx - fry);
-					val += nmag*(perlin ? perlin3(ax, ay, az) : simplex3(ax, ay, az));
-					nmag *= 0.5f; nfreq *= 1.92f;
-				}
-				val += (float)z*zscale;
-				if (normalize) {val = clip_pm1(val);}
-				d_out[i] = val;
-			});
+			vox_noise_job_t J;
+			J.l0 = l0; J.l1 = l1; J.l2 = l2; J.v0 = v0; J.v1 = v1; J.v2 = v2; J.o0 = o0; J.o1 = o1; J.o2 = o2; J.frx = frx; J.fry = fry; J.mag = mag; J.freq = freq; J.zscale = zscale;
+			J.nn = nn; J.normalize = normalize; J.nx = nx; J.nz = nz; J.y0 = y0;
+			be.voxel_noise(d_out, nvox, J, perlin, opt.gen_fused != 0);
 		}
 	}
 };

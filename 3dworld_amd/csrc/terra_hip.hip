@@ -4,6 +4,7 @@
 // (see 3dworld_amd/build.py).  There is no host execution path in this library: every entry point needs a HIP device.
 #include "terra_kernels.hpp"
 #include "terra_fused.hpp"
+#include "terra_fz_api.hpp"
 #include "terra_simple_paths.hpp"
 #include "terra_xfer.hpp"
 #include <stdlib.h>
@@ -271,6 +272,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *mm, uint32_t const *nlut) {
 		if (simple_kernels) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
 		use();
+		if (job.fused) {TERRA_HIP_CHECK((hipError_t)terra_fz_noise_grid(job.mode, &job, &nc, &L, smx, smy, out, mm, nlut, (void *)stream)); return true;} // TERRA_GEN_FUSED: the contraction-allowed build (terra_fz.hip)
 		dim3 const grid((job.nx + 127)/128, (job.ny + terra::NG_ROWS - 1)/terra::NG_ROWS), block(256); // 64 lanes x 2 cells per row segment, 4 rows at a time, NG_ROWS rows per block
 		terra::noise_oct_t const oc = terra::make_noise_oct(nc);
 		switch (job.mode) {
@@ -293,6 +295,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			terra::grid_job_t job;
 			job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = job.ny = tw; job.nxp = nxpv; job.nyp = nypv;
 			job.mode = md; job.shape = shp; job.kstart = kstart; job.glaciate = glaciate ? 1 : 0; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so; job.plain_only = 0;
+			if (fused) {TERRA_HIP_CHECK((hipError_t)terra_fz_noise_tiles(refs, n, nux, d_sm, d_m0, &job, &nc, &L, zvals, tw, nlut, (void *)stream)); return;} // "gen.fused"
 			terra::noise_oct_t const oc = terra::make_noise_oct(nc);
 			size_t const threads = (size_t)n*tw*((tw + 1)/2);
 			dim3 const grid((unsigned)((threads + 255)/256)), block(256);
@@ -416,6 +419,17 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			TERRA_HIP_CHECK(hipGetLastError());
 		}
 		quantize16_simple(vals + n8*8, n - n8*8, val_add, val_div, pix + n8*16); // the tail (or everything, unaligned / cross-check)
+	}
+	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool fused) {
+		if (simple_kernels) {voxel_noise_simple(out, nvox, J, perlin); return;}
+		if (nvox == 0) return;
+		use();
+		if ((nvox + 255)/256 > 0x7FFFFFFFull) throw std::invalid_argument("voxel_fill: grid too large");
+		if (fused) {TERRA_HIP_CHECK((hipError_t)terra_fz_voxel_noise(perlin ? 1 : 0, out, nvox, &J, (void *)stream)); return;} // "gen.fused": the contraction-allowed build
+		dim3 const grid((unsigned)((nvox + 255)/256)), block(256);
+		if (perlin) {hipLaunchKernelGGL(terra::k_voxel_noise<true>, grid, block, 0, stream, out, nvox, J);}
+		else        {hipLaunchKernelGGL(terra::k_voxel_noise<false>, grid, block, 0, stream, out, nvox, J);}
+		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, bool fused = false) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused); return;}

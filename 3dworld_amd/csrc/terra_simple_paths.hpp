@@ -203,6 +203,9 @@ template<class DERIVED> struct simple_paths {
 			if (have) {TERRA_ATOMIC_MIN(&d[0], f2ord(lo)); TERRA_ATOMIC_MIN(&d[1], ~f2ord(hi));} // max as min of the complement
 		});
 	}
+	void voxel_noise_simple(float *out, size_t nvox, vox_noise_job_t const &J, bool perlin) {
+		self().launch(nvox, [=] TERRA_LAMBDA (size_t i) {out[i] = voxel_noise_cell(i, J, perlin);});
+	}
 	// voxel sine field: val = sum_k xv[k]*yv[k]*zv[k] (src/upsurface.cpp:60-70); d_tab = [nx + ny + nz][60]
 	// fused ("gen.fused"): (xv*yv) rounds as in the reference, its multiply-add with zv and the z term round once each (k_sine_grid_mx<SGF_VOXELS> is this, bit for bit)
 	void voxel_sines_simple(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, bool fused = false) {

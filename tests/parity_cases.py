@@ -1486,3 +1486,50 @@ def case_fused_voxels(pkg, t, orc, shapes=((40, 24, 32), (7, 5, 200), (33, 31, 1
             worst = max(worst, d/max(float(np.abs(exact).max()), mag))
     assert_bit_equal(orc.voxel_fill(*args), t.voxel_fill(*args), "option off again: the exact field")
     return worst
+
+
+def case_fused_fbm(pkg, t, orc, mode, n, expect_active=False, shape=0):
+    """the per-cell fBm kernels in the tolerance mode (terra_fz.hip: the same source with contraction allowed): no restatement to pin bits to -- which a*b + c are fused is
+    the compiler's choice -- so ONE bar: every cell within 1e-5 * zmax_est of the reference's arithmetic.  Grid (ragged) + a tile batch.  -> worst |dz| / zmax_est"""
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode, mesh_gen_shape=shape)
+    st = t.init_scene(pc_); orc.init(oc)
+    tol = FUSED_REL_TOL*float(st.zmax_est)
+    exact = orc.gen_grid(-n/2, -n/2 + 3, st.DX_VAL, st.DY_VAL, n, n - 17, 1)
+    b = t.gen_grid(-n/2, -n/2 + 3, st.DX_VAL, st.DY_VAL, n, n - 17, pkg.GEN_GLACIATE | pkg.GEN_FUSED)
+    d = float(np.abs(b.astype(np.float64) - exact).max())
+    assert d <= tol, (mode, n, d, tol)
+    if mode == 4:  # the domain warp has no fused kernel (its inner sums' last bits come back multiplied by the outer field's slope: beyond the bar): the exact values
+        assert_bit_equal(exact, b, "domain warp under TERRA_GEN_FUSED: the exact kernel")
+    elif expect_active:
+        assert (b.view(np.uint32) != exact.view(np.uint32)).any(), "the tolerance mode did not change a single bit: is the contraction-allowed build in use?"
+    tiles = ((0, 0), (-3, 7), (20, -31))
+    t.set_option("gen.fused", "1")
+    try:
+        z, _, _, _ = t.tiles_create_zvals(tiles, 0)
+    finally:
+        t.set_option("gen.fused", "0")
+    for i, (tx, ty) in enumerate(tiles):
+        zo, _ = orc.tile_create_zvals(tx, ty, 0)
+        dt = float(np.abs(z[i].astype(np.float64) - zo).max())
+        assert dt <= tol, (mode, (tx, ty), dt, tol)
+        d = max(d, dt)
+    return d/float(st.zmax_est)
+
+
+def case_fused_voxel_fbm(pkg, t, orc, gen_mode, dims, expect_active=False):
+    pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+    t.init_scene(pc_); orc.init(oc)
+    nx, ny, nz = dims
+    args = (nx, ny, nz, VOX["lo"], VOX["vsz"], VOX["off"], 0.8, 1.3, 7, 9, gen_mode, -0.02, 0)
+    exact = orc.voxel_fill(*args)
+    t.set_option("gen.fused", "1")
+    try:
+        b = t.voxel_fill(*args)
+    finally:
+        t.set_option("gen.fused", "0")
+    tol = FUSED_REL_TOL*max(float(np.abs(exact).max()), 0.8)
+    d = float(np.abs(b.astype(np.float64) - exact).max())
+    assert d <= tol, (gen_mode, dims, d, tol)
+    if expect_active:
+        assert (b.view(np.uint32) != exact.view(np.uint32)).any()
+    return d/max(float(np.abs(exact).max()), 0.8)

@@ -57,6 +57,36 @@ def test_fused_voxel_field_at_bench_size(pkg, gpu, orc, nz):
     assert int((v.view(np.uint32) != exact.view(np.uint32)).sum()) > v.size//10
 
 
+@pytest.mark.parametrize("mode,shape", [(1, 0), (2, 0), (3, 0), (4, 0), (1, 2), (2, 1)])
+def test_fused_fbm_small(pkg, gpu, orc, mode, shape):
+    worst = pc.case_fused_fbm(pkg, gpu, orc, mode, 300, expect_active=True, shape=shape)
+    assert worst < 5e-6, worst
+
+
+@pytest.mark.parametrize("gen_mode", [1, 2])
+def test_fused_voxel_fbm(pkg, gpu, orc, gen_mode):
+    assert pc.case_fused_voxel_fbm(pkg, gpu, orc, gen_mode, (40, 24, 64), expect_active=True) < 5e-6
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_fbm_4096_every_cell(pkg, gpu, orc, mode):
+    """BASELINE config 2's size in the fBm modes with a fused kernel (simplex, Perlin; the domain warp keeps the exact one, see case_fused_fbm): all 4096^2 cells within 1e-5 * zmax_est"""
+    N = 4096
+    st = gpu.init_scene(pkg.make_config(mesh_gen_mode=mode)); orc.init(orclib.make_config(mesh_gen_mode=mode))
+    exact = orc.gen_grid(-N/2, -N/2, st.DX_VAL, st.DY_VAL, N, N, 1)
+    buf = gpu.alloc(N*N*4)
+    try:
+        gpu.gen_grid_dev(buf.ptr, -N/2, -N/2, st.DX_VAL, st.DY_VAL, N, N, pkg.GEN_GLACIATE | pkg.GEN_FUSED)
+        z = buf.download(np.float32, (N, N))
+    finally:
+        buf.free()
+    d = float(np.abs(z - exact).max())
+    assert d <= pc.FUSED_REL_TOL*float(st.zmax_est), (d, float(st.zmax_est))
+    changed = int((z.view(np.uint32) != exact.view(np.uint32)).sum())
+    assert changed > 0
+    print(f"\nfused fBm mode {mode} 4096^2: max |dz| {d/float(st.zmax_est):.3g} * zmax_est, {changed} of {N*N} cells round differently")
+
+
 def test_fused_headline_grid_16384_every_cell(pkg, gpu, orc):
     """the whole 16384^2 headline grid (8 octaves, glaciate + islands) in the tolerance mode: every cell bit-equal to the restated mode and within 1e-5 * zmax_est of the
     reference's arithmetic; then the same 1000 droplets on both grids -- the count of ERODED cells beyond the tolerance decides whether the mode may feed the erosion"""

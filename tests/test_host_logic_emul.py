@@ -352,3 +352,6 @@ def test_fused_tolerance_mode_host_logic(pkg, emul, orc):
     pc.case_fused_minmax_and_option(pkg, emul, orc, n=200)
     pc.case_fused_tiles(pkg, emul, orc, tiles=((0, 0), (-3, 7), (5, 5)))
     pc.case_fused_voxels(pkg, emul, orc, shapes=((40, 24, 32), (7, 5, 50), (1, 1, 1)))
+    for mode in (1, 2, 4):  # (the emulator's per-cell kernels have one build: the flag must reach them and change nothing)
+        assert pc.case_fused_fbm(pkg, emul, orc, mode, 96) == 0.0
+    assert pc.case_fused_voxel_fbm(pkg, emul, orc, 1, (12, 10, 16)) == 0.0
