@@ -8,7 +8,7 @@ include/terra_cxx.hpp.  There is no CPU fall-back: loading fails loudly when lib
 (The directory name starts with a digit, so import it with importlib: `terra = importlib.import_module("3dworld_amd")`.)
 """
 from .terra import (Terra, TerraMulti, DistributedGrid, TerraError, Config, State, TileStats, ErosionReport, Landscape, make_landscape, GRASS_BLOCK_DTYPE, BRUSH_DTYPE, MOD_DTYPE, make_config, default_lib_path,
-                    GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES, GEN_FUSED, ERODE_SERIAL, ERODE_MINZ_IS_MIN, ERODE_SERIAL_WAVE,
+                    GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES, GEN_FUSED, GEN_FAST, ERODE_SERIAL, ERODE_MINZ_IS_MIN, ERODE_SERIAL_WAVE,
                     MGEN_SINE, MGEN_SIMPLEX, MGEN_PERLIN, MGEN_SIMPLEX_GPU, MGEN_DWARP_GPU)
 from .build import build_library
 

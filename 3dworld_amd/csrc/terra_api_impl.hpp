@@ -142,9 +142,9 @@ int terra_gen_build_arrays(terra_gen *g, float x0, float y0, float dx, float dy,
 		std::lock_guard<std::mutex> lock(g->mtx);
 		std::lock_guard<std::recursive_mutex> eng_lock(g->ctx->eng_mtx);
 		bool const no_wait = (flags & TERRA_GEN_NO_WAIT) != 0;
-		uint32_t const key = flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE);
+		uint32_t const key = flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE | TERRA_GEN_FUSED | TERRA_GEN_FAST);
 		int const sev = g->ctx->eng.start_eval_sin, kstart = terra::imax(sev, min_start_sin);
-		bool const same = g->built && g->x0 == x0 && g->y0 == y0 && g->dx == dx && g->dy == dy && g->nx == nx && g->ny == ny && (g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE)) == key && g->kstart == kstart;
+		bool const same = g->built && g->x0 == x0 && g->y0 == y0 && g->dx == dx && g->dy == dy && g->nx == nx && g->ny == ny && (g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE | TERRA_GEN_FUSED | TERRA_GEN_FAST)) == key && g->kstart == kstart;
 		bool const was_running = g->running && same;
 		if (!was_running) { // launch the job (run_gpu_simplex, src/mesh_gen.cpp:652-681)
 			size_t const count = (size_t)nx*ny;
@@ -214,7 +214,7 @@ float terra_gen_eval_index(terra_gen *g, uint32_t x, uint32_t y, int min_start_s
 			float *d = (float *)be.alloc(count*sizeof(float));
 			std::vector<float> tmp(count);
 			try {
-				g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE), want, d); // first term = max(start_eval_sin, want)
+				g->ctx->eng.gen_grid_dev(g->x0, g->y0, g->dx, g->dy, g->nx, g->ny, g->flags & (TERRA_GEN_GLACIATE | TERRA_GEN_FORCE_SINE | TERRA_GEN_FUSED | TERRA_GEN_FAST), want, d); // first term = max(start_eval_sin, want)
 				be.d2h(tmp.data(), d, count*sizeof(float));
 			} catch (...) {be.free(d); g->alt_vals.erase(want); throw;}
 			be.free(d);

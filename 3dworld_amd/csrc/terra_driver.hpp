@@ -33,7 +33,8 @@ struct grid_job_t { // one build_arrays() + eval loop
 	int mode, shape, kstart, glaciate, use_sine_mag;
 	float sine_offset;
 	int plain_only; // sine mode: no cell can leave the short epilogue (see terra_engine::sine_plain_only): the kernel variant without finish_cell() is exact
-	int fused = 0; // TERRA_GEN_FUSED (tolerance mode; sine mode with plain_only): every multiply-add of the sum and of the tail rounds once (sine_cell_fused / finish_cell_fused)
+	int fused = 0; // TERRA_GEN_FUSED (tolerance mode; sine mode with plain_only): every multiply-add of the sum and of the tail rounds once (sine_cell_fused / finish_cell_fused); 2 = TERRA_GEN_FAST
+	float fast_amax = 0.0f; // TERRA_GEN_FAST: the largest |value| the y table can hold (its power-of-two scale on the half-precision matrix pipe, terra_fused.hpp)
 	uint32_t row0 = 0; // the job covers rows [row0, row0 + ny) of a taller grid (row strips of one heightmap on several GPUs): cell row y is eval_index's y + row0
 };
 
@@ -261,7 +262,7 @@ TERRA_HD void tile_normal(float const *z, unsigned x, unsigned y, float dxv, flo
 // ---- terra_set_option (include/terra.h): every behaviour switch of the library in one place.  Nothing in the library reads the process environment; tests and tools
 // translate their TERRA_* variables into these calls (3dworld_amd/terra.py: options_from_env).  Except "gen.fused", no option changes a result.
 struct options_t {
-	int gen_fused = 0;            // "gen.fused" 0 / 1: every generator call behaves as if TERRA_GEN_FUSED were given (the calls without a flags argument: tiles, voxels)
+	int gen_fused = 0;            // "gen.fused" 0 / 1 / 2: every generator call behaves as if TERRA_GEN_FUSED (1) / TERRA_GEN_FAST (2) were given (the calls without a flags argument: tiles, voxels)
 	int ero_lead = 2;             // "ero.lead" 0..2: where a recentred droplet window lies (a cache placement)
 	int ero_batch = 0;            // "ero.batch" >= 1: rounds per host read-back of the multi-version scheduler (0: automatic)
 	int ero_sparse = -1;          // "ero.sparse" 0 / 1: never / always try the sparse scheduler (-1 = "auto": by droplet density)
@@ -286,7 +287,7 @@ struct options_t {
 		long long const n = strtoll(value, &end, 10);
 		bool const is_int = (end != value && *end == '\0');
 		auto const flag = [&](int &dst) {if (!is_int || (n != 0 && n != 1)) return false; dst = (int)n; return true;};
-		if (k == "gen.fused") return flag(gen_fused);
+		if (k == "gen.fused") {if (!is_int || n < 0 || n > 2) return false; gen_fused = (int)n; return true;}
 		if (k == "ero.lead") {if (!is_int || n < 0 || n > 2) return false; ero_lead = (int)n; return true;}
 		if (k == "ero.batch") {if (!is_int || n < 0 || n > (1 << 20)) return false; ero_batch = (int)n; return true;}
 		if (k == "ero.sparse") {if (v == "auto") {ero_sparse = -1; return true;} return flag(ero_sparse);}
@@ -601,7 +602,8 @@ template<class BE> struct terra_engine {
 		job.use_sine_mag = (job.glaciate && hp.sine_mag > 0.0f) ? 1 : 0;
 		job.sine_offset = hp.sine_bias*mesh_scale_z_inv;
 		job.plain_only = (job.mode == MGEN_SINE && sine_plain_only(job.shape, job.kstart)) ? 1 : 0;
-		job.fused = (((flags & TERRA_GEN_FUSED) || opt.gen_fused) && fused_kernel_exists(job.mode, job.plain_only != 0)) ? 1 : 0; // a permission, not a command
+		job.fused = (((flags & (TERRA_GEN_FUSED | TERRA_GEN_FAST)) || opt.gen_fused) && fused_kernel_exists(job.mode, job.plain_only != 0)) ? (((flags & TERRA_GEN_FAST) || opt.gen_fused == 2) ? 2 : 1) : 0; // a permission, not a command
+		job.fast_amax = sine_amp_max(job.kstart);
 		noise_consts_t const nc = consts();
 		sin_lut_t const L = lut();
 		float *smx = scratch<float>(s_smx, job.nxp), *smy = scratch<float>(s_smy, job.nyp);
@@ -852,6 +854,11 @@ template<class BE> struct terra_engine {
 	// TERRA_GEN_FUSED is honoured where a fused kernel meets BASELINE's 1e-5 * zmax_est: sine sums whose every cell takes the short tail (k_sine_grid_mx), simplex / Perlin fBm
 	// (terra_fz.hip).  NOT the domain warp (src/mesh_gen.cpp:734-751): its outer sum is sampled at positions the inner sums displace, so their last-bit differences come back
 	// multiplied by the outer field's slope -- measured 1.25e-5 * zmax_est on a 300 x 283 grid with contraction allowed throughout, for 1.12x.  It keeps the exact kernel.
+	float sine_amp_max(int kstart) const { // max_k |y_scale| of build_arrays (src/mesh_gen.cpp:611): bounds the y table of the sine sum
+		float m = 0.0f;
+		for (int k = imax(kstart, 0); k < F_TABLE_SIZE; ++k) {float const a = fabsf(mesh_scale_z_inv*sinTable[k][0]); if (a > m) {m = a;}}
+		return m;
+	}
 	static bool fused_kernel_exists(int mode, bool sine_plain_only_) {return (mode == MGEN_SINE) ? sine_plain_only_ : (mode != MGEN_DWARP_GPU);}
 	struct spec_cfg_t {uint32_t window = 0 /* auto */, maxb = 256, bshift = 3, slice_steps = 96, max_rounds = 4000000, near_count = 128;} spec_cfg;
 
@@ -1257,7 +1264,7 @@ template<class BE> struct terra_engine {
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
 		bool const plain = md == MGEN_SINE && sine_plain_only(shp, kstart);
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, tw, unique_tiles, glac, d_noise_lut, opt.gen_fused && fused_kernel_exists(md, plain));
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, tw, unique_tiles, glac, d_noise_lut, fused_kernel_exists(md, plain) ? opt.gen_fused : 0, sine_amp_max(kstart));
 		return d_refs;
 	}
 
@@ -1699,7 +1706,12 @@ template<class BE> struct terra_engine {
 				float const step = (d == 0) ? v0 : ((d == 1) ? v1 : v2);
 				uint32_t const cnt = (d == 0) ? nx : ((d == 1) ? ny : nz);
 				float *o = d_pos + ((d == 0) ? (size_t)0 : ((d == 1) ? (size_t)nx : (size_t)nx + ny));
-				for (uint32_t i = 0; i < cnt; ++i) {o[i] = val; val += step;}
+				uint32_t i = 0;
+				for (; i + 8 <= cnt; i += 8) { // (the chain of adds is the work: eight per trip of the loop instead of one -- 17 us -> a few for a 512-cell axis)
+#pragma unroll
+					for (uint32_t e = 0; e < 8; ++e) {o[i + e] = val; val += step;}
+				}
+				for (; i < cnt; ++i) {o[i] = val; val += step;}
 			});
 			be.launch(ntab, [=] TERRA_LAMBDA (size_t i) {
 				size_t const e = i / VOX_SINES; unsigned const k = (unsigned)(i % VOX_SINES);
@@ -1710,7 +1722,9 @@ template<class BE> struct terra_engine {
 				if (d == 0) {v *= rd.v[index2];}
 				d_tab[i] = v;
 			});
-			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize, opt.gen_fused != 0);
+			float amax = 0.0f; // the largest magnitude p[0] of gen_sines: bounds xv (and xv*yv)
+			for (unsigned k = 0; k < VOX_SINES; ++k) {float const a = fabsf(rd.v[VOX_PARAMS*k]); if (a > amax) {amax = a;}}
+			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize, opt.gen_fused, amax);
 		}
 		else {
 			float const l0 = lo[0], l1 = lo[1], l2 = lo[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2], o0 = off[0], o1 = off[1], o2 = off[2];

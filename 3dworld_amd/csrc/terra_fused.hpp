@@ -31,6 +31,7 @@ struct sgf_job_t {
 	float zmax_est, zmax_est2, zmax_est2_inv, sine_offset;
 	int32_t const *tile_map; uint32_t nux, tw; // SGF_TILES: scatter into the per-tile layout [tile][tw][tw]
 	float zscale; int32_t normalize;           // SGF_VOXELS: the tail of voxel_manager::create_procedural (src/voxels.cpp:340-343)
+	void const *xh, *yh; uint32_t nchunks; float unscale; // k_sine_grid_h3: the split half-precision tables [chunk][row][16] and 1 / (their scale factors)
 };
 enum {SGF_GRID = 0, SGF_TILES = 1, SGF_VOXELS = 2};
 
@@ -308,5 +309,211 @@ template<int KIND> __global__ __launch_bounds__(256, 2) void k_sine_grid_mx(sgf_
 #undef TERRA_SGF_LOAD4
 #undef TERRA_SGF_MFMA4
 #undef TERRA_SGF_MFMA4_
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------------------
+// k_sine_grid_h3 -- the same contraction on the HALF-precision matrix pipe (TERRA_GEN_FAST): 16 times the f32 pipe's rate, so the kernel is bound by writing its result.
+//
+// A table value t (scaled by a power of two so that the table's largest magnitude sits near 2^14) is split into two halves, t = h + l with h = half(t), l = half(t - h): 22
+// significant bits, |t - h - l| <= 2^-22 |t| (or 2^-25 absolute in the scaled unit for tiny values: the half format's subnormal step).  A term x*y becomes the three products
+// xh*yh + xh*yl + xl*yh (xl*yl <= 2^-22 |x y| is dropped): each is EXACT in fp32 (11 x 11 bits), the matrix instruction adds them into an fp32 accumulator.  So one k of the
+// reference's sum is three k of v_mfma_f32_32x32x16_f16 -- [yh yl yh] on the row side against [xh xh xl] on the column side -- and 80 terms are 15 instructions per 32 x 32
+// cells instead of 40 of the f32 form at a quarter of their rate each.  The error per term is <= 3 * 2^-22 |x y| plus the accumulator's roundings: the result is within
+// 1e-5 * zmax_est of the reference (BASELINE's bar; the tests measure ~1e-6, the same as the fused-multiply-add chain of k_sine_grid_mx) but it is NOT the value of any simple
+// restatement -- how the instruction rounds its 16-product sum is the hardware's business -- so this form is tested against the tolerance only.
+//
+// Tables (k_split_table below): chunk-major [chunk][row][16 halves], a chunk = 16 consecutive k of the tripled sum = 32 bytes per row: lane l of a wave reads the 16 bytes
+// (row l & 31, halves 8 (l >> 5) .. + 7) -- a wave's operand load is ONE contiguous kilobyte.  Which k a lane half holds is the same on both sides, so the sum is complete
+// whatever the instruction's internal k order.  4 operand loads (4 KB) per 4 instructions (128 matrix cycles) per wave: the L2 supplies that at about half of the matrix
+// pipe's rate, which is still twice what the result's stores allow.  Blocks of 4 waves x (64 x 64) cells as in k_sine_grid_mx, one tile per block (the tiles of a CU's
+// resident blocks are in different phases by themselves: three to four waves per SIMD fit).
+typedef _Float16 sgh_h8 __attribute__((ext_vector_type(8)));
+typedef uint32_t sgh_u4 __attribute__((ext_vector_type(4)));
+
+// T: f32 table, k-major [k][np] (zero padded rows); H: [chunk][np][16] halves.  Tripled index q = 3 (k - kstart) + j; ROWSIDE: pieces (h, l, h), else (h, h, l).  One thread
+// per (chunk, row): 32 bytes out.
+template<bool ROWSIDE> __global__ __launch_bounds__(256) void k_split_table(float const *__restrict__ T, uint32_t np, int32_t kstart, int32_t kend, uint32_t nchunks, float scale, sgh_u4 *__restrict__ H) {
+	size_t const i = (size_t)blockIdx.x*256 + threadIdx.x;
+	if (i >= (size_t)nchunks*np) return;
+	uint32_t const chunk = (uint32_t)(i / np), row = (uint32_t)(i % np);
+	_Float16 v[16];
+#pragma unroll
+	for (int e = 0; e < 16; ++e) {
+		int const q = (int)chunk*16 + e, k = kstart + q/3, j = q % 3;
+		float t = 0.0f;
+		if (k < kend) {t = T[(size_t)k*np + row]*scale;}
+		_Float16 const h = (_Float16)t, l = (_Float16)(t - (float)h);
+		v[e] = ((ROWSIDE ? (j == 1) : (j == 2)) ? l : h);
+	}
+	sgh_u4 o[2];
+	__builtin_memcpy(o, v, 32);
+	H[2*i] = o[0]; H[2*i + 1] = o[1];
+}
+
+// the voxel field's tables split straight from noise_gen_3d's [entry][NS] sine table (entries: nx x values, then ny y values, then nz z values; src/upsurface.cpp:41-57),
+// no f32 copy in between.  ROWSIDE: a row is an (x, y) column, its value the product xv[x][k]*yv[y][k], rounded as the reference rounds it; else a row is a z cell.
+// One thread per ROW: its NS values are read once (neighbouring threads read neighbouring table rows) and leave as ceil(3 NS / 16) 32-byte pieces, one per chunk plane --
+// a wave writes 2 KB runs.  (One thread per (chunk, row) re-read the table rows through 240-byte strides: 88 us for the 512^2 columns of a field instead of 30.)
+template<bool ROWSIDE, int NS> __global__ __launch_bounds__(256) void k_split_voxel_table(float const *__restrict__ tab, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t np, float scale, sgh_u4 *__restrict__ H) {
+	size_t const row = (size_t)blockIdx.x*256 + threadIdx.x;
+	if (row >= np) return;
+	bool const live = ROWSIDE ? (row < (size_t)nx*ny) : (row < nz);
+	float t[NS];
+	if (live) {
+		float const *pa = ROWSIDE ? tab + (row % nx)*NS : tab + ((size_t)nx + ny + row)*NS, *pb = ROWSIDE ? tab + ((size_t)nx + row / nx)*NS : pa;
+#pragma unroll
+		for (int k = 0; k < NS; ++k) {t[k] = ROWSIDE ? __fmul_rn(pa[k], pb[k])*scale : pa[k]*scale;}
+	}
+	else {
+#pragma unroll
+		for (int k = 0; k < NS; ++k) {t[k] = 0.0f;}
+	}
+	constexpr int NCHUNKS = (3*NS + 15)/16;
+#pragma unroll
+	for (int chunk = 0; chunk < NCHUNKS; ++chunk) {
+		_Float16 v[16];
+#pragma unroll
+		for (int e = 0; e < 16; ++e) {
+			int const q = chunk*16 + e, k = q/3, j = q % 3;
+			float const tk = (k < NS) ? t[(k < NS) ? k : 0] : 0.0f;
+			_Float16 const h = (_Float16)tk, l = (_Float16)(tk - (float)h);
+			v[e] = ((ROWSIDE ? (j == 1) : (j == 2)) ? l : h);
+		}
+		sgh_u4 o[2];
+		__builtin_memcpy(o, v, 32);
+		size_t const i = (size_t)chunk*np + row;
+		H[2*i] = o[0]; H[2*i + 1] = o[1];
+	}
+}
+
+__device__ __forceinline__ sgh_h8 sgh_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {return __builtin_bit_cast(sgh_h8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));}
+
+template<int KIND> __global__ __launch_bounds__(256, 2) void k_sine_grid_h3(sgf_job_t const J) {
+	constexpr bool TILES = (KIND == SGF_TILES), VOX = (KIND == SGF_VOXELS);
+	unsigned const lane = threadIdx.x & 63u, half = lane >> 5, c = lane & 31u;
+	unsigned const w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	unsigned bxi = 0, byi = 0;
+	if (!sgf_tile_of_block(blockIdx.x, J.ntx, J.nty, J.rowgroup, bxi, byi)) return; // (block-uniform)
+	unsigned const x0 = bxi*128u + (w & 1u)*64u, y0 = byi*128u + (w >> 1)*64u;
+	__amdgpu_buffer_rsrc_t const ra = sgf_rsrc((char const *)J.yh + (size_t)y0*32u), rb = sgf_rsrc((char const *)J.xh + (size_t)x0*32u);
+	uint32_t const v0 = c*32u + half*16u, v1 = v0 + 1024u; // the lane's bytes in a chunk: rows c and 32 + c
+	uint32_t const sa = J.nyp*32u, sb = J.nxp*32u;         // bytes per chunk
+	int const n = (int)J.nchunks;
+	sgf_v16 acc[2][2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+#pragma unroll
+			for (int v = 0; v < 16; ++v) {acc[i][j][v] = 0.0f;}
+		}
+	}
+	sgh_h8 a0[2], a1[2], b0[2], b1[2];
+#define TERRA_SGH_LOAD(S, Q) {uint32_t const q_ = (uint32_t)(Q); a0[S] = sgh_ld(ra, v0, q_*sa); a1[S] = sgh_ld(ra, v1, q_*sa); b0[S] = sgh_ld(rb, v0, q_*sb); b1[S] = sgh_ld(rb, v1, q_*sb);}
+#define TERRA_SGH_MFMA(S) \
+	acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[S], b0[S], acc[0][0], 0, 0, 0); \
+	acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[S], b1[S], acc[0][1], 0, 0, 0); \
+	acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b0[S], acc[1][0], 0, 0, 0); \
+	acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S], acc[1][1], 0, 0, 0);
+	if (n > 0) {
+		TERRA_SGH_LOAD(0, 0)
+		int q = 0;
+		for (; q + 2 <= n; q += 2) { // two register sets: a chunk's operands arrive while the previous chunk is multiplied (reads past the last chunk repeat it, never multiplied)
+			TERRA_SGH_LOAD(1, q + 1)
+			TERRA_SGH_MFMA(0)
+			TERRA_SGH_LOAD(0, (q + 2 < n) ? q + 2 : n - 1)
+			TERRA_SGH_MFMA(1)
+		}
+		if (q < n) {TERRA_SGH_MFMA(0)}
+	}
+#undef TERRA_SGH_MFMA
+#undef TERRA_SGH_LOAD
+	// ---- the tail of the cell (as k_sine_grid_mx) and the stores: accumulator register v of tile (i, j) is the cell (row 32 i + 8 (v >> 2) + 4 half + (v & 3), column 32 j + c)
+	bool const gl = J.glaciate != 0, sm = J.sine_mag != 0, norm = J.normalize != 0;
+	sgf_v2 const us = {J.unscale, J.unscale}, zme = {J.zmax_est, J.zmax_est}, inv = {J.zmax_est2_inv, J.zmax_est2_inv}, z2 = {J.zmax_est2, J.zmax_est2}, off = {J.sine_offset, J.sine_offset}, zsc = {J.zscale, J.zscale};
+	// two cells (rows r, r + 1 of a column) per instruction; the tail itself is k_sine_grid_mx's (every a*b + c rounds once)
+	auto const finish = [&](sgf_v2 z, sgf_v2 sx, sgf_v2 sy) -> sgf_v2 {
+		z = z*us; // (a power of two: exact)
+		if (VOX) {
+			z = __builtin_elementwise_fma(sx, zsc, z);
+			if (norm) {
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {float const m = (z[e] < 1.0f) ? z[e] : 1.0f; z[e] = (-1.0f < m) ? m : -1.0f;}
+			}
+			return z;
+		}
+		if (gl) {sgf_v2 const rel = (z + zme)*inv; z = __builtin_elementwise_fma((rel*rel)*rel, z2, -zme);}
+		if (sm) {z = z + __builtin_elementwise_fma(sx, sy, off);}
+		return z;
+	};
+	float sxv[2] = {0.0f, 0.0f};
+	if (VOX) {sxv[0] = (float)(x0 + c); sxv[1] = (float)(x0 + 32u + c);}
+	else if (sm) {sxv[0] = J.smx[x0 + c]; sxv[1] = J.smx[x0 + 32u + c];}
+	float fmn = INFINITY, fmx = -INFINITY;
+	bool const inside = (x0 + 64u <= J.nx) && (y0 + 64u <= J.ny); // wave-uniform
+	unsigned t_ux[2] = {0, 0}, t_cx[2] = {0, 0};
+	if (TILES) {
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {unsigned const x = x0 + 32u*j + c; t_ux[j] = x/J.tw; t_cx[j] = x - t_ux[j]*J.tw;}
+	}
+	// a tile inside a row-major grid: buffer stores -- the lane's byte offset never changes, the row is the scalar offset: no vector address arithmetic at all
+	uint32_t const row_bytes = 4u*J.nx;
+	__amdgpu_buffer_rsrc_t const ro = sgf_rsrc(J.out + (TILES ? (size_t)0 : (size_t)y0*J.nx + x0));
+	uint32_t const vo[2] = {4u*half*row_bytes + 4u*c, 4u*half*row_bytes + 4u*c + 128u};
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			unsigned const yq = y0 + 32u*i + 8u*q + 4u*half;
+			float4 sy4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (!VOX && sm) {sy4 = *(float4 const *)(J.smy + yq);}
+			sgf_v2 const sy01 = {sy4.x, sy4.y}, sy23 = {sy4.z, sy4.w};
+			unsigned uy = 0, cy = 0;
+			if (TILES) {uy = yq/J.tw; cy = yq - uy*J.tw;}
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+				sgf_v2 const sx = {sxv[j], sxv[j]};
+				sgf_v2 const z01 = finish(sgf_v2{acc[i][j][4*q], acc[i][j][4*q + 1]}, sx, sy01), z23 = finish(sgf_v2{acc[i][j][4*q + 2], acc[i][j][4*q + 3]}, sx, sy23);
+				float const zr[4] = {z01.x, z01.y, z23.x, z23.y};
+				if (!TILES && inside) {
+					fmn = sgf_min3(sgf_min3(fmn, zr[0], zr[1]), zr[2], zr[3]); fmx = sgf_max3(sgf_max3(fmx, zr[0], zr[1]), zr[2], zr[3]); // (NaNs are skipped, as min_eq / max_eq never let one win)
+					uint32_t const so = (uint32_t)(32*i + 8*q)*row_bytes;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zr[r]), ro, vo[j], so + (uint32_t)r*row_bytes, 2);}
+				}
+				else { // border tiles and the per-tile layout
+					unsigned const x = x0 + 32u*j + c;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						unsigned const y = yq + (unsigned)r;
+						if (x < J.nx && y < J.ny) {
+							fmn = fminf(fmn, zr[r]); fmx = fmaxf(fmx, zr[r]);
+							if (TILES) {
+								unsigned uyr = uy, cyr = cy + (unsigned)r;
+								if (cyr >= J.tw) {cyr -= J.tw; ++uyr;}
+								int const tl = J.tile_map[uyr*J.nux + t_ux[j]];
+								if (tl >= 0) {J.out[(size_t)tl*J.tw*J.tw + cyr*J.tw + t_cx[j]] = zr[r];}
+							}
+							else {J.out[(size_t)y*J.nx + x] = zr[r];}
+						}
+					}
+				}
+			}
+		}
+	}
+	if (J.mm) {
+		uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+		if (fmn <= fmx) {lo = sgf_f2ord(fmn); hi = ~sgf_f2ord(fmx);}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			uint32_t const l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+			lo = (l2 < lo) ? l2 : lo; hi = (h2 < hi) ? h2 : hi;
+		}
+		if (lane == 0 && lo != 0xFFFFFFFFu) {
+			if (lo < __hip_atomic_load(&J.mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {atomicMin(&J.mm[0], lo);}
+			if (hi < __hip_atomic_load(&J.mm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {atomicMin(&J.mm[1], hi);}
+		}
+	}
+}
 
 } // namespace terra

@@ -1,8 +1,7 @@
 // terra_fz.hip -- the TOLERANCE-mode build of the per-cell noise kernels (TERRA_GEN_FUSED / terra_set_option "gen.fused", include/terra.h).
 //
 // The second translation unit of libterra_hip.so.  It compiles terra_noise_kernels.hpp -- the very source terra_hip.hip compiles without contraction -- under the namespace
-// name terra_fz with floating-point contraction allowed: k_noise_grid / k_noise_tiles (get_noise_zval's fBm and domain warp, src/mesh_gen.cpp:706-751) and k_voxel_noise
-// (voxel_manager::create_procedural's lattice field, src/voxels.cpp:312-345) evaluate the reference's expression trees with every a*b + c the compiler finds rounded once.
+// name terra_fz with floating-point contraction allowed: k_noise_grid / k_noise_tiles (get_noise_zval's simplex / Perlin fBm, src/mesh_gen.cpp:706-751) evaluate the reference's expression trees with every a*b + c the compiler finds rounded once.
 // The exact kernels pay a multiply AND an add for each of those; BASELINE's bar for the z values is 1e-5 relative, and the reference's own GPU off-load of these functions
 // (shaders/simplex_noise.part) is not bit-equal to its CPU path either.  Nothing here is reachable unless the caller asks for the mode.
 //
@@ -40,14 +39,5 @@ int terra_fz_noise_tiles(void const *refs_, uint32_t n, uint32_t nux, float cons
 	case terra::MGEN_SIMPLEX_GPU: hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX_GPU>, grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut, oc); break;
 	default:                      hipLaunchKernelGGL(terra::k_noise_tiles<terra::MGEN_SIMPLEX>,     grid, block, 0, stream, refs, n, nux, d_sm, d_m0, job, nc, L, zvals, tw, nlut, oc); break;
 	}
-	return (int)hipGetLastError();
-}
-
-int terra_fz_voxel_noise(int perlin, float *out, size_t nvox, void const *J_, void *stream_) {
-	terra::vox_noise_job_t const J = *(terra::vox_noise_job_t const *)J_;
-	hipStream_t const stream = (hipStream_t)stream_;
-	dim3 const grid((unsigned)((nvox + 255)/256)), block(256);
-	if (perlin) {hipLaunchKernelGGL(terra::k_voxel_noise<true>, grid, block, 0, stream, out, nvox, J);}
-	else        {hipLaunchKernelGGL(terra::k_voxel_noise<false>, grid, block, 0, stream, out, nvox, J);}
 	return (int)hipGetLastError();
 }

@@ -46,6 +46,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	~hip_backend_t() {
 		if (pin) (void)hipHostFree(pin);
+		if (h3_tab) (void)hipFree(h3_tab);
 		if (tile_pad) (void)hipFree(tile_pad);
 		if (tile_order) (void)hipFree(tile_order);
 		if (tile_acc) (void)hipFree(tile_acc);
@@ -245,6 +246,32 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 
+	// TERRA_GEN_FAST (terra_fused.hpp: k_sine_grid_h3): split the f32 tables of J (k-major, rows padded to nxp / nyp) into scaled half-precision pairs and run the contraction on
+	// the half-precision matrix pipe.  amax_y / amax_x: the largest magnitude the row / column table can hold.  Returns false when the tables are too large for its 32-bit offsets.
+	void *h3_tab = nullptr; size_t h3_tab_bytes = 0;
+	static float h3_scale(float amax) {int e = 0; if (amax > 0.0f && amax < 3.0e38f) {(void)frexpf(amax, &e);} return ldexpf(1.0f, 14 - e);} // amax < 2^e: scaled magnitudes stay below 2^14
+	// vox_tab: (voxels) noise_gen_3d's [entry][nsines] sine table with the field's nx, ny -- the split tables are then made straight from it (J.xt / J.yt unused)
+	template<int KIND> bool sine_grid_h3(terra::sgf_job_t J, float amax_x, float amax_y, float const *vox_tab = nullptr, uint32_t vnx = 0, uint32_t vny = 0) {
+		int const nk = (J.kstart < J.kend) ? J.kend - J.kstart : 0;
+		uint32_t const nchunks = (uint32_t)((3*nk + 15)/16);
+		if ((uint64_t)std::max(J.nxp, J.nyp)*32u*(nchunks + 1) >= 0xFFFFFFFFull) return false;
+		size_t const bx = (size_t)nchunks*J.nxp*32u, by = (size_t)nchunks*J.nyp*32u;
+		if (bx + by + 64 > h3_tab_bytes) {if (h3_tab) {sync(); (void)hipFree(h3_tab);} TERRA_HIP_CHECK(hipMalloc(&h3_tab, bx + by + 64)); h3_tab_bytes = bx + by + 64;}
+		float const sx = h3_scale(amax_x), sy = h3_scale(amax_y);
+		J.xh = h3_tab; J.yh = (char *)h3_tab + bx; J.nchunks = nchunks; J.unscale = 1.0f/(sx*sy);
+		if (nchunks && vox_tab) {
+			hipLaunchKernelGGL((terra::k_split_voxel_table<false, terra::VOX_SINES>), dim3((J.nxp + 255)/256), dim3(256), 0, stream, vox_tab, vnx, vny, J.nx, J.nxp, sx, (terra::sgh_u4 *)J.xh);
+			hipLaunchKernelGGL((terra::k_split_voxel_table<true, terra::VOX_SINES>),  dim3((J.nyp + 255)/256), dim3(256), 0, stream, vox_tab, vnx, vny, J.nx, J.nyp, sy, (terra::sgh_u4 *)J.yh);
+		}
+		else if (nchunks) {
+			hipLaunchKernelGGL(terra::k_split_table<false>, dim3((unsigned)(((size_t)nchunks*J.nxp + 255)/256)), dim3(256), 0, stream, J.xt, J.nxp, J.kstart, J.kend, nchunks, sx, (terra::sgh_u4 *)J.xh);
+			hipLaunchKernelGGL(terra::k_split_table<true>,  dim3((unsigned)(((size_t)nchunks*J.nyp + 255)/256)), dim3(256), 0, stream, J.yt, J.nyp, J.kstart, J.kend, nchunks, sy, (terra::sgh_u4 *)J.yh);
+		}
+		unsigned const nb = J.ntx*J.nty, grid = ((nb + 7)/8)*8;
+		hipLaunchKernelGGL(terra::k_sine_grid_h3<KIND>, dim3(grid), dim3(256), 0, stream, J);
+		TERRA_HIP_CHECK(hipGetLastError());
+		return true;
+	}
 	// mm (optional): device uint32[2] pre-set to 0xFFFFFFFF receiving min f2ord(z) / min ~f2ord(z); returns false when the caller must run minmax() itself
 	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *mm) {
 		if (simple_kernels) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
@@ -256,6 +283,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			J.xt = xt; J.yt = yt; J.smx = smx; J.smy = smy; J.out = out; J.mm = mm; J.nx = job.nx; J.ny = job.ny; J.nxp = job.nxp; J.nyp = job.nyp; J.ntx = ntx; J.nty = nty; J.rowgroup = sg_rowgroup;
 			J.kstart = job.kstart; J.kend = terra::F_TABLE_SIZE; J.glaciate = (job.glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (job.glaciate && job.use_sine_mag) ? 1 : 0;
 			J.zmax_est = nc.zmax_est; J.zmax_est2 = nc.zmax_est2; J.zmax_est2_inv = nc.zmax_est2_inv; J.sine_offset = job.sine_offset;
+			if (job.fused == 2 && sine_grid_h3<terra::SGF_GRID>(J, 1.0f, job.fast_amax)) return true; // TERRA_GEN_FAST (|SINF| <= 1 bounds the x table)
 			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_GRID>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
 			TERRA_HIP_CHECK(hipGetLastError());
 			return true;
@@ -286,7 +314,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr, bool fused = false)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr, int fused = 0, float fast_amax = 0.0f)
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
@@ -327,6 +355,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			J.kstart = kstart; J.kend = terra::F_TABLE_SIZE; J.glaciate = (glaciate && nc.glaciate) ? 1 : 0; J.sine_mag = (glaciate && use_sm) ? 1 : 0;
 			J.zmax_est = nc.zmax_est; J.zmax_est2 = nc.zmax_est2; J.zmax_est2_inv = nc.zmax_est2_inv; J.sine_offset = so;
 			J.tile_map = tm; J.nux = nux; J.tw = tw;
+			if (fused == 2 && sine_grid_h3<terra::SGF_TILES>(J, 1.0f, fast_amax)) return;
 			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_TILES>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
@@ -425,18 +454,25 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (nvox == 0) return;
 		use();
 		if ((nvox + 255)/256 > 0x7FFFFFFFull) throw std::invalid_argument("voxel_fill: grid too large");
-		if (fused) {TERRA_HIP_CHECK((hipError_t)terra_fz_voxel_noise(perlin ? 1 : 0, out, nvox, &J, (void *)stream)); return;} // "gen.fused": the contraction-allowed build
+		// "gen.fused" has no kernel here: glm's 3-D lattice noise picks its gradients by the SIGN of expressions that are exactly zero at some of the hash's 49 / 289 values
+		// (h = 1 - |x| - |y| in simplex(vec3), gz = 0.5 - |gx| - |gy| in perlin(vec3); noise.inl:149-157,690-700), so one contracted rounding flips a gradient: measured 0.146
+		// on a 40 x 24 x 64 Perlin field for 1.2x.  (The 2-D kernels read those terms from the lattice table the exact code builds: they are immune.)  The exact kernel answers.
+		(void)fused;
 		dim3 const grid((unsigned)((nvox + 255)/256)), block(256);
 		if (perlin) {hipLaunchKernelGGL(terra::k_voxel_noise<true>, grid, block, 0, stream, out, nvox, J);}
 		else        {hipLaunchKernelGGL(terra::k_voxel_noise<false>, grid, block, 0, stream, out, nvox, J);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, bool fused = false) {
+	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float fast_amax = 0.0f) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused); return;}
 		use();
 		if (fused && (uint64_t)nx*ny <= 0x7FFFFF80ull) { // "gen.fused": the field as a (columns x 60) x (60 x nz) product on the f32 matrix pipe (terra_fused.hpp)
 			size_t const ncol = (size_t)nx*ny;
 			uint32_t const nyp = (uint32_t)((ncol + 127)/128*128), nxp = (nz + 127)/128*128;
+			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
+			J.out = out; J.nx = nz; J.ny = (uint32_t)ncol; J.nxp = nxp; J.nyp = nyp; J.ntx = nxp/128; J.nty = nyp/128; J.rowgroup = sg_rowgroup;
+			J.kstart = 0; J.kend = terra::VOX_SINES; J.zscale = zscale; J.normalize = normalize;
+			if (fused == 2 && sine_grid_h3<terra::SGF_VOXELS>(J, 1.0f, fast_amax, d_tab, nx, ny)) return; // TERRA_GEN_FAST (|zv| <= 1; |xv*yv| <= the largest magnitude)
 			size_t const np = (size_t)terra::VOX_SINES*((size_t)nyp + nxp);
 			if (np*4 > vox_p_bytes) {if (vox_p) {sync(); (void)hipFree(vox_p);} TERRA_HIP_CHECK(hipMalloc((void **)&vox_p, np*4)); vox_p_bytes = np*4;}
 			float *const pt = vox_p, *const zt = vox_p + (size_t)terra::VOX_SINES*nyp;
@@ -454,9 +490,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 					zt[j] = (z < nz) ? d_tab[((size_t)nx + ny + z)*terra::VOX_SINES + k] : 0.0f;
 				}
 			});
-			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
-			J.xt = zt; J.yt = pt; J.out = out; J.nx = nz; J.ny = (uint32_t)ncol; J.nxp = nxp; J.nyp = nyp; J.ntx = nxp/128; J.nty = nyp/128; J.rowgroup = sg_rowgroup;
-			J.kstart = 0; J.kend = terra::VOX_SINES; J.zscale = zscale; J.normalize = normalize;
+			J.xt = zt; J.yt = pt;
 			unsigned const nb = J.ntx*J.nty, grid = ((nb + 7)/8)*8;
 			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_VOXELS>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
 			TERRA_HIP_CHECK(hipGetLastError());

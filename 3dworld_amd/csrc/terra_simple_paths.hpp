@@ -24,7 +24,7 @@ template<class DERIVED> struct simple_paths {
 	// tiles: xt / yt = k-major tables of all distinct tile columns / rows side by side (row lengths nxpv / nypv), d_sm = [nux + nuy][zv] sine-mag terms,
 	// d_m0 = per distinct tx / ty grid origin (mx0 / my0)
 	void tile_grid_simple(uint32_t n, tile_ref_pod_t const *refs, uint32_t nux, uint32_t /*nuy*/, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv,
-		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals, uint32_t zv, bool glaciate = true, bool fused = false)
+		float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float sine_offset, noise_consts_t const &nc, sin_lut_t const &L, float dxv, float dyv, float *zvals, uint32_t zv, bool glaciate = true, int fused = 0)
 	{
 		self().launch((size_t)n*zv*zv, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const t = (unsigned)(i / (zv*zv)), p = (unsigned)(i % (zv*zv)), y = p / zv, x = p % zv;
@@ -208,7 +208,7 @@ template<class DERIVED> struct simple_paths {
 	}
 	// voxel sine field: val = sum_k xv[k]*yv[k]*zv[k] (src/upsurface.cpp:60-70); d_tab = [nx + ny + nz][60]
 	// fused ("gen.fused"): (xv*yv) rounds as in the reference, its multiply-add with zv and the z term round once each (k_sine_grid_mx<SGF_VOXELS> is this, bit for bit)
-	void voxel_sines_simple(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, bool fused = false) {
+	void voxel_sines_simple(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0) {
 		self().launch((size_t)nx*ny*nz, [=] TERRA_LAMBDA (size_t i) {
 			unsigned const z = (unsigned)(i % nz), x = (unsigned)((i / nz) % nx), y = (unsigned)(i / ((size_t)nz*nx));
 			float const *xv = d_tab + (size_t)x*VOX_SINES, *yv = d_tab + ((size_t)nx + y)*VOX_SINES, *zvp = d_tab + ((size_t)nx + ny + z)*VOX_SINES;

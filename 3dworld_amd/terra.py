@@ -5,7 +5,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES, GEN_FUSED = 1, 2, 4, 8, 16
+GEN_GLACIATE, GEN_FORCE_SINE, GEN_NO_WAIT, GEN_CACHE_VALUES, GEN_FUSED, GEN_FAST = 1, 2, 4, 8, 16, 32
 ERODE_SERIAL, ERODE_MINZ_IS_MIN, ERODE_SERIAL_WAVE = 1, 2, 4
 MGEN_SINE, MGEN_SIMPLEX, MGEN_PERLIN, MGEN_SIMPLEX_GPU, MGEN_DWARP_GPU = range(5)
 

@@ -461,6 +461,7 @@ def main():
         detail.update({"ms_noise_kernels": round(ms_gen, 4), "ms_grid_kernel": round(ms_grid, 4), "ms_minmax_unfused": round(ms_minmax, 4), "ms_erosion": round(ms_ero, 4)})
         if not args.no_extras:
             bench_detail.modes_and_dense(env, detail, ms_gen, ms_ero)
+            bench_detail.fused_modes(env, detail)
             if world == 1:  # (rank 0 alone runs these: no collective with another rank inside)
                 bench_detail.end_to_end(env, detail)
                 bench_detail.onegrid_rank_floor(env, detail, args.simulate_world)

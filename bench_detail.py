@@ -131,6 +131,76 @@ def modes_and_dense(env, detail, ms_gen, ms_ero):
     detail["dense_erosion"] = de
 
 
+def fused_modes(env, detail):
+    """rank 0: the TOLERANCE modes beside the bit-exact default -- TERRA_GEN_FUSED (one rounding per multiply-add: the sine sums on the f32 matrix
+    pipe, bit-equal to the restated mode; simplex / Perlin with contraction allowed) and TERRA_GEN_FAST (the sine sums on the half-precision matrix pipe with split operands),
+    both within 1e-5 * zmax_est of the reference.  The 16384^2 noise-only grid of the headline, the noise-only fBm grids, the 512^3 and 512 x 512 x 64 voxel fields.
+    `parity` names the -m gpu tests that hold every number's configuration to its bar; `eroded_cells_beyond_tol` is why the headline `value` stays on the exact path."""
+    import os
+    pkg, t, z, st, N, cells, args, torch = env.pkg, env.t, env.z, env.st, env.N, env.cells, env.args, env.torch
+    x0, y0 = env.x0, env.y0
+    out = {}
+
+    def time_grid(flags, reps=6):
+        t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, flags)
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < 0.5 * args.clock_warmup_ms:
+            t.gen_grid_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, flags)
+        t.timer_start()
+        for _ in range(reps):
+            t.gen_grid_minmax_dev(z.data_ptr(), x0, y0, st.DX_VAL, st.DY_VAL, N, N, flags)
+        return t.timer_stop() / reps
+
+    fl = flops_per_cell(env.mode, args.octaves)
+    sine = {}
+    for name, fb in (() if env.mode != 0 else (("exact", 0), ("fused", pkg.GEN_FUSED), ("fast", pkg.GEN_FAST))):
+        ms = time_grid(pkg.GEN_GLACIATE | fb)
+        sine[name] = {"ms_noise_call": round(ms, 4), "gcells_s_noise_only": round(cells / ms / 1e6, 2), "tflops_8d": round(fl * cells / (ms * 1e-3) / 1e12, 2),
+                      "frac_fp32_peak": round(fl * cells / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "write_tb_s": round(cells * 4 / (ms * 1e-3) / 1e12, 3)}
+    sine["note"] = ("ms_noise_call = table launches + grid kernel + fused min / max, HIP events; fast: bound by writing the grid (write_tb_s of the ~8 TB/s HBM peak), "
+                    "its effective flop rate is above the fp32 vector peak because the work runs on the half-precision matrix pipe")
+    out["sine_16384"] = sine
+    fb_modes = {}
+    for name, m in env.MODES.items():
+        if m in (0, 4):
+            continue  # (the domain warp has no fused kernel: beyond the bar, see terra_driver.hpp fused_kernel_exists)
+        t.init_scene(pkg.make_config(mesh_gen_mode=m, mesh_freq_filter=9 - args.octaves))
+        e, f = time_grid(pkg.GEN_GLACIATE, 3), time_grid(pkg.GEN_GLACIATE | pkg.GEN_FUSED, 3)
+        fb_modes[name] = {"ms_exact": round(e, 4), "ms_fused": round(f, 4), "speedup": round(e / f, 3), "gcells_s_fused": round(cells / f / 1e6, 2)}
+    t.init_scene(pkg.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - args.octaves))
+    out["fbm_16384"] = fb_modes
+    vox = {}
+    VN = 512
+    for nz in (512, 64):
+        buf = torch.empty(VN * VN * nz, dtype=torch.float32, device=env.dev)
+        row = {}
+        for name, lvl in (("exact", "0"), ("fused", "1"), ("fast", "2")):
+            t.set_option("gen.fused", lvl)
+            try:
+                call = lambda: t.voxel_fill_dev(buf.data_ptr(), VN, VN, nz, (-1.0, -1.0, -0.25), (2.0 / VN, 2.0 / VN, 0.5 / nz), (0.0, 0.0, 0.0), 1.0, 1.0, 123, 456, 0, 0.0, 1)  # noqa: E731
+                for _ in range(4):
+                    call()
+                t.timer_start()
+                for _ in range(10):
+                    call()
+                ms = t.timer_stop() / 10
+            finally:
+                t.set_option("gen.fused", "0")
+            row[name] = {"ms_per_field": round(ms, 4), "gvoxels_s": round(VN * VN * nz / ms / 1e6, 1)}
+        vox[f"{VN}x{VN}x{nz}"] = row
+        del buf
+    out["voxels"] = vox
+    beyond = None
+    try:
+        beyond = int(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_fused_eroded_beyond.txt")).read().split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    out["eroded_cells_beyond_tol"] = {"count": beyond, "of": 16384 * 16384, "droplets": 1000, "source": "tests/test_gpu_fused.py::test_fused_headline_grid_16384_every_cell (recorded: profiles/r06_fused_eroded_beyond.txt)",
+                                      "consequence": "the droplet paths amplify last-bit differences (the count is not 0): the headline value stays on the bit-exact path"}
+    out["parity"] = "tests/test_gpu_fused.py: fused = bit-equal to the restated mode AND <= 1e-5*zmax_est of the reference (whole 16384^2 grid, 4096 tiles, 512^3 / 512x512x64 fields); fast and fBm-fused = the tolerance bar only"
+    detail["fused"] = out
+
+
 def end_to_end(env, detail):
     """SURVEY 8(d) "(ii) end-to-end incl. D2H z": the z grid of every heightmap delivered to HOST memory.  (a) the library: noise + min + erosion on the device, map i
     on the PCIe link (terra_download_async: bands on four streams, csrc/terra_xfer.hpp) while map i + 1 is computed -- into a pinned array (terra_host_alloc) and into an ordinary

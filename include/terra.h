@@ -136,6 +136,10 @@ typedef struct terra_gen terra_gen;
  * evaluated by the exact kernel.  Do not feed fused heights to apply_erosion when the droplet paths must be the reference's: erosion amplifies a last-bit difference.
  * The calls without a flags argument (tiles, voxels) take it from terra_set_option(ctx, "gen.fused", "1"). */
 #define TERRA_GEN_FUSED        16u
+/* The cheapest form within the same tolerance (implies TERRA_GEN_FUSED where it has no kernel of its own): the sine sum's tables are split into scaled half-precision pairs and
+ * the contraction runs on the half-precision matrix pipe, 16 times the f32 pipe's rate (csrc/terra_fused.hpp: k_sine_grid_h3) -- the kernel is then bound by writing its result.
+ * Within 1e-5 * zmax_est of the reference like TERRA_GEN_FUSED (measured ~1e-6), but not the value of any restatement: tested against the tolerance only.  Option "gen.fused" = "2". */
+#define TERRA_GEN_FAST         32u
 /* flags of terra_apply_erosion*_dev */
 #define TERRA_ERODE_SERIAL        1u /* walk droplets one by one on one lane (reference order, no speculation): debugging / tiny grids */
 #define TERRA_ERODE_SERIAL_WAVE   4u /* droplets one after another, each simulated by a whole wave through the LDS window (no speculation) */
@@ -151,7 +155,7 @@ int  terra_set_stream(terra_ctx *ctx, void *hip_stream);   /* use the caller's h
 int  terra_synchronize(terra_ctx *ctx);
 /* ---- options: every behaviour switch of the library (nothing in it reads the process environment).  Values are strings; an unknown key or a value outside the key's
  * range is TERRA_ERR_ARG and changes nothing.  The call drains the context's stream first.  Only "gen.fused" changes a result.
- *   "gen.fused"            "0" | "1"      every generator call of this context behaves as if TERRA_GEN_FUSED were given (tile batches and voxel fields have no flags argument)
+ *   "gen.fused"            "0" | "1" | "2"   every generator call of this context behaves as if TERRA_GEN_FUSED ("1") / TERRA_GEN_FAST ("2") were given (tile batches and voxel fields have no flags argument)
  *   "kernels.simple"       "0" | "1"      one-thread-per-cell cross-check kernels instead of the tiled ones (tests)
  *   "graphs"               "0" | "1"      replay the erosion rounds as hipGraphs (default 1)
  *   "sg.kc" "20"|"27"|"45", "sg.kc_tiles" "27"|"45", "sg.rowgroup" "1".."1024"      LDS chunking / tile walk of the exact sine kernel

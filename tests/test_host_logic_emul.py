@@ -355,3 +355,4 @@ def test_fused_tolerance_mode_host_logic(pkg, emul, orc):
     for mode in (1, 2, 4):  # (the emulator's per-cell kernels have one build: the flag must reach them and change nothing)
         assert pc.case_fused_fbm(pkg, emul, orc, mode, 96) == 0.0
     assert pc.case_fused_voxel_fbm(pkg, emul, orc, 1, (12, 10, 16)) == 0.0
+    assert pc.case_fast_mode(pkg, emul, orc, sizes=((260, 150), (1, 1)), vox_shapes=((12, 10, 16),)) < 2e-6  # (the emulator answers TERRA_GEN_FAST with the fused form)

@@ -1,8 +1,9 @@
-mkdir -p gpurun_out/r06d; O=gpurun_out/r06d
-python -m pytest tests/test_gpu_fused.py -q -s -x 2>&1 | grep -v "^fused grid" | tail -25 > $O/fused.log
-for f in 0 1; do
-  TERRA_GEN_FUSED=$f python tools/prof_noise.py 4096 10 1,2,4 8 2>&1 | head -3 >> $O/times.txt
-  TERRA_GEN_FUSED=$f python tools/prof_noise.py 16384 3 1,2,4 8 2>&1 | head -3 >> $O/times.txt
-  TERRA_GEN_FUSED=$f python tools/prof_voxels.py 512 64 1,2 >> $O/times.txt 2>&1
-done
-cat $O/fused.log $O/times.txt
+mkdir -p gpurun_out/r06h; O=$PWD/gpurun_out/r06h
+python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^fused grid" | tail -6 > $O/tests.log
+python bench.py > $O/bench.json 2> $O/bench.err
+cat $O/tests.log; tail -3 $O/bench.err; python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r06h/bench.json").read().strip().splitlines()[-1])
+print({k:d[k] for k in ("value","ms_per_step","roofline")})
+print(json.dumps(d["detail"].get("fused"), indent=1))
+PY
