@@ -63,9 +63,9 @@ int terra_create(terra_ctx **out, int device_index) {
 		*out = c;
 	TERRA_CATCH
 }
-void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.sync();} catch (...) {} delete ctx;}}
+void terra_destroy(terra_ctx *ctx) {if (ctx) {try {ctx->eng.be.download_wait();} catch (...) {} try {ctx->eng.be.sync();} catch (...) {} delete ctx;}} // (a pending terra_download_async still reads device scratch)
 int terra_set_stream(terra_ctx *ctx, void *s) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.set_stream(s); TERRA_CATCH}
-int terra_release_scratch(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.release_scratch(); TERRA_CATCH}
+int terra_release_scratch(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.download_wait(); ctx->eng.release_scratch(); TERRA_CATCH}
 int terra_synchronize(terra_ctx *ctx) {TERRA_CHECK_CTX TERRA_TRY ctx->eng.be.sync(); TERRA_CATCH}
 int terra_set_option(terra_ctx *ctx, const char *key, const char *value) {
 	TERRA_CHECK_CTX if (!key || !value) return terra::fail(TERRA_ERR_ARG, "terra_set_option: null key / value");

@@ -363,7 +363,7 @@ template<class BE> struct terra_engine {
 	uint32_t *spec_blocks_clean = nullptr; size_t spec_blocks_n = 0; // s_spec_blocks is known to be all-NIL for this pointer / block count
 	template<class T> T *scratch(scratch_t &s, size_t count) {
 		size_t const bytes = std::max<size_t>(count*sizeof(T), 256);
-		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p);} s.p = be.alloc(bytes); s.bytes = bytes;}
+		if (bytes > s.bytes) {if (s.p) {be.sync(); be.free(s.p); s.p = nullptr; s.bytes = 0;} s.p = be.alloc(bytes); s.bytes = bytes;} // (a failed allocation leaves an empty buffer, not a stale pointer)
 		return (T *)s.p;
 	}
 	float *host_grid_scratch(size_t bytes) {return (float *)scratch<uint8_t>(s_hostgrid, bytes);} // device copy of a caller's host array (the host-pointer entry points)
@@ -939,7 +939,16 @@ template<class BE> struct terra_engine {
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2];
 		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)N*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)N*sb.maxb*8); o_bl[b] = carve((size_t)N*sb.maxb*4); o_bc[b] = carve((size_t)N*4);}
 		size_t const o_slot = carve((size_t)N*4*6), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
-		uint8_t *base = scratch<uint8_t>(s_spec, off); // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
+		// ~137 KB per droplet.  When the buffer has to grow, the request must fit what the device has free (the same budget rule as the general scheduler's ring, incl. the
+		// "ero.mem_budget" test knob); if it does not -- or the allocation fails anyway -- nothing has been touched yet: the general scheduler takes the whole run
+		if (off > s_spec.bytes) {
+			size_t avail = be.mem_free() + s_spec.bytes, reserve = (size_t)1 << 30;
+			if (opt.ero_mem_budget >= 0) {avail = (size_t)opt.ero_mem_budget; reserve = 0;}
+			if (off + reserve > avail) {first = 0; return false;}
+		}
+		uint8_t *base = nullptr;
+		try {base = scratch<uint8_t>(s_spec, off);} // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
+		catch (std::exception const &) {first = 0; return false;}
 		for (int b = 0; b < 2; ++b) {
 			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]);

@@ -17,7 +17,7 @@
 //               slot are sliced (suspended at a step boundary, resumed next round); the lowest uncommitted droplet always has final inputs, so the fixed point
 //               -- every version equal to the serial loop's -- is reached (terra_driver.hpp: speculative_erosion).
 //   serial (the overflow fall-back, TERRA_ERODE_SERIAL*): one lane / one wave walks the droplets in order directly on the grid.
-//   tiles: the whole clamp-padded 138x138 tile in LDS, one wave, droplets in order (terra_kernels.hpp: k_tile_erosion; k_tile_erosion2 = two waves per tile, opt-in).
+//   tiles: the whole clamp-padded 138x138 tile in LDS, one wave, droplets in order (terra_kernels.hpp: k_tile_erosion).
 //
 // All arithmetic is the reference's, operation for operation, in fp32 without FMA contraction; std::min/max NaN behaviour
 // and x86 float->int conversion are reproduced because the reference does produce NaNs (v = sqrtf(v*v + Kg*dh) with dh < 0).

@@ -74,7 +74,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	// host buffers are ordinary pageable memory (often stack variables): copies are stream-ordered and then waited for
 	void h2d(void *d, void const *h, size_t bytes) {
 		use();
-		if (bytes >= BIG_XFER) {xfer.submit(device, stream, const_cast<void *>(h), d, bytes, true); xfer.wait_all(); return;} // (the host waits: later kernels of any stream see the data)
+		if (bytes >= BIG_XFER) {xfer.submit(device, stream, const_cast<void *>(h), d, bytes, true, [this](hipEvent_t e) {return record_via_side(e);}); xfer.wait_all(); return;} // (the host waits: later kernels of any stream see the data)
 		TERRA_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); TERRA_HIP_CHECK(hipStreamSynchronize(stream));
 	}
 	// small parameter blocks (tile references, per-column constants, dependency orders): staged through a pinned ring and copied asynchronously, stream-ordered -- the
@@ -99,7 +99,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	// ---- big host <-> device transfers (terra_xfer.hpp): stream-ordered behind the work enqueued so far, asynchronous to the host and to the context's later kernels
 	static constexpr size_t BIG_XFER = (size_t)16 << 20;
 	terra::xfer_engine_t xfer;
-	void download_async(void const *d, void *h, size_t bytes) {use(); xfer.submit(device, stream, h, const_cast<void *>(d), bytes, false);}
+	void download_async(void const *d, void *h, size_t bytes) {use(); xfer.submit(device, stream, h, const_cast<void *>(d), bytes, false, [this](hipEvent_t e) {return record_via_side(e);});}
 	void download_wait() {xfer.wait_all();}
 	static void *host_alloc(size_t bytes) {void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {(void)hipGetLastError(); return nullptr;} return p;}
 	static void host_free(void *p) {if (p) (void)hipHostFree(p);}
@@ -166,13 +166,17 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	// then refuses the wait and poisons the capture (hipErrorStreamCaptureUnsupported; the erosion schedulers capture their rounds on first use) -- so the record goes through
 	// a side stream of the context that never captures: [stream: relay event] -> [side stream: wait relay, record e]
 	hipStream_t side_stream = nullptr; hipEvent_t relay_ev = nullptr;
-	void event_record(void *e) {
-		use();
-		if (!side_stream) {TERRA_HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking)); TERRA_HIP_CHECK(hipEventCreateWithFlags(&relay_ev, hipEventDisableTiming));}
-		TERRA_HIP_CHECK(hipEventRecord(relay_ev, stream));
-		TERRA_HIP_CHECK(hipStreamWaitEvent(side_stream, relay_ev, 0));
-		TERRA_HIP_CHECK(hipEventRecord((hipEvent_t)e, side_stream));
+	hipError_t record_via_side(hipEvent_t e) {
+		hipError_t r = hipSuccess;
+		if (!side_stream) {
+			if ((r = hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking)) != hipSuccess) return r;
+			if ((r = hipEventCreateWithFlags(&relay_ev, hipEventDisableTiming)) != hipSuccess) return r;
+		}
+		if ((r = hipEventRecord(relay_ev, stream)) != hipSuccess) return r;
+		if ((r = hipStreamWaitEvent(side_stream, relay_ev, 0)) != hipSuccess) return r;
+		return hipEventRecord(e, side_stream);
 	}
+	void event_record(void *e) {use(); TERRA_HIP_CHECK(record_via_side((hipEvent_t)e));}
 	void event_wait(void *e) {use(); TERRA_HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)e, 0));}
 	static void event_destroy(void *e) {if (e) (void)hipEventDestroy((hipEvent_t)e);}
 	static void event_synchronize(void *e) {TERRA_HIP_CHECK(hipEventSynchronize((hipEvent_t)e));}

@@ -118,11 +118,15 @@ struct xfer_engine_t {
 		}
 	}
 	// enqueue; `compute` is the stream whose work so far the transfer must wait for (and, for an upload, the stream that must wait for wait_all() before using the data: the caller does)
-	void submit(int dev, hipStream_t compute, void *host, void *devp, size_t bytes, bool to_device) {
+	// `record_ready(e)`: records e stream-ordered behind `compute`'s work so far WITHOUT making `compute` the event's last-recording stream -- the workers wait for it later
+	// (hipStreamWaitEvent), and by then `compute` may be capturing a graph (the erosion schedulers capture their rounds on first use of a shape): HIP refuses a wait on an
+	// event last recorded in a capturing stream and invalidates the capture.  The backend relays through its never-capturing side stream, as terra_event_record does.
+	template<class RECORD> void submit(int dev, hipStream_t compute, void *host, void *devp, size_t bytes, bool to_device, RECORD record_ready) {
 		if (bytes == 0) return;
+		(void)compute;
 		start(dev);
 		job_t j; j.host = (uint8_t *)host; j.dev = (uint8_t *)devp; j.bytes = bytes; j.to_device = to_device; j.host_pinned = is_pinned(host); j.ready = nullptr;
-		if (hipEventCreateWithFlags(&j.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(j.ready, compute) != hipSuccess) {
+		if (hipEventCreateWithFlags(&j.ready, hipEventDisableTiming) != hipSuccess || record_ready(j.ready) != hipSuccess) {
 			if (j.ready) (void)hipEventDestroy(j.ready);
 			throw std::runtime_error("terra transfer: event set-up failed");
 		}

@@ -213,12 +213,18 @@ def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cp
     sockdir = None
     if world > 1:  # a directory only this user can enter, made by rank 0 and announced through the process group
         import tempfile
-        box = [None]
+        box, dir_err = [None], None
         try:
             if rank == 0 and "TERRA_DGRID_SOCKDIR" not in os.environ:
                 box[0] = tempfile.mkdtemp(prefix="terra_dgrid_")
-        except OSError:
-            box[0] = None
+                if len(box[0].encode()) > 255:  # the announcement below carries 255 bytes: a longer path would send the other ranks to a directory that does not exist
+                    dir_err = f"socket directory path longer than 255 bytes ({box[0]!r}): set TMPDIR or TERRA_DGRID_SOCKDIR to a shorter one"
+        except OSError as e:
+            dir_err = f"mkdtemp failed: {e!r}"  # (no silent fall-back to a world-writable directory)
+        if not _all_ok(dist, dir_err is None, coll_device):
+            os.close(fd)
+            g.destroy()
+            raise RuntimeError(f"terra_dgrid: no private socket directory ({dir_err or 'rank 0 could not make one'})")
         # rank 0's path to everybody: one all_reduce(sum) of its bytes (the other ranks contribute zeros) -- the same kind of collective, on the same device, as every
         # other one of this module (no pickling, no object collectives)
         import torch

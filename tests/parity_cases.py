@@ -1282,6 +1282,24 @@ def case_big_transfers(pkg, t, orc, sizes=((4096, 4096), (2051, 2047), (300, 200
             t.download_wait()                                              # nothing pending: returns at once
         finally:
             pin.free(); a.free(); b.free()
+    # an overlapped download followed at once by an erosion whose rounds are CAPTURED into graphs for the first time (a droplet count this context has not seen): the
+    # workers' wait for the download's ready event must not land on an event last recorded in the capturing stream (the ready event is recorded through the side stream)
+    n = 2300
+    a, b = t.alloc(n * n * 4), t.alloc(n * n * 4)
+    try:
+        t.gen_grid_dev(a.ptr, -n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, pkg.GEN_GLACIATE)
+        mn, _ = t.gen_grid_minmax_dev(b.ptr, 7.0, -n / 2, st.DX_VAL, st.DY_VAL, n, n, pkg.GEN_GLACIATE)
+        pag = np.full((n, n), -7.0, np.float32)
+        t.download_async(a.ptr, pag)
+        t.apply_erosion_dev(b.ptr, n, n, mn, 1237, pkg.ERODE_MINZ_IS_MIN)   # first use of this shape / count
+        t.apply_erosion_dev(b.ptr, n, n, mn, 61, 0)
+        t.download_wait()
+        assert_bit_equal(orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1), pag, "download overlapped with a first-use (capturing) erosion")
+        g = orc.gen_grid(7.0, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+        orc.apply_erosion(g, float(g.min()), 1237); orc.apply_erosion(g, float(mn), 61)
+        assert_bit_equal(g, b.download(np.float32, (n, n)), "the erosions beside the download")
+    finally:
+        a.free(); b.free()
     # the host-pointer entry points ride the same engine: terra_apply_erosion on a host array of 16 MiB+
     n = 2100
     g = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)

@@ -344,6 +344,20 @@ def test_erosion_ring_is_capped_by_free_memory_and_scratch_can_be_released(pkg, 
         t.close()
 
 
+def test_sparse_scheduler_hands_over_when_its_scratch_does_not_fit(pkg, emul, orc):
+    """the sparse scheduler's scratch (~137 KB per droplet) obeys the same free-memory rule as the ring: forced on with a budget it cannot fit, the run goes to the
+    general scheduler -- same result, no sparse droplets in the report"""
+    emul.set_option("ero.sparse", "1"); emul.set_option("ero.mem_budget", str(24 << 20))
+    try:
+        r, _ = pc.case_erosion_vs_oracle(pkg, emul, orc, 200, 400)   # 400 droplets x 137 KB = 55 MB > 24 MB
+        assert r.sparse_droplets == 0, r.as_dict()
+        emul.set_option("ero.mem_budget", "-1")
+        r, _ = pc.case_erosion_vs_oracle(pkg, emul, orc, 200, 400)
+        assert r.sparse_droplets > 0, r.as_dict()
+    finally:
+        emul.set_option("ero.sparse", "auto"); emul.set_option("ero.mem_budget", "-1")
+
+
 def test_fused_tolerance_mode_host_logic(pkg, emul, orc):
     """TERRA_GEN_FUSED / option "gen.fused" through the emulator (the per-cell form of the mode, sine_cell_fused): the flag plumbing, the `no fused kernel` fall-back,
     the option switch, and both bars -- bit-equal to the restated mode, within 1e-5 * zmax_est of the reference's arithmetic"""

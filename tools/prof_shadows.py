@@ -16,6 +16,6 @@ for light in ((0.6, 0.5, 0.4), (-0.8, 0.3, 0.25)):
     for _ in range(reps):
         t.synchronize(); t0 = time.perf_counter()
         t.tiles_mesh_shadows_dev(tiles, zt.ptr, light, sm.ptr); t.synchronize()
-        print(f"light {light}: shadows {1e3*(time.perf_counter()-t0):.2f} ms  (TERRA_SHADOW_CHAIN={os.environ.get('TERRA_SHADOW_CHAIN', 'default')})")
+        print(f"light {light}: shadows {1e3*(time.perf_counter()-t0):.2f} ms")
 m = sm.download(np.uint8, (n, 130, 130))
 print("shadowed cells", int((m != 0).sum()))
