@@ -261,6 +261,14 @@ int terra_gen_grid(terra_ctx *ctx, float x0, float y0, float dx, float dy, uint3
 	TERRA_CATCH
 }
 
+int terra_eval_points(terra_ctx *ctx, const float *xy, uint32_t n, uint32_t kind, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *out) {
+	TERRA_CHECK_CTX if (n && (!xy || !out)) return terra::fail(TERRA_ERR_ARG, "terra_eval_points: null pointer");
+	TERRA_TRY std::lock_guard<std::recursive_mutex> lk(ctx->eng_mtx); ctx->eng.eval_points(xy, n, kind, xy_scale, no_xyoff, xoff2, yoff2, out); TERRA_CATCH
+}
+int terra_eval_points_dev(terra_ctx *ctx, const float *d_xy, uint32_t n, uint32_t kind, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *d_out) {
+	TERRA_CHECK_CTX if (n && (!d_xy || !d_out)) return terra::fail(TERRA_ERR_ARG, "terra_eval_points_dev: null pointer");
+	TERRA_TRY std::lock_guard<std::recursive_mutex> lk(ctx->eng_mtx); ctx->eng.eval_points_dev(d_xy, n, kind, xy_scale, no_xyoff, xoff2, yoff2, d_out); TERRA_CATCH
+}
 int terra_eval_mesh_sin_terms(terra_ctx *ctx, float xv, float yv, float *out) {
 	TERRA_CHECK_CTX if (!out) return terra::fail(TERRA_ERR_ARG, "null out");
 	TERRA_TRY *out = ctx->eng.eval_mesh_sin_terms(xv, yv); TERRA_CATCH

@@ -677,6 +677,68 @@ template<class BE> struct terra_engine {
 		}
 		return zval;
 	}
+	// ================================================================ all-modes point queries (a8)
+	// kind 0: eval_mesh_sin_terms_scaled(x, y, xy_scale) (src/mesh_gen.cpp:807-813; index-space coordinates: the detail noise of heightmap tiles, the density fields of the
+	// vegetation callers); kind 1: get_exact_zval(x, y, no_xyoff) (src/mesh_gen.cpp:816-847; world-space: collision / building placement / camera height) in the tiled-terrain
+	// world -- index space, scroll offset, then the heightmap texture (+ detail) when one is set, else noise + glaciate + islands / volcano.  Not here: the two branches that
+	// only read the caller's own state (the ground-mode mesh_height look-up :821-825; the `texture named but not loaded yet` constant :839-843).
+	void eval_points_dev(float const *d_xy, uint32_t n, uint32_t kind, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *d_out) {
+		require_scene();
+		if (n == 0) return;
+		if (kind > 1) throw std::invalid_argument("eval_points: kind must be TERRA_POINTS_SCALED or TERRA_POINTS_EXACT");
+		noise_consts_t const nc = consts();
+		sin_lut_t const L = lut();
+		float const *st = sinTable_dev();
+		hmap_view_t const hv = hmap_view();
+		bool const hm = using_hmap(), hm_detail = using_hmap_with_detail();
+		int const md = mode, shp = shape, k0 = start_eval_sin;
+		float const half_x = (float)(cfg.mesh_x >> 1), half_y = (float)(cfg.mesh_y >> 1), xss = cfg.scene_x, yss = cfg.scene_y, dxi = DX_VAL_INV, dyi = DY_VAL_INV, msc = mesh_scale, mszi = mesh_scale_z_inv;
+		be.launch(n, [=] TERRA_LAMBDA (size_t i) {
+			auto const scaled = [&](float xval, float yval, float xys) -> float { // eval_mesh_sin_terms_scaled
+				float const xv = xys*(xval - half_x), yv = xys*(yval - half_y);
+				if (md != MGEN_SINE) {
+					switch (md) {
+					case MGEN_PERLIN:      return noise_zval<MGEN_PERLIN>(xv, yv, shp, nc);
+					case MGEN_DWARP_GPU:   return noise_zval<MGEN_DWARP_GPU>(xv, yv, shp, nc);
+					case MGEN_SIMPLEX_GPU: return noise_zval<MGEN_SIMPLEX_GPU>(xv, yv, shp, nc);
+					default:               return noise_zval<MGEN_SIMPLEX>(xv, yv, shp, nc);
+					}
+				}
+				float const ax = msc*xv, ay = msc*yv;
+				float zval = 0.0f; // eval_mesh_sin_terms (src/mesh_gen.cpp:797-805)
+				for (int k = k0; k < F_TABLE_SIZE; ++k) {float const *stk = st + 5*k; zval += stk[0]*L.SINF(stk[3]*ay + stk[1])*L.SINF(stk[4]*ax + stk[2]);}
+				return apply_noise_shape_final(zval*mszi, shp, nc.hp);
+			};
+			float const xin = d_xy[2*i], yin = d_xy[2*i + 1];
+			if (kind == 0) {d_out[i] = scaled(xin, yin, xy_scale); return;}
+			float xval = (float)((double)((xin + xss)*dxi) + 0.5), yval = (float)((double)((yin + yss)*dyi) + 0.5); // real -> index space, `+ 0.5` formed in double (src/mesh_gen.cpp:818-819)
+			if (!no_xyoff) {xval += (float)xoff2; yval += (float)yoff2;}
+			float zval;
+			if (hm) {
+				if (!no_xyoff) {xval = (float)((double)xval - 0.5); yval = (float)((double)yval - 0.5);}
+				zval = hv.interpolate_height(xval, yval);
+				if (hm_detail) {zval += 0.01f*scaled(xval, yval, 16.0f);} // HMAP_DETAIL_MAG, HMAP_DETAIL_SCALE (src/heightmap.h:8-9)
+			}
+			else {
+				zval = scaled(xval, yval, 1.0f);
+				if (nc.glaciate) {float const relh = (zval + nc.zmax_est)*nc.zmax_est2_inv; zval = glaciate_exp_fn(relh, nc.custom_glaciate_exp)*nc.zmax_est2 - nc.zmax_est;}
+				if (nc.hp.sine_mag > 0.0f) { // apply_mesh_sine (src/mesh_gen.cpp:373-379)
+					float const fx = xval - half_x, fy = yval - half_y, freq = nc.mesh_scale*nc.hp.sine_freq;
+					zval += (nc.hp.sine_mag*L.COSF(fx*freq)*L.COSF(fy*freq) + nc.hp.sine_bias)*nc.mesh_scale_z_inv;
+					if (nc.hp.volcano_width > 0.0f && nc.hp.volcano_height > 0.0f) {zval += volcano_height(fx, fy, nc, L);}
+				}
+			}
+			d_out[i] = zval;
+		});
+	}
+	void eval_points(float const *h_xy, uint32_t n, uint32_t kind, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *h_out) {
+		require_scene();
+		if (n == 0) return;
+		float *d = scratch<float>(s_misc, (size_t)n*3 + 64); // (sinTable_dev / consts use buffers of their own)
+		be.h2d(d, h_xy, (size_t)n*2*sizeof(float));
+		eval_points_dev(d, n, kind, xy_scale, no_xyoff, xoff2, yoff2, d + (size_t)n*2);
+		be.d2h(h_out, d + (size_t)n*2, (size_t)n*sizeof(float));
+	}
 	// glaciate() (src/mesh_gen.cpp:388-404): in-place apply_glaciate + apply_mesh_sine over a MESH_X x MESH_Y ground mesh; zbottom/ztop = min/max after
 	void glaciate_mesh_dev(float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop) {
 		require_scene();

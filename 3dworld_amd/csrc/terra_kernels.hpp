@@ -297,6 +297,21 @@ __global__ __launch_bounds__(256) void k_tile_land_cells(float const *__restrict
 	for (int off = 32; off > 0; off >>= 1) {cnt += __shfl_down(cnt, off, 64);}
 	if ((threadIdx.x & 63) == 0 && cnt) {atomicAdd(&land[blockIdx.x], cnt);}
 }
+// the stable descending order of the tiles by land count, without a sort: tile i goes to position #{j : land[j] > land[i]} + #{j < i : land[j] == land[i]}
+__global__ __launch_bounds__(256) void k_tile_order_by_land(uint32_t const *__restrict__ land, uint32_t n, uint32_t *__restrict__ order) {
+	__shared__ uint32_t s_land[256];
+	uint32_t const i = blockIdx.x*256 + threadIdx.x;
+	uint32_t const mine = (i < n) ? land[i] : 0u;
+	uint32_t pos = 0;
+	for (uint32_t j0 = 0; j0 < n; j0 += 256) {
+		__syncthreads();
+		s_land[threadIdx.x] = (j0 + threadIdx.x < n) ? land[j0 + threadIdx.x] : 0u;
+		__syncthreads();
+		uint32_t const cnt = (n - j0 < 256u) ? n - j0 : 256u;
+		for (uint32_t e = 0; e < cnt; ++e) {uint32_t const l = s_land[e]; pos += (l > mine || (l == mine && j0 + e < i)) ? 1u : 0u;}
+	}
+	if (i < n) {order[pos] = i;}
+}
 // `order` (or null): the tile each block takes.  Blocks are dispatched in index order and only two tiles fit a CU, so the batch is a list-scheduling
 // problem: handing out the longest chains first keeps the heavy land tiles from forming the tail of the launch.
 __global__ __launch_bounds__(64) void k_tile_erosion(float *__restrict__ zvals, erosion_consts_t ec, uint32_t iters, uint32_t const *__restrict__ order, uint32_t const *__restrict__ land) {

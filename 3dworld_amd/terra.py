@@ -106,6 +106,8 @@ _PROTOS = {
     "terra_set_stream": (_i32, [_vp, _vp]),
     "terra_synchronize": (_i32, [_vp]),
     "terra_set_option": (_i32, [_vp, C.c_char_p, C.c_char_p]),
+    "terra_eval_points": (_i32, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_float, _i32, _i32, _i32, _vp]),
+    "terra_eval_points_dev": (_i32, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_float, _i32, _i32, _i32, _vp]),
     "terra_host_alloc": (_vp, [_sz]),
     "terra_host_free": (None, [_vp]),
     "terra_download_async": (_i32, [_vp, _vp, _vp, _sz]),
@@ -589,6 +591,16 @@ class Terra:
         self._ck(self.lib.terra_gen_grid_rows_minmax_dev(self.ctx, x0, y0, dx, dy, nx, ny, flags, min_start_sin, row0, nrows, ptr,
                                                          C.byref(mn) if want_minmax else None, C.byref(mx) if want_minmax else None))
         return (mn.value, mx.value) if want_minmax else None
+
+    def eval_points(self, xy, exact, xy_scale=1.0, no_xyoff=False, xoff2=0, yoff2=0):
+        """terra_eval_points: eval_mesh_sin_terms_scaled (exact=False) / get_exact_zval (exact=True) for the points xy[n][2]"""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.empty(len(xy), np.float32)
+        self._ck(self.lib.terra_eval_points(self.ctx, xy.ctypes.data, len(xy), 1 if exact else 0, xy_scale, int(bool(no_xyoff)), xoff2, yoff2, out.ctypes.data))
+        return out
+
+    def eval_points_dev(self, xy_ptr, n, out_ptr, exact, xy_scale=1.0, no_xyoff=False, xoff2=0, yoff2=0):
+        self._ck(self.lib.terra_eval_points_dev(self.ctx, xy_ptr, n, 1 if exact else 0, xy_scale, int(bool(no_xyoff)), xoff2, yoff2, out_ptr))
 
     def eval_mesh_sin_terms(self, xv, yv):
         out = C.c_float()

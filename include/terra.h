@@ -244,6 +244,18 @@ int  terra_gen_grid_rows_minmax_async_dev(terra_ctx *ctx, float x0, float y0, fl
  * glaciate() (src/mesh_gen.cpp:388-404): in-place apply_glaciate + apply_mesh_sine over the MESH_X x MESH_Y ground mesh (xoff2/yoff2 = scroll offsets);
  * h_zbottom_ztop (optional) receives {zbottom, ztop}. */
 int  terra_eval_mesh_sin_terms(terra_ctx *ctx, float xv, float yv, float *out);
+/* The all-modes point queries, batched (n points, xy[2 i] = x, xy[2 i + 1] = y), evaluated on the device:
+ *   TERRA_POINTS_SCALED  out[i] = eval_mesh_sin_terms_scaled(x, y, xy_scale) (src/mesh_gen.cpp:807-813): index-space coordinates; sine mode = the sine sum scaled and shaped,
+ *                        the fBm modes go to get_noise_zval (the detail noise of heightmap tiles src/tiled_mesh.cpp:499-503, density fields)
+ *   TERRA_POINTS_EXACT   out[i] = get_exact_zval(x, y, no_xyoff) (src/mesh_gen.cpp:816-847): world-space point -> index space (+ xoff2 / yoff2, the reference's scroll-offset
+ *                        globals, unless no_xyoff) -> the heightmap texture (+ detail noise) when terra_hmap_set_dev gave one, else noise + apply_glaciate +
+ *                        apply_mesh_sine (islands, volcano).  What collision / building placement / biome code calls (src/tiled_mesh.cpp:332-338, src/voxels.cpp:434).
+ * Not covered: get_exact_zval's two branches that only read the caller's state -- the ground-mode mesh_height[][] look-up (:821-825) and the constant returned while a named
+ * texture is not loaded yet (:839-843).  xy_scale is ignored by TERRA_POINTS_EXACT; no_xyoff / xoff2 / yoff2 by TERRA_POINTS_SCALED. */
+#define TERRA_POINTS_SCALED 0u
+#define TERRA_POINTS_EXACT  1u
+int  terra_eval_points(terra_ctx *ctx, const float *xy, uint32_t n, uint32_t kind, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *out);
+int  terra_eval_points_dev(terra_ctx *ctx, const float *d_xy, uint32_t n, uint32_t kind, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *d_out);
 int  terra_glaciate_mesh_dev(terra_ctx *ctx, float *d_mesh, uint32_t nx, uint32_t ny, int xoff2, int yoff2, float *h_zbottom_ztop);
 
 /* ---- erosion: apply_erosion (src/erosion.cpp:14).  In place; silently returns TERRA_OK when num_iters == 0 or erode_amount <= 0.

@@ -346,6 +346,14 @@ REF_API void ref_apply_erosion(float *hmap, int xsize, int ysize, float min_zval
 REF_API float ref_get_noise_zval(float x, float y, int mode, int shape) {return get_noise_zval(x, y, mode, shape);}
 REF_API float ref_gen_noise(float x, float y, int mode, int shape) {return gen_noise(x, y, mode, shape);}
 REF_API float ref_eval_mesh_sin_terms(float x, float y) {return eval_mesh_sin_terms(x, y);}
+float eval_mesh_sin_terms_scaled(float xval, float yval, float xy_scale); // src/mesh_gen.cpp:807
+float get_exact_zval(float xval, float yval, bool no_xyoff);               // src/mesh_gen.cpp:816
+REF_API void ref_eval_points(float const *xy, unsigned n, int exact, float xy_scale, int no_xyoff, int xo2, int yo2, float *out) { // the reference's own functions, its own scroll-offset globals
+	int const sx(xoff2), sy(yoff2);
+	xoff2 = xo2; yoff2 = yo2;
+	for (unsigned i = 0; i < n; ++i) {out[i] = (exact ? get_exact_zval(xy[2*i], xy[2*i+1], (no_xyoff != 0)) : eval_mesh_sin_terms_scaled(xy[2*i], xy[2*i+1], xy_scale));}
+	xoff2 = sx; yoff2 = sy;
+}
 REF_API float ref_glm_simplex2(float x, float y) {return glm::simplex(glm::vec2(x, y));}
 REF_API float ref_glm_perlin2 (float x, float y) {return glm::perlin (glm::vec2(x, y));}
 REF_API float ref_glm_simplex3(float x, float y, float z) {return glm::simplex(glm::vec3(x, y, z));}

@@ -1053,6 +1053,36 @@ int orc_hmap_read_and_apply_mod(char const *fn) { /* src/heightmap.cpp:424-440 *
 static int using_hmap(void) {return hm_data != NULL;}                                   /* using_tiled_terrain_hmap_tex, src/tiled_mesh.cpp:273 */
 static int using_hmap_with_detail(void) {return using_hmap() && mesh_scale < 0.75f;}   /* src/tiled_mesh.cpp:274 */
 static float get_xy_scale(void) {int const add_detail = using_hmap_with_detail(); if (!add_detail && using_hmap()) return 0.0f; return add_detail ? HMAP_DETAIL_SCALE : 1.0f;} /* src/tiled_mesh.cpp:447-451 */
+/* a8, the all-modes point queries.  eval_mesh_sin_terms_scaled (src/mesh_gen.cpp:807-813): index-space coordinates, the noise modes go to get_noise_zval */
+static float eval_mesh_sin_terms_scaled(float xval, float yval, float xy_scale) {
+	float const xv = xy_scale*(xval - (float)(MESH_X_SIZE >> 1)), yv = xy_scale*(yval - (float)(MESH_Y_SIZE >> 1));
+	if (mesh_gen_mode != ORC_MGEN_SINE) {return get_noise_zval(xv, yv, mesh_gen_mode, mesh_gen_shape);}
+	float val = eval_mesh_sin_terms(mesh_scale*xv, mesh_scale*yv)*mesh_scale_z_inv;
+	apply_noise_shape_final(&val, mesh_gen_shape);
+	return val;
+}
+/* get_exact_zval (src/mesh_gen.cpp:816-847), tiled-terrain world: world-space point -> index space (+ the scroll offset xoff2 / yoff2 unless no_xyoff) -> the heightmap
+ * texture (+ detail noise) when one is set, else noise + glaciate + the island term.  The two branches that only read caller state are not restated: the ground-mode mesh
+ * look-up (:821-825, an array read) and the `texture named but not loaded yet` constant (:839-843). */
+static float get_exact_zval(float xval_in, float yval_in, int no_xyoff, int xoff2, int yoff2) {
+	float xval = (float)((double)((xval_in + X_SCENE_SIZE)*DX_VAL_INV) + 0.5); /* `+ 0.5` is a double literal: the sum is formed in double, then stored to float */
+	float yval = (float)((double)((yval_in + Y_SCENE_SIZE)*DY_VAL_INV) + 0.5);
+	if (!no_xyoff) {xval += (float)xoff2; yval += (float)yoff2;}
+	if (using_hmap()) {
+		if (!no_xyoff) {xval = (float)((double)xval - 0.5); yval = (float)((double)yval - 0.5);}
+		float zval = hm_interpolate_height(xval, yval);
+		if (using_hmap_with_detail()) {zval += HMAP_DETAIL_MAG*eval_mesh_sin_terms_scaled(xval, yval, HMAP_DETAIL_SCALE);}
+		return zval;
+	}
+	float zval = eval_mesh_sin_terms_scaled(xval, yval, 1.0f);
+	apply_glaciate(&zval);
+	apply_mesh_sine(&zval, (xval - (float)(MESH_X_SIZE >> 1)), (yval - (float)(MESH_Y_SIZE >> 1)));
+	return zval;
+}
+void orc_eval_points(float const *xy, unsigned n, int exact, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *out) {
+	for (unsigned i = 0; i < n; ++i) {out[i] = exact ? get_exact_zval(xy[2*i], xy[2*i + 1], no_xyoff, xoff2, yoff2) : eval_mesh_sin_terms_scaled(xy[2*i], xy[2*i + 1], xy_scale);}
+}
+
 
 /* enable_tiled_mesh_ao (src/3DWorld.cpp:73,1778): config flag read by the tile code */
 static int enable_tiled_mesh_ao = 0;

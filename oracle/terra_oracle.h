@@ -74,6 +74,8 @@ void  orc_apply_erosion_stats(float *hmap, int xsize, int ysize, float min_zval,
 float orc_get_noise_zval(float x, float y, int mode, int shape);
 float orc_gen_noise(float x, float y, int mode, int shape);
 float orc_eval_mesh_sin_terms(float x, float y);
+/* eval_mesh_sin_terms_scaled (exact = 0) / get_exact_zval (exact = 1) for n points xy[2 i], xy[2 i + 1] (src/mesh_gen.cpp:807-847) */
+void  orc_eval_points(float const *xy, unsigned n, int exact, float xy_scale, int no_xyoff, int xoff2, int yoff2, float *out);
 float orc_glm_simplex2(float x, float y);
 float orc_glm_perlin2(float x, float y);
 float orc_glm_simplex3(float x, float y, float z);

@@ -163,6 +163,7 @@ class Checker:
         f("get_noise_zval", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
         f("gen_noise", C.c_float, [C.c_float, C.c_float, C.c_int, C.c_int])
         f("eval_mesh_sin_terms", C.c_float, [C.c_float, C.c_float])
+        f("eval_points", None, [C.c_void_p, C.c_uint, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p])
         f("glm_simplex2", C.c_float, [C.c_float] * 2)
         f("glm_perlin2", C.c_float, [C.c_float] * 2)
         f("glm_simplex3", C.c_float, [C.c_float] * 3)
@@ -287,6 +288,13 @@ class Checker:
     def noise_zval(self, x, y, mode, shape=0): return self._get_noise_zval(x, y, mode, shape)
     def gen_noise(self, x, y, mode, shape=0): return self._gen_noise(x, y, mode, shape)
     def eval_mesh_sin_terms(self, x, y): return self._eval_mesh_sin_terms(x, y)
+
+    def eval_points(self, xy, exact, xy_scale=1.0, no_xyoff=False, xoff2=0, yoff2=0):
+        """eval_mesh_sin_terms_scaled (exact=False) / get_exact_zval (exact=True) for the points xy[n][2] (src/mesh_gen.cpp:807-847)"""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.empty(len(xy), np.float32)
+        self._eval_points(xy.ctypes.data, len(xy), int(bool(exact)), xy_scale, int(bool(no_xyoff)), xoff2, yoff2, out.ctypes.data)
+        return out
     def simplex2(self, x, y): return self._glm_simplex2(x, y)
     def perlin2(self, x, y): return self._glm_perlin2(x, y)
     def simplex3(self, x, y, z): return self._glm_simplex3(x, y, z)

@@ -1592,3 +1592,50 @@ def case_fast_mode(pkg, t, orc, sizes=((260, 150), (129, 131), (1, 1), (1000, 51
     finally:
         t.set_option("gen.fused", "0")
     return worst
+
+
+def points_sample(n, seed, span):
+    """n query points: random ones over +-span, plus a lattice of exact half / whole cell positions and the origin (where the index-space conversion rounds)"""
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-span, span, (n, 2)).astype(np.float32)
+    xy[:9] = [(0, 0), (0.03125, -0.03125), (-4, -4), (4, 4), (3.96875, -3.96875), (1e-3, 2e-3), (-17.5, 33.25), (100.0, -250.0), (0.015625, 0.046875)]
+    return xy
+
+
+def case_eval_points(pkg, t, chk, n=600):
+    """terra_eval_points: eval_mesh_sin_terms_scaled and get_exact_zval in all five noise modes (+ shapes, custom glaciate exponent, islands / volcano), with and without the
+    scroll offset, and the heightmap-texture branch with and without the detail noise -- against `chk` (the restatement, or the compiled reference itself)"""
+    vol = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 1200.0, 4.0]
+    cases = [dict(mesh_gen_mode=0), dict(mesh_gen_mode=0, mesh_gen_shape=1, mesh_freq_filter=1), dict(mesh_gen_mode=1), dict(mesh_gen_mode=2, mesh_gen_shape=2), dict(mesh_gen_mode=3),
+             dict(mesh_gen_mode=4), dict(mesh_gen_mode=0, hmap=vol), dict(mesh_gen_mode=1, custom_glaciate_exp=2.5), dict(mesh_gen_mode=0, glaciate=0), dict(mesh_gen_mode=2, mesh_scale=0.5)]
+    for kw in cases:
+        pc_, oc = cfg_pair(pkg, **kw)
+        t.init_scene(pc_); chk.init(oc)
+        xy = points_sample(n, 3, 40.0)
+        for (nox, xo, yo) in ((False, 0, 0), (False, 137, -4021), (True, 55, 66)):
+            assert_bit_equal(chk.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), t.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), f"get_exact_zval {kw} no_xyoff {nox} off {xo},{yo}")
+        ixy = points_sample(n, 4, 300.0)
+        for sc in (1.0, 16.0, 0.37):
+            assert_bit_equal(chk.eval_points(ixy, False, xy_scale=sc), t.eval_points(ixy, False, xy_scale=sc), f"eval_mesh_sin_terms_scaled {kw} xy_scale {sc}")
+    # the heightmap-texture branch (using_tiled_terrain_hmap_tex): bilinear texel look-up, + HMAP_DETAIL_MAG * detail noise below mesh_scale 0.75
+    s0 = chk.init(orclib.make_config(mesh_gen_mode=0))
+    g = chk.gen_grid(-96, -96, s0.DX_VAL, s0.DY_VAL, 192, 192, 1)
+    q, mn, dz = chk.quantize16(g)
+    pix16 = np.ascontiguousarray(q.reshape(192, 192, 2))
+    dzs = float(np.float32(np.float64(dz) / 255.0))
+    buf = None
+    try:
+        for mesh_scale, mode in ((1.0, 0), (0.5, 0), (0.6, 1), (2.0, 2)):
+            pc_, oc = cfg_pair(pkg, mesh_gen_mode=mode, mesh_scale=mesh_scale)
+            t.init_scene(pc_); chk.init(oc)
+            if buf is None:
+                buf = t.alloc(pix16.nbytes).upload(pix16)
+            t.hmap_set_dev(buf.ptr, 192, 192, 2, float(mn), dzs); chk.hmap_set(pix16, float(mn), dzs)
+            xy = points_sample(n, 5, 12.0)
+            for (nox, xo, yo) in ((False, 0, 0), (False, -31, 77), (True, 0, 0)):
+                assert_bit_equal(chk.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), t.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), f"get_exact_zval on a heightmap texture, mesh_scale {mesh_scale} mode {mode}")
+    finally:
+        t.hmap_set_dev(None); chk.hmap_set(None)
+        if buf is not None:
+            buf.free()
+    assert len(t.eval_points(np.zeros((0, 2), np.float32), True)) == 0

@@ -165,6 +165,11 @@ def test_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs):
     pc.case_voxel_slabs(pkg, gpu, orc, gen_mode, shape, nslabs)
 
 
+def test_eval_points_all_modes(pkg, gpu, orc):
+    """terra_eval_points (a8: eval_mesh_sin_terms_scaled + get_exact_zval), every mode and branch, bit-exact"""
+    pc.case_eval_points(pkg, gpu, orc)
+
+
 def test_ground_mesh_and_point_queries(pkg, gpu, orc):
     pc.case_ground_mesh_and_point_queries(pkg, gpu, orc)
 

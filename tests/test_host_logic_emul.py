@@ -211,6 +211,10 @@ def test_ground_mesh_and_point_queries(pkg, emul, orc):
     pc.case_ground_mesh_and_point_queries(pkg, emul, orc)
 
 
+def test_eval_points_all_modes(pkg, emul, orc):
+    pc.case_eval_points(pkg, emul, orc, n=200)
+
+
 def test_mesh_text_file_read_write(pkg, emul, orc, tmp_path):
     pc.case_mesh_text_file(pkg, emul, orc, tmp_path)
 

@@ -348,6 +348,35 @@ def test_oracle_vs_reference_hmap_tiles(orc, ref):
         ref.hmap_set(None); orc.hmap_set(None)
 
 
+def test_oracle_vs_reference_point_queries(orc, ref):
+    """a8: eval_mesh_sin_terms_scaled / get_exact_zval of the restatement against the reference's own functions (src/mesh_gen.cpp:807-847, compiled in place), all noise
+    modes, scroll offsets, the heightmap-texture branch with and without detail noise"""
+    import parity_cases as pc
+    ref.set_num_threads(1)
+    vol = [1000.0, 0, 0, 0, 1000.0, 0, 0, 0, 0, 5.0, 0.001, -4.0, 1200.0, 4.0]
+    for kw in (dict(mesh_gen_mode=0), dict(mesh_gen_mode=0, mesh_gen_shape=1, mesh_freq_filter=1), dict(mesh_gen_mode=1), dict(mesh_gen_mode=2, mesh_gen_shape=2), dict(mesh_gen_mode=3),
+               dict(mesh_gen_mode=4), dict(mesh_gen_mode=0, hmap=vol), dict(mesh_gen_mode=1, custom_glaciate_exp=2.5), dict(mesh_gen_mode=0, glaciate=0), dict(mesh_gen_mode=2, mesh_scale=0.5)):
+        cfg = orclib.make_config(**kw)
+        ref.init(cfg); orc.init(cfg)
+        xy = pc.points_sample(400, 3, 40.0)
+        for (nox, xo, yo) in ((False, 0, 0), (False, 137, -4021), (True, 55, 66)):
+            assert_bit_equal(ref.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), orc.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), f"get_exact_zval {kw} {nox} {xo} {yo}")
+        ixy = pc.points_sample(400, 4, 300.0)
+        for sc in (1.0, 16.0, 0.37):
+            assert_bit_equal(ref.eval_points(ixy, False, xy_scale=sc), orc.eval_points(ixy, False, xy_scale=sc), f"eval_mesh_sin_terms_scaled {kw} {sc}")
+    pix, mn, dzs = _hmap_pixels(ref)
+    try:
+        for mesh_scale, mode in ((1.0, 0), (0.5, 0), (0.6, 1), (2.0, 2)):
+            cfg = orclib.make_config(mesh_gen_mode=mode, mesh_scale=mesh_scale)
+            ref.init(cfg); orc.init(cfg)
+            ref.hmap_set(pix, mn, dzs); orc.hmap_set(pix, mn, dzs)
+            xy = pc.points_sample(400, 5, 12.0)
+            for (nox, xo, yo) in ((False, 0, 0), (False, -31, 77), (True, 0, 0)):
+                assert_bit_equal(ref.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), orc.eval_points(xy, True, no_xyoff=nox, xoff2=xo, yoff2=yo), f"hmap texture points scale {mesh_scale} mode {mode}")
+    finally:
+        ref.hmap_set(None); orc.hmap_set(None)
+
+
 LIGHTS = [(0.6, 0.5, 0.4), (-0.8, 0.3, 0.25), (0.2, -0.9, 0.15), (-0.5, -0.5, 0.8), (1.0, 0.0, 0.3), (0.0, -1.0, 0.2), (0.3, 0.4, -5.0), (0.0, 0.0, 1.0), (0.05, 0.9, 0.02)]
 
 
