@@ -1671,7 +1671,8 @@ template<class BE> struct terra_engine {
 			float const xv = msc*(xp ? xv2 : xv1) + bxo, yv = msc*(yp ? yv2 : yv1);
 			float const mult = which ? 1.0f : 5.0f; // dirt_mult, veg_mult
 			float const ax = mult*xv, ay = mult*yv;
-			float zval = 0.0f; // eval_mesh_sin_terms (src/mesh_gen.cpp:797-805)
+			float zval = 0.0f; // eval_mesh_sin_terms (src/mesh_gen.cpp:797-805); the terms are independent up to the final chain of adds: eight of them (their table look-ups) in flight at once
+#pragma unroll 8
 			for (int k = k0; k < F_TABLE_SIZE; ++k) {
 				float const *stk = d_st + 5*k;
 				zval += stk[0]*L.SINF(stk[3]*ay + stk[1])*L.SINF(stk[4]*ax + stk[2]);
@@ -1722,7 +1723,11 @@ template<class BE> struct terra_engine {
 		be.fill8(d_any, 0, n);
 		uint32_t *d_w32 = (uint32_t *)d_weights; // n*129*129*4 bytes from a device allocation: 4-byte aligned
 		if (((uintptr_t)d_weights & 3u) != 0) throw std::invalid_argument("tiles_create_weights: d_weights must be 4-byte aligned");
-		be.launch(ntex, [=] TERRA_LAMBDA (size_t i) {
+		if (!opt.weights_simple && be.tile_weights(c, d_refs, n, d_zvals, d_rand, d_params, d_w32, d_blocks, d_any)) { // k_tile_weights: texels + grass blocks in one launch
+			if (d_has_grass) {be.launch(n, [=] TERRA_LAMBDA (size_t i) {d_has_grass[i] = d_any[i];});}
+			return;
+		}
+		be.launch(ntex, [=] TERRA_LAMBDA (size_t i) { // the per-texel form ("weights.simple": cross-check; the emulator)
 			unsigned const t = (unsigned)(i / (ts*ts)), p = (unsigned)(i % (ts*ts)), y = p / ts, x = p % ts;
 			unsigned flags;
 			d_w32[i] = weights_texel(c, d_zvals + (size_t)t*zv*zv, d_params + (size_t)t*12, d_rand[i], x, y, flags);

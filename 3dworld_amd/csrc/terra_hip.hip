@@ -459,6 +459,13 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		}
 		quantize16_simple(vals + n8*8, n - n8*8, val_add, val_div, pix + n8*16); // the tail (or everything, unaligned / cross-check)
 	}
+	bool tile_weights(terra::landscape_consts_t const &c, terra::tile_ref_pod_t const *refs, uint32_t n, float const *zvals, float const *noise, float const *params, uint32_t *w32, terra::grass_block_pod_t *blocks, uint8_t *any_grass) {
+		if (simple_kernels || (uint64_t)n*terra::WK_BANDS > 0x7FFFFFFFull) return false;
+		use();
+		hipLaunchKernelGGL(terra::k_tile_weights, dim3(n*terra::WK_BANDS), dim3(256), 0, stream, c, refs, zvals, noise, params, w32, blocks, any_grass);
+		TERRA_HIP_CHECK(hipGetLastError());
+		return true;
+	}
 	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool fused) {
 		if (simple_kernels) {voxel_noise_simple(out, nvox, J, perlin); return;}
 		if (nvox == 0) return;

@@ -705,6 +705,56 @@ __global__ __launch_bounds__(256) void k_minmax(float const *__restrict__ vals, 
 	wave_minmax_publish(mlo, mhi, d);
 }
 
+// ------------------------------------------------------------------ f3: landscape weights texture (tile_t::create_texture, src/tiled_mesh.cpp:1071-1240) + grass blocks
+// One block per 32-row band of a tile (the fourth band takes row 128 as well): the band's 33 / 34 height rows are staged in LDS once -- a texel reads its cell's four corners
+// from there -- the texels are walked in linear order (consecutive lanes = consecutive texels: the noise field is read and the RGBA words are written in full lines), and the
+// band's 8 x 32 grass blocks (add_grass_block_at, src/tiled_mesh.cpp:1354-1371) are folded from the flags the texels left in LDS: no flag array in HBM, no second launch.
+constexpr uint32_t WK_BAND = 32, WK_BANDS = 4;
+__global__ __launch_bounds__(256) void k_tile_weights(landscape_consts_t c, tile_ref_pod_t const *__restrict__ refs, float const *__restrict__ zvals, float const *__restrict__ noise,
+	float const *__restrict__ params, uint32_t *__restrict__ w32, grass_block_pod_t *__restrict__ blocks, uint8_t *__restrict__ any_grass)
+{
+	__shared__ float s_z[(WK_BAND + 2)*WT_ZV];
+	__shared__ uint8_t s_flag[(WK_BAND + 1)*WT_TEX + 3];
+	uint32_t const t = blockIdx.x/WK_BANDS, band = blockIdx.x % WK_BANDS, y0 = band*WK_BAND, rows = (band == WK_BANDS - 1) ? WK_BAND + 1 : WK_BAND;
+	float const *zt = zvals + (size_t)t*WT_ZV*WT_ZV + (size_t)y0*WT_ZV;
+	for (uint32_t i = threadIdx.x; i < (rows + 1)*WT_ZV; i += 256) {s_z[i] = zt[i];}
+	biome_corners_t bio;
+#pragma unroll
+	for (int k = 0; k < 12; ++k) {bio.v[k] = params[(size_t)t*12 + k];} // (block-uniform: scalar loads)
+	__syncthreads();
+	size_t const tex0 = (size_t)t*WT_TEX*WT_TEX + (size_t)y0*WT_TEX;
+	bool grass_here = false;
+	for (uint32_t p = threadIdx.x; p < rows*WT_TEX; p += 256) {
+		uint32_t const yy = p/WT_TEX, x = p - yy*WT_TEX;
+		float const *zc = s_z + yy*WT_ZV + x;
+		unsigned flags;
+		w32[tex0 + p] = weights_texel_v(c, corner_heights_t{zc[0], zc[1], zc[WT_ZV], zc[WT_ZV + 1]}, bio, noise[tex0 + p], x, y0 + yy, flags);
+		s_flag[p] = (uint8_t)flags;
+		grass_here |= (flags & 1u) != 0;
+	}
+	if (grass_here) {any_grass[t] = 1;} // has_any_grass: every writer stores the same value
+	if (!blocks) return;
+	__syncthreads();
+	// the band's grass blocks: 8 rows of 32 blocks of 4 x 4 texels = one per thread, texels in the reference's row-major order (the first contributor picks the block's ix)
+	uint32_t const bx = threadIdx.x & 31u, byl = threadIdx.x >> 5;
+	tile_ref_pod_t const r = refs[t];
+	grass_block_pod_t gb = {0u, 0.0f, 0.0f};
+	for (uint32_t yy = byl*GRASS_BLOCK_SZ; yy < (byl + 1)*GRASS_BLOCK_SZ; ++yy) {
+		for (uint32_t x = bx*GRASS_BLOCK_SZ; x < (bx + 1)*GRASS_BLOCK_SZ; ++x) {
+			if (!(s_flag[yy*WT_TEX + x] & 2u)) continue;
+			float const *zc = s_z + yy*WT_ZV + x;
+			corner_heights_t const h{zc[0], zc[1], zc[WT_ZV], zc[WT_ZV + 1]};
+			float const lowest = min4_std(h), highest = max4_std(h);
+			if (gb.ix == 0) {
+				gb.ix = ((((uint32_t)(r.tx*128) + x) + 1567u*((uint32_t)(r.ty*128) + y0 + yy)) % c.num_rnd_grass_blocks) + 1; // int + unsigned: unsigned arithmetic
+				gb.zmin = lowest; gb.zmax = highest;
+			}
+			else {gb.zmin = min_std(gb.zmin, lowest); gb.zmax = max_std(gb.zmax, highest);}
+		}
+	}
+	blocks[(size_t)t*GRASS_BLOCK_DIM*GRASS_BLOCK_DIM + (size_t)(band*(WK_BAND/GRASS_BLOCK_SZ) + byl)*GRASS_BLOCK_DIM + bx] = gb;
+}
+
 // ------------------------------------------------------------------ K10: 16-bit quantise (heightmap_t::from_floats + write_pixel_16_bits, src/heightmap.cpp:205-215, src/Textures.cpp:1889-1893)
 // HBM-bound, 4 B read + 2 B written per cell: eight cells per thread = two 16-byte loads and one 16-byte store of {fraction, integer} byte pairs
 __device__ __forceinline__ uint32_t q16_pair(float z, float val_add, float val_div) {

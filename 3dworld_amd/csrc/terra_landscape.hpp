@@ -43,74 +43,102 @@ TERRA_HD void get_tids(landscape_consts_t const &c, float relh, int &k1, int &k2
 		k2 = k1;
 	}
 }
-TERRA_HD float bilinear_param(float const *prm, int var, float x, float y) { // BILINEAR_INTERP (src/tiled_mesh.cpp:189), prm[yp][xp][{veg, grass, dirt}]
-	float const a00 = prm[var], a01 = prm[3 + var], a10 = prm[6 + var], a11 = prm[9 + var];
-	return y*(x*a11 + (1.0f - x)*a10) + (1.0f - y)*(x*a01 + (1.0f - x)*a00);
+// ---- one texel.  The reference's per-texel body (src/tiled_mesh.cpp:1146-1200) is a long straight run of statements; here it is cut along what a texel can BE:
+//   * a texel whose four corner heights fall into ONE layer that is neither grass nor snow (sea floor, beaches, bare dirt / rock bands: most of an ocean tile) has a
+//     one-hot weight vector -- nothing to blend, no slope, no double arithmetic; only dirt under vegetation still asks the biome field for its sand share;
+//   * everything else goes through blend_texel(), which evaluates the reference's statements in their order with their float / double promotions.
+// Both give the bytes of the reference's statements (the one-hot case is those statements with t = 0, weight_scale = 1 folded: 0 + 1.0*(1.0 - 0.0) = 1, the other sums 0).
+struct corner_heights_t {float z00, z01, z10, z11;}; // the texel's cell: (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1)
+struct biome_corners_t {float v[12];};               // update_terrain_params: [yp][xp][{vegetation, grass, dirt}] at the tile's corners
+TERRA_HD float biome_at(biome_corners_t const &b, int which, float fx, float fy) { // BILINEAR_INTERP (src/tiled_mesh.cpp:189)
+	float const p00 = b.v[which], p01 = b.v[3 + which], p10 = b.v[6 + which], p11 = b.v[9 + which];
+	return fy*(fx*p11 + (1.0f - fx)*p10) + (1.0f - fy)*(fx*p01 + (1.0f - fx)*p00);
 }
-TERRA_HD float weight_add(float w, double v) {return (float)((double)w + v);} // "float += double expression"
-TERRA_HD uint32_t weight_to_u8(float w) {return ((double)w <= 0.01) ? 0u : (((double)w >= 0.99) ? 255u : (uint32_t)(unsigned char)(255.0*(double)w));}
+TERRA_HD float add_dbl(float w, double v) {return (float)((double)w + v);} // a float accumulator taking a double expression
+TERRA_HD uint32_t weight_byte(float w) {return ((double)w <= 0.01) ? 0u : (((double)w >= 0.99) ? 255u : (uint32_t)(unsigned char)(255.0*(double)w));}
+TERRA_HD uint32_t pack_weights(float const (&w)[5]) {return weight_byte(w[0]) | (weight_byte(w[1]) << 8) | (weight_byte(w[2]) << 16) | (weight_byte(w[3]) << 24);} // (snow is the remainder)
+TERRA_HD float min4_std(corner_heights_t const &h) {return min_std(min_std(h.z00, h.z01), min_std(h.z10, h.z11));}
+TERRA_HD float max4_std(corner_heights_t const &h) {return max_std(max_std(h.z00, h.z01), max_std(h.z10, h.z11));}
 
-// one texel (x, y) of the 129x129 weights texture; returns RGBA packed little-endian.  flags: bit 0 = grass (has_any_grass), bit 1 = contributes to its grass block
-TERRA_HD uint32_t weights_texel(landscape_consts_t const &c, float const *zvals /*130x130*/, float const *prm /*12*/, float rand_val, unsigned x, unsigned y, unsigned &flags) {
-	unsigned const ix = y*WT_ZV + x;
-	float weights[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-	float const mh00 = zvals[ix], mh01 = zvals[ix+1], mh10 = zvals[ix+WT_ZV], mh11 = zvals[ix+WT_ZV+1];
-	float const mhmin = min_std(min_std(mh00, mh01), min_std(mh10, mh11)), mhmax = max_std(max_std(mh00, mh01), max_std(mh10, mh11));
-	float const rand_offset = c.noise_scale*rand_val;
-	float const relh1 = c.relh_adj_tex + (mhmin - c.zmin)*c.dz_inv + rand_offset, relh2 = c.relh_adj_tex + (mhmax - c.zmin)*c.dz_inv + rand_offset;
-	int k1, k2, k3, k4;
-	get_tids(c, relh1, k1, k2, nullptr);
-	get_tids(c, relh2, k3, k4, nullptr);
-	bool const same_tid = (k1 == k4);
-	float t = 0.0f;
-	k2 = k4;
-	if (!same_tid) {
-		float const relh = c.relh_adj_tex + (mh00 - c.zmin)*c.dz_inv;
-		get_tids(c, relh, k1, k2, &t);
-	}
-	float weight_scale = 1.0f;
-	bool const grass = (k1 == LT_GROUND || k2 == LT_GROUND), snow = (k2 == LT_SNOW);
-	flags = grass ? 1u : 0u;
-	if (grass || snow) {
-		float const st0 = sthresh_v(snow, 0), st1 = sthresh_v(snow, 1);
-		float const nx = c.DY_VAL*(mh00 - mh01), ny = c.DX_VAL*(mh00 - mh10), nz = c.dxdy; // get_norm_not_normalized (src/tiled_mesh.h:281)
-		float vnz = c.vnz_scale*nz/sqrtf(nx*nx + ny*ny + nz*nz);
-		if (grass && vnz > st1) {vnz = clip01(1.0f + 20.0f*rand_offset);}
-		if (vnz < st1) { // steep slopes: dirt / rock replaces grass, rock replaces snow
-			if (grass) {
-				float rock_weight = (k1 == LT_GROUND || k2 == LT_ROCK) ? t : 0.0f;
-				float const steepness = (float)(1.0 - (double)clip01((vnz - 0.5f*st0)*c.steep_mult_rock));
-				rock_weight  = (float)((double)rock_weight*(1.0 - (double)steepness) + (double)steepness);
-				weight_scale = clip01((vnz - st0)*c.steep_mult_grass);
-				weights[LT_ROCK] = weight_add(weights[LT_ROCK], (1.0 - (double)weight_scale)*(double)rock_weight);
-				weights[LT_DIRT] = weight_add(weights[LT_DIRT], (1.0 - (double)weight_scale)*(1.0 - (double)rock_weight));
-			}
-			else {
-				weight_scale = clip01(2.0f*(vnz - st0)*c.steep_mult_snow);
-				weights[LT_ROCK] = weight_add(weights[LT_ROCK], 1.0 - (double)weight_scale);
-			}
-		}
-	}
-	weights[k2] += weight_scale*t;
-	weights[k1] = weight_add(weights[k1], (double)weight_scale*(1.0 - (double)t));
-	float const xy_mult = 1.0f/128.0f, xv = (float)x*xy_mult, yv = (float)y*xy_mult;
-	if (c.vegetation > 0.0f) { // convert dirt to sand only when there is vegetation
-		float const dirt_scale = bilinear_param(prm, 2, xv, yv);
-		if (dirt_scale < 1.0f) {
-			weights[LT_SAND] = weight_add(weights[LT_SAND], (1.0 - (double)dirt_scale)*(double)weights[LT_DIRT]);
-			weights[LT_DIRT] *= dirt_scale;
-		}
+// sand taken out of dirt (where the biome's dirt share is below one) and out of grass (biome's grass share, none under water); sets flag bit 1 when the texel feeds a grass block
+TERRA_HD void biome_to_sand(landscape_consts_t const &c, biome_corners_t const &bio, float (&w)[5], bool grass, float lowest, unsigned x, unsigned y, unsigned &flags) {
+	float const fx = (float)x*(1.0f/128.0f), fy = (float)y*(1.0f/128.0f);
+	if (c.vegetation > 0.0f) {
+		float const keep = biome_at(bio, 2, fx, fy);
+		if (keep < 1.0f) {w[LT_SAND] = add_dbl(w[LT_SAND], (1.0 - (double)keep)*(double)w[LT_DIRT]); w[LT_DIRT] *= keep;}
 	}
 	if (grass) {
-		float const grass_scale = (mhmin < c.water_level) ? 0.0f : bilinear_param(prm, 1, xv, yv); // no grass under water
-		if (grass_scale < 1.0f) { // convert grass to sand
-			float const gscale = clip01(2.5f*(grass_scale - 0.5f) + 0.5f);
-			weights[LT_SAND]   = weight_add(weights[LT_SAND], (1.0 - (double)gscale)*(double)weights[LT_GROUND]);
-			weights[LT_GROUND] *= gscale;
+		float const share = (lowest < c.water_level) ? 0.0f : biome_at(bio, 1, fx, fy);
+		if (share < 1.0f) {
+			float const keep = clip01(2.5f*(share - 0.5f) + 0.5f);
+			w[LT_SAND] = add_dbl(w[LT_SAND], (1.0 - (double)keep)*(double)w[LT_GROUND]); w[LT_GROUND] *= keep;
 		}
-		if (grass_scale > 0.0f && c.gen_grass_map && x < WT_SIZE && y < WT_SIZE) {flags |= 2u;}
+		if (share > 0.0f && c.gen_grass_map && x < WT_SIZE && y < WT_SIZE) {flags |= 2u;}
 	}
-	return weight_to_u8(weights[0]) | (weight_to_u8(weights[1]) << 8) | (weight_to_u8(weights[2]) << 16) | (weight_to_u8(weights[3]) << 24);
+}
+// the general texel: layers la (lower) / lb (upper) blended by t, slopes turning grass into dirt / rock and snow into rock
+TERRA_HD uint32_t blend_texel(landscape_consts_t const &c, corner_heights_t const &h, biome_corners_t const &bio, float jitter, float lowest, int la, int lb, float t, unsigned x, unsigned y, unsigned &flags) {
+	float w[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+	bool const grass = (la == LT_GROUND || lb == LT_GROUND), snow = (lb == LT_SNOW);
+	flags = grass ? 1u : 0u;
+	float cover = 1.0f; // what the slope leaves of the layers
+	if (grass || snow) {
+		float const lo = sthresh_v(snow, 0), hi = sthresh_v(snow, 1);
+		float const gx = c.DY_VAL*(h.z00 - h.z01), gy = c.DX_VAL*(h.z00 - h.z10), gz = c.dxdy; // get_norm_not_normalized (src/tiled_mesh.h:281)
+		float up = c.vnz_scale*gz/sqrtf(gx*gx + gy*gy + gz*gz);
+		if (grass && up > hi) {up = clip01(1.0f + 20.0f*jitter);}
+		if (up < hi) {
+			if (grass) {
+				float rock = (la == LT_GROUND || lb == LT_ROCK) ? t : 0.0f;
+				float const steep = (float)(1.0 - (double)clip01((up - 0.5f*lo)*c.steep_mult_rock));
+				rock  = (float)((double)rock*(1.0 - (double)steep) + (double)steep);
+				cover = clip01((up - lo)*c.steep_mult_grass);
+				w[LT_ROCK] = add_dbl(w[LT_ROCK], (1.0 - (double)cover)*(double)rock);
+				w[LT_DIRT] = add_dbl(w[LT_DIRT], (1.0 - (double)cover)*(1.0 - (double)rock));
+			}
+			else {
+				cover = clip01(2.0f*(up - lo)*c.steep_mult_snow);
+				w[LT_ROCK] = add_dbl(w[LT_ROCK], 1.0 - (double)cover);
+			}
+		}
+	}
+	w[lb] += cover*t;
+	w[la] = add_dbl(w[la], (double)cover*(1.0 - (double)t));
+	biome_to_sand(c, bio, w, grass, lowest, x, y, flags);
+	return pack_weights(w);
+}
+// one texel (x, y) of the 129 x 129 weights texture -> RGBA packed little-endian.  flags: bit 0 = grass (has_any_grass), bit 1 = contributes to its grass block
+TERRA_HD uint32_t weights_texel_v(landscape_consts_t const &c, corner_heights_t const &h, biome_corners_t const &bio, float rand_val, unsigned x, unsigned y, unsigned &flags) {
+	float const lowest = min4_std(h), highest = max4_std(h), jitter = c.noise_scale*rand_val;
+	float const rel_lo = c.relh_adj_tex + (lowest - c.zmin)*c.dz_inv + jitter, rel_hi = c.relh_adj_tex + (highest - c.zmin)*c.dz_inv + jitter;
+	int lo_a, lo_b, hi_a, hi_b;
+	get_tids(c, rel_lo, lo_a, lo_b, nullptr);
+	get_tids(c, rel_hi, hi_a, hi_b, nullptr);
+	if (lo_a == hi_b) { // one layer from the lowest corner's lower candidate to the highest corner's upper one
+		int const layer = lo_a;
+		if (layer != LT_GROUND && layer != LT_SNOW) { // one-hot: bytes directly
+			flags = 0u;
+			if (layer == LT_DIRT && c.vegetation > 0.0f) {
+				float const keep = biome_at(bio, 2, (float)x*(1.0f/128.0f), (float)y*(1.0f/128.0f));
+				if (keep < 1.0f) {float const sand = add_dbl(0.0f, (1.0 - (double)keep)*1.0), dirt = 1.0f*keep; return weight_byte(sand) | (weight_byte(dirt) << 8);}
+			}
+			return 255u << (8*layer);
+		}
+		// (a shortcut for grass on a SURELY gentle slope -- the square root and the division replaced by a comparison of squares with a margin -- was measured and lost:
+		// 445 -> 490 us for the 64 x 64 batch.  A wave executes every path one of its 64 texels takes; land rows mix gentle and steep cells, so the shortcut was added work.)
+		return blend_texel(c, h, bio, jitter, lowest, layer, layer, 0.0f, x, y, flags);
+	}
+	// several layers under the cell: the corner (x, y) decides, without the jitter, and may sit in a blend zone
+	float t = 0.0f;
+	int la, lb;
+	get_tids(c, c.relh_adj_tex + (h.z00 - c.zmin)*c.dz_inv, la, lb, &t);
+	return blend_texel(c, h, bio, jitter, lowest, la, lb, t, x, y, flags);
+}
+TERRA_HD uint32_t weights_texel(landscape_consts_t const &c, float const *zvals /*130x130*/, float const *prm /*12*/, float rand_val, unsigned x, unsigned y, unsigned &flags) {
+	unsigned const ix = y*WT_ZV + x;
+	biome_corners_t bio;
+	for (int k = 0; k < 12; ++k) {bio.v[k] = prm[k];}
+	return weights_texel_v(c, corner_heights_t{zvals[ix], zvals[ix+1], zvals[ix+WT_ZV], zvals[ix+WT_ZV+1]}, bio, rand_val, x, y, flags);
 }
 
 struct grass_block_pod_t {uint32_t ix; float zmin, zmax;}; // tile_t::grass_block_t (src/tiled_mesh.h:186); ix 0 = unused
