@@ -1478,7 +1478,7 @@ template<class BE> struct terra_engine {
 			}
 			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {return level[a] < level[b];});
 		}
-		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*nslots*zv*8 + ((size_t)n + 1)*4 + 256*4;
+		size_t const bytes = (size_t)n*4 + adj.size()*4 + (size_t)2*nslots*zv*8 + ((size_t)n + 1)*4 + 256*4 + ((size_t)nslots + 2)*4 + 256;
 		uint8_t *base = scratch<uint8_t>(s_shadow, bytes);
 		uint32_t *d_order = (uint32_t *)base;
 		int32_t *d_adj = (int32_t *)(base + (((size_t)n*4 + 255) & ~(size_t)255));
@@ -1505,7 +1505,9 @@ template<class BE> struct terra_engine {
 			}
 		}
 		uint32_t const npaths = 4*zv;
-		for (uint32_t first = 0; first < n;) {
+		uint32_t *d_sync = (uint32_t *)((uint8_t *)d_out + (((size_t)2*nslots*zv*8 + 255) & ~(size_t)255)); // the ticket counter of the dataflow launch
+		if (be.tile_shadows_flow(c, n, nslots, d_order, d_adj, d_zvals, d_out, d_smask, npaths, d_sync)) {} // one launch; tiles start as their two upstream tiles publish
+		else for (uint32_t first = 0; first < n;) { // "shadows.levels" / cross-check kernels / the emulator: one launch per dependency level
 			uint32_t last = first;
 			while (last < n && level[order[last]] == level[order[first]]) ++last;
 			be.tile_shadows(c, last - first, d_order + first, d_adj, nslots, d_zvals, d_out, d_smask, npaths);
@@ -1515,7 +1517,7 @@ template<class BE> struct terra_engine {
 			float *eo = d_edge_out; uint32_t const ns = nslots;
 			be.launch((size_t)n*2*zv, [=] TERRA_LAMBDA (size_t j) {
 				uint32_t const e = (uint32_t)(j % zv), d = (uint32_t)((j / zv) % 2), i = (uint32_t)(j / (2*zv));
-				unsigned long long const v = d_out[((size_t)d*ns + i)*zv + e];
+				unsigned long long const v = d_out[((size_t)d*ns + i)*zv + e] & ~(1ull << 63); // (bit 63: the dataflow launch's `published` mark)
 				if (v != 0) {uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); float f; memcpy(&f, &b, 4); eo[j] = f;}
 			});
 		}
@@ -1525,7 +1527,7 @@ template<class BE> struct terra_engine {
 			for (uint32_t i = 0; i < n; ++i) {
 				for (uint32_t d = 0; d < 2; ++d) {
 					for (uint32_t e = 0; e < zv; ++e) {
-						unsigned long long const v = h[((size_t)d*nslots + i)*zv + e];
+						unsigned long long const v = h[((size_t)d*nslots + i)*zv + e] & ~(1ull << 63); // (bit 63: the dataflow launch's `published` mark)
 						if (v != 0) {uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); memcpy(&edge_out[((size_t)i*2 + d)*zv + e], &b, 4);}
 					}
 				}

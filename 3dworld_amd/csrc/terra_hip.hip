@@ -36,6 +36,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		// LDS-tiled kernels use > 64 KiB of dynamic LDS (160 KiB per CU on gfx950)
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_erosion, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_level, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_flow, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 	}
@@ -369,6 +370,16 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		else if (plain_only) {hipLaunchKernelGGL((terra::k_sine_grid<true, false>), dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		else            {hipLaunchKernelGGL((terra::k_sine_grid<true, true>),  dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, d_sm, d_sm + (size_t)nux*tw, zvals, ntx, nty, (uint32_t *)nullptr, tl);}
 		TERRA_HIP_CHECK(hipGetLastError());
+	}
+	// the whole batch in one dataflow launch (k_tile_shadows_flow); sync_words: the ticket counter, zeroed here.  false: use the per-level launches.  Leaves SHADOW_EDGE_PUB set in `out`
+	bool tile_shadows_flow(terra::shadow_consts_t const &c, uint32_t ntiles, uint32_t nslots, uint32_t const *ord, int32_t const *adj, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np, uint32_t *sync_words) {
+		if (simple_kernels || ((uintptr_t)sm & 3) || (opt && opt->shadows_levels)) return false;
+		use();
+		fill32(sync_words, 0u, 1); // the ticket (the edge arrays were zeroed by the caller: no stale `published` bit)
+		unsigned const grid = std::min<unsigned>(ntiles, (unsigned)(2*num_cus));
+		hipLaunchKernelGGL(terra::k_tile_shadows_flow, dim3(grid), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, nslots, ntiles, ord, adj, z, out, sm, np, sync_words);
+		TERRA_HIP_CHECK(hipGetLastError());
+		return true;
 	}
 	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {
 		if (simple_kernels || ((uintptr_t)sm & 3)) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np); return;} // the block ORs its mask out a word at a time

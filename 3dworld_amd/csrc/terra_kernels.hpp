@@ -620,6 +620,7 @@ template<bool OWN> __global__ __launch_bounds__(AO_THREADS) __attribute__((amdgp
 
 // ------------------------------------------------------------------ row f2: mesh shadows, one launch per dependency level
 // An outgoing edge height travels between tiles as (dependency order << 32 | float bits) under a 64-bit max; 0 = nothing arrived (MESH_MIN_Z).
+constexpr unsigned long long SHADOW_EDGE_PUB = 1ull << 63; // (k_tile_shadows_flow) this word of a finished tile's edge array has been published
 struct shadow_edge_t {
 	__device__ static float decode(unsigned long long v) {if (v == 0) return -1.0E6f; uint32_t const b = (uint32_t)(v & 0xFFFFFFFFull); float f; memcpy(&f, &b, 4); return f;}
 	__device__ static unsigned long long pack(uint32_t order, float v) {uint32_t b; memcpy(&b, &v, 4); return ((unsigned long long)order << 32) | b;}
@@ -672,6 +673,74 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 	if (tid < 2*zv) {
 		unsigned long long const v = s_out[tid];
 		if (v) {out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)] = v;}
+	}
+}
+
+// The whole batch as ONE dataflow launch.  A tile needs the edge arrays of its two neighbours toward the light (src/tiled_mesh.cpp:664-692) and nothing else: a launch per
+// dependency LEVEL (127 of them for a 64 x 64 batch) makes every tile wait for the slowest tile of the level before -- and for two launch gaps.  Here blocks take tiles from
+// a queue in level order (an atomic ticket; `order` lists a tile's dependencies before it), stage the tile's heights, and only then wait for the upstream tiles' `done`
+// words.  Progress: a waiting block holds a ticket, the tile it waits for has a LOWER ticket and was therefore taken by a block that is running -- whatever the grid size and
+// however many blocks are resident; the lowest ticket in flight never waits.
+// Hand-off between workgroups (they sit on other CUs, maybe other XCDs: neither their L1 nor their L2 is ours): the edge words ARE the flags.  A finished tile stores ALL
+// 260 words of its two edge arrays as 8-byte agent-scope (write-through) stores with SHADOW_EDGE_PUB set -- `nothing arrived at this cell` is published as 0 | PUB -- and a
+// consumer lane polls exactly the word it needs with relaxed agent-scope loads until the bit is there: no flag word, no fence, no second round trip (a `done` word per tile
+// with a release / acquire pair was measured first: ~5 us more per tile of a 127-tile chain).  While a tile is far from its turn only ONE lane per upstream tile polls,
+// sleeping in between; the 260 lanes join when that lane has seen the first word.  `ticket` is zeroed by the caller per call, the edge arrays too (no stale PUB bit);
+// the virtual halo slots (index >= ntiles) were written before the launch and are read without polling.
+__global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_consts_t c, uint32_t n, uint32_t ntiles, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
+	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, uint32_t *ticket)
+{
+	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
+	__shared__ uint32_t s_ticket;
+	unsigned const zv = 130, tid = threadIdx.x;
+	float *s_in = s_sh_mh + zv*zv;
+	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv);
+	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
+	for (;;) {
+		if (tid == 0) {s_ticket = atomicAdd(ticket, 1u);}
+		__syncthreads();
+		uint32_t const k = s_ticket;
+		if (k >= ntiles) return; // (block-uniform)
+		uint32_t const t = order[k];
+		int32_t const ax = adj[2*t], ay = adj[2*t + 1];
+		float const *z = zvals + (size_t)t*zv*zv;
+		// everything that does not depend on the neighbours first
+		if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}}
+		else {for (unsigned i = tid; i < zv*zv; i += SH_LEVEL_THREADS) {s_sh_mh[i] = z[i];}}
+		for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {s_mask[i] = 0u;}
+		if (tid < 64) { // far from this tile's turn: lane 0 watches the x neighbour's first word, lane 1 the y neighbour's
+			int32_t const a = (tid == 0) ? ax : ((tid == 1) ? ay : -1);
+			unsigned long long const *w = (a >= 0 && (uint32_t)a < ntiles) ? &out[((size_t)((tid == 0) ? 1 : 0)*n + a)*zv] : nullptr;
+			for (;;) {
+				bool const ready = !w || (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SHADOW_EDGE_PUB) != 0ull;
+				if (__all(ready)) break;
+				__builtin_amdgcn_s_sleep(8);
+			}
+		}
+		__syncthreads();
+		if (tid < 2*zv) { // in.x(i) = the y-neighbour's out_x, in.y(i) = the x-neighbour's out_y (src/tiled_mesh.cpp:676-687): every lane waits for its own word
+			bool const isx = tid < zv; unsigned const i = isx ? tid : tid - zv; int32_t const a = isx ? ay : ax;
+			float v = -1.0E6f;
+			if (a >= 0) {
+				unsigned long long const *w = &out[((size_t)(isx ? 0 : 1)*n + a)*zv + i];
+				unsigned long long e = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((uint32_t)a < ntiles) {while (!(e & SHADOW_EDGE_PUB)) {__builtin_amdgcn_s_sleep(1); e = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);}}
+				v = shadow_edge_t::decode(e & ~SHADOW_EDGE_PUB);
+			}
+			s_in[tid] = v;
+			s_out[tid] = 0ull; // 0 = never written
+		}
+		__syncthreads();
+		shadow_lds_in_t const in{s_in, s_in + zv};
+		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
+		for (unsigned p = tid; p < npaths; p += SH_LEVEL_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+		__syncthreads();
+		if (tid < 2*zv) { // the edges first, every word: somebody may be polling it
+			__hip_atomic_store(&out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)], s_out[tid] | SHADOW_EDGE_PUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned; read by later launches only
+		for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {gm[i] = s_mask[i] | c.mask_fill;}
+		__syncthreads(); // (the next tile's staging overwrites the mask words being copied out)
 	}
 }
 

@@ -112,6 +112,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	}
 	void minmax(float const *vals, size_t n, uint32_t *d) {minmax_simple(vals, n, d);}
 	void quantize16(float const *vals, size_t n, float val_add, float val_div, uint8_t *pix) {quantize16_simple(vals, n, val_add, val_div, pix);}
+	bool tile_shadows_flow(terra::shadow_consts_t const &, uint32_t, uint32_t, uint32_t const *, int32_t const *, float const *, unsigned long long *, uint8_t *, uint32_t, uint32_t *) {return false;} // (level by level)
 	bool tile_weights(terra::landscape_consts_t const &, terra::tile_ref_pod_t const *, uint32_t, float const *, float const *, float const *, uint32_t *, terra::grass_block_pod_t *, uint8_t *) {return false;} // (the per-texel form)
 	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool /*fused: the exact values are within every tolerance*/) {voxel_noise_simple(out, nvox, J, perlin);}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float = 0.0f) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused);}
