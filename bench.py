@@ -70,6 +70,8 @@ def parse():
     p.add_argument("--grids-in-flight", type=int, default=8, help="onegrid: distributed grids in flight (a grid is reused this many steps later)")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
+    p.add_argument("--preflight", action="store_true", help="N > 1 smoke of every cross-device path in < 30 s: process group, one collective, the one-grid mapping (HIP VMM export / import / "
+                   "peer access), a peer copy, one sharded step; rank 0 prints {\"preflight\": ...} naming the first failing call, then the process exits (no bench line)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-rccl-world1", action="store_true", help="N = 1: do not create the one-rank RCCL group (the collectives of the sharded paths are then skipped)")
     p.add_argument("--clock-warmup-ms", type=float, default=150.0, help="untimed steps run for this long right before every timed region so that it runs at the chip's sustained clock (a cold MI355X needs ~30 ms of load to get there, an idle gap of 5 ms already costs 12 %%: profiles/r04_clock_ramp.txt); 0 = only the W warm-up steps")
@@ -157,6 +159,96 @@ class c_stdout_to_stderr:
         return False
 
 
+def preflight(args, torch, dist, pkg, dmod, rank, world, local_rank, dev, coll_dev, backend):
+    """Every path a multi-GPU run crosses a device boundary on, once, small, each stage named: what first contact with an 8-GPU node should run before the scaling bench.
+    A stage that raises on any rank is reported by rank 0 with the exception text (the ranks agree on the outcome through one all_reduce per stage, so nobody hangs)."""
+    import traceback
+    stages, failed = [], [None]
+
+    def agree(ok):
+        if dist is None:
+            return ok
+        f = torch.tensor([0 if ok else 1], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(f)
+        return int(f.item()) == 0
+
+    def stage(name, fn):
+        if failed[0]:
+            return
+        t0, err = time.perf_counter(), None
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+            traceback.print_exc(file=sys.stderr)
+        ok = agree(err is None)
+        stages.append({"stage": name, "ok": ok, "ms": round((time.perf_counter() - t0) * 1e3, 1), **({"error": err} if err else {})})
+        if not ok:
+            failed[0] = name
+
+    st_box, t_box, grid_box = {}, {}, {}
+
+    def s_context():
+        t_box["t"] = pkg.Terra(local_rank)
+        st_box["st"] = t_box["t"].init_scene(pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
+
+    def s_collective():
+        if dist is None:
+            return
+        v = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=coll_dev)
+        dist.all_reduce(v)
+        assert float(v[0]) == world * (world + 1) / 2, f"all_reduce gave {float(v[0])}"
+
+    def s_onegrid():
+        n = 1024
+        g, rows = dmod.create_distributed_grid(pkg.terra, t_box["t"], dist, n, n, "preflight", coll_dev)  # HIP VMM: export / import / map / peer access
+        grid_box["g"], grid_box["rows"], grid_box["n"] = g, rows, n
+
+    def s_strip_fill_and_peer_read():
+        g, rows, n, t, st = grid_box["g"], grid_box["rows"], grid_box["n"], t_box["t"], st_box["st"]
+        r0, r1 = rows[rank]
+        t.gen_grid_rows_minmax_dev(g.ptr + r0 * n * 4, -n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, r0, r1 - r0)  # this rank's rows into its own HBM
+        t.synchronize()
+        if dist is not None:
+            dist.barrier()
+        peer = (rank + 1) % world
+        p0, p1 = rows[peer]
+        np = __import__("numpy")
+        got = np.empty(n, np.float32)
+        t._ck(t.lib.terra_memcpy_d2h(t.ctx, got.ctypes.data, g.ptr + p0 * n * 4, n * 4))  # one row of the neighbour's strip, read through the mapping
+        want = t.gen_grid(-n / 2, -n / 2 + p0, st.DX_VAL, st.DY_VAL, n, 1, pkg.GEN_GLACIATE)[0]
+        assert (got == want).all(), "a row read through the peer mapping differs from the row computed locally"
+
+    def s_erode_across_strips():
+        g, n, t = grid_box["g"], grid_box["n"], t_box["t"]
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            t.apply_erosion_dev(g.ptr, n, n, -1.0e9, 200)  # droplets walk rows that live in every rank's HBM
+            t.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    stage("context", s_context)
+    stage("collective", s_collective)
+    stage("onegrid_vmm_mapping", s_onegrid)
+    stage("strip_fill_and_peer_read", s_strip_fill_and_peer_read)
+    stage("erode_across_strips", s_erode_across_strips)
+    try:
+        if "g" in grid_box:
+            grid_box["g"].destroy()
+        if "t" in t_box:
+            t_box["t"].close()
+    except Exception:  # noqa: BLE001
+        pass
+    if rank == 0:
+        print(json.dumps({"preflight": "ok" if not failed[0] else "failed", "failed_stage": failed[0], "n_gpus": world, "backend": backend, "stages": stages}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    if failed[0]:
+        raise SystemExit(3)
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -230,6 +322,9 @@ def main():
     if not os.path.exists(pkg.default_lib_path()):
         raise SystemExit("libterra_hip.so missing: run __graft_entry__.build() (no CPU fall-back)")
     dmod = importlib.import_module("3dworld_amd.dist")
+    if args.preflight:
+        preflight(args, torch, dist if have_group else None, pkg, dmod, rank, world, local_rank, dev, coll_dev, backend)
+        return
     mode = MODES[args.mode]
     N = args.size
     cells = N * N

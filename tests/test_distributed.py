@@ -226,6 +226,21 @@ def test_bench_self_launches_two_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_preflight_two_ranks_names_every_stage():
+    """`bench.py --gpus 2 --preflight`: process group, a collective, the one-grid VMM mapping, a row read through the peer mapping, an erosion across both strips -- each a
+    named stage in one JSON line (both ranks on GPU 0 here; on an 8-GPU node the same command is the first thing to run)"""
+    import subprocess
+    env = dict(os.environ, TERRA_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json_line(r.stdout)
+    assert line["preflight"] == "ok" and line["n_gpus"] == 2 and line["failed_stage"] is None
+    assert [s["stage"] for s in line["stages"]] == ["context", "collective", "onegrid_vmm_mapping", "strip_fill_and_peer_read", "erode_across_strips"] and all(s["ok"] for s in line["stages"])
+
+
+@pytest.mark.gpu
 def test_bench_world1_runs_its_collectives_through_rccl():
     """N = 1 on the GPU box: bench.py creates a one-rank RCCL group, so the device-tensor all_reduce / barrier branches of the sharded paths execute through RCCL"""
     import subprocess
