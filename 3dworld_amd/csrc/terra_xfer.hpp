@@ -77,12 +77,13 @@ struct xfer_engine_t {
 		hipError_t e = hipStreamWaitEvent(st, j.ready, 0);
 		if (e != hipSuccess) {fail("hipStreamWaitEvent", e); return;}
 		size_t const nb = (j.bytes + BAND - 1)/BAND;
-		if (j.host_pinned) { // the caller's array is the DMA target / source
-			for (size_t b = (size_t)k; b < nb; b += K) {
-				size_t const off = b*BAND, n = (j.bytes - off < BAND) ? j.bytes - off : BAND;
-				e = j.to_device ? hipMemcpyAsync(j.dev + off, j.host + off, n, hipMemcpyHostToDevice, st) : hipMemcpyAsync(j.host + off, j.dev + off, n, hipMemcpyDeviceToHost, st);
-				if (e != hipSuccess) {fail("hipMemcpyAsync", e); return;}
-			}
+		if (j.host_pinned) {
+			// the caller's array is the DMA target / source: ONE copy on ONE stream.  (Bands on all K streams -- what the staged path below needs to overlap its CPU copies --
+			// only make the DMA queues compete when there is nothing to overlap: the driver's box delivered 42 GB/s that way against 56 for a single hipMemcpy, BENCH_r05
+			// detail.end_to_end, and the staged pageable path 49.)
+			if (k != 0) return;
+			e = j.to_device ? hipMemcpyAsync(j.dev, j.host, j.bytes, hipMemcpyHostToDevice, st) : hipMemcpyAsync(j.host, j.dev, j.bytes, hipMemcpyDeviceToHost, st);
+			if (e != hipSuccess) {fail("hipMemcpyAsync", e); return;}
 			e = hipStreamSynchronize(st);
 			if (e != hipSuccess) {fail("hipStreamSynchronize", e);}
 			return;

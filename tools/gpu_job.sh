@@ -3,7 +3,7 @@
 #   gpu_job.sh check   <tag>                         what the driver does at round end: pytest -m gpu, smoke(), the bench line with the driver's flags
 #   gpu_job.sh tests   <tag> [pytest args]           pytest -m gpu with extra arguments (e.g. "tests/test_gpu_at_size.py -k tile")
 #   gpu_job.sh bench   <tag> [bench.py args]         one bench.py line (+ a second one with --pipelines 1 --no-extras when no args are given)
-#   gpu_job.sh profile <tag> [what ...]              rocprofv3 --kernel-trace --stats summaries; what = bench | p1 | tiles | tile_erosion | weights | ao | voxels | noise | erosion (default: all)
+#   gpu_job.sh profile <tag> [what ...]              rocprofv3 --kernel-trace --stats summaries; what = bench | p1 | tiles | tile_erosion | weights | ao | voxels | voxels64 | noise | erosion | shadows | fused | fast (default: the first nine)
 #   gpu_job.sh pmc     <tag> <driver.py args> -- <kernel substr ...>   FETCH_SIZE, WRITE_SIZE and the SQ set, one --pmc pass each, over tools/<driver>
 #   gpu_job.sh erosion <tag> "<grid> <droplets> <W:slice[,W:slice..]>" ...   dense-erosion timings (tools/ero_sweep.py); TERRA_ERO_* knobs pass through the environment
 #   gpu_job.sh multirank <tag>                       2 ranks on one GPU over gloo: bench.py self-launch + the sharded workloads
@@ -61,6 +61,10 @@ profile)
 		voxels) prof voxels python "$ROOT/tools/prof_voxels.py" ;;
 		noise) prof noise16384 python "$ROOT/tools/prof_noise.py" 16384 2 1,2,4 ;;
 		erosion) prof erosion_dense python "$ROOT/tools/prof_erosion.py" 4096 1000000 ;;
+		shadows) prof shadows python "$ROOT/tools/prof_shadows.py" 3 ;;
+		fused) TERRA_GEN_FUSED=1 prof noise_fused python "$ROOT/tools/prof_noise.py" 16384 6 0,1,2 8; TERRA_GEN_FUSED=1 prof voxels_fused python "$ROOT/tools/prof_voxels.py" 512 512; TERRA_GEN_FUSED=1 prof voxels64_fused python "$ROOT/tools/prof_voxels.py" 512 64 ;;
+		fast) TERRA_GEN_FUSED=2 prof noise_fast python "$ROOT/tools/prof_noise.py" 16384 6 0 8; TERRA_GEN_FUSED=2 prof voxels_fast python "$ROOT/tools/prof_voxels.py" 512 512; TERRA_GEN_FUSED=2 prof voxels64_fast python "$ROOT/tools/prof_voxels.py" 512 64 ;;
+		voxels64) prof voxels64 python "$ROOT/tools/prof_voxels.py" 512 64 0,1,2 ;;
 		esac
 	done
 	;;
