@@ -32,6 +32,7 @@ struct sgf_job_t {
 	int32_t const *tile_map; uint32_t nux, tw; // SGF_TILES: scatter into the per-tile layout [tile][tw][tw]
 	float zscale; int32_t normalize;           // SGF_VOXELS: the tail of voxel_manager::create_procedural (src/voxels.cpp:340-343)
 	void const *xh, *yh; uint32_t nchunks; float unscale; // k_sine_grid_h3: the split half-precision tables [chunk][row][16] and 1 / (their scale factors)
+	uint32_t narrow;         // k_sine_grid_h3: the grid is at most 64 columns wide (a voxel field with nz <= 64): a block's four waves take 64 x 256 cells instead of 128 x 128 (nty counts 256-row tiles)
 };
 enum {SGF_GRID = 0, SGF_TILES = 1, SGF_VOXELS = 2};
 
@@ -394,7 +395,7 @@ template<int KIND> __global__ __launch_bounds__(256, 2) void k_sine_grid_h3(sgf_
 	unsigned const w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	unsigned bxi = 0, byi = 0;
 	if (!sgf_tile_of_block(blockIdx.x, J.ntx, J.nty, J.rowgroup, bxi, byi)) return; // (block-uniform)
-	unsigned const x0 = bxi*128u + (w & 1u)*64u, y0 = byi*128u + (w >> 1)*64u;
+	unsigned const x0 = J.narrow ? 0u : bxi*128u + (w & 1u)*64u, y0 = J.narrow ? byi*256u + w*64u : byi*128u + (w >> 1)*64u;
 	__amdgpu_buffer_rsrc_t const ra = sgf_rsrc((char const *)J.yh + (size_t)y0*32u), rb = sgf_rsrc((char const *)J.xh + (size_t)x0*32u);
 	uint32_t const v0 = c*32u + half*16u, v1 = v0 + 1024u; // the lane's bytes in a chunk: rows c and 32 + c
 	uint32_t const sa = J.nyp*32u, sb = J.nxp*32u;         // bytes per chunk

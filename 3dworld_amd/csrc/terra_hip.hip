@@ -272,6 +272,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			hipLaunchKernelGGL(terra::k_split_table<false>, dim3((unsigned)(((size_t)nchunks*J.nxp + 255)/256)), dim3(256), 0, stream, J.xt, J.nxp, J.kstart, J.kend, nchunks, sx, (terra::sgh_u4 *)J.xh);
 			hipLaunchKernelGGL(terra::k_split_table<true>,  dim3((unsigned)(((size_t)nchunks*J.nyp + 255)/256)), dim3(256), 0, stream, J.yt, J.nyp, J.kstart, J.kend, nchunks, sy, (terra::sgh_u4 *)J.yh);
 		}
+		if (KIND == terra::SGF_VOXELS && J.nx <= 64 && (J.nyp % 256u) == 0) {J.narrow = 1; J.ntx = 1; J.nty = J.nyp/256u;} // (rows beyond ny: zero table rows, nothing stored)
 		unsigned const nb = J.ntx*J.nty, grid = ((nb + 7)/8)*8;
 		hipLaunchKernelGGL(terra::k_sine_grid_h3<KIND>, dim3(grid), dim3(256), 0, stream, J);
 		TERRA_HIP_CHECK(hipGetLastError());
@@ -494,9 +495,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float fast_amax = 0.0f) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused); return;}
 		use();
-		if (fused && (uint64_t)nx*ny <= 0x7FFFFF80ull) { // "gen.fused": the field as a (columns x 60) x (60 x nz) product on the f32 matrix pipe (terra_fused.hpp)
+		if (fused && (uint64_t)nx*ny <= 0x7FFFFF00ull) { // "gen.fused": the field as a (columns x 60) x (60 x nz) product on the f32 matrix pipe (terra_fused.hpp)
 			size_t const ncol = (size_t)nx*ny;
-			uint32_t const nyp = (uint32_t)((ncol + 127)/128*128), nxp = (nz + 127)/128*128;
+			uint32_t const nyp = (uint32_t)((ncol + 255)/256*256), nxp = (nz + 127)/128*128; // (256: the narrow form of k_sine_grid_h3 walks 256-row tiles)
 			terra::sgf_job_t J; memset(&J, 0, sizeof(J));
 			J.out = out; J.nx = nz; J.ny = (uint32_t)ncol; J.nxp = nxp; J.nyp = nyp; J.ntx = nxp/128; J.nty = nyp/128; J.rowgroup = sg_rowgroup;
 			J.kstart = 0; J.kend = terra::VOX_SINES; J.zscale = zscale; J.normalize = normalize;

@@ -155,8 +155,13 @@ def fused_modes(env, detail):
     sine = {}
     for name, fb in (() if env.mode != 0 else (("exact", 0), ("fused", pkg.GEN_FUSED), ("fast", pkg.GEN_FAST))):
         ms = time_grid(pkg.GEN_GLACIATE | fb)
-        sine[name] = {"ms_noise_call": round(ms, 4), "gcells_s_noise_only": round(cells / ms / 1e6, 2), "tflops_8d": round(fl * cells / (ms * 1e-3) / 1e12, 2),
-                      "frac_fp32_peak": round(fl * cells / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "write_tb_s": round(cells * 4 / (ms * 1e-3) / 1e12, 3)}
+        tf, wb = fl * cells / (ms * 1e-3) / 1e12, cells * 4 / (ms * 1e-3) / 1e9
+        sine[name] = {"ms_noise_call": round(ms, 4), "gcells_s_noise_only": round(cells / ms / 1e6, 2), "tflops_8d": round(tf, 2),
+                      "frac_fp32_peak": round(tf / FP32_PEAK_TFLOPS, 4), "write_tb_s": round(wb / 1e3, 3),
+                      # exact: separate multiplies and adds on the vector ALU; fused: the f32 matrix pipe (same 157.3 TFLOP/s datapath); fast: the half-precision matrix pipe has
+                      # 16x that, the kernel is bound by writing its 4 B per cell (k_sine_grid_h3)
+                      "roofline": ({"bound": "hbm", "achieved": round(wb, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(wb / 8000.0, 4)} if name == "fast" else
+                                   {"bound": "mfma" if name == "fused" else "valu", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4)})}
     sine["note"] = ("ms_noise_call = table launches + grid kernel + fused min / max, HIP events; fast: bound by writing the grid (write_tb_s of the ~8 TB/s HBM peak), "
                     "its effective flop rate is above the fp32 vector peak because the work runs on the half-precision matrix pipe")
     out["sine_16384"] = sine

@@ -53,6 +53,13 @@ def test_product_does_not_link_the_oracle(product_lib):
                 assert "liboracle" not in txt and "terra_oracle" not in txt and "orclib" not in txt, f
 
 
+def test_library_reads_no_environment_variable():
+    """behaviour switches come through terra_set_option (include/terra.h), never through the process environment of whoever loaded the library"""
+    for f in os.listdir(os.path.join(ROOT, "3dworld_amd", "csrc")):
+        if f.endswith((".hpp", ".hip")):
+            assert "getenv" not in open(os.path.join(ROOT, "3dworld_amd", "csrc", f)).read(), f
+
+
 def test_cxx_mirror_header_keeps_reference_signatures():
     """include/terra_cxx.hpp: mesh_xy_grid_cache_t::build_arrays/enable_glaciate/eval_index and apply_erosion with the reference's signatures."""
     import subprocess
