@@ -1452,7 +1452,10 @@ def case_fused_minmax_and_option(pkg, t, orc, n=300):
         t.set_option("no.such.key", "1")
 
 
-def case_fused_tiles(pkg, t, orc, tiles=((0, 0), (-3, 7), (20, -31), (5, 5), (5, -2), (-32, -32), (6, 5), (6, -2))):
+DENSE_ODD_TILES = tuple((tx, ty) for ty in range(3, 6) for tx in range(-2, 3))  # 5 x 3: a dense batch (the one-virtual-grid kernels) with an ODD number of tile columns
+
+
+def case_fused_tiles(pkg, t, orc, tiles=((0, 0), (-3, 7), (20, -31), (5, 5), (5, -2), (-32, -32), (6, 5), (6, -2)) + DENSE_ODD_TILES):
     """tile_t::create_zvals under option "gen.fused": zvals bit-equal to the restated mode and within tolerance of the reference; the integer outputs (water bbox)
     and the normal bytes are those of the reference's functions applied to the fused heights -> (boundary flips of the bbox vs the exact tiles, normal bytes that differ)"""
     pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
@@ -1569,6 +1572,14 @@ def case_fast_mode(pkg, t, orc, sizes=((260, 150), (129, 131), (1, 1), (1000, 51
     pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
     st = t.init_scene(pc_); orc.init(oc)
     tol = FUSED_REL_TOL*float(st.zmax_est)
+    t.set_option("gen.fused", "2")
+    try:
+        zd, _, _, _ = t.tiles_create_zvals(DENSE_ODD_TILES, 0, stats=False, normals=False)  # dense, odd column count: the scatter kernel's island-table offsets are not 16-byte multiples
+        for i, (tx, ty) in enumerate(DENSE_ODD_TILES):
+            zo, _ = orc.tile_create_zvals(tx, ty, 0)
+            assert float(np.abs(zd[i].astype(np.float64) - zo).max()) <= tol, (tx, ty)
+    finally:
+        t.set_option("gen.fused", "0")
     tiles = ((0, 0), (-3, 7), (20, -31), (5, 5), (5, -2), (-32, -32), (6, 5), (6, -2))
     t.set_option("gen.fused", "2")
     try:
