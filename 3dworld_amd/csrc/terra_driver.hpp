@@ -325,6 +325,27 @@ TERRA_HD float voxel_noise_cell(size_t i, vox_noise_job_t const &J, bool perlin)
 	return val;
 }
 
+// the same for the voxels (x, y, z) and (x, y, z + 1) of a column, lattice part from the 3-D table (terra_noise.hpp: perlin3_lut_z2 / simplex3_lut): bit-identical to two
+// calls of voxel_noise_cell (tests/emul: terra_emul_noise3_lut_mismatches; the GPU parity tests of the fields)
+template<bool PERLIN> TERRA_HD nv2 voxel_noise_pair(unsigned x, unsigned y, unsigned z, vox_noise_job_t const &J, char const *tab) {
+	float const px = ((float)x*J.v0 + J.l0) + J.o0, py = ((float)y*J.v1 + J.l1) + J.o1;
+	nv2 const zf = {(float)z, (float)(z + 1)};
+	nv2 const pz = (zf*J.v2 + J.l2) + J.o2;
+	nv2 val = {0.0f, 0.0f};
+	float nmag = J.mag, nfreq = (float)(0.25*(double)J.freq);
+	float const frz = J.frx - J.fry;
+	for (int n = 0; n < J.nn; ++n) {
+		float const ax = nfreq*px + J.frx, ay = nfreq*py + J.fry;
+		nv2 const az = nfreq*pz + frz;
+		nv2 const v = PERLIN ? perlin3_lut_z2<true>(ax, ay, az, tab) : simplex3_lut<true>(nv2{ax, ax}, nv2{ay, ay}, az, tab);
+		val += nmag*v;
+		nmag *= 0.5f; nfreq *= 1.92f;
+	}
+	val += zf*J.zscale;
+	if (J.normalize) {val = nv2{clip_pm1(val[0]), clip_pm1(val[1])};}
+	return val;
+}
+
 template<class BE> struct terra_engine {
 	BE be;
 	options_t opt;
@@ -351,6 +372,7 @@ template<class BE> struct terra_engine {
 	std::vector<float> h_sin_table;
 	float *d_sin_table = nullptr;
 	float *d_sinTable = nullptr; bool sinTable_dev_valid = false; // device copy of sinTable[90][5]: the per-grid constants of build_arrays are derived on the device (no upload per call)
+	uint32_t *d_noise3_lut = nullptr; // lattice tables of the 3-D fields (noise3_lut_fill): simplex, then Perlin
 	uint32_t *d_noise_lut = nullptr; // lattice tables of the fBm kernels (terra_noise.hpp: noise_lut_fill), built once per context on the device
 	terra_erosion_report report{};
 
@@ -378,6 +400,7 @@ template<class BE> struct terra_engine {
 		for (scratch_t *s : {&s_xt, &s_yt, &s_smx, &s_smy, &s_misc, &s_border, &s_spec, &s_spec_blocks, &s_tiles, &s_ao, &s_shadow, &s_shadow_map, &s_shadow_gather, &s_vox, &s_sk, &s_mm, &s_hostgrid}) {if (s->p) be.free(s->p);}
 		if (d_sin_table) be.free(d_sin_table);
 		if (d_noise_lut) be.free(d_noise_lut);
+		if (d_noise3_lut) be.free(d_noise3_lut);
 		if (d_sinTable) be.free(d_sinTable);
 	}
 
@@ -405,6 +428,8 @@ template<class BE> struct terra_engine {
 		be.h2d(d_sin_table, h_sin_table.data(), 2*TSIZE*sizeof(float));
 		uint32_t *nl = d_noise_lut = (uint32_t *)be.alloc(NOISE_LUT_DWORDS*sizeof(uint32_t));
 		be.launch(NOISE_LUT_DWORDS, [=] TERRA_LAMBDA (size_t i) {nl[i] = noise_lut_fill((unsigned)i);}); // the per-cell code itself fills the table: same bits by construction
+		uint32_t *n3 = d_noise3_lut = (uint32_t *)be.alloc(2*NOISE3_LUT_DWORDS*sizeof(uint32_t)); // [0]: simplex(vec3), [1]: perlin(vec3)
+		be.launch(2*NOISE3_LUT_DWORDS, [=] TERRA_LAMBDA (size_t i) {n3[i] = noise3_lut_fill((unsigned)(i % NOISE3_LUT_DWORDS), i >= NOISE3_LUT_DWORDS);});
 	}
 	void set_scene_constants() { // src/matrix_ops.cpp:59-84
 		MESH_HEIGHT   = 0.10f*cfg.scene_z;
@@ -1812,7 +1837,7 @@ template<class BE> struct terra_engine {
 			vox_noise_job_t J;
 			J.l0 = l0; J.l1 = l1; J.l2 = l2; J.v0 = v0; J.v1 = v1; J.v2 = v2; J.o0 = o0; J.o1 = o1; J.o2 = o2; J.frx = frx; J.fry = fry; J.mag = mag; J.freq = freq; J.zscale = zscale;
 			J.nn = nn; J.normalize = normalize; J.nx = nx; J.nz = nz; J.y0 = y0;
-			be.voxel_noise(d_out, nvox, J, perlin, opt.gen_fused != 0);
+			be.voxel_noise(d_out, nvox, J, perlin, opt.gen_fused != 0, d_noise3_lut + (perlin ? NOISE3_LUT_DWORDS : 0u));
 		}
 	}
 };

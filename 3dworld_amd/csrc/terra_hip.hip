@@ -478,18 +478,20 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
-	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool fused) {
+	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool fused, uint32_t const *lut3) {
 		if (simple_kernels) {voxel_noise_simple(out, nvox, J, perlin); return;}
 		if (nvox == 0) return;
 		use();
-		if ((nvox + 255)/256 > 0x7FFFFFFFull) throw std::invalid_argument("voxel_fill: grid too large");
 		// "gen.fused" has no kernel here: glm's 3-D lattice noise picks its gradients by the SIGN of expressions that are exactly zero at some of the hash's 49 / 289 values
 		// (h = 1 - |x| - |y| in simplex(vec3), gz = 0.5 - |gx| - |gy| in perlin(vec3); noise.inl:149-157,690-700), so one contracted rounding flips a gradient: measured 0.146
-		// on a 40 x 24 x 64 Perlin field for 1.2x.  (The 2-D kernels read those terms from the lattice table the exact code builds: they are immune.)  The exact kernel answers.
+		// on a 40 x 24 x 64 Perlin field for 1.2x.  The exact kernel answers (its gradients come from the table the exact code builds).
 		(void)fused;
-		dim3 const grid((unsigned)((nvox + 255)/256)), block(256);
-		if (perlin) {hipLaunchKernelGGL(terra::k_voxel_noise<true>, grid, block, 0, stream, out, nvox, J);}
-		else        {hipLaunchKernelGGL(terra::k_voxel_noise<false>, grid, block, 0, stream, out, nvox, J);}
+		uint32_t const nzp = (J.nz + 1)/2; // pairs (z, z + 1) per column
+		size_t const npairs = (nvox / J.nz)*nzp, per_block = (size_t)256*terra::VN_CHUNKS;
+		if ((npairs + per_block - 1)/per_block > 0x7FFFFFFFull) throw std::invalid_argument("voxel_fill: grid too large");
+		dim3 const grid((unsigned)((npairs + per_block - 1)/per_block)), block(256);
+		if (perlin) {hipLaunchKernelGGL(terra::k_voxel_noise<true>, grid, block, 0, stream, out, npairs, nzp, J, lut3);}
+		else        {hipLaunchKernelGGL(terra::k_voxel_noise<false>, grid, block, 0, stream, out, npairs, nzp, J, lut3);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float fast_amax = 0.0f) {

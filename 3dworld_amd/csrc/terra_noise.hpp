@@ -354,6 +354,122 @@ struct noise_tab_nocheck_t { // for sample positions the caller has bounded (fbm
 	TERRA_HD nv2 perlin(nv2 x, nv2 y) const {return perlin2_lut<false>(x, y, ptab);}
 };
 
+// ---- 3-D lattice tables (the voxel fields of voxel_manager::create_procedural, src/voxels.cpp:312-345).  The same observation as in 2-D: glm's perlin(vec3) / simplex(vec3)
+// reach the lattice through permute() of small integers only -- permute(permute(permute(a) + b) + c) with every argument an exact integer in 0 .. 580 -- and everything they
+// compute from the hashed point (the gradient and its taylorInvSqrt norm, ~45 of the ~55 instructions per corner) depends on that integer alone.  One table of permute()
+// stored as BYTE offsets (value*4: the next look-up's index, or the gradient's) and three arrays {gx*norm, gy*norm, gz*norm}, all filled by the per-voxel code itself
+// (noise3_lut_fill): 5.8 KB of LDS.  Two voxels per lane (z, z + 1): Perlin's x / y lattice work is shared by the pair, the rest runs on register pairs.
+//   layout (dwords): PERMB[584] | GX[292] GY[292] GZ[292]
+constexpr unsigned NOISE3_PERM_N = 584, NOISE3_G_N = 292, NOISE3_LUT_DWORDS = NOISE3_PERM_N + 3*NOISE3_G_N; // 1460 = 365 x 4
+// the gradient of perlin(vec3) at a corner whose hash is hz, times its norm (gtc/noise.inl:91-118 for one lane of the vec4s)
+TERRA_HD void perlin3_gradn(float hz, float g[3]) {
+	float const seventh = (float)(1.0/7.0);
+	float gx = hz*seventh;
+	float gy = gl_fract(floorf(gx)*seventh) - 0.5f;
+	gx = gl_fract(gx);
+	float const gz = 0.5f - fabsf(gx) - fabsf(gy);
+	float const sz = gl_step(gz, 0.0f);
+	gx -= sz*(gl_step(0.0f, gx) - 0.5f);
+	gy -= sz*(gl_step(0.0f, gy) - 0.5f);
+	float const nrm = gl_tinvsqrt(gx*gx + gy*gy + gz*gz);
+	g[0] = gx*nrm; g[1] = gy*nrm; g[2] = gz*nrm;
+}
+// the gradient of simplex(vec3) at a corner whose hash is pm, times its norm (gtc/noise.inl:675-708)
+TERRA_HD void simplex3_gradn(float pm, float g[3]) {
+	float const n_ = 0.142857142857f;
+	float const ns0 = n_*2.0f - 0.0f, ns1 = n_*0.5f - 1.0f, ns2 = n_*1.0f - 0.0f;
+	float const j  = pm - 49.0f*floorf(pm*ns2*ns2);
+	float const x_ = floorf(j*ns2);
+	float const y_ = floorf(j - 7.0f*x_);
+	float const qx = x_*ns0 + ns1, qy = y_*ns0 + ns1;
+	float const qh = 1.0f - fabsf(qx) - fabsf(qy);
+	float const sh = -gl_step(qh, 0.0f);
+	float const gx = qx + (floorf(qx)*2.0f + 1.0f)*sh, gy = qy + (floorf(qy)*2.0f + 1.0f)*sh;
+	float const nrm = gl_tinvsqrt(gx*gx + gy*gy + qh*qh);
+	g[0] = gx*nrm; g[1] = gy*nrm; g[2] = qh*nrm;
+}
+TERRA_HD uint32_t noise3_lut_fill(unsigned i, bool perlin) { // dword i of the table
+	if (i < NOISE3_PERM_N) {return (uint32_t)(int)gl_permute<float>((float)i) << 2;}
+	unsigned const k = i - NOISE3_PERM_N, c = k / NOISE3_G_N, v = k % NOISE3_G_N;
+	float g[3];
+	if (perlin) {perlin3_gradn((float)v, g);} else {simplex3_gradn((float)v, g);}
+	return nt_bits(g[c]);
+}
+TERRA_HD int nt_ldi(char const *p) {return *(int const *)p;}
+constexpr int NOISE3_GX = NOISE3_PERM_N*4, NOISE3_GS = NOISE3_G_N*4; // byte offset of GX, byte stride between the gradient arrays
+// glm::perlin(vec3) at (px, py, pz[0]) and (px, py, pz[1]), lattice part from the table.  CHECK: the direct code when a lattice coordinate is not a small integer
+template<bool CHECK> TERRA_HD nv2 perlin3_lut_z2(float px, float py, nv2 pz, char const *tab) {
+	float const flx = floorf(px), fly = floorf(py);
+	nv2 const flz = nt_floor(pz);
+	if (CHECK && TERRA_UNLIKELY(!(fabsf(flx) < 4194304.0f && fabsf(fly) < 4194304.0f && nt_all_below(flz, 4194304.0f)))) {return nv2{perlin3(px, py, pz[0]), perlin3(px, py, pz[1])};}
+	float const f0x = px - flx, f0y = py - fly, f1x = f0x - 1.0f, f1y = f0y - 1.0f;
+	nv2 const f0z = pz - flz, f1z = f0z - 1.0f;
+	// residues (0 .. 289, exact integers) as byte offsets into PERMB
+	int const ix0 = (int)gl_mod289<float>(flx) << 2, ix1 = (int)gl_mod289<float>(flx + 1.0f) << 2, iy0 = (int)gl_mod289<float>(fly) << 2, iy1 = (int)gl_mod289<float>(fly + 1.0f) << 2;
+	nv2 const cz0 = gl_mod289<nv2>(flz), cz1 = gl_mod289<nv2>(flz + 1.0f);
+	char const *const tx0 = tab + nt_ldi(tab + ix0), *const tx1 = tab + nt_ldi(tab + ix1);                 // permute(hx) + ...
+	char const *const t[4] = {tab + nt_ldi(tx0 + iy0), tab + nt_ldi(tx1 + iy0), tab + nt_ldi(tx0 + iy1), tab + nt_ldi(tx1 + iy1)}; // hxy + ... for (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+	int const iz0[2] = {(int)cz0[0] << 2, (int)cz0[1] << 2}, iz1[2] = {(int)cz1[0] << 2, (int)cz1[1] << 2};
+	nv2 nlo[4], nhi[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		float const fxc = (c & 1) ? f1x : f0x, fyc = (c & 2) ? f1y : f0y;
+		char const *const g0a = tab + NOISE3_GX + nt_ldi(t[c] + iz0[0]), *const g0b = tab + NOISE3_GX + nt_ldi(t[c] + iz0[1]);
+		char const *const g1a = tab + NOISE3_GX + nt_ldi(t[c] + iz1[0]), *const g1b = tab + NOISE3_GX + nt_ldi(t[c] + iz1[1]);
+		nv2 const gx0 = {nt_ldf(g0a), nt_ldf(g0b)}, gy0 = {nt_ldf(g0a + NOISE3_GS), nt_ldf(g0b + NOISE3_GS)}, gz0 = {nt_ldf(g0a + 2*NOISE3_GS), nt_ldf(g0b + 2*NOISE3_GS)};
+		nv2 const gx1 = {nt_ldf(g1a), nt_ldf(g1b)}, gy1 = {nt_ldf(g1a + NOISE3_GS), nt_ldf(g1b + NOISE3_GS)}, gz1 = {nt_ldf(g1a + 2*NOISE3_GS), nt_ldf(g1b + 2*NOISE3_GS)};
+		nlo[c] = gx0*fxc + gy0*fyc + gz0*f0z;
+		nhi[c] = gx1*fxc + gy1*fyc + gz1*f1z;
+	}
+	float const ux = gl_fade(f0x), uy = gl_fade(f0y);
+	nv2 const uz = gl_fade(f0z);
+	nv2 const z0 = gl_mix(nlo[0], nhi[0], uz), z1 = gl_mix(nlo[1], nhi[1], uz), z2 = gl_mix(nlo[2], nhi[2], uz), z3 = gl_mix(nlo[3], nhi[3], uz);
+	nv2 const y0 = gl_mix(z0, z2, nt_bc<nv2>(uy)), y1 = gl_mix(z1, z3, nt_bc<nv2>(uy));
+	return 2.2f*gl_mix(y0, y1, nt_bc<nv2>(ux));
+}
+// glm::simplex(vec3) for two positions
+template<bool CHECK> TERRA_HD nv2 simplex3_lut(nv2 vx, nv2 vy, nv2 vz, char const *tab) {
+	float const G = (float)(1.0/6.0), F = (float)(1.0/3.0);
+	nv2 const one = nt_bc<nv2>(1.0f), zero = nt_bc<nv2>(0.0f);
+	nv2 const skew = vx*F + vy*F + vz*F;
+	nv2 const c0 = nt_floor(vx + skew), c1 = nt_floor(vy + skew), c2 = nt_floor(vz + skew);
+	if (CHECK && TERRA_UNLIKELY(!(nt_all_below(c0, 4194304.0f) && nt_all_below(c1, 4194304.0f) && nt_all_below(c2, 4194304.0f)))) {
+		return nv2{simplex3(vx[0], vy[0], vz[0]), simplex3(vx[1], vy[1], vz[1])};
+	}
+	nv2 const unskew = c0*G + c1*G + c2*G;
+	nv2 const a0 = vx - c0 + unskew, a1 = vy - c1 + unskew, a2 = vz - c2 + unskew; // x0
+	// g = step(x0.yzx, x0.xyz): 1 where x0 >= x0.yzx; l = 1 - g; i1 = min(g, l.zxy), i2 = max(g, l.zxy) -- on {0, 1} that is "and" / "or"
+	ni2 const g0 = ~(a0 < a1), g1 = ~(a1 < a2), g2 = ~(a2 < a0);
+	ni2 const p0 = g0 & ~g2, p1 = g1 & ~g0, p2 = g2 & ~g1; // i1
+	ni2 const q0 = g0 | ~g2, q1 = g1 | ~g0, q2 = g2 | ~g1; // i2
+	nv2 const o10 = nt_sel(p0, one, zero), o11 = nt_sel(p1, one, zero), o12 = nt_sel(p2, one, zero);
+	nv2 const o20 = nt_sel(q0, one, zero), o21 = nt_sel(q1, one, zero), o22 = nt_sel(q2, one, zero);
+	nv2 const b0 = a0 - o10 + G, b1 = a1 - o11 + G, b2 = a2 - o12 + G;
+	nv2 const d0 = a0 - o20 + F, d1 = a1 - o21 + F, d2 = a2 - o22 + F;
+	nv2 const e0 = a0 - 0.5f, e1 = a1 - 0.5f, e2 = a2 - 0.5f;
+	nv2 const r0 = gl_mod289<nv2>(c0), r1 = gl_mod289<nv2>(c1), r2 = gl_mod289<nv2>(c2);
+	nv2 dp[4];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int const i0 = (int)r0[e] << 2, i1 = (int)r1[e] << 2, i2 = (int)r2[e] << 2;
+		int const x1 = p0[e] ? 4 : 0, y1 = p1[e] ? 4 : 0, z1 = p2[e] ? 4 : 0, x2 = q0[e] ? 4 : 0, y2 = q1[e] ? 4 : 0, z2 = q2[e] ? 4 : 0;
+		// permute(permute(permute(ci.z + off.z) + ci.y + off.y) + ci.x + off.x) for off = 0, i1, i2, 1
+		char const *const gA = tab + NOISE3_GX + nt_ldi(tab + nt_ldi(tab + nt_ldi(tab + i2)      + i1)      + i0);
+		char const *const gB = tab + NOISE3_GX + nt_ldi(tab + nt_ldi(tab + nt_ldi(tab + i2 + z1) + i1 + y1) + i0 + x1);
+		char const *const gC = tab + NOISE3_GX + nt_ldi(tab + nt_ldi(tab + nt_ldi(tab + i2 + z2) + i1 + y2) + i0 + x2);
+		char const *const gD = tab + NOISE3_GX + nt_ldi(tab + nt_ldi(tab + nt_ldi(tab + i2 + 4)  + i1 + 4)  + i0 + 4);
+		dp[0][e] = nt_ldf(gA)*a0[e] + nt_ldf(gA + NOISE3_GS)*a1[e] + nt_ldf(gA + 2*NOISE3_GS)*a2[e];
+		dp[1][e] = nt_ldf(gB)*b0[e] + nt_ldf(gB + NOISE3_GS)*b1[e] + nt_ldf(gB + 2*NOISE3_GS)*b2[e];
+		dp[2][e] = nt_ldf(gC)*d0[e] + nt_ldf(gC + NOISE3_GS)*d1[e] + nt_ldf(gC + 2*NOISE3_GS)*d2[e];
+		dp[3][e] = nt_ldf(gD)*e0[e] + nt_ldf(gD + NOISE3_GS)*e1[e] + nt_ldf(gD + 2*NOISE3_GS)*e2[e];
+	}
+	// (everything is finite here: std::max(m, 0) is fmaxf)
+	nv2 wa = nt_max0(0.6f - (a0*a0 + a1*a1 + a2*a2)), wb = nt_max0(0.6f - (b0*b0 + b1*b1 + b2*b2)), wc = nt_max0(0.6f - (d0*d0 + d1*d1 + d2*d2)), wd = nt_max0(0.6f - (e0*e0 + e1*e1 + e2*e2));
+	wa = wa*wa; wb = wb*wb; wc = wc*wc; wd = wd*wd;
+	wa = wa*wa; wb = wb*wb; wc = wc*wc; wd = wd*wd;
+	return 42.0f*((wa*dp[0] + wb*dp[1]) + (wc*dp[2] + wd*dp[3]));
+}
+
 // ---- noise shaping (src/mesh_gen.cpp:555-571)
 TERRA_HD float postproc_noise_zval(float z, hmap_params_t const &h) {
 	if (z > h.plat_bot) {z = h.plat_bot + h.plat_h*(z - h.plat_bot) + min_std(h.plat_max, h.plat_s*(z - h.plat_bot));}

@@ -107,10 +107,30 @@ template<int MODE> __global__ __launch_bounds__(256) void k_noise_tiles(tile_ref
 	if (x + 1 < tw) {o[1] = finish_cell(zz[1], job, nc, L, smx, smy, x + 1, y);}
 }
 
-// ------------------------------------------------------------------ K9: 3-D lattice field (voxel_manager::create_procedural, src/voxels.cpp:312-345), one voxel per lane, z fastest
-template<bool PERLIN> __global__ __launch_bounds__(256) void k_voxel_noise(float *__restrict__ out, size_t nvox, vox_noise_job_t J) {
-	size_t const i = (size_t)blockIdx.x*256 + threadIdx.x;
-	if (i < nvox) {out[i] = voxel_noise_cell(i, J, PERLIN);}
+// ------------------------------------------------------------------ K9: 3-D lattice field (voxel_manager::create_procedural, src/voxels.cpp:312-345), z fastest
+// Two voxels of a column per lane, (z, z + 1): the lattice hashes and gradients come from the 3-D table in LDS (noise3_lut_fill: 5.8 KB per block, staged once for
+// VN_CHUNKS x 256 pairs), Perlin's x / y lattice work is shared by the pair and the interpolation runs on register pairs.  One voxel per lane with the direct code was
+// 2114 (Perlin) / 1721 (simplex) vector instructions per voxel for five octaves (profiles/r06_pmc_voxel_noise_summary.txt).
+constexpr unsigned VN_CHUNKS = 8;
+template<bool PERLIN> __global__ __launch_bounds__(256) void k_voxel_noise(float *__restrict__ out, size_t npairs, uint32_t nzp, vox_noise_job_t J, uint32_t const *__restrict__ lut) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_lut[NOISE3_LUT_DWORDS];
+	for (unsigned i = threadIdx.x; i < NOISE3_LUT_DWORDS/4; i += 256) {((uint4 *)s_lut)[i] = ((uint4 const *)lut)[i];}
+	__syncthreads();
+	char const *const tab = (char const *)s_lut;
+#pragma unroll 1
+	for (unsigned c = 0; c < VN_CHUNKS; ++c) {
+		size_t const i = ((size_t)blockIdx.x*VN_CHUNKS + c)*256 + threadIdx.x;
+		if (i >= npairs) break;
+		size_t const col = i / nzp;
+		unsigned const z = (unsigned)(i - col*nzp)*2u, x = (unsigned)(col % J.nx), y = (unsigned)(col / J.nx) + J.y0;
+		nv2 const v = voxel_noise_pair<PERLIN>(x, y, z, J, tab);
+		float *o = out + col*J.nz + z;
+		if (z + 1 < J.nz) {
+			if ((J.nz & 1u) == 0) {*(nv2 *)o = v;} // (even nz: every pair starts on an 8-byte boundary)
+			else {o[0] = v[0]; o[1] = v[1];}
+		}
+		else {o[0] = v[0];}
+	}
 }
 
 } // namespace terra

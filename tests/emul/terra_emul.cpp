@@ -114,7 +114,18 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 	void quantize16(float const *vals, size_t n, float val_add, float val_div, uint8_t *pix) {quantize16_simple(vals, n, val_add, val_div, pix);}
 	bool tile_shadows_flow(terra::shadow_consts_t const &, uint32_t, uint32_t, uint32_t const *, int32_t const *, float const *, unsigned long long *, uint8_t *, uint32_t, uint32_t *) {return false;} // (level by level)
 	bool tile_weights(terra::landscape_consts_t const &, terra::tile_ref_pod_t const *, uint32_t, float const *, float const *, float const *, uint32_t *, terra::grass_block_pod_t *, uint8_t *) {return false;} // (the per-texel form)
-	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool /*fused: the exact values are within every tolerance*/) {voxel_noise_simple(out, nvox, J, perlin);}
+	// the pair evaluation of the HIP kernel (k_voxel_noise) over the same table, serially: columns x (z, z + 1) pairs
+	void voxel_noise(float *out, size_t nvox, terra::vox_noise_job_t const &J, bool perlin, bool /*fused: the exact values are within every tolerance*/, uint32_t const *lut3) {
+		size_t const ncol = nvox / J.nz;
+		for (size_t col = 0; col < ncol; ++col) {
+			unsigned const x = (unsigned)(col % J.nx), y = (unsigned)(col / J.nx) + J.y0;
+			for (unsigned z = 0; z < J.nz; z += 2) {
+				terra::nv2 const v = perlin ? terra::voxel_noise_pair<true>(x, y, z, J, (char const *)lut3) : terra::voxel_noise_pair<false>(x, y, z, J, (char const *)lut3);
+				out[col*J.nz + z] = v[0];
+				if (z + 1 < J.nz) {out[col*J.nz + z + 1] = v[1];}
+			}
+		}
+	}
 	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float = 0.0f) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused);}
 };
 typedef cpu_backend_t terra_backend_t;
@@ -206,6 +217,46 @@ extern "C" unsigned long long terra_emul_noise_lut_mismatches(unsigned n, uint32
 			terra::nv2 const p2 = ns.perlin(xs, ys), s2 = ns.simplex(xs, ys);
 			if (!same(p2[0], terra::perlin2(xs[0], ys[0])) || !same(p2[1], terra::perlin2(xs[1], ys[1]))) ++bad;
 			if (!same(s2[0], terra::simplex2(xs[0], ys[0])) || !same(s2[1], terra::simplex2(xs[1], ys[1]))) ++bad;
+		}
+	}
+	return bad;
+}
+
+// the 3-D table-driven lattice noise of the voxel-field kernel (perlin3_lut_z2 / simplex3_lut over noise3_lut_fill) against the direct evaluation: bit-identical on random
+// positions at several scales, next to the lattice planes where mod 289 wraps, beyond the 2^22 switch to the direct code, and on every hash value (a 300^2 x 4 lattice patch)
+extern "C" unsigned long long terra_emul_noise3_lut_mismatches(unsigned n, uint32_t seed) {
+	unsigned long long bad = 0;
+	std::vector<uint32_t> tab(2*terra::NOISE3_LUT_DWORDS + 4);
+	uint32_t *t = (uint32_t *)(((uintptr_t)tab.data() + 15) & ~(uintptr_t)15);
+	for (unsigned i = 0; i < 2*terra::NOISE3_LUT_DWORDS; ++i) {t[i] = terra::noise3_lut_fill(i % terra::NOISE3_LUT_DWORDS, i >= terra::NOISE3_LUT_DWORDS);}
+	char const *ts = (char const *)t, *tp = (char const *)(t + terra::NOISE3_LUT_DWORDS);
+	auto rnd = [&]() {seed = seed*1664525u + 1013904223u; return seed;};
+	auto rf = [&](float lo, float hi) {return lo + (hi - lo)*(float)(rnd() >> 8)*(1.0f/16777216.0f);};
+	auto same = [&](float a, float b) {return memcmp(&a, &b, 4) == 0 || (a != a && b != b);};
+	auto check = [&](float x0, float y0, float z0, float x1, float y1, float z1) {
+		terra::nv2 const p = terra::perlin3_lut_z2<true>(x0, y0, terra::nv2{z0, z1}, tp);
+		if (!same(p[0], terra::perlin3(x0, y0, z0)) || !same(p[1], terra::perlin3(x0, y0, z1))) ++bad;
+		terra::nv2 const s = terra::simplex3_lut<true>(terra::nv2{x0, x1}, terra::nv2{y0, y1}, terra::nv2{z0, z1}, ts);
+		if (!same(s[0], terra::simplex3(x0, y0, z0)) || !same(s[1], terra::simplex3(x1, y1, z1))) ++bad;
+	};
+	for (unsigned i = 0; i < n; ++i) {
+		unsigned const kind = i % 6;
+		float v[6];
+		if (kind == 0) {for (float &f : v) {f = rf(-3e6f, 3e6f);}}       // around the 2^22 switch
+		else if (kind == 1) {for (float &f : v) {f = rf(-1e8f, 1e8f);}}  // far beyond it
+		else if (kind == 2) {                                            // next to the wrap planes: lattice coordinate 289*k - 1 .. 289*k + 1
+			for (float &f : v) {f = (float)((int)(rnd() % 41) - 20)*289.0f + rf(-1.5f, 1.5f);}
+			if (i & 8) {v[1] = rf(-400.0f, 400.0f);} if (i & 16) {v[5] = rf(-400.0f, 400.0f);}
+		}
+		else {float const s = (kind == 3) ? 300.0f : ((kind == 4) ? 3.0f : 30000.0f); for (float &f : v) {f = rf(-s, s);}}
+		check(v[0], v[1], v[2], v[3], v[4], v[5]);
+	}
+	for (int cz = -2; cz < 2; ++cz) { // every (x, y) lattice column incl. the 288 | 289 planes, a few z planes around 0 and around the wrap
+		for (int cy = -5; cy < 295; ++cy) {
+			for (int cx = -5; cx < 295; ++cx) {
+				float const zb = (float)(cz + ((cy & 1) ? 289 : 0));
+				check((float)cx + 0.37f, (float)cy + 0.29f, zb + 0.41f, (float)cx + 0.81f, (float)cy + 0.63f, zb + 1.17f);
+			}
 		}
 	}
 	return bad;

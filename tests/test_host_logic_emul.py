@@ -49,6 +49,16 @@ def test_lattice_table_noise_equals_direct_evaluation(emul_lib):
     assert lib.terra_emul_noise_lut_mismatches(400000, 11) == 0
 
 
+def test_3d_lattice_table_noise_equals_direct_evaluation(emul_lib):
+    """k_voxel_noise reads glm's perlin(vec3) / simplex(vec3) hashes and gradients from a 3-D table (terra_noise.hpp: noise3_lut_fill, perlin3_lut_z2, simplex3_lut), two
+    voxels per lane: same bits as the direct evaluation on random positions, next to the mod-289 wrap planes, beyond the 2^22 switch, on every (x, y) lattice column"""
+    import ctypes
+    lib = ctypes.CDLL(emul_lib)
+    lib.terra_emul_noise3_lut_mismatches.restype = ctypes.c_ulonglong
+    lib.terra_emul_noise3_lut_mismatches.argtypes = [ctypes.c_uint, ctypes.c_uint32]
+    assert lib.terra_emul_noise3_lut_mismatches(300000, 13) == 0
+
+
 def test_block_records_of_regular_fbm_sums_equal_direct_evaluation(emul_lib):
     """regular fBm sums read their gradient terms from per-block records (one per lattice cell and octave, terra_noise.hpp: noise_blocktab_build / fbm2_bt):
     every cell of random 128 x 16 patches (random origin incl. the mod-289 wrap columns, spacing, octave count, shape) gives the bits of the direct sum"""
