@@ -287,6 +287,32 @@ int terra_apply_erosion_devmin_dev(terra_ctx *ctx, float *d, int xs, int ys, con
 	TERRA_CHECK_CTX if (!d || !d_min_zval) return terra::fail(TERRA_ERR_ARG, "null argument");
 	TERRA_TRY ctx->eng.apply_erosion_dev(d, xs, ys, 0.0f, iters, flags, d_min_zval); TERRA_CATCH
 }
+size_t terra_erosion_shard_arena_bytes(terra_ctx *ctx, uint32_t iters) {
+	if (!ctx) return 0;
+	return ctx->eng.sparse_arena_bytes(iters);
+}
+int terra_erosion_shard_trace_dev(terra_ctx *ctx, float *d, int xs, int ys, uint32_t iters, uint32_t row0, uint32_t nrows, void *d_arena) {
+	TERRA_CHECK_CTX if (!d || !d_arena) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (ys <= 0 || row0 > (uint32_t)ys || nrows > (uint32_t)ys - row0) return terra::fail(TERRA_ERR_ARG, "terra_erosion_shard_trace_dev: rows outside the grid");
+	TERRA_TRY
+		terra::sparse_shard_t sh{};
+		sh.phase = 1; sh.row0 = row0; sh.row1 = row0 + nrows; sh.arena = (uint8_t *)d_arena;
+		ctx->eng.apply_erosion_dev(d, xs, ys, 0.0f, iters, 0, nullptr, &sh);
+	TERRA_CATCH
+}
+int terra_erosion_shard_finish_dev(terra_ctx *ctx, float *d, int xs, int ys, const float *d_min_zval, uint32_t iters, uint32_t flags, uint32_t world, uint32_t self, const uint32_t *row_end, void *d_arena_self, size_t arena_stride) {
+	TERRA_CHECK_CTX if (!d || !d_min_zval || !row_end || !d_arena_self) return terra::fail(TERRA_ERR_ARG, "null argument");
+	if (world == 0 || world > terra::SPARSE_SHARD_MAX_WORLD || self >= world) return terra::fail(TERRA_ERR_ARG, "terra_erosion_shard_finish_dev: world must be 1 .. 16 and self below it");
+	for (uint32_t r = 0; r < world; ++r) {
+		if ((r && row_end[r] < row_end[r - 1]) || (r + 1 == world && (ys <= 0 || row_end[r] != (uint32_t)ys))) return terra::fail(TERRA_ERR_ARG, "terra_erosion_shard_finish_dev: row_end must be non-decreasing and end at ysize");
+	}
+	TERRA_TRY
+		terra::sparse_shard_t sh{};
+		sh.phase = 2; sh.arena = (uint8_t *)d_arena_self; sh.world = world; sh.self = self; sh.stride = (long long)arena_stride;
+		for (uint32_t r = 0; r < world; ++r) {sh.rows.end[r] = row_end[r];}
+		ctx->eng.apply_erosion_dev(d, xs, ys, 0.0f, iters, flags, d_min_zval, &sh);
+	TERRA_CATCH
+}
 int terra_apply_erosion(terra_ctx *ctx, float *h, int xs, int ys, float min_zval, uint32_t iters) {
 	TERRA_CHECK_CTX if (!h) return terra::fail(TERRA_ERR_ARG, "null heightmap");
 	TERRA_TRY

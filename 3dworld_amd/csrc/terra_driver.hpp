@@ -951,7 +951,9 @@ template<class BE> struct terra_engine {
 
 	// d_min (optional): min_zval is read from this DEVICE float when the final clamp runs (the only place apply_erosion uses it, src/erosion.cpp:158-162) -- the caller's
 	// noise kernel left it there (gen_grid_dev's d_minmax), no host round trip between a heightmap's noise and its erosion
-	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags, float const *d_min = nullptr) {
+	// sh (optional): one phase of a sharded run (sparse_shard_t).  Phase 1 only traces -- nothing is written to the grid, and when the sparse scheduler would not be tried for
+	// this run it does nothing at all; phase 2 is this call with the traces taken from the ranks' arenas instead of made here.
+	void apply_erosion_dev(float *d_hmap, int xsize, int ysize, float min_zval, uint32_t num_iters, uint32_t flags, float const *d_min = nullptr, sparse_shard_t const *sh = nullptr) {
 		require_scene();
 		if (d_min) {min_zval = 0.0f;} // (kept out of every launch argument and of the hipGraph key: a new minimum must not mean a new capture)
 		report = terra_erosion_report{};
@@ -959,12 +961,15 @@ template<class BE> struct terra_engine {
 		if (xsize <= 0 || ysize <= 0 || (uint64_t)(xsize + 8)*(uint64_t)(ysize + 8) >= (1ull << 30)) throw std::invalid_argument("apply_erosion: bad grid size");
 		check_erosion_iters(num_iters);
 		erosion_consts_t const ec = make_erosion_consts(xsize, ysize, min_zval);
+		if (sh && (flags & (TERRA_ERODE_SERIAL | TERRA_ERODE_SERIAL_WAVE))) throw std::invalid_argument("sharded erosion: not with the serial flags");
+		if (sh && sh->phase == 1 && !sparse_wanted(ec, num_iters)) return; // (the eroding rank will not look at the arenas either: same test, same answer)
 		grid_view_t g;
 		g.interior = d_hmap; g.xsize = xsize; g.ysize = ysize; g.NX = ec.NX; g.NY = ec.NY;
 		size_t const nborder = grid_view_t::border_floats(xsize, ysize);
 		g.border = scratch<float>(s_border, nborder);
 		be.launch(nborder, [=] TERRA_LAMBDA (size_t i) {border_init_body(g, i);});
 		report.droplets = num_iters;
+		if (sh && sh->phase == 1) {uint32_t first = 0; (void)sparse_erosion(g, ec, num_iters, false, nullptr, first, sh); return;}
 
 		if (flags & TERRA_ERODE_SERIAL) {
 			be.launch(1, [=] TERRA_LAMBDA (size_t) {
@@ -985,7 +990,7 @@ template<class BE> struct terra_engine {
 			// tried -- goes through the multi-version scheduler, which then clamps the whole grid (its record of written cells starts where it starts)
 			uint32_t first = 0;
 			if (sparse_wanted(ec, num_iters)) {
-				if (sparse_erosion(g, ec, num_iters, sparse, d_min, first)) return; // complete, sparse clamp applied
+				if (sparse_erosion(g, ec, num_iters, sparse, d_min, first, sh)) return; // complete, sparse clamp applied
 			}
 			if (first < num_iters && speculative_erosion(g, ec, num_iters, sparse && first == 0, d_min, first)) return; // sparse clamp already applied to every written cell
 		}
@@ -1012,30 +1017,42 @@ template<class BE> struct terra_engine {
 	}
 	// true: all droplets are committed and the clamp is applied (sparsely).  false: droplets [0, first) are on the grid, the caller continues from `first` with the
 	// general scheduler (and clamps the whole grid) -- first == num_iters: only the clamp is left.
-	bool sparse_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t N, bool record_touched, float const *d_min, uint32_t &first) {
+	// A SHARDED run (one grid over several GPUs; include/terra.h: terra_erosion_shard_*): the sparse scheduler's read-only phases run where the rows live.
+	//   phase 1 (every rank, the eroding one included): probe + lean traces of the droplets that start in rows [row0, row1), into the caller's arena -- nothing else, no marks;
+	//   phase 2 (the eroding rank): gather every rank's traces into its own arena (sparse_gather_wave), then check / commit / re-trace / clamp as a single context would.
+	static uint32_t sparse_touched_cap(uint32_t N) {return (uint32_t)std::min<uint64_t>((uint64_t)N*1024u + 65536u, 64u << 20);}
+	size_t sparse_arena_bytes(uint32_t N) const { // the layout below with the record of written cells included: what a rank's arena must hold
+		uint32_t const maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB);
+		auto up = [](size_t b) {return (b + 255) & ~(size_t)255;};
+		return 2*(up((size_t)N*maxb*SPEC_PAGE*4) + up((size_t)N*maxb*8) + up((size_t)N*maxb*4) + up((size_t)N*4)) + up((size_t)N*4*6) + up(sizeof(sparse_ctl_t)) + up((size_t)sparse_touched_cap(N)*4 + 4);
+	}
+	bool sparse_erosion(grid_view_t const &g, erosion_consts_t const &ec, uint32_t N, bool record_touched, float const *d_min, uint32_t &first, sparse_shard_t const *sh = nullptr) {
 		sparse_buffers_t sb{};
 		sb.grid = g; sb.ec = ec; sb.N = N;
+		if (sh && sh->phase == 1) {sb.shard = 1; sb.row0 = sh->row0; sb.row1 = sh->row1;}
 		sb.maxb = std::min<uint32_t>(std::max<uint32_t>(spec_cfg.maxb, 16), SPEC_MAXB);
 		sb.nbx = ((uint32_t)ec.NX >> 3) + 1; sb.nby = ((uint32_t)ec.NY >> 3) + 1;
 		sb.max_retraces = SPARSE_MAX_RETRACES;
 		if (opt.ero_sparse_retraces >= 0) {sb.max_retraces = (uint32_t)opt.ero_sparse_retraces;}
 		size_t const nblocks = (size_t)sb.nbx*sb.nby;
-		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)N*1024u + 65536u, 64u << 20) : 0u;
+		uint32_t const touched_cap = record_touched ? sparse_touched_cap(N) : 0u;
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2];
 		for (int b = 0; b < 2; ++b) {o_vals[b] = carve((size_t)N*sb.maxb*SPEC_PAGE*4); o_mask[b] = carve((size_t)N*sb.maxb*8); o_bl[b] = carve((size_t)N*sb.maxb*4); o_bc[b] = carve((size_t)N*4);}
-		size_t const o_slot = carve((size_t)N*4*6), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4);
+		size_t const o_slot = carve((size_t)N*4*6), o_ctl = carve(sizeof(sparse_ctl_t)), o_touched = carve((size_t)touched_cap*4 + 4); // (the record comes last: the arenas of a sharded run agree on everything in front of it)
 		// ~137 KB per droplet.  When the buffer has to grow, the request must fit what the device has free (the same budget rule as the general scheduler's ring, incl. the
 		// "ero.mem_budget" test knob); if it does not -- or the allocation fails anyway -- nothing has been touched yet: the general scheduler takes the whole run
-		if (off > s_spec.bytes) {
+		if (!sh && off > s_spec.bytes) {
 			size_t avail = be.mem_free() + s_spec.bytes, reserve = (size_t)1 << 30;
 			if (opt.ero_mem_budget >= 0) {avail = (size_t)opt.ero_mem_budget; reserve = 0;}
 			if (off + reserve > avail) {first = 0; return false;}
 		}
-		uint8_t *base = nullptr;
-		try {base = scratch<uint8_t>(s_spec, off);} // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
-		catch (std::exception const &) {first = 0; return false;}
+		uint8_t *base = sh ? sh->arena : nullptr; // (a sharded run works in the caller's arena: sparse_arena_bytes())
+		if (!sh) {
+			try {base = scratch<uint8_t>(s_spec, off);} // (the general scheduler's ring lives in the same grow-only buffer: the two never run at the same time)
+			catch (std::exception const &) {first = 0; return false;}
+		}
 		for (int b = 0; b < 2; ++b) {
 			sb.page_vals[b] = (float *)(base + o_vals[b]); sb.page_mask[b] = (unsigned long long *)(base + o_mask[b]);
 			sb.blk_list[b] = (uint32_t *)(base + o_bl[b]); sb.blk_cnt[b] = (uint32_t *)(base + o_bc[b]);
@@ -1045,21 +1062,38 @@ template<class BE> struct terra_engine {
 		sb.trace_groups = (N <= 64) ? N : std::max<uint32_t>(64, N/4); // a quarter of the droplets at most get a wave of their own at once: enough for a map with some ocean, and a fully dry map's waves then take four droplets each
 		sb.ctl = (sparse_ctl_t *)(base + o_ctl);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
+		if (sh && sh->phase == 1) { // a tracer: the first step of its droplets, then their lean traces -- into the arena, nothing else (no marks: wmin stays with the eroding rank)
+			sparse_buffers_t const s = sb;
+			be.launch(1, [=] TERRA_LAMBDA (size_t) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}, 64);
+			be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_probe_body(s, (uint32_t)i);});
+			be.launch_waves_lean(s.trace_groups, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
+			first = 0;
+			return false;
+		}
 		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks); // [head | dirty_min] of the general scheduler, all SPEC_NIL between runs: wmin borrows the second half
 		if (spec_blocks_clean != blk_arrays || spec_blocks_n != nblocks) {be.fill32(blk_arrays, SPEC_NIL, 2*nblocks);}
 		spec_blocks_clean = nullptr;
 		sb.wmin = blk_arrays + nblocks;
 		sparse_buffers_t const s = sb;
+		sparse_shard_t const shv = sh ? *sh : sparse_shard_t{};
+		bool const gather = sh != nullptr; // (phase 2)
 		auto rounds = [&](bool with_first) { // [control block, probe, trace, check, commit,] then: re-trace the lowest conflicted droplet, check, commit -- one hipGraph each way
-			struct {sparse_buffers_t s; uint32_t with_first; uint32_t tag;} gkey;
+			struct {sparse_buffers_t s; uint32_t with_first; uint32_t tag; sparse_shard_t sh;} gkey;
 			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.s.ec.min_zval = 0.0f; gkey.with_first = with_first ? 1u : 0u; gkey.tag = 0x53505253u; // (min_zval: read by the clamp only, which is not part of the graph)
+			if (gather) {gkey.sh.phase = 2; gkey.sh.world = shv.world; gkey.sh.self = shv.self; gkey.sh.stride = shv.stride; gkey.sh.rows = shv.rows;}
 			if (be.graph_replay(&gkey, sizeof(gkey))) return;
 			bool const cap = be.graph_begin();
 			try {
 				if (with_first) {
 					be.launch(1, [=] TERRA_LAMBDA (size_t) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}, 64);
+					if (gather) { // the traces were made where the rows live (phase 1 on every rank): fetch them, make the marks, build the work list
+						sparse_rows_t const rows = shv.rows; uint32_t const world = shv.world, self = shv.self; long long const stride = shv.stride;
+						be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_gather_wave(s, (uint32_t)i, rows, world, self, stride);});
+					}
+					else {
 					be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_probe_body(s, (uint32_t)i);}); // the first step of every droplet: most end there
 					be.launch_waves_lean(s.trace_groups, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
+					}
 					be.launch_waves_nolds(N, [=] TERRA_LAMBDA (size_t i) {sparse_check_wave(s, (uint32_t)i);});
 					be.launch_waves_nolds(s.trace_groups, [=] TERRA_LAMBDA (size_t i) {sparse_commit_wave(s, (uint32_t)i);});
 				}

@@ -1482,7 +1482,16 @@ struct sparse_buffers_t {
 	uint32_t *wmin;       // [nbx*nby] lowest droplet that wrote the block in any of its traces (SPEC_NIL: nobody); reset through the block lists at the end of the run
 	uint32_t *touched; uint32_t touched_cap;
 	sparse_ctl_t *ctl;
+	// a SHARDED run (one grid whose row strips live on several GPUs): every rank probes / traces the droplets that START in its rows [row0, row1) into its own
+	// arena (shard = 1: the other droplets are skipped, nobody marks wmin[]); the eroding rank then gathers all traces into its arena, makes the marks and goes on as usual
+	uint32_t shard, row0, row1;
 };
+// the interior row a droplet starts in (droplet_start's first two draws, src/erosion.cpp:67-70)
+TERRA_HD uint32_t sparse_start_row(erosion_consts_t const &ec, uint32_t j) {
+	rand_gen_t r; r.set_state((int)j + 11, 79*(int64_t)(int)j + 121);
+	(void)(r.rand() % ec.xsize);
+	return (uint32_t)(r.rand() % ec.ysize);
+}
 
 // backing store of a lean trace: reads = the grid (+ what this trace wrote back earlier), writes = private pages
 struct lean_back_t {
@@ -1593,7 +1602,7 @@ TERRA_HD void sparse_trace_droplet(sparse_buffers_t const &sb, uint32_t iter, ui
 		uint32_t const b = mem.back.my_blks[e] & SPEC_BLK_ID;
 		mem.back.my_masks[e] = m;
 		mem.back.my_blks[e] = m ? (b | SPEC_BLK_WRITTEN) : b;
-		if (m && !failed) {TERRA_ATOMIC_MIN(&sb.wmin[b], iter);}
+		if (m && !failed && !sb.shard) {TERRA_ATOMIC_MIN(&sb.wmin[b], iter);}
 	}
 	if (TERRA_LANE0) {
 		sb.blk_cnt[buf][iter] = n; sb.cur[iter] = buf;
@@ -1626,6 +1635,10 @@ struct probe_mem_t {
 	TERRA_HD void erode(int, int, float, float, float) {wrote = true;}
 };
 TERRA_HD void sparse_probe_body(sparse_buffers_t const &sb, uint32_t j) {
+	if (sb.shard) { // a tracer of a sharded run: only the droplets that start in its rows
+		uint32_t const z = sparse_start_row(sb.ec, j);
+		if (z < sb.row0 || z >= sb.row1) {sb.cur[j] = 0; sb.blk_cnt[0][j] = 0; sb.blk_cnt[1][j] = 0; sb.nsteps[j] = 0; sb.nan[j] = 0; sb.state[j] = SPARSE_TRACED; sb.queued[j] = 0; return;}
+	}
 	probe_mem_t m;
 	m.g = sb.grid; m.blks = sb.blk_list[0] + (size_t)j*sb.maxb; m.nblk = 0; m.nbx = sb.nbx; m.NXm1 = sb.ec.NX - 1; m.NYm1 = sb.ec.NY - 1; m.wrote = false;
 	droplet_state_t d;
@@ -1642,6 +1655,42 @@ TERRA_HD void sparse_probe_body(sparse_buffers_t const &sb, uint32_t j) {
 TERRA_HD void sparse_trace_wave(sparse_buffers_t const &sb, uint32_t group, lean_scratch_t const &ws) {
 	uint32_t const n = wave_uniform(sb.ctl->nwork);
 	for (uint32_t k = group; k < n; k += sb.trace_groups) {sparse_trace_droplet(sb, wave_uniform(sb.work[k]), 0u, SPARSE_TRACED, ws);}
+}
+// ---- the eroding rank of a sharded run: one wave per droplet fetches the trace its owner made (block list, masks, the pages of written blocks, the droplet's counters)
+// from the owner's arena -- every arena has the layout of this one, rank r's lies (r - self)*stride bytes from it in the mapped range -- makes the marks the trace did not
+// make and puts the droplet on the work list.  Afterwards this arena is what a single context would hold after its own probe + trace passes (marks and work list are sets:
+// their order does not matter), and check / commit / re-trace run unchanged.
+struct sparse_rows_t {uint32_t end[16];}; // rank r owns the interior rows [end[r-1], end[r])
+struct sparse_shard_t {int phase; uint32_t row0, row1; uint8_t *arena; uint32_t world, self; long long stride; sparse_rows_t rows;}; // one phase of a sharded run (terra_engine::sparse_erosion)
+constexpr uint32_t SPARSE_SHARD_MAX_WORLD = 16;
+template<class T> TERRA_HD T *sparse_peer(T *local, long long rel) {return (T *)((char *)local + rel);}
+TERRA_HD void sparse_gather_wave(sparse_buffers_t const &sb, uint32_t j, sparse_rows_t const &rows, uint32_t world, uint32_t self, long long stride) {
+	uint32_t const z = sparse_start_row(sb.ec, j);
+	uint32_t owner = 0;
+	while (owner + 1 < world && z >= rows.end[owner]) {++owner;}
+	long long const rel = ((long long)owner - (long long)self)*stride;
+	size_t const pbase = (size_t)j*sb.maxb;
+	uint32_t const n = wave_uniform(*sparse_peer(&sb.blk_cnt[0][j], rel)), st = wave_uniform(*sparse_peer(&sb.state[j], rel)), q = wave_uniform(*sparse_peer(&sb.queued[j], rel));
+	uint32_t const ns = wave_uniform(*sparse_peer(&sb.nsteps[j], rel));
+	uint32_t const *sbl = sparse_peer(sb.blk_list[0] + pbase, rel);
+	if (owner != self) {
+		unsigned long long const *smk = sparse_peer(sb.page_mask[0] + pbase, rel);
+		float const *spv = sparse_peer(sb.page_vals[0] + pbase*SPEC_PAGE, rel);
+		TERRA_LANES(e, n) {sb.blk_list[0][pbase + e] = sbl[e]; sb.page_mask[0][pbase + e] = smk[e];}
+		for (uint32_t e = 0; e < n; ++e) {
+			if (!(wave_uniform(sbl[e]) & SPEC_BLK_WRITTEN)) continue; // (a page is read for the cells its mask names only)
+			TERRA_LANES(c, SPEC_PAGE) {sb.page_vals[0][(pbase + e)*SPEC_PAGE + c] = spv[(size_t)e*SPEC_PAGE + c];}
+		}
+		if (TERRA_LANE0) {
+			sb.blk_cnt[0][j] = n; sb.blk_cnt[1][j] = 0; sb.cur[j] = 0; sb.state[j] = st; sb.nsteps[j] = ns; sb.nan[j] = *sparse_peer(&sb.nan[j], rel); sb.queued[j] = q;
+		}
+	}
+	if (st != (uint32_t)SPARSE_FAILED) {TERRA_LANES(e, n) {uint32_t const ent = sbl[e]; if (ent & SPEC_BLK_WRITTEN) {TERRA_ATOMIC_MIN(&sb.wmin[ent & SPEC_BLK_ID], j);}}}
+	if (TERRA_LANE0 && q) {
+		sb.work[TERRA_ATOMIC_ADD(&sb.ctl->nwork, 1u)] = j;
+		TERRA_ATOMIC_ADD(&sb.ctl->traced_steps, (unsigned long long)ns);
+	}
+	TERRA_WAVE_SYNC();
 }
 // a later round (ONE wave): everything below the lowest conflicted droplet is committed; that droplet is traced again on the grid as it stands now
 TERRA_HD void sparse_retrace_wave(sparse_buffers_t const &sb, lean_scratch_t const &ws) {

@@ -192,7 +192,7 @@ def _all_ok(dist, ok, coll_device="cpu"):
     return float(t.item()) > 0.5
 
 
-def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cpu"):
+def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cpu", strip_bytes=None):
     """ONE nx x ny float grid over all ranks of `dist`: this rank's rows live in its HBM, everybody maps the whole grid (see include/terra.h, terra_dgrid_*).
     Returns (grid, rows) with grid.ptr the mapped device pointer and rows[r] = (r0, r1) of rank r.  Raises RuntimeError on EVERY rank when any rank failed (a runtime
     without virtual memory management, devices that cannot map each other ...): the two steps end in an agreement, so nobody is left waiting in a collective."""
@@ -200,7 +200,11 @@ def create_distributed_grid(terra_mod, terra, dist, nx, ny, tag, coll_device="cp
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
     g, fd, err = None, -1, None
     try:  # step 1: the local strip and its descriptor
-        rows, strip_bytes = strip_rows_aligned(terra_mod, terra, nx, ny, world)
+        if strip_bytes is None:
+            rows, strip_bytes = strip_rows_aligned(terra_mod, terra, nx, ny, world)
+        else:  # a plain byte array in equal strips (the trace arenas of a sharded erosion): nx / ny unused
+            gran = terra_mod.DistributedGrid.granularity(terra)
+            rows, strip_bytes = None, -(-int(strip_bytes) // gran) * gran
         g = terra_mod.DistributedGrid(terra, [strip_bytes] * world, rank)
         if world > 1:
             fd = g.export_fd()
@@ -278,10 +282,14 @@ class OneHeightmapPipeline:
       reuse     `grids` grids are in flight; before a rank contributes to the all_reduce of step s it waits (host) until the erosion of step s - grids + 1 is complete if
                 it was that step's eroder -- so when the all_reduce of step s returns anywhere, that erosion is complete everywhere and step s + 1 may overwrite its grid."""
 
-    def __init__(self, terra_mod, make_ctx, cfg, dist, nx, ny, droplets, tag, grids=8, eroders=2, coll_device="cpu"):
+    def __init__(self, terra_mod, make_ctx, cfg, dist, nx, ny, droplets, tag, grids=8, eroders=2, coll_device="cpu", shard_traces=None):
         import os
         import threading
         self.pkg, self.dist, self.nx, self.ny, self.droplets = terra_mod, dist, nx, ny, droplets
+        # shard_traces (opt-in; TERRA_ONEGRID_SHARD_TRACES=1): the sparse erosion scheduler's read-only phases run where the rows live (terra_erosion_shard_*): after a
+        # step's all_reduce every rank probes / traces the droplets that START in its strip into its own arena (one more terra_dgrid per grid in flight, the strips are the
+        # arenas), a second collective says "all traces made", the eroding rank gathers the traces over xGMI and checks / commits.  Same grid, bit for bit.
+        self.shard = (os.environ.get("TERRA_ONEGRID_SHARD_TRACES", "0") == "1") if shard_traces is None else bool(shard_traces)
         self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
         self.nctx = make_ctx()
         self.st = self.nctx.init_scene(cfg)
@@ -304,6 +312,28 @@ class OneHeightmapPipeline:
             self.rows = rows
         self.coll_device = coll_device
         self._threading = threading
+        self.tctx, self.arenas, self._pg2, self._hmin = None, [], None, []
+        if self.shard:
+            try:
+                self.tctx = make_ctx()
+                self.tctx.init_scene(cfg)
+                self.arena_stride = None
+                for g in range(grids):
+                    ag, _ = create_distributed_grid(terra_mod, self.nctx, dist, 0, 0, f"{tag}_arena_{g}", coll_device, strip_bytes=self.tctx.erosion_shard_arena_bytes(droplets))
+                    self.arenas.append(ag)
+                    self.arena_stride = ag.strip_bytes[0]
+                    self._hmin.append(self.tctx.alloc(8))
+                self.row_end = [r1 for (_, r1) in self.rows]
+                if dist is not None and dist.is_initialized() and self.world > 1:
+                    self._pg2 = dist.new_group()  # the "traces made" collectives: a communicator of their own, so that they never queue in front of the next steps' all_reduce(min)
+            except Exception:
+                self._free_shard()
+                for x in self.grids:
+                    x.destroy()
+                self.nctx.close()
+                for c in self.ectx:
+                    c.close()
+                raise
         # A collective that runs on the device (RCCL) lets a step be enqueued without a host round trip -- the form tools/bench_native_onegrid.c has in C: the strip's
         # {min, max} stay in HBM (terra_gen_grid_rows_minmax_async_dev), all_reduce(min) works on that float on the noise context's stream, the eroding context's
         # stream waits for an event behind it and the final clamp reads min(vals) from HBM (terra_apply_erosion_devmin_dev).  Measured on one GPU at a simulated world
@@ -317,9 +347,35 @@ class OneHeightmapPipeline:
             self._mm = torch.zeros((grids, 2), dtype=torch.float32, device=coll_device)
             torch.cuda.current_stream(coll_device).synchronize()  # (the fill ran on the current stream; everything else touches _mm on _tstream)
             self._ev = [self.nctx.event_create() for _ in range(grids)]
+            if self.shard:
+                self._tstream2 = torch.cuda.Stream(device=coll_device)
+                self.tctx.set_stream(self._tstream2.cuda_stream)
+                self._ev2 = [self.tctx.event_create() for _ in range(grids)]
+                self._flag = torch.zeros(grids, dtype=torch.float32, device=coll_device)
+                torch.cuda.current_stream(coll_device).synchronize()
+
+    def _free_shard(self):
+        for a in self.arenas:
+            a.destroy()
+        self.arenas = []
+        for b in self._hmin:
+            b.free()
+        self._hmin = []
+        if self.tctx is not None:
+            self.tctx.close()
+            self.tctx = None
+
+    def _traces_made(self, ok=True):
+        """host-side collective of the sharded form: every rank's traces of the step are complete (and whether all of them worked)"""
+        if self.dist is None or not self.dist.is_initialized() or self.world == 1:
+            return ok
+        import torch
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=self.coll_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self._pg2)
+        return float(t.item()) > 0.5
 
     def close(self):
-        for c in [self.nctx] + self.ectx:
+        for c in [self.nctx] + self.ectx + ([self.tctx] if self.tctx is not None else []):
             c.synchronize()
         if self.dist is not None and self.dist.is_initialized():
             self.dist.barrier()  # nobody unmaps a strip a peer may still be reading
@@ -329,6 +385,12 @@ class OneHeightmapPipeline:
             for e in self._ev:
                 self.nctx.event_destroy(e)
             self.nctx.set_stream(None)
+            if self.shard:
+                for e in self._ev2:
+                    self.tctx.event_destroy(e)
+                self.tctx.set_stream(None)
+        if self.shard:
+            self._free_shard()
         self.nctx.close()
         for c in self.ectx:
             c.close()
@@ -366,8 +428,13 @@ class OneHeightmapPipeline:
                     return
                 s, g = job
                 try:
-                    c.event_wait(self._ev[g])  # behind the step's noise and its all_reduce, on the device
-                    c.apply_erosion_devmin_dev(self.grids[g].ptr, self.nx, self.ny, self._mm[g].data_ptr(), self.droplets, pkg.ERODE_MINZ_IS_MIN)
+                    if self.shard:
+                        c.event_wait(self._ev2[g])  # behind every rank's traces of the step (the second collective), on the device
+                        c.erosion_shard_finish_dev(self.grids[g].ptr, self.nx, self.ny, self._mm[g].data_ptr(), self.droplets, pkg.ERODE_MINZ_IS_MIN, self.world, self.rank,
+                                                   self.row_end, self.arenas[g].strip_ptr(self.rank), self.arena_stride)
+                    else:
+                        c.event_wait(self._ev[g])  # behind the step's noise and its all_reduce, on the device
+                        c.apply_erosion_devmin_dev(self.grids[g].ptr, self.nx, self.ny, self._mm[g].data_ptr(), self.droplets, pkg.ERODE_MINZ_IS_MIN)
                     c.synchronize()
                     if collect is not None:
                         collect(s, self.grids[g].ptr)
@@ -398,6 +465,17 @@ class OneHeightmapPipeline:
                     if group:
                         self.dist.all_reduce(self._mm[g, 0:1], op=self.dist.ReduceOp.MIN)  # enqueued: ordered behind the strip's kernels and in front of the record below
                     self.nctx.event_record(self._ev[g])
+                    if self.shard:  # this rank's traces behind the step's all_reduce, on the tracer context's stream; then "all traces made" on that stream, in its own group
+                        with torch.cuda.stream(self._tstream2):
+                            try:
+                                self.tctx.event_wait(self._ev[g])
+                                if not errs:
+                                    self.tctx.erosion_shard_trace_dev(self.grids[g].ptr, self.nx, self.ny, self.droplets, r0, r1 - r0, self.arenas[g].strip_ptr(self.rank))
+                            except Exception as e:  # noqa: BLE001
+                                errs.append(repr(e))
+                            if group and self._pg2 is not None:
+                                self.dist.all_reduce(self._flag[g:g + 1], op=self.dist.ReduceOp.MIN, group=self._pg2)
+                            self.tctx.event_record(self._ev2[g])
                     if s % self.world == self.rank and not errs:
                         done[s] = self._threading.Event()
                         jobs[mine % len(jobs)].put((s, g))
@@ -411,6 +489,8 @@ class OneHeightmapPipeline:
                 x.join()
         try:
             self.nctx.synchronize()
+            if self.shard:
+                self.tctx.synchronize()
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
         _, ok = self._all_reduce_min(0.0, not errs)  # every rank's erosions are complete, and whether any of them failed
@@ -436,7 +516,13 @@ class OneHeightmapPipeline:
                     return
                 s, g, mn = job
                 try:
-                    c.apply_erosion_dev(self.grids[g].ptr, self.nx, self.ny, mn, self.droplets, pkg.ERODE_MINZ_IS_MIN)
+                    if self.shard:
+                        import numpy as np
+                        self._hmin[g].upload(np.array([mn, 0.0], np.float32))
+                        c.erosion_shard_finish_dev(self.grids[g].ptr, self.nx, self.ny, self._hmin[g].ptr, self.droplets, pkg.ERODE_MINZ_IS_MIN, self.world, self.rank,
+                                                   self.row_end, self.arenas[g].strip_ptr(self.rank), self.arena_stride)
+                    else:
+                        c.apply_erosion_dev(self.grids[g].ptr, self.nx, self.ny, mn, self.droplets, pkg.ERODE_MINZ_IS_MIN)
                     c.synchronize()
                     if collect is not None:
                         collect(s, self.grids[g].ptr)
@@ -466,6 +552,16 @@ class OneHeightmapPipeline:
                     if not errs:
                         errs.append("an erosion failed on another rank")
                     break
+                if self.shard:  # the grid is complete everywhere: my strip's droplets, then "all traces made"
+                    try:
+                        self.tctx.erosion_shard_trace_dev(self.grids[g].ptr, self.nx, self.ny, self.droplets, r0, r1 - r0, self.arenas[g].strip_ptr(self.rank))
+                        self.tctx.synchronize()
+                    except Exception as e:  # noqa: BLE001
+                        errs.append(repr(e))
+                    if not self._traces_made(not errs):
+                        if not errs:
+                            errs.append("a trace failed on another rank")
+                        break
                 if s % self.world == self.rank:
                     done[s] = self._threading.Event()
                     jobs[mine % len(jobs)].put((s, g, mn))

@@ -145,6 +145,9 @@ _PROTOS = {
     "terra_event_synchronize": (_i32, [_vp]),
     "terra_event_destroy": (None, [_vp]),
     "terra_apply_erosion_devmin_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32]),
+    "terra_erosion_shard_arena_bytes": (C.c_size_t, [_vp, _u32]),
+    "terra_erosion_shard_trace_dev": (_i32, [_vp, _vp, _i32, _i32, _u32, _u32, _u32, _vp]),
+    "terra_erosion_shard_finish_dev": (_i32, [_vp, _vp, _i32, _i32, _vp, _u32, _u32, _u32, _u32, C.POINTER(_u32), _vp, C.c_size_t]),
     "terra_gen_grid_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _vp, _vp]),
     "terra_gen_grid_rows_minmax_async_dev": (_i32, [_vp, _f, _f, _f, _f, _u32, _u32, _u32, _i32, _u32, _u32, _vp, _vp]),
     "terra_get_erosion_report": (_i32, [_vp, C.POINTER(ErosionReport)]),
@@ -623,6 +626,19 @@ class Terra:
     def apply_erosion_devmin_dev(self, ptr, xsize, ysize, min_ptr, iters, flags=0):
         """apply_erosion with min_zval read from device memory (one float) when the final clamp runs"""
         self._ck(self.lib.terra_apply_erosion_devmin_dev(self.ctx, ptr, xsize, ysize, min_ptr, iters, flags))
+
+    def erosion_shard_arena_bytes(self, iters):
+        """bytes of one rank's arena of a sharded erosion (terra_erosion_shard_*)"""
+        return int(self.lib.terra_erosion_shard_arena_bytes(self.ctx, iters))
+
+    def erosion_shard_trace_dev(self, ptr, xsize, ysize, iters, row0, nrows, arena_ptr):
+        """probe / trace the droplets that start in rows [row0, row0 + nrows) into this rank's arena (nothing is written to the grid)"""
+        self._ck(self.lib.terra_erosion_shard_trace_dev(self.ctx, ptr, xsize, ysize, iters, row0, nrows, arena_ptr))
+
+    def erosion_shard_finish_dev(self, ptr, xsize, ysize, min_ptr, iters, flags, world, self_rank, row_end, arena_self_ptr, arena_stride):
+        """the eroding rank: gather the ranks' traces, check / commit / re-trace / clamp = apply_erosion_devmin_dev on the same grid"""
+        re = (C.c_uint32 * world)(*[int(v) for v in row_end])
+        self._ck(self.lib.terra_erosion_shard_finish_dev(self.ctx, ptr, xsize, ysize, min_ptr, iters, flags, world, self_rank, re, arena_self_ptr, arena_stride))
 
     def event_create(self):
         e = C.c_void_p()

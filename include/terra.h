@@ -265,6 +265,22 @@ int  terra_apply_erosion_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int 
  * stream was made to wait for) when the final clamp runs, the only use apply_erosion makes of it (src/erosion.cpp:158-162) */
 int  terra_apply_erosion_devmin_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, const float *d_min_zval, uint32_t num_iters, uint32_t flags);
 int  terra_apply_erosion(terra_ctx *ctx, float *h_heightmap, int xsize, int ysize, float min_zval, uint32_t num_iters);
+/* ---- the erosion of ONE grid whose row strips live on several GPUs (terra_dgrid below), with the sparse scheduler's read-only phases run where the
+ * rows live.  apply_erosion (src/erosion.cpp:14) is one serial droplet order over the whole map, so it is the eroding rank that checks and commits -- but the first step of
+ * every droplet and the trace of the ones that move read the ORIGINAL grid only, and a droplet spends its life near where it starts: rank r probes / traces the droplets
+ * that start in its rows into its own HBM, the eroding rank fetches the (small) traces over xGMI instead of walking remote rows window by window.
+ *   every rank r (the eroding one too), once the whole grid is written:
+ *       terra_erosion_shard_trace_dev(ctx, d_grid, xsize, ysize, num_iters, row0_r, nrows_r, d_arena_r)
+ *   the eroding rank, once every rank's trace call has completed (the caller's collective / event):
+ *       terra_erosion_shard_finish_dev(ctx, d_grid, xsize, ysize, d_min_zval, num_iters, flags, world, self, row_end, d_arena_self, arena_stride)
+ *         = terra_apply_erosion_devmin_dev on the same grid, bit for bit (the traces are the ones it would have made itself).
+ * d_arena_r: terra_erosion_shard_arena_bytes() bytes of rank r's memory, all of them mapped on the eroding rank arena_stride bytes apart in rank order (one more
+ * terra_dgrid whose strips are the arenas); row_end[r] = first row after rank r's strip (row_end[world - 1] = ysize); world <= 16.  Runs the sparse scheduler would not
+ * take (many droplets on a small map) make the trace call a no-op and the finish call the ordinary erosion.  Not with TERRA_ERODE_SERIAL*. */
+size_t terra_erosion_shard_arena_bytes(terra_ctx *ctx, uint32_t num_iters);
+int  terra_erosion_shard_trace_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, uint32_t num_iters, uint32_t row0, uint32_t nrows, void *d_arena);
+int  terra_erosion_shard_finish_dev(terra_ctx *ctx, float *d_heightmap, int xsize, int ysize, const float *d_min_zval, uint32_t num_iters, uint32_t flags,
+                                    uint32_t world, uint32_t self, const uint32_t *row_end, void *d_arena_self, size_t arena_stride);
 int  terra_get_erosion_report(terra_ctx *ctx, terra_erosion_report *out);
 /* tuning of the speculative scheduler (0 keeps a value): droplets in flight (ring slots; default automatic from the grid size, 0xFFFFFFFF restores that; at most
  * 2^20 is accepted, and a run uses at most (2^25 - 1)/block_list_capacity slots: version pages are addressed with 31-bit float indices),

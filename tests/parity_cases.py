@@ -180,6 +180,69 @@ def case_erosion_sparse(pkg, t, orc, n, iters, force="1", retraces=None, flags=0
     return r, stats
 
 
+def case_erosion_sharded(pkg, make_ctx, orc, n, iters, world, eroder, force=None, retraces=None, uneven=True):
+    """terra_erosion_shard_*: `world` contexts stand for the ranks of the one-grid pipeline -- each traces the droplets that start in its row strip into its own arena, the
+    eroding one gathers the traces and checks / commits.  The grid must come out as the oracle's apply_erosion (and a single context's) bit for bit, whatever the split:
+    uneven strips, an empty strip, the eroder in the middle, conflicts between droplets of different strips (forced sparse with a re-trace allowance), a hand-over to the
+    general scheduler (small allowance), and a run the sparse scheduler does not take at all (the trace calls are then no-ops, the finish call the ordinary erosion)."""
+    import os
+    keys = ("TERRA_ERO_SPARSE", "TERRA_ERO_SPARSE_RETRACES")
+    old = {k: os.environ.get(k) for k in keys}
+    ctxs = []
+    try:
+        for k, v in zip(keys, (force, retraces)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        ctxs = [make_ctx() for _ in range(world)]
+        pc_, oc = cfg_pair(pkg, mesh_gen_mode=0)
+        for c in ctxs:
+            st = c.init_scene(pc_)
+        orc.init(oc)
+        a = orc.gen_grid(-n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, 1)
+        mn = float(a.min())
+        b = a.copy()
+        stats, steps = orc.apply_erosion_stats(a, mn, iters)
+        if uneven and world > 1:  # uneven strips, the last but one EMPTY when there are three or more
+            cuts = sorted({(n * (2 * r + 1)) // (2 * world + 1) for r in range(1, world)})
+            ends = (cuts + [n] * world)[:world - 1] + [n]
+            if world >= 3:
+                ends[world - 2] = ends[world - 3]
+        else:
+            ends = [n * (r + 1) // world for r in range(world)]
+        e = ctxs[eroder]
+        stride = (e.erosion_shard_arena_bytes(iters) + 4095) // 4096 * 4096
+        arena = e.alloc(stride * world)
+        grid = e.alloc(b.nbytes).upload(b)
+        dmin = e.alloc(8).upload(np.array([mn, 0.0], np.float32))
+        e.synchronize()
+        r0 = 0
+        for r, c in enumerate(ctxs):  # (any order: the traces only read the grid)
+            c.erosion_shard_trace_dev(grid.ptr, n, n, iters, r0, ends[r] - r0, arena.ptr + r * stride)
+            r0 = ends[r]
+        for c in ctxs:
+            c.synchronize()
+        e.erosion_shard_finish_dev(grid.ptr, n, n, dmin.ptr, iters, pkg.ERODE_MINZ_IS_MIN, world, eroder, ends, arena.ptr + eroder * stride, stride)
+        e.synchronize()
+        got = grid.download(np.float32, (n, n))
+        assert_bit_equal(a, got, f"sharded erosion {n}x{n} {iters} droplets, {world} strips {ends}, eroder {eroder}")
+        rep = e.erosion_report()
+        assert rep.steps == stats.steps, (rep.steps, stats.steps)
+        assert rep.nan_droplets == stats.nan_droplets
+        for x in (arena, grid, dmin):
+            x.free()
+        return rep
+    finally:
+        for c in ctxs:
+            c.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def case_erosion_edge_sparse(pkg, t, orc):
     """the edge cases of case_erosion_edge under the sparse scheduler: all ocean (every droplet is settled by the probe pass), flat land (every first step takes the
     random-direction branch and writes: nobody is), a coast (both kinds mixed, droplets that die on their first step next to ones that walk)"""

@@ -311,10 +311,12 @@ def _dgrid_download(t, ptr, shape):
     return out
 
 
-def _one_grid_worker(rank, world, port, lib, out_dir, nx, ny, droplets, steps, grids):
+def _one_grid_worker(rank, world, port, lib, out_dir, nx, ny, droplets, steps, grids, shard=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if shard:  # the sparse scheduler forced on (these maps are small) with an allowance that lets it resolve every conflict itself, droplets of both strips among them
+        os.environ["TERRA_ONEGRID_SHARD_TRACES"] = "1"; os.environ["TERRA_ERO_SPARSE"] = "1"; os.environ["TERRA_ERO_SPARSE_RETRACES"] = "100000"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("3dworld_amd")
     dmod = importlib.import_module("3dworld_amd.dist")
@@ -359,6 +361,26 @@ def test_two_ranks_erode_one_heightmap_whose_strips_live_on_both(emul_lib, orc, 
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
 
+def test_two_ranks_erode_one_heightmap_with_the_traces_made_by_the_strip_owners(emul_lib, orc, tmp_path):
+    """the same pipeline with terra_erosion_shard_*: after a step's all_reduce each rank traces the droplets that start in ITS rows into its own arena (a second
+    terra_dgrid per grid in flight), a second collective, and the step's eroder gathers the traces through the mapping and checks / commits -- the oracle's grids"""
+    import torch.multiprocessing as mp
+    nx, ny, droplets, steps, grids = 256, 160, 150, 5, 3
+    port = 38500 + os.getpid() % 2000
+    mp.spawn(_one_grid_worker, args=(2, port, emul_lib, str(tmp_path), nx, ny, droplets, steps, grids, True), nprocs=2, join=True)
+    _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
+
+
+@pytest.mark.gpu
+def test_two_ranks_shard_the_traces_on_the_hip_library(orc, tmp_path):
+    """... through libterra_hip.so: two processes on GPU 0, the arenas hipMemCreate allocations mapped by the peer; the eroding process reads the other one's traces"""
+    import torch.multiprocessing as mp
+    nx, ny, droplets, steps, grids = 2048, 1024, 400, 6, 3
+    port = 39500 + os.getpid() % 2000
+    mp.spawn(_one_grid_worker, args=(2, port, None, str(tmp_path), nx, ny, droplets, steps, grids, True), nprocs=2, join=True)
+    _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
+
+
 @pytest.mark.gpu
 def test_two_ranks_erode_one_heightmap_on_the_hip_library(orc, tmp_path):
     """the same through libterra_hip.so: two processes on GPU 0, every strip a hipMemCreate allocation exported as a file descriptor, imported and mapped by the peer
@@ -370,9 +392,11 @@ def test_two_ranks_erode_one_heightmap_on_the_hip_library(orc, tmp_path):
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
 
-def _one_grid_device_paced_worker(rank, world, out_dir, nx, ny, droplets, steps, grids):
+def _one_grid_device_paced_worker(rank, world, out_dir, nx, ny, droplets, steps, grids, shard=False):
     import torch
     import torch.distributed as dist
+    if shard:
+        os.environ["TERRA_ONEGRID_SHARD_TRACES"] = "1"
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", store=dist.HashStore(), rank=rank, world_size=world)
@@ -399,6 +423,15 @@ def test_one_rank_device_paced_pipeline_over_rccl_equals_oracle(orc, tmp_path):
     import torch.multiprocessing as mp
     nx, ny, droplets, steps, grids = 2048, 1024, 1000, 7, 3
     mp.spawn(_one_grid_device_paced_worker, args=(1, str(tmp_path), nx, ny, droplets, steps, grids), nprocs=1, join=True)
+    _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 0)
+
+
+@pytest.mark.gpu
+def test_one_rank_device_paced_pipeline_with_sharded_traces_equals_oracle(orc, tmp_path):
+    """the enqueue-only pipeline with the trace / finish split (one rank: its strip is the whole grid, the tracer context's stream and events are the real ones)"""
+    import torch.multiprocessing as mp
+    nx, ny, droplets, steps, grids = 2048, 1024, 300, 7, 3
+    mp.spawn(_one_grid_device_paced_worker, args=(1, str(tmp_path), nx, ny, droplets, steps, grids, True), nprocs=1, join=True)
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 0)
 
 

@@ -116,6 +116,22 @@ def test_sparse_erosion_scheduler(pkg, gpu, orc, n, iters, retraces, flags):
         assert 0 < r.sparse_droplets < iters and r.sparse_retraces <= retraces
 
 
+@pytest.mark.parametrize("n,iters,world,eroder,force,retraces", [
+    (1024, 60, 2, 0, None, None), (2048, 300, 3, 1, None, None), (512, 400, 3, 2, "1", 100000), (256, 500, 2, 1, "1", 3), (128, 120, 2, 0, "1", 0),
+    (192, 3000, 2, 1, None, None), (640, 250, 1, 0, "1", 100000), (2048, 2000, 8, 5, "1", 40), (4096, 1000, 8, 3, None, None)])
+def test_sharded_sparse_erosion(pkg, gpu, orc, n, iters, world, eroder, force, retraces):
+    """terra_erosion_shard_*: the ranks of the one-grid pipeline as contexts on this GPU (own streams, arenas a stride apart in one allocation): each traces the droplets
+    that start in its strip, the eroding one gathers the traces and checks / commits -- the oracle's grid bit for bit (uneven and empty strips, cross-strip conflicts,
+    hand-over to the general scheduler, the dense run the sparse scheduler does not take, eight strips)"""
+    rep = pc.case_erosion_sharded(pkg, lambda: pkg.Terra(0), orc, n, iters, world, eroder, force, retraces)
+    if retraces == 100000:
+        assert rep.sparse_droplets == iters and rep.sparse_retraces > 0
+    elif retraces == 3:
+        assert 0 < rep.sparse_droplets < iters
+    elif force is None and iters == 3000:
+        assert rep.sparse_droplets == 0
+
+
 def test_sparse_erosion_edge_cases_and_probe_pass(pkg, gpu, orc):
     pc.case_erosion_edge_sparse(pkg, gpu, orc)
 

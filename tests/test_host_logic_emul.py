@@ -168,6 +168,26 @@ def test_sparse_erosion_scheduler(pkg, emul, orc, n, iters, retraces, flags):
         assert 0 < r.sparse_droplets < iters and r.sparse_retraces <= retraces                              # a committed prefix, the rest by the multi-version scheduler
 
 
+@pytest.mark.parametrize("n,iters,world,eroder,force,retraces", [
+    (1024, 60, 2, 0, None, None),      # the sparse scheduler by its own choice, two strips
+    (1024, 60, 3, 1, None, None),      # three strips (one empty), the eroder in the middle
+    (512, 400, 3, 2, "1", 100000),     # forced onto a map where droplets of different strips meet: every conflict resolved by a re-trace on the eroding rank
+    (256, 500, 2, 1, "1", 3),          # ... and with a small allowance: a committed prefix, then the general scheduler
+    (128, 120, 2, 0, "1", 0),          # ... gives up at once
+    (96, 200, 2, 1, None, None),       # a dense run: the sparse scheduler is not tried, the trace calls do nothing
+    (640, 250, 1, 0, "1", 100000),     # one rank: the calls compose to the ordinary erosion
+])
+def test_sharded_sparse_erosion(pkg, emul_lib, orc, n, iters, world, eroder, force, retraces):
+    """SURVEY 8e rows 2-3 / VERDICT r05 item 6: the sparse scheduler's read-only phases sharded by strip owner (terra_erosion_shard_*), the ranks as contexts of one process"""
+    rep = pc.case_erosion_sharded(pkg, lambda: pkg.Terra(0, emul_lib), orc, n, iters, world, eroder, force, retraces)
+    if retraces == 100000:
+        assert rep.sparse_droplets == iters and rep.sparse_retraces > 0
+    elif retraces == 3:
+        assert 0 < rep.sparse_droplets < iters
+    elif force is None and iters == 200:
+        assert rep.sparse_droplets == 0
+
+
 def test_sparse_erosion_edge_cases_and_probe_pass(pkg, emul, orc):
     pc.case_erosion_edge_sparse(pkg, emul, orc)
 
