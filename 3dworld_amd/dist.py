@@ -282,7 +282,7 @@ class OneHeightmapPipeline:
       reuse     `grids` grids are in flight; before a rank contributes to the all_reduce of step s it waits (host) until the erosion of step s - grids + 1 is complete if
                 it was that step's eroder -- so when the all_reduce of step s returns anywhere, that erosion is complete everywhere and step s + 1 may overwrite its grid."""
 
-    def __init__(self, terra_mod, make_ctx, cfg, dist, nx, ny, droplets, tag, grids=8, eroders=2, coll_device="cpu", shard_traces=None):
+    def __init__(self, terra_mod, make_ctx, cfg, dist, nx, ny, droplets, tag, grids=8, eroders=2, coll_device="cpu", shard_traces=None, tracers=3):
         import os
         import threading
         self.pkg, self.dist, self.nx, self.ny, self.droplets = terra_mod, dist, nx, ny, droplets
@@ -312,20 +312,40 @@ class OneHeightmapPipeline:
             self.rows = rows
         self.coll_device = coll_device
         self._threading = threading
-        self.tctx, self.arenas, self._pg2, self._hmin = None, [], None, []
+        self.tctxs, self.arenas, self._pg2, self._hmin = [], [], None, []
         if self.shard:
             try:
-                self.tctx = make_ctx()
-                self.tctx.init_scene(cfg)
+                # a strip's traces are a latency chain (its longest droplet: a few hundred dependent steps), longer than a strip's noise at N = 8: consecutive steps' traces
+                # overlap on `tracers` contexts (own streams), as consecutive erosions do on the eroder contexts
+                for _ in range(max(1, tracers)):
+                    c = make_ctx()
+                    self.tctxs.append(c)
+                    c.init_scene(cfg)
                 self.arena_stride = None
                 for g in range(grids):
-                    ag, _ = create_distributed_grid(terra_mod, self.nctx, dist, 0, 0, f"{tag}_arena_{g}", coll_device, strip_bytes=self.tctx.erosion_shard_arena_bytes(droplets))
+                    ag, _ = create_distributed_grid(terra_mod, self.nctx, dist, 0, 0, f"{tag}_arena_{g}", coll_device, strip_bytes=self.tctxs[0].erosion_shard_arena_bytes(droplets))
                     self.arenas.append(ag)
                     self.arena_stride = ag.strip_bytes[0]
-                    self._hmin.append(self.tctx.alloc(8))
+                    self._hmin.append(self.tctxs[0].alloc(8))
                 self.row_end = [r1 for (_, r1) in self.rows]
                 if dist is not None and dist.is_initialized() and self.world > 1:
-                    self._pg2 = dist.new_group()  # the "traces made" collectives: a communicator of their own, so that they never queue in front of the next steps' all_reduce(min)
+                    # the "traces made" collectives: a communicator of their own, so that they never queue in front of the next steps' all_reduce(min).  (A new communicator
+                    # prints a banner on the C stdout: a bench line must stay alone there)
+                    import sys
+                    sys.stdout.flush()
+                    saved = os.dup(1)
+                    os.dup2(2, 1)
+                    try:
+                        self._pg2 = dist.new_group()
+                        if str(coll_device) == "cpu":
+                            self._traces_made(True)  # (gloo connects at the first collective)
+                    finally:
+                        import ctypes
+                        try:
+                            ctypes.CDLL(None).fflush(None)
+                        finally:
+                            os.dup2(saved, 1)
+                            os.close(saved)
             except Exception:
                 self._free_shard()
                 for x in self.grids:
@@ -348,9 +368,10 @@ class OneHeightmapPipeline:
             torch.cuda.current_stream(coll_device).synchronize()  # (the fill ran on the current stream; everything else touches _mm on _tstream)
             self._ev = [self.nctx.event_create() for _ in range(grids)]
             if self.shard:
-                self._tstream2 = torch.cuda.Stream(device=coll_device)
-                self.tctx.set_stream(self._tstream2.cuda_stream)
-                self._ev2 = [self.tctx.event_create() for _ in range(grids)]
+                self._tstream2 = [torch.cuda.Stream(device=coll_device) for _ in self.tctxs]
+                for c, st2 in zip(self.tctxs, self._tstream2):
+                    c.set_stream(st2.cuda_stream)
+                self._ev2 = [self.tctxs[0].event_create() for _ in range(grids)]
                 self._flag = torch.zeros(grids, dtype=torch.float32, device=coll_device)
                 torch.cuda.current_stream(coll_device).synchronize()
 
@@ -361,9 +382,9 @@ class OneHeightmapPipeline:
         for b in self._hmin:
             b.free()
         self._hmin = []
-        if self.tctx is not None:
-            self.tctx.close()
-            self.tctx = None
+        for c in self.tctxs:
+            c.close()
+        self.tctxs = []
 
     def _traces_made(self, ok=True):
         """host-side collective of the sharded form: every rank's traces of the step are complete (and whether all of them worked)"""
@@ -375,7 +396,7 @@ class OneHeightmapPipeline:
         return float(t.item()) > 0.5
 
     def close(self):
-        for c in [self.nctx] + self.ectx + ([self.tctx] if self.tctx is not None else []):
+        for c in [self.nctx] + self.ectx + self.tctxs:
             c.synchronize()
         if self.dist is not None and self.dist.is_initialized():
             self.dist.barrier()  # nobody unmaps a strip a peer may still be reading
@@ -387,8 +408,9 @@ class OneHeightmapPipeline:
             self.nctx.set_stream(None)
             if self.shard:
                 for e in self._ev2:
-                    self.tctx.event_destroy(e)
-                self.tctx.set_stream(None)
+                    self.tctxs[0].event_destroy(e)
+                for c in self.tctxs:
+                    c.set_stream(None)
         if self.shard:
             self._free_shard()
         self.nctx.close()
@@ -465,17 +487,18 @@ class OneHeightmapPipeline:
                     if group:
                         self.dist.all_reduce(self._mm[g, 0:1], op=self.dist.ReduceOp.MIN)  # enqueued: ordered behind the strip's kernels and in front of the record below
                     self.nctx.event_record(self._ev[g])
-                    if self.shard:  # this rank's traces behind the step's all_reduce, on the tracer context's stream; then "all traces made" on that stream, in its own group
-                        with torch.cuda.stream(self._tstream2):
+                    if self.shard:  # this rank's traces behind the step's all_reduce, on a tracer context's stream; then "all traces made" on that stream, in its own group
+                        tc = self.tctxs[s % len(self.tctxs)]
+                        with torch.cuda.stream(self._tstream2[s % len(self.tctxs)]):
                             try:
-                                self.tctx.event_wait(self._ev[g])
+                                tc.event_wait(self._ev[g])
                                 if not errs:
-                                    self.tctx.erosion_shard_trace_dev(self.grids[g].ptr, self.nx, self.ny, self.droplets, r0, r1 - r0, self.arenas[g].strip_ptr(self.rank))
+                                    tc.erosion_shard_trace_dev(self.grids[g].ptr, self.nx, self.ny, self.droplets, r0, r1 - r0, self.arenas[g].strip_ptr(self.rank))
                             except Exception as e:  # noqa: BLE001
                                 errs.append(repr(e))
                             if group and self._pg2 is not None:
                                 self.dist.all_reduce(self._flag[g:g + 1], op=self.dist.ReduceOp.MIN, group=self._pg2)
-                            self.tctx.event_record(self._ev2[g])
+                            tc.event_record(self._ev2[g])
                     if s % self.world == self.rank and not errs:
                         done[s] = self._threading.Event()
                         jobs[mine % len(jobs)].put((s, g))
@@ -489,8 +512,8 @@ class OneHeightmapPipeline:
                 x.join()
         try:
             self.nctx.synchronize()
-            if self.shard:
-                self.tctx.synchronize()
+            for c in self.tctxs:
+                c.synchronize()
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
         _, ok = self._all_reduce_min(0.0, not errs)  # every rank's erosions are complete, and whether any of them failed
@@ -554,8 +577,8 @@ class OneHeightmapPipeline:
                     break
                 if self.shard:  # the grid is complete everywhere: my strip's droplets, then "all traces made"
                     try:
-                        self.tctx.erosion_shard_trace_dev(self.grids[g].ptr, self.nx, self.ny, self.droplets, r0, r1 - r0, self.arenas[g].strip_ptr(self.rank))
-                        self.tctx.synchronize()
+                        self.tctxs[0].erosion_shard_trace_dev(self.grids[g].ptr, self.nx, self.ny, self.droplets, r0, r1 - r0, self.arenas[g].strip_ptr(self.rank))
+                        self.tctxs[0].synchronize()
                     except Exception as e:  # noqa: BLE001
                         errs.append(repr(e))
                     if not self._traces_made(not errs):

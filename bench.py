@@ -67,6 +67,7 @@ def parse():
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
                         "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
+    p.add_argument("--no-shard-ab", action="store_true", help="onegrid: do not time the second form of the line (the sparse erosion's traces made by the strip owners, terra_erosion_shard_*)")
     p.add_argument("--grids-in-flight", type=int, default=8, help="onegrid: distributed grids in flight (a grid is reused this many steps later)")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
     p.add_argument("--no-extras", action="store_true", help="skip the single / strips / tiles / modes measurements under `detail`")
@@ -216,8 +217,13 @@ def preflight(args, torch, dist, pkg, dmod, rank, world, local_rank, dev, coll_d
         np = __import__("numpy")
         got = np.empty(n, np.float32)
         t._ck(t.lib.terra_memcpy_d2h(t.ctx, got.ctypes.data, g.ptr + p0 * n * 4, n * 4))  # one row of the neighbour's strip, read through the mapping
-        want = t.gen_grid(-n / 2, -n / 2 + p0, st.DX_VAL, st.DY_VAL, n, 1, pkg.GEN_GLACIATE)[0]
-        assert (got == want).all(), "a row read through the peer mapping differs from the row computed locally"
+        tmp = t.alloc(n * 4)  # the same row computed here (the rows entry point is bit-identical to the full grid's rows: tests/test_gpu_parity.py)
+        t.gen_grid_rows_minmax_dev(tmp.ptr, -n / 2, -n / 2, st.DX_VAL, st.DY_VAL, n, n, p0, 1)
+        t.synchronize()
+        want = tmp.download(np.float32, (n,))
+        tmp.free()
+        bad = int((got != want).sum())
+        assert bad == 0, f"a row read through the peer mapping differs from the row computed locally (rank {rank}, row {p0} of rank {peer}: {bad} of {n} cells, first got {got[:3].tolist()} want {want[:3].tolist()})"
 
     def s_erode_across_strips():
         g, n, t = grid_box["g"], grid_box["n"], t_box["t"]
@@ -490,6 +496,25 @@ def main():
             value_strong = cells * K / dts / 1e9
             if value_weak is not None:
                 detail["regions"] = {"value_weak": round(value_weak, 4), "ms_per_step": round(dt / K * 1e3, 4), "scaling": "weak", "workload": workload_w, "parallelism": par_w}
+            # the same line with the sparse erosion scheduler's read-only phases made by the strip owners (terra_erosion_shard_*, dist.py shard_traces): same grids, bit for
+            # bit; which form is faster at N > 1 is a question for the hardware (remote window traffic of the traces vs a second collective per step), so both are timed and
+            # the line carries the faster one as `value` and both in detail
+            if not args.no_shard_ab:
+                pipe2 = None
+                try:
+                    pipe2 = dmod.OneHeightmapPipeline(pkg, lambda: pkg.Terra(local_rank), pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves), dist if have_group and world > 1 else None,
+                                                      N, N, args.droplets, tag=tag + "_sh", grids=max(2, args.grids_in_flight), eroders=2, coll_device=coll_dev, shard_traces=True)
+                    dts2 = timed(lambda k: pipe2.run(k), K, max(W, 2), "onegrid")
+                    detail["onegrid_sharded_traces"] = {"value_strong": round(cells * K / dts2 / 1e9, 4), "ms_per_step": round(dts2 / K * 1e3, 4), "plain_value_strong": round(value_strong, 4),
+                                                        "what": "every rank probes / traces the droplets that start in its rows into its own arena behind the step's all_reduce, a second collective, the eroding rank gathers the traces and checks / commits"}
+                    if dts2 < dts and (world > 1 or args.workload == "onegrid"):
+                        dts, value_strong = dts2, cells * K / dts2 / 1e9
+                        par_s += "; the sparse erosion scheduler's probe / trace phases made by the strip owners (terra_erosion_shard_*), one more 4-byte collective per step"
+                except RuntimeError as e:  # (raised on every rank together)
+                    detail["onegrid_sharded_traces"] = {"error": str(e)[:400]}
+                finally:
+                    if pipe2 is not None:
+                        pipe2.close()
             if world > 1 or args.workload == "onegrid":
                 dt, value, scaling, workload, par = dts, value_strong, "strong", workload_s, par_s
             else:  # N = 1: the region and the one grid are the same heightmap; the headline stays the 4-pipeline form, the one-grid pipeline (1 rank) is printed beside it

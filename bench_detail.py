@@ -363,10 +363,113 @@ def onegrid_rank_floor(env, detail, sim_world):
             t0 = time.perf_counter(); dev_steps(K); t.synchronize(); d_dev = (time.perf_counter() - t0) / K
             dev_steps(sim_world, sim_world); t.synchronize(); ectx.synchronize()
             t0 = time.perf_counter(); dev_steps(K, sim_world); t.synchronize(); ectx.synchronize(); d_dev_both = (time.perf_counter() - t0) / K
+            # the same with the sparse scheduler's read-only phases sharded by strip owner (terra_erosion_shard_*, dist.py shard_traces): EVERY step this rank probes / traces the
+            # droplets that start in its strip on a tracer context (own stream, behind the step's all_reduce), and every sim_world-th step its eroder gathers the traces of
+            # all sim_world arenas and checks / commits (the other ranks' arenas: traced once, up front -- what the gather would find there)
+            try:
+                D = env.args.droplets
+                tctx = pkg.Terra(env.local_rank); tctx.init_scene(pkg.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - env.args.octaves))
+                stride = -(-tctx.erosion_shard_arena_bytes(D) // 4096) * 4096
+                arena = torch.empty(stride * sim_world, dtype=torch.uint8, device=env.dev)
+                row_end = [min((r + 1) * rows, N) for r in range(sim_world)]
+                for r in range(sim_world):
+                    r0 = min(r * rows, N)
+                    tctx.erosion_shard_trace_dev(env.ez.data_ptr(), N, N, D, r0, row_end[r] - r0, arena.data_ptr() + r * stride)
+                tctx.synchronize()
+                NT = 3  # tracer contexts: consecutive steps' traces overlap (each is a latency chain longer than a strip's noise), as in OneHeightmapPipeline
+                tcs = [tctx] + [pkg.Terra(env.local_rank) for _ in range(NT - 1)]
+                for c in tcs[1:]:
+                    c.init_scene(pkg.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - env.args.octaves))
+                streams2 = [torch.cuda.Stream(device=env.dev) for _ in tcs]
+                for c, s2 in zip(tcs, streams2):
+                    c.set_stream(s2.cuda_stream)
+                ev2 = tctx.event_create()
+                mmz = torch.tensor([env.full_min, 0.0], dtype=torch.float32, device=env.dev)
+                flag = torch.zeros(1, dtype=torch.float32, device=env.dev)
+                pg2 = None
+                if env.have_group:  # "all traces made" in a communicator of its own (as in OneHeightmapPipeline): in the step's group it would queue in front of the next step's all_reduce(min)
+                    import os
+                    import sys
+                    sys.stdout.flush()
+                    saved = os.dup(1)
+                    os.dup2(2, 1)  # (a new communicator prints a banner on the C stdout)
+                    try:
+                        pg2 = dist.new_group()
+                        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg2)
+                        torch.cuda.synchronize(env.dev)
+                    finally:
+                        import ctypes
+                        try:
+                            ctypes.CDLL(None).fflush(None)
+                        finally:
+                            os.dup2(saved, 1)
+                            os.close(saved)
+                torch.cuda.current_stream(env.dev).synchronize()
+
+                def shard_steps(k, erode_every=0):
+                    import threading
+                    th = None
+                    for s in range(k):
+                        with torch.cuda.stream(stream):
+                            t.gen_grid_rows_minmax_async_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 0, rows, mm.data_ptr(), pkg.GEN_GLACIATE)
+                            if env.have_group:
+                                dist.all_reduce(mm[0:1], op=dist.ReduceOp.MIN)
+                            t.event_record(ev)
+                        tc = tcs[s % NT]
+                        with torch.cuda.stream(streams2[s % NT]):
+                            tc.event_wait(ev)
+                            tc.erosion_shard_trace_dev(env.ez.data_ptr(), N, N, D, 0, rows, arena.data_ptr())
+                            if env.have_group:
+                                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg2)  # "all traces made"
+                            tc.event_record(ev2)
+                        if erode_every and s % erode_every == 0:
+                            if th is not None:
+                                th.join()
+
+                            def job():
+                                ectx.event_wait(ev2)
+                                ectx.erosion_shard_finish_dev(env.ez.data_ptr(), N, N, mmz.data_ptr(), D, pkg.ERODE_MINZ_IS_MIN, sim_world, 0, row_end, arena.data_ptr(), stride)
+                            th = threading.Thread(target=job)
+                            th.start()
+                    if th is not None:
+                        th.join()
+                try:
+                    def sync_all():
+                        t.synchronize(); ectx.synchronize()
+                        for c in tcs:
+                            c.synchronize()
+                    shard_steps(sim_world, sim_world); sync_all()
+                    t0 = time.perf_counter(); shard_steps(K, sim_world); sync_all(); d_shard = (time.perf_counter() - t0) / K
+                    tctx.timer_start()
+                    for _ in range(8):
+                        tctx.erosion_shard_trace_dev(env.ez.data_ptr(), N, N, D, 0, rows, arena.data_ptr())
+                    ms_trace = tctx.timer_stop() / 8
+                    ectx.synchronize(); ectx.timer_start()
+                    for _ in range(4):
+                        ectx.erosion_shard_finish_dev(env.ez.data_ptr(), N, N, mmz.data_ptr(), D, pkg.ERODE_MINZ_IS_MIN, sim_world, 0, row_end, arena.data_ptr(), stride)
+                    ms_finish = ectx.timer_stop() / 4
+                    ectx.timer_start()
+                    for _ in range(4):
+                        ectx.apply_erosion_dev(env.ez.data_ptr(), N, N, env.full_min, D, pkg.ERODE_MINZ_IS_MIN)
+                    ms_whole = ectx.timer_stop() / 4
+                    sharded = {"ms_step_enqueue_only_sharded_traces_with_every_%dth_finish" % sim_world: round(d_shard * 1e3, 4), "ms_trace_own_strip": round(ms_trace, 4), "tracer_contexts": NT,
+                               "ms_finish_gather_check_commit": round(ms_finish, 4), "ms_whole_erosion_one_context": round(ms_whole, 4),
+                               "note": "per step: strip noise + all_reduce, this rank's 1/%d of the traces on a tracer context, a second collective; every %dth step the eroder gathers all arenas and "
+                                       "commits (instead of tracing all droplets itself, most of them over xGMI)" % (sim_world, sim_world)}
+                finally:
+                    for c in tcs:
+                        c.synchronize(); c.set_stream(None)
+                    tctx.event_destroy(ev2)
+                    for c in tcs:
+                        c.close()
+            except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench line is missing
+                sharded = {"error": repr(e)[:300]}
         finally:
             t.synchronize(); t.set_stream(None); t.event_destroy(ev)
     if own:
         ectx.close()
+    if d_dev is None:
+        sharded = None
     floor = max(d_both, d_noise) if d_dev is None else max(d_dev, d_dev_both)
     detail["onegrid_rank_floor"] = {"simulated_world": sim_world, "rows_per_rank": rows, "steps": K,
                                     "ms_strip_noise_device": round(ms_dev, 4), "ms_step_noise_allreduce_item": round(d_noise * 1e3, 4),
@@ -374,6 +477,7 @@ def onegrid_rank_floor(env, detail, sim_world):
                                     "ms_step_with_every_%dth_erosion" % sim_world: round(d_both * 1e3, 4),
                                     "ms_step_enqueue_only": None if d_dev is None else round(d_dev * 1e3, 4),
                                     "ms_step_enqueue_only_with_every_%dth_erosion" % sim_world: None if d_dev_both is None else round(d_dev_both * 1e3, 4),
+                                    "sharded_traces": sharded,
                                     "predicted_gcells_s_at_that_world": round(N * N / floor / 1e9, 1),
                                     "predicted_from": "the read-back step (gloo / no device collective)" if d_dev is None else "the enqueue-only step (what the pipeline runs under RCCL)",
                                     "collective": ("all_reduce(min) over " + env.backend_name + " (one-rank group on this box)") if env.have_group else "none (no process group)",
