@@ -265,6 +265,8 @@ struct options_t {
 	int gen_fused = 0;            // "gen.fused" 0 / 1 / 2: every generator call behaves as if TERRA_GEN_FUSED (1) / TERRA_GEN_FAST (2) were given (the calls without a flags argument: tiles, voxels)
 	int ero_lead = 2;             // "ero.lead" 0..2: where a recentred droplet window lies (a cache placement)
 	int ero_batch = 0;            // "ero.batch" >= 1: rounds per host read-back of the multi-version scheduler (0: automatic)
+	int ero_fuse = 3;             // "ero.fuse" bits: 1 = a batch of rounds is ONE graph, 2 = marks + unlink + publish in one launch, 4 = commit + resume + hand-over + end of round in one launch
+	                              // (results never depend on it).  Measured, same box (profiles/r06_erosion_fuse_ab.txt): 1 and 2 are neutral (-0.7 %), 4 LOSES 9-36 %: not on by default
 	int ero_sparse = -1;          // "ero.sparse" 0 / 1: never / always try the sparse scheduler (-1 = "auto": by droplet density)
 	int ero_sparse_retraces = -1; // "ero.sparse_retraces" >= 0: re-traces before the sparse scheduler hands over (-1: default 8)
 	int ero_live = 1;             // "ero.live" 0 / 1: a droplet's first trace is visible to higher droplets while it grows
@@ -289,6 +291,7 @@ struct options_t {
 		auto const flag = [&](int &dst) {if (!is_int || (n != 0 && n != 1)) return false; dst = (int)n; return true;};
 		if (k == "gen.fused") {if (!is_int || n < 0 || n > 2) return false; gen_fused = (int)n; return true;}
 		if (k == "ero.lead") {if (!is_int || n < 0 || n > 2) return false; ero_lead = (int)n; return true;}
+		if (k == "ero.fuse") {if (!is_int || n < 0 || n > 7) return false; ero_fuse = (int)n; return true;}
 		if (k == "ero.batch") {if (!is_int || n < 0 || n > (1 << 20)) return false; ero_batch = (int)n; return true;}
 		if (k == "ero.sparse") {if (v == "auto") {ero_sparse = -1; return true;} return flag(ero_sparse);}
 		if (k == "ero.sparse_retraces") {if (!is_int || n < -1 || n > (1 << 20)) return false; ero_sparse_retraces = (int)n; return true;}
@@ -1173,7 +1176,7 @@ template<class BE> struct terra_engine {
 		size_t off = 0;
 		auto carve = [&](size_t bytes) {size_t const o = off; off += (bytes + 255) & ~(size_t)255; return o;};
 		size_t o_vals[2], o_mask[2], o_bl[2], o_bc[2], o_cks[2], o_ckn[2], o_cku[2], o_ckm[2], o_ckc[2], o_ui[2], o_uv[2], o_un[2];
-		size_t o_slot = 0, o_state = 0, o_resume = 0, o_next = 0, o_nodeblk = 0, o_dlist = 0, o_ctl = 0, o_touched = 0;
+		size_t o_slot = 0, o_state = 0, o_resume = 0, o_next = 0, o_nodeblk = 0, o_dlist = 0, o_ctl = 0, o_touched = 0, o_done = 0;
 		uint32_t const touched_cap = record_touched ? (uint32_t)std::min<uint64_t>((uint64_t)num_iters*1024u + 65536u, 64u << 20) : 0u;
 		auto layout = [&](uint32_t W) {
 			off = 0;
@@ -1188,6 +1191,7 @@ template<class BE> struct terra_engine {
 			o_state = carve((size_t)W*sizeof(droplet_state_t)); o_resume = carve((size_t)W*sizeof(spec_resume_t));
 			o_next = carve((size_t)W*sb.maxb*sizeof(spec_u32x4)); o_nodeblk = carve((size_t)W*sb.maxb*4); o_dlist = carve((size_t)W*sb.maxb*16); o_ctl = carve(sizeof(spec_ctl_t));
 			o_touched = carve((size_t)touched_cap*4 + 4);
+			o_done = carve(((size_t)W + 63)/64*4);
 			return off;
 		};
 		{
@@ -1213,6 +1217,7 @@ template<class BE> struct terra_engine {
 		sb.linked = slot_arrays + 9*(size_t)W; sb.rsrc = slot_arrays + 10*(size_t)W; sb.rat = slot_arrays + 11*(size_t)W; sb.rentry = slot_arrays + 12*(size_t)W; sb.vbuf = slot_arrays + 13*(size_t)W;
 		sb.state = (droplet_state_t *)(base + o_state); sb.resume = (spec_resume_t *)(base + o_resume);
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
+		sb.done_cnt = (uint32_t *)(base + o_done);
 		sb.node_rec = (spec_u32x4 *)(base + o_next); sb.node_blk = (uint32_t *)(base + o_nodeblk); sb.dirty_list = (uint32_t *)(base + o_dlist); sb.dirty_list2[0] = sb.dirty_list + 2*(size_t)W*sb.maxb; sb.dirty_list2[1] = sb.dirty_list + 3*(size_t)W*sb.maxb; sb.ctl = (spec_ctl_t *)(base + o_ctl);
 		// block -> list head and block -> dirty mark: one entry per 8x8 block of the padded grid.  Every run resets exactly the entries it set
 		// (spec_unlink_body / spec_undirty_body), so the O(grid) fill is paid only when the arrays are (re)allocated or the grid shape changes.
@@ -1227,6 +1232,7 @@ template<class BE> struct terra_engine {
 		be.fill32(sb.blk_cnt[0], 0, W); be.fill32(sb.blk_cnt[1], 0, W);
 		for (int b = 0; b < 2; ++b) {be.fill32(sb.ck_cnt[b], 0, W); be.fill32(sb.undo_n[b], 0, W);}
 		be.fill32(sb.node_blk, SPEC_NIL, (size_t)W*sb.maxb);
+		be.fill32(sb.done_cnt, 0, ((size_t)W + 63)/64);
 		be.launch(W, [=] TERRA_LAMBDA (size_t i) { // the first W droplets take the slots (num_iters - first >= W); droplet `it` lives in slot it % W
 			uint32_t const it = first + (uint32_t)i, slot = it % s.W;
 			s.it[slot] = it; s.phase[slot] = SPEC_FRESH;
@@ -1236,27 +1242,35 @@ template<class BE> struct terra_engine {
 		uint32_t const slice = std::max<uint32_t>(spec_cfg.slice_steps, 1);
 		uint32_t host_base = first, launched = 0;
 		spec_ctl_t hc{};
-		// One round = 8 dependent launches (the trace waves, five bookkeeping passes, the commit / checkpoint-resume waves, the end-of-round bookkeeping), captured once into a hipGraph and
+		// One round = 7 dependent launches (the trace waves; marks + unlink + publish; link + mark; restarts + commit point; commit + resume; hand-over; end of round -- "ero.fuse" 4 folds the last three
+		// into one, which loses), a batch of rounds captured into ONE hipGraph and
 		// replayed.  Nothing in a round needs a host decision -- the step budget, the commit point and the pause behind a failed droplet are all taken from the
 		// device-resident control block -- so the host queues rounds in batches and reads the control block back once per batch; a round after the end (or while the
 		// lowest droplet waits for its serial fall-back) finds nothing to do.
-		auto one_round = [&]() {
-			struct {spec_buffers_t s; uint32_t slice; uint32_t tag;} gkey;
-			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.s.ec.min_zval = 0.0f; gkey.slice = slice; gkey.tag = 0x524e4432u; // (min_zval: read by the clamp only, which is not part of the graph)
+		// nrounds rounds as ONE graph: consecutive graph launches leave ~9-13 us between them (profiles/r06_erosion_round_anatomy.txt), launches inside a graph none
+		int const fuse = opt.ero_fuse;
+		auto some_rounds = [&](uint32_t nrounds) {
+			struct {spec_buffers_t s; uint32_t slice; uint32_t tag; uint32_t nrounds; uint32_t fuse;} gkey;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.s.ec.min_zval = 0.0f; gkey.slice = slice; gkey.tag = 0x524e4432u; gkey.nrounds = nrounds; gkey.fuse = (uint32_t)fuse; // (min_zval: read by the clamp only, which is not part of the graph)
 			if (be.graph_replay(&gkey, sizeof(gkey))) return;
 			bool const cap = be.graph_begin();
 			try {
+			  for (uint32_t rr = 0; rr < nrounds; ++rr) {
 				// workgroups are dispatched in index order and a ring has more droplets than the chip holds waves: workgroup i takes the i-th in-flight droplet (slot (base + i) % W), so
 				// that the droplets next in line for the commit -- the long, unbudgeted traces everybody waits for -- start first instead of wherever their slot number falls
 				be.launch_waves(W, [=] TERRA_LAMBDA (size_t i, wave_scratch_t const &ws) {spec_trace_wave(s, (uint32_t)(((uint64_t)s.ctl->base + i) % s.W), slice, ws);});
-				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_post_wave(s, (uint32_t)i);});
-				// the three passes below: 64 logical threads per slot that walk the slot's entries up to the count in use (a footprint holds ~30 of its 256 entries;
+				// dirty marks from the OLD published versions, then the slot's nodes out of the writer lists and its finished version published (one wave per slot: spec_post_unlink_flip_wave)
+				if (fuse & 2) {be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_post_unlink_flip_wave(s, (uint32_t)i);});}
+				else {
+					be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_post_wave(s, (uint32_t)i);});
+					be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) {
+						uint32_t const slot = (uint32_t)(i >> 6), l = (uint32_t)(i & 63u), n = s.linked[slot];
+						for (uint32_t e = l; e < n; e += 64) {spec_unlink_body(s, slot*s.maxb + e);}
+						if (l == 0) {spec_flip_body(s, slot);}
+					});
+				}
+				// the two passes below: 64 logical threads per slot that walk the slot's entries up to the count in use (a footprint holds ~30 of its 256 entries;
 				// one thread per (slot, entry) made these passes cost as much as the traces on a 32768-slot ring)
-				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // publish the finished versions; take the writer lists apart (both after the dirty marks were made from the OLD published versions)
-					uint32_t const slot = (uint32_t)(i >> 6), l = (uint32_t)(i & 63u), n = s.linked[slot];
-					for (uint32_t e = l; e < n; e += 64) {spec_unlink_body(s, slot*s.maxb + e);}
-					if (l == 0) {spec_flip_body(s, slot);}
-				});
 				be.launch((size_t)W*64, [=] TERRA_LAMBDA (size_t i) { // rebuild the writer lists from the published versions; who must start over
 					uint32_t const slot = (uint32_t)(i >> 6), l = (uint32_t)(i & 63u);
 					uint32_t const pub = spec_visible_count(s, slot), run = s.run_nblk[slot], n = (pub > run) ? pub : run; // (pub: entries of the version higher droplets read)
@@ -1268,12 +1282,14 @@ template<class BE> struct terra_engine {
 					for (size_t k = i; k < nd; k += (size_t)s.W*64) {spec_undirty_body(s, (uint32_t)k);}
 					if (i < s.W) {spec_scan_body(s, (uint32_t)i);}
 				});
-				be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) { // commit; and a re-trace that can resume from a checkpoint becomes a suspended trace at that checkpoint
-					spec_flush_wave(s, (uint32_t)i);
-					spec_resume_wave(s, (uint32_t)i);
-				});
-				be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
-				be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
+				// commit; a re-trace that can resume from a checkpoint becomes a suspended trace at that checkpoint; committed slots go to the next droplets; the last wave closes the round
+				if (fuse & 4) {be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_close_wave(s, (uint32_t)i);});}
+				else {
+					be.launch_waves_nolds(W, [=] TERRA_LAMBDA (size_t i) {spec_flush_wave(s, (uint32_t)i); spec_resume_wave(s, (uint32_t)i);});
+					be.launch(W, [=] TERRA_LAMBDA (size_t i) {spec_admit_body(s, (uint32_t)i);});
+					be.launch(1, [=] TERRA_LAMBDA (size_t) {spec_advance_body(s);});
+				}
+			  }
 			} catch (...) {be.graph_abort(); throw;}
 			if (cap) {be.graph_end(&gkey, sizeof(gkey));}
 		};
@@ -1281,10 +1297,9 @@ template<class BE> struct terra_engine {
 			// the first batch is short (a sparse map is done after two rounds); later ones amortise the read-back over 8 rounds
 			uint32_t batch = (launched == 0) ? 2u : 8u;
 			if (spec_batch_override()) {batch = spec_batch_override();}
-			for (uint32_t r = 0; r < batch; ++r) {
-				if (launched >= spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
-				one_round(); ++launched;
-			}
+			if (launched + batch > spec_cfg.max_rounds) throw std::runtime_error("speculative erosion: round limit reached");
+			if (fuse & 1) {some_rounds(batch);} else {for (uint32_t r = 0; r < batch; ++r) {some_rounds(1);}}
+			launched += batch;
 			be.d2h(&hc, sb.ctl, sizeof(hc)); // the one host round trip of the batch
 			host_base = hc.base;
 			if (host_base < num_iters && hc.stop_at == host_base) { // the lowest uncommitted droplet overflowed its block list: it runs alone, directly on the grid

@@ -441,6 +441,7 @@ struct direct_mem_t {
 // LDS executes one wave's instructions in order: a store by one lane is seen by a later load of another lane without waiting for anything.  The fence keeps the
 // COMPILER from moving memory operations across it and costs no instruction (wavefront scope)
 #define TERRA_WAVE_FENCE() do {__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();} while (0)
+#define TERRA_ORDER_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup") // this wave's earlier memory operations have completed (no cache maintenance: a wait, and the compiler keeps the order)
 #define TERRA_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define TERRA_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define TERRA_ATOMIC_ADD(p, v) atomicAdd((p), (v))
@@ -466,6 +467,7 @@ template<class T> inline T terra_host_atomic_exch(T *p, T v) {T o = *p; *p = v; 
 template<class T> inline T terra_host_atomic_cas(T *p, T c, T v) {T o = *p; if (o == c) *p = v; return o;}
 #define TERRA_ATOMIC_MIN(p, v) terra_host_atomic_min((p), (v))
 #define TERRA_ATOMIC_MAX(p, v) terra_host_atomic_max((p), (v))
+#define TERRA_ORDER_FENCE() do {} while (0)
 #define TERRA_ATOMIC_ADD(p, v) terra_host_atomic_add((p), (v))
 #define TERRA_ATOMIC_OR(p, v) terra_host_atomic_or((p), (v))
 #define TERRA_ATOMIC_EXCH(p, v) terra_host_atomic_exch((p), (v))
@@ -880,6 +882,7 @@ struct spec_ctl_t { // device-resident control block: a round needs no host deci
 	unsigned long long round_max_pack;                   // the round's longest wave body: its ticks << 44 | ticks in window moves << 24 | ticks before + after the steps << 10 | steps/4
 	unsigned long long crit_own_shift, crit_own_edge, crit_own_steps; // the packed fields summed over the rounds
 	unsigned long long round_max_pack2, crit_own_flush, crit_own_load, crit_own_prep; // same key: ticks << 44 | write-back << 28 | plain loads << 14 | block flags
+	uint32_t waves_done, pad5_;                         // waves of the round's last launch that have finished: the last one closes the round (spec_close_wave)
 };
 struct spec_resume_t {uint32_t nblk, flags, undo_n, nck;}; // spec_back_t state of a suspended trace (its masks and pages are in the version buffer)
 
@@ -936,6 +939,7 @@ struct spec_buffers_t {
 	uint32_t *dirty_list2[2]; // [W*maxb] each: blocks dirtied AFTER a round's mark pass (a growing version rolled back or dropped, spec_resume_wave) for the NEXT round's; ctl->nd2[], ctl->par
 	uint32_t *touched;     // [touched_cap] padded-cell ids written to the grid (for the sparse final clamp)
 	uint32_t touched_cap;
+	uint32_t *done_cnt;    // [(W + 63)/64] waves of the round's last launch that have finished, per 64 slots (spec_close_wave); all zero between launches
 	spec_ctl_t *ctl;
 };
 
@@ -2054,6 +2058,39 @@ TERRA_HD void spec_fallback_advance_body(spec_buffers_t const &sb) {
 	c.new_base = (nb < sb.num_iters) ? (uint32_t)nb : sb.num_iters;
 	c.stop_at = SPEC_NIL; c.new_stop = SPEC_NIL; c.unfinished = 0;
 	c.steps += c.fb_steps; c.traced_steps += c.fb_steps; c.nan_droplets += c.fb_nan;
+}
+// ---- the bookkeeping launches of a round, fused where no other slot's pass has to lie in between (profiles/r06_erosion_round_anatomy.txt: every launch of a round costs
+// 4-5 us whatever it does, and the five small ones did 1-3 us of work each):
+//   after the traces: the slot's comparison with its published version (dirty marks), its nodes taken out of the writer lists, its finished version published -- post reads
+//     nothing another slot's unlink or flip writes (its own lists, masks and pages only), so the three passes of a slot run back to back in the slot's wave;
+//   at the end: the slot's commit, its checkpoint resume, its hand-over to the next droplet (all of them touch the slot's own arrays; other slots' commits read the writer
+//     lists' node records, which keep the droplet numbers of the link pass) -- and the wave that finishes LAST closes the round (spec_advance_body).
+TERRA_HD void spec_post_unlink_flip_wave(spec_buffers_t const &sb, uint32_t slot) {
+	spec_post_wave(sb, slot);
+	uint32_t const n = wave_uniform(sb.linked[slot]);
+	TERRA_LANES(e, n) {spec_unlink_body(sb, slot*sb.maxb + (uint32_t)e);}
+	if (TERRA_LANE0) {spec_flip_body(sb, slot);}
+}
+TERRA_HD void spec_close_wave(spec_buffers_t const &sb, uint32_t slot) {
+	spec_flush_wave(sb, slot);
+	spec_resume_wave(sb, slot);
+	TERRA_WAVE_SYNC();
+	if (TERRA_LANE0) {
+		spec_admit_body(sb, slot);
+		// The closing thread needs nothing another wave of this launch WROTE (they change the control block through atomics only, and not the words it rewrites): what it
+		// needs is that every wave has finished READING new_base / par / nd2 before they change -- a wave counts itself done after its own reads have returned.  (An
+		// agent-scope fence per wave here -- a cache write-back each, 32768 of them on a 16384^2 ring -- made the round 2.5x longer.)
+		// Two levels of counters (64 slots each, then the groups): thousands of atomics on ONE word take ~10 ns each, one after the other -- 0.4 ms of a round on a 32768-slot ring.
+		TERRA_ORDER_FENCE();
+		uint32_t const grp = slot >> 6, ngrp = (sb.W + 63u) >> 6, in_grp = (grp + 1 == ngrp) ? sb.W - (grp << 6) : 64u;
+		if (TERRA_ATOMIC_ADD(&sb.done_cnt[grp], 1u) == in_grp - 1) {
+			sb.done_cnt[grp] = 0;
+			if (TERRA_ATOMIC_ADD(&sb.ctl->waves_done, 1u) == ngrp - 1) {
+				sb.ctl->waves_done = 0;
+				spec_advance_body(sb);
+			}
+		}
+	}
 }
 // ring initialisation = the clamp-padded copy of src/erosion.cpp:31-37 restricted to the ring; one thread per ring float
 TERRA_HD void border_init_body(grid_view_t const &g, size_t i) {

@@ -162,7 +162,7 @@ int  terra_synchronize(terra_ctx *ctx);
  *   "tile_erosion"         "lds" | "window"   the whole padded tile in LDS (default) or a 32 x 32 window over a copy in HBM
  *   "weights.simple"       "0" | "1"      per-texel form of the weights-texture pass;   "shadows.levels" "0" | "1"   one launch per dependency level of the mesh shadows
  *   "ero.sparse"           "0" | "1" | "auto"   never / always / by droplet density try the sparse erosion scheduler;   "ero.sparse_retraces" n
- *   "ero.lead" "0".."2", "ero.batch" n, "ero.live" "0"|"1", "ero.diag" "0"|"1", "ero.ck" "steps:max"|"default", "ero.near" n|"default", "ero.mem_budget" bytes|"-1"
+ *   "ero.lead" "0".."2", "ero.batch" n, "ero.fuse" 0..7, "ero.live" "0"|"1", "ero.diag" "0"|"1", "ero.ck" "steps:max"|"default", "ero.near" n|"default", "ero.mem_budget" bytes|"-1"
  *                                          scheduling knobs of the multi-version erosion scheduler (terra_set_erosion_tuning has the documented ones) */
 int  terra_set_option(terra_ctx *ctx, const char *key, const char *value);
 /* ---- whole grids between host and device.  The reference's callers own HOST arrays (cached_vals of build_arrays, src/mesh_gen.cpp:597-603; apply_erosion's float*,

@@ -111,6 +111,24 @@ def test_erosion_sliding_ring(pkg, emul, orc, n, iters, window, slice_steps, blk
         assert r.serial_fallbacks >= 1
 
 
+@pytest.mark.parametrize("fuse", ["0", "4", "7"])
+def test_erosion_round_launch_fusion_knob(pkg, emul, orc, fuse):
+    """"ero.fuse": the round's bookkeeping passes folded into fewer launches (a batch of rounds as one graph, marks + unlink + publish in one wave, commit + resume + hand-over
+    + end of round in one wave closed by the wave that finishes last) -- every combination gives the serial result (the default, 3, runs everywhere else)"""
+    import os
+    old = os.environ.get("TERRA_ERO_FUSE")
+    os.environ["TERRA_ERO_FUSE"] = fuse
+    try:
+        r, _ = pc.case_erosion_sliding_ring(pkg, emul, orc, 160, 2500, 48, 5, near=8, ck="2:16")
+        assert r.checkpoint_resumes > 0 and r.rounds > r.windows
+    finally:
+        if old is None:
+            os.environ.pop("TERRA_ERO_FUSE", None)
+        else:
+            os.environ["TERRA_ERO_FUSE"] = old
+        emul.apply_env_options()
+
+
 @pytest.mark.parametrize("ck,near,window,slice_steps", [("1:16", 0, 64, 16), ("2:16", 8, 48, 5), ("4:16", 100000, 64, 16), ("7:3", 0, 32, 9), ("32:0", 4, 64, 16), ("3:16", 2, 200, 64)])
 def test_erosion_checkpointed_retraces(pkg, emul, orc, ck, near, window, slice_steps):
     """re-traces that resume from a checkpoint of the droplet's previous trace: dense droplets on a small map (every droplet conflicts with its neighbours in the ring),
