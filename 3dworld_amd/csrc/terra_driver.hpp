@@ -970,9 +970,9 @@ template<class BE> struct terra_engine {
 		g.interior = d_hmap; g.xsize = xsize; g.ysize = ysize; g.NX = ec.NX; g.NY = ec.NY;
 		size_t const nborder = grid_view_t::border_floats(xsize, ysize);
 		g.border = scratch<float>(s_border, nborder);
-		be.launch(nborder, [=] TERRA_LAMBDA (size_t i) {border_init_body(g, i);});
 		report.droplets = num_iters;
-		if (sh && sh->phase == 1) {uint32_t first = 0; (void)sparse_erosion(g, ec, num_iters, false, nullptr, first, sh); return;}
+		if (sh && sh->phase == 1) {uint32_t first = 0; (void)sparse_erosion(g, ec, num_iters, false, nullptr, first, sh); return;} // (its graph holds the border launch too)
+		be.launch(nborder, [=] TERRA_LAMBDA (size_t i) {border_init_body(g, i);});
 
 		if (flags & TERRA_ERODE_SERIAL) {
 			be.launch(1, [=] TERRA_LAMBDA (size_t) {
@@ -1067,10 +1067,20 @@ template<class BE> struct terra_engine {
 		sb.touched = record_touched ? (uint32_t *)(base + o_touched) : nullptr; sb.touched_cap = touched_cap;
 		if (sh && sh->phase == 1) { // a tracer: the first step of its droplets, then their lean traces -- into the arena, nothing else (no marks: wmin stays with the eroding rank)
 			sparse_buffers_t const s = sb;
-			be.launch(1, [=] TERRA_LAMBDA (size_t) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}, 64);
-			be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_probe_body(s, (uint32_t)i);});
-			be.launch_waves_lean(s.trace_groups, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
+			// one graph: a rank makes this call every step of the one-grid pipeline, from a host thread that also enqueues the step's noise and collectives
+			struct {sparse_buffers_t s; uint32_t tag;} gkey;
+			memset(&gkey, 0, sizeof(gkey)); gkey.s = s; gkey.tag = 0x53504831u;
 			first = 0;
+			if (be.graph_replay(&gkey, sizeof(gkey))) return false;
+			bool const cap = be.graph_begin();
+			try {
+				grid_view_t const gg = g;
+				be.launch(grid_view_t::border_floats(g.xsize, g.ysize), [=] TERRA_LAMBDA (size_t i) {border_init_body(gg, i);});
+				be.launch(1, [=] TERRA_LAMBDA (size_t) {sparse_ctl_t c{}; c.base = 0; c.c = s.N; *s.ctl = c;}, 64);
+				be.launch(N, [=] TERRA_LAMBDA (size_t i) {sparse_probe_body(s, (uint32_t)i);});
+				be.launch_waves_lean(s.trace_groups, [=] TERRA_LAMBDA (size_t i, lean_scratch_t const &ws) {sparse_trace_wave(s, (uint32_t)i, ws);});
+			} catch (...) {be.graph_abort(); throw;}
+			if (cap) {be.graph_end(&gkey, sizeof(gkey));}
 			return false;
 		}
 		uint32_t *blk_arrays = scratch<uint32_t>(s_spec_blocks, 2*nblocks); // [head | dirty_min] of the general scheduler, all SPEC_NIL between runs: wmin borrows the second half

@@ -204,7 +204,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		return true;
 	}
 	void graph_abort() {if (capturing) {hipGraph_t g = nullptr; (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); capturing = false;}}
-	void graph_end(void const *key, size_t n) { // instantiate, remember (8 slots, least recently used goes), launch
+	void graph_end(void const *key, size_t n) { // instantiate, remember (16 slots -- a tracer context of the one-grid pipeline holds one per grid in flight --, least recently used goes), launch
 		hipGraph_t g = nullptr;
 		capturing = false;
 		TERRA_HIP_CHECK(hipStreamEndCapture(stream, &g));
@@ -212,7 +212,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipError_t const e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
 		if (e != hipSuccess) {(void)hipGraphDestroy(g); throw std::runtime_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));}
 		graph_slot_t *slot = nullptr;
-		if (graphs.size() < 8) {graphs.emplace_back(); slot = &graphs.back();}
+		if (graphs.size() < 16) {graphs.emplace_back(); slot = &graphs.back();}
 		else {slot = &graphs[0]; for (graph_slot_t &c : graphs) {if (c.last_use < slot->last_use) slot = &c;} graph_drop(*slot);}
 		slot->key.assign((uint8_t const *)key, (uint8_t const *)key + n); slot->graph = g; slot->exec = ex; slot->last_use = ++graph_clock;
 		TERRA_HIP_CHECK(hipGraphLaunch(ex, stream));

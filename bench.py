@@ -67,6 +67,7 @@ def parse():
     p.add_argument("--workload", default="heightmap", choices=["heightmap", "onegrid", "regions", "strips", "tiles"],
                    help="which measurement is the headline `value`.  heightmap (default): at N = 1 one 16384^2 heightmap per step on the GPU; at N > 1 ONE 16384^2 heightmap per step on all "
                         "GPUs together, erosion included (= onegrid, strong scaling), with the independent-regions number (= regions, weak scaling) beside it as value_weak")
+    p.add_argument("--shard-ab", action="store_true", help="onegrid at N > 1: also time the line with the sparse erosion's traces made by the strip owners and report the faster form as `value` (default at N > 1: off)")
     p.add_argument("--no-shard-ab", action="store_true", help="onegrid: do not time the second form of the line (the sparse erosion's traces made by the strip owners, terra_erosion_shard_*)")
     p.add_argument("--grids-in-flight", type=int, default=8, help="onegrid: distributed grids in flight (a grid is reused this many steps later)")
     p.add_argument("--tile-droplets", type=int, default=0, help="--workload tiles: erosion_iters_tt of the headline tile batch")
@@ -235,11 +236,53 @@ def preflight(args, torch, dist, pkg, dmod, rank, world, local_rank, dev, coll_d
         if dist is not None:
             dist.barrier()
 
+    def s_sharded_traces():
+        # terra_erosion_shard_*: every rank traces the droplets that start in its rows into its arena (one more mapped array), rank 0 gathers them through the mapping and
+        # commits; compared with the same erosion by one context on a private copy of the grid
+        g, rows, n, t = grid_box["g"], grid_box["rows"], grid_box["n"], t_box["t"]
+        np = __import__("numpy")
+        D = 40
+        t.gen_grid_rows_minmax_dev(g.ptr + rows[rank][0] * n * 4, -n / 2, -n / 2, st_box["st"].DX_VAL, st_box["st"].DY_VAL, n, n, rows[rank][0], rows[rank][1] - rows[rank][0])
+        t.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ag, _ = dmod.create_distributed_grid(pkg.terra, t, dist, 0, 0, "preflight_arena", coll_dev, strip_bytes=t.erosion_shard_arena_bytes(D))  # (raises on every rank together)
+        err = None  # (whatever happens on one rank, every rank passes the same two barriers: the stage's outcome is agreed on afterwards)
+        try:
+            ref = t.alloc(n * n * 4)
+            whole = np.empty((n, n), np.float32)
+            t._ck(t.lib.terra_memcpy_d2h(t.ctx, whole.ctypes.data, g.ptr, whole.nbytes))
+            ref.upload(whole)
+            dmin = t.alloc(8).upload(np.array([-1.0e9, 0.0], np.float32))
+            t.erosion_shard_trace_dev(g.ptr, n, n, D, rows[rank][0], rows[rank][1] - rows[rank][0], ag.strip_ptr(rank))
+            t.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if dist is not None:
+            dist.barrier()
+        if rank == 0 and err is None:
+            try:
+                t.erosion_shard_finish_dev(g.ptr, n, n, dmin.ptr, D, 0, world, 0, [r1 for (_, r1) in rows], ag.strip_ptr(0), ag.strip_bytes[0])
+                t.apply_erosion_devmin_dev(ref.ptr, n, n, dmin.ptr, D, 0)
+                t.synchronize()
+                got = np.empty((n, n), np.float32)
+                t._ck(t.lib.terra_memcpy_d2h(t.ctx, got.ctypes.data, g.ptr, got.nbytes))
+                want = ref.download(np.float32, (n, n))
+                assert (got.view(np.uint32) == want.view(np.uint32)).all(), "the sharded erosion's grid differs from one context's"
+            except Exception as e:  # noqa: BLE001
+                err = e
+        if dist is not None:
+            dist.barrier()
+        ag.destroy()
+        if err is not None:
+            raise err
+
     stage("context", s_context)
     stage("collective", s_collective)
     stage("onegrid_vmm_mapping", s_onegrid)
     stage("strip_fill_and_peer_read", s_strip_fill_and_peer_read)
     stage("erode_across_strips", s_erode_across_strips)
+    stage("sharded_traces", s_sharded_traces)
     try:
         if "g" in grid_box:
             grid_box["g"].destroy()
@@ -499,7 +542,9 @@ def main():
             # the same line with the sparse erosion scheduler's read-only phases made by the strip owners (terra_erosion_shard_*, dist.py shard_traces): same grids, bit for
             # bit; which form is faster at N > 1 is a question for the hardware (remote window traffic of the traces vs a second collective per step), so both are timed and
             # the line carries the faster one as `value` and both in detail
-            if not args.no_shard_ab:
+            # (timed by default on ONE GPU, where every part of it runs in this repository's tests; at N > 1 only with --shard-ab: its cross-device parts -- a second
+            # communicator, arenas read through peer mappings -- have never met a multi-GPU node, and a run that measures the scaling curve must not depend on them)
+            if (world == 1 and not args.no_shard_ab) or args.shard_ab:
                 pipe2 = None
                 try:
                     pipe2 = dmod.OneHeightmapPipeline(pkg, lambda: pkg.Terra(local_rank), pkg.make_config(mesh_gen_mode=mode, mesh_freq_filter=9 - args.octaves), dist if have_group and world > 1 else None,

@@ -376,7 +376,7 @@ def onegrid_rank_floor(env, detail, sim_world):
                     r0 = min(r * rows, N)
                     tctx.erosion_shard_trace_dev(env.ez.data_ptr(), N, N, D, r0, row_end[r] - r0, arena.data_ptr() + r * stride)
                 tctx.synchronize()
-                NT = 3  # tracer contexts: consecutive steps' traces overlap (each is a latency chain longer than a strip's noise), as in OneHeightmapPipeline
+                NT = int(__import__("os").environ.get("TERRA_BENCH_TRACERS", "3"))  # tracer contexts: consecutive steps' traces overlap (each is a latency chain longer than a strip's noise), as in OneHeightmapPipeline
                 tcs = [tctx] + [pkg.Terra(env.local_rank) for _ in range(NT - 1)]
                 for c in tcs[1:]:
                     c.init_scene(pkg.make_config(mesh_gen_mode=env.mode, mesh_freq_filter=9 - env.args.octaves))
@@ -406,22 +406,35 @@ def onegrid_rank_floor(env, detail, sim_world):
                             os.close(saved)
                 torch.cuda.current_stream(env.dev).synchronize()
 
+                host_parts = {}
+
                 def shard_steps(k, erode_every=0):
                     import threading
                     th = None
+                    pc_ = time.perf_counter
                     for s in range(k):
+                        a0 = pc_()
                         with torch.cuda.stream(stream):
                             t.gen_grid_rows_minmax_async_dev(z.data_ptr(), -N / 2, -N / 2, st.DX_VAL, st.DY_VAL, N, N, 0, rows, mm.data_ptr(), pkg.GEN_GLACIATE)
+                            a1 = pc_()
                             if env.have_group:
                                 dist.all_reduce(mm[0:1], op=dist.ReduceOp.MIN)
+                            a2 = pc_()
                             t.event_record(ev)
+                        a3 = pc_()
                         tc = tcs[s % NT]
                         with torch.cuda.stream(streams2[s % NT]):
                             tc.event_wait(ev)
+                            a4 = pc_()
                             tc.erosion_shard_trace_dev(env.ez.data_ptr(), N, N, D, 0, rows, arena.data_ptr())
+                            a5 = pc_()
                             if env.have_group:
                                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg2)  # "all traces made"
+                            a6 = pc_()
                             tc.event_record(ev2)
+                        a7 = pc_()
+                        for nm, dv in (("noise", a1 - a0), ("allreduce_min", a2 - a1), ("event_record", a3 - a2), ("event_wait", a4 - a3), ("trace_call", a5 - a4), ("allreduce_flag", a6 - a5), ("event_record2", a7 - a6)):
+                            host_parts[nm] = host_parts.get(nm, 0.0) + dv
                         if erode_every and s % erode_every == 0:
                             if th is not None:
                                 th.join()
@@ -439,7 +452,8 @@ def onegrid_rank_floor(env, detail, sim_world):
                         for c in tcs:
                             c.synchronize()
                     shard_steps(sim_world, sim_world); sync_all()
-                    t0 = time.perf_counter(); shard_steps(K, sim_world); sync_all(); d_shard = (time.perf_counter() - t0) / K
+                    host_parts.clear()
+                    t0 = time.perf_counter(); shard_steps(K, sim_world); d_shard_host = (time.perf_counter() - t0) / K; sync_all(); d_shard = (time.perf_counter() - t0) / K
                     tctx.timer_start()
                     for _ in range(8):
                         tctx.erosion_shard_trace_dev(env.ez.data_ptr(), N, N, D, 0, rows, arena.data_ptr())
@@ -452,7 +466,7 @@ def onegrid_rank_floor(env, detail, sim_world):
                     for _ in range(4):
                         ectx.apply_erosion_dev(env.ez.data_ptr(), N, N, env.full_min, D, pkg.ERODE_MINZ_IS_MIN)
                     ms_whole = ectx.timer_stop() / 4
-                    sharded = {"ms_step_enqueue_only_sharded_traces_with_every_%dth_finish" % sim_world: round(d_shard * 1e3, 4), "ms_trace_own_strip": round(ms_trace, 4), "tracer_contexts": NT,
+                    sharded = {"ms_step_enqueue_only_sharded_traces_with_every_%dth_finish" % sim_world: round(d_shard * 1e3, 4), "ms_step_host_enqueue": round(d_shard_host * 1e3, 4), "host_us_per_step_by_call": {k_: round(v_ / K * 1e6, 1) for k_, v_ in host_parts.items()}, "ms_trace_own_strip": round(ms_trace, 4), "tracer_contexts": NT,
                                "ms_finish_gather_check_commit": round(ms_finish, 4), "ms_whole_erosion_one_context": round(ms_whole, 4),
                                "note": "per step: strip noise + all_reduce, this rank's 1/%d of the traces on a tracer context, a second collective; every %dth step the eroder gathers all arenas and "
                                        "commits (instead of tracing all droplets itself, most of them over xGMI)" % (sim_world, sim_world)}

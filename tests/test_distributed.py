@@ -237,7 +237,7 @@ def test_bench_preflight_two_ranks_names_every_stage():
     assert r.returncode == 0, r.stderr[-3000:]
     line = _last_json_line(r.stdout)
     assert line["preflight"] == "ok" and line["n_gpus"] == 2 and line["failed_stage"] is None
-    assert [s["stage"] for s in line["stages"]] == ["context", "collective", "onegrid_vmm_mapping", "strip_fill_and_peer_read", "erode_across_strips"] and all(s["ok"] for s in line["stages"])
+    assert [s["stage"] for s in line["stages"]] == ["context", "collective", "onegrid_vmm_mapping", "strip_fill_and_peer_read", "erode_across_strips", "sharded_traces"] and all(s["ok"] for s in line["stages"])
 
 
 @pytest.mark.gpu
