@@ -643,7 +643,7 @@ def main():
         hbm = 4.0 * cells / (ms_k * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, profiles/*_pmc_traffic.json), only for the configuration they were taken on
         traffic_source = None
-        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]["k_sine_grid"]
                 if mode == 0 and N == 16384 and args.octaves == 8:
