@@ -42,6 +42,14 @@ def test_c_driver_ranks_on_the_emulator_equal_one_context(emul_driver, ranks, st
     assert d["check"] == "bit-equal" and d["ranks"] == ranks and d["steps"] == steps
 
 
+@pytest.mark.parametrize("ranks,steps,n,droplets,grids,eroders", [(2, 4, 512, 40, 3, 2), (3, 5, 640, 60, 2, 1)])
+def test_c_driver_sharded_traces_on_the_emulator_equal_one_context(emul_driver, ranks, steps, n, droplets, grids, eroders):
+    """--shard-traces: every rank traces the droplets that start in its rows into its arena (terra_erosion_shard_trace_dev), the step's eroder gathers them through the
+    mapping (terra_erosion_shard_finish_dev); few droplets on these maps, so that the sparse scheduler takes the run by its own rule"""
+    d = run(emul_driver, ranks, steps, n, droplets, "--same-device", "--coll", "shm", "--check", "--shard-traces", "--grids", grids, "--eroders", eroders, "--warmup", 2)
+    assert d["check"] == "bit-equal" and d["ranks"] == ranks and d["shard_traces"] == 1
+
+
 def test_c_driver_rank_floor_mode_on_the_emulator(emul_driver):
     d = run(emul_driver, 1, 4, 256, 200, "--same-device", "--coll", "shm", "--simulate-world", 4)
     assert d["simulate_world"] == 4 and d["ms_per_step"] > 0
@@ -67,6 +75,14 @@ def hip_driver(tmp_path_factory):
 def test_c_driver_one_rank_through_rccl_equals_one_context(hip_driver):
     d = run(hip_driver, 1, 6, 2048, 1000, "--check", "--warmup", 2)
     assert d["coll"] == "rccl" and d["check"] == "bit-equal"
+
+
+@pytest.mark.gpu
+def test_c_driver_sharded_traces_one_rank_rccl_and_two_ranks_on_gpu0(hip_driver):
+    d = run(hip_driver, 1, 6, 2048, 300, "--check", "--shard-traces", "--warmup", 2)
+    assert d["coll"] == "rccl" and d["check"] == "bit-equal" and d["shard_traces"] == 1
+    d = run(hip_driver, 2, 6, 2048, 300, "--same-device", "--check", "--shard-traces", "--warmup", 2, "--grids", 3)
+    assert d["coll"] == "shm" and d["check"] == "bit-equal" and d["ranks"] == 2
 
 
 @pytest.mark.gpu

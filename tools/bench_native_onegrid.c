@@ -11,11 +11,14 @@
  *             well (host round trip per step): RCCL refuses two ranks on one device, so that is how two ranks are tested on a one-GPU box (--same-device).
  *   --simulate-world W   ONE rank does what one rank of W does per step (1/W of the rows, the whole-grid erosion every W-th step, the all-reduce over a one-rank communicator):
  *             the per-rank step floor, measurable on one GPU.
+ *   --shard-traces   the sparse erosion scheduler's read-only phases made by the strip owners (terra_erosion_shard_*): behind a step's all-reduce every rank traces the
+ *             droplets that start in ITS rows into its own arena (one more terra_dgrid per grid in flight: the strips are the arenas) on a tracer context, a second one-float
+ *             all-reduce on a communicator of its own says "all traces made", and the step's eroder gathers the traces through the mapping and checks / commits.
  *   --check   the last step's grid is compared byte for byte with the same map made by one context alone.
  * build: gcc -O2 -std=c99 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include tools/bench_native_onegrid.c -L3dworld_amd -lterra_hip -L/opt/rocm/lib -lrccl -lamdhip64 -lpthread \
  *            -Wl,-rpath,$PWD/3dworld_amd -Wl,-rpath,/opt/rocm/lib -o tools/_bin/bench_native_onegrid
  * usage: bench_native_onegrid [ranks=all GPUs] [steps=16] [size=16384] [droplets=1000] [--same-device] [--coll rccl|shm] [--grids 8] [--eroders 2] [--warmup 4]
- *                             [--simulate-world W] [--check]                                                                                                        */
+ *                             [--simulate-world W] [--shard-traces] [--check]                                                                                                        */
 #define _GNU_SOURCE
 #include "terra.h"
 #include <hip/hip_runtime_api.h>
@@ -53,7 +56,7 @@ typedef struct {
 	atomic_uint arrived[2];          /* all-reduce slots: counts up by `ranks` per use */
 	float val[2][MAXR][2];
 	atomic_uint bar;                 /* barrier: counts up by `ranks` per use */
-	ncclUniqueId id;
+	ncclUniqueId id, id2;
 	double elapsed[MAXR];
 } shared_t;
 static shared_t *sh;
@@ -129,6 +132,7 @@ static pthread_mutex_t done_mu = PTHREAD_MUTEX_INITIALIZER; static pthread_cond_
 static unsigned char *done; /* [steps] */
 static float *grid_ptr[MAXG]; static float *d_mm; static terra_event *ev_noise[MAXG];
 static int N = 16384, droplets = 1000;
+static int shard = 0; static char *arena_ptr[MAXG]; static size_t arena_stride = 0; static terra_event *ev_trace[MAXG]; static uint32_t row_end[MAXR]; /* --shard-traces */
 static void *eroder_main(void *arg) {
 	eroder_t *e = (eroder_t *)arg;
 	for (;;) {
@@ -137,8 +141,15 @@ static void *eroder_main(void *arg) {
 		if (e->head == e->tail) {pthread_mutex_unlock(&e->mu); return NULL;}
 		job_t const j = e->q[e->head++ % e->cap];
 		pthread_mutex_unlock(&e->mu);
+		if (shard) { /* behind every rank's traces of the step; the traces come out of the ranks' arenas */
+			CK(terra_event_wait(e->ctx, ev_trace[j.g]));
+			CK(terra_erosion_shard_finish_dev(e->ctx, grid_ptr[j.g], N, N, d_mm + 2*j.g, (uint32_t)droplets, TERRA_ERODE_MINZ_IS_MIN, (uint32_t)ranks, (uint32_t)g_rank, row_end,
+				arena_ptr[j.g] + (size_t)g_rank*arena_stride, arena_stride));
+		}
+		else {
 		CK(terra_event_wait(e->ctx, ev_noise[j.g])); /* behind the step's noise and its all-reduce, on the device */
 		CK(terra_apply_erosion_devmin_dev(e->ctx, grid_ptr[j.g], N, N, d_mm + 2*j.g, (uint32_t)droplets, TERRA_ERODE_MINZ_IS_MIN));
+		}
 		CK(terra_synchronize(e->ctx));
 		pthread_mutex_lock(&done_mu); done[j.s] = 1; pthread_cond_broadcast(&done_cv); pthread_mutex_unlock(&done_mu);
 	}
@@ -155,7 +166,7 @@ static void scene(terra_config *c) { /* the synthetic scene of BASELINE.md secti
 }
 static size_t gcd_sz(size_t a, size_t b) {while (b) {size_t const t = a % b; a = b; b = t;} return a;}
 
-typedef struct {int steps, warmup, same, use_rccl, G, E, sim, check; char dir[64];} opts_t;
+typedef struct {int steps, warmup, same, use_rccl, G, E, sim, check, shard; char dir[64];} opts_t;
 
 static int rank_main(opts_t const *o) {
 	int const dev = o->same ? 0 : g_rank, world = ranks, sim = o->sim > 1 ? o->sim : 1;
@@ -172,12 +183,20 @@ static int rank_main(opts_t const *o) {
 		CK(terra_create(&ero[i].ctx, dev)); CK(terra_init_scene(ero[i].ctx, &c));
 		pthread_mutex_init(&ero[i].mu, NULL); pthread_cond_init(&ero[i].cv, NULL);
 	}
-	ncclComm_t comm = NULL;
+	ncclComm_t comm = NULL, comm2 = NULL;
+	terra_ctx *tctx = NULL; hipStream_t S2 = NULL; float *d_flag = NULL;
+	shard = o->shard;
+	if (shard) { /* the tracer context: this rank's probe / trace passes, behind the step's all-reduce, beside the next steps' noise */
+		CK(terra_create(&tctx, dev));
+		if (o->use_rccl) {HCK(hipStreamCreateWithFlags(&S2, hipStreamNonBlocking)); CK(terra_set_stream(tctx, (void *)S2));}
+		CK(terra_init_scene(tctx, &c));
+	}
 	if (o->use_rccl) {
-		if (g_rank == 0) {NCK(ncclGetUniqueId(&sh->id));}
+		if (g_rank == 0) {NCK(ncclGetUniqueId(&sh->id)); if (shard) {NCK(ncclGetUniqueId(&sh->id2));}}
 		shm_barrier();
 		ncclUniqueId id = sh->id;
 		NCK(ncclCommInitRank(&comm, world, id, g_rank));
+		if (shard) {ncclUniqueId id2 = sh->id2; NCK(ncclCommInitRank(&comm2, world, id2, g_rank));} /* "all traces made": never queued in front of the next steps' all-reduce(min) */
 	}
 	/* ---- the grids: strips whose byte size is a multiple of the mapping granularity */
 	size_t const gran = terra_dgrid_granularity(nctx), row_bytes = (size_t)N*sizeof(float);
@@ -201,6 +220,25 @@ static int rank_main(opts_t const *o) {
 		}
 		void *base = NULL; CK(terra_dgrid_map(dg[g], &base)); grid_ptr[g] = (float *)base;
 		CK(terra_event_create(nctx, &ev_noise[g]));
+	}
+	terra_dgrid *ag[MAXG];
+	if (shard) { /* the arenas: one more distributed array per grid in flight, strip r = rank r's arena */
+		size_t const need = terra_erosion_shard_arena_bytes(tctx, (uint32_t)droplets);
+		arena_stride = (need + gran - 1)/gran*gran;
+		size_t ab[MAXR]; for (int r = 0; r < world; ++r) {ab[r] = arena_stride; row_end[r] = (uint32_t)(((size_t)(r + 1)*per < (size_t)N) ? (size_t)(r + 1)*per : (size_t)N);}
+		for (int g = 0; g < o->G; ++g) {
+			CK(terra_dgrid_create(nctx, (uint32_t)world, ab, (uint32_t)g_rank, &ag[g]));
+			if (world > 1) {
+				int fd = -1, peer[MAXR]; for (int r = 0; r < world; ++r) {peer[r] = -1;}
+				CK(terra_dgrid_export_fd(ag[g], &fd));
+				exchange_fds(o->dir, MAXG + g, fd, peer);
+				close(fd);
+				for (int r = 0; r < world; ++r) {if (r != g_rank) {CK(terra_dgrid_import_fd(ag[g], (uint32_t)r, peer[r])); close(peer[r]);}}
+			}
+			void *base = NULL; CK(terra_dgrid_map(ag[g], &base)); arena_ptr[g] = (char *)base;
+			CK(terra_event_create(tctx, &ev_trace[g]));
+		}
+		if (o->use_rccl) {CK(terra_malloc(tctx, (void **)&d_flag, (size_t)o->G*sizeof(float))); HCK(hipMemset(d_flag, 0, (size_t)o->G*sizeof(float)));}
 	}
 	CK(terra_malloc(nctx, (void **)&d_mm, (size_t)o->G*2*sizeof(float)));
 	int const total = o->warmup + o->steps;
@@ -226,10 +264,18 @@ static int rank_main(opts_t const *o) {
 				CK(terra_memcpy_h2d(nctx, d_mm + 2*g, &v[0], sizeof(float)));
 			}
 			CK(terra_event_record(nctx, ev_noise[g]));
+			if (shard) { /* my strip's droplets, then "all traces made" */
+				CK(terra_event_wait(tctx, ev_noise[g]));
+				CK(terra_erosion_shard_trace_dev(tctx, grid_ptr[g], N, N, (uint32_t)droplets, (uint32_t)r0, (uint32_t)(r1 - r0), arena_ptr[g] + (size_t)g_rank*arena_stride));
+				if (o->use_rccl) {NCK(ncclAllReduce(d_flag + g, d_flag + g, 1, ncclFloat, ncclMin, comm2, S2));}
+				else if (world > 1) {float v[2] = {0.0f, 1.0f}; CK(terra_synchronize(tctx)); shm_allreduce_min2(v);}
+				CK(terra_event_record(tctx, ev_trace[g]));
+			}
 			if ((s % (world*sim)) == g_rank) {post(&ero[mine++ % o->E], s, g);} else {pthread_mutex_lock(&done_mu); done[s] = 1; pthread_mutex_unlock(&done_mu);}
 		}
 		for (int s = first; s < s_end; ++s) {wait_done(s);} /* my erosions */
 		CK(terra_synchronize(nctx));
+		if (shard) {CK(terra_synchronize(tctx));}
 		shm_barrier(); /* everybody's erosions: no grid is touched by anyone any more */
 		if (phase == 0) {t0 = now();} else {elapsed = now() - t0;}
 		first = s_end;
@@ -253,14 +299,21 @@ static int rank_main(opts_t const *o) {
 	if (g_rank == 0) {
 		double worst = 0.0; for (int r = 0; r < world; ++r) {worst = sh->elapsed[r] > worst ? sh->elapsed[r] : worst;}
 		printf("{\"what\": \"one heightmap per step on all ranks (C driver, one process per GPU)\", \"ranks\": %d, \"same_device\": %d, \"simulate_world\": %d, \"coll\": \"%s\", \"grid\": %d, "
-			"\"droplets\": %d, \"grids_in_flight\": %d, \"eroders\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"%s\": %.2f, \"scaling\": \"strong\", \"check\": \"%s\"}\n",
-			world, o->same ? 1 : 0, sim, o->use_rccl ? "rccl" : "shm", N, droplets, o->G, o->E, o->steps, o->warmup, 1e3*worst/o->steps,
+			"\"droplets\": %d, \"grids_in_flight\": %d, \"eroders\": %d, \"shard_traces\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"%s\": %.2f, \"scaling\": \"strong\", \"check\": \"%s\"}\n",
+			world, o->same ? 1 : 0, sim, o->use_rccl ? "rccl" : "shm", N, droplets, o->G, o->E, shard, o->steps, o->warmup, 1e3*worst/o->steps,
 			sim > 1 ? "gcells_per_s_predicted_at_simulated_world" : "gcells_per_s", (double)N*(double)N*(double)o->steps/worst/1e9, verdict); /* a step is one whole map, whoever made which rows */
 		fflush(stdout);
 	}
 	shm_barrier(); /* rank 0 has read the grids: nobody unmaps a strip a peer may still be reading */
 	for (int i = 0; i < o->E; ++i) {pthread_mutex_lock(&ero[i].mu); ero[i].stop = 1; pthread_cond_signal(&ero[i].cv); pthread_mutex_unlock(&ero[i].mu); pthread_join(ero[i].th, NULL);}
 	if (comm) {NCK(ncclCommDestroy(comm));}
+	if (comm2) {NCK(ncclCommDestroy(comm2));}
+	if (shard) {
+		for (int g = 0; g < o->G; ++g) {terra_event_destroy(ev_trace[g]); terra_dgrid_destroy(ag[g]);}
+		if (d_flag) {terra_free(tctx, d_flag);}
+		terra_destroy(tctx);
+		if (S2) {HCK(hipStreamDestroy(S2));}
+	}
 	for (int g = 0; g < o->G; ++g) {terra_event_destroy(ev_noise[g]); terra_dgrid_destroy(dg[g]);}
 	terra_free(nctx, d_mm);
 	for (int i = 0; i < o->E; ++i) {terra_destroy(ero[i].ctx);}
@@ -275,6 +328,7 @@ int main(int argc, char **argv) {
 	for (int i = 1; i < argc; ++i) {
 		if (strcmp(argv[i], "--same-device") == 0) {o.same = 1;}
 		else if (strcmp(argv[i], "--check") == 0) {o.check = 1;}
+		else if (strcmp(argv[i], "--shard-traces") == 0) {o.shard = 1;}
 		else if (strcmp(argv[i], "--coll") == 0 && i + 1 < argc) {o.use_rccl = strcmp(argv[++i], "shm") != 0;}
 		else if (strcmp(argv[i], "--grids") == 0 && i + 1 < argc) {o.G = atoi(argv[++i]);}
 		else if (strcmp(argv[i], "--eroders") == 0 && i + 1 < argc) {o.E = atoi(argv[++i]);}
@@ -307,7 +361,7 @@ int main(int argc, char **argv) {
 		int n = 0; if (read(p[0], &n, sizeof(n)) != (ssize_t)sizeof(n)) {n = 0;} waitpid(c, NULL, 0); close(p[0]); close(p[1]);
 		R = n;
 	}
-	if (R < 1 || R > MAXR || o.steps < 1 || o.warmup < 0 || N < 256 || o.G < 2 || o.G > MAXG || o.E < 1 || o.E > MAXE || (o.sim > 1 && R != 1) || o.steps + o.warmup > 100000) {
+	if (R < 1 || R > MAXR || o.steps < 1 || o.warmup < 0 || N < 256 || o.G < 2 || o.G > MAXG || o.E < 1 || o.E > MAXE || (o.sim > 1 && R != 1) || (o.sim > 1 && o.shard) || (o.shard && R > 16) || o.steps + o.warmup > 100000) {
 		fprintf(stderr, "bad arguments (ranks %d)\n", R); return 2;
 	}
 	snprintf(o.dir, sizeof(o.dir), "/tmp/terra_onegrid_XXXXXX");
@@ -328,7 +382,7 @@ int main(int argc, char **argv) {
 		int n = 0, seen = 0; av[n++] = argv[0];
 		for (int i = 1; i < argc; ++i) {
 			int const is_opt = strncmp(argv[i], "--", 2) == 0;
-			if (is_opt) {av[n++] = argv[i]; if (strcmp(argv[i], "--same-device") != 0 && strcmp(argv[i], "--check") != 0 && i + 1 < argc) {av[n++] = argv[++i];} continue;}
+			if (is_opt) {av[n++] = argv[i]; if (strcmp(argv[i], "--same-device") != 0 && strcmp(argv[i], "--check") != 0 && strcmp(argv[i], "--shard-traces") != 0 && i + 1 < argc) {av[n++] = argv[++i];} continue;}
 			av[n++] = (seen++ == 0) ? rs : argv[i];
 		}
 		if (seen == 0) {av[n++] = rs;}

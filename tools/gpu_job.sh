@@ -99,7 +99,7 @@ native)
 	# one heightmap per step on all ranks, one C process per GPU (terra.h + rccl.h): one rank through RCCL, what one rank of eight does per step, two ranks sharing this GPU (checked)
 	gcc -O2 -std=c99 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include tools/bench_native_onegrid.c -L3dworld_amd -lterra_hip -L/opt/rocm/lib -lrccl -lamdhip64 -lpthread -lm -Wl,-rpath,"$ROOT/3dworld_amd" -Wl,-rpath,/opt/rocm/lib -o tools/_bin/bench_native_onegrid || exit 1
 	B=tools/_bin/bench_native_onegrid
-	(timeout 120 $B 1 32 16384 1000 --warmup 8; timeout 120 $B 1 64 16384 1000 --warmup 8 --simulate-world 8; timeout 120 $B 1 64 16384 1000 --warmup 8 --simulate-world 8 --eroders 1; timeout 200 $B 2 16 4096 1000 --same-device --warmup 4 --check) 2>&1 | grep "^{" | tee "$OUT/bench_native_onegrid.jsonl"
+	(timeout 120 $B 1 32 16384 1000 --warmup 8; timeout 120 $B 1 64 16384 1000 --warmup 8 --simulate-world 8; timeout 120 $B 1 64 16384 1000 --warmup 8 --simulate-world 8 --eroders 1; timeout 200 $B 2 16 4096 1000 --same-device --warmup 4 --check; timeout 120 $B 1 32 16384 1000 --warmup 8 --shard-traces --check; timeout 200 $B 2 16 4096 300 --same-device --warmup 4 --shard-traces --check) 2>&1 | grep "^{" | tee "$OUT/bench_native_onegrid.jsonl"
 	;;
 stepcost)
 	mkdir -p tools/_bin
