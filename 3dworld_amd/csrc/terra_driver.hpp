@@ -275,6 +275,7 @@ struct options_t {
 	bool ero_near_set = false; int ero_near = 0; // "ero.near" n (negative: ring / -n): droplets next in line for the commit that trace to the end
 	long long ero_mem_budget = -1; // "ero.mem_budget" bytes: pretend this much device memory is free when the ring has to grow (tests)
 	int simple_kernels = 0;       // "kernels.simple" 0 / 1: the one-thread-per-cell cross-check kernels instead of the tiled ones
+	int voxels_cols = 1;          // "voxels.cols" 0 / 1: the lane-per-column voxel sine kernel (no P array) wherever the depth is a multiple of 4; 0: the z-lane kernel over the P stream everywhere (results never depend on it)
 	int graphs = 1;               // "graphs" 0 / 1: replay the erosion rounds as hipGraphs
 	int sg_kc = 27, sg_kc_tiles = 27; // "sg.kc" 20 / 27 / 45, "sg.kc_tiles" 27 / 45: terms per LDS chunk of k_sine_grid (heightmap / tile batch)
 	int sg_rowgroup = 4;          // "sg.rowgroup" 1..1024: tile rows walked together by k_sine_grid
@@ -301,6 +302,7 @@ struct options_t {
 		if (k == "ero.near") {if (v == "default") {ero_near_set = false; return true;} if (!is_int || n < -(1 << 20) || n > (1 << 20)) return false; ero_near_set = true; ero_near = (int)n; return true;}
 		if (k == "ero.mem_budget") {if (!is_int || n < -1) return false; ero_mem_budget = n; return true;}
 		if (k == "kernels.simple") return flag(simple_kernels);
+		if (k == "voxels.cols") return flag(voxels_cols);
 		if (k == "graphs") return flag(graphs);
 		if (k == "sg.kc") {if (!is_int || (n != 20 && n != 27 && n != 45)) return false; sg_kc = (int)n; return true;}
 		if (k == "sg.kc_tiles") {if (!is_int || (n != 27 && n != 45)) return false; sg_kc_tiles = (int)n; return true;}
@@ -1859,8 +1861,9 @@ template<class BE> struct terra_engine {
 				m *= 0.5f; f /= 0.4f; // M_ATTEN_FACTOR, F_ATTEN_FACTOR (src/upsurface.cpp:10-11)
 			}
 			size_t const ntab = ((size_t)nx + nys + nz)*VOX_SINES, npos = (size_t)nx + ny + nz; // tables of the slab's rows only, positions of the whole axes
-			float *d_base = scratch<float>(s_vox, ntab + npos + 64);
-			float *d_tab = d_base, *d_pos = d_base + ntab;
+			uint32_t const nzp = (nz + 63u) & ~63u; // the z table once more as [z/8][k][z%8]: what the lane-per-column kernel reads as scalar operands, eight z at a time
+			float *d_base = scratch<float>(s_vox, ntab + npos + 64 + (size_t)nzp*VOX_SINES);
+			float *d_tab = d_base, *d_pos = d_base + ntab, *d_zt = d_base + ((ntab + npos + 63) & ~(size_t)63);
 			// gen_xyz_vals (src/upsurface.cpp:41-57): val accumulates `val += step` sequentially, so the positions of an axis are a serial prefix sum: one thread per axis
 			float const s0 = lo[0] + off[0], s1 = lo[1] + off[1], s2 = lo[2] + off[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2];
 			be.launch(3, [=] TERRA_LAMBDA (size_t d) {
@@ -1883,10 +1886,11 @@ template<class BE> struct terra_engine {
 				float v = L.SINF(rd.v[index2+1]*d_pos[pe] + rd.v[index2+2]);
 				if (d == 0) {v *= rd.v[index2];}
 				d_tab[i] = v;
+				if (d == 2) {size_t const zz = e - nx - nys; d_zt[((zz >> 3)*VOX_SINES + k)*8 + (zz & 7)] = v;} // [z/8][k][z%8]; (entries behind nz are never stored to the field: left as they are)
 			});
 			float amax = 0.0f; // the largest magnitude p[0] of gen_sines: bounds xv (and xv*yv)
 			for (unsigned k = 0; k < VOX_SINES; ++k) {float const a = fabsf(rd.v[VOX_PARAMS*k]); if (a > amax) {amax = a;}}
-			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize, opt.gen_fused, amax);
+			be.voxel_sines(d_out, nx, nys, nz, d_tab, zscale, normalize, opt.gen_fused, amax, d_zt, nzp);
 		}
 		else {
 			float const l0 = lo[0], l1 = lo[1], l2 = lo[2], v0 = vsz[0], v1 = vsz[1], v2 = vsz[2], o0 = off[0], o1 = off[1], o2 = off[2];

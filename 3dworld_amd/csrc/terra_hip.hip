@@ -21,6 +21,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	float *tile_pad = nullptr; size_t tile_pad_bytes = 0;
 	uint32_t *tile_order = nullptr; size_t tile_order_bytes = 0; // k_tile_erosion's land counts + launch order
 	float *vox_p = nullptr; size_t vox_p_bytes = 0;
+	bool vox_cols = true; // "voxels.cols": the lane-per-column voxel sine kernel (k_voxel_sines_cols) where it applies (nz a multiple of 4)
 	int sg_kc = 27; // "sg.kc": terms per LDS chunk of the heightmap's sine kernel (27: 3 chunks of <= 27 for 8 octaves, 29.7 KB per block; 45: 2 chunks, 48 KB)
 	unsigned sg_rowgroup = 4; // "sg.rowgroup": tile rows walked together by k_sine_grid (L2 reuse of table slices)
 
@@ -42,7 +43,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 	}
 	void options_changed() { // (the engine has drained the stream)
 		if (!opt) return;
-		simple_kernels = opt->simple_kernels != 0; sg_kc = opt->sg_kc; sg_rowgroup = (unsigned)opt->sg_rowgroup;
+		simple_kernels = opt->simple_kernels != 0; sg_kc = opt->sg_kc; sg_rowgroup = (unsigned)opt->sg_rowgroup; vox_cols = opt->voxels_cols != 0;
 		if (graphs_enabled != (opt->graphs != 0)) {for (graph_slot_t &g : graphs) {graph_drop(g);} graphs_enabled = opt->graphs != 0;}
 	}
 	~hip_backend_t() {
@@ -494,7 +495,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		else        {hipLaunchKernelGGL(terra::k_voxel_noise<false>, grid, block, 0, stream, out, npairs, nzp, J, lut3);}
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
-	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float fast_amax = 0.0f) {
+	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float fast_amax = 0.0f, float const *d_zt = nullptr, uint32_t nzp = 0) {
 		if (simple_kernels) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused); return;}
 		use();
 		if (fused && (uint64_t)nx*ny <= 0x7FFFFF00ull) { // "gen.fused": the field as a (columns x 60) x (60 x nz) product on the f32 matrix pipe (terra_fused.hpp)
@@ -524,6 +525,12 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			J.xt = zt; J.yt = pt;
 			unsigned const nb = J.ntx*J.nty, grid = ((nb + 7)/8)*8;
 			hipLaunchKernelGGL(terra::k_sine_grid_mx<terra::SGF_VOXELS>, dim3(std::min(grid, (unsigned)(2*num_cus + 7)/8*8)), dim3(256), 0, stream, J);
+			TERRA_HIP_CHECK(hipGetLastError());
+			return;
+		}
+		if ((nz & 3u) == 0 && vox_cols && d_zt) { // a lane per column, the products in registers, the z table as scalar operands (k_voxel_sines_cols): no P array
+			size_t const ncolc = (size_t)nx*ny;
+			hipLaunchKernelGGL(terra::k_voxel_sines_cols, dim3((unsigned)((ncolc + terra::VC_COLS - 1)/terra::VC_COLS), (nz + terra::VC_Z - 1)/terra::VC_Z), dim3(256), 0, stream, out, nx, ny, nz, nzp, d_tab, d_zt, zscale, normalize);
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
 		}

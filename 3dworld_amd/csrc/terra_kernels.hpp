@@ -856,14 +856,21 @@ constexpr int VX_PSTRIDE = 128; // floats per column pair in P: 60 interleaved p
 typedef float vx_v16f __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_voxel_P(float *__restrict__ P, float *__restrict__ ZT, uint32_t nx, uint32_t ny, uint32_t nz, float const *__restrict__ tab) {
 	// P[(col/2)*128 + k*2 + (col & 1)], columns padded to an even count with zeros; ZT[k][z] = the z table transposed, so that lane z of the main kernel reads it coalesced
+	// a thread makes BOTH products of a column pair for one k and writes them as one 8-byte word: consecutive threads write consecutive words (one product per thread wrote
+	// every other float of a line: 34 us for the 63 MB of a 512 x 512 field, half of what the 512 x 512 x 64 field's own kernel takes)
 	size_t i = (size_t)blockIdx.x*256 + threadIdx.x; size_t const ncol = (size_t)nx*ny, ncol2 = (ncol + 1) & ~(size_t)1;
-	if (i < ncol2*VOX_SINES) {
-		uint32_t const k = (uint32_t)(i % VOX_SINES); size_t const c = i / VOX_SINES;
-		float v = 0.0f;
-		if (c < ncol) {uint32_t const x = (uint32_t)(c % nx), y = (uint32_t)(c / nx); v = __fmul_rn(tab[(size_t)x*VOX_SINES + k], tab[((size_t)nx + y)*VOX_SINES + k]);}
-		P[(c >> 1)*VX_PSTRIDE + k*2 + (c & 1)] = v;
+	if (i < (ncol2/2)*VOX_SINES) {
+		uint32_t const k = (uint32_t)(i % VOX_SINES); size_t const pr = i / VOX_SINES;
+		sg_v2f v = {0.0f, 0.0f};
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			size_t const c = 2*pr + (size_t)h;
+			if (c < ncol) {uint32_t const x = (uint32_t)(c % nx), y = (uint32_t)(c / nx); v[h] = __fmul_rn(tab[(size_t)x*VOX_SINES + k], tab[((size_t)nx + y)*VOX_SINES + k]);}
+		}
+		*(sg_v2f *)&P[pr*VX_PSTRIDE + k*2] = v;
 		return;
 	}
+	if (i < ncol2*VOX_SINES) return; // (the launch is sized for one thread per product: the upper half of those threads has nothing to do)
 	i -= ncol2*VOX_SINES;
 	if (i >= (size_t)nz*VOX_SINES) return;
 	uint32_t const z = (uint32_t)(i % nz), k = (uint32_t)(i / nz);
@@ -891,12 +898,16 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 	// (a lane per 64-byte line), so that the scalar loads find the lines in the L2 instead of paying the HBM latency chunk by chunk.
 	size_t const last_pair = (ncol - 1) >> 1;
 	float const *pp = P + (c0 >> 1)*VX_PSTRIDE; // chunk 0 of this block's first column pair
-	float touched;
+	float touched, touched2;
 	{
-		unsigned const line = (threadIdx.x >> 6)*32u + (threadIdx.x & 31u); // 4 waves x 32 lines x 64 B = 16 column pairs x 512 B
-		size_t const pair = (c0 >> 1) + (line >> 3);
-		float const *tp = P + ((pair <= last_pair) ? pair : last_pair)*VX_PSTRIDE + (line & 7u)*16u;
-		asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(tp));
+		// 128 lines of 64 B = 16 column pairs x 512 B.  A block of four waves (nz >= 256) touches 32 lines per wave; a block of ONE wave (the reference's own 64-deep field)
+		// must touch them all itself -- with lines 32 .. 127 left to the scalar loads the 512 x 512 x 64 field took 83 us instead of ~45
+		// (two loads per lane at most; both destination registers stay allocated until the waits at the end of the kernel: the loads are asynchronous to the compiler)
+		unsigned const nw = blockDim.x >> 6, per_wave = 128u/nw, base = (threadIdx.x >> 6)*per_wave, l0 = threadIdx.x & 63u;
+		unsigned const la = base + ((l0 < per_wave) ? l0 : 0u), lb = base + ((l0 + 64u < per_wave) ? l0 + 64u : ((l0 < per_wave) ? l0 : 0u));
+		size_t const pa = (c0 >> 1) + (la >> 3), pb = (c0 >> 1) + (lb >> 3);
+		float const *ta = P + ((pa <= last_pair) ? pa : last_pair)*VX_PSTRIDE + (la & 7u)*16u, *tb = P + ((pb <= last_pair) ? pb : last_pair)*VX_PSTRIDE + (lb & 7u)*16u;
+		asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(touched), "=&v"(touched2) : "v"(ta), "v"(tb));
 	}
 	vx_v16f b0, b1, b2, b3;
 	asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(b0), "=&s"(b1) : "s"(pp));
@@ -921,10 +932,89 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 			if (col + 1 < ncol) {__builtin_nontemporal_store(vb, &out[(col + 1)*nz + z]);}
 		}
 	}
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(touched)); // the last prefetch and the touch load land before the wave ends
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(touched), "+v"(touched2)); // the last prefetch and the touch loads land before the wave ends
 #undef VX_CHUNK
 #undef VX_STEP
 #undef VX_NEXT
 }
 
+// ---- the same field with a LANE PER COLUMN (round 6).  k_voxel_sines streams a 63 MB array of products P = xv*yv (for a 512 x 512 field) through the scalar unit: as much
+// traffic as a 64-deep field's own output, a launch to make it, and per wave a chain of 64 waits on scalar loads -- the reference's own 512 x 512 x 64 field
+// (scene_config/config_voxel_params.txt:1-3) ran at a third of the 512^3 field's rate per voxel.  Here a lane owns a column: its 60 products live in 30 register pairs (made from
+// the x / y tables once per block and 64 z: no P array, no launch for it) and the z table -- uniform over the wave -- arrives as SCALAR operands (s_load_dwordx8 of the
+// transposed table ZT[k][z]: 15 KB per block, shared by its four waves and hot in the scalar cache), eight z per pass = four independent packed accumulator chains.  (The z
+// slice in LDS, read as 16-byte broadcasts, was LDS-bound: a broadcast still moves 1 KB per wave and read.)  The results leave through a 64 x 16 transposition piece in LDS so
+// that the stores are 16-byte words of whole 64-byte segments.  Same arithmetic, same order as k_voxel_sines: product rounded, then added, k ascending.
+constexpr unsigned VC_COLS = 256, VC_Z = 64, VC_PIECE = 16, VC_TSTRIDE = 20; // columns per block (a lane each), z per block, z per transposition piece, floats per column in it
+typedef float vc_v8f __attribute__((ext_vector_type(8)));
+// the table is read through the CONSTANT address space: nothing writes it while the kernel runs, and a uniform load from there is a scalar load whatever stores lie around it
+// (as a plain global pointer the compiler kept the loads of the first pass scalar and made vector loads + readfirstlane of the rest, behind the kernel's own stores)
+typedef float vc_v16f __attribute__((ext_vector_type(16)));
+typedef vc_v16f const __attribute__((address_space(4))) *vc_zt_ptr;
+template<int ODD> __device__ __forceinline__ void vc_mul_add4(sg_v2f (&acc)[4], sg_v2f pp, vc_v8f zz) {
+	sg_v2f t0, t1, t2, t3;
+	sg_v2f const z0 = {zz.s0, zz.s1}, z1 = {zz.s2, zz.s3}, z2 = {zz.s4, zz.s5}, z3 = {zz.s6, zz.s7};
+	if (ODD == 0) {
+		asm("v_pk_mul_f32 %4, %8, %9 op_sel:[0,0] op_sel_hi:[0,1]\n\tv_pk_mul_f32 %5, %8, %10 op_sel:[0,0] op_sel_hi:[0,1]\n\tv_pk_mul_f32 %6, %8, %11 op_sel:[0,0] op_sel_hi:[0,1]\n\tv_pk_mul_f32 %7, %8, %12 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+		    "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %5\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %7"
+		    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(pp), "s"(z0), "s"(z1), "s"(z2), "s"(z3));
+	}
+	else {
+		asm("v_pk_mul_f32 %4, %8, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\tv_pk_mul_f32 %5, %8, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\tv_pk_mul_f32 %6, %8, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\tv_pk_mul_f32 %7, %8, %12 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+		    "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %5\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %7"
+		    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(pp), "s"(z0), "s"(z1), "s"(z2), "s"(z3));
+	}
+}
+// ZT[z/8][k][z%8]: the z table in passes of eight z (written by the table launch of terra_engine::voxel_fill_dev; nzp/8 passes: whole 64-z slices) -- the 60 rows of a pass are
+// 1920 contiguous bytes, two rows per 64-byte scalar load; what lies behind nz is never stored
+__global__ __launch_bounds__(256, 4) void k_voxel_sines_cols(float *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nzp, float const *__restrict__ tab, float const *__restrict__ ZT, float zscale, int normalize) {
+	__shared__ __attribute__((aligned(16))) float s_tp[4][64*VC_TSTRIDE];         // per wave: 64 columns x 16 z, 20 floats per column (16-byte aligned rows)
+	size_t const ncol = (size_t)nx*ny, c = (size_t)blockIdx.x*VC_COLS + threadIdx.x;
+	uint32_t const z0 = blockIdx.y*VC_Z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	sg_v2f pp[VOX_SINES/2];
+	{
+		bool const live = c < ncol;
+		uint32_t const x = live ? (uint32_t)(c % nx) : 0u, y = live ? (uint32_t)(c / nx) : 0u;
+		float const *xt = tab + (size_t)x*VOX_SINES, *yt = tab + ((size_t)nx + y)*VOX_SINES;
+#pragma unroll
+		for (unsigned j = 0; j < VOX_SINES/2; ++j) {pp[j] = sg_v2f{__fmul_rn(xt[2*j], yt[2*j]), __fmul_rn(xt[2*j + 1], yt[2*j + 1])};}
+	}
+	float *tp = s_tp[wave];
+	size_t const wc0 = (size_t)blockIdx.x*VC_COLS + (size_t)wave*64; // the wave's first column
+#pragma unroll 1
+	for (unsigned piece = 0; piece < VC_Z/VC_PIECE; ++piece) {
+		if (z0 + piece*VC_PIECE >= nz) break;
+#pragma unroll
+		for (unsigned half = 0; half < 2; ++half) { // eight z per pass
+			unsigned const zl = piece*VC_PIECE + half*8;
+			float const *zrow = ZT + (size_t)((z0 + zl) >> 3)*(VOX_SINES*8); // (wave-uniform: scalar loads)
+			sg_v2f acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+			for (unsigned j = 0; j < VOX_SINES/2; ++j) {
+				vc_v16f const zz = *(vc_zt_ptr)(uintptr_t)(zrow + 16*j); // the eight z of this pass for k = 2j and k = 2j + 1: one 64-byte scalar load
+				vc_mul_add4<0>(acc, pp[j], vc_v8f{zz.s0, zz.s1, zz.s2, zz.s3, zz.s4, zz.s5, zz.s6, zz.s7});
+				vc_mul_add4<1>(acc, pp[j], vc_v8f{zz.s8, zz.s9, zz.sa, zz.sb, zz.sc, zz.sd, zz.se, zz.sf});
+			}
+			float v[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+#pragma unroll
+			for (unsigned q = 0; q < 8; ++q) {
+				float r = __fadd_rn(v[q], __fmul_rn((float)(z0 + zl + q), zscale));
+				if (normalize) {r = clip_pm1(r);}
+				v[q] = r;
+			}
+			*(st_f4 *)&tp[lane*VC_TSTRIDE + half*8]     = st_f4{v[0], v[1], v[2], v[3]};
+			*(st_f4 *)&tp[lane*VC_TSTRIDE + half*8 + 4] = st_f4{v[4], v[5], v[6], v[7]};
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+		// the piece leaves transposed: a lane stores four consecutive z of one column (16 bytes), four lanes a column's 64-byte segment
+		uint32_t const zp = z0 + piece*VC_PIECE;
+#pragma unroll
+		for (unsigned q = 0; q < 4; ++q) {
+			unsigned const idx = q*64 + lane, col = idx >> 2, zq = (idx & 3u)*4u;
+			st_f4 const w = *(st_f4 const *)&tp[col*VC_TSTRIDE + zq];
+			if (wc0 + col < ncol && zp + zq < nz) {__builtin_nontemporal_store(w, (st_f4 *)&out[(wc0 + col)*nz + zp + zq]);}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+	}
+}
 } // namespace terra

@@ -126,7 +126,7 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 			}
 		}
 	}
-	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float = 0.0f) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused);}
+	void voxel_sines(float *out, uint32_t nx, uint32_t ny, uint32_t nz, float const *d_tab, float zscale, int normalize, int fused = 0, float = 0.0f, float const * = nullptr, uint32_t = 0) {voxel_sines_simple(out, nx, ny, nz, d_tab, zscale, normalize, fused);}
 };
 typedef cpu_backend_t terra_backend_t;
 #include "../../3dworld_amd/csrc/terra_api_impl.hpp"
