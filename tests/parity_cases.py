@@ -831,6 +831,35 @@ def case_voxels_vs_oracle(pkg, t, orc, mode, dims):
     assert_bit_equal(a, b, f"voxels {dims} mode {mode}")
 
 
+def case_voxels_random(pkg, t, orc, seed, cases, big):
+    """fixed-seed random voxel fields against the oracle: all three generators, shapes that exercise every path of the kernels (depths that are / are not multiples of 4 and
+    of 64, a single column, column counts that are not multiples of 256, odd depths for the pair kernel), positions far from the origin (the lattice tables' wrap planes and
+    the 2^22 switch of the 3-D noise), zscale / normalize on and off, and a y slab of each field"""
+    rng = np.random.default_rng(seed)
+    pc, oc = cfg_pair(pkg, mesh_gen_mode=0, mesh_freq_filter=int(rng.integers(0, 5)))
+    t.init_scene(pc); orc.init(oc)
+    top = 70 if big else 14
+    for k in range(cases):
+        mode = int(rng.choice([0, 0, 1, 2]))
+        nz = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 33, 60, 64, 68, 100, 128, 129, 132] if big else [1, 3, 4, 8, 12, 17]))
+        nx, ny = int(rng.integers(1, top)), int(rng.integers(1, top))
+        if k % 5 == 0:
+            nx, ny = (300, 3) if big else (20, 1)  # more than one block of 256 columns with a ragged tail
+        far = float(rng.choice([0.0, 0.0, 289.0 * 3, -289.0 * 7, 4.0e6 if mode else 50.0]))
+        lo = (float(rng.uniform(-2, 2)) + far, float(rng.uniform(-2, 2)) - far, float(rng.uniform(-1, 1)))
+        vsz = (float(rng.uniform(0.001, 0.3)), float(rng.uniform(0.001, 0.3)), float(rng.uniform(0.001, 0.3)))
+        off = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
+        args = (float(rng.uniform(0.2, 2.0)), float(rng.uniform(0.2, 6.0)), int(rng.integers(0, 1000)), int(rng.integers(0, 1000)), mode, float(rng.choice([0.0, -0.02, 0.004])), int(rng.integers(0, 2)))
+        ref = orc.voxel_fill(nx, ny, nz, lo, vsz, off, *args)
+        got = t.voxel_fill(nx, ny, nz, lo, vsz, off, *args)
+        assert_bit_equal(ref, got, f"random voxels case {k}: {nx}x{ny}x{nz} mode {mode} far {far}")
+        y0 = int(rng.integers(0, ny)); nys = int(rng.integers(1, ny - y0 + 1))
+        buf = t.alloc(nx * nys * nz * 4)
+        t.voxel_fill_slab_dev(buf.ptr, nx, ny, nz, lo, vsz, off, *args, y0, nys)
+        z = buf.download(np.float32, (nys, nx, nz)); buf.free()
+        assert_bit_equal(ref[y0:y0 + nys], z, f"random voxels case {k}: slab [{y0}, {y0 + nys})")
+
+
 def case_proc_gen(pkg, t, orc, N, iters):
     """heightmap_t::proc_gen: generate + glaciate + erosion(min(vals)) + 16-bit quantise."""
     pc, oc = cfg_pair(pkg, mesh_gen_mode=0)

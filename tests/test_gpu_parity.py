@@ -153,6 +153,12 @@ def test_tile_golden(pkg, gpu):
     pc.case_tile_golden(pkg, gpu)
 
 
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_voxels_random_shapes(pkg, gpu, orc, seed):
+    """k_voxel_sines_cols / k_voxel_sines / k_voxel_noise on random shapes, positions, generators and slabs"""
+    pc.case_voxels_random(pkg, gpu, orc, seed, 24, big=True)
+
+
 def test_voxels(pkg, gpu, orc):
     pc.case_voxels_golden(pkg, gpu)
     pc.case_voxels_vs_oracle(pkg, gpu, orc, 0, (96, 64, 64))

@@ -240,6 +240,10 @@ def test_tile_golden(pkg, emul):
     pc.case_tile_golden(pkg, emul)
 
 
+def test_voxels_random_shapes(pkg, emul, orc):
+    pc.case_voxels_random(pkg, emul, orc, 5, 10, big=False)
+
+
 def test_voxels(pkg, emul, orc):
     pc.case_voxels_golden(pkg, emul)
     pc.case_voxels_vs_oracle(pkg, emul, orc, 0, (33, 17, 20))
