@@ -945,6 +945,8 @@ __global__ __launch_bounds__(256) void k_voxel_sines(float *__restrict__ out, ui
 // transposed table ZT[k][z]: 15 KB per block, shared by its four waves and hot in the scalar cache), eight z per pass = four independent packed accumulator chains.  (The z
 // slice in LDS, read as 16-byte broadcasts, was LDS-bound: a broadcast still moves 1 KB per wave and read.)  The results leave through a 64 x 16 transposition piece in LDS so
 // that the stores are 16-byte words of whole 64-byte segments.  Same arithmetic, same order as k_voxel_sines: product rounded, then added, k ascending.
+// (Pipelining the scalar loads by hand -- stages of two loads, double-buffered, the next stage issued behind the wait for this one -- was measured EQUAL, 47.4 vs 45.7 us for
+// 512 x 512 x 64, with the scalar registers at their limit: the compiler's schedule stays.  What is left against the 29 us of packed instructions at full issue is not the waits.)
 constexpr unsigned VC_COLS = 256, VC_Z = 64, VC_PIECE = 16, VC_TSTRIDE = 20; // columns per block (a lane each), z per block, z per transposition piece, floats per column in it
 typedef float vc_v8f __attribute__((ext_vector_type(8)));
 // the table is read through the CONSTANT address space: nothing writes it while the kernel runs, and a uniform load from there is a scalar load whatever stores lie around it
