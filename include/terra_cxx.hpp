@@ -86,6 +86,24 @@ inline float eval_mesh_sin_terms(float xv, float yv) {
 	check(terra_eval_mesh_sin_terms(default_ctx(), xv, yv, &z), "eval_mesh_sin_terms");
 	return z;
 }
+// ---- eval_mesh_sin_terms_scaled (src/mesh_gen.cpp:807-813) and get_exact_zval (:816-847): the all-modes point queries; a batch at a time where the caller has one
+// (biome parameters of a tile's corners src/tiled_mesh.cpp:332-338, voxel terrain src/voxels.cpp:434), else one point
+inline void eval_mesh_sin_terms_scaled(float const *xy, unsigned n, float xy_scale, float *out) {
+	check(terra_eval_points(default_ctx(), xy, n, TERRA_POINTS_SCALED, xy_scale, 0, 0, 0, out), "eval_mesh_sin_terms_scaled");
+}
+inline float eval_mesh_sin_terms_scaled(float xval, float yval, float xy_scale) {
+	float const xy[2] = {xval, yval}; float z = 0.0f;
+	eval_mesh_sin_terms_scaled(xy, 1, xy_scale, &z);
+	return z;
+}
+inline void get_exact_zval(float const *xy, unsigned n, float *out, bool no_xyoff = false, int xoff2 = 0, int yoff2 = 0) { // xoff2 / yoff2: the reference's scroll-offset globals
+	check(terra_eval_points(default_ctx(), xy, n, TERRA_POINTS_EXACT, 1.0f, no_xyoff ? 1 : 0, xoff2, yoff2, out), "get_exact_zval");
+}
+inline float get_exact_zval(float xval, float yval, bool no_xyoff = false, int xoff2 = 0, int yoff2 = 0) {
+	float const xy[2] = {xval, yval}; float z = 0.0f;
+	get_exact_zval(xy, 1, &z, no_xyoff, xoff2, yoff2);
+	return z;
+}
 // ---- glaciate() over the ground mesh (src/mesh_gen.cpp:388-404): in place on a device buffer, returns zbottom / ztop
 inline void glaciate_mesh_dev(float *d_mesh, unsigned nx, unsigned ny, int xoff2, int yoff2, float &zbottom, float &ztop) {
 	float zz[2] = {0.0f, 0.0f};

@@ -1,5 +1,5 @@
 // tests/cxx_mirror_run.cpp -- include/terra_cxx.hpp EXECUTED: the engine-side C++ mirror of the reference's call surface, driven exactly as an engine caller would
-// (heightmap_t::proc_gen's pattern, src/heightmap.cpp:135-143,169; tile_t::create_zvals; eval_mesh_sin_terms), linked against libterra_emul.so on the CPU box and
+// (heightmap_t::proc_gen's pattern, src/heightmap.cpp:135-143,169; tile_t::create_zvals; eval_mesh_sin_terms, eval_mesh_sin_terms_scaled, get_exact_zval), linked against libterra_emul.so on the CPU box and
 // against libterra_hip.so on the GPU box (tests/test_engine_in_the_loop.py compares the floats it writes with the oracle).
 #include "terra_cxx.hpp"
 #include <cstring>
@@ -47,6 +47,14 @@ int main(int argc, char **argv) {
 		out.insert(out.end(), z.begin(), z.end());
 		tiles_upload_normal_texture(txy, 1, z.data(), &ts2, nm2.data(), &mnz2); // the post pass alone over those zvals: the same stats, normals and min_normal_z
 		if (std::memcmp(&ts, &ts2, sizeof(ts)) != 0 || nm != nm2 || std::memcmp(&mnz, &mnz2, sizeof(float)) != 0) return 6;
+	}
+	{ // the all-modes point queries: one point and a batch, in index space (scaled) and in world space (exact, with a scroll offset)
+		float const q[4][2] = {{0.5f, 0.5f}, {-10.25f, 3.0f}, {100.0f, -77.5f}, {3.75f, 12.5f}};
+		float zs[4], ze[4];
+		eval_mesh_sin_terms_scaled(&q[0][0], 4, 0.5f, zs);
+		get_exact_zval(&q[0][0], 4, ze, false, 3, -2);
+		out.insert(out.end(), zs, zs + 4); out.insert(out.end(), ze, ze + 4);
+		out.push_back(eval_mesh_sin_terms_scaled(q[1][0], q[1][1], 0.5f)); out.push_back(get_exact_zval(q[2][0], q[2][1], false, 3, -2));
 	}
 	FILE *f = std::fopen(argv[1], "wb");
 	if (!f) return 5;

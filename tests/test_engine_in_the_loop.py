@@ -113,6 +113,12 @@ def _check_cxx_mirror(vals, orc):
     assert_bit_equal(np.array([orc.eval_mesh_sin_terms(x, y) for x, y in pts], np.float32), vals[2 * k:2 * k + 3], "terra_cxx::eval_mesh_sin_terms")
     zt, _ = orc.tile_create_zvals(2, -1, 80)
     assert_bit_equal(zt.reshape(-1), vals[2 * k + 3:2 * k + 3 + 130 * 130], "terra_cxx::tiles_create_zvals")
+    b = 2 * k + 3 + 130 * 130
+    q = np.array([(0.5, 0.5), (-10.25, 3.0), (100.0, -77.5), (3.75, 12.5)], np.float32)
+    zs, ze = orc.eval_points(q, False, xy_scale=0.5), orc.eval_points(q, True, xoff2=3, yoff2=-2)
+    assert_bit_equal(zs, vals[b:b + 4], "terra_cxx::eval_mesh_sin_terms_scaled (batch)")
+    assert_bit_equal(ze, vals[b + 4:b + 8], "terra_cxx::get_exact_zval (batch)")
+    assert_bit_equal(np.array([zs[1], ze[2]], np.float32), vals[b + 8:b + 10], "terra_cxx point queries, one point")
 
 
 def test_cxx_mirror_header_runs_emul(orc, emul_lib, tmp_path):
