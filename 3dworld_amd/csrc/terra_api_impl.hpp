@@ -303,6 +303,7 @@ int terra_erosion_shard_trace_dev(terra_ctx *ctx, float *d, int xs, int ys, uint
 int terra_erosion_shard_finish_dev(terra_ctx *ctx, float *d, int xs, int ys, const float *d_min_zval, uint32_t iters, uint32_t flags, uint32_t world, uint32_t self, const uint32_t *row_end, void *d_arena_self, size_t arena_stride) {
 	TERRA_CHECK_CTX if (!d || !d_min_zval || !row_end || !d_arena_self) return terra::fail(TERRA_ERR_ARG, "null argument");
 	if (world == 0 || world > terra::SPARSE_SHARD_MAX_WORLD || self >= world) return terra::fail(TERRA_ERR_ARG, "terra_erosion_shard_finish_dev: world must be 1 .. 16 and self below it");
+	if (world > 1 && arena_stride < ctx->eng.sparse_arena_bytes(iters)) return terra::fail(TERRA_ERR_ARG, "terra_erosion_shard_finish_dev: arena_stride is smaller than an arena (terra_erosion_shard_arena_bytes)");
 	for (uint32_t r = 0; r < world; ++r) {
 		if ((r && row_end[r] < row_end[r - 1]) || (r + 1 == world && (ys <= 0 || row_end[r] != (uint32_t)ys))) return terra::fail(TERRA_ERR_ARG, "terra_erosion_shard_finish_dev: row_end must be non-decreasing and end at ysize");
 	}

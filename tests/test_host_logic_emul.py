@@ -206,6 +206,21 @@ def test_sharded_sparse_erosion(pkg, emul_lib, orc, n, iters, world, eroder, for
         assert rep.sparse_droplets == 0
 
 
+def test_sharded_erosion_argument_errors(pkg, emul):
+    """terra_erosion_shard_*: rows outside the grid, a world beyond 16, self outside the world, a row_end that does not end at ysize, a stride smaller than an arena"""
+    import ctypes as C
+    emul.init_scene(pkg.make_config(mesh_gen_mode=0))
+    n, d = 64, 10
+    g = emul.alloc(n * n * 4); a = emul.alloc(emul.erosion_shard_arena_bytes(d) * 2); m = emul.alloc(8)
+    with pytest.raises(pkg.TerraError):
+        emul.erosion_shard_trace_dev(g.ptr, n, n, d, 60, 10, a.ptr)
+    for world, self_rank, ends, stride in [(17, 0, [n] * 17, 1 << 30), (2, 2, [32, n], 1 << 30), (2, 0, [32, n - 1], 1 << 30), (2, 0, [40, 32], 1 << 30), (2, 0, [32, n], 4096)]:
+        with pytest.raises(pkg.TerraError):
+            emul.erosion_shard_finish_dev(g.ptr, n, n, m.ptr, d, 0, world, self_rank, ends, a.ptr, stride)
+    for b in (g, a, m):
+        b.free()
+
+
 def test_sparse_erosion_edge_cases_and_probe_pass(pkg, emul, orc):
     pc.case_erosion_edge_sparse(pkg, emul, orc)
 
