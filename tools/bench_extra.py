@@ -111,8 +111,7 @@ t.init_scene(pkg.make_config(mesh_gen_mode=0))
 lo, vsz, off = (-15.9, -15.9, -1.0), (0.0622, 0.0622, 0.0625), (0.0, 0.0, 0.0)
 for dims in ((512, 512, 64), (512, 512, 512)):
     v = t.alloc(dims[0] * dims[1] * dims[2] * 4)
-    for name, mode in (("sines", 0), ("simplex", 1)):
-        if mode == 1 and dims[2] == 512: continue
+    for name, mode in (("sines", 0), ("simplex", 1), ("perlin", 2)):
         ms = timed(lambda: t.voxel_fill_dev(v.ptr, dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, mode, 0.01, 1), reps=2)
         out[f"C5_voxels_{dims[0]}x{dims[1]}x{dims[2]}_{name}_gvoxels_s"] = round(dims[0] * dims[1] * dims[2] / ms / 1e6, 2)
     v.free()
@@ -204,5 +203,9 @@ if "--no-cpu" not in sys.argv:
     dims = (512, 512, 64)  # (OpenMP over y, src/voxels.cpp:312: 512 rows for the host's threads)
     dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, 0, 0.01, 1))
     cpu["C5_voxels_512x512x64_sines_gvoxels_s_allthr"] = round(dims[0] * dims[1] * dims[2] / dt / 1e9, 4)
+    for name, mode in (("simplex", 1), ("perlin", 2)):  # the lattice fields (glm, src/voxels.cpp:328-338): the reference on all host threads
+        dims = (256, 256, 64)
+        dt, _ = wall(lambda: ck.voxel_fill(dims[0], dims[1], dims[2], lo, vsz, off, 1.0, 1.0, 123, 456, mode, 0.01, 1))
+        cpu[f"C5_voxels_256x256x64_{name}_gvoxels_s_allthr"] = round(dims[0] * dims[1] * dims[2] / dt / 1e9, 4)
     out["cpu"] = cpu
 print(json.dumps(out))
