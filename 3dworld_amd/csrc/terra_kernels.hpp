@@ -159,6 +159,85 @@ template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(
 	// The common configuration (linear shape, no plateau/crater/crack, no volcano) takes a short path with the island terms of the
 	// thread's 8 columns / 8 rows loaded once; anything else goes through the general finish_cell().  Same arithmetic either way.
 	bool const vec_ok = ((job.nx & 3u) == 0) && !TILES;
+	if (!GENERAL && TILES && (job.nx & 3u) == 0) {
+		// the tile batch's common case: the packed epilogue of the grid (below), then the scatter into the per-tile layout -- a 4-cell group that lies in one tile goes out as ONE
+		// 16-byte store (tile rows are 4-byte aligned only: tw = 130, 201, 129), a group across a tile boundary cell by cell.  (The per-cell epilogue with 8-byte stores made this
+		// variant run at 0.7 of the grid kernel's rate: profiles/r06_tiles_kernel_stats.txt.)
+		typedef sg_v2f v2f;
+		typedef float st_f4u __attribute__((ext_vector_type(4), aligned(4)));
+		bool const gl = job.glaciate && nc.glaciate, sm = job.glaciate && job.use_sine_mag;
+		float4 sx[2], sy[2];
+		sx[0] = sx[1] = sy[0] = sy[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (sm) { // (the batch's island tables end with the virtual grid: nothing is read behind nx / ny; nx is a multiple of 4 here, ny need not be)
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				unsigned const x = bx0 + h*64 + tx*4, y = by0 + h*64 + ty*4;
+				if (x < job.nx) {sx[h] = *(float4 const *)(smx + x);}
+				sy[h] = make_float4((y < job.ny) ? smy[y] : 0.0f, (y + 1 < job.ny) ? smy[y + 1] : 0.0f, (y + 2 < job.ny) ? smy[y + 2] : 0.0f, (y + 3 < job.ny) ? smy[y + 3] : 0.0f);
+			}
+		}
+		v2f const zme = {nc.zmax_est, nc.zmax_est}, inv = {nc.zmax_est2_inv, nc.zmax_est2_inv}, z2 = {nc.zmax_est2, nc.zmax_est2}, off = {job.sine_offset, job.sine_offset};
+		unsigned const tw = tiles.tw, nuy = job.ny/tw; // (the virtual grid is nux x nuy tiles of tw x tw cells)
+		unsigned ux0[2], cx0[2], uy0[2], cy0[2];
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {unsigned const x = bx0 + half*64 + tx*4; ux0[half] = x/tw; cx0[half] = x - ux0[half]*tw;}
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {unsigned const y = by0 + g*64 + ty*4; uy0[g] = y/tw; cy0[g] = y - uy0[g]*tw;}
+		// the tiles under the thread's cells: two tile columns per half at most (a group may cross into the next), two tile rows per 4-row group
+		int tmap[2][2][2][2];
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {
+#pragma unroll
+			for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+				for (int half = 0; half < 2; ++half) {
+#pragma unroll
+					for (int dx = 0; dx < 2; ++dx) {
+						unsigned const uy = uy0[g] + dy, ux = ux0[half] + dx;
+						tmap[g][dy][half][dx] = (uy < nuy && ux < tiles.nux) ? tiles.tile_map[uy*tiles.nux + ux] : -1;
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < SG_TY; ++i) {
+			unsigned const y = by0 + (i >> 2)*64 + ty*4 + (i & 3);
+			if (y >= job.ny) continue;
+			float const syq[4] = {sy[i >> 2].x, sy[i >> 2].y, sy[i >> 2].z, sy[i >> 2].w};
+			v2f const syi = {syq[i & 3], syq[i & 3]};
+			unsigned cy = cy0[i >> 2] + (unsigned)(i & 3); int dy = 0;
+			if (cy >= tw) {cy -= tw; dy = 1;}
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {
+				unsigned const x = bx0 + half*64 + tx*4;
+				if (x >= job.nx) continue;
+				v2f z01 = acc[i][half*2], z23 = acc[i][half*2 + 1];
+				if (gl) {
+					v2f const r01 = (z01 + zme)*inv, r23 = (z23 + zme)*inv;
+					z01 = ((r01*r01)*r01)*z2 - zme; z23 = ((r23*r23)*r23)*z2 - zme;
+				}
+				if (sm) {
+					v2f const s01 = {sx[half].x, sx[half].y}, s23 = {sx[half].z, sx[half].w};
+					z01 = z01 + (s01*syi + off); z23 = z23 + (s23*syi + off);
+				}
+				unsigned const cx = cx0[half];
+				int const ta = dy ? tmap[i >> 2][1][half][0] : tmap[i >> 2][0][half][0], tb = dy ? tmap[i >> 2][1][half][1] : tmap[i >> 2][0][half][1];
+				if (cx + 3 < tw) { // the whole group in one tile row
+					if (ta >= 0) {*(st_f4u *)(out + (size_t)ta*tw*tw + cy*tw + cx) = st_f4u{z01.x, z01.y, z23.x, z23.y};}
+				}
+				else {
+					float const v[4] = {z01.x, z01.y, z23.x, z23.y};
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						bool const next = cx + (unsigned)j >= tw;
+						int const t = next ? tb : ta;
+						if (t >= 0) {out[(size_t)t*tw*tw + cy*tw + (next ? cx + (unsigned)j - tw : cx + (unsigned)j)] = v[j];}
+					}
+				}
+			}
+		}
+		return; // (a tile batch has no fused min / max)
+	}
 	if (!GENERAL && !TILES && vec_ok) {
 		// the common case, two cells per instruction (v_pk_mul_f32 / v_pk_add_f32): the island tables are zero-padded to the tile grid, rows of 4 cells
 		// are either wholly inside the grid or wholly outside
