@@ -88,6 +88,22 @@ def sharded(env, detail, run_steps):
         env.t.synchronize()
     dv = env.timed(voxel_steps, ke, 2, "voxels")
     detail["voxels"] = {"grid": f"{VN}^3", "steps": ke, "ms_per_field": round(dv / ke * 1e3, 4), "gvoxels_s": round(VN ** 3 * ke / dv / 1e9, 2), "scaling": "strong", "y_rows_per_rank": v1 - v0, "collective": "none"}
+    # the same entry point's lattice generators (glm simplex / Perlin fBm, src/voxels.cpp:328-338) at the reference's own field size (scene_config/config_voxel_params.txt:1-3), rank 0 only
+    if env.rank == 0:
+        nzr = 64
+        vb = env.torch.empty(VN * VN * nzr, dtype=env.torch.float32, device=env.dev)
+        fb = {}
+        for name, gm in (("sines", 0), ("simplex", 1), ("perlin", 2)):
+            call = lambda gm=gm: env.t.voxel_fill_dev(vb.data_ptr(), VN, VN, nzr, (-1.0, -1.0, -0.25), (2.0 / VN, 2.0 / VN, 0.5 / nzr), (0.0, 0.0, 0.0), 1.0, 1.0, 123, 456, gm, 0.0, 1)  # noqa: E731
+            for _ in range(3):
+                call()
+            env.t.synchronize(); env.t.timer_start()
+            for _ in range(8):
+                call()
+            ms = env.t.timer_stop() / 8
+            fb[name] = {"ms_per_field": round(ms, 4), "gvoxels_s": round(VN * VN * nzr / ms / 1e6, 1)}
+        detail["voxels_512x512x64"] = fb
+        del vb
 
 
 def modes_and_dense(env, detail, ms_gen, ms_ero):
