@@ -49,6 +49,10 @@ TERRA_HD float ord2f(uint32_t o) {uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFF
 
 // ---- "simple" (one logical thread per cell) bodies shared by the CPU emulator and the GPU cross-check kernels
 struct tile_ref_pod_t {int32_t tx, ty; uint32_t xi, yi;};
+// a band of a tile's tw x tw field (tile_fields_dev): twx x twy cells per tile whose coordinate c stands for field coordinate c + (c >= split ? gap : 0); ostride = tw.
+// The AO context without its centre: rows [0, 36) + [166, 201) x all 201 columns, then rows [36, 166) x columns [0, 36) + [166, 201)
+struct tile_band_t {uint32_t twx, twy, ostride, xsplit, xgap, ysplit, ygap;};
+TERRA_HD uint32_t tile_band_coord(uint32_t c, uint32_t split, uint32_t gap) {return c + ((c >= split) ? gap : 0u);}
 
 TERRA_HD float sine_cell(grid_job_t const &job, float const *xt, float const *yt, unsigned x, unsigned y) {
 	float z = 0.0f;
@@ -275,6 +279,7 @@ struct options_t {
 	bool ero_near_set = false; int ero_near = 0; // "ero.near" n (negative: ring / -n): droplets next in line for the commit that trace to the end
 	long long ero_mem_budget = -1; // "ero.mem_budget" bytes: pretend this much device memory is free when the ring has to grow (tests)
 	int simple_kernels = 0;       // "kernels.simple" 0 / 1: the one-thread-per-cell cross-check kernels instead of the tiled ones
+	int ao_bands = 1;             // "ao.bands" 0 / 1: the AO context of a tile batch as four bands around each tile (the centre comes from the tile's own heights anyway) where the backend can (results never depend on it)
 	int voxels_cols = 1;          // "voxels.cols" 0 / 1: the lane-per-column voxel sine kernel (no P array) wherever the depth is a multiple of 4; 0: the z-lane kernel over the P stream everywhere (results never depend on it)
 	int graphs = 1;               // "graphs" 0 / 1: replay the erosion rounds as hipGraphs
 	int sg_kc = 27, sg_kc_tiles = 27; // "sg.kc" 20 / 27 / 45, "sg.kc_tiles" 27 / 45: terms per LDS chunk of k_sine_grid (heightmap / tile batch)
@@ -303,6 +308,7 @@ struct options_t {
 		if (k == "ero.mem_budget") {if (!is_int || n < -1) return false; ero_mem_budget = n; return true;}
 		if (k == "kernels.simple") return flag(simple_kernels);
 		if (k == "voxels.cols") return flag(voxels_cols);
+		if (k == "ao.bands") return flag(ao_bands);
 		if (k == "graphs") return flag(graphs);
 		if (k == "sg.kc") {if (!is_int || (n != 20 && n != 27 && n != 45)) return false; sg_kc = (int)n; return true;}
 		if (k == "sg.kc_tiles") {if (!is_int || (n != 27 && n != 45)) return false; sg_kc_tiles = (int)n; return true;}
@@ -1349,9 +1355,11 @@ template<class BE> struct terra_engine {
 	// + the eval_index loop (src/tiled_mesh.cpp:458-464,480-488,494-505).  tw = 130, shift = 0: the tile's zvals; tw = 201, shift = 36: its AO context.
 	// Returns the device copy of the tile references (valid until the next tile call of this context).
 	tile_ref_pod_t const *tile_fields_dev(int32_t const *tile_xy, uint32_t n, uint32_t tw, int shift, float *d_out, float xy_scale = 1.0f, // xy_scale 0: only the tile references
-		bool glac = true, bool force_sine = false, int min_start_sin = 0) // enable_glaciate() after build_arrays; build_arrays' force_sine_mode; eval_index's min_start_sin
+		bool glac = true, bool force_sine = false, int min_start_sin = 0, // enable_glaciate() after build_arrays; build_arrays' force_sine_mode; eval_index's min_start_sin
+		tile_band_t const *band = nullptr, bool *band_used = nullptr)         // band: only these cells of every tile's field, if the backend can (*band_used); else the whole fields
 	{
 		uint32_t const size = 128, zv = tw;
+		if (band_used) {*band_used = false;}
 		float const fdx = xy_scale*DX_VAL, fdy = xy_scale*DY_VAL; // setup_height_gen_async: build_arrays(..., xy_scale*DX_VAL, xy_scale*DY_VAL, ...)
 		// a tile's X table depends only on its tile x, its Y table only on its tile y: build each distinct one once
 		std::vector<int32_t> ux, uy;
@@ -1370,8 +1378,13 @@ template<class BE> struct terra_engine {
 		{std::vector<std::pair<int32_t, int32_t>> tt; for (uint32_t i = 0; i < n; ++i) {tt.push_back(std::make_pair(tile_xy[2*i], tile_xy[2*i+1]));} std::sort(tt.begin(), tt.end()); unique_tiles = (std::adjacent_find(tt.begin(), tt.end()) == tt.end());}
 		// tables of all distinct tile columns / rows side by side, k-major like the big-grid tables: xt[k][u*tw + c], yt[k][u*tw + c].
 		// The batch is then ONE "virtual" (nux*tw) x (nuy*tw) sine grid whose cells are exactly the requested tiles' cells.
-		uint32_t const nxpv = round_up(nux*zv, 128), nypv = round_up(nuy*zv, 128);
-		size_t const tab_floats = (size_t)F_TABLE_SIZE*(nxpv + nypv), sm_floats = (size_t)(nux + nuy)*zv;
+		int const md_ = force_sine ? (int)MGEN_SINE : mode;
+		bool const banded = band && xy_scale != 0.0f && d_out && be.tile_band_ok(n, nux, nuy, band->twx, unique_tiles, md_ == MGEN_SINE && sine_plain_only(force_sine ? 0 : shape, imax(start_eval_sin, min_start_sin)), md_);
+		if (band_used) {*band_used = banded;}
+		tile_band_t const bd = banded ? *band : tile_band_t{zv, zv, zv, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+		uint32_t const zvx = bd.twx, zvy = bd.twy; // cells per tile in the virtual grid
+		uint32_t const nxpv = round_up(nux*zvx, 128), nypv = round_up(nuy*zvy, 128);
+		size_t const tab_floats = (size_t)F_TABLE_SIZE*(nxpv + nypv), sm_floats = (size_t)nux*zvx + (size_t)nuy*zvy;
 		// one parameter block: tile references | origins of the distinct columns / rows | their per-k constants -- assembled on the host, ONE asynchronous upload
 		size_t const o_refs = 0, o_m0 = (refs.size()*sizeof(tile_ref_t) + 255) & ~(size_t)255, o_sk = o_m0 + (((size_t)(nux + nuy)*4 + 255) & ~(size_t)255);
 		size_t const par_bytes = o_sk + (((nux + nuy)*sizeof(sine_k_t) + 255) & ~(size_t)255);
@@ -1399,10 +1412,10 @@ template<class BE> struct terra_engine {
 		float const dxv = fdx, dyv = fdy, dxi = DX_VAL_INV, dyi = DY_VAL_INV;
 		if (use_sm) { // enable_glaciate per distinct tx / ty
 			float const sm_scale = hp.sine_mag*mesh_scale_z_inv, freq = mesh_scale*hp.sine_freq;
-			be.launch((size_t)(nux + nuy)*zv, [=] TERRA_LAMBDA (size_t i) {
-				unsigned const u = (unsigned)(i / zv), c = (unsigned)(i % zv);
-				if (u < nux) {d_sm[i] = sm_scale*L.COSF(((float)c*dxv + d_m0[u])*dxi*freq);}
-				else         {d_sm[i] = L.COSF(((float)c*dyv + d_m0[u])*dyi*freq);}
+			size_t const nsx = (size_t)nux*zvx;
+			be.launch(sm_floats, [=] TERRA_LAMBDA (size_t i) { // (c: the cell's coordinate in the tile's field -- a band's coordinates skip its gap)
+				if (i < nsx) {unsigned const u = (unsigned)(i / zvx), c = tile_band_coord((unsigned)(i % zvx), bd.xsplit, bd.xgap); d_sm[i] = sm_scale*L.COSF(((float)c*dxv + d_m0[u])*dxi*freq);}
+				else {size_t const j = i - nsx; unsigned const u = (unsigned)(j / zvy), c = tile_band_coord((unsigned)(j % zvy), bd.ysplit, bd.ygap); d_sm[i] = L.COSF(((float)c*dyv + d_m0[nux + u])*dyi*freq);}
 			});
 		}
 		float *d_taby = d_tab + (size_t)F_TABLE_SIZE*nxpv;
@@ -1410,7 +1423,8 @@ template<class BE> struct terra_engine {
 			be.launch(tab_floats, [=] TERRA_LAMBDA (size_t i) {
 				bool const isx = i < (size_t)F_TABLE_SIZE*nxpv;
 				size_t const j = isx ? i : i - (size_t)F_TABLE_SIZE*nxpv;
-				unsigned const rowlen = isx ? nxpv : nypv, k = (unsigned)(j / rowlen), v = (unsigned)(j % rowlen), u = v / zv, c = v % zv;
+				unsigned const rowlen = isx ? nxpv : nypv, per = isx ? zvx : zvy, k = (unsigned)(j / rowlen), v = (unsigned)(j % rowlen), u = v / per;
+				unsigned const c = isx ? tile_band_coord(v % per, bd.xsplit, bd.xgap) : tile_band_coord(v % per, bd.ysplit, bd.ygap); // the cell's coordinate in the tile's field
 				float val = 0.0f; // zero padding up to a multiple of 128
 				if (u < (isx ? nux : nuy)) {
 					sine_k_t const &sk = d_sk[isx ? u : nux + u];
@@ -1421,7 +1435,8 @@ template<class BE> struct terra_engine {
 		}
 		float const sine_offset = hp.sine_bias*mesh_scale_z_inv;
 		bool const plain = md == MGEN_SINE && sine_plain_only(shp, kstart);
-		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, tw, unique_tiles, glac, d_noise_lut, fused_kernel_exists(md, plain) ? opt.gen_fused : 0, sine_amp_max(kstart));
+		be.tile_grid(n, d_refs, nux, nuy, d_tab, d_taby, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, sine_offset, nc, L, dxv, dyv, d_out, plain, banded ? zvx : tw, unique_tiles, glac, d_noise_lut, fused_kernel_exists(md, plain) ? opt.gen_fused : 0, sine_amp_max(kstart),
+			banded ? &bd : nullptr);
 		return d_refs;
 	}
 
@@ -1629,10 +1644,18 @@ template<class BE> struct terra_engine {
 		if (n == 0) return;
 		uint32_t const zv = 130, cs = AO_CTX, rl = AO_RAY_LEN;
 		float *d_ctx = scratch<float>(s_ao, (size_t)n*cs*cs);
-		if (using_hmap()) {tile_hmap_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);} else {tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);}
 		// inside the tile the context is the tile's own zvals (src/tiled_mesh.cpp:622): the kernel takes those cells from d_zvals while it stages the context (a copy pass
 		// into d_ctx first was 168 us for 4096 tiles)
 		bool const own = using_hmap() || !ao_context_zvals();
+		if (using_hmap()) {tile_hmap_fields_dev(tile_xy, n, cs, (int)rl, d_ctx);}
+		else {
+			// ... so with `own` the centre of the context -- 130^2 of 201^2 cells, 42 % -- is never read: where the backend can, only the four bands around the tile are evaluated
+			// (a cell's value does not depend on its neighbours: the same bits), as two launches: the rows above and below the tile, then the columns beside it
+			tile_band_t const rows_band = {cs, cs - zv, cs, 0xFFFFFFFFu, 0u, rl, zv}, cols_band = {cs - zv, zv, cs, rl, zv, 0u, rl};
+			bool banded = false;
+			tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx, 1.0f, true, false, 0, (own && opt.ao_bands) ? &rows_band : nullptr, &banded);
+			if (banded) {tile_fields_dev(tile_xy, n, cs, (int)rl, d_ctx, 1.0f, true, false, 0, &cols_band, &banded);}
+		}
 		float const dz = (float)(0.5*(double)HALF_DXY);
 		be.tile_ao(n, d_zvals, d_ctx, d_ao, dz, own);
 	}

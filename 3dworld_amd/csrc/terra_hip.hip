@@ -295,7 +295,7 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 			TERRA_HIP_CHECK(hipGetLastError());
 			return true;
 		}
-		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup, 0};
+		terra::sg_tiles_t const tl{nullptr, nullptr, 0, sg_rowgroup, 0, 0, 0, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0};
 		if (job.plain_only) {
 			auto const go = [&](auto kern) {hipLaunchKernelGGL(kern, dim3(grid), dim3(terra::SG_THREADS), 0, stream, job, nc, L, xt, yt, smx, smy, out, ntx, nty, mm, tl);};
 			if (sg_kc == 27) go(terra::k_sine_grid<false, false, 27>); else if (sg_kc == 20) go(terra::k_sine_grid<false, false, 20>); else go(terra::k_sine_grid<false, false, 45>);
@@ -320,8 +320,13 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		return true;
 	}
 	int32_t *tile_map = nullptr; size_t tile_map_count = 0;
+	// may a band of the tiles' fields be evaluated instead of whole squares?  Only where tile_grid takes the packed epilogue of the plain sine kernel (the one that knows bands)
+	bool tile_band_ok(uint32_t n, uint32_t nux, uint32_t nuy, uint32_t twx, bool unique_tiles, bool plain_only, int md) const {
+		return !simple_kernels && md == terra::MGEN_SINE && unique_tiles && plain_only && (uint64_t)n*2 >= (uint64_t)nux*nuy && ((nux*twx) & 3u) == 0 && (!opt || opt->sg_kc_tiles == 27) && (!opt || opt->ao_bands != 0);
+	}
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0,
-		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr, int fused = 0, float fast_amax = 0.0f)
+		int md, int shp, int kstart, bool use_sm, float so, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool plain_only, uint32_t tw, bool unique_tiles, bool glaciate = true, uint32_t const *nlut = nullptr, int fused = 0, float fast_amax = 0.0f,
+		terra::tile_band_t const *band = nullptr) // band (tile_band_ok() said yes): tw = the band's cells per tile in x
 	{
 		// sine mode and a batch that fills at least half of (distinct tile columns) x (distinct tile rows): ONE LDS-tiled k_sine_grid launch over the
 		// virtual grid, scattered into the per-tile layout.  Sparse batches and the fBm modes are per-cell anyway.
@@ -351,10 +356,11 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		int32_t *tm = tile_map;
 		launch(n, [=] TERRA_LAMBDA (size_t i) {terra::tile_ref_pod_t const r = refs[i]; tm[(size_t)r.yi*nux + r.xi] = (int32_t)i;});
 		terra::grid_job_t job;
-		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*tw; job.ny = nuy*tw; job.nxp = nxpv; job.nyp = nypv;
+		job.mx0 = 0; job.my0 = 0; job.mdx = dxv; job.mdy = dyv; job.nx = nux*tw; job.ny = nuy*(band ? band->twy : tw); job.nxp = nxpv; job.nyp = nypv;
 		job.mode = terra::MGEN_SINE; job.shape = shp; job.kstart = kstart; job.glaciate = glaciate ? 1 : 0; job.use_sine_mag = use_sm ? 1 : 0; job.sine_offset = so;
 		unsigned const ntx = job.nxp/terra::SG_BX, nty = (job.ny + terra::SG_BY - 1)/terra::SG_BY, nb = ntx*nty, grid = ((nb + 7)/8)*8;
-		terra::sg_tiles_t const tl{tm, d_m0, nux, sg_rowgroup, tw};
+		terra::sg_tiles_t tl{tm, d_m0, nux, sg_rowgroup, tw, tw, tw, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0};
+		if (band) {tl.twy = band->twy; tl.ostride = band->ostride; tl.xsplit = band->xsplit; tl.xgap = band->xgap; tl.ysplit = band->ysplit; tl.ygap = band->ygap; fused = 0;}
 		job.plain_only = plain_only ? 1 : 0;
 		if (fused && plain_only) { // "gen.fused": the batch's virtual grid on the matrix pipe, scattered into the per-tile layout
 			terra::sgf_job_t J; memset(&J, 0, sizeof(J));

@@ -70,7 +70,10 @@ __device__ __forceinline__ bool sg_tile_of_block(unsigned b, unsigned ntx, unsig
 	return bx < ntx;
 }
 
-struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup; uint32_t tw;}; // tw: cells per tile edge of the virtual grid (130 zvals, 201 AO context)
+struct sg_tiles_t {int32_t const *tile_map; float const *m0; uint32_t nux; uint32_t rowgroup; uint32_t tw; // tw: cells per tile edge of the virtual grid (130 zvals, 201 AO context)
+	// a BAND of the tiles' fields (round 6: the AO context without the centre nobody reads): tw x twy virtual cells per tile, written into the tile's ostride x ostride field at
+	// (c + (c >= split ? gap : 0)) -- the square case: twy = ostride = tw, splits at 0xFFFFFFFF.  Only the packed epilogue of the plain kernel knows about it (the launcher checks).
+	uint32_t twy, ostride, xsplit, xgap, ysplit, ygap;};
 
 typedef float sg_v2f __attribute__((ext_vector_type(2)));
 // Two rows x eight columns per call: r0[jp] += {x0*y0, x1*y0}, r1[jp] += {x0*y1, x1*y1} with (y0,y1) = one register pair straight from ds_read_b128.
@@ -177,12 +180,12 @@ template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(
 			}
 		}
 		v2f const zme = {nc.zmax_est, nc.zmax_est}, inv = {nc.zmax_est2_inv, nc.zmax_est2_inv}, z2 = {nc.zmax_est2, nc.zmax_est2}, off = {job.sine_offset, job.sine_offset};
-		unsigned const tw = tiles.tw, nuy = job.ny/tw; // (the virtual grid is nux x nuy tiles of tw x tw cells)
+		unsigned const tw = tiles.tw, twy = tiles.twy, os = tiles.ostride, nuy = job.ny/twy; // (the virtual grid is nux x nuy tiles of tw x twy cells)
 		unsigned ux0[2], cx0[2], uy0[2], cy0[2];
 #pragma unroll
 		for (int half = 0; half < 2; ++half) {unsigned const x = bx0 + half*64 + tx*4; ux0[half] = x/tw; cx0[half] = x - ux0[half]*tw;}
 #pragma unroll
-		for (int g = 0; g < 2; ++g) {unsigned const y = by0 + g*64 + ty*4; uy0[g] = y/tw; cy0[g] = y - uy0[g]*tw;}
+		for (int g = 0; g < 2; ++g) {unsigned const y = by0 + g*64 + ty*4; uy0[g] = y/twy; cy0[g] = y - uy0[g]*twy;}
 		// the tiles under the thread's cells: two tile columns per half at most (a group may cross into the next), two tile rows per 4-row group
 		int tmap[2][2][2][2];
 #pragma unroll
@@ -206,7 +209,8 @@ template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(
 			float const syq[4] = {sy[i >> 2].x, sy[i >> 2].y, sy[i >> 2].z, sy[i >> 2].w};
 			v2f const syi = {syq[i & 3], syq[i & 3]};
 			unsigned cy = cy0[i >> 2] + (unsigned)(i & 3); int dy = 0;
-			if (cy >= tw) {cy -= tw; dy = 1;}
+			if (cy >= twy) {cy -= twy; dy = 1;}
+			unsigned const oy = cy + ((cy >= tiles.ysplit) ? tiles.ygap : 0u); // row of the tile's field
 #pragma unroll
 			for (int half = 0; half < 2; ++half) {
 				unsigned const x = bx0 + half*64 + tx*4;
@@ -222,8 +226,9 @@ template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(
 				}
 				unsigned const cx = cx0[half];
 				int const ta = dy ? tmap[i >> 2][1][half][0] : tmap[i >> 2][0][half][0], tb = dy ? tmap[i >> 2][1][half][1] : tmap[i >> 2][0][half][1];
-				if (cx + 3 < tw) { // the whole group in one tile row
-					if (ta >= 0) {*(st_f4u *)(out + (size_t)ta*tw*tw + cy*tw + cx) = st_f4u{z01.x, z01.y, z23.x, z23.y};}
+				if (cx + 3 < tw && (cx + 3 < tiles.xsplit || cx >= tiles.xsplit)) { // the whole group in one tile row (and on one side of a band's gap)
+					unsigned const ox = cx + ((cx >= tiles.xsplit) ? tiles.xgap : 0u);
+					if (ta >= 0) {*(st_f4u *)(out + (size_t)ta*os*os + oy*os + ox) = st_f4u{z01.x, z01.y, z23.x, z23.y};}
 				}
 				else {
 					float const v[4] = {z01.x, z01.y, z23.x, z23.y};
@@ -231,7 +236,8 @@ template<bool TILES, bool GENERAL, int KC = SG_KC> __global__ __launch_bounds__(
 					for (int j = 0; j < 4; ++j) {
 						bool const next = cx + (unsigned)j >= tw;
 						int const t = next ? tb : ta;
-						if (t >= 0) {out[(size_t)t*tw*tw + cy*tw + (next ? cx + (unsigned)j - tw : cx + (unsigned)j)] = v[j];}
+						unsigned const cxx = next ? cx + (unsigned)j - tw : cx + (unsigned)j, ox = cxx + ((cxx >= tiles.xsplit) ? tiles.xgap : 0u);
+						if (t >= 0) {out[(size_t)t*os*os + oy*os + ox] = v[j];}
 					}
 				}
 			}

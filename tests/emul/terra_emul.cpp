@@ -90,8 +90,9 @@ struct cpu_backend_t : terra::simple_paths<cpu_backend_t> {
 
 	bool sine_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *xt, float const *yt, float const *smx, float const *smy, float *out, uint32_t *) {sine_grid_simple(job, nc, L, xt, yt, smx, smy, out); return false;}
 	bool noise_grid(terra::grid_job_t const &job, terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float const *smx, float const *smy, float *out, uint32_t *, uint32_t const *) {noise_grid_simple(job, nc, L, smx, smy, out); return false;}
+	bool tile_band_ok(uint32_t, uint32_t, uint32_t, uint32_t, bool, bool, int) const {return false;} // (the per-cell path evaluates whole squares)
 	void tile_grid(uint32_t n, terra::tile_ref_pod_t const *refs, uint32_t nux, uint32_t nuy, float const *xt, float const *yt, uint32_t nxpv, uint32_t nypv, float const *d_sm, float const *d_m0, int md, int shp, int kstart, bool use_sm, float so,
-		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool /*plain_only*/, uint32_t tw, bool /*unique_tiles*/, bool glaciate = true, uint32_t const * = nullptr, int fused = 0, float = 0.0f) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate, fused);}
+		terra::noise_consts_t const &nc, terra::sin_lut_t const &L, float dxv, float dyv, float *zvals, bool /*plain_only*/, uint32_t tw, bool /*unique_tiles*/, bool glaciate = true, uint32_t const * = nullptr, int fused = 0, float = 0.0f, terra::tile_band_t const * = nullptr) {tile_grid_simple(n, refs, nux, nuy, xt, yt, nxpv, nypv, d_sm, d_m0, md, shp, kstart, use_sm, so, nc, L, dxv, dyv, zvals, tw, glaciate, fused);}
 	void tile_post(uint32_t n, terra::tile_ref_pod_t const *refs, float const *z, terra_tile_stats *st, uint8_t *nm, float *mnz, float wpz, float rad_c, float dxv, float dyv, float dxy) {tile_post_simple(n, refs, z, st, nm, mnz, wpz, rad_c, dxv, dyv, dxy);}
 	void tile_erosion(uint32_t n, float *zvals, terra::erosion_consts_t const &ec, uint32_t iters) {
 		// tiles cycle through the three implementations: wave-cooperative whole-tile-in-LDS (k_tile_erosion's body; lanes run sequentially here), scalar, wave + window

@@ -402,7 +402,7 @@ def test_multi_contexts_in_one_process(pkg, orc, ndev, big):
 
 
 @pytest.mark.parametrize("env", [{"TERRA_GRAPHS": "0"}, {"TERRA_ERO_CK": "1:16", "TERRA_ERO_NEAR": "4"}, {"TERRA_ERO_CK": "40:0", "TERRA_ERO_LEAD": "0"}, {"TERRA_ERO_BATCH": "1", "TERRA_ERO_LEAD": "1"},
-                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_SPARSE": "1", "TERRA_ERO_SPARSE_RETRACES": "12"}, {"TERRA_ERO_FUSE": "0"}, {"TERRA_ERO_FUSE": "7"}, {"TERRA_VOXELS_COLS": "0"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}, {"TERRA_SG_KC_TILES": "45"}])
+                                 {"TERRA_TILE_EROSION": "window"}, {"TERRA_SIMPLE_KERNELS": "1"}, {"TERRA_SG_ROWGROUP": "2"}, {"TERRA_ERO_SPARSE": "1", "TERRA_ERO_SPARSE_RETRACES": "12"}, {"TERRA_ERO_FUSE": "0"}, {"TERRA_ERO_FUSE": "7"}, {"TERRA_VOXELS_COLS": "0"}, {"TERRA_AO_BANDS": "0"}, {"TERRA_ERO_MEM_BUDGET": "200000000"}, {"TERRA_SG_KC": "45"}, {"TERRA_SG_KC": "20"}, {"TERRA_SG_KC_TILES": "45"}])
 def test_experiment_knobs_never_change_a_result(pkg, orc, monkeypatch, env):
     """the environment knobs of DESIGN.md section 5 choose schedules, launch forms and cross-check kernels, never values: a whole-map erosion with re-traces, an eroded tile
     batch and its mesh shadows under each of them, bit for bit against the oracle (the knobs are read when a context is created)"""
