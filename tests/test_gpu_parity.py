@@ -153,6 +153,25 @@ def test_tile_golden(pkg, gpu):
     pc.case_tile_golden(pkg, gpu)
 
 
+@pytest.mark.parametrize("bands,eroded", [("1", 0), ("0", 0), ("1", 60)])
+def test_tile_ao_context_as_bands_and_as_squares(pkg, gpu, orc, bands, eroded):
+    """calc_mesh_ao_lighting over a dense 8 x 4 batch (a tile-column count the band form accepts): the AO context evaluated as four bands around each tile ("ao.bands" 1: its
+    centre is the tile's own, here also eroded, heights) and as whole squares -- the oracle's bytes either way"""
+    pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
+    gpu.init_scene(pc_); orc.init(oc)
+    tiles = [(tx, ty) for ty in range(-2, 2) for tx in range(3, 11)]
+    gpu.set_option("ao.bands", bands)
+    try:
+        z, _, _, _ = gpu.tiles_create_zvals(tiles, eroded)
+        ao = gpu.tiles_ao_lighting(tiles, z)
+    finally:
+        gpu.set_option("ao.bands", "1")
+    for i, (tx, ty) in enumerate(tiles):
+        zo, _ = orc.tile_create_zvals(tx, ty, eroded)
+        assert_bit_equal(z[i], zo, f"zvals {tx},{ty}")
+        assert (ao[i] == orc.tile_ao_lighting(tx, ty, zo)).all(), (bands, eroded, tx, ty)
+
+
 @pytest.mark.parametrize("seed", [5, 6, 7])
 def test_voxels_random_shapes(pkg, gpu, orc, seed):
     """k_voxel_sines_cols / k_voxel_sines / k_voxel_noise on random shapes, positions, generators and slabs"""
