@@ -231,6 +231,10 @@ def load_library(path=None):
     path = path or default_lib_path()
     if not os.path.exists(path):
         raise TerraError(-4, f"{path} not found: build it with __graft_entry__.build() (hipcc, gfx950). There is no CPU fall-back.")
+    if os.path.abspath(path) == os.path.join(HERE, "libterra_hip.so"):  # the shipped library must be the tree's sources (a .so left by an experiment computes something else)
+        from . import build as _build
+        if _build.needs_build():
+            raise TerraError(-4, f"{path} was not built from the sources in 3dworld_amd/csrc: run __graft_entry__.build()")
     lib = C.CDLL(path)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # raises AttributeError if the ABI is incomplete

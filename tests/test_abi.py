@@ -78,3 +78,14 @@ def test_header_is_plain_c99(tmp_path):
                    'typedef char a5[(sizeof(terra_tile_stats) == 156) ? 1 : -1];\n'
                    'int main(void) {terra_ctx *c = 0; (void)c; return 0;}\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], check=True)
+
+
+def test_loader_refuses_a_library_built_from_other_sources(tmp_path, monkeypatch):
+    """a libterra_hip.so left in the tree by an experiment computes something else: the binding refuses it instead of running it (the hash file names the sources it was built from)"""
+    import importlib
+    terra = importlib.import_module("3dworld_amd.terra")
+    bmod = importlib.import_module("3dworld_amd.build")
+    terra.load_library()  # the tree as it is: fresh
+    monkeypatch.setattr(bmod, "source_hash", lambda: "0" * 64)
+    with pytest.raises(terra.TerraError, match="not built from the sources"):
+        terra.load_library()
