@@ -280,6 +280,7 @@ struct options_t {
 	long long ero_mem_budget = -1; // "ero.mem_budget" bytes: pretend this much device memory is free when the ring has to grow (tests)
 	int simple_kernels = 0;       // "kernels.simple" 0 / 1: the one-thread-per-cell cross-check kernels instead of the tiled ones
 	int ao_bands = 1;             // "ao.bands" 0 / 1: the AO context of a tile batch as four bands around each tile (the centre comes from the tile's own heights anyway) where the backend can (results never depend on it)
+	int ao_whole = 1;             // "ao.whole" 0 / 1: the AO rays of a tile from ONE workgroup holding the tile's whole 201 x 201 context in LDS (k_tile_ao_tile); 0: four 33-row bands per tile, each staging its context rows twice (k_tile_ao) (results never depend on it)
 	int voxels_cols = 1;          // "voxels.cols" 0 / 1: the lane-per-column voxel sine kernel (no P array) wherever the depth is a multiple of 4; 0: the z-lane kernel over the P stream everywhere (results never depend on it)
 	int graphs = 1;               // "graphs" 0 / 1: replay the erosion rounds as hipGraphs
 	int sg_kc = 27, sg_kc_tiles = 27; // "sg.kc" 20 / 27 / 45, "sg.kc_tiles" 27 / 45: terms per LDS chunk of k_sine_grid (heightmap / tile batch)
@@ -309,6 +310,7 @@ struct options_t {
 		if (k == "kernels.simple") return flag(simple_kernels);
 		if (k == "voxels.cols") return flag(voxels_cols);
 		if (k == "ao.bands") return flag(ao_bands);
+		if (k == "ao.whole") return flag(ao_whole);
 		if (k == "graphs") return flag(graphs);
 		if (k == "sg.kc") {if (!is_int || (n != 20 && n != 27 && n != 45)) return false; sg_kc = (int)n; return true;}
 		if (k == "sg.kc_tiles") {if (!is_int || (n != 27 && n != 45)) return false; sg_kc_tiles = (int)n; return true;}

@@ -40,6 +40,10 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_shadows_flow, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
 		TERRA_HIP_CHECK(hipFuncSetAttribute((void const *)terra::k_tile_ao<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64*1024));
+		// the whole context of a tile in one workgroup's LDS (162 408 of the CU's 163 840 bytes); a runtime that refuses the size leaves the band kernel in charge
+		ao_tile_ok = hipFuncSetAttribute((void const *)terra::k_tile_ao_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)terra::AOT_LDS) == hipSuccess
+			&& hipFuncSetAttribute((void const *)terra::k_tile_ao_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)terra::AOT_LDS) == hipSuccess;
+		if (!ao_tile_ok) {(void)hipGetLastError();}
 	}
 	void options_changed() { // (the engine has drained the stream)
 		if (!opt) return;
@@ -395,9 +399,16 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
+	bool ao_tile_ok = false;
 	void tile_ao(uint32_t n, float const *z, float const *ctx, uint8_t *ao, float dz, bool own) {
 		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz, own); return;}
 		use();
+		if (ao_tile_ok && (!opt || opt->ao_whole)) { // one workgroup per tile, the context staged once
+			if (own) {hipLaunchKernelGGL(terra::k_tile_ao_tile<true>, dim3(n), dim3(terra::AOT_THREADS), terra::AOT_LDS, stream, z, ctx, ao, dz);}
+			else {hipLaunchKernelGGL(terra::k_tile_ao_tile<false>, dim3(n), dim3(terra::AOT_THREADS), terra::AOT_LDS, stream, z, ctx, ao, dz);}
+			TERRA_HIP_CHECK(hipGetLastError());
+			return;
+		}
 		unsigned const nbands = (terra::AO_TEX + terra::AO_BAND - 1)/terra::AO_BAND;
 		size_t const lds = (size_t)(terra::AO_BAND + terra::AO_RL)*terra::AO_CS*sizeof(float);
 		if (own) {hipLaunchKernelGGL(terra::k_tile_ao<true>, dim3(n*nbands), dim3(terra::AO_THREADS), lds, stream, z, ctx, ao, dz);}

@@ -703,6 +703,104 @@ template<bool OWN> __global__ __launch_bounds__(AO_THREADS) __attribute__((amdgp
 	if (w == 3 && lane < rows) {out[(size_t)(y0 + lane)*AO_TEX + 128] = ao_byte(attC);}
 }
 
+// ---- the whole tile's context in LDS (k_tile_ao_tile): one block of 16 waves per tile, the 201 x 201 context staged ONCE -- 201 rows x 202 floats = 162 408 of the CU's
+// 163 840 bytes -- instead of 68 rows twice per 33-row band (2.7 x 201 rows per tile, and the staging of a band was as long as its rays).  A lane owns the texel PAIR
+// (2 lane, 2 lane + 1) of a row, a wave a row: the two texels' samples of a ray step are neighbours in LDS, one 8-byte read (256 B per clock against the 4-byte read's 128)
+// where the step's x offset is even; where it is odd the pair straddles two aligned 8-byte words and takes both (the 4-byte reads of a lane pair would be 2-way bank
+// conflicts at a stride of two dwords).  Per texel pair 40 + 2 x 24 eight-byte reads = 176 LDS cycles instead of 256, four waves per SIMD instead of two to hide them;
+// the compares (2 instructions per sample) are what is left.  Column 128 is a lane per row.  Same integer sums as k_tile_ao / tile_ao_simple.
+constexpr unsigned AOT_THREADS = 1024, AOT_S = 202, AOT_LDS = AO_CS*AOT_S*4;
+typedef float ao_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float ao_lds_f;   // (the volatile reads below must know they are LDS reads: a generic volatile pointer becomes a flat load)
+typedef __attribute__((address_space(3))) ao_f2 ao_lds_f2;
+// the 16 samples of one ray of a texel pair (sb: the sample 36 steps up and left of the pair's first texel -- an even dword: every offset below is non-negative and known
+// at compile time).  volatile LDS reads: each stays ONE ds_read_b64 -- the compiler otherwise pairs them into ds_read2_b64, half the rate per byte, and narrows the odd case
+// to 4-byte reads -- and they keep their place between the `pins` of the caller, which is how the next ray's reads get in flight before this ray's compares
+template<int DX, int DY> __device__ __forceinline__ void ao_pair_load(ao_lds_f const *sb, float (&a)[8], float (&b)[8]) {
+#pragma unroll
+	for (int s = 0; s < 8; ++s) {
+		int const T = (s + 1)*(s + 2)/2, off = ((int)AO_RL + T*DY)*(int)AOT_S + (int)AO_RL + T*DX;
+		if ((off & 1) == 0) {ao_f2 const v = *(ao_lds_f2 const volatile *)(sb + off); a[s] = v.x; b[s] = v.y;}
+		else {ao_f2 const u = *(ao_lds_f2 const volatile *)(sb + off - 1), v = *(ao_lds_f2 const volatile *)(sb + off + 1); a[s] = u.y; b[s] = v.x;}
+	}
+}
+__device__ __forceinline__ void ao_pair_hits(float const (&a)[8], float const (&b)[8], float const (&zr0)[8], float const (&zr1)[8], unsigned &att0, unsigned &att1) {
+	unsigned r0 = 0, r1 = 0;
+#pragma unroll
+	for (int s = 7; s >= 0; --s) {r0 = (a[s] > zr0[s]) ? (unsigned)(8 - s) : r0; r1 = (b[s] > zr1[s]) ? (unsigned)(8 - s) : r1;}
+	att0 += r0; att1 += r1;
+	asm volatile("" : "+v"(att0), "+v"(att1)); // the pin: this ray's sums exist before the reads of the ray after next are issued (all eight rays' reads up front spill at 128 registers)
+}
+template<int DX, int DY> __device__ __forceinline__ unsigned ao_march_one(float const *sb, float const (&zr)[8]) { // one texel, context rows AOT_S apart
+	float smp[8];
+#pragma unroll
+	for (int s = 0; s < 8; ++s) {int const T = (s + 1)*(s + 2)/2; smp[s] = sb[((int)AO_RL + T*DY)*(int)AOT_S + (int)AO_RL + T*DX];}
+	unsigned att = 0;
+#pragma unroll
+	for (int s = 7; s >= 0; --s) {att = (smp[s] > zr[s]) ? (unsigned)(8 - s) : att;}
+	return att;
+}
+template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
+	extern __shared__ __attribute__((aligned(16))) float s_aot[];
+	unsigned const t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	unsigned const w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	float const *c = ctx + (size_t)t*AO_CS*AO_CS, *z = zvals + (size_t)t*130*130;
+	uint8_t *out = ao + (size_t)t*AO_TEX*AO_TEX;
+	{ // staging: thread = context column, four rows per trip of the block; 51 rows per thread in three batches of 17 loads, each batch in flight before its LDS stores
+		unsigned const col = tid & 255u, rq = tid >> 8;
+		bool const col_ok = col < AO_CS, col_own = OWN && (col - AO_RL) < 130u;
+#pragma unroll
+		for (unsigned bt = 0; bt < 3; ++bt) {
+			float stg[17];
+#pragma unroll
+			for (unsigned k = 0; k < 17; ++k) {
+				unsigned const r = rq + 4u*(bt*17u + k);
+				bool const ok = col_ok && r < AO_CS;
+				float const *p = c + (size_t)(ok ? r : 0u)*AO_CS + (col_ok ? col : 0u);
+				if (OWN) {bool const in = ok && col_own && (r - AO_RL) < 130u; p = in ? z + (size_t)(r - AO_RL)*130 + (col - AO_RL) : p;}
+				stg[k] = *p;
+			}
+#pragma unroll
+			for (unsigned k = 0; k < 17; ++k) {unsigned const r = rq + 4u*(bt*17u + k); if (col_ok && r < AO_CS) {s_aot[r*AOT_S + col] = stg[k];}}
+		}
+	}
+	__syncthreads();
+	for (unsigned y = w; y < AO_TEX; y += AOT_THREADS/64) { // a row of 64 texel pairs
+		unsigned const x0 = 2u*lane;
+		float z0 = z[(size_t)y*130 + x0], z1 = z[(size_t)y*130 + x0 + 1];
+		float zr0[8], zr1[8];
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {z0 += dz; z1 += dz; zr0[s] = z0; zr1[s] = z1;} // every ray rises by dz per step: sequential float adds, as in the reference
+		ao_lds_f const *sb = (ao_lds_f const *)s_aot + y*AOT_S + x0;
+		unsigned a0 = 0, a1 = 0;
+		float pa[8], pb[8], qa[8], qb[8]; // two rays in flight
+		ao_pair_load<-1, -1>(sb, pa, pb);
+		ao_pair_load< 0, -1>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 1, -1>(sb, pa, pb); ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
+		ao_pair_load<-1,  0>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 1,  0>(sb, pa, pb); ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
+		ao_pair_load<-1,  1>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 0,  1>(sb, pa, pb); ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
+		ao_pair_load< 1,  1>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
+		uint8_t *o = out + (size_t)y*AO_TEX + x0;
+		o[0] = ao_byte(a0); o[1] = ao_byte(a1);
+	}
+	if (w >= 1 && w <= 3) { // column 128: a lane per row, on the waves that had a row less than wave 0
+		unsigned const y = (w - 1)*64u + lane;
+		if (y < AO_TEX) {
+			float z0 = z[(size_t)y*130 + 128];
+			float zr[8];
+#pragma unroll
+			for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;}
+			float const *sb = s_aot + y*AOT_S + 128;
+			unsigned const att = ao_march_one<-1, -1>(sb, zr) + ao_march_one<0, -1>(sb, zr) + ao_march_one<1, -1>(sb, zr) + ao_march_one<-1, 0>(sb, zr) + ao_march_one<1, 0>(sb, zr)
+				+ ao_march_one<-1, 1>(sb, zr) + ao_march_one<0, 1>(sb, zr) + ao_march_one<1, 1>(sb, zr);
+			out[(size_t)y*AO_TEX + 128] = ao_byte(att);
+		}
+	}
+}
+
 // ------------------------------------------------------------------ row f2: mesh shadows, one launch per dependency level
 // An outgoing edge height travels between tiles as (dependency order << 32 | float bits) under a 64-bit max; 0 = nothing arrived (MESH_MIN_Z).
 constexpr unsigned long long SHADOW_EDGE_PUB = 1ull << 63; // (k_tile_shadows_flow) this word of a finished tile's edge array has been published

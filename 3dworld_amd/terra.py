@@ -306,7 +306,7 @@ class PinnedArray:
 ENV_OPTIONS = {
     "TERRA_GEN_FUSED": ("gen.fused", "0"), "TERRA_SIMPLE_KERNELS": ("kernels.simple", "0"), "TERRA_GRAPHS": ("graphs", "1"),
     "TERRA_SG_KC": ("sg.kc", "27"), "TERRA_SG_KC_TILES": ("sg.kc_tiles", "27"), "TERRA_SG_ROWGROUP": ("sg.rowgroup", "4"), "TERRA_TILE_EROSION": ("tile_erosion", "lds"),
-    "TERRA_WEIGHTS_SIMPLE": ("weights.simple", "0"), "TERRA_VOXELS_COLS": ("voxels.cols", "1"), "TERRA_AO_BANDS": ("ao.bands", "1"), "TERRA_SHADOWS_LEVELS": ("shadows.levels", "0"),
+    "TERRA_WEIGHTS_SIMPLE": ("weights.simple", "0"), "TERRA_VOXELS_COLS": ("voxels.cols", "1"), "TERRA_AO_BANDS": ("ao.bands", "1"), "TERRA_AO_WHOLE": ("ao.whole", "1"), "TERRA_SHADOWS_LEVELS": ("shadows.levels", "0"),
     "TERRA_ERO_SPARSE": ("ero.sparse", "auto"), "TERRA_ERO_SPARSE_RETRACES": ("ero.sparse_retraces", "-1"), "TERRA_ERO_LEAD": ("ero.lead", "2"), "TERRA_ERO_BATCH": ("ero.batch", "0"), "TERRA_ERO_FUSE": ("ero.fuse", "3"),
     "TERRA_ERO_LIVE": ("ero.live", "1"), "TERRA_ERO_DIAG": ("ero.diag", "0"), "TERRA_ERO_CK": ("ero.ck", "default"), "TERRA_ERO_NEAR": ("ero.near", "default"),
     "TERRA_ERO_MEM_BUDGET": ("ero.mem_budget", "-1"),

@@ -162,6 +162,7 @@ int  terra_synchronize(terra_ctx *ctx);
  *   "tile_erosion"         "lds" | "window"   the whole padded tile in LDS (default) or a 32 x 32 window over a copy in HBM
  *   "weights.simple"       "0" | "1"      per-texel form of the weights-texture pass;   "shadows.levels" "0" | "1"   one launch per dependency level of the mesh shadows
  *   "ao.bands"             "1" | "0"      the AO context of a tile batch evaluated as four bands around each tile (its centre is the tile's own heights) / as whole squares
+ *   "ao.whole"             "1" | "0"      the AO rays of a tile from one workgroup that holds the tile's whole 201 x 201 context in LDS / from four 33-row band workgroups
  *   "voxels.cols"          "1" | "0"      the lane-per-column form of the voxel sine field (no array of x*y products) wherever the depth is a multiple of 4 / the z-lane form everywhere
  *   "ero.sparse"           "0" | "1" | "auto"   never / always / by droplet density try the sparse erosion scheduler;   "ero.sparse_retraces" n
  *   "ero.lead" "0".."2", "ero.batch" n, "ero.fuse" 0..7, "ero.live" "0"|"1", "ero.diag" "0"|"1", "ero.ck" "steps:max"|"default", "ero.near" n|"default", "ero.mem_budget" bytes|"-1"

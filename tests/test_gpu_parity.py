@@ -153,19 +153,20 @@ def test_tile_golden(pkg, gpu):
     pc.case_tile_golden(pkg, gpu)
 
 
-@pytest.mark.parametrize("bands,eroded", [("1", 0), ("0", 0), ("1", 60)])
-def test_tile_ao_context_as_bands_and_as_squares(pkg, gpu, orc, bands, eroded):
+@pytest.mark.parametrize("bands,eroded,whole", [("1", 0, "1"), ("0", 0, "1"), ("1", 60, "1"), ("1", 0, "0"), ("0", 60, "0")])
+def test_tile_ao_context_as_bands_and_as_squares(pkg, gpu, orc, bands, eroded, whole):
     """calc_mesh_ao_lighting over a dense 8 x 4 batch (a tile-column count the band form accepts): the AO context evaluated as four bands around each tile ("ao.bands" 1: its
-    centre is the tile's own, here also eroded, heights) and as whole squares -- the oracle's bytes either way"""
+    centre is the tile's own, here also eroded, heights) and as whole squares; the rays from one workgroup per tile with the whole context in LDS ("ao.whole" 1,
+    k_tile_ao_tile) and from four band workgroups (k_tile_ao) -- the oracle's bytes every way"""
     pc_, oc = pc.cfg_pair(pkg, mesh_gen_mode=0)
     gpu.init_scene(pc_); orc.init(oc)
     tiles = [(tx, ty) for ty in range(-2, 2) for tx in range(3, 11)]
-    gpu.set_option("ao.bands", bands)
+    gpu.set_option("ao.bands", bands); gpu.set_option("ao.whole", whole)
     try:
         z, _, _, _ = gpu.tiles_create_zvals(tiles, eroded)
         ao = gpu.tiles_ao_lighting(tiles, z)
     finally:
-        gpu.set_option("ao.bands", "1")
+        gpu.set_option("ao.bands", "1"); gpu.set_option("ao.whole", "1")
     for i, (tx, ty) in enumerate(tiles):
         zo, _ = orc.tile_create_zvals(tx, ty, eroded)
         assert_bit_equal(z[i], zo, f"zvals {tx},{ty}")
