@@ -404,8 +404,9 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		if (simple_kernels) {tile_ao_simple(n, z, ctx, ao, dz, own); return;}
 		use();
 		if (ao_tile_ok && (!opt || opt->ao_whole)) { // one workgroup per tile, the context staged once
-			if (own) {hipLaunchKernelGGL(terra::k_tile_ao_tile<true>, dim3(n), dim3(terra::AOT_THREADS), terra::AOT_LDS, stream, z, ctx, ao, dz);}
-			else {hipLaunchKernelGGL(terra::k_tile_ao_tile<false>, dim3(n), dim3(terra::AOT_THREADS), terra::AOT_LDS, stream, z, ctx, ao, dz);}
+			unsigned const grid = std::min<unsigned>(n, (unsigned)num_cus); // persistent: a CU holds one of these workgroups
+			if (own) {hipLaunchKernelGGL(terra::k_tile_ao_tile<true>, dim3(grid), dim3(terra::AOT_THREADS), terra::AOT_LDS, stream, z, ctx, ao, dz, n);}
+			else {hipLaunchKernelGGL(terra::k_tile_ao_tile<false>, dim3(grid), dim3(terra::AOT_THREADS), terra::AOT_LDS, stream, z, ctx, ao, dz, n);}
 			TERRA_HIP_CHECK(hipGetLastError());
 			return;
 		}

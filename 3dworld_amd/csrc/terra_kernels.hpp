@@ -740,56 +740,68 @@ template<int DX, int DY> __device__ __forceinline__ unsigned ao_march_one(float 
 	for (int s = 7; s >= 0; --s) {att = (smp[s] > zr[s]) ? (unsigned)(8 - s) : att;}
 	return att;
 }
-template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz) {
-	extern __shared__ __attribute__((aligned(16))) float s_aot[];
-	unsigned const t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
-	unsigned const w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+// Staging: thread = context column, the block's four 256-thread quarters take every fourth row: 51 values per thread.  They are LOADED into registers while the tile before is
+// still being computed (the block is persistent: tiles blockIdx.x, + gridDim.x, ...) and stored to LDS when its rays are done: a CU holds one workgroup (the LDS is full), so
+// nobody else would hide the loads.  Which source a cell has (OWN: the tile's own heights inside the tile) is a scalar test per row and a per-thread base + stride.
+constexpr unsigned AOT_STG = 51;
+template<bool OWN> __device__ __forceinline__ void aot_stage_load(float const *__restrict__ zvals, float const *__restrict__ ctx, unsigned t, unsigned col, unsigned rq, float (&stg)[AOT_STG]) {
 	float const *c = ctx + (size_t)t*AO_CS*AO_CS, *z = zvals + (size_t)t*130*130;
-	uint8_t *out = ao + (size_t)t*AO_TEX*AO_TEX;
-	{ // staging: thread = context column, four rows per trip of the block; 51 rows per thread in three batches of 17 loads, each batch in flight before its LDS stores
-		unsigned const col = tid & 255u, rq = tid >> 8;
-		bool const col_ok = col < AO_CS, col_own = OWN && (col - AO_RL) < 130u;
+	bool const col_ok = col < AO_CS, col_own = OWN && (col - AO_RL) < 130u;
+	float const *base_out = c + (col_ok ? col : 0u);
+	float const *base_in = col_own ? z + (col - AO_RL) - (size_t)AO_RL*130 : base_out; // centre rows: r*130 from here is row r - 36 of the tile
+	unsigned const stride_in = col_own ? 130u : AO_CS;
 #pragma unroll
-		for (unsigned bt = 0; bt < 3; ++bt) {
-			float stg[17];
-#pragma unroll
-			for (unsigned k = 0; k < 17; ++k) {
-				unsigned const r = rq + 4u*(bt*17u + k);
-				bool const ok = col_ok && r < AO_CS;
-				float const *p = c + (size_t)(ok ? r : 0u)*AO_CS + (col_ok ? col : 0u);
-				if (OWN) {bool const in = ok && col_own && (r - AO_RL) < 130u; p = in ? z + (size_t)(r - AO_RL)*130 + (col - AO_RL) : p;}
-				stg[k] = *p;
-			}
-#pragma unroll
-			for (unsigned k = 0; k < 17; ++k) {unsigned const r = rq + 4u*(bt*17u + k); if (col_ok && r < AO_CS) {s_aot[r*AOT_S + col] = stg[k];}}
-		}
+	for (unsigned k = 0; k < AOT_STG; ++k) {
+		unsigned const r = rq + 4u*k, rr = (r < AO_CS) ? r : 0u; // (scalar: rq is wave-uniform)
+		float const *p = (OWN && (rr - AO_RL) < 130u) ? base_in + rr*stride_in : base_out + rr*AO_CS;
+		stg[k] = *p;
 	}
+}
+__device__ __forceinline__ void aot_stage_store(float *s, unsigned col, unsigned rq, float const (&stg)[AOT_STG]) {
+	if (col >= AO_CS) return;
+#pragma unroll
+	for (unsigned k = 0; k < AOT_STG; ++k) {unsigned const r = rq + 4u*k; if (r < AO_CS) {s[r*AOT_S + col] = stg[k];}}
+}
+template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz, unsigned n) {
+	extern __shared__ __attribute__((aligned(16))) float s_aot[];
+	unsigned const tid = threadIdx.x, lane = tid & 63u, col = tid & 255u;
+	unsigned const w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), rq = w >> 2;
+	float stg[AOT_STG];
+	if (blockIdx.x < n) {aot_stage_load<OWN>(zvals, ctx, blockIdx.x, col, rq, stg);}
+	for (unsigned t = blockIdx.x; t < n; t += gridDim.x) {
+	float const *z = zvals + (size_t)t*130*130;
+	uint8_t *out = ao + (size_t)t*AO_TEX*AO_TEX;
+	aot_stage_store(s_aot, col, rq, stg);
 	__syncthreads();
+	// in flight behind this tile's rays -- which then must not wait for a global load of their own (a wave's loads return in order): with OWN the texels' heights are the
+	// centre of the staged context; without, they are the caller's zvals (not the context's centre) and the next tile is loaded after the rays instead
+	if (OWN && t + gridDim.x < n) {aot_stage_load<OWN>(zvals, ctx, t + gridDim.x, col, rq, stg);}
 	for (unsigned y = w; y < AO_TEX; y += AOT_THREADS/64) { // a row of 64 texel pairs
 		unsigned const x0 = 2u*lane;
-		float z0 = z[(size_t)y*130 + x0], z1 = z[(size_t)y*130 + x0 + 1];
+		float z0, z1;
+		if (OWN) {ao_f2 const v = *(ao_f2 const *)(s_aot + (y + AO_RL)*AOT_S + AO_RL + x0); z0 = v.x; z1 = v.y;}
+		else {z0 = z[(size_t)y*130 + x0]; z1 = z[(size_t)y*130 + x0 + 1];}
 		float zr0[8], zr1[8];
 #pragma unroll
 		for (int s = 0; s < 8; ++s) {z0 += dz; z1 += dz; zr0[s] = z0; zr1[s] = z1;} // every ray rises by dz per step: sequential float adds, as in the reference
 		ao_lds_f const *sb = (ao_lds_f const *)s_aot + y*AOT_S + x0;
 		unsigned a0 = 0, a1 = 0;
-		float pa[8], pb[8], qa[8], qb[8]; // two rays in flight
-		ao_pair_load<-1, -1>(sb, pa, pb);
-		ao_pair_load< 0, -1>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 1, -1>(sb, pa, pb); ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
-		ao_pair_load<-1,  0>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 1,  0>(sb, pa, pb); ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
-		ao_pair_load<-1,  1>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 0,  1>(sb, pa, pb); ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
-		ao_pair_load< 1,  1>(sb, qa, qb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_hits(qa, qb, zr0, zr1, a0, a1);
+		float pa[8], pb[8]; // one ray in flight (two were measured at the same speed without the register prefetch of the next tile, which needs their registers)
+		ao_pair_load<-1, -1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 0, -1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 1, -1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load<-1,  0>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 1,  0>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load<-1,  1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 0,  1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		ao_pair_load< 1,  1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
 		uint8_t *o = out + (size_t)y*AO_TEX + x0;
 		o[0] = ao_byte(a0); o[1] = ao_byte(a1);
 	}
 	if (w >= 1 && w <= 3) { // column 128: a lane per row, on the waves that had a row less than wave 0
 		unsigned const y = (w - 1)*64u + lane;
 		if (y < AO_TEX) {
-			float z0 = z[(size_t)y*130 + 128];
+			float z0 = OWN ? s_aot[(y + AO_RL)*AOT_S + AO_RL + 128] : z[(size_t)y*130 + 128];
 			float zr[8];
 #pragma unroll
 			for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;}
@@ -798,6 +810,9 @@ template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile
 				+ ao_march_one<-1, 1>(sb, zr) + ao_march_one<0, 1>(sb, zr) + ao_march_one<1, 1>(sb, zr);
 			out[(size_t)y*AO_TEX + 128] = ao_byte(att);
 		}
+	}
+	if (!OWN && t + gridDim.x < n) {aot_stage_load<OWN>(zvals, ctx, t + gridDim.x, col, rq, stg);}
+	__syncthreads(); // (the next tile's staging overwrites the context)
 	}
 }
 
