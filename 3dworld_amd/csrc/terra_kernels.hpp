@@ -713,23 +713,23 @@ constexpr unsigned AOT_THREADS = 1024, AOT_S = 202, AOT_LDS = AO_CS*AOT_S*4;
 typedef float ao_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float ao_lds_f;   // (the volatile reads below must know they are LDS reads: a generic volatile pointer becomes a flat load)
 typedef __attribute__((address_space(3))) ao_f2 ao_lds_f2;
-// the 16 samples of one ray of a texel pair (sb: the sample 36 steps up and left of the pair's first texel -- an even dword: every offset below is non-negative and known
-// at compile time).  volatile LDS reads: each stays ONE ds_read_b64 -- the compiler otherwise pairs them into ds_read2_b64, half the rate per byte, and narrows the odd case
-// to 4-byte reads -- and they keep their place between the `pins` of the caller, which is how the next ray's reads get in flight before this ray's compares
-template<int DX, int DY> __device__ __forceinline__ void ao_pair_load(ao_lds_f const *sb, float (&a)[8], float (&b)[8]) {
+// Half a ray of a texel pair (steps 4 H .. 4 H + 3): the unit the row loop keeps two of in flight.  sb: the sample 36 steps up and left of the pair's first texel -- an even
+// dword: every offset below is non-negative and known at compile time.  volatile LDS reads: each stays ONE ds_read_b64 -- the compiler otherwise pairs them into ds_read2_b64,
+// half the rate per byte, and narrows the odd case to 4-byte reads -- and they keep their place between the `pins` of ao_pair_hits4 (an empty asm volatile on the ray's sums):
+// all eight rays' reads moved to the front spill at 128 registers.  (One whole ray in flight and two half rays in flight measure the same, 382 / 380 us: with four waves per
+// SIMD the LDS latency is hidden either way.)
+template<int DX, int DY, int H> __device__ __forceinline__ void ao_pair_load4(ao_lds_f const *sb, float (&a)[4], float (&b)[4]) {
 #pragma unroll
-	for (int s = 0; s < 8; ++s) {
-		int const T = (s + 1)*(s + 2)/2, off = ((int)AO_RL + T*DY)*(int)AOT_S + (int)AO_RL + T*DX;
-		if ((off & 1) == 0) {ao_f2 const v = *(ao_lds_f2 const volatile *)(sb + off); a[s] = v.x; b[s] = v.y;}
-		else {ao_f2 const u = *(ao_lds_f2 const volatile *)(sb + off - 1), v = *(ao_lds_f2 const volatile *)(sb + off + 1); a[s] = u.y; b[s] = v.x;}
+	for (int i = 0; i < 4; ++i) {
+		int const s = 4*H + i, T = (s + 1)*(s + 2)/2, off = ((int)AO_RL + T*DY)*(int)AOT_S + (int)AO_RL + T*DX;
+		if ((off & 1) == 0) {ao_f2 const v = *(ao_lds_f2 const volatile *)(sb + off); a[i] = v.x; b[i] = v.y;}
+		else {ao_f2 const u = *(ao_lds_f2 const volatile *)(sb + off - 1), v = *(ao_lds_f2 const volatile *)(sb + off + 1); a[i] = u.y; b[i] = v.x;}
 	}
 }
-__device__ __forceinline__ void ao_pair_hits(float const (&a)[8], float const (&b)[8], float const (&zr0)[8], float const (&zr1)[8], unsigned &att0, unsigned &att1) {
-	unsigned r0 = 0, r1 = 0;
+template<int H> __device__ __forceinline__ void ao_pair_hits4(float const (&a)[4], float const (&b)[4], float const (&zr0)[8], float const (&zr1)[8], unsigned &r0, unsigned &r1) {
 #pragma unroll
-	for (int s = 7; s >= 0; --s) {r0 = (a[s] > zr0[s]) ? (unsigned)(8 - s) : r0; r1 = (b[s] > zr1[s]) ? (unsigned)(8 - s) : r1;}
-	att0 += r0; att1 += r1;
-	asm volatile("" : "+v"(att0), "+v"(att1)); // the pin: this ray's sums exist before the reads of the ray after next are issued (all eight rays' reads up front spill at 128 registers)
+	for (int i = 3; i >= 0; --i) {int const s = 4*H + i; r0 = (a[i] > zr0[s]) ? (unsigned)(8 - s) : r0; r1 = (b[i] > zr1[s]) ? (unsigned)(8 - s) : r1;}
+	asm volatile("" : "+v"(r0), "+v"(r1)); // the pin
 }
 template<int DX, int DY> __device__ __forceinline__ unsigned ao_march_one(float const *sb, float const (&zr)[8]) { // one texel, context rows AOT_S apart
 	float smp[8];
@@ -750,10 +750,15 @@ template<bool OWN> __device__ __forceinline__ void aot_stage_load(float const *_
 	float const *base_out = c + (col_ok ? col : 0u);
 	float const *base_in = col_own ? z + (col - AO_RL) - (size_t)AO_RL*130 : base_out; // centre rows: r*130 from here is row r - 36 of the tile
 	unsigned const stride_in = col_own ? 130u : AO_CS;
+	// rows rq + 4k: for k = 9 .. 40 they lie inside the tile whatever rq is (36 .. 163 + rq), for k = 41 (164 .. 167) it depends on rq, the others never do -- no
+	// per-element choice between two pointers but for that one
 #pragma unroll
 	for (unsigned k = 0; k < AOT_STG; ++k) {
 		unsigned const r = rq + 4u*k, rr = (r < AO_CS) ? r : 0u; // (scalar: rq is wave-uniform)
-		float const *p = (OWN && (rr - AO_RL) < 130u) ? base_in + rr*stride_in : base_out + rr*AO_CS;
+		float const *p;
+		if (OWN && k >= 9 && k <= 40) {p = base_in + __umul24(rr, stride_in);}
+		else if (OWN && k == 41) {p = ((rr - AO_RL) < 130u) ? base_in + __umul24(rr, stride_in) : base_out + rr*AO_CS;}
+		else {p = base_out + rr*AO_CS;}
 		stg[k] = *p;
 	}
 }
@@ -764,6 +769,7 @@ __device__ __forceinline__ void aot_stage_store(float *s, unsigned col, unsigned
 }
 template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile(float const *__restrict__ zvals, float const *__restrict__ ctx, uint8_t *__restrict__ ao, float dz, unsigned n) {
 	extern __shared__ __attribute__((aligned(16))) float s_aot[];
+	__shared__ unsigned s_item;
 	unsigned const tid = threadIdx.x, lane = tid & 63u, col = tid & 255u;
 	unsigned const w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), rq = w >> 2;
 	float stg[AOT_STG];
@@ -772,12 +778,31 @@ template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile
 	float const *z = zvals + (size_t)t*130*130;
 	uint8_t *out = ao + (size_t)t*AO_TEX*AO_TEX;
 	aot_stage_store(s_aot, col, rq, stg);
+	if (tid == 0) {s_item = 0u;}
 	__syncthreads();
 	// in flight behind this tile's rays -- which then must not wait for a global load of their own (a wave's loads return in order): with OWN the texels' heights are the
 	// centre of the staged context; without, they are the caller's zvals (not the context's centre) and the next tile is loaded after the rays instead
 	if (OWN && t + gridDim.x < n) {aot_stage_load<OWN>(zvals, ctx, t + gridDim.x, col, rq, stg);}
-	for (unsigned y = w; y < AO_TEX; y += AOT_THREADS/64) { // a row of 64 texel pairs
-		unsigned const x0 = 2u*lane;
+	for (;;) { // work items of the tile, dealt out by a counter in LDS (a fixed deal leaves one wave with a ninth row while the others wait at the barrier): 129 rows of 64 texel pairs, then column 128 in three pieces
+		unsigned item = 0;
+		if (lane == 0) {item = atomicAdd(&s_item, 1u);}
+		item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+		if (item >= AO_TEX) {
+			if (item >= AO_TEX + 3u) break;
+			unsigned const y = (item - AO_TEX)*64u + lane; // column 128: a lane per row
+			if (y < AO_TEX) {
+				float z0 = OWN ? s_aot[(y + AO_RL)*AOT_S + AO_RL + 128] : z[(size_t)y*130 + 128];
+				float zr[8];
+#pragma unroll
+				for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;}
+				float const *sb = s_aot + y*AOT_S + 128;
+				unsigned const att = ao_march_one<-1, -1>(sb, zr) + ao_march_one<0, -1>(sb, zr) + ao_march_one<1, -1>(sb, zr) + ao_march_one<-1, 0>(sb, zr) + ao_march_one<1, 0>(sb, zr)
+					+ ao_march_one<-1, 1>(sb, zr) + ao_march_one<0, 1>(sb, zr) + ao_march_one<1, 1>(sb, zr);
+				out[(size_t)y*AO_TEX + 128] = ao_byte(att);
+			}
+			continue;
+		}
+		unsigned const y = item, x0 = 2u*lane;
 		float z0, z1;
 		if (OWN) {ao_f2 const v = *(ao_f2 const *)(s_aot + (y + AO_RL)*AOT_S + AO_RL + x0); z0 = v.x; z1 = v.y;}
 		else {z0 = z[(size_t)y*130 + x0]; z1 = z[(size_t)y*130 + x0 + 1];}
@@ -786,30 +811,22 @@ template<bool OWN> __global__ __launch_bounds__(AOT_THREADS) void k_tile_ao_tile
 		for (int s = 0; s < 8; ++s) {z0 += dz; z1 += dz; zr0[s] = z0; zr1[s] = z1;} // every ray rises by dz per step: sequential float adds, as in the reference
 		ao_lds_f const *sb = (ao_lds_f const *)s_aot + y*AOT_S + x0;
 		unsigned a0 = 0, a1 = 0;
-		float pa[8], pb[8]; // one ray in flight (two were measured at the same speed without the register prefetch of the next tile, which needs their registers)
-		ao_pair_load<-1, -1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 0, -1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 1, -1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load<-1,  0>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 1,  0>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load<-1,  1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 0,  1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
-		ao_pair_load< 1,  1>(sb, pa, pb); ao_pair_hits(pa, pb, zr0, zr1, a0, a1);
+		// two HALF rays in flight: the far half (steps 4 .. 7, scanned first: the nearest hit wins) of a ray is loaded behind the near half of the ray before it
+		float pa[4], pb[4], qa[4], qb[4];
+		unsigned r0 = 0, r1 = 0;
+#define TERRA_AO_RAY(DX, DY, NEXT) ao_pair_load4<DX, DY, 0>(sb, qa, qb); ao_pair_hits4<1>(pa, pb, zr0, zr1, r0, r1); NEXT; ao_pair_hits4<0>(qa, qb, zr0, zr1, r0, r1); a0 += r0; a1 += r1; r0 = r1 = 0;
+		ao_pair_load4<-1, -1, 1>(sb, pa, pb);
+		TERRA_AO_RAY(-1, -1, (ao_pair_load4< 0, -1, 1>(sb, pa, pb)))
+		TERRA_AO_RAY( 0, -1, (ao_pair_load4< 1, -1, 1>(sb, pa, pb)))
+		TERRA_AO_RAY( 1, -1, (ao_pair_load4<-1,  0, 1>(sb, pa, pb)))
+		TERRA_AO_RAY(-1,  0, (ao_pair_load4< 1,  0, 1>(sb, pa, pb)))
+		TERRA_AO_RAY( 1,  0, (ao_pair_load4<-1,  1, 1>(sb, pa, pb)))
+		TERRA_AO_RAY(-1,  1, (ao_pair_load4< 0,  1, 1>(sb, pa, pb)))
+		TERRA_AO_RAY( 0,  1, (ao_pair_load4< 1,  1, 1>(sb, pa, pb)))
+		TERRA_AO_RAY( 1,  1, (void)0)
+#undef TERRA_AO_RAY
 		uint8_t *o = out + (size_t)y*AO_TEX + x0;
 		o[0] = ao_byte(a0); o[1] = ao_byte(a1);
-	}
-	if (w >= 1 && w <= 3) { // column 128: a lane per row, on the waves that had a row less than wave 0
-		unsigned const y = (w - 1)*64u + lane;
-		if (y < AO_TEX) {
-			float z0 = OWN ? s_aot[(y + AO_RL)*AOT_S + AO_RL + 128] : z[(size_t)y*130 + 128];
-			float zr[8];
-#pragma unroll
-			for (int s = 0; s < 8; ++s) {z0 += dz; zr[s] = z0;}
-			float const *sb = s_aot + y*AOT_S + 128;
-			unsigned const att = ao_march_one<-1, -1>(sb, zr) + ao_march_one<0, -1>(sb, zr) + ao_march_one<1, -1>(sb, zr) + ao_march_one<-1, 0>(sb, zr) + ao_march_one<1, 0>(sb, zr)
-				+ ao_march_one<-1, 1>(sb, zr) + ao_march_one<0, 1>(sb, zr) + ao_march_one<1, 1>(sb, zr);
-			out[(size_t)y*AO_TEX + 128] = ao_byte(att);
-		}
 	}
 	if (!OWN && t + gridDim.x < n) {aot_stage_load<OWN>(zvals, ctx, t + gridDim.x, col, rq, stg);}
 	__syncthreads(); // (the next tile's staging overwrites the context)
