@@ -181,6 +181,47 @@ template<class IN, class OUT> TERRA_HD void shadow_trace_path(shadow_consts_t co
 	}
 }
 
+// A sweep's walk, set up once: end cells, Bresenham steps (the statements of shadow_trace_path above, for the callers that want them apart: the lean sweep of the LDS
+// kernels and the host's lane order).  false: the sweep misses the tile.
+struct shadow_path_t {int xa, ya, xb, yb, longest, shortest, dx1, dy1, dx2, dy2;};
+TERRA_HD bool shadow_path_setup(shadow_consts_t const &c, unsigned p, shadow_path_t &w) {
+	shadow_pt_t v1;
+	if (p < 2u*(unsigned)c.ysize) {v1.x = c.xval((c.dirx > 0) ? 0 : c.xsize); v1.y = (float)((double)-c.Y_SCENE_SIZE + 0.5*(double)c.DY_VAL*(double)(int)p); v1.z = 0.0f;}
+	else {int const xx = (int)(p - 2u*(unsigned)c.ysize); v1.x = (float)((double)-c.X_SCENE_SIZE + 0.5*(double)c.DX_VAL*(double)xx); v1.y = c.yval((c.diry > 0) ? 0 : c.ysize); v1.z = 0.0f;}
+	shadow_pt_t v2 = {v1.x + c.dirx*c.dist, v1.y + c.diry*c.dist, v1.z + 0.0f};
+	float const d[3][2] = {{-c.X_SCENE_SIZE, c.xval(c.xsize)}, {-c.Y_SCENE_SIZE, c.yval(c.ysize)}, {c.zmin, c.zmax}};
+	if (!shadow_line_clip(v1, v2, d)) return false;
+	w.xa = c.xpos(v1.x); w.ya = c.ypos(v1.y); w.xb = c.xpos(v2.x); w.yb = c.ypos(v2.y);
+	int const dx = w.xb - w.xa, dy = w.yb - w.ya;
+	w.dx1 = 0; w.dy1 = 0; w.dx2 = 0; w.dy2 = 0;
+	if (dx < 0) {w.dx1 = -1; w.dx2 = -1;} else if (dx > 0) {w.dx1 = 1; w.dx2 = 1;}
+	if (dy < 0) {w.dy1 = -1;} else if (dy > 0) {w.dy1 = 1;}
+	w.longest = (dx < 0) ? -dx : dx; w.shortest = (dy < 0) ? -dy : dy;
+	if (w.longest <= w.shortest) {
+		int const tmp = w.longest; w.longest = w.shortest; w.shortest = tmp;
+		if (dy < 0) {w.dy2 = -1;} else if (dy > 0) {w.dy2 = 1;}
+		w.dx2 = 0;
+	}
+	return true;
+}
+// Which sweep a lane of the LDS kernels takes.  A tile's sweeps have every length from 0 to the tile's width, a wave costs its longest sweep, and what a tile costs is the
+// instructions of the waves that share a SIMD (waves i, i + 4, i + 8 of a workgroup do) -- so the sweeps are sorted by length, cut into waves of 64, and the waves dealt to
+// the four SIMDs longest with shortest: chunks 0 1 2 3 | 7 6 5 4 | 8 ...  Any order gives the same bytes (a sweep's writes carry the sweep's number, not the lane's).
+// lanes: a multiple of 64; 0xFFFF = an idle lane.  false: more sweeps than lanes.
+inline bool shadow_lane_order(shadow_consts_t const &c, uint32_t npaths, uint32_t lanes, uint16_t *lane_path) {
+	if (npaths > lanes || npaths >= 0xFFFFu || (lanes & 63u)) return false;
+	std::vector<std::pair<int, uint32_t>> len(npaths);
+	for (uint32_t p = 0; p < npaths; ++p) {shadow_path_t w; len[p] = std::make_pair(shadow_path_setup(c, p, w) ? -(w.longest + 1) : 0, p);}
+	std::stable_sort(len.begin(), len.end());
+	uint32_t const nw = lanes/64;
+	for (uint32_t k = 0; k < nw; ++k) { // chunk k -> wave
+		uint32_t const round = k/4, pos = k % 4, wave = 4*round + ((round & 1u) ? 3 - pos : pos);
+		uint32_t const dst = (wave < nw) ? wave : k; // (a last, partial round keeps its order)
+		for (uint32_t l = 0; l < 64; ++l) {uint32_t const j = 64*k + l; lane_path[64*dst + l] = (j < npaths) ? (uint16_t)len[j].second : (uint16_t)0xFFFF;}
+	}
+	return true;
+}
+
 // terrain_hmap_manager_t's sampling of a heightmap texture (src/heightmap.cpp:60-84,310-407; value scaling src/mesh_gen.cpp:120): the image stays where the
 // caller put it in HBM (1 byte per pixel, or 2 = {fraction, integer} as written by terra_quantize16_dev / write_pixel_16_bits)
 struct hmap_view_t {

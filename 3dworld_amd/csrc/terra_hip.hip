@@ -384,19 +384,32 @@ struct hip_backend_t : terra::simple_paths<hip_backend_t> {
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	// the whole batch in one dataflow launch (k_tile_shadows_flow); sync_words: the ticket counter, zeroed here.  false: use the per-level launches.  Leaves SHADOW_EDGE_PUB set in `out`
+	// the lane order of the shadow kernels (terra::shadow_lane_order) for the last light / tile geometry seen: the per-level launches of a batch ask for it once per level
+	terra::shadow_consts_t lanes_key; uint32_t lanes_np = 0; bool lanes_ok = false; terra::shadow_lanes_t lanes_cached;
+	bool shadow_lanes(terra::shadow_consts_t const &c, uint32_t np, terra::shadow_lanes_t &lanes) {
+		if (lanes_np != np || memcmp(&lanes_key, &c, sizeof(c)) != 0) {
+			memset(&lanes_key, 0, sizeof(lanes_key)); memcpy(&lanes_key, &c, sizeof(c)); lanes_np = np;
+			lanes_ok = terra::shadow_lane_order(c, np, terra::SH_LEVEL_THREADS, lanes_cached.path);
+		}
+		lanes = lanes_cached;
+		return lanes_ok;
+	}
 	bool tile_shadows_flow(terra::shadow_consts_t const &c, uint32_t ntiles, uint32_t nslots, uint32_t const *ord, int32_t const *adj, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np, uint32_t *sync_words) {
 		if (simple_kernels || ((uintptr_t)sm & 3) || (opt && opt->shadows_levels)) return false;
+		terra::shadow_lanes_t lanes;
+		if (!shadow_lanes(c, np, lanes)) return false;
 		use();
 		fill32(sync_words, 0u, 1); // the ticket (the edge arrays were zeroed by the caller: no stale `published` bit)
 		unsigned const grid = std::min<unsigned>(ntiles, (unsigned)(2*num_cus));
-		hipLaunchKernelGGL(terra::k_tile_shadows_flow, dim3(grid), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, nslots, ntiles, ord, adj, z, out, sm, np, sync_words);
+		hipLaunchKernelGGL(terra::k_tile_shadows_flow, dim3(grid), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, nslots, ntiles, ord, adj, z, out, sm, np, sync_words, lanes);
 		TERRA_HIP_CHECK(hipGetLastError());
 		return true;
 	}
 	void tile_shadows(terra::shadow_consts_t const &c, uint32_t cnt, uint32_t const *ord, int32_t const *adj, uint32_t n, float const *z, unsigned long long *out, uint8_t *sm, uint32_t np) {
-		if (simple_kernels || ((uintptr_t)sm & 3)) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np); return;} // the block ORs its mask out a word at a time
+		terra::shadow_lanes_t lanes;
+		if (simple_kernels || ((uintptr_t)sm & 3) || !shadow_lanes(c, np, lanes)) {tile_shadows_simple(c, cnt, ord, adj, n, z, out, sm, np); return;} // the block ORs its mask out a word at a time
 		use();
-		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np);
+		hipLaunchKernelGGL(terra::k_tile_shadows_level, dim3(cnt), dim3(terra::SH_LEVEL_THREADS), terra::SH_LEVEL_LDS, stream, c, n, ord, adj, z, out, sm, np, lanes);
 		TERRA_HIP_CHECK(hipGetLastError());
 	}
 	bool ao_tile_ok = false;

@@ -855,12 +855,62 @@ struct shadow_lds_in_t {
 struct shadow_lds_out_t {
 	uint8_t *sm; unsigned long long *ox, *oy; int xsize; // all LDS
 	__device__ void shadow(int x, int y) {sm[y*xsize + x] = 0x02;} // MESH_SHADOW: every writer stores the same byte
+	__device__ void shadow_at(int idx) {sm[idx] = 0x02;}            // (the mask and the heights have the same row length)
 	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], shadow_edge_t::pack(order, v));}
 	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], shadow_edge_t::pack(order, v));}
 };
+// The sweep of the LDS kernels (same arithmetic as shadow_trace_path, which the per-thread cross-check kernels and the emulator keep): a tile is a chain of <= 131 dependent
+// steps per sweep and the batch a chain of tiles, so what a step costs is what the row costs.  Cut out of the step: the incoming edge heights are looked at only while a sweep
+// is still on its first column / row (x and y move away from xa / ya monotonically: a wave-uniform branch that is not taken after the first steps), the outgoing ones only
+// where a shadowed step sits on the last column / row; the cell index and the coordinate along the light's dominant axis are carried instead of multiplied out; the last
+// unshadowed height is carried as the double it is used as; the rest of the step is selects, not branches.
+template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_lean(shadow_consts_t const &c, float const *mh, IN const &in, unsigned p, OUT &out) {
+	shadow_path_t w;
+	if (!shadow_path_setup(c, p, w)) return;
+	int const xa = w.xa, ya = w.ya, xb = w.xb, yb = w.yb, longest = w.longest, shortest = w.shortest, dx1 = w.dx1, dy1 = w.dy1, dx2 = w.dx2, dy2 = w.dy2;
+	bool const dim = (fabsf(c.dirx) < fabsf(c.diry));
+	double const dir_ratio = (double)(c.dirz/(dim ? c.diry : c.dirx));
+	float const org_d = dim ? -c.Y_SCENE_SIZE : -c.X_SCENE_SIZE, step_d = dim ? c.DY_VAL : c.DX_VAL;
+	int x = xa, y = ya, numerator = longest >> 1;
+	int const xs = c.xsize, di1 = dy1*xs + dx1, di2 = dy2*xs + dx2, dc1 = dim ? dy1 : dx1, dc2 = dim ? dy2 : dx2;
+	int idx = y*xs + x, cc = dim ? y : x; // the cell and its coordinate along the dominant light axis
+	bool inited = false;
+	float cur_d = 0.0f; double cur_zd = 0.0;
+	for (int i = 0; i <= longest; i++) {
+		bool const valid = (unsigned)x < (unsigned)c.xsize && (unsigned)y < (unsigned)c.ysize;
+		float const pt_z = mh[valid ? idx : 0], pt_d = org_d + step_d*(float)cc;
+		bool const on_edge = valid && (x == xa || y == ya);
+		if (__any(on_edge)) { // (wave-uniform)
+			if (on_edge) {
+				float siv;
+				if (x == xa && (siv = in.y(y)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
+				else if (y == ya && (siv = in.x(x)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
+			}
+		}
+		float const shadow_z = (float)((double)(pt_d - cur_d)*dir_ratio + cur_zd);
+		bool const sh = valid && inited && shadow_z > pt_z;
+		if (sh) {out.shadow_at(idx);}
+		bool const at_end = sh && (x == xb || y == yb);
+		if (__any(at_end)) { // (wave-uniform)
+			if (at_end) {
+				uint32_t const order = p*1024u + (uint32_t)i + 1u;
+				if (x == xb) {out.out_y(y, order, shadow_z);}
+				if (y == yb) {out.out_x(x, order, shadow_z);}
+			}
+		}
+		bool const upd = valid && !sh;
+		cur_d = upd ? pt_d : cur_d; cur_zd = upd ? (double)pt_z : cur_zd;
+		inited = inited || valid;
+		numerator += shortest;
+		bool const both = numerator >= longest;
+		numerator -= both ? longest : 0;
+		x += both ? dx1 : dx2; y += both ? dy1 : dy2; idx += both ? di1 : di2; cc += both ? dc1 : dc2;
+	}
+}
+struct shadow_lanes_t {uint16_t path[SH_LEVEL_THREADS];}; // which sweep a lane takes (shadow_lane_order), 0xFFFF = none; travels as a kernel argument
 constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130; // heights, in edges, out edges, shadow bytes = 87 660 bytes
 __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
-	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths)
+	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, shadow_lanes_t lanes)
 {
 	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
 	unsigned const zv = 130, tid = threadIdx.x;
@@ -881,7 +931,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 	__syncthreads();
 	shadow_lds_in_t const in{s_in, s_in + zv};
 	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-	for (unsigned p = tid; p < npaths; p += SH_LEVEL_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+	{unsigned const p = lanes.path[tid]; if (p < npaths) {shadow_trace_path_lean(c, s_sh_mh, in, p, o);}}
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
 	for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {gm[i] = s_mask[i] | c.mask_fill;} // plain stores: nobody else writes this tile's mask
@@ -903,7 +953,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 // sleeping in between; the 260 lanes join when that lane has seen the first word.  `ticket` is zeroed by the caller per call, the edge arrays too (no stale PUB bit);
 // the virtual halo slots (index >= ntiles) were written before the launch and are read without polling.
 __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_consts_t c, uint32_t n, uint32_t ntiles, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
-	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, uint32_t *ticket)
+	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, uint32_t *ticket, shadow_lanes_t lanes)
 {
 	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
 	__shared__ uint32_t s_ticket;
@@ -948,7 +998,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_c
 		__syncthreads();
 		shadow_lds_in_t const in{s_in, s_in + zv};
 		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-		for (unsigned p = tid; p < npaths; p += SH_LEVEL_THREADS) {shadow_trace_path(c, s_sh_mh, in, p, o);}
+		{unsigned const p = lanes.path[tid]; if (p < npaths) {shadow_trace_path_lean(c, s_sh_mh, in, p, o);}}
 		__syncthreads();
 		if (tid < 2*zv) { // the edges first, every word: somebody may be polling it
 			__hip_atomic_store(&out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)], s_out[tid] | SHADOW_EDGE_PUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

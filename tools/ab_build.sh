@@ -11,5 +11,5 @@ mkdir -p "$D/include"; cp "$ROOT/include/terra.h" "$D/include/"
 [ -n "$PATCH" ] && python3 "$PATCH" "$D/csrc"
 # (csrc includes "../../include/terra.h": keep the relative layout)
 mkdir -p "$D/x"; mv "$D/csrc" "$D/x/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-gpu-rdc -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-result "$D/x/csrc/terra_hip.hip" -o "$D/libterra_hip.so" -lz
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-gpu-rdc -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-result "$D/x/csrc/terra_hip.hip" "$D/x/csrc/terra_fz.hip" -o "$D/libterra_hip.so" -lz
 echo "built $D/libterra_hip.so"
