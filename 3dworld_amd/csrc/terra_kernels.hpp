@@ -872,40 +872,51 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 	double const dir_ratio = (double)(c.dirz/(dim ? c.diry : c.dirx));
 	float const org_d = dim ? -c.Y_SCENE_SIZE : -c.X_SCENE_SIZE, step_d = dim ? c.DY_VAL : c.DX_VAL;
 	int x = xa, y = ya, numerator = longest >> 1;
-	int const xs = c.xsize, di1 = dy1*xs + dx1, di2 = dy2*xs + dx2, dc1 = dim ? dy1 : dx1, dc2 = dim ? dy2 : dx2;
-	int idx = y*xs + x, cc = dim ? y : x; // the cell and its coordinate along the dominant light axis
+	int const xs = c.xsize, di1 = dy1*xs + dx1, di2 = dy2*xs + dx2, dc1 = dim ? dy1 : dx1, dc2 = dim ? dy2 : dx2, last_cell = xs*c.ysize - 1;
+	int idx = y*xs + x, cc = dim ? y : x, i = 0; // the cell, its coordinate along the dominant light axis, the step
 	bool inited = false;
 	float cur_d = 0.0f; double cur_zd = 0.0;
-	for (int i = 0; i <= longest; i++) {
-		bool const valid = (unsigned)x < (unsigned)c.xsize && (unsigned)y < (unsigned)c.ysize;
-		float const pt_z = mh[valid ? idx : 0], pt_d = org_d + step_d*(float)cc;
-		bool const on_edge = valid && (x == xa || y == ya);
-		if (__any(on_edge)) { // (wave-uniform)
-			if (on_edge) {
-				float siv;
-				if (x == xa && (siv = in.y(y)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
-				else if (y == ya && (siv = in.x(x)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
-			}
+	float nxt_z = mh[min(max(idx, 0), last_cell)]; // the height of the cell a step works on is read one step ahead: its address does not depend on the shadow state
+	// one step; FULL: on the first / last column or row of the walk (edge heights come in / go out, the cell may lie just outside the tile)
+	auto step = [&](auto full_tag) {
+		constexpr bool FULL = decltype(full_tag)::value;
+		int const x0 = x, y0 = y, idx0 = idx, cc0 = cc, i0 = i;
+		float const pt_z = nxt_z;
+		numerator += shortest;
+		bool const both = numerator >= longest;
+		numerator -= both ? longest : 0;
+		x += both ? dx1 : dx2; y += both ? dy1 : dy2; idx += both ? di1 : di2; cc += both ? dc1 : dc2; ++i;
+		nxt_z = mh[min(max(idx, 0), last_cell)];
+		bool const valid = FULL ? ((unsigned)x0 < (unsigned)c.xsize && (unsigned)y0 < (unsigned)c.ysize) : true;
+		float const pt_d = org_d + step_d*(float)cc0;
+		if (FULL && valid) {
+			float siv;
+			if (x0 == xa && (siv = in.y(y0)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
+			else if (y0 == ya && (siv = in.x(x0)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
 		}
 		float const shadow_z = (float)((double)(pt_d - cur_d)*dir_ratio + cur_zd);
 		bool const sh = valid && inited && shadow_z > pt_z;
-		if (sh) {out.shadow_at(idx);}
-		bool const at_end = sh && (x == xb || y == yb);
-		if (__any(at_end)) { // (wave-uniform)
-			if (at_end) {
-				uint32_t const order = p*1024u + (uint32_t)i + 1u;
-				if (x == xb) {out.out_y(y, order, shadow_z);}
-				if (y == yb) {out.out_x(x, order, shadow_z);}
+		if (sh) {
+			out.shadow_at(idx0);
+			if (FULL) {
+				uint32_t const order = p*1024u + (uint32_t)i0 + 1u;
+				if (x0 == xb) {out.out_y(y0, order, shadow_z);}
+				if (y0 == yb) {out.out_x(x0, order, shadow_z);}
 			}
 		}
 		bool const upd = valid && !sh;
 		cur_d = upd ? pt_d : cur_d; cur_zd = upd ? (double)pt_z : cur_zd;
 		inited = inited || valid;
-		numerator += shortest;
-		bool const both = numerator >= longest;
-		numerator -= both ? longest : 0;
-		x += both ? dx1 : dx2; y += both ? dy1 : dy2; idx += both ? di1 : di2; cc += both ? dc1 : dc2;
+	};
+	// x and y move away from xa / ya and toward xb / yb monotonically: three wave-uniform phases -- while some lane is still on its first column / row; the middle, which no lane's
+	// edge words can touch (and every cell lies inside the tile: strictly between the walk's end columns and rows); from where the first lane reaches its last column / row
+	while (__any(i <= longest && (x == xa || y == ya))) {if (i <= longest) {step(std::true_type());}}
+	for (;;) {
+		bool const act = i <= longest;
+		if (!__any(act) || __any(act && (x == xb || y == yb))) break;
+		if (act) {step(std::false_type());}
 	}
+	while (__any(i <= longest)) {if (i <= longest) {step(std::true_type());}}
 }
 struct shadow_lanes_t {uint16_t path[SH_LEVEL_THREADS];}; // which sweep a lane takes (shadow_lane_order), 0xFFFF = none; travels as a kernel argument
 constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130; // heights, in edges, out edges, shadow bytes = 87 660 bytes
