@@ -204,12 +204,41 @@ TERRA_HD bool shadow_path_setup(shadow_consts_t const &c, unsigned p, shadow_pat
 	}
 	return true;
 }
+// The walk's first and last zone in closed form: steps [0, first_end) are on the walk's first column or row (x == xa || y == ya), steps [last_begin, longest] on its last
+// (x == xb || y == yb); the dominant coordinate moves at every step, the other one has moved m(i) = floor(((longest >> 1) + i*shortest)/longest) times when step i is made.
+TERRA_HD void shadow_path_zones(int longest, int shortest, int &first_end, int &last_begin) {
+	int const n0 = longest >> 1;
+	if (longest <= 0 || shortest <= 0) {first_end = longest + 1; last_begin = 0; return;} // the minor coordinate never moves: every step is in both zones
+	first_end = (longest - n0 + shortest - 1)/shortest;            // m(i) == 0  <=>  n0 + i*shortest < longest
+	last_begin = (shortest*longest - n0 + shortest - 1)/shortest;  // m(i) == shortest  <=>  n0 + i*shortest >= shortest*longest
+	if (first_end < 1) {first_end = 1;}
+	if (last_begin > longest) {last_begin = longest;}
+}
+// ... checked against the walk itself for every pair a tile of up to 256 cells can have (once per process, on the host; the kernels that rely on the zones are not used if it fails)
+inline bool shadow_path_zones_hold() {
+	static int const ok = [] {
+		for (int longest = 0; longest <= 257; ++longest) {
+			for (int shortest = 0; shortest <= longest; ++shortest) {
+				int fe, lb; shadow_path_zones(longest, shortest, fe, lb);
+				int numerator = longest >> 1, major = 0, minor = 0;
+				for (int i = 0; i <= longest; ++i) {
+					bool const on_first = (major == 0 || minor == 0), on_last = (major == longest || minor == shortest);
+					if (on_first != (i < fe) || on_last != (i >= lb)) return 0;
+					numerator += shortest;
+					if (numerator >= longest) {numerator -= longest; ++major; ++minor;} else {++major;}
+				}
+			}
+		}
+		return 1;
+	}();
+	return ok != 0;
+}
 // Which sweep a lane of the LDS kernels takes.  A tile's sweeps have every length from 0 to the tile's width, a wave costs its longest sweep, and what a tile costs is the
 // instructions of the waves that share a SIMD (waves i, i + 4, i + 8 of a workgroup do) -- so the sweeps are sorted by length, cut into waves of 64, and the waves dealt to
 // the four SIMDs longest with shortest: chunks 0 1 2 3 | 7 6 5 4 | 8 ...  Any order gives the same bytes (a sweep's writes carry the sweep's number, not the lane's).
 // lanes: a multiple of 64; 0xFFFF = an idle lane.  false: more sweeps than lanes.
 inline bool shadow_lane_order(shadow_consts_t const &c, uint32_t npaths, uint32_t lanes, uint16_t *lane_path) {
-	if (npaths > lanes || npaths >= 0xFFFFu || (lanes & 63u)) return false;
+	if (npaths > lanes || npaths >= 0xFFFFu || (lanes & 63u) || c.xsize > 256 || c.ysize > 256 || !shadow_path_zones_hold()) return false;
 	std::vector<std::pair<int, uint32_t>> len(npaths);
 	for (uint32_t p = 0; p < npaths; ++p) {shadow_path_t w; len[p] = std::make_pair(shadow_path_setup(c, p, w) ? -(w.longest + 1) : 0, p);}
 	std::stable_sort(len.begin(), len.end());

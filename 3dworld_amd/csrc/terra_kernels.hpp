@@ -864,10 +864,12 @@ struct shadow_lds_out_t {
 // is still on its first column / row (x and y move away from xa / ya monotonically: a wave-uniform branch that is not taken after the first steps), the outgoing ones only
 // where a shadowed step sits on the last column / row; the cell index and the coordinate along the light's dominant axis are carried instead of multiplied out; the last
 // unshadowed height is carried as the double it is used as; the rest of the step is selects, not branches.
-template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_lean(shadow_consts_t const &c, float const *mh, IN const &in, unsigned p, OUT &out) {
-	shadow_path_t w;
-	if (!shadow_path_setup(c, p, w)) return;
-	int const xa = w.xa, ya = w.ya, xb = w.xb, yb = w.yb, longest = w.longest, shortest = w.shortest, dx1 = w.dx1, dy1 = w.dy1, dx2 = w.dx2, dy2 = w.dy2;
+__device__ __forceinline__ int shadow_wave_max(int v) {for (int off = 32; off; off >>= 1) {v = max(v, __shfl_xor(v, off));} return __builtin_amdgcn_readfirstlane(v);} // (all 64 lanes active; the result in a scalar register: loop bounds)
+template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_lean(shadow_consts_t const &c, float const *mh, IN const &in, unsigned p, unsigned npaths, OUT &out) {
+	// (called by every lane of a wave, sweep or not: the phases below are the wave's; npaths: lanes with p >= npaths have no sweep)
+	shadow_path_t w = {0, 0, 0, 0, -1, 0, 0, 0, 0, 0};
+	bool const has = p < npaths && shadow_path_setup(c, p, w);
+	int const xa = w.xa, ya = w.ya, xb = w.xb, yb = w.yb, longest = has ? w.longest : -1, shortest = w.shortest, dx1 = w.dx1, dy1 = w.dy1, dx2 = w.dx2, dy2 = w.dy2;
 	bool const dim = (fabsf(c.dirx) < fabsf(c.diry));
 	double const dir_ratio = (double)(c.dirz/(dim ? c.diry : c.dirx));
 	float const org_d = dim ? -c.Y_SCENE_SIZE : -c.X_SCENE_SIZE, step_d = dim ? c.DY_VAL : c.DX_VAL;
@@ -882,6 +884,7 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 		constexpr bool FULL = decltype(full_tag)::value;
 		int const x0 = x, y0 = y, idx0 = idx, cc0 = cc, i0 = i;
 		float const pt_z = nxt_z;
+		double const pt_zd = (double)pt_z; // (beside the chain, not inside the branch that needs it)
 		numerator += shortest;
 		bool const both = numerator >= longest;
 		numerator -= both ? longest : 0;
@@ -905,18 +908,20 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 			}
 		}
 		bool const upd = valid && !sh;
-		cur_d = upd ? pt_d : cur_d; cur_zd = upd ? (double)pt_z : cur_zd;
+		cur_d = upd ? pt_d : cur_d; cur_zd = upd ? pt_zd : cur_zd;
 		inited = inited || valid;
 	};
-	// x and y move away from xa / ya and toward xb / yb monotonically: three wave-uniform phases -- while some lane is still on its first column / row; the middle, which no lane's
-	// edge words can touch (and every cell lies inside the tile: strictly between the walk's end columns and rows); from where the first lane reaches its last column / row
-	while (__any(i <= longest && (x == xa || y == ya))) {if (i <= longest) {step(std::true_type());}}
-	for (;;) {
-		bool const act = i <= longest;
-		if (!__any(act) || __any(act && (x == xb || y == yb))) break;
-		if (act) {step(std::false_type());}
-	}
-	while (__any(i <= longest)) {if (i <= longest) {step(std::true_type());}}
+	// x and y move away from xa / ya and toward xb / yb monotonically, and where a walk leaves its first column / row and reaches its last is known in closed form
+	// (shadow_path_zones): three phases with wave-uniform trip counts -- until the last lane has left its first zone; the middle, which no lane's edge words can touch and whose
+	// cells lie strictly inside the tile (no loop test, no zone test, no bounds test per step: the wave's lanes all have a step to make); from where the first lane reaches its last zone
+	int first_end = 0, last_begin = 0x7FFFFFFF;
+	if (has) {shadow_path_zones(longest, shortest, first_end, last_begin);}
+	int const n1 = shadow_wave_max(first_end), e = -shadow_wave_max(-last_begin), lmax = shadow_wave_max(longest);
+	if (!has) return;
+	int k = 0;
+	for (; k < n1; ++k) {if (i <= longest) {step(std::true_type());}}
+	for (; k < e; ++k) {step(std::false_type());}
+	for (; k <= lmax; ++k) {if (i <= longest) {step(std::true_type());}}
 }
 struct shadow_lanes_t {uint16_t path[SH_LEVEL_THREADS];}; // which sweep a lane takes (shadow_lane_order), 0xFFFF = none; travels as a kernel argument
 constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130; // heights, in edges, out edges, shadow bytes = 87 660 bytes
@@ -942,7 +947,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 	__syncthreads();
 	shadow_lds_in_t const in{s_in, s_in + zv};
 	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-	{unsigned const p = lanes.path[tid]; if (p < npaths) {shadow_trace_path_lean(c, s_sh_mh, in, p, o);}}
+	shadow_trace_path_lean(c, s_sh_mh, in, lanes.path[tid], npaths, o);
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
 	for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {gm[i] = s_mask[i] | c.mask_fill;} // plain stores: nobody else writes this tile's mask
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_c
 		__syncthreads();
 		shadow_lds_in_t const in{s_in, s_in + zv};
 		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-		{unsigned const p = lanes.path[tid]; if (p < npaths) {shadow_trace_path_lean(c, s_sh_mh, in, p, o);}}
+		shadow_trace_path_lean(c, s_sh_mh, in, lanes.path[tid], npaths, o);
 		__syncthreads();
 		if (tid < 2*zv) { // the edges first, every word: somebody may be polling it
 			__hip_atomic_store(&out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)], s_out[tid] | SHADOW_EDGE_PUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
