@@ -856,6 +856,7 @@ struct shadow_lds_out_t {
 	uint8_t *sm; unsigned long long *ox, *oy; int xsize; // all LDS
 	__device__ void shadow(int x, int y) {sm[y*xsize + x] = 0x02;} // MESH_SHADOW: every writer stores the same byte
 	__device__ void shadow_at(int idx) {sm[idx] = 0x02;}            // (the mask and the heights have the same row length)
+	__device__ void shadow_if(bool sh, int idx) {sm[sh ? idx : xsize*xsize] = 0x02;} // branch-free: an unshadowed step writes the spare byte behind the mask (130 x 130 tiles: the LDS kernels' layout)
 	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], shadow_edge_t::pack(order, v));}
 	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], shadow_edge_t::pack(order, v));}
 };
@@ -865,11 +866,26 @@ struct shadow_lds_out_t {
 // where a shadowed step sits on the last column / row; the cell index and the coordinate along the light's dominant axis are carried instead of multiplied out; the last
 // unshadowed height is carried as the double it is used as; the rest of the step is selects, not branches.
 __device__ __forceinline__ int shadow_wave_max(int v) {for (int off = 32; off; off >>= 1) {v = max(v, __shfl_xor(v, off));} return __builtin_amdgcn_readfirstlane(v);} // (all 64 lanes active; the result in a scalar register: loop bounds)
-template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_lean(shadow_consts_t const &c, float const *mh, IN const &in, unsigned p, unsigned npaths, OUT &out) {
-	// (called by every lane of a wave, sweep or not: the phases below are the wave's; npaths: lanes with p >= npaths have no sweep)
-	shadow_path_t w = {0, 0, 0, 0, -1, 0, 0, 0, 0, 0};
-	bool const has = p < npaths && shadow_path_setup(c, p, w);
-	int const xa = w.xa, ya = w.ya, xb = w.xb, yb = w.yb, longest = has ? w.longest : -1, shortest = w.shortest, dx1 = w.dx1, dy1 = w.dy1, dx2 = w.dx2, dy2 = w.dy2;
+// A lane's sweep and its wave's phases: the same for every tile of a batch (the light and the tile geometry are), so a persistent block makes it once, not per tile (the line
+// clip with its divisions and three wave reductions were ~10 % of a tile's time).  Called by every lane of a wave, sweep or not (p >= npaths: none): the phases are the wave's.
+struct shadow_plan_t {shadow_path_t w; unsigned p; bool has; int n1, e, lmax;};
+__device__ __forceinline__ shadow_plan_t shadow_sweep_plan(shadow_consts_t const &c, unsigned p, unsigned npaths) {
+	shadow_plan_t pl;
+	pl.w = shadow_path_t{0, 0, 0, 0, -1, 0, 0, 0, 0, 0}; pl.p = p;
+	pl.has = p < npaths && shadow_path_setup(c, p, pl.w);
+	if (!pl.has) {pl.w.longest = -1;}
+	// x and y move away from xa / ya and toward xb / yb monotonically, and where a walk leaves its first column / row and reaches its last is known in closed form
+	// (shadow_path_zones): three phases with wave-uniform trip counts -- until the last lane has left its first zone; the middle, which no lane's edge words can touch and whose
+	// cells lie strictly inside the tile; from where the first lane reaches its last zone
+	int first_end = 0, last_begin = 0x7FFFFFFF;
+	if (pl.has) {shadow_path_zones(pl.w.longest, pl.w.shortest, first_end, last_begin);}
+	pl.n1 = shadow_wave_max(first_end); pl.e = -shadow_wave_max(-last_begin); pl.lmax = shadow_wave_max(pl.w.longest);
+	return pl;
+}
+template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_lean(shadow_consts_t const &c, float const *mh, IN const &in, shadow_plan_t const &pl, OUT &out) {
+	if (!pl.has) return;
+	shadow_path_t const &w = pl.w; unsigned const p = pl.p;
+	int const xa = w.xa, ya = w.ya, xb = w.xb, yb = w.yb, longest = w.longest, shortest = w.shortest, dx1 = w.dx1, dy1 = w.dy1, dx2 = w.dx2, dy2 = w.dy2;
 	bool const dim = (fabsf(c.dirx) < fabsf(c.diry));
 	double const dir_ratio = (double)(c.dirz/(dim ? c.diry : c.dirx));
 	float const org_d = dim ? -c.Y_SCENE_SIZE : -c.X_SCENE_SIZE, step_d = dim ? c.DY_VAL : c.DX_VAL;
@@ -879,9 +895,9 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 	bool inited = false;
 	float cur_d = 0.0f; double cur_zd = 0.0;
 	float nxt_z = mh[min(max(idx, 0), last_cell)]; // the height of the cell a step works on is read one step ahead: its address does not depend on the shadow state
-	// one step; FULL: on the first / last column or row of the walk (edge heights come in / go out, the cell may lie just outside the tile)
-	auto step = [&](auto full_tag) {
-		constexpr bool FULL = decltype(full_tag)::value;
+	// one step of the first or the last phase: on the first / last column or row of the walk (edge heights come in / go out, the cell may lie just outside the tile)
+	auto step = [&](auto in_tag) { // EDGE_IN: some lane may still be on its first column / row (the last phase: none is)
+		constexpr bool EDGE_IN = decltype(in_tag)::value; constexpr bool FULL = true;
 		int const x0 = x, y0 = y, idx0 = idx, cc0 = cc, i0 = i;
 		float const pt_z = nxt_z;
 		double const pt_zd = (double)pt_z; // (beside the chain, not inside the branch that needs it)
@@ -892,7 +908,7 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 		nxt_z = mh[min(max(idx, 0), last_cell)];
 		bool const valid = FULL ? ((unsigned)x0 < (unsigned)c.xsize && (unsigned)y0 < (unsigned)c.ysize) : true;
 		float const pt_d = org_d + step_d*(float)cc0;
-		if (FULL && valid) {
+		if (EDGE_IN && valid) {
 			float siv;
 			if (x0 == xa && (siv = in.y(y0)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
 			else if (y0 == ya && (siv = in.x(x0)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
@@ -911,20 +927,37 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 		cur_d = upd ? pt_d : cur_d; cur_zd = upd ? pt_zd : cur_zd;
 		inited = inited || valid;
 	};
-	// x and y move away from xa / ya and toward xb / yb monotonically, and where a walk leaves its first column / row and reaches its last is known in closed form
-	// (shadow_path_zones): three phases with wave-uniform trip counts -- until the last lane has left its first zone; the middle, which no lane's edge words can touch and whose
-	// cells lie strictly inside the tile (no loop test, no zone test, no bounds test per step: the wave's lanes all have a step to make); from where the first lane reaches its last zone
-	int first_end = 0, last_begin = 0x7FFFFFFF;
-	if (has) {shadow_path_zones(longest, shortest, first_end, last_begin);}
-	int const n1 = shadow_wave_max(first_end), e = -shadow_wave_max(-last_begin), lmax = shadow_wave_max(longest);
-	if (!has) return;
+	int const n1 = pl.n1, e = pl.e, lmax = pl.lmax; // the wave's phases (shadow_sweep_plan): the middle has no loop test, no zone test, no bounds test per step -- the wave's lanes all have a step to make
 	int k = 0;
 	for (; k < n1; ++k) {if (i <= longest) {step(std::true_type());}}
-	for (; k < e; ++k) {step(std::false_type());}
-	for (; k <= lmax; ++k) {if (i <= longest) {step(std::true_type());}}
+	if (k < e) { // the middle: straight-line steps -- no x / y (recomputed behind it), no bounds, `not yet inited` folded into the caster (a caster at -inf shadows nothing), the
+		// shadow byte stored with a selected address instead of a branch
+		if (!inited) {cur_d = 0.0f; cur_zd = -(double)INFINITY;}
+		int const k0 = k;
+		for (; k < e; ++k) {
+			int const idx0 = idx, cc0 = cc;
+			float const pt_z = nxt_z;
+			double const pt_zd = (double)pt_z;
+			numerator += shortest;
+			bool const both = numerator >= longest;
+			numerator -= both ? longest : 0;
+			idx += both ? di1 : di2; cc += both ? dc1 : dc2;
+			nxt_z = mh[idx]; // (a walk's cell: at worst one column / row past the tile, still this block's LDS)
+			float const pt_d = org_d + step_d*(float)cc0;
+			float const shadow_z = (float)((double)(pt_d - cur_d)*dir_ratio + cur_zd);
+			bool const sh = shadow_z > pt_z;
+			out.shadow_if(sh, idx0);
+			cur_d = sh ? cur_d : pt_d; cur_zd = sh ? cur_zd : pt_zd;
+		}
+		inited = true;
+		i += k - k0;
+		int const m = (longest > 0) ? ((longest >> 1) + i*shortest)/longest : 0; // how often the minor coordinate has moved in i steps
+		x = xa + dx2*i + (dx1 - dx2)*m; y = ya + dy2*i + (dy1 - dy2)*m;
+	}
+	for (; k <= lmax; ++k) {if (i <= longest) {step(std::false_type());}}
 }
 struct shadow_lanes_t {uint16_t path[SH_LEVEL_THREADS];}; // which sweep a lane takes (shadow_lane_order), 0xFFFF = none; travels as a kernel argument
-constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130; // heights, in edges, out edges, shadow bytes = 87 660 bytes
+constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130 + 16; // heights, in edges, out edges, shadow bytes (+ the spare byte of shadow_if) = 87 676 bytes
 __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
 	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, shadow_lanes_t lanes)
 {
@@ -947,7 +980,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 	__syncthreads();
 	shadow_lds_in_t const in{s_in, s_in + zv};
 	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-	shadow_trace_path_lean(c, s_sh_mh, in, lanes.path[tid], npaths, o);
+	shadow_trace_path_lean(c, s_sh_mh, in, shadow_sweep_plan(c, lanes.path[tid], npaths), o);
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
 	for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {gm[i] = s_mask[i] | c.mask_fill;} // plain stores: nobody else writes this tile's mask
@@ -977,6 +1010,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_c
 	float *s_in = s_sh_mh + zv*zv;
 	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv);
 	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
+	shadow_plan_t const plan = shadow_sweep_plan(c, lanes.path[tid], npaths); // (the same for every tile)
 	for (;;) {
 		if (tid == 0) {s_ticket = atomicAdd(ticket, 1u);}
 		__syncthreads();
@@ -1014,7 +1048,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_c
 		__syncthreads();
 		shadow_lds_in_t const in{s_in, s_in + zv};
 		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
-		shadow_trace_path_lean(c, s_sh_mh, in, lanes.path[tid], npaths, o);
+		shadow_trace_path_lean(c, s_sh_mh, in, plan, o);
 		__syncthreads();
 		if (tid < 2*zv) { // the edges first, every word: somebody may be polling it
 			__hip_atomic_store(&out[((size_t)((tid < zv) ? 0 : 1)*n + t)*zv + ((tid < zv) ? tid : tid - zv)], s_out[tid] | SHADOW_EDGE_PUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
