@@ -854,9 +854,12 @@ struct shadow_lds_in_t {
 };
 struct shadow_lds_out_t {
 	uint8_t *sm; unsigned long long *ox, *oy; int xsize; // all LDS
+	int spare_b; unsigned long long *spare_q; // this lane's spare byte (an index into sm) and spare 8-byte slot: where the branch-free steps write when they have nothing to write
 	__device__ void shadow(int x, int y) {sm[y*xsize + x] = 0x02;} // MESH_SHADOW: every writer stores the same byte
 	__device__ void shadow_at(int idx) {sm[idx] = 0x02;}            // (the mask and the heights have the same row length)
-	__device__ void shadow_if(bool sh, int idx) {sm[sh ? idx : xsize*xsize] = 0x02;} // branch-free: an unshadowed step writes the spare byte behind the mask (130 x 130 tiles: the LDS kernels' layout)
+	__device__ void shadow_if(bool sh, int idx) {sm[sh ? idx : spare_b] = 0x02;} // branch-free: a selected address instead of a skipped store
+	__device__ void out_x_if(bool on, int i, unsigned long long v) {atomicMax(on ? &ox[i] : spare_q, v);}
+	__device__ void out_y_if(bool on, int i, unsigned long long v) {atomicMax(on ? &oy[i] : spare_q, v);}
 	__device__ void out_x(int i, uint32_t order, float v) {atomicMax(&ox[i], shadow_edge_t::pack(order, v));}
 	__device__ void out_y(int i, uint32_t order, float v) {atomicMax(&oy[i], shadow_edge_t::pack(order, v));}
 };
@@ -892,47 +895,45 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 	int x = xa, y = ya, numerator = longest >> 1;
 	int const xs = c.xsize, di1 = dy1*xs + dx1, di2 = dy2*xs + dx2, dc1 = dim ? dy1 : dx1, dc2 = dim ? dy2 : dx2, last_cell = xs*c.ysize - 1;
 	int idx = y*xs + x, cc = dim ? y : x, i = 0; // the cell, its coordinate along the dominant light axis, the step
-	bool inited = false;
-	float cur_d = 0.0f; double cur_zd = 0.0;
+	float cur_d; double cur_zd; // the caster (the last unshadowed point: its coordinate along the light's axis, its height)
 	float nxt_z = mh[min(max(idx, 0), last_cell)]; // the height of the cell a step works on is read one step ahead: its address does not depend on the shadow state
-	// one step of the first or the last phase: on the first / last column or row of the walk (edge heights come in / go out, the cell may lie just outside the tile)
-	auto step = [&](auto in_tag) { // EDGE_IN: some lane may still be on its first column / row (the last phase: none is)
-		constexpr bool EDGE_IN = decltype(in_tag)::value; constexpr bool FULL = true;
+	// One step of the first or the last phase (on the first / last column or row of the walk: edge heights come in / go out, the cell may lie just outside the tile), straight-line:
+	// lanes whose sweep has ended and cells outside the tile are folded into `valid`, `not yet inited` into the caster (a caster at -inf shadows nothing: the step then takes the
+	// cell as the new caster, which is what the reference's `inited` does), the incoming edge heights are read whether needed or not and selected, the outgoing ones go through LDS
+	// atomics on selected addresses (the lane's spare slot when the step has nothing to hand on).  EDGE_IN: some lane may still be on its first column / row.
+	cur_d = 0.0f; cur_zd = -(double)INFINITY;
+	auto zone_step = [&](auto in_tag) {
+		constexpr bool EDGE_IN = decltype(in_tag)::value;
 		int const x0 = x, y0 = y, idx0 = idx, cc0 = cc, i0 = i;
 		float const pt_z = nxt_z;
-		double const pt_zd = (double)pt_z; // (beside the chain, not inside the branch that needs it)
+		double const pt_zd = (double)pt_z;
 		numerator += shortest;
 		bool const both = numerator >= longest;
 		numerator -= both ? longest : 0;
 		x += both ? dx1 : dx2; y += both ? dy1 : dy2; idx += both ? di1 : di2; cc += both ? dc1 : dc2; ++i;
 		nxt_z = mh[min(max(idx, 0), last_cell)];
-		bool const valid = FULL ? ((unsigned)x0 < (unsigned)c.xsize && (unsigned)y0 < (unsigned)c.ysize) : true;
+		bool const valid = i0 <= longest && (unsigned)x0 < (unsigned)c.xsize && (unsigned)y0 < (unsigned)c.ysize;
 		float const pt_d = org_d + step_d*(float)cc0;
-		if (EDGE_IN && valid) {
-			float siv;
-			if (x0 == xa && (siv = in.y(y0)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
-			else if (y0 == ya && (siv = in.x(x0)) > -1.0E6f) {cur_d = pt_d; cur_zd = (double)siv; inited = true;}
+		if (EDGE_IN) {
+			float const siy = in.y(min(max(y0, 0), c.ysize - 1)), six = in.x(min(max(x0, 0), c.xsize - 1));
+			bool const take_y = valid && x0 == xa && siy > -1.0E6f, take_x = valid && !take_y && y0 == ya && six > -1.0E6f;
+			float const siv = take_y ? siy : six;
+			cur_d = (take_y || take_x) ? pt_d : cur_d; cur_zd = (take_y || take_x) ? (double)siv : cur_zd;
 		}
 		float const shadow_z = (float)((double)(pt_d - cur_d)*dir_ratio + cur_zd);
-		bool const sh = valid && inited && shadow_z > pt_z;
-		if (sh) {
-			out.shadow_at(idx0);
-			if (FULL) {
-				uint32_t const order = p*1024u + (uint32_t)i0 + 1u;
-				if (x0 == xb) {out.out_y(y0, order, shadow_z);}
-				if (y0 == yb) {out.out_x(x0, order, shadow_z);}
-			}
-		}
+		bool const sh = valid && shadow_z > pt_z;
+		out.shadow_if(sh, idx0);
+		unsigned long long const word = shadow_edge_t::pack(p*1024u + (uint32_t)i0 + 1u, shadow_z);
+		out.out_y_if(sh && x0 == xb, y0, word);
+		out.out_x_if(sh && y0 == yb, x0, word);
 		bool const upd = valid && !sh;
 		cur_d = upd ? pt_d : cur_d; cur_zd = upd ? pt_zd : cur_zd;
-		inited = inited || valid;
 	};
 	int const n1 = pl.n1, e = pl.e, lmax = pl.lmax; // the wave's phases (shadow_sweep_plan): the middle has no loop test, no zone test, no bounds test per step -- the wave's lanes all have a step to make
 	int k = 0;
-	for (; k < n1; ++k) {if (i <= longest) {step(std::true_type());}}
+	for (; k < n1; ++k) {zone_step(std::true_type());}
 	if (k < e) { // the middle: straight-line steps -- no x / y (recomputed behind it), no bounds, `not yet inited` folded into the caster (a caster at -inf shadows nothing), the
 		// shadow byte stored with a selected address instead of a branch
-		if (!inited) {cur_d = 0.0f; cur_zd = -(double)INFINITY;}
 		int const k0 = k;
 		for (; k < e; ++k) {
 			int const idx0 = idx, cc0 = cc;
@@ -949,15 +950,15 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 			out.shadow_if(sh, idx0);
 			cur_d = sh ? cur_d : pt_d; cur_zd = sh ? cur_zd : pt_zd;
 		}
-		inited = true;
 		i += k - k0;
 		int const m = (longest > 0) ? ((longest >> 1) + i*shortest)/longest : 0; // how often the minor coordinate has moved in i steps
 		x = xa + dx2*i + (dx1 - dx2)*m; y = ya + dy2*i + (dy1 - dy2)*m;
 	}
-	for (; k <= lmax; ++k) {if (i <= longest) {step(std::false_type());}}
+	for (; k <= lmax; ++k) {zone_step(std::false_type());}
 }
 struct shadow_lanes_t {uint16_t path[SH_LEVEL_THREADS];}; // which sweep a lane takes (shadow_lane_order), 0xFFFF = none; travels as a kernel argument
-constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + 130*130 + 16; // heights, in edges, out edges, shadow bytes (+ the spare byte of shadow_if) = 87 676 bytes
+constexpr unsigned SH_SPARE_B = 130*130, SH_SPARE_Q = (130*130 + SH_LEVEL_THREADS + 4 + 7)/8*8; // byte offsets from the mask: a spare byte per lane, then (8-byte aligned: the mask starts at 70 720) a spare 8-byte slot per lane
+constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + SH_SPARE_Q + SH_LEVEL_THREADS*8; // heights, in edges, out edges, shadow bytes, the lanes' spare bytes and slots = 92 808 bytes
 __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
 	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, shadow_lanes_t lanes)
 {
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 	}
 	__syncthreads();
 	shadow_lds_in_t const in{s_in, s_in + zv};
-	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
+	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv, (int)(SH_SPARE_B + tid), (unsigned long long *)((uint8_t *)s_mask + SH_SPARE_Q) + tid};
 	shadow_trace_path_lean(c, s_sh_mh, in, shadow_sweep_plan(c, lanes.path[tid], npaths), o);
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
@@ -1047,7 +1048,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_c
 		}
 		__syncthreads();
 		shadow_lds_in_t const in{s_in, s_in + zv};
-		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv};
+		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv, (int)(SH_SPARE_B + tid), (unsigned long long *)((uint8_t *)s_mask + SH_SPARE_Q) + tid};
 		shadow_trace_path_lean(c, s_sh_mh, in, plan, o);
 		__syncthreads();
 		if (tid < 2*zv) { // the edges first, every word: somebody may be polling it
