@@ -957,19 +957,23 @@ template<class IN, class OUT> __device__ __forceinline__ void shadow_trace_path_
 	for (; k <= lmax; ++k) {zone_step(std::false_type());}
 }
 struct shadow_lanes_t {uint16_t path[SH_LEVEL_THREADS];}; // which sweep a lane takes (shadow_lane_order), 0xFFFF = none; travels as a kernel argument
-constexpr unsigned SH_SPARE_B = 130*130, SH_SPARE_Q = (130*130 + SH_LEVEL_THREADS + 4 + 7)/8*8; // byte offsets from the mask: a spare byte per lane, then (8-byte aligned: the mask starts at 70 720) a spare 8-byte slot per lane
-constexpr unsigned SH_LEVEL_LDS = 130*130*4 + 2*130*4 + 2*130*8 + SH_SPARE_Q + SH_LEVEL_THREADS*8; // heights, in edges, out edges, shadow bytes, the lanes' spare bytes and slots = 92 808 bytes
+// LDS of the shadow kernels: the shadow bytes FIRST (the sweep's byte stores and height reads then carry their array's offset as the instruction's 16-bit immediate: behind
+// 70 KB of heights the mask's offset did not fit and cost an addition per step: 1.71 -> 1.65 ms), a spare byte per lane behind them, the heights (16-byte aligned), the
+// decoded incoming edges, the outgoing edge words, a spare 8-byte slot per lane.  (The cell's coordinate along the light's axis from a 132-entry table in LDS instead of a
+// conversion, a multiplication and an addition per step was measured and LOST, 1.65 -> 1.72 ms: a second LDS read per step to wait for.)
+constexpr unsigned SH_SPARE_B = 130*130, SH_OFF_MH = (130*130 + SH_LEVEL_THREADS + 15)/16*16; // byte offsets: the lanes' spare bytes, the heights
+constexpr unsigned SH_LEVEL_LDS = SH_OFF_MH + 130*130*4 + 2*130*4 + 2*130*8 + SH_LEVEL_THREADS*8; // = 17 488 + 67 600 + 1 040 + 2 080 + 4 608 = 92 816 bytes
 __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_consts_t c, uint32_t n, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
 	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, shadow_lanes_t lanes)
 {
-	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_sh_raw[];
 	unsigned const zv = 130, tid = threadIdx.x;
 	uint32_t const t = order[blockIdx.x];
 	int32_t const ax = adj[2*t], ay = adj[2*t + 1];
 	float const *z = zvals + (size_t)t*zv*zv;
-	float *s_in = s_sh_mh + zv*zv;
-	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv); // byte offset 68 640: 8-byte aligned
-	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
+	uint32_t *s_mask = (uint32_t *)s_sh_raw;
+	float *s_sh_mh = (float *)(s_sh_raw + SH_OFF_MH), *s_in = s_sh_mh + zv*zv;
+	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv); // (8-byte aligned: 17 488 + 67 600 + 1 040)
 	if (((uintptr_t)z & 15) == 0) {for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {((float4 *)s_sh_mh)[i] = ((float4 const *)z)[i];}} // 67 600 bytes per tile
 	else {for (unsigned i = tid; i < zv*zv; i += SH_LEVEL_THREADS) {s_sh_mh[i] = z[i];}}
 	for (unsigned i = tid; i < zv*zv/4; i += SH_LEVEL_THREADS) {s_mask[i] = 0u;}
@@ -980,7 +984,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 	}
 	__syncthreads();
 	shadow_lds_in_t const in{s_in, s_in + zv};
-	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv, (int)(SH_SPARE_B + tid), (unsigned long long *)((uint8_t *)s_mask + SH_SPARE_Q) + tid};
+	shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv, (int)(SH_SPARE_B + tid), s_out + 2*zv + tid};
 	shadow_trace_path_lean(c, s_sh_mh, in, shadow_sweep_plan(c, lanes.path[tid], npaths), o);
 	__syncthreads();
 	uint32_t *gm = (uint32_t *)(smask + (size_t)t*zv*zv); // 16 900 bytes per tile: word-aligned
@@ -1005,12 +1009,12 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_level(shadow_
 __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_consts_t c, uint32_t n, uint32_t ntiles, uint32_t const *__restrict__ order, int32_t const *__restrict__ adj,
 	float const *__restrict__ zvals, unsigned long long *out, uint8_t *smask, uint32_t npaths, uint32_t *ticket, shadow_lanes_t lanes)
 {
-	extern __shared__ __attribute__((aligned(16))) float s_sh_mh[];
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_sh_raw[];
 	__shared__ uint32_t s_ticket;
 	unsigned const zv = 130, tid = threadIdx.x;
-	float *s_in = s_sh_mh + zv*zv;
+	uint32_t *s_mask = (uint32_t *)s_sh_raw;
+	float *s_sh_mh = (float *)(s_sh_raw + SH_OFF_MH), *s_in = s_sh_mh + zv*zv;
 	unsigned long long *s_out = (unsigned long long *)(s_in + 2*zv);
-	uint32_t *s_mask = (uint32_t *)(s_out + 2*zv);
 	shadow_plan_t const plan = shadow_sweep_plan(c, lanes.path[tid], npaths); // (the same for every tile)
 	for (;;) {
 		if (tid == 0) {s_ticket = atomicAdd(ticket, 1u);}
@@ -1048,7 +1052,7 @@ __global__ __launch_bounds__(SH_LEVEL_THREADS) void k_tile_shadows_flow(shadow_c
 		}
 		__syncthreads();
 		shadow_lds_in_t const in{s_in, s_in + zv};
-		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv, (int)(SH_SPARE_B + tid), (unsigned long long *)((uint8_t *)s_mask + SH_SPARE_Q) + tid};
+		shadow_lds_out_t o{(uint8_t *)s_mask, s_out, s_out + zv, (int)zv, (int)(SH_SPARE_B + tid), s_out + 2*zv + tid};
 		shadow_trace_path_lean(c, s_sh_mh, in, plan, o);
 		__syncthreads();
 		if (tid < 2*zv) { // the edges first, every word: somebody may be polling it
