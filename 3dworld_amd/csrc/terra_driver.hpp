@@ -1610,14 +1610,30 @@ template<class BE> struct terra_engine {
 		c.dist = (float)(2.0*(double)(cfg.mesh_x + cfg.mesh_y)/(double)sqrtf(c.dirx*c.dirx + c.diry*c.diry)); // 2.0*XY_SUM_SIZE/sqrt(...)
 		// dependency levels
 		int const sx = (lx < 0.0f) ? -1 : 1, sy = (ly < 0.0f) ? -1 : 1;
+		// which entry of the batch a tile is: a table over the batch's bounding box where that is not much larger than the batch (the usual case, a block of tiles: the
+		// ordered map cost more host time than the lookups are worth), the map otherwise; a tile listed twice is its last entry either way
 		std::map<std::pair<int32_t, int32_t>, uint32_t> index;
-		for (uint32_t i = 0; i < n; ++i) {index[std::make_pair(tile_xy[2*i], tile_xy[2*i+1])] = i;}
+		std::vector<int32_t> grid; int64_t gx0 = 0, gy0 = 0, gw = 0, gh = 0;
+		{
+			int64_t x0 = tile_xy[0], x1 = x0, y0 = tile_xy[1], y1 = y0;
+			for (uint32_t i = 1; i < n; ++i) {int64_t const tx = tile_xy[2*i], ty = tile_xy[2*i+1]; x0 = std::min(x0, tx); x1 = std::max(x1, tx); y0 = std::min(y0, ty); y1 = std::max(y1, ty);}
+			int64_t const w = x1 - x0 + 1, h = y1 - y0 + 1;
+			if (w <= (1 << 20) && h <= (1 << 20) && w*h <= 4*(int64_t)n + 64) {
+				gx0 = x0; gy0 = y0; gw = w; gh = h; grid.assign((size_t)(w*h), -1);
+				for (uint32_t i = 0; i < n; ++i) {grid[(size_t)((tile_xy[2*i+1] - y0)*w + (tile_xy[2*i] - x0))] = (int32_t)i;}
+			}
+			else {for (uint32_t i = 0; i < n; ++i) {index[std::make_pair(tile_xy[2*i], tile_xy[2*i+1])] = i;}}
+		}
+		auto const entry_of = [&](int64_t tx, int64_t ty) -> int32_t {
+			if (gw) {int64_t const ix = tx - gx0, iy = ty - gy0; return (ix >= 0 && iy >= 0 && ix < gw && iy < gh) ? grid[(size_t)(iy*gw + ix)] : -1;}
+			auto const it = index.find(std::make_pair((int32_t)tx, (int32_t)ty));
+			return (tx < INT32_MIN || tx > INT32_MAX || ty < INT32_MIN || ty > INT32_MAX || it == index.end()) ? -1 : (int32_t)it->second;
+		};
 		std::vector<int32_t> adj(2*(size_t)n, -1); // [i][0]: neighbour in x toward the light (its sh_out_y is our sh_in_y), [i][1]: neighbour in y
 		std::vector<uint32_t> level(n, 0), order(n);
 		for (uint32_t i = 0; i < n; ++i) {
-			auto ax = index.find(std::make_pair(tile_xy[2*i] + sx, tile_xy[2*i+1])), ay = index.find(std::make_pair(tile_xy[2*i], tile_xy[2*i+1] + sy));
-			if (ax != index.end()) adj[2*i] = (int32_t)ax->second;
-			if (ay != index.end()) adj[2*i+1] = (int32_t)ay->second;
+			adj[2*i] = entry_of((int64_t)tile_xy[2*i] + sx, tile_xy[2*i+1]);
+			adj[2*i+1] = entry_of(tile_xy[2*i], (int64_t)tile_xy[2*i+1] + sy);
 		}
 		// halo: a present incoming edge becomes a virtual neighbour slot n + k whose out-array holds the received heights
 		std::vector<unsigned long long> virt; // [nvirt][zv]

@@ -429,7 +429,9 @@ class OneHeightmapPipeline:
         return float(h[0]), h[1] > 0.5
 
     def run(self, k, origin=None, collect=None):
-        """k steps (see _run_host_paced for the arguments); with a collective that runs on the device the steps are only enqueued (_run_device_paced)."""
+        """k steps (see _run_host_paced for the arguments); with a collective that runs on the device the steps are only enqueued (_run_device_paced).
+        collect(s, ptr) is called from the eroder THREADS (one per eroder context, possibly at the same time): it must not use the pipeline's contexts -- a context is not
+        for two threads at once -- but one of its own (the grid is final and the eroder's stream drained when it is called)."""
         return self._run_device_paced(k, origin, collect) if self._dev_paced else self._run_host_paced(k, origin, collect)
 
     def _run_device_paced(self, k, origin=None, collect=None):

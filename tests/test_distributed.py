@@ -323,8 +323,16 @@ def _one_grid_worker(rank, world, port, lib, out_dir, nx, ny, droplets, steps, g
     pipe = dmod.OneHeightmapPipeline(pkg, lambda: pkg.Terra(0, lib), pkg.make_config(mesh_gen_mode=0, mesh_freq_filter=1), dist, nx, ny, droplets, tag=f"t{port}", grids=grids, eroders=2)
     assert pipe.rows[0][0] == 0 and pipe.rows[-1][1] == ny and all(a[1] == b[0] for a, b in zip(pipe.rows, pipe.rows[1:]))
 
+    # collect() is called from the pipeline's eroder threads (two here), each with its own context: the copies go through a context of their own behind a lock -- a context
+    # is not for two threads at once (through ectx[0], one thread's copy could land in the stream the other was capturing its first erosion graph on: a rare
+    # `capturing stream has unjoined work`)
+    import threading
+    dl, dl_lock = pkg.Terra(0, lib), threading.Lock()
+
     def collect(s, ptr):  # on the rank that eroded step s: the WHOLE grid through the mapped pointer (the other rank's rows included)
-        np.save(os.path.join(out_dir, f"grid_{s}.npy"), _dgrid_download(pipe.ectx[0], ptr, (ny, nx)))
+        with dl_lock:
+            a = _dgrid_download(dl, ptr, (ny, nx))
+        np.save(os.path.join(out_dir, f"grid_{s}.npy"), a)
 
     pipe.run(steps, origin=lambda s: (-nx / 2 + 40.0 * s, -ny / 2 - 25.0 * s), collect=collect)
     dist.barrier()
@@ -406,8 +414,13 @@ def _one_grid_device_paced_worker(rank, world, out_dir, nx, ny, droplets, steps,
                                      coll_device=torch.device("cuda:0"))
     assert pipe._dev_paced
 
+    import threading
+    dl, dl_lock = pkg.Terra(0), threading.Lock()  # (see _one_grid_worker: the eroder threads' copies through a context of their own)
+
     def collect(s, ptr):
-        np.save(os.path.join(out_dir, f"grid_{s}.npy"), _dgrid_download(pipe.ectx[0], ptr, (ny, nx)))
+        with dl_lock:
+            a = _dgrid_download(dl, ptr, (ny, nx))
+        np.save(os.path.join(out_dir, f"grid_{s}.npy"), a)
 
     origin = lambda s: (-nx / 2 + 40.0 * s, -ny / 2 - 25.0 * s)  # noqa: E731
     pipe.run(steps, origin=origin, collect=collect)
