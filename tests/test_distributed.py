@@ -13,6 +13,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+
+def _free_port():
+    """a TCP port nobody is listening on right now, from the kernel (a port computed from the pid lies in the ephemeral range: one whole-suite run in ~10 found it taken -- EADDRINUSE)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def partition(n_units, world, rank):
     """contiguous block partition used by bench.py's tiles workload (3dworld_amd/dist.py: partition_tiles)"""
     dmod = importlib.import_module("3dworld_amd.dist")
@@ -49,7 +58,7 @@ def test_partition_covers_all_units_once():
 def test_two_ranks_tile_sharding_matches_oracle(emul_lib, orc, tmp_path):
     import torch.multiprocessing as mp
     import orclib
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, emul_lib, str(tmp_path)), nprocs=2, join=True)
     z = np.concatenate([np.load(tmp_path / f"z_{r}.npy") for r in range(2)])
     tiles = [(tx, ty) for ty in range(-2, 2) for tx in range(-3, 2)]
@@ -85,7 +94,7 @@ def test_two_ranks_one_heightmap_as_row_strips(emul_lib, orc, tmp_path, mode, nx
     (gloo here, RCCL on the MI355X node).  The union equals the oracle's full grid bit for bit and every rank holds the global min / max."""
     import torch.multiprocessing as mp
     import orclib
-    port = 33500 + (os.getpid() + mode) % 2000
+    port = _free_port()
     mp.spawn(_strips_worker, args=(2, port, emul_lib, str(tmp_path), mode, nx, ny), nprocs=2, join=True)
     z = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(2)])
     s = orc.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
@@ -103,7 +112,7 @@ def test_two_ranks_one_heightmap_as_row_strips_on_the_hip_library(orc, tmp_path)
     import torch.multiprocessing as mp
     import orclib
     mode, nx, ny = 0, 1030, 517
-    port = 35500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_strips_worker, args=(2, port, None, str(tmp_path), mode, nx, ny), nprocs=2, join=True)
     z = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(2)])
     s = orc.init(orclib.make_config(mesh_gen_mode=mode, mesh_freq_filter=1))
@@ -154,7 +163,7 @@ def test_two_ranks_mesh_shadows_with_edge_exchange(emul_lib, orc, tmp_path, ligh
     the MI355X node); the union equals the single-process result for lights from both x directions (pipeline runs either way)."""
     import torch.multiprocessing as mp
     import orclib
-    port = 31500 + (os.getpid() + int(light[0] * 10)) % 2000
+    port = _free_port()
     mp.spawn(_shadow_worker, args=(2, port, emul_lib, str(tmp_path), light), nprocs=2, join=True)
     tiles = [(tx, ty) for ty in range(-1, 2) for tx in range(-3, 3)]
     orc.init(orclib.make_config(mesh_gen_mode=0))
@@ -290,7 +299,7 @@ def test_rccl_one_rank_group_runs_the_device_collectives(orc, tmp_path):
     """the `nccl` (= RCCL) branches of 3dworld_amd/dist.py on the 1-GPU box: a one-rank group, device tensors through all_reduce, results equal to the oracle's"""
     import torch.multiprocessing as mp
     import orclib
-    port = 37500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_nccl_world1_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     nx, ny = 1030, 517
     s = orc.init(orclib.make_config(mesh_gen_mode=0, mesh_freq_filter=1))
@@ -364,7 +373,7 @@ def test_two_ranks_erode_one_heightmap_whose_strips_live_on_both(emul_lib, orc, 
     both emulator processes; on the GPU box they are hipMemCreate allocations (tests/test_distributed.py::test_two_ranks_erode_one_heightmap_on_the_hip_library)."""
     import torch.multiprocessing as mp
     nx, ny, droplets, steps, grids = 256, 100, 300, 7, 3
-    port = 36500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_one_grid_worker, args=(2, port, emul_lib, str(tmp_path), nx, ny, droplets, steps, grids), nprocs=2, join=True)
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
@@ -374,7 +383,7 @@ def test_two_ranks_erode_one_heightmap_with_the_traces_made_by_the_strip_owners(
     terra_dgrid per grid in flight), a second collective, and the step's eroder gathers the traces through the mapping and checks / commits -- the oracle's grids"""
     import torch.multiprocessing as mp
     nx, ny, droplets, steps, grids = 256, 160, 150, 5, 3
-    port = 38500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_one_grid_worker, args=(2, port, emul_lib, str(tmp_path), nx, ny, droplets, steps, grids, True), nprocs=2, join=True)
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
@@ -384,7 +393,7 @@ def test_two_ranks_shard_the_traces_on_the_hip_library(orc, tmp_path):
     """... through libterra_hip.so: two processes on GPU 0, the arenas hipMemCreate allocations mapped by the peer; the eroding process reads the other one's traces"""
     import torch.multiprocessing as mp
     nx, ny, droplets, steps, grids = 2048, 1024, 400, 6, 3
-    port = 39500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_one_grid_worker, args=(2, port, None, str(tmp_path), nx, ny, droplets, steps, grids, True), nprocs=2, join=True)
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
@@ -395,7 +404,7 @@ def test_two_ranks_erode_one_heightmap_on_the_hip_library(orc, tmp_path):
     (hipMemImportFromShareableHandle / hipMemMap / hipMemSetAccess) -- the erosion kernels run over memory that belongs to another process"""
     import torch.multiprocessing as mp
     nx, ny, droplets, steps, grids = 2048, 1024, 1000, 6, 3
-    port = 37500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_one_grid_worker, args=(2, port, None, str(tmp_path), nx, ny, droplets, steps, grids), nprocs=2, join=True)
     _check_one_grid(orc, str(tmp_path), nx, ny, droplets, steps, grids, 2)
 
